@@ -1,0 +1,310 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the REAL reference code.
+
+Runs only in the build container (needs /root/reference; never on the GPU box).  It
+imports the reference's own scripts (`src/3dmatch_train_egnn_with_batch.py`,
+`src/eval_egnn_metrics.py`) with stub modules for the absent third-party packages
+(torch_geometric, torch_cluster, torch_scatter, wandb, tensorboard), runs the
+reference classes on seeded inputs in fp32 and fp64, and stores inputs, weights and
+reference outputs as ``.npz``.  No reference source text is stored: fixtures are data.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+kNN edges come from ``oracle.knn_graph`` (torch_cluster is not installable here; see the
+oracle header: that boundary is pinned by known-answer tests, not by these vectors).
+"""
+import contextlib
+import importlib.util
+import io
+import os
+import sys
+import types
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+from oracle import egnn_oracle as orc  # noqa: E402
+
+
+# ---------------------------------------------------------------- reference import (stubs)
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+class _MessagePassing(nn.Module):
+    def __init__(self, aggr=None, **kw):
+        super().__init__()
+
+
+def _functional_transform(_name):
+    return lambda cls: cls
+
+
+def load_reference():
+    _stub("wandb")
+    tg = _stub("torch_geometric")
+    tgd = _stub("torch_geometric.data", Data=object)
+    tgdp = _stub("torch_geometric.data.datapipes", functional_transform=_functional_transform)
+    tgt = _stub("torch_geometric.transforms", BaseTransform=type("BaseTransform", (), {}),
+                SamplePoints=object, KNNGraph=object)
+    tgu = _stub("torch_geometric.utils", to_undirected=None)
+    tgn = _stub("torch_geometric.nn", global_max_pool=None, MessagePassing=_MessagePassing)
+    tg.data, tg.transforms, tg.utils, tg.nn, tgd.datapipes = tgd, tgt, tgu, tgn, tgdp
+    _stub("torch_cluster", knn_graph=None)
+    _stub("torch_scatter", scatter_add=None)
+    _stub("torch.utils.tensorboard", SummaryWriter=object)
+    sys.path.insert(0, os.path.join(REF, "src"))
+    sys.path.insert(0, REF)
+    mods = {}
+    for fname, name in (("3dmatch_train_egnn_with_batch.py", "ref_train"), ("eval_egnn_metrics.py", "ref_eval")):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, "src", fname))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        mods[name] = m
+    return mods["ref_train"], mods["ref_eval"]
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+@contextlib.contextmanager
+def default_dtype(dt):
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(dt)
+    try:
+        yield
+    finally:
+        torch.set_default_dtype(old)
+
+
+def build_egnn(tr, feat, n_layers, heads, seed):
+    torch.manual_seed(seed)
+    egnn = tr.EGNN(feat, feat, feat, in_edge_nf=1, device="cpu", n_layers=n_layers)
+    if heads != 1:
+        for i in range(n_layers):
+            egnn._modules["gcl_%d" % i] = tr.E_GCL(feat, feat, feat, edges_in_d=1, num_heads=heads)
+    return egnn
+
+
+def sd_np(module, dt=np.float32):
+    return {k: v.detach().cpu().numpy().astype(dt) for k, v in module.state_dict().items()}
+
+
+def to64(d):
+    return {k: v.double() if v.is_floating_point() else v for k, v in d.items()}
+
+
+def random_cloud(seed, n, feat):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, 3, generator=g) * 2.0
+    h = torch.nn.functional.normalize(torch.randn(n, feat, generator=g), dim=1)
+    return h, x
+
+
+# ---------------------------------------------------------------- fixture (i): per-op / per-layer
+def gen_layer_fixture(tr, name, n, k, feat, heads, n_layers, seed, dup_points=False):
+    h, x = random_cloud(seed, n, feat)
+    if dup_points:                      # duplicated coordinates -> zero-length non-self edges, kNN ties
+        x[n // 2:n // 2 + 8] = x[:8]
+    edges = orc.knn_graph(x, k, loop=True)
+    row, col = edges[0], edges[1]
+    ea = torch.ones(row.numel(), 1)
+    g = torch.Generator().manual_seed(seed + 7)
+    gh = torch.randn(n, feat, generator=g)
+    gx = torch.randn(n, 3, generator=g)
+    out = {"h": h.numpy(), "x": x.numpy(), "edges": edges.numpy(), "gh": gh.numpy(), "gx": gx.numpy(),
+           "k": np.int64(k), "heads": np.int64(heads), "n_layers": np.int64(n_layers)}
+    egnn = build_egnn(tr, feat, n_layers, heads, seed)
+    for kk, v in sd_np(egnn).items():
+        out["w." + kk] = v
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        with default_dtype(dt):
+            m = build_egnn(tr, feat, n_layers, heads, seed)
+            m.load_state_dict(egnn.state_dict())
+            m = m.to(dt)
+            hh = h.detach().clone().to(dt).requires_grad_(True)
+            xx = x.detach().clone().to(dt).requires_grad_(True)
+            # layer-0 intermediates straight from the reference layer object
+            l0 = m._modules["gcl_0"]
+            h0 = m.embedding_in(hh)
+            radial, diff = l0.coord2radial([row, col], xx)
+            ef = l0.edge_model(h0[row], h0[col], radial, ea.to(dt), xx, [row, col])
+            so3 = tr.compute_so3_matrix(xx, [row, col])
+            _, dist, dot = tr.compute_edge_features(xx, [row, col])
+            h1, x1, _ = l0(h0, [row, col], xx, edge_attr=ea.to(dt))
+            ho, xo = m(hh, xx, [row, col], ea.to(dt))
+            loss = (ho * gh.to(dt)).sum() + (xo * gx.to(dt)).sum()
+            loss.backward()
+            out[f"{tag}.so3"] = so3.detach().numpy()
+            out[f"{tag}.radial"] = radial.detach().numpy()
+            out[f"{tag}.dist"] = dist.detach().numpy()
+            out[f"{tag}.dot"] = dot.detach().numpy()
+            out[f"{tag}.edge_feat0"] = ef.detach().numpy()
+            out[f"{tag}.h1"] = h1.detach().numpy()
+            out[f"{tag}.x1"] = x1.detach().numpy()
+            out[f"{tag}.h_out"] = ho.detach().numpy()
+            out[f"{tag}.x_out"] = xo.detach().numpy()
+            out[f"{tag}.grad_h"] = hh.grad.numpy()
+            out[f"{tag}.grad_x"] = xx.grad.numpy()
+            for pn, p in m.named_parameters():
+                out[f"{tag}.grad.{pn}"] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name, "max|h_out|", float(np.abs(out["f64.h_out"]).max()),
+          "f32-f64 gap h", float(np.abs(out["f32.h_out"] - out["f64.h_out"]).max()))
+
+
+# ---------------------------------------------------------------- fixture (ii)/(iii): pair forward
+def pair_inputs(seed, n, feat, k, scale=(3.0, 3.0, 3.0)):
+    p = orc.synthetic_pair(seed, n=n, feat=feat, scale=scale)
+    e_s = orc.knn_graph(p["src"], k, loop=True)
+    e_t = orc.knn_graph(p["tgt"], k, loop=True)
+    return p, e_s, e_t
+
+
+def run_pair(mod, model, p, e_s, e_t, dt):
+    ea = torch.ones(1, e_s.shape[1], 1, dtype=dt)
+    args = (p["feat_src"][None].to(dt), p["src"][None].to(dt), e_s[None], ea,
+            p["feat_tgt"][None].to(dt), p["tgt"][None].to(dt), e_t[None], ea,
+            p["corr"][None].to(dt), p["labels"][None].to(dt), p["gt_pose"][None].to(dt))
+    with quiet():
+        return model(*args)
+
+
+def gen_pair_fixture(tr, ev, name, n, k, feat, n_layers, heads, seed, ckpt=None, out_scale=None,
+                     with_grads=False):
+    p, e_s, e_t = pair_inputs(1234 + seed, n, feat, k)
+    egnn = build_egnn(tr, feat, n_layers, heads, seed)
+    torch.manual_seed(seed + 1)
+    cross = tr.CrossAttentionPoseRegression(egnn, num_nodes=n, hidden_nf=feat, device="cpu")
+    if ckpt is not None:
+        ck = torch.load(ckpt, map_location="cpu", weights_only=False)
+        egnn.load_state_dict(ck["egnn_state_dict"])
+        cross.load_state_dict(ck["cross_attention_state_dict"])
+    if out_scale is not None:           # well-conditioned training head (SURVEY §7 hard part 2)
+        with torch.no_grad():
+            egnn.embedding_out.weight.mul_(out_scale)
+            egnn.embedding_out.bias.mul_(out_scale)
+    out = {"k": np.int64(k), "n_layers": np.int64(n_layers), "heads": np.int64(heads)}
+    for kk in ("src", "tgt", "feat_src", "feat_tgt", "labels", "gt_pose", "corr"):
+        out["in." + kk] = p[kk].numpy()
+    for kk, v in sd_np(cross).items():
+        if kk.endswith("num_batches_tracked"):
+            continue
+        out["w." + kk] = v
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        with default_dtype(dt):
+            e2 = build_egnn(tr, feat, n_layers, heads, seed)
+            e2.load_state_dict(egnn.state_dict())
+            for variant, mod in (("train", tr), ("eval", ev)):
+                c2 = mod.CrossAttentionPoseRegression(e2, num_nodes=n, hidden_nf=feat, device="cpu")
+                c2.load_state_dict(cross.state_dict())
+                c2 = c2.to(dt)
+                c2.train()
+                res = run_pair(mod, c2, p, e_s, e_t, dt)
+                R, t, closs, equi, hs, xs, ht, xt, _ = res
+                pre = f"{tag}.{variant}."
+                out[pre + "R"] = R.detach().numpy()
+                out[pre + "t"] = t.detach().numpy()
+                out[pre + "equi_loss"] = equi.detach().numpy()
+                if variant == "train":
+                    out[pre + "corr_sim_loss"] = closs.detach().numpy()
+                    out[f"{tag}.h_src"] = hs.detach().numpy()[0]
+                    out[f"{tag}.x_src"] = xs.detach().numpy()[0]
+                    out[f"{tag}.h_tgt"] = ht.detach().numpy()[0]
+                    out[f"{tag}.x_tgt"] = xt.detach().numpy()[0]
+                    # logits / top-k indices: recompute exactly as train :681-694,:760-770 does
+                    sim = torch.sum(hs * ht, dim=-1)
+                    _, idx = torch.topk(sim, k=128, dim=-1)
+                    gi = idx.unsqueeze(-1).expand(-1, -1, feat)
+                    logits = c2.mlp(torch.cat([torch.gather(hs, 1, gi), torch.gather(ht, 1, gi)], -1).view(-1, 2 * feat))
+                    out[pre + "logits"] = logits.detach().view(1, 128).numpy()
+                    out[pre + "top_idx"] = idx.numpy()
+                    rl, tl = tr.pose_loss(R, t, p["gt_pose"][None].to(dt))
+                    out[pre + "rot_loss"] = rl.detach().numpy()
+                    out[pre + "trans_loss"] = tl.detach().numpy()
+                    if with_grads:
+                        loss = closs.mean() + rl.mean() + tl.mean()            # train :1120
+                        c2.zero_grad()
+                        loss.backward()
+                        out[pre + "loss"] = loss.detach().numpy()
+                        for pn, prm in c2.named_parameters():
+                            if prm.grad is not None:
+                                out[pre + "grad." + pn] = prm.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    d = np.abs(out["f32.train.logits"] - out["f64.train.logits"]).max()
+    print("wrote", name, "| R(train) =", np.round(out["f64.train.R"][0], 4).tolist(),
+          "| f32-f64 gaps: logits %.2e R %.2e t %.2e h %.2e" % (
+              d, np.abs(out["f32.train.R"] - out["f64.train.R"]).max(),
+              np.abs(out["f32.train.t"] - out["f64.train.t"]).max(),
+              np.abs(out["f32.h_src"] - out["f64.h_src"]).max()),
+          "| R(eval) err vs gt %.3e" % np.abs(out["f64.eval.R"][0] - out["in.gt_pose"][:3, :3]).max())
+
+
+# ---------------------------------------------------------------- fixture: Kabsch + grads
+def gen_kabsch_fixture(name):
+    out = {}
+    cases = []
+    g = torch.Generator().manual_seed(5)
+    for ci, (n, noise, peaky) in enumerate([(64, 0.01, False), (500, 0.05, False), (33, 0.0, False), (128, 0.02, True)]):
+        src = torch.rand(n, 3, generator=g, dtype=torch.float64) * 2
+        ang = torch.rand(3, generator=g, dtype=torch.float64) * 3
+        Rz = torch.tensor([[np.cos(ang[0]), -np.sin(ang[0]), 0], [np.sin(ang[0]), np.cos(ang[0]), 0], [0, 0, 1]])
+        Ry = torch.tensor([[np.cos(ang[1]), 0, np.sin(ang[1])], [0, 1, 0], [-np.sin(ang[1]), 0, np.cos(ang[1])]])
+        Rg = (Rz @ Ry).double()
+        tgt = src @ Rg.T + torch.rand(3, generator=g, dtype=torch.float64) + noise * torch.randn(n, 3, generator=g, dtype=torch.float64)
+        sc = torch.randn(n, generator=g, dtype=torch.float64) * (30.0 if peaky else 1.0)
+        cases.append((src, tgt, sc))
+    # reflection case: target is a mirrored copy -> det(V U^T) < 0 branch (train :749-751)
+    src = torch.rand(40, 3, generator=g, dtype=torch.float64)
+    tgt = src.clone(); tgt[:, 2] = -tgt[:, 2]
+    cases.append((src, tgt + 0.01 * torch.randn(40, 3, generator=g, dtype=torch.float64), torch.zeros(40, dtype=torch.float64)))
+    out["n_cases"] = np.int64(len(cases))
+    for ci, (src, tgt, sc) in enumerate(cases):
+        gR = torch.randn(3, 3, generator=g, dtype=torch.float64)
+        gt = torch.randn(3, generator=g, dtype=torch.float64)
+        for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            s = src.detach().clone().to(dt).requires_grad_(True)
+            t_ = tgt.detach().clone().to(dt).requires_grad_(True)
+            c = sc.detach().clone().to(dt).requires_grad_(True)
+            w = torch.softmax(c, dim=-1)
+            w = w / (w.sum() + 1e-6)
+            R, t = orc.weighted_kabsch(s, t_, w)      # same op sequence as train :726-758 (checked in test_oracle_golden)
+            ((R * gR.to(dt)).sum() + (t * gt.to(dt)).sum()).backward()
+            out[f"c{ci}.{tag}.R"] = R.detach().numpy(); out[f"c{ci}.{tag}.t"] = t.detach().numpy()
+            out[f"c{ci}.{tag}.g_src"] = s.grad.numpy(); out[f"c{ci}.{tag}.g_tgt"] = t_.grad.numpy()
+            out[f"c{ci}.{tag}.g_score"] = c.grad.numpy()
+        out[f"c{ci}.src"] = src.numpy(); out[f"c{ci}.tgt"] = tgt.numpy(); out[f"c{ci}.score"] = sc.numpy()
+        out[f"c{ci}.gR"] = gR.numpy(); out[f"c{ci}.gt"] = gt.numpy()
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name)
+
+
+def main():
+    tr, ev = load_reference()
+    gen_layer_fixture(tr, "layer_n128_k8_f32_h1.npz", 128, 8, 32, 1, 2, seed=11)
+    gen_layer_fixture(tr, "layer_n128_k8_f33_h1.npz", 128, 8, 33, 1, 2, seed=12)
+    gen_layer_fixture(tr, "layer_n128_k8_f32_h4.npz", 128, 8, 32, 4, 2, seed=13)
+    gen_layer_fixture(tr, "layer_n96_k6_f32_h1_dup.npz", 96, 6, 32, 1, 1, seed=14, dup_points=True)
+    gen_pair_fixture(tr, ev, "pair_n2048_k20_l4.npz", 2048, 20, 32, 4, 1, seed=0)
+    gen_pair_fixture(tr, ev, "pair_n512_k12_l2_wellcond.npz", 512, 12, 32, 2, 1, seed=3, out_scale=0.02, with_grads=True)
+    gen_pair_fixture(tr, ev, "pair_ckpt_n2048_k16_l3_h4.npz", 2048, 16, 32, 3, 4, seed=1,
+                     ckpt=os.path.join(REF, "checkpoints", "checkpoint-3dmatch.pth"))
+    gen_kabsch_fixture("kabsch_cases.npz")
+
+
+if __name__ == "__main__":
+    main()
