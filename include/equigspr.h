@@ -1,0 +1,151 @@
+/*
+ * equigspr.h -- C-ABI of the MI355X-native Equi-GSPR registration hot path.
+ *
+ * libequigspr.so (built from the .hip files in se3_equi_graph_registration_amd/csrc for gfx950) exports
+ * exactly the entry points below.  Plain pointers and sizes only: no torch types, no C++
+ * types.  Every pointer is a DEVICE pointer unless it says "host".  All floating point is
+ * fp32; all functions enqueue on `stream` (a hipStream_t passed as void*) and never
+ * synchronise the host, never allocate (hipGraph-capturable: callers own every buffer and
+ * size the workspaces with the *_size() helpers).
+ *
+ * The reference has no FFI: its hot path is Python calling ATen ops.  Each entry point
+ * therefore cites the reference Python interface (file:line under /root/reference) that
+ * it replaces; INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Return value: 0 on success; a positive hipError_t for a HIP failure; a negative
+ * EQUIGSPR_E* for an argument error.  equigspr_last_error() gives the text (thread-local).
+ */
+#ifndef EQUIGSPR_H
+#define EQUIGSPR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EQUIGSPR_EINVAL   (-1)  /* bad shape / size / null pointer                         */
+#define EQUIGSPR_ENOTSUP  (-2)  /* configuration outside the compiled kernel set             */
+#define EQUIGSPR_ABI_VERSION 1
+
+/* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
+ * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
+ * Supported kernel set: hidden_nf in {32, 33}, num_heads in {1, 4} (hidden_nf % num_heads == 0),
+ * in_nf/out_nf <= 64, in_edge_nf in {0, 1}, 1 <= n_layers <= 16. */
+typedef struct equigspr_egnn_config {
+    int32_t in_nf;       /* in_node_nf  */
+    int32_t hidden_nf;   /* hidden_nf   */
+    int32_t out_nf;      /* out_node_nf */
+    int32_t in_edge_nf;  /* in_edge_nf (edge_attr width) */
+    int32_t n_layers;
+    int32_t num_heads;
+} equigspr_egnn_config;
+
+/* Graph in the device format every layer reuses (built once per batch of clouds).
+ * row = message/aggregation index (= the NEIGHBOUR for torch_cluster.knn_graph output),
+ * col = the other endpoint (the centre); both are global node ids over all clouds.
+ * rptr/rperm: for node j the edges with row==j, ascending edge id (reproduces the CPU
+ * scatter_add_ summation order of unsorted_segment_sum, :343-348).  cptr/cperm: same by col. */
+typedef struct equigspr_graph {
+    int32_t n_nodes;
+    int32_t n_edges;
+    const int32_t* row;    /* [E] */
+    const int32_t* col;    /* [E] */
+    const int32_t* rptr;   /* [N+1] */
+    const int32_t* rperm;  /* [E] */
+    const int32_t* cptr;   /* [N+1] */
+    const int32_t* cperm;  /* [E] */
+} equigspr_graph;
+
+int         equigspr_abi_version(void);
+const char* equigspr_last_error(void);
+
+/* ---- parameter block ---------------------------------------------------------------
+ * All EGNN parameters live in ONE flat fp32 buffer (and their gradients in another of the
+ * same layout -- the single bucket the data-parallel all-reduce sends over xGMI).  Order =
+ * the reference module's named_parameters() order, each tensor in PyTorch [out,in] layout:
+ *   embedding_in.weight [hid,in], embedding_in.bias, embedding_out.weight [out,hid], .bias,
+ *   per layer i: for head j: edge_mlps.j.0.weight [hid/H, 2*hid+12+in_edge_nf], .0.bias,
+ *                            edge_mlps.j.2.weight [hid/H, hid/H], .2.bias;
+ *                layer_norm.weight, .bias; node_mlp.0.weight [hid,2*hid], .0.bias,
+ *                node_mlp.2.weight [hid,hid], .2.bias; coord_mlp.0.weight [hid,hid], .0.bias,
+ *                coord_mlp.2.weight [1,hid].
+ * (state_dict keys: src/3dmatch_train_egnn_with_batch.py:202-229,:320-325.) */
+int64_t equigspr_egnn_param_count(const equigspr_egnn_config* cfg);
+/* offset (in floats) of layer i's block inside the flat buffer; i == n_layers -> total */
+int64_t equigspr_egnn_layer_offset(const equigspr_egnn_config* cfg, int32_t layer);
+
+/* ---- A1: k-NN graph -----------------------------------------------------------------
+ * Replaces torch_cluster.knn_graph(x, k, loop) as called per cloud at
+ * src/3dmatch_train_egnn_with_batch.py:1005-1006 (eval :1156-1157, kitti :975-976), for
+ * n_clouds equally sized clouds in one launch.
+ *   x          [n_clouds*n, 3]
+ *   edges_i64  [n_clouds, 2, n*k] or NULL: per cloud [neighbour; centre], LOCAL indices,
+ *              centre-major, ascending (d2, index) -- the reference LongTensor layout.
+ *   row32/col32 [n_clouds*n*k] or NULL: same edges as GLOBAL int32 node ids (device format).
+ * Distance contract: d2 = fl(fl(fl(dx*dx)+fl(dy*dy))+fl(dz*dz)), ties by lower index.
+ * Limits: 1 <= k <= 64, k <= n (k <= n-1 when loop==0), n <= 8192. */
+int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, int32_t k, int32_t loop,
+                       int64_t* edges_i64, int32_t* row32, int32_t* col32, int32_t force_slow_path,
+                       void* stream);
+
+/* ---- graph index build ---------------------------------------------------------------
+ * Builds rptr/rperm (key=row) or cptr/cperm (key=col): stable counting sort of edge ids.
+ * Replaces the implicit scatter_add_ indexing of unsorted_segment_sum (:343-348).
+ *   key [E] global ids in [0,N);  ptr [N+1];  perm [E];  scratch: int32 [N+1]. */
+int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n_nodes,
+                       int32_t* ptr, int32_t* perm, int32_t* scratch, void* stream);
+/* int64 reference edge list [2,E] (one cloud, local ids) -> int32 global ids (+node_offset) */
+int equigspr_edges_i64_to_i32(const int64_t* edges_i64, int32_t n_edges, int32_t node_offset,
+                              int32_t* row32, int32_t* col32, void* stream);
+
+/* ---- A3-A9: EGNN forward ---------------------------------------------------------------
+ * Replaces EGNN.forward(h, x, edges, edge_attr) (src/3dmatch_train_egnn_with_batch.py:328-340)
+ * = embedding_in, n_layers x E_GCL.forward (:280-289: coord2radial :271, edge_model :231,
+ * coord_model :262, node_model :252), embedding_out -- for ALL clouds of a batch at once.
+ *   params    flat parameter block (above)
+ *   h_in      [N, in_nf]     x_in [N,3]     edge_attr [E, in_edge_nf] or NULL (= all ones)
+ *   h_out     [N, out_nf]    x_out [N,3]
+ *   saved     float[equigspr_egnn_saved_size]   activations kept for backward (NULL = inference)
+ *   work      float[equigspr_egnn_work_size]    scratch */
+int64_t equigspr_egnn_saved_size(const equigspr_egnn_config* cfg, int32_t n_nodes);
+int64_t equigspr_egnn_work_size(const equigspr_egnn_config* cfg, int32_t n_nodes, int32_t n_edges);
+int equigspr_egnn_forward(const equigspr_egnn_config* cfg, const float* params,
+                          const equigspr_graph* g, const float* h_in, const float* x_in,
+                          const float* edge_attr, float* h_out, float* x_out,
+                          float* saved, float* work, void* stream);
+
+/* ---- A14: EGNN backward --------------------------------------------------------------
+ * Replaces autograd through EGNN.forward (loss.backward(), :1126).  Recomputes the per-edge
+ * activations from `saved`.
+ *   grad_h_out [N,out_nf], grad_x_out [N,3]    incoming
+ *   grad_params flat, same layout as params: ACCUMULATED into (+=) (caller zeroes)
+ *   grad_h_in [N,in_nf] or NULL, grad_x_in [N,3] or NULL   (overwritten)
+ *   work  float[equigspr_egnn_bwd_work_size] */
+int64_t equigspr_egnn_bwd_work_size(const equigspr_egnn_config* cfg, int32_t n_nodes, int32_t n_edges);
+int equigspr_egnn_backward(const equigspr_egnn_config* cfg, const float* params,
+                           const equigspr_graph* g, const float* h_in, const float* edge_attr,
+                           const float* saved, const float* grad_h_out, const float* grad_x_out,
+                           float* grad_params, float* grad_h_in, float* grad_x_in,
+                           float* work, void* stream);
+
+/* ---- A12: batched weighted Kabsch / 3x3 SVD pose head ---------------------------------
+ * Replaces the per-sample loop body at src/3dmatch_train_egnn_with_batch.py:726-758
+ * (eval :786-818): weighted centroids, H = sum w (s-cs)(t-ct)^T + 1e-6 I, SVD, R = V U^T with
+ * the det<0 fix on the smallest singular direction, t = ct - R cs.  Zero-weight points do
+ * not contribute (masking by weight); all-zero weights give R = I, t = 0 (:708-711).
+ *   src,tgt [B,n,3]   w [B,n]   R [B,9] row-major   t [B,3]   aux float[B*EQUIGSPR_KABSCH_AUX]
+ * Backward: closed form through the polar factor (1/(s_i+s_j) terms), finite for repeated
+ * singular values. */
+#define EQUIGSPR_KABSCH_AUX 48
+int equigspr_kabsch_forward(const float* src, const float* tgt, const float* w, int32_t batch,
+                            int32_t n, float* R, float* t, float* aux, void* stream);
+int equigspr_kabsch_backward(const float* src, const float* tgt, const float* w, const float* aux,
+                             const float* grad_R, const float* grad_t, int32_t batch, int32_t n,
+                             float* grad_src, float* grad_tgt, float* grad_w, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EQUIGSPR_H */

@@ -1,0 +1,18 @@
+"""MI355X-native Equi-GSPR registration hot path (k-NN graph -> EGNN message passing ->
+weighted-SVD pose head) behind the reference's own Python interface.
+
+Everything computes in hand-written HIP kernels for gfx950 reached through the C-ABI of
+``include/equigspr.h`` (``libequigspr.so``); importing the ops without the built library
+raises -- there is no CPU fallback.
+"""
+from ._lib import lib, LIB_PATH, declared_symbols  # noqa: F401
+from .ops import DeviceGraph, weighted_kabsch, knn_graph_batched  # noqa: F401
+from .graph import knn_graph, get_edges_batch, get_edges_from_idx, build_pair_graph  # noqa: F401
+from .egnn import EGNN, E_GCL  # noqa: F401
+from .pose import (CrossAttentionPoseRegression, pose_loss, compute_losses, egnn_equi_loss,  # noqa: F401
+                   unsorted_segment_sum, unsorted_segment_mean)
+from .synth import synthetic_pair, synthetic_batch  # noqa: F401
+
+__all__ = ["EGNN", "E_GCL", "CrossAttentionPoseRegression", "knn_graph", "get_edges_batch", "get_edges_from_idx",
+           "build_pair_graph", "DeviceGraph", "weighted_kabsch", "pose_loss", "compute_losses", "egnn_equi_loss",
+           "unsorted_segment_sum", "unsorted_segment_mean", "synthetic_pair", "synthetic_batch"]

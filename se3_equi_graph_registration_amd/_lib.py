@@ -1,0 +1,86 @@
+"""ctypes binding of libequigspr.so (the C-ABI declared in include/equigspr.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, every
+op raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C se3_equi_graph_registration_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from ctypes import POINTER, Structure, c_char_p, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libequigspr.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "equigspr.h")
+KABSCH_AUX = 48
+
+
+class EgnnConfig(Structure):
+    _fields_ = [("in_nf", c_int32), ("hidden_nf", c_int32), ("out_nf", c_int32),
+                ("in_edge_nf", c_int32), ("n_layers", c_int32), ("num_heads", c_int32)]
+
+
+class Graph(Structure):
+    _fields_ = [("n_nodes", c_int32), ("n_edges", c_int32), ("row", c_void_p), ("col", c_void_p),
+                ("rptr", c_void_p), ("rperm", c_void_p), ("cptr", c_void_p), ("cperm", c_void_p)]
+
+
+_SIGNATURES = {
+    "equigspr_abi_version": (ctypes.c_int, []),
+    "equigspr_last_error": (c_char_p, []),
+    "equigspr_egnn_param_count": (c_int64, [POINTER(EgnnConfig)]),
+    "equigspr_egnn_layer_offset": (c_int64, [POINTER(EgnnConfig), c_int32]),
+    "equigspr_knn_graph": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                          c_void_p, c_int32, c_void_p]),
+    "equigspr_build_csr": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "equigspr_edges_i64_to_i32": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "equigspr_egnn_saved_size": (c_int64, [POINTER(EgnnConfig), c_int32]),
+    "equigspr_egnn_work_size": (c_int64, [POINTER(EgnnConfig), c_int32, c_int32]),
+    "equigspr_egnn_forward": (ctypes.c_int, [POINTER(EgnnConfig), c_void_p, POINTER(Graph), c_void_p, c_void_p,
+                                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "equigspr_egnn_bwd_work_size": (c_int64, [POINTER(EgnnConfig), c_int32, c_int32]),
+    "equigspr_egnn_backward": (ctypes.c_int, [POINTER(EgnnConfig), c_void_p, POINTER(Graph), c_void_p, c_void_p,
+                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_void_p]),
+    "equigspr_kabsch_forward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                                               c_void_p, c_void_p]),
+    "equigspr_kabsch_backward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    """Function names declared in include/equigspr.h (used by the export test)."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(equigspr_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    """Load (once) and return the shared library; raises loudly when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built. "
+                "Run `python -c \"import __graft_entry__ as g; g.build()\"` "
+                "(there is no CPU fallback in this package).")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if L.equigspr_abi_version() != 1:
+            raise RuntimeError("libequigspr.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().equigspr_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,46 @@
+// Shared host-side plumbing for the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/equigspr.h"
+#include "egnn_math.h"
+
+namespace eq {
+
+void set_error(const char* fmt, ...);   // api.hip
+
+#define EQ_CHECK_ARG(cond, code, ...)            \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::eq::set_error(__VA_ARGS__);        \
+            return (code);                       \
+        }                                        \
+    } while (0)
+
+#define EQ_CHECK_LAUNCH(what)                                                     \
+    do {                                                                          \
+        hipError_t _e = hipGetLastError();                                        \
+        if (_e != hipSuccess) {                                                   \
+            ::eq::set_error("%s: %s", (what), hipGetErrorString(_e));            \
+            return (int)_e;                                                       \
+        }                                                                         \
+    } while (0)
+
+constexpr int kWave = 64;
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// padded feature stride used by every internal [rows x F] fp32 buffer (16-byte rows)
+static inline int fpad(int F) { return round_up(F, 4); }
+
+inline bool config_supported(const equigspr_egnn_config* c) {
+    if (!c) return false;
+    const bool f_ok = (c->hidden_nf == 32 && (c->num_heads == 1 || c->num_heads == 4)) ||
+                      (c->hidden_nf == 33 && c->num_heads == 1);
+    return f_ok && c->in_nf >= 1 && c->in_nf <= 64 && c->out_nf >= 1 && c->out_nf <= 64 &&
+           (c->in_edge_nf == 0 || c->in_edge_nf == 1) && c->n_layers >= 1 && c->n_layers <= 16;
+}
+
+}  // namespace eq

@@ -1,0 +1,335 @@
+// EGNN forward for gfx950: embedding_in -> L x E_GCL -> embedding_out, all clouds of a batch
+// in one launch per stage.
+//
+// Per layer two kernels (reference E_GCL.forward :280-289):
+//   edge kernel : one lane per edge.  The 77-wide concat [h_r|h_c|geo|attr] (:238-242) is
+//                 never built: W1 is split into [W_src | W_tgt | W_geo | w_attr]; W_src*h and
+//                 W_tgt*h + b1 are projected ONCE PER NODE (P buffer) by the previous node
+//                 kernel, so an edge only adds two gathered 128-B rows and a 13-column
+//                 geometry product.  Then SiLU, block-diagonal W2, LayerNorm, coord MLP, all
+//                 in registers with wave-uniform (scalar-loaded) weights.  Writes m_e and
+//                 trans_e once.
+//   node kernel : G lanes per node (lane = feature).  Sums m_e / trans_e over the node's
+//                 incoming-edge list in ascending edge id (atomic-free, bitwise reproducible,
+//                 the CPU scatter_add_ order of unsorted_segment_sum :343-348), node MLP with
+//                 residual (:252-260), coordinate update (:262-268), and the NEXT layer's
+//                 per-node projections (or embedding_out after the last layer).
+#include "common.h"
+
+namespace eq {
+
+template <int F> struct Geom {
+    static constexpr int FP = (F + 3) / 4 * 4;     // padded row (16-byte rows)
+    static constexpr int G = F <= 32 ? 32 : 64;    // lanes per node in node kernels
+    static constexpr int NS = 256 / G;             // node slots per 256-thread block
+    static constexpr int PS = 2 * FP;              // P row: [Pr (FP) | Pc (FP)]
+};
+
+// y = sum_i W[row][i] * v[i], W row-major with row stride `ld`, v in LDS (broadcast reads)
+__device__ __forceinline__ float row_dot(const float* __restrict__ wrow, const float* v, int n) {
+    float acc = 0.0f;
+    for (int i = 0; i < n; ++i) acc = fmaf(wrow[i], v[i], acc);
+    return acc;
+}
+
+// per-node projections for a layer: Pr = W1[:, 0:F] h ; Pc = W1[:, F:2F] h + b1
+template <int F, int H, int A>
+__device__ __forceinline__ void project_pre(const float* __restrict__ lw, const float* hv, int f,
+                                            float* __restrict__ prow) {
+    using LL = LP<F, H, A>;
+    constexpr int FP = Geom<F>::FP;
+    if (f < F) {
+        const float* w = lw + LL::w1_off(f, 0);
+        prow[f] = row_dot(w, hv, F);
+        prow[FP + f] = lw[LL::b1_off(f)] + row_dot(w + F, hv, F);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// embedding_in (+ layer-0 projections).  h0 -> hs0, x -> xs0
+// ---------------------------------------------------------------------------------------
+template <int F, int H, int A>
+__global__ __launch_bounds__(256) void embed_in_kernel(const float* __restrict__ params, int in_nf, int w_in, int b_in,
+                                                       int layer0, const float* __restrict__ h_in,
+                                                       const float* __restrict__ x_in, int n_nodes,
+                                                       float* __restrict__ h0, float* __restrict__ x0,
+                                                       float* __restrict__ P) {
+    constexpr int FP = Geom<F>::FP, G = Geom<F>::G, NS = Geom<F>::NS, PS = Geom<F>::PS;
+    __shared__ float vin[NS][64];
+    __shared__ float hv[NS][FP];
+    const int slot = threadIdx.x / G, f = threadIdx.x % G;
+    const int groups = (n_nodes + NS - 1) / NS;
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int j = grp * NS + slot;
+        const bool live = j < n_nodes;
+        __syncthreads();
+        if (live) {
+            for (int i = f; i < in_nf; i += G) vin[slot][i] = h_in[(size_t)j * in_nf + i];
+            if (f < 3) x0[(size_t)j * 3 + f] = x_in[(size_t)j * 3 + f];
+        }
+        __syncthreads();
+        if (live && f < F) {
+            const float v = params[b_in + f] + row_dot(params + w_in + f * in_nf, vin[slot], in_nf);
+            h0[(size_t)j * FP + f] = v;
+            hv[slot][f] = v;
+        }
+        __syncthreads();
+        if (live) project_pre<F, H, A>(params + layer0, hv[slot], f, P + (size_t)j * PS);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// edge kernel
+// ---------------------------------------------------------------------------------------
+template <int F, int H, int A>
+struct EdgeFwd {
+    using LL = LP<F, H, A>;
+    static constexpr int FH = F / H;
+
+    // forward of one edge up to s; fills the activations the backward needs when asked.
+    // t1: pre-activation of the first edge Linear; u -> xhat (normalised), m; q pre-activation.
+    __device__ static __forceinline__ void run(const float* __restrict__ lw, const float* __restrict__ prow,
+                                               const float* __restrict__ pcrow, const float geo[kGeo], float attr,
+                                               float t1[F], float xhat[F], float& rstd, float m[F], float q[F],
+                                               float& s) {
+        constexpr int FP = Geom<F>::FP;
+        // gather the two per-node projections (16-byte loads)
+        float pr[FP], pc[FP];
+#pragma unroll
+        for (int v = 0; v < FP / 4; ++v) {
+            const float4 a = reinterpret_cast<const float4*>(prow)[v];
+            const float4 b = reinterpret_cast<const float4*>(pcrow)[v];
+            pr[4 * v] = a.x; pr[4 * v + 1] = a.y; pr[4 * v + 2] = a.z; pr[4 * v + 3] = a.w;
+            pc[4 * v] = b.x; pc[4 * v + 1] = b.y; pc[4 * v + 2] = b.z; pc[4 * v + 3] = b.w;
+        }
+#pragma unroll
+        for (int o = 0; o < F; ++o) {
+            const float* w = lw + LL::w1_off(o, 2 * F);
+            float acc = pr[o] + pc[o];
+#pragma unroll
+            for (int g = 0; g < kGeo; ++g) acc = fmaf(w[g], geo[g], acc);
+            if (A) acc = fmaf(w[kGeo], attr, acc);
+            t1[o] = acc;
+        }
+        float g1[F];
+#pragma unroll
+        for (int o = 0; o < F; ++o) g1[o] = silu(t1[o]);
+        float u[F];
+        float mean = 0.0f;
+#pragma unroll
+        for (int o = 0; o < F; ++o) {
+            float acc = lw[LL::b2_off(o)];
+            const int hb = (o / FH) * FH;
+#pragma unroll
+            for (int i = 0; i < FH; ++i) acc = fmaf(lw[LL::w2_off(o, hb + i)], g1[hb + i], acc);
+            u[o] = acc;
+            mean += acc;
+        }
+        mean *= (1.0f / F);
+        float var = 0.0f;
+#pragma unroll
+        for (int o = 0; o < F; ++o) { const float c = u[o] - mean; var = fmaf(c, c, var); }
+        var *= (1.0f / F);
+        rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+        for (int o = 0; o < F; ++o) {
+            xhat[o] = (u[o] - mean) * rstd;
+            m[o] = fmaf(xhat[o], lw[LL::ln_g + o], lw[LL::ln_b + o]);
+        }
+        s = 0.0f;
+#pragma unroll
+        for (int o = 0; o < F; ++o) {
+            float acc = lw[LL::b6 + o];
+#pragma unroll
+            for (int i = 0; i < F; ++i) acc = fmaf(lw[LL::w6 + o * F + i], m[i], acc);
+            q[o] = acc;
+            s = fmaf(lw[LL::w7 + o], silu(acc), s);
+        }
+    }
+};
+
+template <int F, int H, int A>
+__global__ __launch_bounds__(256) void edge_fwd_kernel(const float* __restrict__ lw, const int* __restrict__ row,
+                                                       const int* __restrict__ col, const float* __restrict__ edge_attr,
+                                                       const float* __restrict__ x, const float* __restrict__ P,
+                                                       int n_edges, float* __restrict__ m_out,
+                                                       float* __restrict__ trans_out) {
+    constexpr int FP = Geom<F>::FP, PS = Geom<F>::PS;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_edges) return;
+    const int r = row[e], c = col[e];
+    float xr[3], xc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { xr[i] = x[(size_t)r * 3 + i]; xc[i] = x[(size_t)c * 3 + i]; }
+    EdgeGeo eg;
+    edge_geometry(xr, xc, eg);
+    const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
+    float t1[F], xhat[F], m[F], q[F], rstd, s;
+    EdgeFwd<F, H, A>::run(lw, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg.g, attr, t1, xhat, rstd, m, q, s);
+    float4* mo = reinterpret_cast<float4*>(m_out + (size_t)e * FP);
+#pragma unroll
+    for (int v = 0; v < FP / 4; ++v) {
+        float4 o;
+        o.x = m[4 * v];
+        o.y = (4 * v + 1 < F) ? m[(4 * v + 1 < F) ? 4 * v + 1 : 0] : 0.0f;
+        o.z = (4 * v + 2 < F) ? m[(4 * v + 2 < F) ? 4 * v + 2 : 0] : 0.0f;
+        o.w = (4 * v + 3 < F) ? m[(4 * v + 3 < F) ? 4 * v + 3 : 0] : 0.0f;
+        mo[v] = o;
+    }
+    float4 tr;
+    tr.x = eg.d[0] * s; tr.y = eg.d[1] * s; tr.z = eg.d[2] * s; tr.w = 0.0f;      // :264
+    reinterpret_cast<float4*>(trans_out)[e] = tr;
+}
+
+// ---------------------------------------------------------------------------------------
+// node kernel
+// ---------------------------------------------------------------------------------------
+template <int F, int H, int A>
+__global__ __launch_bounds__(256) void node_fwd_kernel(
+    const float* __restrict__ lw,        // this layer's block
+    const float* __restrict__ next_lw,   // next layer's block (projections) or nullptr on the last layer
+    const float* __restrict__ w_out, const float* __restrict__ b_out, int out_nf,   // embedding_out (last layer)
+    const int* __restrict__ rptr, const int* __restrict__ rperm, const float* __restrict__ m_in,
+    const float* __restrict__ trans_in, const float* __restrict__ h, const float* __restrict__ x, int n_nodes,
+    float* __restrict__ h_next, float* __restrict__ x_next, float* __restrict__ agg_save,
+    float* __restrict__ P, float* __restrict__ h_out) {
+    using LL = LP<F, H, A>;
+    constexpr int FP = Geom<F>::FP, G = Geom<F>::G, NS = Geom<F>::NS, PS = Geom<F>::PS;
+    __shared__ float vin[NS][2 * FP];
+    __shared__ float hid[NS][FP];
+    __shared__ float hnew[NS][FP];
+    const int slot = threadIdx.x / G, f = threadIdx.x % G;
+    const int groups = (n_nodes + NS - 1) / NS;
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int j = grp * NS + slot;
+        const bool live = j < n_nodes;
+        const bool act = live && f < F;
+        float hj = 0.0f, agg = 0.0f, xagg = 0.0f;
+        if (live) {
+            const int lo = rptr[j], hi = rptr[j + 1];
+            if (f < F) {
+                hj = h[(size_t)j * FP + f];
+                for (int a = lo; a < hi; ++a) agg += m_in[(size_t)rperm[a] * FP + f];      // ascending edge id
+            }
+            if (f < 3) {
+                for (int a = lo; a < hi; ++a) xagg += trans_in[(size_t)rperm[a] * 4 + f];
+                x_next[(size_t)j * 3 + f] = x[(size_t)j * 3 + f] + xagg;                    // :267
+            }
+        }
+        __syncthreads();
+        if (act) {
+            vin[slot][f] = hj;
+            vin[slot][F + f] = agg;
+            if (agg_save) agg_save[(size_t)j * FP + f] = agg;
+        }
+        __syncthreads();
+        if (act) hid[slot][f] = silu(lw[LL::b4 + f] + row_dot(lw + LL::w4 + f * 2 * F, vin[slot], 2 * F));
+        __syncthreads();
+        if (act) {
+            const float hn = hj + lw[LL::b5 + f] + row_dot(lw + LL::w5 + f * F, hid[slot], F);   // :257-259
+            h_next[(size_t)j * FP + f] = hn;
+            hnew[slot][f] = hn;
+        }
+        __syncthreads();
+        if (live) {
+            if (next_lw) {
+                project_pre<F, H, A>(next_lw, hnew[slot], f, P + (size_t)j * PS);
+            } else {
+                for (int o = f; o < out_nf; o += G)
+                    h_out[(size_t)j * out_nf + o] = b_out[o] + row_dot(w_out + o * F, hnew[slot], F);   // :337
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------------
+struct FwdBuffers {
+    float *P, *m, *trans;        // work
+    float *hs, *xs, *aggs;       // saved (or ping-pong in work when not training)
+    bool training;
+};
+
+static inline int64_t saved_floats(int F, int L, int64_t N) {
+    const int FP = fpad(F);
+    return (int64_t)(L + 1) * N * FP + (int64_t)(L + 1) * N * 3 + (int64_t)L * N * FP;
+}
+static inline int64_t work_floats(int F, int64_t N, int64_t E) {
+    const int FP = fpad(F);
+    // P | m | trans | ping-pong h (2) | ping-pong x (2)
+    return N * 2 * FP + E * FP + E * 4 + 2 * N * FP + 2 * N * 3 + 64;
+}
+
+template <int F, int H, int A>
+static int forward_impl(const equigspr_egnn_config* cfg, const float* params, const equigspr_graph* g,
+                        const float* h_in, const float* x_in, const float* edge_attr, float* h_out, float* x_out,
+                        float* saved, float* work, hipStream_t s) {
+    const ModelLayout ML = make_model_layout(cfg->in_nf, F, cfg->out_nf, A, cfg->n_layers, H);
+    const int N = g->n_nodes, E = g->n_edges, L = cfg->n_layers;
+    constexpr int FP = Geom<F>::FP, NS = Geom<F>::NS;
+    float* P = work;
+    float* m = P + (size_t)N * 2 * FP;
+    float* trans = m + (size_t)E * FP;
+    float* pp_h = trans + (size_t)E * 4;
+    float* pp_x = pp_h + (size_t)2 * N * FP;
+    const bool training = saved != nullptr;
+    float* hs = saved;
+    float* xs = training ? saved + (size_t)(L + 1) * N * FP : nullptr;
+    float* aggs = training ? xs + (size_t)(L + 1) * N * 3 : nullptr;
+    auto hbuf = [&](int l) { return training ? hs + (size_t)l * N * FP : pp_h + (size_t)(l & 1) * N * FP; };
+    auto xbuf = [&](int l) { return training ? xs + (size_t)l * N * 3 : pp_x + (size_t)(l & 1) * N * 3; };
+
+    const int node_groups = ceil_div(N, NS);
+    const int node_grid = node_groups < 2048 ? node_groups : 2048;
+    hipLaunchKernelGGL((embed_in_kernel<F, H, A>), dim3(node_grid), dim3(256), 0, s, params, cfg->in_nf, ML.w_in,
+                       ML.b_in, ML.layer0, h_in, x_in, N, hbuf(0), xbuf(0), P);
+    for (int l = 0; l < L; ++l) {
+        const float* lw = params + ML.layer0 + (size_t)l * ML.layer_size;
+        const bool last = (l == L - 1);
+        if (E > 0)
+            hipLaunchKernelGGL((edge_fwd_kernel<F, H, A>), dim3(ceil_div(E, 256)), dim3(256), 0, s, lw, g->row, g->col,
+                               edge_attr, xbuf(l), P, E, m, trans);
+        float* xn = last ? x_out : xbuf(l + 1);
+        hipLaunchKernelGGL((node_fwd_kernel<F, H, A>), dim3(node_grid), dim3(256), 0, s, lw,
+                           last ? nullptr : lw + ML.layer_size, params + ML.w_out, params + ML.b_out, cfg->out_nf,
+                           g->rptr, g->rperm, m, trans, hbuf(l), xbuf(l), N, hbuf(l + 1), xn,
+                           training ? aggs + (size_t)l * N * FP : nullptr, P, h_out);
+        if (last && training) {   // keep x_L with the saved activations too (backward reads xs[L] never; cheap copy skipped)
+        }
+    }
+    EQ_CHECK_LAUNCH("egnn_forward");
+    return 0;
+}
+
+}  // namespace eq
+
+extern "C" int64_t equigspr_egnn_saved_size(const equigspr_egnn_config* cfg, int32_t n_nodes) {
+    if (!eq::config_supported(cfg) || n_nodes < 0) return -1;
+    return eq::saved_floats(cfg->hidden_nf, cfg->n_layers, n_nodes);
+}
+
+extern "C" int64_t equigspr_egnn_work_size(const equigspr_egnn_config* cfg, int32_t n_nodes, int32_t n_edges) {
+    if (!eq::config_supported(cfg) || n_nodes < 0 || n_edges < 0) return -1;
+    return eq::work_floats(cfg->hidden_nf, n_nodes, n_edges);
+}
+
+extern "C" int equigspr_egnn_forward(const equigspr_egnn_config* cfg, const float* params, const equigspr_graph* g,
+                                     const float* h_in, const float* x_in, const float* edge_attr, float* h_out,
+                                     float* x_out, float* saved, float* work, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(config_supported(cfg), EQUIGSPR_ENOTSUP,
+                 "egnn_forward: unsupported config (hidden_nf in {32,33}, heads in {1,4}, in/out<=64, in_edge_nf in {0,1})");
+    EQ_CHECK_ARG(params && g && h_in && x_in && h_out && x_out && work, EQUIGSPR_EINVAL, "egnn_forward: null pointer");
+    EQ_CHECK_ARG(g->n_nodes >= 1 && g->n_edges >= 0 && g->row && g->col && g->rptr && g->rperm, EQUIGSPR_EINVAL,
+                 "egnn_forward: incomplete graph");
+    hipStream_t s = (hipStream_t)stream;
+    const int F = cfg->hidden_nf, H = cfg->num_heads, A = cfg->in_edge_nf;
+#define EQ_DISPATCH(FF, HH, AA) \
+    if (F == FF && H == HH && A == AA) return forward_impl<FF, HH, AA>(cfg, params, g, h_in, x_in, edge_attr, h_out, x_out, saved, work, s);
+    EQ_DISPATCH(32, 1, 1) EQ_DISPATCH(32, 1, 0) EQ_DISPATCH(32, 4, 1) EQ_DISPATCH(32, 4, 0)
+    EQ_DISPATCH(33, 1, 1) EQ_DISPATCH(33, 1, 0)
+#undef EQ_DISPATCH
+    set_error("egnn_forward: no kernel for F=%d H=%d A=%d", F, H, A);
+    return EQUIGSPR_ENOTSUP;
+}

@@ -1,0 +1,199 @@
+// Per-edge math of one E_GCL layer, shared by the HIP kernels and by the host-side unit
+// test (tests/test_host_math.py compiles this header with g++ to check the formulas on CPU
+// before they ever reach a GPU).  Everything here is `EQ_HD` (host + device) and scalar.
+//
+// Reference math: src/3dmatch_train_egnn_with_batch.py:
+//   compute_so3_matrix :128-173, compute_edge_features :176-181, E_GCL.coord2radial :271-278.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define EQ_HD __host__ __device__ __forceinline__
+#else
+#define EQ_HD inline
+#endif
+
+namespace eq {
+
+// z-vector geometry block, in the reference's concatenation order (:238):
+//   [radial, dist, dot, a0,b0,c0, a1,b1,c1, a2,b2,c2]
+constexpr int kGeo = 12;
+
+struct EdgeGeo {
+    float d[3];       // coord_diff = x[row] - x[col]                      (:273)
+    float g[kGeo];    // radial, dist, dot, so3_flat[9]
+    float inv_na;     // 1/(|d|+1e-8)    (kept for backward)
+    float inv_nb;     // 1/(|p|+1e-8)
+    float p[3];       // cross(x_r, x_c)
+    float pn;         // |p|
+    bool  degenerate; // frame replaced by identity (:152-163)
+};
+
+EQ_HD float silu(float v) { return v / (1.0f + expf(-v)); }
+// d/dv silu(v) = s(v) * (1 + v * (1 - s(v)))
+EQ_HD float silu_grad(float v) {
+    float s = 1.0f / (1.0f + expf(-v));
+    return s * (1.0f + v * (1.0f - s));
+}
+
+EQ_HD void cross3(const float* a, const float* b, float* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+EQ_HD float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+EQ_HD void edge_geometry(const float xr[3], const float xc[3], EdgeGeo& e) {
+    for (int i = 0; i < 3; ++i) e.d[i] = xr[i] - xc[i];
+    const float radial = dot3(e.d, e.d);                    // :274
+    const float dist = sqrtf(radial);                       // :179
+    e.g[0] = radial;
+    e.g[1] = dist;
+    e.g[2] = dot3(xr, xc);                                  // :180
+    e.inv_na = 1.0f / (dist + 1e-8f);                       // :140
+    float a[3], b[3], c[3];
+    for (int i = 0; i < 3; ++i) a[i] = e.d[i] * e.inv_na;
+    cross3(xr, xc, e.p);                                    // :143
+    e.pn = sqrtf(dot3(e.p, e.p));
+    e.inv_nb = 1.0f / (e.pn + 1e-8f);                       // :144
+    for (int i = 0; i < 3; ++i) b[i] = e.p[i] * e.inv_nb;
+    cross3(a, b, c);                                        // :149
+    const float thr = 1e-6f;                                // :130
+    e.degenerate = (sqrtf(dot3(a, a)) < thr) || (sqrtf(dot3(b, b)) < thr) || (sqrtf(dot3(c, c)) < thr);
+    if (e.degenerate) {                                     // :163 identity frame
+        for (int i = 0; i < 9; ++i) e.g[3 + i] = (i % 4 == 0) ? 1.0f : 0.0f;
+    } else {                                                // stack(dim=2).view(-1,9): [a_i, b_i, c_i] per row i
+        for (int i = 0; i < 3; ++i) {
+            e.g[3 + 3 * i + 0] = a[i];
+            e.g[3 + 3 * i + 1] = b[i];
+            e.g[3 + 3 * i + 2] = c[i];
+        }
+    }
+}
+
+// Backward of edge_geometry (+ the direct coord_diff path of coord_model, :264).
+//   gg[12]  = dL/d g,   gd[3] = dL/d coord_diff (from trans = coord_diff * s)
+// Outputs dL/dx_r, dL/dx_c (overwritten).
+EQ_HD void edge_geometry_backward(const float xr[3], const float xc[3], const EdgeGeo& e,
+                                  const float gg[kGeo], const float gd[3], float gxr[3], float gxc[3]) {
+    float gdt[3];                      // total gradient w.r.t. d = x_r - x_c
+    const float dist = e.g[1];
+    const float inv_dist = dist > 0.0f ? 1.0f / dist : 0.0f;     // torch.norm backward: 0 at 0
+    for (int i = 0; i < 3; ++i) {
+        gdt[i] = gd[i] + 2.0f * e.d[i] * gg[0] + e.d[i] * inv_dist * gg[1];
+        gxr[i] = xc[i] * gg[2];
+        gxc[i] = xr[i] * gg[2];
+    }
+    if (!e.degenerate) {
+        float a[3], b[3], ga[3], gb[3], gc[3];
+        for (int i = 0; i < 3; ++i) {
+            a[i] = e.d[i] * e.inv_na;
+            b[i] = e.p[i] * e.inv_nb;
+            ga[i] = gg[3 + 3 * i + 0];
+            gb[i] = gg[3 + 3 * i + 1];
+            gc[i] = gg[3 + 3 * i + 2];
+        }
+        // c = a x b  ->  ga += b x gc ; gb += gc x a
+        float t0[3], t1[3];
+        cross3(b, gc, t0);
+        cross3(gc, a, t1);
+        for (int i = 0; i < 3; ++i) { ga[i] += t0[i]; gb[i] += t1[i]; }
+        // a = d / (n + eps):  gd += ga/(n+eps) - d (d.ga) / (n (n+eps)^2)
+        const float dga = dot3(e.d, ga);
+        const float ka = dga * inv_dist * e.inv_na * e.inv_na;
+        for (int i = 0; i < 3; ++i) gdt[i] += ga[i] * e.inv_na - e.d[i] * ka;
+        // b = p / (|p| + eps)
+        const float inv_pn = e.pn > 0.0f ? 1.0f / e.pn : 0.0f;
+        const float pgb = dot3(e.p, gb);
+        const float kb = pgb * inv_pn * e.inv_nb * e.inv_nb;
+        float gp[3];
+        for (int i = 0; i < 3; ++i) gp[i] = gb[i] * e.inv_nb - e.p[i] * kb;
+        // p = x_r x x_c  ->  gxr += x_c x gp ; gxc += gp x x_r
+        cross3(xc, gp, t0);
+        cross3(gp, xr, t1);
+        for (int i = 0; i < 3; ++i) { gxr[i] += t0[i]; gxc[i] += t1[i]; }
+    }
+    for (int i = 0; i < 3; ++i) { gxr[i] += gdt[i]; gxc[i] -= gdt[i]; }
+}
+
+// ------------------------------------------------------------------------------------
+// Flat parameter-block layout (include/equigspr.h "parameter block").
+// ------------------------------------------------------------------------------------
+struct LayerLayout {
+    int F, H, A, FH, D;
+    // offsets (floats) relative to the layer block
+    int head_stride, w1, b1, w2, b2;      // per head: + j*head_stride
+    int ln_g, ln_b, w4, b4, w5, b5, w6, b6, w7, size;
+};
+
+EQ_HD LayerLayout make_layer_layout(int F, int H, int A) {
+    LayerLayout L;
+    L.F = F; L.H = H; L.A = A; L.FH = F / H; L.D = 2 * F + kGeo + A;
+    L.w1 = 0;
+    L.b1 = L.w1 + L.FH * L.D;
+    L.w2 = L.b1 + L.FH;
+    L.b2 = L.w2 + L.FH * L.FH;
+    L.head_stride = L.b2 + L.FH;
+    int o = L.H * L.head_stride;
+    L.ln_g = o; o += F;
+    L.ln_b = o; o += F;
+    L.w4 = o; o += F * 2 * F;
+    L.b4 = o; o += F;
+    L.w5 = o; o += F * F;
+    L.b5 = o; o += F;
+    L.w6 = o; o += F * F;
+    L.b6 = o; o += F;
+    L.w7 = o; o += F;
+    L.size = o;
+    return L;
+}
+
+// Compile-time twin of LayerLayout for the kernels (every offset folds to an immediate).
+template <int F_, int H_, int A_>
+struct LP {
+    static constexpr int F = F_, H = H_, A = A_;
+    static constexpr int FH = F / H;
+    static constexpr int D = 2 * F + kGeo + A;
+    static constexpr int w1 = 0;
+    static constexpr int b1 = w1 + FH * D;
+    static constexpr int w2 = b1 + FH;
+    static constexpr int b2 = w2 + FH * FH;
+    static constexpr int head_stride = b2 + FH;
+    static constexpr int ln_g = H * head_stride;
+    static constexpr int ln_b = ln_g + F;
+    static constexpr int w4 = ln_b + F;
+    static constexpr int b4 = w4 + F * 2 * F;
+    static constexpr int w5 = b4 + F;
+    static constexpr int b5 = w5 + F * F;
+    static constexpr int w6 = b5 + F;
+    static constexpr int b6 = w6 + F * F;
+    static constexpr int w7 = b6 + F;
+    static constexpr int size = w7 + F;
+    // W1[o][c], stacked over heads
+    static constexpr EQ_HD int w1_off(int o, int c) { return (o / FH) * head_stride + w1 + (o % FH) * D + c; }
+    static constexpr EQ_HD int b1_off(int o) { return (o / FH) * head_stride + b1 + (o % FH); }
+    // W2 is block diagonal: valid only when o and i are in the same head
+    static constexpr EQ_HD int w2_off(int o, int i) { return (o / FH) * head_stride + w2 + (o % FH) * FH + (i % FH); }
+    static constexpr EQ_HD int b2_off(int o) { return (o / FH) * head_stride + b2 + (o % FH); }
+};
+
+struct ModelLayout {
+    int in_nf, F, out_nf, A, L, H;
+    int w_in, b_in, w_out, b_out, layer0, layer_size, total;
+};
+EQ_HD ModelLayout make_model_layout(int in_nf, int F, int out_nf, int A, int L, int H) {
+    ModelLayout M;
+    M.in_nf = in_nf; M.F = F; M.out_nf = out_nf; M.A = A; M.L = L; M.H = H;
+    int o = 0;
+    M.w_in = o; o += F * in_nf;
+    M.b_in = o; o += F;
+    M.w_out = o; o += out_nf * F;
+    M.b_out = o; o += out_nf;
+    M.layer0 = o;
+    M.layer_size = make_layer_layout(F, H, A).size;
+    M.total = o + L * M.layer_size;
+    return M;
+}
+
+}  // namespace eq

@@ -1,0 +1,288 @@
+// Batched weighted Kabsch pose head for gfx950: one 256-thread workgroup per pair.
+//   pass 1  weighted centroids            (wave shuffles + LDS across the 4 waves)
+//   pass 2  H = sum w (s-cs)(t-ct)^T      (same reduction, 15 partial sums)
+//   lane 0  H += 1e-6 I; one-sided Jacobi SVD of the 3x3 in fp64; R = V D U^T with D flipping
+//           the smallest singular direction when det(V U^T) < 0; t = ct - R cs.
+// The reference's host-visible `if torch.det(R_b) < 0` (train :749) is a device-side select;
+// nothing synchronises with the host.  Backward is the closed form through the polar factor.
+//
+// Reference: src/3dmatch_train_egnn_with_batch.py:726-758, src/eval_egnn_metrics.py:786-818.
+#include "common.h"
+
+namespace eq {
+
+template <int NV>
+__device__ __forceinline__ void block_reduce_sum(float (&v)[NV], float* smem /* [4*NV] */, float* out /* LDS [NV] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float a = v[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        v[i] = a;
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) smem[wave * NV + i] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) out[threadIdx.x] = smem[threadIdx.x] + smem[NV + threadIdx.x] + smem[2 * NV + threadIdx.x] + smem[3 * NV + threadIdx.x];
+    __syncthreads();
+}
+
+__device__ inline double det3(const double m[9]) {
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+// One-sided Jacobi: A V = B with orthogonal columns; sigma_i = |B_i|, U_i = B_i / sigma_i.
+__device__ inline void svd3_jacobi(const double A[9], double U[9], double sig[3], double V[9]) {
+    double B[9];
+    for (int i = 0; i < 9; ++i) { B[i] = A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        bool rotated = false;
+        for (int pair = 0; pair < 3; ++pair) {
+            const int p = pair == 2 ? 1 : 0, q = pair == 0 ? 1 : 2;
+            double al = 0, be = 0, ga = 0;
+            for (int r = 0; r < 3; ++r) {
+                al += B[r * 3 + p] * B[r * 3 + p];
+                be += B[r * 3 + q] * B[r * 3 + q];
+                ga += B[r * 3 + p] * B[r * 3 + q];
+            }
+            if (fabs(ga) > 1e-300 && fabs(ga) > 1e-17 * sqrt(al * be)) {
+                rotated = true;
+                const double ze = (be - al) / (2.0 * ga);
+                const double tt = (ze == 0.0) ? 1.0 : copysign(1.0, ze) / (fabs(ze) + sqrt(1.0 + ze * ze));
+                const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
+                for (int r = 0; r < 3; ++r) {
+                    const double bp = B[r * 3 + p], bq = B[r * 3 + q];
+                    B[r * 3 + p] = c * bp - s * bq;
+                    B[r * 3 + q] = s * bp + c * bq;
+                    const double vp = V[r * 3 + p], vq = V[r * 3 + q];
+                    V[r * 3 + p] = c * vp - s * vq;
+                    V[r * 3 + q] = s * vp + c * vq;
+                }
+            }
+        }
+        if (!rotated) break;
+    }
+    for (int i = 0; i < 3; ++i) sig[i] = sqrt(B[0 * 3 + i] * B[0 * 3 + i] + B[1 * 3 + i] * B[1 * 3 + i] + B[2 * 3 + i] * B[2 * 3 + i]);
+    // smallest direction may be numerically null: complete it from the other two
+    int lo = 0;
+    if (sig[1] < sig[lo]) lo = 1;
+    if (sig[2] < sig[lo]) lo = 2;
+    const double smax = fmax(sig[0], fmax(sig[1], sig[2]));
+    for (int i = 0; i < 3; ++i) {
+        if (i == lo && sig[i] <= 1e-280 + 1e-18 * smax) continue;
+        for (int r = 0; r < 3; ++r) U[r * 3 + i] = B[r * 3 + i] / sig[i];
+    }
+    if (sig[lo] <= 1e-280 + 1e-18 * smax) {
+        const int a = (lo + 1) % 3, b = (lo + 2) % 3;
+        U[0 * 3 + lo] = U[1 * 3 + a] * U[2 * 3 + b] - U[2 * 3 + a] * U[1 * 3 + b];
+        U[1 * 3 + lo] = U[2 * 3 + a] * U[0 * 3 + b] - U[0 * 3 + a] * U[2 * 3 + b];
+        U[2 * 3 + lo] = U[0 * 3 + a] * U[1 * 3 + b] - U[1 * 3 + a] * U[0 * 3 + b];
+    }
+}
+
+// aux layout (floats): cs[0:3] ct[3:6] U[6:15] s~[15:18] R[18:27] sum w(s-cs)[27:30] sum w(t-ct)[30:33]
+__global__ __launch_bounds__(256) void kabsch_fwd_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                         const float* __restrict__ w, int n, float* __restrict__ Rout,
+                                                         float* __restrict__ tout, float* __restrict__ aux) {
+    __shared__ float red[4 * 15];
+    __shared__ float res[16];
+    const int b = blockIdx.x;
+    const float* s = src + (size_t)b * n * 3;
+    const float* t = tgt + (size_t)b * n * 3;
+    const float* wb = w + (size_t)b * n;
+    float c6[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float wi = wb[i];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            c6[a] = fmaf(wi, s[i * 3 + a], c6[a]);
+            c6[3 + a] = fmaf(wi, t[i * 3 + a], c6[3 + a]);
+        }
+    }
+    block_reduce_sum<6>(c6, red, res);
+    float cs[3], ct[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { cs[a] = res[a]; ct[a] = res[3 + a]; }
+    __syncthreads();
+    float h15[15];
+#pragma unroll
+    for (int a = 0; a < 15; ++a) h15[a] = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float wi = wb[i];
+        float ds[3], dt[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { ds[a] = s[i * 3 + a] - cs[a]; dt[a] = t[i * 3 + a] - ct[a]; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float wa = wi * ds[a];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) h15[a * 3 + c] = fmaf(wa, dt[c], h15[a * 3 + c]);
+            h15[9 + a] += wa;
+            h15[12 + a] = fmaf(wi, dt[a], h15[12 + a]);
+        }
+    }
+    block_reduce_sum<15>(h15, red, res);
+    if (threadIdx.x == 0) {
+        double H[9], U[9], V[9], sg[3];
+        for (int i = 0; i < 9; ++i) H[i] = (double)(res[i] + ((i % 4 == 0) ? 1e-6f : 0.0f));     // :738 (fp32 add)
+        svd3_jacobi(H, U, sg, V);
+        int lo = 0;
+        if (sg[1] < sg[lo]) lo = 1;
+        if (sg[2] < sg[lo]) lo = 2;
+        double sgn[3] = {1.0, 1.0, 1.0};
+        if (det3(V) * det3(U) < 0.0) sgn[lo] = -1.0;                                             // :749-751
+        double R[9];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {
+                double acc = 0;
+                for (int i = 0; i < 3; ++i) acc += sgn[i] * V[a * 3 + i] * U[c * 3 + i];
+                R[a * 3 + c] = acc;
+            }
+        float* ax = aux + (size_t)b * EQUIGSPR_KABSCH_AUX;
+        for (int a = 0; a < 3; ++a) {
+            const double ta = (double)ct[a] - (R[a * 3 + 0] * cs[0] + R[a * 3 + 1] * cs[1] + R[a * 3 + 2] * cs[2]);   // :754
+            tout[b * 3 + a] = (float)ta;
+            ax[a] = cs[a];
+            ax[3 + a] = ct[a];
+            ax[15 + a] = (float)(sgn[a] * sg[a]);
+            ax[27 + a] = res[9 + a];
+            ax[30 + a] = res[12 + a];
+        }
+        for (int i = 0; i < 9; ++i) {
+            Rout[b * 9 + i] = (float)R[i];
+            ax[6 + i] = (float)U[i];
+            ax[18 + i] = (float)R[i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void kabsch_bwd_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                         const float* __restrict__ w, const float* __restrict__ aux,
+                                                         const float* __restrict__ gR, const float* __restrict__ gt, int n,
+                                                         float* __restrict__ gsrc, float* __restrict__ gtgt,
+                                                         float* __restrict__ gw) {
+    __shared__ float sh[9 + 3 + 3];   // gH, g_cs, g_ct
+    const int b = blockIdx.x;
+    const float* ax = aux + (size_t)b * EQUIGSPR_KABSCH_AUX;
+    if (threadIdx.x == 0) {
+        double cs[3], U[9], st[3], R[9], G[9], g_cs[3], g_ct[3], gtv[3];
+        for (int a = 0; a < 3; ++a) { cs[a] = ax[a]; st[a] = ax[15 + a]; gtv[a] = gt[b * 3 + a]; }
+        for (int i = 0; i < 9; ++i) { U[i] = ax[6 + i]; R[i] = ax[18 + i]; }
+        for (int a = 0; a < 3; ++a) {
+            g_ct[a] = gtv[a];
+            g_cs[a] = -(R[0 * 3 + a] * gtv[0] + R[1 * 3 + a] * gtv[1] + R[2 * 3 + a] * gtv[2]);
+            for (int c = 0; c < 3; ++c) G[a * 3 + c] = (double)gR[b * 9 + a * 3 + c] - gtv[a] * cs[c];
+        }
+        // M = U^T R^T G U
+        double T1[9], T2[9], M[9];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {                 // T1 = R^T G
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) acc += R[k * 3 + a] * G[k * 3 + c];
+                T1[a * 3 + c] = acc;
+            }
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {                 // T2 = T1 U
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) acc += T1[a * 3 + k] * U[k * 3 + c];
+                T2[a * 3 + c] = acc;
+            }
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {                 // M = U^T T2
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) acc += U[k * 3 + a] * T2[k * 3 + c];
+                M[a * 3 + c] = acc;
+            }
+        double Nm[9];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {
+                const double den = st[a] + st[c];
+                Nm[a * 3 + c] = (a != c && fabs(den) > 1e-30) ? M[a * 3 + c] / den : 0.0;
+            }
+        double Sk[9];                                       // N - N^T
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) Sk[a * 3 + c] = Nm[a * 3 + c] - Nm[c * 3 + a];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {                 // T1 = U Sk
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) acc += U[a * 3 + k] * Sk[k * 3 + c];
+                T1[a * 3 + c] = acc;
+            }
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {                 // T2 = T1 U^T  (= K - K^T)
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) acc += T1[a * 3 + k] * U[c * 3 + k];
+                T2[a * 3 + c] = acc;
+            }
+        double gH[9];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {                 // gA = R T2 ; gH = gA^T
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) acc += R[a * 3 + k] * T2[k * 3 + c];
+                gH[c * 3 + a] = acc;
+            }
+        for (int a = 0; a < 3; ++a) {
+            double a1 = 0, a2 = 0;
+            for (int c = 0; c < 3; ++c) {
+                a1 += gH[a * 3 + c] * ax[30 + c];            // gH * sum w (t-ct)
+                a2 += gH[c * 3 + a] * ax[27 + c];            // gH^T * sum w (s-cs)
+            }
+            g_cs[a] -= a1;
+            g_ct[a] -= a2;
+        }
+        for (int i = 0; i < 9; ++i) sh[i] = (float)gH[i];
+        for (int a = 0; a < 3; ++a) { sh[9 + a] = (float)g_cs[a]; sh[12 + a] = (float)g_ct[a]; }
+    }
+    __syncthreads();
+    float gH[9], g_cs[3], g_ct[3], cs[3], ct[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gH[i] = sh[i];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { g_cs[a] = sh[9 + a]; g_ct[a] = sh[12 + a]; cs[a] = ax[a]; ct[a] = ax[3 + a]; }
+    const float* s = src + (size_t)b * n * 3;
+    const float* t = tgt + (size_t)b * n * 3;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float wi = w[(size_t)b * n + i];
+        float sv[3], tv[3], ds[3], dt[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { sv[a] = s[i * 3 + a]; tv[a] = t[i * 3 + a]; ds[a] = sv[a] - cs[a]; dt[a] = tv[a] - ct[a]; }
+        float gwi = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float hs = gH[a * 3 + 0] * dt[0] + gH[a * 3 + 1] * dt[1] + gH[a * 3 + 2] * dt[2];      // (gH dt)_a
+            const float ht = gH[0 * 3 + a] * ds[0] + gH[1 * 3 + a] * ds[1] + gH[2 * 3 + a] * ds[2];      // (gH^T ds)_a
+            if (gsrc) gsrc[((size_t)b * n + i) * 3 + a] = wi * (hs + g_cs[a]);
+            if (gtgt) gtgt[((size_t)b * n + i) * 3 + a] = wi * (ht + g_ct[a]);
+            gwi += ds[a] * hs + sv[a] * g_cs[a] + tv[a] * g_ct[a];
+        }
+        if (gw) gw[(size_t)b * n + i] = gwi;
+    }
+}
+
+}  // namespace eq
+
+extern "C" int equigspr_kabsch_forward(const float* src, const float* tgt, const float* w, int32_t batch, int32_t n,
+                                       float* R, float* t, float* aux, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(src && tgt && w && R && t && aux, EQUIGSPR_EINVAL, "kabsch_forward: null pointer");
+    EQ_CHECK_ARG(batch >= 1 && n >= 1, EQUIGSPR_EINVAL, "kabsch_forward: need batch>=1, n>=1");
+    hipLaunchKernelGGL(kabsch_fwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, src, tgt, w, n, R, t, aux);
+    EQ_CHECK_LAUNCH("kabsch_fwd_kernel");
+    return 0;
+}
+
+extern "C" int equigspr_kabsch_backward(const float* src, const float* tgt, const float* w, const float* aux,
+                                        const float* grad_R, const float* grad_t, int32_t batch, int32_t n,
+                                        float* grad_src, float* grad_tgt, float* grad_w, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(src && tgt && w && aux && grad_R && grad_t, EQUIGSPR_EINVAL, "kabsch_backward: null pointer");
+    EQ_CHECK_ARG(batch >= 1 && n >= 1, EQUIGSPR_EINVAL, "kabsch_backward: need batch>=1, n>=1");
+    hipLaunchKernelGGL(kabsch_bwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, src, tgt, w, aux, grad_R,
+                       grad_t, n, grad_src, grad_tgt, grad_w);
+    EQ_CHECK_LAUNCH("kabsch_bwd_kernel");
+    return 0;
+}

@@ -1,0 +1,254 @@
+// k-NN graph build + inverse-index (CSR) build for gfx950.
+//
+// knn: one 64-lane wavefront per query point, brute force over the query's cloud (N <= 8192
+// -> <= 128 candidates per lane held in VGPRs).  Selection is exact and deterministic:
+//   fast path : tau = k-th smallest of the 64 per-lane minima (an upper bound of the k-th
+//               distance), compact the (usually ~1.2k) candidates <= tau through LDS, one
+//               64-lane bitonic sort on (d2,index) keys, emit the first k.
+//   slow path : k rounds of wave-wide min extraction (taken when more than 64 candidates
+//               tie under tau, e.g. heavily duplicated points; also forced by tests).
+// Both paths produce the (d2, index)-lexicographic order of oracle.knn_graph bit for bit.
+//
+// Replaces torch_cluster.knn_graph at src/3dmatch_train_egnn_with_batch.py:1005-1006.
+#include "common.h"
+
+namespace eq {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 wave_bitonic_sort(u64 key, int lane) {
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const u64 other = __shfl_xor(key, j, 64);
+            const bool up = (lane & k2) == 0;
+            const bool lower = (lane & j) == 0;
+            const u64 mn = key < other ? key : other;
+            const u64 mx = key < other ? other : key;
+            key = (lower == up) ? mn : mx;
+        }
+    }
+    return key;
+}
+
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#pragma unroll
+    for (int j = 32; j > 0; j >>= 1) {
+        const u64 o = __shfl_xor(v, j, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ u64 pack_key(float d2, int idx) {
+    return ((u64)__float_as_uint(d2) << 32) | (unsigned)idx;
+}
+
+template <int NPL>
+__global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, int n_clouds, int n, int k,
+                                                 int loop, long long* __restrict__ edges,
+                                                 int* __restrict__ row32, int* __restrict__ col32,
+                                                 int force_slow) {
+    __shared__ u64 list[64];
+    const int lane = threadIdx.x;
+    const int qg = blockIdx.x;                 // query id over all clouds
+    const int cloud = qg / n;
+    const int q = qg - cloud * n;
+    const float* __restrict__ xc = x + (size_t)cloud * n * 3;
+    const float qx = xc[q * 3 + 0], qy = xc[q * 3 + 1], qz = xc[q * 3 + 2];
+    const float INF = __uint_as_float(0x7f800000u);
+
+    float d[NPL];
+    float lmin = INF;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int idx = i * 64 + lane;
+        float v = INF;
+        if (idx < n) {
+            // exact, contraction-free arithmetic contract (see oracle.knn_graph)
+            const float dx = __fsub_rn(qx, xc[idx * 3 + 0]);
+            const float dy = __fsub_rn(qy, xc[idx * 3 + 1]);
+            const float dz = __fsub_rn(qz, xc[idx * 3 + 2]);
+            v = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            if (!loop && idx == q) v = INF;
+        }
+        d[i] = v;
+        lmin = fminf(lmin, v);
+    }
+
+    int out_idx = 0;
+    // ---- fast path -------------------------------------------------------------------
+    const u64 sorted_min = wave_bitonic_sort(pack_key(lmin, lane), lane);
+    const unsigned tau_bits = (unsigned)(__shfl(sorted_min, k - 1, 64) >> 32);
+    const float tau = __uint_as_float(tau_bits);
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) cnt += __popcll(__ballot(d[i] <= tau));
+    const bool fast = (cnt <= 64) && (cnt >= k) && !force_slow;   // wave-uniform
+    if (fast) {
+        int base = 0;
+        const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+            const bool pred = d[i] <= tau;
+            const u64 mask = __ballot(pred);
+            if (pred) list[base + __popcll(mask & lt_mask)] = pack_key(d[i], i * 64 + lane);
+            base += __popcll(mask);
+        }
+        __syncthreads();   // single-wave block: orders the LDS writes before the reads below
+        u64 key = lane < cnt ? list[lane] : ~0ull;
+        key = wave_bitonic_sort(key, lane);
+        out_idx = (int)(unsigned)(key & 0xffffffffu);
+    } else {
+        // ---- slow path: k rounds of "smallest key strictly greater than the previous one"
+        u64 last = 0;
+        bool have_last = false;
+        for (int t = 0; t < k; ++t) {
+            u64 best = ~0ull;
+#pragma unroll
+            for (int i = 0; i < NPL; ++i) {
+                const u64 key = pack_key(d[i], i * 64 + lane);
+                const bool ok = !have_last || key > last;
+                best = (ok && key < best) ? key : best;
+            }
+            best = wave_min_u64(best);
+            if (lane == t) out_idx = (int)(unsigned)(best & 0xffffffffu);
+            last = best;
+            have_last = true;
+        }
+    }
+    if (lane < k) {
+        const size_t e = (size_t)q * k + lane;
+        const size_t epc = (size_t)n * k;
+        if (edges) {
+            edges[(size_t)cloud * 2 * epc + e] = out_idx;
+            edges[(size_t)cloud * 2 * epc + epc + e] = q;
+        }
+        if (row32) row32[(size_t)cloud * epc + e] = cloud * n + out_idx;
+        if (col32) col32[(size_t)cloud * epc + e] = cloud * n + q;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// CSR build: stable counting sort of edge ids by key
+// ---------------------------------------------------------------------------------------
+__global__ void csr_count_kernel(const int* __restrict__ key, int n_edges, int* __restrict__ cnt) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_edges) atomicAdd(&cnt[key[e]], 1);
+}
+
+// exclusive scan of cnt[0..n) -> ptr[0..n], cursor[0..n) = ptr[0..n) ; single block of 1024
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int* __restrict__ cnt_cursor, int n, int* __restrict__ ptr) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int chunk = (n + 1023) / 1024;
+    const int lo = t * chunk;
+    const int hi = min(lo + chunk, n);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += cnt_cursor[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = part[t] - s;   // exclusive prefix of this thread's chunk
+    for (int i = lo; i < hi; ++i) {
+        const int c = cnt_cursor[i];
+        ptr[i] = run;
+        cnt_cursor[i] = run;
+        run += c;
+    }
+    if (t == 1023) ptr[n] = part[1023];
+}
+
+__global__ void csr_fill_kernel(const int* __restrict__ key, int n_edges, int* __restrict__ cursor,
+                                int* __restrict__ perm) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_edges) perm[atomicAdd(&cursor[key[e]], 1)] = e;
+}
+
+// each node's segment back into ascending edge order (atomics filled it in arbitrary order)
+__global__ void csr_sort_kernel(const int* __restrict__ ptr, int n_nodes, int* __restrict__ perm) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_nodes) return;
+    const int lo = ptr[j], hi = ptr[j + 1];
+    for (int a = lo + 1; a < hi; ++a) {
+        const int v = perm[a];
+        int b = a - 1;
+        while (b >= lo && perm[b] > v) {
+            perm[b + 1] = perm[b];
+            --b;
+        }
+        perm[b + 1] = v;
+    }
+}
+
+__global__ void edges_i64_to_i32_kernel(const long long* __restrict__ edges, int n_edges, int off,
+                                        int* __restrict__ row32, int* __restrict__ col32) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_edges) {
+        row32[e] = (int)edges[e] + off;
+        col32[e] = (int)edges[(size_t)n_edges + e] + off;
+    }
+}
+
+}  // namespace eq
+
+extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, int32_t k, int32_t loop,
+                                  int64_t* edges_i64, int32_t* row32, int32_t* col32,
+                                  int32_t force_slow_path, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(x != nullptr, EQUIGSPR_EINVAL, "knn_graph: x is null");
+    EQ_CHECK_ARG(n_clouds >= 1 && n >= 1, EQUIGSPR_EINVAL, "knn_graph: need n_clouds>=1, n>=1");
+    EQ_CHECK_ARG(n <= 8192, EQUIGSPR_ENOTSUP, "knn_graph: n=%d > 8192 points per cloud", n);
+    EQ_CHECK_ARG(k >= 1 && k <= 64, EQUIGSPR_ENOTSUP, "knn_graph: k=%d outside [1,64]", k);
+    EQ_CHECK_ARG(k <= (loop ? n : n - 1), EQUIGSPR_EINVAL, "knn_graph: k=%d exceeds candidates (n=%d, loop=%d)", k, n, loop);
+    EQ_CHECK_ARG((long long)n_clouds * n * k < (1ll << 31), EQUIGSPR_EINVAL, "knn_graph: edge count overflows int32");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(n_clouds * n), block(64);
+    long long* e64 = reinterpret_cast<long long*>(edges_i64);
+    if (n <= 256)
+        hipLaunchKernelGGL(knn_kernel<4>, grid, block, 0, s, x, n_clouds, n, k, loop, e64, row32, col32, force_slow_path);
+    else if (n <= 2048)
+        hipLaunchKernelGGL(knn_kernel<32>, grid, block, 0, s, x, n_clouds, n, k, loop, e64, row32, col32, force_slow_path);
+    else if (n <= 4096)
+        hipLaunchKernelGGL(knn_kernel<64>, grid, block, 0, s, x, n_clouds, n, k, loop, e64, row32, col32, force_slow_path);
+    else
+        hipLaunchKernelGGL(knn_kernel<128>, grid, block, 0, s, x, n_clouds, n, k, loop, e64, row32, col32, force_slow_path);
+    EQ_CHECK_LAUNCH("knn_kernel");
+    return 0;
+}
+
+extern "C" int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n_nodes, int32_t* ptr,
+                                  int32_t* perm, int32_t* scratch, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(key && ptr && perm && scratch, EQUIGSPR_EINVAL, "build_csr: null pointer");
+    EQ_CHECK_ARG(n_edges >= 0 && n_nodes >= 1, EQUIGSPR_EINVAL, "build_csr: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t err = hipMemsetAsync(scratch, 0, sizeof(int) * (size_t)(n_nodes + 1), s);
+    if (err != hipSuccess) { set_error("build_csr memset: %s", hipGetErrorString(err)); return (int)err; }
+    if (n_edges > 0)
+        hipLaunchKernelGGL(csr_count_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, key, n_edges, scratch);
+    hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, scratch, n_nodes, ptr);
+    if (n_edges > 0) {
+        hipLaunchKernelGGL(csr_fill_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, key, n_edges, scratch, perm);
+        hipLaunchKernelGGL(csr_sort_kernel, dim3(ceil_div(n_nodes, 256)), dim3(256), 0, s, ptr, n_nodes, perm);
+    }
+    EQ_CHECK_LAUNCH("build_csr");
+    return 0;
+}
+
+extern "C" int equigspr_edges_i64_to_i32(const int64_t* edges_i64, int32_t n_edges, int32_t node_offset,
+                                         int32_t* row32, int32_t* col32, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(edges_i64 && row32 && col32 && n_edges >= 0, EQUIGSPR_EINVAL, "edges_i64_to_i32: bad args");
+    if (n_edges == 0) return 0;
+    hipLaunchKernelGGL(edges_i64_to_i32_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const long long*>(edges_i64), n_edges, node_offset, row32, col32);
+    EQ_CHECK_LAUNCH("edges_i64_to_i32");
+    return 0;
+}

@@ -1,0 +1,220 @@
+"""Host-side mirror of the reference EGNN interface, backed by the HIP kernels.
+
+``EGNN`` / ``E_GCL`` keep the constructor signatures, parameter names (``state_dict`` keys)
+and the ``forward(h, x, edges, edge_attr)`` contract of the reference
+(src/3dmatch_train_egnn_with_batch.py:185-340; signature donor src/clean_so3_model.py:162),
+plus ``num_heads`` so the shipped checkpoints load.
+
+MI355X-first layout: all parameters of an ``EGNN`` are views into ONE flat fp32 device
+buffer (``EGNN.flat_params``), all their gradients views into ONE flat buffer
+(``EGNN.flat_grads``) -- the kernels read the block directly and the data-parallel
+all-reduce sends it as a single bucket over xGMI.  There is no CPU fallback: calling
+``forward`` with CPU tensors raises.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import ops
+from .ops import DeviceGraph
+
+
+class E_GCL(nn.Module):
+    """Parameter container of one layer; same submodule names as the reference (train :185-229).
+    The layer math runs inside ``EGNN.forward`` (fused HIP path); a stand-alone
+    ``E_GCL.forward`` is provided through a one-layer EGNN with identity embeddings."""
+
+    def __init__(self, input_nf, output_nf, hidden_nf, edges_in_d=0, num_heads=1, act_fn=nn.SiLU(), residual=True,
+                 attention=False, normalize=False, tanh=False, device="cuda:0"):
+        super().__init__()
+        if not (input_nf == output_nf == hidden_nf):
+            raise NotImplementedError("HIP E_GCL needs input_nf == hidden_nf == output_nf (as every reference call site)")
+        if not isinstance(act_fn, nn.SiLU):
+            raise NotImplementedError("HIP E_GCL implements act_fn=nn.SiLU() only (the reference default)")
+        if not residual or normalize or tanh:
+            raise NotImplementedError("HIP E_GCL implements residual=True, normalize=False, tanh=False "
+                                      "(the only combination the reference scripts use; normalize=True would hit "
+                                      "the undefined self.epsilon at train :276)")
+        if hidden_nf % num_heads:
+            raise ValueError("hidden_nf must be divisible by num_heads")
+        self.residual, self.attention, self.normalize, self.tanh = residual, attention, normalize, tanh
+        self.num_heads, self.device = num_heads, device
+        self.hidden_nf, self.edges_in_d = hidden_nf, edges_in_d
+        feature_dim = 2 * input_nf + edges_in_d + 1 + 9 + 2          # train :196-199
+        hh = hidden_nf // num_heads
+        self.edge_mlps = nn.ModuleList([
+            nn.Sequential(nn.Linear(feature_dim, hh), act_fn, nn.Linear(hh, hh)) for _ in range(num_heads)])
+        self.layer_norm = nn.LayerNorm(hidden_nf)
+        self.node_mlp = nn.Sequential(nn.Linear(hidden_nf + input_nf, hidden_nf), act_fn, nn.Linear(hidden_nf, output_nf))
+        last = nn.Linear(hidden_nf, 1, bias=False)
+        nn.init.xavier_uniform_(last.weight, gain=1e-3)             # train :219-220
+        self.coord_mlp = nn.Sequential(nn.Linear(hidden_nf, hidden_nf), act_fn, last)
+
+    def forward(self, h, edge_index, coord, edge_attr=None):
+        """Stand-alone layer call (train :280-289) -> (h, coord, edge_attr)."""
+        f = self.hidden_nf
+        wrap = EGNN(f, f, f, in_edge_nf=self.edges_in_d, device=h.device, n_layers=1, num_heads=self.num_heads)
+        with torch.no_grad():
+            wrap.embedding_in.weight.copy_(torch.eye(f)); wrap.embedding_in.bias.zero_()
+            wrap.embedding_out.weight.copy_(torch.eye(f)); wrap.embedding_out.bias.zero_()
+            wrap.gcl_0.load_state_dict(self.state_dict())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("stand-alone E_GCL.forward is inference-only; train through EGNN")
+        with torch.no_grad():
+            h2, x2 = wrap(h, coord, edge_index, edge_attr)
+        return h2, x2, edge_attr
+
+
+class _EgnnFn(torch.autograd.Function):
+    """Autograd node around equigspr_egnn_forward / equigspr_egnn_backward.  Parameter
+    gradients are accumulated by the kernel straight into ``model.flat_grads`` (whose views
+    are the parameters' ``.grad``); only the input gradients travel through autograd."""
+
+    @staticmethod
+    def forward(ctx, h, x, anchor, model, graph, edge_attr, training):
+        h_out, x_out, saved = ops.egnn_forward(model.cfg, model.flat_params, graph, h, x, edge_attr, training)
+        ctx.model, ctx.graph, ctx.edge_attr = model, graph, edge_attr
+        if training:
+            ctx.save_for_backward(h, saved)
+        return h_out, x_out
+
+    @staticmethod
+    def backward(ctx, gh, gx):
+        model = ctx.model
+        h, saved = ctx.saved_tensors
+        n = ctx.graph.n_nodes
+        gh = torch.zeros(n, model.cfg.out_nf, dtype=torch.float32, device=h.device) if gh is None else gh
+        gx = torch.zeros(n, 3, dtype=torch.float32, device=h.device) if gx is None else gx
+        model._attach_grads()
+        ghi, gxi = ops.egnn_backward(model.cfg, model.flat_params, ctx.graph, h, ctx.edge_attr, saved, gh, gx,
+                                     model.flat_grads, (ctx.needs_input_grad[0], ctx.needs_input_grad[1]))
+        return ghi, gxi, None, None, None, None, None
+
+
+class EGNN(nn.Module):
+    """Drop-in for the reference ``EGNN`` (train :293-340)."""
+
+    def __init__(self, in_node_nf, hidden_nf, out_node_nf, in_edge_nf=0, device="cuda:0", act_fn=nn.SiLU(), n_layers=5,
+                 residual=True, attention=True, normalize=False, tanh=False, num_heads=1):
+        super().__init__()
+        self.hidden_nf, self.device, self.n_layers = hidden_nf, device, n_layers
+        self.in_node_nf, self.out_node_nf, self.in_edge_nf, self.num_heads = in_node_nf, out_node_nf, in_edge_nf, num_heads
+        self.embedding_in = nn.Linear(in_node_nf, hidden_nf)
+        self.embedding_out = nn.Linear(hidden_nf, out_node_nf)
+        for i in range(n_layers):
+            self.add_module("gcl_%d" % i, E_GCL(hidden_nf, hidden_nf, hidden_nf, edges_in_d=in_edge_nf, num_heads=num_heads,
+                                                act_fn=act_fn, residual=residual, attention=attention,
+                                                normalize=normalize, tanh=tanh))
+        self.cfg = ops.make_config(in_node_nf, hidden_nf, out_node_nf, in_edge_nf, n_layers, num_heads)
+        self.flat_params: Optional[torch.Tensor] = None
+        self.flat_grads: Optional[torch.Tensor] = None
+        self._graph_cache = {}
+        self.to(device)                                             # train :326
+
+    # -- flat parameter block ----------------------------------------------------------
+    def _ordered_params(self) -> List[nn.Parameter]:
+        return [p for _, p in self.named_parameters()]      # == C-ABI block order (include/equigspr.h)
+
+    def _ensure_flat(self):
+        ps = self._ordered_params()
+        flat = self.flat_params
+        ok = flat is not None and flat.device == ps[0].device
+        if ok:
+            off = 0
+            base = flat.data_ptr()
+            for p in ps:
+                if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                    ok = False
+                    break
+                off += p.numel()
+        if ok:
+            return
+        dev = ps[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("EGNN parameters are on %s: this package runs only on the MI355X (HIP) device; "
+                               "move the module with .to('cuda')" % dev)
+        total = sum(p.numel() for p in ps)
+        if total != ops.param_count(self.cfg):
+            raise RuntimeError("internal: parameter count differs from the C-ABI block layout")
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        grads = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in ps:
+                n = p.numel()
+                flat[off:off + n].copy_(p.detach().reshape(-1).float())
+                old_grad = p.grad
+                p.data = flat[off:off + n].view(p.shape)
+                if old_grad is not None:
+                    grads[off:off + n].copy_(old_grad.reshape(-1))
+                p.grad = grads[off:off + n].view(p.shape)
+                off += n
+        self.flat_params, self.flat_grads = flat, grads
+
+    def _attach_grads(self):
+        """(Re)attach ``.grad`` views into the flat bucket.  A parameter whose ``.grad`` is ``None``
+        was reset by ``optimizer.zero_grad(set_to_none=True)``: its slice of the bucket is zeroed
+        first, because the backward kernels ACCUMULATE into the bucket."""
+        ps = self._ordered_params()
+        missing = [p.grad is None for p in ps]
+        if not any(missing):
+            return
+        if all(missing):
+            self.flat_grads.zero_()
+        off = 0
+        for p, miss in zip(ps, missing):
+            n = p.numel()
+            if miss:
+                if not all(missing):
+                    self.flat_grads[off:off + n].zero_()
+                p.grad = self.flat_grads[off:off + n].view(p.shape)
+            off += n
+
+    def zero_grad(self, set_to_none: bool = False):          # keep the bucket views alive by default
+        if self.flat_grads is not None and not set_to_none:
+            self.flat_grads.zero_()
+            self._attach_grads()
+        else:
+            super().zero_grad(set_to_none=set_to_none)
+
+    # -- graph handling ----------------------------------------------------------------
+    def _graph_for(self, edges, n_nodes: int) -> DeviceGraph:
+        if isinstance(edges, DeviceGraph):
+            return edges
+        if isinstance(edges, torch.Tensor):
+            row, col = edges[0], edges[1]
+        else:
+            row, col = edges[0], edges[1]
+        key = (row.data_ptr(), col.data_ptr(), row._version, col._version, row.numel(), n_nodes)
+        g = self._graph_cache.get(key)
+        if g is None:
+            if len(self._graph_cache) > 8:
+                self._graph_cache.clear()
+            e = torch.stack([row, col]).to(torch.int64)
+            g = DeviceGraph.from_edge_lists([e], n_nodes)
+            g._keepalive = (row, col)
+            self._graph_cache[key] = g
+        return g
+
+    # -- reference signature -----------------------------------------------------------
+    def forward(self, h, x, edges, edge_attr):
+        """``h [N,in_node_nf]``, ``x [N,3]``, ``edges=[row,col]`` (LongTensors, list or ``[2,E]``) or a
+        prebuilt ``DeviceGraph``, ``edge_attr [E,in_edge_nf]`` -> ``(h [N,out_node_nf], x [N,3])``."""
+        self._ensure_flat()
+        if h.dim() != 2 or x.dim() != 2:
+            raise RuntimeError("EGNN.forward expects h [N,F] and x [N,3] (one cloud or a pre-batched graph)")
+        graph = self._graph_for(edges, h.shape[0])
+        if self.in_edge_nf == 0:
+            edge_attr = None
+        elif edge_attr is None:
+            raise RuntimeError("EGNN was built with in_edge_nf=1 but edge_attr is None")
+        else:
+            edge_attr = edge_attr.reshape(-1).contiguous().float()
+        anchor = self.embedding_in.weight
+        training = torch.is_grad_enabled() and (anchor.requires_grad or h.requires_grad or x.requires_grad)
+        if training and graph.cptr is None:
+            raise RuntimeError("EGNN.forward: training needs a DeviceGraph built with need_col_index=True")
+        return _EgnnFn.apply(h.contiguous().float(), x.contiguous().float(), anchor, self, graph, edge_attr, training)

@@ -1,0 +1,54 @@
+"""Graph construction with the reference call signatures, on the HIP path.
+
+``knn_graph(x, k, loop=True)`` mirrors ``torch_cluster.knn_graph`` as the scripts call it
+(src/3dmatch_train_egnn_with_batch.py:1005-1006); ``get_edges_batch`` mirrors train :380-403.
+``build_pair_graph`` is the batched MI355X entry the training harness uses: one kNN launch for
+all 2B clouds, emitting the device graph directly (no int64 edge lists, no per-sample loop).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .ops import DeviceGraph
+
+
+def knn_graph(x: torch.Tensor, k: int, batch=None, loop: bool = False, flow: str = "source_to_target",
+              force_slow_path: bool = False) -> torch.Tensor:
+    """``x [N,3]`` -> LongTensor ``[2, N*k]``: row 0 = neighbour, row 1 = centre, centre-major,
+    ascending (distance, index).  NOTE torch_cluster's default is ``loop=False``; the reference
+    always passes ``loop=True``."""
+    if batch is not None:
+        raise NotImplementedError("knn_graph: pass one cloud per call (as the reference does) or use build_pair_graph")
+    if flow != "source_to_target":
+        raise NotImplementedError("knn_graph: only flow='source_to_target' (the reference default)")
+    if x.dim() != 2 or x.shape[1] != 3:
+        raise RuntimeError("knn_graph: x must be [N,3]")
+    e64, _, _ = ops.knn_graph_batched(x.contiguous().float().unsqueeze(0), k, loop, want_i64=True,
+                                      force_slow_path=force_slow_path)
+    return e64[0]
+
+
+def get_edges_from_idx(graph_idx):
+    """train :372-378."""
+    return [graph_idx[0], graph_idx[1]]
+
+
+def get_edges_batch(graph_idx, n_nodes: int, batch_size: int):
+    """train :380-403 -> ([row, col], ones[E*batch_size, 1])."""
+    row, col = graph_idx[0], graph_idx[1]
+    edge_attr = torch.ones(row.numel() * batch_size, 1, device=row.device)
+    if batch_size == 1:
+        return [row, col], edge_attr
+    rows = [row + n_nodes * i for i in range(batch_size)]
+    cols = [col + n_nodes * i for i in range(batch_size)]
+    return [torch.cat(rows), torch.cat(cols)], edge_attr
+
+
+def build_pair_graph(xyz_src: torch.Tensor, xyz_tgt: torch.Tensor, k: int, loop: bool = True,
+                     need_col_index: bool = True) -> DeviceGraph:
+    """``xyz_* [B,N,3]`` -> one DeviceGraph over the 2B clouds ``[src_0..src_B-1, tgt_0..tgt_B-1]``."""
+    x = torch.cat([xyz_src, xyz_tgt], dim=0).contiguous().float()
+    nc, n, _ = x.shape
+    _, r32, c32 = ops.knn_graph_batched(x, k, loop, want_i64=False, want_i32=True)
+    return DeviceGraph(r32, c32, nc * n, knn_k=k, need_col_index=need_col_index)

@@ -1,0 +1,200 @@
+"""Thin wrappers: torch device tensors -> raw pointers -> the C-ABI of libequigspr.so.
+
+PyTorch is plumbing here (device memory, the current HIP stream, autograd bookkeeping);
+all arithmetic happens in the HIP kernels.  Every wrapper validates device / dtype /
+contiguity and raises ``RuntimeError`` -- the error behaviour the reference gets from ATen.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import EgnnConfig, Graph, KABSCH_AUX
+
+
+def _need(t: torch.Tensor, name: str, dtype, ndim: Optional[int] = None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the MI355X (cuda/HIP) device, got {t.device}; "
+                           "this package has no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError(f"{name}: expected {ndim} dims, got shape {tuple(t.shape)}")
+    return t
+
+
+def _p(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_config(in_nf, hidden_nf, out_nf, in_edge_nf, n_layers, num_heads) -> EgnnConfig:
+    cfg = EgnnConfig(int(in_nf), int(hidden_nf), int(out_nf), int(in_edge_nf), int(n_layers), int(num_heads))
+    if _lib.lib().equigspr_egnn_param_count(ctypes.byref(cfg)) < 0:
+        raise NotImplementedError(
+            f"EGNN config outside the compiled HIP kernel set: hidden_nf={hidden_nf} (32|33), num_heads={num_heads} "
+            f"(1|4, must divide hidden_nf), in/out_nf<=64, in_edge_nf in (0,1), n_layers<=16")
+    return cfg
+
+
+def param_count(cfg: EgnnConfig) -> int:
+    return int(_lib.lib().equigspr_egnn_param_count(ctypes.byref(cfg)))
+
+
+# ----------------------------------------------------------------------------------- graph
+class DeviceGraph:
+    """Batched graph in the device format (int32 global ids + inverse indices)."""
+
+    def __init__(self, row32, col32, n_nodes: int, knn_k: Optional[int] = None, need_col_index: bool = True):
+        L = _lib.lib()
+        self.row, self.col = _need(row32, "row32", torch.int32, 1), _need(col32, "col32", torch.int32, 1)
+        self.n_nodes, self.n_edges = int(n_nodes), int(row32.numel())
+        dev = row32.device
+        scratch = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
+        self.rptr = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
+        self.rperm = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
+        _lib.check(L.equigspr_build_csr(_p(self.row), self.n_edges, self.n_nodes, _p(self.rptr), _p(self.rperm),
+                                        _p(scratch), _stream()), "build_csr(row)")
+        self.cptr = self.cperm = None
+        if need_col_index:
+            if knn_k is not None:      # centre-major kNN list: the col index is the identity permutation
+                self.cptr = torch.arange(0, self.n_edges + 1, knn_k, dtype=torch.int32, device=dev)
+                self.cperm = torch.arange(self.n_edges, dtype=torch.int32, device=dev)
+            else:
+                self.cptr = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
+                self.cperm = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
+                _lib.check(L.equigspr_build_csr(_p(self.col), self.n_edges, self.n_nodes, _p(self.cptr),
+                                                _p(self.cperm), _p(scratch), _stream()), "build_csr(col)")
+        self.struct = Graph(self.n_nodes, self.n_edges, self.row.data_ptr(), self.col.data_ptr(),
+                            self.rptr.data_ptr(), self.rperm.data_ptr(),
+                            self.cptr.data_ptr() if self.cptr is not None else None,
+                            self.cperm.data_ptr() if self.cperm is not None else None)
+
+    @staticmethod
+    def from_edge_lists(edge_lists, n_per_cloud: int, need_col_index: bool = True) -> "DeviceGraph":
+        """``edge_lists``: iterable of int64 ``[2,E_i]`` tensors with LOCAL ids, one per cloud
+        (the reference's per-sample ``edges`` argument); clouds get node offsets i*n_per_cloud."""
+        L = _lib.lib()
+        edge_lists = list(edge_lists)
+        tot = sum(int(e.shape[1]) for e in edge_lists)
+        dev = edge_lists[0].device
+        row = torch.empty(max(tot, 1), dtype=torch.int32, device=dev)[:tot]
+        col = torch.empty(max(tot, 1), dtype=torch.int32, device=dev)[:tot]
+        off = 0
+        for i, e in enumerate(edge_lists):
+            e = _need(e if e.is_contiguous() else e.contiguous(), "edges", torch.int64, 2)
+            ne = int(e.shape[1])
+            _lib.check(L.equigspr_edges_i64_to_i32(_p(e), ne, i * n_per_cloud, ctypes.c_void_p(row.data_ptr() + 4 * off),
+                                                   ctypes.c_void_p(col.data_ptr() + 4 * off), _stream()),
+                       "edges_i64_to_i32")
+            off += ne
+        return DeviceGraph(row, col, len(edge_lists) * n_per_cloud, need_col_index=need_col_index)
+
+
+def knn_graph_batched(x: torch.Tensor, k: int, loop: bool = True, want_i64: bool = True, want_i32: bool = False,
+                      force_slow_path: bool = False):
+    """``x [n_clouds, n, 3]`` -> (edges int64 ``[n_clouds,2,n*k]`` | None, row32 | None, col32 | None)."""
+    _need(x, "x", torch.float32, 3)
+    nc, n, three = x.shape
+    if three != 3:
+        raise RuntimeError("knn_graph: x must be [n_clouds, n, 3]")
+    dev = x.device
+    e64 = torch.empty(nc, 2, n * k, dtype=torch.int64, device=dev) if want_i64 else None
+    r32 = torch.empty(nc * n * k, dtype=torch.int32, device=dev) if want_i32 else None
+    c32 = torch.empty(nc * n * k, dtype=torch.int32, device=dev) if want_i32 else None
+    _lib.check(_lib.lib().equigspr_knn_graph(_p(x), nc, n, int(k), int(bool(loop)), _p(e64), _p(r32), _p(c32),
+                                             int(bool(force_slow_path)), _stream()), "knn_graph")
+    return e64, r32, c32
+
+
+# ----------------------------------------------------------------------------------- EGNN
+def egnn_forward(cfg: EgnnConfig, params: torch.Tensor, graph: DeviceGraph, h: torch.Tensor, x: torch.Tensor,
+                 edge_attr: Optional[torch.Tensor], training: bool):
+    L = _lib.lib()
+    _need(params, "params", torch.float32, 1)
+    _need(h, "h", torch.float32, 2)
+    _need(x, "x", torch.float32, 2)
+    n = graph.n_nodes
+    if h.shape != (n, cfg.in_nf) or x.shape != (n, 3):
+        raise RuntimeError(f"egnn_forward: h {tuple(h.shape)} / x {tuple(x.shape)} do not match the graph "
+                           f"({n} nodes) and in_node_nf={cfg.in_nf}")
+    if params.numel() != param_count(cfg):
+        raise RuntimeError("egnn_forward: parameter block has the wrong size")
+    if edge_attr is not None:
+        _need(edge_attr, "edge_attr", torch.float32)
+        if cfg.in_edge_nf != 1 or edge_attr.numel() != graph.n_edges:
+            raise RuntimeError(f"egnn_forward: edge_attr must be [E,{cfg.in_edge_nf}] with E={graph.n_edges}")
+    dev = h.device
+    h_out = torch.empty(n, cfg.out_nf, dtype=torch.float32, device=dev)
+    x_out = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    work = torch.empty(int(L.equigspr_egnn_work_size(ctypes.byref(cfg), n, graph.n_edges)), dtype=torch.float32, device=dev)
+    saved = torch.empty(int(L.equigspr_egnn_saved_size(ctypes.byref(cfg), n)), dtype=torch.float32, device=dev) if training else None
+    _lib.check(L.equigspr_egnn_forward(ctypes.byref(cfg), _p(params), ctypes.byref(graph.struct), _p(h), _p(x),
+                                       _p(edge_attr), _p(h_out), _p(x_out), _p(saved), _p(work), _stream()),
+               "egnn_forward")
+    return h_out, x_out, saved
+
+
+def egnn_backward(cfg: EgnnConfig, params, graph: DeviceGraph, h_in, edge_attr, saved, grad_h_out, grad_x_out,
+                  grad_params, need_input_grads: Tuple[bool, bool]):
+    L = _lib.lib()
+    n = graph.n_nodes
+    if graph.cptr is None:
+        raise RuntimeError("egnn_backward: the graph was built without its col index")
+    dev = h_in.device
+    gh = _need(grad_h_out.contiguous(), "grad_h_out", torch.float32, 2)
+    gx = _need(grad_x_out.contiguous(), "grad_x_out", torch.float32, 2)
+    _need(grad_params, "grad_params", torch.float32, 1)
+    grad_h_in = torch.empty(n, cfg.in_nf, dtype=torch.float32, device=dev) if need_input_grads[0] else None
+    grad_x_in = torch.empty(n, 3, dtype=torch.float32, device=dev) if need_input_grads[1] else None
+    work = torch.empty(int(L.equigspr_egnn_bwd_work_size(ctypes.byref(cfg), n, graph.n_edges)), dtype=torch.float32, device=dev)
+    _lib.check(L.equigspr_egnn_backward(ctypes.byref(cfg), _p(params), ctypes.byref(graph.struct), _p(h_in),
+                                        _p(edge_attr), _p(saved), _p(gh), _p(gx), _p(grad_params), _p(grad_h_in),
+                                        _p(grad_x_in), _p(work), _stream()), "egnn_backward")
+    return grad_h_in, grad_x_in
+
+
+# ----------------------------------------------------------------------------------- Kabsch
+class _KabschFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, tgt, w):
+        src = _need(src.contiguous(), "src", torch.float32, 3)
+        tgt = _need(tgt.contiguous(), "tgt", torch.float32, 3)
+        w = _need(w.contiguous(), "weights", torch.float32, 2)
+        b, n, _ = src.shape
+        if tgt.shape != src.shape or w.shape != (b, n) or src.shape[2] != 3:
+            raise RuntimeError("weighted_kabsch: src/tgt [B,n,3], weights [B,n]")
+        R = torch.empty(b, 3, 3, dtype=torch.float32, device=src.device)
+        t = torch.empty(b, 3, dtype=torch.float32, device=src.device)
+        aux = torch.empty(b, KABSCH_AUX, dtype=torch.float32, device=src.device)
+        _lib.check(_lib.lib().equigspr_kabsch_forward(_p(src), _p(tgt), _p(w), b, n, _p(R), _p(t), _p(aux), _stream()),
+                   "kabsch_forward")
+        ctx.save_for_backward(src, tgt, w, aux)
+        return R, t
+
+    @staticmethod
+    def backward(ctx, gR, gt):
+        src, tgt, w, aux = ctx.saved_tensors
+        b, n, _ = src.shape
+        gR = torch.zeros(b, 3, 3, dtype=torch.float32, device=src.device) if gR is None else gR.contiguous()
+        gt = torch.zeros(b, 3, dtype=torch.float32, device=src.device) if gt is None else gt.contiguous()
+        gs, gtg, gw = torch.empty_like(src), torch.empty_like(tgt), torch.empty_like(w)
+        _lib.check(_lib.lib().equigspr_kabsch_backward(_p(src), _p(tgt), _p(w), _p(aux), _p(gR), _p(gt), b, n,
+                                                       _p(gs), _p(gtg), _p(gw), _stream()), "kabsch_backward")
+        return gs, gtg, gw
+
+
+def weighted_kabsch(src: torch.Tensor, tgt: torch.Tensor, weights: torch.Tensor):
+    """Batched weighted Kabsch (reference train :726-758).  ``src,tgt [B,n,3]``, ``weights [B,n]``
+    (zero weight = masked out) -> ``R [B,3,3]``, ``t [B,3]``; differentiable."""
+    return _KabschFn.apply(src, tgt, weights)
