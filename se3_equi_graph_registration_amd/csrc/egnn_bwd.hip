@@ -1,10 +1,728 @@
-// placeholder until the backward kernels land (next commit)
-#include "common.h"
-extern "C" int64_t equigspr_egnn_bwd_work_size(const equigspr_egnn_config* cfg, int32_t n_nodes, int32_t n_edges) { return 64; }
+// EGNN backward for gfx950 (replaces autograd through EGNN.forward; reference loss.backward(),
+// src/3dmatch_train_egnn_with_batch.py:1126).  Derivation: tests/manual_backward.py, checked on
+// CPU against the reference's own autograd gradients (tests/test_backward_derivation.py).
+//
+// Per layer, walking l = L-1 .. 0 with G_h = dL/dh_{l+1}, G_x = dL/dx_{l+1}:
+//   node_bwd   (lane = feature, G lanes per node)  node-MLP backward -> dagg, dh_part; re-projects
+//              P_l = [W_src h_l | W_tgt h_l + b1] for the edge recompute; dW4,db4,dW5,db5 partials.
+//   edge_bwd   (lane = edge)  recomputes the edge forward from (P_l, x_l) in registers, runs the
+//              edge backward with wave-uniform (scalar-loaded) weights, writes dt1_e, dL/dx_r,
+//              dL/dx_c per edge.  Weight gradients are sums over edges of outer products: the
+//              per-edge vectors are transposed through wave-private LDS tiles and accumulated
+//              with fp32 MFMA (v_mfma_f32_32x32x2_f32, K = edges) -- exact fp32, VALU stays free.
+//   gather_bwd (lane = feature)  dP_r / dP_c / dx via the row / col inverse indices (ascending
+//              edge id, atomic-free) -> G_h, G_x of layer l; dW_src, dW_tgt, db1 partials.
+// Every workgroup writes its partial weight gradients to a private slab; a reduce kernel sums
+// the slabs in fixed order into the flat gradient block (+=): bitwise reproducible, no atomics.
+#include "egnn_device.h"
+
+namespace eq {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kNodeBwdBlocks = 256;   // slab count of the node-level kernels
+constexpr int kEdgeBwdBlocks = 1024;  // max slab count of the edge kernel
+
+// ---- slab sizes ---------------------------------------------------------------------------
+template <int F> struct Slabs {
+    static constexpr int node = F * 2 * F + F + F * F + F;          // dW4 | db4 | dW5 | db5
+    static constexpr int gather = 2 * F * F + F;                    // dW1a | dW1b | db1
+    static constexpr int e_geo = 0;                                  // F x 16 (12 geo + attr + pad)
+    static constexpr int e_w2 = F * 16;
+    static constexpr int e_w6 = e_w2 + F * F;
+    static constexpr int e_b2 = e_w6 + F * F;
+    static constexpr int e_b6 = e_b2 + F;
+    static constexpr int e_gam = e_b6 + F;
+    static constexpr int e_bet = e_gam + F;
+    static constexpr int e_w7 = e_bet + F;
+    static constexpr int edge = e_w7 + F;
+};
+
+// Deterministic in-block reduction of per-lane accumulator rows into an LDS slab.
+//   lane (slot, f) owns row f: acc[0..n)  ->  sl[off + f*n + i]
+template <int NS, int NMAX>
+__device__ __forceinline__ void slab_rows(float* sl, int off, int n, const float (&acc)[NMAX], int slot, int f,
+                                          bool active) {
+    for (int s = 0; s < NS; ++s) {
+        __syncthreads();
+        if (slot == s && active) {
+#pragma unroll
+            for (int i = 0; i < NMAX; ++i)
+                if (i < n) sl[off + f * n + i] = (s == 0 ? 0.0f : sl[off + f * n + i]) + acc[i];
+        }
+    }
+}
+template <int NS>
+__device__ __forceinline__ void slab_scalar(float* sl, int off, float v, int slot, int f, bool active) {
+    for (int s = 0; s < NS; ++s) {
+        __syncthreads();
+        if (slot == s && active) sl[off + f] = (s == 0 ? 0.0f : sl[off + f]) + v;
+    }
+}
+__device__ __forceinline__ void slab_flush(const float* sl, float* __restrict__ dst, int size) {
+    __syncthreads();
+    for (int t = threadIdx.x; t < size; t += 256) dst[(size_t)blockIdx.x * size + t] = sl[t];
+}
+
+// ---------------------------------------------------------------------------------------
+// embedding_out backward:  G_h = gh_out W_out ;  dW_out, db_out partials ; G_x = gx_out
+// ---------------------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(256) void embed_out_bwd_kernel(const float* __restrict__ w_out, int out_nf,
+                                                            const float* __restrict__ gh_out,
+                                                            const float* __restrict__ gx_out,
+                                                            const float* __restrict__ hL, int n_nodes,
+                                                            float* __restrict__ Gh, float* __restrict__ Gx,
+                                                            float* __restrict__ slab) {
+    constexpr int FP = Geom<F>::FP, G = Geom<F>::G, NS = Geom<F>::NS;
+    __shared__ float gho[NS][64];
+    __shared__ float sl[64 * F + 64];
+    const int slot = threadIdx.x / G, f = threadIdx.x % G;
+    float accW[64];
+    float accb[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int o = 0; o < 64; ++o) accW[o] = 0.0f;
+    const int groups = (n_nodes + NS - 1) / NS;
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int j = grp * NS + slot;
+        const bool live = j < n_nodes;
+        __syncthreads();
+        if (live) {
+            for (int o = f; o < out_nf; o += G) gho[slot][o] = gh_out[(size_t)j * out_nf + o];
+            if (f < 3) Gx[(size_t)j * 4 + f] = gx_out[(size_t)j * 3 + f];
+        }
+        __syncthreads();
+        if (live) {
+            if (f < F) {
+                const float hv = hL[(size_t)j * FP + f];
+                float g = 0.0f;
+                for (int o = 0; o < out_nf; ++o) g = fmaf(gho[slot][o], w_out[o * F + f], g);
+                Gh[(size_t)j * FP + f] = g;
+#pragma unroll
+                for (int o = 0; o < 64; ++o)
+                    if (o < out_nf) accW[o] = fmaf(gho[slot][o], hv, accW[o]);
+            }
+            if (f < out_nf) accb[0] += gho[slot][f];
+            if (f + G < out_nf) accb[1] += gho[slot][f + G];
+        }
+    }
+    // slab: dW_out[o][i] at o*F+i (lane f owns column i=f) ; db_out at out_nf*F + o
+    for (int s = 0; s < NS; ++s) {
+        __syncthreads();
+        if (slot == s) {
+            if (f < F) {
+#pragma unroll
+                for (int o = 0; o < 64; ++o)
+                    if (o < out_nf) sl[o * F + f] = (s == 0 ? 0.0f : sl[o * F + f]) + accW[o];
+            }
+            if (f < out_nf) sl[out_nf * F + f] = (s == 0 ? 0.0f : sl[out_nf * F + f]) + accb[0];
+            if (f + G < out_nf) sl[out_nf * F + f + G] = (s == 0 ? 0.0f : sl[out_nf * F + f + G]) + accb[1];
+        }
+    }
+    slab_flush(sl, slab, out_nf * F + out_nf);
+}
+
+// ---------------------------------------------------------------------------------------
+// embedding_in backward:  dW_in, db_in partials ; grad_h_in = G_h0 W_in
+// ---------------------------------------------------------------------------------------
+template <int F>
+__global__ __launch_bounds__(256) void embed_in_bwd_kernel(const float* __restrict__ w_in, int in_nf,
+                                                           const float* __restrict__ Gh0, const float* __restrict__ h_in,
+                                                           int n_nodes, float* __restrict__ grad_h_in,
+                                                           float* __restrict__ slab) {
+    constexpr int FP = Geom<F>::FP, G = Geom<F>::G, NS = Geom<F>::NS;
+    __shared__ float vin[NS][64];
+    __shared__ float gv[NS][FP];
+    __shared__ float sl[64 * F + F];
+    const int slot = threadIdx.x / G, f = threadIdx.x % G;
+    float accW[64];
+    float accb = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) accW[i] = 0.0f;
+    const int groups = (n_nodes + NS - 1) / NS;
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int j = grp * NS + slot;
+        const bool live = j < n_nodes;
+        __syncthreads();
+        float g = 0.0f;
+        if (live) {
+            for (int i = f; i < in_nf; i += G) vin[slot][i] = h_in[(size_t)j * in_nf + i];
+            if (f < F) { g = Gh0[(size_t)j * FP + f]; gv[slot][f] = g; }
+        }
+        __syncthreads();
+        if (live) {
+            if (f < F) {
+                accb += g;
+#pragma unroll
+                for (int i = 0; i < 64; ++i)
+                    if (i < in_nf) accW[i] = fmaf(g, vin[slot][i], accW[i]);
+            }
+            if (grad_h_in) {
+                for (int i = f; i < in_nf; i += G) {
+                    float a = 0.0f;
+                    for (int o = 0; o < F; ++o) a = fmaf(gv[slot][o], w_in[o * in_nf + i], a);
+                    grad_h_in[(size_t)j * in_nf + i] = a;
+                }
+            }
+        }
+    }
+    slab_rows<NS, 64>(sl, 0, in_nf, accW, slot, f, f < F);
+    slab_scalar<NS>(sl, F * in_nf, accb, slot, f, f < F);
+    slab_flush(sl, slab, F * in_nf + F);
+}
+
+// ---------------------------------------------------------------------------------------
+// node-MLP backward (+ re-projection of P for the edge recompute)
+// ---------------------------------------------------------------------------------------
+template <int F, int H, int A>
+__global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__ lw, const float* __restrict__ Gh,
+                                                       const float* __restrict__ h, const float* __restrict__ agg,
+                                                       int n_nodes, float* __restrict__ dh_part,
+                                                       float* __restrict__ dagg, float* __restrict__ P,
+                                                       float* __restrict__ slab) {
+    using LL = LP<F, H, A>;
+    using SB = Slabs<F>;
+    constexpr int FP = Geom<F>::FP, G = Geom<F>::G, NS = Geom<F>::NS, PS = Geom<F>::PS;
+    __shared__ float vin[NS][2 * FP];
+    __shared__ float hid[NS][FP];
+    __shared__ float ghv[NS][FP];
+    __shared__ float dvv[NS][FP];
+    __shared__ float sl[SB::node];
+    const int slot = threadIdx.x / G, f = threadIdx.x % G;
+    float aW4[2 * F], aW5[F];
+    float ab4 = 0.0f, ab5 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2 * F; ++i) aW4[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < F; ++i) aW5[i] = 0.0f;
+    const int groups = (n_nodes + NS - 1) / NS;
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int j = grp * NS + slot;
+        const bool act = (j < n_nodes) && (f < F);
+        float g = 0.0f, v = 0.0f;
+        __syncthreads();
+        if (act) {
+            g = Gh[(size_t)j * FP + f];
+            vin[slot][f] = h[(size_t)j * FP + f];
+            vin[slot][F + f] = agg[(size_t)j * FP + f];
+            ghv[slot][f] = g;
+        }
+        __syncthreads();
+        if (act) {
+            v = lw[LL::b4 + f] + row_dot(lw + LL::w4 + f * 2 * F, vin[slot], 2 * F);
+            hid[slot][f] = silu(v);
+        }
+        if (j < n_nodes) project_pre<F, H, A>(lw, vin[slot], f, P + (size_t)j * PS);
+        __syncthreads();
+        float dv = 0.0f;
+        if (act) {
+            ab5 += g;
+#pragma unroll
+            for (int i = 0; i < F; ++i) aW5[i] = fmaf(g, hid[slot][i], aW5[i]);
+            float dg = 0.0f;                                   // d silu-output[f] = sum_o G_h[o] W5[o][f]
+            for (int o = 0; o < F; ++o) dg = fmaf(ghv[slot][o], lw[LL::w5 + o * F + f], dg);
+            dv = dg * silu_grad(v);
+            dvv[slot][f] = dv;
+            ab4 += dv;
+#pragma unroll
+            for (int i = 0; i < 2 * F; ++i) aW4[i] = fmaf(dv, vin[slot][i], aW4[i]);
+        }
+        __syncthreads();
+        if (act) {
+            float d_h = 0.0f, d_a = 0.0f;
+            for (int o = 0; o < F; ++o) {
+                const float d = dvv[slot][o];
+                d_h = fmaf(d, lw[LL::w4 + o * 2 * F + f], d_h);
+                d_a = fmaf(d, lw[LL::w4 + o * 2 * F + F + f], d_a);
+            }
+            dh_part[(size_t)j * FP + f] = g + d_h;             // residual + node-MLP path
+            dagg[(size_t)j * FP + f] = d_a;
+        }
+    }
+    const bool own = f < F;
+    slab_rows<NS, 2 * F>(sl, 0, 2 * F, aW4, slot, f, own);
+    slab_scalar<NS>(sl, F * 2 * F, ab4, slot, f, own);
+    slab_rows<NS, F>(sl, F * 2 * F + F, F, aW5, slot, f, own);
+    slab_scalar<NS>(sl, F * 2 * F + F + F * F, ab5, slot, f, own);
+    slab_flush(sl, slab, SB::node);
+}
+
+// ---------------------------------------------------------------------------------------
+// gather backward: dP_r, dP_c, dx through the inverse indices
+// ---------------------------------------------------------------------------------------
+template <int F, int H, int A>
+__global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict__ lw, const int* __restrict__ rptr,
+                                                         const int* __restrict__ rperm, const int* __restrict__ cptr,
+                                                         const int* __restrict__ cperm, const float* __restrict__ dt1,
+                                                         const float* __restrict__ gxr, const float* __restrict__ gxc,
+                                                         const float* __restrict__ dh_part, const float* __restrict__ Gx,
+                                                         const float* __restrict__ h, int n_nodes,
+                                                         float* __restrict__ Gh_new, float* __restrict__ Gx_new,
+                                                         float* __restrict__ gx_out3, float* __restrict__ slab) {
+    using LL = LP<F, H, A>;
+    using SB = Slabs<F>;
+    constexpr int FP = Geom<F>::FP, G = Geom<F>::G, NS = Geom<F>::NS;
+    __shared__ float hv[NS][FP];
+    __shared__ float prv[NS][FP];
+    __shared__ float pcv[NS][FP];
+    __shared__ float sl[SB::gather];
+    const int slot = threadIdx.x / G, f = threadIdx.x % G;
+    float aWa[F], aWb[F];
+    float ab1 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < F; ++i) { aWa[i] = 0.0f; aWb[i] = 0.0f; }
+    const int groups = (n_nodes + NS - 1) / NS;
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int j = grp * NS + slot;
+        const bool live = j < n_nodes;
+        const bool act = live && f < F;
+        float dpr = 0.0f, dpc = 0.0f;
+        __syncthreads();
+        if (live) {
+            const int rlo = rptr[j], rhi = rptr[j + 1], clo = cptr[j], chi = cptr[j + 1];
+            if (f < F) {
+                for (int a = rlo; a < rhi; ++a) dpr += dt1[(size_t)rperm[a] * FP + f];
+                for (int a = clo; a < chi; ++a) dpc += dt1[(size_t)cperm[a] * FP + f];
+                hv[slot][f] = h[(size_t)j * FP + f];
+                prv[slot][f] = dpr;
+                pcv[slot][f] = dpc;
+            }
+            if (f < 3) {
+                float gx = Gx[(size_t)j * 4 + f];
+                for (int a = rlo; a < rhi; ++a) gx += gxr[(size_t)rperm[a] * 4 + f];
+                for (int a = clo; a < chi; ++a) gx += gxc[(size_t)cperm[a] * 4 + f];
+                Gx_new[(size_t)j * 4 + f] = gx;
+                if (gx_out3) gx_out3[(size_t)j * 3 + f] = gx;
+            }
+        }
+        __syncthreads();
+        if (act) {
+            ab1 += dpc;
+#pragma unroll
+            for (int i = 0; i < F; ++i) {
+                const float hi = hv[slot][i];
+                aWa[i] = fmaf(dpr, hi, aWa[i]);
+                aWb[i] = fmaf(dpc, hi, aWb[i]);
+            }
+            float gh = dh_part[(size_t)j * FP + f];
+            for (int o = 0; o < F; ++o) {
+                const float* w = lw + LL::w1_off(o, 0);
+                gh = fmaf(prv[slot][o], w[f], gh);
+                gh = fmaf(pcv[slot][o], w[F + f], gh);
+            }
+            Gh_new[(size_t)j * FP + f] = gh;
+        }
+    }
+    const bool own = f < F;
+    slab_rows<NS, F>(sl, 0, F, aWa, slot, f, own);
+    slab_rows<NS, F>(sl, F * F, F, aWb, slot, f, own);
+    slab_scalar<NS>(sl, 2 * F * F, ab1, slot, f, own);
+    slab_flush(sl, slab, SB::gather);
+}
+
+// ---------------------------------------------------------------------------------------
+// edge backward
+// ---------------------------------------------------------------------------------------
+// One pass over a wave-private pair of LDS tiles X[64][LD], Y[64][LD] (row = edge of the chunk):
+//   acc[rb][cb] += X^T Y (32x32 blocks, K = 64 edges, fp32 MFMA), csx += column sums of X,
+//   csy += column sums of Y.  Lane l: column (l & 31), edge parity (l >> 5).
+template <int NB, int NBY, int LD, bool kMfma>
+__device__ __forceinline__ void tile_pass(const float* X, const float* Y, f32x16 (&acc)[NB][NBY], float (&csx)[NB],
+                                          float (&csy)[NBY], int lane) {
+    const int f = lane & 31, hh = lane >> 5;
+#pragma unroll 2
+    for (int s = 0; s < 32; ++s) {
+        const int e = 2 * s + hh;
+        float a[NB], b[NBY];
+#pragma unroll
+        for (int rb = 0; rb < NB; ++rb) { a[rb] = X[e * LD + rb * 32 + f]; csx[rb] += a[rb]; }
+#pragma unroll
+        for (int cb = 0; cb < NBY; ++cb) { b[cb] = Y[e * LD + cb * 32 + f]; csy[cb] += b[cb]; }
+        if (kMfma) {
+#pragma unroll
+            for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < NBY; ++cb)
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
+        }
+    }
+}
+
+template <int F, int H, int A>
+__global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__ lw, const int* __restrict__ row,
+                                                       const int* __restrict__ col, const float* __restrict__ edge_attr,
+                                                       const float* __restrict__ x, const float* __restrict__ P,
+                                                       const float* __restrict__ dagg, const float* __restrict__ Gx,
+                                                       int n_edges, float* __restrict__ dt1_out,
+                                                       float* __restrict__ gxr_out, float* __restrict__ gxc_out,
+                                                       float* __restrict__ slab) {
+    using LL = LP<F, H, A>;
+    using SB = Slabs<F>;
+    constexpr int FP = Geom<F>::FP, PS = Geom<F>::PS, FH = F / H;
+    constexpr int NB = (F + 31) / 32;
+    constexpr int LD = NB * 32 + 1;
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* X = smem + (size_t)wave * 2 * 64 * LD;
+    float* Y = X + 64 * LD;
+
+    f32x16 acc6[NB][NB], acc2[NB][NB], accg[NB][1], accn[NB][1];
+    float cs_b6[NB], cs_b2[NB], cs_gam[NB], cs_bet[NB], cs_w7[NB], cs_scr[NB], cs_scr1[1];
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) {
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc6[rb][cb][r] = 0.0f; acc2[rb][cb][r] = 0.0f; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accg[rb][0][r] = 0.0f; accn[rb][0][r] = 0.0f; }
+        cs_b6[rb] = cs_b2[rb] = cs_gam[rb] = cs_bet[rb] = cs_w7[rb] = cs_scr[rb] = 0.0f;
+    }
+    cs_scr1[0] = 0.0f;
+
+    const int chunks = (n_edges + 255) / 256;
+    for (int ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+        const int e_raw = ch * 256 + threadIdx.x;
+        const bool valid = e_raw < n_edges;
+        const int e = valid ? e_raw : n_edges - 1;
+        const float z = valid ? 1.0f : 0.0f;
+        const int r = row[e], c = col[e];
+        float xr[3], xc[3], gxv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { xr[i] = x[(size_t)r * 3 + i]; xc[i] = x[(size_t)c * 3 + i]; gxv[i] = Gx[(size_t)r * 4 + i]; }
+        EdgeGeo eg;
+        edge_geometry(xr, xc, eg);
+        const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
+        float t1[F], xhat[F], m[F], q[F], rstd, s;
+        EdgeFwd<F, H, A>::run(lw, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg.g, attr, t1, xhat, rstd, m, q, s);
+
+        // ---- coord head backward:  trans = d * s,  s = w7 . silu(q)
+        const float ds = dot3(eg.d, gxv) * z;
+        float gd[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gd[i] = s * gxv[i];
+        float dq[F];
+#pragma unroll
+        for (int o = 0; o < F; ++o) {
+            const float w7 = lw[LL::w7 + o];
+            dq[o] = w7 * ds * silu_grad(q[o]);
+            X[lane * LD + o] = dq[o];
+            Y[lane * LD + o] = m[o];
+        }
+        __builtin_amdgcn_wave_barrier();
+        tile_pass<NB, NB, LD, true>(X, Y, acc6, cs_b6, cs_scr, lane);          // dW6 += dq^T m ; db6 += sum dq
+        __builtin_amdgcn_wave_barrier();
+        // ---- dm = dagg[row] + W6^T dq
+        float dm[F];
+        {
+            const float4* dar = reinterpret_cast<const float4*>(dagg + (size_t)r * FP);
+#pragma unroll
+            for (int v = 0; v < FP / 4; ++v) {
+                const float4 a = dar[v];
+                dm[4 * v] = a.x * z;
+                if (4 * v + 1 < F) dm[(4 * v + 1 < F) ? 4 * v + 1 : 0] = a.y * z;
+                if (4 * v + 2 < F) dm[(4 * v + 2 < F) ? 4 * v + 2 : 0] = a.z * z;
+                if (4 * v + 3 < F) dm[(4 * v + 3 < F) ? 4 * v + 3 : 0] = a.w * z;
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < F; ++o) {
+#pragma unroll
+            for (int i = 0; i < F; ++i) dm[i] = fmaf(lw[LL::w6 + o * F + i], dq[o], dm[i]);
+        }
+        // ---- stage [p*ds | dm*xhat] then [dm]: column sums only (dw7, dgamma, dbeta)
+#pragma unroll
+        for (int o = 0; o < F; ++o) {
+            X[lane * LD + o] = silu(q[o]) * ds;
+            Y[lane * LD + o] = dm[o] * xhat[o];
+        }
+        __builtin_amdgcn_wave_barrier();
+        tile_pass<NB, NB, LD, false>(X, Y, acc6, cs_w7, cs_gam, lane);
+        __builtin_amdgcn_wave_barrier();
+        // ---- LayerNorm backward
+        float du[F];
+        {
+            float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < F; ++i) {
+                const float dxh = dm[i] * lw[LL::ln_g + i];
+                du[i] = dxh;
+                m1 += dxh;
+                m2 = fmaf(dxh, xhat[i], m2);
+            }
+            m1 *= (1.0f / F);
+            m2 *= (1.0f / F);
+#pragma unroll
+            for (int i = 0; i < F; ++i) du[i] = rstd * (du[i] - m1 - xhat[i] * m2);
+        }
+        // ---- stage [du | g1]: dW2 += du^T g1, db2 += sum du ; and dbeta via a second X-only pass below
+#pragma unroll
+        for (int o = 0; o < F; ++o) {
+            X[lane * LD + o] = du[o];
+            Y[lane * LD + o] = silu(t1[o]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        tile_pass<NB, NB, LD, true>(X, Y, acc2, cs_b2, cs_scr, lane);
+        __builtin_amdgcn_wave_barrier();
+        // ---- dt1 = (W2^T du) * silu'(t1)
+        float dt1[F];
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+            const int hb = (i / FH) * FH;
+            float a = 0.0f;
+#pragma unroll
+            for (int o = 0; o < FH; ++o) a = fmaf(lw[LL::w2_off(hb + o, i)], du[hb + o], a);
+            dt1[i] = a * silu_grad(t1[i]);
+        }
+        // ---- stage [dt1 | geo,attr] (dWgeo) ; dm goes into X's partner tile for dbeta afterwards
+#pragma unroll
+        for (int o = 0; o < F; ++o) X[lane * LD + o] = dt1[o];
+#pragma unroll
+        for (int gI = 0; gI < kGeo; ++gI) Y[lane * LD + gI] = eg.g[gI];
+        Y[lane * LD + kGeo] = attr;
+        Y[lane * LD + kGeo + 1] = 0.0f; Y[lane * LD + kGeo + 2] = 0.0f; Y[lane * LD + kGeo + 3] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        tile_pass<NB, 1, LD, true>(X, Y, accg, cs_scr, cs_scr1, lane);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int o = 0; o < F; ++o) X[lane * LD + o] = dm[o];
+        __builtin_amdgcn_wave_barrier();
+        tile_pass<NB, 1, LD, false>(X, Y, accn, cs_bet, cs_scr1, lane);
+        __builtin_amdgcn_wave_barrier();
+        // ---- geometry backward
+        float gg[kGeo];
+#pragma unroll
+        for (int gI = 0; gI < kGeo; ++gI) {
+            float a = 0.0f;
+#pragma unroll
+            for (int o = 0; o < F; ++o) a = fmaf(lw[LL::w1_off(o, 2 * F + gI)], dt1[o], a);
+            gg[gI] = a;
+        }
+        float gxr[3], gxc[3];
+        edge_geometry_backward(xr, xc, eg, gg, gd, gxr, gxc);
+        if (valid) {
+            float4* o4 = reinterpret_cast<float4*>(dt1_out + (size_t)e * FP);
+#pragma unroll
+            for (int v = 0; v < FP / 4; ++v) {
+                float4 o;
+                o.x = dt1[4 * v];
+                o.y = (4 * v + 1 < F) ? dt1[(4 * v + 1 < F) ? 4 * v + 1 : 0] : 0.0f;
+                o.z = (4 * v + 2 < F) ? dt1[(4 * v + 2 < F) ? 4 * v + 2 : 0] : 0.0f;
+                o.w = (4 * v + 3 < F) ? dt1[(4 * v + 3 < F) ? 4 * v + 3 : 0] : 0.0f;
+                o4[v] = o;
+            }
+            reinterpret_cast<float4*>(gxr_out)[e] = make_float4(gxr[0], gxr[1], gxr[2], 0.0f);
+            reinterpret_cast<float4*>(gxc_out)[e] = make_float4(gxc[0], gxc[1], gxc[2], 0.0f);
+        }
+    }
+
+    // ---- block reduction of the 4 waves' partials into one slab (fixed order) ----------------
+    float* sl = smem;      // aliases the tiles: every wave is past its last tile read after the barrier
+    const int f = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) {          // fold the two edge-parity halves of the column sums
+        cs_b6[rb] += __shfl_xor(cs_b6[rb], 32, 64);
+        cs_b2[rb] += __shfl_xor(cs_b2[rb], 32, 64);
+        cs_gam[rb] += __shfl_xor(cs_gam[rb], 32, 64);
+        cs_bet[rb] += __shfl_xor(cs_bet[rb], 32, 64);
+        cs_w7[rb] += __shfl_xor(cs_w7[rb], 32, 64);
+    }
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+            const bool first = (w == 0);
+#pragma unroll
+            for (int rb = 0; rb < NB; ++rb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int orow = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (orow < F) {
+#pragma unroll
+                        for (int cb = 0; cb < NB; ++cb) {
+                            const int ocol = cb * 32 + f;
+                            if (ocol < F) {
+                                const int i2 = SB::e_w2 + orow * F + ocol, i6 = SB::e_w6 + orow * F + ocol;
+                                sl[i2] = (first ? 0.0f : sl[i2]) + acc2[rb][cb][r];
+                                sl[i6] = (first ? 0.0f : sl[i6]) + acc6[rb][cb][r];
+                            }
+                        }
+                        if (f < 16) {
+                            const int ig = SB::e_geo + orow * 16 + f;
+                            sl[ig] = (first ? 0.0f : sl[ig]) + accg[rb][0][r];
+                        }
+                    }
+                }
+                const int ccol = rb * 32 + f;
+                if (hh == 0 && ccol < F) {
+                    sl[SB::e_b2 + ccol] = (first ? 0.0f : sl[SB::e_b2 + ccol]) + cs_b2[rb];
+                    sl[SB::e_b6 + ccol] = (first ? 0.0f : sl[SB::e_b6 + ccol]) + cs_b6[rb];
+                    sl[SB::e_gam + ccol] = (first ? 0.0f : sl[SB::e_gam + ccol]) + cs_gam[rb];
+                    sl[SB::e_bet + ccol] = (first ? 0.0f : sl[SB::e_bet + ccol]) + cs_bet[rb];
+                    sl[SB::e_w7 + ccol] = (first ? 0.0f : sl[SB::e_w7 + ccol]) + cs_w7[rb];
+                }
+            }
+        }
+    }
+    slab_flush(sl, slab, SB::edge);
+}
+
+// ---------------------------------------------------------------------------------------
+// slab reduction into the flat gradient block (+=), fixed order
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float sum_slabs(const float* __restrict__ slab, int n_slabs, int stride, int idx) {
+    float a = 0.0f;
+    for (int s = 0; s < n_slabs; ++s) a += slab[(size_t)s * stride + idx];
+    return a;
+}
+
+template <int F, int H, int A>
+__global__ void layer_grad_reduce_kernel(const float* __restrict__ node_slab, int n_node, const float* __restrict__ edge_slab,
+                                         int n_edge, const float* __restrict__ gat_slab, int n_gat,
+                                         float* __restrict__ grad_layer) {
+    using LL = LP<F, H, A>;
+    using SB = Slabs<F>;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= LL::size) return;
+    float v;
+    if (idx < H * LL::head_stride) {
+        const int j = idx / LL::head_stride, r = idx % LL::head_stride;
+        if (r < LL::b1) {
+            const int o = j * LL::FH + r / LL::D, c = r % LL::D;
+            if (c < F) v = sum_slabs(gat_slab, n_gat, SB::gather, o * F + c);
+            else if (c < 2 * F) v = sum_slabs(gat_slab, n_gat, SB::gather, F * F + o * F + (c - F));
+            else v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_geo + o * 16 + (c - 2 * F));
+        } else if (r < LL::w2) {
+            v = sum_slabs(gat_slab, n_gat, SB::gather, 2 * F * F + j * LL::FH + (r - LL::b1));
+        } else if (r < LL::b2) {
+            const int ol = (r - LL::w2) / LL::FH, il = (r - LL::w2) % LL::FH;
+            v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_w2 + (j * LL::FH + ol) * F + j * LL::FH + il);
+        } else {
+            v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_b2 + j * LL::FH + (r - LL::b2));
+        }
+    } else if (idx < LL::ln_b) v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_gam + (idx - LL::ln_g));
+    else if (idx < LL::w4) v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_bet + (idx - LL::ln_b));
+    else if (idx < LL::w6) v = sum_slabs(node_slab, n_node, SB::node, idx - LL::w4);      // W4|b4|W5|b5 contiguous in both
+    else if (idx < LL::b6) v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_w6 + (idx - LL::w6));
+    else if (idx < LL::w7) v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_b6 + (idx - LL::b6));
+    else v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_w7 + (idx - LL::w7));
+    grad_layer[idx] += v;
+}
+
+__global__ void plain_grad_reduce_kernel(const float* __restrict__ slab, int n_slabs, int size, float* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < size) dst[idx] += sum_slabs(slab, n_slabs, size, idx);
+}
+
+// ---------------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------------
+struct BwdLayout {
+    size_t Gh[2], Gx[2], dh_part, dagg, P, dt1, gxr, gxc, node_slab, edge_slab, gat_slab, emb_slab, total;
+};
+static BwdLayout bwd_layout(int F, int in_nf, int out_nf, int64_t N, int64_t E) {
+    const int FP = fpad(F);
+    BwdLayout B;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
+    B.Gh[0] = take(N * FP); B.Gh[1] = take(N * FP);
+    B.Gx[0] = take(N * 4); B.Gx[1] = take(N * 4);
+    B.dh_part = take(N * FP); B.dagg = take(N * FP); B.P = take(N * 2 * FP);
+    B.dt1 = take(E * FP); B.gxr = take(E * 4); B.gxc = take(E * 4);
+    const size_t node_sz = (size_t)F * 2 * F + F + F * F + F, gat_sz = 2 * (size_t)F * F + F;
+    const size_t edge_sz = (size_t)F * 16 + 2 * F * F + 5 * F;
+    B.node_slab = take(kNodeBwdBlocks * node_sz);
+    B.edge_slab = take(kEdgeBwdBlocks * edge_sz);
+    B.gat_slab = take(kNodeBwdBlocks * gat_sz);
+    const size_t emb = (size_t)64 * F + 64;
+    B.emb_slab = take(kNodeBwdBlocks * emb);
+    B.total = o;
+    return B;
+}
+
+template <int F, int H, int A>
+static int backward_impl(const equigspr_egnn_config* cfg, const float* params, const equigspr_graph* g,
+                         const float* h_in, const float* edge_attr, const float* saved, const float* gh_out,
+                         const float* gx_out, float* grad_params, float* grad_h_in, float* grad_x_in, float* work,
+                         hipStream_t s) {
+    using SB = Slabs<F>;
+    const ModelLayout ML = make_model_layout(cfg->in_nf, F, cfg->out_nf, A, cfg->n_layers, H);
+    const int N = g->n_nodes, E = g->n_edges, L = cfg->n_layers;
+    constexpr int FP = Geom<F>::FP, NS = Geom<F>::NS, NB = (F + 31) / 32, LD = NB * 32 + 1;
+    const BwdLayout B = bwd_layout(F, cfg->in_nf, cfg->out_nf, N, E);
+    const float* hs = saved;
+    const float* xs = saved + (size_t)(L + 1) * N * FP;
+    const float* aggs = xs + (size_t)(L + 1) * N * 3;
+    const int groups = ceil_div(N, NS);
+    const int ngrid = groups < kNodeBwdBlocks ? groups : kNodeBwdBlocks;
+    const int chunks = ceil_div(E, 256);
+    const int egrid = chunks < kEdgeBwdBlocks ? chunks : kEdgeBwdBlocks;
+    const size_t edge_smem = sizeof(float) * (size_t)4 * 2 * 64 * LD;
+    static bool attr_set = false;
+    {
+        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_bwd_kernel<F, H, A>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)edge_smem);
+        if (err != hipSuccess) { set_error("hipFuncSetAttribute(edge_bwd): %s", hipGetErrorString(err)); return (int)err; }
+        (void)attr_set;
+    }
+    int cur = 0;
+    float* Gh = work + B.Gh[cur];
+    float* Gx = work + B.Gx[cur];
+    // embedding_out
+    hipLaunchKernelGGL((embed_out_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_out, cfg->out_nf, gh_out,
+                       gx_out, hs + (size_t)L * N * FP, N, Gh, Gx, work + B.emb_slab);
+    hipLaunchKernelGGL(plain_grad_reduce_kernel, dim3(ceil_div(cfg->out_nf * F + cfg->out_nf, 256)), dim3(256), 0, s,
+                       work + B.emb_slab, ngrid, cfg->out_nf * F + cfg->out_nf, grad_params + ML.w_out);
+    for (int l = L - 1; l >= 0; --l) {
+        const float* lw = params + ML.layer0 + (size_t)l * ML.layer_size;
+        const float* h_l = hs + (size_t)l * N * FP;
+        const float* x_l = xs + (size_t)l * N * 3;
+        hipLaunchKernelGGL((node_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, work + B.Gh[cur], h_l,
+                           aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg, work + B.P, work + B.node_slab);
+        if (E > 0)
+            hipLaunchKernelGGL((edge_bwd_kernel<F, H, A>), dim3(egrid), dim3(256), edge_smem, s, lw, g->row, g->col,
+                               edge_attr, x_l, work + B.P, work + B.dagg, work + B.Gx[cur], E, work + B.dt1,
+                               work + B.gxr, work + B.gxc, work + B.edge_slab);
+        const int nxt = cur ^ 1;
+        hipLaunchKernelGGL((gather_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, g->rptr, g->rperm, g->cptr,
+                           g->cperm, work + B.dt1, work + B.gxr, work + B.gxc, work + B.dh_part, work + B.Gx[cur], h_l, N,
+                           work + B.Gh[nxt], work + B.Gx[nxt], (l == 0) ? grad_x_in : nullptr, work + B.gat_slab);
+        hipLaunchKernelGGL((layer_grad_reduce_kernel<F, H, A>), dim3(ceil_div(ML.layer_size, 256)), dim3(256), 0, s,
+                           work + B.node_slab, ngrid, work + B.edge_slab, E > 0 ? egrid : 0, work + B.gat_slab, ngrid,
+                           grad_params + ML.layer0 + (size_t)l * ML.layer_size);
+        cur = nxt;
+    }
+    hipLaunchKernelGGL((embed_in_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_in, cfg->in_nf,
+                       work + B.Gh[cur], h_in, N, grad_h_in, work + B.emb_slab);
+    hipLaunchKernelGGL(plain_grad_reduce_kernel, dim3(ceil_div(F * cfg->in_nf + F, 256)), dim3(256), 0, s,
+                       work + B.emb_slab, ngrid, F * cfg->in_nf + F, grad_params + ML.w_in);
+    EQ_CHECK_LAUNCH("egnn_backward");
+    return 0;
+}
+
+}  // namespace eq
+
+extern "C" int64_t equigspr_egnn_bwd_work_size(const equigspr_egnn_config* cfg, int32_t n_nodes, int32_t n_edges) {
+    if (!eq::config_supported(cfg) || n_nodes < 0 || n_edges < 0) return -1;
+    return (int64_t)eq::bwd_layout(cfg->hidden_nf, cfg->in_nf, cfg->out_nf, n_nodes, n_edges).total;
+}
+
 extern "C" int equigspr_egnn_backward(const equigspr_egnn_config* cfg, const float* params, const equigspr_graph* g,
                                       const float* h_in, const float* edge_attr, const float* saved,
                                       const float* grad_h_out, const float* grad_x_out, float* grad_params,
                                       float* grad_h_in, float* grad_x_in, float* work, void* stream) {
-    eq::set_error("egnn_backward: not built yet");
+    using namespace eq;
+    EQ_CHECK_ARG(config_supported(cfg), EQUIGSPR_ENOTSUP, "egnn_backward: unsupported config");
+    EQ_CHECK_ARG(params && g && h_in && saved && grad_h_out && grad_x_out && grad_params && work, EQUIGSPR_EINVAL,
+                 "egnn_backward: null pointer");
+    EQ_CHECK_ARG(g->n_nodes >= 1 && g->n_edges >= 0 && g->row && g->col && g->rptr && g->rperm && g->cptr && g->cperm,
+                 EQUIGSPR_EINVAL, "egnn_backward: incomplete graph (needs row and col inverse indices)");
+    hipStream_t s = (hipStream_t)stream;
+    const int F = cfg->hidden_nf, H = cfg->num_heads, A = cfg->in_edge_nf;
+#define EQ_DISPATCH(FF, HH, AA) \
+    if (F == FF && H == HH && A == AA) return backward_impl<FF, HH, AA>(cfg, params, g, h_in, edge_attr, saved, grad_h_out, grad_x_out, grad_params, grad_h_in, grad_x_in, work, s);
+    EQ_DISPATCH(32, 1, 1) EQ_DISPATCH(32, 1, 0) EQ_DISPATCH(32, 4, 1) EQ_DISPATCH(32, 4, 0)
+    EQ_DISPATCH(33, 1, 1) EQ_DISPATCH(33, 1, 0)
+#undef EQ_DISPATCH
+    set_error("egnn_backward: no kernel for F=%d H=%d A=%d", F, H, A);
     return EQUIGSPR_ENOTSUP;
 }

@@ -14,36 +14,9 @@
 //                 the CPU scatter_add_ order of unsorted_segment_sum :343-348), node MLP with
 //                 residual (:252-260), coordinate update (:262-268), and the NEXT layer's
 //                 per-node projections (or embedding_out after the last layer).
-#include "common.h"
+#include "egnn_device.h"
 
 namespace eq {
-
-template <int F> struct Geom {
-    static constexpr int FP = (F + 3) / 4 * 4;     // padded row (16-byte rows)
-    static constexpr int G = F <= 32 ? 32 : 64;    // lanes per node in node kernels
-    static constexpr int NS = 256 / G;             // node slots per 256-thread block
-    static constexpr int PS = 2 * FP;              // P row: [Pr (FP) | Pc (FP)]
-};
-
-// y = sum_i W[row][i] * v[i], W row-major with row stride `ld`, v in LDS (broadcast reads)
-__device__ __forceinline__ float row_dot(const float* __restrict__ wrow, const float* v, int n) {
-    float acc = 0.0f;
-    for (int i = 0; i < n; ++i) acc = fmaf(wrow[i], v[i], acc);
-    return acc;
-}
-
-// per-node projections for a layer: Pr = W1[:, 0:F] h ; Pc = W1[:, F:2F] h + b1
-template <int F, int H, int A>
-__device__ __forceinline__ void project_pre(const float* __restrict__ lw, const float* hv, int f,
-                                            float* __restrict__ prow) {
-    using LL = LP<F, H, A>;
-    constexpr int FP = Geom<F>::FP;
-    if (f < F) {
-        const float* w = lw + LL::w1_off(f, 0);
-        prow[f] = row_dot(w, hv, F);
-        prow[FP + f] = lw[LL::b1_off(f)] + row_dot(w + F, hv, F);
-    }
-}
 
 // ---------------------------------------------------------------------------------------
 // embedding_in (+ layer-0 projections).  h0 -> hs0, x -> xs0
@@ -77,76 +50,6 @@ __global__ __launch_bounds__(256) void embed_in_kernel(const float* __restrict__
         if (live) project_pre<F, H, A>(params + layer0, hv[slot], f, P + (size_t)j * PS);
     }
 }
-
-// ---------------------------------------------------------------------------------------
-// edge kernel
-// ---------------------------------------------------------------------------------------
-template <int F, int H, int A>
-struct EdgeFwd {
-    using LL = LP<F, H, A>;
-    static constexpr int FH = F / H;
-
-    // forward of one edge up to s; fills the activations the backward needs when asked.
-    // t1: pre-activation of the first edge Linear; u -> xhat (normalised), m; q pre-activation.
-    __device__ static __forceinline__ void run(const float* __restrict__ lw, const float* __restrict__ prow,
-                                               const float* __restrict__ pcrow, const float geo[kGeo], float attr,
-                                               float t1[F], float xhat[F], float& rstd, float m[F], float q[F],
-                                               float& s) {
-        constexpr int FP = Geom<F>::FP;
-        // gather the two per-node projections (16-byte loads)
-        float pr[FP], pc[FP];
-#pragma unroll
-        for (int v = 0; v < FP / 4; ++v) {
-            const float4 a = reinterpret_cast<const float4*>(prow)[v];
-            const float4 b = reinterpret_cast<const float4*>(pcrow)[v];
-            pr[4 * v] = a.x; pr[4 * v + 1] = a.y; pr[4 * v + 2] = a.z; pr[4 * v + 3] = a.w;
-            pc[4 * v] = b.x; pc[4 * v + 1] = b.y; pc[4 * v + 2] = b.z; pc[4 * v + 3] = b.w;
-        }
-#pragma unroll
-        for (int o = 0; o < F; ++o) {
-            const float* w = lw + LL::w1_off(o, 2 * F);
-            float acc = pr[o] + pc[o];
-#pragma unroll
-            for (int g = 0; g < kGeo; ++g) acc = fmaf(w[g], geo[g], acc);
-            if (A) acc = fmaf(w[kGeo], attr, acc);
-            t1[o] = acc;
-        }
-        float g1[F];
-#pragma unroll
-        for (int o = 0; o < F; ++o) g1[o] = silu(t1[o]);
-        float u[F];
-        float mean = 0.0f;
-#pragma unroll
-        for (int o = 0; o < F; ++o) {
-            float acc = lw[LL::b2_off(o)];
-            const int hb = (o / FH) * FH;
-#pragma unroll
-            for (int i = 0; i < FH; ++i) acc = fmaf(lw[LL::w2_off(o, hb + i)], g1[hb + i], acc);
-            u[o] = acc;
-            mean += acc;
-        }
-        mean *= (1.0f / F);
-        float var = 0.0f;
-#pragma unroll
-        for (int o = 0; o < F; ++o) { const float c = u[o] - mean; var = fmaf(c, c, var); }
-        var *= (1.0f / F);
-        rstd = 1.0f / sqrtf(var + 1e-5f);
-#pragma unroll
-        for (int o = 0; o < F; ++o) {
-            xhat[o] = (u[o] - mean) * rstd;
-            m[o] = fmaf(xhat[o], lw[LL::ln_g + o], lw[LL::ln_b + o]);
-        }
-        s = 0.0f;
-#pragma unroll
-        for (int o = 0; o < F; ++o) {
-            float acc = lw[LL::b6 + o];
-#pragma unroll
-            for (int i = 0; i < F; ++i) acc = fmaf(lw[LL::w6 + o * F + i], m[i], acc);
-            q[o] = acc;
-            s = fmaf(lw[LL::w7 + o], silu(acc), s);
-        }
-    }
-};
 
 template <int F, int H, int A>
 __global__ __launch_bounds__(256) void edge_fwd_kernel(const float* __restrict__ lw, const int* __restrict__ row,

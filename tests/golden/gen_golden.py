@@ -168,8 +168,11 @@ def gen_layer_fixture(tr, name, n, k, feat, heads, n_layers, seed, dup_points=Fa
 
 
 # ---------------------------------------------------------------- fixture (ii)/(iii): pair forward
-def pair_inputs(seed, n, feat, k, scale=(3.0, 3.0, 3.0)):
+def pair_inputs(seed, n, feat, k, scale=(3.0, 3.0, 3.0), tgt_noise=0.0):
     p = orc.synthetic_pair(seed, n=n, feat=feat, scale=scale)
+    if tgt_noise > 0:      # keeps the pose error away from 0, where the reference's fp32 arccos gradient is NaN
+        g = torch.Generator().manual_seed(seed + 99)
+        p["tgt"] = p["tgt"] + tgt_noise * torch.randn(n, 3, generator=g)
     e_s = orc.knn_graph(p["src"], k, loop=True)
     e_t = orc.knn_graph(p["tgt"], k, loop=True)
     return p, e_s, e_t
@@ -185,8 +188,8 @@ def run_pair(mod, model, p, e_s, e_t, dt):
 
 
 def gen_pair_fixture(tr, ev, name, n, k, feat, n_layers, heads, seed, ckpt=None, out_scale=None,
-                     with_grads=False):
-    p, e_s, e_t = pair_inputs(1234 + seed, n, feat, k)
+                     with_grads=False, tgt_noise=0.0):
+    p, e_s, e_t = pair_inputs(1234 + seed, n, feat, k, tgt_noise=tgt_noise)
     egnn = build_egnn(tr, feat, n_layers, heads, seed)
     torch.manual_seed(seed + 1)
     cross = tr.CrossAttentionPoseRegression(egnn, num_nodes=n, hidden_nf=feat, device="cpu")
@@ -295,12 +298,17 @@ def gen_kabsch_fixture(name):
 
 def main():
     tr, ev = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "wellcond":     # regenerate just this fixture
+        gen_pair_fixture(tr, ev, "pair_n512_k12_l2_wellcond.npz", 512, 12, 32, 2, 1, seed=3, out_scale=0.02, with_grads=True,
+                         tgt_noise=0.05)
+        return
     gen_layer_fixture(tr, "layer_n128_k8_f32_h1.npz", 128, 8, 32, 1, 2, seed=11)
     gen_layer_fixture(tr, "layer_n128_k8_f33_h1.npz", 128, 8, 33, 1, 2, seed=12)
     gen_layer_fixture(tr, "layer_n128_k8_f32_h4.npz", 128, 8, 32, 4, 2, seed=13)
     gen_layer_fixture(tr, "layer_n96_k6_f32_h1_dup.npz", 96, 6, 32, 1, 1, seed=14, dup_points=True)
     gen_pair_fixture(tr, ev, "pair_n2048_k20_l4.npz", 2048, 20, 32, 4, 1, seed=0)
-    gen_pair_fixture(tr, ev, "pair_n512_k12_l2_wellcond.npz", 512, 12, 32, 2, 1, seed=3, out_scale=0.02, with_grads=True)
+    gen_pair_fixture(tr, ev, "pair_n512_k12_l2_wellcond.npz", 512, 12, 32, 2, 1, seed=3, out_scale=0.02, with_grads=True,
+                     tgt_noise=0.05)
     gen_pair_fixture(tr, ev, "pair_ckpt_n2048_k16_l3_h4.npz", 2048, 16, 32, 3, 4, seed=1,
                      ckpt=os.path.join(REF, "checkpoints", "checkpoint-3dmatch.pth"))
     gen_kabsch_fixture("kabsch_cases.npz")

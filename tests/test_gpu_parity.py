@@ -253,3 +253,104 @@ def test_kabsch_degenerate_and_masked(pk):
     assert torch.allclose(R[0].cpu(), torch.eye(3), atol=1e-6) and torch.allclose(R[1].cpu(), torch.eye(3), atol=1e-6)
     assert torch.allclose(tt[0].cpu(), (t[0, 7] - s[0, 7]).cpu() * w[0, 7].cpu(), atol=1e-5)
     assert torch.allclose(tt[1].cpu(), torch.zeros(3), atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------ EGNN backward
+def _grad_check(got, ref32, ref64, name, k=6.0, rel=2e-5):
+    ref64 = np.asarray(ref64, dtype=np.float64)
+    scale = max(1e-6, float(np.abs(ref64).max()))
+    gap = float(np.abs(np.asarray(ref32, dtype=np.float64) - ref64).max())
+    tol = k * gap + rel * scale
+    err = float(np.abs(got.detach().cpu().numpy().astype(np.float64) - ref64).max())
+    assert err <= tol, f"{name}: err {err:.3e} > tol {tol:.3e} (scale {scale:.3e}, ref fp32 gap {gap:.3e})"
+
+
+@pytest.mark.parametrize("name", LAYER_FIX)
+def test_egnn_backward_golden(pk, golden_dir, name):
+    fx = np.load(os.path.join(golden_dir, name))
+    m = build_egnn(pk, fx)
+    h = torch.from_numpy(fx["h"]).cuda().requires_grad_(True)
+    x = torch.from_numpy(fx["x"]).cuda().requires_grad_(True)
+    edges = torch.from_numpy(fx["edges"]).cuda()
+    ea = torch.ones(edges.shape[1], 1, device="cuda")
+    ho, xo = m(h, x, [edges[0], edges[1]], ea)
+    loss = (ho * torch.from_numpy(fx["gh"]).cuda()).sum() + (xo * torch.from_numpy(fx["gx"]).cuda()).sum()
+    m.zero_grad()
+    loss.backward()
+    _grad_check(h.grad, fx["f32.grad_h"], fx["f64.grad_h"], f"{name} grad_h")
+    _grad_check(x.grad, fx["f32.grad_x"], fx["f64.grad_x"], f"{name} grad_x")
+    for pn, p in m.named_parameters():
+        assert p.grad is not None, pn
+        _grad_check(p.grad, fx["f32.grad." + pn], fx["f64.grad." + pn], f"{name} grad {pn}")
+    # gradients are views of ONE flat bucket, in parameter-block order
+    off = 0
+    for pn, p in m.named_parameters():
+        assert p.grad.data_ptr() == m.flat_grads.data_ptr() + 4 * off
+        off += p.numel()
+    # accumulation semantics (+=) and zero_grad(set_to_none=True) recovery
+    g1 = m.flat_grads.clone()
+    ho, xo = m(h, x, [edges[0], edges[1]], ea)
+    ((ho * torch.from_numpy(fx["gh"]).cuda()).sum() + (xo * torch.from_numpy(fx["gx"]).cuda()).sum()).backward()
+    assert torch.allclose(m.flat_grads, 2 * g1, rtol=1e-6, atol=1e-7)
+    for p in m.parameters():
+        p.grad = None
+    ho, xo = m(h, x, [edges[0], edges[1]], ea)
+    ((ho * torch.from_numpy(fx["gh"]).cuda()).sum() + (xo * torch.from_numpy(fx["gx"]).cuda()).sum()).backward()
+    assert torch.equal(m.flat_grads, g1)          # deterministic: bitwise identical to the first backward
+
+
+def test_train_step_gradients_golden(pk, golden_dir):
+    """Full training loss (train :1120: corr+sim, geodesic rotation, translation direction) on the
+    well-conditioned pair: loss and every parameter gradient against the reference autograd."""
+    fx = np.load(os.path.join(golden_dir, "pair_n512_k12_l2_wellcond.npz"))
+    models = _pair_models(pk, fx)
+    mt = models["train"]
+    args = _pair_inputs(pk, fx)
+    R, t, closs, equi, *_ = mt(*args)
+    rl, tl = pk.pose_loss(R, t, args[-1])
+    loss = closs.mean() + rl.mean() + tl.mean()
+    np.testing.assert_allclose(loss.item(), float(fx["f64.train.loss"]), rtol=1e-4)
+    assert float(np.abs(R.detach().cpu().numpy() - fx["f64.train.R"]).max()) <= 1e-4
+    mt.zero_grad()
+    loss.backward()
+    checked = 0
+    for pn, p in mt.named_parameters():
+        key = "train.grad." + pn
+        if "f64." + key in fx.files:
+            assert p.grad is not None, pn
+            _grad_check(p.grad, fx["f32." + key], fx["f64." + key], pn, k=8.0, rel=5e-5)
+            checked += 1
+    assert checked > 20
+
+
+def test_backward_random_graph_vs_oracle_autograd(pk):
+    """Non-kNN edge list (hub, isolated nodes, self loops, multi-edges), random edge_attr, 3 layers, 4 heads."""
+    g = torch.Generator().manual_seed(33)
+    n, e = 257, 3001
+    torch.manual_seed(9)
+    m = pk.EGNN(32, 32, 32, in_edge_nf=1, device="cuda", n_layers=3, num_heads=4)
+    h = torch.randn(n, 32, generator=g); x = torch.rand(n, 3, generator=g) * 2
+    row = torch.randint(0, n - 7, (e,), generator=g); col = torch.randint(0, n - 7, (e,), generator=g)
+    row[:40] = 3; row[40:45] = col[40:45]
+    ea = torch.rand(e, 1, generator=g)
+    gh = torch.randn(n, 32, generator=g); gx = torch.randn(n, 3, generator=g)
+    refs = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        w = {k: v.detach().cpu().to(dt).requires_grad_(True) for k, v in m.state_dict().items()}
+        hh = h.to(dt).clone().requires_grad_(True); xx = x.to(dt).clone().requires_grad_(True)
+        ho, xo = orc.egnn_forward(w, hh, xx, [row, col], ea.to(dt))
+        ((ho * gh.to(dt)).sum() + (xo * gx.to(dt)).sum()).backward()
+        refs[tag] = dict(h=hh.grad.numpy(), x=xx.grad.numpy(), **{k: v.grad.numpy() for k, v in w.items()})
+    hc = h.cuda().requires_grad_(True); xc = x.cuda().requires_grad_(True)
+    ho, xo = m(hc, xc, [row.cuda(), col.cuda()], ea.cuda())
+    m.zero_grad()
+    ((ho * gh.cuda()).sum() + (xo * gx.cuda()).sum()).backward()
+    _grad_check(hc.grad, refs["f32"]["h"], refs["f64"]["h"], "grad_h")
+    _grad_check(xc.grad, refs["f32"]["x"], refs["f64"]["x"], "grad_x")
+    for pn, p in m.named_parameters():
+        _grad_check(p.grad, refs["f32"][pn], refs["f64"][pn], pn)
+
+
+def test_smoke_entry(pk):
+    import __graft_entry__
+    __graft_entry__.smoke()
