@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""Registration pairs/sec of the Equi-GSPR hot path on MI355X (BASELINE.json metric).
+
+A "step" = one full training pass of the hot path over one batch of synthetic pairs:
+  k-NN graph for all 2B clouds (one launch) + inverse index -> batched EGNN forward ->
+  pose head (top-k logits MLP, weighted Kabsch/SVD) -> losses (train :1120) -> backward
+  (HIP EGNN + Kabsch backward) -> [all-reduce of the two flat gradient buckets over RCCL] ->
+  Adam step.  Inputs are resident in HBM before the timed region.
+Default workload = BASELINE configs[1]: one 2048-point pair, k=20, 4 EGNN layers, batch=1,
+forward+backward on 1 GPU.  With --gpus N every rank processes its own batch (weak scaling:
+pairs are independent; the only exchange is the gradient all-reduce).
+
+Prints ONE JSON line on rank 0 (schema: see repo prompt) including
+  "roofline":     algorithmic bytes of the EGNN message-passing edge kernel / its HIP-event
+                  duration (equigspr_time_edge_* hooks), against 8 TB/s HBM;
+  "cpu_baseline": the oracle (CPU restatement of the reference, PyTorch CPU ops, fp32) timed on
+                  this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_PEAK_TF = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1, help="pairs per GPU per step")
+    ap.add_argument("--n", type=int, default=2048)
+    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--feat", type=int, default=32)
+    ap.add_argument("--heads", type=int, default=1)
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--forward-only", action="store_true", help="diagnostic: inference step (not the headline metric)")
+    return ap.parse_args()
+
+
+def build_step(pkg, args, dev, world):
+    torch.manual_seed(0)
+    egnn = pkg.EGNN(args.feat, args.feat, args.feat, in_edge_nf=1, device=dev, n_layers=args.layers, num_heads=args.heads)
+    model = pkg.CrossAttentionPoseRegression(egnn, num_nodes=args.n, hidden_nf=args.feat, device=dev).to(dev)
+    egnn._ensure_flat()
+    from se3_equi_graph_registration_amd.dp import DataParallelStep
+    dp = DataParallelStep(model, egnn)
+    dp.broadcast_parameters(0)
+    rank = dist.get_rank() if world > 1 else 0
+    scale = (3.0, 3.0, 3.0)
+    batch = pkg.synthetic_batch(1234 + rank * args.batch, args.batch, n=args.n, feat=args.feat, scale=scale, device=dev)
+    ones = torch.ones(args.batch, args.n * args.k, 1, device=dev)
+    # one fused Adam over the two flat buckets (the per-tensor parameters are views of them)
+    opt_params = []
+    for flat, grad in ((egnn.flat_params, egnn.flat_grads), (dp.head.flat, dp.head.grad)):
+        if flat is None:
+            continue
+        p = torch.nn.Parameter(flat, requires_grad=True)
+        p.grad = grad
+        opt_params.append(p)
+    capturable = not args.no_graph
+    opt = torch.optim.Adam(opt_params, lr=1e-4, capturable=capturable, foreach=True)       # train :1412
+
+    def fwd_bwd():
+        graph = pkg.build_pair_graph(batch["src"], batch["tgt"], args.k, loop=True)
+        out = model(batch["feat_src"], batch["src"], graph, ones, batch["feat_tgt"], batch["tgt"], graph, ones,
+                    batch["corr"], batch["labels"], batch["gt_pose"])
+        if args.forward_only:
+            return out[2]
+        R, t, closs = out[0], out[1], out[2]
+        rl, tl = pkg.pose_loss(R, t, batch["gt_pose"])
+        loss = closs.mean() + rl.mean() + tl.mean()                                          # train :1120
+        loss.backward()
+        return loss
+
+    def zero():
+        dp.zero_grad()
+
+    def opt_step():
+        opt.step()
+
+    return dict(model=model, egnn=egnn, dp=dp, batch=batch, ones=ones, fwd_bwd=fwd_bwd, zero=zero, opt_step=opt_step)
+
+
+def make_runner(S, args, world, dev):
+    """Returns (callable running one step, used_graph)."""
+    def eager():
+        S["zero"]()
+        if args.forward_only:
+            with torch.no_grad():
+                return S["fwd_bwd"]()
+        loss = S["fwd_bwd"]()
+        S["dp"].sync()
+        S["opt_step"]()
+        return loss
+
+    if args.no_graph:
+        return eager, False
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if world == 1 or args.forward_only:
+            g = torch.cuda.CUDAGraph()
+            S["zero"]()
+            with torch.cuda.graph(g):
+                if args.forward_only:
+                    with torch.no_grad():
+                        S["loss"] = S["fwd_bwd"]()
+                else:
+                    S["zero"]()
+                    S["loss"] = S["fwd_bwd"]()
+                    S["opt_step"]()
+            return (lambda: g.replay()), True
+        # multi-GPU: graph A = zero+fwd+bwd, eager RCCL all-reduce of the two buckets, graph B = Adam
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(ga):
+            S["zero"]()
+            S["loss"] = S["fwd_bwd"]()
+        with torch.cuda.graph(gb):
+            S["opt_step"]()
+
+        def run():
+            ga.replay()
+            S["dp"].sync()
+            gb.replay()
+        return run, True
+    except Exception as exc:        # capture unsupported -> eager launches (reported in the JSON)
+        print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+        torch.cuda.synchronize()
+        return eager, False
+
+
+def roofline(pkg, S, args, dev):
+    """HIP-event timing of the edge (message-passing) kernels, forward and backward."""
+    from se3_equi_graph_registration_amd import _lib, ops
+    L = _lib.lib()
+    egnn, batch = S["egnn"], S["batch"]
+    B, N = args.batch, args.n
+    graph = pkg.build_pair_graph(batch["src"], batch["tgt"], args.k, loop=True)
+    h = torch.cat([batch["feat_src"].reshape(B * N, -1), batch["feat_tgt"].reshape(B * N, -1)]).contiguous()
+    x = torch.cat([batch["src"].reshape(B * N, 3), batch["tgt"].reshape(B * N, 3)]).contiguous()
+    cfg = egnn.cfg
+    E = graph.n_edges
+    work = torch.empty(int(L.equigspr_egnn_work_size(ctypes.byref(cfg), graph.n_nodes, E)), device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ms = ctypes.c_float(0.0)
+    iters = 50
+    _lib.check(L.equigspr_time_edge_fwd(ctypes.byref(cfg), ctypes.c_void_p(egnn.flat_params.data_ptr()),
+                                        ctypes.byref(graph.struct), ctypes.c_void_p(h.data_ptr()),
+                                        ctypes.c_void_p(x.data_ptr()), None, ctypes.c_void_p(work.data_ptr()), iters,
+                                        ctypes.byref(ms), stream), "time_edge_fwd")
+    fwd_ms = ms.value
+    _, _, saved = ops.egnn_forward(cfg, egnn.flat_params, graph, h, x, None, True)
+    bwork = torch.empty(int(L.equigspr_egnn_bwd_work_size(ctypes.byref(cfg), graph.n_nodes, E)), device=dev)
+    _lib.check(L.equigspr_time_edge_bwd(ctypes.byref(cfg), ctypes.c_void_p(egnn.flat_params.data_ptr()),
+                                        ctypes.byref(graph.struct), None, ctypes.c_void_p(saved.data_ptr()),
+                                        ctypes.c_void_p(bwork.data_ptr()), iters, ctypes.byref(ms), stream), "time_edge_bwd")
+    bwd_ms = ms.value
+    F = args.feat
+    bytes_fwd = (2 * (F + 3) * 4 + 2 * 4 + 4 + (F + 3) * 4) * E          # 432 B/edge-layer at F=32
+    bytes_bwd = 2 * bytes_fwd
+    flops_fwd = (2 * (2 * F + 13) * F + 2 * F * F + 2 * F * F + 2 * F + 12 * F) * E
+    dom_is_bwd = bwd_ms >= fwd_ms and not args.forward_only
+    a_f = bytes_fwd / (fwd_ms * 1e-3) / 1e9
+    a_b = bytes_bwd / (bwd_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "kernel": "edge_bwd_kernel" if dom_is_bwd else "edge_fwd_kernel",
+            "achieved": round(a_b if dom_is_bwd else a_f, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round((a_b if dom_is_bwd else a_f) / HBM_PEAK_GBS, 5), "traffic": None,
+            "edges_per_launch": E, "algorithmic_bytes_per_launch": bytes_bwd if dom_is_bwd else bytes_fwd,
+            "launch_ms": round(bwd_ms if dom_is_bwd else fwd_ms, 5)}
+    extra = {"edge_fwd_ms": round(fwd_ms, 5), "edge_bwd_ms": round(bwd_ms, 5),
+             "edge_fwd_GBs": round(a_f, 2), "edge_bwd_GBs": round(a_b, 2),
+             "edge_fwd_fp32_frac": round(flops_fwd / (fwd_ms * 1e-3) / 1e12 / FP32_PEAK_TF, 5)}
+    return roof, extra
+
+
+def cpu_baseline(args):
+    """Oracle (CPU restatement of the reference path, PyTorch CPU fp32), same workload, bounded time."""
+    from oracle import egnn_oracle as orc
+    import se3_equi_graph_registration_amd as pkg
+    torch.manual_seed(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    egnn = pkg.EGNN(args.feat, args.feat, args.feat, in_edge_nf=1, device="cpu", n_layers=args.layers, num_heads=args.heads)
+    model = pkg.CrossAttentionPoseRegression(egnn, num_nodes=args.n, hidden_nf=args.feat, device="cpu")
+    we = {k: v.detach().clone().requires_grad_(True) for k, v in egnn.state_dict().items()}
+    wc = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()
+          if not k.startswith("egnn.") and v.is_floating_point()}
+    b = pkg.synthetic_batch(1234, args.batch, n=args.n, feat=args.feat)
+
+    def step():
+        t0 = time.perf_counter()
+        es = torch.stack([orc.knn_graph(b["src"][i], args.k) for i in range(args.batch)])
+        et = torch.stack([orc.knn_graph(b["tgt"][i], args.k) for i in range(args.batch)])
+        t_knn = time.perf_counter() - t0
+        ea = torch.ones(args.batch, es.shape[2], 1)
+        res, _ = orc.pair_forward_train(we, wc, b["feat_src"], b["src"], es, ea, b["feat_tgt"], b["tgt"], et, ea,
+                                        b["corr"], b["labels"], b["gt_pose"])
+        if not args.forward_only:
+            rl, tl = orc.pose_loss(res[0], res[1], b["gt_pose"])
+            (res[2].mean() + rl.mean() + tl.mean()).backward()
+            for v in list(we.values()) + list(wc.values()):
+                v.grad = None
+        return t_knn
+
+    # pick the thread count: this path is many small memory-bound ATen ops, and all host cores
+    # (256 on the GPU box) is ~100x SLOWER than 8-32 threads; time one step at each candidate.
+    best_t, best_dt = 1, None
+    for cand in (8, 16, 32, 64):
+        if cand > cores:
+            break
+        torch.set_num_threads(cand)
+        step()                               # warm-up at this setting
+        t0 = time.perf_counter(); step(); dt = time.perf_counter() - t0
+        if best_dt is None or dt < best_dt:
+            best_t, best_dt = cand, dt
+    torch.set_num_threads(best_t)
+    cores = best_t
+    n_done, t_start, t_knn = 0, time.perf_counter(), 0.0
+    while True:
+        t_knn += step()
+        n_done += 1
+        el = time.perf_counter() - t_start
+        if el >= args.cpu_seconds or n_done >= 200:
+            break
+    return {"value": round(args.batch * n_done / el, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n_done} steps of the same workload (B={args.batch}, N={args.n}, k={args.k}, L={args.layers}, "
+                      f"{'forward' if args.forward_only else 'forward+backward'}; numpy kNN restatement took "
+                      f"{100 * t_knn / el:.0f}% of the time; no optimizer step) in {el:.1f}s; torch CPU threads={cores} "
+                      f"(fastest of 8/16/32/64; host has {os.cpu_count()} cores)",
+            "threads": torch.get_num_threads()}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    rank = dist.get_rank() if world > 1 else 0
+    import se3_equi_graph_registration_amd as pkg
+    pkg.lib()
+
+    S = build_step(pkg, args, dev, world)
+    run, used_graph = make_runner(S, args, world, dev)
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    finite = bool(torch.isfinite(S["egnn"].flat_params).all().item())
+
+    if rank == 0:
+        roof, extra = roofline(pkg, S, args, dev)
+        out = {
+            "metric": "registration pairs/sec (2048-pt, k=20, 4 EGNN layers)",
+            "value": round(world * args.batch * args.steps / el, 3), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * el / args.steps, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{'inference' if args.forward_only else 'training'} step: {args.batch} pair(s)/GPU x "
+                                   f"{args.n} pts, k={args.k}, {args.layers} EGNN layers, F={args.feat}, heads={args.heads}; "
+                                   "kNN+index, EGNN fwd, pose head (Kabsch/SVD), "
+                                   + ("no backward" if args.forward_only else "losses, backward, grad all-reduce, Adam"),
+                       "pairs_per_gpu": args.batch, "points": args.n, "k": args.k, "layers": args.layers,
+                       "hipgraph": used_graph, "parallelism": f"dp{world}", "params_finite": finite},
+            "roofline": roof, "kernels": extra,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,6 +145,18 @@ int equigspr_kabsch_backward(const float* src, const float* tgt, const float* w,
                              const float* grad_R, const float* grad_t, int32_t batch, int32_t n,
                              float* grad_src, float* grad_tgt, float* grad_w, void* stream);
 
+/* ---- measurement hooks (bench.py's roofline leg; NOT part of the drop-in path) -----------
+ * Average duration in ms (written to HOST memory) of the EGNN message-passing edge kernel,
+ * measured with HIP events on `stream` over `iters` back-to-back launches (these two calls
+ * synchronise the host).  fwd: layer 0's edge kernel after embedding_in.  bwd: the last
+ * layer's edge backward kernel; `saved` from a training-mode equigspr_egnn_forward. */
+int equigspr_time_edge_fwd(const equigspr_egnn_config* cfg, const float* params, const equigspr_graph* g,
+                           const float* h_in, const float* x_in, const float* edge_attr, float* work,
+                           int32_t iters, float* ms_out_host, void* stream);
+int equigspr_time_edge_bwd(const equigspr_egnn_config* cfg, const float* params, const equigspr_graph* g,
+                           const float* edge_attr, const float* saved, float* bwd_work, int32_t iters,
+                           float* ms_out_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,10 @@ _SIGNATURES = {
     "equigspr_egnn_backward": (ctypes.c_int, [POINTER(EgnnConfig), c_void_p, POINTER(Graph), c_void_p, c_void_p,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p]),
+    "equigspr_time_edge_fwd": (ctypes.c_int, [POINTER(EgnnConfig), c_void_p, POINTER(Graph), c_void_p, c_void_p, c_void_p,
+                                              c_void_p, c_int32, POINTER(ctypes.c_float), c_void_p]),
+    "equigspr_time_edge_bwd": (ctypes.c_int, [POINTER(EgnnConfig), c_void_p, POINTER(Graph), c_void_p, c_void_p, c_void_p,
+                                              c_int32, POINTER(ctypes.c_float), c_void_p]),
     "equigspr_kabsch_forward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                                c_void_p, c_void_p]),
     "equigspr_kabsch_backward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -188,7 +188,14 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__
     __shared__ float ghv[NS][FP];
     __shared__ float dvv[NS][FP];
     __shared__ float sl[SB::node];
+    __shared__ float wts[4 * F * (F + 1)];      // W4^T | W_src^T | W_tgt^T
+    float* W4T = wts;
+    float* WaT = wts + 2 * F * (F + 1);
+    float* WbT = WaT + F * (F + 1);
     const int slot = threadIdx.x / G, f = threadIdx.x % G;
+    stage_T<F>(W4T, lw + LL::w4, 2 * F, 2 * F);
+    stage_w1_T<F, H, A>(WaT, lw, 0);
+    stage_w1_T<F, H, A>(WbT, lw, F);
     float aW4[2 * F], aW5[F];
     float ab4 = 0.0f, ab5 = 0.0f;
 #pragma unroll
@@ -209,10 +216,10 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__
         }
         __syncthreads();
         if (act) {
-            v = lw[LL::b4 + f] + row_dot(lw + LL::w4 + f * 2 * F, vin[slot], 2 * F);
+            v = lw[LL::b4 + f] + col_dot<F>(W4T, f, vin[slot], 2 * F);
             hid[slot][f] = silu(v);
         }
-        if (j < n_nodes) project_pre<F, H, A>(lw, vin[slot], f, P + (size_t)j * PS);
+        if (j < n_nodes) project_pre<F, H, A>(lw, WaT, WbT, vin[slot], f, P + (size_t)j * PS);
         __syncthreads();
         float dv = 0.0f;
         if (act) {
@@ -349,7 +356,7 @@ __device__ __forceinline__ void tile_pass(const float* X, const float* Y, f32x16
 }
 
 template <int F, int H, int A>
-__global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__ lw, const int* __restrict__ row,
+__global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__ lw_in, const int* __restrict__ row,
                                                        const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                        const float* __restrict__ x, const float* __restrict__ P,
                                                        const float* __restrict__ dagg, const float* __restrict__ Gx,
@@ -381,7 +388,12 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__
     cs_scr1[0] = 0.0f;
 
     const int chunks = (n_edges + 255) / 256;
+    const float* lw_base = lw_in;
     for (int ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
+        // Re-materialise the weight pointer every chunk: without this the compiler hoists ALL ~4.6k
+        // wave-uniform weight loads out of the loop and spills them (v_writelane/v_readlane storm).
+        const float* lw = lw_base;
+        asm volatile("" : "+s"(lw));
         const int e_raw = ch * 256 + threadIdx.x;
         const bool valid = e_raw < n_edges;
         const int e = valid ? e_raw : n_edges - 1;
@@ -467,13 +479,15 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__
         // ---- dt1 = (W2^T du) * silu'(t1)
         float dt1[F];
 #pragma unroll
-        for (int i = 0; i < F; ++i) {
-            const int hb = (i / FH) * FH;
-            float a = 0.0f;
+        for (int i = 0; i < F; ++i) dt1[i] = 0.0f;
 #pragma unroll
-            for (int o = 0; o < FH; ++o) a = fmaf(lw[LL::w2_off(hb + o, i)], du[hb + o], a);
-            dt1[i] = a * silu_grad(t1[i]);
+        for (int o = 0; o < F; ++o) {                       // row o of W2 is contiguous: wide scalar loads
+            const int hb = (o / FH) * FH;
+#pragma unroll
+            for (int i = 0; i < FH; ++i) dt1[hb + i] = fmaf(lw[LL::w2_off(o, hb + i)], du[o], dt1[hb + i]);
         }
+#pragma unroll
+        for (int i = 0; i < F; ++i) dt1[i] *= silu_grad(t1[i]);
         // ---- stage [dt1 | geo,attr] (dWgeo) ; dm goes into X's partner tile for dbeta afterwards
 #pragma unroll
         for (int o = 0; o < F; ++o) X[lane * LD + o] = dt1[o];
@@ -492,11 +506,12 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__
         // ---- geometry backward
         float gg[kGeo];
 #pragma unroll
-        for (int gI = 0; gI < kGeo; ++gI) {
-            float a = 0.0f;
+        for (int gI = 0; gI < kGeo; ++gI) gg[gI] = 0.0f;
 #pragma unroll
-            for (int o = 0; o < F; ++o) a = fmaf(lw[LL::w1_off(o, 2 * F + gI)], dt1[o], a);
-            gg[gI] = a;
+        for (int o = 0; o < F; ++o) {
+            const float* w = lw + LL::w1_off(o, 2 * F);
+#pragma unroll
+            for (int gI = 0; gI < kGeo; ++gI) gg[gI] = fmaf(w[gI], dt1[o], gg[gI]);
         }
         float gxr[3], gxc[3];
         edge_geometry_backward(xr, xc, eg, gg, gd, gxr, gxc);
@@ -569,48 +584,75 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------
 // slab reduction into the flat gradient block (+=), fixed order
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ float sum_slabs(const float* __restrict__ slab, int n_slabs, int stride, int idx) {
+// 256-thread block = 32 consecutive gradient entries x 8 slab partitions; partition p sums slabs
+// p, p+8, ... (coalesced 128-B rows), then the 8 partials are added in order: fixed order, no atomics.
+__device__ __forceinline__ float sum_slabs_part(const float* __restrict__ slab, int n_slabs, int stride, int idx, int part) {
     float a = 0.0f;
-    for (int s = 0; s < n_slabs; ++s) a += slab[(size_t)s * stride + idx];
+#pragma unroll 4
+    for (int s = part; s < n_slabs; s += 8) a += slab[(size_t)s * stride + idx];
     return a;
+}
+__device__ __forceinline__ void finish_parts(float v, int lane, int part, bool live, float* __restrict__ dst) {
+    __shared__ float red[8][33];
+    red[part][lane] = v;
+    __syncthreads();
+    if (part == 0 && live) {
+        float a = red[0][lane];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) a += red[p][lane];
+        *dst += a;
+    }
 }
 
 template <int F, int H, int A>
-__global__ void layer_grad_reduce_kernel(const float* __restrict__ node_slab, int n_node, const float* __restrict__ edge_slab,
-                                         int n_edge, const float* __restrict__ gat_slab, int n_gat,
-                                         float* __restrict__ grad_layer) {
+__global__ __launch_bounds__(256) void layer_grad_reduce_kernel(const float* __restrict__ node_slab, int n_node,
+                                                                const float* __restrict__ edge_slab, int n_edge,
+                                                                const float* __restrict__ gat_slab, int n_gat,
+                                                                float* __restrict__ grad_layer) {
     using LL = LP<F, H, A>;
     using SB = Slabs<F>;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= LL::size) return;
-    float v;
-    if (idx < H * LL::head_stride) {
-        const int j = idx / LL::head_stride, r = idx % LL::head_stride;
-        if (r < LL::b1) {
-            const int o = j * LL::FH + r / LL::D, c = r % LL::D;
-            if (c < F) v = sum_slabs(gat_slab, n_gat, SB::gather, o * F + c);
-            else if (c < 2 * F) v = sum_slabs(gat_slab, n_gat, SB::gather, F * F + o * F + (c - F));
-            else v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_geo + o * 16 + (c - 2 * F));
-        } else if (r < LL::w2) {
-            v = sum_slabs(gat_slab, n_gat, SB::gather, 2 * F * F + j * LL::FH + (r - LL::b1));
-        } else if (r < LL::b2) {
-            const int ol = (r - LL::w2) / LL::FH, il = (r - LL::w2) % LL::FH;
-            v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_w2 + (j * LL::FH + ol) * F + j * LL::FH + il);
-        } else {
-            v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_b2 + j * LL::FH + (r - LL::b2));
-        }
-    } else if (idx < LL::ln_b) v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_gam + (idx - LL::ln_g));
-    else if (idx < LL::w4) v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_bet + (idx - LL::ln_b));
-    else if (idx < LL::w6) v = sum_slabs(node_slab, n_node, SB::node, idx - LL::w4);      // W4|b4|W5|b5 contiguous in both
-    else if (idx < LL::b6) v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_w6 + (idx - LL::w6));
-    else if (idx < LL::w7) v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_b6 + (idx - LL::b6));
-    else v = sum_slabs(edge_slab, n_edge, SB::edge, SB::e_w7 + (idx - LL::w7));
-    grad_layer[idx] += v;
+    const int lane = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + lane;
+    const bool live = idx < LL::size;
+    const float* src = nullptr;
+    int n = 0, stride = 0, si = 0;
+    auto edge = [&](int i) { src = edge_slab; n = n_edge; stride = SB::edge; si = i; };
+    auto node = [&](int i) { src = node_slab; n = n_node; stride = SB::node; si = i; };
+    auto gat = [&](int i) { src = gat_slab; n = n_gat; stride = SB::gather; si = i; };
+    if (live) {
+        if (idx < H * LL::head_stride) {
+            const int j = idx / LL::head_stride, r = idx % LL::head_stride;
+            if (r < LL::b1) {
+                const int o = j * LL::FH + r / LL::D, c = r % LL::D;
+                if (c < F) gat(o * F + c);
+                else if (c < 2 * F) gat(F * F + o * F + (c - F));
+                else edge(SB::e_geo + o * 16 + (c - 2 * F));
+            } else if (r < LL::w2) {
+                gat(2 * F * F + j * LL::FH + (r - LL::b1));
+            } else if (r < LL::b2) {
+                const int ol = (r - LL::w2) / LL::FH, il = (r - LL::w2) % LL::FH;
+                edge(SB::e_w2 + (j * LL::FH + ol) * F + j * LL::FH + il);
+            } else {
+                edge(SB::e_b2 + j * LL::FH + (r - LL::b2));
+            }
+        } else if (idx < LL::ln_b) edge(SB::e_gam + (idx - LL::ln_g));
+        else if (idx < LL::w4) edge(SB::e_bet + (idx - LL::ln_b));
+        else if (idx < LL::w6) node(idx - LL::w4);                       // W4|b4|W5|b5 contiguous in both layouts
+        else if (idx < LL::b6) edge(SB::e_w6 + (idx - LL::w6));
+        else if (idx < LL::w7) edge(SB::e_b6 + (idx - LL::b6));
+        else edge(SB::e_w7 + (idx - LL::w7));
+    }
+    const float v = live ? sum_slabs_part(src, n, stride, si, part) : 0.0f;
+    finish_parts(v, lane, part, live, grad_layer + (live ? idx : 0));
 }
 
-__global__ void plain_grad_reduce_kernel(const float* __restrict__ slab, int n_slabs, int size, float* __restrict__ dst) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < size) dst[idx] += sum_slabs(slab, n_slabs, size, idx);
+__global__ __launch_bounds__(256) void plain_grad_reduce_kernel(const float* __restrict__ slab, int n_slabs, int size,
+                                                                float* __restrict__ dst) {
+    const int lane = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + lane;
+    const bool live = idx < size;
+    const float v = live ? sum_slabs_part(slab, n_slabs, size, idx, part) : 0.0f;
+    finish_parts(v, lane, part, live, dst + (live ? idx : 0));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -657,12 +699,12 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
     const int chunks = ceil_div(E, 256);
     const int egrid = chunks < kEdgeBwdBlocks ? chunks : kEdgeBwdBlocks;
     const size_t edge_smem = sizeof(float) * (size_t)4 * 2 * 64 * LD;
-    static bool attr_set = false;
-    {
+    static bool attr_set = false;      // once per instantiation (first call happens outside any graph capture)
+    if (!attr_set) {
         hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_bwd_kernel<F, H, A>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)edge_smem);
         if (err != hipSuccess) { set_error("hipFuncSetAttribute(edge_bwd): %s", hipGetErrorString(err)); return (int)err; }
-        (void)attr_set;
+        attr_set = true;
     }
     int cur = 0;
     float* Gh = work + B.Gh[cur];
@@ -670,7 +712,7 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
     // embedding_out
     hipLaunchKernelGGL((embed_out_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_out, cfg->out_nf, gh_out,
                        gx_out, hs + (size_t)L * N * FP, N, Gh, Gx, work + B.emb_slab);
-    hipLaunchKernelGGL(plain_grad_reduce_kernel, dim3(ceil_div(cfg->out_nf * F + cfg->out_nf, 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(plain_grad_reduce_kernel, dim3(ceil_div(cfg->out_nf * F + cfg->out_nf, 32)), dim3(256), 0, s,
                        work + B.emb_slab, ngrid, cfg->out_nf * F + cfg->out_nf, grad_params + ML.w_out);
     for (int l = L - 1; l >= 0; --l) {
         const float* lw = params + ML.layer0 + (size_t)l * ML.layer_size;
@@ -686,16 +728,64 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
         hipLaunchKernelGGL((gather_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, g->rptr, g->rperm, g->cptr,
                            g->cperm, work + B.dt1, work + B.gxr, work + B.gxc, work + B.dh_part, work + B.Gx[cur], h_l, N,
                            work + B.Gh[nxt], work + B.Gx[nxt], (l == 0) ? grad_x_in : nullptr, work + B.gat_slab);
-        hipLaunchKernelGGL((layer_grad_reduce_kernel<F, H, A>), dim3(ceil_div(ML.layer_size, 256)), dim3(256), 0, s,
+        hipLaunchKernelGGL((layer_grad_reduce_kernel<F, H, A>), dim3(ceil_div(ML.layer_size, 32)), dim3(256), 0, s,
                            work + B.node_slab, ngrid, work + B.edge_slab, E > 0 ? egrid : 0, work + B.gat_slab, ngrid,
                            grad_params + ML.layer0 + (size_t)l * ML.layer_size);
         cur = nxt;
     }
     hipLaunchKernelGGL((embed_in_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_in, cfg->in_nf,
                        work + B.Gh[cur], h_in, N, grad_h_in, work + B.emb_slab);
-    hipLaunchKernelGGL(plain_grad_reduce_kernel, dim3(ceil_div(F * cfg->in_nf + F, 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(plain_grad_reduce_kernel, dim3(ceil_div(F * cfg->in_nf + F, 32)), dim3(256), 0, s,
                        work + B.emb_slab, ngrid, F * cfg->in_nf + F, grad_params + ML.w_in);
     EQ_CHECK_LAUNCH("egnn_backward");
+    return 0;
+}
+
+// measurement hook: average duration of the last layer's edge backward kernel (HIP events on `s`).
+// `saved` must come from a training-mode equigspr_egnn_forward on the same inputs.
+template <int F, int H, int A>
+static int time_edge_bwd_impl(const equigspr_egnn_config* cfg, const float* params, const equigspr_graph* g,
+                              const float* edge_attr, const float* saved, float* work, int iters, float* ms_out,
+                              hipStream_t s) {
+    const ModelLayout ML = make_model_layout(cfg->in_nf, F, cfg->out_nf, A, cfg->n_layers, H);
+    const int N = g->n_nodes, E = g->n_edges, L = cfg->n_layers;
+    constexpr int FP = Geom<F>::FP, NS = Geom<F>::NS, NB = (F + 31) / 32, LD = NB * 32 + 1;
+    const BwdLayout B = bwd_layout(F, cfg->in_nf, cfg->out_nf, N, E);
+    const float* hs = saved;
+    const float* xs = saved + (size_t)(L + 1) * N * FP;
+    const float* aggs = xs + (size_t)(L + 1) * N * 3;
+    const int l = L - 1;
+    const float* lw = params + ML.layer0 + (size_t)l * ML.layer_size;
+    const int groups = ceil_div(N, NS);
+    const int ngrid = groups < kNodeBwdBlocks ? groups : kNodeBwdBlocks;
+    const int chunks = ceil_div(E, 256);
+    const int egrid = chunks < kEdgeBwdBlocks ? chunks : kEdgeBwdBlocks;
+    const size_t edge_smem = sizeof(float) * (size_t)4 * 2 * 64 * LD;
+    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_bwd_kernel<F, H, A>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)edge_smem);
+    if (err != hipSuccess) { set_error("hipFuncSetAttribute(edge_bwd): %s", hipGetErrorString(err)); return (int)err; }
+    // synthetic upstream gradient: G_h = h_L (any finite data), G_x = x_{L-1} padded
+    (void)hipMemsetAsync(work + B.Gx[0], 0, sizeof(float) * (size_t)N * 4, s);
+    hipLaunchKernelGGL((node_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, hs + (size_t)L * N * FP,
+                       hs + (size_t)l * N * FP, aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg, work + B.P,
+                       work + B.node_slab);
+    auto launch = [&]() {
+        hipLaunchKernelGGL((edge_bwd_kernel<F, H, A>), dim3(egrid), dim3(256), edge_smem, s, lw, g->row, g->col, edge_attr,
+                           xs + (size_t)l * N * 3, work + B.P, work + B.dagg, work + B.Gx[0], E, work + B.dt1, work + B.gxr,
+                           work + B.gxc, work + B.edge_slab);
+    };
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    launch();
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) launch();
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_out = ms / iters;
+    EQ_CHECK_LAUNCH("time_edge_bwd");
     return 0;
 }
 
@@ -724,5 +814,21 @@ extern "C" int equigspr_egnn_backward(const equigspr_egnn_config* cfg, const flo
     EQ_DISPATCH(33, 1, 1) EQ_DISPATCH(33, 1, 0)
 #undef EQ_DISPATCH
     set_error("egnn_backward: no kernel for F=%d H=%d A=%d", F, H, A);
+    return EQUIGSPR_ENOTSUP;
+}
+
+extern "C" int equigspr_time_edge_bwd(const equigspr_egnn_config* cfg, const float* params, const equigspr_graph* g,
+                                      const float* edge_attr, const float* saved, float* bwd_work, int32_t iters,
+                                      float* ms_out_host, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(config_supported(cfg) && params && g && saved && bwd_work && ms_out_host && iters >= 1 && g->n_edges > 0,
+                 EQUIGSPR_EINVAL, "time_edge_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int F = cfg->hidden_nf, H = cfg->num_heads, A = cfg->in_edge_nf;
+#define EQ_DISPATCH(FF, HH, AA) \
+    if (F == FF && H == HH && A == AA) return time_edge_bwd_impl<FF, HH, AA>(cfg, params, g, edge_attr, saved, bwd_work, iters, ms_out_host, s);
+    EQ_DISPATCH(32, 1, 1) EQ_DISPATCH(32, 1, 0) EQ_DISPATCH(32, 4, 1) EQ_DISPATCH(32, 4, 0)
+    EQ_DISPATCH(33, 1, 1) EQ_DISPATCH(33, 1, 0)
+#undef EQ_DISPATCH
     return EQUIGSPR_ENOTSUP;
 }

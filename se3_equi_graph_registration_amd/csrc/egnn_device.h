@@ -18,16 +18,43 @@ __device__ __forceinline__ float row_dot(const float* __restrict__ wrow, const f
     return acc;
 }
 
-// per-node projections for a layer: Pr = W1[:, 0:F] h ; Pc = W1[:, F:2F] h + b1
+// ---- LDS-resident transposed weights for the node kernels --------------------------------
+// A lane owns one OUTPUT feature f and needs row f of W: read straight from global that is a
+// 64-way uncoalesced access.  Each workgroup therefore stages W^T once (WT[i][f], row stride
+// ROWS+1 -> conflict-free for the staging writes and for the per-lane reads) and every node
+// iteration reads it from LDS.
+template <int ROWS>
+__device__ __forceinline__ void stage_T(float* dst, const float* __restrict__ src, int cols, int ld) {
+    for (int t = threadIdx.x; t < ROWS * cols; t += 256) {
+        const int o = t / cols, i = t - o * cols;
+        dst[i * (ROWS + 1) + o] = src[(size_t)o * ld + i];
+    }
+}
+// W1[:, c0:c0+F] of a layer (head-interleaved rows) transposed
 template <int F, int H, int A>
-__device__ __forceinline__ void project_pre(const float* __restrict__ lw, const float* hv, int f,
-                                            float* __restrict__ prow) {
+__device__ __forceinline__ void stage_w1_T(float* dst, const float* __restrict__ lw, int c0) {
+    using LL = LP<F, H, A>;
+    for (int t = threadIdx.x; t < F * F; t += 256) {
+        const int o = t / F, i = t - o * F;
+        dst[i * (F + 1) + o] = lw[LL::w1_off(o, c0 + i)];
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ float col_dot(const float* WT, int f, const float* v, int n) {
+    float acc = 0.0f;
+    for (int i = 0; i < n; ++i) acc = fmaf(WT[i * (ROWS + 1) + f], v[i], acc);
+    return acc;
+}
+
+// per-node projections for a layer: Pr = W1[:, 0:F] h ; Pc = W1[:, F:2F] h + b1  (weights in LDS)
+template <int F, int H, int A>
+__device__ __forceinline__ void project_pre(const float* __restrict__ lw, const float* WaT, const float* WbT,
+                                            const float* hv, int f, float* __restrict__ prow) {
     using LL = LP<F, H, A>;
     constexpr int FP = Geom<F>::FP;
     if (f < F) {
-        const float* w = lw + LL::w1_off(f, 0);
-        prow[f] = row_dot(w, hv, F);
-        prow[FP + f] = lw[LL::b1_off(f)] + row_dot(w + F, hv, F);
+        prow[f] = col_dot<F>(WaT, f, hv, F);
+        prow[FP + f] = lw[LL::b1_off(f)] + col_dot<F>(WbT, f, hv, F);
     }
 }
 

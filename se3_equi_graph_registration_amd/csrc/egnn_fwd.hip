@@ -30,7 +30,13 @@ __global__ __launch_bounds__(256) void embed_in_kernel(const float* __restrict__
     constexpr int FP = Geom<F>::FP, G = Geom<F>::G, NS = Geom<F>::NS, PS = Geom<F>::PS;
     __shared__ float vin[NS][64];
     __shared__ float hv[NS][FP];
+    __shared__ float WinT[64 * (F + 1)];
+    __shared__ float WaT[F * (F + 1)];
+    __shared__ float WbT[F * (F + 1)];
     const int slot = threadIdx.x / G, f = threadIdx.x % G;
+    stage_T<F>(WinT, params + w_in, in_nf, in_nf);
+    stage_w1_T<F, H, A>(WaT, params + layer0, 0);
+    stage_w1_T<F, H, A>(WbT, params + layer0, F);
     const int groups = (n_nodes + NS - 1) / NS;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int j = grp * NS + slot;
@@ -42,12 +48,12 @@ __global__ __launch_bounds__(256) void embed_in_kernel(const float* __restrict__
         }
         __syncthreads();
         if (live && f < F) {
-            const float v = params[b_in + f] + row_dot(params + w_in + f * in_nf, vin[slot], in_nf);
+            const float v = params[b_in + f] + col_dot<F>(WinT, f, vin[slot], in_nf);
             h0[(size_t)j * FP + f] = v;
             hv[slot][f] = v;
         }
         __syncthreads();
-        if (live) project_pre<F, H, A>(params + layer0, hv[slot], f, P + (size_t)j * PS);
+        if (live) project_pre<F, H, A>(params + layer0, WaT, WbT, hv[slot], f, P + (size_t)j * PS);
     }
 }
 
@@ -101,7 +107,22 @@ __global__ __launch_bounds__(256) void node_fwd_kernel(
     __shared__ float vin[NS][2 * FP];
     __shared__ float hid[NS][FP];
     __shared__ float hnew[NS][FP];
+    __shared__ float W4T[2 * F * (F + 1)];
+    __shared__ float W5T[F * (F + 1)];
+    __shared__ float WaT[64 * (F + 1) > F * 65 ? 64 * (F + 1) : F * 65];   // next layer's W_src^T, or W_out^T [F][out_nf+1 <= 65]
+    __shared__ float WbT[F * (F + 1)];
     const int slot = threadIdx.x / G, f = threadIdx.x % G;
+    stage_T<F>(W4T, lw + LL::w4, 2 * F, 2 * F);
+    stage_T<F>(W5T, lw + LL::w5, F, F);
+    if (next_lw) {
+        stage_w1_T<F, H, A>(WaT, next_lw, 0);
+        stage_w1_T<F, H, A>(WbT, next_lw, F);
+    } else {
+        for (int t = threadIdx.x; t < out_nf * F; t += 256) {       // W_out^T: [i][o], row stride 65
+            const int o = t / F, i = t - o * F;
+            WaT[i * 65 + o] = w_out[t];
+        }
+    }
     const int groups = (n_nodes + NS - 1) / NS;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int j = grp * NS + slot;
@@ -126,20 +147,23 @@ __global__ __launch_bounds__(256) void node_fwd_kernel(
             if (agg_save) agg_save[(size_t)j * FP + f] = agg;
         }
         __syncthreads();
-        if (act) hid[slot][f] = silu(lw[LL::b4 + f] + row_dot(lw + LL::w4 + f * 2 * F, vin[slot], 2 * F));
+        if (act) hid[slot][f] = silu(lw[LL::b4 + f] + col_dot<F>(W4T, f, vin[slot], 2 * F));
         __syncthreads();
         if (act) {
-            const float hn = hj + lw[LL::b5 + f] + row_dot(lw + LL::w5 + f * F, hid[slot], F);   // :257-259
+            const float hn = hj + lw[LL::b5 + f] + col_dot<F>(W5T, f, hid[slot], F);   // :257-259
             h_next[(size_t)j * FP + f] = hn;
             hnew[slot][f] = hn;
         }
         __syncthreads();
         if (live) {
             if (next_lw) {
-                project_pre<F, H, A>(next_lw, hnew[slot], f, P + (size_t)j * PS);
+                project_pre<F, H, A>(next_lw, WaT, WbT, hnew[slot], f, P + (size_t)j * PS);
             } else {
-                for (int o = f; o < out_nf; o += G)
-                    h_out[(size_t)j * out_nf + o] = b_out[o] + row_dot(w_out + o * F, hnew[slot], F);   // :337
+                for (int o = f; o < out_nf; o += G) {
+                    float a = b_out[o];
+                    for (int i = 0; i < F; ++i) a = fmaf(WaT[i * 65 + o], hnew[slot][i], a);
+                    h_out[(size_t)j * out_nf + o] = a;                                                    // :337
+                }
             }
         }
     }
@@ -162,6 +186,41 @@ static inline int64_t work_floats(int F, int64_t N, int64_t E) {
     const int FP = fpad(F);
     // P | m | trans | ping-pong h (2) | ping-pong x (2)
     return N * 2 * FP + E * FP + E * 4 + 2 * N * FP + 2 * N * 3 + 64;
+}
+
+// measurement hook: average duration of the layer-0 edge kernel, HIP events on `s`
+template <int F, int H, int A>
+static int time_edge_fwd_impl(const equigspr_egnn_config* cfg, const float* params, const equigspr_graph* g,
+                              const float* h_in, const float* x_in, const float* edge_attr, float* work, int iters,
+                              float* ms_out, hipStream_t s) {
+    const ModelLayout ML = make_model_layout(cfg->in_nf, F, cfg->out_nf, A, cfg->n_layers, H);
+    const int N = g->n_nodes, E = g->n_edges;
+    constexpr int FP = Geom<F>::FP, NS = Geom<F>::NS;
+    float* P = work;
+    float* m = P + (size_t)N * 2 * FP;
+    float* trans = m + (size_t)E * FP;
+    float* pp_h = trans + (size_t)E * 4;
+    float* pp_x = pp_h + (size_t)2 * N * FP;
+    const int node_groups = ceil_div(N, NS);
+    hipLaunchKernelGGL((embed_in_kernel<F, H, A>), dim3(node_groups < 2048 ? node_groups : 2048), dim3(256), 0, s, params,
+                       cfg->in_nf, ML.w_in, ML.b_in, ML.layer0, h_in, x_in, N, pp_h, pp_x, P);
+    const float* lw = params + ML.layer0;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((edge_fwd_kernel<F, H, A>), dim3(ceil_div(E, 256)), dim3(256), 0, s, lw, g->row, g->col, edge_attr,
+                       pp_x, P, E, m, trans);      // warm
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i)
+        hipLaunchKernelGGL((edge_fwd_kernel<F, H, A>), dim3(ceil_div(E, 256)), dim3(256), 0, s, lw, g->row, g->col,
+                           edge_attr, pp_x, P, E, m, trans);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_out = ms / iters;
+    EQ_CHECK_LAUNCH("time_edge_fwd");
+    return 0;
 }
 
 template <int F, int H, int A>
@@ -234,5 +293,21 @@ extern "C" int equigspr_egnn_forward(const equigspr_egnn_config* cfg, const floa
     EQ_DISPATCH(33, 1, 1) EQ_DISPATCH(33, 1, 0)
 #undef EQ_DISPATCH
     set_error("egnn_forward: no kernel for F=%d H=%d A=%d", F, H, A);
+    return EQUIGSPR_ENOTSUP;
+}
+
+extern "C" int equigspr_time_edge_fwd(const equigspr_egnn_config* cfg, const float* params, const equigspr_graph* g,
+                                      const float* h_in, const float* x_in, const float* edge_attr, float* work,
+                                      int32_t iters, float* ms_out_host, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(config_supported(cfg) && params && g && h_in && x_in && work && ms_out_host && iters >= 1 && g->n_edges > 0,
+                 EQUIGSPR_EINVAL, "time_edge_fwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int F = cfg->hidden_nf, H = cfg->num_heads, A = cfg->in_edge_nf;
+#define EQ_DISPATCH(FF, HH, AA) \
+    if (F == FF && H == HH && A == AA) return time_edge_fwd_impl<FF, HH, AA>(cfg, params, g, h_in, x_in, edge_attr, work, iters, ms_out_host, s);
+    EQ_DISPATCH(32, 1, 1) EQ_DISPATCH(32, 1, 0) EQ_DISPATCH(32, 4, 1) EQ_DISPATCH(32, 4, 0)
+    EQ_DISPATCH(33, 1, 1) EQ_DISPATCH(33, 1, 0)
+#undef EQ_DISPATCH
     return EQUIGSPR_ENOTSUP;
 }

@@ -171,19 +171,26 @@ __global__ void csr_fill_kernel(const int* __restrict__ key, int n_edges, int* _
     if (e < n_edges) perm[atomicAdd(&cursor[key[e]], 1)] = e;
 }
 
-// each node's segment back into ascending edge order (atomics filled it in arbitrary order)
-__global__ void csr_sort_kernel(const int* __restrict__ ptr, int n_nodes, int* __restrict__ perm) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_nodes) return;
+// each node's segment back into ascending edge order (atomics filled it in arbitrary order):
+// one wave per node, <= 64 entries sorted with a wave bitonic network, longer segments serially.
+__global__ __launch_bounds__(256) void csr_sort_kernel(const int* __restrict__ ptr, int n_nodes, int* __restrict__ perm) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n_nodes) return;                     // wave-uniform
     const int lo = ptr[j], hi = ptr[j + 1];
-    for (int a = lo + 1; a < hi; ++a) {
-        const int v = perm[a];
-        int b = a - 1;
-        while (b >= lo && perm[b] > v) {
-            perm[b + 1] = perm[b];
-            --b;
+    const int len = hi - lo;
+    if (len <= 1) return;
+    if (len <= 64) {
+        u64 key = lane < len ? (u64)(unsigned)perm[lo + lane] : ~0ull;
+        key = wave_bitonic_sort(key, lane);
+        if (lane < len) perm[lo + lane] = (int)(unsigned)key;
+    } else if (lane == 0) {
+        for (int a = lo + 1; a < hi; ++a) {
+            const int v = perm[a];
+            int b = a - 1;
+            while (b >= lo && perm[b] > v) { perm[b + 1] = perm[b]; --b; }
+            perm[b + 1] = v;
         }
-        perm[b + 1] = v;
     }
 }
 
@@ -236,7 +243,7 @@ extern "C" int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n
     hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, scratch, n_nodes, ptr);
     if (n_edges > 0) {
         hipLaunchKernelGGL(csr_fill_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, key, n_edges, scratch, perm);
-        hipLaunchKernelGGL(csr_sort_kernel, dim3(ceil_div(n_nodes, 256)), dim3(256), 0, s, ptr, n_nodes, perm);
+        hipLaunchKernelGGL(csr_sort_kernel, dim3(ceil_div(n_nodes, 4)), dim3(256), 0, s, ptr, n_nodes, perm);
     }
     EQ_CHECK_LAUNCH("build_csr");
     return 0;
