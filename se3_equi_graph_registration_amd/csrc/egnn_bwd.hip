@@ -14,11 +14,10 @@
 //              edge id, atomic-free) -> G_h, G_x of layer l; dW_src, dW_tgt, db1 partials.
 // Every workgroup writes its partial weight gradients to a private slab; a reduce kernel sums
 // the slabs in fixed order into the flat gradient block (+=): bitwise reproducible, no atomics.
-#include "egnn_device.h"
+#include "egnn_mfma.h"
 
 namespace eq {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kNodeBwdBlocks = 256;   // slab count of the node-level kernels
 constexpr int kEdgeBwdBlocks = 1024;  // max slab count of the edge kernel
@@ -287,17 +286,15 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
         __syncthreads();
         if (live) {
             const int rlo = rptr[j], rhi = rptr[j + 1], clo = cptr[j], chi = cptr[j + 1];
+            float gx = (f < 3) ? Gx[(size_t)j * 4 + f] : 0.0f;
+            segment_sum<G, true>(rperm, rlo, rhi, dt1, FP, gxr, f, f < F, dpr, gx);
+            segment_sum<G, true>(cperm, clo, chi, dt1, FP, gxc, f, f < F, dpc, gx);
             if (f < F) {
-                for (int a = rlo; a < rhi; ++a) dpr += dt1[(size_t)rperm[a] * FP + f];
-                for (int a = clo; a < chi; ++a) dpc += dt1[(size_t)cperm[a] * FP + f];
                 hv[slot][f] = h[(size_t)j * FP + f];
                 prv[slot][f] = dpr;
                 pcv[slot][f] = dpc;
             }
             if (f < 3) {
-                float gx = Gx[(size_t)j * 4 + f];
-                for (int a = rlo; a < rhi; ++a) gx += gxr[(size_t)rperm[a] * 4 + f];
-                for (int a = clo; a < chi; ++a) gx += gxc[(size_t)cperm[a] * 4 + f];
                 Gx_new[(size_t)j * 4 + f] = gx;
                 if (gx_out3) gx_out3[(size_t)j * 3 + f] = gx;
             }
@@ -333,12 +330,12 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
 // One pass over a wave-private pair of LDS tiles X[64][LD], Y[64][LD] (row = edge of the chunk):
 //   acc[rb][cb] += X^T Y (32x32 blocks, K = 64 edges, fp32 MFMA), csx += column sums of X,
 //   csy += column sums of Y.  Lane l: column (l & 31), edge parity (l >> 5).
-template <int NB, int NBY, int LD, bool kMfma>
+template <int NB, int NBY, int LD, bool kMfma, int KE = 64>
 __device__ __forceinline__ void tile_pass(const float* X, const float* Y, f32x16 (&acc)[NB][NBY], float (&csx)[NB],
                                           float (&csy)[NBY], int lane) {
     const int f = lane & 31, hh = lane >> 5;
 #pragma unroll 2
-    for (int s = 0; s < 32; ++s) {
+    for (int s = 0; s < KE / 2; ++s) {
         const int e = 2 * s + hh;
         float a[NB], b[NBY];
 #pragma unroll
@@ -582,6 +579,258 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------
+// edge backward, MFMA formulation (hidden_nf == 32): one wave per 32-edge tile (egnn_mfma.h).
+// Forward recompute and the three transposed products (W6^T dq, W2^T du, Wgeo^T dt1) run on
+// the matrix cores with register-resident weights; only the weight-gradient outer products
+// (sum over edges) go through wave-private LDS tiles, as in the generic kernel.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_half_row(float* tile_row, int h, const float (&v)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(tile_row + 8 * q + 4 * h) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+template <int H, int A>
+__global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restrict__ lw, const int* __restrict__ row,
+                                                            const int* __restrict__ col, const float* __restrict__ edge_attr,
+                                                            const float* __restrict__ x, const float* __restrict__ P,
+                                                            const float* __restrict__ dagg, const float* __restrict__ Gx,
+                                                            int n_edges, float* __restrict__ dt1_out,
+                                                            float* __restrict__ gxr_out, float* __restrict__ gxc_out,
+                                                            float* __restrict__ slab) {
+    constexpr int F = 32, FP = 32, PS = 64, LD = 36;
+    using SB = Slabs<F>;
+    __shared__ __attribute__((aligned(16))) float tiles[4 * 2 * 32 * LD];
+    __shared__ float wsm[TileWeightsLds::size];
+    const int lane = threadIdx.x & 63, el = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
+    float* X = tiles + (size_t)wv * 2 * 32 * LD;
+    float* Y = X + 32 * LD;
+    stage_tile_weights<H, A>(wsm, lw);
+    __syncthreads();
+    TileWeights<H, A> W;
+    TileWeightsBwd<H, A> WB;
+    W.load(wsm, lane);
+    WB.load(wsm, lane);
+
+    f32x16 acc6[1][1], acc2[1][1], accg[1][1];
+    float cs_b6[1] = {0.0f}, cs_b2[1] = {0.0f}, cs_gam[1] = {0.0f}, cs_bet[1] = {0.0f}, cs_w7[1] = {0.0f}, cs_scr[1] = {0.0f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc6[0][0][r] = 0.0f; acc2[0][0][r] = 0.0f; accg[0][0][r] = 0.0f; }
+
+    const int n_tiles = (n_edges + 31) / 32;
+    for (int tile = wave; tile < n_tiles; tile += n_waves) {
+        const int e_raw = tile * 32 + el;
+        const bool valid = e_raw < n_edges;
+        const int e = valid ? e_raw : n_edges - 1;
+        const float z = valid ? 1.0f : 0.0f;
+        const int r = row[e], c = col[e];
+        float xr[3], xc[3], gxv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { xr[i] = x[(size_t)r * 3 + i]; xc[i] = x[(size_t)c * 3 + i]; gxv[i] = Gx[(size_t)r * 4 + i]; }
+        EdgeGeo eg;
+        edge_geometry(xr, xc, eg);
+        const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
+        TileFwd o;
+        tile_forward<H, A>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
+
+        // ---- coord head backward
+        const float ds = dot3(eg.d, gxv) * z;
+        float gd[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gd[i] = o.s * gxv[i];
+        float dq[16], pds[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float sg = 1.0f / (1.0f + expf(-o.q[k]));
+            pds[k] = o.q[k] * sg * ds;
+            dq[k] = W.w7[k] * ds * (sg * (1.0f + o.q[k] * (1.0f - sg)));
+        }
+        stage_half_row(X + el * LD, h, dq);
+        stage_half_row(Y + el * LD, h, o.m);
+        __builtin_amdgcn_wave_barrier();
+        tile_pass<1, 1, LD, true, 32>(X, Y, acc6, cs_b6, cs_scr, lane);           // dW6 += dq^T m ; db6 += sum dq
+        __builtin_amdgcn_wave_barrier();
+        // ---- dm = dagg[row] + W6^T dq
+        float dm[16];
+        {
+            float da[16];
+            load_half_row(dagg + (size_t)r * FP, h, da);
+            f32x16 a;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = da[k] * z;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(WB.w6t[s], dq[s], a, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dm[k] = a[k];
+        }
+        {
+            float t[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t[k] = dm[k] * o.xhat[k];
+            stage_half_row(X + el * LD, h, pds);
+            stage_half_row(Y + el * LD, h, t);
+        }
+        __builtin_amdgcn_wave_barrier();
+        tile_pass<1, 1, LD, false, 32>(X, Y, acc6, cs_w7, cs_gam, lane);          // dw7, dgamma (column sums only)
+        __builtin_amdgcn_wave_barrier();
+        // ---- LayerNorm backward
+        float du[16];
+        {
+            float m1 = 0.0f, m2 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                du[k] = dm[k] * W.gam[k];
+                m1 += du[k];
+                m2 = fmaf(du[k], o.xhat[k], m2);
+            }
+            m1 += xhalf(m1);
+            m2 += xhalf(m2);
+            m1 *= (1.0f / 32.0f);
+            m2 *= (1.0f / 32.0f);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) du[k] = o.rstd * (du[k] - m1 - o.xhat[k] * m2);
+        }
+        float sg1[16];
+        {
+            float g1[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float sg = 1.0f / (1.0f + expf(-o.t1[k]));
+                g1[k] = o.t1[k] * sg;
+                sg1[k] = sg * (1.0f + o.t1[k] * (1.0f - sg));
+            }
+            stage_half_row(X + el * LD, h, du);
+            stage_half_row(Y + el * LD, h, g1);
+        }
+        __builtin_amdgcn_wave_barrier();
+        tile_pass<1, 1, LD, true, 32>(X, Y, acc2, cs_b2, cs_scr, lane);           // dW2 += du^T g1 ; db2 += sum du
+        __builtin_amdgcn_wave_barrier();
+        // ---- dt1 = (W2^T du) * silu'(t1)
+        float dt1[16];
+        {
+            f32x16 a;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(WB.w2t[s], du[s], a, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dt1[k] = a[k] * sg1[k];
+        }
+        stage_half_row(X + el * LD, h, dt1);
+        if (h == 0) {
+            float ga[16];
+#pragma unroll
+            for (int k = 0; k < kGeo; ++k) ga[k] = eg.g[k];
+            ga[12] = attr; ga[13] = 0.0f; ga[14] = 0.0f; ga[15] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(Y + el * LD + 4 * q) = make_float4(ga[4 * q], ga[4 * q + 1], ga[4 * q + 2], ga[4 * q + 3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        tile_pass<1, 1, LD, true, 32>(X, Y, accg, cs_scr, cs_scr, lane);          // dWgeo|dwattr += dt1^T [geo, attr]
+        __builtin_amdgcn_wave_barrier();
+        stage_half_row(X + el * LD, h, dm);
+        __builtin_amdgcn_wave_barrier();
+        tile_pass<1, 1, LD, false, 32>(X, Y, accg, cs_bet, cs_scr, lane);         // dbeta = sum dm
+        __builtin_amdgcn_wave_barrier();
+        // ---- dgeo = Wgeo^T dt1 (rows 0..11 of a 32-row product), then the geometry backward
+        float gg[kGeo];
+        {
+            f32x16 a;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(WB.wgt[s], dt1[s], a, 0, 0, 0);
+            // lane half h holds geo rows fidx(k,h): h=0 -> 0..3 (k 0..3), 8..11 (k 4..7); h=1 -> 4..7 (k 0..3)
+            float mine[8], other[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { mine[k] = a[k]; other[k] = xhalf(mine[k]); }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                gg[k] = h ? other[k] : mine[k];
+                gg[4 + k] = h ? mine[k] : other[k];
+                gg[8 + k] = h ? other[4 + k] : mine[4 + k];
+            }
+        }
+        float gxr[3], gxc[3];
+        edge_geometry_backward(xr, xc, eg, gg, gd, gxr, gxc);
+        if (valid) {
+            store_half_row(dt1_out + (size_t)e * FP, h, dt1);
+            if (h == 0) {
+                reinterpret_cast<float4*>(gxr_out)[e] = make_float4(gxr[0], gxr[1], gxr[2], 0.0f);
+                reinterpret_cast<float4*>(gxc_out)[e] = make_float4(gxc[0], gxc[1], gxc[2], 0.0f);
+            }
+        }
+    }
+
+    // ---- block reduction of the 4 waves' partials into one slab (fixed order) ----------------
+    float* sl = tiles;
+    const int f = lane & 31, hh = lane >> 5;
+    cs_b6[0] += xhalf(cs_b6[0]);
+    cs_b2[0] += xhalf(cs_b2[0]);
+    cs_gam[0] += xhalf(cs_gam[0]);
+    cs_bet[0] += xhalf(cs_bet[0]);
+    cs_w7[0] += xhalf(cs_w7[0]);
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wv == w) {
+            const bool first = (w == 0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int orow = (k & 3) + 8 * (k >> 2) + 4 * hh;
+                const int i2 = SB::e_w2 + orow * F + f, i6 = SB::e_w6 + orow * F + f;
+                sl[i2] = (first ? 0.0f : sl[i2]) + acc2[0][0][k];
+                sl[i6] = (first ? 0.0f : sl[i6]) + acc6[0][0][k];
+                if (f < 16) {
+                    const int ig = SB::e_geo + orow * 16 + f;
+                    sl[ig] = (first ? 0.0f : sl[ig]) + accg[0][0][k];
+                }
+            }
+            if (hh == 0) {
+                sl[SB::e_b2 + f] = (first ? 0.0f : sl[SB::e_b2 + f]) + cs_b2[0];
+                sl[SB::e_b6 + f] = (first ? 0.0f : sl[SB::e_b6 + f]) + cs_b6[0];
+                sl[SB::e_gam + f] = (first ? 0.0f : sl[SB::e_gam + f]) + cs_gam[0];
+                sl[SB::e_bet + f] = (first ? 0.0f : sl[SB::e_bet + f]) + cs_bet[0];
+                sl[SB::e_w7 + f] = (first ? 0.0f : sl[SB::e_w7 + f]) + cs_w7[0];
+            }
+        }
+    }
+    slab_flush(sl, slab, SB::edge);
+}
+
+template <int F, int H, int A>
+static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
+                           const float* dagg, const float* Gx, float* dt1, float* gxr, float* gxc, float* slab,
+                           hipStream_t s, int* n_slabs) {
+    const int E = g->n_edges;
+    if constexpr (F == 32) {
+        const int tiles = ceil_div(E, 32);
+        int blocks = ceil_div(tiles, 4);
+        blocks = blocks < 1 ? 1 : (blocks > kEdgeBwdBlocks ? kEdgeBwdBlocks : blocks);
+        hipLaunchKernelGGL((edge_bwd_mfma_kernel<H, A>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
+                           dagg, Gx, E, dt1, gxr, gxc, slab);
+        *n_slabs = blocks;
+    } else {
+        constexpr int NB = (F + 31) / 32, LD = NB * 32 + 1;
+        const int chunks = ceil_div(E, 256);
+        const int egrid = chunks < kEdgeBwdBlocks ? chunks : kEdgeBwdBlocks;
+        const size_t edge_smem = sizeof(float) * (size_t)4 * 2 * 64 * LD;
+        static bool attr_set = false;      // once per instantiation (first call happens outside any graph capture)
+        if (!attr_set) {
+            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_bwd_kernel<F, H, A>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)edge_smem);
+            if (err != hipSuccess) { set_error("hipFuncSetAttribute(edge_bwd): %s", hipGetErrorString(err)); return (int)err; }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((edge_bwd_kernel<F, H, A>), dim3(egrid), dim3(256), edge_smem, s, lw, g->row, g->col, edge_attr, x,
+                           P, dagg, Gx, E, dt1, gxr, gxc, slab);
+        *n_slabs = egrid;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // slab reduction into the flat gradient block (+=), fixed order
 // ---------------------------------------------------------------------------------------
 // 256-thread block = 32 consecutive gradient entries x 8 slab partitions; partition p sums slabs
@@ -696,16 +945,7 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
     const float* aggs = xs + (size_t)(L + 1) * N * 3;
     const int groups = ceil_div(N, NS);
     const int ngrid = groups < kNodeBwdBlocks ? groups : kNodeBwdBlocks;
-    const int chunks = ceil_div(E, 256);
-    const int egrid = chunks < kEdgeBwdBlocks ? chunks : kEdgeBwdBlocks;
-    const size_t edge_smem = sizeof(float) * (size_t)4 * 2 * 64 * LD;
-    static bool attr_set = false;      // once per instantiation (first call happens outside any graph capture)
-    if (!attr_set) {
-        hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_bwd_kernel<F, H, A>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)edge_smem);
-        if (err != hipSuccess) { set_error("hipFuncSetAttribute(edge_bwd): %s", hipGetErrorString(err)); return (int)err; }
-        attr_set = true;
-    }
+    int egrid = 0;
     int cur = 0;
     float* Gh = work + B.Gh[cur];
     float* Gx = work + B.Gx[cur];
@@ -720,10 +960,11 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
         const float* x_l = xs + (size_t)l * N * 3;
         hipLaunchKernelGGL((node_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, work + B.Gh[cur], h_l,
                            aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg, work + B.P, work + B.node_slab);
-        if (E > 0)
-            hipLaunchKernelGGL((edge_bwd_kernel<F, H, A>), dim3(egrid), dim3(256), edge_smem, s, lw, g->row, g->col,
-                               edge_attr, x_l, work + B.P, work + B.dagg, work + B.Gx[cur], E, work + B.dt1,
-                               work + B.gxr, work + B.gxc, work + B.edge_slab);
+        if (E > 0) {
+            const int rc = launch_edge_bwd<F, H, A>(lw, g, edge_attr, x_l, work + B.P, work + B.dagg, work + B.Gx[cur],
+                                                    work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab, s, &egrid);
+            if (rc) return rc;
+        }
         const int nxt = cur ^ 1;
         hipLaunchKernelGGL((gather_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, g->rptr, g->rperm, g->cptr,
                            g->cperm, work + B.dt1, work + B.gxr, work + B.gxc, work + B.dh_part, work + B.Gx[cur], h_l, N,
@@ -758,21 +999,15 @@ static int time_edge_bwd_impl(const equigspr_egnn_config* cfg, const float* para
     const float* lw = params + ML.layer0 + (size_t)l * ML.layer_size;
     const int groups = ceil_div(N, NS);
     const int ngrid = groups < kNodeBwdBlocks ? groups : kNodeBwdBlocks;
-    const int chunks = ceil_div(E, 256);
-    const int egrid = chunks < kEdgeBwdBlocks ? chunks : kEdgeBwdBlocks;
-    const size_t edge_smem = sizeof(float) * (size_t)4 * 2 * 64 * LD;
-    hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_bwd_kernel<F, H, A>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)edge_smem);
-    if (err != hipSuccess) { set_error("hipFuncSetAttribute(edge_bwd): %s", hipGetErrorString(err)); return (int)err; }
+    int egrid = 0;
     // synthetic upstream gradient: G_h = h_L (any finite data), G_x = x_{L-1} padded
     (void)hipMemsetAsync(work + B.Gx[0], 0, sizeof(float) * (size_t)N * 4, s);
     hipLaunchKernelGGL((node_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, hs + (size_t)L * N * FP,
                        hs + (size_t)l * N * FP, aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg, work + B.P,
                        work + B.node_slab);
     auto launch = [&]() {
-        hipLaunchKernelGGL((edge_bwd_kernel<F, H, A>), dim3(egrid), dim3(256), edge_smem, s, lw, g->row, g->col, edge_attr,
-                           xs + (size_t)l * N * 3, work + B.P, work + B.dagg, work + B.Gx[0], E, work + B.dt1, work + B.gxr,
-                           work + B.gxc, work + B.edge_slab);
+        (void)launch_edge_bwd<F, H, A>(lw, g, edge_attr, xs + (size_t)l * N * 3, work + B.P, work + B.dagg, work + B.Gx[0],
+                                       work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab, s, &egrid);
     };
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);

@@ -18,6 +18,36 @@ __device__ __forceinline__ float row_dot(const float* __restrict__ wrow, const f
     return acc;
 }
 
+// ---- latency-tolerant segment sums --------------------------------------------------------
+// acc_f += sum over a in [lo,hi) of data[perm[a]][f] (and, for lanes f < 3, of data3[perm[a]][f]),
+// strictly in ascending a (the CPU scatter_add_ order).  The G lanes of a node first fetch up to
+// G indices with ONE coalesced load, broadcast them with shuffles, and keep 8 independent row
+// loads in flight per lane before the (ordered) adds -- instead of a dependent index->row chain.
+template <int G, bool kHas3>
+__device__ __forceinline__ void segment_sum(const int* __restrict__ perm, int lo, int hi, const float* __restrict__ data,
+                                            int stride, const float* __restrict__ data3, int f, bool f_active,
+                                            float& acc, float& acc3) {
+    for (int base = lo; base < hi; base += G) {
+        const int cnt = min(G, hi - base);
+        const int my = (f < cnt) ? perm[base + f] : 0;
+        for (int a0 = 0; a0 < cnt; a0 += 8) {
+            float v[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = __shfl(my, (a0 + u) & (G - 1), G);
+                const bool in = (a0 + u) < cnt;
+                v[u] = (in && f_active) ? data[(size_t)e * stride + f] : 0.0f;
+                if (kHas3) w[u] = (in && f < 3) ? data3[(size_t)e * 4 + f] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc += v[u];
+                if (kHas3) acc3 += w[u];
+            }
+        }
+    }
+}
+
 // ---- LDS-resident transposed weights for the node kernels --------------------------------
 // A lane owns one OUTPUT feature f and needs row f of W: read straight from global that is a
 // 64-way uncoalesced access.  Each workgroup therefore stages W^T once (WT[i][f], row stride

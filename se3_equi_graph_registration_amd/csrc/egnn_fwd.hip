@@ -14,7 +14,7 @@
 //                 the CPU scatter_add_ order of unsorted_segment_sum :343-348), node MLP with
 //                 residual (:252-260), coordinate update (:262-268), and the NEXT layer's
 //                 per-node projections (or embedding_out after the last layer).
-#include "egnn_device.h"
+#include "egnn_mfma.h"
 
 namespace eq {
 
@@ -91,6 +91,61 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------
+// edge kernel, MFMA formulation (hidden_nf == 32): one wave per 32-edge tile, weights in VGPRs
+// ---------------------------------------------------------------------------------------
+template <int H, int A>
+__global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restrict__ lw, const int* __restrict__ row,
+                                                            const int* __restrict__ col, const float* __restrict__ edge_attr,
+                                                            const float* __restrict__ x, const float* __restrict__ P,
+                                                            int n_edges, float* __restrict__ m_out,
+                                                            float* __restrict__ trans_out) {
+    constexpr int FP = 32, PS = 64;
+    const int lane = threadIdx.x & 63, el = lane & 31, h = lane >> 5;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    __shared__ float wsm[TileWeightsLds::size];
+    stage_tile_weights<H, A>(wsm, lw);
+    __syncthreads();
+    TileWeights<H, A> W;
+    W.load(wsm, lane);
+    const int tiles = (n_edges + 31) / 32;
+    for (int tile = wave; tile < tiles; tile += n_waves) {
+        const int e_raw = tile * 32 + el;
+        const bool valid = e_raw < n_edges;
+        const int e = valid ? e_raw : n_edges - 1;
+        const int r = row[e], c = col[e];
+        float xr[3], xc[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { xr[i] = x[(size_t)r * 3 + i]; xc[i] = x[(size_t)c * 3 + i]; }
+        EdgeGeo eg;
+        edge_geometry(xr, xc, eg);
+        const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
+        TileFwd o;
+        tile_forward<H, A>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
+        if (valid) {
+            store_half_row(m_out + (size_t)e * FP, h, o.m);
+            if (h == 0)
+                reinterpret_cast<float4*>(trans_out)[e] = make_float4(eg.d[0] * o.s, eg.d[1] * o.s, eg.d[2] * o.s, 0.0f);   // :264
+        }
+    }
+}
+
+template <int F, int H, int A>
+static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
+                            float* m, float* trans, hipStream_t s) {
+    const int E = g->n_edges;
+    if constexpr (F == 32) {
+        const int tiles = ceil_div(E, 32);
+        int blocks = ceil_div(tiles, 4);          // one 32-edge tile per wave: latency is hidden across waves
+        blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+        hipLaunchKernelGGL((edge_fwd_mfma_kernel<H, A>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
+                           E, m, trans);
+    } else {
+        hipLaunchKernelGGL((edge_fwd_kernel<F, H, A>), dim3(ceil_div(E, 256)), dim3(256), 0, s, lw, g->row, g->col,
+                           edge_attr, x, P, E, m, trans);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // node kernel
 // ---------------------------------------------------------------------------------------
 template <int F, int H, int A>
@@ -131,14 +186,9 @@ __global__ __launch_bounds__(256) void node_fwd_kernel(
         float hj = 0.0f, agg = 0.0f, xagg = 0.0f;
         if (live) {
             const int lo = rptr[j], hi = rptr[j + 1];
-            if (f < F) {
-                hj = h[(size_t)j * FP + f];
-                for (int a = lo; a < hi; ++a) agg += m_in[(size_t)rperm[a] * FP + f];      // ascending edge id
-            }
-            if (f < 3) {
-                for (int a = lo; a < hi; ++a) xagg += trans_in[(size_t)rperm[a] * 4 + f];
-                x_next[(size_t)j * 3 + f] = x[(size_t)j * 3 + f] + xagg;                    // :267
-            }
+            if (f < F) hj = h[(size_t)j * FP + f];
+            segment_sum<G, true>(rperm, lo, hi, m_in, FP, trans_in, f, f < F, agg, xagg);   // ascending edge id
+            if (f < 3) x_next[(size_t)j * 3 + f] = x[(size_t)j * 3 + f] + xagg;              // :267
         }
         __syncthreads();
         if (act) {
@@ -207,12 +257,9 @@ static int time_edge_fwd_impl(const equigspr_egnn_config* cfg, const float* para
     const float* lw = params + ML.layer0;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    hipLaunchKernelGGL((edge_fwd_kernel<F, H, A>), dim3(ceil_div(E, 256)), dim3(256), 0, s, lw, g->row, g->col, edge_attr,
-                       pp_x, P, E, m, trans);      // warm
+    launch_edge_fwd<F, H, A>(lw, g, edge_attr, pp_x, P, m, trans, s);      // warm
     (void)hipEventRecord(e0, s);
-    for (int i = 0; i < iters; ++i)
-        hipLaunchKernelGGL((edge_fwd_kernel<F, H, A>), dim3(ceil_div(E, 256)), dim3(256), 0, s, lw, g->row, g->col,
-                           edge_attr, pp_x, P, E, m, trans);
+    for (int i = 0; i < iters; ++i) launch_edge_fwd<F, H, A>(lw, g, edge_attr, pp_x, P, m, trans, s);
     (void)hipEventRecord(e1, s);
     (void)hipEventSynchronize(e1);
     float ms = 0.0f;
@@ -249,9 +296,7 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
     for (int l = 0; l < L; ++l) {
         const float* lw = params + ML.layer0 + (size_t)l * ML.layer_size;
         const bool last = (l == L - 1);
-        if (E > 0)
-            hipLaunchKernelGGL((edge_fwd_kernel<F, H, A>), dim3(ceil_div(E, 256)), dim3(256), 0, s, lw, g->row, g->col,
-                               edge_attr, xbuf(l), P, E, m, trans);
+        if (E > 0) launch_edge_fwd<F, H, A>(lw, g, edge_attr, xbuf(l), P, m, trans, s);
         float* xn = last ? x_out : xbuf(l + 1);
         hipLaunchKernelGGL((node_fwd_kernel<F, H, A>), dim3(node_grid), dim3(256), 0, s, lw,
                            last ? nullptr : lw + ML.layer_size, params + ML.w_out, params + ML.b_out, cfg->out_nf,

@@ -1,0 +1,167 @@
+// MFMA formulation of the per-edge MLP chain (hidden_nf == 32), shared by the forward and
+// backward edge kernels.
+//
+// A wave works on a TILE of 32 edges.  Lane l = (e = l & 31, h = l >> 5) owns edge e of the tile and
+// HALF of its 32 features: register r (0..15) holds feature fidx(r,h) = (r&3) + 8*(r>>2) + 4*h.
+// That is exactly the C/D layout of v_mfma_f32_32x32x2_f32 with D[i = feature][j = edge], and
+// -- with the K index of step s mapped to feature fidx(s,h) -- register s of such a tile is
+// ALSO the B operand of step s of the next product.  So a whole chain
+//      t1 = (P_r + P_c) + Wgeo*geo -> SiLU -> W2 -> LayerNorm -> W6 -> SiLU -> w7.
+// runs as 7 + 16 + 16 MFMAs per 32 edges with the weights held in VGPRs (the A operands, loaded
+// once per wave), no LDS, no cross-lane traffic except one lane-half exchange for the LayerNorm
+// and the final dot product.  fp32 MFMA is an exact fmaf chain (guide §3), so numerics match
+// the VALU formulation.  The backward uses the transposed weights as A operands the same way.
+#pragma once
+#include "egnn_device.h"
+
+namespace eq {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ constexpr int fidx(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }   // partner lane of the other half
+
+// Per-workgroup LDS image of the layer's edge-MLP weights (filled with coalesced global reads,
+// rows padded to odd strides so the per-lane operand fetches below are bank-conflict-free).
+struct TileWeightsLds {
+    static constexpr int GS = 15;                      // Wgeo row stride: 13 used columns
+    static constexpr int WS = 33;                      // W2full / W6 row stride
+    static constexpr int o_geo = 0, o_w2 = 32 * GS, o_w6 = o_w2 + 32 * WS, o_vec = o_w6 + 32 * WS;   // vec: b2|gam|bet|b6|w7
+    static constexpr int size = o_vec + 5 * 32;
+};
+
+template <int H, int A>
+__device__ __forceinline__ void stage_tile_weights(float* sm, const float* __restrict__ lw) {
+    constexpr int F = 32;
+    using LL = LP<F, H, A>;
+    using T = TileWeightsLds;
+    constexpr int FH = F / H;
+    for (int t = threadIdx.x; t < 32 * T::GS; t += 256) {
+        const int i = t / T::GS, k = t - i * T::GS;
+        sm[T::o_geo + t] = (k < kGeo + A) ? lw[LL::w1_off(i, 2 * F + k)] : 0.0f;
+    }
+    for (int t = threadIdx.x; t < 32 * 32; t += 256) {
+        const int i = t >> 5, k = t & 31;
+        sm[T::o_w2 + i * T::WS + k] = (i / FH == k / FH) ? lw[LL::w2_off(i, k)] : 0.0f;
+        sm[T::o_w6 + i * T::WS + k] = lw[LL::w6 + t];
+    }
+    if (threadIdx.x < 32) {
+        const int k = threadIdx.x;
+        sm[T::o_vec + k] = lw[LL::b2_off(k)];
+        sm[T::o_vec + 32 + k] = lw[LL::ln_g + k];
+        sm[T::o_vec + 64 + k] = lw[LL::ln_b + k];
+        sm[T::o_vec + 96 + k] = lw[LL::b6 + k];
+        sm[T::o_vec + 128 + k] = lw[LL::w7 + k];
+    }
+}
+
+template <int H, int A>
+struct TileWeights {
+    float wg[7];                 // A operand of the geometry product: W1[i][2F + 2s+h]
+    float w2[16], w6[16];        // A operands: W2full[i][fidx(s,h)], W6[i][fidx(s,h)]
+    float b2[16], gam[16], bet[16], b6[16], w7[16];   // per-feature vectors in tile layout
+
+    __device__ __forceinline__ void load(const float* sm, int lane) {
+        using T = TileWeightsLds;
+        const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int s = 0; s < 7; ++s) wg[s] = sm[T::o_geo + i * T::GS + 2 * s + h];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = fidx(s, h);
+            w2[s] = sm[T::o_w2 + i * T::WS + k];
+            w6[s] = sm[T::o_w6 + i * T::WS + k];
+            b2[s] = sm[T::o_vec + k];
+            gam[s] = sm[T::o_vec + 32 + k];
+            bet[s] = sm[T::o_vec + 64 + k];
+            b6[s] = sm[T::o_vec + 96 + k];
+            w7[s] = sm[T::o_vec + 128 + k];
+        }
+    }
+};
+
+template <int H, int A>
+struct TileWeightsBwd {
+    float w6t[16], w2t[16], wgt[16];   // A operands of the transposed products
+
+    __device__ __forceinline__ void load(const float* sm, int lane) {
+        using T = TileWeightsLds;
+        const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = fidx(s, h);
+            w6t[s] = sm[T::o_w6 + k * T::WS + i];                              // W6^T[i][k]
+            w2t[s] = sm[T::o_w2 + k * T::WS + i];                              // W2^T[i][k]
+            wgt[s] = (i < kGeo) ? sm[T::o_geo + k * T::GS + i] : 0.0f;         // Wgeo^T[g = i][k]
+        }
+    }
+};
+
+// gather 16 of the 32 floats of a 128-byte row: features fidx(r,h), r = 0..15 (4 x 16-byte loads)
+__device__ __forceinline__ void load_half_row(const float* __restrict__ row, int h, float (&v)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(row + 8 * q + 4 * h);
+        v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+    }
+}
+__device__ __forceinline__ void store_half_row(float* __restrict__ row, int h, const float (&v)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(row + 8 * q + 4 * h) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+}
+
+// everything the backward needs from the forward of one tile
+struct TileFwd {
+    float t1[16], xhat[16], m[16], q[16];
+    float rstd, s;
+};
+
+template <int H, int A>
+__device__ __forceinline__ void tile_forward(const TileWeights<H, A>& W, const float* __restrict__ prow,
+                                             const float* __restrict__ pcrow, const EdgeGeo& eg, float attr, int h,
+                                             TileFwd& o) {
+    float pr[16], pc[16];
+    load_half_row(prow, h, pr);
+    load_half_row(pcrow, h, pc);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = pr[r] + pc[r];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        // B operand: z-geometry entry k = 2s+h of this lane's edge (12 geo values, then edge_attr)
+        const float g0 = (2 * s < kGeo) ? eg.g[(2 * s < kGeo) ? 2 * s : 0] : ((2 * s == kGeo) ? attr : 0.0f);
+        const float g1 = (2 * s + 1 < kGeo) ? eg.g[(2 * s + 1 < kGeo) ? 2 * s + 1 : 0] : ((2 * s + 1 == kGeo) ? attr : 0.0f);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W.wg[s], h ? g1 : g0, acc, 0, 0, 0);
+    }
+    f32x16 acc2, acc6;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o.t1[r] = acc[r]; acc2[r] = W.b2[r]; acc6[r] = W.b6[r]; }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w2[s], silu(o.t1[s]), acc2, 0, 0, 0);
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += acc2[r];
+    sum += xhalf(sum);
+    const float mean = sum * (1.0f / 32.0f);
+    float var = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float c = acc2[r] - mean; var = fmaf(c, c, var); }
+    var += xhalf(var);
+    var *= (1.0f / 32.0f);
+    o.rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        o.xhat[r] = (acc2[r] - mean) * o.rstd;
+        o.m[r] = fmaf(o.xhat[r], W.gam[r], W.bet[r]);
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc6 = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w6[s], o.m[s], acc6, 0, 0, 0);
+    float sp = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o.q[r] = acc6[r]; sp = fmaf(W.w7[r], silu(acc6[r]), sp); }
+    o.s = sp + xhalf(sp);
+}
+
+}  // namespace eq
