@@ -1,0 +1,123 @@
+"""CPU, world_size=2 over gloo: the data-parallel step (flat buckets, shard ranges, bucketed
+all-reduce) used by bench.py --gpus N.  The HIP kernels cannot run here, so the EGNN is stood in
+by a tiny module exposing the same flat_params / flat_grads contract; what is under test is the
+N>1 host path: sharding, broadcast, exactly-two collectives per step, averaged gradients."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+from se3_equi_graph_registration_amd.dp import DataParallelStep, FlatBucket, shard_range
+
+
+class FakeEgnn(nn.Module):
+    """Same contract as EGNN: parameters are views of flat_params, grads views of flat_grads."""
+
+    def __init__(self):
+        super().__init__()
+        self.lin = nn.Linear(4, 3)
+        b = FlatBucket(self.parameters())
+        self.flat_params, self.flat_grads = b.flat, b.grad
+        self._bucket = b
+
+    def zero_grad(self, set_to_none=False):
+        self._bucket.zero_grad()
+
+    def forward(self, x):
+        return self.lin(x)
+
+
+class Pair(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.egnn = FakeEgnn()
+        self.mlp = nn.Sequential(nn.Linear(3, 5), nn.ReLU(), nn.Linear(5, 1))
+        self.unused = nn.Linear(2, 2)
+
+    def forward(self, x):
+        return self.mlp(self.egnn(x)).sum()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)              # different init per rank: broadcast must fix it
+    model = Pair()
+    dp = DataParallelStep(model, model.egnn)
+    dp.broadcast_parameters(0)
+    data = torch.arange(8 * 4, dtype=torch.float32).view(8, 4) / 10.0
+    lo, hi = shard_range(8, rank, world)
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    dp.zero_grad()
+    model(data[lo:hi]).backward()
+    dp.sync()
+    dist.all_reduce = orig
+    q.put((rank, model.egnn.flat_params.clone(), model.egnn.flat_grads.clone(), dp.head.grad.clone(), len(calls),
+           [p.grad is not None and p.grad.data_ptr() != 0 for p in model.mlp.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_sync_matches_full_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, p0, g0, h0, n0, _), (_, p1, g1, h1, n1, _) = res
+    assert torch.equal(p0, p1)                                   # broadcast made the replicas identical
+    assert torch.equal(g0, g1) and torch.equal(h0, h1)           # all-reduced buckets agree
+    assert n0 == 2 and n1 == 2                                   # exactly two collectives per step
+    # reference: single process, rank-0 weights, mean of the two shard gradients
+    torch.manual_seed(100)
+    ref = Pair()
+    data = torch.arange(8 * 4, dtype=torch.float32).view(8, 4) / 10.0
+    acc_e, acc_h = torch.zeros_like(g0), torch.zeros_like(h0)
+    for r in range(world):
+        lo, hi = shard_range(8, r, world)
+        ref.zero_grad()
+        ref(data[lo:hi]).backward()
+        acc_e += torch.cat([p.grad.reshape(-1) for p in ref.egnn.parameters()])
+        acc_h += torch.cat([p.grad.reshape(-1) for p in list(ref.mlp.parameters()) + list(ref.unused.parameters())
+                            if p.grad is not None] + [torch.zeros(sum(p.numel() for p in ref.unused.parameters()))])[:h0.numel()]
+    torch.testing.assert_close(g0, acc_e / world, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(h0[:acc_h.numel()], acc_h / world, rtol=1e-6, atol=1e-7)
+
+
+def test_shard_range_partitions_contiguously():
+    for n in (1, 7, 8, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_flat_bucket_views_survive_zero_grad():
+    m = nn.Linear(3, 2)
+    b = FlatBucket(m.parameters())
+    assert m.weight.data_ptr() == b.flat.data_ptr()
+    m(torch.ones(1, 3)).sum().backward()
+    assert float(b.grad.abs().sum()) > 0
+    for p in m.parameters():
+        p.grad = None
+    b.zero_grad()
+    assert all(p.grad is not None for p in m.parameters()) and float(b.grad.abs().sum()) == 0
+    m(torch.ones(1, 3)).sum().backward()
+    assert m.weight.grad.data_ptr() == b.grad.data_ptr() and float(b.grad.abs().sum()) > 0
