@@ -37,30 +37,61 @@ template <int F> struct Slabs {
     static constexpr int edge = e_w7 + F;
 };
 
-// Deterministic in-block reduction of per-lane accumulator rows into an LDS slab.
-//   lane (slot, f) owns row f: acc[0..n)  ->  sl[off + f*n + i]
-template <int NS, int NMAX>
-__device__ __forceinline__ void slab_rows(float* sl, int off, int n, const float (&acc)[NMAX], int slot, int f,
-                                          bool active) {
-    for (int s = 0; s < NS; ++s) {
-        __syncthreads();
-        if (slot == s && active) {
+// Node-level weight gradients are sums over nodes of outer products a_j (x) b_j.  After a group of
+// NS nodes has left its vectors in LDS, ALL 256 threads accumulate: thread (f = tid % G, c = tid / G)
+// owns row f, column chunk c of the matrix -- distinct outputs per thread, so there is no
+// cross-thread reduction at all, and the partial goes straight to the block's global slab.
+template <int G, int NCOLS>
+struct OuterAcc {
+    static constexpr int NC = 256 / G, CPC = (NCOLS + NC - 1) / NC;
+    float acc[CPC];
+    __device__ __forceinline__ void init() {
 #pragma unroll
-            for (int i = 0; i < NMAX; ++i)
-                if (i < n) sl[off + f * n + i] = (s == 0 ? 0.0f : sl[off + f * n + i]) + acc[i];
+        for (int j = 0; j < CPC; ++j) acc[j] = 0.0f;
+    }
+    // a: LDS [NS][lda] (row vectors), b: LDS [NS][ldb]; ns live nodes in this group
+    __device__ __forceinline__ void add(const float* a, int lda, const float* b, int ldb, int ns, int ncols) {
+        const int f = threadIdx.x % G, c = threadIdx.x / G;
+        for (int s = 0; s < ns; ++s) {
+            const float av = a[s * lda + f];
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) {
+                const int col = c * CPC + j;
+                if (col < ncols) acc[j] = fmaf(av, b[s * ldb + col], acc[j]);
+            }
         }
     }
-}
-template <int NS>
-__device__ __forceinline__ void slab_scalar(float* sl, int off, float v, int slot, int f, bool active) {
-    for (int s = 0; s < NS; ++s) {
-        __syncthreads();
-        if (slot == s && active) sl[off + f] = (s == 0 ? 0.0f : sl[off + f]) + v;
+    __device__ __forceinline__ void store(float* __restrict__ dst, int nrows, int ncols) const {
+        const int f = threadIdx.x % G, c = threadIdx.x / G;
+        if (f < nrows) {
+#pragma unroll
+            for (int j = 0; j < CPC; ++j) {
+                const int col = c * CPC + j;
+                if (col < ncols) dst[f * ncols + col] = acc[j];
+            }
+        }
     }
-}
+};
+// column sums (bias gradients): threads of chunk 0 own one row each
+template <int G>
+struct VecAcc {
+    float acc;
+    __device__ __forceinline__ void init() { acc = 0.0f; }
+    __device__ __forceinline__ void add(const float* a, int lda, int ns) {
+        const int f = threadIdx.x % G;
+        if (threadIdx.x < G)
+            for (int s = 0; s < ns; ++s) acc += a[s * lda + f];
+    }
+    __device__ __forceinline__ void store(float* __restrict__ dst, int nrows) const {
+        if (threadIdx.x < G && (int)(threadIdx.x % G) < nrows) dst[threadIdx.x % G] = acc;
+    }
+};
 __device__ __forceinline__ void slab_flush(const float* sl, float* __restrict__ dst, int size) {
     __syncthreads();
     for (int t = threadIdx.x; t < size; t += 256) dst[(size_t)blockIdx.x * size + t] = sl[t];
+}
+__device__ __forceinline__ void stage_copy(float* dst, const float* __restrict__ src, int n) {
+    for (int t = threadIdx.x; t < n; t += 256) dst[t] = src[t];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -75,50 +106,36 @@ __global__ __launch_bounds__(256) void embed_out_bwd_kernel(const float* __restr
                                                             float* __restrict__ slab) {
     constexpr int FP = Geom<F>::FP, G = Geom<F>::G, NS = Geom<F>::NS;
     __shared__ float gho[NS][64];
-    __shared__ float sl[64 * F + 64];
+    __shared__ float hlv[NS][FP];
+    __shared__ float wo[64 * F];
     const int slot = threadIdx.x / G, f = threadIdx.x % G;
-    float accW[64];
-    float accb[2] = {0.0f, 0.0f};
-#pragma unroll
-    for (int o = 0; o < 64; ++o) accW[o] = 0.0f;
+    stage_copy(wo, w_out, out_nf * F);
+    OuterAcc<64, F> aW;          // rows = out feature (<= 64), cols = F
+    VecAcc<64> ab;
+    aW.init(); ab.init();
     const int groups = (n_nodes + NS - 1) / NS;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int j = grp * NS + slot;
         const bool live = j < n_nodes;
         __syncthreads();
         if (live) {
-            for (int o = f; o < out_nf; o += G) gho[slot][o] = gh_out[(size_t)j * out_nf + o];
+            for (int o = f; o < 64; o += G) gho[slot][o] = (o < out_nf) ? gh_out[(size_t)j * out_nf + o] : 0.0f;
+            if (f < F) hlv[slot][f] = hL[(size_t)j * FP + f];
             if (f < 3) Gx[(size_t)j * 4 + f] = gx_out[(size_t)j * 3 + f];
         }
         __syncthreads();
-        if (live) {
-            if (f < F) {
-                const float hv = hL[(size_t)j * FP + f];
-                float g = 0.0f;
-                for (int o = 0; o < out_nf; ++o) g = fmaf(gho[slot][o], w_out[o * F + f], g);
-                Gh[(size_t)j * FP + f] = g;
-#pragma unroll
-                for (int o = 0; o < 64; ++o)
-                    if (o < out_nf) accW[o] = fmaf(gho[slot][o], hv, accW[o]);
-            }
-            if (f < out_nf) accb[0] += gho[slot][f];
-            if (f + G < out_nf) accb[1] += gho[slot][f + G];
+        if (live && f < F) {
+            float g = 0.0f;
+            for (int o = 0; o < out_nf; ++o) g = fmaf(gho[slot][o], wo[o * F + f], g);
+            Gh[(size_t)j * FP + f] = g;
         }
+        const int ns = min(NS, n_nodes - grp * NS);
+        aW.add(&gho[0][0], 64, &hlv[0][0], FP, ns, F);
+        ab.add(&gho[0][0], 64, ns);
     }
-    // slab: dW_out[o][i] at o*F+i (lane f owns column i=f) ; db_out at out_nf*F + o
-    for (int s = 0; s < NS; ++s) {
-        __syncthreads();
-        if (slot == s) {
-            if (f < F) {
-#pragma unroll
-                for (int o = 0; o < 64; ++o)
-                    if (o < out_nf) sl[o * F + f] = (s == 0 ? 0.0f : sl[o * F + f]) + accW[o];
-            }
-            if (f < out_nf) sl[out_nf * F + f] = (s == 0 ? 0.0f : sl[out_nf * F + f]) + accb[0];
-            if (f + G < out_nf) sl[out_nf * F + f + G] = (s == 0 ? 0.0f : sl[out_nf * F + f + G]) + accb[1];
-        }
-    }
-    slab_flush(sl, slab, out_nf * F + out_nf);
+    float* my = slab + (size_t)blockIdx.x * (out_nf * F + out_nf);
+    aW.store(my, out_nf, F);
+    ab.store(my + out_nf * F, out_nf);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -132,42 +149,36 @@ __global__ __launch_bounds__(256) void embed_in_bwd_kernel(const float* __restri
     constexpr int FP = Geom<F>::FP, G = Geom<F>::G, NS = Geom<F>::NS;
     __shared__ float vin[NS][64];
     __shared__ float gv[NS][FP];
-    __shared__ float sl[64 * F + F];
+    __shared__ float wi[F * 64];
     const int slot = threadIdx.x / G, f = threadIdx.x % G;
-    float accW[64];
-    float accb = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 64; ++i) accW[i] = 0.0f;
+    stage_copy(wi, w_in, F * in_nf);
+    OuterAcc<G, 64> aW;          // rows = hidden feature, cols = in feature (<= 64)
+    VecAcc<G> ab;
+    aW.init(); ab.init();
     const int groups = (n_nodes + NS - 1) / NS;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int j = grp * NS + slot;
         const bool live = j < n_nodes;
         __syncthreads();
-        float g = 0.0f;
         if (live) {
             for (int i = f; i < in_nf; i += G) vin[slot][i] = h_in[(size_t)j * in_nf + i];
-            if (f < F) { g = Gh0[(size_t)j * FP + f]; gv[slot][f] = g; }
+            if (f < F) gv[slot][f] = Gh0[(size_t)j * FP + f];
         }
         __syncthreads();
-        if (live) {
-            if (f < F) {
-                accb += g;
-#pragma unroll
-                for (int i = 0; i < 64; ++i)
-                    if (i < in_nf) accW[i] = fmaf(g, vin[slot][i], accW[i]);
-            }
-            if (grad_h_in) {
-                for (int i = f; i < in_nf; i += G) {
-                    float a = 0.0f;
-                    for (int o = 0; o < F; ++o) a = fmaf(gv[slot][o], w_in[o * in_nf + i], a);
-                    grad_h_in[(size_t)j * in_nf + i] = a;
-                }
+        if (live && grad_h_in) {
+            for (int i = f; i < in_nf; i += G) {
+                float a = 0.0f;
+                for (int o = 0; o < F; ++o) a = fmaf(gv[slot][o], wi[o * in_nf + i], a);
+                grad_h_in[(size_t)j * in_nf + i] = a;
             }
         }
+        const int ns = min(NS, n_nodes - grp * NS);
+        aW.add(&gv[0][0], FP, &vin[0][0], 64, ns, in_nf);
+        ab.add(&gv[0][0], FP, ns);
     }
-    slab_rows<NS, 64>(sl, 0, in_nf, accW, slot, f, f < F);
-    slab_scalar<NS>(sl, F * in_nf, accb, slot, f, f < F);
-    slab_flush(sl, slab, F * in_nf + F);
+    float* my = slab + (size_t)blockIdx.x * (F * in_nf + F);
+    aW.store(my, F, in_nf);
+    ab.store(my + F * in_nf, F);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -186,8 +197,8 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__
     __shared__ float hid[NS][FP];
     __shared__ float ghv[NS][FP];
     __shared__ float dvv[NS][FP];
-    __shared__ float sl[SB::node];
-    __shared__ float wts[4 * F * (F + 1)];      // W4^T | W_src^T | W_tgt^T
+    __shared__ float wts[4 * F * (F + 1)];      // W4^T | W_src^T | W_tgt^T  (transposed, odd stride)
+    __shared__ float w45[3 * F * F];            // W4 | W5 row-major (column reads are lane-consecutive)
     float* W4T = wts;
     float* WaT = wts + 2 * F * (F + 1);
     float* WbT = WaT + F * (F + 1);
@@ -195,12 +206,14 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__
     stage_T<F>(W4T, lw + LL::w4, 2 * F, 2 * F);
     stage_w1_T<F, H, A>(WaT, lw, 0);
     stage_w1_T<F, H, A>(WbT, lw, F);
-    float aW4[2 * F], aW5[F];
-    float ab4 = 0.0f, ab5 = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 2 * F; ++i) aW4[i] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < F; ++i) aW5[i] = 0.0f;
+    stage_copy(w45, lw + LL::w4, 2 * F * F);
+    stage_copy(w45 + 2 * F * F, lw + LL::w5, F * F);
+    const float* W4 = w45;
+    const float* W5 = w45 + 2 * F * F;
+    OuterAcc<G, 2 * F> aW4;
+    OuterAcc<G, F> aW5;
+    VecAcc<G> ab4, ab5;
+    aW4.init(); aW5.init(); ab4.init(); ab5.init();
     const int groups = (n_nodes + NS - 1) / NS;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int j = grp * NS + slot;
@@ -217,40 +230,33 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__
         if (act) {
             v = lw[LL::b4 + f] + col_dot<F>(W4T, f, vin[slot], 2 * F);
             hid[slot][f] = silu(v);
+            float dg = 0.0f;                                   // d silu-output[f] = sum_o G_h[o] W5[o][f]
+            for (int o = 0; o < F; ++o) dg = fmaf(ghv[slot][o], W5[o * F + f], dg);
+            dvv[slot][f] = dg * silu_grad(v);
         }
         if (j < n_nodes) project_pre<F, H, A>(lw, WaT, WbT, vin[slot], f, P + (size_t)j * PS);
-        __syncthreads();
-        float dv = 0.0f;
-        if (act) {
-            ab5 += g;
-#pragma unroll
-            for (int i = 0; i < F; ++i) aW5[i] = fmaf(g, hid[slot][i], aW5[i]);
-            float dg = 0.0f;                                   // d silu-output[f] = sum_o G_h[o] W5[o][f]
-            for (int o = 0; o < F; ++o) dg = fmaf(ghv[slot][o], lw[LL::w5 + o * F + f], dg);
-            dv = dg * silu_grad(v);
-            dvv[slot][f] = dv;
-            ab4 += dv;
-#pragma unroll
-            for (int i = 0; i < 2 * F; ++i) aW4[i] = fmaf(dv, vin[slot][i], aW4[i]);
-        }
         __syncthreads();
         if (act) {
             float d_h = 0.0f, d_a = 0.0f;
             for (int o = 0; o < F; ++o) {
                 const float d = dvv[slot][o];
-                d_h = fmaf(d, lw[LL::w4 + o * 2 * F + f], d_h);
-                d_a = fmaf(d, lw[LL::w4 + o * 2 * F + F + f], d_a);
+                d_h = fmaf(d, W4[o * 2 * F + f], d_h);
+                d_a = fmaf(d, W4[o * 2 * F + F + f], d_a);
             }
             dh_part[(size_t)j * FP + f] = g + d_h;             // residual + node-MLP path
             dagg[(size_t)j * FP + f] = d_a;
         }
+        const int ns = min(NS, n_nodes - grp * NS);
+        aW4.add(&dvv[0][0], FP, &vin[0][0], 2 * FP, ns, 2 * F);
+        aW5.add(&ghv[0][0], FP, &hid[0][0], FP, ns, F);
+        ab4.add(&dvv[0][0], FP, ns);
+        ab5.add(&ghv[0][0], FP, ns);
     }
-    const bool own = f < F;
-    slab_rows<NS, 2 * F>(sl, 0, 2 * F, aW4, slot, f, own);
-    slab_scalar<NS>(sl, F * 2 * F, ab4, slot, f, own);
-    slab_rows<NS, F>(sl, F * 2 * F + F, F, aW5, slot, f, own);
-    slab_scalar<NS>(sl, F * 2 * F + F + F * F, ab5, slot, f, own);
-    slab_flush(sl, slab, SB::node);
+    float* my = slab + (size_t)blockIdx.x * SB::node;
+    aW4.store(my, F, 2 * F);
+    ab4.store(my + F * 2 * F, F);
+    aW5.store(my + F * 2 * F + F, F, F);
+    ab5.store(my + F * 2 * F + F + F * F, F);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -271,12 +277,15 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
     __shared__ float hv[NS][FP];
     __shared__ float prv[NS][FP];
     __shared__ float pcv[NS][FP];
-    __shared__ float sl[SB::gather];
+    __shared__ float w1[F * 2 * F];             // W1[:, 0:2F] row-major [o][2F]
     const int slot = threadIdx.x / G, f = threadIdx.x % G;
-    float aWa[F], aWb[F];
-    float ab1 = 0.0f;
-#pragma unroll
-    for (int i = 0; i < F; ++i) { aWa[i] = 0.0f; aWb[i] = 0.0f; }
+    for (int t = threadIdx.x; t < F * 2 * F; t += 256) {
+        const int o = t / (2 * F), c = t - o * 2 * F;
+        w1[t] = lw[LL::w1_off(o, c)];
+    }
+    OuterAcc<G, F> aWa, aWb;
+    VecAcc<G> ab1;
+    aWa.init(); aWb.init(); ab1.init();
     const int groups = (n_nodes + NS - 1) / NS;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int j = grp * NS + slot;
@@ -301,27 +310,22 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
         }
         __syncthreads();
         if (act) {
-            ab1 += dpc;
-#pragma unroll
-            for (int i = 0; i < F; ++i) {
-                const float hi = hv[slot][i];
-                aWa[i] = fmaf(dpr, hi, aWa[i]);
-                aWb[i] = fmaf(dpc, hi, aWb[i]);
-            }
             float gh = dh_part[(size_t)j * FP + f];
             for (int o = 0; o < F; ++o) {
-                const float* w = lw + LL::w1_off(o, 0);
-                gh = fmaf(prv[slot][o], w[f], gh);
-                gh = fmaf(pcv[slot][o], w[F + f], gh);
+                gh = fmaf(prv[slot][o], w1[o * 2 * F + f], gh);
+                gh = fmaf(pcv[slot][o], w1[o * 2 * F + F + f], gh);
             }
             Gh_new[(size_t)j * FP + f] = gh;
         }
+        const int ns = min(NS, n_nodes - grp * NS);
+        aWa.add(&prv[0][0], FP, &hv[0][0], FP, ns, F);
+        aWb.add(&pcv[0][0], FP, &hv[0][0], FP, ns, F);
+        ab1.add(&pcv[0][0], FP, ns);
     }
-    const bool own = f < F;
-    slab_rows<NS, F>(sl, 0, F, aWa, slot, f, own);
-    slab_rows<NS, F>(sl, F * F, F, aWb, slot, f, own);
-    slab_scalar<NS>(sl, 2 * F * F, ab1, slot, f, own);
-    slab_flush(sl, slab, SB::gather);
+    float* my = slab + (size_t)blockIdx.x * SB::gather;
+    aWa.store(my, F, F);
+    aWb.store(my + F * F, F, F);
+    ab1.store(my + 2 * F * F, F);
 }
 
 // ---------------------------------------------------------------------------------------
