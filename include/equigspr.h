@@ -145,6 +145,38 @@ int equigspr_kabsch_backward(const float* src, const float* tgt, const float* w,
                              const float* grad_R, const float* grad_t, int32_t batch, int32_t n,
                              float* grad_src, float* grad_tgt, float* grad_w, void* stream);
 
+/* ---- A10: fused training pose head ------------------------------------------------------
+ * Replaces the body of CrossAttentionPoseRegression.forward AFTER the EGNN calls
+ * (src/3dmatch_train_egnn_with_batch.py:677-796) except the Kabsch solve (equigspr_kabsch_*):
+ * sim = <h_s,h_t> (:681) and raw_sim (:682), top-K by sim (:684, ties by lower index), gather +
+ * Linear-ReLU-Linear-ReLU-Linear logits (:760-770), BCEWithLogits (:772-773), the standardised
+ * similarity MSE (:777-781, batch-wide mean / unbiased std), egnn_equi_loss (:860-893), and the
+ * label-masked softmax Kabsch weights (:717-724; invalid points get weight 0).
+ *   hs,ht [B,N,F]  raw_hs,raw_ht [B,N,F_raw]  xs,xt [B,N,3]  labels [B,N] (0/1)  gt_pose [B,16]
+ *   mlp: flat [w1 (F x 2F), b1, w2 (F/2 x F), b2, w3 (F/2), b3]  (equigspr_head_mlp_size floats)
+ * Outputs kept for backward: sim,rsim,cosv [B,N], pos int32 [B,N], wts [B,N], top_idx int64 [B,K],
+ * logits [B,K], a1 [B,K,F], a2 [B,K,F/2]; out_scalars[0] = corr_loss+sim_loss, [1] = equi loss,
+ * [2..7] = statistics reused by the backward.  work: equigspr_head_work_bytes bytes (8-byte aligned).
+ * Backward: g_corr_sim / g_equi are DEVICE scalars (may be NULL = 0); gw = dL/d wts from
+ * equigspr_kabsch_backward; writes ghs,ght; ADDS the equi-loss terms into gxs,gxt (which hold the
+ * Kabsch coordinate gradients); ADDS into grad_mlp. */
+int64_t equigspr_head_mlp_size(int32_t F);
+int64_t equigspr_head_work_bytes(int32_t B, int32_t N);
+int equigspr_head_forward(const float* hs, const float* ht, const float* raw_hs, const float* raw_ht,
+                          const float* xs, const float* xt, const float* labels, const float* gt_pose,
+                          const float* mlp, int32_t B, int32_t N, int32_t F, int32_t F_raw, int32_t K,
+                          float* sim, float* rsim, float* cosv, int32_t* pos, float* wts, int64_t* top_idx,
+                          float* logits, float* a1_save, float* a2_save, void* work, float* out_scalars,
+                          void* stream);
+int equigspr_head_backward(const float* hs, const float* ht, const float* xs, const float* xt,
+                           const float* labels, const float* gt_pose, const float* mlp, const float* sim,
+                           const float* rsim, const float* cosv, const int32_t* pos, const float* wts,
+                           const int64_t* top_idx, const float* logits, const float* a1_save,
+                           const float* a2_save, const float* fin_scalars, const float* g_corr_sim,
+                           const float* g_equi, const float* gw, int32_t B, int32_t N, int32_t F, int32_t K,
+                           float* gsim, float* dinp, float* mlp_slab, float* grad_mlp, float* ghs, float* ght,
+                           float* gxs, float* gxt, void* stream);
+
 /* ---- measurement hooks (bench.py's roofline leg; NOT part of the drop-in path) -----------
  * Average duration in ms (written to HOST memory) of the EGNN message-passing edge kernel,
  * measured with HIP events on `stream` over `iters` back-to-back launches (these two calls

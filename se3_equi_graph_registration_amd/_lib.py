@@ -48,6 +48,10 @@ _SIGNATURES = {
                                               c_void_p, c_int32, POINTER(ctypes.c_float), c_void_p]),
     "equigspr_time_edge_bwd": (ctypes.c_int, [POINTER(EgnnConfig), c_void_p, POINTER(Graph), c_void_p, c_void_p, c_void_p,
                                               c_int32, POINTER(ctypes.c_float), c_void_p]),
+    "equigspr_head_mlp_size": (c_int64, [c_int32]),
+    "equigspr_head_work_bytes": (c_int64, [c_int32, c_int32]),
+    "equigspr_head_forward": (ctypes.c_int, [c_void_p] * 9 + [c_int32] * 5 + [c_void_p] * 12),
+    "equigspr_head_backward": (ctypes.c_int, [c_void_p] * 20 + [c_int32] * 4 + [c_void_p] * 9),
     "equigspr_kabsch_forward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                                c_void_p, c_void_p]),
     "equigspr_kabsch_backward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -1,0 +1,549 @@
+// Fused training pose head for gfx950: everything CrossAttentionPoseRegression.forward does AFTER the
+// EGNN (src/3dmatch_train_egnn_with_batch.py:677-796) and its backward, as a handful of kernels instead
+// of ~220 small ATen launches:
+//   head_node_kernel   per node: sim = <h_s,h_t> (:681), raw_sim (:682), the two egnn_equi_loss terms
+//                      (:860-893); per-block fp64 partial sums for the batch-wide mean/std (:777-778)
+//   head_pair_kernel   per pair (one workgroup): masked softmax weights (:717-724), top-k by a full
+//                      bitonic sort in LDS (:684), gather + 3-layer MLP logits (:760-770), BCE (:772),
+//                      similarity-MSE partials (:777-781)
+//   (equigspr_kabsch_forward gives R, t from the weights)
+//   head_finalize      scalars: corr_loss + sim_loss, equi loss
+//   backward: head_pair_bwd_kernel (softmax / BCE / MLP backward, MLP weight-gradient slabs),
+//             head_node_bwd_kernel (d h_s, d h_t, d x_s, d x_t), head_mlp_reduce (slabs -> grads, +=)
+// Layouts: h_* [B,N,F] with row stride F; x_* [B,N,3]; labels [B,N] (float 0/1); gt_pose [B,16].
+#include "common.h"
+
+namespace eq {
+
+typedef unsigned long long u64;
+constexpr int kHeadPartials = 8;     // sum s, sum s^2, sum r, sum r^2, rot, feat, (unused x2)
+constexpr int kMaxK = 256;
+
+__device__ __forceinline__ unsigned orderable(float v) {
+    const unsigned b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__device__ __forceinline__ double block_sum_d(double v, double* red /*[4]*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__device__ __forceinline__ float block_max_f(float v, float* red /*[4]*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_node_kernel(const float* __restrict__ hs, const float* __restrict__ ht,
+                                                        const float* __restrict__ rhs, const float* __restrict__ rht,
+                                                        const float* __restrict__ xs, const float* __restrict__ xt,
+                                                        const float* __restrict__ labels, const float* __restrict__ gt_pose,
+                                                        int B, int N, int F, int Fr, float* __restrict__ sim,
+                                                        float* __restrict__ rsim, float* __restrict__ cosv,
+                                                        int* __restrict__ pos, double* __restrict__ partials) {
+    __shared__ double red[4];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long M = (long long)B * N;
+    double p[6] = {0, 0, 0, 0, 0, 0};
+    if (i < M) {
+        const int b = (int)(i / N);
+        const float* a = hs + i * F;
+        const float* c = ht + i * F;
+        float s = 0.0f, na = 0.0f, nc = 0.0f;
+        for (int f = 0; f < F; ++f) { s = fmaf(a[f], c[f], s); na = fmaf(a[f], a[f], na); nc = fmaf(c[f], c[f], nc); }
+        float r = 0.0f;
+        const float* ra = rhs + i * Fr;
+        const float* rc = rht + i * Fr;
+        for (int f = 0; f < Fr; ++f) r = fmaf(ra[f], rc[f], r);
+        sim[i] = s;
+        rsim[i] = r;
+        pos[i] = -1;
+        const float y = labels[i];
+        const float cs = s / (fmaxf(sqrtf(na), 1e-8f) * fmaxf(sqrtf(nc), 1e-8f));       // F.cosine_similarity (:887)
+        cosv[i] = cs;
+        const float* G = gt_pose + (size_t)b * 16;
+        float ch = 0.0f;
+#pragma unroll
+        for (int r3 = 0; r3 < 3; ++r3) {
+            const float d = G[r3 * 4 + 0] * xs[i * 3 + 0] + G[r3 * 4 + 1] * xs[i * 3 + 1] + G[r3 * 4 + 2] * xs[i * 3 + 2] +
+                            G[r3 * 4 + 3] - xt[i * 3 + r3];
+            ch = fmaf(d, d, ch);
+        }
+        p[0] = s; p[1] = (double)s * s; p[2] = r; p[3] = (double)r * r; p[4] = (double)ch * y; p[5] = (double)(cs - y) * (cs - y);
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const double t = block_sum_d(p[q], red);
+        if (threadIdx.x == 0) partials[(size_t)blockIdx.x * kHeadPartials + q] = t;
+    }
+}
+
+// stats[0..3] = mean_s, std_s(unbiased), mean_r, std_r ; stats[4] = rot sum, stats[5] = feat sum
+__device__ __forceinline__ void head_stats(const double* __restrict__ partials, int n_blocks, long long M, double* red,
+                                           double (&st)[6]) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = threadIdx.x; k < n_blocks; k += 256)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc[q] += partials[(size_t)k * kHeadPartials + q];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) acc[q] = block_sum_d(acc[q], red);
+    const double ms = acc[0] / M, mr = acc[2] / M;
+    const double vs = fmax((acc[1] - M * ms * ms) / (M - 1), 0.0), vr = fmax((acc[3] - M * mr * mr) / (M - 1), 0.0);
+    st[0] = ms; st[1] = sqrt(vs); st[2] = mr; st[3] = sqrt(vr); st[4] = acc[4]; st[5] = acc[5];
+}
+
+struct MlpDims { int in, h1, h2; };     // in = 2F, h1 = F, h2 = F/2, out = 1
+
+// LDS layout of head_pair kernels (floats):
+//   keys  u64 [Npad]          (fwd only)
+//   inp   [K][in+1], a1 [K][h1+1], a2 [K][h2+1], w1 [h1][in], w2 [h2][h1], w3[h2], biases
+__global__ __launch_bounds__(256) void head_pair_kernel(
+    const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
+    const float* __restrict__ sim, const float* __restrict__ rsim, const double* __restrict__ partials, int n_blocks_a,
+    const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+    const float* __restrict__ w3, const float* __restrict__ b3, int B, int N, int Npad, int F, int K, MlpDims md,
+    float* __restrict__ wts, int* __restrict__ pos, long long* __restrict__ top_idx, float* __restrict__ logits,
+    float* __restrict__ a1_save, float* __restrict__ a2_save, double* __restrict__ pair_part /*[B][4]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ double red[4];
+    __shared__ float redf[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const long long M = (long long)B * N;
+    const float* sb = sim + (size_t)b * N;
+    const float* rb = rsim + (size_t)b * N;
+    const float* yb = labels + (size_t)b * N;
+    u64* keys = reinterpret_cast<u64*>(smem_raw);
+    float* fl = reinterpret_cast<float*>(smem_raw + sizeof(u64) * (size_t)Npad);
+    const int ld_in = md.in + 1, ld1 = md.h1 + 1, ld2 = md.h2 + 1;
+    float* inp = fl;
+    float* a1 = inp + K * ld_in;
+    float* a2 = a1 + K * ld1;
+    float* W1 = a2 + K * ld2;
+    float* W2 = W1 + md.h1 * md.in;
+    float* W3 = W2 + md.h2 * md.h1;
+    float* Bs = W3 + md.h2;              // b1 | b2 | b3
+
+    double st[6];
+    head_stats(partials, n_blocks_a, M, red, st);
+    const float mu_s = (float)st[0], sd_s = (float)st[1], mu_r = (float)st[2], sd_r = (float)st[3];
+
+    // ---- similarity-MSE partials (:777-781) and masked softmax (:717-724)
+    double sq = 0, se = 0, ses = 0;
+    float mx = -INFINITY;
+    for (int i = tid; i < N; i += 256) {
+        const float zs = (sb[i] - mu_s) / (sd_s + 1e-6f), zr = (rb[i] - mu_r) / (sd_r + 1e-6f);
+        const float e = zs - zr;
+        sq += (double)e * e; se += e; ses += (double)e * (sb[i] - mu_s);
+        if (yb[i] != 0.0f) mx = fmaxf(mx, sb[i]);
+        keys[i] = ((u64)(~orderable(sb[i])) << 32) | (unsigned)i;       // ascending key == descending sim, then index
+    }
+    for (int i = N + tid; i < Npad; i += 256) keys[i] = ~0ull;
+    sq = block_sum_d(sq, red); se = block_sum_d(se, red); ses = block_sum_d(ses, red);
+    mx = block_max_f(mx, redf);
+    double den = 0;
+    for (int i = tid; i < N; i += 256)
+        if (yb[i] != 0.0f) den += expf(sb[i] - mx);
+    den = block_sum_d(den, red);
+    double usum = 0;
+    for (int i = tid; i < N; i += 256) {
+        const float u = (yb[i] != 0.0f && den > 0.0) ? expf(sb[i] - mx) / (float)den : 0.0f;
+        usum += u;
+    }
+    usum = block_sum_d(usum, red);
+    const float S = (float)usum;
+    for (int i = tid; i < N; i += 256) {
+        const float u = (yb[i] != 0.0f && den > 0.0) ? expf(sb[i] - mx) / (float)den : 0.0f;
+        wts[(size_t)b * N + i] = u / (S + 1e-6f);
+    }
+    // ---- stage the MLP weights while the sort runs
+    for (int t = tid; t < md.h1 * md.in; t += 256) W1[t] = w1[t];
+    for (int t = tid; t < md.h2 * md.h1; t += 256) W2[t] = w2[t];
+    for (int t = tid; t < md.h2; t += 256) W3[t] = w3[t];
+    for (int t = tid; t < md.h1; t += 256) Bs[t] = b1[t];
+    for (int t = tid; t < md.h2; t += 256) Bs[md.h1 + t] = b2[t];
+    if (tid == 0) Bs[md.h1 + md.h2] = b3[0];
+    // ---- full bitonic sort of the keys
+    __syncthreads();
+    for (int k2 = 2; k2 <= Npad; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < Npad / 2; t += 256) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int hi = lo | j;
+                const bool up = (lo & k2) == 0;
+                const u64 a = keys[lo], c = keys[hi];
+                if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- gather the K selected rows (:688-689), cat [h_s | h_t]
+    for (int t = tid; t < K * md.in; t += 256) {
+        const int j = t / md.in, c = t - j * md.in;
+        const int idx = (int)(unsigned)(keys[j] & 0xffffffffu);
+        const float v = (c < F) ? hs[((size_t)b * N + idx) * F + c] : ht[((size_t)b * N + idx) * F + (c - F)];
+        inp[j * ld_in + c] = v;
+    }
+    if (tid < K) {
+        const int idx = (int)(unsigned)(keys[tid] & 0xffffffffu);
+        top_idx[(size_t)b * K + tid] = idx;
+        pos[(size_t)b * N + idx] = tid;
+    }
+    __syncthreads();
+    // ---- MLP: Linear-ReLU-Linear-ReLU-Linear (:594-600); thread = (row j, output chunk)
+    for (int t = tid; t < K * md.h1; t += 256) {
+        const int j = t / md.h1, o = t - j * md.h1;
+        float acc = Bs[o];
+        for (int i = 0; i < md.in; ++i) acc = fmaf(W1[o * md.in + i], inp[j * ld_in + i], acc);
+        acc = fmaxf(acc, 0.0f);
+        a1[j * ld1 + o] = acc;
+        a1_save[((size_t)b * K + j) * md.h1 + o] = acc;
+    }
+    __syncthreads();
+    for (int t = tid; t < K * md.h2; t += 256) {
+        const int j = t / md.h2, o = t - j * md.h2;
+        float acc = Bs[md.h1 + o];
+        for (int i = 0; i < md.h1; ++i) acc = fmaf(W2[o * md.h1 + i], a1[j * ld1 + i], acc);
+        acc = fmaxf(acc, 0.0f);
+        a2[j * ld2 + o] = acc;
+        a2_save[((size_t)b * K + j) * md.h2 + o] = acc;
+    }
+    __syncthreads();
+    double bce = 0;
+    if (tid < K) {
+        float z = Bs[md.h1 + md.h2];
+        for (int i = 0; i < md.h2; ++i) z = fmaf(W3[i], a2[tid * ld2 + i], z);
+        logits[(size_t)b * K + tid] = z;
+        const int idx = (int)(unsigned)(keys[tid] & 0xffffffffu);
+        const float y = yb[idx];
+        bce = fmaxf(z, 0.0f) - z * y + log1pf(expf(-fabsf(z)));                          // BCEWithLogits (:772-773)
+    }
+    bce = block_sum_d(bce, red);
+    if (tid == 0) {
+        double* pp = pair_part + (size_t)b * 4;
+        pp[0] = bce; pp[1] = sq; pp[2] = se; pp[3] = ses;
+    }
+}
+
+// out[0] = corr_loss + sim_loss, out[1] = equi loss, out[2..7] = mu_s, sd_s, mu_r, sd_r, sum e, sum e (s - mu_s)
+__global__ __launch_bounds__(256) void head_finalize_kernel(const double* __restrict__ partials, int n_blocks_a,
+                                                            const double* __restrict__ pair_part, int B, int N, int K,
+                                                            float* __restrict__ out) {
+    __shared__ double red[4];
+    const long long M = (long long)B * N;
+    double st[6];
+    head_stats(partials, n_blocks_a, M, red, st);
+    double acc[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < B; b += 256)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += pair_part[(size_t)b * 4 + q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = block_sum_d(acc[q], red);
+    if (threadIdx.x == 0) {
+        out[0] = (float)(acc[0] / ((double)B * K) + acc[1] / (double)M);
+        out[1] = (float)(st[4] / (double)M + st[5] / (double)M);
+        out[2] = (float)st[0]; out[3] = (float)st[1]; out[4] = (float)st[2]; out[5] = (float)st[3];
+        out[6] = (float)acc[2]; out[7] = (float)acc[3];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------
+// mlp slab per pair: dW1 [h1*in] | db1 [h1] | dW2 [h2*h1] | db2 [h2] | dW3 [h2] | db3 [1]
+__global__ __launch_bounds__(256) void head_pair_bwd_kernel(
+    const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
+    const float* __restrict__ sim, const float* __restrict__ rsim, const float* __restrict__ wts,
+    const float* __restrict__ gw, const long long* __restrict__ top_idx, const float* __restrict__ logits,
+    const float* __restrict__ a1_save, const float* __restrict__ a2_save, const float* __restrict__ w1,
+    const float* __restrict__ w2, const float* __restrict__ w3, const float* __restrict__ fin /*[8]*/,
+    const float* __restrict__ g_cs_ptr, int B, int N, int F, int K, MlpDims md, float* __restrict__ gsim,
+    float* __restrict__ dinp /*[B][K][in]*/, float* __restrict__ mlp_slab) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ double red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const long long M = (long long)B * N;
+    const float g_cs = g_cs_ptr ? g_cs_ptr[0] : 0.0f;
+    const float* sb = sim + (size_t)b * N;
+    const float* rb = rsim + (size_t)b * N;
+    const float* yb = labels + (size_t)b * N;
+    const float* gwb = gw + (size_t)b * N;
+    float* fl = reinterpret_cast<float*>(smem_raw);
+    const int ld_in = md.in + 1, ld1 = md.h1 + 1, ld2 = md.h2 + 1;
+    float* inp = fl;
+    float* a1 = inp + K * ld_in;
+    float* a2 = a1 + K * ld1;
+    float* d1 = a2 + K * ld2;            // d pre-activation 1  [K][h1+1]
+    float* d2 = d1 + K * ld1;            // d pre-activation 2  [K][h2+1]
+    float* dz = d2 + K * ld2;            // [K]
+    float* W1 = dz + K;
+    float* W2 = W1 + md.h1 * md.in;
+    float* W3 = W2 + md.h2 * md.h1;
+
+    // ---- weights softmax backward: w = u / (Su + eps), u = softmax_valid(sim) (recomputed as in forward)
+    //      gu_i = gw_i/(Su+eps) - (sum_j gw_j u_j)/(Su+eps)^2 ; gscore_i = u_i (gu_i - sum_j gu_j u_j)
+    __shared__ float redf[4];
+    float mx = -INFINITY;
+    for (int i = tid; i < N; i += 256)
+        if (yb[i] != 0.0f) mx = fmaxf(mx, sb[i]);
+    mx = block_max_f(mx, redf);
+    double den = 0;
+    for (int i = tid; i < N; i += 256)
+        if (yb[i] != 0.0f) den += expf(sb[i] - mx);
+    den = block_sum_d(den, red);
+    const float fden = (float)den;
+    double Su = 0, gwu = 0;
+    for (int i = tid; i < N; i += 256) {
+        const float u = (yb[i] != 0.0f && fden > 0.0f) ? expf(sb[i] - mx) / fden : 0.0f;
+        Su += u;
+        gwu += (double)gwb[i] * u;
+    }
+    Su = block_sum_d(Su, red);
+    gwu = block_sum_d(gwu, red);
+    const double sc = (double)((float)Su + 1e-6f);
+    double guu = 0;
+    for (int i = tid; i < N; i += 256) {
+        const float u = (yb[i] != 0.0f && fden > 0.0f) ? expf(sb[i] - mx) / fden : 0.0f;
+        const double gu = gwb[i] / sc - gwu / (sc * sc);
+        guu += gu * u;
+    }
+    guu = block_sum_d(guu, red);
+    // ---- similarity-MSE backward (:777-781)
+    const float mu_s = fin[2], sd_s = fin[3], mu_r = fin[4], sd_r = fin[5], sum_e = fin[6], sum_es = fin[7];
+    const float cmse = 2.0f / (float)M * g_cs;
+    const float inv_sd = 1.0f / (sd_s + 1e-6f);
+    const float k2 = (sd_s > 0.0f) ? sum_es * inv_sd * inv_sd / ((float)(M - 1) * sd_s) : 0.0f;
+    for (int i = tid; i < N; i += 256) {
+        const float u = (yb[i] != 0.0f && fden > 0.0f) ? expf(sb[i] - mx) / fden : 0.0f;
+        const double gu = gwb[i] / sc - gwu / (sc * sc);
+        float g = (float)(u * (gu - guu));
+        const float zs = (sb[i] - mu_s) * inv_sd, zr = (rb[i] - mu_r) / (sd_r + 1e-6f);
+        const float e = zs - zr;
+        g += cmse * ((e - sum_e / (float)M) * inv_sd - k2 * (sb[i] - mu_s));
+        gsim[(size_t)b * N + i] = g;
+    }
+    // ---- BCE + MLP backward on the K selected rows
+    for (int t = tid; t < md.h1 * md.in; t += 256) W1[t] = w1[t];
+    for (int t = tid; t < md.h2 * md.h1; t += 256) W2[t] = w2[t];
+    for (int t = tid; t < md.h2; t += 256) W3[t] = w3[t];
+    for (int t = tid; t < K * md.in; t += 256) {
+        const int j = t / md.in, c = t - j * md.in;
+        const int idx = (int)top_idx[(size_t)b * K + j];
+        inp[j * ld_in + c] = (c < F) ? hs[((size_t)b * N + idx) * F + c] : ht[((size_t)b * N + idx) * F + (c - F)];
+    }
+    for (int t = tid; t < K * md.h1; t += 256) { const int j = t / md.h1, o = t - j * md.h1; a1[j * ld1 + o] = a1_save[((size_t)b * K + j) * md.h1 + o]; }
+    for (int t = tid; t < K * md.h2; t += 256) { const int j = t / md.h2, o = t - j * md.h2; a2[j * ld2 + o] = a2_save[((size_t)b * K + j) * md.h2 + o]; }
+    if (tid < K) {
+        const float z = logits[(size_t)b * K + tid];
+        const float y = yb[(int)top_idx[(size_t)b * K + tid]];
+        dz[tid] = g_cs * (1.0f / (1.0f + expf(-z)) - y) / ((float)B * K);
+    }
+    __syncthreads();
+    for (int t = tid; t < K * md.h2; t += 256) {
+        const int j = t / md.h2, o = t - j * md.h2;
+        d2[j * ld2 + o] = (a2[j * ld2 + o] > 0.0f) ? dz[j] * W3[o] : 0.0f;
+    }
+    __syncthreads();
+    for (int t = tid; t < K * md.h1; t += 256) {
+        const int j = t / md.h1, o = t - j * md.h1;
+        float acc = 0.0f;
+        for (int q = 0; q < md.h2; ++q) acc = fmaf(d2[j * ld2 + q], W2[q * md.h1 + o], acc);
+        d1[j * ld1 + o] = (a1[j * ld1 + o] > 0.0f) ? acc : 0.0f;
+    }
+    __syncthreads();
+    for (int t = tid; t < K * md.in; t += 256) {
+        const int j = t / md.in, c = t - j * md.in;
+        float acc = 0.0f;
+        for (int q = 0; q < md.h1; ++q) acc = fmaf(d1[j * ld1 + q], W1[q * md.in + c], acc);
+        dinp[((size_t)b * K + j) * md.in + c] = acc;
+    }
+    // ---- weight-gradient slab of this pair (thread-owned outputs, sums over the K rows)
+    float* sl = mlp_slab + (size_t)b * (md.h1 * md.in + md.h1 + md.h2 * md.h1 + md.h2 + md.h2 + 1);
+    for (int t = tid; t < md.h1 * md.in; t += 256) {
+        const int o = t / md.in, c = t - o * md.in;
+        float acc = 0.0f;
+        for (int j = 0; j < K; ++j) acc = fmaf(d1[j * ld1 + o], inp[j * ld_in + c], acc);
+        sl[t] = acc;
+    }
+    float* p = sl + md.h1 * md.in;
+    for (int o = tid; o < md.h1; o += 256) { float acc = 0.0f; for (int j = 0; j < K; ++j) acc += d1[j * ld1 + o]; p[o] = acc; }
+    p += md.h1;
+    for (int t = tid; t < md.h2 * md.h1; t += 256) {
+        const int o = t / md.h1, c = t - o * md.h1;
+        float acc = 0.0f;
+        for (int j = 0; j < K; ++j) acc = fmaf(d2[j * ld2 + o], a1[j * ld1 + c], acc);
+        p[t] = acc;
+    }
+    p += md.h2 * md.h1;
+    for (int o = tid; o < md.h2; o += 256) { float acc = 0.0f; for (int j = 0; j < K; ++j) acc += d2[j * ld2 + o]; p[o] = acc; }
+    p += md.h2;
+    for (int o = tid; o < md.h2; o += 256) { float acc = 0.0f; for (int j = 0; j < K; ++j) acc = fmaf(dz[j], a2[j * ld2 + o], acc); p[o] = acc; }
+    p += md.h2;
+    if (tid == 0) { float acc = 0.0f; for (int j = 0; j < K; ++j) acc += dz[j]; p[0] = acc; }
+}
+
+__global__ __launch_bounds__(256) void head_node_bwd_kernel(
+    const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ xs, const float* __restrict__ xt,
+    const float* __restrict__ labels, const float* __restrict__ gt_pose, const float* __restrict__ gsim,
+    const float* __restrict__ cosv, const int* __restrict__ pos, const float* __restrict__ dinp,
+    const float* __restrict__ g_equi_ptr, int B, int N, int F, int K, int in_dim, float* __restrict__ ghs,
+    float* __restrict__ ght, float* __restrict__ gxs /* += */, float* __restrict__ gxt /* += */) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long M = (long long)B * N;
+    if (i >= M) return;
+    const int b = (int)(i / N);
+    const float g_eq = g_equi_ptr ? g_equi_ptr[0] : 0.0f;
+    const float gs = gsim[i];
+    const int pj = pos[i];
+    const float* a = hs + i * F;
+    const float* c = ht + i * F;
+    float ka = 0.0f, kc = 0.0f, kx = 0.0f;     // feature-loss (cosine) terms
+    if (g_eq != 0.0f) {
+        float s = 0.0f, na = 0.0f, nc = 0.0f;
+        for (int f = 0; f < F; ++f) { s = fmaf(a[f], c[f], s); na = fmaf(a[f], a[f], na); nc = fmaf(c[f], c[f], nc); }
+        const float la = fmaxf(sqrtf(na), 1e-8f), lc = fmaxf(sqrtf(nc), 1e-8f);
+        const float cs = cosv[i];
+        const float gcos = g_eq * 2.0f * (cs - labels[i]) / (float)M;
+        kx = gcos / (la * lc);                 // d cos/da = c/(|a||c|) - cos a/|a|^2
+        ka = gcos * cs / (la * la);
+        kc = gcos * cs / (lc * lc);
+    }
+    const float* dj = (pj >= 0) ? dinp + ((size_t)b * K + pj) * in_dim : nullptr;
+    for (int f = 0; f < F; ++f) {
+        float ga = gs * c[f] + kx * c[f] - ka * a[f];
+        float gc = gs * a[f] + kx * a[f] - kc * c[f];
+        if (dj) { ga += dj[f]; gc += dj[F + f]; }
+        ghs[i * F + f] = ga;
+        ght[i * F + f] = gc;
+    }
+    if (g_eq != 0.0f) {                        // rotation-consistency term (:881-884)
+        const float* G = gt_pose + (size_t)b * 16;
+        const float y = labels[i];
+        float d[3];
+#pragma unroll
+        for (int r3 = 0; r3 < 3; ++r3)
+            d[r3] = G[r3 * 4 + 0] * xs[i * 3 + 0] + G[r3 * 4 + 1] * xs[i * 3 + 1] + G[r3 * 4 + 2] * xs[i * 3 + 2] + G[r3 * 4 + 3] - xt[i * 3 + r3];
+        const float k = g_eq * 2.0f * y / (float)M;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            gxs[i * 3 + q] += k * (G[0 * 4 + q] * d[0] + G[1 * 4 + q] * d[1] + G[2 * 4 + q] * d[2]);
+            gxt[i * 3 + q] -= k * d[q];
+        }
+    }
+}
+
+__global__ void head_mlp_reduce_kernel(const float* __restrict__ slab, int B, int size, float* __restrict__ dst) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= size) return;
+    float a = 0.0f;
+    for (int b = 0; b < B; ++b) a += slab[(size_t)b * size + t];
+    dst[t] += a;
+}
+
+static inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+static inline size_t fwd_smem(int Npad, int K, MlpDims md) {
+    return sizeof(u64) * (size_t)Npad + sizeof(float) * ((size_t)K * (md.in + 1) + (size_t)K * (md.h1 + 1) + (size_t)K * (md.h2 + 1) +
+                                                          (size_t)md.h1 * md.in + (size_t)md.h2 * md.h1 + md.h2 + md.h1 + md.h2 + 1 + 8);
+}
+static inline size_t bwd_smem(int K, MlpDims md) {
+    return sizeof(float) * ((size_t)K * (md.in + 1) + 2 * (size_t)K * (md.h1 + 1) + 2 * (size_t)K * (md.h2 + 1) + K +
+                            (size_t)md.h1 * md.in + (size_t)md.h2 * md.h1 + md.h2 + 8);
+}
+
+}  // namespace eq
+
+extern "C" int64_t equigspr_head_mlp_size(int32_t F) {
+    const int in = 2 * F, h1 = F, h2 = F / 2;
+    return (int64_t)h1 * in + h1 + (int64_t)h2 * h1 + h2 + h2 + 1;
+}
+
+// workspace (doubles first): partials [nA][8] d | pair_part [B][4] d | then floats: fin[8]
+extern "C" int64_t equigspr_head_work_bytes(int32_t B, int32_t N) {
+    const int64_t nA = ((int64_t)B * N + 255) / 256;
+    return 8 * (nA * eq::kHeadPartials + (int64_t)B * 4) + 4 * 16;
+}
+
+extern "C" int equigspr_head_forward(const float* hs, const float* ht, const float* raw_hs, const float* raw_ht,
+                                     const float* xs, const float* xt, const float* labels, const float* gt_pose,
+                                     const float* mlp /* flat: w1,b1,w2,b2,w3,b3 */, int32_t B, int32_t N, int32_t F,
+                                     int32_t F_raw, int32_t K, float* sim, float* rsim, float* cosv, int32_t* pos,
+                                     float* wts, int64_t* top_idx, float* logits, float* a1_save, float* a2_save,
+                                     void* work, float* out_scalars /* [8] device */, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(hs && ht && raw_hs && raw_ht && xs && xt && labels && gt_pose && mlp && sim && rsim && cosv && pos && wts &&
+                     top_idx && logits && a1_save && a2_save && work && out_scalars, EQUIGSPR_EINVAL, "head_forward: null pointer");
+    EQ_CHECK_ARG(B >= 1 && N >= 2 && F >= 2 && F <= 64 && F_raw >= 1 && K >= 1 && K <= kMaxK && K <= N && N <= 16384,
+                 EQUIGSPR_ENOTSUP, "head_forward: need 2<=F<=64, 1<=K<=min(256,N), N<=16384");
+    hipStream_t s = (hipStream_t)stream;
+    const MlpDims md{2 * F, F, F / 2};
+    const int nA = ceil_div((long long)B * N, 256);
+    double* partials = reinterpret_cast<double*>(work);
+    double* pair_part = partials + (size_t)nA * kHeadPartials;
+    const float* w1 = mlp;
+    const float* b1 = w1 + md.h1 * md.in;
+    const float* w2 = b1 + md.h1;
+    const float* b2 = w2 + md.h2 * md.h1;
+    const float* w3 = b2 + md.h2;
+    const float* b3 = w3 + md.h2;
+    hipLaunchKernelGGL(head_node_kernel, dim3(nA), dim3(256), 0, s, hs, ht, raw_hs, raw_ht, xs, xt, labels, gt_pose, B, N, F,
+                       F_raw, sim, rsim, cosv, pos, partials);
+    const int Npad = next_pow2(N);
+    const size_t sm = fwd_smem(Npad, K, md);
+    static size_t sm_set = 0;
+    if (sm > sm_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_pair_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) { set_error("head_forward: %s", hipGetErrorString(e)); return (int)e; }
+        sm_set = sm;
+    }
+    hipLaunchKernelGGL(head_pair_kernel, dim3(B), dim3(256), sm, s, hs, ht, labels, sim, rsim, partials, nA, w1, b1, w2, b2, w3,
+                       b3, B, N, Npad, F, K, md, wts, pos, reinterpret_cast<long long*>(top_idx), logits, a1_save, a2_save,
+                       pair_part);
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, partials, nA, pair_part, B, N, K, out_scalars);
+    EQ_CHECK_LAUNCH("head_forward");
+    return 0;
+}
+
+extern "C" int equigspr_head_backward(const float* hs, const float* ht, const float* xs, const float* xt,
+                                      const float* labels, const float* gt_pose, const float* mlp, const float* sim,
+                                      const float* rsim, const float* cosv, const int32_t* pos, const float* wts,
+                                      const int64_t* top_idx, const float* logits, const float* a1_save,
+                                      const float* a2_save, const float* fin_scalars, const float* g_corr_sim,
+                                      const float* g_equi, const float* gw, int32_t B, int32_t N, int32_t F, int32_t K,
+                                      float* gsim, float* dinp, float* mlp_slab, float* grad_mlp /* += */, float* ghs,
+                                      float* ght, float* gxs /* += */, float* gxt /* += */, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(hs && ht && xs && xt && labels && gt_pose && mlp && sim && rsim && cosv && pos && wts && top_idx && logits &&
+                     a1_save && a2_save && fin_scalars && gw && gsim && dinp && mlp_slab && grad_mlp && ghs && ght && gxs && gxt,
+                 EQUIGSPR_EINVAL, "head_backward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const MlpDims md{2 * F, F, F / 2};
+    const float* w1 = mlp;
+    const float* w2 = w1 + md.h1 * md.in + md.h1;
+    const float* w3 = w2 + md.h2 * md.h1 + md.h2;
+    const size_t sm = bwd_smem(K, md);
+    static size_t sm_set = 0;
+    if (sm > sm_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_pair_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) { set_error("head_backward: %s", hipGetErrorString(e)); return (int)e; }
+        sm_set = sm;
+    }
+    hipLaunchKernelGGL(head_pair_bwd_kernel, dim3(B), dim3(256), sm, s, hs, ht, labels, sim, rsim, wts, gw,
+                       reinterpret_cast<const long long*>(top_idx), logits, a1_save, a2_save, w1, w2, w3, fin_scalars,
+                       g_corr_sim, B, N, F, K, md, gsim, dinp, mlp_slab);
+    const int nA = ceil_div((long long)B * N, 256);
+    hipLaunchKernelGGL(head_node_bwd_kernel, dim3(nA), dim3(256), 0, s, hs, ht, xs, xt, labels, gt_pose, gsim, cosv, pos, dinp,
+                       g_equi, B, N, F, K, md.in, ghs, ght, gxs, gxt);
+    const int msz = (int)equigspr_head_mlp_size(F);
+    hipLaunchKernelGGL(head_mlp_reduce_kernel, dim3(ceil_div(msz, 256)), dim3(256), 0, s, mlp_slab, B, msz, grad_mlp);
+    EQ_CHECK_LAUNCH("head_backward");
+    return 0;
+}

@@ -198,3 +198,97 @@ def weighted_kabsch(src: torch.Tensor, tgt: torch.Tensor, weights: torch.Tensor)
     """Batched weighted Kabsch (reference train :726-758).  ``src,tgt [B,n,3]``, ``weights [B,n]``
     (zero weight = masked out) -> ``R [B,3,3]``, ``t [B,3]``; differentiable."""
     return _KabschFn.apply(src, tgt, weights)
+
+
+# ----------------------------------------------------------------------------------- fused training head
+class _HeadFn(torch.autograd.Function):
+    """equigspr_head_forward + equigspr_kabsch_forward, and their backwards, as one autograd node.
+    Outputs: R [B,3,3], t [B,3], corr_loss+sim_loss (scalar), equi loss (scalar), logits [B,K], top_idx [B,K]."""
+
+    @staticmethod
+    def forward(ctx, hs, ht, xs, xt, raw_hs, raw_ht, labels, gt_pose, topk, *mlp_params):
+        L = _lib.lib()
+        hs, ht, xs, xt = (_need(t.contiguous(), "head input", torch.float32, 3) for t in (hs, ht, xs, xt))
+        raw_hs = _need(raw_hs.contiguous().float(), "raw_h_src", torch.float32, 3)
+        raw_ht = _need(raw_ht.contiguous().float(), "raw_h_tgt", torch.float32, 3)
+        B, N, Fd = hs.shape
+        labels = _need(labels.reshape(B, N).contiguous().float(), "labels", torch.float32, 2)
+        gt = _need(gt_pose.reshape(B, 16).contiguous().float(), "gt_pose", torch.float32, 2)
+        K = int(topk)
+        dev = hs.device
+        msz = int(L.equigspr_head_mlp_size(Fd))
+        # the six MLP tensors are adjacent views of one bucket when dp.FlatBucket owns them; else pack them
+        flat = None
+        p0 = mlp_params[0]
+        off = 0
+        adjacent = True
+        for q in mlp_params:
+            if q.data_ptr() != p0.data_ptr() + 4 * off or not q.is_contiguous():
+                adjacent = False
+                break
+            off += q.numel()
+        if adjacent and off == msz:
+            flat = p0.detach().reshape(-1).as_strided((msz,), (1,))
+        else:
+            flat = torch.cat([q.detach().reshape(-1) for q in mlp_params])
+        if flat.numel() != msz:
+            raise RuntimeError("pose head MLP must be Linear(2F,F)-ReLU-Linear(F,F//2)-ReLU-Linear(F//2,1)")
+        f32 = dict(dtype=torch.float32, device=dev)
+        sim, rsim, cosv, wts = (torch.empty(B, N, **f32) for _ in range(4))
+        pos = torch.empty(B, N, dtype=torch.int32, device=dev)
+        top_idx = torch.empty(B, K, dtype=torch.int64, device=dev)
+        logits = torch.empty(B, K, **f32)
+        a1 = torch.empty(B, K, Fd, **f32)
+        a2 = torch.empty(B, K, Fd // 2, **f32)
+        work = torch.empty(int(L.equigspr_head_work_bytes(B, N)) // 8 + 1, dtype=torch.float64, device=dev)
+        fin = torch.empty(8, **f32)
+        _lib.check(L.equigspr_head_forward(_p(hs), _p(ht), _p(raw_hs), _p(raw_ht), _p(xs), _p(xt), _p(labels), _p(gt),
+                                           _p(flat), B, N, Fd, raw_hs.shape[2], K, _p(sim), _p(rsim), _p(cosv), _p(pos),
+                                           _p(wts), _p(top_idx), _p(logits), _p(a1), _p(a2), _p(work), _p(fin), _stream()),
+                   "head_forward")
+        R = torch.empty(B, 3, 3, **f32)
+        t = torch.empty(B, 3, **f32)
+        aux = torch.empty(B, KABSCH_AUX, **f32)
+        _lib.check(L.equigspr_kabsch_forward(_p(xs), _p(xt), _p(wts), B, N, _p(R), _p(t), _p(aux), _stream()), "kabsch_forward")
+        ctx.save_for_backward(hs, ht, xs, xt, labels, gt, flat, sim, rsim, cosv, pos, wts, top_idx, logits, a1, a2, fin, aux)
+        ctx.dims = (B, N, Fd, K, msz)
+        ctx.mlp_shapes = [tuple(q.shape) for q in mlp_params]
+        ctx.mark_non_differentiable(top_idx, logits)      # the logits' only consumer (BCE) is inside the head
+        ctx.set_materialize_grads(False)
+        return R, t, fin[0], fin[1], logits, top_idx
+
+    @staticmethod
+    def backward(ctx, gR, gt_, g_cs, g_eq, g_logits, _g_idx):
+        L = _lib.lib()
+        (hs, ht, xs, xt, labels, gt, flat, sim, rsim, cosv, pos, wts, top_idx, logits, a1, a2, fin, aux) = ctx.saved_tensors
+        B, N, Fd, K, msz = ctx.dims
+        dev = hs.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        gR = torch.zeros(B, 3, 3, **f32) if gR is None else gR.contiguous()
+        gt_ = torch.zeros(B, 3, **f32) if gt_ is None else gt_.contiguous()
+        gxs, gxt, gw = torch.empty_like(xs), torch.empty_like(xt), torch.empty_like(wts)
+        _lib.check(L.equigspr_kabsch_backward(_p(xs), _p(xt), _p(wts), _p(aux), _p(gR), _p(gt_), B, N, _p(gxs), _p(gxt),
+                                              _p(gw), _stream()), "kabsch_backward")
+        ghs, ght = torch.empty_like(hs), torch.empty_like(ht)
+        gsim = torch.empty(B, N, **f32)
+        dinp = torch.empty(B, K, 2 * Fd, **f32)
+        slab = torch.empty(B, msz, **f32)
+        gmlp = torch.zeros(msz, **f32)
+        g_cs = None if g_cs is None else g_cs.contiguous().float()
+        g_eq = None if g_eq is None else g_eq.contiguous().float()
+        _lib.check(L.equigspr_head_backward(_p(hs), _p(ht), _p(xs), _p(xt), _p(labels), _p(gt), _p(flat), _p(sim), _p(rsim),
+                                            _p(cosv), _p(pos), _p(wts), _p(top_idx), _p(logits), _p(a1), _p(a2), _p(fin),
+                                            _p(g_cs), _p(g_eq), _p(gw), B, N, Fd, K, _p(gsim), _p(dinp), _p(slab), _p(gmlp),
+                                            _p(ghs), _p(ght), _p(gxs), _p(gxt), _stream()), "head_backward")
+        grads, off = [], 0
+        for shp in ctx.mlp_shapes:
+            n = 1
+            for d in shp:
+                n *= d
+            grads.append(gmlp[off:off + n].view(shp))
+            off += n
+        return (ghs, ght, gxs, gxt, None, None, None, None, None, *grads)
+
+
+def fused_pose_head(hs, ht, xs, xt, raw_hs, raw_ht, labels, gt_pose, topk, mlp_params):
+    return _HeadFn.apply(hs, ht, xs, xt, raw_hs, raw_ht, labels, gt_pose, topk, *mlp_params)

@@ -74,8 +74,9 @@ def unsorted_segment_mean(data, segment_ids, num_segments):
 
 # ------------------------------------------------------------------------------ pair model
 class CrossAttentionPoseRegression(nn.Module):
-    def __init__(self, egnn, num_nodes=2048, hidden_nf=33, device="cuda:0", variant="train", topk=128):
+    def __init__(self, egnn, num_nodes=2048, hidden_nf=33, device="cuda:0", variant="train", topk=128, fused_head=True):
         super().__init__()
+        self.fused_head = fused_head
         if variant not in ("train", "eval"):
             raise ValueError("variant must be 'train' or 'eval'")
         self.egnn, self.hidden_nf, self.num_nodes, self.device = egnn, hidden_nf, num_nodes, device
@@ -122,6 +123,15 @@ class CrossAttentionPoseRegression(nn.Module):
         B, N, Fd = h_src.shape
         raw_h_src, raw_h_tgt = h_src, h_tgt
         hs, xs, ht, xt = self._run_egnn(h_src, x_src, edges_src, edge_attr_src, h_tgt, x_tgt, edges_tgt, edge_attr_tgt)
+        if self.fused_head and hs.shape[-1] <= 64 and self.topk <= min(256, N) and N <= 16384 and \
+                self.mlp[0].in_features == 2 * hs.shape[-1]:
+            # one HIP head (csrc/head.hip) instead of ~220 small ATen launches; same math as the lines below
+            mlp_params = [self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias,
+                          self.mlp[4].weight, self.mlp[4].bias]
+            R, t, closs, total_loss, logits, top_idx = ops.fused_pose_head(hs, ht, xs, xt, raw_h_src, raw_h_tgt, labels,
+                                                                           gt_pose, self.topk, mlp_params)
+            self.last_logits, self.last_top_idx = logits.detach(), top_idx
+            return R, t, closs, total_loss, hs, xs, ht, xt, labels
         total_loss = egnn_equi_loss(hs, xs, ht, xt, gt_pose[:, :3, :3], gt_pose[:, :3, -1], labels)       # :677
         sim = torch.sum(hs * ht, dim=-1, keepdim=True)                                                     # :681
         raw_sim = torch.sum(raw_h_src * raw_h_tgt, dim=-1, keepdim=True)                                   # :682

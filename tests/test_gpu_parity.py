@@ -354,3 +354,37 @@ def test_backward_random_graph_vs_oracle_autograd(pk):
 def test_smoke_entry(pk):
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+# ------------------------------------------------------------------------------------ fused head
+@pytest.mark.parametrize("name", ["pair_n512_k12_l2_wellcond.npz", "pair_n2048_k20_l4.npz"])
+def test_fused_head_matches_aten_head(pk, golden_dir, name):
+    """csrc/head.hip against the same head written with PyTorch-ROCm ops (fused_head=False): forward values,
+    and all gradients of corr+sim+equi+pose losses (the equi term exercises the optional g_equi path)."""
+    fx = np.load(os.path.join(golden_dir, name))
+    res = {}
+    for fused in (True, False):
+        models = _pair_models(pk, fx)
+        mt = models["train"]
+        mt.fused_head = fused
+        args = _pair_inputs(pk, fx)
+        R, t, closs, equi, hs, xs, ht, xt, _ = mt(*args)
+        rl, tl = pk.pose_loss(R, t, args[-1])
+        wcond = "wellcond" in name
+        loss = closs + 0.5 * equi + ((rl.mean() + tl.mean()) if wcond else (R * 0.3).sum() + (t * 0.7).sum())
+        mt.zero_grad()
+        loss.backward()
+        res[fused] = dict(R=R.detach(), t=t.detach(), closs=closs.detach(), equi=equi.detach(), idx=mt.last_top_idx.clone(),
+                          logits=mt.last_logits.clone(), g=mt.egnn.flat_grads.clone(),
+                          gm=torch.cat([p.grad.reshape(-1) for p in mt.mlp.parameters()]))
+    a, b = res[True], res[False]
+    assert set(a["idx"][0].tolist()) == set(b["idx"][0].tolist())
+    o1, o2 = torch.sort(a["idx"][0])[1], torch.sort(b["idx"][0])[1]
+    assert torch.allclose(a["logits"][0][o1], b["logits"][0][o2], rtol=1e-4, atol=1e-4 * float(b["logits"].abs().max()))
+    assert torch.allclose(a["R"], b["R"], atol=2e-5) and torch.allclose(a["t"], b["t"], atol=2e-5)
+    assert torch.allclose(a["closs"], b["closs"], rtol=2e-4, atol=1e-5)
+    assert torch.allclose(a["equi"], b["equi"], rtol=2e-4, atol=1e-5)
+    for key in ("g", "gm"):
+        scale = float(b[key].abs().max())
+        err = float((a[key] - b[key]).abs().max())
+        assert err <= 2e-3 * scale + 1e-7, f"{name} {key}: err {err:.3e} scale {scale:.3e}"
