@@ -155,8 +155,9 @@ int equigspr_kabsch_backward(const float* src, const float* tgt, const float* w,
  *   hs,ht [B,N,F]  raw_hs,raw_ht [B,N,F_raw]  xs,xt [B,N,3]  labels [B,N] (0/1)  gt_pose [B,16]
  *   mlp: flat [w1 (F x 2F), b1, w2 (F/2 x F), b2, w3 (F/2), b3]  (equigspr_head_mlp_size floats)
  * Outputs kept for backward: sim,rsim,cosv [B,N], pos int32 [B,N], wts [B,N], top_idx int64 [B,K],
- * logits [B,K], a1 [B,K,F], a2 [B,K,F/2]; out_scalars[0] = corr_loss+sim_loss, [1] = equi loss,
- * [2..7] = statistics reused by the backward.  work: equigspr_head_work_bytes bytes (8-byte aligned).
+ * logits [B,K], a1 [B,K,F], a2 [B,K,F/2]; out_scalars (16 floats): [0] = corr_loss+sim_loss, [1] = equi
+ * loss, [2..9] = statistics reused by the backward.  work: equigspr_head_work_bytes bytes (8-byte aligned),
+ * must be passed unchanged to the backward.  Limits: F <= 64, K <= min(256, N), N <= 4096.
  * Backward: g_corr_sim / g_equi are DEVICE scalars (may be NULL = 0); gw = dL/d wts from
  * equigspr_kabsch_backward; writes ghs,ght; ADDS the equi-loss terms into gxs,gxt (which hold the
  * Kabsch coordinate gradients); ADDS into grad_mlp. */
@@ -174,7 +175,7 @@ int equigspr_head_backward(const float* hs, const float* ht, const float* xs, co
                            const int64_t* top_idx, const float* logits, const float* a1_save,
                            const float* a2_save, const float* fin_scalars, const float* g_corr_sim,
                            const float* g_equi, const float* gw, int32_t B, int32_t N, int32_t F, int32_t K,
-                           float* gsim, float* dinp, float* mlp_slab, float* grad_mlp, float* ghs, float* ght,
+                           void* work, float* dinp, float* mlp_slab, float* grad_mlp, float* ghs, float* ght,
                            float* gxs, float* gxt, void* stream);
 
 /* ---- measurement hooks (bench.py's roofline leg; NOT part of the drop-in path) -----------

@@ -42,6 +42,15 @@ __device__ __forceinline__ float block_max_f(float v, float* red /*[4]*/) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K1: 8 nodes x 32 lanes per block (lane = feature, and feature+32), grid (ceil(N/8), B)
+// per-block fp64 partials: sum s, sum s^2, sum r, sum r^2, rot, feat, max_valid(s), sum_valid exp(s - max)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float grp32_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+    return v;
+}
+
 __global__ __launch_bounds__(256) void head_node_kernel(const float* __restrict__ hs, const float* __restrict__ ht,
                                                         const float* __restrict__ rhs, const float* __restrict__ rht,
                                                         const float* __restrict__ xs, const float* __restrict__ xt,
@@ -49,48 +58,60 @@ __global__ __launch_bounds__(256) void head_node_kernel(const float* __restrict_
                                                         int B, int N, int F, int Fr, float* __restrict__ sim,
                                                         float* __restrict__ rsim, float* __restrict__ cosv,
                                                         int* __restrict__ pos, double* __restrict__ partials) {
-    __shared__ double red[4];
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long M = (long long)B * N;
-    double p[6] = {0, 0, 0, 0, 0, 0};
-    if (i < M) {
-        const int b = (int)(i / N);
-        const float* a = hs + i * F;
-        const float* c = ht + i * F;
-        float s = 0.0f, na = 0.0f, nc = 0.0f;
-        for (int f = 0; f < F; ++f) { s = fmaf(a[f], c[f], s); na = fmaf(a[f], a[f], na); nc = fmaf(c[f], c[f], nc); }
-        float r = 0.0f;
-        const float* ra = rhs + i * Fr;
-        const float* rc = rht + i * Fr;
-        for (int f = 0; f < Fr; ++f) r = fmaf(ra[f], rc[f], r);
-        sim[i] = s;
-        rsim[i] = r;
-        pos[i] = -1;
-        const float y = labels[i];
-        const float cs = s / (fmaxf(sqrtf(na), 1e-8f) * fmaxf(sqrtf(nc), 1e-8f));       // F.cosine_similarity (:887)
-        cosv[i] = cs;
-        const float* G = gt_pose + (size_t)b * 16;
-        float ch = 0.0f;
-#pragma unroll
-        for (int r3 = 0; r3 < 3; ++r3) {
-            const float d = G[r3 * 4 + 0] * xs[i * 3 + 0] + G[r3 * 4 + 1] * xs[i * 3 + 1] + G[r3 * 4 + 2] * xs[i * 3 + 2] +
-                            G[r3 * 4 + 3] - xt[i * 3 + r3];
-            ch = fmaf(d, d, ch);
-        }
-        p[0] = s; p[1] = (double)s * s; p[2] = r; p[3] = (double)r * r; p[4] = (double)ch * y; p[5] = (double)(cs - y) * (cs - y);
+    __shared__ float nv[8][6];     // s, r, rot, feat, valid, (pad)
+    const int slot = threadIdx.x >> 5, f = threadIdx.x & 31;
+    const int b = blockIdx.y, n = blockIdx.x * 8 + slot;
+    const bool live = n < N;
+    const long long i = (long long)b * N + (live ? n : 0);
+    float s = 0.0f, na = 0.0f, nc = 0.0f, r = 0.0f;
+    if (live) {
+        for (int k = f; k < F; k += 32) { const float a = hs[i * F + k], c = ht[i * F + k]; s = fmaf(a, c, s); na = fmaf(a, a, na); nc = fmaf(c, c, nc); }
+        for (int k = f; k < Fr; k += 32) r = fmaf(rhs[i * Fr + k], rht[i * Fr + k], r);
     }
+    s = grp32_sum(s); na = grp32_sum(na); nc = grp32_sum(nc); r = grp32_sum(r);
+    if (f == 0) {
+        float rot = 0.0f, feat = 0.0f, y = 0.0f;
+        if (live) {
+            y = labels[i];
+            const float cs = s / (fmaxf(sqrtf(na), 1e-8f) * fmaxf(sqrtf(nc), 1e-8f));       // F.cosine_similarity (:887)
+            const float* G = gt_pose + (size_t)b * 16;
+            float ch = 0.0f;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const double t = block_sum_d(p[q], red);
-        if (threadIdx.x == 0) partials[(size_t)blockIdx.x * kHeadPartials + q] = t;
+            for (int r3 = 0; r3 < 3; ++r3) {
+                const float d = G[r3 * 4 + 0] * xs[i * 3 + 0] + G[r3 * 4 + 1] * xs[i * 3 + 1] + G[r3 * 4 + 2] * xs[i * 3 + 2] +
+                                G[r3 * 4 + 3] - xt[i * 3 + r3];
+                ch = fmaf(d, d, ch);
+            }
+            sim[i] = s; rsim[i] = r; cosv[i] = cs; pos[i] = -1;
+            rot = ch * y; feat = (cs - y) * (cs - y);
+        }
+        nv[slot][0] = live ? s : 0.0f; nv[slot][1] = live ? r : 0.0f; nv[slot][2] = rot; nv[slot][3] = feat;
+        nv[slot][4] = (live && y != 0.0f) ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double p[6] = {0, 0, 0, 0, 0, 0};
+        float mx = -INFINITY;
+        for (int q = 0; q < 8; ++q) {
+            const double sv = nv[q][0], rv = nv[q][1];
+            p[0] += sv; p[1] += sv * sv; p[2] += rv; p[3] += rv * rv; p[4] += nv[q][2]; p[5] += nv[q][3];
+            if (nv[q][4] != 0.0f) mx = fmaxf(mx, nv[q][0]);
+        }
+        double se = 0;
+        for (int q = 0; q < 8; ++q)
+            if (nv[q][4] != 0.0f) se += expf(nv[q][0] - mx);
+        double* out = partials + ((size_t)b * gridDim.x + blockIdx.x) * kHeadPartials;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) out[q] = p[q];
+        out[6] = mx; out[7] = se;
     }
 }
 
-// stats[0..3] = mean_s, std_s(unbiased), mean_r, std_r ; stats[4] = rot sum, stats[5] = feat sum
-__device__ __forceinline__ void head_stats(const double* __restrict__ partials, int n_blocks, long long M, double* red,
+// stats: mean_s, std_s (unbiased), mean_r, std_r, rot sum, feat sum  over ALL pairs
+__device__ __forceinline__ void head_stats(const double* __restrict__ partials, int n_rec, long long M, double* red,
                                            double (&st)[6]) {
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int k = threadIdx.x; k < n_blocks; k += 256)
+    for (int k = threadIdx.x; k < n_rec; k += 256)
 #pragma unroll
         for (int q = 0; q < 6; ++q) acc[q] += partials[(size_t)k * kHeadPartials + q];
 #pragma unroll
@@ -101,80 +122,115 @@ __device__ __forceinline__ void head_stats(const double* __restrict__ partials, 
 }
 
 struct MlpDims { int in, h1, h2; };     // in = 2F, h1 = F, h2 = F/2, out = 1
+constexpr int kCand = 512;              // candidate list of the radix select
 
-// LDS layout of head_pair kernels (floats):
-//   keys  u64 [Npad]          (fwd only)
-//   inp   [K][in+1], a1 [K][h1+1], a2 [K][h2+1], w1 [h1][in], w2 [h2][h1], w3[h2], biases
+// K2: one workgroup per pair: softmax scalars, top-K (radix select + small bitonic sort), MLP, BCE
 __global__ __launch_bounds__(256) void head_pair_kernel(
     const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
-    const float* __restrict__ sim, const float* __restrict__ rsim, const double* __restrict__ partials, int n_blocks_a,
+    const float* __restrict__ sim, const double* __restrict__ partials, int nbp,
     const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
     const float* __restrict__ w3, const float* __restrict__ b3, int B, int N, int Npad, int F, int K, MlpDims md,
-    float* __restrict__ wts, int* __restrict__ pos, long long* __restrict__ top_idx, float* __restrict__ logits,
-    float* __restrict__ a1_save, float* __restrict__ a2_save, double* __restrict__ pair_part /*[B][4]*/) {
+    int* __restrict__ pos, long long* __restrict__ top_idx, float* __restrict__ logits,
+    float* __restrict__ a1_save, float* __restrict__ a2_save, float* __restrict__ pair_f /*[B][4]*/,
+    double* __restrict__ pair_part /*[B][2]*/, float* __restrict__ fin) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double red[4];
     __shared__ float redf[4];
+    __shared__ unsigned hist[256];
+    __shared__ int sel[3];
     const int b = blockIdx.x, tid = threadIdx.x;
     const long long M = (long long)B * N;
     const float* sb = sim + (size_t)b * N;
-    const float* rb = rsim + (size_t)b * N;
     const float* yb = labels + (size_t)b * N;
-    u64* keys = reinterpret_cast<u64*>(smem_raw);
-    float* fl = reinterpret_cast<float*>(smem_raw + sizeof(u64) * (size_t)Npad);
+    u64* keys = reinterpret_cast<u64*>(smem_raw);                                   // [Npad] (fallback) / candidates
+    unsigned* khi = reinterpret_cast<unsigned*>(smem_raw + sizeof(u64) * (size_t)(Npad > kCand ? Npad : kCand));   // [N]
+    float* fl = reinterpret_cast<float*>(khi + N);
     const int ld_in = md.in + 1, ld1 = md.h1 + 1, ld2 = md.h2 + 1;
     float* inp = fl;
     float* a1 = inp + K * ld_in;
     float* a2 = a1 + K * ld1;
-    float* W1 = a2 + K * ld2;
-    float* W2 = W1 + md.h1 * md.in;
-    float* W3 = W2 + md.h2 * md.h1;
+    float* W1 = a2 + K * ld2;            // transposed: [in][h1+1]
+    float* W2 = W1 + md.in * ld1;        // transposed: [h1][h2+1]
+    float* W3 = W2 + md.h1 * ld2;
     float* Bs = W3 + md.h2;              // b1 | b2 | b3
 
     double st[6];
-    head_stats(partials, n_blocks_a, M, red, st);
-    const float mu_s = (float)st[0], sd_s = (float)st[1], mu_r = (float)st[2], sd_r = (float)st[3];
-
-    // ---- similarity-MSE partials (:777-781) and masked softmax (:717-724)
-    double sq = 0, se = 0, ses = 0;
+    head_stats(partials, B * nbp, M, red, st);
+    // ---- masked softmax scalars from the per-block (max, sum exp) records of this pair (:717-724)
+    const double* pp = partials + (size_t)b * nbp * kHeadPartials;
     float mx = -INFINITY;
-    for (int i = tid; i < N; i += 256) {
-        const float zs = (sb[i] - mu_s) / (sd_s + 1e-6f), zr = (rb[i] - mu_r) / (sd_r + 1e-6f);
-        const float e = zs - zr;
-        sq += (double)e * e; se += e; ses += (double)e * (sb[i] - mu_s);
-        if (yb[i] != 0.0f) mx = fmaxf(mx, sb[i]);
-        keys[i] = ((u64)(~orderable(sb[i])) << 32) | (unsigned)i;       // ascending key == descending sim, then index
-    }
-    for (int i = N + tid; i < Npad; i += 256) keys[i] = ~0ull;
-    sq = block_sum_d(sq, red); se = block_sum_d(se, red); ses = block_sum_d(ses, red);
+    for (int k = tid; k < nbp; k += 256) mx = fmaxf(mx, (float)pp[(size_t)k * kHeadPartials + 6]);
     mx = block_max_f(mx, redf);
     double den = 0;
-    for (int i = tid; i < N; i += 256)
-        if (yb[i] != 0.0f) den += expf(sb[i] - mx);
+    for (int k = tid; k < nbp; k += 256) {
+        const float bm = (float)pp[(size_t)k * kHeadPartials + 6];
+        if (bm > -INFINITY) den += pp[(size_t)k * kHeadPartials + 7] * (double)expf(bm - mx);
+    }
     den = block_sum_d(den, red);
-    double usum = 0;
-    for (int i = tid; i < N; i += 256) {
-        const float u = (yb[i] != 0.0f && den > 0.0) ? expf(sb[i] - mx) / (float)den : 0.0f;
-        usum += u;
+    if (tid == 0) {
+        float* pf = pair_f + (size_t)b * 4;
+        pf[0] = mx; pf[1] = (float)den; pf[2] = (den > 0.0) ? 1.0f : 0.0f; pf[3] = 0.0f;
+        if (b == 0) { fin[2] = (float)st[0]; fin[3] = (float)st[1]; fin[4] = (float)st[2]; fin[5] = (float)st[3]; fin[8] = (float)st[4]; fin[9] = (float)st[5]; }
     }
-    usum = block_sum_d(usum, red);
-    const float S = (float)usum;
-    for (int i = tid; i < N; i += 256) {
-        const float u = (yb[i] != 0.0f && den > 0.0) ? expf(sb[i] - mx) / (float)den : 0.0f;
-        wts[(size_t)b * N + i] = u / (S + 1e-6f);
-    }
-    // ---- stage the MLP weights while the sort runs
-    for (int t = tid; t < md.h1 * md.in; t += 256) W1[t] = w1[t];
-    for (int t = tid; t < md.h2 * md.h1; t += 256) W2[t] = w2[t];
+    // ---- stage the MLP weights: W1^T [in][h1+1], W2^T [h1][h2+1] (bank-conflict-free for lane = output)
+    for (int t = tid; t < md.h1 * md.in; t += 256) { const int o = t / md.in, i = t - o * md.in; W1[i * ld1 + o] = w1[t]; }
+    for (int t = tid; t < md.h2 * md.h1; t += 256) { const int o = t / md.h1, i = t - o * md.h1; W2[i * ld2 + o] = w2[t]; }
     for (int t = tid; t < md.h2; t += 256) W3[t] = w3[t];
     for (int t = tid; t < md.h1; t += 256) Bs[t] = b1[t];
     for (int t = tid; t < md.h2; t += 256) Bs[md.h1 + t] = b2[t];
     if (tid == 0) Bs[md.h1 + md.h2] = b3[0];
-    // ---- full bitonic sort of the keys
+    // ---- top-K (:684): ascending key == descending sim, then lower index.  MSB radix select on the value
+    //      bits finds the K-th value T; candidates {v < T} + {v == T} are sorted exactly; if more than kCand
+    //      candidates tie (degenerate inputs) fall back to a full bitonic sort.
+    for (int i = tid; i < N; i += 256) khi[i] = ~orderable(sb[i]);
+    unsigned prefix = 0, mask = 0;
+    int need = K;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < N; i += 256) {
+            const unsigned v = khi[i];
+            if ((v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, bin = 255;
+            for (int q = 0; q < 256; ++q) {
+                const int c = (int)hist[q];
+                if (cum + c >= need) { bin = q; break; }
+                cum += c;
+            }
+            sel[0] = bin; sel[1] = cum; sel[2] = (int)hist[bin];
+        }
+        __syncthreads();
+        need -= sel[1];
+        prefix |= (unsigned)sel[0] << shift;
+        mask |= 255u << shift;
+    }
+    const int n_less = K - need, n_tie = sel[2];
+    const int total = n_less + n_tie;
+    int P;
+    if (total <= kCand) {
+        if (tid == 0) sel[0] = 0;
+        __syncthreads();
+        for (int i = tid; i < N; i += 256) {
+            const unsigned v = khi[i];
+            if (v <= prefix) keys[atomicAdd(&sel[0], 1)] = ((u64)v << 32) | (unsigned)i;
+        }
+        P = 2;
+        while (P < total) P <<= 1;
+        __syncthreads();
+        for (int i = total + tid; i < P; i += 256) keys[i] = ~0ull;
+    } else {
+        for (int i = tid; i < N; i += 256) keys[i] = ((u64)khi[i] << 32) | (unsigned)i;
+        for (int i = N + tid; i < Npad; i += 256) keys[i] = ~0ull;
+        P = Npad;
+    }
     __syncthreads();
-    for (int k2 = 2; k2 <= Npad; k2 <<= 1) {
+    for (int k2 = 2; k2 <= P; k2 <<= 1) {
         for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < Npad / 2; t += 256) {
+            for (int t = tid; t < P / 2; t += 256) {
                 const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const int hi = lo | j;
                 const bool up = (lo & k2) == 0;
@@ -197,11 +253,11 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
         pos[(size_t)b * N + idx] = tid;
     }
     __syncthreads();
-    // ---- MLP: Linear-ReLU-Linear-ReLU-Linear (:594-600); thread = (row j, output chunk)
+    // ---- MLP: Linear-ReLU-Linear-ReLU-Linear (:594-600)
     for (int t = tid; t < K * md.h1; t += 256) {
         const int j = t / md.h1, o = t - j * md.h1;
         float acc = Bs[o];
-        for (int i = 0; i < md.in; ++i) acc = fmaf(W1[o * md.in + i], inp[j * ld_in + i], acc);
+        for (int i = 0; i < md.in; ++i) acc = fmaf(W1[i * ld1 + o], inp[j * ld_in + i], acc);
         acc = fmaxf(acc, 0.0f);
         a1[j * ld1 + o] = acc;
         a1_save[((size_t)b * K + j) * md.h1 + o] = acc;
@@ -210,7 +266,7 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
     for (int t = tid; t < K * md.h2; t += 256) {
         const int j = t / md.h2, o = t - j * md.h2;
         float acc = Bs[md.h1 + o];
-        for (int i = 0; i < md.h1; ++i) acc = fmaf(W2[o * md.h1 + i], a1[j * ld1 + i], acc);
+        for (int i = 0; i < md.h1; ++i) acc = fmaf(W2[i * ld2 + o], a1[j * ld1 + i], acc);
         acc = fmaxf(acc, 0.0f);
         a2[j * ld2 + o] = acc;
         a2_save[((size_t)b * K + j) * md.h2 + o] = acc;
@@ -226,53 +282,67 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
         bce = fmaxf(z, 0.0f) - z * y + log1pf(expf(-fabsf(z)));                          // BCEWithLogits (:772-773)
     }
     bce = block_sum_d(bce, red);
-    if (tid == 0) {
-        double* pp = pair_part + (size_t)b * 4;
-        pp[0] = bce; pp[1] = sq; pp[2] = se; pp[3] = ses;
-    }
+    if (tid == 0) pair_part[(size_t)b * 2] = bce;
 }
 
-// out[0] = corr_loss + sim_loss, out[1] = equi loss, out[2..7] = mu_s, sd_s, mu_r, sd_r, sum e, sum e (s - mu_s)
-__global__ __launch_bounds__(256) void head_finalize_kernel(const double* __restrict__ partials, int n_blocks_a,
+// K3: one thread per node: Kabsch weights (:718-724) and the similarity-MSE partial sums (:777-781)
+__global__ __launch_bounds__(256) void head_weights_kernel(const float* __restrict__ sim, const float* __restrict__ rsim,
+                                                           const float* __restrict__ labels, const float* __restrict__ pair_f,
+                                                           const float* __restrict__ fin, int B, int N,
+                                                           float* __restrict__ wts, double* __restrict__ partC) {
+    __shared__ double red[4];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long M = (long long)B * N;
+    double q0 = 0, q1 = 0, q2 = 0;
+    if (i < M) {
+        const int b = (int)(i / N);
+        const float mx = pair_f[b * 4], den = pair_f[b * 4 + 1], Su = pair_f[b * 4 + 2];
+        const float s = sim[i];
+        const float u = (labels[i] != 0.0f && den > 0.0f) ? expf(s - mx) / den : 0.0f;
+        wts[i] = u / (Su + 1e-6f);
+        const float zs = (s - fin[2]) / (fin[3] + 1e-6f), zr = (rsim[i] - fin[4]) / (fin[5] + 1e-6f);
+        const float e = zs - zr;
+        q0 = (double)e * e; q1 = e; q2 = (double)e * (s - fin[2]);
+    }
+    q0 = block_sum_d(q0, red); q1 = block_sum_d(q1, red); q2 = block_sum_d(q2, red);
+    if (threadIdx.x == 0) { partC[(size_t)blockIdx.x * 3] = q0; partC[(size_t)blockIdx.x * 3 + 1] = q1; partC[(size_t)blockIdx.x * 3 + 2] = q2; }
+}
+
+// out[0] = corr_loss + sim_loss, out[1] = equi loss, out[2..5] = mu_s, sd_s, mu_r, sd_r (written by K2),
+// out[6] = sum e, out[7] = sum e (s - mu_s), out[8], out[9] = rot / feat sums (written by K2)
+__global__ __launch_bounds__(256) void head_finalize_kernel(const double* __restrict__ partC, int nC,
                                                             const double* __restrict__ pair_part, int B, int N, int K,
                                                             float* __restrict__ out) {
     __shared__ double red[4];
     const long long M = (long long)B * N;
-    double st[6];
-    head_stats(partials, n_blocks_a, M, red, st);
-    double acc[4] = {0, 0, 0, 0};
-    for (int b = threadIdx.x; b < B; b += 256)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] += pair_part[(size_t)b * 4 + q];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = block_sum_d(acc[q], red);
+    double a0 = 0, a1 = 0, a2 = 0, bce = 0;
+    for (int k = threadIdx.x; k < nC; k += 256) { a0 += partC[(size_t)k * 3]; a1 += partC[(size_t)k * 3 + 1]; a2 += partC[(size_t)k * 3 + 2]; }
+    for (int b = threadIdx.x; b < B; b += 256) bce += pair_part[(size_t)b * 2];
+    a0 = block_sum_d(a0, red); a1 = block_sum_d(a1, red); a2 = block_sum_d(a2, red); bce = block_sum_d(bce, red);
     if (threadIdx.x == 0) {
-        out[0] = (float)(acc[0] / ((double)B * K) + acc[1] / (double)M);
-        out[1] = (float)(st[4] / (double)M + st[5] / (double)M);
-        out[2] = (float)st[0]; out[3] = (float)st[1]; out[4] = (float)st[2]; out[5] = (float)st[3];
-        out[6] = (float)acc[2]; out[7] = (float)acc[3];
+        out[0] = (float)(bce / ((double)B * K) + a0 / (double)M);
+        out[1] = (float)(((double)out[8] + (double)out[9]) / (double)M);
+        out[6] = (float)a1; out[7] = (float)a2;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------
+// KB1: per pair: gwu = sum_i gw_i u_i ; BCE + MLP backward on the K rows ; MLP weight-gradient slab
 // mlp slab per pair: dW1 [h1*in] | db1 [h1] | dW2 [h2*h1] | db2 [h2] | dW3 [h2] | db3 [1]
 __global__ __launch_bounds__(256) void head_pair_bwd_kernel(
     const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
-    const float* __restrict__ sim, const float* __restrict__ rsim, const float* __restrict__ wts,
-    const float* __restrict__ gw, const long long* __restrict__ top_idx, const float* __restrict__ logits,
-    const float* __restrict__ a1_save, const float* __restrict__ a2_save, const float* __restrict__ w1,
-    const float* __restrict__ w2, const float* __restrict__ w3, const float* __restrict__ fin /*[8]*/,
-    const float* __restrict__ g_cs_ptr, int B, int N, int F, int K, MlpDims md, float* __restrict__ gsim,
-    float* __restrict__ dinp /*[B][K][in]*/, float* __restrict__ mlp_slab) {
+    const float* __restrict__ sim, const float* __restrict__ pair_f, const float* __restrict__ gw,
+    const long long* __restrict__ top_idx, const float* __restrict__ logits, const float* __restrict__ a1_save,
+    const float* __restrict__ a2_save, const float* __restrict__ w1, const float* __restrict__ w2,
+    const float* __restrict__ w3, const float* __restrict__ g_cs_ptr, int B, int N, int F, int K, MlpDims md,
+    float* __restrict__ pair_g /*[B]*/, float* __restrict__ dinp /*[B][K][in]*/, float* __restrict__ mlp_slab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double red[4];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const long long M = (long long)B * N;
     const float g_cs = g_cs_ptr ? g_cs_ptr[0] : 0.0f;
     const float* sb = sim + (size_t)b * N;
-    const float* rb = rsim + (size_t)b * N;
     const float* yb = labels + (size_t)b * N;
     const float* gwb = gw + (size_t)b * N;
     float* fl = reinterpret_cast<float*>(smem_raw);
@@ -283,53 +353,17 @@ __global__ __launch_bounds__(256) void head_pair_bwd_kernel(
     float* d1 = a2 + K * ld2;            // d pre-activation 1  [K][h1+1]
     float* d2 = d1 + K * ld1;            // d pre-activation 2  [K][h2+1]
     float* dz = d2 + K * ld2;            // [K]
-    float* W1 = dz + K;
-    float* W2 = W1 + md.h1 * md.in;
+    float* W1 = dz + K;                  // row-major [h1][in]: reads are lane-consecutive in `in`
+    float* W2 = W1 + md.h1 * md.in;      // row-major [h2][h1]
     float* W3 = W2 + md.h2 * md.h1;
 
-    // ---- weights softmax backward: w = u / (Su + eps), u = softmax_valid(sim) (recomputed as in forward)
-    //      gu_i = gw_i/(Su+eps) - (sum_j gw_j u_j)/(Su+eps)^2 ; gscore_i = u_i (gu_i - sum_j gu_j u_j)
-    __shared__ float redf[4];
-    float mx = -INFINITY;
+    const float mx = pair_f[b * 4], den = pair_f[b * 4 + 1];
+    double gwu = 0;
     for (int i = tid; i < N; i += 256)
-        if (yb[i] != 0.0f) mx = fmaxf(mx, sb[i]);
-    mx = block_max_f(mx, redf);
-    double den = 0;
-    for (int i = tid; i < N; i += 256)
-        if (yb[i] != 0.0f) den += expf(sb[i] - mx);
-    den = block_sum_d(den, red);
-    const float fden = (float)den;
-    double Su = 0, gwu = 0;
-    for (int i = tid; i < N; i += 256) {
-        const float u = (yb[i] != 0.0f && fden > 0.0f) ? expf(sb[i] - mx) / fden : 0.0f;
-        Su += u;
-        gwu += (double)gwb[i] * u;
-    }
-    Su = block_sum_d(Su, red);
+        if (yb[i] != 0.0f && den > 0.0f) gwu += (double)gwb[i] * (double)(expf(sb[i] - mx) / den);
     gwu = block_sum_d(gwu, red);
-    const double sc = (double)((float)Su + 1e-6f);
-    double guu = 0;
-    for (int i = tid; i < N; i += 256) {
-        const float u = (yb[i] != 0.0f && fden > 0.0f) ? expf(sb[i] - mx) / fden : 0.0f;
-        const double gu = gwb[i] / sc - gwu / (sc * sc);
-        guu += gu * u;
-    }
-    guu = block_sum_d(guu, red);
-    // ---- similarity-MSE backward (:777-781)
-    const float mu_s = fin[2], sd_s = fin[3], mu_r = fin[4], sd_r = fin[5], sum_e = fin[6], sum_es = fin[7];
-    const float cmse = 2.0f / (float)M * g_cs;
-    const float inv_sd = 1.0f / (sd_s + 1e-6f);
-    const float k2 = (sd_s > 0.0f) ? sum_es * inv_sd * inv_sd / ((float)(M - 1) * sd_s) : 0.0f;
-    for (int i = tid; i < N; i += 256) {
-        const float u = (yb[i] != 0.0f && fden > 0.0f) ? expf(sb[i] - mx) / fden : 0.0f;
-        const double gu = gwb[i] / sc - gwu / (sc * sc);
-        float g = (float)(u * (gu - guu));
-        const float zs = (sb[i] - mu_s) * inv_sd, zr = (rb[i] - mu_r) / (sd_r + 1e-6f);
-        const float e = zs - zr;
-        g += cmse * ((e - sum_e / (float)M) * inv_sd - k2 * (sb[i] - mu_s));
-        gsim[(size_t)b * N + i] = g;
-    }
-    // ---- BCE + MLP backward on the K selected rows
+    if (tid == 0) pair_g[b] = (float)gwu;
+
     for (int t = tid; t < md.h1 * md.in; t += 256) W1[t] = w1[t];
     for (int t = tid; t < md.h2 * md.h1; t += 256) W2[t] = w2[t];
     for (int t = tid; t < md.h2; t += 256) W3[t] = w3[t];
@@ -389,53 +423,71 @@ __global__ __launch_bounds__(256) void head_pair_bwd_kernel(
     if (tid == 0) { float acc = 0.0f; for (int j = 0; j < K; ++j) acc += dz[j]; p[0] = acc; }
 }
 
+// KB2: 8 nodes x 32 lanes per block: d sim (softmax + similarity-MSE), then d h_s, d h_t, d x_s, d x_t
 __global__ __launch_bounds__(256) void head_node_bwd_kernel(
     const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ xs, const float* __restrict__ xt,
-    const float* __restrict__ labels, const float* __restrict__ gt_pose, const float* __restrict__ gsim,
-    const float* __restrict__ cosv, const int* __restrict__ pos, const float* __restrict__ dinp,
+    const float* __restrict__ labels, const float* __restrict__ gt_pose, const float* __restrict__ sim,
+    const float* __restrict__ rsim, const float* __restrict__ cosv, const int* __restrict__ pos,
+    const float* __restrict__ dinp, const float* __restrict__ gw, const float* __restrict__ pair_f,
+    const float* __restrict__ pair_g, const float* __restrict__ fin, const float* __restrict__ g_cs_ptr,
     const float* __restrict__ g_equi_ptr, int B, int N, int F, int K, int in_dim, float* __restrict__ ghs,
     float* __restrict__ ght, float* __restrict__ gxs /* += */, float* __restrict__ gxt /* += */) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int slot = threadIdx.x >> 5, f = threadIdx.x & 31;
+    const int b = blockIdx.y, n = blockIdx.x * 8 + slot;
+    if (n >= N) return;
+    const long long i = (long long)b * N + n;
     const long long M = (long long)B * N;
-    if (i >= M) return;
-    const int b = (int)(i / N);
     const float g_eq = g_equi_ptr ? g_equi_ptr[0] : 0.0f;
-    const float gs = gsim[i];
+    const float g_cs = g_cs_ptr ? g_cs_ptr[0] : 0.0f;
+    const float y = labels[i], s = sim[i];
+    // softmax-normalised weights backward
+    const float mx = pair_f[b * 4], den = pair_f[b * 4 + 1], Su = pair_f[b * 4 + 2], gwu = pair_g[b];
+    const float sc = Su + 1e-6f;
+    const float u = (y != 0.0f && den > 0.0f) ? expf(s - mx) / den : 0.0f;
+    const float gu = gw[i] / sc - gwu / (sc * sc);
+    const float guu = gwu / sc - gwu * Su / (sc * sc);
+    float gs = u * (gu - guu);
+    // similarity-MSE backward (:777-781): zs = (s - mu)/(sd + eps), sd unbiased over all B*N
+    {
+        const float mu_s = fin[2], sd_s = fin[3], mu_r = fin[4], sd_r = fin[5], sum_e = fin[6], sum_es = fin[7];
+        const float inv_sd = 1.0f / (sd_s + 1e-6f);
+        const float zs = (s - mu_s) * inv_sd, zr = (rsim[i] - mu_r) / (sd_r + 1e-6f);
+        const float e = zs - zr;
+        const float k2 = (sd_s > 0.0f) ? sum_es * inv_sd * inv_sd / ((float)(M - 1) * sd_s) : 0.0f;
+        gs += (2.0f / (float)M * g_cs) * ((e - sum_e / (float)M) * inv_sd - k2 * (s - mu_s));
+    }
     const int pj = pos[i];
     const float* a = hs + i * F;
     const float* c = ht + i * F;
     float ka = 0.0f, kc = 0.0f, kx = 0.0f;     // feature-loss (cosine) terms
     if (g_eq != 0.0f) {
-        float s = 0.0f, na = 0.0f, nc = 0.0f;
-        for (int f = 0; f < F; ++f) { s = fmaf(a[f], c[f], s); na = fmaf(a[f], a[f], na); nc = fmaf(c[f], c[f], nc); }
+        float na = 0.0f, nc = 0.0f;
+        for (int k = f; k < F; k += 32) { na = fmaf(a[k], a[k], na); nc = fmaf(c[k], c[k], nc); }
+        na = grp32_sum(na); nc = grp32_sum(nc);
         const float la = fmaxf(sqrtf(na), 1e-8f), lc = fmaxf(sqrtf(nc), 1e-8f);
         const float cs = cosv[i];
-        const float gcos = g_eq * 2.0f * (cs - labels[i]) / (float)M;
+        const float gcos = g_eq * 2.0f * (cs - y) / (float)M;
         kx = gcos / (la * lc);                 // d cos/da = c/(|a||c|) - cos a/|a|^2
         ka = gcos * cs / (la * la);
         kc = gcos * cs / (lc * lc);
     }
     const float* dj = (pj >= 0) ? dinp + ((size_t)b * K + pj) * in_dim : nullptr;
-    for (int f = 0; f < F; ++f) {
-        float ga = gs * c[f] + kx * c[f] - ka * a[f];
-        float gc = gs * a[f] + kx * a[f] - kc * c[f];
-        if (dj) { ga += dj[f]; gc += dj[F + f]; }
-        ghs[i * F + f] = ga;
-        ght[i * F + f] = gc;
+    for (int k = f; k < F; k += 32) {
+        float ga = gs * c[k] + kx * c[k] - ka * a[k];
+        float gc = gs * a[k] + kx * a[k] - kc * c[k];
+        if (dj) { ga += dj[k]; gc += dj[F + k]; }
+        ghs[i * F + k] = ga;
+        ght[i * F + k] = gc;
     }
-    if (g_eq != 0.0f) {                        // rotation-consistency term (:881-884)
+    if (g_eq != 0.0f && f < 3) {               // rotation-consistency term (:881-884)
         const float* G = gt_pose + (size_t)b * 16;
-        const float y = labels[i];
         float d[3];
 #pragma unroll
         for (int r3 = 0; r3 < 3; ++r3)
             d[r3] = G[r3 * 4 + 0] * xs[i * 3 + 0] + G[r3 * 4 + 1] * xs[i * 3 + 1] + G[r3 * 4 + 2] * xs[i * 3 + 2] + G[r3 * 4 + 3] - xt[i * 3 + r3];
         const float k = g_eq * 2.0f * y / (float)M;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            gxs[i * 3 + q] += k * (G[0 * 4 + q] * d[0] + G[1 * 4 + q] * d[1] + G[2 * 4 + q] * d[2]);
-            gxt[i * 3 + q] -= k * d[q];
-        }
+        gxs[i * 3 + f] += k * (G[0 * 4 + f] * d[0] + G[1 * 4 + f] * d[1] + G[2 * 4 + f] * d[2]);
+        gxt[i * 3 + f] -= k * d[f];
     }
 }
 
@@ -448,13 +500,30 @@ __global__ void head_mlp_reduce_kernel(const float* __restrict__ slab, int B, in
 }
 
 static inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
-static inline size_t fwd_smem(int Npad, int K, MlpDims md) {
-    return sizeof(u64) * (size_t)Npad + sizeof(float) * ((size_t)K * (md.in + 1) + (size_t)K * (md.h1 + 1) + (size_t)K * (md.h2 + 1) +
-                                                          (size_t)md.h1 * md.in + (size_t)md.h2 * md.h1 + md.h2 + md.h1 + md.h2 + 1 + 8);
+static inline size_t fwd_smem(int N, int Npad, int K, MlpDims md) {
+    const size_t keys = sizeof(u64) * (size_t)(Npad > kCand ? Npad : kCand);
+    return keys + sizeof(unsigned) * (size_t)N +
+           sizeof(float) * ((size_t)K * (md.in + 1) + (size_t)K * (md.h1 + 1) + (size_t)K * (md.h2 + 1) +
+                            (size_t)md.in * (md.h1 + 1) + (size_t)md.h1 * (md.h2 + 1) + md.h2 + md.h1 + md.h2 + 1 + 8);
 }
 static inline size_t bwd_smem(int K, MlpDims md) {
     return sizeof(float) * ((size_t)K * (md.in + 1) + 2 * (size_t)K * (md.h1 + 1) + 2 * (size_t)K * (md.h2 + 1) + K +
                             (size_t)md.h1 * md.in + (size_t)md.h2 * md.h1 + md.h2 + 8);
+}
+struct HeadWork { double *partA, *partC, *pair_part; float *pair_f, *pair_g; int nbp, nC; size_t bytes; };
+static inline HeadWork head_work(void* base, int B, int N) {
+    HeadWork w;
+    w.nbp = ceil_div(N, 8);
+    w.nC = ceil_div((long long)B * N, 256);
+    char* p = reinterpret_cast<char*>(base);
+    size_t o = 0;
+    w.partA = reinterpret_cast<double*>(p + o); o += sizeof(double) * (size_t)B * w.nbp * kHeadPartials;
+    w.partC = reinterpret_cast<double*>(p + o); o += sizeof(double) * (size_t)w.nC * 3;
+    w.pair_part = reinterpret_cast<double*>(p + o); o += sizeof(double) * (size_t)B * 2;
+    w.pair_f = reinterpret_cast<float*>(p + o); o += sizeof(float) * (size_t)B * 4;
+    w.pair_g = reinterpret_cast<float*>(p + o); o += sizeof(float) * (size_t)B;
+    w.bytes = o + 64;
+    return w;
 }
 
 }  // namespace eq
@@ -464,10 +533,8 @@ extern "C" int64_t equigspr_head_mlp_size(int32_t F) {
     return (int64_t)h1 * in + h1 + (int64_t)h2 * h1 + h2 + h2 + 1;
 }
 
-// workspace (doubles first): partials [nA][8] d | pair_part [B][4] d | then floats: fin[8]
 extern "C" int64_t equigspr_head_work_bytes(int32_t B, int32_t N) {
-    const int64_t nA = ((int64_t)B * N + 255) / 256;
-    return 8 * (nA * eq::kHeadPartials + (int64_t)B * 4) + 4 * 16;
+    return (int64_t)eq::head_work(nullptr, B, N).bytes;
 }
 
 extern "C" int equigspr_head_forward(const float* hs, const float* ht, const float* raw_hs, const float* raw_ht,
@@ -475,27 +542,25 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
                                      const float* mlp /* flat: w1,b1,w2,b2,w3,b3 */, int32_t B, int32_t N, int32_t F,
                                      int32_t F_raw, int32_t K, float* sim, float* rsim, float* cosv, int32_t* pos,
                                      float* wts, int64_t* top_idx, float* logits, float* a1_save, float* a2_save,
-                                     void* work, float* out_scalars /* [8] device */, void* stream) {
+                                     void* work, float* out_scalars /* [16] device */, void* stream) {
     using namespace eq;
     EQ_CHECK_ARG(hs && ht && raw_hs && raw_ht && xs && xt && labels && gt_pose && mlp && sim && rsim && cosv && pos && wts &&
                      top_idx && logits && a1_save && a2_save && work && out_scalars, EQUIGSPR_EINVAL, "head_forward: null pointer");
-    EQ_CHECK_ARG(B >= 1 && N >= 2 && F >= 2 && F <= 64 && F_raw >= 1 && K >= 1 && K <= kMaxK && K <= N && N <= 16384,
-                 EQUIGSPR_ENOTSUP, "head_forward: need 2<=F<=64, 1<=K<=min(256,N), N<=16384");
+    EQ_CHECK_ARG(B >= 1 && N >= 2 && F >= 2 && F <= 64 && F_raw >= 1 && F_raw <= 64 && K >= 1 && K <= kMaxK && K <= N && N <= 4096,
+                 EQUIGSPR_ENOTSUP, "head_forward: need 2<=F<=64, 1<=K<=min(256,N), N<=4096");
     hipStream_t s = (hipStream_t)stream;
     const MlpDims md{2 * F, F, F / 2};
-    const int nA = ceil_div((long long)B * N, 256);
-    double* partials = reinterpret_cast<double*>(work);
-    double* pair_part = partials + (size_t)nA * kHeadPartials;
+    const HeadWork W = head_work(work, B, N);
     const float* w1 = mlp;
     const float* b1 = w1 + md.h1 * md.in;
     const float* w2 = b1 + md.h1;
     const float* b2 = w2 + md.h2 * md.h1;
     const float* w3 = b2 + md.h2;
     const float* b3 = w3 + md.h2;
-    hipLaunchKernelGGL(head_node_kernel, dim3(nA), dim3(256), 0, s, hs, ht, raw_hs, raw_ht, xs, xt, labels, gt_pose, B, N, F,
-                       F_raw, sim, rsim, cosv, pos, partials);
+    hipLaunchKernelGGL(head_node_kernel, dim3(W.nbp, B), dim3(256), 0, s, hs, ht, raw_hs, raw_ht, xs, xt, labels, gt_pose, B, N,
+                       F, F_raw, sim, rsim, cosv, pos, W.partA);
     const int Npad = next_pow2(N);
-    const size_t sm = fwd_smem(Npad, K, md);
+    const size_t sm = fwd_smem(N, Npad, K, md);
     static size_t sm_set = 0;
     if (sm > sm_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_pair_kernel),
@@ -503,10 +568,12 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
         if (e != hipSuccess) { set_error("head_forward: %s", hipGetErrorString(e)); return (int)e; }
         sm_set = sm;
     }
-    hipLaunchKernelGGL(head_pair_kernel, dim3(B), dim3(256), sm, s, hs, ht, labels, sim, rsim, partials, nA, w1, b1, w2, b2, w3,
-                       b3, B, N, Npad, F, K, md, wts, pos, reinterpret_cast<long long*>(top_idx), logits, a1_save, a2_save,
-                       pair_part);
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, partials, nA, pair_part, B, N, K, out_scalars);
+    hipLaunchKernelGGL(head_pair_kernel, dim3(B), dim3(256), sm, s, hs, ht, labels, sim, W.partA, W.nbp, w1, b1, w2, b2, w3, b3,
+                       B, N, Npad, F, K, md, pos, reinterpret_cast<long long*>(top_idx), logits, a1_save, a2_save, W.pair_f,
+                       W.pair_part, out_scalars);
+    hipLaunchKernelGGL(head_weights_kernel, dim3(W.nC), dim3(256), 0, s, sim, rsim, labels, W.pair_f, out_scalars, B, N, wts,
+                       W.partC);
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, W.partC, W.nC, W.pair_part, B, N, K, out_scalars);
     EQ_CHECK_LAUNCH("head_forward");
     return 0;
 }
@@ -517,14 +584,15 @@ extern "C" int equigspr_head_backward(const float* hs, const float* ht, const fl
                                       const int64_t* top_idx, const float* logits, const float* a1_save,
                                       const float* a2_save, const float* fin_scalars, const float* g_corr_sim,
                                       const float* g_equi, const float* gw, int32_t B, int32_t N, int32_t F, int32_t K,
-                                      float* gsim, float* dinp, float* mlp_slab, float* grad_mlp /* += */, float* ghs,
-                                      float* ght, float* gxs /* += */, float* gxt /* += */, void* stream) {
+                                      void* work /* the forward's */, float* dinp, float* mlp_slab, float* grad_mlp /* += */,
+                                      float* ghs, float* ght, float* gxs /* += */, float* gxt /* += */, void* stream) {
     using namespace eq;
     EQ_CHECK_ARG(hs && ht && xs && xt && labels && gt_pose && mlp && sim && rsim && cosv && pos && wts && top_idx && logits &&
-                     a1_save && a2_save && fin_scalars && gw && gsim && dinp && mlp_slab && grad_mlp && ghs && ght && gxs && gxt,
+                     a1_save && a2_save && fin_scalars && gw && work && dinp && mlp_slab && grad_mlp && ghs && ght && gxs && gxt,
                  EQUIGSPR_EINVAL, "head_backward: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const MlpDims md{2 * F, F, F / 2};
+    const HeadWork W = head_work(work, B, N);
     const float* w1 = mlp;
     const float* w2 = w1 + md.h1 * md.in + md.h1;
     const float* w3 = w2 + md.h2 * md.h1 + md.h2;
@@ -536,12 +604,11 @@ extern "C" int equigspr_head_backward(const float* hs, const float* ht, const fl
         if (e != hipSuccess) { set_error("head_backward: %s", hipGetErrorString(e)); return (int)e; }
         sm_set = sm;
     }
-    hipLaunchKernelGGL(head_pair_bwd_kernel, dim3(B), dim3(256), sm, s, hs, ht, labels, sim, rsim, wts, gw,
-                       reinterpret_cast<const long long*>(top_idx), logits, a1_save, a2_save, w1, w2, w3, fin_scalars,
-                       g_corr_sim, B, N, F, K, md, gsim, dinp, mlp_slab);
-    const int nA = ceil_div((long long)B * N, 256);
-    hipLaunchKernelGGL(head_node_bwd_kernel, dim3(nA), dim3(256), 0, s, hs, ht, xs, xt, labels, gt_pose, gsim, cosv, pos, dinp,
-                       g_equi, B, N, F, K, md.in, ghs, ght, gxs, gxt);
+    hipLaunchKernelGGL(head_pair_bwd_kernel, dim3(B), dim3(256), sm, s, hs, ht, labels, sim, W.pair_f, gw,
+                       reinterpret_cast<const long long*>(top_idx), logits, a1_save, a2_save, w1, w2, w3, g_corr_sim, B, N, F, K,
+                       md, W.pair_g, dinp, mlp_slab);
+    hipLaunchKernelGGL(head_node_bwd_kernel, dim3(W.nbp, B), dim3(256), 0, s, hs, ht, xs, xt, labels, gt_pose, sim, rsim, cosv,
+                       pos, dinp, gw, W.pair_f, W.pair_g, fin_scalars, g_corr_sim, g_equi, B, N, F, K, md.in, ghs, ght, gxs, gxt);
     const int msz = (int)equigspr_head_mlp_size(F);
     hipLaunchKernelGGL(head_mlp_reduce_kernel, dim3(ceil_div(msz, 256)), dim3(256), 0, s, mlp_slab, B, msz, grad_mlp);
     EQ_CHECK_LAUNCH("head_backward");

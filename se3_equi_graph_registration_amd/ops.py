@@ -241,7 +241,7 @@ class _HeadFn(torch.autograd.Function):
         a1 = torch.empty(B, K, Fd, **f32)
         a2 = torch.empty(B, K, Fd // 2, **f32)
         work = torch.empty(int(L.equigspr_head_work_bytes(B, N)) // 8 + 1, dtype=torch.float64, device=dev)
-        fin = torch.empty(8, **f32)
+        fin = torch.empty(16, **f32)
         _lib.check(L.equigspr_head_forward(_p(hs), _p(ht), _p(raw_hs), _p(raw_ht), _p(xs), _p(xt), _p(labels), _p(gt),
                                            _p(flat), B, N, Fd, raw_hs.shape[2], K, _p(sim), _p(rsim), _p(cosv), _p(pos),
                                            _p(wts), _p(top_idx), _p(logits), _p(a1), _p(a2), _p(work), _p(fin), _stream()),
@@ -250,7 +250,7 @@ class _HeadFn(torch.autograd.Function):
         t = torch.empty(B, 3, **f32)
         aux = torch.empty(B, KABSCH_AUX, **f32)
         _lib.check(L.equigspr_kabsch_forward(_p(xs), _p(xt), _p(wts), B, N, _p(R), _p(t), _p(aux), _stream()), "kabsch_forward")
-        ctx.save_for_backward(hs, ht, xs, xt, labels, gt, flat, sim, rsim, cosv, pos, wts, top_idx, logits, a1, a2, fin, aux)
+        ctx.save_for_backward(hs, ht, xs, xt, labels, gt, flat, sim, rsim, cosv, pos, wts, top_idx, logits, a1, a2, fin, aux, work)
         ctx.dims = (B, N, Fd, K, msz)
         ctx.mlp_shapes = [tuple(q.shape) for q in mlp_params]
         ctx.mark_non_differentiable(top_idx, logits)      # the logits' only consumer (BCE) is inside the head
@@ -260,7 +260,7 @@ class _HeadFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gR, gt_, g_cs, g_eq, g_logits, _g_idx):
         L = _lib.lib()
-        (hs, ht, xs, xt, labels, gt, flat, sim, rsim, cosv, pos, wts, top_idx, logits, a1, a2, fin, aux) = ctx.saved_tensors
+        (hs, ht, xs, xt, labels, gt, flat, sim, rsim, cosv, pos, wts, top_idx, logits, a1, a2, fin, aux, work) = ctx.saved_tensors
         B, N, Fd, K, msz = ctx.dims
         dev = hs.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -270,7 +270,6 @@ class _HeadFn(torch.autograd.Function):
         _lib.check(L.equigspr_kabsch_backward(_p(xs), _p(xt), _p(wts), _p(aux), _p(gR), _p(gt_), B, N, _p(gxs), _p(gxt),
                                               _p(gw), _stream()), "kabsch_backward")
         ghs, ght = torch.empty_like(hs), torch.empty_like(ht)
-        gsim = torch.empty(B, N, **f32)
         dinp = torch.empty(B, K, 2 * Fd, **f32)
         slab = torch.empty(B, msz, **f32)
         gmlp = torch.zeros(msz, **f32)
@@ -278,7 +277,7 @@ class _HeadFn(torch.autograd.Function):
         g_eq = None if g_eq is None else g_eq.contiguous().float()
         _lib.check(L.equigspr_head_backward(_p(hs), _p(ht), _p(xs), _p(xt), _p(labels), _p(gt), _p(flat), _p(sim), _p(rsim),
                                             _p(cosv), _p(pos), _p(wts), _p(top_idx), _p(logits), _p(a1), _p(a2), _p(fin),
-                                            _p(g_cs), _p(g_eq), _p(gw), B, N, Fd, K, _p(gsim), _p(dinp), _p(slab), _p(gmlp),
+                                            _p(g_cs), _p(g_eq), _p(gw), B, N, Fd, K, _p(work), _p(dinp), _p(slab), _p(gmlp),
                                             _p(ghs), _p(ght), _p(gxs), _p(gxt), _stream()), "head_backward")
         grads, off = [], 0
         for shp in ctx.mlp_shapes:

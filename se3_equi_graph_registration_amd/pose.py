@@ -123,7 +123,7 @@ class CrossAttentionPoseRegression(nn.Module):
         B, N, Fd = h_src.shape
         raw_h_src, raw_h_tgt = h_src, h_tgt
         hs, xs, ht, xt = self._run_egnn(h_src, x_src, edges_src, edge_attr_src, h_tgt, x_tgt, edges_tgt, edge_attr_tgt)
-        if self.fused_head and hs.shape[-1] <= 64 and self.topk <= min(256, N) and N <= 16384 and \
+        if self.fused_head and hs.shape[-1] <= 64 and self.topk <= min(256, N) and N <= 4096 and \
                 self.mlp[0].in_features == 2 * hs.shape[-1]:
             # one HIP head (csrc/head.hip) instead of ~220 small ATen launches; same math as the lines below
             mlp_params = [self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias,
