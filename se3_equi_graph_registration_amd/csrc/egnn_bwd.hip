@@ -613,9 +613,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
     stage_tile_weights<H, A>(wsm, lw);
     __syncthreads();
     TileWeights<H, A> W;
-    TileWeightsBwd<H, A> WB;
     W.load(wsm, lane);
-    WB.load(wsm, lane);
 
     f32x16 acc6[1][1], acc2[1][1], accg[1][1];
     float cs_b6[1] = {0.0f}, cs_b2[1] = {0.0f}, cs_gam[1] = {0.0f}, cs_bet[1] = {0.0f}, cs_w7[1] = {0.0f}, cs_scr[1] = {0.0f};
@@ -624,6 +622,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
 
     const int n_tiles = (n_edges + 31) / 32;
     for (int tile = wave; tile < n_tiles; tile += n_waves) {
+        W.refresh();
         const int e_raw = tile * 32 + el;
         const bool valid = e_raw < n_edges;
         const int e = valid ? e_raw : n_edges - 1;
@@ -648,7 +647,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         for (int k = 0; k < 16; ++k) {
             const float sg = 1.0f / (1.0f + expf(-o.q[k]));
             pds[k] = o.q[k] * sg * ds;
-            dq[k] = W.w7[k] * ds * (sg * (1.0f + o.q[k] * (1.0f - sg)));
+            dq[k] = W.w7(k) * ds * (sg * (1.0f + o.q[k] * (1.0f - sg)));
         }
         stage_half_row(X + el * LD, h, dq);
         stage_half_row(Y + el * LD, h, o.m);
@@ -664,7 +663,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = da[k] * z;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(WB.w6t[s], dq[s], a, 0, 0, 0);
+            for (int s = 0; s < 16; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w6t(s), dq[s], a, 0, 0, 0);
 #pragma unroll
             for (int k = 0; k < 16; ++k) dm[k] = a[k];
         }
@@ -678,13 +677,17 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         __builtin_amdgcn_wave_barrier();
         tile_pass<1, 1, LD, false, 32>(X, Y, acc6, cs_w7, cs_gam, lane);          // dw7, dgamma (column sums only)
         __builtin_amdgcn_wave_barrier();
+        stage_half_row(X + el * LD, h, dm);
+        __builtin_amdgcn_wave_barrier();
+        tile_pass<1, 1, LD, false, 32>(X, Y, acc6, cs_bet, cs_scr, lane);         // dbeta = sum dm
+        __builtin_amdgcn_wave_barrier();
         // ---- LayerNorm backward
         float du[16];
         {
             float m1 = 0.0f, m2 = 0.0f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                du[k] = dm[k] * W.gam[k];
+                du[k] = dm[k] * W.gam(k);
                 m1 += du[k];
                 m2 = fmaf(du[k], o.xhat[k], m2);
             }
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = 0.0f;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(WB.w2t[s], du[s], a, 0, 0, 0);
+            for (int s = 0; s < 16; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w2t(s), du[s], a, 0, 0, 0);
 #pragma unroll
             for (int k = 0; k < 16; ++k) dt1[k] = a[k] * sg1[k];
         }
@@ -734,10 +737,6 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         __builtin_amdgcn_wave_barrier();
         tile_pass<1, 1, LD, true, 32>(X, Y, accg, cs_scr, cs_scr, lane);          // dWgeo|dwattr += dt1^T [geo, attr]
         __builtin_amdgcn_wave_barrier();
-        stage_half_row(X + el * LD, h, dm);
-        __builtin_amdgcn_wave_barrier();
-        tile_pass<1, 1, LD, false, 32>(X, Y, accg, cs_bet, cs_scr, lane);         // dbeta = sum dm
-        __builtin_amdgcn_wave_barrier();
         // ---- dgeo = Wgeo^T dt1 (rows 0..11 of a 32-row product), then the geometry backward
         float gg[kGeo];
         {
@@ -745,7 +744,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = 0.0f;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(WB.wgt[s], dt1[s], a, 0, 0, 0);
+            for (int s = 0; s < 16; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.wgt(s), dt1[s], a, 0, 0, 0);
             // lane half h holds geo rows fidx(k,h): h=0 -> 0..3 (k 0..3), 8..11 (k 4..7); h=1 -> 4..7 (k 0..3)
             float mine[8], other[8];
 #pragma unroll

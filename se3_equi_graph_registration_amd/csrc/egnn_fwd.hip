@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restr
     W.load(wsm, lane);
     const int tiles = (n_edges + 31) / 32;
     for (int tile = wave; tile < tiles; tile += n_waves) {
+        W.refresh();
         const int e_raw = tile * 32 + el;
         const bool valid = e_raw < n_edges;
         const int e = valid ? e_raw : n_edges - 1;

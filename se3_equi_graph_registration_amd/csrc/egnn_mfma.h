@@ -56,46 +56,30 @@ __device__ __forceinline__ void stage_tile_weights(float* sm, const float* __res
     }
 }
 
+// Operand accessors: the MFMA A operands and the per-feature vectors are fetched from the LDS image
+// right where they are used (one conflict-free ds_read per MFMA) instead of living in ~170 VGPRs,
+// which is what lets two to four waves share a SIMD.  `refresh()` re-materialises the base pointer
+// so the compiler cannot hoist the (loop-invariant) reads out of the tile loop back into registers.
 template <int H, int A>
 struct TileWeights {
-    float wg[7];                 // A operand of the geometry product: W1[i][2F + 2s+h]
-    float w2[16], w6[16];        // A operands: W2full[i][fidx(s,h)], W6[i][fidx(s,h)]
-    float b2[16], gam[16], bet[16], b6[16], w7[16];   // per-feature vectors in tile layout
-
-    __device__ __forceinline__ void load(const float* sm, int lane) {
-        using T = TileWeightsLds;
-        const int i = lane & 31, h = lane >> 5;
-#pragma unroll
-        for (int s = 0; s < 7; ++s) wg[s] = sm[T::o_geo + i * T::GS + 2 * s + h];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int k = fidx(s, h);
-            w2[s] = sm[T::o_w2 + i * T::WS + k];
-            w6[s] = sm[T::o_w6 + i * T::WS + k];
-            b2[s] = sm[T::o_vec + k];
-            gam[s] = sm[T::o_vec + 32 + k];
-            bet[s] = sm[T::o_vec + 64 + k];
-            b6[s] = sm[T::o_vec + 96 + k];
-            w7[s] = sm[T::o_vec + 128 + k];
-        }
-    }
-};
-
-template <int H, int A>
-struct TileWeightsBwd {
-    float w6t[16], w2t[16], wgt[16];   // A operands of the transposed products
-
-    __device__ __forceinline__ void load(const float* sm, int lane) {
-        using T = TileWeightsLds;
-        const int i = lane & 31, h = lane >> 5;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int k = fidx(s, h);
-            w6t[s] = sm[T::o_w6 + k * T::WS + i];                              // W6^T[i][k]
-            w2t[s] = sm[T::o_w2 + k * T::WS + i];                              // W2^T[i][k]
-            wgt[s] = (i < kGeo) ? sm[T::o_geo + k * T::GS + i] : 0.0f;         // Wgeo^T[g = i][k]
-        }
-    }
+    using T = TileWeightsLds;
+    const float* sm;
+    int i, h;
+    __device__ __forceinline__ void load(const float* s, int lane) { sm = s; i = lane & 31; h = lane >> 5; }
+    __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(sm)); }
+    __device__ __forceinline__ float wg(int s) const { return sm[T::o_geo + i * T::GS + 2 * s + h]; }
+    __device__ __forceinline__ float w2(int s) const { return sm[T::o_w2 + i * T::WS + fidx(s, h)]; }
+    __device__ __forceinline__ float w6(int s) const { return sm[T::o_w6 + i * T::WS + fidx(s, h)]; }
+    __device__ __forceinline__ float vec(int which, int r) const { return sm[T::o_vec + 32 * which + fidx(r, h)]; }
+    __device__ __forceinline__ float b2(int r) const { return vec(0, r); }
+    __device__ __forceinline__ float gam(int r) const { return vec(1, r); }
+    __device__ __forceinline__ float bet(int r) const { return vec(2, r); }
+    __device__ __forceinline__ float b6(int r) const { return vec(3, r); }
+    __device__ __forceinline__ float w7(int r) const { return vec(4, r); }
+    // transposed products of the backward
+    __device__ __forceinline__ float w6t(int s) const { return sm[T::o_w6 + fidx(s, h) * T::WS + i]; }
+    __device__ __forceinline__ float w2t(int s) const { return sm[T::o_w2 + fidx(s, h) * T::WS + i]; }
+    __device__ __forceinline__ float wgt(int s) const { return (i < kGeo) ? sm[T::o_geo + fidx(s, h) * T::GS + i] : 0.0f; }
 };
 
 // gather 16 of the 32 floats of a 128-byte row: features fidx(r,h), r = 0..15 (4 x 16-byte loads)
@@ -133,13 +117,13 @@ __device__ __forceinline__ void tile_forward(const TileWeights<H, A>& W, const f
         // B operand: z-geometry entry k = 2s+h of this lane's edge (12 geo values, then edge_attr)
         const float g0 = (2 * s < kGeo) ? eg.g[(2 * s < kGeo) ? 2 * s : 0] : ((2 * s == kGeo) ? attr : 0.0f);
         const float g1 = (2 * s + 1 < kGeo) ? eg.g[(2 * s + 1 < kGeo) ? 2 * s + 1 : 0] : ((2 * s + 1 == kGeo) ? attr : 0.0f);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W.wg[s], h ? g1 : g0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(W.wg(s), h ? g1 : g0, acc, 0, 0, 0);
     }
     f32x16 acc2, acc6;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o.t1[r] = acc[r]; acc2[r] = W.b2[r]; acc6[r] = W.b6[r]; }
+    for (int r = 0; r < 16; ++r) { o.t1[r] = acc[r]; acc2[r] = W.b2(r); acc6[r] = W.b6(r); }
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w2[s], silu(o.t1[s]), acc2, 0, 0, 0);
+    for (int s = 0; s < 16; ++s) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w2(s), silu(o.t1[s]), acc2, 0, 0, 0);
     float sum = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sum += acc2[r];
@@ -154,13 +138,13 @@ __device__ __forceinline__ void tile_forward(const TileWeights<H, A>& W, const f
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         o.xhat[r] = (acc2[r] - mean) * o.rstd;
-        o.m[r] = fmaf(o.xhat[r], W.gam[r], W.bet[r]);
+        o.m[r] = fmaf(o.xhat[r], W.gam(r), W.bet(r));
     }
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc6 = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w6[s], o.m[s], acc6, 0, 0, 0);
+    for (int s = 0; s < 16; ++s) acc6 = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w6(s), o.m[s], acc6, 0, 0, 0);
     float sp = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o.q[r] = acc6[r]; sp = fmaf(W.w7[r], silu(acc6[r]), sp); }
+    for (int r = 0; r < 16; ++r) { o.q[r] = acc6[r]; sp = fmaf(W.w7(r), silu(acc6[r]), sp); }
     o.s = sp + xhalf(sp);
 }
 
