@@ -67,16 +67,8 @@ def build_step(pkg, args, dev, world):
     scale = (3.0, 3.0, 3.0)
     batch = pkg.synthetic_batch(1234 + rank * args.batch, args.batch, n=args.n, feat=args.feat, scale=scale, device=dev)
     ones = torch.ones(args.batch, args.n * args.k, 1, device=dev)
-    # one fused Adam over the two flat buckets (the per-tensor parameters are views of them)
-    opt_params = []
-    for flat, grad in ((egnn.flat_params, egnn.flat_grads), (dp.head.flat, dp.head.grad)):
-        if flat is None:
-            continue
-        p = torch.nn.Parameter(flat, requires_grad=True)
-        p.grad = grad
-        opt_params.append(p)
-    capturable = not args.no_graph
-    opt = torch.optim.Adam(opt_params, lr=1e-4, capturable=capturable, foreach=True)       # train :1412
+    # one fused Adam launch over the two flat buckets (the per-tensor parameters are views of them); train :1412
+    opt = pkg.FlatAdam([(egnn.flat_params, egnn.flat_grads), (dp.head.flat, dp.head.grad)], lr=1e-4)
 
     def fwd_bwd():
         graph = pkg.build_pair_graph(batch["src"], batch["tgt"], args.k, loop=True)
@@ -103,10 +95,7 @@ def build_step(pkg, args, dev, world):
         with torch.no_grad():
             for dst, src in zip([t for t in (egnn.flat_params, dp.head.flat) if t is not None], init):
                 dst.copy_(src)
-            for st in opt.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+            opt.reset_state()
 
     def opt_step():
         opt.step()
@@ -147,6 +136,12 @@ def make_runner(S, args, world, dev):
                     S["zero"]()
                     S["loss"] = S["fwd_bwd"]()
                     S["opt_step"]()
+            # the periodic weight restore is captured too: eager launches interleaved with graph replays
+            # fault on this ROCm stack ("write access to a read-only page" in the next replay)
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                S["restore"]()
+            S["restore"] = lambda: gr.replay()
             return (lambda: g.replay()), True
         # multi-GPU: graph A = zero+fwd+bwd, eager RCCL all-reduce of the two buckets, graph B = Adam
         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -155,6 +150,11 @@ def make_runner(S, args, world, dev):
             S["loss"] = S["fwd_bwd"]()
         with torch.cuda.graph(gb):
             S["opt_step"]()
+
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            S["restore"]()
+        S["restore"] = lambda: gr.replay()
 
         def run():
             ga.replay()

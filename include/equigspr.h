@@ -178,6 +178,22 @@ int equigspr_head_backward(const float* hs, const float* ht, const float* xs, co
                            void* work, float* dinp, float* mlp_slab, float* grad_mlp, float* ghs, float* ght,
                            float* gxs, float* gxt, void* stream);
 
+/* ---- A13 (pose part) + optimizer: small fused training-step kernels ------------------------
+ * pose_loss: replaces pose_loss() (src/3dmatch_train_egnn_with_batch.py:896-962): rot_loss[b] =
+ * arccos(clamp((trace(R^T R_gt)-1)/2)), trans_loss[b] = arccos(clamp(cos(t, t_gt))).  R [B,9], t [B,3],
+ * gt_pose [B,16]; backward takes dL/drot_loss, dL/dtrans_loss [B] (NULL = 0) and OVERWRITES grad_R, grad_t.
+ * The gradient is -inf at zero pose error, exactly as in the reference.
+ * adam_step: torch.optim.Adam(lr, betas, eps) semantics (train :1412) over 1..4 flat fp32 buckets in one
+ * launch.  The pointer/size arrays are HOST arrays of n_buckets entries; step_dev is a DEVICE float[2]
+ * (zero-initialised) holding the step count, so the call is hipGraph-capturable. */
+int equigspr_pose_loss_forward(const float* R, const float* t, const float* gt_pose, int32_t B, float* rot_loss,
+                               float* trans_loss, void* stream);
+int equigspr_pose_loss_backward(const float* R, const float* t, const float* gt_pose, const float* g_rot,
+                                const float* g_trans, int32_t B, float* grad_R, float* grad_t, void* stream);
+int equigspr_adam_step(int32_t n_buckets, float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const int64_t* sizes, float* step_dev, float lr, float beta1,
+                       float beta2, float eps, void* stream);
+
 /* ---- measurement hooks (bench.py's roofline leg; NOT part of the drop-in path) -----------
  * Average duration in ms (written to HOST memory) of the EGNN message-passing edge kernel,
  * measured with HIP events on `stream` over `iters` back-to-back launches (these two calls

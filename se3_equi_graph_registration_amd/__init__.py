@@ -6,7 +6,7 @@ Everything computes in hand-written HIP kernels for gfx950 reached through the C
 raises -- there is no CPU fallback.
 """
 from ._lib import lib, LIB_PATH, declared_symbols  # noqa: F401
-from .ops import DeviceGraph, weighted_kabsch, knn_graph_batched  # noqa: F401
+from .ops import DeviceGraph, weighted_kabsch, knn_graph_batched, FlatAdam  # noqa: F401
 from .graph import knn_graph, get_edges_batch, get_edges_from_idx, build_pair_graph  # noqa: F401
 from .egnn import EGNN, E_GCL  # noqa: F401
 from .pose import (CrossAttentionPoseRegression, pose_loss, compute_losses, egnn_equi_loss,  # noqa: F401

@@ -1,0 +1,127 @@
+// Small fused training-step kernels: the pose loss of the reference training loop and a flat-bucket Adam.
+//   pose loss : pose_loss() of src/3dmatch_train_egnn_with_batch.py:896-962 (geodesic rotation angle :952,
+//               translation-direction angle :955-960), forward + backward, one thread per pair;
+//   Adam      : torch.optim.Adam semantics (lr, betas, eps; no weight decay / amsgrad -- train :1412) over up
+//               to four flat fp32 buckets in ONE launch; the step counter lives on the device so the whole
+//               optimizer step is hipGraph-capturable.
+#include "common.h"
+
+namespace eq {
+
+__global__ void pose_loss_fwd_kernel(const float* __restrict__ R, const float* __restrict__ t, const float* __restrict__ gt_pose,
+                                     int B, float* __restrict__ rot_loss, float* __restrict__ trans_loss) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* Rb = R + (size_t)b * 9;
+    const float* G = gt_pose + (size_t)b * 16;
+    float tr = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tr = fmaf(Rb[i * 3 + j], G[i * 4 + j], tr);          // trace(R^T R_gt)
+    rot_loss[b] = acosf(fminf(fmaxf((tr - 1.0f) * 0.5f, -1.0f), 1.0f));
+    float dp = 0.0f, nt = 0.0f, ng = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const float a = t[b * 3 + i], g = G[i * 4 + 3]; dp = fmaf(a, g, dp); nt = fmaf(a, a, nt); ng = fmaf(g, g, ng); }
+    const float c = dp / (sqrtf(nt) * sqrtf(ng));
+    trans_loss[b] = acosf(fminf(fmaxf(c, -1.0f), 1.0f));
+}
+
+__global__ void pose_loss_bwd_kernel(const float* __restrict__ R, const float* __restrict__ t, const float* __restrict__ gt_pose,
+                                     const float* __restrict__ g_rot, const float* __restrict__ g_trans, int B,
+                                     float* __restrict__ gR, float* __restrict__ gt) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* Rb = R + (size_t)b * 9;
+    const float* G = gt_pose + (size_t)b * 16;
+    float tr = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tr = fmaf(Rb[i * 3 + j], G[i * 4 + j], tr);
+    const float x = (tr - 1.0f) * 0.5f;
+    // torch.clamp passes the gradient on [min, max] inclusive; acos'(x) = -1/sqrt(1-x^2) (the reference's singularity at x = 1)
+    const float dx = (x >= -1.0f && x <= 1.0f) ? -1.0f / sqrtf(1.0f - x * x) : 0.0f;
+    const float kr = (g_rot ? g_rot[b] : 0.0f) * dx * 0.5f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gR[(size_t)b * 9 + i * 3 + j] = kr * G[i * 4 + j];
+    float dp = 0.0f, nt = 0.0f, ng = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const float a = t[b * 3 + i], g = G[i * 4 + 3]; dp = fmaf(a, g, dp); nt = fmaf(a, a, nt); ng = fmaf(g, g, ng); }
+    const float lt = sqrtf(nt), lg = sqrtf(ng);
+    const float c = dp / (lt * lg);
+    const float dc = (c >= -1.0f && c <= 1.0f) ? -1.0f / sqrtf(1.0f - c * c) : 0.0f;
+    const float kt = (g_trans ? g_trans[b] : 0.0f) * dc;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gt[b * 3 + i] = kt * (G[i * 4 + 3] / (lt * lg) - c * t[b * 3 + i] / nt);
+}
+
+struct AdamBuckets {
+    float* p[4]; const float* g[4]; float* m[4]; float* v[4]; long long n[4]; int count;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamBuckets bk, float* __restrict__ step, float lr, float b1, float b2,
+                                                   float eps) {
+    // every thread reads the SAME pre-increment step value; thread 0 of block 0 publishes step+1 for the NEXT launch
+    // through a second word so late-starting blocks cannot observe it: step[0] = value used now, step[1] = next
+    const float tcur = step[0] + 1.0f;
+    const float bc1 = 1.0f - powf(b1, tcur), bc2s = sqrtf(1.0f - powf(b2, tcur));
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+    for (int k = 0; k < bk.count; ++k) {
+        for (long long i = gid; i < bk.n[k]; i += stride) {
+            const float g = bk.g[k][i];
+            const float m = b1 * bk.m[k][i] + (1.0f - b1) * g;
+            const float v = b2 * bk.v[k][i] + (1.0f - b2) * g * g;
+            bk.m[k][i] = m;
+            bk.v[k][i] = v;
+            bk.p[k][i] -= (lr / bc1) * m / (sqrtf(v) / bc2s + eps);
+        }
+    }
+    if (gid == 0) step[1] = tcur;
+}
+__global__ void adam_commit_kernel(float* __restrict__ step) { step[0] = step[1]; }
+
+}  // namespace eq
+
+extern "C" int equigspr_pose_loss_forward(const float* R, const float* t, const float* gt_pose, int32_t B, float* rot_loss,
+                                          float* trans_loss, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(R && t && gt_pose && rot_loss && trans_loss && B >= 1, EQUIGSPR_EINVAL, "pose_loss_forward: bad arguments");
+    hipLaunchKernelGGL(pose_loss_fwd_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, R, t, gt_pose, B, rot_loss, trans_loss);
+    EQ_CHECK_LAUNCH("pose_loss_forward");
+    return 0;
+}
+
+extern "C" int equigspr_pose_loss_backward(const float* R, const float* t, const float* gt_pose, const float* g_rot,
+                                           const float* g_trans, int32_t B, float* grad_R, float* grad_t, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(R && t && gt_pose && grad_R && grad_t && B >= 1, EQUIGSPR_EINVAL, "pose_loss_backward: bad arguments");
+    hipLaunchKernelGGL(pose_loss_bwd_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, R, t, gt_pose, g_rot, g_trans, B,
+                       grad_R, grad_t);
+    EQ_CHECK_LAUNCH("pose_loss_backward");
+    return 0;
+}
+
+extern "C" int equigspr_adam_step(int32_t n_buckets, float* const* params, const float* const* grads, float* const* exp_avg,
+                                  float* const* exp_avg_sq, const int64_t* sizes /* host arrays */, float* step_dev /* [2] */,
+                                  float lr, float beta1, float beta2, float eps, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(n_buckets >= 1 && n_buckets <= 4 && params && grads && exp_avg && exp_avg_sq && sizes && step_dev,
+                 EQUIGSPR_EINVAL, "adam_step: 1..4 buckets, non-null arrays");
+    AdamBuckets bk;
+    bk.count = n_buckets;
+    long long tot = 0;
+    for (int k = 0; k < n_buckets; ++k) {
+        bk.p[k] = params[k]; bk.g[k] = grads[k]; bk.m[k] = exp_avg[k]; bk.v[k] = exp_avg_sq[k]; bk.n[k] = sizes[k];
+        tot += sizes[k];
+    }
+    int blocks = ceil_div(tot, 256 * 4);
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, bk, step_dev, lr, beta1, beta2, eps);
+    hipLaunchKernelGGL(adam_commit_kernel, dim3(1), dim3(1), 0, s, step_dev);
+    EQ_CHECK_LAUNCH("adam_step");
+    return 0;
+}

@@ -291,3 +291,62 @@ class _HeadFn(torch.autograd.Function):
 
 def fused_pose_head(hs, ht, xs, xt, raw_hs, raw_ht, labels, gt_pose, topk, mlp_params):
     return _HeadFn.apply(hs, ht, xs, xt, raw_hs, raw_ht, labels, gt_pose, topk, *mlp_params)
+
+
+# ----------------------------------------------------------------------------------- pose loss / Adam
+class _PoseLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, R, t, gt_pose):
+        R = _need(R.contiguous(), "pred_rot", torch.float32, 3)
+        t = _need(t.contiguous(), "pred_translation", torch.float32, 2)
+        B = R.shape[0]
+        gt = _need(gt_pose.reshape(B, 16).contiguous().float(), "gt_pose", torch.float32, 2)
+        rot = torch.empty(B, dtype=torch.float32, device=R.device)
+        tr = torch.empty(B, dtype=torch.float32, device=R.device)
+        _lib.check(_lib.lib().equigspr_pose_loss_forward(_p(R), _p(t), _p(gt), B, _p(rot), _p(tr), _stream()), "pose_loss_forward")
+        ctx.save_for_backward(R, t, gt)
+        ctx.set_materialize_grads(False)
+        return rot, tr
+
+    @staticmethod
+    def backward(ctx, g_rot, g_tr):
+        R, t, gt = ctx.saved_tensors
+        B = R.shape[0]
+        gR, gt_ = torch.empty_like(R), torch.empty_like(t)
+        g_rot = None if g_rot is None else g_rot.contiguous().float()
+        g_tr = None if g_tr is None else g_tr.contiguous().float()
+        _lib.check(_lib.lib().equigspr_pose_loss_backward(_p(R), _p(t), _p(gt), _p(g_rot), _p(g_tr), B, _p(gR), _p(gt_),
+                                                          _stream()), "pose_loss_backward")
+        return gR, gt_, None
+
+
+def fused_pose_loss(pred_rot, pred_translation, gt_pose):
+    return _PoseLossFn.apply(pred_rot, pred_translation, gt_pose)
+
+
+class FlatAdam:
+    """torch.optim.Adam(lr, betas, eps) semantics over flat fp32 buckets, one HIP launch per step
+    (reference optimizer: train :1412).  ``buckets`` = list of (param_flat, grad_flat) device tensors."""
+
+    def __init__(self, buckets, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
+        self.buckets = [(p, g) for p, g in buckets if p is not None]
+        if not 1 <= len(self.buckets) <= 4:
+            raise ValueError("FlatAdam takes 1..4 buckets")
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.exp_avg = [torch.zeros_like(p) for p, _ in self.buckets]
+        self.exp_avg_sq = [torch.zeros_like(p) for p, _ in self.buckets]
+        self.step_dev = torch.zeros(2, dtype=torch.float32, device=self.buckets[0][0].device)
+        n = len(self.buckets)
+        arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        self._p, self._g = arr([p for p, _ in self.buckets]), arr([g for _, g in self.buckets])
+        self._m, self._v = arr(self.exp_avg), arr(self.exp_avg_sq)
+        self._n = (ctypes.c_int64 * n)(*[p.numel() for p, _ in self.buckets])
+
+    def step(self):
+        _lib.check(_lib.lib().equigspr_adam_step(len(self.buckets), self._p, self._g, self._m, self._v, self._n,
+                                                 _p(self.step_dev), self.lr, self.betas[0], self.betas[1], self.eps,
+                                                 _stream()), "adam_step")
+
+    def reset_state(self):
+        for t in self.exp_avg + self.exp_avg_sq + [self.step_dev]:
+            t.zero_()

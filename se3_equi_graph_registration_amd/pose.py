@@ -35,7 +35,10 @@ def egnn_equi_loss(h_src, x_src, h_tgt, x_tgt, R_gt, t_gt, labels):
 
 
 def pose_loss(pred_rot, pred_translation, gt_pose, delta=1.5):
-    """train :896-962 -> (rotation geodesic loss [B], translation direction loss [B])."""
+    """train :896-962 -> (rotation geodesic loss [B], translation direction loss [B]); one fused HIP
+    kernel each way on device tensors (csrc/train_ops.hip), the same formulas in ATen ops otherwise."""
+    if pred_rot.is_cuda and pred_rot.dtype == torch.float32:
+        return ops.fused_pose_loss(pred_rot, pred_translation, gt_pose)
     gt_t, gt_R = gt_pose[:, :3, 3], gt_pose[:, :3, :3]
     Rd = torch.matmul(pred_rot.transpose(-1, -2), gt_R)
     tr = Rd.diagonal(dim1=-2, dim2=-1).sum(-1)

@@ -388,3 +388,43 @@ def test_fused_head_matches_aten_head(pk, golden_dir, name):
         scale = float(b[key].abs().max())
         err = float((a[key] - b[key]).abs().max())
         assert err <= 2e-3 * scale + 1e-7, f"{name} {key}: err {err:.3e} scale {scale:.3e}"
+
+
+# ------------------------------------------------------------------------------------ small fused training ops
+def test_fused_pose_loss_matches_aten(pk):
+    g = torch.Generator().manual_seed(4)
+    B = 5
+    q, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))
+    q = q * torch.sign(torch.det(q))[:, None, None]
+    gq, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))
+    pose = torch.eye(4).repeat(B, 1, 1); pose[:, :3, :3] = gq; pose[:, :3, 3] = torch.rand(B, 3, generator=g)
+    t = torch.rand(B, 3, generator=g)
+    w1, w2 = torch.rand(B, generator=g), torch.rand(B, generator=g)
+    ref = {}
+    for dev in ("cpu", "cuda"):
+        R_ = q.clone().to(dev).requires_grad_(True); t_ = t.clone().to(dev).requires_grad_(True)
+        rl, tl = pk.pose_loss(R_, t_, pose.to(dev))
+        ((rl * w1.to(dev)).sum() + (tl * w2.to(dev)).sum()).backward()
+        ref[dev] = (rl.detach().cpu(), tl.detach().cpu(), R_.grad.cpu(), t_.grad.cpu())
+    for a, b in zip(ref["cpu"], ref["cuda"]):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-5)
+    o_rl, o_tl = orc.pose_loss(q, t, pose)
+    assert torch.allclose(ref["cuda"][0], o_rl, rtol=2e-4, atol=2e-5) and torch.allclose(ref["cuda"][1], o_tl, rtol=2e-4, atol=2e-5)
+
+
+def test_flat_adam_matches_torch_adam(pk):
+    g = torch.Generator().manual_seed(8)
+    p0 = [torch.randn(1000, generator=g), torch.randn(77, generator=g)]
+    grads = [[torch.randn(1000, generator=g), torch.randn(77, generator=g)] for _ in range(6)]
+    ref = [torch.nn.Parameter(p.clone().cuda()) for p in p0]
+    opt = torch.optim.Adam(ref, lr=1e-3)
+    mine = [p.clone().cuda() for p in p0]
+    mgr = [torch.zeros_like(p) for p in mine]
+    fa = pk.FlatAdam(list(zip(mine, mgr)), lr=1e-3)
+    for step in grads:
+        for r, m, gg in zip(ref, mgr, step):
+            r.grad = gg.cuda(); m.copy_(gg.cuda())
+        opt.step(); fa.step()
+    for r, m in zip(ref, mine):
+        assert torch.allclose(r.detach(), m, rtol=1e-5, atol=1e-6)
+    assert float(fa.step_dev[0]) == 6.0
