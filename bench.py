@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--feat", type=int, default=32)
     ap.add_argument("--heads", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--graph-collectives", action="store_true", help="N>1: capture the RCCL all-reduce inside the step graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: inference step (not the headline metric)")
@@ -104,18 +105,26 @@ def build_step(pkg, args, dev, world):
 
 
 def make_runner(S, args, world, dev):
-    """Returns (callable running one step, used_graph)."""
+    """Returns (callable running one step, used_graph).
+
+    1 GPU: the whole step (zero, kNN, fwd, head, losses, bwd, Adam) is ONE hipGraph.  N GPUs: the step has an
+    RCCL all-reduce in the middle; eager launches interleaved with graph replays fault on this ROCm stack
+    (write to a read-only page in the following replay -- reproduced on 1 GPU with a stand-in eager op), so
+    the N>1 default is eager launches; --graph-collectives captures the all-reduce inside the single graph."""
+    dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+
     def eager():
         S["zero"]()
         if args.forward_only:
             with torch.no_grad():
                 return S["fwd_bwd"]()
         loss = S["fwd_bwd"]()
-        S["dp"].sync()
+        if dist_on:
+            S["dp"].sync(force=dist_on)
         S["opt_step"]()
         return loss
 
-    if args.no_graph:
+    if args.no_graph or (dist_on and not args.graph_collectives):
         return eager, False
     try:
         side = torch.cuda.Stream()
@@ -125,42 +134,24 @@ def make_runner(S, args, world, dev):
                 eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if world == 1 or args.forward_only:
-            g = torch.cuda.CUDAGraph()
-            S["zero"]()
-            with torch.cuda.graph(g):
-                if args.forward_only:
-                    with torch.no_grad():
-                        S["loss"] = S["fwd_bwd"]()
-                else:
-                    S["zero"]()
+        g = torch.cuda.CUDAGraph()
+        S["zero"]()
+        with torch.cuda.graph(g):
+            if args.forward_only:
+                with torch.no_grad():
                     S["loss"] = S["fwd_bwd"]()
-                    S["opt_step"]()
-            # the periodic weight restore is captured too: eager launches interleaved with graph replays
-            # fault on this ROCm stack ("write access to a read-only page" in the next replay)
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
-                S["restore"]()
-            S["restore"] = lambda: gr.replay()
-            return (lambda: g.replay()), True
-        # multi-GPU: graph A = zero+fwd+bwd, eager RCCL all-reduce of the two buckets, graph B = Adam
-        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(ga):
-            S["zero"]()
-            S["loss"] = S["fwd_bwd"]()
-        with torch.cuda.graph(gb):
-            S["opt_step"]()
-
+            else:
+                S["zero"]()
+                S["loss"] = S["fwd_bwd"]()
+                if dist_on:
+                    S["dp"].sync(force=dist_on)
+                S["opt_step"]()
+        # the periodic weight restore is captured too (no eager launches between replays)
         gr = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gr):
             S["restore"]()
         S["restore"] = lambda: gr.replay()
-
-        def run():
-            ga.replay()
-            S["dp"].sync()
-            gb.replay()
-        return run, True
+        return (lambda: g.replay()), True
     except Exception as exc:        # capture unsupported -> eager launches (reported in the JSON)
         print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
         torch.cuda.synchronize()
@@ -276,8 +267,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)
     rank = dist.get_rank() if world > 1 else 0
     import se3_equi_graph_registration_amd as pkg
@@ -328,7 +322,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -88,8 +88,8 @@ class DataParallelStep:
         if self.head.flat is not None:
             dist.broadcast(self.head.flat, src, group=self.group)
 
-    def sync(self):
-        if self.world == 1:
+    def sync(self, force: bool = False):
+        if self.world == 1 and not force:
             return
         for b in self.buckets():
             dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
