@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
     float* Y = X + 32 * LD;
     stage_tile_weights<H, A>(wsm, lw);
     __syncthreads();
-    TileWeights<H, A> W;
+    TileWeights<H, A, true> W;
     W.load(wsm, lane);
 
     f32x16 acc6[1][1], acc2[1][1], accg[1][1];
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         edge_geometry(xr, xc, eg);
         const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
         TileFwd o;
-        tile_forward<H, A>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
+        tile_forward<H, A, true>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
 
         // ---- coord head backward
         const float ds = dot3(eg.d, gxv) * z;

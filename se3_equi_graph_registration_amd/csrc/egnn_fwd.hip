@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restr
         edge_geometry(xr, xc, eg);
         const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
         TileFwd o;
-        tile_forward<H, A>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
+        tile_forward<H, A, false>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
         if (valid) {
             store_half_row(m_out + (size_t)e * FP, h, o.m);
             if (h == 0)

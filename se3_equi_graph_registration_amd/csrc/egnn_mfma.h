@@ -56,30 +56,54 @@ __device__ __forceinline__ void stage_tile_weights(float* sm, const float* __res
     }
 }
 
-// Operand accessors: the MFMA A operands and the per-feature vectors are fetched from the LDS image
-// right where they are used (one conflict-free ds_read per MFMA) instead of living in ~170 VGPRs,
-// which is what lets two to four waves share a SIMD.  `refresh()` re-materialises the base pointer
-// so the compiler cannot hoist the (loop-invariant) reads out of the tile loop back into registers.
-template <int H, int A>
+// Operand accessors.  kCached = false: the MFMA A operands and the per-feature vectors are fetched from
+// the LDS image right where they are used (one conflict-free ds_read per MFMA) instead of living in ~170
+// VGPRs -- that lets four forward waves share a SIMD; `refresh()` re-materialises the base pointer so the
+// compiler cannot hoist the loop-invariant reads back into registers.  kCached = true: everything is read
+// once per wave into registers (the backward kernel runs at one wave per SIMD anyway, where exposed LDS
+// latency costs more than the registers).
+template <int H, int A, bool kCached = false>
 struct TileWeights {
     using T = TileWeightsLds;
     const float* sm;
     int i, h;
-    __device__ __forceinline__ void load(const float* s, int lane) { sm = s; i = lane & 31; h = lane >> 5; }
-    __device__ __forceinline__ void refresh() { asm volatile("" : "+v"(sm)); }
-    __device__ __forceinline__ float wg(int s) const { return sm[T::o_geo + i * T::GS + 2 * s + h]; }
-    __device__ __forceinline__ float w2(int s) const { return sm[T::o_w2 + i * T::WS + fidx(s, h)]; }
-    __device__ __forceinline__ float w6(int s) const { return sm[T::o_w6 + i * T::WS + fidx(s, h)]; }
-    __device__ __forceinline__ float vec(int which, int r) const { return sm[T::o_vec + 32 * which + fidx(r, h)]; }
+    float c_wg[kCached ? 7 : 1], c_w2[kCached ? 16 : 1], c_w6[kCached ? 16 : 1], c_vec[kCached ? 80 : 1];
+    float c_w6t[kCached ? 16 : 1], c_w2t[kCached ? 16 : 1], c_wgt[kCached ? 16 : 1];
+    __device__ __forceinline__ float l_wg(int s) const { return sm[T::o_geo + i * T::GS + 2 * s + h]; }
+    __device__ __forceinline__ float l_w2(int s) const { return sm[T::o_w2 + i * T::WS + fidx(s, h)]; }
+    __device__ __forceinline__ float l_w6(int s) const { return sm[T::o_w6 + i * T::WS + fidx(s, h)]; }
+    __device__ __forceinline__ float l_vec(int which, int r) const { return sm[T::o_vec + 32 * which + fidx(r, h)]; }
+    __device__ __forceinline__ float l_w6t(int s) const { return sm[T::o_w6 + fidx(s, h) * T::WS + i]; }
+    __device__ __forceinline__ float l_w2t(int s) const { return sm[T::o_w2 + fidx(s, h) * T::WS + i]; }
+    __device__ __forceinline__ float l_wgt(int s) const { return (i < kGeo) ? sm[T::o_geo + fidx(s, h) * T::GS + i] : 0.0f; }
+    __device__ __forceinline__ void load(const float* s_, int lane) {
+        sm = s_; i = lane & 31; h = lane >> 5;
+        if (kCached) {
+#pragma unroll
+            for (int s = 0; s < 7; ++s) c_wg[kCached ? s : 0] = l_wg(s);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                c_w2[kCached ? s : 0] = l_w2(s); c_w6[kCached ? s : 0] = l_w6(s);
+                c_w6t[kCached ? s : 0] = l_w6t(s); c_w2t[kCached ? s : 0] = l_w2t(s); c_wgt[kCached ? s : 0] = l_wgt(s);
+#pragma unroll
+                for (int w = 0; w < 5; ++w) c_vec[kCached ? w * 16 + s : 0] = l_vec(w, s);
+            }
+        }
+    }
+    __device__ __forceinline__ void refresh() { if (!kCached) asm volatile("" : "+v"(sm)); }
+    __device__ __forceinline__ float wg(int s) const { return kCached ? c_wg[kCached ? s : 0] : l_wg(s); }
+    __device__ __forceinline__ float w2(int s) const { return kCached ? c_w2[kCached ? s : 0] : l_w2(s); }
+    __device__ __forceinline__ float w6(int s) const { return kCached ? c_w6[kCached ? s : 0] : l_w6(s); }
+    __device__ __forceinline__ float vec(int which, int r) const { return kCached ? c_vec[kCached ? which * 16 + r : 0] : l_vec(which, r); }
     __device__ __forceinline__ float b2(int r) const { return vec(0, r); }
     __device__ __forceinline__ float gam(int r) const { return vec(1, r); }
     __device__ __forceinline__ float bet(int r) const { return vec(2, r); }
     __device__ __forceinline__ float b6(int r) const { return vec(3, r); }
     __device__ __forceinline__ float w7(int r) const { return vec(4, r); }
     // transposed products of the backward
-    __device__ __forceinline__ float w6t(int s) const { return sm[T::o_w6 + fidx(s, h) * T::WS + i]; }
-    __device__ __forceinline__ float w2t(int s) const { return sm[T::o_w2 + fidx(s, h) * T::WS + i]; }
-    __device__ __forceinline__ float wgt(int s) const { return (i < kGeo) ? sm[T::o_geo + fidx(s, h) * T::GS + i] : 0.0f; }
+    __device__ __forceinline__ float w6t(int s) const { return kCached ? c_w6t[kCached ? s : 0] : l_w6t(s); }
+    __device__ __forceinline__ float w2t(int s) const { return kCached ? c_w2t[kCached ? s : 0] : l_w2t(s); }
+    __device__ __forceinline__ float wgt(int s) const { return kCached ? c_wgt[kCached ? s : 0] : l_wgt(s); }
 };
 
 // gather 16 of the 32 floats of a 128-byte row: features fidx(r,h), r = 0..15 (4 x 16-byte loads)
@@ -102,8 +126,8 @@ struct TileFwd {
     float rstd, s;
 };
 
-template <int H, int A>
-__device__ __forceinline__ void tile_forward(const TileWeights<H, A>& W, const float* __restrict__ prow,
+template <int H, int A, bool kCached>
+__device__ __forceinline__ void tile_forward(const TileWeights<H, A, kCached>& W, const float* __restrict__ prow,
                                              const float* __restrict__ pcrow, const EdgeGeo& eg, float attr, int h,
                                              TileFwd& o) {
     float pr[16], pc[16];
