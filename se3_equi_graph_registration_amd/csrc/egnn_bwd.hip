@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         float dq[16], pds[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const float sg = 1.0f / (1.0f + expf(-o.q[k]));
+            const float sg = o.sgq[k];
             pds[k] = o.q[k] * sg * ds;
             dq[k] = W.w7(k) * ds * (sg * (1.0f + o.q[k] * (1.0f - sg)));
         }
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
             float g1[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                const float sg = 1.0f / (1.0f + expf(-o.t1[k]));
+                const float sg = o.sg1[k];
                 g1[k] = o.t1[k] * sg;
                 sg1[k] = sg * (1.0f + o.t1[k] * (1.0f - sg));
             }

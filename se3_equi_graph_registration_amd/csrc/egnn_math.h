@@ -31,6 +31,15 @@ struct EdgeGeo {
 };
 
 EQ_HD float silu(float v) { return v / (1.0f + expf(-v)); }
+// sigmoid with the hardware reciprocal (v_rcp_f32, <= 1 ulp) instead of the ~10-instruction IEEE division
+// sequence; used by the MFMA edge kernels where SiLU / SiLU' are a third of the vector work.
+EQ_HD float sigmoid_fast(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(1.0f + expf(-v));
+#else
+    return 1.0f / (1.0f + expf(-v));
+#endif
+}
 // d/dv silu(v) = s(v) * (1 + v * (1 - s(v)))
 EQ_HD float silu_grad(float v) {
     float s = 1.0f / (1.0f + expf(-v));

@@ -123,6 +123,7 @@ __device__ __forceinline__ void store_half_row(float* __restrict__ row, int h, c
 // everything the backward needs from the forward of one tile
 struct TileFwd {
     float t1[16], xhat[16], m[16], q[16];
+    float sg1[16], sgq[16];      // sigmoid(t1), sigmoid(q): SiLU = v*sg, SiLU' = sg*(1 + v*(1-sg)) without a second exp
     float rstd, s;
 };
 
@@ -147,7 +148,10 @@ __device__ __forceinline__ void tile_forward(const TileWeights<H, A, kCached>& W
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o.t1[r] = acc[r]; acc2[r] = W.b2(r); acc6[r] = W.b6(r); }
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w2(s), silu(o.t1[s]), acc2, 0, 0, 0);
+    for (int s = 0; s < 16; ++s) {
+        o.sg1[s] = sigmoid_fast(o.t1[s]);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w2(s), o.t1[s] * o.sg1[s], acc2, 0, 0, 0);
+    }
     float sum = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sum += acc2[r];
@@ -168,7 +172,7 @@ __device__ __forceinline__ void tile_forward(const TileWeights<H, A, kCached>& W
     for (int s = 0; s < 16; ++s) acc6 = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w6(s), o.m[s], acc6, 0, 0, 0);
     float sp = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o.q[r] = acc6[r]; sp = fmaf(W.w7(r), silu(acc6[r]), sp); }
+    for (int r = 0; r < 16; ++r) { o.q[r] = acc6[r]; o.sgq[r] = sigmoid_fast(acc6[r]); sp = fmaf(W.w7(r), acc6[r] * o.sgq[r], sp); }
     o.s = sp + xhalf(sp);
 }
 
