@@ -163,6 +163,7 @@ int equigspr_kabsch_backward(const float* src, const float* tgt, const float* w,
  * Kabsch coordinate gradients); ADDS into grad_mlp. */
 int64_t equigspr_head_mlp_size(int32_t F);
 int64_t equigspr_head_work_bytes(int32_t B, int32_t N);
+int64_t equigspr_head_slab_count(int32_t B, int32_t K);   /* mlp_slab = slab_count * head_mlp_size floats */
 int equigspr_head_forward(const float* hs, const float* ht, const float* raw_hs, const float* raw_ht,
                           const float* xs, const float* xt, const float* labels, const float* gt_pose,
                           const float* mlp, int32_t B, int32_t N, int32_t F, int32_t F_raw, int32_t K,

@@ -50,6 +50,7 @@ _SIGNATURES = {
                                               c_int32, POINTER(ctypes.c_float), c_void_p]),
     "equigspr_head_mlp_size": (c_int64, [c_int32]),
     "equigspr_head_work_bytes": (c_int64, [c_int32, c_int32]),
+    "equigspr_head_slab_count": (c_int64, [c_int32, c_int32]),
     "equigspr_head_forward": (ctypes.c_int, [c_void_p] * 9 + [c_int32] * 5 + [c_void_p] * 12),
     "equigspr_head_backward": (ctypes.c_int, [c_void_p] * 20 + [c_int32] * 4 + [c_void_p] * 9),
     "equigspr_pose_loss_forward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),

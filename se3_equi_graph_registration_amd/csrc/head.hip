@@ -121,7 +121,33 @@ __device__ __forceinline__ void head_stats(const double* __restrict__ partials, 
     st[0] = ms; st[1] = sqrt(vs); st[2] = mr; st[3] = sqrt(vr); st[4] = acc[4]; st[5] = acc[5];
 }
 
-struct MlpDims { int in, h1, h2; };     // in = 2F, h1 = F, h2 = F/2, out = 1
+struct MlpDims { int in, h1, h2; };
+
+// inp[j][c] = cat(h_s[idx_j], h_t[idx_j])[c]: 8 independent global loads in flight per thread (a single
+// workgroup per pair has nothing else to hide the latency with)
+__device__ __forceinline__ void gather_rows(const float* __restrict__ hs, const float* __restrict__ ht, const int* idxs,
+                                            int b, int N, int F, int K, int in_dim, int ld_in, float* inp) {
+    const int total = K * in_dim;
+    for (int t0 = threadIdx.x; t0 < total; t0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + u * 256;
+            v[u] = 0.0f;
+            if (t < total) {
+                const int j = t / in_dim, c = t - j * in_dim;
+                const size_t rowoff = ((size_t)b * N + idxs[j]) * F;
+                v[u] = (c < F) ? hs[rowoff + c] : ht[rowoff + (c - F)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + u * 256;
+            if (t < total) { const int j = t / in_dim, c = t - j * in_dim; inp[j * ld_in + c] = v[u]; }
+        }
+    }
+}
+     // in = 2F, h1 = F, h2 = F/2, out = 1
 constexpr int kCand = 512;              // candidate list of the radix select
 
 // K2: one workgroup per pair: softmax scalars, top-K (radix select + small bitonic sort), MLP, BCE
@@ -138,22 +164,13 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
     __shared__ float redf[4];
     __shared__ unsigned hist[256];
     __shared__ int sel[3];
+    __shared__ int wtot[4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const long long M = (long long)B * N;
     const float* sb = sim + (size_t)b * N;
     const float* yb = labels + (size_t)b * N;
     u64* keys = reinterpret_cast<u64*>(smem_raw);                                   // [Npad] (fallback) / candidates
     unsigned* khi = reinterpret_cast<unsigned*>(smem_raw + sizeof(u64) * (size_t)(Npad > kCand ? Npad : kCand));   // [N]
-    float* fl = reinterpret_cast<float*>(khi + N);
-    const int ld_in = md.in + 1, ld1 = md.h1 + 1, ld2 = md.h2 + 1;
-    float* inp = fl;
-    float* a1 = inp + K * ld_in;
-    float* a2 = a1 + K * ld1;
-    float* W1 = a2 + K * ld2;            // transposed: [in][h1+1]
-    float* W2 = W1 + md.in * ld1;        // transposed: [h1][h2+1]
-    float* W3 = W2 + md.h1 * ld2;
-    float* Bs = W3 + md.h2;              // b1 | b2 | b3
-
     double st[6];
     head_stats(partials, B * nbp, M, red, st);
     // ---- masked softmax scalars from the per-block (max, sum exp) records of this pair (:717-724)
@@ -172,13 +189,6 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
         pf[0] = mx; pf[1] = (float)den; pf[2] = (den > 0.0) ? 1.0f : 0.0f; pf[3] = 0.0f;
         if (b == 0) { fin[2] = (float)st[0]; fin[3] = (float)st[1]; fin[4] = (float)st[2]; fin[5] = (float)st[3]; fin[8] = (float)st[4]; fin[9] = (float)st[5]; }
     }
-    // ---- stage the MLP weights: W1^T [in][h1+1], W2^T [h1][h2+1] (bank-conflict-free for lane = output)
-    for (int t = tid; t < md.h1 * md.in; t += 256) { const int o = t / md.in, i = t - o * md.in; W1[i * ld1 + o] = w1[t]; }
-    for (int t = tid; t < md.h2 * md.h1; t += 256) { const int o = t / md.h1, i = t - o * md.h1; W2[i * ld2 + o] = w2[t]; }
-    for (int t = tid; t < md.h2; t += 256) W3[t] = w3[t];
-    for (int t = tid; t < md.h1; t += 256) Bs[t] = b1[t];
-    for (int t = tid; t < md.h2; t += 256) Bs[md.h1 + t] = b2[t];
-    if (tid == 0) Bs[md.h1 + md.h2] = b3[0];
     // ---- top-K (:684): ascending key == descending sim, then lower index.  MSB radix select on the value
     //      bits finds the K-th value T; candidates {v < T} + {v == T} are sorted exactly; if more than kCand
     //      candidates tie (degenerate inputs) fall back to a full bitonic sort.
@@ -194,14 +204,21 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
             if ((v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-            int cum = 0, bin = 255;
-            for (int q = 0; q < 256; ++q) {
-                const int c = (int)hist[q];
-                if (cum + c >= need) { bin = q; break; }
-                cum += c;
+        {   // inclusive scan of the 256 bins (one per thread): wave scan + 4 wave totals; the selected bin is the
+            // first whose inclusive count reaches `need`
+            const int c = (int)hist[tid];
+            int inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(inc, o, 64);
+                if ((tid & 63) >= o) inc += v;
             }
-            sel[0] = bin; sel[1] = cum; sel[2] = (int)hist[bin];
+            if ((tid & 63) == 63) wtot[tid >> 6] = inc;
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < (tid >> 6); ++w) base += wtot[w];
+            inc += base;
+            if (inc >= need && inc - c < need) { sel[0] = tid; sel[1] = inc - c; sel[2] = c; }
         }
         __syncthreads();
         need -= sel[1];
@@ -240,49 +257,78 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
             __syncthreads();
         }
     }
-    // ---- gather the K selected rows (:688-689), cat [h_s | h_t]
-    for (int t = tid; t < K * md.in; t += 256) {
-        const int j = t / md.in, c = t - j * md.in;
-        const int idx = (int)(unsigned)(keys[j] & 0xffffffffu);
-        const float v = (c < F) ? hs[((size_t)b * N + idx) * F + c] : ht[((size_t)b * N + idx) * F + (c - F)];
-        inp[j * ld_in + c] = v;
-    }
     if (tid < K) {
         const int idx = (int)(unsigned)(keys[tid] & 0xffffffffu);
         top_idx[(size_t)b * K + tid] = idx;
         pos[(size_t)b * N + idx] = tid;
     }
+}
+
+// K2b: the correspondence MLP on the K selected rows (:760-773), kRowsPerBlock rows per workgroup so the
+// work spreads over the chip instead of one CU per pair.  grid (ceil(K/kRowsPerBlock), B)
+constexpr int kRowsPerBlock = 16;
+constexpr int kMaxIn = 128, kMaxH1 = 64, kMaxH2 = 32;
+
+__global__ __launch_bounds__(256) void head_mlp_kernel(
+    const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
+    const long long* __restrict__ top_idx, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
+    int B, int N, int F, int K, MlpDims md, float* __restrict__ logits, float* __restrict__ a1_save,
+    float* __restrict__ a2_save, double* __restrict__ pair_part) {
+    __shared__ float inp[kRowsPerBlock * (kMaxIn + 1)];
+    __shared__ float a1[kRowsPerBlock * (kMaxH1 + 1)];
+    __shared__ float a2[kRowsPerBlock * (kMaxH2 + 1)];
+    __shared__ float W1[kMaxIn * (kMaxH1 + 1)];      // transposed [in][h1+1]
+    __shared__ float W2[kMaxH1 * (kMaxH2 + 1)];      // transposed [h1][h2+1]
+    __shared__ float W3[kMaxH2];
+    __shared__ float Bs[kMaxH1 + kMaxH2 + 1];
+    __shared__ int idxs[kRowsPerBlock];
+    __shared__ double red[4];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int j0 = blockIdx.x * kRowsPerBlock;
+    const int Kb = min(kRowsPerBlock, K - j0);
+    const int ld_in = md.in + 1, ld1 = md.h1 + 1, ld2 = md.h2 + 1;
+    const float* yb = labels + (size_t)b * N;
+    for (int t = tid; t < md.h1 * md.in; t += 256) { const int o = t / md.in, i = t - o * md.in; W1[i * ld1 + o] = w1[t]; }
+    for (int t = tid; t < md.h2 * md.h1; t += 256) { const int o = t / md.h1, i = t - o * md.h1; W2[i * ld2 + o] = w2[t]; }
+    for (int t = tid; t < md.h2; t += 256) W3[t] = w3[t];
+    for (int t = tid; t < md.h1; t += 256) Bs[t] = b1[t];
+    for (int t = tid; t < md.h2; t += 256) Bs[md.h1 + t] = b2[t];
+    if (tid == 0) Bs[md.h1 + md.h2] = b3[0];
+    if (tid < Kb) idxs[tid] = (int)top_idx[(size_t)b * K + j0 + tid];
     __syncthreads();
-    // ---- MLP: Linear-ReLU-Linear-ReLU-Linear (:594-600)
-    for (int t = tid; t < K * md.h1; t += 256) {
+    gather_rows(hs, ht, idxs, b, N, F, Kb, md.in, ld_in, inp);
+    __syncthreads();
+    for (int t = tid; t < Kb * md.h1; t += 256) {
         const int j = t / md.h1, o = t - j * md.h1;
         float acc = Bs[o];
+#pragma unroll 8
         for (int i = 0; i < md.in; ++i) acc = fmaf(W1[i * ld1 + o], inp[j * ld_in + i], acc);
         acc = fmaxf(acc, 0.0f);
         a1[j * ld1 + o] = acc;
-        a1_save[((size_t)b * K + j) * md.h1 + o] = acc;
+        a1_save[((size_t)b * K + j0 + j) * md.h1 + o] = acc;
     }
     __syncthreads();
-    for (int t = tid; t < K * md.h2; t += 256) {
+    for (int t = tid; t < Kb * md.h2; t += 256) {
         const int j = t / md.h2, o = t - j * md.h2;
         float acc = Bs[md.h1 + o];
+#pragma unroll 8
         for (int i = 0; i < md.h1; ++i) acc = fmaf(W2[i * ld2 + o], a1[j * ld1 + i], acc);
         acc = fmaxf(acc, 0.0f);
         a2[j * ld2 + o] = acc;
-        a2_save[((size_t)b * K + j) * md.h2 + o] = acc;
+        a2_save[((size_t)b * K + j0 + j) * md.h2 + o] = acc;
     }
     __syncthreads();
     double bce = 0;
-    if (tid < K) {
+    if (tid < Kb) {
         float z = Bs[md.h1 + md.h2];
         for (int i = 0; i < md.h2; ++i) z = fmaf(W3[i], a2[tid * ld2 + i], z);
-        logits[(size_t)b * K + tid] = z;
-        const int idx = (int)(unsigned)(keys[tid] & 0xffffffffu);
-        const float y = yb[idx];
+        logits[(size_t)b * K + j0 + tid] = z;
+        const float y = yb[idxs[tid]];
         bce = fmaxf(z, 0.0f) - z * y + log1pf(expf(-fabsf(z)));                          // BCEWithLogits (:772-773)
     }
     bce = block_sum_d(bce, red);
-    if (tid == 0) pair_part[(size_t)b * 2] = bce;
+    if (tid == 0) pair_part[(size_t)b * gridDim.x + blockIdx.x] = bce;
 }
 
 // K3: one thread per node: Kabsch weights (:718-724) and the similarity-MSE partial sums (:777-781)
@@ -311,13 +357,13 @@ __global__ __launch_bounds__(256) void head_weights_kernel(const float* __restri
 // out[0] = corr_loss + sim_loss, out[1] = equi loss, out[2..5] = mu_s, sd_s, mu_r, sd_r (written by K2),
 // out[6] = sum e, out[7] = sum e (s - mu_s), out[8], out[9] = rot / feat sums (written by K2)
 __global__ __launch_bounds__(256) void head_finalize_kernel(const double* __restrict__ partC, int nC,
-                                                            const double* __restrict__ pair_part, int B, int N, int K,
+                                                            const double* __restrict__ pair_part, int nblk, int B, int N, int K,
                                                             float* __restrict__ out) {
     __shared__ double red[4];
     const long long M = (long long)B * N;
     double a0 = 0, a1 = 0, a2 = 0, bce = 0;
     for (int k = threadIdx.x; k < nC; k += 256) { a0 += partC[(size_t)k * 3]; a1 += partC[(size_t)k * 3 + 1]; a2 += partC[(size_t)k * 3 + 2]; }
-    for (int b = threadIdx.x; b < B; b += 256) bce += pair_part[(size_t)b * 2];
+    for (int b = threadIdx.x; b < B * nblk; b += 256) bce += pair_part[b];
     a0 = block_sum_d(a0, red); a1 = block_sum_d(a1, red); a2 = block_sum_d(a2, red); bce = block_sum_d(bce, red);
     if (threadIdx.x == 0) {
         out[0] = (float)(bce / ((double)B * K) + a0 / (double)M);
@@ -329,8 +375,9 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const double* __rest
 // ---------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------
-// KB1: per pair: gwu = sum_i gw_i u_i ; BCE + MLP backward on the K rows ; MLP weight-gradient slab
-// mlp slab per pair: dW1 [h1*in] | db1 [h1] | dW2 [h2*h1] | db2 [h2] | dW3 [h2] | db3 [1]
+// KB1: grid (ceil(K/kRowsPerBlock), B): BCE + MLP backward on this block's rows, its MLP weight-gradient slab;
+// block 0 of each pair also reduces gwu = sum_i gw_i u_i for the softmax backward.
+// mlp slab layout: dW1 [h1*in] | db1 [h1] | dW2 [h2*h1] | db2 [h2] | dW3 [h2] | db3 [1]
 __global__ __launch_bounds__(256) void head_pair_bwd_kernel(
     const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
     const float* __restrict__ sim, const float* __restrict__ pair_f, const float* __restrict__ gw,
@@ -338,89 +385,97 @@ __global__ __launch_bounds__(256) void head_pair_bwd_kernel(
     const float* __restrict__ a2_save, const float* __restrict__ w1, const float* __restrict__ w2,
     const float* __restrict__ w3, const float* __restrict__ g_cs_ptr, int B, int N, int F, int K, MlpDims md,
     float* __restrict__ pair_g /*[B]*/, float* __restrict__ dinp /*[B][K][in]*/, float* __restrict__ mlp_slab) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int R = kRowsPerBlock;
+    __shared__ float inp[R * (kMaxIn + 1)];
+    __shared__ float a1[R * (kMaxH1 + 1)];
+    __shared__ float a2[R * (kMaxH2 + 1)];
+    __shared__ float d1[R * (kMaxH1 + 1)];
+    __shared__ float d2[R * (kMaxH2 + 1)];
+    __shared__ float dz[R];
+    __shared__ float W1[kMaxH1 * kMaxIn];     // row-major [h1][in]
+    __shared__ float W2[kMaxH2 * kMaxH1];     // row-major [h2][h1]
+    __shared__ float W3[kMaxH2];
+    __shared__ int idxs[R];
     __shared__ double red[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int j0 = blockIdx.x * R;
+    const int Kb = min(R, K - j0);
     const float g_cs = g_cs_ptr ? g_cs_ptr[0] : 0.0f;
     const float* sb = sim + (size_t)b * N;
     const float* yb = labels + (size_t)b * N;
     const float* gwb = gw + (size_t)b * N;
-    float* fl = reinterpret_cast<float*>(smem_raw);
     const int ld_in = md.in + 1, ld1 = md.h1 + 1, ld2 = md.h2 + 1;
-    float* inp = fl;
-    float* a1 = inp + K * ld_in;
-    float* a2 = a1 + K * ld1;
-    float* d1 = a2 + K * ld2;            // d pre-activation 1  [K][h1+1]
-    float* d2 = d1 + K * ld1;            // d pre-activation 2  [K][h2+1]
-    float* dz = d2 + K * ld2;            // [K]
-    float* W1 = dz + K;                  // row-major [h1][in]: reads are lane-consecutive in `in`
-    float* W2 = W1 + md.h1 * md.in;      // row-major [h2][h1]
-    float* W3 = W2 + md.h2 * md.h1;
-
-    const float mx = pair_f[b * 4], den = pair_f[b * 4 + 1];
-    double gwu = 0;
-    for (int i = tid; i < N; i += 256)
-        if (yb[i] != 0.0f && den > 0.0f) gwu += (double)gwb[i] * (double)(expf(sb[i] - mx) / den);
-    gwu = block_sum_d(gwu, red);
-    if (tid == 0) pair_g[b] = (float)gwu;
-
+    if (blockIdx.x == 0) {
+        const float mx = pair_f[b * 4], den = pair_f[b * 4 + 1];
+        double gwu = 0;
+        for (int i = tid; i < N; i += 256)
+            if (yb[i] != 0.0f && den > 0.0f) gwu += (double)gwb[i] * (double)(expf(sb[i] - mx) / den);
+        gwu = block_sum_d(gwu, red);
+        if (tid == 0) pair_g[b] = (float)gwu;
+    }
     for (int t = tid; t < md.h1 * md.in; t += 256) W1[t] = w1[t];
     for (int t = tid; t < md.h2 * md.h1; t += 256) W2[t] = w2[t];
     for (int t = tid; t < md.h2; t += 256) W3[t] = w3[t];
-    for (int t = tid; t < K * md.in; t += 256) {
-        const int j = t / md.in, c = t - j * md.in;
-        const int idx = (int)top_idx[(size_t)b * K + j];
-        inp[j * ld_in + c] = (c < F) ? hs[((size_t)b * N + idx) * F + c] : ht[((size_t)b * N + idx) * F + (c - F)];
-    }
-    for (int t = tid; t < K * md.h1; t += 256) { const int j = t / md.h1, o = t - j * md.h1; a1[j * ld1 + o] = a1_save[((size_t)b * K + j) * md.h1 + o]; }
-    for (int t = tid; t < K * md.h2; t += 256) { const int j = t / md.h2, o = t - j * md.h2; a2[j * ld2 + o] = a2_save[((size_t)b * K + j) * md.h2 + o]; }
-    if (tid < K) {
-        const float z = logits[(size_t)b * K + tid];
-        const float y = yb[(int)top_idx[(size_t)b * K + tid]];
+    if (tid < Kb) idxs[tid] = (int)top_idx[(size_t)b * K + j0 + tid];
+    __syncthreads();
+    gather_rows(hs, ht, idxs, b, N, F, Kb, md.in, ld_in, inp);
+    for (int t = tid; t < Kb * md.h1; t += 256) { const int j = t / md.h1, o = t - j * md.h1; a1[j * ld1 + o] = a1_save[((size_t)b * K + j0) * md.h1 + t]; }
+    for (int t = tid; t < Kb * md.h2; t += 256) { const int j = t / md.h2, o = t - j * md.h2; a2[j * ld2 + o] = a2_save[((size_t)b * K + j0) * md.h2 + t]; }
+    if (tid < Kb) {
+        const float z = logits[(size_t)b * K + j0 + tid];
+        const float y = yb[idxs[tid]];
         dz[tid] = g_cs * (1.0f / (1.0f + expf(-z)) - y) / ((float)B * K);
     }
     __syncthreads();
-    for (int t = tid; t < K * md.h2; t += 256) {
+    for (int t = tid; t < Kb * md.h2; t += 256) {
         const int j = t / md.h2, o = t - j * md.h2;
         d2[j * ld2 + o] = (a2[j * ld2 + o] > 0.0f) ? dz[j] * W3[o] : 0.0f;
     }
     __syncthreads();
-    for (int t = tid; t < K * md.h1; t += 256) {
+    for (int t = tid; t < Kb * md.h1; t += 256) {
         const int j = t / md.h1, o = t - j * md.h1;
         float acc = 0.0f;
+#pragma unroll 8
         for (int q = 0; q < md.h2; ++q) acc = fmaf(d2[j * ld2 + q], W2[q * md.h1 + o], acc);
         d1[j * ld1 + o] = (a1[j * ld1 + o] > 0.0f) ? acc : 0.0f;
     }
     __syncthreads();
-    for (int t = tid; t < K * md.in; t += 256) {
+    for (int t = tid; t < Kb * md.in; t += 256) {
         const int j = t / md.in, c = t - j * md.in;
         float acc = 0.0f;
+#pragma unroll 8
         for (int q = 0; q < md.h1; ++q) acc = fmaf(d1[j * ld1 + q], W1[q * md.in + c], acc);
-        dinp[((size_t)b * K + j) * md.in + c] = acc;
+        dinp[((size_t)b * K + j0 + j) * md.in + c] = acc;
     }
-    // ---- weight-gradient slab of this pair (thread-owned outputs, sums over the K rows)
-    float* sl = mlp_slab + (size_t)b * (md.h1 * md.in + md.h1 + md.h2 * md.h1 + md.h2 + md.h2 + 1);
+    // ---- weight-gradient slab of this block (thread-owned outputs, sums over its rows)
+    const int msz = md.h1 * md.in + md.h1 + md.h2 * md.h1 + md.h2 + md.h2 + 1;
+    float* sl = mlp_slab + ((size_t)b * gridDim.x + blockIdx.x) * msz;
     for (int t = tid; t < md.h1 * md.in; t += 256) {
         const int o = t / md.in, c = t - o * md.in;
         float acc = 0.0f;
-        for (int j = 0; j < K; ++j) acc = fmaf(d1[j * ld1 + o], inp[j * ld_in + c], acc);
+#pragma unroll 8
+        for (int j = 0; j < Kb; ++j) acc = fmaf(d1[j * ld1 + o], inp[j * ld_in + c], acc);
         sl[t] = acc;
     }
-    float* p = sl + md.h1 * md.in;
-    for (int o = tid; o < md.h1; o += 256) { float acc = 0.0f; for (int j = 0; j < K; ++j) acc += d1[j * ld1 + o]; p[o] = acc; }
-    p += md.h1;
+    float* p_db1 = sl + md.h1 * md.in;
+    float* p_w2 = p_db1 + md.h1;
     for (int t = tid; t < md.h2 * md.h1; t += 256) {
         const int o = t / md.h1, c = t - o * md.h1;
         float acc = 0.0f;
-        for (int j = 0; j < K; ++j) acc = fmaf(d2[j * ld2 + o], a1[j * ld1 + c], acc);
-        p[t] = acc;
+#pragma unroll 8
+        for (int j = 0; j < Kb; ++j) acc = fmaf(d2[j * ld2 + o], a1[j * ld1 + c], acc);
+        p_w2[t] = acc;
     }
-    p += md.h2 * md.h1;
-    for (int o = tid; o < md.h2; o += 256) { float acc = 0.0f; for (int j = 0; j < K; ++j) acc += d2[j * ld2 + o]; p[o] = acc; }
-    p += md.h2;
-    for (int o = tid; o < md.h2; o += 256) { float acc = 0.0f; for (int j = 0; j < K; ++j) acc = fmaf(dz[j], a2[j * ld2 + o], acc); p[o] = acc; }
-    p += md.h2;
-    if (tid == 0) { float acc = 0.0f; for (int j = 0; j < K; ++j) acc += dz[j]; p[0] = acc; }
+    float* p_db2 = p_w2 + md.h2 * md.h1;
+    float* p_w3 = p_db2 + md.h2;
+    float* p_db3 = p_w3 + md.h2;
+    for (int t = tid; t < md.h1 + 2 * md.h2 + 1; t += 256) {      // the four small column sums (<= 16 rows each)
+        float acc = 0.0f;
+        if (t < md.h1) { for (int j = 0; j < Kb; ++j) acc += d1[j * ld1 + t]; p_db1[t] = acc; }
+        else if (t < md.h1 + md.h2) { const int o = t - md.h1; for (int j = 0; j < Kb; ++j) acc += d2[j * ld2 + o]; p_db2[o] = acc; }
+        else if (t < md.h1 + 2 * md.h2) { const int o = t - md.h1 - md.h2; for (int j = 0; j < Kb; ++j) acc = fmaf(dz[j], a2[j * ld2 + o], acc); p_w3[o] = acc; }
+        else { for (int j = 0; j < Kb; ++j) acc += dz[j]; p_db3[0] = acc; }
+    }
 }
 
 // KB2: 8 nodes x 32 lanes per block: d sim (softmax + similarity-MSE), then d h_s, d h_t, d x_s, d x_t
@@ -502,16 +557,10 @@ __global__ void head_mlp_reduce_kernel(const float* __restrict__ slab, int B, in
 static inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 static inline size_t fwd_smem(int N, int Npad, int K, MlpDims md) {
     const size_t keys = sizeof(u64) * (size_t)(Npad > kCand ? Npad : kCand);
-    return keys + sizeof(unsigned) * (size_t)N +
-           sizeof(float) * ((size_t)K * (md.in + 1) + (size_t)K * (md.h1 + 1) + (size_t)K * (md.h2 + 1) +
-                            (size_t)md.in * (md.h1 + 1) + (size_t)md.h1 * (md.h2 + 1) + md.h2 + md.h1 + md.h2 + 1 + 8);
-}
-static inline size_t bwd_smem(int K, MlpDims md) {
-    return sizeof(float) * ((size_t)K * (md.in + 1) + 2 * (size_t)K * (md.h1 + 1) + 2 * (size_t)K * (md.h2 + 1) + K +
-                            (size_t)md.h1 * md.in + (size_t)md.h2 * md.h1 + md.h2 + 8);
+    return keys + sizeof(unsigned) * (size_t)N + 64;
 }
 struct HeadWork { double *partA, *partC, *pair_part; float *pair_f, *pair_g; int nbp, nC; size_t bytes; };
-static inline HeadWork head_work(void* base, int B, int N) {
+static inline HeadWork head_work(void* base, int B, int N) {   // pair_part sized for kMaxK/kRowsPerBlock row blocks
     HeadWork w;
     w.nbp = ceil_div(N, 8);
     w.nC = ceil_div((long long)B * N, 256);
@@ -519,7 +568,7 @@ static inline HeadWork head_work(void* base, int B, int N) {
     size_t o = 0;
     w.partA = reinterpret_cast<double*>(p + o); o += sizeof(double) * (size_t)B * w.nbp * kHeadPartials;
     w.partC = reinterpret_cast<double*>(p + o); o += sizeof(double) * (size_t)w.nC * 3;
-    w.pair_part = reinterpret_cast<double*>(p + o); o += sizeof(double) * (size_t)B * 2;
+    w.pair_part = reinterpret_cast<double*>(p + o); o += sizeof(double) * (size_t)B * (kMaxK / kRowsPerBlock);
     w.pair_f = reinterpret_cast<float*>(p + o); o += sizeof(float) * (size_t)B * 4;
     w.pair_g = reinterpret_cast<float*>(p + o); o += sizeof(float) * (size_t)B;
     w.bytes = o + 64;
@@ -532,6 +581,8 @@ extern "C" int64_t equigspr_head_mlp_size(int32_t F) {
     const int in = 2 * F, h1 = F, h2 = F / 2;
     return (int64_t)h1 * in + h1 + (int64_t)h2 * h1 + h2 + h2 + 1;
 }
+
+extern "C" int64_t equigspr_head_slab_count(int32_t B, int32_t K) { return (int64_t)B * eq::ceil_div(K, eq::kRowsPerBlock); }
 
 extern "C" int64_t equigspr_head_work_bytes(int32_t B, int32_t N) {
     return (int64_t)eq::head_work(nullptr, B, N).bytes;
@@ -571,9 +622,12 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
     hipLaunchKernelGGL(head_pair_kernel, dim3(B), dim3(256), sm, s, hs, ht, labels, sim, W.partA, W.nbp, w1, b1, w2, b2, w3, b3,
                        B, N, Npad, F, K, md, pos, reinterpret_cast<long long*>(top_idx), logits, a1_save, a2_save, W.pair_f,
                        W.pair_part, out_scalars);
+    const int nblk = ceil_div(K, kRowsPerBlock);
+    hipLaunchKernelGGL(head_mlp_kernel, dim3(nblk, B), dim3(256), 0, s, hs, ht, labels, reinterpret_cast<const long long*>(top_idx),
+                       w1, b1, w2, b2, w3, b3, B, N, F, K, md, logits, a1_save, a2_save, W.pair_part);
     hipLaunchKernelGGL(head_weights_kernel, dim3(W.nC), dim3(256), 0, s, sim, rsim, labels, W.pair_f, out_scalars, B, N, wts,
                        W.partC);
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, W.partC, W.nC, W.pair_part, B, N, K, out_scalars);
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, W.partC, W.nC, W.pair_part, nblk, B, N, K, out_scalars);
     EQ_CHECK_LAUNCH("head_forward");
     return 0;
 }
@@ -596,21 +650,14 @@ extern "C" int equigspr_head_backward(const float* hs, const float* ht, const fl
     const float* w1 = mlp;
     const float* w2 = w1 + md.h1 * md.in + md.h1;
     const float* w3 = w2 + md.h2 * md.h1 + md.h2;
-    const size_t sm = bwd_smem(K, md);
-    static size_t sm_set = 0;
-    if (sm > sm_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_pair_bwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        if (e != hipSuccess) { set_error("head_backward: %s", hipGetErrorString(e)); return (int)e; }
-        sm_set = sm;
-    }
-    hipLaunchKernelGGL(head_pair_bwd_kernel, dim3(B), dim3(256), sm, s, hs, ht, labels, sim, W.pair_f, gw,
+    const int nblk = ceil_div(K, kRowsPerBlock);
+    hipLaunchKernelGGL(head_pair_bwd_kernel, dim3(nblk, B), dim3(256), 0, s, hs, ht, labels, sim, W.pair_f, gw,
                        reinterpret_cast<const long long*>(top_idx), logits, a1_save, a2_save, w1, w2, w3, g_corr_sim, B, N, F, K,
                        md, W.pair_g, dinp, mlp_slab);
     hipLaunchKernelGGL(head_node_bwd_kernel, dim3(W.nbp, B), dim3(256), 0, s, hs, ht, xs, xt, labels, gt_pose, sim, rsim, cosv,
                        pos, dinp, gw, W.pair_f, W.pair_g, fin_scalars, g_corr_sim, g_equi, B, N, F, K, md.in, ghs, ght, gxs, gxt);
     const int msz = (int)equigspr_head_mlp_size(F);
-    hipLaunchKernelGGL(head_mlp_reduce_kernel, dim3(ceil_div(msz, 256)), dim3(256), 0, s, mlp_slab, B, msz, grad_mlp);
+    hipLaunchKernelGGL(head_mlp_reduce_kernel, dim3(ceil_div(msz, 256)), dim3(256), 0, s, mlp_slab, B * nblk, msz, grad_mlp);
     EQ_CHECK_LAUNCH("head_backward");
     return 0;
 }

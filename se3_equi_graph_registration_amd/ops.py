@@ -271,7 +271,7 @@ class _HeadFn(torch.autograd.Function):
                                               _p(gw), _stream()), "kabsch_backward")
         ghs, ght = torch.empty_like(hs), torch.empty_like(ht)
         dinp = torch.empty(B, K, 2 * Fd, **f32)
-        slab = torch.empty(B, msz, **f32)
+        slab = torch.empty(int(L.equigspr_head_slab_count(B, K)), msz, **f32)
         gmlp = torch.zeros(msz, **f32)
         g_cs = None if g_cs is None else g_cs.contiguous().float()
         g_eq = None if g_eq is None else g_eq.contiguous().float()
