@@ -188,17 +188,27 @@ def roofline(pkg, S, args, dev):
     bytes_fwd = (2 * (F + 3) * 4 + 2 * 4 + 4 + (F + 3) * 4) * E          # 432 B/edge-layer at F=32
     bytes_bwd = 2 * bytes_fwd
     flops_fwd = (2 * (2 * F + 13) * F + 2 * F * F + 2 * F * F + 2 * F + 12 * F) * E
+    # HBM traffic per launch from the committed rocprofv3 PMC passes (profiles/), when they cover this workload
+    traffic = {"fwd": None, "bwd": None}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_edge_kernels.json")))
+        if pmc["workload"]["edges_per_launch"] == E and pmc["workload"]["feat"] == F:
+            traffic = {"fwd": pmc["edge_fwd_mfma_kernel"]["traffic_bytes"], "bwd": pmc["edge_bwd_mfma_kernel"]["traffic_bytes"]}
+    except Exception:
+        pass
     dom_is_bwd = bwd_ms >= fwd_ms and not args.forward_only
     a_f = bytes_fwd / (fwd_ms * 1e-3) / 1e9
     a_b = bytes_bwd / (bwd_ms * 1e-3) / 1e9
     roof = {"bound": "hbm", "kernel": "edge_bwd_kernel" if dom_is_bwd else "edge_fwd_kernel",
             "achieved": round(a_b if dom_is_bwd else a_f, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round((a_b if dom_is_bwd else a_f) / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round((a_b if dom_is_bwd else a_f) / HBM_PEAK_GBS, 5), "traffic": traffic["bwd" if dom_is_bwd else "fwd"],
             "edges_per_launch": E, "algorithmic_bytes_per_launch": bytes_bwd if dom_is_bwd else bytes_fwd,
             "launch_ms": round(bwd_ms if dom_is_bwd else fwd_ms, 5)}
     extra = {"edge_fwd_ms": round(fwd_ms, 5), "edge_bwd_ms": round(bwd_ms, 5),
              "edge_fwd_GBs": round(a_f, 2), "edge_bwd_GBs": round(a_b, 2),
-             "edge_fwd_fp32_frac": round(flops_fwd / (fwd_ms * 1e-3) / 1e12 / FP32_PEAK_TF, 5)}
+             "edge_fwd_fp32_frac": round(flops_fwd / (fwd_ms * 1e-3) / 1e12 / FP32_PEAK_TF, 5),
+             "edge_fwd_hbm_frac": round(a_f / HBM_PEAK_GBS, 5), "edge_bwd_hbm_frac": round(a_b / HBM_PEAK_GBS, 5),
+             "edge_fwd_traffic": traffic["fwd"], "edge_bwd_traffic": traffic["bwd"]}
     return roof, extra
 
 

@@ -19,7 +19,7 @@
 namespace eq {
 
 
-constexpr int kNodeBwdBlocks = 256;   // slab count of the node-level kernels
+constexpr int kNodeBwdBlocks = 1024;   // slab count of the node-level kernels
 constexpr int kEdgeBwdBlocks = 1024;  // max slab count of the edge kernel
 
 // ---- slab sizes ---------------------------------------------------------------------------
