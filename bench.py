@@ -73,7 +73,7 @@ def build_step(pkg, args, dev, world):
 
     def fwd_bwd():
         graph = pkg.build_pair_graph(batch["src"], batch["tgt"], args.k, loop=True)
-        out = model(batch["feat_src"], batch["src"], graph, ones, batch["feat_tgt"], batch["tgt"], graph, ones,
+        out = model(batch["feat_src"], batch["src"], graph, None, batch["feat_tgt"], batch["tgt"], graph, None,
                     batch["corr"], batch["labels"], batch["gt_pose"])
         if args.forward_only:
             return out[2]

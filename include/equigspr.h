@@ -138,7 +138,7 @@ int equigspr_egnn_backward(const equigspr_egnn_config* cfg, const float* params,
  *   src,tgt [B,n,3]   w [B,n]   R [B,9] row-major   t [B,3]   aux float[B*EQUIGSPR_KABSCH_AUX]
  * Backward: closed form through the polar factor (1/(s_i+s_j) terms), finite for repeated
  * singular values. */
-#define EQUIGSPR_KABSCH_AUX 48
+#define EQUIGSPR_KABSCH_AUX 320
 int equigspr_kabsch_forward(const float* src, const float* tgt, const float* w, int32_t batch,
                             int32_t n, float* R, float* t, float* aux, void* stream);
 int equigspr_kabsch_backward(const float* src, const float* tgt, const float* w, const float* aux,

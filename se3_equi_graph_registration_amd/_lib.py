@@ -14,7 +14,7 @@ from ctypes import POINTER, Structure, c_char_p, c_int32, c_int64, c_void_p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EQUIGSPR_LIB", os.path.join(_HERE, "libequigspr.so"))   # override: kernel experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "equigspr.h")
-KABSCH_AUX = 48
+KABSCH_AUX = 320
 
 
 class EgnnConfig(Structure):

@@ -1,8 +1,7 @@
-// Batched weighted Kabsch pose head for gfx950: one 256-thread workgroup per pair.
-//   pass 1  weighted centroids            (wave shuffles + LDS across the 4 waves)
-//   pass 2  H = sum w (s-cs)(t-ct)^T      (same reduction, 15 partial sums)
-//   lane 0  H += 1e-6 I; one-sided Jacobi SVD of the 3x3 in fp64; R = V D U^T with D flipping
-//           the smallest singular direction when det(V U^T) < 0; t = ct - R cs.
+// Batched weighted Kabsch pose head for gfx950.
+//   moments  fp64 partial raw moments of the weighted clouds, several workgroups per pair
+//   solve    H = sum w (s-cs)(t-ct)^T + 1e-6 I; one-sided Jacobi SVD of the 3x3 in fp64 on one lane;
+//            R = V D U^T with D flipping the smallest singular direction when det(V U^T) < 0; t = ct - R cs.
 // The reference's host-visible `if torch.det(R_b) < 0` (train :749) is a device-side select;
 // nothing synchronises with the host.  Backward is the closed form through the polar factor.
 //
@@ -85,50 +84,80 @@ __device__ inline void svd3_jacobi(const double A[9], double U[9], double sig[3]
 }
 
 // aux layout (floats): cs[0:3] ct[3:6] U[6:15] s~[15:18] R[18:27] sum w(s-cs)[27:30] sum w(t-ct)[30:33]
-__global__ __launch_bounds__(256) void kabsch_fwd_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
-                                                         const float* __restrict__ w, int n, float* __restrict__ Rout,
-                                                         float* __restrict__ tout, float* __restrict__ aux) {
-    __shared__ float red[4 * 15];
-    __shared__ float res[16];
-    const int b = blockIdx.x;
+//
+// Forward in two short launches so that a single pair (B = 1) is not serialised on one CU:
+//   kabsch_moments_kernel  grid (nb, B): fp64 partial raw moments  W = sum w, S = sum w s, T = sum w t, M = sum w s t^T
+//   kabsch_solve_kernel    grid B: cs = fl32(S), ct = fl32(T) (the reference does not divide by W),
+//                          H = sum w (s-cs)(t-ct)^T = M - S ct^T - cs T^T + W cs ct^T, then the 3x3 SVD on one lane.
+constexpr int kKabschParts = 16;   // doubles per partial record: W, S[3], T[3], M[9]
+constexpr int kKabschMaxBlocks = 8;   // partial records live in the pair's aux record behind the first 48 floats
+static_assert(48 + kKabschMaxBlocks * kKabschParts * 2 <= EQUIGSPR_KABSCH_AUX, "aux record too small");
+__device__ __forceinline__ double* kabsch_part(float* aux, int b) { return reinterpret_cast<double*>(aux + (size_t)b * EQUIGSPR_KABSCH_AUX + 48); }
+
+__device__ __forceinline__ double block_sum_d256(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void kabsch_moments_kernel(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                             const float* __restrict__ w, int n, float* __restrict__ aux) {
+    __shared__ double red[4];
+    const int b = blockIdx.y;
+    double* part = kabsch_part(aux, b);
     const float* s = src + (size_t)b * n * 3;
     const float* t = tgt + (size_t)b * n * 3;
     const float* wb = w + (size_t)b * n;
-    float c6[6] = {0, 0, 0, 0, 0, 0};
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float wi = wb[i];
+    double m[kKabschParts];
+#pragma unroll
+    for (int q = 0; q < kKabschParts; ++q) m[q] = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const double wi = wb[i];
+        const double sv[3] = {s[i * 3], s[i * 3 + 1], s[i * 3 + 2]}, tv[3] = {t[i * 3], t[i * 3 + 1], t[i * 3 + 2]};
+        m[0] += wi;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            c6[a] = fmaf(wi, s[i * 3 + a], c6[a]);
-            c6[3 + a] = fmaf(wi, t[i * 3 + a], c6[3 + a]);
+            m[1 + a] += wi * sv[a];
+            m[4 + a] += wi * tv[a];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) m[7 + a * 3 + c] += wi * sv[a] * tv[c];
         }
     }
-    block_reduce_sum<6>(c6, red, res);
-    float cs[3], ct[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { cs[a] = res[a]; ct[a] = res[3 + a]; }
-    __syncthreads();
-    float h15[15];
-#pragma unroll
-    for (int a = 0; a < 15; ++a) h15[a] = 0.0f;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float wi = wb[i];
-        float ds[3], dt[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) { ds[a] = s[i * 3 + a] - cs[a]; dt[a] = t[i * 3 + a] - ct[a]; }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float wa = wi * ds[a];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) h15[a * 3 + c] = fmaf(wa, dt[c], h15[a * 3 + c]);
-            h15[9 + a] += wa;
-            h15[12 + a] = fmaf(wi, dt[a], h15[12 + a]);
-        }
+    for (int q = 0; q < kKabschParts; ++q) {
+        const double v = block_sum_d256(m[q], red);
+        if (threadIdx.x == 0) part[(size_t)blockIdx.x * kKabschParts + q] = v;
     }
-    block_reduce_sum<15>(h15, red, res);
-    if (threadIdx.x == 0) {
+}
+
+__global__ __launch_bounds__(64) void kabsch_solve_kernel(int nb, float* __restrict__ Rout, float* __restrict__ tout,
+                                                          float* __restrict__ aux) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const double* part = kabsch_part(aux, b);
+    double m[kKabschParts];
+#pragma unroll
+    for (int q = 0; q < kKabschParts; ++q) {
+        double v = 0.0;
+        for (int k = lane; k < nb; k += 64) v += part[(size_t)k * kKabschParts + q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        m[q] = v;
+    }
+    if (lane == 0) {
+        const double W = m[0];
+        const float csf[3] = {(float)m[1], (float)m[2], (float)m[3]}, ctf[3] = {(float)m[4], (float)m[5], (float)m[6]};
         double H[9], U[9], V[9], sg[3];
-        for (int i = 0; i < 9; ++i) H[i] = (double)(res[i] + ((i % 4 == 0) ? 1e-6f : 0.0f));     // :738 (fp32 add)
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {
+                // H about the fp32-ROUNDED centroids the backward also uses (consistency matters: with near
+                // one-hot weights s_j - cs is ~1e-5 |s| and the gradient terms cancel to that accuracy)
+                const float h = (float)(m[7 + a * 3 + c] - m[1 + a] * (double)ctf[c] - (double)csf[a] * m[4 + c] +
+                                        W * (double)csf[a] * (double)ctf[c]);
+                H[a * 3 + c] = (double)(h + ((a == c) ? 1e-6f : 0.0f));                        // :738 (fp32 add)
+            }
         svd3_jacobi(H, U, sg, V);
         int lo = 0;
         if (sg[1] < sg[lo]) lo = 1;
@@ -144,13 +173,13 @@ __global__ __launch_bounds__(256) void kabsch_fwd_kernel(const float* __restrict
             }
         float* ax = aux + (size_t)b * EQUIGSPR_KABSCH_AUX;
         for (int a = 0; a < 3; ++a) {
-            const double ta = (double)ct[a] - (R[a * 3 + 0] * cs[0] + R[a * 3 + 1] * cs[1] + R[a * 3 + 2] * cs[2]);   // :754
+            const double ta = (double)ctf[a] - (R[a * 3 + 0] * csf[0] + R[a * 3 + 1] * csf[1] + R[a * 3 + 2] * csf[2]);   // :754
             tout[b * 3 + a] = (float)ta;
-            ax[a] = cs[a];
-            ax[3 + a] = ct[a];
+            ax[a] = csf[a];
+            ax[3 + a] = ctf[a];
             ax[15 + a] = (float)(sgn[a] * sg[a]);
-            ax[27 + a] = res[9 + a];
-            ax[30 + a] = res[12 + a];
+            ax[27 + a] = (float)(m[1 + a] - W * (double)csf[a]);       // sum w (s - cs)
+            ax[30 + a] = (float)(m[4 + a] - W * (double)ctf[a]);       // sum w (t - ct)
         }
         for (int i = 0; i < 9; ++i) {
             Rout[b * 9 + i] = (float)R[i];
@@ -270,7 +299,10 @@ extern "C" int equigspr_kabsch_forward(const float* src, const float* tgt, const
     using namespace eq;
     EQ_CHECK_ARG(src && tgt && w && R && t && aux, EQUIGSPR_EINVAL, "kabsch_forward: null pointer");
     EQ_CHECK_ARG(batch >= 1 && n >= 1, EQUIGSPR_EINVAL, "kabsch_forward: need batch>=1, n>=1");
-    hipLaunchKernelGGL(kabsch_fwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, src, tgt, w, n, R, t, aux);
+    int nb = (n + 255) / 256;
+    if (nb > kKabschMaxBlocks) nb = kKabschMaxBlocks;
+    hipLaunchKernelGGL(kabsch_moments_kernel, dim3(nb, batch), dim3(256), 0, (hipStream_t)stream, src, tgt, w, n, aux);
+    hipLaunchKernelGGL(kabsch_solve_kernel, dim3(batch), dim3(64), 0, (hipStream_t)stream, nb, R, t, aux);
     EQ_CHECK_LAUNCH("kabsch_fwd_kernel");
     return 0;
 }

@@ -22,6 +22,9 @@ from . import ops
 from .ops import DeviceGraph
 
 
+EGNN_ONES = "ones"      # sentinel for edge_attr: the constant all-ones attribute (kernel-side, no tensor)
+
+
 class E_GCL(nn.Module):
     """Parameter container of one layer; same submodule names as the reference (train :185-229).
     The layer math runs inside ``EGNN.forward`` (fused HIP path); a stand-alone
@@ -207,7 +210,7 @@ class EGNN(nn.Module):
         if h.dim() != 2 or x.dim() != 2:
             raise RuntimeError("EGNN.forward expects h [N,F] and x [N,3] (one cloud or a pre-batched graph)")
         graph = self._graph_for(edges, h.shape[0])
-        if self.in_edge_nf == 0:
+        if self.in_edge_nf == 0 or (isinstance(edge_attr, str) and edge_attr == EGNN_ONES):
             edge_attr = None
         elif edge_attr is None:
             raise RuntimeError("EGNN was built with in_edge_nf=1 but edge_attr is None")

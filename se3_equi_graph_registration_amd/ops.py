@@ -52,6 +52,9 @@ def param_count(cfg: EgnnConfig) -> int:
 
 
 # ----------------------------------------------------------------------------------- graph
+_KNN_COL_INDEX = {}
+
+
 class DeviceGraph:
     """Batched graph in the device format (int32 global ids + inverse indices)."""
 
@@ -67,9 +70,14 @@ class DeviceGraph:
                                         _p(scratch), _stream()), "build_csr(row)")
         self.cptr = self.cperm = None
         if need_col_index:
-            if knn_k is not None:      # centre-major kNN list: the col index is the identity permutation
-                self.cptr = torch.arange(0, self.n_edges + 1, knn_k, dtype=torch.int32, device=dev)
-                self.cperm = torch.arange(self.n_edges, dtype=torch.int32, device=dev)
+            if knn_k is not None:      # centre-major kNN list: the col index is the identity permutation (cached)
+                key = (self.n_edges, int(knn_k), str(dev))
+                if key not in _KNN_COL_INDEX:
+                    if len(_KNN_COL_INDEX) > 16:
+                        _KNN_COL_INDEX.clear()
+                    _KNN_COL_INDEX[key] = (torch.arange(0, self.n_edges + 1, knn_k, dtype=torch.int32, device=dev),
+                                           torch.arange(self.n_edges, dtype=torch.int32, device=dev))
+                self.cptr, self.cperm = _KNN_COL_INDEX[key]
             else:
                 self.cptr = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
                 self.cperm = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)

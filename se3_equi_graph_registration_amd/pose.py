@@ -22,6 +22,7 @@ from torch import nn
 
 from . import ops
 from .ops import DeviceGraph
+from .egnn import EGNN_ONES
 
 
 # ------------------------------------------------------------------------------ losses (A13)
@@ -109,10 +110,10 @@ class CrossAttentionPoseRegression(nn.Module):
             graph = DeviceGraph.from_edge_lists(lists, N)
         h_all = torch.cat([h_src.reshape(B * N, Fd), h_tgt.reshape(B * N, Fd)], dim=0)
         x_all = torch.cat([x_src.reshape(B * N, 3), x_tgt.reshape(B * N, 3)], dim=0)
-        if self.egnn.in_edge_nf == 0 or ea_src is None:
+        if self.egnn.in_edge_nf == 0:
             ea = None
-            if self.egnn.in_edge_nf != 0:
-                raise RuntimeError("edge_attr is required (EGNN built with in_edge_nf=1)")
+        elif ea_src is None:
+            ea = EGNN_ONES          # extension: None = the reference's constant all-ones edge_attr (train :387)
         else:
             ea = torch.cat([ea_src.reshape(-1), ea_tgt.reshape(-1)], dim=0)
         h_o, x_o = self.egnn(h_all, x_all, graph, ea)
