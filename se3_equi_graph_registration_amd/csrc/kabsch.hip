@@ -48,7 +48,7 @@ __device__ inline void svd3_jacobi(const double A[9], double U[9], double sig[3]
                 be += B[r * 3 + q] * B[r * 3 + q];
                 ga += B[r * 3 + p] * B[r * 3 + q];
             }
-            if (fabs(ga) > 1e-300 && fabs(ga) > 1e-17 * sqrt(al * be)) {
+            if (fabs(ga) > 1e-300 && fabs(ga) > 1e-15 * sqrt(al * be)) {   // (1e-17 is below fp64 round-off: it never converged, 40 sweeps)
                 rotated = true;
                 const double ze = (be - al) / (2.0 * ga);
                 const double tt = (ze == 0.0) ? 1.0 : copysign(1.0, ze) / (fabs(ze) + sqrt(1.0 + ze * ze));
