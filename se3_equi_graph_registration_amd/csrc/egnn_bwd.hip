@@ -809,8 +809,10 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
     const int E = g->n_edges;
     if constexpr (F == 32) {
         const int tiles = ceil_div(E, 32);
+        // persistent waves: one workgroup per CU (the kernel runs at one wave per SIMD), each wave loops over
+        // its tiles -- the weight staging and the slab epilogue are paid 256 times, not once per 4 tiles
         int blocks = ceil_div(tiles, 4);
-        blocks = blocks < 1 ? 1 : (blocks > kEdgeBwdBlocks ? kEdgeBwdBlocks : blocks);
+        blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
         hipLaunchKernelGGL((edge_bwd_mfma_kernel<H, A>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
                            dagg, Gx, E, dt1, gxr, gxc, slab);
         *n_slabs = blocks;
