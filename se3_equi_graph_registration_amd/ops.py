@@ -214,9 +214,15 @@ class _HeadFn(torch.autograd.Function):
     Outputs: R [B,3,3], t [B,3], corr_loss+sim_loss (scalar), equi loss (scalar), logits [B,K], top_idx [B,K]."""
 
     @staticmethod
-    def forward(ctx, hs, ht, xs, xt, raw_hs, raw_ht, labels, gt_pose, topk, *mlp_params):
+    def forward(ctx, h_all, x_all, raw_hs, raw_ht, labels, gt_pose, topk, *mlp_params):
+        # h_all [2*B*N, F], x_all [2*B*N, 3]: the EGNN outputs for [src clouds..., tgt clouds...]; taking the
+        # un-sliced tensors keeps four slice-backward (zeros + copy) launches out of the autograd graph
         L = _lib.lib()
-        hs, ht, xs, xt = (_need(t.contiguous(), "head input", torch.float32, 3) for t in (hs, ht, xs, xt))
+        h_all = _need(h_all.contiguous(), "h_all", torch.float32, 2)
+        x_all = _need(x_all.contiguous(), "x_all", torch.float32, 2)
+        B0, N0 = raw_hs.shape[0], raw_hs.shape[1]
+        hs, ht = h_all[:B0 * N0].view(B0, N0, -1), h_all[B0 * N0:].view(B0, N0, -1)
+        xs, xt = x_all[:B0 * N0].view(B0, N0, 3), x_all[B0 * N0:].view(B0, N0, 3)
         raw_hs = _need(raw_hs.contiguous().float(), "raw_h_src", torch.float32, 3)
         raw_ht = _need(raw_ht.contiguous().float(), "raw_h_tgt", torch.float32, 3)
         B, N, Fd = hs.shape
@@ -274,10 +280,12 @@ class _HeadFn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         gR = torch.zeros(B, 3, 3, **f32) if gR is None else gR.contiguous()
         gt_ = torch.zeros(B, 3, **f32) if gt_ is None else gt_.contiguous()
-        gxs, gxt, gw = torch.empty_like(xs), torch.empty_like(xt), torch.empty_like(wts)
+        gx_all = torch.empty(2 * B * N, 3, **f32)
+        gxs, gxt, gw = gx_all[:B * N], gx_all[B * N:], torch.empty_like(wts)
         _lib.check(L.equigspr_kabsch_backward(_p(xs), _p(xt), _p(wts), _p(aux), _p(gR), _p(gt_), B, N, _p(gxs), _p(gxt),
                                               _p(gw), _stream()), "kabsch_backward")
-        ghs, ght = torch.empty_like(hs), torch.empty_like(ht)
+        gh_all = torch.empty(2 * B * N, Fd, **f32)
+        ghs, ght = gh_all[:B * N], gh_all[B * N:]
         dinp = torch.empty(B, K, 2 * Fd, **f32)
         slab = torch.empty(int(L.equigspr_head_slab_count(B, K)), msz, **f32)
         gmlp = torch.zeros(msz, **f32)
@@ -294,11 +302,12 @@ class _HeadFn(torch.autograd.Function):
                 n *= d
             grads.append(gmlp[off:off + n].view(shp))
             off += n
-        return (ghs, ght, gxs, gxt, None, None, None, None, None, *grads)
+        return (gh_all, gx_all, None, None, None, None, None, *grads)
 
 
-def fused_pose_head(hs, ht, xs, xt, raw_hs, raw_ht, labels, gt_pose, topk, mlp_params):
-    return _HeadFn.apply(hs, ht, xs, xt, raw_hs, raw_ht, labels, gt_pose, topk, *mlp_params)
+def fused_pose_head(h_all, x_all, raw_hs, raw_ht, labels, gt_pose, topk, mlp_params):
+    """``h_all [2BN,F]``, ``x_all [2BN,3]`` = EGNN outputs for [src clouds..., tgt clouds...]."""
+    return _HeadFn.apply(h_all, x_all, raw_hs, raw_ht, labels, gt_pose, topk, *mlp_params)
 
 
 # ----------------------------------------------------------------------------------- pose loss / Adam

@@ -118,6 +118,7 @@ class CrossAttentionPoseRegression(nn.Module):
             ea = torch.cat([ea_src.reshape(-1), ea_tgt.reshape(-1)], dim=0)
         h_o, x_o = self.egnn(h_all, x_all, graph, ea)
         Fo = h_o.shape[1]
+        self._egnn_out = (h_o, x_o)
         return (h_o[:B * N].view(B, N, Fo), x_o[:B * N].view(B, N, 3), h_o[B * N:].view(B, N, Fo), x_o[B * N:].view(B, N, 3))
 
     def forward(self, h_src, x_src, edges_src, edge_attr_src, h_tgt, x_tgt, edges_tgt, edge_attr_tgt, corr, labels, gt_pose):
@@ -132,7 +133,9 @@ class CrossAttentionPoseRegression(nn.Module):
             # one HIP head (csrc/head.hip) instead of ~220 small ATen launches; same math as the lines below
             mlp_params = [self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias,
                           self.mlp[4].weight, self.mlp[4].bias]
-            R, t, closs, total_loss, logits, top_idx = ops.fused_pose_head(hs, ht, xs, xt, raw_h_src, raw_h_tgt, labels,
+            h_o, x_o = self._egnn_out
+            self._egnn_out = None
+            R, t, closs, total_loss, logits, top_idx = ops.fused_pose_head(h_o, x_o, raw_h_src, raw_h_tgt, labels,
                                                                            gt_pose, self.topk, mlp_params)
             self.last_logits, self.last_top_idx = logits.detach(), top_idx
             return R, t, closs, total_loss, hs, xs, ht, xt, labels
