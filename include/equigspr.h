@@ -195,6 +195,14 @@ int equigspr_adam_step(int32_t n_buckets, float* const* params, const float* con
                        float* const* exp_avg_sq, const int64_t* sizes, float* step_dev, float lr, float beta1,
                        float beta2, float eps, void* stream);
 
+/* ---- A15: SO3TensorProductLayer.forward (src/clean_so3_model.py:34-52) ------------------------
+ * y = W2 relu(W1 vec(D x x^T) + b1) + b2, D = input_dim (the bmm of the two broadcast views sums D identical
+ * products).  x [n_rows, D], w1 [2*out, D*D], w2 [out, 2*out], y [n_rows, out]; w1t_scratch: D*D*2*out floats.
+ * Compiled for input_dim = output_dim = 32 (the reference's instantiation, :85); inference only. */
+int equigspr_so3_tensor_product_forward(const float* x, int32_t n_rows, int32_t input_dim, int32_t output_dim,
+                                        const float* w1, const float* b1, const float* w2, const float* b2,
+                                        float* w1t_scratch, float* y, void* stream);
+
 /* ---- measurement hooks (bench.py's roofline leg; NOT part of the drop-in path) -----------
  * Average duration in ms (written to HOST memory) of the EGNN message-passing edge kernel,
  * measured with HIP events on `stream` over `iters` back-to-back launches (these two calls

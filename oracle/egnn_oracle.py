@@ -321,6 +321,19 @@ def pair_forward_eval(we, wc, h_src, x_src, edges_src, ea_src, h_tgt, x_tgt, edg
 
 
 # --------------------------------------------------------------------------------------
+# A15: SO3TensorProductLayer (src/clean_so3_model.py:34-52)
+# --------------------------------------------------------------------------------------
+def so3_tensor_product(w: Dict[str, Tensor], x: Tensor) -> Tensor:
+    """``mlp(vec(bmm(x[:, :, None].expand(D), x[:, None, :].expand(D))))`` -- the bmm of the two broadcast
+    views sums D identical products, so entry (i, k) is ``D * x_i * x_k`` (clean_so3_model.py:45-52).
+    ``w``: state_dict of the layer (``mlp.0.weight [2*out, D*D]``, ``mlp.0.bias``, ``mlp.2.weight``, ``mlp.2.bias``)."""
+    d = x.shape[1]
+    tp = torch.bmm(x.unsqueeze(2).expand(-1, -1, d), x.unsqueeze(1).expand(-1, d, -1)).reshape(x.shape[0], -1)
+    hid = torch.relu(tp @ w["mlp.0.weight"].t() + w["mlp.0.bias"])
+    return hid @ w["mlp.2.weight"].t() + w["mlp.2.bias"]
+
+
+# --------------------------------------------------------------------------------------
 # §8(d) synthetic pair generator (mirrors datasets/ThreeDMatch.py:18-43 augmentation shape)
 # --------------------------------------------------------------------------------------
 def synthetic_pair(seed: int, n: int = 2048, feat: int = 32, scale=(3.0, 3.0, 3.0), inlier: float = 0.5):

@@ -12,7 +12,8 @@ from .egnn import EGNN, E_GCL  # noqa: F401
 from .pose import (CrossAttentionPoseRegression, pose_loss, compute_losses, egnn_equi_loss,  # noqa: F401
                    unsorted_segment_sum, unsorted_segment_mean)
 from .synth import synthetic_pair, synthetic_batch  # noqa: F401
+from .so3 import SO3TensorProductLayer  # noqa: F401
 
 __all__ = ["EGNN", "E_GCL", "CrossAttentionPoseRegression", "knn_graph", "get_edges_batch", "get_edges_from_idx",
            "build_pair_graph", "DeviceGraph", "weighted_kabsch", "pose_loss", "compute_losses", "egnn_equi_loss",
-           "unsorted_segment_sum", "unsorted_segment_mean", "synthetic_pair", "synthetic_batch"]
+           "unsorted_segment_sum", "unsorted_segment_mean", "synthetic_pair", "synthetic_batch", "SO3TensorProductLayer", "FlatAdam"]

@@ -296,8 +296,29 @@ def gen_kabsch_fixture(name):
     print("wrote", name)
 
 
+def gen_so3tp_fixture(name, n_rows=1000, d=32, seed=21):
+    """A15: the real ``SO3TensorProductLayer`` of src/clean_so3_model.py:34-52 (imported with the same stubs)."""
+    spec = importlib.util.spec_from_file_location("ref_clean_so3", os.path.join(REF, "src", "clean_so3_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    with quiet():
+        spec.loader.exec_module(m)
+    torch.manual_seed(seed)
+    layer = m.SO3TensorProductLayer(d, d)
+    x = torch.randn(n_rows, d)
+    with torch.no_grad():
+        y32 = layer(x)
+        y64 = layer.double()(x.double())
+    out = {"x": x.numpy(), "y": y32.numpy(), "y64": y64.numpy()}
+    out.update({"w." + k: v.float().numpy() for k, v in layer.state_dict().items()})
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name)
+
+
 def main():
     tr, ev = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "so3tp":
+        gen_so3tp_fixture("so3tp_d32.npz")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "wellcond":     # regenerate just this fixture
         gen_pair_fixture(tr, ev, "pair_n512_k12_l2_wellcond.npz", 512, 12, 32, 2, 1, seed=3, out_scale=0.02, with_grads=True,
                          tgt_noise=0.05)
@@ -312,6 +333,7 @@ def main():
     gen_pair_fixture(tr, ev, "pair_ckpt_n2048_k16_l3_h4.npz", 2048, 16, 32, 3, 4, seed=1,
                      ckpt=os.path.join(REF, "checkpoints", "checkpoint-3dmatch.pth"))
     gen_kabsch_fixture("kabsch_cases.npz")
+    gen_so3tp_fixture("so3tp_d32.npz")
 
 
 if __name__ == "__main__":

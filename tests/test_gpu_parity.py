@@ -428,3 +428,42 @@ def test_flat_adam_matches_torch_adam(pk):
     for r, m in zip(ref, mine):
         assert torch.allclose(r.detach(), m, rtol=1e-5, atol=1e-6)
     assert float(fa.step_dev[0]) == 6.0
+
+
+# ------------------------------------------------------------------------------------------------
+# A15: SO3TensorProductLayer (src/clean_so3_model.py:34-52), MFMA forward
+# ------------------------------------------------------------------------------------------------
+def _so3_layer(pk, fx):
+    layer = pk.SO3TensorProductLayer(32, 32)
+    layer.load_state_dict({k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("w.")})
+    return layer.cuda()
+
+
+def test_so3_tensor_product_golden(pk, golden_dir):
+    fx = np.load(os.path.join(golden_dir, "so3tp_d32.npz"))
+    layer = _so3_layer(pk, fx)
+    with torch.no_grad():
+        y = layer(torch.from_numpy(fx["x"]).cuda()).cpu().numpy().astype(np.float64)
+    assert y.shape == fx["y64"].shape
+    assert np.abs(y - fx["y64"]).max() <= anchored_tol(fx["y"], fx["y64"])
+
+
+@pytest.mark.parametrize("n_rows", [1, 31, 33, 40960])
+def test_so3_tensor_product_sizes(pk, golden_dir, n_rows):
+    fx = np.load(os.path.join(golden_dir, "so3tp_d32.npz"))
+    layer = _so3_layer(pk, fx)
+    x = torch.randn(n_rows, 32, generator=torch.Generator().manual_seed(n_rows))
+    w64 = {k[2:]: torch.from_numpy(fx[k]).double() for k in fx.files if k.startswith("w.")}
+    ref64 = orc.so3_tensor_product(w64, x.double()).numpy()
+    ref32 = orc.so3_tensor_product({k: v.float() for k, v in w64.items()}, x).numpy()
+    with torch.no_grad():
+        y = layer(x.cuda()).cpu().numpy().astype(np.float64)
+    assert np.abs(y - ref64).max() <= anchored_tol(ref32, ref64)
+
+
+def test_so3_tensor_product_rejects(pk):
+    with pytest.raises(NotImplementedError):
+        with torch.no_grad():
+            pk.SO3TensorProductLayer(16, 16).cuda()(torch.zeros(4, 16, device="cuda"))
+    with pytest.raises(NotImplementedError):
+        pk.SO3TensorProductLayer(32, 32).cuda()(torch.zeros(4, 32, device="cuda"))     # grad mode: forward-only op

@@ -149,3 +149,12 @@ def test_knn_duplicates_and_ties():
     assert e[0, 0:3].tolist() == [0, 2, 4]       # three coincident points, index order
     assert e[0, 6:9].tolist() == [0, 2, 4]
     assert e[0, 3:6].tolist() == [1, 0, 2]       # self first (d=0), then ties by index
+
+
+def test_so3_tensor_product_golden(golden_dir):
+    """A15: oracle vs the real SO3TensorProductLayer (src/clean_so3_model.py:34-52)."""
+    fx = np.load(os.path.join(golden_dir, "so3tp_d32.npz"))
+    for dt, key, tol in ((torch.float32, "y", 2e-5), (torch.float64, "y64", 1e-11)):
+        y = orc.so3_tensor_product(weights(fx, dt), torch.from_numpy(fx["x"]).to(dt))
+        ref = fx[key]
+        assert np.abs(y.numpy() - ref).max() <= tol * max(1.0, np.abs(ref).max())
