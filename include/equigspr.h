@@ -203,6 +203,29 @@ int equigspr_so3_tensor_product_forward(const float* x, int32_t n_rows, int32_t 
                                         const float* w1, const float* b1, const float* w2, const float* b2,
                                         float* w1t_scratch, float* y, void* stream);
 
+/* ---- A17: gcnLayer (src/gcnLayer.py) ------------------------------------------------------------
+ * build_graph :58-67 (_get_weights :28-46, get_normalize_adj :49-56): w_ij = exp(-d_ij^2 / sigma2), sigma2 =
+ * mean_i(d(i, k-th neighbour))^2, no self loops, symmetrised by max, D^-1/2 A D^-1/2 -- returned as CSR by node
+ * with LOCAL column ids (fp64 arithmetic, fp32 storage) instead of the reference's scipy [N,N] matrix.
+ *   coords [n_clouds*n,3]; nbr/col = row32/col32 of equigspr_knn_graph(loop=1) (k includes the point itself, as
+ *   cKDTree.query(k) does); rptr/rperm = equigspr_build_csr(key=nbr).  sigma2 double[n_clouds]; cnt_scratch int32[N+1];
+ *   dinv float[N]; adj_ptr int32[N+1]; adj_idx/adj_val [2*N*(k-1)] (upper bound on the symmetrised edge count). */
+int equigspr_gcn_build_graph(const float* coords, int32_t n_clouds, int32_t n, int32_t k, const int32_t* nbr,
+                             const int32_t* col, const int32_t* rptr, const int32_t* rperm, double* sigma2,
+                             int32_t* cnt_scratch, float* dinv, int32_t* adj_ptr, int32_t* adj_idx, float* adj_val,
+                             void* stream);
+/* scatter the CSR into a zero-initialised dense [n_clouds, n, n] (parity with the reference matrix) */
+int equigspr_gcn_adjacency_to_dense(const int32_t* adj_ptr, const int32_t* adj_idx, const float* adj_val,
+                                    int32_t n_clouds, int32_t n, float* dense_zeroed, void* stream);
+/* GraphConvolution.forward :77-80 = Conv1d_1x1(bmm(x, adj)):  x [B,C_in,n] -> y [B,C_out,n].
+ * adj_ptr != NULL: fused sparse gather over the CSR (adj_clouds = 1 shares one adjacency, = B one per sample);
+ * adj_ptr == NULL: x already holds bmm(x, adj) (dense adjacency multiplied by the caller's library GEMM). */
+int equigspr_gcn_conv_forward(const float* x, int32_t n_batch, int32_t c_in, int32_t c_out, int32_t n,
+                              const int32_t* adj_ptr, const int32_t* adj_idx, const float* adj_val, int32_t adj_clouds,
+                              const float* weight, const float* bias, float* y, void* stream);
+/* GlobalPooling.forward :90-94: x [B,C,n] -> out [B,2C] = [max over n | mean over n] */
+int equigspr_gcn_global_pool(const float* x, int32_t n_batch, int32_t channels, int32_t n, float* out, void* stream);
+
 /* ---- measurement hooks (bench.py's roofline leg; NOT part of the drop-in path) -----------
  * Average duration in ms (written to HOST memory) of the EGNN message-passing edge kernel,
  * measured with HIP events on `stream` over `iters` back-to-back launches (these two calls

@@ -321,6 +321,41 @@ def pair_forward_eval(we, wc, h_src, x_src, edges_src, ea_src, h_tgt, x_tgt, edg
 
 
 # --------------------------------------------------------------------------------------
+# A17: gcnLayer (src/gcnLayer.py)
+# --------------------------------------------------------------------------------------
+def gcn_build_graph(coordinates, k: int = 25):
+    """Dense fp64 restatement of ``build_graph`` :58-67 (``_get_weights`` :28-46, ``get_normalize_adj`` :49-56):
+    k nearest points INCLUDING the point itself (cKDTree.query), Gaussian weights with sigma2 = mean(k-th distance)^2,
+    zero diagonal, symmetrise by max, D^-1/2 A D^-1/2.  Brute-force distances (N <= a few thousand)."""
+    import numpy as np
+    x = np.asarray(coordinates, dtype=np.float64)
+    n = x.shape[0]
+    d = np.sqrt(((x[:, None, :] - x[None, :, :]) ** 2).sum(-1))
+    order = np.argsort(d, axis=1, kind="stable")[:, :k]
+    dist = np.take_along_axis(d, order, axis=1)
+    sigma2 = np.mean(dist[:, -1]) ** 2
+    w = np.zeros((n, n))
+    np.put_along_axis(w, order, np.exp(-dist ** 2 / sigma2), axis=1)
+    np.fill_diagonal(w, 0.0)
+    w = np.maximum(w, w.T)
+    with np.errstate(divide="ignore"):
+        d_inv = np.power(w.sum(1), -0.5)
+    d_inv[np.isinf(d_inv)] = 0.0
+    return (w * d_inv[None, :]).T * d_inv[None, :]
+
+
+def gcn_graph_convolution(w: Dict[str, Tensor], adj: Tensor, x: Tensor) -> Tensor:
+    """``GraphConvolution.forward`` :77-80: ``conv1x1(bmm(x, adj))``; ``w``: ``conv.weight [out,in,1]``, ``conv.bias``."""
+    y = torch.einsum("oc,bcn->bon", w["conv.weight"][:, :, 0], torch.bmm(x, adj))
+    return y + w["conv.bias"][None, :, None] if "conv.bias" in w else y
+
+
+def gcn_global_pooling(x: Tensor) -> Tensor:
+    """``GlobalPooling.forward`` :90-94."""
+    return torch.cat((x.max(dim=2).values, x.mean(dim=2)), dim=-1)
+
+
+# --------------------------------------------------------------------------------------
 # A15: SO3TensorProductLayer (src/clean_so3_model.py:34-52)
 # --------------------------------------------------------------------------------------
 def so3_tensor_product(w: Dict[str, Tensor], x: Tensor) -> Tensor:

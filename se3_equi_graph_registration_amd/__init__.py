@@ -13,7 +13,9 @@ from .pose import (CrossAttentionPoseRegression, pose_loss, compute_losses, egnn
                    unsorted_segment_sum, unsorted_segment_mean)
 from .synth import synthetic_pair, synthetic_batch  # noqa: F401
 from .so3 import SO3TensorProductLayer  # noqa: F401
+from .gcn import build_graph, GraphConvolution, GlobalPooling, KnnAdjacency  # noqa: F401
 
 __all__ = ["EGNN", "E_GCL", "CrossAttentionPoseRegression", "knn_graph", "get_edges_batch", "get_edges_from_idx",
            "build_pair_graph", "DeviceGraph", "weighted_kabsch", "pose_loss", "compute_losses", "egnn_equi_loss",
-           "unsorted_segment_sum", "unsorted_segment_mean", "synthetic_pair", "synthetic_batch", "SO3TensorProductLayer", "FlatAdam"]
+           "unsorted_segment_sum", "unsorted_segment_mean", "synthetic_pair", "synthetic_batch", "SO3TensorProductLayer", "FlatAdam", "build_graph", "GraphConvolution",
+           "GlobalPooling", "KnnAdjacency"]

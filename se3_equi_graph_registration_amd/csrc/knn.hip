@@ -11,6 +11,7 @@
 //
 // Replaces torch_cluster.knn_graph at src/3dmatch_train_egnn_with_batch.py:1005-1006.
 #include "common.h"
+#include "scan.h"
 
 namespace eq {
 
@@ -139,32 +140,6 @@ __global__ void csr_count_kernel(const int* __restrict__ key, int n_edges, int* 
 }
 
 // exclusive scan of cnt[0..n) -> ptr[0..n], cursor[0..n) = ptr[0..n) ; single block of 1024
-__global__ __launch_bounds__(1024) void csr_scan_kernel(int* __restrict__ cnt_cursor, int n, int* __restrict__ ptr) {
-    __shared__ int part[1024];
-    const int t = threadIdx.x;
-    const int chunk = (n + 1023) / 1024;
-    const int lo = t * chunk;
-    const int hi = min(lo + chunk, n);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += cnt_cursor[i];
-    part[t] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = (t >= off) ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    int run = part[t] - s;   // exclusive prefix of this thread's chunk
-    for (int i = lo; i < hi; ++i) {
-        const int c = cnt_cursor[i];
-        ptr[i] = run;
-        cnt_cursor[i] = run;
-        run += c;
-    }
-    if (t == 1023) ptr[n] = part[1023];
-}
-
 __global__ void csr_fill_kernel(const int* __restrict__ key, int n_edges, int* __restrict__ cursor,
                                 int* __restrict__ perm) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -240,7 +215,7 @@ extern "C" int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n
     if (err != hipSuccess) { set_error("build_csr memset: %s", hipGetErrorString(err)); return (int)err; }
     if (n_edges > 0)
         hipLaunchKernelGGL(csr_count_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, key, n_edges, scratch);
-    hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, s, scratch, n_nodes, ptr);
+    hipLaunchKernelGGL(csr_scan_kernel<0>, dim3(1), dim3(1024), 0, s, scratch, n_nodes, ptr);
     if (n_edges > 0) {
         hipLaunchKernelGGL(csr_fill_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, key, n_edges, scratch, perm);
         hipLaunchKernelGGL(csr_sort_kernel, dim3(ceil_div(n_nodes, 4)), dim3(256), 0, s, ptr, n_nodes, perm);

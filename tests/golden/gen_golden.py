@@ -314,8 +314,36 @@ def gen_so3tp_fixture(name, n_rows=1000, d=32, seed=21):
     print("wrote", name)
 
 
+def gen_gcn_fixture(name, n=300, k=9, c_out=16, batch=2, seed=31):
+    """A17: the real src/gcnLayer.py (build_graph on scipy/cKDTree, GraphConvolution, GlobalPooling)."""
+    spec = importlib.util.spec_from_file_location("ref_gcn", os.path.join(REF, "src", "gcnLayer.py"))
+    m = importlib.util.module_from_spec(spec)
+    with quiet():
+        spec.loader.exec_module(m)
+    rng = np.random.default_rng(seed)
+    coords = rng.standard_normal((batch, n, 3)).astype(np.float32)
+    with quiet():
+        adj = np.stack([m.build_graph(coords[b], k=k).toarray() for b in range(batch)])      # fp64 [B,n,n]
+    torch.manual_seed(seed)
+    layer = m.GraphConvolution(3, c_out)
+    x = torch.from_numpy(coords).transpose(1, 2).contiguous()                                    # [B,3,n]
+    with torch.no_grad():
+        y = layer(torch.from_numpy(adj).float(), x)
+        pooled = m.GlobalPooling()(y)
+        y64 = layer.double()(torch.from_numpy(adj), x.double())
+        pooled64 = m.GlobalPooling()(y64)
+    out = {"coords": coords, "k": np.int64(k), "adj64": adj, "y": y.numpy(), "y64": y64.numpy(), "pooled": pooled.numpy(),
+           "pooled64": pooled64.numpy()}
+    out.update({"w." + kk: v.float().numpy() for kk, v in layer.state_dict().items()})
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name)
+
+
 def main():
     tr, ev = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "gcn":
+        gen_gcn_fixture("gcn_n300_k9.npz")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "so3tp":
         gen_so3tp_fixture("so3tp_d32.npz")
         return
@@ -334,6 +362,7 @@ def main():
                      ckpt=os.path.join(REF, "checkpoints", "checkpoint-3dmatch.pth"))
     gen_kabsch_fixture("kabsch_cases.npz")
     gen_so3tp_fixture("so3tp_d32.npz")
+    gen_gcn_fixture("gcn_n300_k9.npz")
 
 
 if __name__ == "__main__":

@@ -467,3 +467,57 @@ def test_so3_tensor_product_rejects(pk):
             pk.SO3TensorProductLayer(16, 16).cuda()(torch.zeros(4, 16, device="cuda"))
     with pytest.raises(NotImplementedError):
         pk.SO3TensorProductLayer(32, 32).cuda()(torch.zeros(4, 32, device="cuda"))     # grad mode: forward-only op
+
+
+# ------------------------------------------------------------------------------------------------
+# A17: gcnLayer (src/gcnLayer.py): build_graph / GraphConvolution / GlobalPooling
+# ------------------------------------------------------------------------------------------------
+def test_gcn_build_graph_golden(pk, golden_dir):
+    fx = np.load(os.path.join(golden_dir, "gcn_n300_k9.npz"))
+    coords, k = fx["coords"], int(fx["k"])
+    adj = pk.build_graph(torch.from_numpy(coords).cuda(), k=k)
+    dense = adj.to_dense().cpu().numpy()
+    assert ((dense != 0) == (fx["adj64"] != 0)).all()                       # same symmetrised edge set
+    assert np.abs(dense - fx["adj64"]).max() <= 2e-7                        # fp64 arithmetic, fp32 storage
+    assert np.array_equal(dense, dense.transpose(0, 2, 1))
+    single = pk.build_graph(coords[0], k=k)                                 # numpy [n,3], as the reference takes it
+    assert np.array_equal(single.to_dense().cpu().numpy(), dense[0])
+
+
+def test_gcn_conv_and_pool_golden(pk, golden_dir):
+    fx = np.load(os.path.join(golden_dir, "gcn_n300_k9.npz"))
+    coords, k = fx["coords"], int(fx["k"])
+    layer = pk.GraphConvolution(3, fx["y"].shape[1])
+    layer.load_state_dict({kk[2:]: torch.from_numpy(fx[kk]) for kk in fx.files if kk.startswith("w.")})
+    layer = layer.cuda()
+    x = torch.from_numpy(coords).cuda().transpose(1, 2).contiguous()
+    adj = pk.build_graph(torch.from_numpy(coords).cuda(), k=k)
+    tol = anchored_tol(fx["y"], fx["y64"])
+    with torch.no_grad():
+        y_sparse = layer(adj, x)
+        y_dense = layer(torch.from_numpy(fx["adj64"]).float().cuda(), x)    # the reference's dense-tensor call form
+        pooled = pk.GlobalPooling()(y_sparse)
+    assert np.abs(y_sparse.cpu().numpy() - fx["y64"]).max() <= tol
+    assert np.abs(y_dense.cpu().numpy() - fx["y64"]).max() <= tol
+    assert np.abs(pooled.cpu().numpy() - fx["pooled64"]).max() <= tol
+    with pytest.raises(NotImplementedError):
+        layer(adj, x)                                                       # grad mode: forward-only op
+
+
+@pytest.mark.parametrize("n,k,c_in,c_out", [(1024, 25, 3, 64), (257, 5, 33, 7)])
+def test_gcn_random_vs_oracle(pk, n, k, c_in, c_out):
+    g = torch.Generator().manual_seed(n + k)
+    coords = torch.randn(2, n, 3, generator=g)
+    x = torch.randn(2, c_in, n, generator=g)
+    layer = pk.GraphConvolution(c_in, c_out)
+    w64 = {kk: v.detach().double() for kk, v in layer.state_dict().items()}
+    adj64 = np.stack([orc.gcn_build_graph(coords[b].numpy(), k) for b in range(2)])
+    y64 = orc.gcn_graph_convolution(w64, torch.from_numpy(adj64), x.double())
+    y32 = orc.gcn_graph_convolution({kk: v.float() for kk, v in w64.items()}, torch.from_numpy(adj64).float(), x)
+    with torch.no_grad():
+        adj = pk.build_graph(coords.cuda(), k=k)
+        y = layer.cuda()(adj, x.cuda())
+        pooled = pk.GlobalPooling()(y)
+    assert np.abs(adj.to_dense().cpu().numpy() - adj64).max() <= 2e-7
+    assert np.abs(y.cpu().numpy() - y64.numpy()).max() <= anchored_tol(y32.numpy(), y64.numpy())
+    assert np.abs(pooled.cpu().numpy() - orc.gcn_global_pooling(y64).numpy()).max() <= anchored_tol(y32.numpy(), y64.numpy())

@@ -158,3 +158,19 @@ def test_so3_tensor_product_golden(golden_dir):
         y = orc.so3_tensor_product(weights(fx, dt), torch.from_numpy(fx["x"]).to(dt))
         ref = fx[key]
         assert np.abs(y.numpy() - ref).max() <= tol * max(1.0, np.abs(ref).max())
+
+
+def test_gcn_layer_golden(golden_dir):
+    """A17: oracle vs the real src/gcnLayer.py (build_graph on scipy/cKDTree, GraphConvolution, GlobalPooling)."""
+    fx = np.load(os.path.join(golden_dir, "gcn_n300_k9.npz"))
+    coords, k = fx["coords"], int(fx["k"])
+    adj = np.stack([orc.gcn_build_graph(coords[b], k) for b in range(coords.shape[0])])
+    assert np.abs(adj - fx["adj64"]).max() <= 1e-12
+    assert ((adj != 0) == (fx["adj64"] != 0)).all()
+    w = weights(fx, torch.float64)
+    x = torch.from_numpy(coords).double().transpose(1, 2)
+    y = orc.gcn_graph_convolution(w, torch.from_numpy(adj), x)
+    assert np.abs(y.numpy() - fx["y64"]).max() <= 1e-12
+    assert np.abs(orc.gcn_global_pooling(y).numpy() - fx["pooled64"]).max() <= 1e-12
+    y32 = orc.gcn_graph_convolution(weights(fx, torch.float32), torch.from_numpy(adj).float(), x.float())
+    assert np.abs(y32.numpy() - fx["y"]).max() <= 2e-6
