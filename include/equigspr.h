@@ -226,6 +226,21 @@ int equigspr_gcn_conv_forward(const float* x, int32_t n_batch, int32_t c_in, int
 /* GlobalPooling.forward :90-94: x [B,C,n] -> out [B,2C] = [max over n | mean over n] */
 int equigspr_gcn_global_pool(const float* x, int32_t n_batch, int32_t channels, int32_t n, float* out, void* stream);
 
+/* ---- A16: real spherical harmonics and the equivariant kernel basis (tools/) --------------------------
+ * equigspr_sh_forward: all degrees 0..max_l in one pass; Y row layout [(max_l+1)^2], degree l at [l^2, (l+1)^2),
+ * m = -l..l (tools/spherical_harmonics.py:107-123).  `in` is float or double (in_is_f64) and holds
+ *   mode 0: cartesian [n,3]   (basis.py:57-95 axis convention; also writes sph [n,3] = radius, alpha, beta if non-NULL)
+ *   mode 1: (theta, phi) [n,2]                       (get_spherical_harmonics(l, theta, phi))
+ *   mode 2: spherical [n,3] = (radius, alpha, beta)  (precompute_sh: theta = pi - beta, phi = alpha; irr_repr.py:103-104)
+ * fp64 arithmetic; y (fp32) and/or y64 (fp64) receive the result.  max_l <= 8. */
+int equigspr_sh_forward(const void* in, int32_t in_is_f64, int64_t n, int32_t mode, int32_t max_l, float* sph, float* y,
+                        double* y64, void* stream);
+/* get_basis inner product (tools/basis.py:186-198) for one (d_in, d_out):
+ *   out [n, (2 d_out+1)(2 d_in+1), nJ] = stack_J( Y_J Q_J^T ),  J = |d_in-d_out| .. d_in+d_out,
+ *   q [nJ, (2 d_out+1)(2 d_in+1), 2 (d_in+d_out) + 1] (rows of Q_J, zero padded); y from equigspr_sh_forward (max_l). */
+int equigspr_sh_basis_forward(const float* y, int64_t n, int32_t max_l, int32_t d_in, int32_t d_out, const float* q,
+                              float* out, void* stream);
+
 /* ---- measurement hooks (bench.py's roofline leg; NOT part of the drop-in path) -----------
  * Average duration in ms (written to HOST memory) of the EGNN message-passing edge kernel,
  * measured with HIP events on `stream` over `iters` back-to-back launches (these two calls

@@ -14,7 +14,7 @@ reference's own ``tools/spherical_harmonics.py`` / ``tools/basis.py`` (tests/gol
 data blob (tools/irr_repr.py:12-20) which the repository does not ship, and the sign of ``Q_J`` is whatever LAPACK
 returned on the author's machine.  Here D^l(R) is recovered from the property the reference's own test pins
 (tests/test_irrep_repr.py: ``Y(R x) = D(R) Y(x)``) and ``Q_J`` is the unique unit null vector of the same Sylvester
-system (basis.py:113-121), sign-normalised so that its largest-magnitude entry is positive."""
+system (basis.py:113-121), sign-normalised so that its first entry within 10 % of the largest magnitude is positive."""
 from __future__ import annotations
 
 from itertools import product
@@ -115,7 +115,7 @@ _ANGLES = [(0.3 + 1.1 * i, 0.7 + 0.9 * i, 1.9 + 0.5 * i) for i in range(5)]
 
 def basis_transformation_Q_J(j: int, d_in: int, d_out: int) -> np.ndarray:
     """Unit null vector of the stacked Sylvester systems kron(D_out (x) D_in, I) - kron(I, D_J^T) (basis.py:104-138),
-    reshaped to [(2 d_out + 1)(2 d_in + 1), 2J + 1]; sign: largest-magnitude entry positive."""
+    reshaped to [(2 d_out + 1)(2 d_in + 1), 2J + 1]; sign: first entry within 10 % of the largest magnitude positive."""
     rows = []
     for a, b, c in _ANGLES:
         r_t = np.kron(irr_repr(d_out, a, b, c), irr_repr(d_in, a, b, c))
@@ -125,7 +125,7 @@ def basis_transformation_Q_J(j: int, d_in: int, d_out: int) -> np.ndarray:
     null = vt[s < 1e-10] if (s < 1e-10).any() else vt[-1:]
     assert null.shape[0] == 1, null.shape
     q = null[0]
-    q = q * np.sign(q[np.argmax(np.abs(q))])
+    q = q * np.sign(q[np.flatnonzero(np.abs(q) > 0.9 * np.abs(q).max())[0]])
     return q.reshape((2 * d_out + 1) * (2 * d_in + 1), 2 * j + 1)
 
 

@@ -339,7 +339,58 @@ def gen_gcn_fixture(name, n=300, k=9, c_out=16, batch=2, seed=31):
     print("wrote", name)
 
 
+def gen_sh_fixture(name, n=257, max_l=6, seed=41):
+    """A16: the real tools/spherical_harmonics.py and tools/basis.py::get_spherical_from_cartesian.  The reference
+    files import the absent third-party package ``se3_transformer_pytorch`` for their helpers: its ``utils`` is the
+    reference's own tools/utils.py; ``irr_repr`` cannot be loaded at all (it needs the J_dense blob the repository does
+    not ship, tools/irr_repr.py:12-20), so only functions that never touch it are executed here and the composition
+    ``theta = pi - beta, phi = alpha`` (tools/irr_repr.py:103-104) is applied by this script."""
+    from math import pi
+
+    def load(modname, fname):
+        spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, "tools", fname))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = m
+        spec.loader.exec_module(m)
+        return m
+    os.environ["CLEAR_CACHE"] = "1"                      # no disk cache under ~/.cache.equivariant_attention
+    _stub("se3_transformer_pytorch")
+    load("se3_transformer_pytorch.utils", "utils.py")
+    shm = load("se3_transformer_pytorch.spherical_harmonics", "spherical_harmonics.py")
+    _stub("se3_transformer_pytorch.irr_repr", irr_repr=None, spherical_harmonics=None)
+    bas = load("se3_transformer_pytorch.basis", "basis.py")
+    rng = np.random.default_rng(seed)
+    cart = rng.standard_normal((n, 3)).astype(np.float32)
+    cart[0] = (0.0, 1.5, 0.0)                            # on the polar axis (input component 1), both signs
+    cart[1] = (0.0, -0.5, 0.0)
+    cart[2] = (0.0, 0.0, 0.0)                            # zero vector: atan2(0, 0) = 0
+    cart[3] = (1.0, 0.0, 0.0)
+    out = {"cart": cart, "max_l": np.int64(max_l)}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        c = torch.from_numpy(cart).to(dt)
+        sph = bas.get_spherical_from_cartesian(c)
+        out["sph_" + tag] = sph.numpy()
+        ys = []
+        for l in range(max_l + 1):
+            ys.append(shm.get_spherical_harmonics(l, pi - sph[..., 2], sph[..., 1]))
+            shm.clear_spherical_harmonics_cache()
+        out["y_" + tag] = torch.cat(ys, dim=-1).numpy()
+    theta = 0.1 * rng.standard_normal((n,))               # the angle distribution of tests/test_spherical_harmonics.py
+    phi = 0.1 * rng.standard_normal((n,))
+    out["theta"], out["phi"] = theta, phi
+    ys = []
+    for l in range(8):
+        ys.append(shm.get_spherical_harmonics(l, torch.from_numpy(theta), torch.from_numpy(phi)))
+        shm.clear_spherical_harmonics_cache()
+    out["y_angles_f64"] = torch.cat(ys, dim=-1).numpy()
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "sh":
+        gen_sh_fixture("sh_l6.npz")
+        return
     tr, ev = load_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "gcn":
         gen_gcn_fixture("gcn_n300_k9.npz")
@@ -363,6 +414,7 @@ def main():
     gen_kabsch_fixture("kabsch_cases.npz")
     gen_so3tp_fixture("so3tp_d32.npz")
     gen_gcn_fixture("gcn_n300_k9.npz")
+    gen_sh_fixture("sh_l6.npz")
 
 
 if __name__ == "__main__":

@@ -521,3 +521,49 @@ def test_gcn_random_vs_oracle(pk, n, k, c_in, c_out):
     assert np.abs(adj.to_dense().cpu().numpy() - adj64).max() <= 2e-7
     assert np.abs(y.cpu().numpy() - y64.numpy()).max() <= anchored_tol(y32.numpy(), y64.numpy())
     assert np.abs(pooled.cpu().numpy() - orc.gcn_global_pooling(y64).numpy()).max() <= anchored_tol(y32.numpy(), y64.numpy())
+
+
+# ------------------------------------------------------------------------------------------------
+# A16: spherical harmonics / irrep basis (tools/spherical_harmonics.py, tools/basis.py)
+# ------------------------------------------------------------------------------------------------
+def test_sh_golden(pk, golden_dir):
+    from math import pi
+    from se3_equi_graph_registration_amd import sh
+    fx = np.load(os.path.join(golden_dir, "sh_l6.npz"))
+    max_l = int(fx["max_l"])
+    cart = torch.from_numpy(fx["cart"]).cuda()
+    sph = sh.get_spherical_from_cartesian(cart)
+    assert np.abs(sph.cpu().numpy() - fx["sph_f64"]).max() <= 4 * np.abs(fx["sph_f32"] - fx["sph_f64"]).max() + 1e-6
+    tol = anchored_tol(fx["y_f32"], fx["y_f64"])
+    ys = sh.precompute_sh(torch.from_numpy(fx["sph_f64"]).cuda(), max_l)                    # fp64 spherical input
+    y = torch.cat([ys[j] for j in range(max_l + 1)], dim=-1).cpu().numpy()
+    assert y.dtype == np.float64 and np.abs(y - fx["y_f64"]).max() <= 1e-12
+    ys = sh.precompute_sh(sph, max_l)                                                       # fp32 spherical input
+    y = torch.cat([ys[j] for j in range(max_l + 1)], dim=-1).cpu().numpy()
+    assert np.abs(y - fx["y_f64"]).max() <= tol
+    theta, phi = torch.from_numpy(fx["theta"]).cuda(), torch.from_numpy(fx["phi"]).cuda()
+    y = torch.cat([sh.get_spherical_harmonics(l, theta, phi) for l in range(8)], dim=-1).cpu().numpy()
+    assert np.abs(y - fx["y_angles_f64"]).max() <= 1e-12
+    assert np.abs(sh.get_spherical_harmonics_element(3, -2, theta, phi).cpu().numpy() - fx["y_angles_f64"][:, 9 + 1]).max() <= 1e-12
+
+
+@pytest.mark.parametrize("max_degree,shape", [(1, (2, 500)), (3, (3, 7, 11)), (2, (40960,))])
+def test_get_basis_vs_oracle(pk, max_degree, shape):
+    from oracle import sh_oracle as so
+    from se3_equi_graph_registration_amd import sh
+    g = torch.Generator().manual_seed(max_degree)
+    r = torch.randn(*shape, 3, generator=g)
+    if len(shape) == 2:
+        r[0, 0] = torch.tensor([0.0, 2.0, 0.0])            # polar axis and the zero vector
+        r[0, 1] = 0.0
+    n_check = min(r.reshape(-1, 3).shape[0], 2000)
+    basis = sh.get_basis(r.cuda(), max_degree)
+    assert len(basis) == (max_degree + 1) ** 2
+    flat = r.reshape(-1, 3)[:n_check]
+    ref64 = so.get_basis(flat.double(), max_degree)
+    ref32 = so.get_basis(flat, max_degree)
+    for key, val in basis.items():
+        d_in, d_out = map(int, key.split(","))
+        assert val.shape == (*shape, 1, 2 * d_out + 1, 1, 2 * d_in + 1, 2 * min(d_in, d_out) + 1)
+        got = val.reshape(-1, *val.shape[len(shape):])[:n_check].cpu().numpy().astype(np.float64)
+        assert np.abs(got - ref64[key].numpy()).max() <= anchored_tol(ref32[key].numpy(), ref64[key].numpy()), key
