@@ -46,7 +46,9 @@ def parse():
     ap.add_argument("--feat", type=int, default=32)
     ap.add_argument("--heads", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
-    ap.add_argument("--graph-collectives", action="store_true", help="N>1: capture the RCCL all-reduce inside the step graph")
+    ap.add_argument("--graph-collectives", action="store_true", help="N>1: capture the RCCL all-reduce inside ONE step graph")
+    ap.add_argument("--split-graph", action="store_true",
+                    help="two hipGraphs (zero+fwd+bwd | Adam) with the all-reduce launched eagerly between them (the N>1 default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: inference step (not the headline metric)")
@@ -107,10 +109,10 @@ def build_step(pkg, args, dev, world):
 def make_runner(S, args, world, dev):
     """Returns (callable running one step, used_graph).
 
-    1 GPU: the whole step (zero, kNN, fwd, head, losses, bwd, Adam) is ONE hipGraph.  N GPUs: the step has an
-    RCCL all-reduce in the middle; eager launches interleaved with graph replays fault on this ROCm stack
-    (write to a read-only page in the following replay -- reproduced on 1 GPU with a stand-in eager op), so
-    the N>1 default is eager launches; --graph-collectives captures the all-reduce inside the single graph."""
+    1 GPU: the whole step (zero, kNN, fwd, head, losses, bwd, Adam) is ONE hipGraph.  N GPUs: two hipGraphs
+    (zero + kNN + fwd + head + losses + bwd | Adam) with the two RCCL all-reduces launched eagerly between them
+    (ProcessGroupNCCL's own stream, ordered by events) -- see split_graph_runner.  --graph-collectives captures
+    the all-reduce inside one graph instead; --no-graph launches everything eagerly."""
     dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
 
     def eager():
@@ -124,8 +126,15 @@ def make_runner(S, args, world, dev):
         S["opt_step"]()
         return loss
 
-    if args.no_graph or (dist_on and not args.graph_collectives):
+    if args.no_graph:
         return eager, False
+    if (args.split_graph or (dist_on and not args.graph_collectives)) and not args.forward_only:
+        try:
+            return split_graph_runner(S, args, dist_on, eager), True
+        except Exception as exc:
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize()
+            return eager, False
     try:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -156,6 +165,53 @@ def make_runner(S, args, world, dev):
         print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
         torch.cuda.synchronize()
         return eager, False
+
+
+def split_graph_runner(S, args, dist_on, eager):
+    """Graph A = zero + kNN + fwd + head + losses + bwd; eager middle = the two RCCL all-reduces (ProcessGroupNCCL
+    issues them on its own stream, ordered by events); graph B = Adam.  BENCH_STANDIN=current|side replaces the
+    collective by an eager `mul_` on the gradient buckets on the current / a side stream (1-GPU probe of whether
+    eager launches between replays are safe on this stack)."""
+    standin = os.environ.get("BENCH_STANDIN", "")
+    side = torch.cuda.Stream()
+    warm = torch.cuda.Stream()
+    warm.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(warm):
+        for _ in range(3):
+            eager()
+    torch.cuda.current_stream().wait_stream(warm)
+    torch.cuda.synchronize()
+    ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    S["zero"]()
+    with torch.cuda.graph(ga):
+        S["zero"]()
+        S["loss"] = S["fwd_bwd"]()
+    with torch.cuda.graph(gb, pool=ga.pool()):
+        S["opt_step"]()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, pool=ga.pool()):
+        S["restore"]()
+    S["restore"] = lambda: gr.replay()
+    buckets = S["dp"].buckets()
+
+    def mid():
+        if dist_on:
+            S["dp"].sync(force=True)
+        elif standin == "current":
+            for b in buckets:
+                b.mul_(1.0)
+        elif standin == "side":
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for b in buckets:
+                    b.mul_(1.0)
+            torch.cuda.current_stream().wait_stream(side)
+
+    def step():
+        ga.replay()
+        mid()
+        gb.replay()
+    return step
 
 
 def roofline(pkg, S, args, dev):
@@ -288,7 +344,19 @@ def main():
     pkg.lib()
 
     S = build_step(pkg, args, dev, world)
+    # Everything runs on a non-default stream: on this ROCm stack an eager launch on the NULL stream between two
+    # hipGraph replays on the NULL stream faults in the next replay ("write access to a read-only page"; reproduced
+    # with a single mul_, profiles/README.md); on any other stream the same sequence is fine.  BENCH_NULL_STREAM=1
+    # keeps the null stream (to reproduce the finding).
+    if os.environ.get("BENCH_NULL_STREAM") != "1":
+        work_stream = torch.cuda.Stream()
+        work_stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(work_stream)
     run, used_graph = make_runner(S, args, world, dev)
+    dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    graph_mode = ("none" if not used_graph else
+                  "two graphs + eager all-reduce" if (args.split_graph or (dist_on and not args.graph_collectives)) and not args.forward_only
+                  else "one graph")
     for _ in range(args.warmup):
         run()
     S["restore"]()
@@ -325,7 +393,7 @@ def main():
                                    "kNN+index, EGNN fwd, pose head (Kabsch/SVD), "
                                    + ("no backward" if args.forward_only else "losses, backward, grad all-reduce, Adam"),
                        "pairs_per_gpu": args.batch, "points": args.n, "k": args.k, "layers": args.layers,
-                       "hipgraph": used_graph, "parallelism": f"dp{world}", "params_finite": finite,
+                       "hipgraph": used_graph, "graph_mode": graph_mode, "parallelism": f"dp{world}", "params_finite": finite,
                        "reset_every": args.reset_every},
             "roofline": roof, "kernels": extra,
         }

@@ -57,7 +57,7 @@ def shard_range(n_items: int, rank: int, world: int):
 
 class DataParallelStep:
     """Gradient synchronisation for ``CrossAttentionPoseRegression``-style models whose EGNN
-    exposes ``flat_grads``.  ``sync()`` = sum all-reduce of the two buckets, then 1/world."""
+    exposes ``flat_grads``.  ``sync()`` = mean all-reduce of the two buckets."""
 
     def __init__(self, model: nn.Module, egnn=None, process_group=None):
         self.model, self.group = model, process_group
@@ -91,6 +91,10 @@ class DataParallelStep:
     def sync(self, force: bool = False):
         if self.world == 1 and not force:
             return
+        avg = dist.get_backend(self.group) == "nccl"       # RCCL averages in the collective; gloo has no AVG
         for b in self.buckets():
-            dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
-            b.mul_(1.0 / self.world)
+            if avg:
+                dist.all_reduce(b, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
+                b.mul_(1.0 / self.world)
