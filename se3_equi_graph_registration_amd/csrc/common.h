@@ -7,6 +7,21 @@
 #include "../../include/equigspr.h"
 #include "egnn_math.h"
 
+// Developer trace build (make trace): lane 0 of every wave drains its counters and stores s_memtime into slot k.
+#ifdef EQ_TRACE
+#define EQ_TRACE_SLOTS 16
+static __device__ unsigned long long* eq_trace_ptr = nullptr;      // one copy per translation unit
+#define EQ_STAMP(k)                                                                                         \
+    do {                                                                                                    \
+        __builtin_amdgcn_s_waitcnt(0);                                                                      \
+        if ((threadIdx.x & 63) == 0 && ::eq_trace_ptr)                                                      \
+            ::eq_trace_ptr[(size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * EQ_TRACE_SLOTS + (k)] = \
+                __builtin_amdgcn_s_memtime();                                                               \
+    } while (0)
+#else
+#define EQ_STAMP(k)
+#endif
+
 namespace eq {
 
 void set_error(const char* fmt, ...);   // api.hip

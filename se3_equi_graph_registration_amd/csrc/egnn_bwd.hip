@@ -610,10 +610,12 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
     const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
     float* X = tiles + (size_t)wv * 2 * 32 * LD;
     float* Y = X + 32 * LD;
+    EQ_STAMP(0);
     stage_tile_weights<H, A>(wsm, lw);
     __syncthreads();
     TileWeights<H, A, true> W;
     W.load(wsm, lane);
+    EQ_STAMP(1);
 
     f32x16 acc6[1][1], acc2[1][1], accg[1][1];
     float cs_b6[1] = {0.0f}, cs_b2[1] = {0.0f}, cs_gam[1] = {0.0f}, cs_bet[1] = {0.0f}, cs_w7[1] = {0.0f}, cs_scr[1] = {0.0f};
@@ -628,11 +630,13 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         const int e = valid ? e_raw : n_edges - 1;
         const float z = valid ? 1.0f : 0.0f;
         const int r = row[e], c = col[e];
+        EQ_STAMP(2);
         float xr[3], xc[3], gxv[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) { xr[i] = x[(size_t)r * 3 + i]; xc[i] = x[(size_t)c * 3 + i]; gxv[i] = Gx[(size_t)r * 4 + i]; }
         EdgeGeo eg;
         edge_geometry(xr, xc, eg);
+        EQ_STAMP(3);
         const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
         TileFwd o;
         tile_forward<H, A, true>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
@@ -654,6 +658,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         __builtin_amdgcn_wave_barrier();
         tile_pass<1, 1, LD, true, 32>(X, Y, acc6, cs_b6, cs_scr, lane);           // dW6 += dq^T m ; db6 += sum dq
         __builtin_amdgcn_wave_barrier();
+        EQ_STAMP(7);
         // ---- dm = dagg[row] + W6^T dq
         float dm[16];
         {
@@ -667,6 +672,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < 16; ++k) dm[k] = a[k];
         }
+        EQ_STAMP(8);
         {
             float t[16];
 #pragma unroll
@@ -681,6 +687,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         __builtin_amdgcn_wave_barrier();
         tile_pass<1, 1, LD, false, 32>(X, Y, acc6, cs_bet, cs_scr, lane);         // dbeta = sum dm
         __builtin_amdgcn_wave_barrier();
+        EQ_STAMP(9);
         // ---- LayerNorm backward
         float du[16];
         {
@@ -713,6 +720,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         __builtin_amdgcn_wave_barrier();
         tile_pass<1, 1, LD, true, 32>(X, Y, acc2, cs_b2, cs_scr, lane);           // dW2 += du^T g1 ; db2 += sum du
         __builtin_amdgcn_wave_barrier();
+        EQ_STAMP(10);
         // ---- dt1 = (W2^T du) * silu'(t1)
         float dt1[16];
         {
@@ -724,6 +732,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < 16; ++k) dt1[k] = a[k] * sg1[k];
         }
+        EQ_STAMP(11);
         stage_half_row(X + el * LD, h, dt1);
         if (h == 0) {
             float ga[16];
@@ -737,6 +746,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         __builtin_amdgcn_wave_barrier();
         tile_pass<1, 1, LD, true, 32>(X, Y, accg, cs_scr, cs_scr, lane);          // dWgeo|dwattr += dt1^T [geo, attr]
         __builtin_amdgcn_wave_barrier();
+        EQ_STAMP(12);
         // ---- dgeo = Wgeo^T dt1 (rows 0..11 of a 32-row product), then the geometry backward
         float gg[kGeo];
         {
@@ -765,6 +775,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
                 reinterpret_cast<float4*>(gxc_out)[e] = make_float4(gxc[0], gxc[1], gxc[2], 0.0f);
             }
         }
+        EQ_STAMP(13);
     }
 
     // ---- block reduction of the 4 waves' partials into one slab (fixed order) ----------------
@@ -800,6 +811,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         }
     }
     slab_flush(sl, slab, SB::edge);
+    EQ_STAMP(14);
 }
 
 template <int F, int H, int A>
@@ -1072,3 +1084,9 @@ extern "C" int equigspr_time_edge_bwd(const equigspr_egnn_config* cfg, const flo
 #undef EQ_DISPATCH
     return EQUIGSPR_ENOTSUP;
 }
+
+#ifdef EQ_TRACE
+extern "C" int equigspr_trace_set_bwd(unsigned long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(eq_trace_ptr), &buf, sizeof(buf));
+}
+#endif

@@ -16,6 +16,7 @@
 //                 per-node projections (or embedding_out after the last layer).
 #include "egnn_mfma.h"
 
+
 namespace eq {
 
 // ---------------------------------------------------------------------------------------
@@ -103,10 +104,12 @@ __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restr
     const int lane = threadIdx.x & 63, el = lane & 31, h = lane >> 5;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
     __shared__ float wsm[TileWeightsLds::size];
+    EQ_STAMP(0);
     stage_tile_weights<H, A>(wsm, lw);
     __syncthreads();
     TileWeights<H, A> W;
     W.load(wsm, lane);
+    EQ_STAMP(1);
     const int tiles = (n_edges + 31) / 32;
     for (int tile = wave; tile < tiles; tile += n_waves) {
         W.refresh();
@@ -114,11 +117,13 @@ __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restr
         const bool valid = e_raw < n_edges;
         const int e = valid ? e_raw : n_edges - 1;
         const int r = row[e], c = col[e];
+        EQ_STAMP(2);
         float xr[3], xc[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) { xr[i] = x[(size_t)r * 3 + i]; xc[i] = x[(size_t)c * 3 + i]; }
         EdgeGeo eg;
         edge_geometry(xr, xc, eg);
+        EQ_STAMP(3);
         const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
         TileFwd o;
         tile_forward<H, A, false>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
@@ -127,6 +132,7 @@ __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restr
             if (h == 0)
                 reinterpret_cast<float4*>(trans_out)[e] = make_float4(eg.d[0] * o.s, eg.d[1] * o.s, eg.d[2] * o.s, 0.0f);   // :264
         }
+        EQ_STAMP(7);
     }
 }
 
@@ -357,3 +363,9 @@ extern "C" int equigspr_time_edge_fwd(const equigspr_egnn_config* cfg, const flo
 #undef EQ_DISPATCH
     return EQUIGSPR_ENOTSUP;
 }
+
+#ifdef EQ_TRACE
+extern "C" int equigspr_trace_set_fwd(unsigned long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(eq_trace_ptr), &buf, sizeof(buf));
+}
+#endif

@@ -137,6 +137,7 @@ __device__ __forceinline__ void tile_forward(const TileWeights<H, A, kCached>& W
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = pr[r] + pc[r];
+    EQ_STAMP(4);
 #pragma unroll
     for (int s = 0; s < 7; ++s) {
         // B operand: z-geometry entry k = 2s+h of this lane's edge (12 geo values, then edge_attr)
@@ -155,6 +156,7 @@ __device__ __forceinline__ void tile_forward(const TileWeights<H, A, kCached>& W
     float sum = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sum += acc2[r];
+    EQ_STAMP(5);
     sum += xhalf(sum);
     const float mean = sum * (1.0f / 32.0f);
     float var = 0.0f;
@@ -174,6 +176,7 @@ __device__ __forceinline__ void tile_forward(const TileWeights<H, A, kCached>& W
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o.q[r] = acc6[r]; o.sgq[r] = sigmoid_fast(acc6[r]); sp = fmaf(W.w7(r), acc6[r] * o.sgq[r], sp); }
     o.s = sp + xhalf(sp);
+    EQ_STAMP(6);
 }
 
 }  // namespace eq
