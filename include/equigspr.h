@@ -241,6 +241,27 @@ int equigspr_sh_forward(const void* in, int32_t in_is_f64, int64_t n, int32_t mo
 int equigspr_sh_basis_forward(const float* y, int64_t n, int32_t max_l, int32_t d_in, int32_t d_out, const float* q,
                               float* out, void* stream);
 
+/* ---- N2: evaluation metrics (tools/evaluation_metrics.py:14-43; eval loop src/eval_egnn_metrics.py:1245-1296) ----
+ * Per pair b: out[5b..] = { rotation error [deg] = acos(clip((tr(G_R^T R) - 1)/2)), translation error [cm],
+ * recall = sqrt(TP/n), precision = TP/n, F1 = 2 P R / (P + R + 1e-6) }, TP = #{ ||R src_i + t - tgt_i|| < tau }.
+ * R [B,9] row-major, t [B,3], gt_pose [B,16] row-major 4x4, src/tgt [B,n,3]; fp64 arithmetic; out double[5B]. */
+int equigspr_eval_metrics(const float* R, const float* t, const float* gt_pose, const float* src, const float* tgt,
+                          int32_t n_pairs, int32_t n, double tau, double* out, void* stream);
+
+/* ---- N1: PointNet encoder (src/3dmatch_train_egnn_with_batch.py:52-96) --------------------------------
+ * PointNetLayer.forward :61-68 with aggr='max': out_i = max_{e: tgt(e)=i} Linear2(ReLU(Linear1([h_src(e), pos_src(e) - pos_i])))
+ * (0 for a node without incoming edges; relu_out != 0 applies the ReLU PointNet.forward puts after each layer, :89-92).
+ *   h [N,c_in], pos [N,3]; src [E] = edge_index[0] (global ids); tptr [N+1] / tperm [E] = equigspr_build_csr(key = edge_index[1])
+ *   (tperm NULL: edges already grouped by target in tptr order); w1 [c_out, c_in+3], w2 [c_out, c_out];
+ *   work float[2*N*c_out]; out [N,c_out].  c_in, c_out <= 64. */
+int equigspr_pointnet_layer_forward(const float* h, const float* pos, int32_t n_nodes, int32_t c_in, int32_t c_out,
+                                    const int32_t* src, const int32_t* tptr, const int32_t* tperm, const float* w1,
+                                    const float* b1, const float* w2, const float* b2, int32_t relu_out, float* work,
+                                    float* out, void* stream);
+/* torch_geometric.nn.global_max_pool(x, batch) (:95) for an ascending batch vector: out [n_batches, channels] */
+int equigspr_global_max_pool(const float* x, const int64_t* batch_sorted, int32_t n_nodes, int32_t channels,
+                             int32_t n_batches, float* out, void* stream);
+
 /* ---- measurement hooks (bench.py's roofline leg; NOT part of the drop-in path) -----------
  * Average duration in ms (written to HOST memory) of the EGNN message-passing edge kernel,
  * measured with HIP events on `stream` over `iters` back-to-back launches (these two calls

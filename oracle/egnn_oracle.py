@@ -321,6 +321,48 @@ def pair_forward_eval(we, wc, h_src, x_src, edges_src, ea_src, h_tgt, x_tgt, edg
 
 
 # --------------------------------------------------------------------------------------
+# N1: PointNet encoder (train :52-96)
+# --------------------------------------------------------------------------------------
+def pointnet_layer(w: Dict[str, Tensor], h: Tensor, pos: Tensor, edge_index: Tensor) -> Tensor:
+    """``PointNetLayer.forward`` :61-68: ``propagate`` with aggr='max', flow source_to_target (j = edge_index[0] sends to
+    i = edge_index[1]); message = mlp([h_j, pos_j - pos_i]); nodes without incoming edges get 0 (PyG's scatter-max fill).
+    ``w``: ``mlp.0.weight [out,in+3]``, ``mlp.0.bias``, ``mlp.2.weight``, ``mlp.2.bias``."""
+    j, i = edge_index[0], edge_index[1]
+    msg = torch.cat([h[j], pos[j] - pos[i]], dim=-1)
+    msg = torch.relu(msg @ w["mlp.0.weight"].t() + w["mlp.0.bias"]) @ w["mlp.2.weight"].t() + w["mlp.2.bias"]
+    out = torch.zeros(h.shape[0], msg.shape[1], dtype=msg.dtype)
+    return out.scatter_reduce(0, i[:, None].expand_as(msg), msg, reduce="amax", include_self=False)
+
+
+def pointnet_forward(w: Dict[str, Tensor], pos: Tensor, feats: Tensor, edge_index: Tensor, batch: Tensor):
+    """``PointNet.forward`` :79-96 -> (per-point features before pooling, pooled ``[num_graphs, out]``)."""
+    sub = lambda pre: {k[len(pre):]: v for k, v in w.items() if k.startswith(pre)}
+    h = torch.relu(pointnet_layer(sub("conv1."), feats, pos, edge_index))
+    h = torch.relu(pointnet_layer(sub("conv2."), h, pos, edge_index))
+    nb = int(batch.max()) + 1
+    pooled = torch.full((nb, h.shape[1]), float("-inf"), dtype=h.dtype).scatter_reduce(0, batch[:, None].expand_as(h), h, reduce="amax")
+    return h, pooled
+
+
+# --------------------------------------------------------------------------------------
+# N2: evaluation metrics (tools/evaluation_metrics.py:14-43, eval loop eval :1245-1296)
+# --------------------------------------------------------------------------------------
+def eval_metrics(gt_pose, pred_pose, src_pts, tgt_pts, tau: float = 0.09):
+    """numpy fp64: (rotation error [deg], translation error [cm], recall, precision, f1)."""
+    import numpy as np
+    gt_pose, pred_pose = np.asarray(gt_pose, dtype=np.float64), np.asarray(pred_pose, dtype=np.float64)
+    src_pts, tgt_pts = np.asarray(src_pts, dtype=np.float64), np.asarray(tgt_pts, dtype=np.float64)
+    trans_err = np.linalg.norm(gt_pose[:3, 3] - pred_pose[:3, 3]) * 100
+    rel = gt_pose[:3, :3].T @ pred_pose[:3, :3]
+    rot_err = np.degrees(np.arccos(np.clip((np.trace(rel) - 1) / 2, -1.0, 1.0)))
+    moved = (pred_pose[:3, :3] @ src_pts.T).T + pred_pose[:3, 3]
+    tp = np.sum(np.linalg.norm(moved - tgt_pts, axis=1) < tau)
+    recall = np.sqrt(tp / len(src_pts))
+    precision = tp / len(moved) if len(moved) > 0 else 0.0
+    return rot_err, trans_err, recall, precision, 2 * (precision * recall) / (precision + recall + 1e-6)
+
+
+# --------------------------------------------------------------------------------------
 # A17: gcnLayer (src/gcnLayer.py)
 # --------------------------------------------------------------------------------------
 def gcn_build_graph(coordinates, k: int = 25):

@@ -13,6 +13,8 @@ from .pose import (CrossAttentionPoseRegression, pose_loss, compute_losses, egnn
                    unsorted_segment_sum, unsorted_segment_mean)
 from .synth import synthetic_pair, synthetic_batch  # noqa: F401
 from .so3 import SO3TensorProductLayer  # noqa: F401
+from .pointnet import PointNetLayer, PointNet, global_max_pool  # noqa: F401
+from .metrics import evaluate_batch, calculate_pose_error, registration_recall  # noqa: F401
 from . import sh  # noqa: F401  (A16: spherical harmonics / irrep basis)
 from .sh import get_basis, get_spherical_harmonics, precompute_sh, basis_transformation_Q_J, irr_repr  # noqa: F401
 from .gcn import build_graph, GraphConvolution, GlobalPooling, KnnAdjacency  # noqa: F401

@@ -125,3 +125,67 @@ extern "C" int equigspr_adam_step(int32_t n_buckets, float* const* params, const
     EQ_CHECK_LAUNCH("adam_step");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// N2: evaluation metrics on the device (tools/evaluation_metrics.py:14-43, eval loop eval :1245-1296)
+//   out[b] = { rotation error [deg], translation error [cm], recall = sqrt(TP/n), precision = TP/n, F1 }
+//   TP = #{ i : || R_pred src_i + t_pred - tgt_i || < tau }.  fp64 arithmetic, as the numpy reference.
+// ---------------------------------------------------------------------------------------
+namespace eq {
+__global__ __launch_bounds__(256) void eval_metrics_kernel(const float* __restrict__ R, const float* __restrict__ t,
+                                                           const float* __restrict__ gt_pose, const float* __restrict__ src,
+                                                           const float* __restrict__ tgt, int n, double tau, double* __restrict__ out) {
+    __shared__ int cnt[256];
+    const int b = blockIdx.x;
+    const float* Rb = R + 9 * b;
+    const float* tb = t + 3 * b;
+    const float* G = gt_pose + 16 * b;
+    double r[9], tr[3];
+    for (int i = 0; i < 9; ++i) r[i] = (double)Rb[i];
+    for (int i = 0; i < 3; ++i) tr[i] = (double)tb[i];
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float* s = src + ((size_t)b * n + i) * 3;
+        const float* g = tgt + ((size_t)b * n + i) * 3;
+        double d2 = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            const double v = r[3 * a] * (double)s[0] + r[3 * a + 1] * (double)s[1] + r[3 * a + 2] * (double)s[2] + tr[a] - (double)g[a];
+            d2 += v * v;
+        }
+        c += sqrt(d2) < tau ? 1 : 0;
+    }
+    cnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) cnt[threadIdx.x] += cnt[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double te = 0.0, trace = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            const double d = (double)G[4 * a + 3] - tr[a];
+            te += d * d;
+            for (int k = 0; k < 3; ++k) trace += (double)G[4 * k + a] * r[3 * k + a];        // trace(G_R^T R)
+        }
+        double cosv = (trace - 1.0) * 0.5;
+        cosv = cosv < -1.0 ? -1.0 : (cosv > 1.0 ? 1.0 : cosv);
+        const double tp = (double)cnt[0];
+        const double recall = sqrt(tp / (double)n), precision = n > 0 ? tp / (double)n : 0.0;
+        double* o = out + 5 * b;
+        o[0] = acos(cosv) * (180.0 / 3.14159265358979323846);
+        o[1] = sqrt(te) * 100.0;
+        o[2] = recall;
+        o[3] = precision;
+        o[4] = 2.0 * (precision * recall) / (precision + recall + 1e-6);                      // eval :1276
+    }
+}
+}  // namespace eq
+
+extern "C" int equigspr_eval_metrics(const float* R, const float* t, const float* gt_pose, const float* src, const float* tgt,
+                                     int32_t n_pairs, int32_t n, double tau, double* out, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(R && t && gt_pose && src && tgt && out && n_pairs >= 1 && n >= 1, EQUIGSPR_EINVAL, "eval_metrics: bad arguments");
+    hipLaunchKernelGGL(eval_metrics_kernel, dim3(n_pairs), dim3(256), 0, (hipStream_t)stream, R, t, gt_pose, src, tgt, n, tau, out);
+    EQ_CHECK_LAUNCH("eval_metrics");
+    return 0;
+}

@@ -43,8 +43,26 @@ def _stub(name, **attrs):
 
 
 class _MessagePassing(nn.Module):
+    """Stand-in for torch_geometric.nn.MessagePassing (absent here).  Only the PointNet fixture calls ``propagate``;
+    it follows PyG's documented behaviour for flow='source_to_target': ``x_j = x[edge_index[0]]``,
+    ``x_i = x[edge_index[1]]``, ``message(...)`` per edge, aggregation into ``edge_index[1]`` (max; 0 for nodes
+    without incoming edges)."""
+
     def __init__(self, aggr=None, **kw):
         super().__init__()
+        self.aggr = aggr
+
+    def propagate(self, edge_index, h, pos):
+        j, i = edge_index[0], edge_index[1]
+        msg = self.message(h_j=h[j], pos_j=pos[j], pos_i=pos[i])
+        assert self.aggr == "max"
+        out = torch.zeros(h.shape[0], msg.shape[1], dtype=msg.dtype)
+        return out.scatter_reduce(0, i[:, None].expand_as(msg), msg, reduce="amax", include_self=False)
+
+
+def _global_max_pool(x, batch):
+    nb = int(batch.max()) + 1
+    return torch.full((nb, x.shape[1]), float("-inf"), dtype=x.dtype).scatter_reduce(0, batch[:, None].expand_as(x), x, reduce="amax")
 
 
 def _functional_transform(_name):
@@ -59,7 +77,7 @@ def load_reference():
     tgt = _stub("torch_geometric.transforms", BaseTransform=type("BaseTransform", (), {}),
                 SamplePoints=object, KNNGraph=object)
     tgu = _stub("torch_geometric.utils", to_undirected=None)
-    tgn = _stub("torch_geometric.nn", global_max_pool=None, MessagePassing=_MessagePassing)
+    tgn = _stub("torch_geometric.nn", global_max_pool=_global_max_pool, MessagePassing=_MessagePassing)
     tg.data, tg.transforms, tg.utils, tg.nn, tgd.datapipes = tgd, tgt, tgu, tgn, tgdp
     _stub("torch_cluster", knn_graph=None)
     _stub("torch_scatter", scatter_add=None)
@@ -387,11 +405,78 @@ def gen_sh_fixture(name, n=257, max_l=6, seed=41):
     print("wrote", name)
 
 
+def gen_pointnet_fixture(tr, name, clouds=2, n=200, k=6, seed=61):
+    """N1: the real PointNet / PointNetLayer classes (message MLP, layer wiring, ReLUs) of train :52-96; the
+    max-aggregation and global_max_pool come from the torch_geometric stand-ins above (documented PyG semantics)."""
+    rng = np.random.default_rng(seed)
+    pos = torch.from_numpy(rng.uniform(0, 2, (clouds * n, 3)).astype(np.float32))
+    feats = torch.from_numpy(rng.standard_normal((clouds * n, 5)).astype(np.float32))
+    edges = []
+    for c in range(clouds):
+        e = orc.knn_graph(pos[c * n:(c + 1) * n], k, loop=True) + c * n
+        edges.append(e)
+    edge_index = torch.cat(edges, dim=1)
+    keep = torch.ones(edge_index.shape[1], dtype=torch.bool)
+    keep[edge_index[1] == 3] = False                       # node 3 loses all incoming edges -> aggregates to 0
+    edge_index = edge_index[:, keep][:, torch.from_numpy(rng.permutation(int(keep.sum())))]   # arbitrary edge order
+    batch = torch.arange(clouds).repeat_interleave(n)
+    torch.manual_seed(seed)
+    out = {"pos": pos.numpy(), "feats": feats.numpy(), "edge_index": edge_index.numpy(), "batch": batch.numpy()}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        with default_dtype(dt):
+            torch.manual_seed(seed)
+            net = tr.PointNet(in_num_feature=5, hidden_num_feature=64, output_num_feature=32, device="cpu")
+            if dt == torch.float64:
+                net.load_state_dict({kk: torch.from_numpy(v).double() for kk, v in weights.items()})
+            else:
+                weights = sd_np(net)
+            with torch.no_grad():
+                h1 = net.conv1(h=feats.to(dt), pos=pos.to(dt), edge_index=edge_index)
+                pooled = net(pos.to(dt), feats.to(dt), edge_index, batch)
+        out["conv1_" + tag], out["pooled_" + tag] = h1.numpy(), pooled.numpy()
+    out.update({"w." + kk: v for kk, v in weights.items()})
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name)
+
+
+def gen_metrics_fixture(name, pairs=6, n=512, seed=51):
+    """N2: the real tools/evaluation_metrics.py (calculate_pose_error, registration_recall) on noisy poses."""
+    spec = importlib.util.spec_from_file_location("ref_metrics", os.path.join(REF, "tools", "evaluation_metrics.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(seed)
+    out = {k: [] for k in ("gt", "pred", "src", "tgt", "metrics")}
+    for p in range(pairs):
+        gt = np.eye(4); gt[:3, :3] = Rotation.random(random_state=seed + p).as_matrix(); gt[:3, 3] = rng.uniform(-1, 1, 3)
+        noise = [0.0, 1e-3, 0.01, 0.05, 0.3, 3.0][p % 6]
+        pred = np.eye(4)
+        pred[:3, :3] = Rotation.from_rotvec(noise * rng.standard_normal(3)).as_matrix() @ gt[:3, :3]
+        pred[:3, 3] = gt[:3, 3] + noise * 0.2 * rng.standard_normal(3)
+        src = rng.uniform(-1.5, 1.5, (n, 3))
+        tgt = (gt[:3, :3] @ src.T).T + gt[:3, 3] + 0.02 * rng.standard_normal((n, 3))
+        tgt[: n // 4] = rng.uniform(-1.5, 1.5, (n // 4, 3))                     # outliers
+        gt32, pred32, src32, tgt32 = (a.astype(np.float32) for a in (gt, pred, src, tgt))
+        re, te = m.calculate_pose_error(gt32.astype(np.float64), pred32.astype(np.float64))
+        rec, prec = m.registration_recall(gt32.astype(np.float64), pred32.astype(np.float64), src32.astype(np.float64), tgt32.astype(np.float64))
+        f1 = 2 * (prec * rec) / (prec + rec + 1e-6)                               # eval :1276
+        for k, v in zip(out, (gt32, pred32, src32, tgt32, np.array([re, te, rec, prec, f1]))):
+            out[k].append(v)
+    np.savez_compressed(os.path.join(HERE, name), **{k: np.stack(v) for k, v in out.items()})
+    print("wrote", name)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "metrics":
+        gen_metrics_fixture("metrics_cases.npz")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "sh":
         gen_sh_fixture("sh_l6.npz")
         return
     tr, ev = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "pointnet":
+        gen_pointnet_fixture(tr, "pointnet_n200_k6.npz")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "gcn":
         gen_gcn_fixture("gcn_n300_k9.npz")
         return
@@ -415,6 +500,8 @@ def main():
     gen_so3tp_fixture("so3tp_d32.npz")
     gen_gcn_fixture("gcn_n300_k9.npz")
     gen_sh_fixture("sh_l6.npz")
+    gen_metrics_fixture("metrics_cases.npz")
+    gen_pointnet_fixture(tr, "pointnet_n200_k6.npz")
 
 
 if __name__ == "__main__":

@@ -567,3 +567,62 @@ def test_get_basis_vs_oracle(pk, max_degree, shape):
         assert val.shape == (*shape, 1, 2 * d_out + 1, 1, 2 * d_in + 1, 2 * min(d_in, d_out) + 1)
         got = val.reshape(-1, *val.shape[len(shape):])[:n_check].cpu().numpy().astype(np.float64)
         assert np.abs(got - ref64[key].numpy()).max() <= anchored_tol(ref32[key].numpy(), ref64[key].numpy()), key
+
+
+# ------------------------------------------------------------------------------------------------
+# N2: evaluation metrics on the device (tools/evaluation_metrics.py)
+# ------------------------------------------------------------------------------------------------
+def test_eval_metrics_golden(pk, golden_dir):
+    fx = np.load(os.path.join(golden_dir, "metrics_cases.npz"))
+    t = lambda k: torch.from_numpy(fx[k]).cuda()
+    m = pk.evaluate_batch(t("pred")[:, :3, :3], t("pred")[:, :3, 3], t("gt"), t("src"), t("tgt"))
+    got = torch.stack([m["rotation_error"], m["translation_error"], m["recall"], m["precision"], m["f1"]], dim=1).cpu().numpy()
+    ref = fx["metrics"]
+    # counts are integers: recall / precision / f1 must agree exactly unless a distance sits on the threshold
+    assert np.allclose(got[:, 2:], ref[:, 2:], rtol=0, atol=1e-12)
+    assert np.allclose(got[:, 1], ref[:, 1], rtol=1e-12, atol=1e-9)
+    # acos near 0 amplifies rounding of the trace: compare the angle through its cosine
+    assert np.allclose(np.cos(np.radians(got[:, 0])), np.cos(np.radians(ref[:, 0])), rtol=0, atol=1e-14)
+    assert np.allclose(got[:, 0], ref[:, 0], rtol=1e-6, atol=1e-5)
+    re, te = pk.calculate_pose_error(t("gt")[3], t("pred")[3])
+    rec, prec = pk.registration_recall(t("gt")[3], t("pred")[3], t("src")[3], t("tgt")[3])
+    assert abs(float(te) - ref[3, 1]) < 1e-9 and abs(float(rec) - ref[3, 2]) < 1e-12 and abs(float(prec) - ref[3, 3]) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------
+# N1: PointNet encoder (train :52-96)
+# ------------------------------------------------------------------------------------------------
+def test_pointnet_golden(pk, golden_dir):
+    fx = np.load(os.path.join(golden_dir, "pointnet_n200_k6.npz"))
+    net = pk.PointNet(in_num_feature=5, hidden_num_feature=64, output_num_feature=32, device="cuda")
+    net.load_state_dict({k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("w.")})
+    net = net.cuda()
+    t = lambda k: torch.from_numpy(fx[k]).cuda()
+    with torch.no_grad():
+        h1 = net.conv1(t("feats"), t("pos"), t("edge_index"))
+        pooled = net(t("pos"), t("feats"), t("edge_index"), t("batch"))
+    assert np.abs(h1.cpu().numpy() - fx["conv1_f64"]).max() <= anchored_tol(fx["conv1_f32"], fx["conv1_f64"])
+    assert (h1.cpu().numpy()[3] == 0).all()
+    assert np.abs(pooled.cpu().numpy() - fx["pooled_f64"]).max() <= anchored_tol(fx["pooled_f32"], fx["pooled_f64"])
+    with pytest.raises(NotImplementedError):
+        net.conv1(t("feats"), t("pos"), t("edge_index"))
+
+
+def test_pointnet_reference_call_shape(pk):
+    """The encoder as the training script means to use it (train :1034-1038): 3-d coordinates as features, kNN graph
+    of each cloud, per-point output reshaped to [batch, 2048, 32]; checked against the oracle."""
+    g = torch.Generator().manual_seed(5)
+    b, n, k = 2, 2048, 16
+    pos = torch.rand(b, n, 3, generator=g) * 3
+    net = pk.PointNet(in_num_feature=3, hidden_num_feature=32, output_num_feature=32, device="cuda").cuda()
+    edges, _, _ = pk.knn_graph_batched(pos.cuda(), k, loop=True)
+    ei = torch.cat([edges[c] + c * n for c in range(b)], dim=1)
+    flat = pos.reshape(b * n, 3)
+    with torch.no_grad():
+        enc = net.encode(flat.cuda(), flat.cuda(), ei).view(b, n, -1)
+    w64 = {kk: v.detach().cpu().double() for kk, v in net.state_dict().items()}
+    batch = torch.arange(b).repeat_interleave(n)
+    ref64, _ = orc.pointnet_forward(w64, flat.double(), flat.double(), ei.cpu(), batch)
+    ref32, _ = orc.pointnet_forward({kk: v.float() for kk, v in w64.items()}, flat, flat, ei.cpu(), batch)
+    assert enc.shape == (b, n, 32)
+    assert np.abs(enc.reshape(b * n, -1).cpu().numpy() - ref64.numpy()).max() <= anchored_tol(ref32.numpy(), ref64.numpy())

@@ -174,3 +174,25 @@ def test_gcn_layer_golden(golden_dir):
     assert np.abs(orc.gcn_global_pooling(y).numpy() - fx["pooled64"]).max() <= 1e-12
     y32 = orc.gcn_graph_convolution(weights(fx, torch.float32), torch.from_numpy(adj).float(), x.float())
     assert np.abs(y32.numpy() - fx["y"]).max() <= 2e-6
+
+
+def test_eval_metrics_golden(golden_dir):
+    """N2: oracle vs the real tools/evaluation_metrics.py."""
+    fx = np.load(os.path.join(golden_dir, "metrics_cases.npz"))
+    for p in range(fx["gt"].shape[0]):
+        got = orc.eval_metrics(fx["gt"][p], fx["pred"][p], fx["src"][p], fx["tgt"][p])
+        assert np.allclose(np.array(got), fx["metrics"][p], rtol=1e-12, atol=1e-12)
+
+
+def test_pointnet_golden(golden_dir):
+    """N1: oracle vs the real PointNet/PointNetLayer classes (aggregation by the documented PyG semantics, see gen_golden.py)."""
+    fx = np.load(os.path.join(golden_dir, "pointnet_n200_k6.npz"))
+    ei, batch = torch.from_numpy(fx["edge_index"]), torch.from_numpy(fx["batch"])
+    for tag, dt, tol in (("f32", torch.float32, 2e-6), ("f64", torch.float64, 1e-13)):
+        w = weights(fx, dt)
+        pos, feats = torch.from_numpy(fx["pos"]).to(dt), torch.from_numpy(fx["feats"]).to(dt)
+        h1 = orc.pointnet_layer({k[len("conv1."):]: v for k, v in w.items() if k.startswith("conv1.")}, feats, pos, ei)
+        _, pooled = orc.pointnet_forward(w, pos, feats, ei, batch)
+        assert np.abs(h1.numpy() - fx["conv1_" + tag]).max() <= tol * max(1.0, np.abs(fx["conv1_" + tag]).max())
+        assert np.abs(pooled.numpy() - fx["pooled_" + tag]).max() <= tol * max(1.0, np.abs(fx["pooled_" + tag]).max())
+        assert (h1.numpy()[3] == 0).all()                 # the node without incoming edges
