@@ -4,7 +4,7 @@
 A "step" = one full training pass of the hot path over one batch of synthetic pairs:
   k-NN graph for all 2B clouds (one launch) + inverse index -> batched EGNN forward ->
   pose head (top-k logits MLP, weighted Kabsch/SVD) -> losses (train :1120) -> backward
-  (HIP EGNN + Kabsch backward) -> [all-reduce of the two flat gradient buckets over RCCL] ->
+  (HIP EGNN + Kabsch backward) -> [one all-reduce of the flat gradient bucket over RCCL] ->
   Adam step.  Inputs are resident in HBM before the timed region.
 Default workload = BASELINE configs[1]: one 2048-point pair, k=20, 4 EGNN layers, batch=1,
 forward+backward on 1 GPU.  With --gpus N every rank processes its own batch (weak scaling:
@@ -70,7 +70,7 @@ def build_step(pkg, args, dev, world):
     scale = (3.0, 3.0, 3.0)
     batch = pkg.synthetic_batch(1234 + rank * args.batch, args.batch, n=args.n, feat=args.feat, scale=scale, device=dev)
     ones = torch.ones(args.batch, args.n * args.k, 1, device=dev)
-    # one fused Adam launch over the two flat buckets (the per-tensor parameters are views of them); train :1412
+    # one fused Adam launch over the flat bucket (two views: EGNN block, head; the per-tensor parameters are views of them); train :1412
     opt = pkg.FlatAdam([(egnn.flat_params, egnn.flat_grads), (dp.head.flat, dp.head.grad)], lr=1e-4)
 
     def fwd_bwd():
@@ -110,7 +110,7 @@ def make_runner(S, args, world, dev):
     """Returns (callable running one step, used_graph).
 
     1 GPU: the whole step (zero, kNN, fwd, head, losses, bwd, Adam) is ONE hipGraph.  N GPUs: two hipGraphs
-    (zero + kNN + fwd + head + losses + bwd | Adam) with the two RCCL all-reduces launched eagerly between them
+    (zero + kNN + fwd + head + losses + bwd | Adam) with the RCCL all-reduce launched eagerly between them
     (ProcessGroupNCCL's own stream, ordered by events) -- see split_graph_runner.  --graph-collectives captures
     the all-reduce inside one graph instead; --no-graph launches everything eagerly."""
     dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
@@ -168,7 +168,7 @@ def make_runner(S, args, world, dev):
 
 
 def split_graph_runner(S, args, dist_on, eager):
-    """Graph A = zero + kNN + fwd + head + losses + bwd; eager middle = the two RCCL all-reduces (ProcessGroupNCCL
+    """Graph A = zero + kNN + fwd + head + losses + bwd; eager middle = the RCCL all-reduce of the joint gradient bucket (ProcessGroupNCCL
     issues them on its own stream, ordered by events); graph B = Adam.  BENCH_STANDIN=current|side replaces the
     collective by an eager `mul_` on the gradient buckets on the current / a side stream (1-GPU probe of whether
     eager launches between replays are safe on this stack)."""

@@ -3,8 +3,9 @@
 Pairs are independent, so the step batch is split contiguously across ranks (one process per
 GPU) and the only exchange is the gradient all-reduce.  All gradients live in two flat fp32
 buckets -- ``EGNN.flat_grads`` (filled directly by the HIP backward) and one bucket for the
-remaining trainable parameters (the pose head's small MLP) -- so a step issues exactly two
-collectives over RCCL/xGMI (backend "nccl" on ROCm) or gloo (CPU tests), never one per tensor.
+remaining trainable parameters (the pose head's small MLP).  When the EGNN offers ``rehome`` both
+live in ONE buffer, so a step issues exactly one collective over RCCL/xGMI (backend "nccl" on
+ROCm) or gloo (CPU tests); otherwise two -- never one per tensor.
 The message is ~220-340 KiB: latency-bound on xGMI, so it is not chunked further.
 """
 from __future__ import annotations
@@ -19,15 +20,20 @@ from torch import nn
 class FlatBucket:
     """Re-homes ``params`` (and their grads) as views into one flat buffer each."""
 
-    def __init__(self, params: Iterable[nn.Parameter]):
+    def __init__(self, params: Iterable[nn.Parameter], storage=None):
         self.params: List[nn.Parameter] = [p for p in params]
         if not self.params:
             self.flat = self.grad = None
             return
         dev, dt = self.params[0].device, self.params[0].dtype
         total = sum(p.numel() for p in self.params)
-        self.flat = torch.empty(total, dtype=dt, device=dev)
-        self.grad = torch.zeros(total, dtype=dt, device=dev)
+        if storage is None:
+            self.flat = torch.empty(total, dtype=dt, device=dev)
+            self.grad = torch.zeros(total, dtype=dt, device=dev)
+        else:
+            self.flat, self.grad = storage
+            assert self.flat.numel() == total and self.grad.numel() == total
+            self.grad.zero_()
         off = 0
         with torch.no_grad():
             for p in self.params:
@@ -64,10 +70,24 @@ class DataParallelStep:
         self.egnn = egnn if egnn is not None else getattr(model, "egnn", None)
         egnn_ids = {id(p) for p in self.egnn.parameters()} if self.egnn is not None else set()
         rest = [p for p in model.parameters() if id(p) not in egnn_ids and p.requires_grad]
-        self.head = FlatBucket(rest)
+        self.joint = self.joint_grad = None
+        if self.egnn is not None and hasattr(self.egnn, "rehome") and rest:
+            # ONE buffer [EGNN block | pad to 64 floats | head parameters]: a single collective per step
+            pe = sum(p.numel() for p in self.egnn.parameters())
+            off = (pe + 63) // 64 * 64
+            ph = sum(p.numel() for p in rest)
+            dev = rest[0].device
+            self.joint = torch.zeros(off + ph, dtype=torch.float32, device=dev)
+            self.joint_grad = torch.zeros(off + ph, dtype=torch.float32, device=dev)
+            self.egnn.rehome(self.joint[:pe], self.joint_grad[:pe])
+            self.head = FlatBucket(rest, storage=(self.joint[off:], self.joint_grad[off:]))
+        else:
+            self.head = FlatBucket(rest)
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
 
     def buckets(self):
+        if self.joint_grad is not None:
+            return [self.joint_grad]
         out = []
         if self.egnn is not None and self.egnn.flat_grads is not None:
             out.append(self.egnn.flat_grads)
@@ -82,6 +102,9 @@ class DataParallelStep:
 
     def broadcast_parameters(self, src: int = 0):
         if self.world == 1:
+            return
+        if self.joint is not None:
+            dist.broadcast(self.joint, src, group=self.group)
             return
         if self.egnn is not None and self.egnn.flat_params is not None:
             dist.broadcast(self.egnn.flat_params, src, group=self.group)

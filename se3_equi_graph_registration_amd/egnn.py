@@ -121,9 +121,15 @@ class EGNN(nn.Module):
     def _ordered_params(self) -> List[nn.Parameter]:
         return [p for _, p in self.named_parameters()]      # == C-ABI block order (include/equigspr.h)
 
-    def _ensure_flat(self):
+    def rehome(self, flat: torch.Tensor, grads: torch.Tensor):
+        """Move the parameter block and its gradient bucket into caller-owned storage (fp32, ``param_count`` elements
+        each, 16-byte aligned) -- ``dp.DataParallelStep`` uses this to put the EGNN and the pose-head parameters in ONE
+        buffer, so the gradient exchange is a single all-reduce."""
+        self._ensure_flat(storage=(flat, grads))
+
+    def _ensure_flat(self, storage=None):
         ps = self._ordered_params()
-        flat = self.flat_params
+        flat = self.flat_params if storage is None else None
         ok = flat is not None and flat.device == ps[0].device
         if ok:
             off = 0
@@ -142,8 +148,17 @@ class EGNN(nn.Module):
         total = sum(p.numel() for p in ps)
         if total != ops.param_count(self.cfg):
             raise RuntimeError("internal: parameter count differs from the C-ABI block layout")
-        flat = torch.empty(total, dtype=torch.float32, device=dev)
-        grads = torch.zeros(total, dtype=torch.float32, device=dev)
+        if storage is None:
+            flat = torch.empty(total, dtype=torch.float32, device=dev)
+            grads = torch.zeros(total, dtype=torch.float32, device=dev)
+        else:
+            flat, grads = storage
+            for t in (flat, grads):
+                if (t.dtype != torch.float32 or t.numel() != total or t.device != dev or not t.is_contiguous()
+                        or t.data_ptr() % 16):
+                    raise RuntimeError("EGNN.rehome: storage must be contiguous fp32 CUDA tensors of param_count elements, 16-byte aligned")
+            with torch.no_grad():
+                grads.zero_()
         off = 0
         with torch.no_grad():
             for p in ps:

@@ -1,7 +1,7 @@
 """CPU, world_size=2 over gloo: the data-parallel step (flat buckets, shard ranges, bucketed
 all-reduce) used by bench.py --gpus N.  The HIP kernels cannot run here, so the EGNN is stood in
 by a tiny module exposing the same flat_params / flat_grads contract; what is under test is the
-N>1 host path: sharding, broadcast, exactly-two collectives per step, averaged gradients."""
+N>1 host path: sharding, broadcast, ONE collective per step over the joint bucket, averaged gradients."""
 import os
 import socket
 
@@ -26,6 +26,10 @@ class FakeEgnn(nn.Module):
 
     def zero_grad(self, set_to_none=False):
         self._bucket.zero_grad()
+
+    def rehome(self, flat, grads):                     # EGNN.rehome contract: caller-owned storage
+        b = FlatBucket(self.parameters(), storage=(flat, grads))
+        self.flat_params, self.flat_grads, self._bucket = b.flat, b.grad, b
 
     def forward(self, x):
         return self.lin(x)
@@ -82,7 +86,7 @@ def test_two_rank_gradient_sync_matches_full_batch():
     (_, p0, g0, h0, n0, _), (_, p1, g1, h1, n1, _) = res
     assert torch.equal(p0, p1)                                   # broadcast made the replicas identical
     assert torch.equal(g0, g1) and torch.equal(h0, h1)           # all-reduced buckets agree
-    assert n0 == 2 and n1 == 2                                   # exactly two collectives per step
+    assert n0 == 1 and n1 == 1                                   # joint bucket: exactly one collective per step
     # reference: single process, rank-0 weights, mean of the two shard gradients
     torch.manual_seed(100)
     ref = Pair()
