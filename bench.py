@@ -80,8 +80,11 @@ def build_step(pkg, args, dev, world):
         if args.forward_only:
             return out[2]
         R, t, closs = out[0], out[1], out[2]
-        rl, tl = pkg.pose_loss(R, t, batch["gt_pose"])
-        loss = closs.mean() + rl.mean() + tl.mean()                                          # train :1120
+        if args.aten_head:
+            rl, tl = pkg.pose_loss(R, t, batch["gt_pose"])
+            loss = closs.mean() + rl.mean() + tl.mean()                                      # train :1120, op by op
+        else:
+            loss, _, _ = pkg.registration_loss(R, t, closs, batch["gt_pose"])              # the same sum in one launch
         loss.backward()
         return loss
 

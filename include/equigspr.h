@@ -241,6 +241,15 @@ int equigspr_sh_forward(const void* in, int32_t in_is_f64, int64_t n, int32_t mo
 int equigspr_sh_basis_forward(const float* y, int64_t n, int32_t max_l, int32_t d_in, int32_t d_out, const float* q,
                               float* out, void* stream);
 
+/* ---- training-step loss (src/3dmatch_train_egnn_with_batch.py:1120) ------------------------------------------
+ * loss = corr_loss + mean_b(rot_loss_b) + mean_b(trans_loss_b) with pose_loss() of :896-962, in one launch;
+ * corr_loss: device scalar (the head's BCE + similarity-MSE) or NULL; rot_loss/trans_loss [B] are also returned.
+ * backward: grad_R [B,9], grad_t [B,3] = d loss / d(R, t) * grad_loss (device scalar, NULL = 1). */
+int equigspr_step_loss_forward(const float* R, const float* t, const float* gt_pose, const float* corr_loss, int32_t B,
+                               float* loss, float* rot_loss, float* trans_loss, void* stream);
+int equigspr_step_loss_backward(const float* R, const float* t, const float* gt_pose, const float* grad_loss, int32_t B,
+                                float* grad_R, float* grad_t, void* stream);
+
 /* ---- N2: evaluation metrics (tools/evaluation_metrics.py:14-43; eval loop src/eval_egnn_metrics.py:1245-1296) ----
  * Per pair b: out[5b..] = { rotation error [deg] = acos(clip((tr(G_R^T R) - 1)/2)), translation error [cm],
  * recall = sqrt(TP/n), precision = TP/n, F1 = 2 P R / (P + R + 1e-6) }, TP = #{ ||R src_i + t - tgt_i|| < tau }.

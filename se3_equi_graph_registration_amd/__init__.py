@@ -9,9 +9,10 @@ from ._lib import lib, LIB_PATH, declared_symbols  # noqa: F401
 from .ops import DeviceGraph, weighted_kabsch, knn_graph_batched, FlatAdam  # noqa: F401
 from .graph import knn_graph, get_edges_batch, get_edges_from_idx, build_pair_graph  # noqa: F401
 from .egnn import EGNN, E_GCL  # noqa: F401
-from .pose import (CrossAttentionPoseRegression, pose_loss, compute_losses, egnn_equi_loss,  # noqa: F401
+from .pose import (CrossAttentionPoseRegression, pose_loss, registration_loss, compute_losses, egnn_equi_loss,  # noqa: F401
                    unsorted_segment_sum, unsorted_segment_mean)
 from .synth import synthetic_pair, synthetic_batch  # noqa: F401
+from . import pose  # noqa: F401
 from .so3 import SO3TensorProductLayer  # noqa: F401
 from .pointnet import PointNetLayer, PointNet, global_max_pool  # noqa: F401
 from .metrics import evaluate_batch, calculate_pose_error, registration_recall  # noqa: F401
@@ -20,6 +21,6 @@ from .sh import get_basis, get_spherical_harmonics, precompute_sh, basis_transfo
 from .gcn import build_graph, GraphConvolution, GlobalPooling, KnnAdjacency  # noqa: F401
 
 __all__ = ["EGNN", "E_GCL", "CrossAttentionPoseRegression", "knn_graph", "get_edges_batch", "get_edges_from_idx",
-           "build_pair_graph", "DeviceGraph", "weighted_kabsch", "pose_loss", "compute_losses", "egnn_equi_loss",
+           "build_pair_graph", "DeviceGraph", "weighted_kabsch", "pose_loss", "registration_loss", "compute_losses", "egnn_equi_loss",
            "unsorted_segment_sum", "unsorted_segment_mean", "synthetic_pair", "synthetic_batch", "SO3TensorProductLayer", "FlatAdam", "build_graph", "GraphConvolution",
            "GlobalPooling", "KnnAdjacency"]

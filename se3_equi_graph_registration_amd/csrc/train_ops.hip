@@ -58,6 +58,70 @@ __global__ void pose_loss_bwd_kernel(const float* __restrict__ R, const float* _
     for (int i = 0; i < 3; ++i) gt[b * 3 + i] = kt * (G[i * 4 + 3] / (lt * lg) - c * t[b * 3 + i] / nt);
 }
 
+// Step loss of the training loop (train :1120): loss = corr_loss + mean_b(rot_loss) + mean_b(trans_loss) in ONE launch
+// (the three means, two adds and their autograd nodes are ~10 ATen launches otherwise).  One block; fixed-order sums.
+__global__ __launch_bounds__(256) void step_loss_fwd_kernel(const float* __restrict__ R, const float* __restrict__ t,
+                                                            const float* __restrict__ gt_pose, const float* __restrict__ closs, int B,
+                                                            float* __restrict__ loss, float* __restrict__ rot_loss,
+                                                            float* __restrict__ trans_loss) {
+    __shared__ float sr[256], st[256];
+    float ar = 0.0f, at = 0.0f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float* Rb = R + (size_t)b * 9;
+        const float* G = gt_pose + (size_t)b * 16;
+        float tr = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) tr = fmaf(Rb[i * 3 + j], G[i * 4 + j], tr);
+        const float rl = acosf(fminf(fmaxf((tr - 1.0f) * 0.5f, -1.0f), 1.0f));
+        float dp = 0.0f, nt = 0.0f, ng = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { const float a = t[b * 3 + i], g = G[i * 4 + 3]; dp = fmaf(a, g, dp); nt = fmaf(a, a, nt); ng = fmaf(g, g, ng); }
+        const float tl = acosf(fminf(fmaxf(dp / (sqrtf(nt) * sqrtf(ng)), -1.0f), 1.0f));
+        rot_loss[b] = rl; trans_loss[b] = tl;
+        ar += rl; at += tl;
+    }
+    sr[threadIdx.x] = ar; st[threadIdx.x] = at;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { sr[threadIdx.x] += sr[threadIdx.x + off]; st[threadIdx.x] += st[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (closs ? closs[0] : 0.0f) + sr[0] / (float)B + st[0] / (float)B;
+}
+
+// d loss / d(R, t) = pose-loss gradients scaled by g/B (g = upstream scalar gradient, 1 when NULL)
+__global__ void step_loss_bwd_kernel(const float* __restrict__ R, const float* __restrict__ t, const float* __restrict__ gt_pose,
+                                     const float* __restrict__ g, int B, float* __restrict__ gR, float* __restrict__ gt) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float up = (g ? g[0] : 1.0f) / (float)B;
+    const float* Rb = R + (size_t)b * 9;
+    const float* G = gt_pose + (size_t)b * 16;
+    float tr = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tr = fmaf(Rb[i * 3 + j], G[i * 4 + j], tr);
+    const float x = (tr - 1.0f) * 0.5f;
+    const float dx = (x >= -1.0f && x <= 1.0f) ? -1.0f / sqrtf(1.0f - x * x) : 0.0f;
+    const float kr = up * dx * 0.5f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gR[(size_t)b * 9 + i * 3 + j] = kr * G[i * 4 + j];
+    float dp = 0.0f, nt = 0.0f, ng = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const float a = t[b * 3 + i], gg = G[i * 4 + 3]; dp = fmaf(a, gg, dp); nt = fmaf(a, a, nt); ng = fmaf(gg, gg, ng); }
+    const float lt = sqrtf(nt), lg = sqrtf(ng);
+    const float c = dp / (lt * lg);
+    const float dc = (c >= -1.0f && c <= 1.0f) ? -1.0f / sqrtf(1.0f - c * c) : 0.0f;
+    const float kt = up * dc;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gt[b * 3 + i] = kt * (G[i * 4 + 3] / (lt * lg) - c * t[b * 3 + i] / nt);
+}
+
 struct AdamBuckets {
     float* p[4]; const float* g[4]; float* m[4]; float* v[4]; long long n[4]; int count;
 };
@@ -101,6 +165,24 @@ extern "C" int equigspr_pose_loss_backward(const float* R, const float* t, const
     hipLaunchKernelGGL(pose_loss_bwd_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, R, t, gt_pose, g_rot, g_trans, B,
                        grad_R, grad_t);
     EQ_CHECK_LAUNCH("pose_loss_backward");
+    return 0;
+}
+
+extern "C" int equigspr_step_loss_forward(const float* R, const float* t, const float* gt_pose, const float* corr_loss, int32_t B,
+                                          float* loss, float* rot_loss, float* trans_loss, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(R && t && gt_pose && loss && rot_loss && trans_loss && B >= 1, EQUIGSPR_EINVAL, "step_loss_forward: bad arguments");
+    hipLaunchKernelGGL(step_loss_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, R, t, gt_pose, corr_loss, B, loss, rot_loss, trans_loss);
+    EQ_CHECK_LAUNCH("step_loss_forward");
+    return 0;
+}
+
+extern "C" int equigspr_step_loss_backward(const float* R, const float* t, const float* gt_pose, const float* grad_loss, int32_t B,
+                                           float* grad_R, float* grad_t, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(R && t && gt_pose && grad_R && grad_t && B >= 1, EQUIGSPR_EINVAL, "step_loss_backward: bad arguments");
+    hipLaunchKernelGGL(step_loss_bwd_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, (hipStream_t)stream, R, t, gt_pose, grad_loss, B, grad_R, grad_t);
+    EQ_CHECK_LAUNCH("step_loss_backward");
     return 0;
 }
 

@@ -43,9 +43,10 @@ class FlatBucket:
                 p.grad = self.grad[off:off + n].view(p.shape)
                 off += n
 
-    def zero_grad(self):
+    def zero_grad(self, fill: bool = True):
         if self.grad is not None:
-            self.grad.zero_()
+            if fill:
+                self.grad.zero_()
             off = 0
             for p in self.params:            # autograd accumulates in place into these views
                 n = p.numel()
@@ -96,6 +97,11 @@ class DataParallelStep:
         return out
 
     def zero_grad(self):
+        if self.joint_grad is not None:                 # one fill for the whole joint bucket
+            self.joint_grad.zero_()
+            self.egnn._attach_grads()
+            self.head.zero_grad(fill=False)
+            return
         if self.egnn is not None and self.egnn.flat_grads is not None:
             self.egnn.zero_grad(set_to_none=False)
         self.head.zero_grad()

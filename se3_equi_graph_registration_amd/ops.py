@@ -267,6 +267,7 @@ class _HeadFn(torch.autograd.Function):
         ctx.save_for_backward(hs, ht, xs, xt, labels, gt, flat, sim, rsim, cosv, pos, wts, top_idx, logits, a1, a2, fin, aux, work)
         ctx.dims = (B, N, Fd, K, msz)
         ctx.mlp_shapes = [tuple(q.shape) for q in mlp_params]
+        ctx.mlp_params = list(mlp_params)
         ctx.mark_non_differentiable(top_idx, logits)      # the logits' only consumer (BCE) is inside the head
         ctx.set_materialize_grads(False)
         return R, t, fin[0], fin[1], logits, top_idx
@@ -288,13 +289,18 @@ class _HeadFn(torch.autograd.Function):
         ghs, ght = gh_all[:B * N], gh_all[B * N:]
         dinp = torch.empty(B, K, 2 * Fd, **f32)
         slab = torch.empty(int(L.equigspr_head_slab_count(B, K)), msz, **f32)
-        gmlp = torch.zeros(msz, **f32)
+        # The kernel ACCUMULATES the MLP gradient.  When the parameters' .grad tensors are adjacent views of one flat
+        # bucket (dp.FlatBucket) it accumulates straight into that bucket -- no per-tensor autograd adds.
+        in_place = _adjacent_grad_slice(ctx.mlp_params, msz)
+        gmlp = in_place if in_place is not None else torch.zeros(msz, **f32)
         g_cs = None if g_cs is None else g_cs.contiguous().float()
         g_eq = None if g_eq is None else g_eq.contiguous().float()
         _lib.check(L.equigspr_head_backward(_p(hs), _p(ht), _p(xs), _p(xt), _p(labels), _p(gt), _p(flat), _p(sim), _p(rsim),
                                             _p(cosv), _p(pos), _p(wts), _p(top_idx), _p(logits), _p(a1), _p(a2), _p(fin),
                                             _p(g_cs), _p(g_eq), _p(gw), B, N, Fd, K, _p(work), _p(dinp), _p(slab), _p(gmlp),
                                             _p(ghs), _p(ght), _p(gxs), _p(gxt), _stream()), "head_backward")
+        if in_place is not None:
+            return (gh_all, gx_all, None, None, None, None, None, *([None] * len(ctx.mlp_shapes)))
         grads, off = [], 0
         for shp in ctx.mlp_shapes:
             n = 1
@@ -303,6 +309,22 @@ class _HeadFn(torch.autograd.Function):
             grads.append(gmlp[off:off + n].view(shp))
             off += n
         return (gh_all, gx_all, None, None, None, None, None, *grads)
+
+
+def _adjacent_grad_slice(params, total):
+    """The flat fp32 tensor covering ``[p.grad for p in params]`` if those are adjacent contiguous views, else None."""
+    g0 = params[0].grad
+    if g0 is None:
+        return None
+    off = 0
+    for q in params:
+        g = q.grad
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() != g0.data_ptr() + 4 * off:
+            return None
+        off += q.numel()
+    if off != total:
+        return None
+    return g0.reshape(-1).as_strided((total,), (1,))
 
 
 def fused_pose_head(h_all, x_all, raw_hs, raw_ht, labels, gt_pose, topk, mlp_params):
@@ -339,6 +361,40 @@ class _PoseLossFn(torch.autograd.Function):
 
 def fused_pose_loss(pred_rot, pred_translation, gt_pose):
     return _PoseLossFn.apply(pred_rot, pred_translation, gt_pose)
+
+
+class _StepLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, R, t, corr_loss, gt_pose):
+        R = _need(R.contiguous(), "pred_rot", torch.float32, 3)
+        t = _need(t.contiguous(), "pred_translation", torch.float32, 2)
+        B = R.shape[0]
+        gt = _need(gt_pose.reshape(B, 16).contiguous().float(), "gt_pose", torch.float32, 2)
+        if corr_loss is not None:
+            corr_loss = _need(corr_loss.reshape(1).float(), "corr_loss", torch.float32, 1)
+        out = torch.empty(1 + 2 * B, dtype=torch.float32, device=R.device)
+        _lib.check(_lib.lib().equigspr_step_loss_forward(_p(R), _p(t), _p(gt), _p(corr_loss), B, _p(out), _p(out[1:]), _p(out[1 + B:]),
+                                                         _stream()), "step_loss_forward")
+        ctx.save_for_backward(R, t, gt)
+        ctx.has_corr = corr_loss is not None
+        rot, tr = out[1:1 + B], out[1 + B:]
+        ctx.mark_non_differentiable(rot, tr)
+        return out[0], rot, tr
+
+    @staticmethod
+    def backward(ctx, g, _g_rot, _g_tr):
+        R, t, gt = ctx.saved_tensors
+        B = R.shape[0]
+        gR, gt_ = torch.empty_like(R), torch.empty_like(t)
+        g = None if g is None else g.reshape(1).contiguous().float()
+        _lib.check(_lib.lib().equigspr_step_loss_backward(_p(R), _p(t), _p(gt), _p(g), B, _p(gR), _p(gt_), _stream()), "step_loss_backward")
+        return gR, gt_, (g.reshape(()) if (ctx.has_corr and g is not None) else None), None
+
+
+def fused_step_loss(pred_rot, pred_translation, corr_loss, gt_pose):
+    """``corr_loss.mean() + rot_loss.mean() + trans_loss.mean()`` of the training loop (train :1120) in one launch.
+    Returns ``(loss, rot_loss [B], trans_loss [B])``; the per-pair losses are for logging (not differentiable)."""
+    return _StepLossFn.apply(pred_rot, pred_translation, corr_loss, gt_pose)
 
 
 class FlatAdam:

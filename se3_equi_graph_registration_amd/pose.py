@@ -36,10 +36,24 @@ def egnn_equi_loss(h_src, x_src, h_tgt, x_tgt, R_gt, t_gt, labels):
 
 
 def pose_loss(pred_rot, pred_translation, gt_pose, delta=1.5):
-    """train :896-962 -> (rotation geodesic loss [B], translation direction loss [B]); one fused HIP
-    kernel each way on device tensors (csrc/train_ops.hip), the same formulas in ATen ops otherwise."""
-    if pred_rot.is_cuda and pred_rot.dtype == torch.float32:
-        return ops.fused_pose_loss(pred_rot, pred_translation, gt_pose)
+    """train :896-962 -> (rotation geodesic loss [B], translation direction loss [B]); one fused HIP kernel each way
+    (csrc/train_ops.hip).  Device tensors only -- there is no CPU path."""
+    if not pred_rot.is_cuda:
+        raise RuntimeError("pose_loss: tensors must live on the GPU (this package has no CPU path)")
+    return ops.fused_pose_loss(pred_rot.float(), pred_translation.float(), gt_pose)
+
+
+def registration_loss(pred_rot, pred_translation, corr_loss, gt_pose):
+    """The training loop's scalar loss ``corr_loss.mean() + rot_loss.mean() + trans_loss.mean()`` (train :1117-1120) as ONE
+    HIP launch each way; returns ``(loss, rot_loss [B], trans_loss [B])`` (the per-pair terms are for logging)."""
+    if not pred_rot.is_cuda:
+        raise RuntimeError("registration_loss: tensors must live on the GPU (this package has no CPU path)")
+    return ops.fused_step_loss(pred_rot.float(), pred_translation.float(), corr_loss, gt_pose)
+
+
+def pose_loss_aten(pred_rot, pred_translation, gt_pose):
+    """The same formulas as plain PyTorch ops (what the reference runs, train :896-962): the unfused comparison path of the
+    GPU parity tests (``test_fused_pose_loss_matches_aten``); not called by the product path."""
     gt_t, gt_R = gt_pose[:, :3, 3], gt_pose[:, :3, :3]
     Rd = torch.matmul(pred_rot.transpose(-1, -2), gt_R)
     tr = Rd.diagonal(dim1=-2, dim2=-1).sum(-1)

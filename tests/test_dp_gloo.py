@@ -27,6 +27,9 @@ class FakeEgnn(nn.Module):
     def zero_grad(self, set_to_none=False):
         self._bucket.zero_grad()
 
+    def _attach_grads(self):
+        self._bucket.zero_grad(fill=False)
+
     def rehome(self, flat, grads):                     # EGNN.rehome contract: caller-owned storage
         b = FlatBucket(self.parameters(), storage=(flat, grads))
         self.flat_params, self.flat_grads, self._bucket = b.flat, b.grad, b

@@ -403,13 +403,65 @@ def test_fused_pose_loss_matches_aten(pk):
     ref = {}
     for dev in ("cpu", "cuda"):
         R_ = q.clone().to(dev).requires_grad_(True); t_ = t.clone().to(dev).requires_grad_(True)
-        rl, tl = pk.pose_loss(R_, t_, pose.to(dev))
+        fn = pk.pose_loss if dev == "cuda" else pk.pose.pose_loss_aten          # HIP kernels vs the reference's ATen formula
+        rl, tl = fn(R_, t_, pose.to(dev))
         ((rl * w1.to(dev)).sum() + (tl * w2.to(dev)).sum()).backward()
         ref[dev] = (rl.detach().cpu(), tl.detach().cpu(), R_.grad.cpu(), t_.grad.cpu())
     for a, b in zip(ref["cpu"], ref["cuda"]):
         assert torch.allclose(a, b, rtol=2e-4, atol=2e-5)
     o_rl, o_tl = orc.pose_loss(q, t, pose)
     assert torch.allclose(ref["cuda"][0], o_rl, rtol=2e-4, atol=2e-5) and torch.allclose(ref["cuda"][1], o_tl, rtol=2e-4, atol=2e-5)
+
+
+def test_registration_loss_matches_unfused(pk):
+    """train :1120 as one launch: value and gradients equal corr.mean() + pose_loss means through autograd; CPU tensors raise."""
+    g = torch.Generator().manual_seed(9)
+    for B in (1, 5, 300):
+        q, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))
+        gq, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))
+        pose = torch.eye(4).repeat(B, 1, 1); pose[:, :3, :3] = gq; pose[:, :3, 3] = torch.rand(B, 3, generator=g)
+        t = torch.rand(B, 3, generator=g)
+        res = []
+        for fused in (True, False):
+            R_ = q.clone().cuda().requires_grad_(True); t_ = t.clone().cuda().requires_grad_(True)
+            c_ = torch.tensor(0.37, device="cuda", requires_grad=True)
+            if fused:
+                loss, rl, tl = pk.registration_loss(R_, t_, c_ * 2.0, pose.cuda())
+            else:
+                rl, tl = pk.pose_loss(R_, t_, pose.cuda())
+                loss = (c_ * 2.0).mean() + rl.mean() + tl.mean()
+            (loss * 1.5).backward()
+            res.append((loss.detach(), rl.detach(), tl.detach(), R_.grad, t_.grad, c_.grad))
+        for a, b in zip(*res):
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        pk.registration_loss(q, t, None, pose)
+    with pytest.raises(RuntimeError):
+        pk.pose_loss(q, t, pose)
+
+
+def test_head_gradients_accumulate_into_flat_bucket(pk, golden_dir):
+    """With the head MLP re-homed in a flat bucket (dp.FlatBucket) the HIP backward accumulates into the bucket directly;
+    the result equals the per-tensor autograd path, and a second backward adds on top."""
+    from se3_equi_graph_registration_amd.dp import FlatBucket
+    fx = np.load(os.path.join(golden_dir, "pair_n512_k12_l2_wellcond.npz"))
+    grads = {}
+    for mode in ("tensors", "bucket"):
+        models = _pair_models(pk, fx)
+        args = _pair_inputs(pk, fx)
+        m = models["train"]
+        bucket = FlatBucket(list(m.mlp.parameters())) if mode == "bucket" else None
+        reps = 2 if mode == "bucket" else 1
+        for _ in range(reps):
+            out = m(*args)
+            loss, _, _ = pk.registration_loss(out[0], out[1], out[2], args[-1])
+            loss.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in m.mlp.parameters()])
+        grads[mode] = g / reps
+        if bucket is not None:
+            assert torch.equal(bucket.grad, g)
+    assert float(grads["tensors"].abs().max()) > 0
+    assert torch.allclose(grads["tensors"], grads["bucket"], rtol=1e-5, atol=1e-7)
 
 
 def test_flat_adam_matches_torch_adam(pk):

@@ -110,8 +110,12 @@ def test_losses_match_oracle():
     pose = torch.eye(4).repeat(B, 1, 1); pose[:, :3, 3] = torch.rand(B, 3, generator=g)
     q, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))
     t = torch.rand(B, 3, generator=g)
-    for a, b in zip(pk.pose_loss(q, t, pose), orc.pose_loss(q, t, pose)):
+    for a, b in zip(pk.pose.pose_loss_aten(q, t, pose), orc.pose_loss(q, t, pose)):     # the unfused comparison formula
         assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        pk.pose_loss(q, t, pose)                                                         # product op: GPU tensors only
+    with pytest.raises(RuntimeError):
+        pk.registration_loss(q, t, None, pose)
     for a, b in zip(pk.compute_losses(q, t, hs, xs, ht, xt, lab), orc.compute_losses(q, t, hs, xs, ht, xt, lab)):
         assert torch.equal(a, b)
     assert torch.equal(pk.egnn_equi_loss(hs, xs, ht, xt, pose[:, :3, :3], pose[:, :3, 3], lab),
