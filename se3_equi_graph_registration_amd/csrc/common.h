@@ -11,15 +11,18 @@
 #ifdef EQ_TRACE
 #define EQ_TRACE_SLOTS 16
 static __device__ unsigned long long* eq_trace_ptr = nullptr;      // one copy per translation unit
-#define EQ_STAMP(k)                                                                                         \
+#define EQ_TRACE_WAVES 16384                                        // waves per kernel id
+#define EQ_STAMPK(kid, k)                                                                                   \
     do {                                                                                                    \
         __builtin_amdgcn_s_waitcnt(0);                                                                      \
         if ((threadIdx.x & 63) == 0 && ::eq_trace_ptr)                                                      \
-            ::eq_trace_ptr[(size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * EQ_TRACE_SLOTS + (k)] = \
+            ::eq_trace_ptr[((size_t)(kid) * EQ_TRACE_WAVES + (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6))) * EQ_TRACE_SLOTS + (k)] = \
                 __builtin_amdgcn_s_memtime();                                                               \
     } while (0)
+#define EQ_STAMP(k) EQ_STAMPK(0, k)
 #else
 #define EQ_STAMP(k)
+#define EQ_STAMPK(kid, k)
 #endif
 
 namespace eq {

@@ -90,8 +90,9 @@ __device__ __forceinline__ void slab_flush(const float* sl, float* __restrict__ 
     __syncthreads();
     for (int t = threadIdx.x; t < size; t += 256) dst[(size_t)blockIdx.x * size + t] = sl[t];
 }
+template <int MAXN = 64 * 34>
 __device__ __forceinline__ void stage_copy(float* dst, const float* __restrict__ src, int n) {
-    for (int t = threadIdx.x; t < n; t += 256) dst[t] = src[t];
+    stage_batched<MAXN>(dst, src, n, [](int t) { return t; }, [](int t) { return t; });
 }
 
 // ---------------------------------------------------------------------------------------
@@ -203,11 +204,24 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__
     float* WaT = wts + 2 * F * (F + 1);
     float* WbT = WaT + F * (F + 1);
     const int slot = threadIdx.x / G, f = threadIdx.x % G;
-    stage_T<F>(W4T, lw + LL::w4, 2 * F, 2 * F);
-    stage_w1_T<F, H, A>(WaT, lw, 0);
-    stage_w1_T<F, H, A>(WbT, lw, F);
-    stage_copy(w45, lw + LL::w4, 2 * F * F);
-    stage_copy(w45 + 2 * F * F, lw + LL::w5, F * F);
+    EQ_STAMPK(1, 0);
+    {   // all five matrices' loads in flight together, then the LDS stores
+        const MapT<F> m4{2 * F, 2 * F};
+        const MapW1T<F, H, A> ma{0}, mb{F};
+        Staged<2 * F * F> s4, c4;
+        Staged<F * F> sa, sb, c5;
+        s4.load(lw + LL::w4, 2 * F * F, [=](int t) { return m4.src(t); });
+        sa.load(lw, F * F, [=](int t) { return ma.src(t); });
+        sb.load(lw, F * F, [=](int t) { return mb.src(t); });
+        c4.load(lw + LL::w4, 2 * F * F, [](int t) { return t; });
+        c5.load(lw + LL::w5, F * F, [](int t) { return t; });
+        s4.store(W4T, 2 * F * F, [=](int t) { return m4.dst(t); });
+        sa.store(WaT, F * F, [=](int t) { return ma.dst(t); });
+        sb.store(WbT, F * F, [=](int t) { return mb.dst(t); });
+        c4.store(w45, 2 * F * F, [](int t) { return t; });
+        c5.store(w45 + 2 * F * F, F * F, [](int t) { return t; });
+    }
+    EQ_STAMPK(1, 1);
     const float* W4 = w45;
     const float* W5 = w45 + 2 * F * F;
     OuterAcc<G, 2 * F> aW4;
@@ -227,6 +241,7 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__
             ghv[slot][f] = g;
         }
         __syncthreads();
+        EQ_STAMPK(1, 2);
         if (act) {
             v = lw[LL::b4 + f] + col_dot<F>(W4T, f, vin[slot], 2 * F);
             hid[slot][f] = silu(v);
@@ -234,8 +249,10 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__
             for (int o = 0; o < F; ++o) dg = fmaf(ghv[slot][o], W5[o * F + f], dg);
             dvv[slot][f] = dg * silu_grad(v);
         }
+        EQ_STAMPK(1, 3);
         if (j < n_nodes) project_pre<F, H, A>(lw, WaT, WbT, vin[slot], f, P + (size_t)j * PS);
         __syncthreads();
+        EQ_STAMPK(1, 4);
         if (act) {
             float d_h = 0.0f, d_a = 0.0f;
             for (int o = 0; o < F; ++o) {
@@ -247,16 +264,19 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__
             dagg[(size_t)j * FP + f] = d_a;
         }
         const int ns = min(NS, n_nodes - grp * NS);
+        EQ_STAMPK(1, 5);
         aW4.add(&dvv[0][0], FP, &vin[0][0], 2 * FP, ns, 2 * F);
         aW5.add(&ghv[0][0], FP, &hid[0][0], FP, ns, F);
         ab4.add(&dvv[0][0], FP, ns);
         ab5.add(&ghv[0][0], FP, ns);
+        EQ_STAMPK(1, 6);
     }
     float* my = slab + (size_t)blockIdx.x * SB::node;
     aW4.store(my, F, 2 * F);
     ab4.store(my + F * 2 * F, F);
     aW5.store(my + F * 2 * F + F, F, F);
     ab5.store(my + F * 2 * F + F + F * F, F);
+    EQ_STAMPK(1, 7);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -279,10 +299,10 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
     __shared__ float pcv[NS][FP];
     __shared__ float w1[F * 2 * F];             // W1[:, 0:2F] row-major [o][2F]
     const int slot = threadIdx.x / G, f = threadIdx.x % G;
-    for (int t = threadIdx.x; t < F * 2 * F; t += 256) {
-        const int o = t / (2 * F), c = t - o * 2 * F;
-        w1[t] = lw[LL::w1_off(o, c)];
-    }
+    EQ_STAMPK(2, 0);
+    stage_batched<F * 2 * F>(w1, lw, F * 2 * F, [](int t) { const int o = t / (2 * F); return LL::w1_off(o, t - o * 2 * F); },
+                             [](int t) { return t; });
+    EQ_STAMPK(2, 1);
     OuterAcc<G, F> aWa, aWb;
     VecAcc<G> ab1;
     aWa.init(); aWb.init(); ab1.init();
@@ -309,6 +329,7 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
             }
         }
         __syncthreads();
+        EQ_STAMPK(2, 2);
         if (act) {
             float gh = dh_part[(size_t)j * FP + f];
             for (int o = 0; o < F; ++o) {
@@ -318,14 +339,17 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
             Gh_new[(size_t)j * FP + f] = gh;
         }
         const int ns = min(NS, n_nodes - grp * NS);
+        EQ_STAMPK(2, 3);
         aWa.add(&prv[0][0], FP, &hv[0][0], FP, ns, F);
         aWb.add(&pcv[0][0], FP, &hv[0][0], FP, ns, F);
         ab1.add(&pcv[0][0], FP, ns);
+        EQ_STAMPK(2, 4);
     }
     float* my = slab + (size_t)blockIdx.x * SB::gather;
     aWa.store(my, F, F);
     aWb.store(my + F * F, F, F);
     ab1.store(my + 2 * F * F, F);
+    EQ_STAMPK(2, 5);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -53,21 +53,60 @@ __device__ __forceinline__ void segment_sum(const int* __restrict__ perm, int lo
 // 64-way uncoalesced access.  Each workgroup therefore stages W^T once (WT[i][f], row stride
 // ROWS+1 -> conflict-free for the staging writes and for the per-lane reads) and every node
 // iteration reads it from LDS.
+// Weight staging global -> LDS.  All of a thread's loads are issued before its first LDS store (a load/store pair per
+// loop iteration exposes one L2 round trip per element: 11 k of node_bwd's 34 k ticks in the trace build).
+template <int MAXN>
+struct Staged {                                         // split form: load() of several matrices first, then their store()s
+    static constexpr int PER = (MAXN + 255) / 256;
+    float v[PER];
+    template <typename SrcIdx>
+    __device__ __forceinline__ void load(const float* __restrict__ src, int n, SrcIdx si) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int t = threadIdx.x + 256 * k;
+            v[k] = (t < n) ? src[si(t)] : 0.0f;
+        }
+    }
+    template <typename DstIdx>
+    __device__ __forceinline__ void store(float* dst, int n, DstIdx di) const {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int t = threadIdx.x + 256 * k;
+            if (t < n) dst[di(t)] = v[k];
+        }
+    }
+};
+template <int MAXN, typename SrcIdx, typename DstIdx>
+__device__ __forceinline__ void stage_batched(float* dst, const float* __restrict__ src, int n, SrcIdx si, DstIdx di) {
+    Staged<MAXN> r;
+    r.load(src, n, si);
+    r.store(dst, n, di);
+}
+// index maps of the transposed forms (shared by the one-call and the split staging)
+template <int ROWS> struct MapT {
+    int cols, ld;
+    __device__ __forceinline__ int src(int t) const { const int o = t / cols; return o * ld + (t - o * cols); }
+    __device__ __forceinline__ int dst(int t) const { const int o = t / cols; return (t - o * cols) * (ROWS + 1) + o; }
+};
+template <int F, int H, int A> struct MapW1T {
+    int c0;
+    __device__ __forceinline__ int src(int t) const { const int o = t / F; return LP<F, H, A>::w1_off(o, c0 + (t - o * F)); }
+    __device__ __forceinline__ int dst(int t) const { const int o = t / F; return (t - o * F) * (F + 1) + o; }
+};
+// src [ROWS][ld] (first `cols` columns, cols <= 64) -> dst transposed [cols][ROWS + 1]
 template <int ROWS>
 __device__ __forceinline__ void stage_T(float* dst, const float* __restrict__ src, int cols, int ld) {
-    for (int t = threadIdx.x; t < ROWS * cols; t += 256) {
-        const int o = t / cols, i = t - o * cols;
-        dst[i * (ROWS + 1) + o] = src[(size_t)o * ld + i];
-    }
+    stage_batched<ROWS * 64>(dst, src, ROWS * cols,
+                             [=](int t) { const int o = t / cols; return o * ld + (t - o * cols); },
+                             [=](int t) { const int o = t / cols; return (t - o * cols) * (ROWS + 1) + o; });
 }
 // W1[:, c0:c0+F] of a layer (head-interleaved rows) transposed
 template <int F, int H, int A>
 __device__ __forceinline__ void stage_w1_T(float* dst, const float* __restrict__ lw, int c0) {
     using LL = LP<F, H, A>;
-    for (int t = threadIdx.x; t < F * F; t += 256) {
-        const int o = t / F, i = t - o * F;
-        dst[i * (F + 1) + o] = lw[LL::w1_off(o, c0 + i)];
-    }
+    stage_batched<F * F>(dst, lw, F * F,
+                         [=](int t) { const int o = t / F; return LL::w1_off(o, c0 + (t - o * F)); },
+                         [=](int t) { const int o = t / F; return (t - o * F) * (F + 1) + o; });
 }
 template <int ROWS>
 __device__ __forceinline__ float col_dot(const float* WT, int f, const float* v, int n) {

@@ -174,17 +174,32 @@ __global__ __launch_bounds__(256) void node_fwd_kernel(
     __shared__ float WaT[64 * (F + 1) > F * 65 ? 64 * (F + 1) : F * 65];   // next layer's W_src^T, or W_out^T [F][out_nf+1 <= 65]
     __shared__ float WbT[F * (F + 1)];
     const int slot = threadIdx.x / G, f = threadIdx.x % G;
-    stage_T<F>(W4T, lw + LL::w4, 2 * F, 2 * F);
-    stage_T<F>(W5T, lw + LL::w5, F, F);
-    if (next_lw) {
-        stage_w1_T<F, H, A>(WaT, next_lw, 0);
-        stage_w1_T<F, H, A>(WbT, next_lw, F);
-    } else {
+    EQ_STAMPK(1, 0);
+    {   // all matrices' loads in flight together, then the LDS stores
+        const MapT<F> m4{2 * F, 2 * F}, m5{F, F};
+        const MapW1T<F, H, A> ma{0}, mb{F};
+        Staged<2 * F * F> s4;
+        Staged<F * F> s5, sa, sb;
+        s4.load(lw + LL::w4, 2 * F * F, [=](int t) { return m4.src(t); });
+        s5.load(lw + LL::w5, F * F, [=](int t) { return m5.src(t); });
+        if (next_lw) {
+            sa.load(next_lw, F * F, [=](int t) { return ma.src(t); });
+            sb.load(next_lw, F * F, [=](int t) { return mb.src(t); });
+        }
+        s4.store(W4T, 2 * F * F, [=](int t) { return m4.dst(t); });
+        s5.store(W5T, F * F, [=](int t) { return m5.dst(t); });
+        if (next_lw) {
+            sa.store(WaT, F * F, [=](int t) { return ma.dst(t); });
+            sb.store(WbT, F * F, [=](int t) { return mb.dst(t); });
+        }
+    }
+    if (!next_lw) {
         for (int t = threadIdx.x; t < out_nf * F; t += 256) {       // W_out^T: [i][o], row stride 65
             const int o = t / F, i = t - o * F;
             WaT[i * 65 + o] = w_out[t];
         }
     }
+    EQ_STAMPK(1, 1);
     const int groups = (n_nodes + NS - 1) / NS;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int j = grp * NS + slot;
@@ -197,6 +212,7 @@ __global__ __launch_bounds__(256) void node_fwd_kernel(
             segment_sum<G, true>(rperm, lo, hi, m_in, FP, trans_in, f, f < F, agg, xagg);   // ascending edge id
             if (f < 3) x_next[(size_t)j * 3 + f] = x[(size_t)j * 3 + f] + xagg;              // :267
         }
+        EQ_STAMPK(1, 2);
         __syncthreads();
         if (act) {
             vin[slot][f] = hj;
@@ -212,6 +228,7 @@ __global__ __launch_bounds__(256) void node_fwd_kernel(
             hnew[slot][f] = hn;
         }
         __syncthreads();
+        EQ_STAMPK(1, 3);
         if (live) {
             if (next_lw) {
                 project_pre<F, H, A>(next_lw, WaT, WbT, hnew[slot], f, P + (size_t)j * PS);
@@ -223,6 +240,7 @@ __global__ __launch_bounds__(256) void node_fwd_kernel(
                 }
             }
         }
+        EQ_STAMPK(1, 4);
     }
 }
 

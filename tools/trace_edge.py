@@ -24,14 +24,14 @@ x = torch.cat([batch["src"].reshape(B * N, 3), batch["tgt"].reshape(B * N, 3)]).
 cfg = egnn.cfg
 E = graph.n_edges
 SLOTS = 16
-n_waves = 4 * 4096
-buf = torch.zeros(n_waves * SLOTS, dtype=torch.int64, device=dev)
+WAVES = 16384                       # EQ_TRACE_WAVES: waves per kernel id
+buf = torch.zeros(3 * WAVES * SLOTS, dtype=torch.int64, device=dev)
 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 ms = ctypes.c_float(0.0)
 
 
-def report(name, stamps, labels):
-    st = stamps.cpu().numpy().reshape(-1, SLOTS)
+def report(name, stamps, labels, kid=0):
+    st = stamps.cpu().numpy().reshape(-1, SLOTS)[kid * WAVES:(kid + 1) * WAVES]
     xcd = (np.arange(st.shape[0]) // 4) % 8                 # workgroups round-robin over the 8 XCDs; s_memtime is per XCD
     live = st[:, 0] > 0
     st, xcd = st[live], xcd[live]
@@ -86,3 +86,25 @@ report("edge_bwd (last tile of each wave)", buf,
         (5, "t1, SiLU, W2, sum"), (6, "LN, W6, SiLU, w7"), (7, "coord head bwd + dW6 pass"), (8, "dagg gather + W6^T dq"),
         (9, "dw7/dgamma/dbeta passes"), (10, "LN bwd + dW2 pass"), (11, "W2^T du"), (12, "dWgeo pass"),
         (13, "Wgeo^T dt1, geometry bwd, stores"), (14, "remaining tiles' wait + block reduce + slab flush")])
+
+# ---- node-level kernels: one full forward / backward with the trace pointer set (kernel ids 1, 2)
+raw.equigspr_trace_set_bwd(None)
+buf.zero_()
+raw.equigspr_trace_set_fwd(ctypes.c_void_p(buf.data_ptr()))
+_, _, saved = ops.egnn_forward(cfg, egnn.flat_params, graph, h, x, None, True)
+torch.cuda.synchronize()
+raw.equigspr_trace_set_fwd(None)
+report("node_fwd (last layer launched, last group of each wave)", buf,
+       [(1, "stage W4^T, W5^T, next-layer W_src/W_tgt^T"), (2, "segment sums over incoming edges (m, trans)"),
+        (3, "node MLP (3 barriers)"), (4, "project P for the next layer / embedding_out")], kid=1)
+buf.zero_()
+raw.equigspr_trace_set_bwd(ctypes.c_void_p(buf.data_ptr()))
+gh = torch.randn(graph.n_nodes, F, device=dev); gx = torch.randn(graph.n_nodes, 3, device=dev)
+egnn.flat_grads.zero_()
+ops.egnn_backward(cfg, egnn.flat_params, graph, h, None, saved, gh, gx, egnn.flat_grads, (False, False))
+torch.cuda.synchronize()
+raw.equigspr_trace_set_bwd(None)
+report("node_bwd", buf, [(1, "stage W4^T, W_src^T, W_tgt^T, W4, W5 (29 KB)"), (2, "load Gh, h, agg"), (3, "W4 fwd + W5^T"), (4, "project P"),
+                          (5, "W4^T products, stores"), (6, "outer-product accumulation"), (7, "slab store")], kid=1)
+report("gather_bwd", buf, [(1, "stage W1[:, :2F]"), (2, "segment sums of dt1 over in/out edges"), (3, "W_src^T, W_tgt^T products"),
+                            (4, "outer-product accumulation"), (5, "slab store")], kid=2)
