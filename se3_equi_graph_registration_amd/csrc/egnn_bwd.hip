@@ -52,12 +52,17 @@ struct OuterAcc {
     // a: LDS [NS][lda] (row vectors), b: LDS [NS][ldb]; ns live nodes in this group
     __device__ __forceinline__ void add(const float* a, int lda, const float* b, int ldb, int ns, int ncols) {
         const int f = threadIdx.x % G, c = threadIdx.x / G;
-        for (int s = 0; s < ns; ++s) {
-            const float av = a[s * lda + f];
+        // unrolled over the (at most 8) nodes of a group so that all LDS reads are in flight together; a runtime trip
+        // count serialises one LDS round trip per node (9.7 k of node_bwd's 34 k ticks in the trace build)
 #pragma unroll
-            for (int j = 0; j < CPC; ++j) {
-                const int col = c * CPC + j;
-                if (col < ncols) acc[j] = fmaf(av, b[s * ldb + col], acc[j]);
+        for (int s = 0; s < 8; ++s) {
+            if (s < ns) {
+                const float av = a[s * lda + f];
+#pragma unroll
+                for (int j = 0; j < CPC; ++j) {
+                    const int col = c * CPC + j;
+                    if (col < ncols) acc[j] = fmaf(av, b[s * ldb + col], acc[j]);
+                }
             }
         }
     }
@@ -79,13 +84,42 @@ struct VecAcc {
     __device__ __forceinline__ void init() { acc = 0.0f; }
     __device__ __forceinline__ void add(const float* a, int lda, int ns) {
         const int f = threadIdx.x % G;
-        if (threadIdx.x < G)
-            for (int s = 0; s < ns; ++s) acc += a[s * lda + f];
+        if (threadIdx.x < G) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s < ns) acc += a[s * lda + f];
+        }
     }
     __device__ __forceinline__ void store(float* __restrict__ dst, int nrows) const {
         if (threadIdx.x < G && (int)(threadIdx.x % G) < nrows) dst[threadIdx.x % G] = acc;
     }
 };
+// hidden_nf == 32: the same outer-product sums on the matrix cores.  One wave owns one 32x32 block
+// D[o][i] += sum_n X[n][o] * Y[n][i] over the (<= 8) nodes of a group: 4 v_mfma_f32_32x32x2_f32 and 8 LDS reads per group
+// instead of ~100 LDS reads per thread for the thread-owned form (9.7 k -> ~1 k ticks of node_bwd in the trace build).
+struct MfmaOuter {
+    f32x16 acc;
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    }
+    __device__ __forceinline__ void add(const float* X, int ldx, const float* Y, int ldy, int ns, int lane) {
+        const int el = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int n = 2 * s + h;
+            const float a = (n < ns) ? X[n * ldx + el] : 0.0f;
+            const float b = (n < ns) ? Y[n * ldy + el] : 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void store(float* __restrict__ dst, int ld, int lane) const {   // dst[o * ld + i]
+        const int el = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[fidx(r, h) * ld + el] = acc[r];
+    }
+};
+
 __device__ __forceinline__ void slab_flush(const float* sl, float* __restrict__ dst, int size) {
     __syncthreads();
     for (int t = threadIdx.x; t < size; t += 256) dst[(size_t)blockIdx.x * size + t] = sl[t];
@@ -227,7 +261,11 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__
     OuterAcc<G, 2 * F> aW4;
     OuterAcc<G, F> aW5;
     VecAcc<G> ab4, ab5;
-    aW4.init(); aW5.init(); ab4.init(); ab5.init();
+    MfmaOuter mo;                                   // F == 32: wave 0/1 = dW4 column blocks, wave 2 = dW5, wave 3 = the bias sums
+    float mb4 = 0.0f, mb5 = 0.0f;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if constexpr (F == 32) mo.init();
+    else { aW4.init(); aW5.init(); ab4.init(); ab5.init(); }
     const int groups = (n_nodes + NS - 1) / NS;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int j = grp * NS + slot;
@@ -265,17 +303,34 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__
         }
         const int ns = min(NS, n_nodes - grp * NS);
         EQ_STAMPK(1, 5);
-        aW4.add(&dvv[0][0], FP, &vin[0][0], 2 * FP, ns, 2 * F);
-        aW5.add(&ghv[0][0], FP, &hid[0][0], FP, ns, F);
-        ab4.add(&dvv[0][0], FP, ns);
-        ab5.add(&ghv[0][0], FP, ns);
+        if constexpr (F == 32) {
+            if (wv < 2) mo.add(&dvv[0][0], FP, &vin[0][0] + 32 * wv, 2 * FP, ns, lane);
+            else if (wv == 2) mo.add(&ghv[0][0], FP, &hid[0][0], FP, ns, lane);
+            else {
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    if (n < ns) { mb4 += (lane < 32) ? dvv[n][lane & 31] : 0.0f; mb5 += (lane >= 32) ? ghv[n][lane & 31] : 0.0f; }
+            }
+        } else {
+            aW4.add(&dvv[0][0], FP, &vin[0][0], 2 * FP, ns, 2 * F);
+            aW5.add(&ghv[0][0], FP, &hid[0][0], FP, ns, F);
+            ab4.add(&dvv[0][0], FP, ns);
+            ab5.add(&ghv[0][0], FP, ns);
+        }
         EQ_STAMPK(1, 6);
     }
     float* my = slab + (size_t)blockIdx.x * SB::node;
-    aW4.store(my, F, 2 * F);
-    ab4.store(my + F * 2 * F, F);
-    aW5.store(my + F * 2 * F + F, F, F);
-    ab5.store(my + F * 2 * F + F + F * F, F);
+    if constexpr (F == 32) {
+        if (wv < 2) mo.store(my + 32 * wv, 2 * F, lane);
+        else if (wv == 2) mo.store(my + F * 2 * F + F, F, lane);
+        else if (lane < 32) my[F * 2 * F + lane] = mb4;
+        else my[F * 2 * F + F + F * F + (lane - 32)] = mb5;
+    } else {
+        aW4.store(my, F, 2 * F);
+        ab4.store(my + F * 2 * F, F);
+        aW5.store(my + F * 2 * F + F, F, F);
+        ab5.store(my + F * 2 * F + F + F * F, F);
+    }
     EQ_STAMPK(1, 7);
 }
 
@@ -305,7 +360,11 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
     EQ_STAMPK(2, 1);
     OuterAcc<G, F> aWa, aWb;
     VecAcc<G> ab1;
-    aWa.init(); aWb.init(); ab1.init();
+    MfmaOuter mo;                                   // F == 32: wave 0 = dW_src, wave 1 = dW_tgt, wave 2 = db1
+    float mb1 = 0.0f;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if constexpr (F == 32) mo.init();
+    else { aWa.init(); aWb.init(); ab1.init(); }
     const int groups = (n_nodes + NS - 1) / NS;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int j = grp * NS + slot;
@@ -316,8 +375,10 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
         if (live) {
             const int rlo = rptr[j], rhi = rptr[j + 1], clo = cptr[j], chi = cptr[j + 1];
             float gx = (f < 3) ? Gx[(size_t)j * 4 + f] : 0.0f;
-            segment_sum<G, true>(rperm, rlo, rhi, dt1, FP, gxr, f, f < F, dpr, gx);
-            segment_sum<G, true>(cperm, clo, chi, dt1, FP, gxc, f, f < F, dpc, gx);
+            float gx_r = 0.0f, gx_c = 0.0f;
+            segment_sum_pair<G>(rperm, rlo, rhi, cperm, clo, chi, dt1, FP, gxr, gxc, f, f < F, dpr, dpc, gx_r, gx_c);
+            gx += gx_r;                                // same order as before: identity, row-segment terms, col-segment terms
+            gx += gx_c;
             if (f < F) {
                 hv[slot][f] = h[(size_t)j * FP + f];
                 prv[slot][f] = dpr;
@@ -340,15 +401,30 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
         }
         const int ns = min(NS, n_nodes - grp * NS);
         EQ_STAMPK(2, 3);
-        aWa.add(&prv[0][0], FP, &hv[0][0], FP, ns, F);
-        aWb.add(&pcv[0][0], FP, &hv[0][0], FP, ns, F);
-        ab1.add(&pcv[0][0], FP, ns);
+        if constexpr (F == 32) {
+            if (wv == 0) mo.add(&prv[0][0], FP, &hv[0][0], FP, ns, lane);
+            else if (wv == 1) mo.add(&pcv[0][0], FP, &hv[0][0], FP, ns, lane);
+            else if (wv == 2 && lane < 32) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    if (n < ns) mb1 += pcv[n][lane];
+            }
+        } else {
+            aWa.add(&prv[0][0], FP, &hv[0][0], FP, ns, F);
+            aWb.add(&pcv[0][0], FP, &hv[0][0], FP, ns, F);
+            ab1.add(&pcv[0][0], FP, ns);
+        }
         EQ_STAMPK(2, 4);
     }
     float* my = slab + (size_t)blockIdx.x * SB::gather;
-    aWa.store(my, F, F);
-    aWb.store(my + F * F, F, F);
-    ab1.store(my + 2 * F * F, F);
+    if constexpr (F == 32) {
+        if (wv < 2) mo.store(my + wv * F * F, F, lane);
+        else if (wv == 2 && lane < 32) my[2 * F * F + lane] = mb1;
+    } else {
+        aWa.store(my, F, F);
+        aWb.store(my + F * F, F, F);
+        ab1.store(my + 2 * F * F, F);
+    }
     EQ_STAMPK(2, 5);
 }
 

@@ -21,29 +21,61 @@ __device__ __forceinline__ float row_dot(const float* __restrict__ wrow, const f
 // ---- latency-tolerant segment sums --------------------------------------------------------
 // acc_f += sum over a in [lo,hi) of data[perm[a]][f] (and, for lanes f < 3, of data3[perm[a]][f]),
 // strictly in ascending a (the CPU scatter_add_ order).  The G lanes of a node first fetch up to
-// G indices with ONE coalesced load, broadcast them with shuffles, and keep 8 independent row
+// G indices with ONE coalesced load, broadcast them with shuffles, and keep 16 independent row
 // loads in flight per lane before the (ordered) adds -- instead of a dependent index->row chain.
-template <int G, bool kHas3>
+template <int G, bool kHas3, int D = 16>
 __device__ __forceinline__ void segment_sum(const int* __restrict__ perm, int lo, int hi, const float* __restrict__ data,
                                             int stride, const float* __restrict__ data3, int f, bool f_active,
                                             float& acc, float& acc3) {
     for (int base = lo; base < hi; base += G) {
         const int cnt = min(G, hi - base);
         const int my = (f < cnt) ? perm[base + f] : 0;
-        for (int a0 = 0; a0 < cnt; a0 += 8) {
-            float v[8], w[8];
+        for (int a0 = 0; a0 < cnt; a0 += D) {
+            float v[D], w[D];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < D; ++u) {
                 const int e = __shfl(my, (a0 + u) & (G - 1), G);
                 const bool in = (a0 + u) < cnt;
                 v[u] = (in && f_active) ? data[(size_t)e * stride + f] : 0.0f;
                 if (kHas3) w[u] = (in && f < 3) ? data3[(size_t)e * 4 + f] : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < D; ++u) {
                 acc += v[u];
                 if (kHas3) acc3 += w[u];
             }
+        }
+    }
+}
+
+// Two segments of the same node at once (gather_bwd: the edges where it is the neighbour and those where it is the centre):
+// both index loads and 2 x 8 row loads are in flight together instead of one segment after the other.  Each segment is
+// still summed in ascending position order into its own accumulators.
+template <int G>
+__device__ __forceinline__ void segment_sum_pair(const int* __restrict__ perm_a, int lo_a, int hi_a, const int* __restrict__ perm_b,
+                                                 int lo_b, int hi_b, const float* __restrict__ data, int stride,
+                                                 const float* __restrict__ data3_a, const float* __restrict__ data3_b, int f,
+                                                 bool f_active, float& acc_a, float& acc_b, float& acc3_a, float& acc3_b) {
+    const int na = hi_a - lo_a, nb = hi_b - lo_b;
+    const int n = max(na, nb);
+    for (int base = 0; base < n; base += G) {
+        const int ca = max(0, min(G, na - base)), cb = max(0, min(G, nb - base));
+        const int my_a = (f < ca) ? perm_a[lo_a + base + f] : 0;
+        const int my_b = (f < cb) ? perm_b[lo_b + base + f] : 0;
+        const int cm = max(ca, cb);
+        for (int a0 = 0; a0 < cm; a0 += 8) {
+            float va[8], vb[8], wa[8], wb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ea = __shfl(my_a, (a0 + u) & (G - 1), G), eb = __shfl(my_b, (a0 + u) & (G - 1), G);
+                const bool ia = (a0 + u) < ca, ib = (a0 + u) < cb;
+                va[u] = (ia && f_active) ? data[(size_t)ea * stride + f] : 0.0f;
+                vb[u] = (ib && f_active) ? data[(size_t)eb * stride + f] : 0.0f;
+                wa[u] = (ia && f < 3) ? data3_a[(size_t)ea * 4 + f] : 0.0f;
+                wb[u] = (ib && f < 3) ? data3_b[(size_t)eb * 4 + f] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc_a += va[u]; acc_b += vb[u]; acc3_a += wa[u]; acc3_b += wb[u]; }
         }
     }
 }
