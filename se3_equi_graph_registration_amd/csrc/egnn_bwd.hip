@@ -376,9 +376,9 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
             const int rlo = rptr[j], rhi = rptr[j + 1], clo = cptr[j], chi = cptr[j + 1];
             float gx = (f < 3) ? Gx[(size_t)j * 4 + f] : 0.0f;
             float gx_r = 0.0f, gx_c = 0.0f;
-            segment_sum_pair<G>(rperm, rlo, rhi, cperm, clo, chi, dt1, FP, gxr, gxc, f, f < F, dpr, dpc, gx_r, gx_c);
-            gx += gx_r;                                // same order as before: identity, row-segment terms, col-segment terms
-            gx += gx_c;
+            if constexpr (F == 32) gather_pair32(rperm, rlo, rhi, cperm, clo, chi, dt1, gxr, gxc, f, dpr, dpc, gx_r, gx_c);
+            else segment_sum_pair<G>(rperm, rlo, rhi, cperm, clo, chi, dt1, FP, gxr, gxc, f, f < F, dpr, dpc, gx_r, gx_c);
+            if (f < 3) { gx += gx_r; gx += gx_c; }     // identity, row-segment terms, col-segment terms
             if (f < F) {
                 hv[slot][f] = h[(size_t)j * FP + f];
                 prv[slot][f] = dpr;

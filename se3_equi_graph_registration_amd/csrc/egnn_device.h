@@ -80,6 +80,61 @@ __device__ __forceinline__ void segment_sum_pair(const int* __restrict__ perm_a,
     }
 }
 
+// hidden_nf == 32 form of the paired gather (gather_bwd): a 128-byte row is read by 8 lanes as float4, so the 32 lanes of
+// a node fetch FOUR rows per load instruction and one round of 8 loads per lane covers 32 rows of each segment -- the
+// whole gather is two memory round trips (indices, rows) for all but hub nodes, instead of one per 8 rows.  The 16-byte
+// coordinate rows are read one per lane.  Fixed summation order: ascending per lane, then a 4-way (rows) / 32-way (coords)
+// butterfly.  Returns in lane f: feature f of both row sums, and (f < 3) component f of both coordinate sums.
+__device__ __forceinline__ void gather_pair32(const int* __restrict__ perm_a, int lo_a, int hi_a, const int* __restrict__ perm_b,
+                                              int lo_b, int hi_b, const float* __restrict__ data, const float* __restrict__ data3_a,
+                                              const float* __restrict__ data3_b, int f, float& sum_a, float& sum_b, float& s3_a,
+                                              float& s3_b) {
+    constexpr int G = 32;
+    const int q = f >> 3, v = f & 7;
+    const int na = hi_a - lo_a, nb = hi_b - lo_b, n = max(na, nb);
+    float4 A = make_float4(0.f, 0.f, 0.f, 0.f), B = A, PA = A, PB = A;
+    for (int base = 0; base < n; base += G) {
+        const int ca = max(0, min(G, na - base)), cb = max(0, min(G, nb - base));
+        const int my_a = (f < ca) ? perm_a[lo_a + base + f] : 0;
+        const int my_b = (f < cb) ? perm_b[lo_b + base + f] : 0;
+        float4 ra[8], rb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int a = 4 * u + q;
+            const int ea = __shfl(my_a, a, G), eb = __shfl(my_b, a, G);
+            ra[u] = (a < ca) ? *reinterpret_cast<const float4*>(data + (size_t)ea * 32 + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[u] = (a < cb) ? *reinterpret_cast<const float4*>(data + (size_t)eb * 32 + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float4 pa = (f < ca) ? *reinterpret_cast<const float4*>(data3_a + (size_t)my_a * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 pb = (f < cb) ? *reinterpret_cast<const float4*>(data3_b + (size_t)my_b * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            A.x += ra[u].x; A.y += ra[u].y; A.z += ra[u].z; A.w += ra[u].w;
+            B.x += rb[u].x; B.y += rb[u].y; B.z += rb[u].z; B.w += rb[u].w;
+        }
+        PA.x += pa.x; PA.y += pa.y; PA.z += pa.z;
+        PB.x += pb.x; PB.y += pb.y; PB.z += pb.z;
+    }
+#pragma unroll
+    for (int off = 8; off <= 16; off <<= 1) {           // the 4 row sub-groups
+        A.x += __shfl_xor(A.x, off, G); A.y += __shfl_xor(A.y, off, G); A.z += __shfl_xor(A.z, off, G); A.w += __shfl_xor(A.w, off, G);
+        B.x += __shfl_xor(B.x, off, G); B.y += __shfl_xor(B.y, off, G); B.z += __shfl_xor(B.z, off, G); B.w += __shfl_xor(B.w, off, G);
+    }
+#pragma unroll
+    for (int off = 1; off <= 16; off <<= 1) {           // coordinate partials: one edge per lane
+        PA.x += __shfl_xor(PA.x, off, G); PA.y += __shfl_xor(PA.y, off, G); PA.z += __shfl_xor(PA.z, off, G);
+        PB.x += __shfl_xor(PB.x, off, G); PB.y += __shfl_xor(PB.y, off, G); PB.z += __shfl_xor(PB.z, off, G);
+    }
+    // lane f wants feature f = 4 * (f >> 2) + (f & 3): held by lane (f >> 2) in component (f & 3)
+    const int src = f >> 2, c = f & 3;
+    const float ax = __shfl(A.x, src, G), ay = __shfl(A.y, src, G), az = __shfl(A.z, src, G), aw = __shfl(A.w, src, G);
+    const float bx = __shfl(B.x, src, G), by = __shfl(B.y, src, G), bz = __shfl(B.z, src, G), bw = __shfl(B.w, src, G);
+    sum_a = c == 0 ? ax : (c == 1 ? ay : (c == 2 ? az : aw));
+    sum_b = c == 0 ? bx : (c == 1 ? by : (c == 2 ? bz : bw));
+    s3_a = f == 0 ? PA.x : (f == 1 ? PA.y : PA.z);
+    s3_b = f == 0 ? PB.x : (f == 1 ? PB.y : PB.z);
+}
+
 // ---- LDS-resident transposed weights for the node kernels --------------------------------
 // A lane owns one OUTPUT feature f and needs row f of W: read straight from global that is a
 // 64-way uncoalesced access.  Each workgroup therefore stages W^T once (WT[i][f], row stride
