@@ -704,7 +704,8 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
                                                             float* __restrict__ slab) {
     constexpr int F = 32, FP = 32, PS = 64, LD = 36;
     using SB = Slabs<F>;
-    __shared__ __attribute__((aligned(16))) float tiles[4 * 2 * 32 * LD];
+    constexpr int kTileFloats = 4 * 2 * 32 * LD > 4 * SB::edge ? 4 * 2 * 32 * LD : 4 * SB::edge;   // X/Y tiles, then 4 slab copies
+    __shared__ __attribute__((aligned(16))) float tiles[kTileFloats];
     __shared__ float wsm[TileWeightsLds::size];
     const int lane = threadIdx.x & 63, el = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
     const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
@@ -878,39 +879,35 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         EQ_STAMP(13);
     }
 
-    // ---- block reduction of the 4 waves' partials into one slab (fixed order) ----------------
-    float* sl = tiles;
+    // ---- the 4 waves' partials: each wave writes its own LDS copy (in parallel), then all threads add the four copies in
+    // fixed order straight into the block's global slab (was: four serialised read-modify-write rounds + a flush)
     const int f = lane & 31, hh = lane >> 5;
     cs_b6[0] += xhalf(cs_b6[0]);
     cs_b2[0] += xhalf(cs_b2[0]);
     cs_gam[0] += xhalf(cs_gam[0]);
     cs_bet[0] += xhalf(cs_bet[0]);
     cs_w7[0] += xhalf(cs_w7[0]);
-    for (int w = 0; w < 4; ++w) {
-        __syncthreads();
-        if (wv == w) {
-            const bool first = (w == 0);
+    __syncthreads();                                   // every wave is done with its X/Y tiles
+    {
+        float* sl = tiles + (size_t)wv * SB::edge;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int orow = (k & 3) + 8 * (k >> 2) + 4 * hh;
-                const int i2 = SB::e_w2 + orow * F + f, i6 = SB::e_w6 + orow * F + f;
-                sl[i2] = (first ? 0.0f : sl[i2]) + acc2[0][0][k];
-                sl[i6] = (first ? 0.0f : sl[i6]) + acc6[0][0][k];
-                if (f < 16) {
-                    const int ig = SB::e_geo + orow * 16 + f;
-                    sl[ig] = (first ? 0.0f : sl[ig]) + accg[0][0][k];
-                }
-            }
-            if (hh == 0) {
-                sl[SB::e_b2 + f] = (first ? 0.0f : sl[SB::e_b2 + f]) + cs_b2[0];
-                sl[SB::e_b6 + f] = (first ? 0.0f : sl[SB::e_b6 + f]) + cs_b6[0];
-                sl[SB::e_gam + f] = (first ? 0.0f : sl[SB::e_gam + f]) + cs_gam[0];
-                sl[SB::e_bet + f] = (first ? 0.0f : sl[SB::e_bet + f]) + cs_bet[0];
-                sl[SB::e_w7 + f] = (first ? 0.0f : sl[SB::e_w7 + f]) + cs_w7[0];
-            }
+        for (int k = 0; k < 16; ++k) {
+            const int orow = (k & 3) + 8 * (k >> 2) + 4 * hh;
+            sl[SB::e_w2 + orow * F + f] = acc2[0][0][k];
+            sl[SB::e_w6 + orow * F + f] = acc6[0][0][k];
+            if (f < 16) sl[SB::e_geo + orow * 16 + f] = accg[0][0][k];
+        }
+        if (hh == 0) {
+            sl[SB::e_b2 + f] = cs_b2[0];
+            sl[SB::e_b6 + f] = cs_b6[0];
+            sl[SB::e_gam + f] = cs_gam[0];
+            sl[SB::e_bet + f] = cs_bet[0];
+            sl[SB::e_w7 + f] = cs_w7[0];
         }
     }
-    slab_flush(sl, slab, SB::edge);
+    __syncthreads();
+    for (int t = threadIdx.x; t < SB::edge; t += 256)
+        slab[(size_t)blockIdx.x * SB::edge + t] = ((tiles[t] + tiles[SB::edge + t]) + tiles[2 * SB::edge + t]) + tiles[3 * SB::edge + t];
     EQ_STAMP(14);
 }
 

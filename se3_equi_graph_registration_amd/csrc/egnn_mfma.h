@@ -37,14 +37,29 @@ __device__ __forceinline__ void stage_tile_weights(float* sm, const float* __res
     using LL = LP<F, H, A>;
     using T = TileWeightsLds;
     constexpr int FH = F / H;
-    for (int t = threadIdx.x; t < 32 * T::GS; t += 256) {
-        const int i = t / T::GS, k = t - i * T::GS;
-        sm[T::o_geo + t] = (k < kGeo + A) ? lw[LL::w1_off(i, 2 * F + k)] : 0.0f;
+    // all global loads of a thread first, then its LDS stores (one exposed L2 round trip instead of one per element)
+    float vg[2], v2[4], v6[4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = threadIdx.x + 256 * u, i = t / T::GS, k = t - i * T::GS;
+        vg[u] = (t < 32 * T::GS && k < kGeo + A) ? lw[LL::w1_off(i, 2 * F + k)] : 0.0f;
     }
-    for (int t = threadIdx.x; t < 32 * 32; t += 256) {
-        const int i = t >> 5, k = t & 31;
-        sm[T::o_w2 + i * T::WS + k] = (i / FH == k / FH) ? lw[LL::w2_off(i, k)] : 0.0f;
-        sm[T::o_w6 + i * T::WS + k] = lw[LL::w6 + t];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = threadIdx.x + 256 * u, i = t >> 5, k = t & 31;
+        v2[u] = (i / FH == k / FH) ? lw[LL::w2_off(i, k)] : 0.0f;
+        v6[u] = lw[LL::w6 + t];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int t = threadIdx.x + 256 * u;
+        if (t < 32 * T::GS) sm[T::o_geo + t] = vg[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = threadIdx.x + 256 * u, i = t >> 5, k = t & 31;
+        sm[T::o_w2 + i * T::WS + k] = v2[u];
+        sm[T::o_w6 + i * T::WS + k] = v6[u];
     }
     if (threadIdx.x < 32) {
         const int k = threadIdx.x;
