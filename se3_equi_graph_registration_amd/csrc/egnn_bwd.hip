@@ -16,6 +16,8 @@
 // the slabs in fixed order into the flat gradient block (+=): bitwise reproducible, no atomics.
 #include "egnn_mfma.h"
 
+#include <algorithm>
+
 namespace eq {
 
 
@@ -971,9 +973,15 @@ template <int F, int H, int A>
 __global__ __launch_bounds__(256) void layer_grad_reduce_kernel(const float* __restrict__ node_slab, int n_node,
                                                                 const float* __restrict__ edge_slab, int n_edge,
                                                                 const float* __restrict__ gat_slab, int n_gat,
-                                                                float* __restrict__ grad_layer) {
+                                                                float* __restrict__ grad_layer, size_t slab_layer_stride,
+                                                                size_t grad_layer_stride) {
     using LL = LP<F, H, A>;
     using SB = Slabs<F>;
+    // blockIdx.y = layer: every layer keeps its own slab set, so ONE launch at the end of the backward reduces them all
+    node_slab += blockIdx.y * slab_layer_stride;
+    edge_slab += blockIdx.y * slab_layer_stride;
+    gat_slab += blockIdx.y * slab_layer_stride;
+    grad_layer += blockIdx.y * grad_layer_stride;
     const int lane = threadIdx.x & 31, part = threadIdx.x >> 5;
     const int idx = blockIdx.x * 32 + lane;
     const bool live = idx < LL::size;
@@ -1018,13 +1026,29 @@ __global__ __launch_bounds__(256) void plain_grad_reduce_kernel(const float* __r
     finish_parts(v, lane, part, live, dst + (live ? idx : 0));
 }
 
+// two independent slab reductions in one launch: blocks [0, split) do job A, the rest job B
+__global__ __launch_bounds__(256) void plain_grad_reduce2_kernel(const float* __restrict__ slab_a, int n_a, int size_a,
+                                                                 float* __restrict__ dst_a, int split,
+                                                                 const float* __restrict__ slab_b, int n_b, int size_b,
+                                                                 float* __restrict__ dst_b) {
+    const bool second = (int)blockIdx.x >= split;
+    const float* slab = second ? slab_b : slab_a;
+    const int n_slabs = second ? n_b : n_a, size = second ? size_b : size_a;
+    float* dst = second ? dst_b : dst_a;
+    const int lane = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int idx = ((int)blockIdx.x - (second ? split : 0)) * 32 + lane;
+    const bool live = idx < size;
+    const float v = live ? sum_slabs_part(slab, n_slabs, size, idx, part) : 0.0f;
+    finish_parts(v, lane, part, live, dst + (live ? idx : 0));
+}
+
 // ---------------------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------------------
 struct BwdLayout {
-    size_t Gh[2], Gx[2], dh_part, dagg, P, dt1, gxr, gxc, node_slab, edge_slab, gat_slab, emb_slab, total;
+    size_t Gh[2], Gx[2], dh_part, dagg, P, dt1, gxr, gxc, node_slab, edge_slab, gat_slab, emb_slab, emb_slab2, layer_stride, total;
 };
-static BwdLayout bwd_layout(int F, int in_nf, int out_nf, int64_t N, int64_t E) {
+static BwdLayout bwd_layout(int F, int in_nf, int out_nf, int64_t N, int64_t E, int L = 1) {
     const int FP = fpad(F);
     BwdLayout B;
     size_t o = 0;
@@ -1035,11 +1059,18 @@ static BwdLayout bwd_layout(int F, int in_nf, int out_nf, int64_t N, int64_t E) 
     B.dt1 = take(E * FP); B.gxr = take(E * 4); B.gxc = take(E * 4);
     const size_t node_sz = (size_t)F * 2 * F + F + F * F + F, gat_sz = 2 * (size_t)F * F + F;
     const size_t edge_sz = (size_t)F * 16 + 2 * F * F + 5 * F;
-    B.node_slab = take(kNodeBwdBlocks * node_sz);
-    B.edge_slab = take(kEdgeBwdBlocks * edge_sz);
-    B.gat_slab = take(kNodeBwdBlocks * gat_sz);
+    // slab sets: one per layer (layer l at + l * layer_stride), sized for the blocks this problem actually launches
+    const int NS = 256 / (F <= 32 ? 32 : 64);
+    const size_t node_blocks = std::min<size_t>((N + NS - 1) / NS, kNodeBwdBlocks);
+    const size_t edge_blocks = std::min<size_t>(F == 32 ? 256 : (size_t)((E + 255) / 256), kEdgeBwdBlocks);
     const size_t emb = (size_t)64 * F + 64;
-    B.emb_slab = take(kNodeBwdBlocks * emb);
+    B.emb_slab = take(node_blocks * emb);
+    B.emb_slab2 = take(node_blocks * emb);
+    B.node_slab = take(node_blocks * node_sz);
+    B.edge_slab = take(edge_blocks * edge_sz);
+    B.gat_slab = take(node_blocks * gat_sz);
+    B.layer_stride = o - B.node_slab;
+    o += (size_t)(L - 1) * B.layer_stride;
     B.total = o;
     return B;
 }
@@ -1053,7 +1084,7 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
     const ModelLayout ML = make_model_layout(cfg->in_nf, F, cfg->out_nf, A, cfg->n_layers, H);
     const int N = g->n_nodes, E = g->n_edges, L = cfg->n_layers;
     constexpr int FP = Geom<F>::FP, NS = Geom<F>::NS, NB = (F + 31) / 32, LD = NB * 32 + 1;
-    const BwdLayout B = bwd_layout(F, cfg->in_nf, cfg->out_nf, N, E);
+    const BwdLayout B = bwd_layout(F, cfg->in_nf, cfg->out_nf, N, E, L);
     const float* hs = saved;
     const float* xs = saved + (size_t)(L + 1) * N * FP;
     const float* aggs = xs + (size_t)(L + 1) * N * 3;
@@ -1066,32 +1097,36 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
     // embedding_out
     hipLaunchKernelGGL((embed_out_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_out, cfg->out_nf, gh_out,
                        gx_out, hs + (size_t)L * N * FP, N, Gh, Gx, work + B.emb_slab);
-    hipLaunchKernelGGL(plain_grad_reduce_kernel, dim3(ceil_div(cfg->out_nf * F + cfg->out_nf, 32)), dim3(256), 0, s,
-                       work + B.emb_slab, ngrid, cfg->out_nf * F + cfg->out_nf, grad_params + ML.w_out);
     for (int l = L - 1; l >= 0; --l) {
+        const size_t so = (size_t)l * B.layer_stride;                 // this layer's slab set
         const float* lw = params + ML.layer0 + (size_t)l * ML.layer_size;
         const float* h_l = hs + (size_t)l * N * FP;
         const float* x_l = xs + (size_t)l * N * 3;
         hipLaunchKernelGGL((node_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, work + B.Gh[cur], h_l,
-                           aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg, work + B.P, work + B.node_slab);
+                           aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg, work + B.P, work + B.node_slab + so);
         if (E > 0) {
             const int rc = launch_edge_bwd<F, H, A>(lw, g, edge_attr, x_l, work + B.P, work + B.dagg, work + B.Gx[cur],
-                                                    work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab, s, &egrid);
+                                                    work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab + so, s, &egrid);
             if (rc) return rc;
         }
         const int nxt = cur ^ 1;
         hipLaunchKernelGGL((gather_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, g->rptr, g->rperm, g->cptr,
                            g->cperm, work + B.dt1, work + B.gxr, work + B.gxc, work + B.dh_part, work + B.Gx[cur], h_l, N,
-                           work + B.Gh[nxt], work + B.Gx[nxt], (l == 0) ? grad_x_in : nullptr, work + B.gat_slab);
-        hipLaunchKernelGGL((layer_grad_reduce_kernel<F, H, A>), dim3(ceil_div(ML.layer_size, 32)), dim3(256), 0, s,
-                           work + B.node_slab, ngrid, work + B.edge_slab, E > 0 ? egrid : 0, work + B.gat_slab, ngrid,
-                           grad_params + ML.layer0 + (size_t)l * ML.layer_size);
+                           work + B.Gh[nxt], work + B.Gx[nxt], (l == 0) ? grad_x_in : nullptr, work + B.gat_slab + so);
         cur = nxt;
     }
     hipLaunchKernelGGL((embed_in_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_in, cfg->in_nf,
-                       work + B.Gh[cur], h_in, N, grad_h_in, work + B.emb_slab);
-    hipLaunchKernelGGL(plain_grad_reduce_kernel, dim3(ceil_div(F * cfg->in_nf + F, 32)), dim3(256), 0, s,
-                       work + B.emb_slab, ngrid, F * cfg->in_nf + F, grad_params + ML.w_in);
+                       work + B.Gh[cur], h_in, N, grad_h_in, work + B.emb_slab2);
+    // all slab reductions at the end: one launch for the L layers (blockIdx.y = layer), one for the two embeddings
+    hipLaunchKernelGGL((layer_grad_reduce_kernel<F, H, A>), dim3(ceil_div(ML.layer_size, 32), L), dim3(256), 0, s,
+                       work + B.node_slab, ngrid, work + B.edge_slab, E > 0 ? egrid : 0, work + B.gat_slab, ngrid,
+                       grad_params + ML.layer0, B.layer_stride, (size_t)ML.layer_size);
+    {
+        const int n_out = cfg->out_nf * F + cfg->out_nf, n_in = F * cfg->in_nf + F;
+        hipLaunchKernelGGL(plain_grad_reduce2_kernel, dim3(ceil_div(n_out, 32) + ceil_div(n_in, 32)), dim3(256), 0, s,
+                           work + B.emb_slab, ngrid, n_out, grad_params + ML.w_out, ceil_div(n_out, 32), work + B.emb_slab2, ngrid,
+                           n_in, grad_params + ML.w_in);
+    }
     EQ_CHECK_LAUNCH("egnn_backward");
     return 0;
 }
@@ -1142,7 +1177,7 @@ static int time_edge_bwd_impl(const equigspr_egnn_config* cfg, const float* para
 
 extern "C" int64_t equigspr_egnn_bwd_work_size(const equigspr_egnn_config* cfg, int32_t n_nodes, int32_t n_edges) {
     if (!eq::config_supported(cfg) || n_nodes < 0 || n_edges < 0) return -1;
-    return (int64_t)eq::bwd_layout(cfg->hidden_nf, cfg->in_nf, cfg->out_nf, n_nodes, n_edges).total;
+    return (int64_t)eq::bwd_layout(cfg->hidden_nf, cfg->in_nf, cfg->out_nf, n_nodes, n_edges, cfg->n_layers).total;
 }
 
 extern "C" int equigspr_egnn_backward(const equigspr_egnn_config* cfg, const float* params, const equigspr_graph* g,
