@@ -431,6 +431,139 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------
+// hidden_nf == 32: gather backward of layer l FUSED with the node-MLP backward of layer l-1.  Both are node-local
+// (G_h of layer l-1's output is produced and consumed by the same 32 lanes), so the fused kernel saves a launch, a weight
+// staging phase and the G_h round trip per layer.  Same arithmetic and summation order as the two kernels above.
+// Outer products per group: wave 0 = dW4[:, :32] + db1, wave 1 = dW4[:, 32:], wave 2 = dW5 + dW_src, wave 3 = db4/db5 + dW_tgt.
+// ---------------------------------------------------------------------------------------
+template <int H, int A>
+__global__ __launch_bounds__(256, 2) void gather_node_bwd_kernel(
+    const float* __restrict__ lw_g, const float* __restrict__ lw_n, const int* __restrict__ rptr, const int* __restrict__ rperm,
+    const int* __restrict__ cptr, const int* __restrict__ cperm, const float* __restrict__ dt1, const float* __restrict__ gxr,
+    const float* __restrict__ gxc, const float* __restrict__ Gx, const float* __restrict__ h_g, const float* __restrict__ h_n,
+    const float* __restrict__ agg_n, int n_nodes, float* __restrict__ dh_part, float* __restrict__ dagg, float* __restrict__ P,
+    float* __restrict__ Gx_new, float* __restrict__ gat_slab, float* __restrict__ node_slab) {
+    constexpr int F = 32, FP = 32, G = 32, NS = 8, PS = 64;
+    using LL = LP<F, H, A>;
+    using SB = Slabs<F>;
+    __shared__ float hv[NS][FP];
+    __shared__ float prv[NS][FP];
+    __shared__ float pcv[NS][FP];
+    __shared__ float w1[F * 2 * F];             // layer l: W1[:, 0:2F] row-major
+    __shared__ float vin[NS][2 * FP];
+    __shared__ float hid[NS][FP];
+    __shared__ float ghv[NS][FP];
+    __shared__ float dvv[NS][FP];
+    __shared__ float wts[4 * F * (F + 1)];      // layer l-1: W4^T | W_src^T | W_tgt^T
+    __shared__ float w45[3 * F * F];            // layer l-1: W4 | W5 row-major
+    float* W4T = wts;
+    float* WaT = wts + 2 * F * (F + 1);
+    float* WbT = WaT + F * (F + 1);
+    const int slot = threadIdx.x / G, f = threadIdx.x % G;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    {
+        const MapT<F> m4{2 * F, 2 * F};
+        const MapW1T<F, H, A> ma{0}, mb{F};
+        Staged<2 * F * F> sg, s4, c4;
+        Staged<F * F> sa, sb, c5;
+        sg.load(lw_g, 2 * F * F, [](int t) { const int o = t / (2 * F); return LL::w1_off(o, t - o * 2 * F); });
+        s4.load(lw_n + LL::w4, 2 * F * F, [=](int t) { return m4.src(t); });
+        sa.load(lw_n, F * F, [=](int t) { return ma.src(t); });
+        sb.load(lw_n, F * F, [=](int t) { return mb.src(t); });
+        c4.load(lw_n + LL::w4, 2 * F * F, [](int t) { return t; });
+        c5.load(lw_n + LL::w5, F * F, [](int t) { return t; });
+        sg.store(w1, 2 * F * F, [](int t) { return t; });
+        s4.store(W4T, 2 * F * F, [=](int t) { return m4.dst(t); });
+        sa.store(WaT, F * F, [=](int t) { return ma.dst(t); });
+        sb.store(WbT, F * F, [=](int t) { return mb.dst(t); });
+        c4.store(w45, 2 * F * F, [](int t) { return t; });
+        c5.store(w45 + 2 * F * F, F * F, [](int t) { return t; });
+    }
+    const float* W4 = w45;
+    const float* W5 = w45 + 2 * F * F;
+    MfmaOuter moG, moN;
+    float mb1 = 0.0f, mb4 = 0.0f, mb5 = 0.0f;
+    moG.init(); moN.init();
+    const int groups = (n_nodes + NS - 1) / NS;
+    for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int j = grp * NS + slot;
+        const bool live = j < n_nodes;
+        float dpr = 0.0f, dpc = 0.0f, hn = 0.0f, an = 0.0f, dres = 0.0f;
+        __syncthreads();
+        if (live) {
+            const int rlo = rptr[j], rhi = rptr[j + 1], clo = cptr[j], chi = cptr[j + 1];
+            float gx = (f < 3) ? Gx[(size_t)j * 4 + f] : 0.0f;
+            hn = h_n[(size_t)j * FP + f];              // layer l-1 inputs: in flight with the gather
+            an = agg_n[(size_t)j * FP + f];
+            dres = dh_part[(size_t)j * FP + f];
+            const float hg = h_g[(size_t)j * FP + f];
+            float gx_r = 0.0f, gx_c = 0.0f;
+            gather_pair32(rperm, rlo, rhi, cperm, clo, chi, dt1, gxr, gxc, f, dpr, dpc, gx_r, gx_c);
+            if (f < 3) { gx += gx_r; gx += gx_c; Gx_new[(size_t)j * 4 + f] = gx; }
+            hv[slot][f] = hg;
+            prv[slot][f] = dpr;
+            pcv[slot][f] = dpc;
+        }
+        __syncthreads();
+        float gh = 0.0f;
+        if (live) {
+            gh = dres;
+            for (int o = 0; o < F; ++o) {
+                gh = fmaf(prv[slot][o], w1[o * 2 * F + f], gh);
+                gh = fmaf(pcv[slot][o], w1[o * 2 * F + F + f], gh);
+            }
+            ghv[slot][f] = gh;
+            vin[slot][f] = hn;
+            vin[slot][F + f] = an;
+        }
+        const int ns = min(NS, n_nodes - grp * NS);
+        if (wv == 2) moG.add(&prv[0][0], FP, &hv[0][0], FP, ns, lane);
+        else if (wv == 3) moG.add(&pcv[0][0], FP, &hv[0][0], FP, ns, lane);
+        else if (wv == 0 && lane < 32) {
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+                if (n < ns) mb1 += pcv[n][lane];
+        }
+        __syncthreads();
+        float v = 0.0f;
+        if (live) {
+            v = lw_n[LL::b4 + f] + col_dot<F>(W4T, f, vin[slot], 2 * F);
+            hid[slot][f] = silu(v);
+            float dg = 0.0f;
+            for (int o = 0; o < F; ++o) dg = fmaf(ghv[slot][o], W5[o * F + f], dg);
+            dvv[slot][f] = dg * silu_grad(v);
+            project_pre<F, H, A>(lw_n, WaT, WbT, vin[slot], f, P + (size_t)j * PS);
+        }
+        __syncthreads();
+        if (live) {
+            float d_h = 0.0f, d_a = 0.0f;
+            for (int o = 0; o < F; ++o) {
+                const float d = dvv[slot][o];
+                d_h = fmaf(d, W4[o * 2 * F + f], d_h);
+                d_a = fmaf(d, W4[o * 2 * F + F + f], d_a);
+            }
+            dh_part[(size_t)j * FP + f] = gh + d_h;
+            dagg[(size_t)j * FP + f] = d_a;
+        }
+        if (wv < 2) moN.add(&dvv[0][0], FP, &vin[0][0] + 32 * wv, 2 * FP, ns, lane);
+        else if (wv == 2) moN.add(&ghv[0][0], FP, &hid[0][0], FP, ns, lane);
+        else {
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+                if (n < ns) { mb4 += (lane < 32) ? dvv[n][lane & 31] : 0.0f; mb5 += (lane >= 32) ? ghv[n][lane & 31] : 0.0f; }
+        }
+    }
+    float* myg = gat_slab + (size_t)blockIdx.x * SB::gather;
+    if (wv >= 2) moG.store(myg + (wv - 2) * F * F, F, lane);
+    else if (wv == 0 && lane < 32) myg[2 * F * F + lane] = mb1;
+    float* myn = node_slab + (size_t)blockIdx.x * SB::node;
+    if (wv < 2) moN.store(myn + 32 * wv, 2 * F, lane);
+    else if (wv == 2) moN.store(myn + F * 2 * F + F, F, lane);
+    else if (lane < 32) myn[F * 2 * F + lane] = mb4;
+    else myn[F * 2 * F + F + F * F + (lane - 32)] = mb5;
+}
+
+// ---------------------------------------------------------------------------------------
 // edge backward
 // ---------------------------------------------------------------------------------------
 // One pass over a wave-private pair of LDS tiles X[64][LD], Y[64][LD] (row = edge of the chunk):
@@ -1097,22 +1230,38 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
     // embedding_out
     hipLaunchKernelGGL((embed_out_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_out, cfg->out_nf, gh_out,
                        gx_out, hs + (size_t)L * N * FP, N, Gh, Gx, work + B.emb_slab);
+    auto slab_of = [&](int l) { return (size_t)l * B.layer_stride; };
+    auto launch_node_bwd = [&](int l) {
+        hipLaunchKernelGGL((node_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, params + ML.layer0 + (size_t)l * ML.layer_size,
+                           work + B.Gh[cur], hs + (size_t)l * N * FP, aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg,
+                           work + B.P, work + B.node_slab + slab_of(l));
+    };
+    constexpr bool kFuse = (F == 32);                      // gather_bwd(l) + node_bwd(l-1) in one kernel
+    if (kFuse) launch_node_bwd(L - 1);
     for (int l = L - 1; l >= 0; --l) {
-        const size_t so = (size_t)l * B.layer_stride;                 // this layer's slab set
         const float* lw = params + ML.layer0 + (size_t)l * ML.layer_size;
         const float* h_l = hs + (size_t)l * N * FP;
         const float* x_l = xs + (size_t)l * N * 3;
-        hipLaunchKernelGGL((node_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, work + B.Gh[cur], h_l,
-                           aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg, work + B.P, work + B.node_slab + so);
+        if (!kFuse) launch_node_bwd(l);
         if (E > 0) {
             const int rc = launch_edge_bwd<F, H, A>(lw, g, edge_attr, x_l, work + B.P, work + B.dagg, work + B.Gx[cur],
-                                                    work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab + so, s, &egrid);
+                                                    work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab + slab_of(l), s, &egrid);
             if (rc) return rc;
         }
         const int nxt = cur ^ 1;
+        if constexpr (kFuse) {
+            if (l > 0) {
+                hipLaunchKernelGGL((gather_node_bwd_kernel<H, A>), dim3(ngrid), dim3(256), 0, s, lw, lw - ML.layer_size, g->rptr, g->rperm,
+                                   g->cptr, g->cperm, work + B.dt1, work + B.gxr, work + B.gxc, work + B.Gx[cur], h_l,
+                                   hs + (size_t)(l - 1) * N * FP, aggs + (size_t)(l - 1) * N * FP, N, work + B.dh_part, work + B.dagg,
+                                   work + B.P, work + B.Gx[nxt], work + B.gat_slab + slab_of(l), work + B.node_slab + slab_of(l - 1));
+                cur = nxt;
+                continue;
+            }
+        }
         hipLaunchKernelGGL((gather_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, g->rptr, g->rperm, g->cptr,
                            g->cperm, work + B.dt1, work + B.gxr, work + B.gxc, work + B.dh_part, work + B.Gx[cur], h_l, N,
-                           work + B.Gh[nxt], work + B.Gx[nxt], (l == 0) ? grad_x_in : nullptr, work + B.gat_slab + so);
+                           work + B.Gh[nxt], work + B.Gx[nxt], (l == 0) ? grad_x_in : nullptr, work + B.gat_slab + slab_of(l));
         cur = nxt;
     }
     hipLaunchKernelGGL((embed_in_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_in, cfg->in_nf,
