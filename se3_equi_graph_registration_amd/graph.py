@@ -48,7 +48,7 @@ def get_edges_batch(graph_idx, n_nodes: int, batch_size: int):
 def build_pair_graph(xyz_src: torch.Tensor, xyz_tgt: torch.Tensor, k: int, loop: bool = True,
                      need_col_index: bool = True) -> DeviceGraph:
     """``xyz_* [B,N,3]`` -> one DeviceGraph over the 2B clouds ``[src_0..src_B-1, tgt_0..tgt_B-1]``."""
-    x = torch.cat([xyz_src, xyz_tgt], dim=0).contiguous().float()
+    x = ops.cat_or_view(xyz_src.float(), xyz_tgt.float()).contiguous()     # a view when src/tgt are halves of one tensor
     nc, n, _ = x.shape
     _, r32, c32 = ops.knn_graph_batched(x, k, loop, want_i64=False, want_i32=True)
     return DeviceGraph(r32, c32, nc * n, knn_k=k, need_col_index=need_col_index)

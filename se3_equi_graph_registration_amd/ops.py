@@ -51,6 +51,17 @@ def param_count(cfg: EgnnConfig) -> int:
     return int(_lib.lib().equigspr_egnn_param_count(ctypes.byref(cfg)))
 
 
+def cat_or_view(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``torch.cat([a, b], dim=0)`` -- without the copy when ``b`` already follows ``a`` in the same storage (e.g. the two
+    halves of one stacked ``[2, B, N, C]`` tensor): then the result is a view."""
+    if (a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.shape[1:] == b.shape[1:] and not a.requires_grad
+            and not b.requires_grad and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + a.numel()):
+        shape = (a.shape[0] + b.shape[0],) + tuple(a.shape[1:])
+        return a.as_strided(shape, a.stride())
+    return torch.cat([a, b], dim=0)
+
+
 # ----------------------------------------------------------------------------------- graph
 _KNN_COL_INDEX = {}
 
@@ -377,6 +388,7 @@ class _StepLossFn(torch.autograd.Function):
                                                          _stream()), "step_loss_forward")
         ctx.save_for_backward(R, t, gt)
         ctx.has_corr = corr_loss is not None
+        ctx.set_materialize_grads(False)              # no zero-filled grads for the two logging outputs
         rot, tr = out[1:1 + B], out[1 + B:]
         ctx.mark_non_differentiable(rot, tr)
         return out[0], rot, tr

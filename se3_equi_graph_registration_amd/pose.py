@@ -122,8 +122,8 @@ class CrossAttentionPoseRegression(nn.Module):
         else:
             lists = [edges_src[i] for i in range(B)] + [edges_tgt[i] for i in range(B)]
             graph = DeviceGraph.from_edge_lists(lists, N)
-        h_all = torch.cat([h_src.reshape(B * N, Fd), h_tgt.reshape(B * N, Fd)], dim=0)
-        x_all = torch.cat([x_src.reshape(B * N, 3), x_tgt.reshape(B * N, 3)], dim=0)
+        h_all = ops.cat_or_view(h_src.reshape(B * N, Fd), h_tgt.reshape(B * N, Fd))      # views when src/tgt share one buffer
+        x_all = ops.cat_or_view(x_src.reshape(B * N, 3), x_tgt.reshape(B * N, 3))
         if self.egnn.in_edge_nf == 0:
             ea = None
         elif ea_src is None:

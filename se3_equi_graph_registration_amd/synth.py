@@ -39,4 +39,9 @@ def synthetic_pair(seed: int, n: int = 2048, feat: int = 32, scale=(3.0, 3.0, 3.
 def synthetic_batch(first_seed: int, batch: int, n: int = 2048, feat: int = 32, scale=(3.0, 3.0, 3.0), device="cpu"):
     """Stack ``batch`` pairs (seeds first_seed .. first_seed+batch-1) into [B,...] tensors."""
     ps = [synthetic_pair(first_seed + b, n, feat, scale) for b in range(batch)]
-    return {k: torch.stack([p[k] for p in ps]).to(device) for k in ps[0]}
+    out = {k: torch.stack([p[k] for p in ps]).to(device) for k in ps[0]}
+    # source and target halves of ONE buffer each (a loader's natural layout): the package then concatenates by view
+    for a, b in (("src", "tgt"), ("feat_src", "feat_tgt")):
+        both = torch.stack([out[a], out[b]])
+        out[a], out[b] = both[0], both[1]
+    return out
