@@ -217,7 +217,9 @@ extern "C" int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n
     if (err != hipSuccess) { set_error("build_csr memset: %s", hipGetErrorString(err)); return (int)err; }
     if (n_edges > 0)
         hipLaunchKernelGGL(csr_count_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, key, n_edges, scratch);
-    hipLaunchKernelGGL(csr_scan_kernel<0>, dim3(1), dim3(1024), 0, s, scratch, n_nodes, ptr);
+    // large N: two-level scan; its chunk totals borrow the head of `perm`, which is only written by the fill below
+    const int chunks = ceil_div(n_nodes, kScanChunk);
+    launch_exclusive_scan(scratch, n_nodes, ptr, (n_edges >= chunks && chunks <= 1024) ? perm : nullptr, s);
     if (n_edges > 0) {
         hipLaunchKernelGGL(csr_fill_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, key, n_edges, scratch, perm);
         hipLaunchKernelGGL(csr_sort_kernel, dim3(ceil_div(n_nodes, 4)), dim3(256), 0, s, ptr, n_nodes, perm);

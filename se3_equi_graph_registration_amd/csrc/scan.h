@@ -1,4 +1,5 @@
-// Single-block exclusive scan of per-node counts (N <= a few 100k: one 1024-thread block is launch-latency sized).
+// Exclusive scan of per-node counts: one 1024-thread block for small N (launch-latency sized), a three-launch
+// two-level scan above kScanSingleBlockMax (the single block takes 135 us at N = 131 072).
 #pragma once
 #include "common.h"
 
@@ -30,6 +31,73 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int* __restrict__ cnt_cu
         run += c;
     }
     if (t == 1023) ptr[n] = part[1023];
+}
+
+constexpr int kScanSingleBlockMax = 16384;
+constexpr int kScanChunk = 4096;                 // elements per block of the two-level scan (4 per thread)
+
+// level 1: block b scans its chunk in place (exclusive, local) and writes the chunk total
+template <int kUnused = 0>
+__global__ __launch_bounds__(1024) void scan_chunks_kernel(int* __restrict__ cnt_cursor, int n, int* __restrict__ totals) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x, base = blockIdx.x * kScanChunk + 4 * t;
+    int v[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = (base + k < n) ? cnt_cursor[base + k] : 0; s += v[k]; }
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int a = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += a;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (base + k < n) cnt_cursor[base + k] = run;
+        run += v[k];
+    }
+    if (t == 1023) totals[blockIdx.x] = part[1023];
+}
+// level 2: one block scans the (<= 1024) chunk totals in place (exclusive) and publishes the grand total
+template <int kUnused = 0>
+__global__ __launch_bounds__(1024) void scan_totals_kernel(int* __restrict__ totals, int n_chunks, int* __restrict__ grand) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int v = (t < n_chunks) ? totals[t] : 0;
+    part[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int a = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += a;
+        __syncthreads();
+    }
+    if (t < n_chunks) totals[t] = part[t] - v;
+    if (t == 1023) *grand = part[1023];
+}
+// level 3: add the chunk offsets; ptr[i] = cursor[i] = global exclusive prefix
+template <int kUnused = 0>
+__global__ __launch_bounds__(1024) void scan_apply_kernel(int* __restrict__ cnt_cursor, int n, const int* __restrict__ totals,
+                                                          int* __restrict__ ptr) {
+    const int base = blockIdx.x * kScanChunk + 4 * threadIdx.x, off = totals[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (base + k < n) { const int x = cnt_cursor[base + k] + off; cnt_cursor[base + k] = x; ptr[base + k] = x; }
+}
+
+// cnt_cursor[0..n) counts -> exclusive prefixes in cnt_cursor and ptr, ptr[n] = total.  `totals`: >= ceil(n / 4096) ints of
+// scratch, needed only when n > kScanSingleBlockMax (n <= 4 M).
+static inline void launch_exclusive_scan(int* cnt_cursor, int n, int* ptr, int* totals, hipStream_t s) {
+    if (n <= kScanSingleBlockMax || totals == nullptr) {
+        hipLaunchKernelGGL(csr_scan_kernel<0>, dim3(1), dim3(1024), 0, s, cnt_cursor, n, ptr);
+        return;
+    }
+    const int chunks = (n + kScanChunk - 1) / kScanChunk;
+    hipLaunchKernelGGL(scan_chunks_kernel<0>, dim3(chunks), dim3(1024), 0, s, cnt_cursor, n, totals);
+    hipLaunchKernelGGL(scan_totals_kernel<0>, dim3(1), dim3(1024), 0, s, totals, chunks, ptr + n);
+    hipLaunchKernelGGL(scan_apply_kernel<0>, dim3(chunks), dim3(1024), 0, s, cnt_cursor, n, totals, ptr);
 }
 
 }  // namespace eq
