@@ -150,6 +150,11 @@ __global__ __launch_bounds__(256) void embed_out_bwd_kernel(const float* __restr
     OuterAcc<64, F> aW;          // rows = out feature (<= 64), cols = F
     VecAcc<64> ab;
     aW.init(); ab.init();
+    const bool use_mfma = (F == 32) && out_nf == 32;     // wave 0: the 32x32 outer products on the matrix cores; wave 1: db_out
+    MfmaOuter mo;
+    float mbo = 0.0f;
+    mo.init();
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int groups = (n_nodes + NS - 1) / NS;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int j = grp * NS + slot;
@@ -167,12 +172,26 @@ __global__ __launch_bounds__(256) void embed_out_bwd_kernel(const float* __restr
             Gh[(size_t)j * FP + f] = g;
         }
         const int ns = min(NS, n_nodes - grp * NS);
-        aW.add(&gho[0][0], 64, &hlv[0][0], FP, ns, F);
-        ab.add(&gho[0][0], 64, ns);
+        if (use_mfma) {
+            if (wv == 0) mo.add(&gho[0][0], 64, &hlv[0][0], FP, ns, lane);
+            else if (wv == 1 && lane < 32) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    if (n < ns) mbo += gho[n][lane];
+            }
+        } else {
+            aW.add(&gho[0][0], 64, &hlv[0][0], FP, ns, F);
+            ab.add(&gho[0][0], 64, ns);
+        }
     }
     float* my = slab + (size_t)blockIdx.x * (out_nf * F + out_nf);
-    aW.store(my, out_nf, F);
-    ab.store(my + out_nf * F, out_nf);
+    if (use_mfma) {
+        if (wv == 0) mo.store(my, F, lane);
+        else if (wv == 1 && lane < 32) my[out_nf * F + lane] = mbo;
+    } else {
+        aW.store(my, out_nf, F);
+        ab.store(my + out_nf * F, out_nf);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -192,6 +211,11 @@ __global__ __launch_bounds__(256) void embed_in_bwd_kernel(const float* __restri
     OuterAcc<G, 64> aW;          // rows = hidden feature, cols = in feature (<= 64)
     VecAcc<G> ab;
     aW.init(); ab.init();
+    const bool use_mfma = (F == 32) && in_nf == 32;      // wave 0: matrix cores; wave 1: db_in
+    MfmaOuter mo;
+    float mbi = 0.0f;
+    mo.init();
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int groups = (n_nodes + NS - 1) / NS;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int j = grp * NS + slot;
@@ -210,12 +234,26 @@ __global__ __launch_bounds__(256) void embed_in_bwd_kernel(const float* __restri
             }
         }
         const int ns = min(NS, n_nodes - grp * NS);
-        aW.add(&gv[0][0], FP, &vin[0][0], 64, ns, in_nf);
-        ab.add(&gv[0][0], FP, ns);
+        if (use_mfma) {
+            if (wv == 0) mo.add(&gv[0][0], FP, &vin[0][0], 64, ns, lane);
+            else if (wv == 1 && lane < 32) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    if (n < ns) mbi += gv[n][lane];
+            }
+        } else {
+            aW.add(&gv[0][0], FP, &vin[0][0], 64, ns, in_nf);
+            ab.add(&gv[0][0], FP, ns);
+        }
     }
     float* my = slab + (size_t)blockIdx.x * (F * in_nf + F);
-    aW.store(my, F, in_nf);
-    ab.store(my + F * in_nf, F);
+    if (use_mfma) {
+        if (wv == 0) mo.store(my, in_nf, lane);
+        else if (wv == 1 && lane < 32) my[F * in_nf + lane] = mbi;
+    } else {
+        aW.store(my, F, in_nf);
+        ab.store(my + F * in_nf, F);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
