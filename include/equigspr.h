@@ -271,6 +271,17 @@ int equigspr_pointnet_layer_forward(const float* h, const float* pos, int32_t n_
 int equigspr_global_max_pool(const float* x, const int64_t* batch_sorted, int32_t n_nodes, int32_t channels,
                              int32_t n_batches, float* out, void* stream);
 
+/* ---- N3: correspondence construction (data_preprocess/3DMatch_Feature.py:157-196, test split :331-351) ----------
+ * nearest_idx[i] = argmin_j sqrt(2 - 2 <src_desc_i, tgt_desc_j> + 1e-6) (first minimum, as np.argmin; unit-norm descriptors),
+ * nearest_dist[i] (optional) that minimum; fused MFMA dot products + running argmin, the N x M matrix is never stored.
+ * src_desc [n_src, dim], tgt_desc [n_tgt, dim], dim <= 64.  Call it with the roles swapped for the mutual check. */
+int equigspr_match_descriptors(const float* src_desc, int32_t n_src, const float* tgt_desc, int32_t n_tgt, int32_t dim,
+                               int64_t* nearest_idx, float* nearest_dist, void* stream);
+/* labels[c] = || R_gt src_pts[corr[c][0]] + t_gt - tgt_pts[corr[c][1]] || < inlier_threshold  (:186-190);
+ * corr int64 [n_corr, 2], gt_pose row-major 4x4, labels int32 [n_corr], dist (optional) float [n_corr]. */
+int equigspr_correspondence_labels(const float* src_pts, const float* tgt_pts, const int64_t* corr, int32_t n_corr,
+                                   const float* gt_pose, float inlier_threshold, int32_t* labels, float* dist, void* stream);
+
 /* ---- measurement hooks (bench.py's roofline leg; NOT part of the drop-in path) -----------
  * Average duration in ms (written to HOST memory) of the EGNN message-passing edge kernel,
  * measured with HIP events on `stream` over `iters` back-to-back launches (these two calls

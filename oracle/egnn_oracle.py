@@ -345,6 +345,30 @@ def pointnet_forward(w: Dict[str, Tensor], pos: Tensor, feats: Tensor, edge_inde
 
 
 # --------------------------------------------------------------------------------------
+# N3: correspondence construction (data_preprocess/3DMatch_Feature.py:157-196; test split :331-351)
+# PARITY UNPINNED: the reference code is script-level numpy inside a function that needs open3d and the raw dataset, so it
+# cannot be imported for golden vectors; the lines are restated verbatim here.
+# --------------------------------------------------------------------------------------
+def build_correspondences(src_desc, tgt_desc, src_keypts, tgt_keypts, gt_pose, use_mutual=False, inlier_threshold=0.10):
+    import numpy as np
+    distance = np.sqrt(2 - 2 * (src_desc @ tgt_desc.T) + 1e-6)                                   # :157
+    source_idx = np.argmin(distance, axis=1)
+    source_dis = np.min(distance, axis=1)
+    if use_mutual:                                                                               # :160-163
+        target_idx = np.argmin(distance, axis=0)
+        mutual_nearest = (target_idx[source_idx] == np.arange(source_idx.shape[0]))
+        corr = np.concatenate([np.where(mutual_nearest == 1)[0][:, None], source_idx[mutual_nearest][:, None]], axis=-1)
+    else:
+        corr = np.concatenate([np.arange(source_idx.shape[0])[:, None], source_idx[:, None]], axis=-1)
+    frag1 = src_keypts[corr[:, 0]]                                                               # :186-190
+    frag2 = tgt_keypts[corr[:, 1]]
+    frag1_warp = frag1 @ gt_pose[:3, :3].T + gt_pose[:3, 3]                                      # transform(): R @ pts + t
+    dist = np.sqrt(np.sum(np.power(frag1_warp - frag2, 2), axis=1))
+    labels = (dist < inlier_threshold).astype(np.int32)
+    return corr, labels, source_dis, distance
+
+
+# --------------------------------------------------------------------------------------
 # N2: evaluation metrics (tools/evaluation_metrics.py:14-43, eval loop eval :1245-1296)
 # --------------------------------------------------------------------------------------
 def eval_metrics(gt_pose, pred_pose, src_pts, tgt_pts, tau: float = 0.09):

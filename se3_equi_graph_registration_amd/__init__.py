@@ -14,6 +14,7 @@ from .pose import (CrossAttentionPoseRegression, pose_loss, registration_loss, c
 from .synth import synthetic_pair, synthetic_batch  # noqa: F401
 from . import pose  # noqa: F401
 from .so3 import SO3TensorProductLayer  # noqa: F401
+from .correspondences import match_descriptors, build_correspondences  # noqa: F401
 from .pointnet import PointNetLayer, PointNet, global_max_pool  # noqa: F401
 from .metrics import evaluate_batch, calculate_pose_error, registration_recall  # noqa: F401
 from . import sh  # noqa: F401  (A16: spherical harmonics / irrep basis)

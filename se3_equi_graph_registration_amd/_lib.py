@@ -70,6 +70,8 @@ _SIGNATURES = {
     "equigspr_global_max_pool": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "equigspr_step_loss_forward": (ctypes.c_int, [c_void_p] * 4 + [c_int32] + [c_void_p] * 4),
     "equigspr_step_loss_backward": (ctypes.c_int, [c_void_p] * 4 + [c_int32] + [c_void_p] * 3),
+    "equigspr_match_descriptors": (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "equigspr_correspondence_labels": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, ctypes.c_float, c_void_p, c_void_p, c_void_p]),
     "equigspr_kabsch_forward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                                c_void_p, c_void_p]),
     "equigspr_kabsch_backward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

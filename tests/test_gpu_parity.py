@@ -678,3 +678,42 @@ def test_pointnet_reference_call_shape(pk):
     ref32, _ = orc.pointnet_forward({kk: v.float() for kk, v in w64.items()}, flat, flat, ei.cpu(), batch)
     assert enc.shape == (b, n, 32)
     assert np.abs(enc.reshape(b * n, -1).cpu().numpy() - ref64.numpy()).max() <= anchored_tol(ref32.numpy(), ref64.numpy())
+
+
+# ------------------------------------------------------------------------------------------------
+# N3: descriptor matching + correspondence labels (data_preprocess/3DMatch_Feature.py:157-196)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,m,dim,mutual", [(2048, 2048, 32, False), (2048, 2048, 33, True), (1000, 777, 33, True), (5, 3, 7, False)])
+def test_build_correspondences_vs_oracle(pk, n, m, dim, mutual):
+    rng = np.random.default_rng(n + m + dim)
+    src_desc = rng.standard_normal((n, dim)).astype(np.float32)
+    src_desc /= np.linalg.norm(src_desc, axis=1, keepdims=True)
+    tgt_desc = rng.standard_normal((m, dim)).astype(np.float32)
+    k = min(n, m) // 2
+    tgt_desc[:k] = src_desc[rng.permutation(n)[:k]] + 0.05 * rng.standard_normal((k, dim)).astype(np.float32)   # true matches
+    tgt_desc /= np.linalg.norm(tgt_desc, axis=1, keepdims=True)
+    src_pts = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    pose = np.eye(4, dtype=np.float32)
+    th = 0.7
+    pose[:3, :3] = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]], dtype=np.float32)
+    pose[:3, 3] = (0.3, -0.2, 0.5)
+    tgt_pts = rng.uniform(-1, 1, (m, 3)).astype(np.float32)
+    corr_o, labels_o, dis_o, dmat = orc.build_correspondences(src_desc, tgt_desc, src_pts, tgt_pts, pose, mutual, 0.10)
+    # make a known fraction of the oracle's matches geometric inliers, then recompute
+    sel = corr_o[: max(1, corr_o.shape[0] // 2)]
+    tgt_pts[sel[:, 1]] = src_pts[sel[:, 0]] @ pose[:3, :3].T + pose[:3, 3] + 0.01 * rng.standard_normal((sel.shape[0], 3)).astype(np.float32)
+    corr_o, labels_o, dis_o, dmat = orc.build_correspondences(src_desc, tgt_desc, src_pts, tgt_pts, pose, mutual, 0.10)
+    t = lambda a: torch.from_numpy(a).cuda()
+    corr, labels, dis = pk.build_correspondences(t(src_desc), t(tgt_desc), t(src_pts), t(tgt_pts), t(pose), use_mutual=mutual,
+                                                 inlier_threshold=0.10)
+    # index parity is exact wherever the best and second-best distances differ by more than fp32 round-off of the dot product
+    part = np.partition(dmat, 1, axis=1)[:, :2] if m > 1 else None
+    clear_rows = (part[:, 1] - part[:, 0]) > 1e-5
+    idx, _ = pk.match_descriptors(t(src_desc), t(tgt_desc))
+    assert clear_rows.mean() > 0.99
+    assert np.array_equal(idx.cpu().numpy()[clear_rows], np.argmin(dmat, axis=1)[clear_rows])
+    assert np.abs(dis.cpu().numpy() - dis_o).max() <= 2e-4            # sqrt amplifies dot round-off near distance 0
+    if clear_rows.all() and (not mutual or ((np.partition(dmat, 1, axis=0)[1] - np.partition(dmat, 1, axis=0)[0]) > 1e-5).all()):
+        assert np.array_equal(corr.cpu().numpy(), corr_o)
+        assert np.array_equal(labels.cpu().numpy(), labels_o)
+        assert 0 < labels_o.sum() < labels_o.size or n < 10
