@@ -629,6 +629,24 @@ __device__ __forceinline__ void tile_pass(const float* X, const float* Y, f32x16
     }
 }
 
+// hidden_nf in (32, 64): a second 32-block would hold one live row/column (feature 32).  Instead of 2x2 padded MFMA blocks
+// (4x the matrix work and 192 accumulator registers) only the 32x32 core goes through the matrix cores; column sums still
+// cover both blocks, and the 33rd row/column of each weight gradient comes from column sums of row-scaled copies
+// (border_pass below).
+template <int LD, bool kMfma, bool kY2>
+__device__ __forceinline__ void tile_pass_core(const float* X, const float* Y, f32x16& acc, float (&csx)[2], float (&csy)[2], int lane) {
+    const int f = lane & 31, hh = lane >> 5;
+#pragma unroll 2
+    for (int s = 0; s < 32; ++s) {
+        const int e = 2 * s + hh;
+        const float a0 = X[e * LD + f], a1 = (f == 0) ? X[e * LD + 32] : 0.0f;     // block 1 = feature 32 only (LD = 35)
+        const float b0 = Y[e * LD + f];
+        csx[0] += a0; csx[1] += a1; csy[0] += b0;
+        if (kY2) csy[1] += (f == 0) ? Y[e * LD + 32] : 0.0f;
+        if (kMfma) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+    }
+}
+
 template <int F, int H, int A>
 __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__ lw_in, const int* __restrict__ row,
                                                        const int* __restrict__ col, const float* __restrict__ edge_attr,
@@ -641,31 +659,32 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__
     using SB = Slabs<F>;
     constexpr int FP = Geom<F>::FP, PS = Geom<F>::PS, FH = F / H;
     constexpr int NB = (F + 31) / 32;
-    constexpr int LD = NB * 32 + 1;
+    constexpr int LD = 35;                            // 33 live columns (feature 32 = "block 1"), odd stride
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* X = smem + (size_t)wave * 2 * 64 * LD;
+    float* tiles = smem;
+    float* X = tiles + (size_t)wave * 2 * 64 * LD;
     float* Y = X + 64 * LD;
 
-    f32x16 acc6[NB][NB], acc2[NB][NB], accg[NB][1], accn[NB][1];
-    float cs_b6[NB], cs_b2[NB], cs_gam[NB], cs_bet[NB], cs_w7[NB], cs_scr[NB], cs_scr1[1];
+    static_assert(NB == 2, "the generic edge backward serves hidden_nf in (32, 64); hidden_nf == 32 has the MFMA kernel");
+    f32x16 acc6, acc2, accg;                         // 32x32 cores (accg: 32x16)
+    float cs_b6[NB], cs_b2[NB], cs_gam[NB], cs_bet[NB], cs_w7[NB], cs_scr[NB], cs_scr2[NB];
+    float bc6[NB], br6[NB], bc2[NB], br2[NB], brg[NB];   // border columns (o = f + 32 rb incl. the corner) / border rows of dW6, dW2, dWgeo
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc6[r] = 0.0f; acc2[r] = 0.0f; accg[r] = 0.0f; }
 #pragma unroll
     for (int rb = 0; rb < NB; ++rb) {
-#pragma unroll
-        for (int cb = 0; cb < NB; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc6[rb][cb][r] = 0.0f; acc2[rb][cb][r] = 0.0f; }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { accg[rb][0][r] = 0.0f; accn[rb][0][r] = 0.0f; }
-        cs_b6[rb] = cs_b2[rb] = cs_gam[rb] = cs_bet[rb] = cs_w7[rb] = cs_scr[rb] = 0.0f;
+        cs_b6[rb] = cs_b2[rb] = cs_gam[rb] = cs_bet[rb] = cs_w7[rb] = cs_scr[rb] = cs_scr2[rb] = 0.0f;
+        bc6[rb] = br6[rb] = bc2[rb] = br2[rb] = brg[rb] = 0.0f;
     }
-    cs_scr1[0] = 0.0f;
 
     const int chunks = (n_edges + 255) / 256;
     const float* lw_base = lw_in;
     for (int ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
         // Re-materialise the weight pointer every chunk: without this the compiler hoists ALL ~4.6k
         // wave-uniform weight loads out of the loop and spills them (v_writelane/v_readlane storm).
+        // (Tried: the layer block in LDS -- read as uniform values it is scalarised and spills 1 700 SGPRs, read per lane it
+        // spills 160 VGPRs; neither beats the scalar loads.)
         const float* lw = lw_base;
         asm volatile("" : "+s"(lw));
         const int e_raw = ch * 256 + threadIdx.x;
@@ -696,7 +715,16 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__
             Y[lane * LD + o] = m[o];
         }
         __builtin_amdgcn_wave_barrier();
-        tile_pass<NB, NB, LD, true>(X, Y, acc6, cs_b6, cs_scr, lane);          // dW6 += dq^T m ; db6 += sum dq
+        tile_pass_core<LD, true, false>(X, Y, acc6, cs_b6, cs_scr, lane);      // dW6 core += dq^T m ; db6 += sum dq
+        __builtin_amdgcn_wave_barrier();
+        // borders of dW6: column 32 = sum_e dq[e][o] m[e][32], row 32 = sum_e dq[e][32] m[e][i]
+#pragma unroll
+        for (int o = 0; o < F; ++o) {
+            X[lane * LD + o] = dq[o] * m[F - 1];
+            Y[lane * LD + o] = (o < F - 1) ? dq[F - 1] * m[o] : 0.0f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        tile_pass_core<LD, false, false>(X, Y, acc6, bc6, br6, lane);
         __builtin_amdgcn_wave_barrier();
         // ---- dm = dagg[row] + W6^T dq
         float dm[F];
@@ -723,7 +751,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__
             Y[lane * LD + o] = dm[o] * xhat[o];
         }
         __builtin_amdgcn_wave_barrier();
-        tile_pass<NB, NB, LD, false>(X, Y, acc6, cs_w7, cs_gam, lane);
+        tile_pass_core<LD, false, true>(X, Y, acc6, cs_w7, cs_gam, lane);
         __builtin_amdgcn_wave_barrier();
         // ---- LayerNorm backward
         float du[F];
@@ -748,7 +776,18 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__
             Y[lane * LD + o] = silu(t1[o]);
         }
         __builtin_amdgcn_wave_barrier();
-        tile_pass<NB, NB, LD, true>(X, Y, acc2, cs_b2, cs_scr, lane);
+        tile_pass_core<LD, true, false>(X, Y, acc2, cs_b2, cs_scr, lane);
+        __builtin_amdgcn_wave_barrier();
+        {   // borders of dW2 (H == 1 for hidden_nf == 33: W2 is one dense block)
+            const float g32 = silu(t1[F - 1]);
+#pragma unroll
+            for (int o = 0; o < F; ++o) {
+                X[lane * LD + o] = du[o] * g32;
+                Y[lane * LD + o] = (o < F - 1) ? du[F - 1] * silu(t1[o]) : 0.0f;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        tile_pass_core<LD, false, false>(X, Y, acc2, bc2, br2, lane);
         __builtin_amdgcn_wave_barrier();
         // ---- dt1 = (W2^T du) * silu'(t1)
         float dt1[F];
@@ -770,12 +809,15 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__
         Y[lane * LD + kGeo] = attr;
         Y[lane * LD + kGeo + 1] = 0.0f; Y[lane * LD + kGeo + 2] = 0.0f; Y[lane * LD + kGeo + 3] = 0.0f;
         __builtin_amdgcn_wave_barrier();
-        tile_pass<NB, 1, LD, true>(X, Y, accg, cs_scr, cs_scr1, lane);
+        tile_pass_core<LD, true, false>(X, Y, accg, cs_scr, cs_scr2, lane);    // dWgeo core (rows 0..31) += dt1^T [geo, attr]
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int o = 0; o < F; ++o) X[lane * LD + o] = dm[o];
+#pragma unroll
+        for (int gI = 0; gI < kGeo; ++gI) Y[lane * LD + gI] = dt1[F - 1] * eg.g[gI];      // row 32 of dWgeo
+        Y[lane * LD + kGeo] = dt1[F - 1] * attr;
         __builtin_amdgcn_wave_barrier();
-        tile_pass<NB, 1, LD, false>(X, Y, accn, cs_bet, cs_scr1, lane);
+        tile_pass_core<LD, false, false>(X, Y, accg, cs_bet, brg, lane);        // dbeta = sum dm ; dWgeo[32][:]
         __builtin_amdgcn_wave_barrier();
         // ---- geometry backward
         float gg[kGeo];
@@ -806,7 +848,7 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__
     }
 
     // ---- block reduction of the 4 waves' partials into one slab (fixed order) ----------------
-    float* sl = smem;      // aliases the tiles: every wave is past its last tile read after the barrier
+    float* sl = tiles;     // aliases the tiles: every wave is past its last tile read after the barrier
     const int f = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int rb = 0; rb < NB; ++rb) {          // fold the two edge-parity halves of the column sums
@@ -815,40 +857,41 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__
         cs_gam[rb] += __shfl_xor(cs_gam[rb], 32, 64);
         cs_bet[rb] += __shfl_xor(cs_bet[rb], 32, 64);
         cs_w7[rb] += __shfl_xor(cs_w7[rb], 32, 64);
+        bc6[rb] += __shfl_xor(bc6[rb], 32, 64);
+        bc2[rb] += __shfl_xor(bc2[rb], 32, 64);
     }
+    br6[0] += __shfl_xor(br6[0], 32, 64);
+    br2[0] += __shfl_xor(br2[0], 32, 64);
+    brg[0] += __shfl_xor(brg[0], 32, 64);
     for (int w = 0; w < 4; ++w) {
         __syncthreads();
         if (wave == w) {
             const bool first = (w == 0);
+            auto put = [&](int idx, float v) { sl[idx] = (first ? 0.0f : sl[idx]) + v; };
 #pragma unroll
-            for (int rb = 0; rb < NB; ++rb) {
+            for (int r = 0; r < 16; ++r) {       // 32x32 cores
+                const int orow = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                put(SB::e_w2 + orow * F + f, acc2[r]);
+                put(SB::e_w6 + orow * F + f, acc6[r]);
+                if (f < 16) put(SB::e_geo + orow * 16 + f, accg[r]);
+            }
+            if (hh == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int orow = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (orow < F) {
-#pragma unroll
-                        for (int cb = 0; cb < NB; ++cb) {
-                            const int ocol = cb * 32 + f;
-                            if (ocol < F) {
-                                const int i2 = SB::e_w2 + orow * F + ocol, i6 = SB::e_w6 + orow * F + ocol;
-                                sl[i2] = (first ? 0.0f : sl[i2]) + acc2[rb][cb][r];
-                                sl[i6] = (first ? 0.0f : sl[i6]) + acc6[rb][cb][r];
-                            }
-                        }
-                        if (f < 16) {
-                            const int ig = SB::e_geo + orow * 16 + f;
-                            sl[ig] = (first ? 0.0f : sl[ig]) + accg[rb][0][r];
-                        }
+                for (int rb = 0; rb < NB; ++rb) {
+                    const int ccol = rb * 32 + f;
+                    if (ccol < F) {
+                        put(SB::e_b2 + ccol, cs_b2[rb]);
+                        put(SB::e_b6 + ccol, cs_b6[rb]);
+                        put(SB::e_gam + ccol, cs_gam[rb]);
+                        put(SB::e_bet + ccol, cs_bet[rb]);
+                        put(SB::e_w7 + ccol, cs_w7[rb]);
+                        put(SB::e_w2 + ccol * F + (F - 1), bc2[rb]);       // column 32 (incl. the corner at ccol == 32)
+                        put(SB::e_w6 + ccol * F + (F - 1), bc6[rb]);
                     }
                 }
-                const int ccol = rb * 32 + f;
-                if (hh == 0 && ccol < F) {
-                    sl[SB::e_b2 + ccol] = (first ? 0.0f : sl[SB::e_b2 + ccol]) + cs_b2[rb];
-                    sl[SB::e_b6 + ccol] = (first ? 0.0f : sl[SB::e_b6 + ccol]) + cs_b6[rb];
-                    sl[SB::e_gam + ccol] = (first ? 0.0f : sl[SB::e_gam + ccol]) + cs_gam[rb];
-                    sl[SB::e_bet + ccol] = (first ? 0.0f : sl[SB::e_bet + ccol]) + cs_bet[rb];
-                    sl[SB::e_w7 + ccol] = (first ? 0.0f : sl[SB::e_w7 + ccol]) + cs_w7[rb];
-                }
+                put(SB::e_w2 + (F - 1) * F + f, br2[0]);                    // row 32, columns 0..31
+                put(SB::e_w6 + (F - 1) * F + f, br6[0]);
+                if (f < 16) put(SB::e_geo + (F - 1) * 16 + f, brg[0]);
             }
         }
     }
@@ -1099,7 +1142,7 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
                            dagg, Gx, E, dt1, gxr, gxc, slab);
         *n_slabs = blocks;
     } else {
-        constexpr int NB = (F + 31) / 32, LD = NB * 32 + 1;
+        constexpr int LD = 35;
         const int chunks = ceil_div(E, 256);
         const int egrid = chunks < kEdgeBwdBlocks ? chunks : kEdgeBwdBlocks;
         const size_t edge_smem = sizeof(float) * (size_t)4 * 2 * 64 * LD;
