@@ -80,7 +80,8 @@ __device__ __forceinline__ void stage_tile_weights(float* sm, const float* __res
 template <int H, int A, bool kCached = false>
 struct TileWeights {
     using T = TileWeightsLds;
-    const float* sm;
+    const float* base;     // the workgroup's LDS image (address space known to the compiler: ds_read, not flat_load)
+    const float* sm;       // base + an opaque zero offset (refresh()): keeps the reads inside the tile loop
     int i, h;
     float c_wg[kCached ? 7 : 1], c_w2[kCached ? 16 : 1], c_w6[kCached ? 16 : 1], c_vec[kCached ? 80 : 1];
     float c_w6t[kCached ? 16 : 1], c_w2t[kCached ? 16 : 1], c_wgt[kCached ? 16 : 1];
@@ -92,7 +93,7 @@ struct TileWeights {
     __device__ __forceinline__ float l_w2t(int s) const { return sm[T::o_w2 + fidx(s, h) * T::WS + i]; }
     __device__ __forceinline__ float l_wgt(int s) const { return (i < kGeo) ? sm[T::o_geo + fidx(s, h) * T::GS + i] : 0.0f; }
     __device__ __forceinline__ void load(const float* s_, int lane) {
-        sm = s_; i = lane & 31; h = lane >> 5;
+        base = s_; sm = s_; i = lane & 31; h = lane >> 5;
         if (kCached) {
 #pragma unroll
             for (int s = 0; s < 7; ++s) c_wg[kCached ? s : 0] = l_wg(s);
@@ -105,7 +106,13 @@ struct TileWeights {
             }
         }
     }
-    __device__ __forceinline__ void refresh() { if (!kCached) asm volatile("" : "+v"(sm)); }
+    __device__ __forceinline__ void refresh() {
+        if (!kCached) {
+            int off = 0;
+            asm volatile("" : "+v"(off));          // laundering the POINTER would lose its address space (flat loads)
+            sm = base + off;
+        }
+    }
     __device__ __forceinline__ float wg(int s) const { return kCached ? c_wg[kCached ? s : 0] : l_wg(s); }
     __device__ __forceinline__ float w2(int s) const { return kCached ? c_w2[kCached ? s : 0] : l_w2(s); }
     __device__ __forceinline__ float w6(int s) const { return kCached ? c_w6[kCached ? s : 0] : l_w6(s); }
