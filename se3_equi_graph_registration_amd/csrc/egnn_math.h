@@ -30,7 +30,6 @@ struct EdgeGeo {
     bool  degenerate; // frame replaced by identity (:152-163)
 };
 
-EQ_HD float silu(float v) { return v / (1.0f + expf(-v)); }
 // sigmoid with the hardware reciprocal (v_rcp_f32, <= 1 ulp) instead of the ~10-instruction IEEE division
 // sequence; used by the MFMA edge kernels where SiLU / SiLU' are a third of the vector work.
 EQ_HD float sigmoid_fast(float v) {
@@ -42,9 +41,10 @@ EQ_HD float sigmoid_fast(float v) {
     return 1.0f / (1.0f + expf(-v));
 #endif
 }
+EQ_HD float silu(float v) { return v * sigmoid_fast(v); }
 // d/dv silu(v) = s(v) * (1 + v * (1 - s(v)))
 EQ_HD float silu_grad(float v) {
-    float s = 1.0f / (1.0f + expf(-v));
+    const float s = sigmoid_fast(v);
     return s * (1.0f + v * (1.0f - s));
 }
 
