@@ -685,8 +685,9 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__
         // wave-uniform weight loads out of the loop and spills them (v_writelane/v_readlane storm).
         // (Tried: the layer block in LDS -- read as uniform values it is scalarised and spills 1 700 SGPRs, read per lane it
         // spills 160 VGPRs; neither beats the scalar loads.)
-        const float* lw = lw_base;
-        asm volatile("" : "+s"(lw));
+        int zoff = 0;                                  // launder an OFFSET, not the pointer: a laundered pointer loses its address
+        asm volatile("" : "+s"(zoff));                 // space and every weight read becomes a per-lane flat_load (1 400 x 16 B x 64 lanes)
+        const float* lw = lw_base + zoff;
         const int e_raw = ch * 256 + threadIdx.x;
         const bool valid = e_raw < n_edges;
         const int e = valid ? e_raw : n_edges - 1;
