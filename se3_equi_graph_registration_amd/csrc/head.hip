@@ -172,7 +172,9 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
     u64* keys = reinterpret_cast<u64*>(smem_raw);                                   // [Npad] (fallback) / candidates
     unsigned* khi = reinterpret_cast<unsigned*>(smem_raw + sizeof(u64) * (size_t)(Npad > kCand ? Npad : kCand));   // [N]
     double st[6];
+    EQ_STAMPK(3, 0);
     head_stats(partials, B * nbp, M, red, st);
+    EQ_STAMPK(3, 1);
     // ---- masked softmax scalars from the per-block (max, sum exp) records of this pair (:717-724)
     const double* pp = partials + (size_t)b * nbp * kHeadPartials;
     float mx = -INFINITY;
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
     // ---- top-K (:684): ascending key == descending sim, then lower index.  MSB radix select on the value
     //      bits finds the K-th value T; candidates {v < T} + {v == T} are sorted exactly; if more than kCand
     //      candidates tie (degenerate inputs) fall back to a full bitonic sort.
+    EQ_STAMPK(3, 2);
     for (int i = tid; i < N; i += 256) khi[i] = ~orderable(sb[i]);
     unsigned prefix = 0, mask = 0;
     int need = K;
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
         prefix |= (unsigned)sel[0] << shift;
         mask |= 255u << shift;
     }
+    EQ_STAMPK(3, 3);
     const int n_less = K - need, n_tie = sel[2];
     const int total = n_less + n_tie;
     int P;
@@ -235,10 +239,22 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
             const unsigned v = khi[i];
             if (v <= prefix) keys[atomicAdd(&sel[0], 1)] = ((u64)v << 32) | (unsigned)i;
         }
-        P = 2;
-        while (P < total) P <<= 1;
         __syncthreads();
-        for (int i = total + tid; i < P; i += 256) keys[i] = ~0ull;
+        EQ_STAMPK(3, 4);
+        // <= kCand unique keys: rank by counting (one pass of broadcast LDS reads, one barrier) instead of a bitonic
+        // sort (36 barrier-separated stages at 256 keys); same order
+        for (int t = tid; t < total; t += 256) {
+            const u64 mine = keys[t];
+            int rank = 0;
+            for (int j = 0; j < total; ++j) rank += (keys[j] < mine) ? 1 : 0;
+            if (rank < K) {
+                const int idx = (int)(unsigned)(mine & 0xffffffffu);
+                top_idx[(size_t)b * K + rank] = idx;
+                pos[(size_t)b * N + idx] = rank;
+            }
+        }
+        EQ_STAMPK(3, 5);
+        return;
     } else {
         for (int i = tid; i < N; i += 256) keys[i] = ((u64)khi[i] << 32) | (unsigned)i;
         for (int i = N + tid; i < Npad; i += 256) keys[i] = ~0ull;
@@ -661,3 +677,9 @@ extern "C" int equigspr_head_backward(const float* hs, const float* ht, const fl
     EQ_CHECK_LAUNCH("head_backward");
     return 0;
 }
+
+#ifdef EQ_TRACE
+extern "C" int equigspr_trace_set_head(unsigned long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(eq_trace_ptr), &buf, sizeof(buf));
+}
+#endif

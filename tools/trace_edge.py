@@ -25,7 +25,7 @@ cfg = egnn.cfg
 E = graph.n_edges
 SLOTS = 16
 WAVES = 16384                       # EQ_TRACE_WAVES: waves per kernel id
-buf = torch.zeros(3 * WAVES * SLOTS, dtype=torch.int64, device=dev)
+buf = torch.zeros(4 * WAVES * SLOTS, dtype=torch.int64, device=dev)
 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 ms = ctypes.c_float(0.0)
 
@@ -108,3 +108,15 @@ report("node_bwd", buf, [(1, "stage W4^T, W_src^T, W_tgt^T, W4, W5 (29 KB)"), (2
                           (5, "W4^T products, stores"), (6, "outer-product accumulation"), (7, "slab store")], kid=1)
 report("gather_bwd", buf, [(1, "stage W1[:, :2F]"), (2, "segment sums of dt1 over in/out edges"), (3, "W_src^T, W_tgt^T products"),
                             (4, "outer-product accumulation"), (5, "slab store")], kid=2)
+
+# ---- head select kernel (kernel id 3): one full pair-model forward with the head trace pointer set
+raw.equigspr_trace_set_bwd(None)
+buf.zero_()
+raw.equigspr_trace_set_head(ctypes.c_void_p(buf.data_ptr()))
+model = pk.CrossAttentionPoseRegression(egnn, num_nodes=N, hidden_nf=F, device=dev).to(dev)
+with torch.no_grad():
+    model(batch["feat_src"], batch["src"], graph, None, batch["feat_tgt"], batch["tgt"], graph, None, batch["corr"], batch["labels"], batch["gt_pose"])
+torch.cuda.synchronize()
+raw.equigspr_trace_set_head(None)
+report("head_pair_kernel", buf, [(1, "batch statistics from partials (fp64)"), (2, "masked-softmax scalars"), (3, "keys + 4 radix-select passes"),
+                                 (4, "candidate compaction"), (5, "rank by counting + writes")], kid=3)
