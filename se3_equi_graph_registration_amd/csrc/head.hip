@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double red[4];
     __shared__ float redf[4];
-    __shared__ unsigned hist[256];
+    constexpr int kHistCopies = 16;
+    __shared__ unsigned histp[kHistCopies * 256];
     __shared__ int sel[3];
     __shared__ int wtot[4];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -200,16 +201,21 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
     int need = K;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
-        hist[tid] = 0;
+        // 16 privatised copies of the histogram (by lane & 15): the leading digits of similarity values fall into a
+        // handful of bins, and same-address LDS atomics serialise (the four passes were 18 k of this kernel's 34 k ticks)
+#pragma unroll
+        for (int r = 0; r < kHistCopies; ++r) histp[r * 256 + tid] = 0;
         __syncthreads();
         for (int i = tid; i < N; i += 256) {
             const unsigned v = khi[i];
-            if ((v & mask) == prefix) atomicAdd(&hist[(v >> shift) & 255u], 1u);
+            if ((v & mask) == prefix) atomicAdd(&histp[(tid & (kHistCopies - 1)) * 256 + ((v >> shift) & 255u)], 1u);
         }
         __syncthreads();
         {   // inclusive scan of the 256 bins (one per thread): wave scan + 4 wave totals; the selected bin is the
             // first whose inclusive count reaches `need`
-            const int c = (int)hist[tid];
+            int c = 0;
+#pragma unroll
+            for (int r = 0; r < kHistCopies; ++r) c += (int)histp[r * 256 + tid];
             int inc = c;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
