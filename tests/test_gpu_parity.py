@@ -74,6 +74,19 @@ def test_knn_duplicates_grid_and_batched(pk):
         assert torch.equal(pk.knn_graph(grid.cuda(), k, loop=True).cpu(), orc.knn_graph(grid, k, loop=True))
     same = torch.ones(130, 3)                      # every candidate ties: exercises the slow path fallback
     assert torch.equal(pk.knn_graph(same.cuda(), 9, loop=True).cpu(), orc.knn_graph(same, 9, loop=True))
+    # the tiled multi-query kernel (n > 2048): duplicated points, an integer grid (massive ties -> its slow path), a cloud that
+    # is not a multiple of the 16-query workgroup or of the 2048-point tile, and a batched launch
+    big = torch.rand(2500, 3, generator=g)
+    big[1250:] = big[:1250]
+    for k, loop in ((20, True), (5, False)):
+        assert torch.equal(pk.knn_graph(big.cuda(), k, loop=loop).cpu(), orc.knn_graph(big, k, loop=loop))
+    grid2 = torch.stack(torch.meshgrid(torch.arange(6.), torch.arange(20.), torch.arange(20.), indexing="ij"), -1).reshape(-1, 3)   # 2400
+    for k in (7, 27):
+        assert torch.equal(pk.knn_graph(grid2.cuda(), k, loop=True).cpu(), orc.knn_graph(grid2, k, loop=True))
+    xb2 = torch.rand(2, 2051, 3, generator=g)
+    e64b, _, _ = pk.knn_graph_batched(xb2.cuda(), 9, True, want_i64=True, want_i32=False)
+    for b in range(2):
+        assert torch.equal(e64b[b].cpu(), orc.knn_graph(xb2[b], 9, loop=True))
     # batched launch == per-cloud calls, and the int32 device format agrees with the int64 lists
     xb = torch.rand(3, 256, 3, generator=g)
     e64, r32, c32 = pk.knn_graph_batched(xb.cuda(), 12, True, want_i64=True, want_i32=True)
