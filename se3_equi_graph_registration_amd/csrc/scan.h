@@ -33,7 +33,7 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int* __restrict__ cnt_cu
     if (t == 1023) ptr[n] = part[1023];
 }
 
-constexpr int kScanSingleBlockMax = 16384;
+constexpr int kScanSingleBlockMax = 8192;
 constexpr int kScanChunk = 4096;                 // elements per block of the two-level scan (4 per thread)
 
 // level 1: block b scans its chunk in place (exclusive, local) and writes the chunk total
