@@ -148,7 +148,7 @@ def make_runner(S, args, world, dev):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         S["zero"]()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             if args.forward_only:
                 with torch.no_grad():
                     S["loss"] = S["fwd_bwd"]()
@@ -160,7 +160,7 @@ def make_runner(S, args, world, dev):
                 S["opt_step"]()
         # the periodic weight restore is captured too (no eager launches between replays)
         gr = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gr):
+        with torch.cuda.graph(gr, capture_error_mode="thread_local"):
             S["restore"]()
         S["restore"] = lambda: gr.replay()
         return (lambda: g.replay()), True
@@ -186,13 +186,13 @@ def split_graph_runner(S, args, dist_on, eager):
     torch.cuda.synchronize()
     ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     S["zero"]()
-    with torch.cuda.graph(ga):
+    with torch.cuda.graph(ga, capture_error_mode="thread_local"):
         S["zero"]()
         S["loss"] = S["fwd_bwd"]()
-    with torch.cuda.graph(gb, pool=ga.pool()):
+    with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
         S["opt_step"]()
     gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr, pool=ga.pool()):
+    with torch.cuda.graph(gr, pool=ga.pool(), capture_error_mode="thread_local"):
         S["restore"]()
     S["restore"] = lambda: gr.replay()
     buckets = S["dp"].buckets()
