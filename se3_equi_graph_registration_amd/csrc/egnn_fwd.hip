@@ -94,20 +94,20 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------
 // edge kernel, MFMA formulation (hidden_nf == 32): one wave per 32-edge tile, weights in VGPRs
 // ---------------------------------------------------------------------------------------
-template <int H, int A>
+template <int H, int A, int B = 0>
 __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restrict__ lw, const int* __restrict__ row,
                                                             const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                             const float* __restrict__ x, const float* __restrict__ P,
                                                             int n_edges, float* __restrict__ m_out,
                                                             float* __restrict__ trans_out) {
-    constexpr int FP = 32, PS = 64;
+    constexpr int FP = 32 + 4 * B, PS = 2 * FP;          // hidden_nf = 32 + B, rows padded to 16 bytes
     const int lane = threadIdx.x & 63, el = lane & 31, h = lane >> 5;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
-    __shared__ float wsm[TileWeightsLds::size];
+    __shared__ float wsm[TileWeightsLdsT<B>::size];
     EQ_STAMP(0);
-    stage_tile_weights<H, A>(wsm, lw);
+    stage_tile_weights<H, A, B>(wsm, lw);
     __syncthreads();
-    TileWeights<H, A> W;
+    TileWeights<H, A, false, B> W;
     W.load(wsm, lane);
     EQ_STAMP(1);
     const int tiles = (n_edges + 31) / 32;
@@ -126,9 +126,10 @@ __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restr
         EQ_STAMP(3);
         const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
         TileFwd o;
-        tile_forward<H, A, false>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
+        tile_forward<H, A, false, B>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
         if (valid) {
             store_half_row(m_out + (size_t)e * FP, h, o.m);
+            if (B) store_border(m_out + (size_t)e * FP, h, o.mb);
             if (h == 0)
                 reinterpret_cast<float4*>(trans_out)[e] = make_float4(eg.d[0] * o.s, eg.d[1] * o.s, eg.d[2] * o.s, 0.0f);   // :264
         }
@@ -140,11 +141,11 @@ template <int F, int H, int A>
 static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
                             float* m, float* trans, hipStream_t s) {
     const int E = g->n_edges;
-    if constexpr (F == 32) {
+    if constexpr (F == 32 || (F == 33 && H == 1)) {
         const int tiles = ceil_div(E, 32);
         int blocks = ceil_div(tiles, 4);          // one 32-edge tile per wave: latency is hidden across waves
         blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-        hipLaunchKernelGGL((edge_fwd_mfma_kernel<H, A>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
+        hipLaunchKernelGGL((edge_fwd_mfma_kernel<H, A, F - 32>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
                            E, m, trans);
     } else {
         hipLaunchKernelGGL((edge_fwd_kernel<F, H, A>), dim3(ceil_div(E, 256)), dim3(256), 0, s, lw, g->row, g->col,
