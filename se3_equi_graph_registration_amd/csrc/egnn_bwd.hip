@@ -911,7 +911,7 @@ __device__ __forceinline__ void stage_half_row(float* tile_row, int h, const flo
         *reinterpret_cast<float4*>(tile_row + 8 * q + 4 * h) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
-template <int H, int A>
+template <int H, int A, int B = 0>
 __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restrict__ lw, const int* __restrict__ row,
                                                             const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                             const float* __restrict__ x, const float* __restrict__ P,
@@ -919,24 +919,29 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
                                                             int n_edges, float* __restrict__ dt1_out,
                                                             float* __restrict__ gxr_out, float* __restrict__ gxc_out,
                                                             float* __restrict__ slab) {
-    constexpr int F = 32, FP = 32, PS = 64, LD = 36;
+    constexpr int F = 32 + B, FP = 32 + 4 * B, PS = 2 * FP, LD = 36;     // B = 1: hidden_nf = 33, feature 32 = the border
     using SB = Slabs<F>;
+    using T = TileWeightsLdsT<B>;
     constexpr int kTileFloats = 4 * 2 * 32 * LD > 4 * SB::edge ? 4 * 2 * 32 * LD : 4 * SB::edge;   // X/Y tiles, then 4 slab copies
     __shared__ __attribute__((aligned(16))) float tiles[kTileFloats];
-    __shared__ float wsm[TileWeightsLds::size];
+    __shared__ float wsm[T::size];
     const int lane = threadIdx.x & 63, el = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
     const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
     float* X = tiles + (size_t)wv * 2 * 32 * LD;
     float* Y = X + 32 * LD;
     EQ_STAMP(0);
-    stage_tile_weights<H, A>(wsm, lw);
+    stage_tile_weights<H, A, B>(wsm, lw);
     __syncthreads();
-    TileWeights<H, A, true> W;
+    TileWeights<H, A, true, B> W;
     W.load(wsm, lane);
     EQ_STAMP(1);
 
     f32x16 acc6[1][1], acc2[1][1], accg[1][1];
     float cs_b6[1] = {0.0f}, cs_b2[1] = {0.0f}, cs_gam[1] = {0.0f}, cs_bet[1] = {0.0f}, cs_w7[1] = {0.0f}, cs_scr[1] = {0.0f};
+    // border (B = 1): column 32 / row 32 of dW6, dW2 (per-lane column sums like cs_*), row 32 of dWgeo, and the scalars
+    // (corner entries and the 33rd entry of every per-feature vector) as per-lane partials of the h == 0 lanes
+    float bc6[1] = {0.0f}, br6[1] = {0.0f}, bc2[1] = {0.0f}, br2[1] = {0.0f}, brg[1] = {0.0f};
+    float x_c6 = 0.0f, x_c2 = 0.0f, x_b6 = 0.0f, x_b2 = 0.0f, x_w7 = 0.0f, x_gam = 0.0f, x_bet = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc6[0][0][r] = 0.0f; acc2[0][0][r] = 0.0f; accg[0][0][r] = 0.0f; }
 
@@ -957,7 +962,8 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         EQ_STAMP(3);
         const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
         TileFwd o;
-        tile_forward<H, A, true>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
+        tile_forward<H, A, true, B>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
+        const float zh = (h == 0) ? 1.0f : 0.0f;            // border scalars are identical in both halves: count them once
 
         // ---- coord head backward
         const float ds = dot3(eg.d, gxv) * z;
@@ -971,22 +977,37 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
             pds[k] = o.q[k] * sg * ds;
             dq[k] = W.w7(k) * ds * (sg * (1.0f + o.q[k] * (1.0f - sg)));
         }
+        float dqb = 0.0f, pdsb = 0.0f;
+        if constexpr (B == 1) {
+            pdsb = o.qb * o.sgqb * ds;
+            dqb = W.x_vec(4) * ds * (o.sgqb * (1.0f + o.qb * (1.0f - o.sgqb)));
+            x_c6 = fmaf(zh * dqb, o.mb, x_c6); x_b6 += zh * dqb; x_w7 += zh * pdsb;
+        }
         stage_half_row(X + el * LD, h, dq);
         stage_half_row(Y + el * LD, h, o.m);
         __builtin_amdgcn_wave_barrier();
         tile_pass<1, 1, LD, true, 32>(X, Y, acc6, cs_b6, cs_scr, lane);           // dW6 += dq^T m ; db6 += sum dq
         __builtin_amdgcn_wave_barrier();
+        if constexpr (B == 1) {                                                   // dW6[:, 32] = sum dq * m32 ; dW6[32, :] = sum dq32 * m
+            float xs[16], ys[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { xs[k] = dq[k] * o.mb; ys[k] = dqb * o.m[k]; }
+            stage_half_row(X + el * LD, h, xs);
+            stage_half_row(Y + el * LD, h, ys);
+            __builtin_amdgcn_wave_barrier();
+            tile_pass<1, 1, LD, false, 32>(X, Y, acc6, bc6, br6, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
         EQ_STAMP(7);
         // ---- dm = dagg[row] + W6^T dq
-        float dm[16];
+        float dm[16], dmb = 0.0f;
         {
             float da[16];
             load_half_row(dagg + (size_t)r * FP, h, da);
             f32x16 a;
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = da[k] * z;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w6t(s), dq[s], a, 0, 0, 0);
+            mv_border<true, B>(W, T::o_w6, [&](int s) { return W.w6t(s); }, dq, dqb, a, dmb, B ? dagg[(size_t)r * FP + 32] * z : 0.0f, h);
 #pragma unroll
             for (int k = 0; k < 16; ++k) dm[k] = a[k];
         }
@@ -995,6 +1016,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
             float t[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) t[k] = dm[k] * o.xhat[k];
+            if constexpr (B == 1) { x_gam = fmaf(zh * dmb, o.xhatb, x_gam); x_bet += zh * dmb; }
             stage_half_row(X + el * LD, h, pds);
             stage_half_row(Y + el * LD, h, t);
         }
@@ -1007,7 +1029,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         __builtin_amdgcn_wave_barrier();
         EQ_STAMP(9);
         // ---- LayerNorm backward
-        float du[16];
+        float du[16], dub = 0.0f;
         {
             float m1 = 0.0f, m2 = 0.0f;
 #pragma unroll
@@ -1018,10 +1040,16 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
             }
             m1 += xhalf(m1);
             m2 += xhalf(m2);
-            m1 *= (1.0f / 32.0f);
-            m2 *= (1.0f / 32.0f);
+            if constexpr (B == 1) {
+                dub = dmb * W.x_vec(1);
+                m1 += dub;
+                m2 = fmaf(dub, o.xhatb, m2);
+            }
+            m1 *= (1.0f / F);
+            m2 *= (1.0f / F);
 #pragma unroll
             for (int k = 0; k < 16; ++k) du[k] = o.rstd * (du[k] - m1 - o.xhat[k] * m2);
+            if constexpr (B == 1) dub = o.rstd * (dub - m1 - o.xhatb * m2);
         }
         float sg1[16];
         {
@@ -1034,21 +1062,33 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
             }
             stage_half_row(X + el * LD, h, du);
             stage_half_row(Y + el * LD, h, g1);
+            __builtin_amdgcn_wave_barrier();
+            tile_pass<1, 1, LD, true, 32>(X, Y, acc2, cs_b2, cs_scr, lane);       // dW2 += du^T g1 ; db2 += sum du
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (B == 1) {                                               // dW2[:, 32] = sum du * g1_32 ; dW2[32, :] = sum du32 * g1
+                const float g1b = o.t1b * o.sg1b;
+                x_c2 = fmaf(zh * dub, g1b, x_c2); x_b2 += zh * dub;
+                float xs[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { xs[k] = du[k] * g1b; g1[k] *= dub; }
+                stage_half_row(X + el * LD, h, xs);
+                stage_half_row(Y + el * LD, h, g1);
+                __builtin_amdgcn_wave_barrier();
+                tile_pass<1, 1, LD, false, 32>(X, Y, acc2, bc2, br2, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
         }
-        __builtin_amdgcn_wave_barrier();
-        tile_pass<1, 1, LD, true, 32>(X, Y, acc2, cs_b2, cs_scr, lane);           // dW2 += du^T g1 ; db2 += sum du
-        __builtin_amdgcn_wave_barrier();
         EQ_STAMP(10);
         // ---- dt1 = (W2^T du) * silu'(t1)
-        float dt1[16];
+        float dt1[16], dt1b = 0.0f;
         {
             f32x16 a;
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.w2t(s), du[s], a, 0, 0, 0);
+            mv_border<true, B>(W, T::o_w2, [&](int s) { return W.w2t(s); }, du, dub, a, dt1b, 0.0f, h);
 #pragma unroll
             for (int k = 0; k < 16; ++k) dt1[k] = a[k] * sg1[k];
+            if constexpr (B == 1) dt1b *= o.sg1b * (1.0f + o.t1b * (1.0f - o.sg1b));
         }
         EQ_STAMP(11);
         stage_half_row(X + el * LD, h, dt1);
@@ -1064,6 +1104,20 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         __builtin_amdgcn_wave_barrier();
         tile_pass<1, 1, LD, true, 32>(X, Y, accg, cs_scr, cs_scr, lane);          // dWgeo|dwattr += dt1^T [geo, attr]
         __builtin_amdgcn_wave_barrier();
+        if constexpr (B == 1) {                                                   // dWgeo[32, :] = sum dt1_32 * [geo, attr]
+            if (h == 0) {
+                float ga[16];
+#pragma unroll
+                for (int k = 0; k < kGeo; ++k) ga[k] = dt1b * eg.g[k];
+                ga[12] = dt1b * attr; ga[13] = 0.0f; ga[14] = 0.0f; ga[15] = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(Y + el * LD + 4 * q) = make_float4(ga[4 * q], ga[4 * q + 1], ga[4 * q + 2], ga[4 * q + 3]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            tile_pass<1, 1, LD, false, 32>(X, Y, accg, cs_scr, brg, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
         EQ_STAMP(12);
         // ---- dgeo = Wgeo^T dt1 (rows 0..11 of a 32-row product), then the geometry backward
         float gg[kGeo];
@@ -1073,6 +1127,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
             for (int k = 0; k < 16; ++k) a[k] = 0.0f;
 #pragma unroll
             for (int s = 0; s < 16; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.wgt(s), dt1[s], a, 0, 0, 0);
+            if constexpr (B == 1) a = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? 0.0f : W.x_wg_i(), h ? 0.0f : dt1b, a, 0, 0, 0);
             // lane half h holds geo rows fidx(k,h): h=0 -> 0..3 (k 0..3), 8..11 (k 4..7); h=1 -> 4..7 (k 0..3)
             float mine[8], other[8];
 #pragma unroll
@@ -1088,6 +1143,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         edge_geometry_backward(xr, xc, eg, gg, gd, gxr, gxc);
         if (valid) {
             store_half_row(dt1_out + (size_t)e * FP, h, dt1);
+            if (B) store_border(dt1_out + (size_t)e * FP, h, dt1b);
             if (h == 0) {
                 reinterpret_cast<float4*>(gxr_out)[e] = make_float4(gxr[0], gxr[1], gxr[2], 0.0f);
                 reinterpret_cast<float4*>(gxc_out)[e] = make_float4(gxc[0], gxc[1], gxc[2], 0.0f);
@@ -1104,6 +1160,15 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
     cs_gam[0] += xhalf(cs_gam[0]);
     cs_bet[0] += xhalf(cs_bet[0]);
     cs_w7[0] += xhalf(cs_w7[0]);
+    if constexpr (B == 1) {
+        bc6[0] += xhalf(bc6[0]); br6[0] += xhalf(br6[0]); bc2[0] += xhalf(bc2[0]); br2[0] += xhalf(br2[0]); brg[0] += xhalf(brg[0]);
+#pragma unroll
+        for (int off = 1; off <= 32; off <<= 1) {      // the scalars: sum over the wave (only h == 0 lanes contributed)
+            x_c6 += __shfl_xor(x_c6, off, 64); x_c2 += __shfl_xor(x_c2, off, 64); x_b6 += __shfl_xor(x_b6, off, 64);
+            x_b2 += __shfl_xor(x_b2, off, 64); x_w7 += __shfl_xor(x_w7, off, 64); x_gam += __shfl_xor(x_gam, off, 64);
+            x_bet += __shfl_xor(x_bet, off, 64);
+        }
+    }
     __syncthreads();                                   // every wave is done with its X/Y tiles
     {
         float* sl = tiles + (size_t)wv * SB::edge;
@@ -1120,6 +1185,18 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
             sl[SB::e_gam + f] = cs_gam[0];
             sl[SB::e_bet + f] = cs_bet[0];
             sl[SB::e_w7 + f] = cs_w7[0];
+            if constexpr (B == 1) {
+                sl[SB::e_w6 + f * F + 32] = bc6[0];            // column 32, rows 0..31
+                sl[SB::e_w6 + 32 * F + f] = br6[0];            // row 32, columns 0..31
+                sl[SB::e_w2 + f * F + 32] = bc2[0];
+                sl[SB::e_w2 + 32 * F + f] = br2[0];
+                if (f < 16) sl[SB::e_geo + 32 * 16 + f] = brg[0];
+                if (f == 0) {
+                    sl[SB::e_w6 + 32 * F + 32] = x_c6; sl[SB::e_w2 + 32 * F + 32] = x_c2;
+                    sl[SB::e_b6 + 32] = x_b6; sl[SB::e_b2 + 32] = x_b2; sl[SB::e_w7 + 32] = x_w7;
+                    sl[SB::e_gam + 32] = x_gam; sl[SB::e_bet + 32] = x_bet;
+                }
+            }
         }
     }
     __syncthreads();
@@ -1133,13 +1210,13 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
                            const float* dagg, const float* Gx, float* dt1, float* gxr, float* gxc, float* slab,
                            hipStream_t s, int* n_slabs) {
     const int E = g->n_edges;
-    if constexpr (F == 32) {
+    if constexpr (F == 32 || (F == 33 && H == 1)) {
         const int tiles = ceil_div(E, 32);
         // persistent waves: one workgroup per CU (the kernel runs at one wave per SIMD), each wave loops over
         // its tiles -- the weight staging and the slab epilogue are paid 256 times, not once per 4 tiles
         int blocks = ceil_div(tiles, 4);
         blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
-        hipLaunchKernelGGL((edge_bwd_mfma_kernel<H, A>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
+        hipLaunchKernelGGL((edge_bwd_mfma_kernel<H, A, F - 32>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
                            dagg, Gx, E, dt1, gxr, gxc, slab);
         *n_slabs = blocks;
     } else {
@@ -1277,7 +1354,7 @@ static BwdLayout bwd_layout(int F, int in_nf, int out_nf, int64_t N, int64_t E, 
     // slab sets: one per layer (layer l at + l * layer_stride), sized for the blocks this problem actually launches
     const int NS = 256 / (F <= 32 ? 32 : 64);
     const size_t node_blocks = std::min<size_t>((N + NS - 1) / NS, kNodeBwdBlocks);
-    const size_t edge_blocks = std::min<size_t>(F == 32 ? 256 : (size_t)((E + 255) / 256), kEdgeBwdBlocks);
+    const size_t edge_blocks = std::min<size_t>((F == 32 || F == 33) ? 256 : (size_t)((E + 255) / 256), kEdgeBwdBlocks);
     const size_t emb = (size_t)64 * F + 64;
     B.emb_slab = take(node_blocks * emb);
     B.emb_slab2 = take(node_blocks * emb);
