@@ -302,9 +302,22 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__
     OuterAcc<G, F> aW5;
     VecAcc<G> ab4, ab5;
     MfmaOuter mo;                                   // F == 32: wave 0/1 = dW4 column blocks, wave 2 = dW5, wave 3 = the bias sums
-    float mb4 = 0.0f, mb5 = 0.0f;
+    float mb4 = 0.0f, mb5 = 0.0f, mb4b = 0.0f, mb5b = 0.0f;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if constexpr (F == 32) mo.init();
+    // F == 33: 32-wide cores on the matrix cores (dW4 columns 0..31 and 32..63, dW5), and the 195 left-over entries
+    // (row 32 of both, columns 64..65 of dW4, column 32 of dW5) one per thread
+    float lo_acc = 0.0f;
+    int lo_x = -1, lo_y = 0;                        // left-over entry of this thread: sum_n XL[n][lo_x] * YL[n][lo_y]
+    bool lo_w5 = false;
+    int lo_dst = 0;
+    if constexpr (F == 33) {
+        const int t = threadIdx.x;
+        if (t < 66) { lo_x = 32; lo_y = t; lo_dst = 32 * 2 * F + t; }                                       // dW4[32][0..65]
+        else if (t < 130) { const int u = t - 66; lo_x = u >> 1; lo_y = 64 + (u & 1); lo_dst = lo_x * 2 * F + lo_y; }   // dW4[0..31][64..65]
+        else if (t < 163) { lo_w5 = true; lo_x = 32; lo_y = t - 130; lo_dst = F * 2 * F + F + 32 * F + lo_y; }          // dW5[32][0..32]
+        else if (t < 195) { lo_w5 = true; lo_x = t - 163; lo_y = 32; lo_dst = F * 2 * F + F + lo_x * F + 32; }          // dW5[0..31][32]
+    }
+    if constexpr (F == 32 || F == 33) mo.init();
     else { aW4.init(); aW5.init(); ab4.init(); ab5.init(); }
     const int groups = (n_nodes + NS - 1) / NS;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
@@ -343,13 +356,25 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__
         }
         const int ns = min(NS, n_nodes - grp * NS);
         EQ_STAMPK(1, 5);
-        if constexpr (F == 32) {
+        if constexpr (F == 32 || F == 33) {
             if (wv < 2) mo.add(&dvv[0][0], FP, &vin[0][0] + 32 * wv, 2 * FP, ns, lane);
             else if (wv == 2) mo.add(&ghv[0][0], FP, &hid[0][0], FP, ns, lane);
             else {
 #pragma unroll
-                for (int n = 0; n < 8; ++n)
+                for (int n = 0; n < NS; ++n)
                     if (n < ns) { mb4 += (lane < 32) ? dvv[n][lane & 31] : 0.0f; mb5 += (lane >= 32) ? ghv[n][lane & 31] : 0.0f; }
+            }
+            if constexpr (F == 33) {
+                if (lo_x >= 0) {
+#pragma unroll
+                    for (int n = 0; n < NS; ++n)
+                        if (n < ns) lo_acc = fmaf(lo_w5 ? ghv[n][lo_x] : dvv[n][lo_x], lo_w5 ? hid[n][lo_y] : vin[n][lo_y], lo_acc);
+                }
+                if (wv == 3 && lane == 0) {           // the 33rd bias entries
+#pragma unroll
+                    for (int n = 0; n < NS; ++n)
+                        if (n < ns) { mb4b += dvv[n][32]; mb5b += ghv[n][32]; }
+                }
             }
         } else {
             aW4.add(&dvv[0][0], FP, &vin[0][0], 2 * FP, ns, 2 * F);
@@ -360,11 +385,15 @@ __global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__
         EQ_STAMPK(1, 6);
     }
     float* my = slab + (size_t)blockIdx.x * SB::node;
-    if constexpr (F == 32) {
+    if constexpr (F == 32 || F == 33) {
         if (wv < 2) mo.store(my + 32 * wv, 2 * F, lane);
         else if (wv == 2) mo.store(my + F * 2 * F + F, F, lane);
         else if (lane < 32) my[F * 2 * F + lane] = mb4;
         else my[F * 2 * F + F + F * F + (lane - 32)] = mb5;
+        if constexpr (F == 33) {
+            if (lo_x >= 0) my[lo_dst] = lo_acc;
+            if (wv == 3 && lane == 0) { my[F * 2 * F + 32] = mb4b; my[F * 2 * F + F + F * F + 32] = mb5b; }
+        }
     } else {
         aW4.store(my, F, 2 * F);
         ab4.store(my + F * 2 * F, F);
