@@ -658,276 +658,6 @@ __device__ __forceinline__ void tile_pass(const float* X, const float* Y, f32x16
     }
 }
 
-// hidden_nf in (32, 64): a second 32-block would hold one live row/column (feature 32).  Instead of 2x2 padded MFMA blocks
-// (4x the matrix work and 192 accumulator registers) only the 32x32 core goes through the matrix cores; column sums still
-// cover both blocks, and the 33rd row/column of each weight gradient comes from column sums of row-scaled copies
-// (border_pass below).
-template <int LD, bool kMfma, bool kY2>
-__device__ __forceinline__ void tile_pass_core(const float* X, const float* Y, f32x16& acc, float (&csx)[2], float (&csy)[2], int lane) {
-    const int f = lane & 31, hh = lane >> 5;
-#pragma unroll 2
-    for (int s = 0; s < 32; ++s) {
-        const int e = 2 * s + hh;
-        const float a0 = X[e * LD + f], a1 = (f == 0) ? X[e * LD + 32] : 0.0f;     // block 1 = feature 32 only (LD = 35)
-        const float b0 = Y[e * LD + f];
-        csx[0] += a0; csx[1] += a1; csy[0] += b0;
-        if (kY2) csy[1] += (f == 0) ? Y[e * LD + 32] : 0.0f;
-        if (kMfma) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
-    }
-}
-
-template <int F, int H, int A>
-__global__ __launch_bounds__(256) void edge_bwd_kernel(const float* __restrict__ lw_in, const int* __restrict__ row,
-                                                       const int* __restrict__ col, const float* __restrict__ edge_attr,
-                                                       const float* __restrict__ x, const float* __restrict__ P,
-                                                       const float* __restrict__ dagg, const float* __restrict__ Gx,
-                                                       int n_edges, float* __restrict__ dt1_out,
-                                                       float* __restrict__ gxr_out, float* __restrict__ gxc_out,
-                                                       float* __restrict__ slab) {
-    using LL = LP<F, H, A>;
-    using SB = Slabs<F>;
-    constexpr int FP = Geom<F>::FP, PS = Geom<F>::PS, FH = F / H;
-    constexpr int NB = (F + 31) / 32;
-    constexpr int LD = 35;                            // 33 live columns (feature 32 = "block 1"), odd stride
-    extern __shared__ float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* tiles = smem;
-    float* X = tiles + (size_t)wave * 2 * 64 * LD;
-    float* Y = X + 64 * LD;
-
-    static_assert(NB == 2, "the generic edge backward serves hidden_nf in (32, 64); hidden_nf == 32 has the MFMA kernel");
-    f32x16 acc6, acc2, accg;                         // 32x32 cores (accg: 32x16)
-    float cs_b6[NB], cs_b2[NB], cs_gam[NB], cs_bet[NB], cs_w7[NB], cs_scr[NB], cs_scr2[NB];
-    float bc6[NB], br6[NB], bc2[NB], br2[NB], brg[NB];   // border columns (o = f + 32 rb incl. the corner) / border rows of dW6, dW2, dWgeo
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc6[r] = 0.0f; acc2[r] = 0.0f; accg[r] = 0.0f; }
-#pragma unroll
-    for (int rb = 0; rb < NB; ++rb) {
-        cs_b6[rb] = cs_b2[rb] = cs_gam[rb] = cs_bet[rb] = cs_w7[rb] = cs_scr[rb] = cs_scr2[rb] = 0.0f;
-        bc6[rb] = br6[rb] = bc2[rb] = br2[rb] = brg[rb] = 0.0f;
-    }
-
-    const int chunks = (n_edges + 255) / 256;
-    const float* lw_base = lw_in;
-    for (int ch = blockIdx.x; ch < chunks; ch += gridDim.x) {
-        // Re-materialise the weight pointer every chunk: without this the compiler hoists ALL ~4.6k
-        // wave-uniform weight loads out of the loop and spills them (v_writelane/v_readlane storm).
-        // (Tried: the layer block in LDS -- read as uniform values it is scalarised and spills 1 700 SGPRs, read per lane it
-        // spills 160 VGPRs; neither beats the scalar loads.)
-        int zoff = 0;                                  // launder an OFFSET, not the pointer: a laundered pointer loses its address
-        asm volatile("" : "+s"(zoff));                 // space and every weight read becomes a per-lane flat_load (1 400 x 16 B x 64 lanes)
-        const float* lw = lw_base + zoff;
-        const int e_raw = ch * 256 + threadIdx.x;
-        const bool valid = e_raw < n_edges;
-        const int e = valid ? e_raw : n_edges - 1;
-        const float z = valid ? 1.0f : 0.0f;
-        const int r = row[e], c = col[e];
-        float xr[3], xc[3], gxv[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { xr[i] = x[(size_t)r * 3 + i]; xc[i] = x[(size_t)c * 3 + i]; gxv[i] = Gx[(size_t)r * 4 + i]; }
-        EdgeGeo eg;
-        edge_geometry(xr, xc, eg);
-        const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
-        float t1[F], xhat[F], m[F], q[F], rstd, s;
-        EdgeFwd<F, H, A>::run(lw, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg.g, attr, t1, xhat, rstd, m, q, s);
-
-        // ---- coord head backward:  trans = d * s,  s = w7 . silu(q)
-        const float ds = dot3(eg.d, gxv) * z;
-        float gd[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) gd[i] = s * gxv[i];
-        float dq[F];
-#pragma unroll
-        for (int o = 0; o < F; ++o) {
-            const float w7 = lw[LL::w7 + o];
-            dq[o] = w7 * ds * silu_grad(q[o]);
-            X[lane * LD + o] = dq[o];
-            Y[lane * LD + o] = m[o];
-        }
-        __builtin_amdgcn_wave_barrier();
-        tile_pass_core<LD, true, false>(X, Y, acc6, cs_b6, cs_scr, lane);      // dW6 core += dq^T m ; db6 += sum dq
-        __builtin_amdgcn_wave_barrier();
-        // borders of dW6: column 32 = sum_e dq[e][o] m[e][32], row 32 = sum_e dq[e][32] m[e][i]
-#pragma unroll
-        for (int o = 0; o < F; ++o) {
-            X[lane * LD + o] = dq[o] * m[F - 1];
-            Y[lane * LD + o] = (o < F - 1) ? dq[F - 1] * m[o] : 0.0f;
-        }
-        __builtin_amdgcn_wave_barrier();
-        tile_pass_core<LD, false, false>(X, Y, acc6, bc6, br6, lane);
-        __builtin_amdgcn_wave_barrier();
-        // ---- dm = dagg[row] + W6^T dq
-        float dm[F];
-        {
-            const float4* dar = reinterpret_cast<const float4*>(dagg + (size_t)r * FP);
-#pragma unroll
-            for (int v = 0; v < FP / 4; ++v) {
-                const float4 a = dar[v];
-                dm[4 * v] = a.x * z;
-                if (4 * v + 1 < F) dm[(4 * v + 1 < F) ? 4 * v + 1 : 0] = a.y * z;
-                if (4 * v + 2 < F) dm[(4 * v + 2 < F) ? 4 * v + 2 : 0] = a.z * z;
-                if (4 * v + 3 < F) dm[(4 * v + 3 < F) ? 4 * v + 3 : 0] = a.w * z;
-            }
-        }
-#pragma unroll
-        for (int o = 0; o < F; ++o) {
-#pragma unroll
-            for (int i = 0; i < F; ++i) dm[i] = fmaf(lw[LL::w6 + o * F + i], dq[o], dm[i]);
-        }
-        // ---- stage [p*ds | dm*xhat] then [dm]: column sums only (dw7, dgamma, dbeta)
-#pragma unroll
-        for (int o = 0; o < F; ++o) {
-            X[lane * LD + o] = silu(q[o]) * ds;
-            Y[lane * LD + o] = dm[o] * xhat[o];
-        }
-        __builtin_amdgcn_wave_barrier();
-        tile_pass_core<LD, false, true>(X, Y, acc6, cs_w7, cs_gam, lane);
-        __builtin_amdgcn_wave_barrier();
-        // ---- LayerNorm backward
-        float du[F];
-        {
-            float m1 = 0.0f, m2 = 0.0f;
-#pragma unroll
-            for (int i = 0; i < F; ++i) {
-                const float dxh = dm[i] * lw[LL::ln_g + i];
-                du[i] = dxh;
-                m1 += dxh;
-                m2 = fmaf(dxh, xhat[i], m2);
-            }
-            m1 *= (1.0f / F);
-            m2 *= (1.0f / F);
-#pragma unroll
-            for (int i = 0; i < F; ++i) du[i] = rstd * (du[i] - m1 - xhat[i] * m2);
-        }
-        // ---- stage [du | g1]: dW2 += du^T g1, db2 += sum du ; and dbeta via a second X-only pass below
-#pragma unroll
-        for (int o = 0; o < F; ++o) {
-            X[lane * LD + o] = du[o];
-            Y[lane * LD + o] = silu(t1[o]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        tile_pass_core<LD, true, false>(X, Y, acc2, cs_b2, cs_scr, lane);
-        __builtin_amdgcn_wave_barrier();
-        {   // borders of dW2 (H == 1 for hidden_nf == 33: W2 is one dense block)
-            const float g32 = silu(t1[F - 1]);
-#pragma unroll
-            for (int o = 0; o < F; ++o) {
-                X[lane * LD + o] = du[o] * g32;
-                Y[lane * LD + o] = (o < F - 1) ? du[F - 1] * silu(t1[o]) : 0.0f;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        tile_pass_core<LD, false, false>(X, Y, acc2, bc2, br2, lane);
-        __builtin_amdgcn_wave_barrier();
-        // ---- dt1 = (W2^T du) * silu'(t1)
-        float dt1[F];
-#pragma unroll
-        for (int i = 0; i < F; ++i) dt1[i] = 0.0f;
-#pragma unroll
-        for (int o = 0; o < F; ++o) {                       // row o of W2 is contiguous: wide scalar loads
-            const int hb = (o / FH) * FH;
-#pragma unroll
-            for (int i = 0; i < FH; ++i) dt1[hb + i] = fmaf(lw[LL::w2_off(o, hb + i)], du[o], dt1[hb + i]);
-        }
-#pragma unroll
-        for (int i = 0; i < F; ++i) dt1[i] *= silu_grad(t1[i]);
-        // ---- stage [dt1 | geo,attr] (dWgeo) ; dm goes into X's partner tile for dbeta afterwards
-#pragma unroll
-        for (int o = 0; o < F; ++o) X[lane * LD + o] = dt1[o];
-#pragma unroll
-        for (int gI = 0; gI < kGeo; ++gI) Y[lane * LD + gI] = eg.g[gI];
-        Y[lane * LD + kGeo] = attr;
-        Y[lane * LD + kGeo + 1] = 0.0f; Y[lane * LD + kGeo + 2] = 0.0f; Y[lane * LD + kGeo + 3] = 0.0f;
-        __builtin_amdgcn_wave_barrier();
-        tile_pass_core<LD, true, false>(X, Y, accg, cs_scr, cs_scr2, lane);    // dWgeo core (rows 0..31) += dt1^T [geo, attr]
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int o = 0; o < F; ++o) X[lane * LD + o] = dm[o];
-#pragma unroll
-        for (int gI = 0; gI < kGeo; ++gI) Y[lane * LD + gI] = dt1[F - 1] * eg.g[gI];      // row 32 of dWgeo
-        Y[lane * LD + kGeo] = dt1[F - 1] * attr;
-        __builtin_amdgcn_wave_barrier();
-        tile_pass_core<LD, false, false>(X, Y, accg, cs_bet, brg, lane);        // dbeta = sum dm ; dWgeo[32][:]
-        __builtin_amdgcn_wave_barrier();
-        // ---- geometry backward
-        float gg[kGeo];
-#pragma unroll
-        for (int gI = 0; gI < kGeo; ++gI) gg[gI] = 0.0f;
-#pragma unroll
-        for (int o = 0; o < F; ++o) {
-            const float* w = lw + LL::w1_off(o, 2 * F);
-#pragma unroll
-            for (int gI = 0; gI < kGeo; ++gI) gg[gI] = fmaf(w[gI], dt1[o], gg[gI]);
-        }
-        float gxr[3], gxc[3];
-        edge_geometry_backward(xr, xc, eg, gg, gd, gxr, gxc);
-        if (valid) {
-            float4* o4 = reinterpret_cast<float4*>(dt1_out + (size_t)e * FP);
-#pragma unroll
-            for (int v = 0; v < FP / 4; ++v) {
-                float4 o;
-                o.x = dt1[4 * v];
-                o.y = (4 * v + 1 < F) ? dt1[(4 * v + 1 < F) ? 4 * v + 1 : 0] : 0.0f;
-                o.z = (4 * v + 2 < F) ? dt1[(4 * v + 2 < F) ? 4 * v + 2 : 0] : 0.0f;
-                o.w = (4 * v + 3 < F) ? dt1[(4 * v + 3 < F) ? 4 * v + 3 : 0] : 0.0f;
-                o4[v] = o;
-            }
-            reinterpret_cast<float4*>(gxr_out)[e] = make_float4(gxr[0], gxr[1], gxr[2], 0.0f);
-            reinterpret_cast<float4*>(gxc_out)[e] = make_float4(gxc[0], gxc[1], gxc[2], 0.0f);
-        }
-    }
-
-    // ---- block reduction of the 4 waves' partials into one slab (fixed order) ----------------
-    float* sl = tiles;     // aliases the tiles: every wave is past its last tile read after the barrier
-    const int f = lane & 31, hh = lane >> 5;
-#pragma unroll
-    for (int rb = 0; rb < NB; ++rb) {          // fold the two edge-parity halves of the column sums
-        cs_b6[rb] += __shfl_xor(cs_b6[rb], 32, 64);
-        cs_b2[rb] += __shfl_xor(cs_b2[rb], 32, 64);
-        cs_gam[rb] += __shfl_xor(cs_gam[rb], 32, 64);
-        cs_bet[rb] += __shfl_xor(cs_bet[rb], 32, 64);
-        cs_w7[rb] += __shfl_xor(cs_w7[rb], 32, 64);
-        bc6[rb] += __shfl_xor(bc6[rb], 32, 64);
-        bc2[rb] += __shfl_xor(bc2[rb], 32, 64);
-    }
-    br6[0] += __shfl_xor(br6[0], 32, 64);
-    br2[0] += __shfl_xor(br2[0], 32, 64);
-    brg[0] += __shfl_xor(brg[0], 32, 64);
-    for (int w = 0; w < 4; ++w) {
-        __syncthreads();
-        if (wave == w) {
-            const bool first = (w == 0);
-            auto put = [&](int idx, float v) { sl[idx] = (first ? 0.0f : sl[idx]) + v; };
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {       // 32x32 cores
-                const int orow = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                put(SB::e_w2 + orow * F + f, acc2[r]);
-                put(SB::e_w6 + orow * F + f, acc6[r]);
-                if (f < 16) put(SB::e_geo + orow * 16 + f, accg[r]);
-            }
-            if (hh == 0) {
-#pragma unroll
-                for (int rb = 0; rb < NB; ++rb) {
-                    const int ccol = rb * 32 + f;
-                    if (ccol < F) {
-                        put(SB::e_b2 + ccol, cs_b2[rb]);
-                        put(SB::e_b6 + ccol, cs_b6[rb]);
-                        put(SB::e_gam + ccol, cs_gam[rb]);
-                        put(SB::e_bet + ccol, cs_bet[rb]);
-                        put(SB::e_w7 + ccol, cs_w7[rb]);
-                        put(SB::e_w2 + ccol * F + (F - 1), bc2[rb]);       // column 32 (incl. the corner at ccol == 32)
-                        put(SB::e_w6 + ccol * F + (F - 1), bc6[rb]);
-                    }
-                }
-                put(SB::e_w2 + (F - 1) * F + f, br2[0]);                    // row 32, columns 0..31
-                put(SB::e_w6 + (F - 1) * F + f, br6[0]);
-                if (f < 16) put(SB::e_geo + (F - 1) * 16 + f, brg[0]);
-            }
-        }
-    }
-    slab_flush(sl, slab, SB::edge);
-}
-
 // ---------------------------------------------------------------------------------------
 // edge backward, MFMA formulation (hidden_nf == 32): one wave per 32-edge tile (egnn_mfma.h).
 // Forward recompute and the three transposed products (W6^T dq, W2^T du, Wgeo^T dt1) run on
@@ -1239,31 +969,15 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
                            const float* dagg, const float* Gx, float* dt1, float* gxr, float* gxc, float* slab,
                            hipStream_t s, int* n_slabs) {
     const int E = g->n_edges;
-    if constexpr (F == 32 || (F == 33 && H == 1)) {
-        const int tiles = ceil_div(E, 32);
-        // persistent waves: one workgroup per CU (the kernel runs at one wave per SIMD), each wave loops over
-        // its tiles -- the weight staging and the slab epilogue are paid 256 times, not once per 4 tiles
-        int blocks = ceil_div(tiles, 4);
-        blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
-        hipLaunchKernelGGL((edge_bwd_mfma_kernel<H, A, F - 32>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
-                           dagg, Gx, E, dt1, gxr, gxc, slab);
-        *n_slabs = blocks;
-    } else {
-        constexpr int LD = 35;
-        const int chunks = ceil_div(E, 256);
-        const int egrid = chunks < kEdgeBwdBlocks ? chunks : kEdgeBwdBlocks;
-        const size_t edge_smem = sizeof(float) * (size_t)4 * 2 * 64 * LD;
-        static bool attr_set = false;      // once per instantiation (first call happens outside any graph capture)
-        if (!attr_set) {
-            hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_bwd_kernel<F, H, A>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)edge_smem);
-            if (err != hipSuccess) { set_error("hipFuncSetAttribute(edge_bwd): %s", hipGetErrorString(err)); return (int)err; }
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((edge_bwd_kernel<F, H, A>), dim3(egrid), dim3(256), edge_smem, s, lw, g->row, g->col, edge_attr, x,
-                           P, dagg, Gx, E, dt1, gxr, gxc, slab);
-        *n_slabs = egrid;
-    }
+    static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1 or 4 heads) or 33 (1 head)");
+    const int tiles = ceil_div(E, 32);
+    // persistent waves: one workgroup per CU (the kernel runs at one wave per SIMD), each wave loops over
+    // its tiles -- the weight staging and the slab epilogue are paid 256 times, not once per 4 tiles
+    int blocks = ceil_div(tiles, 4);
+    blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+    hipLaunchKernelGGL((edge_bwd_mfma_kernel<H, A, F - 32>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
+                       dagg, Gx, E, dt1, gxr, gxc, slab);
+    *n_slabs = blocks;
     return 0;
 }
 
@@ -1383,7 +1097,7 @@ static BwdLayout bwd_layout(int F, int in_nf, int out_nf, int64_t N, int64_t E, 
     // slab sets: one per layer (layer l at + l * layer_stride), sized for the blocks this problem actually launches
     const int NS = 256 / (F <= 32 ? 32 : 64);
     const size_t node_blocks = std::min<size_t>((N + NS - 1) / NS, kNodeBwdBlocks);
-    const size_t edge_blocks = std::min<size_t>((F == 32 || F == 33) ? 256 : (size_t)((E + 255) / 256), kEdgeBwdBlocks);
+    const size_t edge_blocks = 256;                    // persistent edge_bwd grid: at most one workgroup per CU
     const size_t emb = (size_t)64 * F + 64;
     B.emb_slab = take(node_blocks * emb);
     B.emb_slab2 = take(node_blocks * emb);

@@ -214,75 +214,4 @@ __device__ __forceinline__ void project_pre(const float* __restrict__ lw, const 
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// edge kernel
-// ---------------------------------------------------------------------------------------
-template <int F, int H, int A>
-struct EdgeFwd {
-    using LL = LP<F, H, A>;
-    static constexpr int FH = F / H;
-
-    // forward of one edge up to s; fills the activations the backward needs when asked.
-    // t1: pre-activation of the first edge Linear; u -> xhat (normalised), m; q pre-activation.
-    __device__ static __forceinline__ void run(const float* __restrict__ lw, const float* __restrict__ prow,
-                                               const float* __restrict__ pcrow, const float geo[kGeo], float attr,
-                                               float t1[F], float xhat[F], float& rstd, float m[F], float q[F],
-                                               float& s) {
-        constexpr int FP = Geom<F>::FP;
-        // gather the two per-node projections (16-byte loads)
-        float pr[FP], pc[FP];
-#pragma unroll
-        for (int v = 0; v < FP / 4; ++v) {
-            const float4 a = reinterpret_cast<const float4*>(prow)[v];
-            const float4 b = reinterpret_cast<const float4*>(pcrow)[v];
-            pr[4 * v] = a.x; pr[4 * v + 1] = a.y; pr[4 * v + 2] = a.z; pr[4 * v + 3] = a.w;
-            pc[4 * v] = b.x; pc[4 * v + 1] = b.y; pc[4 * v + 2] = b.z; pc[4 * v + 3] = b.w;
-        }
-#pragma unroll
-        for (int o = 0; o < F; ++o) {
-            const float* w = lw + LL::w1_off(o, 2 * F);
-            float acc = pr[o] + pc[o];
-#pragma unroll
-            for (int g = 0; g < kGeo; ++g) acc = fmaf(w[g], geo[g], acc);
-            if (A) acc = fmaf(w[kGeo], attr, acc);
-            t1[o] = acc;
-        }
-        float g1[F];
-#pragma unroll
-        for (int o = 0; o < F; ++o) g1[o] = silu(t1[o]);
-        float u[F];
-        float mean = 0.0f;
-#pragma unroll
-        for (int o = 0; o < F; ++o) {
-            float acc = lw[LL::b2_off(o)];
-            const int hb = (o / FH) * FH;
-#pragma unroll
-            for (int i = 0; i < FH; ++i) acc = fmaf(lw[LL::w2_off(o, hb + i)], g1[hb + i], acc);
-            u[o] = acc;
-            mean += acc;
-        }
-        mean *= (1.0f / F);
-        float var = 0.0f;
-#pragma unroll
-        for (int o = 0; o < F; ++o) { const float c = u[o] - mean; var = fmaf(c, c, var); }
-        var *= (1.0f / F);
-        rstd = 1.0f / sqrtf(var + 1e-5f);
-#pragma unroll
-        for (int o = 0; o < F; ++o) {
-            xhat[o] = (u[o] - mean) * rstd;
-            m[o] = fmaf(xhat[o], lw[LL::ln_g + o], lw[LL::ln_b + o]);
-        }
-        s = 0.0f;
-#pragma unroll
-        for (int o = 0; o < F; ++o) {
-            float acc = lw[LL::b6 + o];
-#pragma unroll
-            for (int i = 0; i < F; ++i) acc = fmaf(lw[LL::w6 + o * F + i], m[i], acc);
-            q[o] = acc;
-            s = fmaf(lw[LL::w7 + o], silu(acc), s);
-        }
-    }
-};
-
-
 }  // namespace eq

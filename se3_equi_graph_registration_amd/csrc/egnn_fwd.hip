@@ -58,41 +58,8 @@ __global__ __launch_bounds__(256) void embed_in_kernel(const float* __restrict__
     }
 }
 
-template <int F, int H, int A>
-__global__ __launch_bounds__(256) void edge_fwd_kernel(const float* __restrict__ lw, const int* __restrict__ row,
-                                                       const int* __restrict__ col, const float* __restrict__ edge_attr,
-                                                       const float* __restrict__ x, const float* __restrict__ P,
-                                                       int n_edges, float* __restrict__ m_out,
-                                                       float* __restrict__ trans_out) {
-    constexpr int FP = Geom<F>::FP, PS = Geom<F>::PS;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n_edges) return;
-    const int r = row[e], c = col[e];
-    float xr[3], xc[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { xr[i] = x[(size_t)r * 3 + i]; xc[i] = x[(size_t)c * 3 + i]; }
-    EdgeGeo eg;
-    edge_geometry(xr, xc, eg);
-    const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
-    float t1[F], xhat[F], m[F], q[F], rstd, s;
-    EdgeFwd<F, H, A>::run(lw, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg.g, attr, t1, xhat, rstd, m, q, s);
-    float4* mo = reinterpret_cast<float4*>(m_out + (size_t)e * FP);
-#pragma unroll
-    for (int v = 0; v < FP / 4; ++v) {
-        float4 o;
-        o.x = m[4 * v];
-        o.y = (4 * v + 1 < F) ? m[(4 * v + 1 < F) ? 4 * v + 1 : 0] : 0.0f;
-        o.z = (4 * v + 2 < F) ? m[(4 * v + 2 < F) ? 4 * v + 2 : 0] : 0.0f;
-        o.w = (4 * v + 3 < F) ? m[(4 * v + 3 < F) ? 4 * v + 3 : 0] : 0.0f;
-        mo[v] = o;
-    }
-    float4 tr;
-    tr.x = eg.d[0] * s; tr.y = eg.d[1] * s; tr.z = eg.d[2] * s; tr.w = 0.0f;      // :264
-    reinterpret_cast<float4*>(trans_out)[e] = tr;
-}
-
 // ---------------------------------------------------------------------------------------
-// edge kernel, MFMA formulation (hidden_nf == 32): one wave per 32-edge tile, weights in VGPRs
+// edge kernel, MFMA formulation (hidden_nf = 32 + B): one wave per 32-edge tile
 // ---------------------------------------------------------------------------------------
 template <int H, int A, int B = 0>
 __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restrict__ lw, const int* __restrict__ row,
@@ -141,16 +108,12 @@ template <int F, int H, int A>
 static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
                             float* m, float* trans, hipStream_t s) {
     const int E = g->n_edges;
-    if constexpr (F == 32 || (F == 33 && H == 1)) {
-        const int tiles = ceil_div(E, 32);
-        int blocks = ceil_div(tiles, 4);          // one 32-edge tile per wave: latency is hidden across waves
-        blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-        hipLaunchKernelGGL((edge_fwd_mfma_kernel<H, A, F - 32>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
-                           E, m, trans);
-    } else {
-        hipLaunchKernelGGL((edge_fwd_kernel<F, H, A>), dim3(ceil_div(E, 256)), dim3(256), 0, s, lw, g->row, g->col,
-                           edge_attr, x, P, E, m, trans);
-    }
+    static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1 or 4 heads) or 33 (1 head)");
+    const int tiles = ceil_div(E, 32);
+    int blocks = ceil_div(tiles, 4);          // one 32-edge tile per wave: latency is hidden across waves
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL((edge_fwd_mfma_kernel<H, A, F - 32>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
+                       E, m, trans);
 }
 
 // ---------------------------------------------------------------------------------------
