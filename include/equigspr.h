@@ -27,7 +27,7 @@ extern "C" {
 
 #define EQUIGSPR_EINVAL   (-1)  /* bad shape / size / null pointer                         */
 #define EQUIGSPR_ENOTSUP  (-2)  /* configuration outside the compiled kernel set             */
-#define EQUIGSPR_ABI_VERSION 1
+#define EQUIGSPR_ABI_VERSION 2
 
 /* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
  * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
@@ -56,6 +56,9 @@ typedef struct equigspr_graph {
     const int32_t* rperm;  /* [E] */
     const int32_t* cptr;   /* [N+1] */
     const int32_t* cperm;  /* [E] */
+    const int32_t* rinv;   /* [E] inverse of rperm (equigspr_invert_perm): position of edge e in the by-row order.  The edge
+                              kernels store per-edge rows AT that position, so the node kernels stream each node's segment
+                              [rptr[j], rptr[j+1]) contiguously instead of gathering 128-byte rows through rperm. */
 } equigspr_graph;
 
 int         equigspr_abi_version(void);
@@ -96,6 +99,8 @@ int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, int32_t k, i
  *   key [E] global ids in [0,N);  ptr [N+1];  perm [E];  scratch: int32 [N+1]. */
 int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n_nodes,
                        int32_t* ptr, int32_t* perm, int32_t* scratch, void* stream);
+/* inv[perm[p]] = p for p in [0, n): the rinv field of equigspr_graph from rperm */
+int equigspr_invert_perm(const int32_t* perm, int32_t n, int32_t* inv, void* stream);
 /* int64 reference edge list [2,E] (one cloud, local ids) -> int32 global ids (+node_offset) */
 int equigspr_edges_i64_to_i32(const int64_t* edges_i64, int32_t n_edges, int32_t node_offset,
                               int32_t* row32, int32_t* col32, void* stream);

@@ -24,7 +24,7 @@ class EgnnConfig(Structure):
 
 class Graph(Structure):
     _fields_ = [("n_nodes", c_int32), ("n_edges", c_int32), ("row", c_void_p), ("col", c_void_p),
-                ("rptr", c_void_p), ("rperm", c_void_p), ("cptr", c_void_p), ("cperm", c_void_p)]
+                ("rptr", c_void_p), ("rperm", c_void_p), ("cptr", c_void_p), ("cperm", c_void_p), ("rinv", c_void_p)]
 
 
 _SIGNATURES = {
@@ -35,6 +35,7 @@ _SIGNATURES = {
     "equigspr_knn_graph": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                           c_void_p, c_int32, c_void_p]),
     "equigspr_build_csr": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "equigspr_invert_perm": (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
     "equigspr_edges_i64_to_i32": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "equigspr_egnn_saved_size": (c_int64, [POINTER(EgnnConfig), c_int32]),
     "equigspr_egnn_work_size": (c_int64, [POINTER(EgnnConfig), c_int32, c_int32]),
@@ -102,7 +103,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if L.equigspr_abi_version() != 1:
+        if L.equigspr_abi_version() != 2:
             raise RuntimeError("libequigspr.so ABI version mismatch")
         _lib = L
     return _lib

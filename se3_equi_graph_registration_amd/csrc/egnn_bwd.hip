@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void embed_in_bwd_kernel(const float* __restri
 // node-MLP backward (+ re-projection of P for the edge recompute)
 // ---------------------------------------------------------------------------------------
 template <int F, int H, int A>
-__global__ __launch_bounds__(256) void node_bwd_kernel(const float* __restrict__ lw, const float* __restrict__ Gh,
+__global__ __launch_bounds__(256, 3) void node_bwd_kernel(const float* __restrict__ lw, const float* __restrict__ Gh,
                                                        const float* __restrict__ h, const float* __restrict__ agg,
                                                        int n_nodes, float* __restrict__ dh_part,
                                                        float* __restrict__ dagg, float* __restrict__ P,

@@ -48,6 +48,25 @@ __device__ __forceinline__ void segment_sum(const int* __restrict__ perm, int lo
     }
 }
 
+// The same sum over rows that already lie in segment order (the edge kernels store at rinv[e]): rows lo..hi-1 are
+// contiguous, so there is no index load and every wave-level load is one or two full 128-byte lines.  Same ascending
+// order of additions as segment_sum.
+template <int G, int D = 16>
+__device__ __forceinline__ void segment_sum_sorted(int lo, int hi, const float* __restrict__ data, int stride,
+                                                   const float* __restrict__ data3, int f, bool f_active, float& acc, float& acc3) {
+    for (int a0 = lo; a0 < hi; a0 += D) {
+        float v[D], w[D];
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const bool in = (a0 + u) < hi;
+            v[u] = (in && f_active) ? data[(size_t)(a0 + u) * stride + f] : 0.0f;
+            w[u] = (in && f < 3) ? data3[(size_t)(a0 + u) * 4 + f] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < D; ++u) { acc += v[u]; acc3 += w[u]; }
+    }
+}
+
 // Two segments of the same node at once (gather_bwd: the edges where it is the neighbour and those where it is the centre):
 // both index loads and 2 x 8 row loads are in flight together instead of one segment after the other.  Each segment is
 // still summed in ascending position order into its own accumulators.

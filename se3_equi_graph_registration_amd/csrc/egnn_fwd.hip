@@ -65,7 +65,7 @@ template <int H, int A, int B = 0>
 __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restrict__ lw, const int* __restrict__ row,
                                                             const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                             const float* __restrict__ x, const float* __restrict__ P,
-                                                            int n_edges, float* __restrict__ m_out,
+                                                            const int* __restrict__ rinv, int n_edges, float* __restrict__ m_out,
                                                             float* __restrict__ trans_out) {
     constexpr int FP = 32 + 4 * B, PS = 2 * FP;          // hidden_nf = 32 + B, rows padded to 16 bytes
     const int lane = threadIdx.x & 63, el = lane & 31, h = lane >> 5;
@@ -95,10 +95,12 @@ __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restr
         TileFwd o;
         tile_forward<H, A, false, B>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
         if (valid) {
-            store_half_row(m_out + (size_t)e * FP, h, o.m);
-            if (B) store_border(m_out + (size_t)e * FP, h, o.mb);
+            // stored at the edge's position in the by-row (aggregation) order: node_fwd then streams its segment contiguously
+            const size_t at = (size_t)rinv[e];
+            store_half_row(m_out + at * FP, h, o.m);
+            if (B) store_border(m_out + at * FP, h, o.mb);
             if (h == 0)
-                reinterpret_cast<float4*>(trans_out)[e] = make_float4(eg.d[0] * o.s, eg.d[1] * o.s, eg.d[2] * o.s, 0.0f);   // :264
+                reinterpret_cast<float4*>(trans_out)[at] = make_float4(eg.d[0] * o.s, eg.d[1] * o.s, eg.d[2] * o.s, 0.0f);   // :264
         }
         EQ_STAMP(7);
     }
@@ -113,14 +115,14 @@ static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const floa
     int blocks = ceil_div(tiles, 4);          // one 32-edge tile per wave: latency is hidden across waves
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
     hipLaunchKernelGGL((edge_fwd_mfma_kernel<H, A, F - 32>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
-                       E, m, trans);
+                       g->rinv, E, m, trans);
 }
 
 // ---------------------------------------------------------------------------------------
 // node kernel
 // ---------------------------------------------------------------------------------------
 template <int F, int H, int A>
-__global__ __launch_bounds__(256) void node_fwd_kernel(
+__global__ __launch_bounds__(256, 3) void node_fwd_kernel(
     const float* __restrict__ lw,        // this layer's block
     const float* __restrict__ next_lw,   // next layer's block (projections) or nullptr on the last layer
     const float* __restrict__ w_out, const float* __restrict__ b_out, int out_nf,   // embedding_out (last layer)
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256) void node_fwd_kernel(
         if (live) {
             const int lo = rptr[j], hi = rptr[j + 1];
             if (f < F) hj = h[(size_t)j * FP + f];
-            segment_sum<G, true>(rperm, lo, hi, m_in, FP, trans_in, f, f < F, agg, xagg);   // ascending edge id
+            segment_sum_sorted<G>(lo, hi, m_in, FP, trans_in, f, f < F, agg, xagg);         // rows lo..hi-1 = ascending edge id
             if (f < 3) x_next[(size_t)j * 3 + f] = x[(size_t)j * 3 + f] + xagg;              // :267
         }
         EQ_STAMPK(1, 2);
@@ -317,7 +319,7 @@ extern "C" int equigspr_egnn_forward(const equigspr_egnn_config* cfg, const floa
     EQ_CHECK_ARG(config_supported(cfg), EQUIGSPR_ENOTSUP,
                  "egnn_forward: unsupported config (hidden_nf in {32,33}, heads in {1,4}, in/out<=64, in_edge_nf in {0,1})");
     EQ_CHECK_ARG(params && g && h_in && x_in && h_out && x_out && work, EQUIGSPR_EINVAL, "egnn_forward: null pointer");
-    EQ_CHECK_ARG(g->n_nodes >= 1 && g->n_edges >= 0 && g->row && g->col && g->rptr && g->rperm, EQUIGSPR_EINVAL,
+    EQ_CHECK_ARG(g->n_nodes >= 1 && g->n_edges >= 0 && g->row && g->col && g->rptr && g->rperm && g->rinv, EQUIGSPR_EINVAL,
                  "egnn_forward: incomplete graph");
     hipStream_t s = (hipStream_t)stream;
     const int F = cfg->hidden_nf, H = cfg->num_heads, A = cfg->in_edge_nf;

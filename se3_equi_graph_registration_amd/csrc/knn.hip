@@ -359,6 +359,22 @@ extern "C" int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n
     return 0;
 }
 
+namespace eq {
+__global__ void invert_perm_kernel(const int* __restrict__ perm, int n, int* __restrict__ inv) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) inv[perm[p]] = p;
+}
+}  // namespace eq
+
+extern "C" int equigspr_invert_perm(const int32_t* perm, int32_t n, int32_t* inv, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(perm && inv && n >= 0, EQUIGSPR_EINVAL, "invert_perm: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(invert_perm_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, perm, n, inv);
+    EQ_CHECK_LAUNCH("invert_perm");
+    return 0;
+}
+
 extern "C" int equigspr_edges_i64_to_i32(const int64_t* edges_i64, int32_t n_edges, int32_t node_offset,
                                          int32_t* row32, int32_t* col32, void* stream) {
     using namespace eq;

@@ -79,6 +79,8 @@ class DeviceGraph:
         self.rperm = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
         _lib.check(L.equigspr_build_csr(_p(self.row), self.n_edges, self.n_nodes, _p(self.rptr), _p(self.rperm),
                                         _p(scratch), _stream()), "build_csr(row)")
+        self.rinv = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
+        _lib.check(L.equigspr_invert_perm(_p(self.rperm), self.n_edges, _p(self.rinv), _stream()), "invert_perm")
         self.cptr = self.cperm = None
         if need_col_index:
             if knn_k is not None:      # centre-major kNN list: the col index is the identity permutation (cached)
@@ -97,7 +99,7 @@ class DeviceGraph:
         self.struct = Graph(self.n_nodes, self.n_edges, self.row.data_ptr(), self.col.data_ptr(),
                             self.rptr.data_ptr(), self.rperm.data_ptr(),
                             self.cptr.data_ptr() if self.cptr is not None else None,
-                            self.cperm.data_ptr() if self.cperm is not None else None)
+                            self.cperm.data_ptr() if self.cperm is not None else None, self.rinv.data_ptr())
 
     @staticmethod
     def from_edge_lists(edge_lists, n_per_cloud: int, need_col_index: bool = True) -> "DeviceGraph":
