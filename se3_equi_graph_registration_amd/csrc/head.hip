@@ -291,6 +291,19 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
 constexpr int kRowsPerBlock = 16;
 constexpr int kMaxIn = 128, kMaxH1 = 64, kMaxH2 = 32;
 
+// global -> LDS staging with 8 loads of a thread in flight before its 8 stores (a load/store pair per iteration exposes
+// one L2 round trip per element; the MLP blocks are latency-bound single workgroups)
+template <typename SrcIdx, typename DstIdx>
+__device__ __forceinline__ void stage8(float* dst, const float* __restrict__ src, int n, SrcIdx si, DstIdx di) {
+    for (int t0 = threadIdx.x; t0 < n; t0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int t = t0 + 256 * k; v[k] = (t < n) ? src[si(t)] : 0.0f; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int t = t0 + 256 * k; if (t < n) dst[di(t)] = v[k]; }
+    }
+}
+
 __global__ __launch_bounds__(256) void head_mlp_kernel(
     const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
     const long long* __restrict__ top_idx, const float* __restrict__ w1, const float* __restrict__ b1,
@@ -311,8 +324,8 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(
     const int Kb = min(kRowsPerBlock, K - j0);
     const int ld_in = md.in + 1, ld1 = md.h1 + 1, ld2 = md.h2 + 1;
     const float* yb = labels + (size_t)b * N;
-    for (int t = tid; t < md.h1 * md.in; t += 256) { const int o = t / md.in, i = t - o * md.in; W1[i * ld1 + o] = w1[t]; }
-    for (int t = tid; t < md.h2 * md.h1; t += 256) { const int o = t / md.h1, i = t - o * md.h1; W2[i * ld2 + o] = w2[t]; }
+    stage8(W1, w1, md.h1 * md.in, [](int t) { return t; }, [&](int t) { const int o = t / md.in; return (t - o * md.in) * ld1 + o; });
+    stage8(W2, w2, md.h2 * md.h1, [](int t) { return t; }, [&](int t) { const int o = t / md.h1; return (t - o * md.h1) * ld2 + o; });
     for (int t = tid; t < md.h2; t += 256) W3[t] = w3[t];
     for (int t = tid; t < md.h1; t += 256) Bs[t] = b1[t];
     for (int t = tid; t < md.h2; t += 256) Bs[md.h1 + t] = b2[t];
@@ -435,8 +448,8 @@ __global__ __launch_bounds__(256) void head_pair_bwd_kernel(
         gwu = block_sum_d(gwu, red);
         if (tid == 0) pair_g[b] = (float)gwu;
     }
-    for (int t = tid; t < md.h1 * md.in; t += 256) W1[t] = w1[t];
-    for (int t = tid; t < md.h2 * md.h1; t += 256) W2[t] = w2[t];
+    stage8(W1, w1, md.h1 * md.in, [](int t) { return t; }, [](int t) { return t; });
+    stage8(W2, w2, md.h2 * md.h1, [](int t) { return t; }, [](int t) { return t; });
     for (int t = tid; t < md.h2; t += 256) W3[t] = w3[t];
     if (tid < Kb) idxs[tid] = (int)top_idx[(size_t)b * K + j0 + tid];
     __syncthreads();
