@@ -1239,7 +1239,7 @@ extern "C" int equigspr_egnn_backward(const equigspr_egnn_config* cfg, const flo
     EQ_CHECK_ARG(config_supported(cfg), EQUIGSPR_ENOTSUP, "egnn_backward: unsupported config");
     EQ_CHECK_ARG(params && g && h_in && saved && grad_h_out && grad_x_out && grad_params && work, EQUIGSPR_EINVAL,
                  "egnn_backward: null pointer");
-    EQ_CHECK_ARG(g->n_nodes >= 1 && g->n_edges >= 0 && g->row && g->col && g->rptr && g->rperm && g->cptr && g->cperm,
+    EQ_CHECK_ARG(g->n_nodes >= 1 && g->n_edges >= 0 && g->rptr && g->cptr && (g->n_edges == 0 || (g->row && g->col && g->rperm && g->cperm)),
                  EQUIGSPR_EINVAL, "egnn_backward: incomplete graph (needs row and col inverse indices)");
     hipStream_t s = (hipStream_t)stream;
     const int F = cfg->hidden_nf, H = cfg->num_heads, A = cfg->in_edge_nf;

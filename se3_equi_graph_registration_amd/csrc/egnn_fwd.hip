@@ -319,7 +319,7 @@ extern "C" int equigspr_egnn_forward(const equigspr_egnn_config* cfg, const floa
     EQ_CHECK_ARG(config_supported(cfg), EQUIGSPR_ENOTSUP,
                  "egnn_forward: unsupported config (hidden_nf in {32,33}, heads in {1,4}, in/out<=64, in_edge_nf in {0,1})");
     EQ_CHECK_ARG(params && g && h_in && x_in && h_out && x_out && work, EQUIGSPR_EINVAL, "egnn_forward: null pointer");
-    EQ_CHECK_ARG(g->n_nodes >= 1 && g->n_edges >= 0 && g->row && g->col && g->rptr && g->rperm && g->rinv, EQUIGSPR_EINVAL,
+    EQ_CHECK_ARG(g->n_nodes >= 1 && g->n_edges >= 0 && g->rptr && (g->n_edges == 0 || (g->row && g->col && g->rperm && g->rinv)), EQUIGSPR_EINVAL,
                  "egnn_forward: incomplete graph");
     hipStream_t s = (hipStream_t)stream;
     const int F = cfg->hidden_nf, H = cfg->num_heads, A = cfg->in_edge_nf;

@@ -339,7 +339,7 @@ extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, i
 extern "C" int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n_nodes, int32_t* ptr,
                                   int32_t* perm, int32_t* scratch, void* stream) {
     using namespace eq;
-    EQ_CHECK_ARG(key && ptr && perm && scratch, EQUIGSPR_EINVAL, "build_csr: null pointer");
+    EQ_CHECK_ARG(ptr && scratch && (n_edges == 0 || (key && perm)), EQUIGSPR_EINVAL, "build_csr: null pointer");
     EQ_CHECK_ARG(n_edges >= 0 && n_nodes >= 1, EQUIGSPR_EINVAL, "build_csr: bad sizes");
     hipStream_t s = (hipStream_t)stream;
     // (a single-block LDS count+scan was tried instead of memset + count + scan: 25 us vs ~12 us -- one block cannot hide
@@ -368,8 +368,8 @@ __global__ void invert_perm_kernel(const int* __restrict__ perm, int n, int* __r
 
 extern "C" int equigspr_invert_perm(const int32_t* perm, int32_t n, int32_t* inv, void* stream) {
     using namespace eq;
-    EQ_CHECK_ARG(perm && inv && n >= 0, EQUIGSPR_EINVAL, "invert_perm: bad arguments");
     if (n == 0) return 0;
+    EQ_CHECK_ARG(perm && inv && n > 0, EQUIGSPR_EINVAL, "invert_perm: bad arguments");
     hipLaunchKernelGGL(invert_perm_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, perm, n, inv);
     EQ_CHECK_LAUNCH("invert_perm");
     return 0;
@@ -378,8 +378,8 @@ extern "C" int equigspr_invert_perm(const int32_t* perm, int32_t n, int32_t* inv
 extern "C" int equigspr_edges_i64_to_i32(const int64_t* edges_i64, int32_t n_edges, int32_t node_offset,
                                          int32_t* row32, int32_t* col32, void* stream) {
     using namespace eq;
-    EQ_CHECK_ARG(edges_i64 && row32 && col32 && n_edges >= 0, EQUIGSPR_EINVAL, "edges_i64_to_i32: bad args");
-    if (n_edges == 0) return 0;
+    if (n_edges == 0) return 0;                      // an empty edge list has no storage to point at
+    EQ_CHECK_ARG(edges_i64 && row32 && col32 && n_edges > 0, EQUIGSPR_EINVAL, "edges_i64_to_i32: bad args");
     hipLaunchKernelGGL(edges_i64_to_i32_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const long long*>(edges_i64), n_edges, node_offset, row32, col32);
     EQ_CHECK_LAUNCH("edges_i64_to_i32");

@@ -104,8 +104,8 @@ extern "C" int equigspr_pointnet_layer_forward(const float* h, const float* pos,
                                                const float* b1, const float* w2, const float* b2, int32_t relu_out, float* work,
                                                float* out, void* stream) {
     using namespace eq;
-    EQ_CHECK_ARG(h && pos && src && tptr && w1 && b1 && w2 && b2 && work && out && n_nodes >= 1, EQUIGSPR_EINVAL,
-                 "pointnet_layer_forward: bad arguments");
+    EQ_CHECK_ARG(h && pos && tptr && w1 && b1 && w2 && b2 && work && out && n_nodes >= 1, EQUIGSPR_EINVAL,
+                 "pointnet_layer_forward: bad arguments");           // src may be NULL for a graph without edges
     EQ_CHECK_ARG(c_in >= 1 && c_in <= kPnMax && c_out >= 1 && c_out <= kPnMax, EQUIGSPR_ENOTSUP,
                  "pointnet_layer_forward: channels must be in [1, 64]");
     hipStream_t s = (hipStream_t)stream;

@@ -730,3 +730,53 @@ def test_build_correspondences_vs_oracle(pk, n, m, dim, mutual):
         assert np.array_equal(corr.cpu().numpy(), corr_o)
         assert np.array_equal(labels.cpu().numpy(), labels_o)
         assert 0 < labels_o.sum() < labels_o.size or n < 10
+
+
+def test_egnn_degenerate_graphs_vs_oracle(pk):
+    """Edge cases of the graph input: no edges at all (every node isolated), a single node, one self loop."""
+    torch.manual_seed(3)
+    m = pk.EGNN(32, 32, 32, in_edge_nf=1, device="cuda", n_layers=2)
+    w64 = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    cases = [(17, torch.zeros(2, 0, dtype=torch.int64)), (1, torch.zeros(2, 0, dtype=torch.int64)),
+             (1, torch.zeros(2, 1, dtype=torch.int64)), (5, torch.tensor([[0, 1, 1, 4], [1, 0, 1, 4]]))]
+    for n, edges in cases:
+        h = torch.randn(n, 32, generator=g)
+        x = torch.rand(n, 3, generator=g)
+        ea = torch.ones(edges.shape[1], 1)
+        rh, rx = orc.egnn_forward(w64, h.double(), x.double(), [edges[0], edges[1]], ea.double())
+        with torch.no_grad():
+            gh, gx = m(h.cuda(), x.cuda(), [edges[0].cuda(), edges[1].cuda()], ea.cuda())
+        assert torch.allclose(gh.cpu().double(), rh, rtol=1e-4, atol=1e-5) and torch.allclose(gx.cpu().double(), rx, rtol=1e-4, atol=1e-5)
+    # and the backward on the empty graph: finite gradients equal to the oracle's autograd
+    h = torch.randn(9, 32, generator=g); x = torch.rand(9, 3, generator=g)
+    edges = torch.zeros(2, 0, dtype=torch.int64)
+    wref = {k: v.clone().requires_grad_(True) for k, v in w64.items()}
+    rh, rx = orc.egnn_forward(wref, h.double(), x.double(), [edges[0], edges[1]], torch.ones(0, 1, dtype=torch.float64))
+    (rh.sum() + rx.sum()).backward()
+    m.zero_grad()
+    gh, gx = m(h.cuda(), x.cuda(), [edges[0].cuda(), edges[1].cuda()], torch.ones(0, 1).cuda())
+    (gh.sum() + gx.sum()).backward()
+    for k, p in m.named_parameters():
+        ref = wref[k].grad if wref[k].grad is not None else torch.zeros_like(wref[k])
+        assert torch.allclose(p.grad.cpu().double(), ref, rtol=1e-4, atol=1e-5), k
+
+
+def test_tiny_inputs(pk):
+    """Smallest legal inputs: one-point cloud, k == n, one descriptor, one correspondence, a PointNet graph without edges."""
+    one = torch.rand(1, 3)
+    assert torch.equal(pk.knn_graph(one.cuda(), 1, loop=True).cpu(), torch.zeros(2, 1, dtype=torch.int64))
+    x = torch.rand(7, 3, generator=torch.Generator().manual_seed(0))
+    assert torch.equal(pk.knn_graph(x.cuda(), 7, loop=True).cpu(), orc.knn_graph(x, 7, loop=True))
+    assert torch.equal(pk.knn_graph(x.cuda(), 6, loop=False).cpu(), orc.knn_graph(x, 6, loop=False))
+    idx, dist = pk.match_descriptors(torch.tensor([[1.0, 0.0]]).cuda(), torch.tensor([[0.6, 0.8]]).cuda())
+    assert idx.tolist() == [0] and abs(float(dist[0]) - (2 - 1.2 + 1e-6) ** 0.5) < 1e-6
+    corr, labels, _ = pk.build_correspondences(torch.tensor([[1.0, 0.0]]).cuda(), torch.tensor([[1.0, 0.0]]).cuda(), one.cuda(), one.cuda(),
+                                               torch.eye(4).cuda())
+    assert corr.tolist() == [[0, 0]] and labels.tolist() == [1]
+    R, t = pk.weighted_kabsch(x[None].cuda(), x[None].cuda(), torch.ones(1, 7).cuda())
+    assert torch.allclose(R.cpu(), torch.eye(3)[None], atol=1e-5) and torch.allclose(t.cpu(), torch.zeros(1, 3), atol=1e-5)
+    net = pk.PointNetLayer(3, 8).cuda()
+    with torch.no_grad():
+        out = net(x.cuda(), x.cuda(), torch.zeros(2, 0, dtype=torch.int64).cuda())
+    assert out.shape == (7, 8) and float(out.abs().max()) == 0.0          # no incoming edges: PyG's max-aggregation fill
