@@ -8,6 +8,10 @@
 
 namespace eq {
 
+// torch.clamp semantics: NaN propagates (fminf/fmaxf would turn it into a bound) -- e.g. the translation-direction cosine
+// of a zero translation (a pair without any valid correspondence gets R = I, t = 0, train :708-711) is NaN in the reference
+__device__ __forceinline__ float clamp_unit(float v) { return (v != v) ? v : fminf(fmaxf(v, -1.0f), 1.0f); }
+
 __global__ void pose_loss_fwd_kernel(const float* __restrict__ R, const float* __restrict__ t, const float* __restrict__ gt_pose,
                                      int B, float* __restrict__ rot_loss, float* __restrict__ trans_loss) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -19,12 +23,12 @@ __global__ void pose_loss_fwd_kernel(const float* __restrict__ R, const float* _
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) tr = fmaf(Rb[i * 3 + j], G[i * 4 + j], tr);          // trace(R^T R_gt)
-    rot_loss[b] = acosf(fminf(fmaxf((tr - 1.0f) * 0.5f, -1.0f), 1.0f));
+    rot_loss[b] = acosf(clamp_unit((tr - 1.0f) * 0.5f));
     float dp = 0.0f, nt = 0.0f, ng = 0.0f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) { const float a = t[b * 3 + i], g = G[i * 4 + 3]; dp = fmaf(a, g, dp); nt = fmaf(a, a, nt); ng = fmaf(g, g, ng); }
     const float c = dp / (sqrtf(nt) * sqrtf(ng));
-    trans_loss[b] = acosf(fminf(fmaxf(c, -1.0f), 1.0f));
+    trans_loss[b] = acosf(clamp_unit(c));
 }
 
 __global__ void pose_loss_bwd_kernel(const float* __restrict__ R, const float* __restrict__ t, const float* __restrict__ gt_pose,
@@ -74,11 +78,11 @@ __global__ __launch_bounds__(256) void step_loss_fwd_kernel(const float* __restr
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) tr = fmaf(Rb[i * 3 + j], G[i * 4 + j], tr);
-        const float rl = acosf(fminf(fmaxf((tr - 1.0f) * 0.5f, -1.0f), 1.0f));
+        const float rl = acosf(clamp_unit((tr - 1.0f) * 0.5f));
         float dp = 0.0f, nt = 0.0f, ng = 0.0f;
 #pragma unroll
         for (int i = 0; i < 3; ++i) { const float a = t[b * 3 + i], g = G[i * 4 + 3]; dp = fmaf(a, g, dp); nt = fmaf(a, a, nt); ng = fmaf(g, g, ng); }
-        const float tl = acosf(fminf(fmaxf(dp / (sqrtf(nt) * sqrtf(ng)), -1.0f), 1.0f));
+        const float tl = acosf(clamp_unit(dp / (sqrtf(nt) * sqrtf(ng))));
         rot_loss[b] = rl; trans_loss[b] = tl;
         ar += rl; at += tl;
     }

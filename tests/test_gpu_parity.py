@@ -780,3 +780,21 @@ def test_tiny_inputs(pk):
     with torch.no_grad():
         out = net(x.cuda(), x.cuda(), torch.zeros(2, 0, dtype=torch.int64).cuda())
     assert out.shape == (7, 8) and float(out.abs().max()) == 0.0          # no incoming edges: PyG's max-aggregation fill
+
+
+def test_pair_without_valid_correspondences_matches_reference_semantics(pk):
+    """labels == 0 for a whole pair: the reference sets R = I, t = 0 (train :708-711) and its pose loss then divides by |t| = 0:
+    the loss is NaN there, and here (torch.clamp propagates NaN); the other pair of the batch is unaffected."""
+    torch.manual_seed(0)
+    egnn = pk.EGNN(32, 32, 32, in_edge_nf=1, device="cuda", n_layers=2)
+    model = pk.CrossAttentionPoseRegression(egnn, num_nodes=256, hidden_nf=32, device="cuda").cuda()
+    b = pk.synthetic_batch(5, 2, n=256, feat=32, device="cuda")
+    b["labels"][0] = 0
+    graph = pk.build_pair_graph(b["src"], b["tgt"], 8)
+    with torch.no_grad():
+        out = model(b["feat_src"], b["src"], graph, None, b["feat_tgt"], b["tgt"], graph, None, b["corr"], b["labels"], b["gt_pose"])
+        loss, rl, tl = pk.registration_loss(out[0], out[1], out[2], b["gt_pose"])
+    assert torch.equal(out[0][0].cpu(), torch.eye(3)) and torch.equal(out[1][0].cpu(), torch.zeros(3))
+    o_rl, o_tl = orc.pose_loss(out[0].cpu(), out[1].cpu(), b["gt_pose"].cpu())
+    assert torch.isnan(o_tl[0]) and torch.isnan(tl[0]) and torch.isnan(loss)
+    assert torch.allclose(rl.cpu(), o_rl, atol=1e-5) and torch.allclose(tl[1].cpu(), o_tl[1], atol=1e-5)
