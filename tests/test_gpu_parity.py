@@ -336,17 +336,19 @@ def test_train_step_gradients_golden(pk, golden_dir):
     assert checked > 20
 
 
-def test_backward_random_graph_vs_oracle_autograd(pk):
-    """Non-kNN edge list (hub, isolated nodes, self loops, multi-edges), random edge_attr, 3 layers, 4 heads."""
+@pytest.mark.parametrize("feat,heads,in_nf,out_nf", [(32, 4, 32, 32), (33, 1, 33, 33), (33, 1, 17, 40), (32, 1, 5, 64)])
+def test_backward_random_graph_vs_oracle_autograd(pk, feat, heads, in_nf, out_nf):
+    """Non-kNN edge list (hub, isolated nodes, self loops, multi-edges), random edge_attr, 3 layers; both hidden widths
+    (33 = the MFMA kernels' border path), 1 and 4 heads, embedding widths that differ from the hidden width."""
     g = torch.Generator().manual_seed(33)
     n, e = 257, 3001
     torch.manual_seed(9)
-    m = pk.EGNN(32, 32, 32, in_edge_nf=1, device="cuda", n_layers=3, num_heads=4)
-    h = torch.randn(n, 32, generator=g); x = torch.rand(n, 3, generator=g) * 2
+    m = pk.EGNN(in_nf, feat, out_nf, in_edge_nf=1, device="cuda", n_layers=3, num_heads=heads)
+    h = torch.randn(n, in_nf, generator=g); x = torch.rand(n, 3, generator=g) * 2
     row = torch.randint(0, n - 7, (e,), generator=g); col = torch.randint(0, n - 7, (e,), generator=g)
     row[:40] = 3; row[40:45] = col[40:45]
     ea = torch.rand(e, 1, generator=g)
-    gh = torch.randn(n, 32, generator=g); gx = torch.randn(n, 3, generator=g)
+    gh = torch.randn(n, out_nf, generator=g); gx = torch.randn(n, 3, generator=g)
     refs = {}
     for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
         w = {k: v.detach().cpu().to(dt).requires_grad_(True) for k, v in m.state_dict().items()}
@@ -354,8 +356,11 @@ def test_backward_random_graph_vs_oracle_autograd(pk):
         ho, xo = orc.egnn_forward(w, hh, xx, [row, col], ea.to(dt))
         ((ho * gh.to(dt)).sum() + (xo * gx.to(dt)).sum()).backward()
         refs[tag] = dict(h=hh.grad.numpy(), x=xx.grad.numpy(), **{k: v.grad.numpy() for k, v in w.items()})
+        refs[tag + "_out"] = (ho.detach().numpy(), xo.detach().numpy())
     hc = h.cuda().requires_grad_(True); xc = x.cuda().requires_grad_(True)
     ho, xo = m(hc, xc, [row.cuda(), col.cuda()], ea.cuda())
+    for got, a32, a64 in zip((ho, xo), refs["f32_out"], refs["f64_out"]):
+        assert np.abs(got.detach().cpu().numpy() - a64).max() <= anchored_tol(a32, a64)
     m.zero_grad()
     ((ho * gh.cuda()).sum() + (xo * gx.cuda()).sum()).backward()
     _grad_check(hc.grad, refs["f32"]["h"], refs["f64"]["h"], "grad_h")
