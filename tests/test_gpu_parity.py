@@ -803,3 +803,32 @@ def test_pair_without_valid_correspondences_matches_reference_semantics(pk):
     o_rl, o_tl = orc.pose_loss(out[0].cpu(), out[1].cpu(), b["gt_pose"].cpu())
     assert torch.isnan(o_tl[0]) and torch.isnan(tl[0]) and torch.isnan(loss)
     assert torch.allclose(rl.cpu(), o_rl, atol=1e-5) and torch.allclose(tl[1].cpu(), o_tl[1], atol=1e-5)
+
+
+@pytest.mark.parametrize("feat,B,n,k,scale", [(32, 3, 1000, 7, 3.0), (33, 2, 777, 9, 60.0), (32, 1, 130, 5, 1.0)])
+def test_pair_train_head_odd_shapes_vs_oracle(pk, feat, B, n, k, scale):
+    """Shapes that are not multiples of any tile size (points, k, batch), KITTI-scale coordinates, both hidden widths:
+    R, t, the correspondence loss, the equi loss and the top-k index sets against the oracle."""
+    torch.manual_seed(1)
+    egnn = pk.EGNN(feat, feat, feat, in_edge_nf=1, device="cuda", n_layers=2)
+    with torch.no_grad():
+        egnn.embedding_out.weight.mul_(0.05); egnn.embedding_out.bias.mul_(0.05)
+    model = pk.CrossAttentionPoseRegression(egnn, num_nodes=n, hidden_nf=feat, device="cuda").cuda()
+    b = pk.synthetic_batch(11, B, n=n, feat=feat, scale=(scale, scale, scale / 4), device="cuda")
+    graph = pk.build_pair_graph(b["src"], b["tgt"], k)
+    with torch.no_grad():
+        out = model(b["feat_src"], b["src"], graph, None, b["feat_tgt"], b["tgt"], graph, None, b["corr"], b["labels"], b["gt_pose"])
+    we = {kk: v.detach().cpu().double() for kk, v in egnn.state_dict().items()}
+    wc = {kk: v.detach().cpu().double() for kk, v in model.state_dict().items() if not kk.startswith("egnn.")}
+    e_s = torch.stack([orc.knn_graph(b["src"][i].cpu(), k) for i in range(B)])
+    e_t = torch.stack([orc.knn_graph(b["tgt"][i].cpu(), k) for i in range(B)])
+    ea = torch.ones(B, n * k, 1, dtype=torch.float64)
+    d = lambda name: b[name].cpu().double()
+    ref, extras = orc.pair_forward_train(we, wc, d("feat_src"), d("src"), e_s, ea, d("feat_tgt"), d("tgt"), e_t, ea, d("corr"),
+                                         d("labels"), d("gt_pose"))
+    assert float((out[0].cpu().double() - ref[0]).abs().max()) <= 1e-4
+    assert float((out[1].cpu().double() - ref[1]).abs().max()) <= 1e-4 * max(1.0, scale)
+    assert abs(float(out[2]) - float(ref[2])) <= 2e-4 * max(1.0, abs(float(ref[2])))
+    assert abs(float(out[3]) - float(ref[3])) <= 2e-4 * max(1.0, abs(float(ref[3])))
+    for i in range(B):
+        assert set(model.last_top_idx[i].cpu().tolist()) == set(extras["top_idx"][i].tolist())
