@@ -832,3 +832,46 @@ def test_pair_train_head_odd_shapes_vs_oracle(pk, feat, B, n, k, scale):
     assert abs(float(out[3]) - float(ref[3])) <= 2e-4 * max(1.0, abs(float(ref[3])))
     for i in range(B):
         assert set(model.last_top_idx[i].cpu().tolist()) == set(extras["top_idx"][i].tolist())
+
+
+@pytest.mark.parametrize("feat,B", [(33, 2), (32, 3)])
+def test_train_step_gradients_vs_oracle_autograd(pk, feat, B):
+    """The whole training loss (train :1120) through the fused head, Kabsch, both EGNN passes: every parameter gradient
+    against the oracle's autograd in fp32 and fp64 (hidden_nf = 33 exercises the border path of the MFMA backward)."""
+    n, k = 384, 10
+    torch.manual_seed(2)
+    egnn = pk.EGNN(feat, feat, feat, in_edge_nf=1, device="cuda", n_layers=2)
+    with torch.no_grad():
+        egnn.embedding_out.weight.mul_(0.02); egnn.embedding_out.bias.mul_(0.02)          # well-conditioned head (SURVEY §0.7)
+    model = pk.CrossAttentionPoseRegression(egnn, num_nodes=n, hidden_nf=feat, device="cuda").cuda()
+    b = pk.synthetic_batch(21, B, n=n, feat=feat, device="cuda")
+    b["tgt"] = b["tgt"] + 0.05 * torch.randn(b["tgt"].shape, generator=torch.Generator().manual_seed(3)).cuda()   # away from arccos'(1)
+    graph = pk.build_pair_graph(b["src"], b["tgt"], k)
+    out = model(b["feat_src"], b["src"], graph, None, b["feat_tgt"], b["tgt"], graph, None, b["corr"], b["labels"], b["gt_pose"])
+    loss, _, _ = pk.registration_loss(out[0], out[1], out[2], b["gt_pose"])
+    model.zero_grad()
+    loss.backward()
+    e_s = torch.stack([orc.knn_graph(b["src"][i].cpu(), k) for i in range(B)])
+    e_t = torch.stack([orc.knn_graph(b["tgt"][i].cpu(), k) for i in range(B)])
+    refs = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        we = {kk: v.detach().cpu().to(dt).requires_grad_(True) for kk, v in egnn.state_dict().items()}
+        wc = {kk: v.detach().cpu().to(dt).requires_grad_(True) for kk, v in model.state_dict().items()
+              if not kk.startswith("egnn.") and v.dtype.is_floating_point}
+        d = lambda name: b[name].cpu().to(dt)
+        ea = torch.ones(B, n * k, 1, dtype=dt)
+        ref, _ = orc.pair_forward_train(we, wc, d("feat_src"), d("src"), e_s, ea, d("feat_tgt"), d("tgt"), e_t, ea, d("corr"),
+                                        d("labels"), d("gt_pose"))
+        rl, tl = orc.pose_loss(ref[0], ref[1], d("gt_pose"))
+        l = ref[2].mean() + rl.mean() + tl.mean()
+        l.backward()
+        refs[tag] = dict(loss=float(l.detach()), **{"egnn." + kk: v.grad.numpy() for kk, v in we.items() if v.grad is not None},
+                         **{kk: v.grad.numpy() for kk, v in wc.items() if v.grad is not None})
+    np.testing.assert_allclose(float(loss), refs["f64"]["loss"], rtol=1e-4)
+    checked = 0
+    for pn, p in model.named_parameters():
+        if pn in refs["f64"]:
+            assert p.grad is not None, pn
+            _grad_check(p.grad, refs["f32"][pn], refs["f64"][pn], pn, k=8.0, rel=5e-5)
+            checked += 1
+    assert checked > 20
