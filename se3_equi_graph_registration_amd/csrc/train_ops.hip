@@ -132,8 +132,8 @@ struct AdamBuckets {
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamBuckets bk, float* __restrict__ step, float lr, float b1, float b2,
                                                    float eps) {
-    // every thread reads the SAME pre-increment step value; thread 0 of block 0 publishes step+1 for the NEXT launch
-    // through a second word so late-starting blocks cannot observe it: step[0] = value used now, step[1] = next
+    // every thread reads the SAME pre-increment step value; the LAST workgroup to finish (ticket counter in the second word,
+    // zero between launches) publishes step+1 for the next launch, so no workgroup can observe the new value
     const float tcur = step[0] + 1.0f;
     const float bc1 = 1.0f - powf(b1, tcur), bc2s = sqrtf(1.0f - powf(b2, tcur));
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
@@ -147,9 +147,13 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamBuckets bk, float* __rest
             bk.p[k][i] -= (lr / bc1) * m / (sqrtf(v) / bc2s + eps);
         }
     }
-    if (gid == 0) step[1] = tcur;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned* done = reinterpret_cast<unsigned*>(step + 1);
+        __threadfence();
+        if (atomicAdd(done, 1u) == gridDim.x - 1) { step[0] = tcur; *done = 0u; }
+    }
 }
-__global__ void adam_commit_kernel(float* __restrict__ step) { step[0] = step[1]; }
 
 }  // namespace eq
 
@@ -207,7 +211,6 @@ extern "C" int equigspr_adam_step(int32_t n_buckets, float* const* params, const
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, bk, step_dev, lr, beta1, beta2, eps);
-    hipLaunchKernelGGL(adam_commit_kernel, dim3(1), dim3(1), 0, s, step_dev);
     EQ_CHECK_LAUNCH("adam_step");
     return 0;
 }
