@@ -20,8 +20,10 @@ from .metrics import evaluate_batch, calculate_pose_error, registration_recall  
 from . import sh  # noqa: F401  (A16: spherical harmonics / irrep basis)
 from .sh import get_basis, get_spherical_harmonics, precompute_sh, basis_transformation_Q_J, irr_repr  # noqa: F401
 from .gcn import build_graph, GraphConvolution, GlobalPooling, KnnAdjacency  # noqa: F401
+from . import datasets  # noqa: F401  (N3: pair-file formats, dataset classes, HBM-resident batches)
+from .datasets import ThreeDMatchTrainVal, ThreeDMatchTest, KITTItrainVal, KITTItest, DeviceBatches  # noqa: F401
 
 __all__ = ["EGNN", "E_GCL", "CrossAttentionPoseRegression", "knn_graph", "get_edges_batch", "get_edges_from_idx",
            "build_pair_graph", "DeviceGraph", "weighted_kabsch", "pose_loss", "registration_loss", "compute_losses", "egnn_equi_loss",
            "unsorted_segment_sum", "unsorted_segment_mean", "synthetic_pair", "synthetic_batch", "SO3TensorProductLayer", "FlatAdam", "build_graph", "GraphConvolution",
-           "GlobalPooling", "KnnAdjacency"]
+           "GlobalPooling", "KnnAdjacency", "ThreeDMatchTrainVal", "ThreeDMatchTest", "KITTItrainVal", "KITTItest", "DeviceBatches"]

@@ -466,9 +466,117 @@ def gen_metrics_fixture(name, pairs=6, n=512, seed=51):
     print("wrote", name)
 
 
+def gen_datasets_fixture(name, n_corr=600, feat=40, seed=71):
+    """N3: the real datasets/ThreeDMatch.py and datasets/KITTI.py classes on synthetic pair records written to a temp
+    directory in the three on-disk layouts; np.random / random are seeded before every __getitem__.  Stored: the raw
+    records and the 7-tuples the reference classes returned (plus remap_correspondences on one case)."""
+    import pickle
+    import random as pyrandom
+    import tempfile
+
+    def ref_module(fname):
+        spec = importlib.util.spec_from_file_location("ref_ds_" + fname[:-3], os.path.join(REF, "datasets", fname))
+        m = importlib.util.module_from_spec(spec)
+        with quiet():
+            spec.loader.exec_module(m)
+        return m
+
+    tdm, kitti = ref_module("ThreeDMatch.py"), ref_module("KITTI.py")
+    rng = np.random.default_rng(seed)
+
+    def record(n_pos, n_src=500, n_tgt=450):
+        labels = np.zeros(n_corr, dtype=np.int32)
+        labels[rng.permutation(n_corr)[:n_pos]] = 1
+        gt = np.eye(4)
+        from scipy.spatial.transform import Rotation
+        gt[:3, :3] = Rotation.random(random_state=int(rng.integers(1 << 30))).as_matrix()
+        gt[:3, 3] = rng.uniform(-1, 1, 3)
+        return {"xyz_0": rng.uniform(-2, 2, (n_src, 3)).astype(np.float32), "xyz_1": rng.uniform(-2, 2, (n_tgt, 3)).astype(np.float32),
+                "feat_0": rng.standard_normal((n_src, feat)).astype(np.float32), "feat_1": rng.standard_normal((n_tgt, feat)).astype(np.float32),
+                "corr": np.stack([rng.integers(0, n_src, n_corr), rng.integers(0, n_tgt, n_corr)], axis=1).astype(np.int64),
+                "labels": labels, "gt_pose": gt}
+
+    # correspondences index the source array row by row in the reference classes (src_pts[sampled_indices]), so the
+    # records keep one correspondence per source row: n_src == n_corr
+    recs = {"few": record(60, n_src=n_corr), "many": record(420, n_src=n_corr), "kitti": record(300, n_src=n_corr),
+            "kitti_few": record(90, n_src=n_corr)}
+    out = {f"rec.{r}.{k}": v for r, d in recs.items() for k, v in d.items()}
+    cases = []
+    with tempfile.TemporaryDirectory() as root:
+        for sub in ("train_3dmatch", "test_3dmatch", "train_kitti", "test_kitti"):
+            os.makedirs(os.path.join(root, sub))
+        for r in ("few", "many"):
+            d = recs[r]
+            with open(os.path.join(root, "train_3dmatch", r + ".pkl"), "wb") as f:
+                pickle.dump({"src_keypts": torch.from_numpy(d["xyz_0"])[None], "tgt_keypts": torch.from_numpy(d["xyz_1"])[None],
+                             "src_features": torch.from_numpy(d["feat_0"])[None], "tgt_features": torch.from_numpy(d["feat_1"])[None],
+                             "corr": torch.from_numpy(d["corr"])[None], "gt_labels": torch.from_numpy(d["labels"])[None],
+                             "gt_pose": torch.from_numpy(d["gt_pose"])[None]}, f)
+            with open(os.path.join(root, "test_3dmatch", r + ".pkl"), "wb") as f:
+                pickle.dump(d, f)
+        for r in ("kitti", "kitti_few"):
+            for sub in ("train_kitti", "test_kitti"):
+                with open(os.path.join(root, sub, r + ".npz"), "wb") as f:
+                    np.savez(f, **recs[r])
+        for lst, names in (("train_files.txt", ["few.pkl", "many.pkl"]), ("val_files.txt", ["many.pkl"]), ("test_files.txt", ["few.pkl", "many.pkl"])):
+            with open(os.path.join(root, lst), "w") as f:
+                f.write("\n".join(names) + "\n")
+
+        def run(tag, cls, index, s, num_node, descriptor, split="train", **flags):
+            ds = cls(root=root, split=split, descriptor=descriptor, num_node=num_node,
+                     **{k: v for k, v in flags.items() if k.startswith("augment")})
+            for k, v in flags.items():
+                if not k.startswith("augment"):
+                    setattr(ds, k, v)
+            np.random.seed(s); pyrandom.seed(s)
+            with quiet():
+                item = ds[index]
+            for j, a in enumerate(item):
+                out[f"case.{tag}.{j}"] = np.asarray(a)
+            cases.append(tag)
+
+        run("tdm_train_few", tdm.ThreeDMatchTrainVal, 0, 1, 256, "fcgf")
+        run("tdm_train_many", tdm.ThreeDMatchTrainVal, 1, 2, 256, "fpfh")
+        run("tdm_val_many", tdm.ThreeDMatchTrainVal, 0, 3, 128, "fcgf", split="val")
+        run("tdm_train_synth1", tdm.ThreeDMatchTrainVal, 1, 4, 256, "fcgf", synthetic_pose_flag=True, augment_axis=1)
+        run("tdm_train_synth3", tdm.ThreeDMatchTrainVal, 0, 5, 256, "fcgf", synthetic_pose_flag=True, augment_axis=3,
+            augment_rotation=0.5, augment_translation=0.3)
+        run("tdm_train_norm", tdm.ThreeDMatchTrainVal, 1, 6, 256, "fcgf", normalize_use=True)
+        run("tdm_test_few", tdm.ThreeDMatchTest, 0, 7, 256, "fcgf", split="test")
+        run("tdm_test_many", tdm.ThreeDMatchTest, 1, 8, 256, "fpfh", split="test")
+        for lst, names in (("train_files.txt", ["kitti.npz", "kitti_few.npz"]), ("test_files.txt", ["kitti.npz", "kitti_few.npz"])):
+            with open(os.path.join(root, lst), "w") as f:
+                f.write("\n".join(names) + "\n")
+        # KITTItest reads its records with np.load(f, allow_pickle=True) and uses them after the file is closed, which
+        # only works for a PICKLED dict (numpy's fallback), not for a lazily read .npz archive: test_kitti holds pickles.
+        for r in ("kitti", "kitti_few"):
+            with open(os.path.join(root, "test_kitti", r + ".npz"), "wb") as f:
+                pickle.dump(recs[r], f)
+        run("kitti_test", kitti.KITTItest, 0, 11, 256, "fpfh", split="test")
+        run("kitti_test_few", kitti.KITTItest, 1, 12, 256, "fcgf", split="test")
+        # KITTItrainVal calls np.load(f) without allow_pickle and also reads after closing the file, so as written it
+        # can open neither layout.  To pin everything after the read, np.load is wrapped for these two calls so that
+        # the .npz members are materialised while the file is still open; nothing else is altered.
+        real_load = np.load
+        np.load = lambda f, *a, **kw: {k: v for k, v in real_load(f, *a, **kw).items()}
+        try:
+            run("kitti_train", kitti.KITTItrainVal, 0, 9, 256, "fcgf")
+            run("kitti_train_few_fpfh", kitti.KITTItrainVal, 1, 10, 256, "fpfh")
+        finally:
+            np.load = real_load
+    pairs = np.stack([rng.integers(0, 40, 64), rng.integers(0, 40, 64)], axis=1)
+    out["remap.in"], out["remap.out"] = pairs, tdm.remap_correspondences(pairs, 64)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name, len(cases), "cases")
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "metrics":
         gen_metrics_fixture("metrics_cases.npz")
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "datasets":
+        gen_datasets_fixture("datasets_cases.npz")
         return
     if len(sys.argv) > 1 and sys.argv[1] == "sh":
         gen_sh_fixture("sh_l6.npz")
@@ -502,6 +610,7 @@ def main():
     gen_sh_fixture("sh_l6.npz")
     gen_metrics_fixture("metrics_cases.npz")
     gen_pointnet_fixture(tr, "pointnet_n200_k6.npz")
+    gen_datasets_fixture("datasets_cases.npz")
 
 
 if __name__ == "__main__":
