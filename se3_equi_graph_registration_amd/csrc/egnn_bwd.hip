@@ -703,6 +703,12 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
     float x_c6 = 0.0f, x_c2 = 0.0f, x_b6 = 0.0f, x_b2 = 0.0f, x_w7 = 0.0f, x_gam = 0.0f, x_bet = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc6[0][0][r] = 0.0f; acc2[0][0][r] = 0.0f; accg[0][0][r] = 0.0f; }
+    // dw7, dgamma, dbeta are plain sums over edges of per-lane values: with registers to spare (B = 0) every lane keeps its
+    // own running sums over its tiles and the 32 lanes are added ONCE after the loop, instead of two LDS passes per tile
+    constexpr bool kLaneSums = (B == 0);
+    float ls_w7[kLaneSums ? 16 : 1], ls_gam[kLaneSums ? 16 : 1], ls_bet[kLaneSums ? 16 : 1];
+#pragma unroll
+    for (int r = 0; r < (kLaneSums ? 16 : 1); ++r) { ls_w7[r] = 0.0f; ls_gam[r] = 0.0f; ls_bet[r] = 0.0f; }
 
     const int n_tiles = (n_edges + 31) / 32;
     for (int tile = wave; tile < n_tiles; tile += n_waves) {
@@ -771,21 +777,30 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
             for (int k = 0; k < 16; ++k) dm[k] = a[k];
         }
         EQ_STAMP(8);
-        {
-            float t[16];
+        if constexpr (kLaneSums) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) t[k] = dm[k] * o.xhat[k];
-            if constexpr (B == 1) { x_gam = fmaf(zh * dmb, o.xhatb, x_gam); x_bet += zh * dmb; }
-            stage_half_row(X + el * LD, h, pds);
-            stage_half_row(Y + el * LD, h, t);
+            for (int k = 0; k < 16; ++k) {
+                ls_w7[k] += pds[k];
+                ls_gam[k] = fmaf(dm[k], o.xhat[k], ls_gam[k]);
+                ls_bet[k] += dm[k];
+            }
+        } else {
+            {
+                float t[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) t[k] = dm[k] * o.xhat[k];
+                if constexpr (B == 1) { x_gam = fmaf(zh * dmb, o.xhatb, x_gam); x_bet += zh * dmb; }
+                stage_half_row(X + el * LD, h, pds);
+                stage_half_row(Y + el * LD, h, t);
+            }
+            __builtin_amdgcn_wave_barrier();
+            tile_pass<1, 1, LD, false, 32>(X, Y, acc6, cs_w7, cs_gam, lane);          // dw7, dgamma (column sums only)
+            __builtin_amdgcn_wave_barrier();
+            stage_half_row(X + el * LD, h, dm);
+            __builtin_amdgcn_wave_barrier();
+            tile_pass<1, 1, LD, false, 32>(X, Y, acc6, cs_bet, cs_scr, lane);         // dbeta = sum dm
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
-        tile_pass<1, 1, LD, false, 32>(X, Y, acc6, cs_w7, cs_gam, lane);          // dw7, dgamma (column sums only)
-        __builtin_amdgcn_wave_barrier();
-        stage_half_row(X + el * LD, h, dm);
-        __builtin_amdgcn_wave_barrier();
-        tile_pass<1, 1, LD, false, 32>(X, Y, acc6, cs_bet, cs_scr, lane);         // dbeta = sum dm
-        __builtin_amdgcn_wave_barrier();
         EQ_STAMP(9);
         // ---- LayerNorm backward
         float du[16], dub = 0.0f;
@@ -914,6 +929,17 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
     // ---- the 4 waves' partials: each wave writes its own LDS copy (in parallel), then all threads add the four copies in
     // fixed order straight into the block's global slab (was: four serialised read-modify-write rounds + a flush)
     const int f = lane & 31, hh = lane >> 5;
+    if constexpr (kLaneSums) {                          // the per-lane sums: one transposing pass per vector pair
+        stage_half_row(X + el * LD, h, ls_w7);
+        stage_half_row(Y + el * LD, h, ls_gam);
+        __builtin_amdgcn_wave_barrier();
+        tile_pass<1, 1, LD, false, 32>(X, Y, acc6, cs_w7, cs_gam, lane);
+        __builtin_amdgcn_wave_barrier();
+        stage_half_row(X + el * LD, h, ls_bet);
+        __builtin_amdgcn_wave_barrier();
+        tile_pass<1, 1, LD, false, 32>(X, Y, acc6, cs_bet, cs_scr, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
     cs_b6[0] += xhalf(cs_b6[0]);
     cs_b2[0] += xhalf(cs_b2[0]);
     cs_gam[0] += xhalf(cs_gam[0]);
