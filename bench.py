@@ -85,11 +85,17 @@ def build_step(pkg, args, dev, world):
             loss = closs.mean() + rl.mean() + tl.mean()                                      # train :1120, op by op
         else:
             loss, _, _ = pkg.registration_loss(R, t, closs, batch["gt_pose"])              # the same sum in one launch
-        loss.backward()
+        if cache.get("one") is None or cache["one"].shape != loss.shape:
+            cache["one"] = torch.ones_like(loss)          # created by the eager warm-up: backward() would launch a fill for it every step
+        loss.backward(gradient=cache["one"])
         return loss
 
+    cache = {}
+    dp.zero_grad()          # once: afterwards the Adam launch clears each gradient as it consumes it (optimizer.zero_grad() fused)
+
     def zero():
-        dp.zero_grad()
+        if args.forward_only or args.aten_head:
+            dp.zero_grad()
 
     # The reference's pose loss (train :952,:960) is arccos of a quantity that tends to 1 at a perfect fit, where its
     # gradient is -inf: on ONE repeated synthetic pair training reaches that singularity after ~180 steps (the
@@ -104,7 +110,7 @@ def build_step(pkg, args, dev, world):
             opt.reset_state()
 
     def opt_step():
-        opt.step()
+        opt.step(zero_grad=not args.aten_head)
 
     return dict(model=model, egnn=egnn, dp=dp, batch=batch, ones=ones, fwd_bwd=fwd_bwd, zero=zero, opt_step=opt_step, restore=restore)
 

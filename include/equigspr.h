@@ -27,7 +27,7 @@ extern "C" {
 
 #define EQUIGSPR_EINVAL   (-1)  /* bad shape / size / null pointer                         */
 #define EQUIGSPR_ENOTSUP  (-2)  /* configuration outside the compiled kernel set             */
-#define EQUIGSPR_ABI_VERSION 2
+#define EQUIGSPR_ABI_VERSION 3
 
 /* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
  * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
@@ -96,9 +96,12 @@ int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, int32_t k, i
 /* ---- graph index build ---------------------------------------------------------------
  * Builds rptr/rperm (key=row) or cptr/cperm (key=col): stable counting sort of edge ids.
  * Replaces the implicit scatter_add_ indexing of unsorted_segment_sum (:343-348).
- *   key [E] global ids in [0,N);  ptr [N+1];  perm [E];  scratch: int32 [N+1]. */
-int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n_nodes,
-                       int32_t* ptr, int32_t* perm, int32_t* scratch, void* stream);
+ *   key [E] global ids in [0,N);  ptr [N+1];  perm [E];  inv [E] or NULL: the inverse of perm (inv[perm[p]] = p, the
+ *   rinv field of equigspr_graph), written by the same pass that orders the segments;  scratch: int32 [N+1].
+ *   scratch_is_zero != 0: the caller guarantees scratch is all-zero on entry and the clear is skipped.  On return scratch
+ *   is all-zero again, so one buffer can be handed from call to call on the same stream. */
+int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n_nodes, int32_t* ptr, int32_t* perm,
+                       int32_t* inv, int32_t* scratch, int32_t scratch_is_zero, void* stream);
 /* inv[perm[p]] = p for p in [0, n): the rinv field of equigspr_graph from rperm */
 int equigspr_invert_perm(const int32_t* perm, int32_t n, int32_t* inv, void* stream);
 /* int64 reference edge list [2,E] (one cloud, local ids) -> int32 global ids (+node_offset) */
@@ -190,15 +193,17 @@ int equigspr_head_backward(const float* hs, const float* ht, const float* xs, co
  * gt_pose [B,16]; backward takes dL/drot_loss, dL/dtrans_loss [B] (NULL = 0) and OVERWRITES grad_R, grad_t.
  * The gradient is -inf at zero pose error, exactly as in the reference.
  * adam_step: torch.optim.Adam(lr, betas, eps) semantics (train :1412) over 1..4 flat fp32 buckets in one
- * launch.  The pointer/size arrays are HOST arrays of n_buckets entries; step_dev is a DEVICE float[2]
- * (zero-initialised) holding the step count, so the call is hipGraph-capturable. */
+ * launch.  The pointer/size arrays are HOST arrays of n_buckets entries; step_dev is DEVICE memory, two zero-
+ * initialised 32-bit words (the step count as a float, and the ticket with which the last workgroup publishes
+ * step+1), so the call is hipGraph-capturable.  clear_grads != 0: every gradient is zeroed as it is consumed
+ * (optimizer.zero_grad() fused into the step: the fill launch of the next iteration disappears). */
 int equigspr_pose_loss_forward(const float* R, const float* t, const float* gt_pose, int32_t B, float* rot_loss,
                                float* trans_loss, void* stream);
 int equigspr_pose_loss_backward(const float* R, const float* t, const float* gt_pose, const float* g_rot,
                                 const float* g_trans, int32_t B, float* grad_R, float* grad_t, void* stream);
-int equigspr_adam_step(int32_t n_buckets, float* const* params, const float* const* grads, float* const* exp_avg,
+int equigspr_adam_step(int32_t n_buckets, float* const* params, float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const int64_t* sizes, float* step_dev, float lr, float beta1,
-                       float beta2, float eps, void* stream);
+                       float beta2, float eps, int32_t clear_grads, void* stream);
 
 /* ---- A15: SO3TensorProductLayer.forward (src/clean_so3_model.py:34-52) ------------------------
  * y = W2 relu(W1 vec(D x x^T) + b1) + b2, D = input_dim (the bmm of the two broadcast views sums D identical

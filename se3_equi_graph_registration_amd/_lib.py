@@ -34,7 +34,7 @@ _SIGNATURES = {
     "equigspr_egnn_layer_offset": (c_int64, [POINTER(EgnnConfig), c_int32]),
     "equigspr_knn_graph": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
                                           c_void_p, c_int32, c_void_p]),
-    "equigspr_build_csr": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "equigspr_build_csr": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "equigspr_invert_perm": (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
     "equigspr_edges_i64_to_i32": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "equigspr_egnn_saved_size": (c_int64, [POINTER(EgnnConfig), c_int32]),
@@ -57,7 +57,7 @@ _SIGNATURES = {
     "equigspr_pose_loss_forward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "equigspr_pose_loss_backward": (ctypes.c_int, [c_void_p] * 5 + [c_int32] + [c_void_p] * 3),
     "equigspr_adam_step": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
-                                          POINTER(c_int64), c_void_p] + [ctypes.c_float] * 4 + [c_void_p]),
+                                          POINTER(c_int64), c_void_p] + [ctypes.c_float] * 4 + [c_int32, c_void_p]),
     "equigspr_so3_tensor_product_forward": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 7),
     "equigspr_gcn_build_graph": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 11),
     "equigspr_gcn_adjacency_to_dense": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
@@ -103,7 +103,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if L.equigspr_abi_version() != 2:
+        if L.equigspr_abi_version() != 3:
             raise RuntimeError("libequigspr.so ABI version mismatch")
         _lib = L
     return _lib

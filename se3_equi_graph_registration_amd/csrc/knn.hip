@@ -277,24 +277,37 @@ __global__ void csr_fill_kernel(const int* __restrict__ key, int n_edges, int* _
 }
 
 // each node's segment back into ascending edge order (atomics filled it in arbitrary order):
-// one wave per node, <= 64 entries sorted with a wave bitonic network, longer segments serially.
-__global__ __launch_bounds__(256) void csr_sort_kernel(const int* __restrict__ ptr, int n_nodes, int* __restrict__ perm) {
+// one wave per node, <= 64 entries sorted with a wave bitonic network, longer segments serially.  The same wave writes the
+// inverse permutation of its segment (inv[perm[p]] = p, optional) and hands the node's cursor word back as zero, so the
+// scratch array leaves build_csr the way it must enter it.
+__global__ __launch_bounds__(256) void csr_sort_kernel(const int* __restrict__ ptr, int n_nodes, int* __restrict__ perm,
+                                                       int* __restrict__ inv, int* __restrict__ scratch) {
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= n_nodes) return;                     // wave-uniform
     const int lo = ptr[j], hi = ptr[j + 1];
     const int len = hi - lo;
-    if (len <= 1) return;
+    if (lane == 0) scratch[j] = 0;
     if (len <= 64) {
         u64 key = lane < len ? (u64)(unsigned)perm[lo + lane] : ~0ull;
-        key = wave_bitonic_sort(key, lane);
-        if (lane < len) perm[lo + lane] = (int)(unsigned)key;
-    } else if (lane == 0) {
-        for (int a = lo + 1; a < hi; ++a) {
-            const int v = perm[a];
-            int b = a - 1;
-            while (b >= lo && perm[b] > v) { perm[b + 1] = perm[b]; --b; }
-            perm[b + 1] = v;
+        if (len > 1) key = wave_bitonic_sort(key, lane);          // wave-uniform condition: all 64 lanes take part
+        if (lane < len) {
+            if (len > 1) perm[lo + lane] = (int)(unsigned)key;
+            if (inv) inv[(int)(unsigned)key] = lo + lane;
+        }
+    } else {
+        if (lane == 0) {
+            for (int a = lo + 1; a < hi; ++a) {
+                const int v = perm[a];
+                int b = a - 1;
+                while (b >= lo && perm[b] > v) { perm[b + 1] = perm[b]; --b; }
+                perm[b + 1] = v;
+            }
+        }
+        if (inv) {
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            for (int a = lo + lane; a < hi; a += 64) inv[perm[a]] = a;
         }
     }
 }
@@ -337,15 +350,19 @@ extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, i
 }
 
 extern "C" int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n_nodes, int32_t* ptr,
-                                  int32_t* perm, int32_t* scratch, void* stream) {
+                                  int32_t* perm, int32_t* inv, int32_t* scratch, int32_t scratch_is_zero, void* stream) {
     using namespace eq;
     EQ_CHECK_ARG(ptr && scratch && (n_edges == 0 || (key && perm)), EQUIGSPR_EINVAL, "build_csr: null pointer");
     EQ_CHECK_ARG(n_edges >= 0 && n_nodes >= 1, EQUIGSPR_EINVAL, "build_csr: bad sizes");
     hipStream_t s = (hipStream_t)stream;
-    // (a single-block LDS count+scan was tried instead of memset + count + scan: 25 us vs ~12 us -- one block cannot hide
-    // the key-load latency)
-    hipError_t err = hipMemsetAsync(scratch, 0, sizeof(int) * (size_t)(n_nodes + 1), s);
-    if (err != hipSuccess) { set_error("build_csr memset: %s", hipGetErrorString(err)); return (int)err; }
+    // (a single-block LDS count+scan was tried instead of clear + count + scan: 25 us vs ~12 us -- one block cannot hide
+    // the key-load latency.)  The clear is skipped for a scratch the caller knows to be zero: the sort pass re-zeroes every
+    // word the count/fill passes touched, so a buffer can be handed from call to call (hipMemsetAsync of N+1 words is
+    // two fill launches -- an aligned body and a tail -- i.e. ~10 us of a 0.5 ms step)
+    if (!scratch_is_zero) {
+        hipError_t err = hipMemsetAsync(scratch, 0, sizeof(int) * (size_t)(n_nodes + 1), s);
+        if (err != hipSuccess) { set_error("build_csr memset: %s", hipGetErrorString(err)); return (int)err; }
+    }
     if (n_edges > 0)
         hipLaunchKernelGGL(csr_count_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, key, n_edges, scratch);
     // large N: two-level scan; its chunk totals borrow the head of `perm`, which is only written by the fill below
@@ -353,7 +370,7 @@ extern "C" int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n
     launch_exclusive_scan(scratch, n_nodes, ptr, (n_edges >= chunks && chunks <= 1024) ? perm : nullptr, s);
     if (n_edges > 0) {
         hipLaunchKernelGGL(csr_fill_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, key, n_edges, scratch, perm);
-        hipLaunchKernelGGL(csr_sort_kernel, dim3(ceil_div(n_nodes, 4)), dim3(256), 0, s, ptr, n_nodes, perm);
+        hipLaunchKernelGGL(csr_sort_kernel, dim3(ceil_div(n_nodes, 4)), dim3(256), 0, s, ptr, n_nodes, perm, inv, scratch);
     }
     EQ_CHECK_LAUNCH("build_csr");
     return 0;

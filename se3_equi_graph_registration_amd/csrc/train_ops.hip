@@ -127,9 +127,10 @@ __global__ void step_loss_bwd_kernel(const float* __restrict__ R, const float* _
 }
 
 struct AdamBuckets {
-    float* p[4]; const float* g[4]; float* m[4]; float* v[4]; long long n[4]; int count;
+    float* p[4]; float* g[4]; float* m[4]; float* v[4]; long long n[4]; int count;
 };
 
+template <bool kClear>
 __global__ __launch_bounds__(256) void adam_kernel(AdamBuckets bk, float* __restrict__ step, float lr, float b1, float b2,
                                                    float eps) {
     // every thread reads the SAME pre-increment step value; the LAST workgroup to finish (ticket counter in the second word,
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamBuckets bk, float* __rest
             bk.m[k][i] = m;
             bk.v[k][i] = v;
             bk.p[k][i] -= (lr / bc1) * m / (sqrtf(v) / bc2s + eps);
+            if (kClear) bk.g[k][i] = 0.0f;       // the optimizer step consumes the gradient: no separate zero_grad fill
         }
     }
     __syncthreads();
@@ -194,9 +196,9 @@ extern "C" int equigspr_step_loss_backward(const float* R, const float* t, const
     return 0;
 }
 
-extern "C" int equigspr_adam_step(int32_t n_buckets, float* const* params, const float* const* grads, float* const* exp_avg,
+extern "C" int equigspr_adam_step(int32_t n_buckets, float* const* params, float* const* grads, float* const* exp_avg,
                                   float* const* exp_avg_sq, const int64_t* sizes /* host arrays */, float* step_dev /* [2] */,
-                                  float lr, float beta1, float beta2, float eps, void* stream) {
+                                  float lr, float beta1, float beta2, float eps, int32_t clear_grads, void* stream) {
     using namespace eq;
     EQ_CHECK_ARG(n_buckets >= 1 && n_buckets <= 4 && params && grads && exp_avg && exp_avg_sq && sizes && step_dev,
                  EQUIGSPR_EINVAL, "adam_step: 1..4 buckets, non-null arrays");
@@ -210,7 +212,8 @@ extern "C" int equigspr_adam_step(int32_t n_buckets, float* const* params, const
     int blocks = ceil_div(tot, 256 * 4);
     blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, bk, step_dev, lr, beta1, beta2, eps);
+    if (clear_grads) hipLaunchKernelGGL(adam_kernel<true>, dim3(blocks), dim3(256), 0, s, bk, step_dev, lr, beta1, beta2, eps);
+    else hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, s, bk, step_dev, lr, beta1, beta2, eps);
     EQ_CHECK_LAUNCH("adam_step");
     return 0;
 }

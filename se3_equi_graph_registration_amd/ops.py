@@ -66,6 +66,30 @@ def cat_or_view(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 _KNN_COL_INDEX = {}
 
 
+_CSR_SCRATCH = {}
+
+
+def _csr_scratch(dev, n_words):
+    """The counter array of ``equigspr_build_csr``: the call leaves it all-zero, so one zero-initialised buffer per
+    (device, stream, size) is handed from build to build and the per-call clear (two fill launches) disappears.
+    Returns ``(tensor, is_zero)``."""
+    key = (str(dev), _stream().value, int(n_words))
+    buf = _CSR_SCRATCH.get(key)
+    if buf is not None:
+        return buf, 1
+    if torch.cuda.is_current_stream_capturing():
+        # the capture stream is a fresh one: take the buffer an eager warm-up run left behind for this device and size
+        # (the captured graph then owns it: do not build graphs of that size eagerly on another stream while it replays)
+        for (d, _, n), other in _CSR_SCRATCH.items():
+            if d == key[0] and n == key[2]:
+                return other, 1
+        return torch.empty(n_words, dtype=torch.int32, device=dev), 0
+    if len(_CSR_SCRATCH) > 32:
+        _CSR_SCRATCH.clear()
+    buf = _CSR_SCRATCH[key] = torch.zeros(n_words, dtype=torch.int32, device=dev)
+    return buf, 1
+
+
 class DeviceGraph:
     """Batched graph in the device format (int32 global ids + inverse indices)."""
 
@@ -74,13 +98,16 @@ class DeviceGraph:
         self.row, self.col = _need(row32, "row32", torch.int32, 1), _need(col32, "col32", torch.int32, 1)
         self.n_nodes, self.n_edges = int(n_nodes), int(row32.numel())
         dev = row32.device
-        scratch = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
+        scratch, zeroed = _csr_scratch(dev, self.n_nodes + 1)
         self.rptr = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
         self.rperm = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
-        _lib.check(L.equigspr_build_csr(_p(self.row), self.n_edges, self.n_nodes, _p(self.rptr), _p(self.rperm),
-                                        _p(scratch), _stream()), "build_csr(row)")
         self.rinv = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
-        _lib.check(L.equigspr_invert_perm(_p(self.rperm), self.n_edges, _p(self.rinv), _stream()), "invert_perm")
+        try:      # one call: counting sort by row, the inverse permutation from the same pass, scratch handed back zeroed
+            _lib.check(L.equigspr_build_csr(_p(self.row), self.n_edges, self.n_nodes, _p(self.rptr), _p(self.rperm),
+                                            _p(self.rinv), _p(scratch), zeroed, _stream()), "build_csr(row)")
+        except Exception:
+            _CSR_SCRATCH.clear()
+            raise
         self.cptr = self.cperm = None
         if need_col_index:
             if knn_k is not None:      # centre-major kNN list: the col index is the identity permutation (cached)
@@ -94,8 +121,12 @@ class DeviceGraph:
             else:
                 self.cptr = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
                 self.cperm = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
-                _lib.check(L.equigspr_build_csr(_p(self.col), self.n_edges, self.n_nodes, _p(self.cptr),
-                                                _p(self.cperm), _p(scratch), _stream()), "build_csr(col)")
+                try:
+                    _lib.check(L.equigspr_build_csr(_p(self.col), self.n_edges, self.n_nodes, _p(self.cptr),
+                                                    _p(self.cperm), None, _p(scratch), 1, _stream()), "build_csr(col)")
+                except Exception:
+                    _CSR_SCRATCH.clear()
+                    raise
         self.struct = Graph(self.n_nodes, self.n_edges, self.row.data_ptr(), self.col.data_ptr(),
                             self.rptr.data_ptr(), self.rperm.data_ptr(),
                             self.cptr.data_ptr() if self.cptr is not None else None,
@@ -429,10 +460,12 @@ class FlatAdam:
         self._m, self._v = arr(self.exp_avg), arr(self.exp_avg_sq)
         self._n = (ctypes.c_int64 * n)(*[p.numel() for p, _ in self.buckets])
 
-    def step(self):
+    def step(self, zero_grad: bool = False):
+        """One Adam update; ``zero_grad=True`` also clears the gradient buckets in the same launch (the fused form of
+        ``optimizer.step(); optimizer.zero_grad()``)."""
         _lib.check(_lib.lib().equigspr_adam_step(len(self.buckets), self._p, self._g, self._m, self._v, self._n,
                                                  _p(self.step_dev), self.lr, self.betas[0], self.betas[1], self.eps,
-                                                 _stream()), "adam_step")
+                                                 int(bool(zero_grad)), _stream()), "adam_step")
 
     def reset_state(self):
         for t in self.exp_avg + self.exp_avg_sq + [self.step_dev]:

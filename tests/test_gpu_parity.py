@@ -119,6 +119,50 @@ def test_inverse_index_is_stable_counting_sort(pk):
         cnt = np.bincount(key.numpy(), minlength=n)
         np.testing.assert_array_equal(ptr.cpu().numpy(), np.concatenate([[0], np.cumsum(cnt)]))
         np.testing.assert_array_equal(perm.cpu().numpy()[:e], order)
+    inv = np.empty(e, dtype=np.int64)
+    inv[np.argsort(row.numpy(), kind="stable")] = np.arange(e)
+    np.testing.assert_array_equal(dg.rinv.cpu().numpy()[:e], inv)    # written by the pass that orders the segments
+
+
+def test_build_csr_scratch_contract_and_inverse(pk):
+    """ABI v3: build_csr also writes inv (same values as equigspr_invert_perm), accepts a scratch declared zero, and
+    hands it back all-zero -- including hub segments longer than a wave (serial path) and isolated nodes."""
+    import ctypes
+    from se3_equi_graph_registration_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    n, e = 1500, 20000
+    key = torch.randint(0, n - 100, (e,), generator=g)             # the last 100 nodes stay empty
+    key[:300] = 7                                                   # a 300-entry segment
+    key[300:365] = 9                                                # 65: just past one wave
+    key32 = key.to(torch.int32).cuda()
+    order = np.argsort(key.numpy(), kind="stable")
+    inv_ref = np.empty(e, dtype=np.int64)
+    inv_ref[order] = np.arange(e)
+    scratch = torch.full((n + 1,), 12345, dtype=torch.int32, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    for is_zero in (0, 1, 1):                                       # first call clears the dirty buffer, the next two trust it
+        ptr = torch.empty(n + 1, dtype=torch.int32, device="cuda")
+        perm = torch.empty(e, dtype=torch.int32, device="cuda")
+        inv = torch.empty(e, dtype=torch.int32, device="cuda")
+        _lib.check(L.equigspr_build_csr(p(key32), e, n, p(ptr), p(perm), p(inv), p(scratch), is_zero, ops._stream()), "build_csr")
+        np.testing.assert_array_equal(perm.cpu().numpy(), order)
+        np.testing.assert_array_equal(inv.cpu().numpy(), inv_ref)
+        np.testing.assert_array_equal(ptr.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(key.numpy(), minlength=n))]))
+        assert int(scratch.abs().sum()) == 0
+        inv2 = torch.empty_like(inv)
+        _lib.check(L.equigspr_invert_perm(p(perm), e, p(inv2), ops._stream()), "invert_perm")
+        assert torch.equal(inv, inv2)
+    # inv = NULL is allowed; the cached scratch of DeviceGraph survives many builds of different graphs
+    _lib.check(L.equigspr_build_csr(p(key32), e, n, p(ptr), p(perm), None, p(scratch), 1, ops._stream()), "build_csr")
+    np.testing.assert_array_equal(perm.cpu().numpy(), order)
+    for seed in range(4):
+        gg = torch.Generator().manual_seed(seed)
+        x = torch.rand(2, 600, 3, generator=gg).cuda()
+        graph = pk.build_pair_graph(x[:1], x[1:], 9)
+        row = graph.row.cpu().numpy()
+        np.testing.assert_array_equal(graph.rperm.cpu().numpy(), np.argsort(row, kind="stable"))
+        assert all(int(b.abs().sum()) == 0 for b in ops._CSR_SCRATCH.values())
 
 
 # ------------------------------------------------------------------------------------ EGNN forward
@@ -498,6 +542,18 @@ def test_flat_adam_matches_torch_adam(pk):
     for r, m in zip(ref, mine):
         assert torch.allclose(r.detach(), m, rtol=1e-5, atol=1e-6)
     assert float(fa.step_dev[0]) == 6.0
+    # zero_grad=True: the same update, and the gradient buckets come back cleared (optimizer.zero_grad() fused into the launch)
+    mine2 = [p.clone().cuda() for p in p0]
+    mgr2 = [torch.zeros_like(p) for p in mine2]
+    fb = pk.FlatAdam(list(zip(mine2, mgr2)), lr=1e-3)
+    for step in grads:
+        for m, gg in zip(mgr2, step):
+            assert float(m.abs().max()) == 0.0
+            m.copy_(gg.cuda())
+        fb.step(zero_grad=True)
+    for a, b in zip(mine, mine2):
+        assert torch.equal(a, b)
+    assert all(float(m.abs().max()) == 0.0 for m in mgr2)
 
 
 # ------------------------------------------------------------------------------------------------
