@@ -1030,14 +1030,33 @@ __device__ __forceinline__ void finish_parts(float v, int lane, int part, bool l
     }
 }
 
+// the two embedding slab sets, reduced by the extra grid row blockIdx.y == n_layers of layer_grad_reduce_kernel:
+// blocks [0, split) do job A (embedding_out), the rest job B (embedding_in)
+struct PlainJobs {
+    const float* slab_a; int n_a, size_a; float* dst_a; int split;
+    const float* slab_b; int n_b, size_b; float* dst_b;
+};
+
 template <int F, int H, int A>
 __global__ __launch_bounds__(256) void layer_grad_reduce_kernel(const float* __restrict__ node_slab, int n_node,
                                                                 const float* __restrict__ edge_slab, int n_edge,
                                                                 const float* __restrict__ gat_slab, int n_gat,
                                                                 float* __restrict__ grad_layer, size_t slab_layer_stride,
-                                                                size_t grad_layer_stride) {
+                                                                size_t grad_layer_stride, int n_layers, PlainJobs pj) {
     using LL = LP<F, H, A>;
     using SB = Slabs<F>;
+    if ((int)blockIdx.y == n_layers) {               // block-uniform
+        const bool second = (int)blockIdx.x >= pj.split;
+        const float* slab = second ? pj.slab_b : pj.slab_a;
+        const int n_slabs = second ? pj.n_b : pj.n_a, size = second ? pj.size_b : pj.size_a;
+        float* dst = second ? pj.dst_b : pj.dst_a;
+        const int lane = threadIdx.x & 31, part = threadIdx.x >> 5;
+        const int idx = ((int)blockIdx.x - (second ? pj.split : 0)) * 32 + lane;
+        const bool live = idx < size;
+        const float v = live ? sum_slabs_part(slab, n_slabs, size, idx, part) : 0.0f;
+        finish_parts(v, lane, part, live, dst + (live ? idx : 0));
+        return;
+    }
     // blockIdx.y = layer: every layer keeps its own slab set, so ONE launch at the end of the backward reduces them all
     node_slab += blockIdx.y * slab_layer_stride;
     edge_slab += blockIdx.y * slab_layer_stride;
@@ -1076,31 +1095,6 @@ __global__ __launch_bounds__(256) void layer_grad_reduce_kernel(const float* __r
     }
     const float v = live ? sum_slabs_part(src, n, stride, si, part) : 0.0f;
     finish_parts(v, lane, part, live, grad_layer + (live ? idx : 0));
-}
-
-__global__ __launch_bounds__(256) void plain_grad_reduce_kernel(const float* __restrict__ slab, int n_slabs, int size,
-                                                                float* __restrict__ dst) {
-    const int lane = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + lane;
-    const bool live = idx < size;
-    const float v = live ? sum_slabs_part(slab, n_slabs, size, idx, part) : 0.0f;
-    finish_parts(v, lane, part, live, dst + (live ? idx : 0));
-}
-
-// two independent slab reductions in one launch: blocks [0, split) do job A, the rest job B
-__global__ __launch_bounds__(256) void plain_grad_reduce2_kernel(const float* __restrict__ slab_a, int n_a, int size_a,
-                                                                 float* __restrict__ dst_a, int split,
-                                                                 const float* __restrict__ slab_b, int n_b, int size_b,
-                                                                 float* __restrict__ dst_b) {
-    const bool second = (int)blockIdx.x >= split;
-    const float* slab = second ? slab_b : slab_a;
-    const int n_slabs = second ? n_b : n_a, size = second ? size_b : size_a;
-    float* dst = second ? dst_b : dst_a;
-    const int lane = threadIdx.x & 31, part = threadIdx.x >> 5;
-    const int idx = ((int)blockIdx.x - (second ? split : 0)) * 32 + lane;
-    const bool live = idx < size;
-    const float v = live ? sum_slabs_part(slab, n_slabs, size, idx, part) : 0.0f;
-    finish_parts(v, lane, part, live, dst + (live ? idx : 0));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1194,15 +1188,15 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
     }
     hipLaunchKernelGGL((embed_in_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_in, cfg->in_nf,
                        work + B.Gh[cur], h_in, N, grad_h_in, work + B.emb_slab2);
-    // all slab reductions at the end: one launch for the L layers (blockIdx.y = layer), one for the two embeddings
-    hipLaunchKernelGGL((layer_grad_reduce_kernel<F, H, A>), dim3(ceil_div(ML.layer_size, 32), L), dim3(256), 0, s,
-                       work + B.node_slab, ngrid, work + B.edge_slab, E > 0 ? egrid : 0, work + B.gat_slab, ngrid,
-                       grad_params + ML.layer0, B.layer_stride, (size_t)ML.layer_size);
+    // all slab reductions at the end in ONE launch: grid rows 0..L-1 = the layers, row L = the two embeddings
     {
         const int n_out = cfg->out_nf * F + cfg->out_nf, n_in = F * cfg->in_nf + F;
-        hipLaunchKernelGGL(plain_grad_reduce2_kernel, dim3(ceil_div(n_out, 32) + ceil_div(n_in, 32)), dim3(256), 0, s,
-                           work + B.emb_slab, ngrid, n_out, grad_params + ML.w_out, ceil_div(n_out, 32), work + B.emb_slab2, ngrid,
-                           n_in, grad_params + ML.w_in);
+        const PlainJobs pj{work + B.emb_slab, ngrid, n_out, grad_params + ML.w_out, ceil_div(n_out, 32),
+                           work + B.emb_slab2, ngrid, n_in, grad_params + ML.w_in};
+        const int gx_layer = ceil_div(ML.layer_size, 32), gx_plain = ceil_div(n_out, 32) + ceil_div(n_in, 32);
+        hipLaunchKernelGGL((layer_grad_reduce_kernel<F, H, A>), dim3(gx_layer > gx_plain ? gx_layer : gx_plain, L + 1), dim3(256), 0, s,
+                           work + B.node_slab, ngrid, work + B.edge_slab, E > 0 ? egrid : 0, work + B.gat_slab, ngrid,
+                           grad_params + ML.layer0, B.layer_stride, (size_t)ML.layer_size, L, pj);
     }
     EQ_CHECK_LAUNCH("egnn_backward");
     return 0;

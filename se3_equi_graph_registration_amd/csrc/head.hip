@@ -6,10 +6,13 @@
 //   head_pair_kernel   per pair (one workgroup): masked softmax weights (:717-724), top-k by a full
 //                      bitonic sort in LDS (:684), gather + 3-layer MLP logits (:760-770), BCE (:772),
 //                      similarity-MSE partials (:777-781)
+//   head_mlp_kernel    the MLP on the top-k rows; the per-node Kabsch-weight blocks (head_weights_block) ride in
+//                      the same launch as extra grid columns (both depend only on head_pair_kernel)
 //   (equigspr_kabsch_forward gives R, t from the weights)
 //   head_finalize      scalars: corr_loss + sim_loss, equi loss
 //   backward: head_pair_bwd_kernel (softmax / BCE / MLP backward, MLP weight-gradient slabs),
-//             head_node_bwd_kernel (d h_s, d h_t, d x_s, d x_t), head_mlp_reduce (slabs -> grads, +=)
+//             head_node_bwd_kernel (d h_s, d h_t, d x_s, d x_t; extra grid columns sum the MLP slabs into the grads, +=)
+// A launch inside the step's hipGraph costs ~4.8 us even when empty, hence the piggy-backed blocks.
 // Layouts: h_* [B,N,F] with row stride F; x_* [B,N,3]; labels [B,N] (float 0/1); gt_pose [B,16].
 #include "common.h"
 
@@ -304,12 +307,44 @@ __device__ __forceinline__ void stage8(float* dst, const float* __restrict__ src
     }
 }
 
+// K3 (extra blocks of the head_mlp_kernel launch): one thread per node: Kabsch weights (:718-724) and the similarity-MSE
+// partial sums (:777-781).  Block (xb, b) covers nodes [256 xb, 256 xb + 256) of pair b; its partials go to record b * nCw + xb.
+struct WeightsJob {
+    const float *sim, *rsim, *labels, *pair_f, *fin;
+    float* wts;
+    double* partC;
+};
+__device__ __forceinline__ void head_weights_block(const WeightsJob& j, int xb, int b, int N) {
+    __shared__ double red[4];
+    const int il = xb * 256 + (int)threadIdx.x;
+    double q0 = 0, q1 = 0, q2 = 0;
+    if (il < N) {
+        const size_t i = (size_t)b * N + il;
+        const float mx = j.pair_f[b * 4], den = j.pair_f[b * 4 + 1], Su = j.pair_f[b * 4 + 2];
+        const float s = j.sim[i];
+        const float u = (j.labels[i] != 0.0f && den > 0.0f) ? expf(s - mx) / den : 0.0f;
+        j.wts[i] = u / (Su + 1e-6f);
+        const float zs = (s - j.fin[2]) / (j.fin[3] + 1e-6f), zr = (j.rsim[i] - j.fin[4]) / (j.fin[5] + 1e-6f);
+        const float e = zs - zr;
+        q0 = (double)e * e; q1 = e; q2 = (double)e * (s - j.fin[2]);
+    }
+    q0 = block_sum_d(q0, red); q1 = block_sum_d(q1, red); q2 = block_sum_d(q2, red);
+    if (threadIdx.x == 0) {
+        double* rec = j.partC + ((size_t)b * ((N + 255) / 256) + xb) * 3;
+        rec[0] = q0; rec[1] = q1; rec[2] = q2;
+    }
+}
+
 __global__ __launch_bounds__(256) void head_mlp_kernel(
     const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
     const long long* __restrict__ top_idx, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
     int B, int N, int F, int K, MlpDims md, float* __restrict__ logits, float* __restrict__ a1_save,
-    float* __restrict__ a2_save, double* __restrict__ pair_part) {
+    float* __restrict__ a2_save, double* __restrict__ pair_part, int nblk, WeightsJob wj) {
+    if ((int)blockIdx.x >= nblk) {       // block-uniform: the Kabsch-weight blocks ride in this launch (both only need K2's outputs)
+        head_weights_block(wj, (int)blockIdx.x - nblk, blockIdx.y, N);
+        return;
+    }
     __shared__ float inp[kRowsPerBlock * (kMaxIn + 1)];
     __shared__ float a1[kRowsPerBlock * (kMaxH1 + 1)];
     __shared__ float a2[kRowsPerBlock * (kMaxH2 + 1)];
@@ -363,30 +398,7 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(
         bce = fmaxf(z, 0.0f) - z * y + log1pf(expf(-fabsf(z)));                          // BCEWithLogits (:772-773)
     }
     bce = block_sum_d(bce, red);
-    if (tid == 0) pair_part[(size_t)b * gridDim.x + blockIdx.x] = bce;
-}
-
-// K3: one thread per node: Kabsch weights (:718-724) and the similarity-MSE partial sums (:777-781)
-__global__ __launch_bounds__(256) void head_weights_kernel(const float* __restrict__ sim, const float* __restrict__ rsim,
-                                                           const float* __restrict__ labels, const float* __restrict__ pair_f,
-                                                           const float* __restrict__ fin, int B, int N,
-                                                           float* __restrict__ wts, double* __restrict__ partC) {
-    __shared__ double red[4];
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long M = (long long)B * N;
-    double q0 = 0, q1 = 0, q2 = 0;
-    if (i < M) {
-        const int b = (int)(i / N);
-        const float mx = pair_f[b * 4], den = pair_f[b * 4 + 1], Su = pair_f[b * 4 + 2];
-        const float s = sim[i];
-        const float u = (labels[i] != 0.0f && den > 0.0f) ? expf(s - mx) / den : 0.0f;
-        wts[i] = u / (Su + 1e-6f);
-        const float zs = (s - fin[2]) / (fin[3] + 1e-6f), zr = (rsim[i] - fin[4]) / (fin[5] + 1e-6f);
-        const float e = zs - zr;
-        q0 = (double)e * e; q1 = e; q2 = (double)e * (s - fin[2]);
-    }
-    q0 = block_sum_d(q0, red); q1 = block_sum_d(q1, red); q2 = block_sum_d(q2, red);
-    if (threadIdx.x == 0) { partC[(size_t)blockIdx.x * 3] = q0; partC[(size_t)blockIdx.x * 3 + 1] = q1; partC[(size_t)blockIdx.x * 3 + 2] = q2; }
+    if (tid == 0) pair_part[(size_t)b * nblk + blockIdx.x] = bce;
 }
 
 // out[0] = corr_loss + sim_loss, out[1] = equi loss, out[2..5] = mu_s, sd_s, mu_r, sd_r (written by K2),
@@ -521,7 +533,16 @@ __global__ __launch_bounds__(256) void head_node_bwd_kernel(
     const float* __restrict__ dinp, const float* __restrict__ gw, const float* __restrict__ pair_f,
     const float* __restrict__ pair_g, const float* __restrict__ fin, const float* __restrict__ g_cs_ptr,
     const float* __restrict__ g_equi_ptr, int B, int N, int F, int K, int in_dim, float* __restrict__ ghs,
-    float* __restrict__ ght, float* __restrict__ gxs /* += */, float* __restrict__ gxt /* += */) {
+    float* __restrict__ ght, float* __restrict__ gxs /* += */, float* __restrict__ gxt /* += */, int nbp,
+    const float* __restrict__ mlp_slab, int n_slabs, int msz, float* __restrict__ grad_mlp /* += */) {
+    if ((int)blockIdx.x >= nbp) {        // block-uniform: the MLP weight-gradient slabs of KB1, summed in fixed order, ride in this launch
+        const int t = ((int)blockIdx.x - nbp) * 256 + (int)threadIdx.x;
+        if (blockIdx.y != 0 || t >= msz) return;
+        float a = 0.0f;
+        for (int q = 0; q < n_slabs; ++q) a += mlp_slab[(size_t)q * msz + t];
+        grad_mlp[t] += a;
+        return;
+    }
     const int slot = threadIdx.x >> 5, f = threadIdx.x & 31;
     const int b = blockIdx.y, n = blockIdx.x * 8 + slot;
     if (n >= N) return;
@@ -581,14 +602,6 @@ __global__ __launch_bounds__(256) void head_node_bwd_kernel(
     }
 }
 
-__global__ void head_mlp_reduce_kernel(const float* __restrict__ slab, int B, int size, float* __restrict__ dst) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= size) return;
-    float a = 0.0f;
-    for (int b = 0; b < B; ++b) a += slab[(size_t)b * size + t];
-    dst[t] += a;
-}
-
 static inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 static inline size_t fwd_smem(int N, int Npad, int K, MlpDims md) {
     const size_t keys = sizeof(u64) * (size_t)(Npad > kCand ? Npad : kCand);
@@ -598,7 +611,7 @@ struct HeadWork { double *partA, *partC, *pair_part; float *pair_f, *pair_g; int
 static inline HeadWork head_work(void* base, int B, int N) {   // pair_part sized for kMaxK/kRowsPerBlock row blocks
     HeadWork w;
     w.nbp = ceil_div(N, 8);
-    w.nC = ceil_div((long long)B * N, 256);
+    w.nC = B * ceil_div(N, 256);
     char* p = reinterpret_cast<char*>(base);
     size_t o = 0;
     w.partA = reinterpret_cast<double*>(p + o); o += sizeof(double) * (size_t)B * w.nbp * kHeadPartials;
@@ -658,10 +671,10 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
                        B, N, Npad, F, K, md, pos, reinterpret_cast<long long*>(top_idx), logits, a1_save, a2_save, W.pair_f,
                        W.pair_part, out_scalars);
     const int nblk = ceil_div(K, kRowsPerBlock);
-    hipLaunchKernelGGL(head_mlp_kernel, dim3(nblk, B), dim3(256), 0, s, hs, ht, labels, reinterpret_cast<const long long*>(top_idx),
-                       w1, b1, w2, b2, w3, b3, B, N, F, K, md, logits, a1_save, a2_save, W.pair_part);
-    hipLaunchKernelGGL(head_weights_kernel, dim3(W.nC), dim3(256), 0, s, sim, rsim, labels, W.pair_f, out_scalars, B, N, wts,
-                       W.partC);
+    const WeightsJob wj{sim, rsim, labels, W.pair_f, out_scalars, wts, W.partC};
+    hipLaunchKernelGGL(head_mlp_kernel, dim3(nblk + ceil_div(N, 256), B), dim3(256), 0, s, hs, ht, labels,
+                       reinterpret_cast<const long long*>(top_idx), w1, b1, w2, b2, w3, b3, B, N, F, K, md, logits, a1_save, a2_save,
+                       W.pair_part, nblk, wj);
     hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, W.partC, W.nC, W.pair_part, nblk, B, N, K, out_scalars);
     EQ_CHECK_LAUNCH("head_forward");
     return 0;
@@ -689,10 +702,10 @@ extern "C" int equigspr_head_backward(const float* hs, const float* ht, const fl
     hipLaunchKernelGGL(head_pair_bwd_kernel, dim3(nblk, B), dim3(256), 0, s, hs, ht, labels, sim, W.pair_f, gw,
                        reinterpret_cast<const long long*>(top_idx), logits, a1_save, a2_save, w1, w2, w3, g_corr_sim, B, N, F, K,
                        md, W.pair_g, dinp, mlp_slab);
-    hipLaunchKernelGGL(head_node_bwd_kernel, dim3(W.nbp, B), dim3(256), 0, s, hs, ht, xs, xt, labels, gt_pose, sim, rsim, cosv,
-                       pos, dinp, gw, W.pair_f, W.pair_g, fin_scalars, g_corr_sim, g_equi, B, N, F, K, md.in, ghs, ght, gxs, gxt);
     const int msz = (int)equigspr_head_mlp_size(F);
-    hipLaunchKernelGGL(head_mlp_reduce_kernel, dim3(ceil_div(msz, 256)), dim3(256), 0, s, mlp_slab, B * nblk, msz, grad_mlp);
+    hipLaunchKernelGGL(head_node_bwd_kernel, dim3(W.nbp + ceil_div(msz, 256), B), dim3(256), 0, s, hs, ht, xs, xt, labels, gt_pose,
+                       sim, rsim, cosv, pos, dinp, gw, W.pair_f, W.pair_g, fin_scalars, g_corr_sim, g_equi, B, N, F, K, md.in, ghs, ght,
+                       gxs, gxt, W.nbp, mlp_slab, B * nblk, msz, grad_mlp);
     EQ_CHECK_LAUNCH("head_backward");
     return 0;
 }
