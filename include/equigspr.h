@@ -87,21 +87,28 @@ int64_t equigspr_egnn_layer_offset(const equigspr_egnn_config* cfg, int32_t laye
  *   edges_i64  [n_clouds, 2, n*k] or NULL: per cloud [neighbour; centre], LOCAL indices,
  *              centre-major, ascending (d2, index) -- the reference LongTensor layout.
  *   row32/col32 [n_clouds*n*k] or NULL: same edges as GLOBAL int32 node ids (device format).
+ *   row_hist   [n_clouds*n] int32 or NULL, +=: row_hist[i] += number of edges whose row (neighbour) is node i -- the
+ *              histogram equigspr_build_csr(key = row32) starts from (pass EQUIGSPR_SCRATCH_HISTOGRAM there).
  * Distance contract: d2 = fl(fl(fl(dx*dx)+fl(dy*dy))+fl(dz*dz)), ties by lower index.
  * Limits: 1 <= k <= 64, k <= n (k <= n-1 when loop==0), n <= 8192. */
 int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, int32_t k, int32_t loop,
-                       int64_t* edges_i64, int32_t* row32, int32_t* col32, int32_t force_slow_path,
-                       void* stream);
+                       int64_t* edges_i64, int32_t* row32, int32_t* col32, int32_t* row_hist,
+                       int32_t force_slow_path, void* stream);
 
 /* ---- graph index build ---------------------------------------------------------------
  * Builds rptr/rperm (key=row) or cptr/cperm (key=col): stable counting sort of edge ids.
  * Replaces the implicit scatter_add_ indexing of unsorted_segment_sum (:343-348).
  *   key [E] global ids in [0,N);  ptr [N+1];  perm [E];  inv [E] or NULL: the inverse of perm (inv[perm[p]] = p, the
  *   rinv field of equigspr_graph), written by the same pass that orders the segments;  scratch: int32 [N+1].
- *   scratch_is_zero != 0: the caller guarantees scratch is all-zero on entry and the clear is skipped.  On return scratch
- *   is all-zero again, so one buffer can be handed from call to call on the same stream. */
+ *   scratch_state says what scratch holds on entry: EQUIGSPR_SCRATCH_DIRTY (anything: it is cleared first),
+ *   EQUIGSPR_SCRATCH_ZERO (all-zero: the clear is skipped) or EQUIGSPR_SCRATCH_HISTOGRAM (scratch[i] = number of edges
+ *   with key i, e.g. the row_hist output of equigspr_knn_graph for key = row32: clear and count are skipped).  On return
+ *   scratch is all-zero again, so one buffer can be handed from call to call on the same stream. */
+#define EQUIGSPR_SCRATCH_DIRTY 0
+#define EQUIGSPR_SCRATCH_ZERO 1
+#define EQUIGSPR_SCRATCH_HISTOGRAM 2
 int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n_nodes, int32_t* ptr, int32_t* perm,
-                       int32_t* inv, int32_t* scratch, int32_t scratch_is_zero, void* stream);
+                       int32_t* inv, int32_t* scratch, int32_t scratch_state, void* stream);
 /* inv[perm[p]] = p for p in [0, n): the rinv field of equigspr_graph from rperm */
 int equigspr_invert_perm(const int32_t* perm, int32_t n, int32_t* inv, void* stream);
 /* int64 reference edge list [2,E] (one cloud, local ids) -> int32 global ids (+node_offset) */

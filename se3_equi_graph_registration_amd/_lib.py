@@ -33,7 +33,7 @@ _SIGNATURES = {
     "equigspr_egnn_param_count": (c_int64, [POINTER(EgnnConfig)]),
     "equigspr_egnn_layer_offset": (c_int64, [POINTER(EgnnConfig), c_int32]),
     "equigspr_knn_graph": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
-                                          c_void_p, c_int32, c_void_p]),
+                                          c_void_p, c_void_p, c_int32, c_void_p]),
     "equigspr_build_csr": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "equigspr_invert_perm": (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
     "equigspr_edges_i64_to_i32": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

@@ -50,7 +50,7 @@ template <int NPL>
 __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, int n_clouds, int n, int k,
                                                  int loop, long long* __restrict__ edges,
                                                  int* __restrict__ row32, int* __restrict__ col32,
-                                                 int force_slow) {
+                                                 int* __restrict__ row_hist, int force_slow) {
     __shared__ u64 list[64];
     const int lane = threadIdx.x;
     const int qg = blockIdx.x;                 // query id over all clouds
@@ -128,6 +128,7 @@ __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, in
         }
         if (row32) row32[(size_t)cloud * epc + e] = cloud * n + out_idx;
         if (col32) col32[(size_t)cloud * epc + e] = cloud * n + q;
+        if (row_hist) atomicAdd(&row_hist[cloud * n + out_idx], 1);      // the key histogram build_csr(key = row) starts from
     }
 }
 
@@ -142,7 +143,8 @@ __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, in
 constexpr int kKnnTile = 2048, kKnnQpw = 4;
 __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict__ x, int n_clouds, int n, int k, int loop,
                                                         long long* __restrict__ edges, int* __restrict__ row32,
-                                                        int* __restrict__ col32, int force_slow) {
+                                                        int* __restrict__ col32, int* __restrict__ row_hist,
+                                                        int force_slow) {
     __shared__ float tile[kKnnTile * 3];
     __shared__ u64 list[4 * kKnnQpw][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
             }
             if (row32) row32[(size_t)cloud * epc + e] = cloud * n + out_idx;
             if (col32) col32[(size_t)cloud * epc + e] = cloud * n + q;
+            if (row_hist) atomicAdd(&row_hist[cloud * n + out_idx], 1);
         }
     }
 }
@@ -324,7 +327,7 @@ __global__ void edges_i64_to_i32_kernel(const long long* __restrict__ edges, int
 }  // namespace eq
 
 extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, int32_t k, int32_t loop,
-                                  int64_t* edges_i64, int32_t* row32, int32_t* col32,
+                                  int64_t* edges_i64, int32_t* row32, int32_t* col32, int32_t* row_hist,
                                   int32_t force_slow_path, void* stream) {
     using namespace eq;
     EQ_CHECK_ARG(x != nullptr, EQUIGSPR_EINVAL, "knn_graph: x is null");
@@ -337,20 +340,20 @@ extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, i
     const dim3 grid(n_clouds * n), block(64);
     long long* e64 = reinterpret_cast<long long*>(edges_i64);
     if (n <= 256) {
-        hipLaunchKernelGGL(knn_kernel<4>, grid, block, 0, s, x, n_clouds, n, k, loop, e64, row32, col32, force_slow_path);
+        hipLaunchKernelGGL(knn_kernel<4>, grid, block, 0, s, x, n_clouds, n, k, loop, e64, row32, col32, row_hist, force_slow_path);
     } else if (n <= 2048) {      // measured: the per-query kernel is as fast as the tiled one up to 2 048 points (17.6 us at B=1)
-        hipLaunchKernelGGL(knn_kernel<32>, grid, block, 0, s, x, n_clouds, n, k, loop, e64, row32, col32, force_slow_path);
+        hipLaunchKernelGGL(knn_kernel<32>, grid, block, 0, s, x, n_clouds, n, k, loop, e64, row32, col32, row_hist, force_slow_path);
     } else {                     // 4 096 / 8 192 points: 534 -> ~120 us for two 8 192-point clouds (no 128-value register arrays)
         const int bpc = ceil_div(n, 4 * kKnnQpw);
         hipLaunchKernelGGL(knn_tiled_kernel, dim3(n_clouds * bpc), dim3(256), 0, s, x, n_clouds, n, k, loop, e64, row32, col32,
-                           force_slow_path);
+                           row_hist, force_slow_path);
     }
     EQ_CHECK_LAUNCH("knn_kernel");
     return 0;
 }
 
 extern "C" int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n_nodes, int32_t* ptr,
-                                  int32_t* perm, int32_t* inv, int32_t* scratch, int32_t scratch_is_zero, void* stream) {
+                                  int32_t* perm, int32_t* inv, int32_t* scratch, int32_t scratch_state, void* stream) {
     using namespace eq;
     EQ_CHECK_ARG(ptr && scratch && (n_edges == 0 || (key && perm)), EQUIGSPR_EINVAL, "build_csr: null pointer");
     EQ_CHECK_ARG(n_edges >= 0 && n_nodes >= 1, EQUIGSPR_EINVAL, "build_csr: bad sizes");
@@ -359,11 +362,12 @@ extern "C" int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n
     // the key-load latency.)  The clear is skipped for a scratch the caller knows to be zero: the sort pass re-zeroes every
     // word the count/fill passes touched, so a buffer can be handed from call to call (hipMemsetAsync of N+1 words is
     // two fill launches -- an aligned body and a tail -- i.e. ~10 us of a 0.5 ms step)
-    if (!scratch_is_zero) {
+    EQ_CHECK_ARG(scratch_state >= 0 && scratch_state <= 2, EQUIGSPR_EINVAL, "build_csr: scratch_state must be 0, 1 or 2");
+    if (scratch_state == EQUIGSPR_SCRATCH_DIRTY) {
         hipError_t err = hipMemsetAsync(scratch, 0, sizeof(int) * (size_t)(n_nodes + 1), s);
         if (err != hipSuccess) { set_error("build_csr memset: %s", hipGetErrorString(err)); return (int)err; }
     }
-    if (n_edges > 0)
+    if (n_edges > 0 && scratch_state != EQUIGSPR_SCRATCH_HISTOGRAM)      // (equigspr_knn_graph can leave the histogram behind)
         hipLaunchKernelGGL(csr_count_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, key, n_edges, scratch);
     // large N: two-level scan; its chunk totals borrow the head of `perm`, which is only written by the fill below
     const int chunks = ceil_div(n_nodes, kScanChunk);

@@ -50,5 +50,12 @@ def build_pair_graph(xyz_src: torch.Tensor, xyz_tgt: torch.Tensor, k: int, loop:
     """``xyz_* [B,N,3]`` -> one DeviceGraph over the 2B clouds ``[src_0..src_B-1, tgt_0..tgt_B-1]``."""
     x = ops.cat_or_view(xyz_src.float(), xyz_tgt.float()).contiguous()     # a view when src/tgt are halves of one tensor
     nc, n, _ = x.shape
-    _, r32, c32 = ops.knn_graph_batched(x, k, loop, want_i64=False, want_i32=True)
-    return DeviceGraph(r32, c32, nc * n, knn_k=k, need_col_index=need_col_index)
+    hist, zeroed = ops._csr_scratch(x.device, nc * n + 1)      # the search leaves the row histogram of the index build in it
+    if not zeroed:
+        hist = None
+    try:
+        _, r32, c32 = ops.knn_graph_batched(x, k, loop, want_i64=False, want_i32=True, row_hist=hist)
+    except Exception:
+        ops._CSR_SCRATCH.clear()
+        raise
+    return DeviceGraph(r32, c32, nc * n, knn_k=k, need_col_index=need_col_index, row_hist=hist)

@@ -93,12 +93,14 @@ def _csr_scratch(dev, n_words):
 class DeviceGraph:
     """Batched graph in the device format (int32 global ids + inverse indices)."""
 
-    def __init__(self, row32, col32, n_nodes: int, knn_k: Optional[int] = None, need_col_index: bool = True):
+    def __init__(self, row32, col32, n_nodes: int, knn_k: Optional[int] = None, need_col_index: bool = True,
+                 row_hist: Optional[torch.Tensor] = None):
+        """``row_hist``: the zero-on-exit counter array already holding the row histogram (``knn_graph_batched``)."""
         L = _lib.lib()
         self.row, self.col = _need(row32, "row32", torch.int32, 1), _need(col32, "col32", torch.int32, 1)
         self.n_nodes, self.n_edges = int(n_nodes), int(row32.numel())
         dev = row32.device
-        scratch, zeroed = _csr_scratch(dev, self.n_nodes + 1)
+        scratch, zeroed = (row_hist, 2) if row_hist is not None else _csr_scratch(dev, self.n_nodes + 1)
         self.rptr = torch.empty(self.n_nodes + 1, dtype=torch.int32, device=dev)
         self.rperm = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
         self.rinv = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
@@ -154,8 +156,10 @@ class DeviceGraph:
 
 
 def knn_graph_batched(x: torch.Tensor, k: int, loop: bool = True, want_i64: bool = True, want_i32: bool = False,
-                      force_slow_path: bool = False):
-    """``x [n_clouds, n, 3]`` -> (edges int64 ``[n_clouds,2,n*k]`` | None, row32 | None, col32 | None)."""
+                      force_slow_path: bool = False, row_hist: Optional[torch.Tensor] = None):
+    """``x [n_clouds, n, 3]`` -> (edges int64 ``[n_clouds,2,n*k]`` | None, row32 | None, col32 | None).
+    ``row_hist`` (int32, >= n_clouds*n words, zero on entry): also counts the edges per row node, which is where
+    ``equigspr_build_csr`` would otherwise start."""
     _need(x, "x", torch.float32, 3)
     nc, n, three = x.shape
     if three != 3:
@@ -164,7 +168,7 @@ def knn_graph_batched(x: torch.Tensor, k: int, loop: bool = True, want_i64: bool
     e64 = torch.empty(nc, 2, n * k, dtype=torch.int64, device=dev) if want_i64 else None
     r32 = torch.empty(nc * n * k, dtype=torch.int32, device=dev) if want_i32 else None
     c32 = torch.empty(nc * n * k, dtype=torch.int32, device=dev) if want_i32 else None
-    _lib.check(_lib.lib().equigspr_knn_graph(_p(x), nc, n, int(k), int(bool(loop)), _p(e64), _p(r32), _p(c32),
+    _lib.check(_lib.lib().equigspr_knn_graph(_p(x), nc, n, int(k), int(bool(loop)), _p(e64), _p(r32), _p(c32), _p(row_hist),
                                              int(bool(force_slow_path)), _stream()), "knn_graph")
     return e64, r32, c32
 

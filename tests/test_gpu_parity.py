@@ -163,6 +163,17 @@ def test_build_csr_scratch_contract_and_inverse(pk):
         row = graph.row.cpu().numpy()
         np.testing.assert_array_equal(graph.rperm.cpu().numpy(), np.argsort(row, kind="stable"))
         assert all(int(b.abs().sum()) == 0 for b in ops._CSR_SCRATCH.values())
+        inv = np.empty(row.size, dtype=np.int64)
+        inv[np.argsort(row, kind="stable")] = np.arange(row.size)
+        np.testing.assert_array_equal(graph.rinv.cpu().numpy(), inv)
+    # the search's row histogram (what EQUIGSPR_SCRATCH_HISTOGRAM hands to build_csr), per-query and tiled kernels, += semantics
+    for npts, k in ((600, 9), (2500, 6)):
+        x = torch.rand(2, npts, 3, generator=g).cuda()
+        hist = torch.ones(2 * npts, dtype=torch.int32, device="cuda")
+        _, r32, _ = ops.knn_graph_batched(x, k, True, want_i64=False, want_i32=True, row_hist=hist)
+        np.testing.assert_array_equal(hist.cpu().numpy(), 1 + np.bincount(r32.cpu().numpy(), minlength=2 * npts))
+    with pytest.raises(RuntimeError, match="scratch_state"):
+        _lib.check(L.equigspr_build_csr(p(key32), e, n, p(ptr), p(perm), None, p(scratch), 3, ops._stream()), "build_csr")
 
 
 # ------------------------------------------------------------------------------------ EGNN forward
