@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
 
 // K2b: the correspondence MLP on the K selected rows (:760-773), kRowsPerBlock rows per workgroup so the
 // work spreads over the chip instead of one CU per pair.  grid (ceil(K/kRowsPerBlock), B)
-constexpr int kRowsPerBlock = 16;
+constexpr int kRowsPerBlock = 8;
 constexpr int kMaxIn = 128, kMaxH1 = 64, kMaxH2 = 32;
 
 // global -> LDS staging with 8 loads of a thread in flight before its 8 stores (a load/store pair per iteration exposes
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const double* __rest
 // backward
 // ---------------------------------------------------------------------------------------------------
 // KB1: grid (ceil(K/kRowsPerBlock), B): BCE + MLP backward on this block's rows, its MLP weight-gradient slab;
-// block 0 of each pair also reduces gwu = sum_i gw_i u_i for the softmax backward.
+// one extra block per pair reduces gwu = sum_i gw_i u_i for the softmax backward.
 // mlp slab layout: dW1 [h1*in] | db1 [h1] | dW2 [h2*h1] | db2 [h2] | dW3 [h2] | db3 [1]
 __global__ __launch_bounds__(256) void head_pair_bwd_kernel(
     const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void head_pair_bwd_kernel(
     const long long* __restrict__ top_idx, const float* __restrict__ logits, const float* __restrict__ a1_save,
     const float* __restrict__ a2_save, const float* __restrict__ w1, const float* __restrict__ w2,
     const float* __restrict__ w3, const float* __restrict__ g_cs_ptr, int B, int N, int F, int K, MlpDims md,
-    float* __restrict__ pair_g /*[B]*/, float* __restrict__ dinp /*[B][K][in]*/, float* __restrict__ mlp_slab) {
+    float* __restrict__ pair_g /*[B]*/, float* __restrict__ dinp /*[B][K][in]*/, float* __restrict__ mlp_slab, int nblk) {
     constexpr int R = kRowsPerBlock;
     __shared__ float inp[R * (kMaxIn + 1)];
     __shared__ float a1[R * (kMaxH1 + 1)];
@@ -452,13 +452,14 @@ __global__ __launch_bounds__(256) void head_pair_bwd_kernel(
     const float* yb = labels + (size_t)b * N;
     const float* gwb = gw + (size_t)b * N;
     const int ld_in = md.in + 1, ld1 = md.h1 + 1, ld2 = md.h2 + 1;
-    if (blockIdx.x == 0) {
+    if ((int)blockIdx.x == nblk) {       // one extra block per pair (not on the MLP blocks' critical path): gwu = sum_i gw_i u_i
         const float mx = pair_f[b * 4], den = pair_f[b * 4 + 1];
         double gwu = 0;
         for (int i = tid; i < N; i += 256)
             if (yb[i] != 0.0f && den > 0.0f) gwu += (double)gwb[i] * (double)(expf(sb[i] - mx) / den);
         gwu = block_sum_d(gwu, red);
         if (tid == 0) pair_g[b] = (float)gwu;
+        return;
     }
     stage8(W1, w1, md.h1 * md.in, [](int t) { return t; }, [](int t) { return t; });
     stage8(W2, w2, md.h2 * md.h1, [](int t) { return t; }, [](int t) { return t; });
@@ -496,7 +497,7 @@ __global__ __launch_bounds__(256) void head_pair_bwd_kernel(
     }
     // ---- weight-gradient slab of this block (thread-owned outputs, sums over its rows)
     const int msz = md.h1 * md.in + md.h1 + md.h2 * md.h1 + md.h2 + md.h2 + 1;
-    float* sl = mlp_slab + ((size_t)b * gridDim.x + blockIdx.x) * msz;
+    float* sl = mlp_slab + ((size_t)b * nblk + blockIdx.x) * msz;
     for (int t = tid; t < md.h1 * md.in; t += 256) {
         const int o = t / md.in, c = t - o * md.in;
         float acc = 0.0f;
@@ -699,9 +700,9 @@ extern "C" int equigspr_head_backward(const float* hs, const float* ht, const fl
     const float* w2 = w1 + md.h1 * md.in + md.h1;
     const float* w3 = w2 + md.h2 * md.h1 + md.h2;
     const int nblk = ceil_div(K, kRowsPerBlock);
-    hipLaunchKernelGGL(head_pair_bwd_kernel, dim3(nblk, B), dim3(256), 0, s, hs, ht, labels, sim, W.pair_f, gw,
+    hipLaunchKernelGGL(head_pair_bwd_kernel, dim3(nblk + 1, B), dim3(256), 0, s, hs, ht, labels, sim, W.pair_f, gw,
                        reinterpret_cast<const long long*>(top_idx), logits, a1_save, a2_save, w1, w2, w3, g_corr_sim, B, N, F, K,
-                       md, W.pair_g, dinp, mlp_slab);
+                       md, W.pair_g, dinp, mlp_slab, nblk);
     const int msz = (int)equigspr_head_mlp_size(F);
     hipLaunchKernelGGL(head_node_bwd_kernel, dim3(W.nbp + ceil_div(msz, 256), B), dim3(256), 0, s, hs, ht, xs, xt, labels, gt_pose,
                        sim, rsim, cosv, pos, dinp, gw, W.pair_f, W.pair_g, fin_scalars, g_corr_sim, g_equi, B, N, F, K, md.in, ghs, ght,
