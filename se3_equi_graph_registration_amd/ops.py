@@ -474,3 +474,56 @@ class FlatAdam:
     def reset_state(self):
         for t in self.exp_avg + self.exp_avg_sq + [self.step_dev]:
             t.zero_()
+
+    # ---- torch.optim.Adam-compatible state (the reference's checkpoints store ``optimizer.state_dict()``, train :1330-1336)
+    def _locate(self, p):
+        """(bucket index, offset) of parameter ``p``, which must be a view into one of the flat parameter buckets."""
+        for k, (flat, _) in enumerate(self.buckets):
+            off = p.data_ptr() - flat.data_ptr()
+            if p.device == flat.device and 0 <= off and off + p.numel() * 4 <= flat.numel() * 4 and off % 4 == 0:
+                return k, off // 4
+        raise ValueError("parameter is not a view into this optimizer's flat buckets")
+
+    def state_dict(self, params):
+        """``torch.optim.Adam(params).state_dict()`` layout for ``params`` (an ordered list of views into the buckets):
+        per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` and one param group.  A parameter whose moments are still
+        exactly zero after at least one step never received a gradient and gets no entry -- as in torch."""
+        params = list(params)
+        step = float(self.step_dev[0].item())
+        state = {}
+        for i, p in enumerate(params):
+            k, off = self._locate(p)
+            m = self.exp_avg[k][off:off + p.numel()].view(p.shape)
+            v = self.exp_avg_sq[k][off:off + p.numel()].view(p.shape)
+            if step > 0 and bool((m != 0).any() | (v != 0).any()):
+                state[i] = {"step": torch.tensor(step), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd, params):
+        """Inverse of ``state_dict``; also accepts what ``torch.optim.Adam.state_dict()`` of the reference run holds.  All
+        stepped parameters must share one step count (one flat update has one bias correction); weight decay and amsgrad
+        are not supported, as the reference does not use them (train :1412)."""
+        params = list(params)
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(params):
+            raise ValueError(f"optimizer state has {sum(len(g['params']) for g in groups)} parameters in {len(groups)} groups; "
+                             f"expected one group of {len(params)}")
+        g = groups[0]
+        if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+            raise ValueError("FlatAdam: weight_decay / amsgrad / maximize are not supported")
+        steps = {float(st["step"]) for st in sd["state"].values()}
+        if len(steps) > 1:
+            raise ValueError(f"FlatAdam keeps one step count; the state holds {sorted(steps)}")
+        self.reset_state()
+        for i, st in sd["state"].items():
+            p = params[g["params"].index(i)] if g["params"] != list(range(len(params))) else params[int(i)]
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} vs parameter {tuple(p.shape)}")
+            k, off = self._locate(p)
+            self.exp_avg[k][off:off + p.numel()].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[k][off:off + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+        self.step_dev[0] = steps.pop() if steps else 0.0
+        self.lr, self.betas, self.eps = float(g["lr"]), (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"])

@@ -1,0 +1,153 @@
+"""The two callers either side of the hot path and the checkpoint format (reference ``src/3dmatch_train_egnn_with_batch.py``):
+
+* ``train_one_epoch`` -- :964-1140: per batch kNN graphs (k = 16, self loops), model forward, ``corr + rot + trans`` loss
+  (:1120), backward, optimizer step.
+* ``validate``        -- :1143-1308: the same forward under ``no_grad``, running means.
+* ``save_checkpoint`` / ``load_checkpoint`` -- :1311-1396: ``{'epoch', 'egnn_state_dict', 'cross_attention_state_dict',
+  'optimizer_state_dict'}``; the optimizer entry is ``torch.optim.Adam.state_dict()``-shaped, so a run can resume from a
+  checkpoint the reference wrote and the reference can resume from one written here.
+* ``make_optimizer``  -- flattens the model into the joint parameter/gradient bucket (``dp.DataParallelStep``) and returns
+  the one-launch Adam over it (reference: ``torch.optim.Adam(model.parameters(), lr)``, :1412).
+
+No logging back ends (tensorboard / wandb writers are accepted and ignored), no schedulers: those stay the caller's.
+Everything between the loader and ``loss.item()`` runs in the HIP kernels; batches are staged to HBM one step ahead.
+"""
+import os
+
+import torch
+
+from . import ops
+from .datasets import DeviceBatches
+from .dp import DataParallelStep
+from .graph import build_pair_graph
+from .pose import registration_loss
+
+
+class StepOptimizer:
+    """``FlatAdam`` over the model's joint bucket with the ``torch.optim`` calls the reference loop makes."""
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, process_group=None):
+        self.model = model
+        model.egnn._ensure_flat()
+        self.dp = DataParallelStep(model, model.egnn, process_group=process_group)
+        self.params = list(model.parameters())                  # torch.optim.Adam(model.parameters()) order
+        self.adam = ops.FlatAdam([(model.egnn.flat_params, model.egnn.flat_grads), (self.dp.head.flat, self.dp.head.grad)],
+                                 lr=lr, betas=betas, eps=eps)
+        self.dp.zero_grad()
+
+    def zero_grad(self, set_to_none: bool = False):
+        pass        # step() clears every gradient as it consumes it (one launch); the buckets start zeroed
+
+    def step(self):
+        self.dp.sync()                                          # mean all-reduce of the joint bucket when world_size > 1
+        self.adam.step(zero_grad=True)
+
+    def state_dict(self):
+        return self.adam.state_dict(self.params)
+
+    def load_state_dict(self, sd):
+        self.adam.load_state_dict(sd, self.params)
+
+    @property
+    def param_groups(self):
+        return [{"lr": self.adam.lr, "betas": self.adam.betas, "eps": self.adam.eps, "params": self.params}]
+
+
+def make_optimizer(model, lr=1e-4, **kw) -> StepOptimizer:
+    return StepOptimizer(model, lr=lr, **kw)
+
+
+def _device_batches(dataloader, device):
+    first_is_cuda = isinstance(dataloader, DeviceBatches)
+    return dataloader if first_is_cuda else DeviceBatches(dataloader, device=device)
+
+
+def _forward(model, batch, k):
+    corr, labels, xyz_0, xyz_1, feat_0, feat_1, gt_pose = batch
+    graph = build_pair_graph(xyz_0, xyz_1, k, loop=True)        # knn_graph(xyz[i], k=16, loop=True) per cloud (:1005-1006)
+    out = model(feat_0, xyz_0, graph, None, feat_1, xyz_1, graph, None, corr, labels, gt_pose)
+    loss, rot, trans = registration_loss(out[0], out[1], out[2], gt_pose)     # corr.mean() + rot.mean() + trans.mean() (:1120)
+    return out, loss, rot, trans
+
+
+def train_one_epoch(model, dataloader, optimizer, device, epoch, writer=None, use_pointnet=False, log_interval=10, beta=1, k=16):
+    """One pass over ``dataloader`` (7-tuples of the dataset classes); returns the average loss.  NaN losses -- the
+    reference's arccos pose loss has them at a perfect fit and for pairs without inliers -- are skipped, not stepped."""
+    if use_pointnet:
+        raise NotImplementedError("use_pointnet=True: encode the clouds with se3_equi_graph_registration_amd.PointNet first "
+                                  "(the reference's call at :1034-1038 passes the arguments in the wrong order)")
+    model.train()
+    total, n = 0.0, 0
+    for batch_idx, batch in enumerate(_device_batches(dataloader, device)):
+        optimizer.zero_grad()
+        _, loss, _, _ = _forward(model, batch, k)
+        loss.backward()
+        value = loss.item()
+        if value != value:
+            if hasattr(optimizer, "dp"):
+                optimizer.dp.zero_grad()
+            else:
+                optimizer.zero_grad()
+            continue
+        optimizer.step()
+        total, n = total + value, n + 1
+        if log_interval and batch_idx % log_interval == 0:
+            print(f"Epoch [{epoch + 1}], Batch [{batch_idx + 1}], Loss: {value:.6f}")
+    avg = total / max(n, 1)
+    print(f"Epoch [{epoch + 1}], Average Loss: {avg:.6f}")
+    return avg
+
+
+@torch.no_grad()
+def validate(model, dataloader, device, epoch, writer=None, use_pointnet=False, beta=1, k=16):
+    """Returns ``(avg_loss, avg_rot_loss + avg_trans_loss, avg_corr_loss)`` over the batches with a finite loss."""
+    model.eval()
+    was_variant = getattr(model, "variant", None)
+    if was_variant is not None:
+        model.variant = "train"          # the reference validates with the training forward (:1208) -- it needs the losses
+    sums, n = [0.0, 0.0, 0.0, 0.0], 0
+    try:
+        for batch in _device_batches(dataloader, device):
+            out, loss, rot, trans = _forward(model, batch, k)
+            vals = [loss.item(), rot.mean().item(), trans.mean().item(), out[2].mean().item()]
+            if vals[0] != vals[0]:
+                continue
+            sums, n = [a + b for a, b in zip(sums, vals)], n + 1
+    finally:
+        if was_variant is not None:
+            model.variant = was_variant
+    avg = [s / max(n, 1) for s in sums]
+    print(f"Validation Loss: {avg[0]:.6f} | Pose rot Loss: {avg[1]:.6f} | Pose trans Loss: {avg[2]:.6f}")
+    return avg[0], avg[1] + avg[2], avg[3]
+
+
+def save_checkpoint(epoch, pointnet, egnn, cross_attention, optimizer, save_dir="./checkpoints2", is_best=False, use_pointnet=False):
+    """``save_dir/model_epoch_{epoch}.pth`` (+ ``save_dir/best_checkpoint``) in the reference layout (:1311-1348)."""
+    os.makedirs(save_dir, exist_ok=True)
+    ckpt = {"epoch": epoch, "egnn_state_dict": egnn.state_dict(), "cross_attention_state_dict": cross_attention.state_dict(),
+            "optimizer_state_dict": optimizer.state_dict()}
+    if use_pointnet and pointnet is not None:
+        ckpt["pointnet_state_dict"] = pointnet.state_dict()
+    path = os.path.join(save_dir, f"model_epoch_{epoch}.pth")
+    torch.save(ckpt, path)
+    if is_best:
+        torch.save(ckpt, os.path.join(save_dir, "best_checkpoint"))
+    return path
+
+
+def load_checkpoint(checkpoint_path, pointnet=None, egnn=None, cross_attention=None, optimizer=None, use_pointnet=False,
+                    device="cuda:0"):
+    """Restores what is passed in and returns ``(checkpoint, epoch)`` (:1350-1396).  ``cross_attention`` contains the EGNN:
+    loading both, as the reference does, writes the EGNN weights twice with the same values."""
+    if not os.path.exists(checkpoint_path):
+        raise FileNotFoundError(f"Checkpoint file {checkpoint_path} not found.")
+    ckpt = torch.load(checkpoint_path, map_location=device, weights_only=False)
+    if use_pointnet and pointnet is not None and "pointnet_state_dict" in ckpt:
+        pointnet.load_state_dict(ckpt["pointnet_state_dict"])
+    if egnn is not None and "egnn_state_dict" in ckpt:
+        egnn.load_state_dict(ckpt["egnn_state_dict"])
+    if cross_attention is not None and "cross_attention_state_dict" in ckpt:
+        cross_attention.load_state_dict(ckpt["cross_attention_state_dict"])
+    if optimizer is not None and "optimizer_state_dict" in ckpt:
+        optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+    return ckpt, ckpt.get("epoch", 0)

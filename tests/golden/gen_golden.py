@@ -14,6 +14,7 @@ kNN edges come from ``oracle.knn_graph`` (torch_cluster is not installable here;
 oracle header: that boundary is pinned by known-answer tests, not by these vectors).
 """
 import contextlib
+import copy
 import importlib.util
 import io
 import os
@@ -466,6 +467,91 @@ def gen_metrics_fixture(name, pairs=6, n=512, seed=51):
     print("wrote", name)
 
 
+def gen_resume_fixture(tr, name, n=512, k=12, feat=32, n_layers=2, heads=1, seed=3, warm=3, steps=2, lr=1e-3):
+    """Checkpoint/resume and the whole training step against the real reference + torch.optim.Adam.
+
+    (a) A reference model (the well-conditioned head of pair_n512_k12_l2_wellcond.npz: the shipped checkpoint's weights give
+    the reference's OWN backward non-finite gradients on a synthetic pair -- SVD backward, SURVEY 7 hard part 2) takes `warm`
+    real training steps (train :1120-1127: loss = corr + rot + trans, backward, optimizer.step); the weights and
+    optimizer.state_dict() at that point are the "checkpoint".  `steps` further steps are the expected continuation, in
+    fp32 and fp64.  (b) The layout of the SHIPPED checkpoint-3dmatch.pth: parameter names / shapes in model.parameters()
+    order, which of them carry Adam state, the step count and hyper-parameters."""
+    p, e_s, e_t = pair_inputs(1234 + seed, n, feat, k, tgt_noise=0.05)
+    out = {"k": np.int64(k), "n_layers": np.int64(n_layers), "heads": np.int64(heads), "steps": np.int64(steps),
+           "warm": np.int64(warm), "lr": np.float64(lr)}
+    for kk in ("src", "tgt", "feat_src", "feat_tgt", "labels", "gt_pose", "corr"):
+        out["in." + kk] = p[kk].numpy()
+
+    def one_step(cross, opt, dt):
+        opt.zero_grad()
+        R, t, closs, equi, hs, xs, ht, xt, _ = run_pair(tr, cross, p, e_s, e_t, dt)
+        rl, tl = tr.pose_loss(R, t, p["gt_pose"][None].to(dt))
+        loss = closs.mean() + rl.mean() + tl.mean()
+        loss.backward()
+        assert all(torch.isfinite(q.grad).all() for q in cross.parameters() if q.grad is not None)
+        opt.step()
+        return float(loss)
+
+    egnn0 = build_egnn(tr, feat, n_layers, heads, seed)
+    torch.manual_seed(seed + 1)
+    cross0 = tr.CrossAttentionPoseRegression(egnn0, num_nodes=n, hidden_nf=feat, device="cpu")
+    with torch.no_grad():
+        egnn0.embedding_out.weight.mul_(0.02)
+        egnn0.embedding_out.bias.mul_(0.02)
+    cross0.train()
+    opt0 = torch.optim.Adam(cross0.parameters(), lr=lr)
+    out["warm.loss"] = np.array([one_step(cross0, opt0, torch.float32) for _ in range(warm)])
+    names = [nm for nm, _ in cross0.named_parameters()]
+    out["names"] = np.array(names)
+    sd0 = copy.deepcopy(opt0.state_dict())
+    out["opt.step"] = np.float64(float(next(iter(sd0["state"].values()))["step"]))
+    out["opt.has_state"] = np.array([i in sd0["state"] for i in range(len(names))])
+    for i, st in sd0["state"].items():
+        out[f"opt.m.{i}"], out[f"opt.v.{i}"] = st["exp_avg"].numpy().copy(), st["exp_avg_sq"].numpy().copy()
+    for nm, v in cross0.state_dict().items():
+        if not nm.endswith("num_batches_tracked"):
+            out["w0." + nm] = v.detach().numpy().copy()
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        with default_dtype(dt):
+            e2 = build_egnn(tr, feat, n_layers, heads, seed)
+            c2 = tr.CrossAttentionPoseRegression(e2, num_nodes=n, hidden_nf=feat, device="cpu")
+            c2.load_state_dict(cross0.state_dict())
+            c2 = c2.to(dt)
+            c2.train()
+            o2 = torch.optim.Adam(c2.parameters(), lr=lr)
+            o2.load_state_dict(copy.deepcopy(sd0))            # the resume itself (torch casts the moments to the parameter dtype;
+                                                              # a copy: load_state_dict keeps the caller's `step` tensors alive and steps them)
+            for s_i in range(1, steps + 1):
+                out[f"{tag}.loss.{s_i}"] = np.float64(one_step(c2, o2, dt))
+                for nm, prm in c2.named_parameters():
+                    out[f"{tag}.w{s_i}.{nm}"] = prm.detach().numpy().copy()
+    # (b) the shipped checkpoint's layout
+    ck = torch.load(os.path.join(REF, "checkpoints", "checkpoint-3dmatch.pth"), map_location="cpu", weights_only=False)
+    es = build_egnn(tr, 32, 3, 4, 0)
+    cs = tr.CrossAttentionPoseRegression(es, num_nodes=2048, hidden_nf=32, device="cpu")
+    cs.load_state_dict(ck["cross_attention_state_dict"])
+    os_ = torch.optim.Adam(cs.parameters(), lr=1e-4)
+    os_.load_state_dict(ck["optimizer_state_dict"])
+    ship = list(cs.named_parameters())
+    for i, (nm, prm) in enumerate(ship):
+        st = ck["optimizer_state_dict"]["state"].get(i)
+        assert st is None or tuple(st["exp_avg"].shape) == tuple(prm.shape), (i, nm)
+    g0 = ck["optimizer_state_dict"]["param_groups"][0]
+    out["ship.names"] = np.array([nm for nm, _ in ship])
+    out["ship.shapes"] = np.array(["x".join(map(str, prm.shape)) for _, prm in ship])
+    out["ship.has_state"] = np.array([i in ck["optimizer_state_dict"]["state"] for i in range(len(ship))])
+    out["ship.step"] = np.float64(float(next(iter(ck["optimizer_state_dict"]["state"].values()))["step"]))
+    out["ship.lr"], out["ship.betas"], out["ship.eps"] = np.float64(g0["lr"]), np.array(g0["betas"]), np.float64(g0["eps"])
+    out["ship.epoch"] = np.int64(ck["epoch"])
+    d = max(np.abs(out[f"f32.w{steps}.{nm}"] - out[f"f64.w{steps}.{nm}"]).max() for nm in names)
+    mv = max(np.abs(out[f"f64.w{steps}.{nm}"] - out["w0." + nm]).max() for nm in names)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name, "| warm losses", np.round(out["warm.loss"], 4).tolist(), "| with state", int(out["opt.has_state"].sum()), "of",
+          len(names), "| loss", [round(float(out[f"f64.loss.{i}"]), 4) for i in range(1, steps + 1)],
+          "| max move %.3e, f32-f64 gap %.3e" % (mv, d), "| shipped: step", out["ship.step"], "state on", int(out["ship.has_state"].sum()),
+          "of", len(ship))
+
+
 def gen_datasets_fixture(name, n_corr=600, feat=40, seed=71):
     """N3: the real datasets/ThreeDMatch.py and datasets/KITTI.py classes on synthetic pair records written to a temp
     directory in the three on-disk layouts; np.random / random are seeded before every __getitem__.  Stored: the raw
@@ -585,6 +671,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "pointnet":
         gen_pointnet_fixture(tr, "pointnet_n200_k6.npz")
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "resume":
+        gen_resume_fixture(tr, "ckpt_resume_step.npz")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "gcn":
         gen_gcn_fixture("gcn_n300_k9.npz")
         return
@@ -611,6 +700,7 @@ def main():
     gen_metrics_fixture("metrics_cases.npz")
     gen_pointnet_fixture(tr, "pointnet_n200_k6.npz")
     gen_datasets_fixture("datasets_cases.npz")
+    gen_resume_fixture(tr, "ckpt_resume_step.npz")
 
 
 if __name__ == "__main__":

@@ -202,3 +202,22 @@ def test_missing_extension_and_cpu_tensors_fail_loudly():
         with pytest.raises((RuntimeError, NotImplementedError)):
             with torch.no_grad():
                 call()
+
+
+def test_parameter_order_matches_the_shipped_checkpoint_layout(golden_dir):
+    """torch.optim.Adam state is keyed by position in model.parameters(); names and shapes must line up with the reference
+    model's for its shipped checkpoint (97 parameters, 85 with Adam state) to resume here (tests/golden/ckpt_resume_step.npz,
+    `ship.*` entries, written from checkpoints/checkpoint-3dmatch.pth by gen_golden.py)."""
+    import os
+    import numpy as np
+    import se3_equi_graph_registration_amd as pk
+    fx = np.load(os.path.join(golden_dir, "ckpt_resume_step.npz"))
+    egnn = pk.EGNN(32, 32, 32, in_edge_nf=1, device="cpu", n_layers=3, num_heads=4)
+    model = pk.CrossAttentionPoseRegression(egnn, num_nodes=2048, hidden_nf=32, device="cpu")
+    mine = list(model.named_parameters())
+    assert [n for n, _ in mine] == fx["ship.names"].tolist()
+    assert ["x".join(map(str, p.shape)) for _, p in mine] == fx["ship.shapes"].tolist()
+    assert len(mine) == 97 and int(fx["ship.has_state"].sum()) == 85
+    # parameters without Adam state in the shipped file are exactly the modules forward never touches (train :602-618)
+    unused = [n for n, has in zip(fx["ship.names"].tolist(), fx["ship.has_state"]) if not has]
+    assert unused and all(n.split(".")[0] in ("shared_mlp_decoder", "shallow_mlp_pose", "bn1", "bn2") for n in unused)
