@@ -27,7 +27,7 @@ extern "C" {
 
 #define EQUIGSPR_EINVAL   (-1)  /* bad shape / size / null pointer                         */
 #define EQUIGSPR_ENOTSUP  (-2)  /* configuration outside the compiled kernel set             */
-#define EQUIGSPR_ABI_VERSION 3
+#define EQUIGSPR_ABI_VERSION 4
 
 /* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
  * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
@@ -173,6 +173,9 @@ int equigspr_kabsch_backward(const float* src, const float* tgt, const float* w,
  * logits [B,K], a1 [B,K,F], a2 [B,K,F/2]; out_scalars (16 floats): [0] = corr_loss+sim_loss, [1] = equi
  * loss, [2..9] = statistics reused by the backward.  work: equigspr_head_work_bytes bytes (8-byte aligned),
  * must be passed unchanged to the backward.  Limits: F <= 64, K <= min(256, N), N <= 4096.
+ * kabsch_R [B,9], kabsch_t [B,3], kabsch_aux [B*EQUIGSPR_KABSCH_AUX] (all three or all NULL): also performs
+ * equigspr_kabsch_forward(xs, xt, wts, ...) -- identical results and aux record -- inside the launch that finishes the
+ * loss scalars, instead of two more launches.
  * Backward: g_corr_sim / g_equi are DEVICE scalars (may be NULL = 0); gw = dL/d wts from
  * equigspr_kabsch_backward; writes ghs,ght; ADDS the equi-loss terms into gxs,gxt (which hold the
  * Kabsch coordinate gradients); ADDS into grad_mlp. */
@@ -184,7 +187,7 @@ int equigspr_head_forward(const float* hs, const float* ht, const float* raw_hs,
                           const float* mlp, int32_t B, int32_t N, int32_t F, int32_t F_raw, int32_t K,
                           float* sim, float* rsim, float* cosv, int32_t* pos, float* wts, int64_t* top_idx,
                           float* logits, float* a1_save, float* a2_save, void* work, float* out_scalars,
-                          void* stream);
+                          float* kabsch_R, float* kabsch_t, float* kabsch_aux, void* stream);
 int equigspr_head_backward(const float* hs, const float* ht, const float* xs, const float* xt,
                            const float* labels, const float* gt_pose, const float* mlp, const float* sim,
                            const float* rsim, const float* cosv, const int32_t* pos, const float* wts,

@@ -52,7 +52,7 @@ _SIGNATURES = {
     "equigspr_head_mlp_size": (c_int64, [c_int32]),
     "equigspr_head_work_bytes": (c_int64, [c_int32, c_int32]),
     "equigspr_head_slab_count": (c_int64, [c_int32, c_int32]),
-    "equigspr_head_forward": (ctypes.c_int, [c_void_p] * 9 + [c_int32] * 5 + [c_void_p] * 12),
+    "equigspr_head_forward": (ctypes.c_int, [c_void_p] * 9 + [c_int32] * 5 + [c_void_p] * 15),
     "equigspr_head_backward": (ctypes.c_int, [c_void_p] * 20 + [c_int32] * 4 + [c_void_p] * 9),
     "equigspr_pose_loss_forward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "equigspr_pose_loss_backward": (ctypes.c_int, [c_void_p] * 5 + [c_int32] + [c_void_p] * 3),
@@ -103,7 +103,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if L.equigspr_abi_version() != 3:
+        if L.equigspr_abi_version() != 4:
             raise RuntimeError("libequigspr.so ABI version mismatch")
         _lib = L
     return _lib

@@ -8,13 +8,15 @@
 //                      similarity-MSE partials (:777-781)
 //   head_mlp_kernel    the MLP on the top-k rows; the per-node Kabsch-weight blocks (head_weights_block) ride in
 //                      the same launch as extra grid columns (both depend only on head_pair_kernel)
-//   (equigspr_kabsch_forward gives R, t from the weights)
-//   head_finalize      scalars: corr_loss + sim_loss, equi loss
+//   head_tail_kernel   Kabsch moments of the weighted clouds, the 3x3 SVD solve by the last block of each pair (ticket), and
+//                      the loss scalars (corr_loss + sim_loss, equi loss) in one launch; without Kabsch outputs the scalars
+//                      alone (head_finalize_kernel) and equigspr_kabsch_forward gives R, t from the weights
 //   backward: head_pair_bwd_kernel (softmax / BCE / MLP backward, MLP weight-gradient slabs),
 //             head_node_bwd_kernel (d h_s, d h_t, d x_s, d x_t; extra grid columns sum the MLP slabs into the grads, +=)
 // A launch inside the step's hipGraph costs ~4.8 us even when empty, hence the piggy-backed blocks.
 // Layouts: h_* [B,N,F] with row stride F; x_* [B,N,3]; labels [B,N] (float 0/1); gt_pose [B,16].
 #include "common.h"
+#include "kabsch_device.h"
 
 namespace eq {
 
@@ -403,9 +405,9 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(
 
 // out[0] = corr_loss + sim_loss, out[1] = equi loss, out[2..5] = mu_s, sd_s, mu_r, sd_r (written by K2),
 // out[6] = sum e, out[7] = sum e (s - mu_s), out[8], out[9] = rot / feat sums (written by K2)
-__global__ __launch_bounds__(256) void head_finalize_kernel(const double* __restrict__ partC, int nC,
-                                                            const double* __restrict__ pair_part, int nblk, int B, int N, int K,
-                                                            float* __restrict__ out) {
+__device__ __forceinline__ void head_finalize_block(const double* __restrict__ partC, int nC,
+                                                    const double* __restrict__ pair_part, int nblk, int B, int N, int K,
+                                                    float* __restrict__ out) {
     __shared__ double red[4];
     const long long M = (long long)B * N;
     double a0 = 0, a1 = 0, a2 = 0, bce = 0;
@@ -417,6 +419,39 @@ __global__ __launch_bounds__(256) void head_finalize_kernel(const double* __rest
         out[1] = (float)(((double)out[8] + (double)out[9]) / (double)M);
         out[6] = (float)a1; out[7] = (float)a2;
     }
+}
+
+__global__ __launch_bounds__(256) void head_finalize_kernel(const double* __restrict__ partC, int nC,
+                                                            const double* __restrict__ pair_part, int nblk, int B, int N, int K,
+                                                            float* __restrict__ out) {
+    head_finalize_block(partC, nC, pair_part, nblk, B, N, K, out);
+}
+
+// K4, the training head's tail in ONE launch, grid (nb + 1, B).  Columns 0..nb-1: the fp64 Kabsch moments of pair b over
+// the weights K3 wrote; the block that finishes a pair last (ticket = the spare fourth word of the pair's pair_f record,
+// zeroed by K2 of the same call) solves it: release fence + device-scope atomic on the writers' side, acquire fence on the
+// reader's.  Column nb of pair 0: the loss scalars (head_finalize), which only need the previous launches.
+__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ xs, const float* __restrict__ xt,
+                                                        const float* __restrict__ wts, int N, int nb, float* __restrict__ R,
+                                                        float* __restrict__ t, float* __restrict__ aux, float* __restrict__ pair_f,
+                                                        const double* __restrict__ partC, int nC,
+                                                        const double* __restrict__ pair_part, int nblk, int B, int K,
+                                                        float* __restrict__ out) {
+    if ((int)blockIdx.x == nb) {
+        if (blockIdx.y == 0) head_finalize_block(partC, nC, pair_part, nblk, B, N, K, out);
+        return;
+    }
+    const int b = blockIdx.y;
+    kabsch_moments_block(xs, xt, wts, N, aux, b, blockIdx.x, nb);     // thread 0 stores this block's record
+    __shared__ int is_last;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        is_last = atomicAdd(reinterpret_cast<unsigned*>(pair_f) + (size_t)b * 4 + 3, 1u) == (unsigned)nb - 1u;
+    }
+    __syncthreads();
+    if (!is_last) return;                                            // block-uniform
+    __threadfence();
+    if (threadIdx.x < 64) kabsch_solve_wave(nb, R, t, aux, b, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -642,7 +677,8 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
                                      const float* mlp /* flat: w1,b1,w2,b2,w3,b3 */, int32_t B, int32_t N, int32_t F,
                                      int32_t F_raw, int32_t K, float* sim, float* rsim, float* cosv, int32_t* pos,
                                      float* wts, int64_t* top_idx, float* logits, float* a1_save, float* a2_save,
-                                     void* work, float* out_scalars /* [16] device */, void* stream) {
+                                     void* work, float* out_scalars /* [16] device */, float* kabsch_R, float* kabsch_t,
+                                     float* kabsch_aux, void* stream) {
     using namespace eq;
     EQ_CHECK_ARG(hs && ht && raw_hs && raw_ht && xs && xt && labels && gt_pose && mlp && sim && rsim && cosv && pos && wts &&
                      top_idx && logits && a1_save && a2_save && work && out_scalars, EQUIGSPR_EINVAL, "head_forward: null pointer");
@@ -676,7 +712,15 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
     hipLaunchKernelGGL(head_mlp_kernel, dim3(nblk + ceil_div(N, 256), B), dim3(256), 0, s, hs, ht, labels,
                        reinterpret_cast<const long long*>(top_idx), w1, b1, w2, b2, w3, b3, B, N, F, K, md, logits, a1_save, a2_save,
                        W.pair_part, nblk, wj);
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, W.partC, W.nC, W.pair_part, nblk, B, N, K, out_scalars);
+    if (kabsch_aux) {      // + equigspr_kabsch_forward(xs, xt, wts) in the same launch as the loss scalars
+        EQ_CHECK_ARG(kabsch_R && kabsch_t, EQUIGSPR_EINVAL, "head_forward: kabsch_R / kabsch_t are null");
+        int nb = (N + 255) / 256;
+        if (nb > kKabschMaxBlocks) nb = kKabschMaxBlocks;
+        hipLaunchKernelGGL(head_tail_kernel, dim3(nb + 1, B), dim3(256), 0, s, xs, xt, wts, N, nb, kabsch_R, kabsch_t, kabsch_aux,
+                           W.pair_f, W.partC, W.nC, W.pair_part, nblk, B, K, out_scalars);
+    } else {
+        hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, W.partC, W.nC, W.pair_part, nblk, B, N, K, out_scalars);
+    }
     EQ_CHECK_LAUNCH("head_forward");
     return 0;
 }

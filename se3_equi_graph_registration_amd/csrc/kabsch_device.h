@@ -1,0 +1,168 @@
+// Device side of the batched weighted Kabsch forward (moments + 3x3 SVD solve), shared by csrc/kabsch.hip (two launches) and
+// the training head's tail kernel in csrc/head.hip (one launch: the last moments block of a pair solves it).
+#pragma once
+#include "common.h"
+
+namespace eq {
+
+__device__ inline double det3(const double m[9]) {
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+// One-sided Jacobi: A V = B with orthogonal columns; sigma_i = |B_i|, U_i = B_i / sigma_i.
+__device__ inline void svd3_jacobi(const double A[9], double U[9], double sig[3], double V[9]) {
+    double B[9];
+    for (int i = 0; i < 9; ++i) { B[i] = A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        bool rotated = false;
+        for (int pair = 0; pair < 3; ++pair) {
+            const int p = pair == 2 ? 1 : 0, q = pair == 0 ? 1 : 2;
+            double al = 0, be = 0, ga = 0;
+            for (int r = 0; r < 3; ++r) {
+                al += B[r * 3 + p] * B[r * 3 + p];
+                be += B[r * 3 + q] * B[r * 3 + q];
+                ga += B[r * 3 + p] * B[r * 3 + q];
+            }
+            if (fabs(ga) > 1e-300 && fabs(ga) > 1e-15 * sqrt(al * be)) {   // (1e-17 is below fp64 round-off: it never converged, 40 sweeps)
+                rotated = true;
+                const double ze = (be - al) / (2.0 * ga);
+                const double tt = (ze == 0.0) ? 1.0 : copysign(1.0, ze) / (fabs(ze) + sqrt(1.0 + ze * ze));
+                const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
+                for (int r = 0; r < 3; ++r) {
+                    const double bp = B[r * 3 + p], bq = B[r * 3 + q];
+                    B[r * 3 + p] = c * bp - s * bq;
+                    B[r * 3 + q] = s * bp + c * bq;
+                    const double vp = V[r * 3 + p], vq = V[r * 3 + q];
+                    V[r * 3 + p] = c * vp - s * vq;
+                    V[r * 3 + q] = s * vp + c * vq;
+                }
+            }
+        }
+        if (!rotated) break;
+    }
+    for (int i = 0; i < 3; ++i) sig[i] = sqrt(B[0 * 3 + i] * B[0 * 3 + i] + B[1 * 3 + i] * B[1 * 3 + i] + B[2 * 3 + i] * B[2 * 3 + i]);
+    // smallest direction may be numerically null: complete it from the other two
+    int lo = 0;
+    if (sig[1] < sig[lo]) lo = 1;
+    if (sig[2] < sig[lo]) lo = 2;
+    const double smax = fmax(sig[0], fmax(sig[1], sig[2]));
+    for (int i = 0; i < 3; ++i) {
+        if (i == lo && sig[i] <= 1e-280 + 1e-18 * smax) continue;
+        for (int r = 0; r < 3; ++r) U[r * 3 + i] = B[r * 3 + i] / sig[i];
+    }
+    if (sig[lo] <= 1e-280 + 1e-18 * smax) {
+        const int a = (lo + 1) % 3, b = (lo + 2) % 3;
+        U[0 * 3 + lo] = U[1 * 3 + a] * U[2 * 3 + b] - U[2 * 3 + a] * U[1 * 3 + b];
+        U[1 * 3 + lo] = U[2 * 3 + a] * U[0 * 3 + b] - U[0 * 3 + a] * U[2 * 3 + b];
+        U[2 * 3 + lo] = U[0 * 3 + a] * U[1 * 3 + b] - U[1 * 3 + a] * U[0 * 3 + b];
+    }
+}
+
+// aux layout (floats): cs[0:3] ct[3:6] U[6:15] s~[15:18] R[18:27] sum w(s-cs)[27:30] sum w(t-ct)[30:33]
+//
+// Forward in two short launches so that a single pair (B = 1) is not serialised on one CU:
+//   kabsch_moments_kernel  grid (nb, B): fp64 partial raw moments  W = sum w, S = sum w s, T = sum w t, M = sum w s t^T
+//   kabsch_solve_kernel    grid B: cs = fl32(S), ct = fl32(T) (the reference does not divide by W),
+//                          H = sum w (s-cs)(t-ct)^T = M - S ct^T - cs T^T + W cs ct^T, then the 3x3 SVD on one lane.
+constexpr int kKabschParts = 16;   // doubles per partial record: W, S[3], T[3], M[9]
+constexpr int kKabschMaxBlocks = 8;   // partial records live in the pair's aux record behind the first 48 floats
+static_assert(48 + kKabschMaxBlocks * kKabschParts * 2 <= EQUIGSPR_KABSCH_AUX, "aux record too small");
+__device__ __forceinline__ double* kabsch_part(float* aux, int b) { return reinterpret_cast<double*>(aux + (size_t)b * EQUIGSPR_KABSCH_AUX + 48); }
+
+__device__ __forceinline__ double block_sum_d256(double v, double* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// one block's share of pair b's moments: block xb of nblocks (256 threads)
+__device__ __forceinline__ void kabsch_moments_block(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                     const float* __restrict__ w, int n, float* __restrict__ aux, int b, int xb,
+                                                     int nblocks) {
+    __shared__ double red[4];
+    double* part = kabsch_part(aux, b);
+    const float* s = src + (size_t)b * n * 3;
+    const float* t = tgt + (size_t)b * n * 3;
+    const float* wb = w + (size_t)b * n;
+    double m[kKabschParts];
+#pragma unroll
+    for (int q = 0; q < kKabschParts; ++q) m[q] = 0.0;
+    for (int i = xb * 256 + threadIdx.x; i < n; i += nblocks * 256) {
+        const double wi = wb[i];
+        const double sv[3] = {s[i * 3], s[i * 3 + 1], s[i * 3 + 2]}, tv[3] = {t[i * 3], t[i * 3 + 1], t[i * 3 + 2]};
+        m[0] += wi;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            m[1 + a] += wi * sv[a];
+            m[4 + a] += wi * tv[a];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) m[7 + a * 3 + c] += wi * sv[a] * tv[c];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kKabschParts; ++q) {
+        const double v = block_sum_d256(m[q], red);
+        if (threadIdx.x == 0) part[(size_t)xb * kKabschParts + q] = v;
+    }
+}
+
+// pair b's solve from its nb partial records; called by ONE full wave (lane = 0..63)
+__device__ __forceinline__ void kabsch_solve_wave(int nb, float* __restrict__ Rout, float* __restrict__ tout, float* __restrict__ aux,
+                                                  int b, int lane) {
+    const double* part = kabsch_part(aux, b);
+    double m[kKabschParts];
+#pragma unroll
+    for (int q = 0; q < kKabschParts; ++q) {
+        double v = 0.0;
+        for (int k = lane; k < nb; k += 64) v += part[(size_t)k * kKabschParts + q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        m[q] = v;
+    }
+    if (lane == 0) {
+        const double W = m[0];
+        const float csf[3] = {(float)m[1], (float)m[2], (float)m[3]}, ctf[3] = {(float)m[4], (float)m[5], (float)m[6]};
+        double H[9], U[9], V[9], sg[3];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {
+                // H about the fp32-ROUNDED centroids the backward also uses (consistency matters: with near
+                // one-hot weights s_j - cs is ~1e-5 |s| and the gradient terms cancel to that accuracy)
+                const float h = (float)(m[7 + a * 3 + c] - m[1 + a] * (double)ctf[c] - (double)csf[a] * m[4 + c] +
+                                        W * (double)csf[a] * (double)ctf[c]);
+                H[a * 3 + c] = (double)(h + ((a == c) ? 1e-6f : 0.0f));                        // :738 (fp32 add)
+            }
+        svd3_jacobi(H, U, sg, V);
+        int lo = 0;
+        if (sg[1] < sg[lo]) lo = 1;
+        if (sg[2] < sg[lo]) lo = 2;
+        double sgn[3] = {1.0, 1.0, 1.0};
+        if (det3(V) * det3(U) < 0.0) sgn[lo] = -1.0;                                             // :749-751
+        double R[9];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {
+                double acc = 0;
+                for (int i = 0; i < 3; ++i) acc += sgn[i] * V[a * 3 + i] * U[c * 3 + i];
+                R[a * 3 + c] = acc;
+            }
+        float* ax = aux + (size_t)b * EQUIGSPR_KABSCH_AUX;
+        for (int a = 0; a < 3; ++a) {
+            const double ta = (double)ctf[a] - (R[a * 3 + 0] * csf[0] + R[a * 3 + 1] * csf[1] + R[a * 3 + 2] * csf[2]);   // :754
+            tout[b * 3 + a] = (float)ta;
+            ax[a] = csf[a];
+            ax[3 + a] = ctf[a];
+            ax[15 + a] = (float)(sgn[a] * sg[a]);
+            ax[27 + a] = (float)(m[1 + a] - W * (double)csf[a]);       // sum w (s - cs)
+            ax[30 + a] = (float)(m[4 + a] - W * (double)ctf[a]);       // sum w (t - ct)
+        }
+        for (int i = 0; i < 9; ++i) {
+            Rout[b * 9 + i] = (float)R[i];
+            ax[6 + i] = (float)U[i];
+            ax[18 + i] = (float)R[i];
+        }
+    }
+}
+
+}  // namespace eq

@@ -304,14 +304,14 @@ class _HeadFn(torch.autograd.Function):
         a2 = torch.empty(B, K, Fd // 2, **f32)
         work = torch.empty(int(L.equigspr_head_work_bytes(B, N)) // 8 + 1, dtype=torch.float64, device=dev)
         fin = torch.empty(16, **f32)
-        _lib.check(L.equigspr_head_forward(_p(hs), _p(ht), _p(raw_hs), _p(raw_ht), _p(xs), _p(xt), _p(labels), _p(gt),
-                                           _p(flat), B, N, Fd, raw_hs.shape[2], K, _p(sim), _p(rsim), _p(cosv), _p(pos),
-                                           _p(wts), _p(top_idx), _p(logits), _p(a1), _p(a2), _p(work), _p(fin), _stream()),
-                   "head_forward")
         R = torch.empty(B, 3, 3, **f32)
         t = torch.empty(B, 3, **f32)
         aux = torch.empty(B, KABSCH_AUX, **f32)
-        _lib.check(L.equigspr_kabsch_forward(_p(xs), _p(xt), _p(wts), B, N, _p(R), _p(t), _p(aux), _stream()), "kabsch_forward")
+        # the weighted Kabsch of (xs, xt, wts) rides in the head's last launch (moments, ticketed solve, loss scalars)
+        _lib.check(L.equigspr_head_forward(_p(hs), _p(ht), _p(raw_hs), _p(raw_ht), _p(xs), _p(xt), _p(labels), _p(gt),
+                                           _p(flat), B, N, Fd, raw_hs.shape[2], K, _p(sim), _p(rsim), _p(cosv), _p(pos),
+                                           _p(wts), _p(top_idx), _p(logits), _p(a1), _p(a2), _p(work), _p(fin),
+                                           _p(R), _p(t), _p(aux), _stream()), "head_forward")
         ctx.save_for_backward(hs, ht, xs, xt, labels, gt, flat, sim, rsim, cosv, pos, wts, top_idx, logits, a1, a2, fin, aux, work)
         ctx.dims = (B, N, Fd, K, msz)
         ctx.mlp_shapes = [tuple(q.shape) for q in mlp_params]

@@ -463,6 +463,31 @@ def test_fused_head_matches_aten_head(pk, golden_dir, name):
         assert err <= 2e-3 * scale + 1e-7, f"{name} {key}: err {err:.3e} scale {scale:.3e}"
 
 
+def test_head_tail_ticket_is_deterministic_and_matches_two_launch_kabsch(pk):
+    """The training head finishes with ONE launch: Kabsch moments by several blocks per pair, the solve by whichever block
+    of the pair finishes last (ticket + fences), the loss scalars by an extra block.  Same R, t as equigspr_kabsch_forward on
+    the weights the ATen-op head computes, and bit-identical over 200 repetitions with 12 pairs x 8 blocks in flight."""
+    torch.manual_seed(5)
+    B, n, feat, k = 12, 2048, 32, 8
+    egnn = pk.EGNN(feat, feat, feat, in_edge_nf=1, device="cuda", n_layers=1)
+    with torch.no_grad():
+        egnn.embedding_out.weight.mul_(0.05); egnn.embedding_out.bias.mul_(0.05)
+    model = pk.CrossAttentionPoseRegression(egnn, num_nodes=n, hidden_nf=feat, device="cuda").cuda()
+    b = pk.synthetic_batch(3, B, n=n, feat=feat, device="cuda")
+    graph = pk.build_pair_graph(b["src"], b["tgt"], k)
+    args = (b["feat_src"], b["src"], graph, None, b["feat_tgt"], b["tgt"], graph, None, b["corr"], b["labels"], b["gt_pose"])
+    with torch.no_grad():
+        first = model(*args)
+        R0, t0, c0 = first[0].clone(), first[1].clone(), first[2].clone()
+        for _ in range(200):
+            out = model(*args)
+            assert torch.equal(out[0], R0) and torch.equal(out[1], t0) and torch.equal(out[2], c0)
+        model.fused_head = False                      # ATen-op head: weights by torch ops, then the two-launch Kabsch
+        ref = model(*args)
+    assert torch.allclose(R0, ref[0], atol=2e-5) and torch.allclose(t0, ref[1], atol=2e-5)
+    assert torch.allclose(c0, ref[2], rtol=2e-4, atol=1e-5)
+
+
 # ------------------------------------------------------------------------------------ small fused training ops
 def test_fused_pose_loss_matches_aten(pk):
     g = torch.Generator().manual_seed(4)
