@@ -424,14 +424,25 @@ class DeviceBatches:
     def __iter__(self):
         q = queue.Queue(maxsize=self.depth)
         stop = object()
+        abandoned = threading.Event()          # the consumer left the loop early: let the producer thread finish
+
+        def put(item):
+            while not abandoned.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def produce():
             try:
                 for batch in self.loader:
-                    q.put(tuple(t.pin_memory() if isinstance(t, torch.Tensor) else t for t in batch))
+                    if not put(tuple(t.pin_memory() if isinstance(t, torch.Tensor) else t for t in batch)):
+                        return
             except BaseException as e:  # surfaced in the consumer
-                q.put(e)
-            q.put(stop)
+                put(e)
+            put(stop)
 
         th = threading.Thread(target=produce, daemon=True)
         th.start()
@@ -450,15 +461,18 @@ class DeviceBatches:
                 raise item
             return item
 
-        nxt = take()
-        pending = upload(nxt) if nxt is not stop else None
-        while pending is not None:
-            dev, ev, _host = pending
+        try:
             nxt = take()
             pending = upload(nxt) if nxt is not stop else None
-            torch.cuda.current_stream(self.device).wait_event(ev)
-            for t in dev:
-                if isinstance(t, torch.Tensor):
-                    t.record_stream(torch.cuda.current_stream(self.device))
-            yield dev
-        th.join()
+            while pending is not None:
+                dev, ev, _host = pending
+                nxt = take()
+                pending = upload(nxt) if nxt is not stop else None
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                for t in dev:
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(torch.cuda.current_stream(self.device))
+                yield dev
+        finally:
+            abandoned.set()
+            th.join()

@@ -92,6 +92,11 @@ def test_device_batches_equal_host_batches(pk, train_root):
         for h, g in zip(hb, db):
             assert torch.equal(h, g.cpu())
     assert list(pk.datasets.DeviceBatches(torch.utils.data.DataLoader(torch.utils.data.TensorDataset(torch.zeros(0, 3))))) == []
+    import threading
+    before = threading.active_count()
+    for first in pk.datasets.DeviceBatches(loader, device="cuda"):               # leaving early ends the staging thread
+        break
+    assert first[2].is_cuda and first[2].shape == host[0][2].shape and threading.active_count() == before
 
     class Boom(torch.utils.data.Dataset):
         def __len__(self):
