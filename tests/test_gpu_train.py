@@ -164,6 +164,15 @@ def test_one_epoch_over_the_dataset_classes(pk, tmp_path):
     assert float(opt.adam.step_dev[0]) == 6.0                       # 2 batches x 3 epochs
     assert v1[2] < v0[2]                                            # correspondence loss on held-out pairs
     assert model.training is False                                  # validate leaves the model in eval mode, like the reference
+    # use_pointnet=True (train :1031-1038): a fresh PointNet(3, 32, 32) encodes the coordinates into the 32 input features
+    torch.manual_seed(1)
+    lp = train.train_one_epoch(model, mk("train"), opt, "cuda", 3, use_pointnet=True, log_interval=0, k=8)
+    vp = train.validate(model, mk("val"), "cuda", 4, use_pointnet=True, k=8)
+    assert np.isfinite(lp) and np.isfinite(vp[0]) and torch.isfinite(egnn.flat_params).all()
+    b = next(iter(pk.datasets.DeviceBatches(mk("val"))))
+    g = pk.build_pair_graph(b[2], b[3], 8)
+    f0, f1 = train._pointnet_features(g, b[2], b[3])
+    assert f0.shape == (2, 256, 32) and f1.shape == (2, 256, 32) and float(f0.min()) >= 0.0 and float(f0.max()) > 0.0   # ReLU output
 
 
 def test_evaluate_model_matches_per_pair_oracle_metrics(pk, fx, tmp_path):
