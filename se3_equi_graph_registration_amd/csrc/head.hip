@@ -13,7 +13,7 @@
 //                      alone (head_finalize_kernel) and equigspr_kabsch_forward gives R, t from the weights
 //   backward: head_pair_bwd_kernel (softmax / BCE / MLP backward, MLP weight-gradient slabs),
 //             head_node_bwd_kernel (d h_s, d h_t, d x_s, d x_t; extra grid columns sum the MLP slabs into the grads, +=)
-// A launch inside the step's hipGraph costs ~4.8 us even when empty, hence the piggy-backed blocks.
+// (Independent small jobs share a launch as extra grid columns.)
 // Layouts: h_* [B,N,F] with row stride F; x_* [B,N,3]; labels [B,N] (float 0/1); gt_pose [B,16].
 #include "common.h"
 #include "kabsch_device.h"
