@@ -253,6 +253,9 @@ def roofline(pkg, S, args, dev):
     bytes_fwd = (2 * (F + 3) * 4 + 2 * 4 + 4 + (F + 3) * 4) * E          # 432 B/edge-layer at F=32
     bytes_bwd = 2 * bytes_fwd
     flops_fwd = (2 * (2 * F + 13) * F + 2 * F * F + 2 * F * F + 2 * F + 12 * F) * E
+    # backward per edge: the forward recompute, the three transposed products (W6^T dq, W2^T du, Wgeo^T dt1) and the three
+    # weight-gradient outer products (dW6, dW2, dWgeo); the h-column blocks of dW1 are node-level work (gather kernels)
+    flops_bwd = flops_fwd + 2 * (2 * F * F + 2 * F * F + 2 * 13 * F) * E
     # HBM traffic per launch from the committed rocprofv3 PMC passes (profiles/), when they cover this workload
     traffic = {"fwd": None, "bwd": None}
     try:
@@ -272,6 +275,7 @@ def roofline(pkg, S, args, dev):
     extra = {"edge_fwd_ms": round(fwd_ms, 5), "edge_bwd_ms": round(bwd_ms, 5),
              "edge_fwd_GBs": round(a_f, 2), "edge_bwd_GBs": round(a_b, 2),
              "edge_fwd_fp32_frac": round(flops_fwd / (fwd_ms * 1e-3) / 1e12 / FP32_PEAK_TF, 5),
+             "edge_bwd_fp32_frac": round(flops_bwd / (bwd_ms * 1e-3) / 1e12 / FP32_PEAK_TF, 5),
              "edge_fwd_hbm_frac": round(a_f / HBM_PEAK_GBS, 5), "edge_bwd_hbm_frac": round(a_b / HBM_PEAK_GBS, 5),
              "edge_fwd_traffic": traffic["fwd"], "edge_bwd_traffic": traffic["bwd"]}
     return roof, extra
