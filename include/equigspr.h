@@ -27,7 +27,7 @@ extern "C" {
 
 #define EQUIGSPR_EINVAL   (-1)  /* bad shape / size / null pointer                         */
 #define EQUIGSPR_ENOTSUP  (-2)  /* configuration outside the compiled kernel set             */
-#define EQUIGSPR_ABI_VERSION 4
+#define EQUIGSPR_ABI_VERSION 5
 
 /* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
  * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
@@ -122,9 +122,11 @@ int equigspr_edges_i64_to_i32(const int64_t* edges_i64, int32_t n_edges, int32_t
  *   params    flat parameter block (above)
  *   h_in      [N, in_nf]     x_in [N,3]     edge_attr [E, in_edge_nf] or NULL (= all ones)
  *   h_out     [N, out_nf]    x_out [N,3]
- *   saved     float[equigspr_egnn_saved_size]   activations kept for backward (NULL = inference)
+ *   saved     float[equigspr_egnn_saved_size]   activations kept for backward (NULL = inference): per layer the node
+ *             states h, x, agg and, per edge, the pre-activation / normalised / coordinate-head rows the backward would
+ *             otherwise recompute with three matrix products (388 B per edge and layer at hidden_nf = 32)
  *   work      float[equigspr_egnn_work_size]    scratch */
-int64_t equigspr_egnn_saved_size(const equigspr_egnn_config* cfg, int32_t n_nodes);
+int64_t equigspr_egnn_saved_size(const equigspr_egnn_config* cfg, int32_t n_nodes, int32_t n_edges);
 int64_t equigspr_egnn_work_size(const equigspr_egnn_config* cfg, int32_t n_nodes, int32_t n_edges);
 int equigspr_egnn_forward(const equigspr_egnn_config* cfg, const float* params,
                           const equigspr_graph* g, const float* h_in, const float* x_in,

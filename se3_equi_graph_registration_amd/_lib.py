@@ -37,7 +37,7 @@ _SIGNATURES = {
     "equigspr_build_csr": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "equigspr_invert_perm": (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
     "equigspr_edges_i64_to_i32": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
-    "equigspr_egnn_saved_size": (c_int64, [POINTER(EgnnConfig), c_int32]),
+    "equigspr_egnn_saved_size": (c_int64, [POINTER(EgnnConfig), c_int32, c_int32]),
     "equigspr_egnn_work_size": (c_int64, [POINTER(EgnnConfig), c_int32, c_int32]),
     "equigspr_egnn_forward": (ctypes.c_int, [POINTER(EgnnConfig), c_void_p, POINTER(Graph), c_void_p, c_void_p,
                                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -103,7 +103,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if L.equigspr_abi_version() != 4:
+        if L.equigspr_abi_version() != 5:
             raise RuntimeError("libequigspr.so ABI version mismatch")
         _lib = L
     return _lib

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256, 3) void node_bwd_kernel(const float* __restric
             dvv[slot][f] = dg * silu_grad(v);
         }
         EQ_STAMPK(1, 3);
-        if (j < n_nodes) project_pre<F, H, A>(lw, WaT, WbT, vin[slot], f, P + (size_t)j * PS);
+        if (j < n_nodes && P) project_pre<F, H, A>(lw, WaT, WbT, vin[slot], f, P + (size_t)j * PS);   // P == NULL: the edge backward restores saved activations
         __syncthreads();
         EQ_STAMPK(1, 4);
         if (act) {
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void gather_node_bwd_kernel(
             float dg = 0.0f;
             for (int o = 0; o < F; ++o) dg = fmaf(ghv[slot][o], W5[o * F + f], dg);
             dvv[slot][f] = dg * silu_grad(v);
-            project_pre<F, H, A>(lw_n, WaT, WbT, vin[slot], f, P + (size_t)j * PS);
+            if (P) project_pre<F, H, A>(lw_n, WaT, WbT, vin[slot], f, P + (size_t)j * PS);
         }
         __syncthreads();
         if (live) {
@@ -670,10 +670,10 @@ __device__ __forceinline__ void stage_half_row(float* tile_row, int h, const flo
         *reinterpret_cast<float4*>(tile_row + 8 * q + 4 * h) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
-template <int H, int A, int B = 0>
+template <int H, int A, int B = 0, bool kRestore = false>
 __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restrict__ lw, const int* __restrict__ row,
                                                             const int* __restrict__ col, const float* __restrict__ edge_attr,
-                                                            const float* __restrict__ x, const float* __restrict__ P,
+                                                            const float* __restrict__ x, const float* __restrict__ P, EdgeSave es,
                                                             const float* __restrict__ dagg, const float* __restrict__ Gx,
                                                             int n_edges, float* __restrict__ dt1_out,
                                                             float* __restrict__ gxr_out, float* __restrict__ gxc_out,
@@ -727,7 +727,10 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         EQ_STAMP(3);
         const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
         TileFwd o;
-        tile_forward<H, A, true, B>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
+        if constexpr (kRestore)      // the forward's per-edge activations, saved in edge order (small problems, see edge_saves_enabled)
+            tile_restore<H, A, true, B>(W, es.t1 + (size_t)e * FP, es.xh + (size_t)e * FP, es.q + (size_t)e * FP, es.rstd[e], h, o);
+        else                         // recompute the three matrix products from the projection rows
+            tile_forward<H, A, true, B>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
         const float zh = (h == 0) ? 1.0f : 0.0f;            // border scalars are identical in both halves: count them once
 
         // ---- coord head backward
@@ -992,7 +995,7 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
 
 template <int F, int H, int A>
 static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
-                           const float* dagg, const float* Gx, float* dt1, float* gxr, float* gxc, float* slab,
+                           EdgeSave es, const float* dagg, const float* Gx, float* dt1, float* gxr, float* gxc, float* slab,
                            hipStream_t s, int* n_slabs) {
     const int E = g->n_edges;
     static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1 or 4 heads) or 33 (1 head)");
@@ -1001,8 +1004,12 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
     // its tiles -- the weight staging and the slab epilogue are paid 256 times, not once per 4 tiles
     int blocks = ceil_div(tiles, 4);
     blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
-    hipLaunchKernelGGL((edge_bwd_mfma_kernel<H, A, F - 32>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
-                       dagg, Gx, E, dt1, gxr, gxc, slab);
+    if (es.t1)
+        hipLaunchKernelGGL((edge_bwd_mfma_kernel<H, A, F - 32, true>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x,
+                           P, es, dagg, Gx, E, dt1, gxr, gxc, slab);
+    else
+        hipLaunchKernelGGL((edge_bwd_mfma_kernel<H, A, F - 32, false>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x,
+                           P, es, dagg, Gx, E, dt1, gxr, gxc, slab);
     *n_slabs = blocks;
     return 0;
 }
@@ -1153,10 +1160,12 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
     hipLaunchKernelGGL((embed_out_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_out, cfg->out_nf, gh_out,
                        gx_out, hs + (size_t)L * N * FP, N, Gh, Gx, work + B.emb_slab);
     auto slab_of = [&](int l) { return (size_t)l * B.layer_stride; };
+    // the projection rows P feed the edge backward's forward recompute only: not produced when it restores saved activations
+    float* const Pbuf = edge_saves_enabled(FP, L, E) ? nullptr : work + B.P;
     auto launch_node_bwd = [&](int l) {
         hipLaunchKernelGGL((node_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, params + ML.layer0 + (size_t)l * ML.layer_size,
                            work + B.Gh[cur], hs + (size_t)l * N * FP, aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg,
-                           work + B.P, work + B.node_slab + slab_of(l));
+                           Pbuf, work + B.node_slab + slab_of(l));
     };
     constexpr bool kFuse = (F == 32);                      // gather_bwd(l) + node_bwd(l-1) in one kernel
     if (kFuse) launch_node_bwd(L - 1);
@@ -1166,7 +1175,9 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
         const float* x_l = xs + (size_t)l * N * 3;
         if (!kFuse) launch_node_bwd(l);
         if (E > 0) {
-            const int rc = launch_edge_bwd<F, H, A>(lw, g, edge_attr, x_l, work + B.P, work + B.dagg, work + B.Gx[cur],
+            const EdgeSave es = edge_saves_enabled(FP, L, E) ? edge_save_of(const_cast<float*>(saved), saved_node_floats(FP, L, N), FP, E, l)
+                                                             : EdgeSave{nullptr, nullptr, nullptr, nullptr};
+            const int rc = launch_edge_bwd<F, H, A>(lw, g, edge_attr, x_l, Pbuf, es, work + B.dagg, work + B.Gx[cur],
                                                     work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab + slab_of(l), s, &egrid);
             if (rc) return rc;
         }
@@ -1176,7 +1187,7 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
                 hipLaunchKernelGGL((gather_node_bwd_kernel<H, A>), dim3(ngrid), dim3(256), 0, s, lw, lw - ML.layer_size, g->rptr, g->rperm,
                                    g->cptr, g->cperm, work + B.dt1, work + B.gxr, work + B.gxc, work + B.Gx[cur], h_l,
                                    hs + (size_t)(l - 1) * N * FP, aggs + (size_t)(l - 1) * N * FP, N, work + B.dh_part, work + B.dagg,
-                                   work + B.P, work + B.Gx[nxt], work + B.gat_slab + slab_of(l), work + B.node_slab + slab_of(l - 1));
+                                   Pbuf, work + B.Gx[nxt], work + B.gat_slab + slab_of(l), work + B.node_slab + slab_of(l - 1));
                 cur = nxt;
                 continue;
             }
@@ -1226,7 +1237,10 @@ static int time_edge_bwd_impl(const equigspr_egnn_config* cfg, const float* para
                        hs + (size_t)l * N * FP, aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg, work + B.P,
                        work + B.node_slab);
     auto launch = [&]() {
-        (void)launch_edge_bwd<F, H, A>(lw, g, edge_attr, xs + (size_t)l * N * 3, work + B.P, work + B.dagg, work + B.Gx[0],
+        (void)launch_edge_bwd<F, H, A>(lw, g, edge_attr, xs + (size_t)l * N * 3, work + B.P,
+                                       edge_saves_enabled(FP, L, E) ? edge_save_of(const_cast<float*>(saved), saved_node_floats(FP, L, N), FP, E, l)
+                                                                    : EdgeSave{nullptr, nullptr, nullptr, nullptr},
+                                       work + B.dagg, work + B.Gx[0],
                                        work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab, s, &egrid);
     };
     hipEvent_t e0, e1;

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restr
                                                             const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                             const float* __restrict__ x, const float* __restrict__ P,
                                                             const int* __restrict__ rinv, int n_edges, float* __restrict__ m_out,
-                                                            float* __restrict__ trans_out) {
+                                                            float* __restrict__ trans_out, EdgeSave es) {
     constexpr int FP = 32 + 4 * B, PS = 2 * FP;          // hidden_nf = 32 + B, rows padded to 16 bytes
     const int lane = threadIdx.x & 63, el = lane & 31, h = lane >> 5;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
@@ -101,6 +101,17 @@ __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restr
             if (B) store_border(m_out + at * FP, h, o.mb);
             if (h == 0)
                 reinterpret_cast<float4*>(trans_out)[at] = make_float4(eg.d[0] * o.s, eg.d[1] * o.s, eg.d[2] * o.s, 0.0f);   // :264
+            if (es.t1) {       // training: what the backward would otherwise recompute with three matrix products, in edge order
+                store_half_row(es.t1 + (size_t)e * FP, h, o.t1);
+                store_half_row(es.xh + (size_t)e * FP, h, o.xhat);
+                store_half_row(es.q + (size_t)e * FP, h, o.q);
+                if (B) {
+                    store_border(es.t1 + (size_t)e * FP, h, o.t1b);
+                    store_border(es.xh + (size_t)e * FP, h, o.xhatb);
+                    store_border(es.q + (size_t)e * FP, h, o.qb);
+                }
+                if (h == 0) es.rstd[e] = o.rstd;
+            }
         }
         EQ_STAMP(7);
     }
@@ -108,14 +119,14 @@ __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restr
 
 template <int F, int H, int A>
 static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
-                            float* m, float* trans, hipStream_t s) {
+                            float* m, float* trans, hipStream_t s, EdgeSave es = EdgeSave{nullptr, nullptr, nullptr, nullptr}) {
     const int E = g->n_edges;
     static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1 or 4 heads) or 33 (1 head)");
     const int tiles = ceil_div(E, 32);
     int blocks = ceil_div(tiles, 4);          // one 32-edge tile per wave: latency is hidden across waves
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
     hipLaunchKernelGGL((edge_fwd_mfma_kernel<H, A, F - 32>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
-                       g->rinv, E, m, trans);
+                       g->rinv, E, m, trans, es);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -219,9 +230,8 @@ struct FwdBuffers {
     bool training;
 };
 
-static inline int64_t saved_floats(int F, int L, int64_t N) {
-    const int FP = fpad(F);
-    return (int64_t)(L + 1) * N * FP + (int64_t)(L + 1) * N * 3 + (int64_t)L * N * FP;
+static inline int64_t saved_floats(int F, int L, int64_t N, int64_t E) {       // node-level block, then L per-edge blocks (if kept)
+    return saved_node_floats(fpad(F), L, N) + (edge_saves_enabled(fpad(F), L, E) ? (int64_t)L * edge_save_floats(fpad(F), E) : 0);
 }
 static inline int64_t work_floats(int F, int64_t N, int64_t E) {
     const int FP = fpad(F);
@@ -287,7 +297,10 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
     for (int l = 0; l < L; ++l) {
         const float* lw = params + ML.layer0 + (size_t)l * ML.layer_size;
         const bool last = (l == L - 1);
-        if (E > 0) launch_edge_fwd<F, H, A>(lw, g, edge_attr, xbuf(l), P, m, trans, s);
+        if (E > 0) {
+            if (training && edge_saves_enabled(FP, L, E)) launch_edge_fwd<F, H, A>(lw, g, edge_attr, xbuf(l), P, m, trans, s, edge_save_of(saved, saved_node_floats(FP, L, N), FP, E, l));
+            else launch_edge_fwd<F, H, A>(lw, g, edge_attr, xbuf(l), P, m, trans, s);
+        }
         float* xn = last ? x_out : xbuf(l + 1);
         hipLaunchKernelGGL((node_fwd_kernel<F, H, A>), dim3(node_grid), dim3(256), 0, s, lw,
                            last ? nullptr : lw + ML.layer_size, params + ML.w_out, params + ML.b_out, cfg->out_nf,
@@ -302,9 +315,9 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
 
 }  // namespace eq
 
-extern "C" int64_t equigspr_egnn_saved_size(const equigspr_egnn_config* cfg, int32_t n_nodes) {
+extern "C" int64_t equigspr_egnn_saved_size(const equigspr_egnn_config* cfg, int32_t n_nodes, int32_t n_edges) {
     if (!eq::config_supported(cfg) || n_nodes < 0) return -1;
-    return eq::saved_floats(cfg->hidden_nf, cfg->n_layers, n_nodes);
+    return eq::saved_floats(cfg->hidden_nf, cfg->n_layers, n_nodes, n_edges);
 }
 
 extern "C" int64_t equigspr_egnn_work_size(const equigspr_egnn_config* cfg, int32_t n_nodes, int32_t n_edges) {

@@ -194,7 +194,7 @@ def egnn_forward(cfg: EgnnConfig, params: torch.Tensor, graph: DeviceGraph, h: t
     h_out = torch.empty(n, cfg.out_nf, dtype=torch.float32, device=dev)
     x_out = torch.empty(n, 3, dtype=torch.float32, device=dev)
     work = torch.empty(int(L.equigspr_egnn_work_size(ctypes.byref(cfg), n, graph.n_edges)), dtype=torch.float32, device=dev)
-    saved = torch.empty(int(L.equigspr_egnn_saved_size(ctypes.byref(cfg), n)), dtype=torch.float32, device=dev) if training else None
+    saved = torch.empty(int(L.equigspr_egnn_saved_size(ctypes.byref(cfg), n, graph.n_edges)), dtype=torch.float32, device=dev) if training else None
     _lib.check(L.equigspr_egnn_forward(ctypes.byref(cfg), _p(params), ctypes.byref(graph.struct), _p(h), _p(x),
                                        _p(edge_attr), _p(h_out), _p(x_out), _p(saved), _p(work), _stream()),
                "egnn_forward")

@@ -463,6 +463,38 @@ def test_fused_head_matches_aten_head(pk, golden_dir, name):
         assert err <= 2e-3 * scale + 1e-7, f"{name} {key}: err {err:.3e} scale {scale:.3e}"
 
 
+@pytest.mark.parametrize("feat", [32, 33])
+def test_saved_activation_backward_equals_recompute_backward(pk, feat):
+    """Small problems keep three per-edge rows from the forward and the edge backward restores them; large ones recompute
+    the three matrix products (csrc/egnn_mfma.h: edge_saves_enabled).  Same inputs through both: same outputs, and gradients
+    that agree to fp32 round-off (the restored values ARE the forward's; the recompute repeats its arithmetic)."""
+    g = torch.Generator().manual_seed(17)
+    n, k = 700, 9
+    x = (torch.rand(2, n, 3, generator=g) * 3).cuda()
+    h = torch.randn(2 * n, feat, generator=g).cuda()
+    graph = pk.build_pair_graph(x[:1], x[1:], k)
+    torch.manual_seed(4)
+    egnn = pk.EGNN(feat, feat, feat, in_edge_nf=1, device="cuda", n_layers=3)
+    gh, gx = torch.randn(2 * n, feat, generator=g).cuda(), torch.randn(2 * n, 3, generator=g).cuda()
+    res = {}
+    try:
+        for mode, mb in (("restore", "4096"), ("recompute", "0")):
+            os.environ["EQUIGSPR_EDGE_SAVE_MB"] = mb
+            egnn.zero_grad()
+            hh, xx = h.clone().requires_grad_(True), x.reshape(2 * n, 3).clone().requires_grad_(True)
+            ho, xo = egnn(hh, xx, graph, torch.ones(graph.n_edges, 1, device="cuda"))
+            ((ho * gh).sum() + (xo * gx).sum()).backward()
+            res[mode] = (ho.detach().clone(), xo.detach().clone(), egnn.flat_grads.clone(), hh.grad.clone(), xx.grad.clone())
+    finally:
+        os.environ.pop("EQUIGSPR_EDGE_SAVE_MB", None)
+    a, b = res["restore"], res["recompute"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    for u, v, name in zip(a[2:], b[2:], ("params", "h_in", "x_in")):
+        scale = float(v.abs().max())
+        assert float((u - v).abs().max()) <= 2e-5 * scale + 1e-7, (name, float((u - v).abs().max()), scale)
+    assert float(b[2].abs().max()) > 0
+
+
 def test_head_tail_ticket_is_deterministic_and_matches_two_launch_kabsch(pk):
     """The training head finishes with ONE launch: Kabsch moments by several blocks per pair, the solve by whichever block
     of the pair finishes last (ticket + fences), the loss scalars by an extra block.  Same R, t as equigspr_kabsch_forward on
