@@ -5,9 +5,10 @@
 // Per layer, walking l = L-1 .. 0 with G_h = dL/dh_{l+1}, G_x = dL/dx_{l+1}:
 //   node_bwd   (lane = feature, G lanes per node)  node-MLP backward -> dagg, dh_part; re-projects
 //              P_l = [W_src h_l | W_tgt h_l + b1] for the edge recompute; dW4,db4,dW5,db5 partials.
-//   edge_bwd   (lane = edge)  recomputes the edge forward from (P_l, x_l) in registers, runs the
-//              edge backward with wave-uniform (scalar-loaded) weights, writes dt1_e, dL/dx_r,
-//              dL/dx_c per edge.  Weight gradients are sums over edges of outer products: the
+//   edge_bwd   (one wave per 32-edge tile)  obtains the tile's forward state either by restoring the three
+//              per-edge rows the forward saved (problems whose saves fit the Infinity Cache: edge_saves_enabled)
+//              or by recomputing the edge forward from (P_l, x_l) on the matrix cores; runs the edge backward,
+//              writes dt1_e, dL/dx_r, dL/dx_c per edge.  Weight gradients are sums over edges of outer products: the
 //              per-edge vectors are transposed through wave-private LDS tiles and accumulated
 //              with fp32 MFMA (v_mfma_f32_32x32x2_f32, K = edges) -- exact fp32, VALU stays free.
 //   gather_bwd (lane = feature)  dP_r / dP_c / dx via the row / col inverse indices (ascending
@@ -660,9 +661,9 @@ __device__ __forceinline__ void tile_pass(const float* X, const float* Y, f32x16
 
 // ---------------------------------------------------------------------------------------
 // edge backward, MFMA formulation (hidden_nf == 32): one wave per 32-edge tile (egnn_mfma.h).
-// Forward recompute and the three transposed products (W6^T dq, W2^T du, Wgeo^T dt1) run on
-// the matrix cores with register-resident weights; only the weight-gradient outer products
-// (sum over edges) go through wave-private LDS tiles, as in the generic kernel.
+// The forward state (kRestore: loaded from the forward's per-edge saves; otherwise recomputed) and the
+// three transposed products (W6^T dq, W2^T du, Wgeo^T dt1) use the matrix cores with register-resident
+// weights; only the weight-gradient outer products (sum over edges) go through wave-private LDS tiles.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void stage_half_row(float* tile_row, int h, const float (&v)[16]) {
 #pragma unroll
