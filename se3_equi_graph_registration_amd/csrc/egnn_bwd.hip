@@ -16,6 +16,7 @@
 // Every workgroup writes its partial weight gradients to a private slab; a reduce kernel sums
 // the slabs in fixed order into the flat gradient block (+=): bitwise reproducible, no atomics.
 #include "egnn_mfma.h"
+#include "egnn_mfma16.h"
 
 #include <algorithm>
 
@@ -994,12 +995,320 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
     EQ_STAMP(14);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// edge backward, 16-edge MFMA formulation (hidden_nf == 32; egnn_mfma16.h).  Eight waves per workgroup, two per SIMD,
+// one workgroup per CU, persistent over the chunks.  Per 16-edge sub-tile: forward recompute (40 MFMAs), the three
+// transposed products W6^T dq, W2^T du, Wgeo^T dt1 (40) and the three weight-gradient outer products with K = edges
+// (40; operands transposed through wave-private LDS tiles).  Geometry forward / backward once per edge in the chunk's
+// front / back phases.
+// ---------------------------------------------------------------------------------------
+// acc[bx][by] += X^T Y over the 16 edges of the tiles X [16][LD], Y [16][ldy] (16 columns per block);
+// K step s, lane group g <-> edge s + 4 g (rows 4 apart: the two groups of a 32-lane LDS access hit disjoint banks)
+template <int NBY, bool kColSum>
+__device__ __forceinline__ void pass16(const float* X, const float* Y, int ldy, int i, int g, f32x4 (&acc)[2][NBY], float (&cs)[2]) {
+    float a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int ed = s + 4 * g;
+        a0[s] = X[ed * Chunk16::LD + i];
+        a1[s] = X[ed * Chunk16::LD + 16 + i];
+        b0[s] = Y[ed * ldy + i];
+        b1[s] = (NBY == 2) ? Y[ed * ldy + 16 + i] : 0.0f;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (kColSum) { cs[0] += a0[s]; cs[1] += a1[s]; }
+        acc[0][0] = mfma16(a0[s], b0[s], acc[0][0]);
+        acc[1][0] = mfma16(a1[s], b0[s], acc[1][0]);
+        if constexpr (NBY == 2) {
+            acc[0][1] = mfma16(a0[s], b1[s], acc[0][1]);
+            acc[1][1] = mfma16(a1[s], b1[s], acc[1][1]);
+        }
+    }
+}
+
+constexpr int kBwd16Waves = 8;
+
+template <int H, int A>
+__global__ __launch_bounds__(512) void edge_bwd16_kernel(const float* __restrict__ lw, const int* __restrict__ row,
+                                                         const int* __restrict__ col, const float* __restrict__ edge_attr,
+                                                         const float* __restrict__ x, const float* __restrict__ P,
+                                                         const float* __restrict__ dagg, const float* __restrict__ Gx, int n_edges,
+                                                         int chunk, float* __restrict__ dt1_out, float* __restrict__ gxr_out,
+                                                         float* __restrict__ gxc_out, float* __restrict__ slab) {
+    using C = Chunk16;
+    using SB = Slabs<32>;
+    constexpr int kScratch = C::bwd_size > SB::edge ? C::bwd_size : SB::edge;      // reused for the waves' slab copies
+    __shared__ __attribute__((aligned(16))) float wsm_[W16::bwd_size];
+    __shared__ __attribute__((aligned(16))) float scratch[kBwd16Waves][kScratch];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const int wave = blockIdx.x * kBwd16Waves + wv, n_waves = gridDim.x * kBwd16Waves;
+    EQ_STAMP(0);
+    stage_w16<H, A, true, 512>(wsm_, lw);
+    __syncthreads();
+    EQ_STAMP(1);
+    float* sc = scratch[wv];
+    int* idx_r = reinterpret_cast<int*>(sc + C::o_r);
+    int* idx_c = reinterpret_cast<int*>(sc + C::o_c);
+    float* ds_buf = sc + C::o_a;
+    float* s_buf = sc + C::o_b;
+    float* front = sc + C::o_front + lane * C::FS;      // this lane's x_r | x_c | G_x[row] for the back phase
+    float* X = sc + C::o_x;
+    float* Y = sc + C::o_y;
+
+    f32x4 acc6[2][2], acc2[2][2], accg[2][1];
+    float cs_b6[2] = {0.0f, 0.0f}, cs_b2[2] = {0.0f, 0.0f}, cs_none[2] = {0.0f, 0.0f};
+    f32x4 ls_w7[2], ls_gam[2], ls_bet[2];             // dw7, dgamma, dbeta: per-lane running sums, reduced once after the loop
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        ls_w7[a] = splat4(0.0f); ls_gam[a] = splat4(0.0f); ls_bet[a] = splat4(0.0f);
+        accg[a][0] = splat4(0.0f);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { acc6[a][b] = splat4(0.0f); acc2[a][b] = splat4(0.0f); }
+    }
+
+    const int n_chunks = (n_edges + chunk - 1) / chunk;
+    auto edge_of = [&](int ch_) { const int cnt_ = min(chunk, n_edges - ch_ * chunk); return ch_ * chunk + (lane < cnt_ ? lane : 0); };
+    // chunk -> wave, static (the summation order of the weight gradients is fixed): half-round k hands four consecutive chunks
+    // (shared centre nodes) to every workgroup; waves 0..3 take the even half-rounds, waves 4..7 the odd ones.  Waves w and
+    // w + 4 share a SIMD, so every SIMD of the chip gets the same number of chunks +- 1 (wave-linear rounds gave the CUs of
+    // the low workgroups a whole extra chunk per wave: 2 or 3 of the 2.5 per wave at one 2 048-point pair).
+    const int ch_step = gridDim.x * kBwd16Waves;
+    int ch = (blockIdx.x + (wv >> 2) * gridDim.x) * 4 + (wv & 3);
+    int e = ch < n_chunks ? edge_of(ch) : 0;
+    int r = row[e], c = col[e];
+    for (; ch < n_chunks; ch += ch_step) {
+        int off = 0;
+        asm volatile("" : "+v"(off));
+        const float* wsm = wsm_ + off;
+        const int base = ch * chunk, cnt = min(chunk, n_edges - base);
+        const bool mine = lane < cnt;
+        EQ_STAMP(2);
+        // ---- front: one lane per edge
+        idx_r[lane] = r; idx_c[lane] = c;
+        float xr[3], xc[3], gxv[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { xr[k] = x[(size_t)r * 3 + k]; xc[k] = x[(size_t)c * 3 + k]; gxv[k] = Gx[(size_t)r * 4 + k]; }
+        const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        // first sub-tile's projection rows and dagg row: in flight with the coordinate gathers
+        PRows pw;
+        f32x4 da[2];
+        {
+            const int rr = idx_r[i];
+            pw.load(P, rr, idx_c[i], g);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) da[b] = ldg4(dagg + (size_t)rr * 32 + 16 * b + 4 * g);
+        }
+        const int chn = ch + ch_step;                  // the next chunk's indices
+        int rn = r, cn = c, en = e;
+        if (chn < n_chunks) { en = edge_of(chn); rn = row[en]; cn = col[en]; }
+        {
+            EdgeGeo eg;
+            edge_geometry(xr, xc, eg);
+            store_geo_row(sc + C::o_geo + lane * C::GS, eg, attr);
+            ds_buf[lane] = mine ? dot3(eg.d, gxv) : 0.0f;           // dL/ds of the coord head (:264); 0 masks padding edges
+            st4(front, f32x4{xr[0], xr[1], xr[2], xc[0]});
+            st4(front + 4, f32x4{xc[1], xc[2], gxv[0], gxv[1]});
+            front[8] = gxv[2];
+        }
+        __builtin_amdgcn_wave_barrier();
+        EQ_STAMP(3);
+
+        const int n_sub = (cnt + 15) >> 4;
+        for (int sub = 0; sub < n_sub; ++sub) {
+            const int el = sub * 16 + i;
+            const bool valid = el < cnt;
+            const float ds = ds_buf[el];
+            float* geo_rows = sc + C::o_geo + sub * 16 * C::GS;
+            PRows pn;                                  // next sub-tile's rows (the last one re-requests its own: harmless)
+            f32x4 dan[2];
+            {
+                const int eln = (sub + 1 < n_sub ? sub + 1 : sub) * 16 + i;
+                const int rrn = idx_r[eln];
+                pn.load(P, rrn, idx_c[eln], g);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) dan[b] = ldg4(dagg + (size_t)rrn * 32 + 16 * b + 4 * g);
+            }
+            Sub16 o;
+            tile_forward16(wsm, geo_rows + i * C::GS, pw, i, g, o);
+            if (g == 0) s_buf[el] = o.s;
+            // ---- coord head backward: s = w7 . SiLU(q)
+            f32x4 dq[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const f32x4 w7 = lds4(wsm + W16::o_vec + 4 * 32 + 16 * b + 4 * g);
+                const f32x4 sg = o.sgq[b], one = splat4(1.0f);
+                ls_w7[b] += (o.q[b] * sg) * splat4(ds);
+                dq[b] = w7 * splat4(ds) * (sg * (one + o.q[b] * (one - sg)));
+                st4(X + i * C::LD + 16 * b + 4 * g, dq[b]);
+                st4(Y + i * C::LD + 16 * b + 4 * g, o.m[b]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            pass16<2, true>(X, Y, C::LD, i, g, acc6, cs_b6);              // dW6 += dq^T m ; db6 += sum dq
+            __builtin_amdgcn_wave_barrier();
+            EQ_STAMP(10);
+            // ---- dm = dagg[row] + W6^T dq   (padding edges: dq = 0 and dagg masked)
+            f32x4 dm[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) dm[b] = valid ? da[b] : splat4(0.0f);
+            mv16(wsm + W16::o_w6t, i, g, dq, dm);
+            EQ_STAMP(11);
+            // ---- LayerNorm backward
+            f32x4 du[2];
+            {
+                float p1 = 0.0f, p2 = 0.0f;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    ls_gam[b] += dm[b] * o.xhat[b];
+                    ls_bet[b] += dm[b];
+                    du[b] = dm[b] * lds4(wsm + W16::o_vec + 1 * 32 + 16 * b + 4 * g);
+                    p1 += hsum4(du[b]);
+                    p2 += hsum4(du[b] * o.xhat[b]);
+                }
+                const float m1 = gsum(p1) * (1.0f / 32.0f), m2 = gsum(p2) * (1.0f / 32.0f);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) du[b] = splat4(o.rstd) * (du[b] - splat4(m1) - o.xhat[b] * splat4(m2));
+            }
+            f32x4 sgp[2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const f32x4 sg = o.sg1[b], one = splat4(1.0f);
+                sgp[b] = sg * (one + o.t1[b] * (one - sg));                 // SiLU'(t1)
+                st4(X + i * C::LD + 16 * b + 4 * g, du[b]);
+                st4(Y + i * C::LD + 16 * b + 4 * g, o.t1[b] * sg);
+            }
+            __builtin_amdgcn_wave_barrier();
+            pass16<2, true>(X, Y, C::LD, i, g, acc2, cs_b2);              // dW2 += du^T SiLU(t1) ; db2 += sum du
+            __builtin_amdgcn_wave_barrier();
+            EQ_STAMP(12);
+            // ---- dt1 = (W2^T du) * SiLU'(t1)
+            f32x4 dt1[2] = {splat4(0.0f), splat4(0.0f)};
+            mv16(wsm + W16::o_w2t, i, g, du, dt1);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                dt1[b] *= sgp[b];
+                st4(X + i * C::LD + 16 * b + 4 * g, dt1[b]);
+                if (valid) st4(dt1_out + (size_t)(base + el) * 32 + 16 * b + 4 * g, dt1[b]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            pass16<1, false>(X, geo_rows, C::GS, i, g, accg, cs_none);     // dWgeo | dw_attr += dt1^T [geo, attr]
+            // ---- dgeo = Wgeo^T dt1: rows 4 g + r of a 16-row product, left in the edge's (now consumed) geometry row
+            f32x4 dg = splat4(0.0f);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const f32x4 a = lds4(wsm + W16::o_wgt + i * W16::WS + 16 * b + 4 * g);
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) dg = mfma16(a[rq], dt1[b][rq], dg);
+            }
+            __builtin_amdgcn_wave_barrier();
+            st4(geo_rows + i * C::GS + 4 * g, dg);
+            __builtin_amdgcn_wave_barrier();
+            pw = pn;
+            da[0] = dan[0]; da[1] = dan[1];
+            EQ_STAMP(13);
+        }
+        // ---- back: one lane per edge, geometry backward (the geometry forward is recomputed from the stashed coordinates:
+        // ~60 instructions per chunk against ~30 registers held across the sub-tile loop)
+        if (mine) {
+            const f32x4 f0 = lds4(front), f1 = lds4(front + 4);
+            const float xr2[3] = {f0[0], f0[1], f0[2]}, xc2[3] = {f0[3], f1[0], f1[1]}, gx2[3] = {f1[2], f1[3], front[8]};
+            EdgeGeo eg;
+            edge_geometry(xr2, xc2, eg);
+            const float* grow = sc + C::o_geo + lane * C::GS;
+            const f32x4 g0 = lds4(grow), g1 = lds4(grow + 4), g2 = lds4(grow + 8);
+            const float gg[kGeo] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3], g2[0], g2[1], g2[2], g2[3]};
+            const float s = s_buf[lane];
+            const float gd[3] = {s * gx2[0], s * gx2[1], s * gx2[2]};
+            float gxr[3], gxc[3];
+            edge_geometry_backward(xr2, xc2, eg, gg, gd, gxr, gxc);
+            reinterpret_cast<float4*>(gxr_out)[base + lane] = make_float4(gxr[0], gxr[1], gxr[2], 0.0f);
+            reinterpret_cast<float4*>(gxc_out)[base + lane] = make_float4(gxc[0], gxc[1], gxc[2], 0.0f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        r = rn; c = cn; e = en;
+        EQ_STAMP(14);
+    }
+
+    // ---- partial sums of the waves: every wave writes a slab copy into its scratch, all threads add the copies in fixed order
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        cs_b6[b] = gsum(cs_b6[b]);
+        cs_b2[b] = gsum(cs_b2[b]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                   // per-lane sums: over the 16 edges (lanes) of the group
+#pragma unroll
+            for (int o_ = 1; o_ <= 8; o_ <<= 1) {
+                ls_w7[b][k] += __shfl_xor(ls_w7[b][k], o_, 64);
+                ls_gam[b][k] += __shfl_xor(ls_gam[b][k], o_, 64);
+                ls_bet[b][k] += __shfl_xor(ls_bet[b][k], o_, 64);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        float* sl = sc;
+#pragma unroll
+        for (int bx = 0; bx < 2; ++bx)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int orow = 16 * bx + 4 * g + k;
+#pragma unroll
+                for (int by = 0; by < 2; ++by) {
+                    sl[SB::e_w2 + orow * 32 + 16 * by + i] = acc2[bx][by][k];
+                    sl[SB::e_w6 + orow * 32 + 16 * by + i] = acc6[bx][by][k];
+                }
+                sl[SB::e_geo + orow * 16 + i] = accg[bx][0][k];
+                if (i == 0) {
+                    sl[SB::e_gam + orow] = ls_gam[bx][k];
+                    sl[SB::e_bet + orow] = ls_bet[bx][k];
+                    sl[SB::e_w7 + orow] = ls_w7[bx][k];
+                }
+            }
+        if (g == 0) {
+#pragma unroll
+            for (int bx = 0; bx < 2; ++bx) {
+                sl[SB::e_b2 + 16 * bx + i] = cs_b2[bx];
+                sl[SB::e_b6 + 16 * bx + i] = cs_b6[bx];
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < SB::edge; t += 512) {
+        float a = scratch[0][t];
+#pragma unroll
+        for (int w = 1; w < kBwd16Waves; ++w) a += scratch[w][t];
+        slab[(size_t)blockIdx.x * SB::edge + t] = a;
+    }
+    EQ_STAMP(15);
+}
+
+static inline int edge_chunk_for16(int E, int waves_resident) {      // see egnn_fwd.hip edge_chunk_for
+    static const int forced = [] { const char* v = getenv("EQUIGSPR_EDGE_CHUNK"); return v ? atoi(v) : 0; }();
+    if (forced == 16 || forced == 32 || forced == 48 || forced == 64) return forced;
+    if ((long long)E >= 64ll * 2 * waves_resident) return 64;
+    if ((long long)E >= 32ll * 2 * waves_resident) return 32;
+    return 16;
+}
+
 template <int F, int H, int A>
 static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
                            EdgeSave es, const float* dagg, const float* Gx, float* dt1, float* gxr, float* gxc, float* slab,
                            hipStream_t s, int* n_slabs) {
     const int E = g->n_edges;
     static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1 or 4 heads) or 33 (1 head)");
+    if constexpr (F == 32) {
+        if (!es.t1) {                          // the 16-edge formulation: one 8-wave workgroup per CU, persistent
+            const int chunk = edge_chunk_for16(E, 256 * kBwd16Waves);
+            int blocks16 = ceil_div(ceil_div(E, chunk), kBwd16Waves);
+            blocks16 = blocks16 < 1 ? 1 : (blocks16 > 256 ? 256 : blocks16);
+            hipLaunchKernelGGL((edge_bwd16_kernel<H, A>), dim3(blocks16), dim3(512), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
+                               E, chunk, dt1, gxr, gxc, slab);
+            *n_slabs = blocks16;
+            return 0;
+        }
+    }
     const int tiles = ceil_div(E, 32);
     // persistent waves: one workgroup per CU (the kernel runs at one wave per SIMD), each wave loops over
     // its tiles -- the weight staging and the slab epilogue are paid 256 times, not once per 4 tiles

@@ -15,6 +15,7 @@
 //                 residual (:252-260), coordinate update (:262-268), and the NEXT layer's
 //                 per-node projections (or embedding_out after the last layer).
 #include "egnn_mfma.h"
+#include "egnn_mfma16.h"
 
 
 namespace eq {
@@ -117,11 +118,127 @@ __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// edge kernel, 16-edge MFMA formulation (hidden_nf == 32; egnn_mfma16.h): a wave per chunk of <= 64 edges.
+// Latency chain of a chunk: indices (requested one chunk ahead) -> coordinate gathers + the first sub-tile's projection
+// rows together -> geometry -> sub-tiles (each requests the next one's projection rows before it computes).
+// ---------------------------------------------------------------------------------------
+constexpr int kFwd16Waves = 4;
+#ifndef EQ_FWD16_OCC
+#define EQ_FWD16_OCC 3                 // 4-wave workgroups per CU (= waves per SIMD) the register budget is set for
+#endif
+
+template <int H, int A>
+__global__ __launch_bounds__(64 * kFwd16Waves, EQ_FWD16_OCC) void edge_fwd16_kernel(const float* __restrict__ lw, const int* __restrict__ row,
+                                                         const int* __restrict__ col, const float* __restrict__ edge_attr,
+                                                         const float* __restrict__ x, const float* __restrict__ P,
+                                                         const int* __restrict__ rinv, int n_edges, int chunk,
+                                                         float* __restrict__ m_out, float* __restrict__ trans_out) {
+    using C = Chunk16;
+    __shared__ __attribute__((aligned(16))) float wsm_[W16::fwd_size];
+    __shared__ __attribute__((aligned(16))) float scratch[kFwd16Waves][C::fwd_size];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+    const int wave = blockIdx.x * kFwd16Waves + wv, n_waves = gridDim.x * kFwd16Waves;
+    EQ_STAMP(0);
+    stage_w16<H, A, false, 64 * kFwd16Waves>(wsm_, lw);
+    __syncthreads();
+    EQ_STAMP(1);
+    float* sc = scratch[wv];
+    int* idx_r = reinterpret_cast<int*>(sc + C::o_r);
+    int* idx_c = reinterpret_cast<int*>(sc + C::o_c);
+    int* pos = reinterpret_cast<int*>(sc + C::o_a);
+    float* s_buf = sc + C::o_b;
+    const int n_chunks = (n_edges + chunk - 1) / chunk;
+    // the four waves of a workgroup take four consecutive chunks (shared centre nodes: their rows hit in L1/L2)
+    const int ch_step = n_waves;
+    int ch = wave;
+    if (ch >= n_chunks) return;
+    auto edge_of = [&](int ch_) { const int cnt_ = min(chunk, n_edges - ch_ * chunk); return ch_ * chunk + (lane < cnt_ ? lane : 0); };
+    int e = edge_of(ch);
+    int r = row[e], c = col[e], at = rinv[e];
+    for (; ch < n_chunks; ch += ch_step) {
+        int off = 0;
+        asm volatile("" : "+v"(off));                  // keeps the weight reads inside the loop (egnn_mfma.h refresh())
+        const float* wsm = wsm_ + off;
+        const int cnt = min(chunk, n_edges - ch * chunk);
+        const bool mine = lane < cnt;
+        EQ_STAMP(2);
+        // ---- front: one lane per edge
+        idx_r[lane] = r; idx_c[lane] = c; pos[lane] = at;
+        float xr[3], xc[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { xr[k] = x[(size_t)r * 3 + k]; xc[k] = x[(size_t)c * 3 + k]; }
+        const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        PRows pw;                                      // first sub-tile's projection rows: in flight with the coordinate gathers
+        pw.load(P, idx_r[i], idx_c[i], g);
+        const int chn = ch + ch_step;                  // the next chunk's indices
+        int rn = r, cn = c, atn = at, en = e;
+        if (chn < n_chunks) { en = edge_of(chn); rn = row[en]; cn = col[en]; atn = rinv[en]; }
+        EdgeGeo eg;
+        edge_geometry(xr, xc, eg);
+        store_geo_row(sc + C::o_geo + lane * C::GS, eg, attr);
+        __builtin_amdgcn_wave_barrier();
+        EQ_STAMP(3);
+        // ---- the chunk's 16-edge sub-tiles
+        const int n_sub = (cnt + 15) >> 4;
+        for (int sub = 0; sub < n_sub; ++sub) {
+            const int el = sub * 16 + i;
+            PRows pn;                                  // next sub-tile's rows (the last one re-requests its own: harmless)
+            {
+                const int eln = (sub + 1 < n_sub ? sub + 1 : sub) * 16 + i;
+                pn.load(P, idx_r[eln], idx_c[eln], g);
+            }
+            Sub16 o;
+            tile_forward16(wsm, sc + C::o_geo + el * C::GS, pw, i, g, o);
+            if (el < cnt) {
+                // stored at the edge's position in the by-row (aggregation) order: node_fwd then streams its segment contiguously
+                float* dst = m_out + (size_t)pos[el] * 32 + 4 * g;
+                st4(dst, o.m[0]);
+                st4(dst + 16, o.m[1]);
+                if (g == 0) s_buf[el] = o.s;
+            }
+            pw = pn;
+            EQ_STAMP(10);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- back: one lane per edge, trans = coord_diff * s   (:264)
+        if (mine) {
+            const float s = s_buf[lane];
+            reinterpret_cast<float4*>(trans_out)[at] = make_float4(eg.d[0] * s, eg.d[1] * s, eg.d[2] * s, 0.0f);
+        }
+        __builtin_amdgcn_wave_barrier();               // the next chunk's front overwrites the scratch
+        r = rn; c = cn; at = atn; e = en;
+        EQ_STAMP(11);
+    }
+}
+
+// chunk size of the 16-edge kernels: 64 edges amortise the per-edge front over four sub-tiles; small problems take
+// smaller chunks so that every SIMD gets work (EQUIGSPR_EDGE_CHUNK overrides, developer knob)
+static inline int edge_chunk_for(int E, int waves_resident) {
+    static const int forced = [] { const char* v = getenv("EQUIGSPR_EDGE_CHUNK"); return v ? atoi(v) : 0; }();
+    if (forced == 16 || forced == 32 || forced == 48 || forced == 64) return forced;
+    if ((long long)E >= 64ll * 2 * waves_resident) return 64;
+    if ((long long)E >= 32ll * 2 * waves_resident) return 32;
+    return 16;
+}
+
 template <int F, int H, int A>
 static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
                             float* m, float* trans, hipStream_t s, EdgeSave es = EdgeSave{nullptr, nullptr, nullptr, nullptr}) {
     const int E = g->n_edges;
     static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1 or 4 heads) or 33 (1 head)");
+    if constexpr (F == 32) {
+        if (!es.t1) {                          // the 16-edge formulation; four 4-wave workgroups per CU
+            const int chunk = edge_chunk_for(E, 256 * 4 * EQ_FWD16_OCC);
+            int blocks16 = ceil_div(ceil_div(E, chunk), kFwd16Waves);
+            blocks16 = blocks16 < 1 ? 1 : (blocks16 > 256 * EQ_FWD16_OCC ? 256 * EQ_FWD16_OCC : blocks16);
+            hipLaunchKernelGGL((edge_fwd16_kernel<H, A>), dim3(blocks16), dim3(64 * kFwd16Waves), 0, s, lw, g->row, g->col, edge_attr, x, P, g->rinv,
+                               E, chunk, m, trans);
+            return;
+        }
+    }
     const int tiles = ceil_div(E, 32);
     int blocks = ceil_div(tiles, 4);          // one 32-edge tile per wave: latency is hidden across waves
     blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);

@@ -48,6 +48,17 @@ EQ_HD float silu_grad(float v) {
     return s * (1.0f + v * (1.0f - s));
 }
 
+// Square root / reciprocal of the per-edge geometry.  On the device: the hardware instructions (v_sqrt_f32, v_rcp_f32,
+// <= 1 ulp) instead of the correctly rounded ~15-instruction sequences hipcc emits for sqrtf() and 1.0f / x -- the edge
+// geometry was a sixth of the edge kernels' vector instructions.  The host twin keeps libm.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EQ_SQRT(v) __builtin_amdgcn_sqrtf(v)
+#define EQ_RCP(v) __builtin_amdgcn_rcpf(v)
+#else
+#define EQ_SQRT(v) sqrtf(v)
+#define EQ_RCP(v) (1.0f / (v))
+#endif
+
 EQ_HD void cross3(const float* a, const float* b, float* c) {
     c[0] = a[1] * b[2] - a[2] * b[1];
     c[1] = a[2] * b[0] - a[0] * b[2];
@@ -58,20 +69,20 @@ EQ_HD float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b
 EQ_HD void edge_geometry(const float xr[3], const float xc[3], EdgeGeo& e) {
     for (int i = 0; i < 3; ++i) e.d[i] = xr[i] - xc[i];
     const float radial = dot3(e.d, e.d);                    // :274
-    const float dist = sqrtf(radial);                       // :179
+    const float dist = EQ_SQRT(radial);                     // :179
     e.g[0] = radial;
     e.g[1] = dist;
     e.g[2] = dot3(xr, xc);                                  // :180
-    e.inv_na = 1.0f / (dist + 1e-8f);                       // :140
+    e.inv_na = EQ_RCP(dist + 1e-8f);                        // :140
     float a[3], b[3], c[3];
     for (int i = 0; i < 3; ++i) a[i] = e.d[i] * e.inv_na;
     cross3(xr, xc, e.p);                                    // :143
-    e.pn = sqrtf(dot3(e.p, e.p));
-    e.inv_nb = 1.0f / (e.pn + 1e-8f);                       // :144
+    e.pn = EQ_SQRT(dot3(e.p, e.p));
+    e.inv_nb = EQ_RCP(e.pn + 1e-8f);                        // :144
     for (int i = 0; i < 3; ++i) b[i] = e.p[i] * e.inv_nb;
     cross3(a, b, c);                                        // :149
-    const float thr = 1e-6f;                                // :130
-    e.degenerate = (sqrtf(dot3(a, a)) < thr) || (sqrtf(dot3(b, b)) < thr) || (sqrtf(dot3(c, c)) < thr);
+    const float thr2 = 1e-6f * 1e-6f;                       // :130, norms compared as squares
+    e.degenerate = (dot3(a, a) < thr2) || (dot3(b, b) < thr2) || (dot3(c, c) < thr2);
     if (e.degenerate) {                                     // :163 identity frame
         for (int i = 0; i < 9; ++i) e.g[3 + i] = (i % 4 == 0) ? 1.0f : 0.0f;
     } else {                                                // stack(dim=2).view(-1,9): [a_i, b_i, c_i] per row i
@@ -90,7 +101,7 @@ EQ_HD void edge_geometry_backward(const float xr[3], const float xc[3], const Ed
                                   const float gg[kGeo], const float gd[3], float gxr[3], float gxc[3]) {
     float gdt[3];                      // total gradient w.r.t. d = x_r - x_c
     const float dist = e.g[1];
-    const float inv_dist = dist > 0.0f ? 1.0f / dist : 0.0f;     // torch.norm backward: 0 at 0
+    const float inv_dist = dist > 0.0f ? EQ_RCP(dist) : 0.0f;    // torch.norm backward: 0 at 0
     for (int i = 0; i < 3; ++i) {
         gdt[i] = gd[i] + 2.0f * e.d[i] * gg[0] + e.d[i] * inv_dist * gg[1];
         gxr[i] = xc[i] * gg[2];
@@ -115,7 +126,7 @@ EQ_HD void edge_geometry_backward(const float xr[3], const float xc[3], const Ed
         const float ka = dga * inv_dist * e.inv_na * e.inv_na;
         for (int i = 0; i < 3; ++i) gdt[i] += ga[i] * e.inv_na - e.d[i] * ka;
         // b = p / (|p| + eps)
-        const float inv_pn = e.pn > 0.0f ? 1.0f / e.pn : 0.0f;
+        const float inv_pn = e.pn > 0.0f ? EQ_RCP(e.pn) : 0.0f;
         const float pgb = dot3(e.p, gb);
         const float kb = pgb * inv_pn * e.inv_nb * e.inv_nb;
         float gp[3];

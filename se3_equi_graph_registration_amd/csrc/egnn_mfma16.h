@@ -1,0 +1,215 @@
+// 16-edge MFMA formulation of the per-edge MLP chain (hidden_nf == 32), shared by the forward and backward edge
+// kernels (reference math: E_GCL.edge_model / coord_model, src/3dmatch_train_egnn_with_batch.py:231-268).
+//
+// A wave walks over CHUNKS of up to 64 consecutive edges:
+//   front  : one lane per edge -- indices, coordinate gathers and the whole edge geometry are computed ONCE per edge
+//            (the 32-edge formulation of egnn_mfma.h computes them in both lane halves) and left in wave-private LDS;
+//   middle : the chunk's 16-edge SUB-TILES one after the other on v_mfma_f32_16x16x4_f32.  Lane l = (e = l & 15,
+//            g = l >> 4) owns edge e of the sub-tile and 8 of its 32 features: v[b][r] = feature 16 b + 4 g + r
+//            (b = 0, 1; r = 0..3).  That is the C/D layout of the instruction with D[i = feature][j = edge], and with
+//            the K index of step (b, r) mapped to feature 16 b + 4 g + r it is also the B operand of the next product,
+//            so the chain  t1 -> SiLU -> W2 -> LayerNorm -> W6 -> SiLU -> w7  needs no cross-lane traffic except the
+//            two-step reductions over g.  A vector costs 8 registers instead of 16: the backward fits two waves per
+//            SIMD with its weight-gradient accumulators, the forward four;
+//   back   : one lane per edge again (coordinate scalar / geometry backward).
+// The weights (A operands) are read from a per-workgroup LDS image with ds_read_b128: one read feeds four MFMAs.
+// fp32 MFMA is an exact fmaf chain, so the numerics are those of the VALU formulation.
+#pragma once
+#include "egnn_device.h"
+
+namespace eq {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ldg4(const float* __restrict__ p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+// sum over the four lane groups g of an edge (lanes e, e + 16, e + 32, e + 48): two VALU lane swaps (v_permlane16_swap,
+// v_permlane32_swap: no LDS round trip, unlike ds_bpermute); every lane of the edge gets the bit-identical sum
+__device__ __forceinline__ float gsum(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);                // rows 0+1 | 2+3
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// LDS image of a layer's edge-MLP weights.  Row strides chosen so that the per-lane 16-byte operand fetches
+// (row = 16 bo + i, column 16 bi + 4 g) of every 16-lane ds_read_b128 group fall on distinct banks.
+struct W16 {
+    static constexpr int WS = 40;                          // 32 x 32 matrices
+    static constexpr int GS = 24;                          // Wgeo [32][16]: columns 0..11 geometry, 12 edge_attr, 13..15 zero
+    static constexpr int o_w2 = 0;
+    static constexpr int o_w6 = o_w2 + 32 * WS;
+    static constexpr int o_wg = o_w6 + 32 * WS;
+    static constexpr int o_vec = o_wg + 32 * GS;           // b2 | gamma | beta | b6 | w7
+    static constexpr int fwd_size = o_vec + 5 * 32;
+    static constexpr int o_w2t = fwd_size;                 // transposed copies for the backward's W^T products
+    static constexpr int o_w6t = o_w2t + 32 * WS;
+    static constexpr int o_wgt = o_w6t + 32 * WS;          // Wgeo^T [16][WS]
+    static constexpr int bwd_size = o_wgt + 16 * WS;
+};
+
+// global -> LDS, all of a thread's loads before its first store.  NT = threads of the workgroup.
+template <int H, int A, bool kBwd, int NT>
+__device__ __forceinline__ void stage_w16(float* sm, const float* __restrict__ lw) {
+    using LL = LP<32, H, A>;
+    constexpr int FH = 32 / H;
+    constexpr int PER = 1024 / NT, PG = (512 + NT - 1) / NT;
+    float v2[PER], v6[PER], vg[PG];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int t = threadIdx.x + NT * u, i = t >> 5, k = t & 31;
+        v2[u] = (i / FH == k / FH) ? lw[LL::w2_off(i, k)] : 0.0f;      // block-diagonal over the heads
+        v6[u] = lw[LL::w6 + t];
+    }
+#pragma unroll
+    for (int u = 0; u < PG; ++u) {
+        const int t = threadIdx.x + NT * u, i = (t >> 4) & 31, k = t & 15;
+        vg[u] = (t < 512 && k < kGeo + A) ? lw[LL::w1_off(i, 64 + k)] : 0.0f;
+    }
+    float vv = 0.0f;
+    if (threadIdx.x < 160) {
+        const int w = threadIdx.x >> 5, k = threadIdx.x & 31;
+        vv = lw[w == 0 ? LL::b2_off(k) : (w == 1 ? LL::ln_g + k : (w == 2 ? LL::ln_b + k : (w == 3 ? LL::b6 + k : LL::w7 + k)))];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int t = threadIdx.x + NT * u, i = t >> 5, k = t & 31;
+        sm[W16::o_w2 + i * W16::WS + k] = v2[u];
+        sm[W16::o_w6 + i * W16::WS + k] = v6[u];
+        if (kBwd) {
+            sm[W16::o_w2t + k * W16::WS + i] = v2[u];
+            sm[W16::o_w6t + k * W16::WS + i] = v6[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < PG; ++u) {
+        const int t = threadIdx.x + NT * u, i = (t >> 4) & 31, k = t & 15;
+        if (t < 512) {
+            sm[W16::o_wg + i * W16::GS + k] = vg[u];
+            if (kBwd) sm[W16::o_wgt + k * W16::WS + i] = vg[u];
+        }
+    }
+    if (threadIdx.x < 160) sm[W16::o_vec + threadIdx.x] = vv;
+}
+
+// acc[bo] += W v for a 32 x 32 LDS image `mat` (row stride WS): 4 ds_read_b128, 16 MFMAs.  For y = W^T v pass the
+// transposed image.  (i, g) = (lane & 15, lane >> 4).
+__device__ __forceinline__ void mv16(const float* mat, int i, int g, const f32x4 (&v)[2], f32x4 (&acc)[2]) {
+    f32x4 a[2][2];
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bo = 0; bo < 2; ++bo) a[bi][bo] = lds4(mat + (16 * bo + i) * W16::WS + 16 * bi + 4 * g);
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[0] = mfma16(a[bi][0][r], v[bi][r], acc[0]);
+            acc[1] = mfma16(a[bi][1][r], v[bi][r], acc[1]);
+        }
+}
+
+__device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
+    return f32x4{sigmoid_fast(v[0]), sigmoid_fast(v[1]), sigmoid_fast(v[2]), sigmoid_fast(v[3])};
+}
+__device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+
+// forward state of one 16-edge sub-tile (what the backward needs of it)
+struct Sub16 {
+    f32x4 t1[2], sg1[2];          // pre-activation of the first edge-MLP layer, sigmoid(t1)
+    f32x4 xhat[2], m[2];          // LayerNorm: normalised value, output (= the message m_ij)
+    f32x4 q[2], sgq[2];           // coord-MLP pre-activation, sigmoid(q)
+    float rstd, s;                // LayerNorm 1/std; coord scalar s = w7 . SiLU(q)   (:264)
+};
+
+// the lane's share (features 16 b + 4 g + r) of the two per-node projection rows of an edge: W_src h[row], W_tgt h[col] + b1
+struct PRows {
+    f32x4 pr[2], pc[2];
+    __device__ __forceinline__ void load(const float* __restrict__ P, int r, int c, int g) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            pr[b] = ldg4(P + (size_t)r * 64 + 16 * b + 4 * g);
+            pc[b] = ldg4(P + (size_t)c * 64 + 32 + 16 * b + 4 * g);
+        }
+    }
+};
+
+// wsm: the workgroup's weight image (through an opaque offset so the loop-invariant reads stay inside the loop);
+// geo_row: this edge's 16 geometry values in LDS; pw: its projection rows (already in registers).
+__device__ __forceinline__ void tile_forward16(const float* wsm, const float* geo_row, const PRows& pw, int i, int g, Sub16& o) {
+    f32x4 acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[b] = pw.pr[b] + pw.pc[b];
+    {   // + Wgeo [geo | attr]: K = 16, step s <-> geometry entry 4 g + s
+        const f32x4 gv = lds4(geo_row + 4 * g);
+        const f32x4 a0 = lds4(wsm + W16::o_wg + i * W16::GS + 4 * g), a1 = lds4(wsm + W16::o_wg + (16 + i) * W16::GS + 4 * g);
+        EQ_STAMP(4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            acc[0] = mfma16(a0[s], gv[s], acc[0]);
+            acc[1] = mfma16(a1[s], gv[s], acc[1]);
+        }
+    }
+    f32x4 a1v[2], u[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        o.t1[b] = acc[b];
+        o.sg1[b] = sigmoid4(acc[b]);
+        a1v[b] = acc[b] * o.sg1[b];                                    // SiLU (:245)
+        u[b] = lds4(wsm + W16::o_vec + 0 * 32 + 16 * b + 4 * g);       // b2
+    }
+    EQ_STAMP(5);
+    mv16(wsm + W16::o_w2, i, g, a1v, u);
+    EQ_STAMP(6);
+    // LayerNorm over the 32 features (biased variance, eps 1e-5; :249)
+    const float mean = gsum(hsum4(u[0]) + hsum4(u[1])) * (1.0f / 32.0f);
+    f32x4 c0 = u[0] - splat4(mean), c1 = u[1] - splat4(mean);
+    const float var = gsum(hsum4(c0 * c0) + hsum4(c1 * c1)) * (1.0f / 32.0f);
+    o.rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+    o.xhat[0] = c0 * splat4(o.rstd);
+    o.xhat[1] = c1 * splat4(o.rstd);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const f32x4 gam = lds4(wsm + W16::o_vec + 1 * 32 + 16 * b + 4 * g), bet = lds4(wsm + W16::o_vec + 2 * 32 + 16 * b + 4 * g);
+        o.m[b] = o.xhat[b] * gam + bet;
+        o.q[b] = lds4(wsm + W16::o_vec + 3 * 32 + 16 * b + 4 * g);     // b6
+    }
+    EQ_STAMP(7);
+    mv16(wsm + W16::o_w6, i, g, o.m, o.q);
+    EQ_STAMP(8);
+    float sp = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        o.sgq[b] = sigmoid4(o.q[b]);
+        const f32x4 w7 = lds4(wsm + W16::o_vec + 4 * 32 + 16 * b + 4 * g);
+        sp += hsum4(w7 * (o.q[b] * o.sgq[b]));
+    }
+    o.s = gsum(sp);
+    EQ_STAMP(9);
+}
+
+// wave-private LDS scratch of a chunk (floats)
+struct Chunk16 {
+    static constexpr int GS = 16;                       // per-edge geometry row [radial, dist, dot, so3(9), attr, 0, 0, 0]
+    static constexpr int o_geo = 0;                     // [64][GS]
+    static constexpr int o_r = 64 * GS, o_c = o_r + 64, o_a = o_c + 64, o_b = o_a + 64;    // row idx, col idx, two words per edge
+    static constexpr int fwd_size = o_b + 64;
+    static constexpr int FS = 12;                       // backward: the edge's x_r, x_c, G_x[row] kept for the back phase
+    static constexpr int o_front = fwd_size;            // [64][FS]
+    static constexpr int LD = 36;                       // transposing tiles X, Y [16][LD] of the backward
+    static constexpr int o_x = o_front + 64 * FS, o_y = o_x + 16 * LD;
+    static constexpr int bwd_size = o_y + 16 * LD;
+};
+
+// front of a chunk: the lane's own edge -> geometry row [radial, dist, dot, so3(9), attr, 0, 0, 0] into LDS
+__device__ __forceinline__ void store_geo_row(float* row, const EdgeGeo& eg, float attr) {
+    st4(row + 0, f32x4{eg.g[0], eg.g[1], eg.g[2], eg.g[3]});
+    st4(row + 4, f32x4{eg.g[4], eg.g[5], eg.g[6], eg.g[7]});
+    st4(row + 8, f32x4{eg.g[8], eg.g[9], eg.g[10], eg.g[11]});
+    st4(row + 12, f32x4{attr, 0.0f, 0.0f, 0.0f});
+}
+
+}  // namespace eq
