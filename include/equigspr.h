@@ -123,8 +123,9 @@ int equigspr_edges_i64_to_i32(const int64_t* edges_i64, int32_t n_edges, int32_t
  *   h_in      [N, in_nf]     x_in [N,3]     edge_attr [E, in_edge_nf] or NULL (= all ones)
  *   h_out     [N, out_nf]    x_out [N,3]
  *   saved     float[equigspr_egnn_saved_size]   activations kept for backward (NULL = inference): per layer the node
- *             states h, x, agg and, per edge, the pre-activation / normalised / coordinate-head rows the backward would
- *             otherwise recompute with three matrix products (388 B per edge and layer at hidden_nf = 32)
+ *             states h, x, agg.  Nothing is kept per edge: the edge backward recomputes the edge forward from the node
+ *             states (flash-style), so the training-mode forward runs the same edge kernel as inference and the size does
+ *             not depend on n_edges (the argument is kept for ABI stability)
  *   work      float[equigspr_egnn_work_size]    scratch */
 int64_t equigspr_egnn_saved_size(const equigspr_egnn_config* cfg, int32_t n_nodes, int32_t n_edges);
 int64_t equigspr_egnn_work_size(const equigspr_egnn_config* cfg, int32_t n_nodes, int32_t n_edges);

@@ -5,9 +5,8 @@
 // Per layer, walking l = L-1 .. 0 with G_h = dL/dh_{l+1}, G_x = dL/dx_{l+1}:
 //   node_bwd   (lane = feature, G lanes per node)  node-MLP backward -> dagg, dh_part; re-projects
 //              P_l = [W_src h_l | W_tgt h_l + b1] for the edge recompute; dW4,db4,dW5,db5 partials.
-//   edge_bwd   (one wave per 32-edge tile)  obtains the tile's forward state either by restoring the three
-//              per-edge rows the forward saved (problems whose saves fit the Infinity Cache: edge_saves_enabled)
-//              or by recomputing the edge forward from (P_l, x_l) on the matrix cores; runs the edge backward,
+//   edge_bwd   (hidden_nf 32: a wave per chunk of <= 64 edges, 16-edge MFMA sub-tiles, egnn_mfma16.h; hidden_nf 33: a wave
+//              per 32-edge tile, egnn_mfma.h)  recomputes the edge forward from (P_l, x_l), runs the edge backward,
 //              writes dt1_e, dL/dx_r, dL/dx_c per edge.  Weight gradients are sums over edges of outer products: the
 //              per-edge vectors are transposed through wave-private LDS tiles and accumulated
 //              with fp32 MFMA (v_mfma_f32_32x32x2_f32, K = edges) -- exact fp32, VALU stays free.
@@ -662,7 +661,7 @@ __device__ __forceinline__ void tile_pass(const float* X, const float* Y, f32x16
 
 // ---------------------------------------------------------------------------------------
 // edge backward, MFMA formulation (hidden_nf == 32): one wave per 32-edge tile (egnn_mfma.h).
-// The forward state (kRestore: loaded from the forward's per-edge saves; otherwise recomputed) and the
+// The forward state (recomputed) and the
 // three transposed products (W6^T dq, W2^T du, Wgeo^T dt1) use the matrix cores with register-resident
 // weights; only the weight-gradient outer products (sum over edges) go through wave-private LDS tiles.
 // ---------------------------------------------------------------------------------------
@@ -672,10 +671,10 @@ __device__ __forceinline__ void stage_half_row(float* tile_row, int h, const flo
         *reinterpret_cast<float4*>(tile_row + 8 * q + 4 * h) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
 }
 
-template <int H, int A, int B = 0, bool kRestore = false>
+template <int H, int A, int B = 0>
 __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restrict__ lw, const int* __restrict__ row,
                                                             const int* __restrict__ col, const float* __restrict__ edge_attr,
-                                                            const float* __restrict__ x, const float* __restrict__ P, EdgeSave es,
+                                                            const float* __restrict__ x, const float* __restrict__ P,
                                                             const float* __restrict__ dagg, const float* __restrict__ Gx,
                                                             int n_edges, float* __restrict__ dt1_out,
                                                             float* __restrict__ gxr_out, float* __restrict__ gxc_out,
@@ -729,10 +728,8 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
         EQ_STAMP(3);
         const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
         TileFwd o;
-        if constexpr (kRestore)      // the forward's per-edge activations, saved in edge order (small problems, see edge_saves_enabled)
-            tile_restore<H, A, true, B>(W, es.t1 + (size_t)e * FP, es.xh + (size_t)e * FP, es.q + (size_t)e * FP, es.rstd[e], h, o);
-        else                         // recompute the three matrix products from the projection rows
-            tile_forward<H, A, true, B>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
+        // the forward state: recomputed from the projection rows (flash-style; nothing per edge is kept by the forward)
+        tile_forward<H, A, true, B>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
         const float zh = (h == 0) ? 1.0f : 0.0f;            // border scalars are identical in both halves: count them once
 
         // ---- coord head backward
@@ -1294,33 +1291,27 @@ static inline int edge_chunk_for16(int E, int waves_resident) {      // see egnn
 
 template <int F, int H, int A>
 static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
-                           EdgeSave es, const float* dagg, const float* Gx, float* dt1, float* gxr, float* gxc, float* slab,
+                           const float* dagg, const float* Gx, float* dt1, float* gxr, float* gxc, float* slab,
                            hipStream_t s, int* n_slabs) {
     const int E = g->n_edges;
     static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1 or 4 heads) or 33 (1 head)");
-    if constexpr (F == 32) {
-        if (!es.t1) {                          // the 16-edge formulation: one 8-wave workgroup per CU, persistent
-            const int chunk = edge_chunk_for16(E, 256 * kBwd16Waves);
-            int blocks16 = ceil_div(ceil_div(E, chunk), kBwd16Waves);
-            blocks16 = blocks16 < 1 ? 1 : (blocks16 > 256 ? 256 : blocks16);
-            hipLaunchKernelGGL((edge_bwd16_kernel<H, A>), dim3(blocks16), dim3(512), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
-                               E, chunk, dt1, gxr, gxc, slab);
-            *n_slabs = blocks16;
-            return 0;
-        }
+    if constexpr (F == 32) {               // the 16-edge formulation: one 8-wave workgroup per CU, persistent
+        const int chunk = edge_chunk_for16(E, 256 * kBwd16Waves);
+        int blocks = ceil_div(ceil_div(E, chunk), kBwd16Waves);
+        blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+        hipLaunchKernelGGL((edge_bwd16_kernel<H, A>), dim3(blocks), dim3(512), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
+                           E, chunk, dt1, gxr, gxc, slab);
+        *n_slabs = blocks;
+    } else {
+        // hidden_nf 33: 32-edge tiles with a border feature (egnn_mfma.h), persistent waves, one workgroup per CU (the kernel
+        // runs at one wave per SIMD): the weight staging and the slab epilogue are paid 256 times, not once per 4 tiles
+        const int tiles = ceil_div(E, 32);
+        int blocks = ceil_div(tiles, 4);
+        blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+        hipLaunchKernelGGL((edge_bwd_mfma_kernel<H, A, 1>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx, E,
+                           dt1, gxr, gxc, slab);
+        *n_slabs = blocks;
     }
-    const int tiles = ceil_div(E, 32);
-    // persistent waves: one workgroup per CU (the kernel runs at one wave per SIMD), each wave loops over
-    // its tiles -- the weight staging and the slab epilogue are paid 256 times, not once per 4 tiles
-    int blocks = ceil_div(tiles, 4);
-    blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
-    if (es.t1)
-        hipLaunchKernelGGL((edge_bwd_mfma_kernel<H, A, F - 32, true>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x,
-                           P, es, dagg, Gx, E, dt1, gxr, gxc, slab);
-    else
-        hipLaunchKernelGGL((edge_bwd_mfma_kernel<H, A, F - 32, false>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x,
-                           P, es, dagg, Gx, E, dt1, gxr, gxc, slab);
-    *n_slabs = blocks;
     return 0;
 }
 
@@ -1470,8 +1461,7 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
     hipLaunchKernelGGL((embed_out_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_out, cfg->out_nf, gh_out,
                        gx_out, hs + (size_t)L * N * FP, N, Gh, Gx, work + B.emb_slab);
     auto slab_of = [&](int l) { return (size_t)l * B.layer_stride; };
-    // the projection rows P feed the edge backward's forward recompute only: not produced when it restores saved activations
-    float* const Pbuf = edge_saves_enabled(FP, L, E) ? nullptr : work + B.P;
+    float* const Pbuf = work + B.P;                        // the projection rows of layer l, re-made by the node backward for the edge recompute
     auto launch_node_bwd = [&](int l) {
         hipLaunchKernelGGL((node_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, params + ML.layer0 + (size_t)l * ML.layer_size,
                            work + B.Gh[cur], hs + (size_t)l * N * FP, aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg,
@@ -1485,9 +1475,7 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
         const float* x_l = xs + (size_t)l * N * 3;
         if (!kFuse) launch_node_bwd(l);
         if (E > 0) {
-            const EdgeSave es = edge_saves_enabled(FP, L, E) ? edge_save_of(const_cast<float*>(saved), saved_node_floats(FP, L, N), FP, E, l)
-                                                             : EdgeSave{nullptr, nullptr, nullptr, nullptr};
-            const int rc = launch_edge_bwd<F, H, A>(lw, g, edge_attr, x_l, Pbuf, es, work + B.dagg, work + B.Gx[cur],
+            const int rc = launch_edge_bwd<F, H, A>(lw, g, edge_attr, x_l, Pbuf, work + B.dagg, work + B.Gx[cur],
                                                     work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab + slab_of(l), s, &egrid);
             if (rc) return rc;
         }
@@ -1547,10 +1535,7 @@ static int time_edge_bwd_impl(const equigspr_egnn_config* cfg, const float* para
                        hs + (size_t)l * N * FP, aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg, work + B.P,
                        work + B.node_slab);
     auto launch = [&]() {
-        (void)launch_edge_bwd<F, H, A>(lw, g, edge_attr, xs + (size_t)l * N * 3, work + B.P,
-                                       edge_saves_enabled(FP, L, E) ? edge_save_of(const_cast<float*>(saved), saved_node_floats(FP, L, N), FP, E, l)
-                                                                    : EdgeSave{nullptr, nullptr, nullptr, nullptr},
-                                       work + B.dagg, work + B.Gx[0],
+        (void)launch_edge_bwd<F, H, A>(lw, g, edge_attr, xs + (size_t)l * N * 3, work + B.P, work + B.dagg, work + B.Gx[0],
                                        work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab, s, &egrid);
     };
     hipEvent_t e0, e1;

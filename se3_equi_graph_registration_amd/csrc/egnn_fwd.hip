@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restr
                                                             const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                             const float* __restrict__ x, const float* __restrict__ P,
                                                             const int* __restrict__ rinv, int n_edges, float* __restrict__ m_out,
-                                                            float* __restrict__ trans_out, EdgeSave es) {
+                                                            float* __restrict__ trans_out) {
     constexpr int FP = 32 + 4 * B, PS = 2 * FP;          // hidden_nf = 32 + B, rows padded to 16 bytes
     const int lane = threadIdx.x & 63, el = lane & 31, h = lane >> 5;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
@@ -102,17 +102,6 @@ __global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restr
             if (B) store_border(m_out + at * FP, h, o.mb);
             if (h == 0)
                 reinterpret_cast<float4*>(trans_out)[at] = make_float4(eg.d[0] * o.s, eg.d[1] * o.s, eg.d[2] * o.s, 0.0f);   // :264
-            if (es.t1) {       // training: what the backward would otherwise recompute with three matrix products, in edge order
-                store_half_row(es.t1 + (size_t)e * FP, h, o.t1);
-                store_half_row(es.xh + (size_t)e * FP, h, o.xhat);
-                store_half_row(es.q + (size_t)e * FP, h, o.q);
-                if (B) {
-                    store_border(es.t1 + (size_t)e * FP, h, o.t1b);
-                    store_border(es.xh + (size_t)e * FP, h, o.xhatb);
-                    store_border(es.q + (size_t)e * FP, h, o.qb);
-                }
-                if (h == 0) es.rstd[e] = o.rstd;
-            }
         }
         EQ_STAMP(7);
     }
@@ -226,24 +215,22 @@ static inline int edge_chunk_for(int E, int waves_resident) {
 
 template <int F, int H, int A>
 static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
-                            float* m, float* trans, hipStream_t s, EdgeSave es = EdgeSave{nullptr, nullptr, nullptr, nullptr}) {
+                            float* m, float* trans, hipStream_t s) {
     const int E = g->n_edges;
     static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1 or 4 heads) or 33 (1 head)");
-    if constexpr (F == 32) {
-        if (!es.t1) {                          // the 16-edge formulation; four 4-wave workgroups per CU
-            const int chunk = edge_chunk_for(E, 256 * 4 * EQ_FWD16_OCC);
-            int blocks16 = ceil_div(ceil_div(E, chunk), kFwd16Waves);
-            blocks16 = blocks16 < 1 ? 1 : (blocks16 > 256 * EQ_FWD16_OCC ? 256 * EQ_FWD16_OCC : blocks16);
-            hipLaunchKernelGGL((edge_fwd16_kernel<H, A>), dim3(blocks16), dim3(64 * kFwd16Waves), 0, s, lw, g->row, g->col, edge_attr, x, P, g->rinv,
-                               E, chunk, m, trans);
-            return;
-        }
+    if constexpr (F == 32) {               // the 16-edge formulation; EQ_FWD16_OCC 4-wave workgroups per CU
+        const int chunk = edge_chunk_for(E, 256 * 4 * EQ_FWD16_OCC);
+        int blocks = ceil_div(ceil_div(E, chunk), kFwd16Waves);
+        blocks = blocks < 1 ? 1 : (blocks > 256 * EQ_FWD16_OCC ? 256 * EQ_FWD16_OCC : blocks);
+        hipLaunchKernelGGL((edge_fwd16_kernel<H, A>), dim3(blocks), dim3(64 * kFwd16Waves), 0, s, lw, g->row, g->col, edge_attr, x, P, g->rinv,
+                           E, chunk, m, trans);
+    } else {                               // hidden_nf 33: 32-edge tiles with a border feature (egnn_mfma.h)
+        const int tiles = ceil_div(E, 32);
+        int blocks = ceil_div(tiles, 4);          // one 32-edge tile per wave: latency is hidden across waves
+        blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+        hipLaunchKernelGGL((edge_fwd_mfma_kernel<H, A, 1>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
+                           g->rinv, E, m, trans);
     }
-    const int tiles = ceil_div(E, 32);
-    int blocks = ceil_div(tiles, 4);          // one 32-edge tile per wave: latency is hidden across waves
-    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-    hipLaunchKernelGGL((edge_fwd_mfma_kernel<H, A, F - 32>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
-                       g->rinv, E, m, trans, es);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -347,8 +334,8 @@ struct FwdBuffers {
     bool training;
 };
 
-static inline int64_t saved_floats(int F, int L, int64_t N, int64_t E) {       // node-level block, then L per-edge blocks (if kept)
-    return saved_node_floats(fpad(F), L, N) + (edge_saves_enabled(fpad(F), L, E) ? (int64_t)L * edge_save_floats(fpad(F), E) : 0);
+static inline int64_t saved_floats(int F, int L, int64_t N) {       // node-level activations only: the edge backward recomputes
+    return saved_node_floats(fpad(F), L, N);
 }
 static inline int64_t work_floats(int F, int64_t N, int64_t E) {
     const int FP = fpad(F);
@@ -415,8 +402,7 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
         const float* lw = params + ML.layer0 + (size_t)l * ML.layer_size;
         const bool last = (l == L - 1);
         if (E > 0) {
-            if (training && edge_saves_enabled(FP, L, E)) launch_edge_fwd<F, H, A>(lw, g, edge_attr, xbuf(l), P, m, trans, s, edge_save_of(saved, saved_node_floats(FP, L, N), FP, E, l));
-            else launch_edge_fwd<F, H, A>(lw, g, edge_attr, xbuf(l), P, m, trans, s);
+            launch_edge_fwd<F, H, A>(lw, g, edge_attr, xbuf(l), P, m, trans, s);
         }
         float* xn = last ? x_out : xbuf(l + 1);
         hipLaunchKernelGGL((node_fwd_kernel<F, H, A>), dim3(node_grid), dim3(256), 0, s, lw,
@@ -434,7 +420,7 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
 
 extern "C" int64_t equigspr_egnn_saved_size(const equigspr_egnn_config* cfg, int32_t n_nodes, int32_t n_edges) {
     if (!eq::config_supported(cfg) || n_nodes < 0) return -1;
-    return eq::saved_floats(cfg->hidden_nf, cfg->n_layers, n_nodes, n_edges);
+    return eq::saved_floats(cfg->hidden_nf, cfg->n_layers, n_nodes);
 }
 
 extern "C" int64_t equigspr_egnn_work_size(const equigspr_egnn_config* cfg, int32_t n_nodes, int32_t n_edges) {

@@ -12,7 +12,6 @@
 // and the final dot product.  fp32 MFMA is an exact fmaf chain (guide §3), so numerics match
 // the VALU formulation.  The backward uses the transposed weights as A operands the same way.
 #pragma once
-#include <stdlib.h>
 #include "egnn_device.h"
 
 namespace eq {
@@ -275,58 +274,8 @@ __device__ __forceinline__ void tile_forward(const TileWeights<H, A, kCached, B>
     EQ_STAMP(6);
 }
 
-// The backward's view of a tile's forward from what the forward kernel SAVED per edge (t1, xhat, q rows and rstd; feature 32
-// of a row in its column 32) instead of recomputing the three matrix products: the sigmoids, m = xhat * gamma + beta and
-// s = w7 . SiLU(q) are cheap per-lane work.  (HBM has the room -- the edge kernels run at 25-35 % of its roofline -- and the
-// 288 GB hold 388 bytes per edge and layer easily.)
-template <int H, int A, bool kCached, int B = 0>
-__device__ __forceinline__ void tile_restore(const TileWeights<H, A, kCached, B>& W, const float* __restrict__ t1_row,
-                                             const float* __restrict__ xh_row, const float* __restrict__ q_row, float rstd,
-                                             int h, TileFwd& o) {
-    load_half_row(t1_row, h, o.t1);
-    load_half_row(xh_row, h, o.xhat);
-    load_half_row(q_row, h, o.q);
-    o.rstd = rstd;
-    float sp = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        o.sg1[r] = sigmoid_fast(o.t1[r]);
-        o.m[r] = fmaf(o.xhat[r], W.gam(r), W.bet(r));
-        o.sgq[r] = sigmoid_fast(o.q[r]);
-        sp = fmaf(W.w7(r), o.q[r] * o.sgq[r], sp);
-    }
-    o.s = sp + xhalf(sp);
-    o.t1b = 0.0f; o.sg1b = 0.0f; o.xhatb = 0.0f; o.mb = 0.0f; o.qb = 0.0f; o.sgqb = 0.0f;
-    if constexpr (B == 1) {
-        o.t1b = t1_row[32]; o.xhatb = xh_row[32]; o.qb = q_row[32];
-        o.sg1b = sigmoid_fast(o.t1b);
-        o.mb = fmaf(o.xhatb, W.x_vec(1), W.x_vec(2));
-        o.sgqb = sigmoid_fast(o.qb);
-        o.s = fmaf(W.x_vec(4), o.qb * o.sgqb, o.s);
-    }
-}
-
-// where the forward keeps a layer's per-edge activations inside `saved` (after the node-level block of `node_floats` floats)
-struct EdgeSave {
-    float *t1, *xh, *q, *rstd;
-};
 static inline int64_t saved_node_floats(int FP, int L, int64_t N) {      // h_0..h_L, x_0..x_L, agg_0..agg_{L-1}; padded to 16 bytes
     return ((int64_t)(L + 1) * N * FP + (int64_t)(L + 1) * N * 3 + (int64_t)L * N * FP + 3) / 4 * 4;
-}
-static inline int64_t edge_save_floats(int FP, int64_t E) { return E * 3 * FP + (E + 3) / 4 * 4; }
-// Save or recompute?  Measured on MI355X (F = 32, L = 4): with the saves of all layers resident in the 256 MB Infinity Cache
-// (one 2 048-point pair: 127 MB) restoring beats recomputing (edge_bwd 34.9 -> 32.3 us, step 0.4705 -> 0.4645 ms); at 16
-// pairs per step (2 GB written and read back through HBM) the same choice costs 18 % of the step.  So the forward keeps the
-// per-edge rows only while they fit a budget well inside that cache, and the backward recomputes otherwise.
-constexpr int64_t kEdgeSaveBudgetBytes = 160ll << 20;
-static inline bool edge_saves_enabled(int FP, int L, int64_t E) {
-    int64_t budget = kEdgeSaveBudgetBytes;
-    if (const char* mb = getenv("EQUIGSPR_EDGE_SAVE_MB")) budget = (int64_t)atoll(mb) << 20;   // 0 = always recompute (tests compare the two)
-    return E > 0 && (int64_t)L * edge_save_floats(FP, E) * 4 <= budget;
-}
-static inline EdgeSave edge_save_of(float* saved, int64_t node_floats, int FP, int64_t E, int layer) {
-    float* base = saved + node_floats + (size_t)layer * edge_save_floats(FP, E);
-    return EdgeSave{base, base + (size_t)E * FP, base + (size_t)2 * E * FP, base + (size_t)3 * E * FP};
 }
 
 }  // namespace eq
