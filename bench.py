@@ -54,7 +54,20 @@ def parse():
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: inference step (not the headline metric)")
     ap.add_argument("--reset-every", type=int, default=100, help="restore the initial weights every this many steps (see build_step)")
     ap.add_argument("--aten-head", action="store_true", help="diagnostic: pose head as PyTorch-ROCm ops instead of csrc/head.hip")
-    return ap.parse_args()
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default=None,
+                    help="BASELINE.json configs: c2 = default (1 pair, 2048 pts); c3 = 16 pairs per step; c4 = one GPU's shard of the "
+                         "KITTI batch (8 pairs x 4096 pts, F=33); c5 = eval sweep (8192 pts, k=32, 8 layers, inference)")
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="repeat the timed block of --steps steps until this much time has been measured; report the median block")
+    ap.add_argument("--allow-eager", action="store_true", help="N>1: fall back to eager launches if hipGraph capture fails (default: exit non-zero)")
+    a = ap.parse_args()
+    if a.workload == "c3":
+        a.batch = 16
+    elif a.workload == "c4":
+        a.batch, a.n, a.feat = 8, 4096, 33
+    elif a.workload == "c5":
+        a.n, a.k, a.layers, a.forward_only = 8192, 32, 8, True
+    return a
 
 
 def build_step(pkg, args, dev, world):
@@ -141,6 +154,9 @@ def make_runner(S, args, world, dev):
         try:
             return split_graph_runner(S, args, dist_on, eager), True
         except Exception as exc:
+            if dist_on and not args.allow_eager:       # a silent eager fallback would misreport the N>1 path
+                print(f"[bench] hipGraph capture failed on the multi-rank path ({type(exc).__name__}: {exc})", file=sys.stderr)
+                raise SystemExit(3)
             print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize()
             return eager, False
@@ -171,6 +187,9 @@ def make_runner(S, args, world, dev):
         S["restore"] = lambda: gr.replay()
         return (lambda: g.replay()), True
     except Exception as exc:        # capture unsupported -> eager launches (reported in the JSON)
+        if dist_on and not args.allow_eager:
+            print(f"[bench] hipGraph capture failed on the multi-rank path ({type(exc).__name__}: {exc})", file=sys.stderr)
+            raise SystemExit(3)
         print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
         torch.cuda.synchronize()
         return eager, False
@@ -223,8 +242,16 @@ def split_graph_runner(S, args, dist_on, eager):
     return step
 
 
+# MFMA instructions the edge kernels issue per tile, and the flops of one such instruction (csrc/egnn_mfma16.h, egnn_mfma.h):
+#   hidden_nf 32: 16-edge sub-tiles of v_mfma_f32_16x16x4_f32 (2 048 flop): forward 8 + 16 + 16; backward recomputes those,
+#                 + three transposed products (16 + 16 + 8) + three weight-gradient outer products (16 + 16 + 8)
+#   hidden_nf 33: 32-edge tiles of v_mfma_f32_32x32x2_f32 (4 096 flop): forward 7 + 17 + 17 (one border step per product);
+#                 backward + 17 + 17 + 17 transposed and 16 + 16 + 16 outer products
+MFMA_PER_TILE = {32: dict(edges=16, flop=2048, fwd=40, bwd=120), 33: dict(edges=32, flop=4096, fwd=41, bwd=140)}
+
+
 def roofline(pkg, S, args, dev):
-    """HIP-event timing of the edge (message-passing) kernels, forward and backward."""
+    """HIP-event timing of the edge (message-passing) kernels, forward and backward, on the stream they are launched on."""
     from se3_equi_graph_registration_amd import _lib, ops
     L = _lib.lib()
     egnn, batch = S["egnn"], S["batch"]
@@ -238,6 +265,7 @@ def roofline(pkg, S, args, dev):
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     ms = ctypes.c_float(0.0)
     iters = 50
+    # the training-mode forward keeps nothing per edge (the backward recomputes), so this IS the kernel of the timed step
     _lib.check(L.equigspr_time_edge_fwd(ctypes.byref(cfg), ctypes.c_void_p(egnn.flat_params.data_ptr()),
                                         ctypes.byref(graph.struct), ctypes.c_void_p(h.data_ptr()),
                                         ctypes.c_void_p(x.data_ptr()), None, ctypes.c_void_p(work.data_ptr()), iters,
@@ -252,16 +280,21 @@ def roofline(pkg, S, args, dev):
     F = args.feat
     bytes_fwd = (2 * (F + 3) * 4 + 2 * 4 + 4 + (F + 3) * 4) * E          # 432 B/edge-layer at F=32
     bytes_bwd = 2 * bytes_fwd
+    # algorithmic flops per edge (the reference's 77-wide first layer counted per edge although its two
+    # h-blocks are projected once per node here), and the flops of the MFMA instructions the kernels actually issue
     flops_fwd = (2 * (2 * F + 13) * F + 2 * F * F + 2 * F * F + 2 * F + 12 * F) * E
-    # backward per edge: the forward recompute, the three transposed products (W6^T dq, W2^T du, Wgeo^T dt1) and the three
-    # weight-gradient outer products (dW6, dW2, dWgeo); the h-column blocks of dW1 are node-level work (gather kernels)
-    flops_bwd = flops_fwd + 2 * (2 * F * F + 2 * F * F + 2 * 13 * F) * E
-    # HBM traffic per launch from the committed rocprofv3 PMC passes (profiles/), when they cover this workload
-    traffic = {"fwd": None, "bwd": None}
+    flops_bwd = flops_fwd + 2 * (2 * F * F + 2 * F * F + 2 * 13 * F) * E       # + transposed products + outer products (the backward recomputes the forward)
+    mm = MFMA_PER_TILE[33 if F == 33 else 32]
+    tiles = (E + mm["edges"] - 1) // mm["edges"]
+    exe_fwd, exe_bwd = tiles * mm["fwd"] * mm["flop"], tiles * mm["bwd"] * mm["flop"]
+    # HBM traffic per launch from the committed rocprofv3 PMC passes of this command (profiles/), when they cover this workload
+    traffic = {"fwd": None, "bwd": None, "source": None}
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_edge_kernels.json")))
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_edge_kernels.json")
+        pmc = json.load(open(pmc_path))
         if pmc["workload"]["edges_per_launch"] == E and pmc["workload"]["feat"] == F:
-            traffic = {"fwd": pmc["edge_fwd_mfma_kernel"]["traffic_bytes"], "bwd": pmc["edge_bwd_mfma_kernel"]["traffic_bytes"]}
+            traffic = {"fwd": pmc["edge_fwd_kernel"]["traffic_bytes"], "bwd": pmc["edge_bwd_kernel"]["traffic_bytes"],
+                       "source": "profiles/r02_pmc_edge_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE)"}
     except Exception:
         pass
     dom_is_bwd = bwd_ms >= fwd_ms and not args.forward_only
@@ -270,24 +303,31 @@ def roofline(pkg, S, args, dev):
     roof = {"bound": "hbm", "kernel": "edge_bwd_kernel" if dom_is_bwd else "edge_fwd_kernel",
             "achieved": round(a_b if dom_is_bwd else a_f, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round((a_b if dom_is_bwd else a_f) / HBM_PEAK_GBS, 5), "traffic": traffic["bwd" if dom_is_bwd else "fwd"],
+            "traffic_source": traffic["source"],
             "edges_per_launch": E, "algorithmic_bytes_per_launch": bytes_bwd if dom_is_bwd else bytes_fwd,
-            "launch_ms": round(bwd_ms if dom_is_bwd else fwd_ms, 5)}
+            "launch_ms": round(bwd_ms if dom_is_bwd else fwd_ms, 5),
+            "backward_mode": "recompute (no per-edge activations kept by the forward)"}
+    tf = lambda fl, t_ms: fl / (t_ms * 1e-3) / 1e12 / FP32_PEAK_TF
     extra = {"edge_fwd_ms": round(fwd_ms, 5), "edge_bwd_ms": round(bwd_ms, 5),
+             "edge_fwd_form": "training form = inference form (the timed step runs this kernel)",
              "edge_fwd_GBs": round(a_f, 2), "edge_bwd_GBs": round(a_b, 2),
-             "edge_fwd_fp32_frac": round(flops_fwd / (fwd_ms * 1e-3) / 1e12 / FP32_PEAK_TF, 5),
-             "edge_bwd_fp32_frac": round(flops_bwd / (bwd_ms * 1e-3) / 1e12 / FP32_PEAK_TF, 5),
+             "edge_fwd_fp32_frac": round(tf(flops_fwd, fwd_ms), 5), "edge_bwd_fp32_frac": round(tf(flops_bwd, bwd_ms), 5),
+             "edge_fwd_executed_mfma_frac": round(tf(exe_fwd, fwd_ms), 5), "edge_bwd_executed_mfma_frac": round(tf(exe_bwd, bwd_ms), 5),
+             "mfma_note": "fp32 MFMA shares the SIMD's fp32 lanes with the VALU on gfx950 (tools/dev/coexec.hip: no co-execution), so "
+                          "executed_mfma_frac is the share of the kernel's SIMD time spent in matrix instructions",
              "edge_fwd_hbm_frac": round(a_f / HBM_PEAK_GBS, 5), "edge_bwd_hbm_frac": round(a_b / HBM_PEAK_GBS, 5),
              "edge_fwd_traffic": traffic["fwd"], "edge_bwd_traffic": traffic["bwd"]}
     return roof, extra
 
 
 def cpu_baseline(args):
-    """Oracle (CPU restatement of the reference path, PyTorch CPU fp32), same workload, bounded time."""
+    """Oracle (CPU restatement of the reference path, PyTorch CPU fp32), same workload, bounded time.  The neighbour search of
+    the timing leg is cdist + topk (what BASELINE.md section 2 timed for the reference's torch_cluster call); the bit-exact
+    numpy restatement oracle.knn_graph is the parity checker, not a fair CPU implementation."""
     from oracle import egnn_oracle as orc
     import se3_equi_graph_registration_amd as pkg
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    host_cores = os.cpu_count() or 1
     egnn = pkg.EGNN(args.feat, args.feat, args.feat, in_edge_nf=1, device="cpu", n_layers=args.layers, num_heads=args.heads)
     model = pkg.CrossAttentionPoseRegression(egnn, num_nodes=args.n, hidden_nf=args.feat, device="cpu")
     we = {k: v.detach().clone().requires_grad_(True) for k, v in egnn.state_dict().items()}
@@ -297,8 +337,8 @@ def cpu_baseline(args):
 
     def step():
         t0 = time.perf_counter()
-        es = torch.stack([orc.knn_graph(b["src"][i], args.k) for i in range(args.batch)])
-        et = torch.stack([orc.knn_graph(b["tgt"][i], args.k) for i in range(args.batch)])
+        es = torch.stack([orc.knn_graph_cdist(b["src"][i], args.k) for i in range(args.batch)])
+        et = torch.stack([orc.knn_graph_cdist(b["tgt"][i], args.k) for i in range(args.batch)])
         t_knn = time.perf_counter() - t0
         ea = torch.ones(args.batch, es.shape[2], 1)
         res, _ = orc.pair_forward_train(we, wc, b["feat_src"], b["src"], es, ea, b["feat_tgt"], b["tgt"], et, ea,
@@ -314,7 +354,7 @@ def cpu_baseline(args):
     # (256 on the GPU box) is ~100x SLOWER than 8-32 threads; time one step at each candidate.
     best_t, best_dt = 1, None
     for cand in (8, 16, 32, 64):
-        if cand > cores:
+        if cand > host_cores:
             break
         torch.set_num_threads(cand)
         step()                               # warm-up at this setting
@@ -322,7 +362,6 @@ def cpu_baseline(args):
         if best_dt is None or dt < best_dt:
             best_t, best_dt = cand, dt
     torch.set_num_threads(best_t)
-    cores = best_t
     n_done, t_start, t_knn = 0, time.perf_counter(), 0.0
     while True:
         t_knn += step()
@@ -330,12 +369,13 @@ def cpu_baseline(args):
         el = time.perf_counter() - t_start
         if el >= args.cpu_seconds or n_done >= 200:
             break
-    return {"value": round(args.batch * n_done / el, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
+    return {"value": round(args.batch * n_done / el, 4), "unit": "pairs/s", "cores": best_t, "kind": "port",
+            "threads": best_t, "host_cores": host_cores,
+            "knn_seconds": round(t_knn, 3), "model_seconds": round(el - t_knn, 3),
             "sample": f"{n_done} steps of the same workload (B={args.batch}, N={args.n}, k={args.k}, L={args.layers}, "
-                      f"{'forward' if args.forward_only else 'forward+backward'}; numpy kNN restatement took "
-                      f"{100 * t_knn / el:.0f}% of the time; no optimizer step) in {el:.1f}s; torch CPU threads={cores} "
-                      f"(fastest of 8/16/32/64; host has {os.cpu_count()} cores)",
-            "threads": torch.get_num_threads()}
+                      f"{'forward' if args.forward_only else 'forward+backward'}, no optimizer step) in {el:.1f}s: kNN (cdist+topk) "
+                      f"{t_knn:.2f}s, model {el - t_knn:.2f}s; torch CPU threads={best_t} (fastest of 8/16/32/64 on a host with "
+                      f"{host_cores} cores: `cores` is the thread count used)"}
 
 
 def main():
@@ -373,33 +413,77 @@ def main():
     for _ in range(args.warmup):
         run()
     S["restore"]()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        run()
-        if args.reset_every > 0 and (i + 1) % args.reset_every == 0 and not args.forward_only:
-            S["restore"]()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+
+    def timed_block():
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; MAX over ranks (seconds)."""
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            run()
+            if args.reset_every > 0 and (i + 1) % args.reset_every == 0 and not args.forward_only:
+                S["restore"]()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    # A block of `steps` steps can be a few milliseconds of GPU time (one pair per step): one hiccup would move the headline.
+    # The block is therefore repeated until --min-seconds have been measured (count fixed from the first block's rank-max
+    # time, so every rank runs the same number) and the MEDIAN block is reported; `steps` stays as given.
+    blocks = [timed_block()]
+    n_blocks = 1 if args.min_seconds <= 0 else max(1, min(400, int(args.min_seconds / max(blocks[0], 1e-6)) + 1))
+    if n_blocks > 1 and n_blocks % 2 == 0:
+        n_blocks += 1
+    while len(blocks) < n_blocks:
+        S["restore"]()
+        blocks.append(timed_block())
+    el = sorted(blocks)[len(blocks) // 2]
     finite = bool(torch.isfinite(S["egnn"].flat_params).all().item())
+
+    # evidence for the N>1 path: which devices the process group really spans, and what the gradient exchange costs alone
+    ranks_seen, allreduce_us = None, None
+    if dist_on:
+        props = torch.cuda.get_device_properties(dev)
+        me = {"rank": rank, "local_rank": local_rank, "device": props.name, "uuid": str(getattr(props, "uuid", "")),
+              "pci_bus_id": getattr(props, "pci_bus_id", None), "host": os.uname().nodename}
+        gathered = [None] * (world if world > 1 else 1)
+        if world > 1:
+            dist.all_gather_object(gathered, me)
+        else:
+            gathered = [me]
+        ranks_seen = gathered
+        bucket = S["dp"].buckets()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            S["dp"].sync(force=True)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(20):
+            S["dp"].sync(force=True)
+        ev1.record()
+        torch.cuda.synchronize()
+        allreduce_us = round(ev0.elapsed_time(ev1) * 1e3 / 20, 2)
+        S["restore"]()
 
     if rank == 0:
         roof, extra = roofline(pkg, S, args, dev)
         out = {
-            "metric": "registration pairs/sec (2048-pt, k=20, 4 EGNN layers)",
+            "metric": f"registration pairs/sec ({args.n}-pt, k={args.k}, {args.layers} EGNN layers)",
             "value": round(world * args.batch * args.steps / el, 3), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * el / args.steps, 5), "higher_is_better": True, "scaling": "weak",
+            "timing": {"blocks": len(blocks), "statistic": "median block of `steps` steps (rank-max per block)",
+                       "ms_per_step_min": round(1e3 * min(blocks) / args.steps, 5), "ms_per_step_max": round(1e3 * max(blocks) / args.steps, 5),
+                       "ms_per_step_first_block": round(1e3 * blocks[0] / args.steps, 5), "seconds_measured": round(sum(blocks), 3)},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{'inference' if args.forward_only else 'training'} step: {args.batch} pair(s)/GPU x "
                                    f"{args.n} pts, k={args.k}, {args.layers} EGNN layers, F={args.feat}, heads={args.heads}; "
@@ -410,6 +494,12 @@ def main():
                        "reset_every": args.reset_every},
             "roofline": roof, "kernels": extra,
         }
+        if dist_on:
+            nb = sum(int(b.numel()) * 4 for b in S["dp"].buckets())
+            out["multi_gpu"] = {"world_size": world, "backend": dist.get_backend(), "ranks_seen": ranks_seen,
+                                "distinct_devices": len({(r["host"], r["uuid"] or r["pci_bus_id"] or r["local_rank"]) for r in ranks_seen}),
+                                "allreduce_bytes": nb, "allreduce_us_isolated": allreduce_us,
+                                "exchange": "one mean all-reduce of the joint flat gradient bucket per step"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

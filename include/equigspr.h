@@ -27,7 +27,7 @@ extern "C" {
 
 #define EQUIGSPR_EINVAL   (-1)  /* bad shape / size / null pointer                         */
 #define EQUIGSPR_ENOTSUP  (-2)  /* configuration outside the compiled kernel set             */
-#define EQUIGSPR_ABI_VERSION 5
+#define EQUIGSPR_ABI_VERSION 6
 
 /* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
  * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
@@ -310,6 +310,9 @@ int equigspr_correspondence_labels(const float* src_pts, const float* tgt_pts, c
  * measured with HIP events on `stream` over `iters` back-to-back launches (these two calls
  * synchronise the host).  fwd: layer 0's edge kernel after embedding_in.  bwd: the last
  * layer's edge backward kernel; `saved` from a training-mode equigspr_egnn_forward. */
+/* Developer / test knob: chunk size (edges per wave pass) of the hidden_nf = 32 edge kernels: 16, 32, 48, 64, or 0 = automatic
+ * (by problem size).  Process-wide; results are bit-identical run to run for any fixed value. */
+int equigspr_set_edge_chunk(int32_t chunk);
 int equigspr_time_edge_fwd(const equigspr_egnn_config* cfg, const float* params, const equigspr_graph* g,
                            const float* h_in, const float* x_in, const float* edge_attr, float* work,
                            int32_t iters, float* ms_out_host, void* stream);

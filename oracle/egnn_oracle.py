@@ -69,6 +69,20 @@ def knn_graph(x: Tensor, k: int, loop: bool = True) -> Tensor:
     return torch.stack([row, col], dim=0)
 
 
+def knn_graph_cdist(x: Tensor, k: int, loop: bool = True) -> Tensor:
+    """Same neighbour lists through ``cdist`` + ``topk`` (what BASELINE.md timed in place of the
+    absent torch_cluster wheel).  Used by bench.py's ``cpu_baseline`` leg: it is the fair CPU cost of the neighbour search,
+    whereas ``knn_graph`` above spells out the fp32 arithmetic contract for bit-exact index parity.  The two agree except on
+    the order of exactly tied distances (tests/test_oracle_golden.py checks the neighbour SETS)."""
+    xf = x.detach().cpu().float()
+    n = xf.shape[0]
+    d = torch.cdist(xf, xf)
+    if not loop:
+        d.fill_diagonal_(float("inf"))
+    idx = torch.topk(d, k, dim=1, largest=False, sorted=True).indices
+    return torch.stack([idx.reshape(-1), torch.arange(n).repeat_interleave(k)], dim=0)
+
+
 # --------------------------------------------------------------------------------------
 # A2  edge helpers (train :372-403)
 # --------------------------------------------------------------------------------------

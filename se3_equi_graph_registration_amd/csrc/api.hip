@@ -1,6 +1,9 @@
 // C-ABI glue that is not a kernel: error text, ABI version, parameter-block layout queries.
 #include "common.h"
 
+#include <atomic>
+#include <stdlib.h>
+
 namespace eq {
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
@@ -9,7 +12,30 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// Chunk size of the 16-edge kernels (egnn_mfma16.h): 64 edges amortise the one-lane-per-edge front over four sub-tiles; small
+// problems take smaller chunks so that every SIMD gets work.  equigspr_set_edge_chunk / EQUIGSPR_EDGE_CHUNK override it.
+static std::atomic<int> g_edge_chunk{-1};
+int edge_chunk_for(int n_edges, int waves_resident) {
+    int forced = g_edge_chunk.load(std::memory_order_relaxed);
+    if (forced < 0) {
+        const char* v = getenv("EQUIGSPR_EDGE_CHUNK");
+        forced = v ? atoi(v) : 0;
+        g_edge_chunk.store(forced, std::memory_order_relaxed);
+    }
+    if (forced == 16 || forced == 32 || forced == 48 || forced == 64) return forced;
+    if ((long long)n_edges >= 64ll * 2 * waves_resident) return 64;
+    if ((long long)n_edges >= 32ll * 2 * waves_resident) return 32;
+    return 16;
+}
 }  // namespace eq
+
+extern "C" int equigspr_set_edge_chunk(int32_t chunk) {
+    EQ_CHECK_ARG(chunk == 0 || chunk == 16 || chunk == 32 || chunk == 48 || chunk == 64, EQUIGSPR_EINVAL,
+                 "set_edge_chunk: 0 (automatic), 16, 32, 48 or 64");
+    eq::g_edge_chunk.store(chunk, std::memory_order_relaxed);
+    return 0;
+}
 
 extern "C" int equigspr_abi_version(void) { return EQUIGSPR_ABI_VERSION; }
 extern "C" const char* equigspr_last_error(void) { return eq::g_err; }

@@ -28,6 +28,7 @@ static __device__ unsigned long long* eq_trace_ptr = nullptr;      // one copy p
 namespace eq {
 
 void set_error(const char* fmt, ...);   // api.hip
+int edge_chunk_for(int n_edges, int waves_resident);   // api.hip: chunk size of the 16-edge kernels
 
 #define EQ_CHECK_ARG(cond, code, ...)            \
     do {                                         \

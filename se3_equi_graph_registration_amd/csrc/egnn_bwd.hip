@@ -1281,14 +1281,6 @@ __global__ __launch_bounds__(512) void edge_bwd16_kernel(const float* __restrict
     EQ_STAMP(15);
 }
 
-static inline int edge_chunk_for16(int E, int waves_resident) {      // see egnn_fwd.hip edge_chunk_for
-    static const int forced = [] { const char* v = getenv("EQUIGSPR_EDGE_CHUNK"); return v ? atoi(v) : 0; }();
-    if (forced == 16 || forced == 32 || forced == 48 || forced == 64) return forced;
-    if ((long long)E >= 64ll * 2 * waves_resident) return 64;
-    if ((long long)E >= 32ll * 2 * waves_resident) return 32;
-    return 16;
-}
-
 template <int F, int H, int A>
 static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
                            const float* dagg, const float* Gx, float* dt1, float* gxr, float* gxc, float* slab,
@@ -1296,7 +1288,7 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
     const int E = g->n_edges;
     static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1 or 4 heads) or 33 (1 head)");
     if constexpr (F == 32) {               // the 16-edge formulation: one 8-wave workgroup per CU, persistent
-        const int chunk = edge_chunk_for16(E, 256 * kBwd16Waves);
+        const int chunk = edge_chunk_for(E, 256 * kBwd16Waves);
         int blocks = ceil_div(ceil_div(E, chunk), kBwd16Waves);
         blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
         hipLaunchKernelGGL((edge_bwd16_kernel<H, A>), dim3(blocks), dim3(512), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,

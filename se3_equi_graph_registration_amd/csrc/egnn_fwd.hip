@@ -203,16 +203,6 @@ __global__ __launch_bounds__(64 * kFwd16Waves, EQ_FWD16_OCC) void edge_fwd16_ker
     }
 }
 
-// chunk size of the 16-edge kernels: 64 edges amortise the per-edge front over four sub-tiles; small problems take
-// smaller chunks so that every SIMD gets work (EQUIGSPR_EDGE_CHUNK overrides, developer knob)
-static inline int edge_chunk_for(int E, int waves_resident) {
-    static const int forced = [] { const char* v = getenv("EQUIGSPR_EDGE_CHUNK"); return v ? atoi(v) : 0; }();
-    if (forced == 16 || forced == 32 || forced == 48 || forced == 64) return forced;
-    if ((long long)E >= 64ll * 2 * waves_resident) return 64;
-    if ((long long)E >= 32ll * 2 * waves_resident) return 32;
-    return 16;
-}
-
 template <int F, int H, int A>
 static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
                             float* m, float* trans, hipStream_t s) {

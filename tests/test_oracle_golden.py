@@ -143,6 +143,18 @@ def test_knn_grid_known_answer():
     assert q not in e2[0, q * 4:(q + 1) * 4].tolist()
 
 
+def test_knn_cdist_form_finds_the_same_neighbour_sets():
+    """bench.py times the CPU baseline with the cdist + topk neighbour search; it must be the same graph as the bit-exact
+    restatement (identical sets per centre on generic points; rows may differ only in the order of tied distances)."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(500, 3, generator=g) * 3
+    for loop in (True, False):
+        a, b = orc.knn_graph(x, 12, loop=loop), orc.knn_graph_cdist(x, 12, loop=loop)
+        assert torch.equal(a[1], b[1])
+        assert torch.equal(torch.sort(a[0].view(500, 12), dim=1).values, torch.sort(b[0].view(500, 12), dim=1).values)
+        assert (a[0] == b[0]).float().mean() > 0.999
+
+
 def test_knn_duplicates_and_ties():
     x = torch.tensor([[0., 0, 0], [1, 0, 0], [0, 0, 0], [2, 0, 0], [0, 0, 0]])
     e = orc.knn_graph(x, 3, loop=True)
