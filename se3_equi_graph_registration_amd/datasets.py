@@ -438,7 +438,8 @@ class DeviceBatches:
         def produce():
             try:
                 for batch in self.loader:
-                    if not put(tuple(t.pin_memory() if isinstance(t, torch.Tensor) else t for t in batch)):
+                    # a collate function may hand back None (or None members) for unreadable pairs: passed through, the loops skip them
+                    if not put(None if batch is None else tuple(t.pin_memory() if isinstance(t, torch.Tensor) else t for t in batch)):
                         return
             except BaseException as e:  # surfaced in the consumer
                 put(e)
@@ -450,7 +451,7 @@ class DeviceBatches:
 
         def upload(batch):
             with torch.cuda.stream(copy_stream):
-                dev = tuple(t.to(self.device, non_blocking=True) if isinstance(t, torch.Tensor) else t for t in batch)
+                dev = None if batch is None else tuple(t.to(self.device, non_blocking=True) if isinstance(t, torch.Tensor) else t for t in batch)
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
             return dev, ev, batch   # keep the pinned source alive until the copy has been waited on
@@ -469,7 +470,7 @@ class DeviceBatches:
                 nxt = take()
                 pending = upload(nxt) if nxt is not stop else None
                 torch.cuda.current_stream(self.device).wait_event(ev)
-                for t in dev:
+                for t in (dev or ()):
                     if isinstance(t, torch.Tensor):
                         t.record_stream(torch.cuda.current_stream(self.device))
                 yield dev

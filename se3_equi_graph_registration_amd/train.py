@@ -11,12 +11,14 @@
 * ``make_optimizer``  -- flattens the model into the joint parameter/gradient bucket (``dp.DataParallelStep``) and returns
   the one-launch Adam over it (reference: ``torch.optim.Adam(model.parameters(), lr)``, :1412).
 
-No logging back ends (tensorboard / wandb writers are accepted and ignored), no schedulers: those stay the caller's.
+No logging back ends (tensorboard / wandb writers are accepted and ignored); ``StepOptimizer`` is a ``torch.optim.Optimizer``,
+so the reference's ``StepLR`` (or any scheduler) drives it unchanged.
 Everything between the loader and ``loss.item()`` runs in the HIP kernels; batches are staged to HBM one step ahead.
 """
 import os
 
 import torch
+import torch.distributed as dist
 
 from . import ops
 from .datasets import DeviceBatches
@@ -26,8 +28,11 @@ from .metrics import evaluate_batch
 from .pose import registration_loss
 
 
-class StepOptimizer:
-    """``FlatAdam`` over the model's joint bucket with the ``torch.optim`` calls the reference loop makes."""
+class StepOptimizer(torch.optim.Optimizer):
+    """``FlatAdam`` over the model's joint bucket behind the ``torch.optim.Optimizer`` interface the reference loop and its
+    scheduler use (``torch.optim.Adam(model.parameters(), lr)`` :1412, ``StepLR(optimizer, 200, 0.5)`` :1413): ONE persistent
+    ``param_groups`` entry whose ``lr`` / ``betas`` / ``eps`` are read at every ``step()``, so schedulers and manual
+    ``for g in optimizer.param_groups: g['lr'] = ...`` edits take effect and end up in ``state_dict()``."""
 
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, process_group=None):
         self.model = model
@@ -36,24 +41,41 @@ class StepOptimizer:
         self.params = list(model.parameters())                  # torch.optim.Adam(model.parameters()) order
         self.adam = ops.FlatAdam([(model.egnn.flat_params, model.egnn.flat_grads), (self.dp.head.flat, self.dp.head.grad)],
                                  lr=lr, betas=betas, eps=eps)
+        super().__init__(self.params, dict(lr=float(lr), betas=(float(betas[0]), float(betas[1])), eps=float(eps), weight_decay=0,
+                                           amsgrad=False, maximize=False))
         self.dp.zero_grad()
 
     def zero_grad(self, set_to_none: bool = False):
         pass        # step() clears every gradient as it consumes it (one launch); the buckets start zeroed
 
-    def step(self):
+    def _push_hyperparameters(self):
+        g = self.param_groups[0]
+        if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+            raise ValueError("StepOptimizer: weight_decay / amsgrad / maximize are not supported (the reference does not use them)")
+        self.adam.lr, self.adam.betas, self.adam.eps = float(g["lr"]), (float(g["betas"][0]), float(g["betas"][1])), float(g["eps"])
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("StepOptimizer.step takes no closure")
+        self._push_hyperparameters()
         self.dp.sync()                                          # mean all-reduce of the joint bucket when world_size > 1
         self.adam.step(zero_grad=True)
 
     def state_dict(self):
-        return self.adam.state_dict(self.params)
+        self._push_hyperparameters()
+        sd = self.adam.state_dict(self.params)
+        extra = {k: v for k, v in self.param_groups[0].items() if k not in sd["param_groups"][0] and k != "params"}
+        sd["param_groups"][0].update(extra)                     # e.g. the scheduler's initial_lr
+        return sd
 
     def load_state_dict(self, sd):
         self.adam.load_state_dict(sd, self.params)
-
-    @property
-    def param_groups(self):
-        return [{"lr": self.adam.lr, "betas": self.adam.betas, "eps": self.adam.eps, "params": self.params}]
+        g, src = self.param_groups[0], sd["param_groups"][0]
+        for key in ("lr", "betas", "eps", "initial_lr"):
+            if key in src:
+                g[key] = tuple(src[key]) if key == "betas" else src[key]
+        self._push_hyperparameters()
 
 
 def make_optimizer(model, lr=1e-4, **kw) -> StepOptimizer:
@@ -80,35 +102,62 @@ def _pointnet_features(graph, xyz_0, xyz_1):
     return feats[:B * N].view(B, N, -1), feats[B * N:].view(B, N, -1)
 
 
-def _forward(model, batch, k, use_pointnet=False):
+def _forward(model, batch, k, use_pointnet=False, loss_mode="3dmatch"):
     corr, labels, xyz_0, xyz_1, feat_0, feat_1, gt_pose = batch
     graph = build_pair_graph(xyz_0, xyz_1, k, loop=True)        # knn_graph(xyz[i], k=16, loop=True) per cloud (:1005-1006)
     if use_pointnet:
         feat_0, feat_1 = _pointnet_features(graph, xyz_0, xyz_1)
     out = model(feat_0, xyz_0, graph, None, feat_1, xyz_1, graph, None, corr, labels, gt_pose)
     loss, rot, trans = registration_loss(out[0], out[1], out[2], gt_pose)     # corr.mean() + rot.mean() + trans.mean() (:1120)
+    if loss_mode == "kitti":        # src/kitti_train_egnn_with_batch.py:1089: loss = corr_loss.mean() + equi_loss (pose losses only logged)
+        loss = out[2].mean() + out[3].mean()
+    elif loss_mode != "3dmatch":
+        raise ValueError("loss_mode: '3dmatch' or 'kitti'")
     return out, loss, rot, trans
 
 
-def train_one_epoch(model, dataloader, optimizer, device, epoch, writer=None, use_pointnet=False, log_interval=10, beta=1, k=16):
-    """One pass over ``dataloader`` (7-tuples of the dataset classes); returns the average loss.  Batches with a NaN loss or
-    a non-finite gradient -- the reference's arccos pose loss produces both at a perfect fit and for pairs without
-    inliers -- are skipped, not stepped."""
+def _step_is_finite(loss, optimizer, model):
+    """1-element device flag: loss and every local gradient finite -- MIN-reduced over the optimizer's process group, so all
+    ranks of a data-parallel job take the same branch (a rank that skipped alone would leave the others in the all-reduce)."""
+    grads = optimizer.dp.buckets() if hasattr(optimizer, "dp") else [p.grad for p in model.parameters() if p.grad is not None]
+    ok = torch.isfinite(loss.detach()).all()
+    for g in grads:
+        ok = ok & torch.isfinite(g).all()
+    flag = ok.to(torch.float32).reshape(1)
+    group = optimizer.dp.group if hasattr(optimizer, "dp") else None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item() > 0.5)
+
+
+def train_one_epoch(model, dataloader, optimizer, device, epoch, writer=None, use_pointnet=False, log_interval=10, beta=1, k=16,
+                    skip_nonfinite=False, loss_mode="3dmatch"):
+    """One pass over ``dataloader`` (7-tuples of the dataset classes); returns the average loss.
+
+    The reference's arccos pose loss is NaN / has a non-finite gradient at a perfect fit and for pairs without inliers.  The
+    reference runs under ``set_detect_anomaly(True)`` (:1124) and stops there: so does this loop by default (``RuntimeError``
+    on every rank of a data-parallel job, the decision is collective).  ``skip_nonfinite=True`` instead drops such a step on
+    all ranks together and keeps going.  Batches containing ``None`` are skipped as in the reference (:969).
+    ``loss_mode``: ``"3dmatch"`` = ``corr + rot + trans`` (train :1120); ``"kitti"`` = ``corr + equi``
+    (``src/kitti_train_egnn_with_batch.py:1089``)."""
     model.train()
     total, n = 0.0, 0
     for batch_idx, batch in enumerate(_device_batches(dataloader, device)):
+        if batch is None or any(item is None for item in batch):
+            continue
         optimizer.zero_grad()
-        _, loss, _, _ = _forward(model, batch, k, use_pointnet)
+        _, loss, _, _ = _forward(model, batch, k, use_pointnet, loss_mode)
         loss.backward()
-        value = loss.item()
-        grads = optimizer.dp.buckets() if hasattr(optimizer, "dp") else [p.grad for p in model.parameters() if p.grad is not None]
-        if value != value or not all(bool(torch.isfinite(g).all()) for g in grads):
-            # the reference runs under set_detect_anomaly(True) (:1124) and would stop here; skipping keeps the weights finite
+        if not _step_is_finite(loss, optimizer, model):
+            if not skip_nonfinite:
+                raise RuntimeError(f"non-finite loss or gradient at epoch {epoch + 1}, batch {batch_idx + 1} (the reference stops "
+                                   "here under set_detect_anomaly; pass skip_nonfinite=True to drop such steps)")
             if hasattr(optimizer, "dp"):
                 optimizer.dp.zero_grad()
             else:
                 optimizer.zero_grad()
             continue
+        value = loss.item()
         optimizer.step()
         total, n = total + value, n + 1
         if log_interval and batch_idx % log_interval == 0:
@@ -128,6 +177,8 @@ def validate(model, dataloader, device, epoch, writer=None, use_pointnet=False, 
     sums, n = [0.0, 0.0, 0.0, 0.0], 0
     try:
         for batch in _device_batches(dataloader, device):
+            if batch is None or any(item is None for item in batch):
+                continue
             out, loss, rot, trans = _forward(model, batch, k, use_pointnet)
             vals = [loss.item(), rot.mean().item(), trans.mean().item(), out[2].mean().item()]
             if vals[0] != vals[0]:
@@ -156,12 +207,14 @@ def save_checkpoint(epoch, pointnet, egnn, cross_attention, optimizer, save_dir=
 
 
 def load_checkpoint(checkpoint_path, pointnet=None, egnn=None, cross_attention=None, optimizer=None, use_pointnet=False,
-                    device="cuda:0"):
+                    device="cuda:0", trust_pickle=False):
     """Restores what is passed in and returns ``(checkpoint, epoch)`` (:1350-1396).  ``cross_attention`` contains the EGNN:
-    loading both, as the reference does, writes the EGNN weights twice with the same values."""
+    loading both, as the reference does, writes the EGNN weights twice with the same values.  The payload (an int epoch,
+    tensor state_dicts, an Adam state of tensors and floats) loads with ``weights_only=True``; ``trust_pickle=True`` falls
+    back to full unpickling for a legacy file from a source you trust."""
     if not os.path.exists(checkpoint_path):
         raise FileNotFoundError(f"Checkpoint file {checkpoint_path} not found.")
-    ckpt = torch.load(checkpoint_path, map_location=device, weights_only=False)
+    ckpt = torch.load(checkpoint_path, map_location=device, weights_only=not trust_pickle)
     if use_pointnet and pointnet is not None and "pointnet_state_dict" in ckpt:
         pointnet.load_state_dict(ckpt["pointnet_state_dict"])
     if egnn is not None and "egnn_state_dict" in ckpt:

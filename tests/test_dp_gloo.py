@@ -128,3 +128,50 @@ def test_flat_bucket_views_survive_zero_grad():
     assert all(p.grad is not None for p in m.parameters()) and float(b.grad.abs().sum()) == 0
     m(torch.ones(1, 3)).sum().backward()
     assert m.weight.grad.data_ptr() == b.grad.data_ptr() and float(b.grad.abs().sum()) > 0
+
+
+# ---- the training loop's skip / stop decision must be collective (a rank that skipped a NaN batch alone left
+# the others waiting in the all-reduce)
+class _FakeOpt:
+    def __init__(self, dp):
+        self.dp = dp
+
+
+def _nan_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from se3_equi_graph_registration_amd.train import _step_is_finite
+    torch.manual_seed(7)
+    model = Pair()
+    dp = DataParallelStep(model, model.egnn)
+    opt = _FakeOpt(dp)
+    out = []
+    for poison in (None, "grad", "loss"):
+        dp.zero_grad()
+        loss = model(torch.ones(2, 4))
+        loss.backward()
+        if rank == 1 and poison == "grad":
+            model.egnn.flat_grads[0] = float("nan")
+        if rank == 1 and poison == "loss":
+            loss = loss * float("inf")
+        ok = _step_is_finite(loss, opt, model)
+        if ok:
+            dp.sync()                      # would dead-lock if the ranks disagreed
+        out.append(ok)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_nonfinite_step_decision_is_collective():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nan_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1] == [True, False, False]

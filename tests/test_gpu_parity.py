@@ -6,9 +6,13 @@ C-ABI (ctypes) from the reference-shaped Python interface, against
 Tolerances (north_star: R/t within 1e-4, logits within 1e-5):
   * indices (kNN, inverse index, top-k sets): bit-exact;
   * R, t: |hip - ref64| <= 1e-4 absolute;
-  * features / logits: the reference's own fp32 run differs from its fp64 run by up to
-    4.7e-5 on these inputs (gen_golden.py prints the gaps), so the check is anchored on fp64:
-    |hip - ref64| <= 4*|ref32 - ref64|_max + 1e-5 * max(1, |ref64|_max).
+  * logits: |hip - ref64| <= 1e-5 ABSOLUTE wherever the reference's own fp32 run is within 5e-6 of its fp64 run on that
+    fixture (the raw north_star bound); where the reference's fp32 arithmetic itself is further from fp64 than that (up to
+    4.7e-5 on these inputs, gen_golden.py prints the gaps) the check is anchored on fp64:
+    |hip - ref64| <= 4*|ref32 - ref64|_max + 1e-5 * max(1, |ref64|_max);
+  * features: the anchored form (|h| reaches 20-180, so 1e-5 absolute is below one fp32 ulp there).
+Every compared tensor's max|hip - ref64|, max|hip - ref32| and the reference's own gap go to gpurun_out/parity_report.json
+(conftest.ParityRecorder; committed per round under profiles/).
 """
 import os
 
@@ -36,6 +40,15 @@ def pk():
 def anchored_tol(ref32, ref64, k=4.0, rel=1e-5):
     gap = float(np.abs(ref32.astype(np.float64) - ref64).max())
     return k * gap + rel * max(1.0, float(np.abs(ref64).max()))
+
+
+NORTH_STAR_LOGITS, NORTH_STAR_RT = 1e-5, 1e-4
+
+
+def logits_tol(ref32, ref64):
+    """north_star's absolute 1e-5 where the reference's own fp32 run resolves it (gap <= 5e-6), else the anchored bound."""
+    gap = float(np.abs(ref32.astype(np.float64) - ref64).max())
+    return NORTH_STAR_LOGITS if gap <= 5e-6 else anchored_tol(ref32, ref64)
 
 
 def build_egnn(pk, fx, prefix="w."):
@@ -178,7 +191,7 @@ def test_build_csr_scratch_contract_and_inverse(pk):
 
 # ------------------------------------------------------------------------------------ EGNN forward
 @pytest.mark.parametrize("name", LAYER_FIX)
-def test_egnn_forward_golden(pk, golden_dir, name):
+def test_egnn_forward_golden(pk, golden_dir, name, parity):
     fx = np.load(os.path.join(golden_dir, name))
     m = build_egnn(pk, fx)
     h, x = torch.from_numpy(fx["h"]).cuda(), torch.from_numpy(fx["x"]).cuda()
@@ -188,7 +201,7 @@ def test_egnn_forward_golden(pk, golden_dir, name):
         ho, xo = m(h, x, [edges[0], edges[1]], ea)
     for got, key in ((ho, "h_out"), (xo, "x_out")):
         tol = anchored_tol(fx["f32." + key], fx["f64." + key])
-        err = float(np.abs(got.cpu().numpy().astype(np.float64) - fx["f64." + key]).max())
+        err, _ = parity(name, "egnn." + key, got, fx["f64." + key], fx["f32." + key])
         assert err <= tol, f"{name} {key}: err {err:.3e} > tol {tol:.3e}"
     # kNN edges rebuilt on the device give the same graph as the fixture's
     k = int(fx["k"])
@@ -242,7 +255,7 @@ def _pair_inputs(pk, fx):
 
 
 @pytest.mark.parametrize("name", PAIR_FIX)
-def test_pair_forward_golden(pk, golden_dir, name):
+def test_pair_forward_golden(pk, golden_dir, name, parity):
     fx = np.load(os.path.join(golden_dir, name))
     models = _pair_models(pk, fx)
     args = _pair_inputs(pk, fx)
@@ -252,27 +265,32 @@ def test_pair_forward_golden(pk, golden_dir, name):
     # features / coordinates after the EGNN
     for got, key in ((hs[0], "h_src"), (xs[0], "x_src"), (ht[0], "h_tgt"), (xt[0], "x_tgt")):
         tol = anchored_tol(fx["f32." + key], fx["f64." + key])
-        err = float(np.abs(got.cpu().numpy().astype(np.float64) - fx["f64." + key]).max())
+        err, _ = parity(name, "pair." + key, got, fx["f64." + key], fx["f32." + key])
         assert err <= tol, f"{name} {key}: err {err:.3e} > tol {tol:.3e}"
     # top-k: same index set; logits compared after aligning by index (SURVEY hard part 3)
     ref_idx, ref_log = fx["f64.train.top_idx"][0], fx["f64.train.logits"][0]
     got_idx, got_log = mt.last_top_idx[0].cpu().numpy(), mt.last_logits[0].cpu().numpy().astype(np.float64)
     assert set(ref_idx.tolist()) == set(got_idx.tolist())
     ref_map = dict(zip(ref_idx.tolist(), ref_log.tolist()))
-    d = max(abs(ref_map[i] - v) for i, v in zip(got_idx.tolist(), got_log.tolist()))
-    tol = anchored_tol(fx["f32.train.logits"], fx["f64.train.logits"])
+    ref32_map = dict(zip(fx["f32.train.top_idx"][0].tolist(), fx["f32.train.logits"][0].tolist())) if "f32.train.top_idx" in fx.files else None
+    aligned64 = np.array([ref_map[i] for i in got_idx.tolist()])
+    aligned32 = np.array([ref32_map[i] for i in got_idx.tolist()]) if ref32_map and set(ref32_map) == set(ref_map) else None
+    d, _ = parity(name, "train.logits", got_log, aligned64, aligned32)
+    tol = logits_tol(fx["f32.train.logits"], fx["f64.train.logits"])
     assert d <= tol, f"{name} logits: err {d:.3e} > tol {tol:.3e}"
     # pose: within 1e-4 of the reference (training head; degenerate regime gives R = I for both)
-    assert float(np.abs(R.cpu().numpy() - fx["f64.train.R"]).max()) <= 1e-4
-    assert float(np.abs(t.cpu().numpy() - fx["f64.train.t"]).max()) <= 1e-4
+    eR, _ = parity(name, "train.R", R, fx["f64.train.R"], fx["f32.train.R"] if "f32.train.R" in fx.files else None)
+    eT, _ = parity(name, "train.t", t, fx["f64.train.t"], fx["f32.train.t"] if "f32.train.t" in fx.files else None)
+    assert eR <= NORTH_STAR_RT and eT <= NORTH_STAR_RT
     np.testing.assert_allclose(closs.item(), float(fx["f64.train.corr_sim_loss"]), rtol=2e-4, atol=1e-5)
     np.testing.assert_allclose(equi.item(), float(fx["f64.train.equi_loss"]), rtol=2e-4, atol=1e-5)
     # evaluation head (well-conditioned: near-uniform weights over raw coordinates)
     with torch.no_grad():
         Re, te, scores, *_ = models["eval"](*args)
     assert scores is None
-    assert float(np.abs(Re.cpu().numpy() - fx["f64.eval.R"]).max()) <= 1e-4
-    assert float(np.abs(te.cpu().numpy() - fx["f64.eval.t"]).max()) <= 1e-4
+    eR, _ = parity(name, "eval.R", Re, fx["f64.eval.R"], fx["f32.eval.R"] if "f32.eval.R" in fx.files else None)
+    eT, _ = parity(name, "eval.t", te, fx["f64.eval.t"], fx["f32.eval.t"] if "f32.eval.t" in fx.files else None)
+    assert eR <= NORTH_STAR_RT and eT <= NORTH_STAR_RT
     assert abs(float(torch.det(Re[0])) - 1.0) < 1e-5
 
 
@@ -324,17 +342,19 @@ def test_kabsch_degenerate_and_masked(pk):
 
 
 # ------------------------------------------------------------------------------------ EGNN backward
-def _grad_check(got, ref32, ref64, name, k=6.0, rel=2e-5):
+def _grad_check(got, ref32, ref64, name, k=6.0, rel=2e-5, parity=None, fixture=None):
     ref64 = np.asarray(ref64, dtype=np.float64)
     scale = max(1e-6, float(np.abs(ref64).max()))
     gap = float(np.abs(np.asarray(ref32, dtype=np.float64) - ref64).max())
     tol = k * gap + rel * scale
     err = float(np.abs(got.detach().cpu().numpy().astype(np.float64) - ref64).max())
+    if parity is not None:
+        parity(fixture, name, got, ref64, ref32)
     assert err <= tol, f"{name}: err {err:.3e} > tol {tol:.3e} (scale {scale:.3e}, ref fp32 gap {gap:.3e})"
 
 
 @pytest.mark.parametrize("name", LAYER_FIX)
-def test_egnn_backward_golden(pk, golden_dir, name):
+def test_egnn_backward_golden(pk, golden_dir, name, parity):
     fx = np.load(os.path.join(golden_dir, name))
     m = build_egnn(pk, fx)
     h = torch.from_numpy(fx["h"]).cuda().requires_grad_(True)
@@ -345,11 +365,11 @@ def test_egnn_backward_golden(pk, golden_dir, name):
     loss = (ho * torch.from_numpy(fx["gh"]).cuda()).sum() + (xo * torch.from_numpy(fx["gx"]).cuda()).sum()
     m.zero_grad()
     loss.backward()
-    _grad_check(h.grad, fx["f32.grad_h"], fx["f64.grad_h"], f"{name} grad_h")
-    _grad_check(x.grad, fx["f32.grad_x"], fx["f64.grad_x"], f"{name} grad_x")
+    _grad_check(h.grad, fx["f32.grad_h"], fx["f64.grad_h"], "grad_h", parity=parity, fixture=name)
+    _grad_check(x.grad, fx["f32.grad_x"], fx["f64.grad_x"], "grad_x", parity=parity, fixture=name)
     for pn, p in m.named_parameters():
         assert p.grad is not None, pn
-        _grad_check(p.grad, fx["f32.grad." + pn], fx["f64.grad." + pn], f"{name} grad {pn}")
+        _grad_check(p.grad, fx["f32.grad." + pn], fx["f64.grad." + pn], "grad." + pn, parity=parity, fixture=name)
     # gradients are views of ONE flat bucket, in parameter-block order
     off = 0
     for pn, p in m.named_parameters():
@@ -367,7 +387,7 @@ def test_egnn_backward_golden(pk, golden_dir, name):
     assert torch.equal(m.flat_grads, g1)          # deterministic: bitwise identical to the first backward
 
 
-def test_train_step_gradients_golden(pk, golden_dir):
+def test_train_step_gradients_golden(pk, golden_dir, parity):
     """Full training loss (train :1120: corr+sim, geodesic rotation, translation direction) on the
     well-conditioned pair: loss and every parameter gradient against the reference autograd."""
     fx = np.load(os.path.join(golden_dir, "pair_n512_k12_l2_wellcond.npz"))
@@ -386,7 +406,8 @@ def test_train_step_gradients_golden(pk, golden_dir):
         key = "train.grad." + pn
         if "f64." + key in fx.files:
             assert p.grad is not None, pn
-            _grad_check(p.grad, fx["f32." + key], fx["f64." + key], pn, k=8.0, rel=5e-5)
+            _grad_check(p.grad, fx["f32." + key], fx["f64." + key], "train.grad." + pn, k=8.0, rel=5e-5, parity=parity,
+                        fixture="pair_n512_k12_l2_wellcond.npz")
             checked += 1
     assert checked > 20
 
