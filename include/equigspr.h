@@ -175,19 +175,23 @@ int equigspr_kabsch_backward(const float* src, const float* tgt, const float* w,
  * Outputs kept for backward: sim,rsim,cosv [B,N], pos int32 [B,N], wts [B,N], top_idx int64 [B,K],
  * logits [B,K], a1 [B,K,F], a2 [B,K,F/2]; out_scalars (16 floats): [0] = corr_loss+sim_loss, [1] = equi
  * loss, [2..9] = statistics reused by the backward.  work: equigspr_head_work_bytes bytes (8-byte aligned),
- * must be passed unchanged to the backward.  Limits: F <= 64, K <= min(256, N), N <= 4096.
+ * must be passed unchanged to the backward.  Limits: F <= 64, K <= N <= 8192 (K = N: every point is scored, as the KITTI script's
+ * top_k = 2048 of 2 048 points does, src/kitti_train_egnn_with_batch.py:661).
+ * flags: EQUIGSPR_HEAD_NO_SIM_LOSS = the KITTI script's forward, which has no similarity-MSE term and returns corr_loss alone
+ * (kitti :766); pass the same flags to the backward.
  * kabsch_R [B,9], kabsch_t [B,3], kabsch_aux [B*EQUIGSPR_KABSCH_AUX] (all three or all NULL): also performs
  * equigspr_kabsch_forward(xs, xt, wts, ...) -- identical results and aux record -- inside the launch that finishes the
  * loss scalars, instead of two more launches.
  * Backward: g_corr_sim / g_equi are DEVICE scalars (may be NULL = 0); gw = dL/d wts from
  * equigspr_kabsch_backward; writes ghs,ght; ADDS the equi-loss terms into gxs,gxt (which hold the
  * Kabsch coordinate gradients); ADDS into grad_mlp. */
+#define EQUIGSPR_HEAD_NO_SIM_LOSS 1
 int64_t equigspr_head_mlp_size(int32_t F);
 int64_t equigspr_head_work_bytes(int32_t B, int32_t N);
 int64_t equigspr_head_slab_count(int32_t B, int32_t K);   /* mlp_slab = slab_count * head_mlp_size floats */
 int equigspr_head_forward(const float* hs, const float* ht, const float* raw_hs, const float* raw_ht,
                           const float* xs, const float* xt, const float* labels, const float* gt_pose,
-                          const float* mlp, int32_t B, int32_t N, int32_t F, int32_t F_raw, int32_t K,
+                          const float* mlp, int32_t B, int32_t N, int32_t F, int32_t F_raw, int32_t K, int32_t flags,
                           float* sim, float* rsim, float* cosv, int32_t* pos, float* wts, int64_t* top_idx,
                           float* logits, float* a1_save, float* a2_save, void* work, float* out_scalars,
                           float* kabsch_R, float* kabsch_t, float* kabsch_aux, void* stream);
@@ -196,7 +200,7 @@ int equigspr_head_backward(const float* hs, const float* ht, const float* xs, co
                            const float* rsim, const float* cosv, const int32_t* pos, const float* wts,
                            const int64_t* top_idx, const float* logits, const float* a1_save,
                            const float* a2_save, const float* fin_scalars, const float* g_corr_sim,
-                           const float* g_equi, const float* gw, int32_t B, int32_t N, int32_t F, int32_t K,
+                           const float* g_equi, const float* gw, int32_t B, int32_t N, int32_t F, int32_t K, int32_t flags,
                            void* work, float* dinp, float* mlp_slab, float* grad_mlp, float* ghs, float* ght,
                            float* gxs, float* gxt, void* stream);
 

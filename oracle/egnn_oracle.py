@@ -273,8 +273,10 @@ def _run_egnn_pairs(we, h_src, x_src, edges_src, ea_src, h_tgt, x_tgt, edges_tgt
 
 def pair_forward_train(we: Dict[str, Tensor], wc: Dict[str, Tensor],
                        h_src, x_src, edges_src, ea_src, h_tgt, x_tgt, edges_tgt, ea_tgt,
-                       corr, labels, gt_pose, topk: int = 128):
-    """Training head.  Returns the reference 9-tuple plus a dict of extras (logits, top-k idx)."""
+                       corr, labels, gt_pose, topk: int = 128, kitti: bool = False):
+    """Training head.  Returns the reference 9-tuple plus a dict of extras (logits, top-k idx).
+    ``kitti=True``: the forward of src/kitti_train_egnn_with_batch.py:619-766 -- identical except ``top_k = 2048`` (:661, pass
+    ``topk=2048``) and no similarity-MSE term: it returns ``corr_loss`` alone (:766)."""
     raw_hs, raw_ht = h_src, h_tgt
     B, N, Fd = h_src.shape
     hs, xs, ht, xt = _run_egnn_pairs(we, h_src, x_src, edges_src, ea_src, h_tgt, x_tgt, edges_tgt, ea_tgt)
@@ -303,6 +305,8 @@ def pair_forward_train(we: Dict[str, Tensor], wc: Dict[str, Tensor],
     raw_n = (raw_sim - raw_sim.mean()) / (raw_sim.std() + 1e-6)                 # :778
     sim_loss = F.mse_loss(sim_n, raw_n)                                         # :781
     extras = dict(logits=logits, top_idx=top_idx, corr_loss=corr_loss, sim_loss=sim_loss)
+    if kitti:
+        return (R, t, corr_loss, equi, hs, xs, ht, xt, labels), extras                 # kitti :766
     return (R, t, corr_loss + sim_loss, equi, hs, xs, ht, xt, labels), extras
 
 

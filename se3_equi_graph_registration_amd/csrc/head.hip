@@ -22,7 +22,7 @@ namespace eq {
 
 typedef unsigned long long u64;
 constexpr int kHeadPartials = 8;     // sum s, sum s^2, sum r, sum r^2, rot, feat, (unused x2)
-constexpr int kMaxK = 256;
+constexpr int kMaxN = 8192;          // head_pair_kernel keeps a pair's keys in LDS: 12 bytes per node
 
 __device__ __forceinline__ unsigned orderable(float v) {
     const unsigned b = __float_as_uint(v);
@@ -284,10 +284,10 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
             __syncthreads();
         }
     }
-    if (tid < K) {
-        const int idx = (int)(unsigned)(keys[tid] & 0xffffffffu);
-        top_idx[(size_t)b * K + tid] = idx;
-        pos[(size_t)b * N + idx] = tid;
+    for (int t = tid; t < K; t += 256) {
+        const int idx = (int)(unsigned)(keys[t] & 0xffffffffu);
+        top_idx[(size_t)b * K + t] = idx;
+        pos[(size_t)b * N + idx] = t;
     }
 }
 
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(
 // out[6] = sum e, out[7] = sum e (s - mu_s), out[8], out[9] = rot / feat sums (written by K2)
 __device__ __forceinline__ void head_finalize_block(const double* __restrict__ partC, int nC,
                                                     const double* __restrict__ pair_part, int nblk, int B, int N, int K,
-                                                    float* __restrict__ out) {
+                                                    float* __restrict__ out, int flags) {
     __shared__ double red[4];
     const long long M = (long long)B * N;
     double a0 = 0, a1 = 0, a2 = 0, bce = 0;
@@ -415,7 +415,8 @@ __device__ __forceinline__ void head_finalize_block(const double* __restrict__ p
     for (int b = threadIdx.x; b < B * nblk; b += 256) bce += pair_part[b];
     a0 = block_sum_d(a0, red); a1 = block_sum_d(a1, red); a2 = block_sum_d(a2, red); bce = block_sum_d(bce, red);
     if (threadIdx.x == 0) {
-        out[0] = (float)(bce / ((double)B * K) + a0 / (double)M);
+        // EQUIGSPR_HEAD_NO_SIM_LOSS: the KITTI script's forward returns corr_loss alone (src/kitti_train_egnn_with_batch.py:766)
+        out[0] = (float)(bce / ((double)B * K) + ((flags & EQUIGSPR_HEAD_NO_SIM_LOSS) ? 0.0 : a0 / (double)M));
         out[1] = (float)(((double)out[8] + (double)out[9]) / (double)M);
         out[6] = (float)a1; out[7] = (float)a2;
     }
@@ -423,8 +424,8 @@ __device__ __forceinline__ void head_finalize_block(const double* __restrict__ p
 
 __global__ __launch_bounds__(256) void head_finalize_kernel(const double* __restrict__ partC, int nC,
                                                             const double* __restrict__ pair_part, int nblk, int B, int N, int K,
-                                                            float* __restrict__ out) {
-    head_finalize_block(partC, nC, pair_part, nblk, B, N, K, out);
+                                                            float* __restrict__ out, int flags) {
+    head_finalize_block(partC, nC, pair_part, nblk, B, N, K, out, flags);
 }
 
 // K4, the training head's tail in ONE launch, grid (nb + 1, B).  Columns 0..nb-1: the fp64 Kabsch moments of pair b over
@@ -436,9 +437,9 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
                                                         float* __restrict__ t, float* __restrict__ aux, float* __restrict__ pair_f,
                                                         const double* __restrict__ partC, int nC,
                                                         const double* __restrict__ pair_part, int nblk, int B, int K,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, int flags) {
     if ((int)blockIdx.x == nb) {
-        if (blockIdx.y == 0) head_finalize_block(partC, nC, pair_part, nblk, B, N, K, out);
+        if (blockIdx.y == 0) head_finalize_block(partC, nC, pair_part, nblk, B, N, K, out, flags);
         return;
     }
     const int b = blockIdx.y;
@@ -570,13 +571,27 @@ __global__ __launch_bounds__(256) void head_node_bwd_kernel(
     const float* __restrict__ pair_g, const float* __restrict__ fin, const float* __restrict__ g_cs_ptr,
     const float* __restrict__ g_equi_ptr, int B, int N, int F, int K, int in_dim, float* __restrict__ ghs,
     float* __restrict__ ght, float* __restrict__ gxs /* += */, float* __restrict__ gxt /* += */, int nbp,
-    const float* __restrict__ mlp_slab, int n_slabs, int msz, float* __restrict__ grad_mlp /* += */) {
+    const float* __restrict__ mlp_slab, int n_slabs, int msz, float* __restrict__ grad_mlp /* += */, int flags) {
     if ((int)blockIdx.x >= nbp) {        // block-uniform: the MLP weight-gradient slabs of KB1, summed in fixed order, ride in this launch
-        const int t = ((int)blockIdx.x - nbp) * 256 + (int)threadIdx.x;
-        if (blockIdx.y != 0 || t >= msz) return;
+        // 32 consecutive entries x 8 slab partitions per block (partition p sums slabs p, p + 8, ...; the 8 partials are then
+        // added in order): K = 2048 leaves thousands of slabs, a one-thread-per-entry loop over them is a serial latency chain
+        __shared__ float red[8][33];
+        const int lane = threadIdx.x & 31, part = threadIdx.x >> 5;
+        const int t = ((int)blockIdx.x - nbp) * 32 + lane;
+        if (blockIdx.y != 0) return;
         float a = 0.0f;
-        for (int q = 0; q < n_slabs; ++q) a += mlp_slab[(size_t)q * msz + t];
-        grad_mlp[t] += a;
+        if (t < msz) {
+#pragma unroll 4
+            for (int q = part; q < n_slabs; q += 8) a += mlp_slab[(size_t)q * msz + t];
+        }
+        red[part][lane] = a;
+        __syncthreads();
+        if (part == 0 && t < msz) {
+            float v = red[0][lane];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) v += red[q][lane];
+            grad_mlp[t] += v;
+        }
         return;
     }
     const int slot = threadIdx.x >> 5, f = threadIdx.x & 31;
@@ -601,7 +616,7 @@ __global__ __launch_bounds__(256) void head_node_bwd_kernel(
         const float zs = (s - mu_s) * inv_sd, zr = (rsim[i] - mu_r) / (sd_r + 1e-6f);
         const float e = zs - zr;
         const float k2 = (sd_s > 0.0f) ? sum_es * inv_sd * inv_sd / ((float)(M - 1) * sd_s) : 0.0f;
-        gs += (2.0f / (float)M * g_cs) * ((e - sum_e / (float)M) * inv_sd - k2 * (s - mu_s));
+        if (!(flags & EQUIGSPR_HEAD_NO_SIM_LOSS)) gs += (2.0f / (float)M * g_cs) * ((e - sum_e / (float)M) * inv_sd - k2 * (s - mu_s));
     }
     const int pj = pos[i];
     const float* a = hs + i * F;
@@ -644,7 +659,7 @@ static inline size_t fwd_smem(int N, int Npad, int K, MlpDims md) {
     return keys + sizeof(unsigned) * (size_t)N + 64;
 }
 struct HeadWork { double *partA, *partC, *pair_part; float *pair_f, *pair_g; int nbp, nC; size_t bytes; };
-static inline HeadWork head_work(void* base, int B, int N) {   // pair_part sized for kMaxK/kRowsPerBlock row blocks
+static inline HeadWork head_work(void* base, int B, int N) {   // pair_part sized for K = N: ceil(N / kRowsPerBlock) row blocks
     HeadWork w;
     w.nbp = ceil_div(N, 8);
     w.nC = B * ceil_div(N, 256);
@@ -652,7 +667,7 @@ static inline HeadWork head_work(void* base, int B, int N) {   // pair_part size
     size_t o = 0;
     w.partA = reinterpret_cast<double*>(p + o); o += sizeof(double) * (size_t)B * w.nbp * kHeadPartials;
     w.partC = reinterpret_cast<double*>(p + o); o += sizeof(double) * (size_t)w.nC * 3;
-    w.pair_part = reinterpret_cast<double*>(p + o); o += sizeof(double) * (size_t)B * (kMaxK / kRowsPerBlock);
+    w.pair_part = reinterpret_cast<double*>(p + o); o += sizeof(double) * (size_t)B * ceil_div(N, kRowsPerBlock);
     w.pair_f = reinterpret_cast<float*>(p + o); o += sizeof(float) * (size_t)B * 4;
     w.pair_g = reinterpret_cast<float*>(p + o); o += sizeof(float) * (size_t)B;
     w.bytes = o + 64;
@@ -675,15 +690,15 @@ extern "C" int64_t equigspr_head_work_bytes(int32_t B, int32_t N) {
 extern "C" int equigspr_head_forward(const float* hs, const float* ht, const float* raw_hs, const float* raw_ht,
                                      const float* xs, const float* xt, const float* labels, const float* gt_pose,
                                      const float* mlp /* flat: w1,b1,w2,b2,w3,b3 */, int32_t B, int32_t N, int32_t F,
-                                     int32_t F_raw, int32_t K, float* sim, float* rsim, float* cosv, int32_t* pos,
+                                     int32_t F_raw, int32_t K, int32_t flags, float* sim, float* rsim, float* cosv, int32_t* pos,
                                      float* wts, int64_t* top_idx, float* logits, float* a1_save, float* a2_save,
                                      void* work, float* out_scalars /* [16] device */, float* kabsch_R, float* kabsch_t,
                                      float* kabsch_aux, void* stream) {
     using namespace eq;
     EQ_CHECK_ARG(hs && ht && raw_hs && raw_ht && xs && xt && labels && gt_pose && mlp && sim && rsim && cosv && pos && wts &&
                      top_idx && logits && a1_save && a2_save && work && out_scalars, EQUIGSPR_EINVAL, "head_forward: null pointer");
-    EQ_CHECK_ARG(B >= 1 && N >= 2 && F >= 2 && F <= 64 && F_raw >= 1 && F_raw <= 64 && K >= 1 && K <= kMaxK && K <= N && N <= 4096,
-                 EQUIGSPR_ENOTSUP, "head_forward: need 2<=F<=64, 1<=K<=min(256,N), N<=4096");
+    EQ_CHECK_ARG(B >= 1 && N >= 2 && F >= 2 && F <= 64 && F_raw >= 1 && F_raw <= 64 && K >= 1 && K <= N && N <= kMaxN,
+                 EQUIGSPR_ENOTSUP, "head_forward: need 2<=F<=64, 1<=K<=N, N<=8192");
     hipStream_t s = (hipStream_t)stream;
     const MlpDims md{2 * F, F, F / 2};
     const HeadWork W = head_work(work, B, N);
@@ -717,9 +732,10 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
         int nb = (N + 255) / 256;
         if (nb > kKabschMaxBlocks) nb = kKabschMaxBlocks;
         hipLaunchKernelGGL(head_tail_kernel, dim3(nb + 1, B), dim3(256), 0, s, xs, xt, wts, N, nb, kabsch_R, kabsch_t, kabsch_aux,
-                           W.pair_f, W.partC, W.nC, W.pair_part, nblk, B, K, out_scalars);
+                           W.pair_f, W.partC, W.nC, W.pair_part, nblk, B, K, out_scalars, (int)flags);
     } else {
-        hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, W.partC, W.nC, W.pair_part, nblk, B, N, K, out_scalars);
+        hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, W.partC, W.nC, W.pair_part, nblk, B, N, K, out_scalars,
+                           (int)flags);
     }
     EQ_CHECK_LAUNCH("head_forward");
     return 0;
@@ -731,7 +747,7 @@ extern "C" int equigspr_head_backward(const float* hs, const float* ht, const fl
                                       const int64_t* top_idx, const float* logits, const float* a1_save,
                                       const float* a2_save, const float* fin_scalars, const float* g_corr_sim,
                                       const float* g_equi, const float* gw, int32_t B, int32_t N, int32_t F, int32_t K,
-                                      void* work /* the forward's */, float* dinp, float* mlp_slab, float* grad_mlp /* += */,
+                                      int32_t flags, void* work /* the forward's */, float* dinp, float* mlp_slab, float* grad_mlp /* += */,
                                       float* ghs, float* ght, float* gxs /* += */, float* gxt /* += */, void* stream) {
     using namespace eq;
     EQ_CHECK_ARG(hs && ht && xs && xt && labels && gt_pose && mlp && sim && rsim && cosv && pos && wts && top_idx && logits &&
@@ -748,9 +764,9 @@ extern "C" int equigspr_head_backward(const float* hs, const float* ht, const fl
                        reinterpret_cast<const long long*>(top_idx), logits, a1_save, a2_save, w1, w2, w3, g_corr_sim, B, N, F, K,
                        md, W.pair_g, dinp, mlp_slab, nblk);
     const int msz = (int)equigspr_head_mlp_size(F);
-    hipLaunchKernelGGL(head_node_bwd_kernel, dim3(W.nbp + ceil_div(msz, 256), B), dim3(256), 0, s, hs, ht, xs, xt, labels, gt_pose,
+    hipLaunchKernelGGL(head_node_bwd_kernel, dim3(W.nbp + ceil_div(msz, 32), B), dim3(256), 0, s, hs, ht, xs, xt, labels, gt_pose,
                        sim, rsim, cosv, pos, dinp, gw, W.pair_f, W.pair_g, fin_scalars, g_corr_sim, g_equi, B, N, F, K, md.in, ghs, ght,
-                       gxs, gxt, W.nbp, mlp_slab, B * nblk, msz, grad_mlp);
+                       gxs, gxt, W.nbp, mlp_slab, B * nblk, msz, grad_mlp, (int)flags);
     EQ_CHECK_LAUNCH("head_backward");
     return 0;
 }

@@ -262,7 +262,7 @@ class _HeadFn(torch.autograd.Function):
     Outputs: R [B,3,3], t [B,3], corr_loss+sim_loss (scalar), equi loss (scalar), logits [B,K], top_idx [B,K]."""
 
     @staticmethod
-    def forward(ctx, h_all, x_all, raw_hs, raw_ht, labels, gt_pose, topk, *mlp_params):
+    def forward(ctx, h_all, x_all, raw_hs, raw_ht, labels, gt_pose, topk, flags, *mlp_params):
         # h_all [2*B*N, F], x_all [2*B*N, 3]: the EGNN outputs for [src clouds..., tgt clouds...]; taking the
         # un-sliced tensors keeps four slice-backward (zeros + copy) launches out of the autograd graph
         L = _lib.lib()
@@ -309,11 +309,12 @@ class _HeadFn(torch.autograd.Function):
         aux = torch.empty(B, KABSCH_AUX, **f32)
         # the weighted Kabsch of (xs, xt, wts) rides in the head's last launch (moments, ticketed solve, loss scalars)
         _lib.check(L.equigspr_head_forward(_p(hs), _p(ht), _p(raw_hs), _p(raw_ht), _p(xs), _p(xt), _p(labels), _p(gt),
-                                           _p(flat), B, N, Fd, raw_hs.shape[2], K, _p(sim), _p(rsim), _p(cosv), _p(pos),
+                                           _p(flat), B, N, Fd, raw_hs.shape[2], K, int(flags), _p(sim), _p(rsim), _p(cosv), _p(pos),
                                            _p(wts), _p(top_idx), _p(logits), _p(a1), _p(a2), _p(work), _p(fin),
                                            _p(R), _p(t), _p(aux), _stream()), "head_forward")
         ctx.save_for_backward(hs, ht, xs, xt, labels, gt, flat, sim, rsim, cosv, pos, wts, top_idx, logits, a1, a2, fin, aux, work)
         ctx.dims = (B, N, Fd, K, msz)
+        ctx.flags = int(flags)
         ctx.mlp_shapes = [tuple(q.shape) for q in mlp_params]
         ctx.mlp_params = list(mlp_params)
         ctx.mark_non_differentiable(top_idx, logits)      # the logits' only consumer (BCE) is inside the head
@@ -345,10 +346,10 @@ class _HeadFn(torch.autograd.Function):
         g_eq = None if g_eq is None else g_eq.contiguous().float()
         _lib.check(L.equigspr_head_backward(_p(hs), _p(ht), _p(xs), _p(xt), _p(labels), _p(gt), _p(flat), _p(sim), _p(rsim),
                                             _p(cosv), _p(pos), _p(wts), _p(top_idx), _p(logits), _p(a1), _p(a2), _p(fin),
-                                            _p(g_cs), _p(g_eq), _p(gw), B, N, Fd, K, _p(work), _p(dinp), _p(slab), _p(gmlp),
+                                            _p(g_cs), _p(g_eq), _p(gw), B, N, Fd, K, ctx.flags, _p(work), _p(dinp), _p(slab), _p(gmlp),
                                             _p(ghs), _p(ght), _p(gxs), _p(gxt), _stream()), "head_backward")
         if in_place is not None:
-            return (gh_all, gx_all, None, None, None, None, None, *([None] * len(ctx.mlp_shapes)))
+            return (gh_all, gx_all, None, None, None, None, None, None, *([None] * len(ctx.mlp_shapes)))
         grads, off = [], 0
         for shp in ctx.mlp_shapes:
             n = 1
@@ -356,7 +357,7 @@ class _HeadFn(torch.autograd.Function):
                 n *= d
             grads.append(gmlp[off:off + n].view(shp))
             off += n
-        return (gh_all, gx_all, None, None, None, None, None, *grads)
+        return (gh_all, gx_all, None, None, None, None, None, None, *grads)
 
 
 def _adjacent_grad_slice(params, total):
@@ -375,9 +376,13 @@ def _adjacent_grad_slice(params, total):
     return g0.reshape(-1).as_strided((total,), (1,))
 
 
-def fused_pose_head(h_all, x_all, raw_hs, raw_ht, labels, gt_pose, topk, mlp_params):
-    """``h_all [2BN,F]``, ``x_all [2BN,3]`` = EGNN outputs for [src clouds..., tgt clouds...]."""
-    return _HeadFn.apply(h_all, x_all, raw_hs, raw_ht, labels, gt_pose, topk, *mlp_params)
+HEAD_NO_SIM_LOSS = 1      # EQUIGSPR_HEAD_NO_SIM_LOSS
+
+
+def fused_pose_head(h_all, x_all, raw_hs, raw_ht, labels, gt_pose, topk, mlp_params, flags=0):
+    """``h_all [2BN,F]``, ``x_all [2BN,3]`` = EGNN outputs for [src clouds..., tgt clouds...].  ``flags``: HEAD_NO_SIM_LOSS for
+    the KITTI script's forward (corr_loss alone)."""
+    return _HeadFn.apply(h_all, x_all, raw_hs, raw_ht, labels, gt_pose, topk, flags, *mlp_params)
 
 
 # ----------------------------------------------------------------------------------- pose loss / Adam

@@ -92,11 +92,13 @@ def unsorted_segment_mean(data, segment_ids, num_segments):
 
 # ------------------------------------------------------------------------------ pair model
 class CrossAttentionPoseRegression(nn.Module):
-    def __init__(self, egnn, num_nodes=2048, hidden_nf=33, device="cuda:0", variant="train", topk=128, fused_head=True):
+    def __init__(self, egnn, num_nodes=2048, hidden_nf=33, device="cuda:0", variant="train", topk=None, fused_head=True):
         super().__init__()
         self.fused_head = fused_head
-        if variant not in ("train", "eval"):
-            raise ValueError("variant must be 'train' or 'eval'")
+        if variant not in ("train", "eval", "kitti"):
+            raise ValueError("variant must be 'train', 'eval' or 'kitti'")
+        if topk is None:        # train :684 / eval :694: 128; the KITTI script scores top_k = 2048 points (kitti :661)
+            topk = 2048 if variant == "kitti" else 128
         self.egnn, self.hidden_nf, self.num_nodes, self.device = egnn, hidden_nf, num_nodes, device
         self.variant, self.topk = variant, topk
         self.mlp = nn.Sequential(nn.Linear(2 * hidden_nf, hidden_nf), nn.ReLU(),
@@ -142,15 +144,18 @@ class CrossAttentionPoseRegression(nn.Module):
         B, N, Fd = h_src.shape
         raw_h_src, raw_h_tgt = h_src, h_tgt
         hs, xs, ht, xt = self._run_egnn(h_src, x_src, edges_src, edge_attr_src, h_tgt, x_tgt, edges_tgt, edge_attr_tgt)
-        if self.fused_head and hs.shape[-1] <= 64 and self.topk <= min(256, N) and N <= 4096 and \
-                self.mlp[0].in_features == 2 * hs.shape[-1]:
+        kitti = self.variant == "kitti"       # src/kitti_train_egnn_with_batch.py:619-766: top_k = 2048, no similarity-MSE term
+        if self.topk > N:
+            raise RuntimeError(f"top-k of {self.topk} out of {N} points (torch.topk raises in the reference, kitti :663)")
+        if self.fused_head and hs.shape[-1] <= 64 and N <= 8192 and self.mlp[0].in_features == 2 * hs.shape[-1]:
             # one HIP head (csrc/head.hip) instead of ~220 small ATen launches; same math as the lines below
             mlp_params = [self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias,
                           self.mlp[4].weight, self.mlp[4].bias]
             h_o, x_o = self._egnn_out
             self._egnn_out = None
             R, t, closs, total_loss, logits, top_idx = ops.fused_pose_head(h_o, x_o, raw_h_src, raw_h_tgt, labels,
-                                                                           gt_pose, self.topk, mlp_params)
+                                                                           gt_pose, self.topk, mlp_params,
+                                                                           flags=ops.HEAD_NO_SIM_LOSS if kitti else 0)
             self.last_logits, self.last_top_idx = logits.detach(), top_idx
             return R, t, closs, total_loss, hs, xs, ht, xt, labels
         total_loss = egnn_equi_loss(hs, xs, ht, xt, gt_pose[:, :3, :3], gt_pose[:, :3, -1], labels)       # :677
@@ -174,6 +179,8 @@ class CrossAttentionPoseRegression(nn.Module):
         raw_n = (raw_sim - raw_sim.mean()) / (raw_sim.std() + 1e-6)                                        # :778
         sim_loss = F.mse_loss(sim_n, raw_n)                                                                # :781
         self.last_logits, self.last_top_idx = logits, top_idx                                             # for parity tests
+        if kitti:
+            return R, t, corr_loss, total_loss, hs, xs, ht, xt, labels                                    # kitti :766
         return R, t, corr_loss + sim_loss, total_loss, hs, xs, ht, xt, labels
 
     def _forward_eval(self, h_src, x_src, edges_src, ea_src, h_tgt, x_tgt, edges_tgt, ea_tgt, corr, labels, gt_pose):

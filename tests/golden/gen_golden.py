@@ -86,11 +86,14 @@ def load_reference():
     sys.path.insert(0, os.path.join(REF, "src"))
     sys.path.insert(0, REF)
     mods = {}
-    for fname, name in (("3dmatch_train_egnn_with_batch.py", "ref_train"), ("eval_egnn_metrics.py", "ref_eval")):
+    for fname, name in (("3dmatch_train_egnn_with_batch.py", "ref_train"), ("eval_egnn_metrics.py", "ref_eval"),
+                        ("kitti_train_egnn_with_batch.py", "ref_kitti")):
         spec = importlib.util.spec_from_file_location(name, os.path.join(REF, "src", fname))
         m = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(m)
         mods[name] = m
+    global REF_KITTI
+    REF_KITTI = mods["ref_kitti"]
     return mods["ref_train"], mods["ref_eval"]
 
 
@@ -274,6 +277,75 @@ def gen_pair_fixture(tr, ev, name, n, k, feat, n_layers, heads, seed, ckpt=None,
               np.abs(out["f32.train.t"] - out["f64.train.t"]).max(),
               np.abs(out["f32.h_src"] - out["f64.h_src"]).max()),
           "| R(eval) err vs gt %.3e" % np.abs(out["f64.eval.R"][0] - out["in.gt_pose"][:3, :3]).max())
+
+
+# ---------------------------------------------------------------- fixture: the KITTI script's pair model + its training loss
+REF_KITTI = None
+
+
+def gen_kitti_fixture(name, n, k, feat, n_layers, seed, out_scale=0.02, tgt_noise=0.05, scale=(60.0, 60.0, 4.0)):
+    """src/kitti_train_egnn_with_batch.py: CrossAttentionPoseRegression.forward with top_k = 2048 (:661) and no similarity
+    term (:766), trained on ``corr_loss.mean() + equi_loss.mean()`` (:1080-1092).  The real classes of that script on a seeded
+    anisotropic pair, fp32 and fp64: outputs, logits over the 2048 selected points, loss and every parameter gradient."""
+    kt = REF_KITTI
+    p = orc.synthetic_pair(1234 + seed, n=n, feat=feat, scale=scale)
+    g = torch.Generator().manual_seed(seed + 99)
+    p["tgt"] = p["tgt"] + tgt_noise * torch.randn(n, 3, generator=g)
+    e_s, e_t = orc.knn_graph(p["src"], k, loop=True), orc.knn_graph(p["tgt"], k, loop=True)
+    torch.manual_seed(seed)
+    egnn = kt.EGNN(feat, feat, feat, in_edge_nf=1, device="cpu", n_layers=n_layers)
+    torch.manual_seed(seed + 1)
+    cross = kt.CrossAttentionPoseRegression(egnn, num_nodes=n, hidden_nf=feat, device="cpu")
+    with torch.no_grad():
+        egnn.embedding_out.weight.mul_(out_scale)
+        egnn.embedding_out.bias.mul_(out_scale)
+    out = {"k": np.int64(k), "n_layers": np.int64(n_layers), "heads": np.int64(1), "top_k": np.int64(2048)}
+    for kk in ("src", "tgt", "feat_src", "feat_tgt", "labels", "gt_pose", "corr"):
+        out["in." + kk] = p[kk].numpy()
+    for kk, v in sd_np(cross).items():
+        if not kk.endswith("num_batches_tracked"):
+            out["w." + kk] = v
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        with default_dtype(dt):
+            torch.manual_seed(seed)
+            e2 = kt.EGNN(feat, feat, feat, in_edge_nf=1, device="cpu", n_layers=n_layers)
+            e2.load_state_dict(egnn.state_dict())
+            c2 = kt.CrossAttentionPoseRegression(e2, num_nodes=n, hidden_nf=feat, device="cpu")
+            c2.load_state_dict(cross.state_dict())
+            c2 = c2.to(dt)
+            c2.train()
+            # fp64 twin only: the script's equi loss calls F.mse_loss(sim, labels.float()) (kitti :858); with fp64 activations the
+            # float32 target breaks autograd ("Found dtype Float but expected Double"), so the target is cast to the input's
+            # dtype for that run.  The fp32 run executes the script untouched.
+            orig_mse = kt.F.mse_loss
+            if dt == torch.float64:
+                kt.F.mse_loss = lambda a, b, *args, **kw: orig_mse(a, b.to(a.dtype), *args, **kw)
+            try:
+                R, t, closs, equi, hs, xs, ht, xt, _ = run_pair(kt, c2, p, e_s, e_t, dt)
+            finally:
+                kt.F.mse_loss = orig_mse
+            pre = f"{tag}.train."
+            out[pre + "R"], out[pre + "t"] = R.detach().numpy(), t.detach().numpy()
+            out[pre + "corr_loss"], out[pre + "equi_loss"] = closs.detach().numpy(), equi.detach().numpy()
+            for key, v in (("h_src", hs), ("x_src", xs), ("h_tgt", ht), ("x_tgt", xt)):
+                out[f"{tag}.{key}"] = v.detach().numpy()[0]
+            sim = torch.sum(hs * ht, dim=-1)
+            _, idx = torch.topk(sim, k=2048, dim=-1)                                        # kitti :661-663
+            gi = idx.unsqueeze(-1).expand(-1, -1, feat)
+            logits = c2.mlp(torch.cat([torch.gather(hs, 1, gi), torch.gather(ht, 1, gi)], -1).view(-1, 2 * feat))
+            out[pre + "logits"], out[pre + "top_idx"] = logits.detach().view(1, 2048).numpy(), idx.numpy()
+            loss = closs.mean() + equi.mean()                                               # kitti :1080-1092
+            c2.zero_grad()
+            loss.backward()
+            out[pre + "loss"] = loss.detach().numpy()
+            for pn, prm in c2.named_parameters():
+                if prm.grad is not None:
+                    out[pre + "grad." + pn] = prm.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print("wrote", name, "| loss %.6f | f32-f64 gaps: logits %.2e R %.2e t %.2e h %.2e" % (
+        float(out["f64.train.loss"]), np.abs(out["f32.train.logits"] - out["f64.train.logits"]).max(),
+        np.abs(out["f32.train.R"] - out["f64.train.R"]).max(), np.abs(out["f32.train.t"] - out["f64.train.t"]).max(),
+        np.abs(out["f32.h_src"] - out["f64.h_src"]).max()))
 
 
 # ---------------------------------------------------------------- fixture: Kabsch + grads
@@ -680,6 +752,10 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "so3tp":
         gen_so3tp_fixture("so3tp_d32.npz")
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "kitti":
+        gen_kitti_fixture("pair_kitti_n2048_k12_l2_f33.npz", 2048, 12, 33, 2, seed=5)
+        gen_kitti_fixture("pair_kitti_n4096_k8_l1_f33.npz", 4096, 8, 33, 1, seed=6)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "wellcond":     # regenerate just this fixture
         gen_pair_fixture(tr, ev, "pair_n512_k12_l2_wellcond.npz", 512, 12, 32, 2, 1, seed=3, out_scale=0.02, with_grads=True,
                          tgt_noise=0.05)
@@ -693,6 +769,8 @@ def main():
                      tgt_noise=0.05)
     gen_pair_fixture(tr, ev, "pair_ckpt_n2048_k16_l3_h4.npz", 2048, 16, 32, 3, 4, seed=1,
                      ckpt=os.path.join(REF, "checkpoints", "checkpoint-3dmatch.pth"))
+    gen_kitti_fixture("pair_kitti_n2048_k12_l2_f33.npz", 2048, 12, 33, 2, seed=5)
+    gen_kitti_fixture("pair_kitti_n4096_k8_l1_f33.npz", 4096, 8, 33, 1, seed=6)
     gen_kabsch_fixture("kabsch_cases.npz")
     gen_so3tp_fixture("so3tp_d32.npz")
     gen_gcn_fixture("gcn_n300_k9.npz")
