@@ -5,8 +5,8 @@
 // Per layer, walking l = L-1 .. 0 with G_h = dL/dh_{l+1}, G_x = dL/dx_{l+1}:
 //   node_bwd   (lane = feature, G lanes per node)  node-MLP backward -> dagg, dh_part; re-projects
 //              P_l = [W_src h_l | W_tgt h_l + b1] for the edge recompute; dW4,db4,dW5,db5 partials.
-//   edge_bwd   (hidden_nf 32: a wave per chunk of <= 64 edges, 16-edge MFMA sub-tiles, egnn_mfma16.h; hidden_nf 33: a wave
-//              per 32-edge tile, egnn_mfma.h)  recomputes the edge forward from (P_l, x_l), runs the edge backward,
+//   edge_bwd   (a wave per chunk of <= 64 edges, 16-edge MFMA sub-tiles, egnn_mfma16.h; hidden_nf 33 with a border feature)
+//              recomputes the edge forward from (P_l, x_l), runs the edge backward,
 //              writes dt1_e, dL/dx_r, dL/dx_c per edge.  Weight gradients are sums over edges of outer products: the
 //              per-edge vectors are transposed through wave-private LDS tiles and accumulated
 //              with fp32 MFMA (v_mfma_f32_32x32x2_f32, K = edges) -- exact fp32, VALU stays free.
@@ -22,7 +22,10 @@
 namespace eq {
 
 
-constexpr int kNodeBwdBlocks = 1024;   // slab count of the node-level kernels
+#ifndef EQ_NODE_BWD_BLOCKS
+#define EQ_NODE_BWD_BLOCKS 1024
+#endif
+constexpr int kNodeBwdBlocks = EQ_NODE_BWD_BLOCKS;   // slab count of the node-level kernels
 constexpr int kEdgeBwdBlocks = 1024;  // max slab count of the edge kernel
 
 // ---- slab sizes ---------------------------------------------------------------------------
@@ -634,365 +637,6 @@ __global__ __launch_bounds__(256, 2) void gather_node_bwd_kernel(
 // ---------------------------------------------------------------------------------------
 // edge backward
 // ---------------------------------------------------------------------------------------
-// One pass over a wave-private pair of LDS tiles X[64][LD], Y[64][LD] (row = edge of the chunk):
-//   acc[rb][cb] += X^T Y (32x32 blocks, K = 64 edges, fp32 MFMA), csx += column sums of X,
-//   csy += column sums of Y.  Lane l: column (l & 31), edge parity (l >> 5).
-template <int NB, int NBY, int LD, bool kMfma, int KE = 64>
-__device__ __forceinline__ void tile_pass(const float* X, const float* Y, f32x16 (&acc)[NB][NBY], float (&csx)[NB],
-                                          float (&csy)[NBY], int lane) {
-    const int f = lane & 31, hh = lane >> 5;
-#pragma unroll 2
-    for (int s = 0; s < KE / 2; ++s) {
-        const int e = 2 * s + hh;
-        float a[NB], b[NBY];
-#pragma unroll
-        for (int rb = 0; rb < NB; ++rb) { a[rb] = X[e * LD + rb * 32 + f]; csx[rb] += a[rb]; }
-#pragma unroll
-        for (int cb = 0; cb < NBY; ++cb) { b[cb] = Y[e * LD + cb * 32 + f]; csy[cb] += b[cb]; }
-        if (kMfma) {
-#pragma unroll
-            for (int rb = 0; rb < NB; ++rb)
-#pragma unroll
-                for (int cb = 0; cb < NBY; ++cb)
-                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------
-// edge backward, MFMA formulation (hidden_nf == 32): one wave per 32-edge tile (egnn_mfma.h).
-// The forward state (recomputed) and the
-// three transposed products (W6^T dq, W2^T du, Wgeo^T dt1) use the matrix cores with register-resident
-// weights; only the weight-gradient outer products (sum over edges) go through wave-private LDS tiles.
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void stage_half_row(float* tile_row, int h, const float (&v)[16]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4*>(tile_row + 8 * q + 4 * h) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-}
-
-template <int H, int A, int B = 0>
-__global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restrict__ lw, const int* __restrict__ row,
-                                                            const int* __restrict__ col, const float* __restrict__ edge_attr,
-                                                            const float* __restrict__ x, const float* __restrict__ P,
-                                                            const float* __restrict__ dagg, const float* __restrict__ Gx,
-                                                            int n_edges, float* __restrict__ dt1_out,
-                                                            float* __restrict__ gxr_out, float* __restrict__ gxc_out,
-                                                            float* __restrict__ slab) {
-    constexpr int F = 32 + B, FP = 32 + 4 * B, PS = 2 * FP, LD = 36;     // B = 1: hidden_nf = 33, feature 32 = the border
-    using SB = Slabs<F>;
-    using T = TileWeightsLdsT<B>;
-    constexpr int kTileFloats = 4 * 2 * 32 * LD > 4 * SB::edge ? 4 * 2 * 32 * LD : 4 * SB::edge;   // X/Y tiles, then 4 slab copies
-    __shared__ __attribute__((aligned(16))) float tiles[kTileFloats];
-    __shared__ float wsm[T::size];
-    const int lane = threadIdx.x & 63, el = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-    const int wave = blockIdx.x * 4 + wv, n_waves = gridDim.x * 4;
-    float* X = tiles + (size_t)wv * 2 * 32 * LD;
-    float* Y = X + 32 * LD;
-    EQ_STAMP(0);
-    stage_tile_weights<H, A, B>(wsm, lw);
-    __syncthreads();
-    TileWeights<H, A, true, B> W;
-    W.load(wsm, lane);
-    EQ_STAMP(1);
-
-    f32x16 acc6[1][1], acc2[1][1], accg[1][1];
-    float cs_b6[1] = {0.0f}, cs_b2[1] = {0.0f}, cs_gam[1] = {0.0f}, cs_bet[1] = {0.0f}, cs_w7[1] = {0.0f}, cs_scr[1] = {0.0f};
-    // border (B = 1): column 32 / row 32 of dW6, dW2 (per-lane column sums like cs_*), row 32 of dWgeo, and the scalars
-    // (corner entries and the 33rd entry of every per-feature vector) as per-lane partials of the h == 0 lanes
-    float bc6[1] = {0.0f}, br6[1] = {0.0f}, bc2[1] = {0.0f}, br2[1] = {0.0f}, brg[1] = {0.0f};
-    float x_c6 = 0.0f, x_c2 = 0.0f, x_b6 = 0.0f, x_b2 = 0.0f, x_w7 = 0.0f, x_gam = 0.0f, x_bet = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc6[0][0][r] = 0.0f; acc2[0][0][r] = 0.0f; accg[0][0][r] = 0.0f; }
-    // dw7, dgamma, dbeta are plain sums over edges of per-lane values: with registers to spare (B = 0) every lane keeps its
-    // own running sums over its tiles and the 32 lanes are added ONCE after the loop, instead of two LDS passes per tile
-    constexpr bool kLaneSums = (B == 0);
-    float ls_w7[kLaneSums ? 16 : 1], ls_gam[kLaneSums ? 16 : 1], ls_bet[kLaneSums ? 16 : 1];
-#pragma unroll
-    for (int r = 0; r < (kLaneSums ? 16 : 1); ++r) { ls_w7[r] = 0.0f; ls_gam[r] = 0.0f; ls_bet[r] = 0.0f; }
-
-    const int n_tiles = (n_edges + 31) / 32;
-    for (int tile = wave; tile < n_tiles; tile += n_waves) {
-        W.refresh();
-        const int e_raw = tile * 32 + el;
-        const bool valid = e_raw < n_edges;
-        const int e = valid ? e_raw : n_edges - 1;
-        const float z = valid ? 1.0f : 0.0f;
-        const int r = row[e], c = col[e];
-        EQ_STAMP(2);
-        float xr[3], xc[3], gxv[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { xr[i] = x[(size_t)r * 3 + i]; xc[i] = x[(size_t)c * 3 + i]; gxv[i] = Gx[(size_t)r * 4 + i]; }
-        EdgeGeo eg;
-        edge_geometry(xr, xc, eg);
-        EQ_STAMP(3);
-        const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
-        TileFwd o;
-        // the forward state: recomputed from the projection rows (flash-style; nothing per edge is kept by the forward)
-        tile_forward<H, A, true, B>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
-        const float zh = (h == 0) ? 1.0f : 0.0f;            // border scalars are identical in both halves: count them once
-
-        // ---- coord head backward
-        const float ds = dot3(eg.d, gxv) * z;
-        float gd[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) gd[i] = o.s * gxv[i];
-        float dq[16], pds[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float sg = o.sgq[k];
-            pds[k] = o.q[k] * sg * ds;
-            dq[k] = W.w7(k) * ds * (sg * (1.0f + o.q[k] * (1.0f - sg)));
-        }
-        float dqb = 0.0f, pdsb = 0.0f;
-        if constexpr (B == 1) {
-            pdsb = o.qb * o.sgqb * ds;
-            dqb = W.x_vec(4) * ds * (o.sgqb * (1.0f + o.qb * (1.0f - o.sgqb)));
-            x_c6 = fmaf(zh * dqb, o.mb, x_c6); x_b6 += zh * dqb; x_w7 += zh * pdsb;
-        }
-        stage_half_row(X + el * LD, h, dq);
-        stage_half_row(Y + el * LD, h, o.m);
-        __builtin_amdgcn_wave_barrier();
-        tile_pass<1, 1, LD, true, 32>(X, Y, acc6, cs_b6, cs_scr, lane);           // dW6 += dq^T m ; db6 += sum dq
-        __builtin_amdgcn_wave_barrier();
-        if constexpr (B == 1) {                                                   // dW6[:, 32] = sum dq * m32 ; dW6[32, :] = sum dq32 * m
-            float xs[16], ys[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) { xs[k] = dq[k] * o.mb; ys[k] = dqb * o.m[k]; }
-            stage_half_row(X + el * LD, h, xs);
-            stage_half_row(Y + el * LD, h, ys);
-            __builtin_amdgcn_wave_barrier();
-            tile_pass<1, 1, LD, false, 32>(X, Y, acc6, bc6, br6, lane);
-            __builtin_amdgcn_wave_barrier();
-        }
-        EQ_STAMP(7);
-        // ---- dm = dagg[row] + W6^T dq
-        float dm[16], dmb = 0.0f;
-        {
-            float da[16];
-            load_half_row(dagg + (size_t)r * FP, h, da);
-            f32x16 a;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = da[k] * z;
-            mv_border<true, B>(W, T::o_w6, [&](int s) { return W.w6t(s); }, dq, dqb, a, dmb, B ? dagg[(size_t)r * FP + 32] * z : 0.0f, h);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) dm[k] = a[k];
-        }
-        EQ_STAMP(8);
-        if constexpr (kLaneSums) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                ls_w7[k] += pds[k];
-                ls_gam[k] = fmaf(dm[k], o.xhat[k], ls_gam[k]);
-                ls_bet[k] += dm[k];
-            }
-        } else {
-            {
-                float t[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) t[k] = dm[k] * o.xhat[k];
-                if constexpr (B == 1) { x_gam = fmaf(zh * dmb, o.xhatb, x_gam); x_bet += zh * dmb; }
-                stage_half_row(X + el * LD, h, pds);
-                stage_half_row(Y + el * LD, h, t);
-            }
-            __builtin_amdgcn_wave_barrier();
-            tile_pass<1, 1, LD, false, 32>(X, Y, acc6, cs_w7, cs_gam, lane);          // dw7, dgamma (column sums only)
-            __builtin_amdgcn_wave_barrier();
-            stage_half_row(X + el * LD, h, dm);
-            __builtin_amdgcn_wave_barrier();
-            tile_pass<1, 1, LD, false, 32>(X, Y, acc6, cs_bet, cs_scr, lane);         // dbeta = sum dm
-            __builtin_amdgcn_wave_barrier();
-        }
-        EQ_STAMP(9);
-        // ---- LayerNorm backward
-        float du[16], dub = 0.0f;
-        {
-            float m1 = 0.0f, m2 = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                du[k] = dm[k] * W.gam(k);
-                m1 += du[k];
-                m2 = fmaf(du[k], o.xhat[k], m2);
-            }
-            m1 += xhalf(m1);
-            m2 += xhalf(m2);
-            if constexpr (B == 1) {
-                dub = dmb * W.x_vec(1);
-                m1 += dub;
-                m2 = fmaf(dub, o.xhatb, m2);
-            }
-            m1 *= (1.0f / F);
-            m2 *= (1.0f / F);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) du[k] = o.rstd * (du[k] - m1 - o.xhat[k] * m2);
-            if constexpr (B == 1) dub = o.rstd * (dub - m1 - o.xhatb * m2);
-        }
-        float sg1[16];
-        {
-            float g1[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float sg = o.sg1[k];
-                g1[k] = o.t1[k] * sg;
-                sg1[k] = sg * (1.0f + o.t1[k] * (1.0f - sg));
-            }
-            stage_half_row(X + el * LD, h, du);
-            stage_half_row(Y + el * LD, h, g1);
-            __builtin_amdgcn_wave_barrier();
-            tile_pass<1, 1, LD, true, 32>(X, Y, acc2, cs_b2, cs_scr, lane);       // dW2 += du^T g1 ; db2 += sum du
-            __builtin_amdgcn_wave_barrier();
-            if constexpr (B == 1) {                                               // dW2[:, 32] = sum du * g1_32 ; dW2[32, :] = sum du32 * g1
-                const float g1b = o.t1b * o.sg1b;
-                x_c2 = fmaf(zh * dub, g1b, x_c2); x_b2 += zh * dub;
-                float xs[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) { xs[k] = du[k] * g1b; g1[k] *= dub; }
-                stage_half_row(X + el * LD, h, xs);
-                stage_half_row(Y + el * LD, h, g1);
-                __builtin_amdgcn_wave_barrier();
-                tile_pass<1, 1, LD, false, 32>(X, Y, acc2, bc2, br2, lane);
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        EQ_STAMP(10);
-        // ---- dt1 = (W2^T du) * silu'(t1)
-        float dt1[16], dt1b = 0.0f;
-        {
-            f32x16 a;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = 0.0f;
-            mv_border<true, B>(W, T::o_w2, [&](int s) { return W.w2t(s); }, du, dub, a, dt1b, 0.0f, h);
-#pragma unroll
-            for (int k = 0; k < 16; ++k) dt1[k] = a[k] * sg1[k];
-            if constexpr (B == 1) dt1b *= o.sg1b * (1.0f + o.t1b * (1.0f - o.sg1b));
-        }
-        EQ_STAMP(11);
-        stage_half_row(X + el * LD, h, dt1);
-        if (h == 0) {
-            float ga[16];
-#pragma unroll
-            for (int k = 0; k < kGeo; ++k) ga[k] = eg.g[k];
-            ga[12] = attr; ga[13] = 0.0f; ga[14] = 0.0f; ga[15] = 0.0f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(Y + el * LD + 4 * q) = make_float4(ga[4 * q], ga[4 * q + 1], ga[4 * q + 2], ga[4 * q + 3]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        tile_pass<1, 1, LD, true, 32>(X, Y, accg, cs_scr, cs_scr, lane);          // dWgeo|dwattr += dt1^T [geo, attr]
-        __builtin_amdgcn_wave_barrier();
-        if constexpr (B == 1) {                                                   // dWgeo[32, :] = sum dt1_32 * [geo, attr]
-            if (h == 0) {
-                float ga[16];
-#pragma unroll
-                for (int k = 0; k < kGeo; ++k) ga[k] = dt1b * eg.g[k];
-                ga[12] = dt1b * attr; ga[13] = 0.0f; ga[14] = 0.0f; ga[15] = 0.0f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(Y + el * LD + 4 * q) = make_float4(ga[4 * q], ga[4 * q + 1], ga[4 * q + 2], ga[4 * q + 3]);
-            }
-            __builtin_amdgcn_wave_barrier();
-            tile_pass<1, 1, LD, false, 32>(X, Y, accg, cs_scr, brg, lane);
-            __builtin_amdgcn_wave_barrier();
-        }
-        EQ_STAMP(12);
-        // ---- dgeo = Wgeo^T dt1 (rows 0..11 of a 32-row product), then the geometry backward
-        float gg[kGeo];
-        {
-            f32x16 a;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(W.wgt(s), dt1[s], a, 0, 0, 0);
-            if constexpr (B == 1) a = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? 0.0f : W.x_wg_i(), h ? 0.0f : dt1b, a, 0, 0, 0);
-            // lane half h holds geo rows fidx(k,h): h=0 -> 0..3 (k 0..3), 8..11 (k 4..7); h=1 -> 4..7 (k 0..3)
-            float mine[8], other[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { mine[k] = a[k]; other[k] = xhalf(mine[k]); }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                gg[k] = h ? other[k] : mine[k];
-                gg[4 + k] = h ? mine[k] : other[k];
-                gg[8 + k] = h ? other[4 + k] : mine[4 + k];
-            }
-        }
-        float gxr[3], gxc[3];
-        edge_geometry_backward(xr, xc, eg, gg, gd, gxr, gxc);
-        if (valid) {
-            store_half_row(dt1_out + (size_t)e * FP, h, dt1);
-            if (B) store_border(dt1_out + (size_t)e * FP, h, dt1b);
-            if (h == 0) {
-                reinterpret_cast<float4*>(gxr_out)[e] = make_float4(gxr[0], gxr[1], gxr[2], 0.0f);
-                reinterpret_cast<float4*>(gxc_out)[e] = make_float4(gxc[0], gxc[1], gxc[2], 0.0f);
-            }
-        }
-        EQ_STAMP(13);
-    }
-
-    // ---- the 4 waves' partials: each wave writes its own LDS copy (in parallel), then all threads add the four copies in
-    // fixed order straight into the block's global slab (was: four serialised read-modify-write rounds + a flush)
-    const int f = lane & 31, hh = lane >> 5;
-    if constexpr (kLaneSums) {                          // the per-lane sums: one transposing pass per vector pair
-        stage_half_row(X + el * LD, h, ls_w7);
-        stage_half_row(Y + el * LD, h, ls_gam);
-        __builtin_amdgcn_wave_barrier();
-        tile_pass<1, 1, LD, false, 32>(X, Y, acc6, cs_w7, cs_gam, lane);
-        __builtin_amdgcn_wave_barrier();
-        stage_half_row(X + el * LD, h, ls_bet);
-        __builtin_amdgcn_wave_barrier();
-        tile_pass<1, 1, LD, false, 32>(X, Y, acc6, cs_bet, cs_scr, lane);
-        __builtin_amdgcn_wave_barrier();
-    }
-    cs_b6[0] += xhalf(cs_b6[0]);
-    cs_b2[0] += xhalf(cs_b2[0]);
-    cs_gam[0] += xhalf(cs_gam[0]);
-    cs_bet[0] += xhalf(cs_bet[0]);
-    cs_w7[0] += xhalf(cs_w7[0]);
-    if constexpr (B == 1) {
-        bc6[0] += xhalf(bc6[0]); br6[0] += xhalf(br6[0]); bc2[0] += xhalf(bc2[0]); br2[0] += xhalf(br2[0]); brg[0] += xhalf(brg[0]);
-#pragma unroll
-        for (int off = 1; off <= 32; off <<= 1) {      // the scalars: sum over the wave (only h == 0 lanes contributed)
-            x_c6 += __shfl_xor(x_c6, off, 64); x_c2 += __shfl_xor(x_c2, off, 64); x_b6 += __shfl_xor(x_b6, off, 64);
-            x_b2 += __shfl_xor(x_b2, off, 64); x_w7 += __shfl_xor(x_w7, off, 64); x_gam += __shfl_xor(x_gam, off, 64);
-            x_bet += __shfl_xor(x_bet, off, 64);
-        }
-    }
-    __syncthreads();                                   // every wave is done with its X/Y tiles
-    {
-        float* sl = tiles + (size_t)wv * SB::edge;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int orow = (k & 3) + 8 * (k >> 2) + 4 * hh;
-            sl[SB::e_w2 + orow * F + f] = acc2[0][0][k];
-            sl[SB::e_w6 + orow * F + f] = acc6[0][0][k];
-            if (f < 16) sl[SB::e_geo + orow * 16 + f] = accg[0][0][k];
-        }
-        if (hh == 0) {
-            sl[SB::e_b2 + f] = cs_b2[0];
-            sl[SB::e_b6 + f] = cs_b6[0];
-            sl[SB::e_gam + f] = cs_gam[0];
-            sl[SB::e_bet + f] = cs_bet[0];
-            sl[SB::e_w7 + f] = cs_w7[0];
-            if constexpr (B == 1) {
-                sl[SB::e_w6 + f * F + 32] = bc6[0];            // column 32, rows 0..31
-                sl[SB::e_w6 + 32 * F + f] = br6[0];            // row 32, columns 0..31
-                sl[SB::e_w2 + f * F + 32] = bc2[0];
-                sl[SB::e_w2 + 32 * F + f] = br2[0];
-                if (f < 16) sl[SB::e_geo + 32 * 16 + f] = brg[0];
-                if (f == 0) {
-                    sl[SB::e_w6 + 32 * F + 32] = x_c6; sl[SB::e_w2 + 32 * F + 32] = x_c2;
-                    sl[SB::e_b6 + 32] = x_b6; sl[SB::e_b2 + 32] = x_b2; sl[SB::e_w7 + 32] = x_w7;
-                    sl[SB::e_gam + 32] = x_gam; sl[SB::e_bet + 32] = x_bet;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < SB::edge; t += 256)
-        slab[(size_t)blockIdx.x * SB::edge + t] = ((tiles[t] + tiles[SB::edge + t]) + tiles[2 * SB::edge + t]) + tiles[3 * SB::edge + t];
-    EQ_STAMP(14);
-}
-
-
 // ---------------------------------------------------------------------------------------
 // edge backward, 16-edge MFMA formulation (hidden_nf == 32; egnn_mfma16.h).  Eight waves per workgroup, two per SIMD,
 // one workgroup per CU, persistent over the chunks.  Per 16-edge sub-tile: forward recompute (40 MFMAs), the three
@@ -1001,10 +645,18 @@ __global__ __launch_bounds__(256) void edge_bwd_mfma_kernel(const float* __restr
 // front / back phases.
 // ---------------------------------------------------------------------------------------
 // acc[bx][by] += X^T Y over the 16 edges of the tiles X [16][LD], Y [16][ldy] (16 columns per block);
-// K step s, lane group g <-> edge s + 4 g (rows 4 apart: the two groups of a 32-lane LDS access hit disjoint banks)
-template <int NBY, bool kColSum>
-__device__ __forceinline__ void pass16(const float* X, const float* Y, int ldy, int i, int g, f32x4 (&acc)[2][NBY], float (&cs)[2]) {
-    float a0[4], a1[4], b0[4], b1[4];
+// K step s, lane group g <-> edge s + 4 g (rows 4 apart: the two groups of a 32-lane LDS access hit disjoint banks).
+// Border (hidden_nf = 33, kB): column 32 of a tile row holds the edge's 33rd feature (a scalar xb / yb per edge):
+//   bcol[bx] += X[:, 16 bx + i] * yb (column 32 of the gradient), brow[by] += xb * Y[:, 16 by + i] (row 32),
+//   corner += xb * yb, xbs += xb; all per lane group g, reduced over g after the chunk loop.
+struct PassBorder {
+    float bcol[2], brow[2], corner, xbs;
+    __device__ __forceinline__ void init() { bcol[0] = bcol[1] = brow[0] = brow[1] = corner = xbs = 0.0f; }
+};
+template <int NBY, bool kColSum, int kB = 0>
+__device__ __forceinline__ void pass16(const float* X, const float* Y, int ldy, int i, int g, f32x4 (&acc)[2][NBY], float (&cs)[2],
+                                       PassBorder& pb) {
+    float a0[4], a1[4], b0[4], b1[4], xb[4], yb[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int ed = s + 4 * g;
@@ -1012,6 +664,8 @@ __device__ __forceinline__ void pass16(const float* X, const float* Y, int ldy, 
         a1[s] = X[ed * Chunk16::LD + 16 + i];
         b0[s] = Y[ed * ldy + i];
         b1[s] = (NBY == 2) ? Y[ed * ldy + 16 + i] : 0.0f;
+        xb[s] = kB ? X[ed * Chunk16::LD + 32] : 0.0f;
+        yb[s] = (kB && NBY == 2) ? Y[ed * ldy + 32] : 0.0f;
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -1022,27 +676,42 @@ __device__ __forceinline__ void pass16(const float* X, const float* Y, int ldy, 
             acc[0][1] = mfma16(a0[s], b1[s], acc[0][1]);
             acc[1][1] = mfma16(a1[s], b1[s], acc[1][1]);
         }
+        if constexpr (kB == 1) {
+            pb.brow[0] = fmaf(xb[s], b0[s], pb.brow[0]);
+            if constexpr (NBY == 2) {
+                pb.brow[1] = fmaf(xb[s], b1[s], pb.brow[1]);
+                pb.bcol[0] = fmaf(a0[s], yb[s], pb.bcol[0]);
+                pb.bcol[1] = fmaf(a1[s], yb[s], pb.bcol[1]);
+                pb.corner = fmaf(xb[s], yb[s], pb.corner);
+                if (kColSum) pb.xbs += xb[s];
+            }
+        }
     }
 }
 
 constexpr int kBwd16Waves = 8;
+#ifndef EQ_BWD16_NW33
+#define EQ_BWD16_NW33 8                // waves per workgroup (= 2 x waves per SIMD) of the hidden_nf = 33 variant
+#endif
+constexpr int bwd16_waves(int kB) { return kB ? EQ_BWD16_NW33 : kBwd16Waves; }
 
-template <int H, int A>
-__global__ __launch_bounds__(512) void edge_bwd16_kernel(const float* __restrict__ lw, const int* __restrict__ row,
+template <int H, int A, int kB = 0>
+__global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const float* __restrict__ lw, const int* __restrict__ row,
                                                          const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                          const float* __restrict__ x, const float* __restrict__ P,
                                                          const float* __restrict__ dagg, const float* __restrict__ Gx, int n_edges,
                                                          int chunk, float* __restrict__ dt1_out, float* __restrict__ gxr_out,
                                                          float* __restrict__ gxc_out, float* __restrict__ slab) {
     using C = Chunk16;
-    using SB = Slabs<32>;
+    constexpr int F = 32 + kB, FP = 32 + 4 * kB;
+    using SB = Slabs<F>;
+    constexpr int NW = bwd16_waves(kB);
     constexpr int kScratch = C::bwd_size > SB::edge ? C::bwd_size : SB::edge;      // reused for the waves' slab copies
-    __shared__ __attribute__((aligned(16))) float wsm_[W16::bwd_size];
-    __shared__ __attribute__((aligned(16))) float scratch[kBwd16Waves][kScratch];
+    __shared__ __attribute__((aligned(16))) float wsm_[W16::image_size(true, kB)];
+    __shared__ __attribute__((aligned(16))) float scratch[NW][kScratch];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
-    const int wave = blockIdx.x * kBwd16Waves + wv, n_waves = gridDim.x * kBwd16Waves;
     EQ_STAMP(0);
-    stage_w16<H, A, true, 512>(wsm_, lw);
+    stage_w16<H, A, true, 64 * NW, kB>(wsm_, lw);
     __syncthreads();
     EQ_STAMP(1);
     float* sc = scratch[wv];
@@ -1057,6 +726,9 @@ __global__ __launch_bounds__(512) void edge_bwd16_kernel(const float* __restrict
     f32x4 acc6[2][2], acc2[2][2], accg[2][1];
     float cs_b6[2] = {0.0f, 0.0f}, cs_b2[2] = {0.0f, 0.0f}, cs_none[2] = {0.0f, 0.0f};
     f32x4 ls_w7[2], ls_gam[2], ls_bet[2];             // dw7, dgamma, dbeta: per-lane running sums, reduced once after the loop
+    PassBorder pb6, pb2, pbg;                          // hidden_nf = 33: row / column 32 of dW6, dW2, row 32 of dWgeo
+    float lsb_w7 = 0.0f, lsb_gam = 0.0f, lsb_bet = 0.0f;     // ... and entry 32 of dw7, dgamma, dbeta (every lane of an edge adds the same)
+    pb6.init(); pb2.init(); pbg.init();
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         ls_w7[a] = splat4(0.0f); ls_gam[a] = splat4(0.0f); ls_bet[a] = splat4(0.0f);
@@ -1071,14 +743,15 @@ __global__ __launch_bounds__(512) void edge_bwd16_kernel(const float* __restrict
     // (shared centre nodes) to every workgroup; waves 0..3 take the even half-rounds, waves 4..7 the odd ones.  Waves w and
     // w + 4 share a SIMD, so every SIMD of the chip gets the same number of chunks +- 1 (wave-linear rounds gave the CUs of
     // the low workgroups a whole extra chunk per wave: 2 or 3 of the 2.5 per wave at one 2 048-point pair).
-    const int ch_step = gridDim.x * kBwd16Waves;
-    int ch = (blockIdx.x + (wv >> 2) * gridDim.x) * 4 + (wv & 3);
+    const int ch_step = gridDim.x * NW;
+    int ch = NW == 8 ? (blockIdx.x + (wv >> 2) * gridDim.x) * 4 + (wv & 3) : blockIdx.x * NW + wv;
     int e = ch < n_chunks ? edge_of(ch) : 0;
     int r = row[e], c = col[e];
     for (; ch < n_chunks; ch += ch_step) {
         int off = 0;
         asm volatile("" : "+v"(off));
         const float* wsm = wsm_ + off;
+        const float* bord = wsm + W16::border_base(true);
         const int base = ch * chunk, cnt = min(chunk, n_edges - base);
         const bool mine = lane < cnt;
         EQ_STAMP(2);
@@ -1090,13 +763,15 @@ __global__ __launch_bounds__(512) void edge_bwd16_kernel(const float* __restrict
         const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
         __builtin_amdgcn_wave_barrier();
         // first sub-tile's projection rows and dagg row: in flight with the coordinate gathers
-        PRows pw;
+        PRowsT<kB> pw;
         f32x4 da[2];
+        float dab = 0.0f;
         {
             const int rr = idx_r[i];
             pw.load(P, rr, idx_c[i], g);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) da[b] = ldg4(dagg + (size_t)rr * 32 + 16 * b + 4 * g);
+            for (int b = 0; b < 2; ++b) da[b] = ldg4(dagg + (size_t)rr * FP + 16 * b + 4 * g);
+            if (kB) dab = dagg[(size_t)rr * FP + 32];
         }
         const int chn = ch + ch_step;                  // the next chunk's indices
         int rn = r, cn = c, en = e;
@@ -1119,20 +794,27 @@ __global__ __launch_bounds__(512) void edge_bwd16_kernel(const float* __restrict
             const bool valid = el < cnt;
             const float ds = ds_buf[el];
             float* geo_rows = sc + C::o_geo + sub * 16 * C::GS;
-            PRows pn;                                  // next sub-tile's rows (the last one re-requests its own: harmless)
+            // next sub-tile's rows, requested before this one computes (the last one re-requests its own: harmless).  hidden_nf
+            // 33 has no registers to hold them (52 spilled at the 256 cap): it requests its rows when it needs them.
+            constexpr bool kAhead = (kB == 0) || (EQ_BWD16_NW33 == 4);
+            PRowsT<kB> pn;
             f32x4 dan[2];
-            {
-                const int eln = (sub + 1 < n_sub ? sub + 1 : sub) * 16 + i;
+            float danb = 0.0f;
+            if (kAhead || sub > 0) {
+                const int eln = (kAhead ? (sub + 1 < n_sub ? sub + 1 : sub) : sub) * 16 + i;
                 const int rrn = idx_r[eln];
                 pn.load(P, rrn, idx_c[eln], g);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) dan[b] = ldg4(dagg + (size_t)rrn * 32 + 16 * b + 4 * g);
+                for (int b = 0; b < 2; ++b) dan[b] = ldg4(dagg + (size_t)rrn * FP + 16 * b + 4 * g);
+                if (kB) danb = dagg[(size_t)rrn * FP + 32];
+                if (!kAhead) { pw = pn; da[0] = dan[0]; da[1] = dan[1]; dab = danb; }
             }
             Sub16 o;
-            tile_forward16(wsm, geo_rows + i * C::GS, pw, i, g, o);
+            tile_forward16<kB>(wsm, bord, geo_rows + i * C::GS, pw, i, g, o);
             if (g == 0) s_buf[el] = o.s;
             // ---- coord head backward: s = w7 . SiLU(q)
             f32x4 dq[2];
+            float dqb = 0.0f;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const f32x4 w7 = lds4(wsm + W16::o_vec + 4 * 32 + 16 * b + 4 * g);
@@ -1142,18 +824,27 @@ __global__ __launch_bounds__(512) void edge_bwd16_kernel(const float* __restrict
                 st4(X + i * C::LD + 16 * b + 4 * g, dq[b]);
                 st4(Y + i * C::LD + 16 * b + 4 * g, o.m[b]);
             }
+            if constexpr (kB == 1) {
+                lsb_w7 = fmaf(o.qb * o.sgqb, ds, lsb_w7);
+                dqb = bord[W16::b_sc + 6] * ds * (o.sgqb * (1.0f + o.qb * (1.0f - o.sgqb)));
+                if (g == 0) { X[i * C::LD + 32] = dqb; Y[i * C::LD + 32] = o.mb; }
+            }
             __builtin_amdgcn_wave_barrier();
-            pass16<2, true>(X, Y, C::LD, i, g, acc6, cs_b6);              // dW6 += dq^T m ; db6 += sum dq
+            pass16<2, true, kB>(X, Y, C::LD, i, g, acc6, cs_b6, pb6);     // dW6 += dq^T m ; db6 += sum dq
             __builtin_amdgcn_wave_barrier();
             EQ_STAMP(10);
             // ---- dm = dagg[row] + W6^T dq   (padding edges: dq = 0 and dagg masked)
             f32x4 dm[2];
+            float dmb = 0.0f;
 #pragma unroll
             for (int b = 0; b < 2; ++b) dm[b] = valid ? da[b] : splat4(0.0f);
             mv16(wsm + W16::o_w6t, i, g, dq, dm);
+            if constexpr (kB == 1)      // W6^T: its column 32 is W6's row 32 and vice versa
+                dmb = (valid ? dab : 0.0f) + mv16_border(bord + W16::b_w6row, bord + W16::b_w6col, bord[W16::b_sc + 1], g, dq, dqb, dm);
             EQ_STAMP(11);
             // ---- LayerNorm backward
             f32x4 du[2];
+            float dub = 0.0f;
             {
                 float p1 = 0.0f, p2 = 0.0f;
 #pragma unroll
@@ -1164,9 +855,18 @@ __global__ __launch_bounds__(512) void edge_bwd16_kernel(const float* __restrict
                     p1 += hsum4(du[b]);
                     p2 += hsum4(du[b] * o.xhat[b]);
                 }
-                const float m1 = gsum(p1) * (1.0f / 32.0f), m2 = gsum(p2) * (1.0f / 32.0f);
+                float m1 = gsum(p1), m2 = gsum(p2);
+                if constexpr (kB == 1) {
+                    lsb_gam = fmaf(dmb, o.xhatb, lsb_gam);
+                    lsb_bet += dmb;
+                    dub = dmb * bord[W16::b_sc + 3];
+                    m1 += dub;
+                    m2 = fmaf(dub, o.xhatb, m2);
+                }
+                m1 *= (1.0f / F); m2 *= (1.0f / F);
 #pragma unroll
                 for (int b = 0; b < 2; ++b) du[b] = splat4(o.rstd) * (du[b] - splat4(m1) - o.xhat[b] * splat4(m2));
+                if constexpr (kB == 1) dub = o.rstd * (dub - m1 - o.xhatb * m2);
             }
             f32x4 sgp[2];
 #pragma unroll
@@ -1176,21 +876,35 @@ __global__ __launch_bounds__(512) void edge_bwd16_kernel(const float* __restrict
                 st4(X + i * C::LD + 16 * b + 4 * g, du[b]);
                 st4(Y + i * C::LD + 16 * b + 4 * g, o.t1[b] * sg);
             }
+            if constexpr (kB == 1) {
+                if (g == 0) { X[i * C::LD + 32] = dub; Y[i * C::LD + 32] = o.t1b * o.sg1b; }
+            }
             __builtin_amdgcn_wave_barrier();
-            pass16<2, true>(X, Y, C::LD, i, g, acc2, cs_b2);              // dW2 += du^T SiLU(t1) ; db2 += sum du
+            pass16<2, true, kB>(X, Y, C::LD, i, g, acc2, cs_b2, pb2);     // dW2 += du^T SiLU(t1) ; db2 += sum du
             __builtin_amdgcn_wave_barrier();
             EQ_STAMP(12);
             // ---- dt1 = (W2^T du) * SiLU'(t1)
             f32x4 dt1[2] = {splat4(0.0f), splat4(0.0f)};
+            float dt1b = 0.0f;
             mv16(wsm + W16::o_w2t, i, g, du, dt1);
+            if constexpr (kB == 1) {
+                dt1b = mv16_border(bord + W16::b_w2row, bord + W16::b_w2col, bord[W16::b_sc + 0], g, du, dub, dt1);
+                dt1b *= o.sg1b * (1.0f + o.t1b * (1.0f - o.sg1b));
+            }
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 dt1[b] *= sgp[b];
                 st4(X + i * C::LD + 16 * b + 4 * g, dt1[b]);
-                if (valid) st4(dt1_out + (size_t)(base + el) * 32 + 16 * b + 4 * g, dt1[b]);
+                if (valid) st4(dt1_out + (size_t)(base + el) * FP + 16 * b + 4 * g, dt1[b]);
+            }
+            if constexpr (kB == 1) {
+                if (g == 0) {
+                    X[i * C::LD + 32] = dt1b;
+                    if (valid) st4(dt1_out + (size_t)(base + el) * FP + 32, f32x4{dt1b, 0.0f, 0.0f, 0.0f});
+                }
             }
             __builtin_amdgcn_wave_barrier();
-            pass16<1, false>(X, geo_rows, C::GS, i, g, accg, cs_none);     // dWgeo | dw_attr += dt1^T [geo, attr]
+            pass16<1, false, kB>(X, geo_rows, C::GS, i, g, accg, cs_none, pbg);     // dWgeo | dw_attr += dt1^T [geo, attr]
             // ---- dgeo = Wgeo^T dt1: rows 4 g + r of a 16-row product, left in the edge's (now consumed) geometry row
             f32x4 dg = splat4(0.0f);
 #pragma unroll
@@ -1199,11 +913,11 @@ __global__ __launch_bounds__(512) void edge_bwd16_kernel(const float* __restrict
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) dg = mfma16(a[rq], dt1[b][rq], dg);
             }
+            if constexpr (kB == 1) dg += lds4(bord + W16::b_wgrow + 4 * g) * splat4(dt1b);
             __builtin_amdgcn_wave_barrier();
             st4(geo_rows + i * C::GS + 4 * g, dg);
             __builtin_amdgcn_wave_barrier();
-            pw = pn;
-            da[0] = dan[0]; da[1] = dan[1];
+            if (kAhead) { pw = pn; da[0] = dan[0]; da[1] = dan[1]; dab = danb; }
             EQ_STAMP(13);
         }
         // ---- back: one lane per edge, geometry backward (the geometry forward is recomputed from the stashed coordinates:
@@ -1229,19 +943,31 @@ __global__ __launch_bounds__(512) void edge_bwd16_kernel(const float* __restrict
     }
 
     // ---- partial sums of the waves: every wave writes a slab copy into its scratch, all threads add the copies in fixed order
+    auto lane16_sum = [](float v) {                    // over the 16 lanes (edges) of a group
+#pragma unroll
+        for (int o_ = 1; o_ <= 8; o_ <<= 1) v += __shfl_xor(v, o_, 64);
+        return v;
+    };
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         cs_b6[b] = gsum(cs_b6[b]);
         cs_b2[b] = gsum(cs_b2[b]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                   // per-lane sums: over the 16 edges (lanes) of the group
-#pragma unroll
-            for (int o_ = 1; o_ <= 8; o_ <<= 1) {
-                ls_w7[b][k] += __shfl_xor(ls_w7[b][k], o_, 64);
-                ls_gam[b][k] += __shfl_xor(ls_gam[b][k], o_, 64);
-                ls_bet[b][k] += __shfl_xor(ls_bet[b][k], o_, 64);
-            }
+            ls_w7[b][k] = lane16_sum(ls_w7[b][k]);
+            ls_gam[b][k] = lane16_sum(ls_gam[b][k]);
+            ls_bet[b][k] = lane16_sum(ls_bet[b][k]);
         }
+        if constexpr (kB == 1) {
+            pb6.bcol[b] = gsum(pb6.bcol[b]); pb6.brow[b] = gsum(pb6.brow[b]);
+            pb2.bcol[b] = gsum(pb2.bcol[b]); pb2.brow[b] = gsum(pb2.brow[b]);
+        }
+    }
+    if constexpr (kB == 1) {
+        pbg.brow[0] = gsum(pbg.brow[0]);
+        pb6.corner = gsum(pb6.corner); pb2.corner = gsum(pb2.corner);
+        pb6.xbs = gsum(pb6.xbs); pb2.xbs = gsum(pb2.xbs);
+        lsb_w7 = lane16_sum(lsb_w7); lsb_gam = lane16_sum(lsb_gam); lsb_bet = lane16_sum(lsb_bet);     // g = 0's copy is written
     }
     __builtin_amdgcn_wave_barrier();
     {
@@ -1253,8 +979,8 @@ __global__ __launch_bounds__(512) void edge_bwd16_kernel(const float* __restrict
                 const int orow = 16 * bx + 4 * g + k;
 #pragma unroll
                 for (int by = 0; by < 2; ++by) {
-                    sl[SB::e_w2 + orow * 32 + 16 * by + i] = acc2[bx][by][k];
-                    sl[SB::e_w6 + orow * 32 + 16 * by + i] = acc6[bx][by][k];
+                    sl[SB::e_w2 + orow * F + 16 * by + i] = acc2[bx][by][k];
+                    sl[SB::e_w6 + orow * F + 16 * by + i] = acc6[bx][by][k];
                 }
                 sl[SB::e_geo + orow * 16 + i] = accg[bx][0][k];
                 if (i == 0) {
@@ -1268,14 +994,28 @@ __global__ __launch_bounds__(512) void edge_bwd16_kernel(const float* __restrict
             for (int bx = 0; bx < 2; ++bx) {
                 sl[SB::e_b2 + 16 * bx + i] = cs_b2[bx];
                 sl[SB::e_b6 + 16 * bx + i] = cs_b6[bx];
+                if constexpr (kB == 1) {
+                    sl[SB::e_w6 + (16 * bx + i) * F + 32] = pb6.bcol[bx];      // column 32, rows 0..31
+                    sl[SB::e_w6 + 32 * F + 16 * bx + i] = pb6.brow[bx];        // row 32, columns 0..31
+                    sl[SB::e_w2 + (16 * bx + i) * F + 32] = pb2.bcol[bx];
+                    sl[SB::e_w2 + 32 * F + 16 * bx + i] = pb2.brow[bx];
+                }
+            }
+            if constexpr (kB == 1) {
+                sl[SB::e_geo + 32 * 16 + i] = pbg.brow[0];
+                if (i == 0) {
+                    sl[SB::e_w6 + 32 * F + 32] = pb6.corner; sl[SB::e_w2 + 32 * F + 32] = pb2.corner;
+                    sl[SB::e_b6 + 32] = pb6.xbs; sl[SB::e_b2 + 32] = pb2.xbs;
+                    sl[SB::e_w7 + 32] = lsb_w7; sl[SB::e_gam + 32] = lsb_gam; sl[SB::e_bet + 32] = lsb_bet;
+                }
             }
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < SB::edge; t += 512) {
+    for (int t = threadIdx.x; t < SB::edge; t += 64 * NW) {
         float a = scratch[0][t];
 #pragma unroll
-        for (int w = 1; w < kBwd16Waves; ++w) a += scratch[w][t];
+        for (int w = 1; w < NW; ++w) a += scratch[w][t];
         slab[(size_t)blockIdx.x * SB::edge + t] = a;
     }
     EQ_STAMP(15);
@@ -1287,21 +1027,13 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
                            hipStream_t s, int* n_slabs) {
     const int E = g->n_edges;
     static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1 or 4 heads) or 33 (1 head)");
-    if constexpr (F == 32) {               // the 16-edge formulation: one 8-wave workgroup per CU, persistent
-        const int chunk = edge_chunk_for(E, 256 * kBwd16Waves);
-        int blocks = ceil_div(ceil_div(E, chunk), kBwd16Waves);
+    {                                      // the 16-edge formulation (hidden_nf 33: with the border feature): one 8-wave workgroup per CU, persistent
+        constexpr int NW = bwd16_waves(F - 32);
+        const int chunk = edge_chunk_for(E, 256 * NW);
+        int blocks = ceil_div(ceil_div(E, chunk), NW);
         blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
-        hipLaunchKernelGGL((edge_bwd16_kernel<H, A>), dim3(blocks), dim3(512), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
+        hipLaunchKernelGGL((edge_bwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * NW), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
                            E, chunk, dt1, gxr, gxc, slab);
-        *n_slabs = blocks;
-    } else {
-        // hidden_nf 33: 32-edge tiles with a border feature (egnn_mfma.h), persistent waves, one workgroup per CU (the kernel
-        // runs at one wave per SIMD): the weight staging and the slab epilogue are paid 256 times, not once per 4 tiles
-        const int tiles = ceil_div(E, 32);
-        int blocks = ceil_div(tiles, 4);
-        blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
-        hipLaunchKernelGGL((edge_bwd_mfma_kernel<H, A, 1>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx, E,
-                           dt1, gxr, gxc, slab);
         *n_slabs = blocks;
     }
     return 0;

@@ -2,13 +2,12 @@
 // in one launch per stage.
 //
 // Per layer two kernels (reference E_GCL.forward :280-289):
-//   edge kernel : one lane per edge.  The 77-wide concat [h_r|h_c|geo|attr] (:238-242) is
-//                 never built: W1 is split into [W_src | W_tgt | W_geo | w_attr]; W_src*h and
-//                 W_tgt*h + b1 are projected ONCE PER NODE (P buffer) by the previous node
-//                 kernel, so an edge only adds two gathered 128-B rows and a 13-column
-//                 geometry product.  Then SiLU, block-diagonal W2, LayerNorm, coord MLP, all
-//                 in registers with wave-uniform (scalar-loaded) weights.  Writes m_e and
-//                 trans_e once.
+//   edge kernel : a wave per chunk of <= 64 edges, 16-edge sub-tiles on v_mfma_f32_16x16x4_f32 (egnn_mfma16.h).  The
+//                 77-wide concat [h_r|h_c|geo|attr] (:238-242) is never built: W1 is split into
+//                 [W_src | W_tgt | W_geo | w_attr]; W_src*h and W_tgt*h + b1 are projected ONCE PER NODE (P buffer) by
+//                 the previous node kernel, so an edge only adds two gathered rows and a 13-column geometry
+//                 product.  Then SiLU, block-diagonal W2, LayerNorm, coord MLP as matrix products with the weights
+//                 read from an LDS image.  Writes m_e and trans_e once, at the edge's position in aggregation order.
 //   node kernel : G lanes per node (lane = feature).  Sums m_e / trans_e over the node's
 //                 incoming-edge list in ascending edge id (atomic-free, bitwise reproducible,
 //                 the CPU scatter_add_ order of unsorted_segment_sum :343-348), node MLP with
@@ -60,55 +59,6 @@ __global__ __launch_bounds__(256) void embed_in_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------
-// edge kernel, MFMA formulation (hidden_nf = 32 + B): one wave per 32-edge tile
-// ---------------------------------------------------------------------------------------
-template <int H, int A, int B = 0>
-__global__ __launch_bounds__(256) void edge_fwd_mfma_kernel(const float* __restrict__ lw, const int* __restrict__ row,
-                                                            const int* __restrict__ col, const float* __restrict__ edge_attr,
-                                                            const float* __restrict__ x, const float* __restrict__ P,
-                                                            const int* __restrict__ rinv, int n_edges, float* __restrict__ m_out,
-                                                            float* __restrict__ trans_out) {
-    constexpr int FP = 32 + 4 * B, PS = 2 * FP;          // hidden_nf = 32 + B, rows padded to 16 bytes
-    const int lane = threadIdx.x & 63, el = lane & 31, h = lane >> 5;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
-    __shared__ float wsm[TileWeightsLdsT<B>::size];
-    EQ_STAMP(0);
-    stage_tile_weights<H, A, B>(wsm, lw);
-    __syncthreads();
-    TileWeights<H, A, false, B> W;
-    W.load(wsm, lane);
-    EQ_STAMP(1);
-    const int tiles = (n_edges + 31) / 32;
-    for (int tile = wave; tile < tiles; tile += n_waves) {
-        W.refresh();
-        const int e_raw = tile * 32 + el;
-        const bool valid = e_raw < n_edges;
-        const int e = valid ? e_raw : n_edges - 1;
-        const int r = row[e], c = col[e];
-        EQ_STAMP(2);
-        float xr[3], xc[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { xr[i] = x[(size_t)r * 3 + i]; xc[i] = x[(size_t)c * 3 + i]; }
-        EdgeGeo eg;
-        edge_geometry(xr, xc, eg);
-        EQ_STAMP(3);
-        const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
-        TileFwd o;
-        tile_forward<H, A, false, B>(W, P + (size_t)r * PS, P + (size_t)c * PS + FP, eg, attr, h, o);
-        if (valid) {
-            // stored at the edge's position in the by-row (aggregation) order: node_fwd then streams its segment contiguously
-            const size_t at = (size_t)rinv[e];
-            store_half_row(m_out + at * FP, h, o.m);
-            if (B) store_border(m_out + at * FP, h, o.mb);
-            if (h == 0)
-                reinterpret_cast<float4*>(trans_out)[at] = make_float4(eg.d[0] * o.s, eg.d[1] * o.s, eg.d[2] * o.s, 0.0f);   // :264
-        }
-        EQ_STAMP(7);
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------
 // edge kernel, 16-edge MFMA formulation (hidden_nf == 32; egnn_mfma16.h): a wave per chunk of <= 64 edges.
 // Latency chain of a chunk: indices (requested one chunk ahead) -> coordinate gathers + the first sub-tile's projection
 // rows together -> geometry -> sub-tiles (each requests the next one's projection rows before it computes).
@@ -118,19 +68,26 @@ constexpr int kFwd16Waves = 4;
 #define EQ_FWD16_OCC 3                 // 4-wave workgroups per CU (= waves per SIMD) the register budget is set for
 #endif
 
-template <int H, int A>
-__global__ __launch_bounds__(64 * kFwd16Waves, EQ_FWD16_OCC) void edge_fwd16_kernel(const float* __restrict__ lw, const int* __restrict__ row,
+// workgroups per CU the register budget is set for: hidden_nf 33 carries the border scalars of two row sets and spills at 168
+#ifndef EQ_FWD16_OCC33
+#define EQ_FWD16_OCC33 2
+#endif
+constexpr int fwd16_occ(int kB) { return kB ? EQ_FWD16_OCC33 : EQ_FWD16_OCC; }
+
+template <int H, int A, int kB = 0>
+__global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_kernel(const float* __restrict__ lw, const int* __restrict__ row,
                                                          const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                          const float* __restrict__ x, const float* __restrict__ P,
                                                          const int* __restrict__ rinv, int n_edges, int chunk,
                                                          float* __restrict__ m_out, float* __restrict__ trans_out) {
     using C = Chunk16;
-    __shared__ __attribute__((aligned(16))) float wsm_[W16::fwd_size];
+    constexpr int FP = 32 + 4 * kB;                    // hidden_nf = 32 + kB, rows padded to 16 bytes
+    __shared__ __attribute__((aligned(16))) float wsm_[W16::image_size(false, kB)];
     __shared__ __attribute__((aligned(16))) float scratch[kFwd16Waves][C::fwd_size];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int wave = blockIdx.x * kFwd16Waves + wv, n_waves = gridDim.x * kFwd16Waves;
     EQ_STAMP(0);
-    stage_w16<H, A, false, 64 * kFwd16Waves>(wsm_, lw);
+    stage_w16<H, A, false, 64 * kFwd16Waves, kB>(wsm_, lw);
     __syncthreads();
     EQ_STAMP(1);
     float* sc = scratch[wv];
@@ -148,8 +105,9 @@ __global__ __launch_bounds__(64 * kFwd16Waves, EQ_FWD16_OCC) void edge_fwd16_ker
     int r = row[e], c = col[e], at = rinv[e];
     for (; ch < n_chunks; ch += ch_step) {
         int off = 0;
-        asm volatile("" : "+v"(off));                  // keeps the weight reads inside the loop (egnn_mfma.h refresh())
+        asm volatile("" : "+v"(off));                  // an opaque zero offset keeps the (loop-invariant) weight reads inside the loop
         const float* wsm = wsm_ + off;
+        const float* bord = wsm + W16::border_base(false);
         const int cnt = min(chunk, n_edges - ch * chunk);
         const bool mine = lane < cnt;
         EQ_STAMP(2);
@@ -160,7 +118,7 @@ __global__ __launch_bounds__(64 * kFwd16Waves, EQ_FWD16_OCC) void edge_fwd16_ker
         for (int k = 0; k < 3; ++k) { xr[k] = x[(size_t)r * 3 + k]; xc[k] = x[(size_t)c * 3 + k]; }
         const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
         __builtin_amdgcn_wave_barrier();
-        PRows pw;                                      // first sub-tile's projection rows: in flight with the coordinate gathers
+        PRowsT<kB> pw;                                 // first sub-tile's projection rows: in flight with the coordinate gathers
         pw.load(P, idx_r[i], idx_c[i], g);
         const int chn = ch + ch_step;                  // the next chunk's indices
         int rn = r, cn = c, atn = at, en = e;
@@ -174,19 +132,22 @@ __global__ __launch_bounds__(64 * kFwd16Waves, EQ_FWD16_OCC) void edge_fwd16_ker
         const int n_sub = (cnt + 15) >> 4;
         for (int sub = 0; sub < n_sub; ++sub) {
             const int el = sub * 16 + i;
-            PRows pn;                                  // next sub-tile's rows (the last one re-requests its own: harmless)
+            PRowsT<kB> pn;                             // next sub-tile's rows (the last one re-requests its own: harmless)
             {
                 const int eln = (sub + 1 < n_sub ? sub + 1 : sub) * 16 + i;
                 pn.load(P, idx_r[eln], idx_c[eln], g);
             }
             Sub16 o;
-            tile_forward16(wsm, sc + C::o_geo + el * C::GS, pw, i, g, o);
+            tile_forward16<kB>(wsm, bord, sc + C::o_geo + el * C::GS, pw, i, g, o);
             if (el < cnt) {
                 // stored at the edge's position in the by-row (aggregation) order: node_fwd then streams its segment contiguously
-                float* dst = m_out + (size_t)pos[el] * 32 + 4 * g;
+                float* dst = m_out + (size_t)pos[el] * FP + 4 * g;
                 st4(dst, o.m[0]);
                 st4(dst + 16, o.m[1]);
-                if (g == 0) s_buf[el] = o.s;
+                if (g == 0) {
+                    s_buf[el] = o.s;
+                    if (kB) st4(dst + 32, f32x4{o.mb, 0.0f, 0.0f, 0.0f});
+                }
             }
             pw = pn;
             EQ_STAMP(10);
@@ -208,18 +169,13 @@ static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const floa
                             float* m, float* trans, hipStream_t s) {
     const int E = g->n_edges;
     static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1 or 4 heads) or 33 (1 head)");
-    if constexpr (F == 32) {               // the 16-edge formulation; EQ_FWD16_OCC 4-wave workgroups per CU
-        const int chunk = edge_chunk_for(E, 256 * 4 * EQ_FWD16_OCC);
+    {                                      // the 16-edge formulation (hidden_nf 33: with the border feature); EQ_FWD16_OCC 4-wave workgroups per CU
+        constexpr int occ = fwd16_occ(F - 32);
+        const int chunk = edge_chunk_for(E, 256 * 4 * occ);
         int blocks = ceil_div(ceil_div(E, chunk), kFwd16Waves);
-        blocks = blocks < 1 ? 1 : (blocks > 256 * EQ_FWD16_OCC ? 256 * EQ_FWD16_OCC : blocks);
-        hipLaunchKernelGGL((edge_fwd16_kernel<H, A>), dim3(blocks), dim3(64 * kFwd16Waves), 0, s, lw, g->row, g->col, edge_attr, x, P, g->rinv,
-                           E, chunk, m, trans);
-    } else {                               // hidden_nf 33: 32-edge tiles with a border feature (egnn_mfma.h)
-        const int tiles = ceil_div(E, 32);
-        int blocks = ceil_div(tiles, 4);          // one 32-edge tile per wave: latency is hidden across waves
-        blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-        hipLaunchKernelGGL((edge_fwd_mfma_kernel<H, A, 1>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P,
-                           g->rinv, E, m, trans);
+        blocks = blocks < 1 ? 1 : (blocks > 256 * occ ? 256 * occ : blocks);
+        hipLaunchKernelGGL((edge_fwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * kFwd16Waves), 0, s, lw, g->row, g->col, edge_attr, x, P,
+                           g->rinv, E, chunk, m, trans);
     }
 }
 
@@ -385,7 +341,10 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
     auto xbuf = [&](int l) { return training ? xs + (size_t)l * N * 3 : pp_x + (size_t)(l & 1) * N * 3; };
 
     const int node_groups = ceil_div(N, NS);
-    const int node_grid = node_groups < 2048 ? node_groups : 2048;
+#ifndef EQ_NODE_FWD_BLOCKS
+#define EQ_NODE_FWD_BLOCKS 2048
+#endif
+    const int node_grid = node_groups < EQ_NODE_FWD_BLOCKS ? node_groups : EQ_NODE_FWD_BLOCKS;
     hipLaunchKernelGGL((embed_in_kernel<F, H, A>), dim3(node_grid), dim3(256), 0, s, params, cfg->in_nf, ML.w_in,
                        ML.b_in, ML.layer0, h_in, x_in, N, hbuf(0), xbuf(0), P);
     for (int l = 0; l < L; ++l) {

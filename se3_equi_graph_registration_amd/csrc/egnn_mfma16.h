@@ -37,6 +37,9 @@ __device__ __forceinline__ float gsum(float v) {
 
 // LDS image of a layer's edge-MLP weights.  Row strides chosen so that the per-lane 16-byte operand fetches
 // (row = 16 bo + i, column 16 bi + 4 g) of every 16-lane ds_read_b128 group fall on distinct banks.
+// hidden_nf = 33 (kB = 1): the 32 x 32 cores stay on the matrix cores; feature 32 (the "border") is a scalar per edge held by
+// all four lanes of the edge -- its column of every matrix costs 8 FMAs per product, its row a per-lane partial dot product
+// and one gsum; the border vectors live in a small extra block of the image.
 struct W16 {
     static constexpr int WS = 40;                          // 32 x 32 matrices
     static constexpr int GS = 24;                          // Wgeo [32][16]: columns 0..11 geometry, 12 edge_attr, 13..15 zero
@@ -49,30 +52,50 @@ struct W16 {
     static constexpr int o_w6t = o_w2t + 32 * WS;
     static constexpr int o_wgt = o_w6t + 32 * WS;          // Wgeo^T [16][WS]
     static constexpr int bwd_size = o_wgt + 16 * WS;
+    // border block (kB = 1), relative to its base: W2[:,32] | W2[32,:] | W6[:,32] | W6[32,:] | Wgeo[32,:16] | scalars
+    static constexpr int b_w2col = 0, b_w2row = 32, b_w6col = 64, b_w6row = 96, b_wgrow = 128, b_sc = 144;
+    static constexpr int border_size = 152;                // scalars: W2[32][32], W6[32][32], b2, gamma, beta, b6, w7 of feature 32
+    static constexpr int image_size(bool bwd, int kB) { return (bwd ? bwd_size : fwd_size) + kB * border_size; }
+    static constexpr int border_base(bool bwd) { return bwd ? bwd_size : fwd_size; }
 };
 
 // global -> LDS, all of a thread's loads before its first store.  NT = threads of the workgroup.
-template <int H, int A, bool kBwd, int NT>
+template <int H, int A, bool kBwd, int NT, int kB = 0>
 __device__ __forceinline__ void stage_w16(float* sm, const float* __restrict__ lw) {
-    using LL = LP<32, H, A>;
-    constexpr int FH = 32 / H;
+    constexpr int F = 32 + kB;
+    using LL = LP<F, H, A>;
+    constexpr int FH = F / H;
     constexpr int PER = 1024 / NT, PG = (512 + NT - 1) / NT;
     float v2[PER], v6[PER], vg[PG];
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
         const int t = threadIdx.x + NT * u, i = t >> 5, k = t & 31;
         v2[u] = (i / FH == k / FH) ? lw[LL::w2_off(i, k)] : 0.0f;      // block-diagonal over the heads
-        v6[u] = lw[LL::w6 + t];
+        v6[u] = lw[LL::w6 + i * F + k];
     }
 #pragma unroll
     for (int u = 0; u < PG; ++u) {
         const int t = threadIdx.x + NT * u, i = (t >> 4) & 31, k = t & 15;
-        vg[u] = (t < 512 && k < kGeo + A) ? lw[LL::w1_off(i, 64 + k)] : 0.0f;
+        vg[u] = (t < 512 && k < kGeo + A) ? lw[LL::w1_off(i, 2 * F + k)] : 0.0f;
     }
     float vv = 0.0f;
     if (threadIdx.x < 160) {
         const int w = threadIdx.x >> 5, k = threadIdx.x & 31;
         vv = lw[w == 0 ? LL::b2_off(k) : (w == 1 ? LL::ln_g + k : (w == 2 ? LL::ln_b + k : (w == 3 ? LL::b6 + k : LL::w7 + k)))];
+    }
+    float vb = 0.0f;
+    if (kB && threadIdx.x < W16::border_size) {
+        const int t = threadIdx.x, k = t & 31;
+        if (t < 32) vb = lw[LL::w2_off(k, 32)];
+        else if (t < 64) vb = lw[LL::w2_off(32, k)];
+        else if (t < 96) vb = lw[LL::w6 + k * F + 32];
+        else if (t < 128) vb = lw[LL::w6 + 32 * F + k];
+        else if (t < 144) vb = (t - 128 < kGeo + A) ? lw[LL::w1_off(32, 2 * F + (t - 128))] : 0.0f;
+        else {
+            const int q = t - 144;
+            vb = q == 0 ? lw[LL::w2_off(32, 32)] : q == 1 ? lw[LL::w6 + 32 * F + 32] : q == 2 ? lw[LL::b2_off(32)] : q == 3 ? lw[LL::ln_g + 32]
+               : q == 4 ? lw[LL::ln_b + 32] : q == 5 ? lw[LL::b6 + 32] : q == 6 ? lw[LL::w7 + 32] : 0.0f;
+        }
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
@@ -93,6 +116,7 @@ __device__ __forceinline__ void stage_w16(float* sm, const float* __restrict__ l
         }
     }
     if (threadIdx.x < 160) sm[W16::o_vec + threadIdx.x] = vv;
+    if (kB && threadIdx.x < W16::border_size) sm[W16::border_base(kBwd) + threadIdx.x] = vb;
 }
 
 // acc[bo] += W v for a 32 x 32 LDS image `mat` (row stride WS): 4 ds_read_b128, 16 MFMAs.  For y = W^T v pass the
@@ -111,38 +135,64 @@ __device__ __forceinline__ void mv16(const float* mat, int i, int g, const f32x4
             acc[1] = mfma16(a[bi][1][r], v[bi][r], acc[1]);
         }
 }
+// border of y = W v (hidden_nf = 33): acc += W[:, 32] vb (column vector `col`), returns W[32, :32] . v + wcc vb (row vector `row`)
+__device__ __forceinline__ float mv16_border(const float* col, const float* row, float wcc, int g, const f32x4 (&v)[2], float vb,
+                                             f32x4 (&acc)[2]) {
+    float p = 0.0f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        acc[b] += lds4(col + 16 * b + 4 * g) * splat4(vb);
+        const f32x4 t = lds4(row + 16 * b + 4 * g) * v[b];
+        p += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+    return gsum(p) + wcc * vb;
+}
 
 __device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
     return f32x4{sigmoid_fast(v[0]), sigmoid_fast(v[1]), sigmoid_fast(v[2]), sigmoid_fast(v[3])};
 }
 __device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
-// forward state of one 16-edge sub-tile (what the backward needs of it)
+// forward state of one 16-edge sub-tile (what the backward needs of it); the *b members: feature 32 (hidden_nf = 33)
 struct Sub16 {
     f32x4 t1[2], sg1[2];          // pre-activation of the first edge-MLP layer, sigmoid(t1)
     f32x4 xhat[2], m[2];          // LayerNorm: normalised value, output (= the message m_ij)
     f32x4 q[2], sgq[2];           // coord-MLP pre-activation, sigmoid(q)
     float rstd, s;                // LayerNorm 1/std; coord scalar s = w7 . SiLU(q)   (:264)
+    float t1b, sg1b, xhatb, mb, qb, sgqb;
 };
 
-// the lane's share (features 16 b + 4 g + r) of the two per-node projection rows of an edge: W_src h[row], W_tgt h[col] + b1
-struct PRows {
+// the lane's share (features 16 b + 4 g + r, and the border feature) of the two per-node projection rows of an edge:
+// W_src h[row], W_tgt h[col] + b1.  FP = padded row of a [*, hidden_nf] buffer (32 or 36 floats).
+template <int kB>
+struct PRowsT {
+    static constexpr int FP = 32 + 4 * kB;
     f32x4 pr[2], pc[2];
+    float prb, pcb;
     __device__ __forceinline__ void load(const float* __restrict__ P, int r, int c, int g) {
+        const float* a = P + (size_t)r * (2 * FP);
+        const float* b_ = P + (size_t)c * (2 * FP) + FP;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            pr[b] = ldg4(P + (size_t)r * 64 + 16 * b + 4 * g);
-            pc[b] = ldg4(P + (size_t)c * 64 + 32 + 16 * b + 4 * g);
+            pr[b] = ldg4(a + 16 * b + 4 * g);
+            pc[b] = ldg4(b_ + 16 * b + 4 * g);
         }
+        prb = kB ? a[32] : 0.0f;
+        pcb = kB ? b_[32] : 0.0f;
     }
 };
+using PRows = PRowsT<0>;
 
-// wsm: the workgroup's weight image (through an opaque offset so the loop-invariant reads stay inside the loop);
-// geo_row: this edge's 16 geometry values in LDS; pw: its projection rows (already in registers).
-__device__ __forceinline__ void tile_forward16(const float* wsm, const float* geo_row, const PRows& pw, int i, int g, Sub16& o) {
+// wsm: the workgroup's weight image (through an opaque offset so the loop-invariant reads stay inside the loop), bord: its
+// border block; geo_row: this edge's 16 geometry values in LDS; pw: its projection rows (already in registers).
+template <int kB>
+__device__ __forceinline__ void tile_forward16(const float* wsm, const float* bord, const float* geo_row, const PRowsT<kB>& pw, int i,
+                                               int g, Sub16& o) {
+    constexpr float kInvF = 1.0f / (32 + kB);
     f32x4 acc[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[b] = pw.pr[b] + pw.pc[b];
+    o.t1b = 0.0f; o.sg1b = 0.0f; o.xhatb = 0.0f; o.mb = 0.0f; o.qb = 0.0f; o.sgqb = 0.0f;
     {   // + Wgeo [geo | attr]: K = 16, step s <-> geometry entry 4 g + s
         const f32x4 gv = lds4(geo_row + 4 * g);
         const f32x4 a0 = lds4(wsm + W16::o_wg + i * W16::GS + 4 * g), a1 = lds4(wsm + W16::o_wg + (16 + i) * W16::GS + 4 * g);
@@ -152,6 +202,7 @@ __device__ __forceinline__ void tile_forward16(const float* wsm, const float* ge
             acc[0] = mfma16(a0[s], gv[s], acc[0]);
             acc[1] = mfma16(a1[s], gv[s], acc[1]);
         }
+        if constexpr (kB == 1) o.t1b = pw.prb + pw.pcb + gsum(hsum4(lds4(bord + W16::b_wgrow + 4 * g) * gv));
     }
     f32x4 a1v[2], u[2];
 #pragma unroll
@@ -163,11 +214,17 @@ __device__ __forceinline__ void tile_forward16(const float* wsm, const float* ge
     }
     EQ_STAMP(5);
     mv16(wsm + W16::o_w2, i, g, a1v, u);
+    float ub = 0.0f;
+    if constexpr (kB == 1) {
+        o.sg1b = sigmoid_fast(o.t1b);
+        ub = bord[W16::b_sc + 2] + mv16_border(bord + W16::b_w2col, bord + W16::b_w2row, bord[W16::b_sc + 0], g, a1v, o.t1b * o.sg1b, u);
+    }
     EQ_STAMP(6);
-    // LayerNorm over the 32 features (biased variance, eps 1e-5; :249)
-    const float mean = gsum(hsum4(u[0]) + hsum4(u[1])) * (1.0f / 32.0f);
+    // LayerNorm over the hidden features (biased variance, eps 1e-5; :249)
+    const float mean = (gsum(hsum4(u[0]) + hsum4(u[1])) + ub) * kInvF;
     f32x4 c0 = u[0] - splat4(mean), c1 = u[1] - splat4(mean);
-    const float var = gsum(hsum4(c0 * c0) + hsum4(c1 * c1)) * (1.0f / 32.0f);
+    const float cb = ub - mean;
+    const float var = (gsum(hsum4(c0 * c0) + hsum4(c1 * c1)) + (kB ? cb * cb : 0.0f)) * kInvF;
     o.rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
     o.xhat[0] = c0 * splat4(o.rstd);
     o.xhat[1] = c1 * splat4(o.rstd);
@@ -179,6 +236,11 @@ __device__ __forceinline__ void tile_forward16(const float* wsm, const float* ge
     }
     EQ_STAMP(7);
     mv16(wsm + W16::o_w6, i, g, o.m, o.q);
+    if constexpr (kB == 1) {
+        o.xhatb = cb * o.rstd;
+        o.mb = fmaf(o.xhatb, bord[W16::b_sc + 3], bord[W16::b_sc + 4]);
+        o.qb = bord[W16::b_sc + 5] + mv16_border(bord + W16::b_w6col, bord + W16::b_w6row, bord[W16::b_sc + 1], g, o.m, o.mb, o.q);
+    }
     EQ_STAMP(8);
     float sp = 0.0f;
 #pragma unroll
@@ -188,6 +250,10 @@ __device__ __forceinline__ void tile_forward16(const float* wsm, const float* ge
         sp += hsum4(w7 * (o.q[b] * o.sgq[b]));
     }
     o.s = gsum(sp);
+    if constexpr (kB == 1) {
+        o.sgqb = sigmoid_fast(o.qb);
+        o.s = fmaf(bord[W16::b_sc + 6], o.qb * o.sgqb, o.s);
+    }
     EQ_STAMP(9);
 }
 
