@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default=None,
                     help="BASELINE.json configs: c2 = default (1 pair, 2048 pts); c3 = 16 pairs per step; c4 = one GPU's shard of the "
                          "KITTI batch (8 pairs x 4096 pts, F=33); c5 = eval sweep (8192 pts, k=32, 8 layers, inference)")
+    ap.add_argument("--edge-basis", choices=["frames", "irreps"], default="frames",
+                    help="frames = the reference's edge inputs; irreps = the fused irrep-basis message passing (SURVEY 8(f) N4, configs[2])")
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="repeat the timed block of --steps steps until this much time has been measured; report the median block")
     ap.add_argument("--allow-eager", action="store_true", help="N>1: fall back to eager launches if hipGraph capture fails (default: exit non-zero)")
@@ -72,7 +74,8 @@ def parse():
 
 def build_step(pkg, args, dev, world):
     torch.manual_seed(0)
-    egnn = pkg.EGNN(args.feat, args.feat, args.feat, in_edge_nf=1, device=dev, n_layers=args.layers, num_heads=args.heads)
+    egnn = pkg.EGNN(args.feat, args.feat, args.feat, in_edge_nf=1, device=dev, n_layers=args.layers, num_heads=args.heads,
+                    edge_basis=args.edge_basis)
     model = pkg.CrossAttentionPoseRegression(egnn, num_nodes=args.n, hidden_nf=args.feat, device=dev,
                                              fused_head=not args.aten_head).to(dev)
     egnn._ensure_flat()
@@ -489,7 +492,7 @@ def main():
                                    f"{args.n} pts, k={args.k}, {args.layers} EGNN layers, F={args.feat}, heads={args.heads}; "
                                    "kNN+index, EGNN fwd, pose head (Kabsch/SVD), "
                                    + ("no backward" if args.forward_only else "losses, backward, grad all-reduce, Adam"),
-                       "pairs_per_gpu": args.batch, "points": args.n, "k": args.k, "layers": args.layers,
+                       "pairs_per_gpu": args.batch, "points": args.n, "k": args.k, "layers": args.layers, "edge_basis": args.edge_basis,
                        "hipgraph": used_graph, "graph_mode": graph_mode, "parallelism": f"dp{world}", "params_finite": finite,
                        "reset_every": args.reset_every},
             "roofline": roof, "kernels": extra,

@@ -27,7 +27,7 @@ extern "C" {
 
 #define EQUIGSPR_EINVAL   (-1)  /* bad shape / size / null pointer                         */
 #define EQUIGSPR_ENOTSUP  (-2)  /* configuration outside the compiled kernel set             */
-#define EQUIGSPR_ABI_VERSION 6
+#define EQUIGSPR_ABI_VERSION 7
 
 /* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
  * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
@@ -40,7 +40,12 @@ typedef struct equigspr_egnn_config {
     int32_t in_edge_nf;  /* in_edge_nf (edge_attr width) */
     int32_t n_layers;
     int32_t num_heads;
+    int32_t edge_basis;  /* EQUIGSPR_BASIS_FRAMES: the reference's 12 geometry inputs (radial, dist, dot, frame vectors; train :128-181).
+                            EQUIGSPR_BASIS_IRREPS: rotation invariants from the degree <= 1 irrep basis kernels
+                            of tools/basis.py::get_basis contracted with the endpoint coordinates (csrc/egnn_math.h) */
 } equigspr_egnn_config;
+#define EQUIGSPR_BASIS_FRAMES 0
+#define EQUIGSPR_BASIS_IRREPS 1
 
 /* Graph in the device format every layer reuses (built once per batch of clouds).
  * row = message/aggregation index (= the NEIGHBOUR for torch_cluster.knn_graph output),

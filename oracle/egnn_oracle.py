@@ -136,6 +136,51 @@ def edge_geometry(x: Tensor, row: Tensor, col: Tensor):
 
 
 # --------------------------------------------------------------------------------------
+# N4: irrep-basis edge features.  No reference layer uses tools/basis.py, so there is nothing to import: this is
+# the DEFINITION the HIP kernels (csrc/egnn_math.h: edge_geometry_irreps) are checked against, written through the A16
+# restatement (oracle/sh_oracle.py::get_basis, itself pinned by the reference's SH vectors and basis properties).
+# --------------------------------------------------------------------------------------
+_BASIS_CACHE: Dict[str, object] = {}
+
+
+def edge_geometry_irreps(x: Tensor, row: Tensor, col: Tensor):
+    """Returns (coord_diff [E,3], geo [E,12]) with geo = [ |d|^2, |d|, x_r^T K_0 x_c, K^(1->0) x_r, K^(1->0) x_c,
+    x_r^T K_2 x_c, x_r^T K_2 x_r, x_c^T K_2 x_c, x_r^T K_0 x_r, x_c^T K_0 x_c, 0, 0 ], where K^(d_in->d_out)_J are the degree <= 1
+    kernels of ``get_basis(d, max_degree=1)`` (tools/basis.py:153-205) at the edge direction d = x_r - x_c.  All rotation
+    invariants.  Zero-length edges (self loops) have no direction: the direction-dependent part of K is dropped (dh = 0)."""
+    from . import sh_oracle as so
+    xr, xc = x[row], x[col]
+    diff = xr - xc
+    radial = torch.sum(diff ** 2, -1)
+    dist = torch.norm(diff, dim=1)
+    nz = dist > 0
+    cols = [radial, dist]
+    u, v = xr[nz], xc[nz]
+    B = so.get_basis(diff[nz].detach() if not diff.requires_grad else diff[nz], 1)
+    k10 = B["1,0"][:, 0, 0, 0, :, 0]                           # [n, 3]: d_in = 1 -> d_out = 0
+    k11 = B["1,1"][:, 0, :, 0, :, :]                           # [n, out 3, in 3, J 3]
+    con = lambda a, j, b: torch.einsum("ni,nij,nj->n", a, k11[..., j], b)  # noqa: E731
+    gen = [con(u, 0, v), (k10 * u).sum(-1), (k10 * v).sum(-1), con(u, 2, v), con(u, 2, u), con(v, 2, v), con(u, 0, u), con(v, 0, v)]
+    # constants of the direction-free part, read off the basis itself (K_0 = c0 I, K_2 = c2 (dh dh^T - I/3))
+    if "c" not in _BASIS_CACHE:
+        e = torch.tensor([[0.0, 0.0, 1.0]], dtype=torch.float64)
+        Be = so.get_basis(e, 1)["1,1"][0, 0, :, 0, :, :]
+        _BASIS_CACHE["c"] = (float(Be[0, 0, 0]), float(Be[2, 2, 2]) * 1.5)      # c0 ; c2 (K_2[z][z] = c2 * 2/3)
+    c0, c2 = _BASIS_CACHE["c"]
+    uz, vz = xr[~nz], xc[~nz]
+    p, a2, b2 = (uz * vz).sum(-1), (uz * uz).sum(-1), (vz * vz).sum(-1)
+    zero = torch.zeros_like(p)
+    deg = [c0 * p, zero, zero, -c2 * p / 3, -c2 * a2 / 3, -c2 * b2 / 3, c0 * a2, c0 * b2]
+    geo = x.new_zeros(row.shape[0], 12)
+    geo = geo.index_put((torch.arange(row.shape[0]),), torch.stack(cols + [zero.new_zeros(row.shape[0])] * 10, dim=1))
+    body = x.new_zeros(row.shape[0], 8)
+    body = body.index_put((torch.nonzero(nz).squeeze(1),), torch.stack(gen, dim=1))
+    body = body.index_put((torch.nonzero(~nz).squeeze(1),), torch.stack(deg, dim=1))
+    geo = torch.cat([geo[:, :2], body, geo[:, 10:]], dim=1)
+    return diff, geo
+
+
+# --------------------------------------------------------------------------------------
 # A7-A9  one E_GCL layer (train :185-289)
 # --------------------------------------------------------------------------------------
 def _num_heads(w: Dict[str, Tensor], prefix: str) -> int:
@@ -146,10 +191,15 @@ def _num_heads(w: Dict[str, Tensor], prefix: str) -> int:
 
 
 def egcl_layer(w: Dict[str, Tensor], prefix: str, h: Tensor, x: Tensor, row: Tensor, col: Tensor,
-               edge_attr: Optional[Tensor], return_intermediates: bool = False):
-    """One layer; ``prefix`` is e.g. ``"gcl_0."``.  Returns (h', x')."""
+               edge_attr: Optional[Tensor], return_intermediates: bool = False, edge_basis: str = "frames"):
+    """One layer; ``prefix`` is e.g. ``"gcl_0."``.  Returns (h', x').  ``edge_basis="irreps"``: the 12 geometry inputs are the
+    irrep-basis invariants of ``edge_geometry_irreps`` (extension N4) instead of the reference's."""
     n = h.shape[0]
-    diff, radial, dist, dot, so3 = edge_geometry(x, row, col)
+    if edge_basis == "irreps":
+        diff, geo = edge_geometry_irreps(x, row, col)
+        radial, dist, dot, so3 = geo[:, 0:1], geo[:, 1:2], geo[:, 2:3], geo[:, 3:12]
+    else:
+        diff, radial, dist, dot, so3 = edge_geometry(x, row, col)
     feats = [h[row], h[col], radial, dist, dot, so3]          # :238
     if edge_attr is not None:
         feats.append(edge_attr)                               # :240-241
@@ -184,13 +234,13 @@ def n_layers_of(w: Dict[str, Tensor]) -> int:
 
 
 def egnn_forward(w: Dict[str, Tensor], h: Tensor, x: Tensor, edges: Sequence[Tensor],
-                 edge_attr: Optional[Tensor], return_layers: bool = False):
+                 edge_attr: Optional[Tensor], return_layers: bool = False, edge_basis: str = "frames"):
     """EGNN.forward (train :328-340).  ``edges`` = [row, col]."""
     row, col = edges[0], edges[1]
     h = F.linear(h, w["embedding_in.weight"], w["embedding_in.bias"])         # :332
     per_layer = []
     for i in range(n_layers_of(w)):                                             # :333-334
-        h, x = egcl_layer(w, f"gcl_{i}.", h, x, row, col, edge_attr)
+        h, x = egcl_layer(w, f"gcl_{i}.", h, x, row, col, edge_attr, edge_basis=edge_basis)
         if return_layers:
             per_layer.append((h, x))
     h = F.linear(h, w["embedding_out.weight"], w["embedding_out.bias"])       # :337

@@ -19,7 +19,7 @@ KABSCH_AUX = 320
 
 class EgnnConfig(Structure):
     _fields_ = [("in_nf", c_int32), ("hidden_nf", c_int32), ("out_nf", c_int32),
-                ("in_edge_nf", c_int32), ("n_layers", c_int32), ("num_heads", c_int32)]
+                ("in_edge_nf", c_int32), ("n_layers", c_int32), ("num_heads", c_int32), ("edge_basis", c_int32)]
 
 
 class Graph(Structure):
@@ -104,7 +104,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if L.equigspr_abi_version() != 6:
+        if L.equigspr_abi_version() != 7:
             raise RuntimeError("libequigspr.so ABI version mismatch")
         _lib = L
     return _lib

@@ -59,7 +59,8 @@ inline bool config_supported(const equigspr_egnn_config* c) {
     const bool f_ok = (c->hidden_nf == 32 && (c->num_heads == 1 || c->num_heads == 4)) ||
                       (c->hidden_nf == 33 && c->num_heads == 1);
     return f_ok && c->in_nf >= 1 && c->in_nf <= 64 && c->out_nf >= 1 && c->out_nf <= 64 &&
-           (c->in_edge_nf == 0 || c->in_edge_nf == 1) && c->n_layers >= 1 && c->n_layers <= 16;
+           (c->in_edge_nf == 0 || c->in_edge_nf == 1) && c->n_layers >= 1 && c->n_layers <= 16 &&
+           (c->edge_basis == EQUIGSPR_BASIS_FRAMES || c->edge_basis == EQUIGSPR_BASIS_IRREPS);
 }
 
 }  // namespace eq

@@ -700,7 +700,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
                                                          const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                          const float* __restrict__ x, const float* __restrict__ P,
                                                          const float* __restrict__ dagg, const float* __restrict__ Gx, int n_edges,
-                                                         int chunk, float* __restrict__ dt1_out, float* __restrict__ gxr_out,
+                                                         int chunk, int basis, float* __restrict__ dt1_out, float* __restrict__ gxr_out,
                                                          float* __restrict__ gxc_out, float* __restrict__ slab) {
     using C = Chunk16;
     constexpr int F = 32 + kB, FP = 32 + 4 * kB;
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
         if (chn < n_chunks) { en = edge_of(chn); rn = row[en]; cn = col[en]; }
         {
             EdgeGeo eg;
-            edge_geometry(xr, xc, eg);
+            edge_geometry_mode(basis, xr, xc, eg);
             store_geo_row(sc + C::o_geo + lane * C::GS, eg, attr);
             ds_buf[lane] = mine ? dot3(eg.d, gxv) : 0.0f;           // dL/ds of the coord head (:264); 0 masks padding edges
             st4(front, f32x4{xr[0], xr[1], xr[2], xc[0]});
@@ -926,14 +926,14 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             const f32x4 f0 = lds4(front), f1 = lds4(front + 4);
             const float xr2[3] = {f0[0], f0[1], f0[2]}, xc2[3] = {f0[3], f1[0], f1[1]}, gx2[3] = {f1[2], f1[3], front[8]};
             EdgeGeo eg;
-            edge_geometry(xr2, xc2, eg);
+            edge_geometry_mode(basis, xr2, xc2, eg);
             const float* grow = sc + C::o_geo + lane * C::GS;
             const f32x4 g0 = lds4(grow), g1 = lds4(grow + 4), g2 = lds4(grow + 8);
             const float gg[kGeo] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3], g2[0], g2[1], g2[2], g2[3]};
             const float s = s_buf[lane];
             const float gd[3] = {s * gx2[0], s * gx2[1], s * gx2[2]};
             float gxr[3], gxc[3];
-            edge_geometry_backward(xr2, xc2, eg, gg, gd, gxr, gxc);
+            edge_geometry_backward_mode(basis, xr2, xc2, eg, gg, gd, gxr, gxc);
             reinterpret_cast<float4*>(gxr_out)[base + lane] = make_float4(gxr[0], gxr[1], gxr[2], 0.0f);
             reinterpret_cast<float4*>(gxc_out)[base + lane] = make_float4(gxc[0], gxc[1], gxc[2], 0.0f);
         }
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
 template <int F, int H, int A>
 static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
                            const float* dagg, const float* Gx, float* dt1, float* gxr, float* gxc, float* slab,
-                           hipStream_t s, int* n_slabs) {
+                           int basis, hipStream_t s, int* n_slabs) {
     const int E = g->n_edges;
     static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1 or 4 heads) or 33 (1 head)");
     {                                      // the 16-edge formulation (hidden_nf 33: with the border feature): one 8-wave workgroup per CU, persistent
@@ -1033,7 +1033,7 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
         int blocks = ceil_div(ceil_div(E, chunk), NW);
         blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
         hipLaunchKernelGGL((edge_bwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * NW), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
-                           E, chunk, dt1, gxr, gxc, slab);
+                           E, chunk, basis, dt1, gxr, gxc, slab);
         *n_slabs = blocks;
     }
     return 0;
@@ -1200,7 +1200,7 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
         if (!kFuse) launch_node_bwd(l);
         if (E > 0) {
             const int rc = launch_edge_bwd<F, H, A>(lw, g, edge_attr, x_l, Pbuf, work + B.dagg, work + B.Gx[cur],
-                                                    work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab + slab_of(l), s, &egrid);
+                                                    work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab + slab_of(l), cfg->edge_basis, s, &egrid);
             if (rc) return rc;
         }
         const int nxt = cur ^ 1;
@@ -1260,7 +1260,7 @@ static int time_edge_bwd_impl(const equigspr_egnn_config* cfg, const float* para
                        work + B.node_slab);
     auto launch = [&]() {
         (void)launch_edge_bwd<F, H, A>(lw, g, edge_attr, xs + (size_t)l * N * 3, work + B.P, work + B.dagg, work + B.Gx[0],
-                                       work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab, s, &egrid);
+                                       work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab, cfg->edge_basis, s, &egrid);
     };
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);

@@ -78,7 +78,7 @@ template <int H, int A, int kB = 0>
 __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_kernel(const float* __restrict__ lw, const int* __restrict__ row,
                                                          const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                          const float* __restrict__ x, const float* __restrict__ P,
-                                                         const int* __restrict__ rinv, int n_edges, int chunk,
+                                                         const int* __restrict__ rinv, int n_edges, int chunk, int basis,
                                                          float* __restrict__ m_out, float* __restrict__ trans_out) {
     using C = Chunk16;
     constexpr int FP = 32 + 4 * kB;                    // hidden_nf = 32 + kB, rows padded to 16 bytes
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
         int rn = r, cn = c, atn = at, en = e;
         if (chn < n_chunks) { en = edge_of(chn); rn = row[en]; cn = col[en]; atn = rinv[en]; }
         EdgeGeo eg;
-        edge_geometry(xr, xc, eg);
+        edge_geometry_mode(basis, xr, xc, eg);
         store_geo_row(sc + C::o_geo + lane * C::GS, eg, attr);
         __builtin_amdgcn_wave_barrier();
         EQ_STAMP(3);
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
 
 template <int F, int H, int A>
 static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
-                            float* m, float* trans, hipStream_t s) {
+                            float* m, float* trans, int basis, hipStream_t s) {
     const int E = g->n_edges;
     static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1 or 4 heads) or 33 (1 head)");
     {                                      // the 16-edge formulation (hidden_nf 33: with the border feature); EQ_FWD16_OCC 4-wave workgroups per CU
@@ -175,7 +175,7 @@ static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const floa
         int blocks = ceil_div(ceil_div(E, chunk), kFwd16Waves);
         blocks = blocks < 1 ? 1 : (blocks > 256 * occ ? 256 * occ : blocks);
         hipLaunchKernelGGL((edge_fwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * kFwd16Waves), 0, s, lw, g->row, g->col, edge_attr, x, P,
-                           g->rinv, E, chunk, m, trans);
+                           g->rinv, E, chunk, basis, m, trans);
     }
 }
 
@@ -308,9 +308,9 @@ static int time_edge_fwd_impl(const equigspr_egnn_config* cfg, const float* para
     const float* lw = params + ML.layer0;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    launch_edge_fwd<F, H, A>(lw, g, edge_attr, pp_x, P, m, trans, s);      // warm
+    launch_edge_fwd<F, H, A>(lw, g, edge_attr, pp_x, P, m, trans, cfg->edge_basis, s);      // warm
     (void)hipEventRecord(e0, s);
-    for (int i = 0; i < iters; ++i) launch_edge_fwd<F, H, A>(lw, g, edge_attr, pp_x, P, m, trans, s);
+    for (int i = 0; i < iters; ++i) launch_edge_fwd<F, H, A>(lw, g, edge_attr, pp_x, P, m, trans, cfg->edge_basis, s);
     (void)hipEventRecord(e1, s);
     (void)hipEventSynchronize(e1);
     float ms = 0.0f;
@@ -351,7 +351,7 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
         const float* lw = params + ML.layer0 + (size_t)l * ML.layer_size;
         const bool last = (l == L - 1);
         if (E > 0) {
-            launch_edge_fwd<F, H, A>(lw, g, edge_attr, xbuf(l), P, m, trans, s);
+            launch_edge_fwd<F, H, A>(lw, g, edge_attr, xbuf(l), P, m, trans, cfg->edge_basis, s);
         }
         float* xn = last ? x_out : xbuf(l + 1);
         hipLaunchKernelGGL((node_fwd_kernel<F, H, A>), dim3(node_grid), dim3(256), 0, s, lw,

@@ -140,6 +140,80 @@ EQ_HD void edge_geometry_backward(const float xr[3], const float xc[3], const Ed
 }
 
 // ------------------------------------------------------------------------------------
+// edge_basis = EQUIGSPR_BASIS_IRREPS: the 12 geometry entries of z are rotation INVARIANTS obtained by
+// contracting the degree <= 1 equivariant basis kernels of tools/basis.py::get_basis (K_J = Y_J Q_J^T, :179-198) with the
+// type-1 features an edge has, its endpoint coordinates -- instead of the raw frame-vector components of compute_so3_matrix,
+// which are not rotation covariant.  With d = x_r - x_c, dh = d / (|d| + 1e-8), the kernels have the closed forms (checked
+// against sh.get_basis / oracle.sh_oracle.get_basis in the tests, signs = this package's deterministic Q_J signs)
+//   K^(1->0)   = kC10 dh^T            K_0^(1->1) = kC0 I          K_2^(1->1) = kC2 (dh dh^T - I / 3)
+//   K_1^(1->1) = kC1 [dh]_x  (its contraction x_r^T K_1 x_c = kC1 dh . (x_r x x_c) vanishes identically: entry 10 is 0)
+// and z_geo = [ |d|^2, |d|, x_r^T K_0 x_c, K^(1->0) x_r, K^(1->0) x_c, x_r^T K_2 x_c, x_r^T K_2 x_r, x_c^T K_2 x_c,
+//               x_r^T K_0 x_r, x_c^T K_0 x_c, 0, 0 ].
+// Every entry is invariant under x -> R x, so h is invariant and the coordinate update (x_r - x_c) s covariant: the layer
+// is SO(3)-equivariant about the origin (the reference's frame features are not).  Zero-length edges (self loops): dh = 0
+// with zero gradient.
+// ------------------------------------------------------------------------------------
+constexpr float kC0 = 0.16286750396763996f;      // 1 / sqrt(12 pi)
+constexpr float kC10 = -0.28209479177387814f;    // -1 / (2 sqrt(pi))
+constexpr float kC2 = 0.3454941494713355f;       // sqrt(3 / (8 pi))
+EQ_HD void edge_geometry_irreps(const float xr[3], const float xc[3], EdgeGeo& e) {
+    for (int i = 0; i < 3; ++i) e.d[i] = xr[i] - xc[i];
+    const float radial = dot3(e.d, e.d);
+    const float dist = EQ_SQRT(radial);
+    e.inv_na = dist > 0.0f ? EQ_RCP(dist + 1e-8f) : 0.0f;
+    float dh[3];
+    for (int i = 0; i < 3; ++i) dh[i] = e.d[i] * e.inv_na;
+    const float u = dot3(dh, xr), v = dot3(dh, xc), p = dot3(xr, xc), a2 = dot3(xr, xr), b2 = dot3(xc, xc);
+    e.g[0] = radial;
+    e.g[1] = dist;
+    e.g[2] = kC0 * p;
+    e.g[3] = kC10 * u;
+    e.g[4] = kC10 * v;
+    e.g[5] = kC2 * (u * v - p * (1.0f / 3.0f));
+    e.g[6] = kC2 * (u * u - a2 * (1.0f / 3.0f));
+    e.g[7] = kC2 * (v * v - b2 * (1.0f / 3.0f));
+    e.g[8] = kC0 * a2;
+    e.g[9] = kC0 * b2;
+    e.g[10] = 0.0f;
+    e.g[11] = 0.0f;
+    e.inv_nb = 0.0f; e.pn = 0.0f; e.p[0] = e.p[1] = e.p[2] = 0.0f;
+    e.degenerate = false;
+}
+EQ_HD void edge_geometry_irreps_backward(const float xr[3], const float xc[3], const EdgeGeo& e, const float gg[kGeo],
+                                         const float gd[3], float gxr[3], float gxc[3]) {
+    const float dist = e.g[1];
+    const float inv_dist = dist > 0.0f ? EQ_RCP(dist) : 0.0f;
+    float dh[3];
+    for (int i = 0; i < 3; ++i) dh[i] = e.d[i] * e.inv_na;
+    const float u = dot3(dh, xr), v = dot3(dh, xc);
+    const float Lu = kC10 * gg[3] + kC2 * (gg[5] * v + 2.0f * gg[6] * u);
+    const float Lv = kC10 * gg[4] + kC2 * (gg[5] * u + 2.0f * gg[7] * v);
+    const float Lp = kC0 * gg[2] - kC2 * gg[5] * (1.0f / 3.0f);
+    const float La = kC0 * gg[8] - kC2 * gg[6] * (1.0f / 3.0f);
+    const float Lb = kC0 * gg[9] - kC2 * gg[7] * (1.0f / 3.0f);
+    float Gh[3];                                   // dL / d dh
+    for (int i = 0; i < 3; ++i) Gh[i] = Lu * xr[i] + Lv * xc[i];
+    // dh = d / (n + eps):  G_d = G_dh / (n + eps) - d (d . G_dh) / (n (n + eps)^2);  n = 0: dh is the constant 0
+    const float dgh = dot3(e.d, Gh);
+    const float kd = dgh * inv_dist * e.inv_na * e.inv_na;
+    for (int i = 0; i < 3; ++i) {
+        const float gdt = gd[i] + 2.0f * e.d[i] * gg[0] + e.d[i] * inv_dist * gg[1] + Gh[i] * e.inv_na - e.d[i] * kd;
+        gxr[i] = Lu * dh[i] + Lp * xc[i] + 2.0f * La * xr[i] + gdt;
+        gxc[i] = Lv * dh[i] + Lp * xr[i] + 2.0f * Lb * xc[i] - gdt;
+    }
+}
+// the two geometry modes behind one call (wave-uniform branch in the kernels)
+EQ_HD void edge_geometry_mode(int basis, const float xr[3], const float xc[3], EdgeGeo& e) {
+    if (basis) edge_geometry_irreps(xr, xc, e);
+    else edge_geometry(xr, xc, e);
+}
+EQ_HD void edge_geometry_backward_mode(int basis, const float xr[3], const float xc[3], const EdgeGeo& e, const float gg[kGeo],
+                                       const float gd[3], float gxr[3], float gxc[3]) {
+    if (basis) edge_geometry_irreps_backward(xr, xc, e, gg, gd, gxr, gxc);
+    else edge_geometry_backward(xr, xc, e, gg, gd, gxr, gxc);
+}
+
+// ------------------------------------------------------------------------------------
 // Flat parameter-block layout (include/equigspr.h "parameter block").
 // ------------------------------------------------------------------------------------
 struct LayerLayout {

@@ -101,8 +101,13 @@ class EGNN(nn.Module):
     """Drop-in for the reference ``EGNN`` (train :293-340)."""
 
     def __init__(self, in_node_nf, hidden_nf, out_node_nf, in_edge_nf=0, device="cuda:0", act_fn=nn.SiLU(), n_layers=5,
-                 residual=True, attention=True, normalize=False, tanh=False, num_heads=1):
+                 residual=True, attention=True, normalize=False, tanh=False, num_heads=1, edge_basis="frames"):
+        """``edge_basis="irreps"`` (extension): the 12 geometric inputs of every edge MLP are rotation
+        invariants from the degree <= 1 irrep basis kernels of ``tools/basis.py::get_basis`` contracted with the endpoint
+        coordinates, instead of the reference's frame-vector components -- same parameter shapes, an SO(3)-equivariant layer
+        (h invariant, x covariant under rotations about the origin)."""
         super().__init__()
+        self.edge_basis = edge_basis
         self.hidden_nf, self.device, self.n_layers = hidden_nf, device, n_layers
         self.in_node_nf, self.out_node_nf, self.in_edge_nf, self.num_heads = in_node_nf, out_node_nf, in_edge_nf, num_heads
         self.embedding_in = nn.Linear(in_node_nf, hidden_nf)
@@ -111,7 +116,7 @@ class EGNN(nn.Module):
             self.add_module("gcl_%d" % i, E_GCL(hidden_nf, hidden_nf, hidden_nf, edges_in_d=in_edge_nf, num_heads=num_heads,
                                                 act_fn=act_fn, residual=residual, attention=attention,
                                                 normalize=normalize, tanh=tanh))
-        self.cfg = ops.make_config(in_node_nf, hidden_nf, out_node_nf, in_edge_nf, n_layers, num_heads)
+        self.cfg = ops.make_config(in_node_nf, hidden_nf, out_node_nf, in_edge_nf, n_layers, num_heads, edge_basis)
         self.flat_params: Optional[torch.Tensor] = None
         self.flat_grads: Optional[torch.Tensor] = None
         self._graph_cache = {}

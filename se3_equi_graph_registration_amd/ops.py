@@ -38,8 +38,13 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def make_config(in_nf, hidden_nf, out_nf, in_edge_nf, n_layers, num_heads) -> EgnnConfig:
-    cfg = EgnnConfig(int(in_nf), int(hidden_nf), int(out_nf), int(in_edge_nf), int(n_layers), int(num_heads))
+EDGE_BASIS = {"frames": 0, "irreps": 1}      # EQUIGSPR_BASIS_FRAMES / EQUIGSPR_BASIS_IRREPS
+
+
+def make_config(in_nf, hidden_nf, out_nf, in_edge_nf, n_layers, num_heads, edge_basis="frames") -> EgnnConfig:
+    if edge_basis not in EDGE_BASIS:
+        raise ValueError("edge_basis: 'frames' (the reference's frame-vector inputs) or 'irreps' (irrep-basis invariants)")
+    cfg = EgnnConfig(int(in_nf), int(hidden_nf), int(out_nf), int(in_edge_nf), int(n_layers), int(num_heads), EDGE_BASIS[edge_basis])
     if _lib.lib().equigspr_egnn_param_count(ctypes.byref(cfg)) < 0:
         raise NotImplementedError(
             f"EGNN config outside the compiled HIP kernel set: hidden_nf={hidden_nf} (32|33), num_heads={num_heads} "

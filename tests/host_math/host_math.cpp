@@ -16,6 +16,18 @@ void hm_edge_geometry_backward(const float* xr, const float* xc, const float* gg
     eq::edge_geometry(xr, xc, e);
     eq::edge_geometry_backward(xr, xc, e, gg, gd, gxr, gxc);
 }
+// edge_basis = irreps (N4): forward values and backward of the irrep-basis invariants
+void hm_edge_geometry_irreps(const float* xr, const float* xc, float* g, float* d) {
+    eq::EdgeGeo e;
+    eq::edge_geometry_mode(1, xr, xc, e);
+    for (int i = 0; i < eq::kGeo; ++i) g[i] = e.g[i];
+    for (int i = 0; i < 3; ++i) d[i] = e.d[i];
+}
+void hm_edge_geometry_irreps_backward(const float* xr, const float* xc, const float* gg, const float* gd, float* gxr, float* gxc) {
+    eq::EdgeGeo e;
+    eq::edge_geometry_mode(1, xr, xc, e);
+    eq::edge_geometry_backward_mode(1, xr, xc, e, gg, gd, gxr, gxc);
+}
 float hm_silu(float v) { return eq::silu(v); }
 float hm_silu_grad(float v) { return eq::silu_grad(v); }
 void hm_layer_layout(int F, int H, int A, int* out /*16*/) {

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 16 and "equigspr_egnn_forward" in names and "equigspr_knn_graph" in names
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.equigspr_abi_version() == 6
+    assert lib.equigspr_abi_version() == 7
     # every declared symbol has a ctypes signature (no compute call is made here)
     assert set(names) == set(_lib._SIGNATURES.keys())
 
@@ -168,6 +168,54 @@ def test_host_geometry_forward_and_backward_match_oracle_autograd(hostmath):
         else:
             np.testing.assert_allclose(gxr, xe.grad[0].numpy(), rtol=3e-4, atol=3e-4)
             np.testing.assert_allclose(gxc, xe.grad[1].numpy(), rtol=3e-4, atol=3e-4)
+
+
+def test_host_irreps_geometry_matches_basis_contraction_and_autograd(hostmath):
+    """edge_basis='irreps' (N4): the closed forms the kernels inline (csrc/egnn_math.h) equal the contraction of the
+    get_basis kernels with the endpoint coordinates (oracle, through oracle/sh_oracle.py), and their hand-written backward
+    equals the oracle's autograd -- incl. a zero-length edge (self loop: dh = 0, no gradient through the direction)."""
+    g = torch.Generator().manual_seed(4)
+    pts = torch.rand(30, 3, generator=g, dtype=torch.float64) * 2 - 1
+    row = torch.tensor([0, 1, 2, 5, 7, 9, 3]); col = torch.tensor([1, 2, 3, 6, 8, 9, 4])
+    diff, geo_ref = orc.edge_geometry_irreps(pts, row, col)
+    gg = torch.randn(len(row), 12, generator=g, dtype=torch.float64)
+    gd = torch.randn(len(row), 3, generator=g, dtype=torch.float64)
+    for e in range(len(row)):
+        xr = pts[row[e]].float().numpy().copy(); xc = pts[col[e]].float().numpy().copy()
+        gbuf = np.zeros(12, np.float32); dbuf = np.zeros(3, np.float32)
+        hostmath.hm_edge_geometry_irreps(_fp(xr), _fp(xc), _fp(gbuf), _fp(dbuf))
+        np.testing.assert_allclose(gbuf, geo_ref[e].numpy(), rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(dbuf, diff[e].numpy(), rtol=1e-6, atol=1e-7)
+        xe = torch.stack([pts[row[e]], pts[col[e]]]).clone().requires_grad_(True)
+        d2, g2 = orc.edge_geometry_irreps(xe, torch.tensor([0]), torch.tensor([1]))
+        ((g2[0] * gg[e]).sum() + (d2[0] * gd[e]).sum()).backward()
+        gxr = np.zeros(3, np.float32); gxc = np.zeros(3, np.float32)
+        gge = gg[e].float().numpy().copy(); gde = gd[e].float().numpy().copy()
+        hostmath.hm_edge_geometry_irreps_backward(_fp(xr), _fp(xc), _fp(gge), _fp(gde), _fp(gxr), _fp(gxc))
+        np.testing.assert_allclose(gxr, xe.grad[0].numpy(), rtol=3e-4, atol=3e-4)
+        np.testing.assert_allclose(gxc, xe.grad[1].numpy(), rtol=3e-4, atol=3e-4)
+
+
+def test_irreps_layer_is_rotation_equivariant_and_frames_layer_is_not():
+    """The property that pins N4 (no reference implementation exists): with irrep-basis edge features the oracle layer
+    stack gives h(Rx) = h(x) and x'(Rx) = R x'(x) to fp64 round-off; the reference's frame-vector features do not."""
+    from scipy.spatial.transform import Rotation
+    g = torch.Generator().manual_seed(8)
+    n, k = 80, 6
+    x = torch.rand(n, 3, generator=g, dtype=torch.float64) * 2 - 1
+    e = orc.knn_graph(x.float(), k)
+    m = pk.EGNN(8, 32, 8, in_edge_nf=1, device="cpu", n_layers=2)
+    w = {kk: v.detach().double() for kk, v in m.state_dict().items()}
+    h = torch.randn(n, 8, generator=g, dtype=torch.float64)
+    ea = torch.ones(e.shape[1], 1, dtype=torch.float64)
+    R = torch.from_numpy(Rotation.random(random_state=3).as_matrix())
+    h1, x1 = orc.egnn_forward(w, h, x, [e[0], e[1]], ea, edge_basis="irreps")
+    h2, x2 = orc.egnn_forward(w, h, x @ R.T, [e[0], e[1]], ea, edge_basis="irreps")
+    assert float((h2 - h1).abs().max()) < 1e-11 and float((x2 - x1 @ R.T).abs().max()) < 1e-11
+    assert float((x1 - x).abs().max()) > 1e-6
+    h3, _ = orc.egnn_forward(w, h, x, [e[0], e[1]], ea)
+    h4, _ = orc.egnn_forward(w, h, x @ R.T, [e[0], e[1]], ea)
+    assert float((h4 - h3).abs().max()) > 1e-3
 
 
 def test_host_silu_and_layout_twin(hostmath):
