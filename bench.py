@@ -477,6 +477,7 @@ def main():
         allreduce_us = round(ev0.elapsed_time(ev1) * 1e3 / 20, 2)
         S["restore"]()
 
+    out = None
     if rank == 0:
         roof, extra = roofline(pkg, S, args, dev)
         out = {
@@ -505,10 +506,18 @@ def main():
                                 "exchange": "one mean all-reduce of the joint flat gradient bucket per step"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio (block-buffered when stdout is a pipe: it would land AFTER this line at
+        # exit); flush it first so that the JSON line is the last thing on stdout
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
