@@ -272,6 +272,154 @@ __global__ __launch_bounds__(256, 3) void node_fwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// node kernel, 16-node MFMA formulation (hidden_nf == 32): ONE wave per 16 nodes, no LDS, no barriers.
+// Lane l = (node n = l & 15, g = l >> 4) owns features 16 b + 4 g + r of its node (the C/D layout of v_mfma_f32_16x16x4_f32 and,
+// as in egnn_mfma16.h, the B operand of the next product).  The segment sums stream the node's rows (stored by the edge kernel in
+// aggregation order) as float4 in ascending edge id -- the same order of additions as the lane-per-feature kernel.  The node
+// MLP (:252-260), the next layer's projections and embedding_out are 32 + 16 + 32 (or <= 64) MFMAs whose A operands are read
+// straight from the parameter block (L2-resident, 16-byte rows) -- the lane-per-feature kernel spent a third of its time
+// staging four matrices into LDS per 8 nodes and the rest in barrier-separated LDS dot products.
+// ---------------------------------------------------------------------------------------
+template <int H, int A, int D>      // D = segment rows in flight per lane (16: a k = 20 neighbourhood is two round trips; 4: registers for occupancy)
+__global__ __launch_bounds__(64) void node_fwd16_kernel(
+    const float* __restrict__ lw, const float* __restrict__ next_lw, const float* __restrict__ w_out, const float* __restrict__ b_out,
+    int out_nf, const int* __restrict__ rptr, const float* __restrict__ m_in, const float* __restrict__ trans_in,
+    const float* __restrict__ h, const float* __restrict__ x, int n_nodes, float* __restrict__ h_next, float* __restrict__ x_next,
+    float* __restrict__ agg_save, float* __restrict__ P, float* __restrict__ h_out) {
+    using LL = LP<32, H, A>;
+    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+    const int j = min((int)blockIdx.x * 16 + i, n_nodes - 1);
+    const bool live = (int)blockIdx.x * 16 + i < n_nodes;
+    const int lo = rptr[j], hi = rptr[j + 1];
+    // weights of the node MLP: requested before the segment loop, consumed after it
+    f32x4 w4a[2][4], w5a[2][2], b4v[2], b5v[2];
+#pragma unroll
+    for (int bo = 0; bo < 2; ++bo) {
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi) w4a[bo][bi] = ldg4(lw + LL::w4 + (16 * bo + i) * 64 + 16 * bi + 4 * g);
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) w5a[bo][bi] = ldg4(lw + LL::w5 + (16 * bo + i) * 32 + 16 * bi + 4 * g);
+        b4v[bo] = ldg4(lw + LL::b4 + 16 * bo + 4 * g);
+        b5v[bo] = ldg4(lw + LL::b5 + 16 * bo + 4 * g);
+    }
+    // next layer's projection weights (W1 rows are 77 floats apart: 4-byte aligned only -> scalar loads), also requested up front
+    float as[2][2][4], at[2][2][4];
+    f32x4 pcb[2];
+    if (next_lw) {
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    as[bi][bo][r] = next_lw[LL::w1_off(16 * bo + i, 16 * bi + 4 * g + r)];
+                    at[bi][bo][r] = next_lw[LL::w1_off(16 * bo + i, 32 + 16 * bi + 4 * g + r)];
+                }
+#pragma unroll
+        for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pcb[bo][r] = next_lw[LL::b1_off(16 * bo + 4 * g + r)];
+    }
+    f32x4 hj[2], agg[2] = {splat4(0.0f), splat4(0.0f)};
+#pragma unroll
+    for (int b = 0; b < 2; ++b) hj[b] = ldg4(h + (size_t)j * 32 + 16 * b + 4 * g);
+    float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- segment sums over rows lo..hi-1 (ascending edge id)
+    const int len = hi - lo;
+    int maxlen = len;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
+    for (int a0 = 0; a0 < maxlen; a0 += D) {
+        f32x4 v[D][2];
+        float4 tv[D];
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const bool in = a0 + u < len;
+            const size_t a = (size_t)(lo + (in ? a0 + u : 0));
+#pragma unroll
+            for (int b = 0; b < 2; ++b) v[u][b] = in ? ldg4(m_in + a * 32 + 16 * b + 4 * g) : splat4(0.0f);
+            tv[u] = (in && g == 0) ? reinterpret_cast<const float4*>(trans_in)[a] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            agg[0] += v[u][0]; agg[1] += v[u][1];
+            xs.x += tv[u].x; xs.y += tv[u].y; xs.z += tv[u].z;
+        }
+    }
+    if (live && g == 0) {                                                             // :267
+        x_next[(size_t)j * 3 + 0] = x[(size_t)j * 3 + 0] + xs.x;
+        x_next[(size_t)j * 3 + 1] = x[(size_t)j * 3 + 1] + xs.y;
+        x_next[(size_t)j * 3 + 2] = x[(size_t)j * 3 + 2] + xs.z;
+    }
+    if (live && agg_save) {
+        st4(agg_save + (size_t)j * 32 + 4 * g, agg[0]);
+        st4(agg_save + (size_t)j * 32 + 16 + 4 * g, agg[1]);
+    }
+    // ---- hid = SiLU(W4 [h | agg] + b4)
+    f32x4 acc[2] = {b4v[0], b4v[1]};
+#pragma unroll
+    for (int bi = 0; bi < 4; ++bi) {
+        const f32x4 bv = bi < 2 ? hj[bi] : agg[bi - 2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[0] = mfma16(w4a[0][bi][r], bv[r], acc[0]);
+            acc[1] = mfma16(w4a[1][bi][r], bv[r], acc[1]);
+        }
+    }
+    f32x4 hid[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) hid[b] = acc[b] * sigmoid4(acc[b]);
+    // ---- h' = h + W5 hid + b5   (:257-259)
+    f32x4 hn[2] = {hj[0] + b5v[0], hj[1] + b5v[1]};
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            hn[0] = mfma16(w5a[0][bi][r], hid[bi][r], hn[0]);
+            hn[1] = mfma16(w5a[1][bi][r], hid[bi][r], hn[1]);
+        }
+    if (live) {
+        st4(h_next + (size_t)j * 32 + 4 * g, hn[0]);
+        st4(h_next + (size_t)j * 32 + 16 + 4 * g, hn[1]);
+    }
+    if (next_lw) {
+        // ---- next layer's projections: P = [W_src h' | W_tgt h' + b1]
+        f32x4 pr[2] = {splat4(0.0f), splat4(0.0f)}, pc[2] = {pcb[0], pcb[1]};
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pr[0] = mfma16(as[bi][0][r], hn[bi][r], pr[0]);
+                pr[1] = mfma16(as[bi][1][r], hn[bi][r], pr[1]);
+                pc[0] = mfma16(at[bi][0][r], hn[bi][r], pc[0]);
+                pc[1] = mfma16(at[bi][1][r], hn[bi][r], pc[1]);
+            }
+        if (live) {
+            float* prow = P + (size_t)j * 64 + 4 * g;
+            st4(prow, pr[0]); st4(prow + 16, pr[1]); st4(prow + 32, pc[0]); st4(prow + 48, pc[1]);
+        }
+    } else {
+        // ---- embedding_out (:337): out_nf <= 64 rows of W_out [out_nf][32]
+        for (int bo = 0; bo * 16 < out_nf; ++bo) {
+            const int orow = 16 * bo + i;
+            f32x4 o4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int oo = 16 * bo + 4 * g + r; o4[r] = oo < out_nf ? b_out[oo] : 0.0f; }
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) {
+                const f32x4 a = orow < out_nf ? ldg4(w_out + (size_t)orow * 32 + 16 * bi + 4 * g) : splat4(0.0f);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o4 = mfma16(a[r], hn[bi][r], o4);
+            }
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int oo = 16 * bo + 4 * g + r; if (oo < out_nf) h_out[(size_t)j * out_nf + oo] = o4[r]; }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------------------
 struct FwdBuffers {
@@ -354,6 +502,20 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
             launch_edge_fwd<F, H, A>(lw, g, edge_attr, xbuf(l), P, m, trans, cfg->edge_basis, s);
         }
         float* xn = last ? x_out : xbuf(l + 1);
+#ifndef EQ_NODE_FWD16
+#define EQ_NODE_FWD16 1
+#endif
+        if constexpr (F == 32 && EQ_NODE_FWD16) {
+            // few nodes: one wave per CU or less, latency decides -> 16 rows in flight; many nodes: 4 (registers for occupancy)
+            if (N <= 16 * 1024)
+                hipLaunchKernelGGL((node_fwd16_kernel<H, A, 16>), dim3(ceil_div(N, 16)), dim3(64), 0, s, lw, last ? nullptr : lw + ML.layer_size,
+                                   params + ML.w_out, params + ML.b_out, cfg->out_nf, g->rptr, m, trans, hbuf(l), xbuf(l), N, hbuf(l + 1), xn,
+                                   training ? aggs + (size_t)l * N * FP : nullptr, P, h_out);
+            else
+                hipLaunchKernelGGL((node_fwd16_kernel<H, A, 4>), dim3(ceil_div(N, 16)), dim3(64), 0, s, lw, last ? nullptr : lw + ML.layer_size,
+                                   params + ML.w_out, params + ML.b_out, cfg->out_nf, g->rptr, m, trans, hbuf(l), xbuf(l), N, hbuf(l + 1), xn,
+                                   training ? aggs + (size_t)l * N * FP : nullptr, P, h_out);
+        } else
         hipLaunchKernelGGL((node_fwd_kernel<F, H, A>), dim3(node_grid), dim3(256), 0, s, lw,
                            last ? nullptr : lw + ML.layer_size, params + ML.w_out, params + ML.b_out, cfg->out_nf,
                            g->rptr, g->rperm, m, trans, hbuf(l), xbuf(l), N, hbuf(l + 1), xn,
