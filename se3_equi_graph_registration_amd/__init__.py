@@ -18,7 +18,8 @@ from .correspondences import match_descriptors, build_correspondences  # noqa: F
 from .pointnet import PointNetLayer, PointNet, global_max_pool  # noqa: F401
 from .metrics import evaluate_batch, calculate_pose_error, registration_recall  # noqa: F401
 from . import sh  # noqa: F401  (A16: spherical harmonics / irrep basis)
-from .sh import get_basis, get_spherical_harmonics, precompute_sh, basis_transformation_Q_J, irr_repr  # noqa: F401
+from .sh import (get_basis, get_spherical_harmonics, precompute_sh, basis_transformation_Q_J, irr_repr,  # noqa: F401
+                 wigner_d_matrix, compose, J_dense)
 from .gcn import build_graph, GraphConvolution, GlobalPooling, KnnAdjacency  # noqa: F401
 from . import datasets  # noqa: F401  (N3: pair-file formats, dataset classes, HBM-resident batches)
 from . import train  # noqa: F401  (train_one_epoch / validate / checkpoints in the reference layout)

@@ -5,11 +5,19 @@ Per-point work (SH of every degree, the ``K_J = Y_J Q_J^T`` contraction) runs in
 constants ``Q_J`` are built once per ``(J, d_in, d_out)`` on the host in fp64 (as the reference does under
 ``torch_default_dtype(float64)`` with an lru/disk cache, basis.py:123-138) and kept on the device.
 
-The reference's ``irr_repr`` needs a ``J_dense`` blob its repository does not ship (tools/irr_repr.py:12-20); here the
-Wigner matrix is recovered from the property the reference's test pins, ``Y(R x) = D(R) Y(x)``
-(tests/test_irrep_repr.py), and ``Q_J`` -- unique up to sign -- is normalised so that its first entry within 10 % of the largest magnitude is positive."""
+The reference's ``wigner_d_matrix`` is ``Z(alpha) J Z(beta) J Z(gamma)`` with ``J`` from a ``J_dense`` blob its repository does
+not ship (tools/irr_repr.py:12-31).  ``J_l`` is the degree-l representation of the half turn about (0, 1, 1)/sqrt(2) -- the
+proper rotation with ``J Rz(b) J = Ry(b)``, ``J^2 = I`` -- so it is rebuilt here from the one property the reference's test
+pins, ``Y(R x) = D(R) Y(x)`` (tests/test_irrep_repr.py), and ``wigner_d_matrix`` / ``irr_repr`` / ``compose`` /
+``spherical_harmonics`` then follow the reference's formulas.  ``Q_J`` -- unique up to sign -- is normalised so that its first
+entry within 10 % of the largest magnitude is positive, and cached on disk like the reference's (``cache_dir``, tools/utils.py:151-206:
+``$CACHE_PATH`` or ``~/.cache.equivariant_attention``; ``CLEAR_CACHE`` disables it)."""
 from __future__ import annotations
 
+import fcntl
+import gzip
+import os
+import pickle
 from functools import lru_cache
 from itertools import product
 from math import pi
@@ -121,16 +129,66 @@ def _rot_np(a, b, c):
 _DIRECTIONS = np.random.default_rng(7).standard_normal((96, 3))
 
 
-def _wigner_np(l, a, b, c):
+def _wigner_of_matrix(l, R):
+    """D^l(R) for a proper rotation matrix R from its defining property Y_l(R x) = D^l(R) Y_l(x) (least squares, fp64)."""
     y = _host_sh(l, _DIRECTIONS)
-    yr = _host_sh(l, _DIRECTIONS @ _rot_np(a, b, c).T)
+    yr = _host_sh(l, _DIRECTIONS @ np.asarray(R, dtype=np.float64).T)
     return np.linalg.lstsq(y, yr, rcond=None)[0].T
 
 
+def _wigner_np(l, a, b, c):
+    return _wigner_of_matrix(l, _rot_np(a, b, c))
+
+
+_J3 = np.array([[-1.0, 0.0, 0.0], [0.0, 0.0, 1.0], [0.0, 1.0, 0.0]])     # half turn about (0, 1, 1)/sqrt(2): J3 Rz(b) J3 = Ry(b)
+
+
+@lru_cache(maxsize=None)
+def _j_np(l):
+    j = _wigner_of_matrix(l, _J3)
+    return 0.5 * (j + j.T)                       # symmetric and involutory up to round-off
+
+
+def J_dense(degree, dtype=None, device=None):
+    """The reference's ``Jd[degree]`` (tools/irr_repr.py:14-20): symmetric, ``J @ J = I``, ``J Z(b) J = D(0, b, 0)``."""
+    return torch.from_numpy(_j_np(int(degree))).to(dtype=dtype or torch.get_default_dtype(), device=device)
+
+
+def z_rot_mat(angle, l):
+    """tools/irr_repr.py:33-42: cos(f angle) on the diagonal, sin(f angle) on the anti-diagonal, f = l, l-1, ..., -l."""
+    angle = torch.as_tensor(angle, dtype=torch.get_default_dtype()) if not torch.is_tensor(angle) else angle
+    order = to_order(l)
+    m = angle.new_zeros((order, order))
+    inds = torch.arange(0, order, 1, dtype=torch.long, device=angle.device)
+    reversed_inds = torch.arange(2 * l, -1, -1, dtype=torch.long, device=angle.device)
+    frequencies = torch.arange(l, -l - 1, -1, dtype=angle.dtype, device=angle.device)
+    m[inds, reversed_inds] = torch.sin(frequencies * angle)
+    m[inds, inds] = torch.cos(frequencies * angle)
+    return m
+
+
+def wigner_d_matrix(degree, alpha, beta, gamma, dtype=None, device=None):
+    """tools/irr_repr.py:22-31: ``Z(alpha) J Z(beta) J Z(gamma)`` for ZYZ Euler angles."""
+    dtype = dtype or torch.get_default_dtype()
+    cast = lambda t: (t if torch.is_tensor(t) else torch.tensor(float(t), dtype=dtype)).to(dtype=dtype, device=device)  # noqa: E731
+    J = J_dense(degree, dtype=dtype, device=device)
+    return z_rot_mat(cast(alpha), degree) @ J @ z_rot_mat(cast(beta), degree) @ J @ z_rot_mat(cast(gamma), degree)
+
+
 def irr_repr(order, alpha, beta, gamma, dtype=None):
-    """Irreducible representation D^order(alpha, beta, gamma) of the ZYZ rotation ``rot`` (tools/irr_repr.py:44-52)."""
-    d = _wigner_np(order, float(alpha), float(beta), float(gamma))
-    return torch.from_numpy(d).to(dtype or torch.get_default_dtype())
+    """Irreducible representation D^order(alpha, beta, gamma) of the ZYZ rotation ``rot`` (tools/irr_repr.py:44-52): through
+    ``wigner_d_matrix``, as the reference computes it."""
+    return wigner_d_matrix(order, alpha, beta, gamma, dtype=dtype or torch.get_default_dtype())
+
+
+def rot_z(gamma):
+    g = float(gamma)
+    return torch.tensor([[np.cos(g), -np.sin(g), 0.0], [np.sin(g), np.cos(g), 0.0], [0.0, 0.0, 1.0]], dtype=torch.get_default_dtype())
+
+
+def rot_y(beta):
+    b = float(beta)
+    return torch.tensor([[np.cos(b), 0.0, np.sin(b)], [0.0, 1.0, 0.0], [-np.sin(b), 0.0, np.cos(b)]], dtype=torch.get_default_dtype())
 
 
 def rot(alpha, beta, gamma):
@@ -138,11 +196,76 @@ def rot(alpha, beta, gamma):
     return torch.from_numpy(_rot_np(float(alpha), float(beta), float(gamma))).to(torch.get_default_dtype())
 
 
+def x_to_alpha_beta(x):
+    """Point on the sphere -> (alpha, beta) (tools/irr_repr.py:76-83)."""
+    x = torch.as_tensor(x, dtype=torch.get_default_dtype())
+    x = x / torch.norm(x)
+    return torch.atan2(x[1], x[0]), torch.acos(x[2])
+
+
+def compose(a1, b1, c1, a2, b2, c2):
+    """(a, b, c) = (a1, b1, c1) composed with (a2, b2, c2) (tools/irr_repr.py:92-101)."""
+    comp = rot(a1, b1, c1) @ rot(a2, b2, c2)
+    xyz = comp @ torch.tensor([0.0, 0.0, 1.0], dtype=comp.dtype)
+    a, b = x_to_alpha_beta(xyz)
+    rotz = rot(0.0, -float(b), -float(a)) @ comp
+    c = torch.atan2(rotz[1, 0], rotz[0, 0])
+    return a, b, c
+
+
+def spherical_harmonics(order, alpha, beta, dtype=None):
+    """tools/irr_repr.py:103-104: ``get_spherical_harmonics(order, theta = pi - beta, phi = alpha)`` (device op: GPU tensors)."""
+    return get_spherical_harmonics(order, theta=(pi - beta), phi=alpha)
+
+
+# --------------------------------------------------------------------------- disk cache of the fp64 constants
+def _cache_path():
+    """``$CACHE_PATH`` or ``~/.cache.equivariant_attention``; None when ``CLEAR_CACHE`` is set (tools/basis.py:15-16)."""
+    if os.environ.get("CLEAR_CACHE") is not None:
+        return None
+    return os.environ.get("CACHE_PATH") or os.path.expanduser("~/.cache.equivariant_attention")
+
+
+def _cached_on_disk(key, compute):
+    """The reference's ``cache_dir`` protocol (tools/utils.py:151-206): ``index.pkl`` maps keys to ``N.pkl.gz`` files, guarded by
+    a lock file (``fcntl.flock`` here; the reference's ``filelock`` package is not a dependency)."""
+    dirname = _cache_path()
+    if dirname is None:
+        return compute()
+    try:
+        os.makedirs(dirname, exist_ok=True)
+        with open(os.path.join(dirname, "mutex"), "a+") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                indexfile = os.path.join(dirname, "index.pkl")
+                index = {}
+                if os.path.exists(indexfile):
+                    with open(indexfile, "rb") as f:
+                        index = pickle.load(f)
+                if key in index:
+                    filename = index[key]
+                else:
+                    index[key] = filename = f"{len(index)}.pkl.gz"
+                    with open(indexfile, "wb") as f:
+                        pickle.dump(index, f)
+                filepath = os.path.join(dirname, filename)
+                if os.path.exists(filepath):
+                    with gzip.open(filepath, "rb") as f:
+                        return pickle.load(f)
+                result = compute()
+                with gzip.open(filepath, "wb") as f:
+                    pickle.dump(result, f)
+                return result
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
+    except OSError:
+        return compute()                          # unwritable cache directory: compute, as without a cache
+
+
 _SYLVESTER_ANGLES = [(4.4, 5.6, 4.6), (4.9, 6.1, 4.1), (0.5, 4.1, 5.4), (2.2, 3.5, 5.6), (2.5, 0.3, 3.9)]
 
 
-@lru_cache(maxsize=None)
-def _q_np(J, order_in, order_out):
+def _q_compute(J, order_in, order_out):
     rows = []
     for a, b, c in _SYLVESTER_ANGLES:
         r_t = np.kron(_wigner_np(order_out, a, b, c), _wigner_np(order_in, a, b, c))
@@ -154,6 +277,12 @@ def _q_np(J, order_in, order_out):
     q = vt[-1]
     q = q * np.sign(q[np.flatnonzero(np.abs(q) > 0.9 * np.abs(q).max())[0]])     # first large entry positive
     return q.reshape(to_order(order_out) * to_order(order_in), to_order(J))
+
+
+@lru_cache(maxsize=None)
+def _q_np(J, order_in, order_out):
+    """RAM cache (lru) over the disk cache, as the reference stacks ``lru_cache`` on ``cache_dir`` (tools/utils.py:158-160)."""
+    return _cached_on_disk(("equigspr.Q_J.v1", int(J), int(order_in), int(order_out)), lambda: _q_compute(J, order_in, order_out))
 
 
 def get_R_tensor(order_out, order_in, a, b, c):
