@@ -27,8 +27,8 @@ EGNN_ONES = "ones"      # sentinel for edge_attr: the constant all-ones attribut
 
 class E_GCL(nn.Module):
     """Parameter container of one layer; same submodule names as the reference (train :185-229).
-    The layer math runs inside ``EGNN.forward`` (fused HIP path); a stand-alone
-    ``E_GCL.forward`` is provided through a one-layer EGNN with identity embeddings."""
+    The layer math runs inside ``EGNN.forward`` (fused HIP path); a stand-alone, differentiable
+    ``E_GCL.forward`` is provided through a one-layer EGNN with identity embeddings that shares this module's parameters."""
 
     def __init__(self, input_nf, output_nf, hidden_nf, edges_in_d=0, num_heads=1, act_fn=nn.SiLU(), residual=True,
                  attention=False, normalize=False, tanh=False, device="cuda:0"):
@@ -57,17 +57,22 @@ class E_GCL(nn.Module):
         self.coord_mlp = nn.Sequential(nn.Linear(hidden_nf, hidden_nf), act_fn, last)
 
     def forward(self, h, edge_index, coord, edge_attr=None):
-        """Stand-alone layer call (train :280-289) -> (h, coord, edge_attr)."""
-        f = self.hidden_nf
-        wrap = EGNN(f, f, f, in_edge_nf=self.edges_in_d, device=h.device, n_layers=1, num_heads=self.num_heads)
-        with torch.no_grad():
-            wrap.embedding_in.weight.copy_(torch.eye(f)); wrap.embedding_in.bias.zero_()
-            wrap.embedding_out.weight.copy_(torch.eye(f)); wrap.embedding_out.bias.zero_()
-            wrap.gcl_0.load_state_dict(self.state_dict())
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("stand-alone E_GCL.forward is inference-only; train through EGNN")
-        with torch.no_grad():
-            h2, x2 = wrap(h, coord, edge_index, edge_attr)
+        """Stand-alone layer call (train :280-289) -> (h, coord, edge_attr).  Runs as a one-layer EGNN with identity embeddings
+        whose ``gcl_0`` IS this module (the same ``nn.Parameter`` objects, re-homed into that EGNN's flat block), so it is
+        differentiable like ``EGNN.forward``: parameter gradients land in this layer's ``.grad``."""
+        wrap = self.__dict__.get("_standalone")
+        dev = h.device
+        if wrap is None or wrap.flat_params is None or wrap.flat_params.device != dev:
+            f = self.hidden_nf
+            wrap = EGNN(f, f, f, in_edge_nf=self.edges_in_d, device=dev, n_layers=1, num_heads=self.num_heads)
+            wrap._modules["gcl_0"] = self.to(dev)
+            with torch.no_grad():
+                wrap.embedding_in.weight.copy_(torch.eye(f)); wrap.embedding_in.bias.zero_()
+                wrap.embedding_out.weight.copy_(torch.eye(f)); wrap.embedding_out.bias.zero_()
+            for q in (*wrap.embedding_in.parameters(), *wrap.embedding_out.parameters()):
+                q.requires_grad_(False)
+            self.__dict__["_standalone"] = wrap        # not a registered submodule: no parameter cycle
+        h2, x2 = wrap(h, coord, edge_index, edge_attr)
         return h2, x2, edge_attr
 
 

@@ -4,7 +4,8 @@
 than as the reference's scipy ``[N, N]`` matrix; ``GraphConvolution`` consumes it in one fused gather + 1x1-conv
 kernel (a dense ``[B, N, N]`` adjacency tensor, as the reference's ``forward`` signature allows, is also accepted:
 the product with it is one library GEMM, the conv stays in HIP); ``GlobalPooling`` is a block reduction.
-Inference only -- the reference imports these layers but never calls them."""
+The reference imports these layers but never calls them; here they are trainable: under grad the backward re-runs the layer
+in device ops on the saved inputs (ops.hip_forward_aten_backward)."""
 from __future__ import annotations
 
 import numpy as np
@@ -12,7 +13,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .ops import _need, _p, _stream, knn_graph_batched
+from .ops import _need, _p, _stream, knn_graph_batched, hip_forward_aten_backward
 
 
 class KnnAdjacency:
@@ -60,9 +61,8 @@ def build_graph(coordinates, k=25, device="cuda"):
     return KnnAdjacency(ptr, idx, val, nc, n, squeeze)
 
 
-def _no_grad_only(name, *tensors):
-    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
-        raise NotImplementedError(f"{name}: the HIP op is forward-only; call it under torch.no_grad()")
+def _wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
 class GraphConvolution(nn.Module):
@@ -71,32 +71,54 @@ class GraphConvolution(nn.Module):
         self.conv = nn.Conv1d(in_features, out_features, kernel_size=1, bias=bias)
 
     def forward(self, adj, x):
-        """``x [B, C_in, n]``; ``adj``: ``KnnAdjacency`` (1 or B clouds) or dense ``[B, n, n]`` -> ``[B, C_out, n]``."""
-        _no_grad_only("GraphConvolution", x, *self.parameters())
+        """``x [B, C_in, n]``; ``adj``: ``KnnAdjacency`` (1 or B clouds) or dense ``[B, n, n]`` -> ``[B, C_out, n]``.
+        Under grad the backward re-runs the layer in device ops (ops.hip_forward_aten_backward); the adjacency is a constant."""
         x = _need(x.contiguous().float(), "x", torch.float32, 3)
         b, c_in, n = x.shape
-        w = self.conv.weight.detach().reshape(self.conv.out_channels, c_in).contiguous()
-        bias = self.conv.bias.detach().contiguous() if self.conv.bias is not None else None
-        y = torch.empty(b, self.conv.out_channels, n, dtype=torch.float32, device=x.device)
+        c_out = self.conv.out_channels
         L = _lib.lib()
-        if isinstance(adj, KnnAdjacency):
+        sparse = isinstance(adj, KnnAdjacency)
+        if sparse:
             if adj.n != n or adj.n_clouds not in (1, b):
                 raise RuntimeError(f"GraphConvolution: adjacency ({adj.n_clouds} x {adj.n}) does not match x {tuple(x.shape)}")
-            _lib.check(L.equigspr_gcn_conv_forward(_p(x), b, c_in, self.conv.out_channels, n, _p(adj.ptr), _p(adj.idx), _p(adj.val),
-                                                   adj.n_clouds, _p(w), _p(bias), _p(y), _stream()), "gcn_conv_forward")
         else:
-            agg = torch.bmm(x, _need(adj, "adj", torch.float32, 3)).contiguous()       # plain library GEMM
-            _lib.check(L.equigspr_gcn_conv_forward(_p(agg), b, c_in, self.conv.out_channels, n, None, None, None, 0, _p(w), _p(bias),
-                                                   _p(y), _stream()), "gcn_conv_forward")
-        return y
+            adj = _need(adj, "adj", torch.float32, 3)
+
+        def hip(x_, w_, bias_):
+            w2 = w_.reshape(c_out, c_in).contiguous()
+            y = torch.empty(b, c_out, n, dtype=torch.float32, device=x_.device)
+            if sparse:
+                _lib.check(L.equigspr_gcn_conv_forward(_p(x_), b, c_in, c_out, n, _p(adj.ptr), _p(adj.idx), _p(adj.val), adj.n_clouds,
+                                                       _p(w2), _p(bias_), _p(y), _stream()), "gcn_conv_forward")
+            else:
+                agg = torch.bmm(x_, adj).contiguous()       # plain library GEMM
+                _lib.check(L.equigspr_gcn_conv_forward(_p(agg), b, c_in, c_out, n, None, None, None, 0, _p(w2), _p(bias_), _p(y), _stream()),
+                           "gcn_conv_forward")
+            return y
+
+        def aten(x_, w_, bias_):
+            dense = adj.to_dense() if sparse else adj
+            dense = dense if dense.dim() == 3 else dense[None]
+            out = torch.einsum("oc,bcn->bon", w_.reshape(c_out, c_in), torch.matmul(x_, dense))      # gcnLayer.py:76-79
+            return out if bias_ is None else out + bias_[None, :, None]
+
+        w, bias = self.conv.weight, self.conv.bias
+        if _wants_grad(x, w, bias):
+            return hip_forward_aten_backward(hip, aten, (x, w, bias))
+        return hip(x, w.detach(), None if bias is None else bias.detach().contiguous())
 
 
 class GlobalPooling(nn.Module):
     def forward(self, x):
         """``x [B, C, n]`` -> ``[B, 2C]`` = max over points || mean over points (gcnLayer.py:90-94)."""
-        _no_grad_only("GlobalPooling", x)
         x = _need(x.contiguous().float(), "x", torch.float32, 3)
         b, c, n = x.shape
-        out = torch.empty(b, 2 * c, dtype=torch.float32, device=x.device)
-        _lib.check(_lib.lib().equigspr_gcn_global_pool(_p(x), b, c, n, _p(out), _stream()), "gcn_global_pool")
-        return out
+
+        def hip(x_):
+            out = torch.empty(b, 2 * c, dtype=torch.float32, device=x_.device)
+            _lib.check(_lib.lib().equigspr_gcn_global_pool(_p(x_), b, c, n, _p(out), _stream()), "gcn_global_pool")
+            return out
+
+        if _wants_grad(x):
+            return hip_forward_aten_backward(hip, lambda x_: torch.cat([x_.amax(dim=2), x_.mean(dim=2)], dim=1), (x,))
+        return hip(x)

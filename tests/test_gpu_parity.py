@@ -679,8 +679,27 @@ def test_so3_tensor_product_rejects(pk):
     with pytest.raises(NotImplementedError):
         with torch.no_grad():
             pk.SO3TensorProductLayer(16, 16).cuda()(torch.zeros(4, 16, device="cuda"))
-    with pytest.raises(NotImplementedError):
-        pk.SO3TensorProductLayer(32, 32).cuda()(torch.zeros(4, 32, device="cuda"))     # grad mode: forward-only op
+
+
+def test_so3_tensor_product_trains(pk):
+    """clean_so3_model.py:34-52 is a trainable nn.Module: input and parameter gradients against the oracle's autograd."""
+    torch.manual_seed(3)
+    layer = pk.SO3TensorProductLayer(32, 32).cuda()
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(700, 32, generator=g) * 0.3)
+    gy = torch.randn(700, 32, generator=g)
+    xg = x.cuda().requires_grad_(True)
+    y = layer(xg)
+    (y * gy.cuda()).sum().backward()
+    w = {k: v.detach().cpu().double().requires_grad_(True) for k, v in layer.state_dict().items()}
+    xr = x.double().requires_grad_(True)
+    yr = orc.so3_tensor_product(w, xr)
+    (yr * gy.double()).sum().backward()
+    assert torch.allclose(y.detach().cpu().double(), yr.detach(), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(xg.grad.cpu().double(), xr.grad, rtol=2e-4, atol=2e-4 * float(xr.grad.abs().max()))
+    for name, p_ in layer.named_parameters():
+        ref = w[name].grad
+        assert torch.allclose(p_.grad.cpu().double(), ref, rtol=2e-4, atol=2e-4 * float(ref.abs().max())), name
 
 
 # ------------------------------------------------------------------------------------------------
@@ -714,8 +733,20 @@ def test_gcn_conv_and_pool_golden(pk, golden_dir):
     assert np.abs(y_sparse.cpu().numpy() - fx["y64"]).max() <= tol
     assert np.abs(y_dense.cpu().numpy() - fx["y64"]).max() <= tol
     assert np.abs(pooled.cpu().numpy() - fx["pooled64"]).max() <= tol
-    with pytest.raises(NotImplementedError):
-        layer(adj, x)                                                       # grad mode: forward-only op
+    # trainable: gradients of both call forms against plain device autograd of the reference formula (gcnLayer.py:76-79)
+    xg = x.clone().requires_grad_(True)
+    layer.zero_grad()
+    gy = torch.randn_like(y_sparse)
+    (layer(adj, xg) * gy).sum().backward()
+    g_sparse = (xg.grad.clone(), layer.conv.weight.grad.clone(), layer.conv.bias.grad.clone())
+    xr = x.clone().requires_grad_(True)
+    layer.zero_grad()
+    (layer.conv(torch.matmul(xr, adj.to_dense()[None] if adj.to_dense().dim() == 2 else adj.to_dense())) * gy).sum().backward()
+    for a, b_ in zip(g_sparse, (xr.grad, layer.conv.weight.grad, layer.conv.bias.grad)):
+        assert torch.allclose(a, b_, rtol=1e-4, atol=1e-4 * float(b_.abs().max()))
+    pg = y_sparse.clone().requires_grad_(True)
+    pk.GlobalPooling()(pg).sum().backward()
+    assert pg.grad is not None and bool(torch.isfinite(pg.grad).all()) and float(pg.grad.abs().sum()) > 0
 
 
 @pytest.mark.parametrize("n,k,c_in,c_out", [(1024, 25, 3, 64), (257, 5, 33, 7)])
@@ -818,8 +849,18 @@ def test_pointnet_golden(pk, golden_dir):
     assert np.abs(h1.cpu().numpy() - fx["conv1_f64"]).max() <= anchored_tol(fx["conv1_f32"], fx["conv1_f64"])
     assert (h1.cpu().numpy()[3] == 0).all()
     assert np.abs(pooled.cpu().numpy() - fx["pooled_f64"]).max() <= anchored_tol(fx["pooled_f32"], fx["pooled_f64"])
-    with pytest.raises(NotImplementedError):
-        net.conv1(t("feats"), t("pos"), t("edge_index"))
+    # trainable: the whole encoder's gradients against the oracle's autograd (fp64)
+    gy = torch.randn(pooled.shape, generator=torch.Generator().manual_seed(2)).cuda()
+    feats = t("feats").clone().requires_grad_(True)
+    net.zero_grad()
+    (net(t("pos"), feats, t("edge_index"), t("batch")) * gy).sum().backward()
+    w = {k: v.detach().cpu().double().requires_grad_(True) for k, v in net.state_dict().items()}
+    fr = t("feats").cpu().double().requires_grad_(True)
+    _, ref = orc.pointnet_forward(w, t("pos").cpu().double(), fr, t("edge_index").cpu(), t("batch").cpu())
+    (ref * gy.cpu().double()).sum().backward()
+    assert torch.allclose(feats.grad.cpu().double(), fr.grad, rtol=2e-4, atol=2e-4 * float(fr.grad.abs().max()))
+    for name, p_ in net.named_parameters():
+        assert torch.allclose(p_.grad.cpu().double(), w[name].grad, rtol=2e-4, atol=2e-4 * float(w[name].grad.abs().max()) + 1e-9), name
 
 
 def test_pointnet_reference_call_shape(pk):
@@ -1019,3 +1060,36 @@ def test_train_step_gradients_vs_oracle_autograd(pk, feat, B):
             _grad_check(p.grad, refs["f32"][pn], refs["f64"][pn], pn, k=8.0, rel=5e-5)
             checked += 1
     assert checked > 20
+
+
+def test_standalone_egcl_layer_is_differentiable(pk):
+    """E_GCL.forward (train :280-289) as a stand-alone trainable layer: outputs and every gradient against the oracle layer."""
+    g = torch.Generator().manual_seed(12)
+    n, k, f = 200, 7, 32
+    x = torch.rand(n, 3, generator=g) * 2
+    h = torch.randn(n, f, generator=g)
+    e = orc.knn_graph(x, k)
+    ea = torch.ones(e.shape[1], 1)
+    torch.manual_seed(2)
+    layer = pk.E_GCL(f, f, f, edges_in_d=1, num_heads=1, device="cuda").cuda()
+    hg, xg = h.cuda().requires_grad_(True), x.cuda().requires_grad_(True)
+    h2, x2, ea2 = layer(hg, [e[0].cuda(), e[1].cuda()], xg, ea.cuda())
+    gh, gx = torch.randn(n, f, generator=g), torch.randn(n, 3, generator=g)
+    ((h2 * gh.cuda()).sum() + (x2 * gx.cuda()).sum()).backward()
+    w = {"gcl_0." + kk: v.detach().cpu().double().requires_grad_(True) for kk, v in layer.state_dict().items()}
+    hr, xr = h.double().requires_grad_(True), x.double().requires_grad_(True)
+    h_ref, x_ref = orc.egcl_layer(w, "gcl_0.", hr, xr, e[0], e[1], ea.double())
+    ((h_ref * gh.double()).sum() + (x_ref * gx.double()).sum()).backward()
+    assert torch.allclose(h2.detach().cpu().double(), h_ref.detach(), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(x2.detach().cpu().double(), x_ref.detach(), rtol=1e-4, atol=1e-5)
+    assert torch.allclose(hg.grad.cpu().double(), hr.grad, rtol=1e-3, atol=1e-4 * float(hr.grad.abs().max()))
+    assert torch.allclose(xg.grad.cpu().double(), xr.grad, rtol=1e-3, atol=1e-4 * float(xr.grad.abs().max()))
+    for name, p_ in layer.named_parameters():
+        ref = w["gcl_0." + name].grad
+        assert p_.grad is not None, name
+        assert torch.allclose(p_.grad.cpu().double(), ref, rtol=1e-3, atol=2e-4 * float(ref.abs().max()) + 1e-9), name
+    # a second call reuses the cached one-layer wrapper and accumulates into the same .grad tensors
+    g1 = layer.coord_mlp[0].weight.grad.clone()
+    h3, x3, _ = layer(hg, [e[0].cuda(), e[1].cuda()], xg, ea.cuda())
+    ((h3 * gh.cuda()).sum() + (x3 * gx.cuda()).sum()).backward()
+    assert torch.allclose(layer.coord_mlp[0].weight.grad, 2 * g1, rtol=1e-5, atol=1e-8)
