@@ -1,0 +1,121 @@
+// TORCH_LIBRARY(equigspr, ...) registration of the C-ABI entry points ("a TORCH_LIBRARY(equigspr, ...) HIP
+// extension ... each also reachable as extern "C" int equigspr_<op>(...)").  Host-only C++: every op checks its tensors, allocates
+// its outputs through ATen on the inputs' device and calls the SAME C-ABI function of libequigspr.so the ctypes binding uses, on
+// the current HIP stream -- so the ops are visible to the dispatcher (torch.ops.equigspr.*), usable from TorchScript / C++ front
+// ends, and there is exactly one implementation underneath.  Built by csrc/Makefile into ../libequigspr_torch.so (g++; no device
+// code here) and loaded with torch.ops.load_library (se3_equi_graph_registration_amd/torch_library.py).
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include "../../include/equigspr.h"
+
+namespace {
+
+void* cur_stream(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+void check(int rc, const char* what) {
+    TORCH_CHECK(rc == 0, "equigspr::", what, ": ", equigspr_last_error(), " (code ", rc, ")");
+}
+void need(const at::Tensor& t, const char* name, at::ScalarType dt, int64_t dim) {
+    TORCH_CHECK(t.is_cuda(), "equigspr: ", name, " must live on the GPU (there is no CPU path)");
+    TORCH_CHECK(t.scalar_type() == dt, "equigspr: ", name, " has the wrong dtype");
+    TORCH_CHECK(dim < 0 || t.dim() == dim, "equigspr: ", name, " must be ", dim, "-dimensional");
+    TORCH_CHECK(t.is_contiguous(), "equigspr: ", name, " must be contiguous");
+}
+
+// knn_graph(x [n, 3], k, loop) -> int64 [2, n k]   (torch_cluster.knn_graph as called at train :1005-1006)
+at::Tensor knn_graph(const at::Tensor& x, int64_t k, bool loop) {
+    need(x, "x", at::kFloat, 2);
+    TORCH_CHECK(x.size(1) == 3, "equigspr::knn_graph: x must be [n, 3]");
+    const int64_t n = x.size(0);
+    auto out = at::empty({1, 2, n * k}, x.options().dtype(at::kLong));
+    check(equigspr_knn_graph(x.data_ptr<float>(), 1, (int32_t)n, (int32_t)k, loop ? 1 : 0, out.data_ptr<int64_t>(), nullptr, nullptr,
+                             nullptr, 0, cur_stream(x)), "knn_graph");
+    return out[0];
+}
+
+// build_inverse_index(key int32 [E], n_nodes) -> (ptr int32 [N + 1], perm int32 [E], inv int32 [E])   (stable counting sort)
+std::tuple<at::Tensor, at::Tensor, at::Tensor> build_inverse_index(const at::Tensor& key, int64_t n_nodes) {
+    need(key, "key", at::kInt, 1);
+    const int64_t e = key.size(0);
+    auto o = key.options();
+    auto ptr = at::empty({n_nodes + 1}, o), perm = at::empty({e}, o), inv = at::empty({e}, o), scratch = at::empty({n_nodes + 1}, o);
+    check(equigspr_build_csr(key.data_ptr<int32_t>(), (int32_t)e, (int32_t)n_nodes, ptr.data_ptr<int32_t>(), perm.data_ptr<int32_t>(),
+                             inv.data_ptr<int32_t>(), scratch.data_ptr<int32_t>(), EQUIGSPR_SCRATCH_DIRTY, cur_stream(key)), "build_csr");
+    return {ptr, perm, inv};
+}
+
+// egnn_forward(params, h [N, in], x [N, 3], row int32 [E], col int32 [E], edge_attr [E] or empty, cfg ints) -> (h_out, x_out)
+// Inference form of EGNN.forward (train :328-340); the graph's inverse indices are built here.
+std::tuple<at::Tensor, at::Tensor> egnn_forward(const at::Tensor& params, const at::Tensor& h, const at::Tensor& x, const at::Tensor& row,
+                                                const at::Tensor& col, const c10::optional<at::Tensor>& edge_attr, int64_t hidden_nf,
+                                                int64_t out_nf, int64_t n_layers, int64_t num_heads, int64_t edge_basis) {
+    need(params, "params", at::kFloat, 1); need(h, "h", at::kFloat, 2); need(x, "x", at::kFloat, 2);
+    need(row, "row", at::kInt, 1); need(col, "col", at::kInt, 1);
+    const int64_t n = h.size(0), e = row.size(0);
+    equigspr_egnn_config cfg{(int32_t)h.size(1), (int32_t)hidden_nf, (int32_t)out_nf, edge_attr.has_value() ? 1 : 0, (int32_t)n_layers,
+                             (int32_t)num_heads, (int32_t)edge_basis};
+    TORCH_CHECK(equigspr_egnn_param_count(&cfg) == params.numel(), "equigspr::egnn_forward: parameter block has ", params.numel(),
+                " floats, the configuration needs ", equigspr_egnn_param_count(&cfg));
+    if (edge_attr.has_value()) need(*edge_attr, "edge_attr", at::kFloat, -1);
+    auto io = row.options();
+    auto rptr = at::empty({n + 1}, io), rperm = at::empty({e}, io), rinv = at::empty({e}, io), scratch = at::empty({n + 1}, io);
+    void* s = cur_stream(h);
+    check(equigspr_build_csr(row.data_ptr<int32_t>(), (int32_t)e, (int32_t)n, rptr.data_ptr<int32_t>(), rperm.data_ptr<int32_t>(),
+                             rinv.data_ptr<int32_t>(), scratch.data_ptr<int32_t>(), EQUIGSPR_SCRATCH_DIRTY, s), "build_csr");
+    equigspr_graph g{(int32_t)n, (int32_t)e, row.data_ptr<int32_t>(), col.data_ptr<int32_t>(), rptr.data_ptr<int32_t>(),
+                     rperm.data_ptr<int32_t>(), nullptr, nullptr, rinv.data_ptr<int32_t>()};
+    auto fo = h.options();
+    auto h_out = at::empty({n, out_nf}, fo), x_out = at::empty({n, 3}, fo);
+    auto work = at::empty({equigspr_egnn_work_size(&cfg, (int32_t)n, (int32_t)e)}, fo);
+    check(equigspr_egnn_forward(&cfg, params.data_ptr<float>(), &g, h.data_ptr<float>(), x.data_ptr<float>(),
+                                edge_attr.has_value() ? edge_attr->data_ptr<float>() : nullptr, h_out.data_ptr<float>(),
+                                x_out.data_ptr<float>(), nullptr, work.data_ptr<float>(), s), "egnn_forward");
+    return {h_out, x_out};
+}
+
+// weighted_kabsch_forward(src [B, n, 3], tgt [B, n, 3], w [B, n]) -> (R [B, 3, 3], t [B, 3], aux)   (train :726-758)
+std::tuple<at::Tensor, at::Tensor, at::Tensor> weighted_kabsch_forward(const at::Tensor& src, const at::Tensor& tgt, const at::Tensor& w) {
+    need(src, "src", at::kFloat, 3); need(tgt, "tgt", at::kFloat, 3); need(w, "weights", at::kFloat, 2);
+    const int64_t b = src.size(0), n = src.size(1);
+    auto R = at::empty({b, 3, 3}, src.options()), t = at::empty({b, 3}, src.options()), aux = at::empty({b, EQUIGSPR_KABSCH_AUX}, src.options());
+    check(equigspr_kabsch_forward(src.data_ptr<float>(), tgt.data_ptr<float>(), w.data_ptr<float>(), (int32_t)b, (int32_t)n,
+                                  R.data_ptr<float>(), t.data_ptr<float>(), aux.data_ptr<float>(), cur_stream(src)), "kabsch_forward");
+    return {R, t, aux};
+}
+
+// weighted_kabsch_backward(src, tgt, w, aux, grad_R, grad_t) -> (grad_src, grad_tgt, grad_w)
+std::tuple<at::Tensor, at::Tensor, at::Tensor> weighted_kabsch_backward(const at::Tensor& src, const at::Tensor& tgt, const at::Tensor& w,
+                                                                         const at::Tensor& aux, const at::Tensor& gR, const at::Tensor& gt) {
+    need(src, "src", at::kFloat, 3); need(tgt, "tgt", at::kFloat, 3); need(w, "weights", at::kFloat, 2); need(aux, "aux", at::kFloat, 2);
+    need(gR, "grad_R", at::kFloat, 3); need(gt, "grad_t", at::kFloat, 2);
+    const int64_t b = src.size(0), n = src.size(1);
+    auto gs = at::empty_like(src), gtt = at::empty_like(tgt), gw = at::empty_like(w);
+    check(equigspr_kabsch_backward(src.data_ptr<float>(), tgt.data_ptr<float>(), w.data_ptr<float>(), aux.data_ptr<float>(),
+                                   gR.data_ptr<float>(), gt.data_ptr<float>(), (int32_t)b, (int32_t)n, gs.data_ptr<float>(),
+                                   gtt.data_ptr<float>(), gw.data_ptr<float>(), cur_stream(src)), "kabsch_backward");
+    return {gs, gtt, gw};
+}
+
+int64_t abi_version() { return equigspr_abi_version(); }
+
+}  // namespace
+
+TORCH_LIBRARY(equigspr, m) {
+    m.def("abi_version() -> int", &abi_version);
+    m.def("knn_graph(Tensor x, int k, bool loop=True) -> Tensor");
+    m.def("build_inverse_index(Tensor key, int n_nodes) -> (Tensor, Tensor, Tensor)");
+    m.def("egnn_forward(Tensor params, Tensor h, Tensor x, Tensor row, Tensor col, Tensor? edge_attr, int hidden_nf, int out_nf, "
+          "int n_layers, int num_heads=1, int edge_basis=0) -> (Tensor, Tensor)");
+    m.def("weighted_kabsch_forward(Tensor src, Tensor tgt, Tensor weights) -> (Tensor, Tensor, Tensor)");
+    m.def("weighted_kabsch_backward(Tensor src, Tensor tgt, Tensor weights, Tensor aux, Tensor grad_R, Tensor grad_t) -> (Tensor, Tensor, Tensor)");
+}
+
+TORCH_LIBRARY_IMPL(equigspr, CUDA, m) {       // the HIP backend key of a ROCm build of PyTorch
+    m.impl("knn_graph", &knn_graph);
+    m.impl("build_inverse_index", &build_inverse_index);
+    m.impl("egnn_forward", &egnn_forward);
+    m.impl("weighted_kabsch_forward", &weighted_kabsch_forward);
+    m.impl("weighted_kabsch_backward", &weighted_kabsch_backward);
+}

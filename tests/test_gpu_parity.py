@@ -1093,3 +1093,42 @@ def test_standalone_egcl_layer_is_differentiable(pk):
     h3, x3, _ = layer(hg, [e[0].cuda(), e[1].cuda()], xg, ea.cuda())
     ((h3 * gh.cuda()).sum() + (x3 * gx.cuda()).sum()).backward()
     assert torch.allclose(layer.coord_mlp[0].weight.grad, 2 * g1, rtol=1e-5, atol=1e-8)
+
+
+def test_torch_library_ops_match_the_ctypes_path(pk):
+    """torch.ops.equigspr.* (TORCH_LIBRARY registration, csrc/torch_ops.cpp) call the same C-ABI functions as the package's ctypes
+    binding: identical outputs, and the dispatcher-level argument checks raise."""
+    from se3_equi_graph_registration_amd import torch_library
+    ops = torch_library.load()
+    g = torch.Generator().manual_seed(23)
+    n, k = 500, 9
+    x = (torch.rand(n, 3, generator=g) * 2).cuda()
+    h = torch.randn(n, 32, generator=g).cuda()
+    e = ops.knn_graph(x, k, True)
+    assert torch.equal(e, pk.knn_graph(x, k, loop=True))
+    row32, col32 = e[0].int().contiguous(), e[1].int().contiguous()
+    ptr, perm, inv = ops.build_inverse_index(row32, n)
+    order = np.argsort(e[0].cpu().numpy(), kind="stable")
+    np.testing.assert_array_equal(perm.cpu().numpy(), order)
+    assert int(ptr[-1]) == n * k and torch.equal(inv[perm.long()].cpu(), torch.arange(n * k, dtype=torch.int32))
+    torch.manual_seed(1)
+    m = pk.EGNN(32, 32, 32, in_edge_nf=1, device="cuda", n_layers=2)
+    with torch.no_grad():
+        h_ref, x_ref = m(h, x, [e[0], e[1]], torch.ones(n * k, 1, device="cuda"))
+    m._ensure_flat()
+    h_o, x_o = ops.egnn_forward(m.flat_params, h, x, row32, col32, torch.ones(n * k, device="cuda"), 32, 32, 2, 1, 0)
+    assert torch.equal(h_o, h_ref) and torch.equal(x_o, x_ref)
+    src, tgt = torch.rand(3, 200, 3, generator=g).cuda(), torch.rand(3, 200, 3, generator=g).cuda()
+    w = torch.softmax(torch.randn(3, 200, generator=g), dim=1).cuda()
+    R, t, aux = ops.weighted_kabsch_forward(src, tgt, w)
+    R2, t2 = pk.weighted_kabsch(src, tgt, w)
+    assert torch.equal(R, R2) and torch.equal(t, t2)
+    gs, gt_, gw = ops.weighted_kabsch_backward(src, tgt, w, aux, torch.ones_like(R), torch.ones_like(t))
+    sr, tr, wr = src.clone().requires_grad_(True), tgt.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    Rr, tt = pk.weighted_kabsch(sr, tr, wr)
+    (Rr.sum() + tt.sum()).backward()
+    assert torch.allclose(gs, sr.grad) and torch.allclose(gt_, tr.grad) and torch.allclose(gw, wr.grad)
+    with pytest.raises(RuntimeError):
+        ops.egnn_forward(m.flat_params[:-1].contiguous(), h, x, row32, col32, None, 32, 32, 2, 1, 0)
+    with pytest.raises(RuntimeError):
+        ops.knn_graph(x.double(), k, True)
