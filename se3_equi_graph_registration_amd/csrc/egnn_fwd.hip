@@ -280,29 +280,40 @@ __global__ __launch_bounds__(256, 3) void node_fwd_kernel(
 // straight from the parameter block (L2-resident, 16-byte rows) -- the lane-per-feature kernel spent a third of its time
 // staging four matrices into LDS per 8 nodes and the rest in barrier-separated LDS dot products.
 // ---------------------------------------------------------------------------------------
-template <int H, int A, int D>      // D = segment rows in flight per lane (16: a k = 20 neighbourhood is two round trips; 4: registers for occupancy)
+// four consecutive matrix entries W[row][col .. col + 3] as an MFMA A-operand quad: one 16-byte load when the row stride keeps
+// them aligned (hidden_nf 32), four 4-byte loads otherwise (hidden_nf 33: 33- / 66- / 79-float rows)
+template <bool kAligned>
+__device__ __forceinline__ f32x4 wquad(const float* __restrict__ w, int row, int ld, int col) {
+    if constexpr (kAligned) return ldg4(w + (size_t)row * ld + col);
+    const float* p = w + (size_t)row * ld + col;
+    return f32x4{p[0], p[1], p[2], p[3]};
+}
+
+template <int H, int A, int D, int kB = 0>      // D = segment rows in flight per lane (16: a k = 20 neighbourhood is two round trips; 4: registers for occupancy)
 __global__ __launch_bounds__(64) void node_fwd16_kernel(
     const float* __restrict__ lw, const float* __restrict__ next_lw, const float* __restrict__ w_out, const float* __restrict__ b_out,
     int out_nf, const int* __restrict__ rptr, const float* __restrict__ m_in, const float* __restrict__ trans_in,
     const float* __restrict__ h, const float* __restrict__ x, int n_nodes, float* __restrict__ h_next, float* __restrict__ x_next,
     float* __restrict__ agg_save, float* __restrict__ P, float* __restrict__ h_out) {
-    using LL = LP<32, H, A>;
+    constexpr int F = 32 + kB, FP = 32 + 4 * kB;      // hidden_nf 33: feature 32 is a scalar per node held by its four lanes (the "border")
+    using LL = LP<F, H, A>;
+    constexpr bool kAl = (kB == 0);
     const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
     const int j = min((int)blockIdx.x * 16 + i, n_nodes - 1);
     const bool live = (int)blockIdx.x * 16 + i < n_nodes;
     const int lo = rptr[j], hi = rptr[j + 1];
-    // weights of the node MLP: requested before the segment loop, consumed after it
+    // weights of the node MLP: requested before the segment loop, consumed after it.  W4 = [F][2F] over [h | agg]
     f32x4 w4a[2][4], w5a[2][2], b4v[2], b5v[2];
 #pragma unroll
     for (int bo = 0; bo < 2; ++bo) {
 #pragma unroll
-        for (int bi = 0; bi < 4; ++bi) w4a[bo][bi] = ldg4(lw + LL::w4 + (16 * bo + i) * 64 + 16 * bi + 4 * g);
+        for (int bi = 0; bi < 4; ++bi) w4a[bo][bi] = wquad<kAl>(lw + LL::w4, 16 * bo + i, 2 * F, (bi < 2 ? 0 : F) + 16 * (bi & 1) + 4 * g);
 #pragma unroll
-        for (int bi = 0; bi < 2; ++bi) w5a[bo][bi] = ldg4(lw + LL::w5 + (16 * bo + i) * 32 + 16 * bi + 4 * g);
-        b4v[bo] = ldg4(lw + LL::b4 + 16 * bo + 4 * g);
-        b5v[bo] = ldg4(lw + LL::b5 + 16 * bo + 4 * g);
+        for (int bi = 0; bi < 2; ++bi) w5a[bo][bi] = wquad<kAl>(lw + LL::w5, 16 * bo + i, F, 16 * bi + 4 * g);
+        b4v[bo] = wquad<kAl>(lw + LL::b4, 0, 0, 16 * bo + 4 * g);
+        b5v[bo] = wquad<kAl>(lw + LL::b5, 0, 0, 16 * bo + 4 * g);
     }
-    // next layer's projection weights (W1 rows are 77 floats apart: 4-byte aligned only -> scalar loads), also requested up front
+    // next layer's projection weights (W1 rows are 2F + 13 floats apart: 4-byte aligned only -> scalar loads), also requested up front
     float as[2][2][4], at[2][2][4];
     f32x4 pcb[2];
     if (next_lw) {
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(64) void node_fwd16_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     as[bi][bo][r] = next_lw[LL::w1_off(16 * bo + i, 16 * bi + 4 * g + r)];
-                    at[bi][bo][r] = next_lw[LL::w1_off(16 * bo + i, 32 + 16 * bi + 4 * g + r)];
+                    at[bi][bo][r] = next_lw[LL::w1_off(16 * bo + i, F + 16 * bi + 4 * g + r)];
                 }
 #pragma unroll
         for (int bo = 0; bo < 2; ++bo)
@@ -322,7 +333,8 @@ __global__ __launch_bounds__(64) void node_fwd16_kernel(
     }
     f32x4 hj[2], agg[2] = {splat4(0.0f), splat4(0.0f)};
 #pragma unroll
-    for (int b = 0; b < 2; ++b) hj[b] = ldg4(h + (size_t)j * 32 + 16 * b + 4 * g);
+    for (int b = 0; b < 2; ++b) hj[b] = ldg4(h + (size_t)j * FP + 16 * b + 4 * g);
+    float hjb = kB ? h[(size_t)j * FP + 32] : 0.0f, aggb = 0.0f;
     float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
     // ---- segment sums over rows lo..hi-1 (ascending edge id)
     const int len = hi - lo;
@@ -332,17 +344,20 @@ __global__ __launch_bounds__(64) void node_fwd16_kernel(
     for (int a0 = 0; a0 < maxlen; a0 += D) {
         f32x4 v[D][2];
         float4 tv[D];
+        float vb[D];
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             const bool in = a0 + u < len;
             const size_t a = (size_t)(lo + (in ? a0 + u : 0));
 #pragma unroll
-            for (int b = 0; b < 2; ++b) v[u][b] = in ? ldg4(m_in + a * 32 + 16 * b + 4 * g) : splat4(0.0f);
+            for (int b = 0; b < 2; ++b) v[u][b] = in ? ldg4(m_in + a * FP + 16 * b + 4 * g) : splat4(0.0f);
+            vb[u] = (kB && in) ? m_in[a * FP + 32] : 0.0f;
             tv[u] = (in && g == 0) ? reinterpret_cast<const float4*>(trans_in)[a] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             agg[0] += v[u][0]; agg[1] += v[u][1];
+            if (kB) aggb += vb[u];
             xs.x += tv[u].x; xs.y += tv[u].y; xs.z += tv[u].z;
         }
     }
@@ -352,9 +367,25 @@ __global__ __launch_bounds__(64) void node_fwd16_kernel(
         x_next[(size_t)j * 3 + 2] = x[(size_t)j * 3 + 2] + xs.z;
     }
     if (live && agg_save) {
-        st4(agg_save + (size_t)j * 32 + 4 * g, agg[0]);
-        st4(agg_save + (size_t)j * 32 + 16 + 4 * g, agg[1]);
+        st4(agg_save + (size_t)j * FP + 4 * g, agg[0]);
+        st4(agg_save + (size_t)j * FP + 16 + 4 * g, agg[1]);
+        if (kB && g == 0) st4(agg_save + (size_t)j * FP + 32, f32x4{aggb, 0.0f, 0.0f, 0.0f});
     }
+    // border helpers: column c of a matrix adds W[o][c] * vb to every output o; row 32 is a per-lane partial dot + lane-group sum
+    auto add_col = [&](f32x4 (&acc)[2], const float* __restrict__ w, int ld, int c, float vb) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[b][r] = fmaf(w[(size_t)(16 * b + 4 * g + r) * ld + c], vb, acc[b][r]);
+    };
+    auto row_dot = [&](const float* __restrict__ wrow, int c0, const f32x4 (&v)[2]) {
+        float p = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p = fmaf(wrow[c0 + 16 * b + 4 * g + r], v[b][r], p);
+        return p;
+    };
     // ---- hid = SiLU(W4 [h | agg] + b4)
     f32x4 acc[2] = {b4v[0], b4v[1]};
 #pragma unroll
@@ -366,9 +397,17 @@ __global__ __launch_bounds__(64) void node_fwd16_kernel(
             acc[1] = mfma16(w4a[1][bi][r], bv[r], acc[1]);
         }
     }
+    float vb4 = 0.0f;
+    if constexpr (kB == 1) {
+        add_col(acc, lw + LL::w4, 2 * F, 32, hjb);
+        add_col(acc, lw + LL::w4, 2 * F, F + 32, aggb);
+        const float* w32 = lw + LL::w4 + (size_t)32 * 2 * F;
+        vb4 = gsum(row_dot(w32, 0, hj) + row_dot(w32, F, agg)) + w32[32] * hjb + w32[F + 32] * aggb + lw[LL::b4 + 32];
+    }
     f32x4 hid[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) hid[b] = acc[b] * sigmoid4(acc[b]);
+    const float hidb = kB ? vb4 * sigmoid_fast(vb4) : 0.0f;
     // ---- h' = h + W5 hid + b5   (:257-259)
     f32x4 hn[2] = {hj[0] + b5v[0], hj[1] + b5v[1]};
 #pragma unroll
@@ -378,9 +417,16 @@ __global__ __launch_bounds__(64) void node_fwd16_kernel(
             hn[0] = mfma16(w5a[0][bi][r], hid[bi][r], hn[0]);
             hn[1] = mfma16(w5a[1][bi][r], hid[bi][r], hn[1]);
         }
+    float hnb = 0.0f;
+    if constexpr (kB == 1) {
+        add_col(hn, lw + LL::w5, F, 32, hidb);
+        const float* w32 = lw + LL::w5 + (size_t)32 * F;
+        hnb = hjb + lw[LL::b5 + 32] + gsum(row_dot(w32, 0, hid)) + w32[32] * hidb;
+    }
     if (live) {
-        st4(h_next + (size_t)j * 32 + 4 * g, hn[0]);
-        st4(h_next + (size_t)j * 32 + 16 + 4 * g, hn[1]);
+        st4(h_next + (size_t)j * FP + 4 * g, hn[0]);
+        st4(h_next + (size_t)j * FP + 16 + 4 * g, hn[1]);
+        if (kB && g == 0) st4(h_next + (size_t)j * FP + 32, f32x4{hnb, 0.0f, 0.0f, 0.0f});
     }
     if (next_lw) {
         // ---- next layer's projections: P = [W_src h' | W_tgt h' + b1]
@@ -394,12 +440,25 @@ __global__ __launch_bounds__(64) void node_fwd16_kernel(
                 pc[0] = mfma16(at[bi][0][r], hn[bi][r], pc[0]);
                 pc[1] = mfma16(at[bi][1][r], hn[bi][r], pc[1]);
             }
+        float prb = 0.0f, pcbb = 0.0f;
+        if constexpr (kB == 1) {          // H == 1 here: W1 is one [33][79] block
+            const float* w1 = next_lw + LL::w1_off(0, 0);
+            add_col(pr, w1, LL::D, 32, hnb);
+            add_col(pc, w1, LL::D, F + 32, hnb);
+            const float* w32 = w1 + (size_t)32 * LL::D;
+            prb = gsum(row_dot(w32, 0, hn)) + w32[32] * hnb;
+            pcbb = gsum(row_dot(w32, F, hn)) + w32[F + 32] * hnb + next_lw[LL::b1_off(32)];
+        }
         if (live) {
-            float* prow = P + (size_t)j * 64 + 4 * g;
-            st4(prow, pr[0]); st4(prow + 16, pr[1]); st4(prow + 32, pc[0]); st4(prow + 48, pc[1]);
+            float* prow = P + (size_t)j * 2 * FP + 4 * g;
+            st4(prow, pr[0]); st4(prow + 16, pr[1]); st4(prow + FP, pc[0]); st4(prow + FP + 16, pc[1]);
+            if (kB && g == 0) {
+                st4(P + (size_t)j * 2 * FP + 32, f32x4{prb, 0.0f, 0.0f, 0.0f});
+                st4(P + (size_t)j * 2 * FP + FP + 32, f32x4{pcbb, 0.0f, 0.0f, 0.0f});
+            }
         }
     } else {
-        // ---- embedding_out (:337): out_nf <= 64 rows of W_out [out_nf][32]
+        // ---- embedding_out (:337): out_nf <= 64 rows of W_out [out_nf][F]
         for (int bo = 0; bo * 16 < out_nf; ++bo) {
             const int orow = 16 * bo + i;
             f32x4 o4;
@@ -407,9 +466,13 @@ __global__ __launch_bounds__(64) void node_fwd16_kernel(
             for (int r = 0; r < 4; ++r) { const int oo = 16 * bo + 4 * g + r; o4[r] = oo < out_nf ? b_out[oo] : 0.0f; }
 #pragma unroll
             for (int bi = 0; bi < 2; ++bi) {
-                const f32x4 a = orow < out_nf ? ldg4(w_out + (size_t)orow * 32 + 16 * bi + 4 * g) : splat4(0.0f);
+                const f32x4 a = orow < out_nf ? wquad<kAl>(w_out, orow, F, 16 * bi + 4 * g) : splat4(0.0f);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o4 = mfma16(a[r], hn[bi][r], o4);
+            }
+            if constexpr (kB == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const int oo = 16 * bo + 4 * g + r; if (oo < out_nf) o4[r] = fmaf(w_out[(size_t)oo * F + 32], hnb, o4[r]); }
             }
             if (live) {
 #pragma unroll
@@ -505,14 +568,14 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
 #ifndef EQ_NODE_FWD16
 #define EQ_NODE_FWD16 1
 #endif
-        if constexpr (F == 32 && EQ_NODE_FWD16) {
+        if constexpr (EQ_NODE_FWD16 && (F == 32 || H == 1)) {
             // few nodes: one wave per CU or less, latency decides -> 16 rows in flight; many nodes: 4 (registers for occupancy)
             if (N <= 16 * 1024)
-                hipLaunchKernelGGL((node_fwd16_kernel<H, A, 16>), dim3(ceil_div(N, 16)), dim3(64), 0, s, lw, last ? nullptr : lw + ML.layer_size,
+                hipLaunchKernelGGL((node_fwd16_kernel<H, A, 16, F - 32>), dim3(ceil_div(N, 16)), dim3(64), 0, s, lw, last ? nullptr : lw + ML.layer_size,
                                    params + ML.w_out, params + ML.b_out, cfg->out_nf, g->rptr, m, trans, hbuf(l), xbuf(l), N, hbuf(l + 1), xn,
                                    training ? aggs + (size_t)l * N * FP : nullptr, P, h_out);
             else
-                hipLaunchKernelGGL((node_fwd16_kernel<H, A, 4>), dim3(ceil_div(N, 16)), dim3(64), 0, s, lw, last ? nullptr : lw + ML.layer_size,
+                hipLaunchKernelGGL((node_fwd16_kernel<H, A, 4, F - 32>), dim3(ceil_div(N, 16)), dim3(64), 0, s, lw, last ? nullptr : lw + ML.layer_size,
                                    params + ML.w_out, params + ML.b_out, cfg->out_nf, g->rptr, m, trans, hbuf(l), xbuf(l), N, hbuf(l + 1), xn,
                                    training ? aggs + (size_t)l * N * FP : nullptr, P, h_out);
         } else
