@@ -16,32 +16,20 @@
 // the slabs in fixed order into the flat gradient block (+=): bitwise reproducible, no atomics.
 #include "egnn_mfma.h"
 #include "egnn_mfma16.h"
+#include "egnn_bwd16.h"
 
 #include <algorithm>
 
 namespace eq {
 
 
-#ifndef EQ_NODE_BWD_BLOCKS
-#define EQ_NODE_BWD_BLOCKS 1024
-#endif
-constexpr int kNodeBwdBlocks = EQ_NODE_BWD_BLOCKS;   // slab count of the node-level kernels
 constexpr int kEdgeBwdBlocks = 1024;  // max slab count of the edge kernel
-
-// ---- slab sizes ---------------------------------------------------------------------------
-template <int F> struct Slabs {
-    static constexpr int node = F * 2 * F + F + F * F + F;          // dW4 | db4 | dW5 | db5
-    static constexpr int gather = 2 * F * F + F;                    // dW1a | dW1b | db1
-    static constexpr int e_geo = 0;                                  // F x 16 (12 geo + attr + pad)
-    static constexpr int e_w2 = F * 16;
-    static constexpr int e_w6 = e_w2 + F * F;
-    static constexpr int e_b2 = e_w6 + F * F;
-    static constexpr int e_b6 = e_b2 + F;
-    static constexpr int e_gam = e_b6 + F;
-    static constexpr int e_bet = e_gam + F;
-    static constexpr int e_w7 = e_bet + F;
-    static constexpr int edge = e_w7 + F;
-};
+#ifndef EQ_NODE_BWD16
+#define EQ_NODE_BWD16 1
+#endif
+#ifndef EQ_NODE_BWD16_MIN
+#define EQ_NODE_BWD16_MIN 16384
+#endif
 
 // Node-level weight gradients are sums over nodes of outer products a_j (x) b_j.  After a group of
 // NS nodes has left its vectors in LDS, ALL 256 threads accumulate: thread (f = tid % G, c = tid / G)
@@ -644,51 +632,6 @@ __global__ __launch_bounds__(256, 2) void gather_node_bwd_kernel(
 // (40; operands transposed through wave-private LDS tiles).  Geometry forward / backward once per edge in the chunk's
 // front / back phases.
 // ---------------------------------------------------------------------------------------
-// acc[bx][by] += X^T Y over the 16 edges of the tiles X [16][LD], Y [16][ldy] (16 columns per block);
-// K step s, lane group g <-> edge s + 4 g (rows 4 apart: the two groups of a 32-lane LDS access hit disjoint banks).
-// Border (hidden_nf = 33, kB): column 32 of a tile row holds the edge's 33rd feature (a scalar xb / yb per edge):
-//   bcol[bx] += X[:, 16 bx + i] * yb (column 32 of the gradient), brow[by] += xb * Y[:, 16 by + i] (row 32),
-//   corner += xb * yb, xbs += xb; all per lane group g, reduced over g after the chunk loop.
-struct PassBorder {
-    float bcol[2], brow[2], corner, xbs;
-    __device__ __forceinline__ void init() { bcol[0] = bcol[1] = brow[0] = brow[1] = corner = xbs = 0.0f; }
-};
-template <int NBY, bool kColSum, int kB = 0>
-__device__ __forceinline__ void pass16(const float* X, const float* Y, int ldy, int i, int g, f32x4 (&acc)[2][NBY], float (&cs)[2],
-                                       PassBorder& pb) {
-    float a0[4], a1[4], b0[4], b1[4], xb[4], yb[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int ed = s + 4 * g;
-        a0[s] = X[ed * Chunk16::LD + i];
-        a1[s] = X[ed * Chunk16::LD + 16 + i];
-        b0[s] = Y[ed * ldy + i];
-        b1[s] = (NBY == 2) ? Y[ed * ldy + 16 + i] : 0.0f;
-        xb[s] = kB ? X[ed * Chunk16::LD + 32] : 0.0f;
-        yb[s] = (kB && NBY == 2) ? Y[ed * ldy + 32] : 0.0f;
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        if (kColSum) { cs[0] += a0[s]; cs[1] += a1[s]; }
-        acc[0][0] = mfma16(a0[s], b0[s], acc[0][0]);
-        acc[1][0] = mfma16(a1[s], b0[s], acc[1][0]);
-        if constexpr (NBY == 2) {
-            acc[0][1] = mfma16(a0[s], b1[s], acc[0][1]);
-            acc[1][1] = mfma16(a1[s], b1[s], acc[1][1]);
-        }
-        if constexpr (kB == 1) {
-            pb.brow[0] = fmaf(xb[s], b0[s], pb.brow[0]);
-            if constexpr (NBY == 2) {
-                pb.brow[1] = fmaf(xb[s], b1[s], pb.brow[1]);
-                pb.bcol[0] = fmaf(a0[s], yb[s], pb.bcol[0]);
-                pb.bcol[1] = fmaf(a1[s], yb[s], pb.bcol[1]);
-                pb.corner = fmaf(xb[s], yb[s], pb.corner);
-                if (kColSum) pb.xbs += xb[s];
-            }
-        }
-    }
-}
-
 constexpr int kBwd16Waves = 8;
 #ifndef EQ_BWD16_NW33
 #define EQ_BWD16_NW33 8                // waves per workgroup (= 2 x waves per SIMD) of the hidden_nf = 33 variant
@@ -1191,19 +1134,48 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
                            work + B.Gh[cur], hs + (size_t)l * N * FP, aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg,
                            Pbuf, work + B.node_slab + slab_of(l));
     };
-    constexpr bool kFuse = (F == 32);                      // gather_bwd(l) + node_bwd(l-1) in one kernel
-    if (kFuse) launch_node_bwd(L - 1);
+    // the 16-node MFMA kernels of egnn_node_bwd.hip: hidden_nf 33 always; hidden_nf 32 from EQ_NODE_BWD16_MIN nodes on (one
+    // 2 048-point pair: 18.4 us against 15.3 us for the per-feature kernel; 16 pairs: 121 against 142 us)
+    const bool k16 = EQ_NODE_BWD16 != 0 && (F == 33 || N > EQ_NODE_BWD16_MIN);
+    constexpr bool kFuse = (F == 32);                      // per-feature kernels: gather_bwd(l) + node_bwd(l-1) in one kernel
+    int nslab = ngrid;                                     // slab copies per layer of the node-level kernels
+    NodeBwd16Args na{};
+    na.rptr = g->rptr; na.rperm = g->rperm; na.cptr = g->cptr; na.cperm = g->cperm;
+    na.dt1 = work + B.dt1; na.gxr = work + B.gxr; na.gxc = work + B.gxc;
+    na.n_nodes = N; na.dh_part = work + B.dh_part; na.dagg = work + B.dagg; na.P = Pbuf;
+    auto node_part = [&](int l) {                          // node-MLP backward of layer l
+        na.lw_n = params + ML.layer0 + (size_t)l * ML.layer_size;
+        na.h_n = hs + (size_t)l * N * FP; na.agg_n = aggs + (size_t)l * N * FP;
+        na.node_slab = work + B.node_slab + slab_of(l);
+    };
+    if (k16) {
+        node_part(L - 1);
+        na.Gh_in = work + B.Gh[cur];
+        const int rc = launch_node_bwd16(F, H, A, kNodeBwdNode, na, s, &nslab);
+        if (rc) return rc;
+    } else if (kFuse) launch_node_bwd(L - 1);
     for (int l = L - 1; l >= 0; --l) {
         const float* lw = params + ML.layer0 + (size_t)l * ML.layer_size;
         const float* h_l = hs + (size_t)l * N * FP;
         const float* x_l = xs + (size_t)l * N * 3;
-        if (!kFuse) launch_node_bwd(l);
+        if (!kFuse && !k16) launch_node_bwd(l);
         if (E > 0) {
             const int rc = launch_edge_bwd<F, H, A>(lw, g, edge_attr, x_l, Pbuf, work + B.dagg, work + B.Gx[cur],
                                                     work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab + slab_of(l), cfg->edge_basis, s, &egrid);
             if (rc) return rc;
         }
         const int nxt = cur ^ 1;
+        if (k16) {
+            na.lw_g = lw; na.h_g = h_l; na.Gx = work + B.Gx[cur]; na.Gx_new = work + B.Gx[nxt];
+            na.gat_slab = work + B.gat_slab + slab_of(l);
+            na.gx_out3 = (l == 0) ? grad_x_in : nullptr;
+            na.Gh_out = work + B.Gh[nxt];
+            if (l > 0) node_part(l - 1);
+            const int rc = launch_node_bwd16(F, H, A, l > 0 ? (kNodeBwdGather | kNodeBwdNode) : kNodeBwdGather, na, s, &nslab);
+            if (rc) return rc;
+            cur = nxt;
+            continue;
+        }
         if constexpr (kFuse) {
             if (l > 0) {
                 hipLaunchKernelGGL((gather_node_bwd_kernel<H, A>), dim3(ngrid), dim3(256), 0, s, lw, lw - ML.layer_size, g->rptr, g->rperm,
@@ -1228,7 +1200,7 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
                            work + B.emb_slab2, ngrid, n_in, grad_params + ML.w_in};
         const int gx_layer = ceil_div(ML.layer_size, 32), gx_plain = ceil_div(n_out, 32) + ceil_div(n_in, 32);
         hipLaunchKernelGGL((layer_grad_reduce_kernel<F, H, A>), dim3(gx_layer > gx_plain ? gx_layer : gx_plain, L + 1), dim3(256), 0, s,
-                           work + B.node_slab, ngrid, work + B.edge_slab, E > 0 ? egrid : 0, work + B.gat_slab, ngrid,
+                           work + B.node_slab, nslab, work + B.edge_slab, E > 0 ? egrid : 0, work + B.gat_slab, nslab,
                            grad_params + ML.layer0, B.layer_stride, (size_t)ML.layer_size, L, pj);
     }
     EQ_CHECK_LAUNCH("egnn_backward");

@@ -412,12 +412,15 @@ def test_train_step_gradients_golden(pk, golden_dir, parity):
     assert checked > 20
 
 
-@pytest.mark.parametrize("feat,heads,in_nf,out_nf", [(32, 4, 32, 32), (33, 1, 33, 33), (33, 1, 17, 40), (32, 1, 5, 64)])
-def test_backward_random_graph_vs_oracle_autograd(pk, feat, heads, in_nf, out_nf):
+@pytest.mark.parametrize("feat,heads,in_nf,out_nf,n,e", [(32, 4, 32, 32, 257, 3001), (33, 1, 33, 33, 257, 3001), (33, 1, 17, 40, 257, 3001),
+                                                         (32, 1, 5, 64, 257, 3001), (32, 1, 5, 7, 16999, 70001), (32, 4, 32, 32, 16999, 70001),
+                                                         (33, 1, 17, 40, 16999, 70001)])
+def test_backward_random_graph_vs_oracle_autograd(pk, feat, heads, in_nf, out_nf, n, e):
     """Non-kNN edge list (hub, isolated nodes, self loops, multi-edges), random edge_attr, 3 layers; both hidden widths
-    (33 = the MFMA kernels' border path), 1 and 4 heads, embedding widths that differ from the hidden width."""
+    (33 = the MFMA kernels' border path), 1 and 4 heads, embedding widths that differ from the hidden width (odd ones:
+    the layers' parameter blocks are then not 16-byte aligned).  More than 16 384 nodes: the 16-node MFMA node backward
+    (csrc/egnn_node_bwd.hip) with 16-node tiles; hidden_nf 33 below that: its 4-node tiles."""
     g = torch.Generator().manual_seed(33)
-    n, e = 257, 3001
     torch.manual_seed(9)
     m = pk.EGNN(in_nf, feat, out_nf, in_edge_nf=1, device="cuda", n_layers=3, num_heads=heads)
     h = torch.randn(n, in_nf, generator=g); x = torch.rand(n, 3, generator=g) * 2
@@ -484,16 +487,19 @@ def test_fused_head_matches_aten_head(pk, golden_dir, name):
         assert err <= 2e-3 * scale + 1e-7, f"{name} {key}: err {err:.3e} scale {scale:.3e}"
 
 
-@pytest.mark.parametrize("feat,chunk", [(32, 0), (32, 64), (32, 48), (32, 16), (33, 0)])
-def test_egnn_backward_is_bitwise_reproducible(pk, feat, chunk):
+@pytest.mark.parametrize("feat,chunk,n", [(32, 0, 700), (32, 64, 700), (32, 48, 700), (32, 16, 700), (33, 0, 700), (32, 0, 9000), (33, 0, 9000)])   # 9000 = 3 pairs of 3000 points: 18 000 nodes
+def test_egnn_backward_is_bitwise_reproducible(pk, feat, chunk, n):
     """The edge backward recomputes the edge forward (nothing per edge is kept) and reduces the weight gradients through
     per-wave partials, per-workgroup slabs and one fixed-order reduction: no atomics, a static chunk -> wave map.  Two
     runs on the same inputs give bit-identical outputs and gradients, for every chunk size of the 16-edge kernels."""
     g = torch.Generator().manual_seed(17)
-    n, k = 700, 9
-    x = (torch.rand(2, n, 3, generator=g) * 3).cuda()
+    k = 9
+    B = 3 if n > 8192 else 1
+    n //= B
+    x = (torch.rand(2 * B, n, 3, generator=g) * 3).cuda()
+    n *= B
     h = torch.randn(2 * n, feat, generator=g).cuda()
-    graph = pk.build_pair_graph(x[:1], x[1:], k)
+    graph = pk.build_pair_graph(x[:B], x[B:], k)
     torch.manual_seed(4)
     egnn = pk.EGNN(feat, feat, feat, in_edge_nf=1, device="cuda", n_layers=3)
     gh, gx = torch.randn(2 * n, feat, generator=g).cuda(), torch.randn(2 * n, 3, generator=g).cuda()
