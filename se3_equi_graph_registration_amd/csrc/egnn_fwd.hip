@@ -280,6 +280,9 @@ __global__ __launch_bounds__(256, 3) void node_fwd_kernel(
 // straight from the parameter block (L2-resident, 16-byte rows) -- the lane-per-feature kernel spent a third of its time
 // staging four matrices into LDS per 8 nodes and the rest in barrier-separated LDS dot products.
 // ---------------------------------------------------------------------------------------
+#ifndef EQ_NODE_FWD16_SMALL
+#define EQ_NODE_FWD16_SMALL 16384
+#endif
 // four consecutive matrix entries W[row][col .. col + 3] as an MFMA A-operand quad: one 16-byte load when the row stride keeps
 // them aligned (hidden_nf 32), four 4-byte loads otherwise (hidden_nf 33: 33- / 66- / 79-float rows)
 template <bool kAligned>
@@ -289,7 +292,10 @@ __device__ __forceinline__ f32x4 wquad(const float* __restrict__ w, int row, int
     return f32x4{p[0], p[1], p[2], p[3]};
 }
 
-template <int H, int A, int D, int kB = 0>      // D = segment rows in flight per lane (16: a k = 20 neighbourhood is two round trips; 4: registers for occupancy)
+// NPT = nodes per wave: 16, or 4 when there are too few nodes to occupy the chip -- the 16 columns then hold every node four
+// times and the copies share out the node's segment (copy p takes rows p, p + 4, ...), so a k = 20 neighbourhood is ONE
+// round trip of 5 rows per lane and four times as many waves are in flight.
+template <int H, int A, int D, int kB = 0, int NPT = 16>      // D = segment rows in flight per lane
 __global__ __launch_bounds__(64) void node_fwd16_kernel(
     const float* __restrict__ lw, const float* __restrict__ next_lw, const float* __restrict__ w_out, const float* __restrict__ b_out,
     int out_nf, const int* __restrict__ rptr, const float* __restrict__ m_in, const float* __restrict__ trans_in,
@@ -298,9 +304,10 @@ __global__ __launch_bounds__(64) void node_fwd16_kernel(
     constexpr int F = 32 + kB, FP = 32 + 4 * kB;      // hidden_nf 33: feature 32 is a scalar per node held by its four lanes (the "border")
     using LL = LP<F, H, A>;
     constexpr bool kAl = (kB == 0);
-    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
-    const int j = min((int)blockIdx.x * 16 + i, n_nodes - 1);
-    const bool live = (int)blockIdx.x * 16 + i < n_nodes;
+    constexpr int NP = 16 / NPT;
+    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4, part = i / NPT;
+    const int j = min((int)blockIdx.x * NPT + (i % NPT), n_nodes - 1);
+    const bool live = (int)blockIdx.x * NPT + (i % NPT) < n_nodes && i < NPT;       // the copy that stores
     const int lo = rptr[j], hi = rptr[j + 1];
     // weights of the node MLP: requested before the segment loop, consumed after it.  W4 = [F][2F] over [h | agg]
     f32x4 w4a[2][4], w5a[2][2], b4v[2], b5v[2];
@@ -341,14 +348,15 @@ __global__ __launch_bounds__(64) void node_fwd16_kernel(
     int maxlen = len;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o, 64));
-    for (int a0 = 0; a0 < maxlen; a0 += D) {
+    for (int a0 = 0; a0 < maxlen; a0 += D * NP) {
         f32x4 v[D][2];
         float4 tv[D];
         float vb[D];
 #pragma unroll
         for (int u = 0; u < D; ++u) {
-            const bool in = a0 + u < len;
-            const size_t a = (size_t)(lo + (in ? a0 + u : 0));
+            const int aa = a0 + part + u * NP;
+            const bool in = aa < len;
+            const size_t a = (size_t)(lo + (in ? aa : 0));
 #pragma unroll
             for (int b = 0; b < 2; ++b) v[u][b] = in ? ldg4(m_in + a * FP + 16 * b + 4 * g) : splat4(0.0f);
             vb[u] = (kB && in) ? m_in[a * FP + 32] : 0.0f;
@@ -359,6 +367,17 @@ __global__ __launch_bounds__(64) void node_fwd16_kernel(
             agg[0] += v[u][0]; agg[1] += v[u][1];
             if (kB) aggb += vb[u];
             xs.x += tv[u].x; xs.y += tv[u].y; xs.z += tv[u].z;
+        }
+    }
+    if constexpr (NP > 1) {                      // the copies of a node add up their parts (every copy gets the same sums)
+#pragma unroll
+        for (int o = NPT; o < 16; o <<= 1) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) agg[b][r] += __shfl_xor(agg[b][r], o, 64);
+            if (kB) aggb += __shfl_xor(aggb, o, 64);
+            xs.x += __shfl_xor(xs.x, o, 64); xs.y += __shfl_xor(xs.y, o, 64); xs.z += __shfl_xor(xs.z, o, 64);
         }
     }
     if (live && g == 0) {                                                             // :267
@@ -570,8 +589,10 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
 #endif
         if constexpr (EQ_NODE_FWD16 && (F == 32 || H == 1)) {
             // few nodes: one wave per CU or less, latency decides -> 16 rows in flight; many nodes: 4 (registers for occupancy)
-            if (N <= 16 * 1024)
-                hipLaunchKernelGGL((node_fwd16_kernel<H, A, 16, F - 32>), dim3(ceil_div(N, 16)), dim3(64), 0, s, lw, last ? nullptr : lw + ML.layer_size,
+            // few nodes: less than one wave per SIMD, latency decides -> 4-node tiles, a whole neighbourhood in flight; many: 16-node tiles,
+            // 4 rows in flight (registers for occupancy)
+            if (N <= EQ_NODE_FWD16_SMALL)
+                hipLaunchKernelGGL((node_fwd16_kernel<H, A, 6, F - 32, 4>), dim3(ceil_div(N, 4)), dim3(64), 0, s, lw, last ? nullptr : lw + ML.layer_size,
                                    params + ML.w_out, params + ML.b_out, cfg->out_nf, g->rptr, m, trans, hbuf(l), xbuf(l), N, hbuf(l + 1), xn,
                                    training ? aggs + (size_t)l * N * FP : nullptr, P, h_out);
             else
