@@ -33,6 +33,19 @@ __device__ __forceinline__ u64 wave_bitonic_sort(u64 key, int lane) {
     return key;
 }
 
+// k-th smallest (1-based) of the wave's 64 non-negative floats given as bit patterns (unsigned order = float order): bisection on
+// the value with one ballot + popcount per step -- one vector instruction per step against ~300 for a 64-lane bitonic sort.
+__device__ __forceinline__ unsigned wave_kth_smallest_bits(unsigned bits, int k) {
+    unsigned lo = 0u, hi = 0x7f800000u;                 // +inf: every lane counts
+    while (lo < hi) {                                   // wave-uniform
+        const unsigned mid = lo + ((hi - lo) >> 1);
+        const int c = __popcll(__ballot(bits <= mid));
+        if (c >= k) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+
 __device__ __forceinline__ u64 wave_min_u64(u64 v) {
 #pragma unroll
     for (int j = 32; j > 0; j >>= 1) {
@@ -80,8 +93,7 @@ __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, in
 
     int out_idx = 0;
     // ---- fast path -------------------------------------------------------------------
-    const u64 sorted_min = wave_bitonic_sort(pack_key(lmin, lane), lane);
-    const unsigned tau_bits = (unsigned)(__shfl(sorted_min, k - 1, 64) >> 32);
+    const unsigned tau_bits = wave_kth_smallest_bits(__float_as_uint(lmin), k);
     const float tau = __uint_as_float(tau_bits);
     int cnt = 0;
 #pragma unroll
@@ -192,8 +204,7 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
     float tau[kKnnQpw];
 #pragma unroll
     for (int u = 0; u < kKnnQpw; ++u) {
-        const u64 sorted_min = wave_bitonic_sort(pack_key(lmin[u], lane), lane);
-        tau[u] = __uint_as_float((unsigned)(__shfl(sorted_min, k - 1, 64) >> 32));
+        tau[u] = __uint_as_float(wave_kth_smallest_bits(__float_as_uint(lmin[u]), k));
     }
     // ---- pass 2: count the candidates <= tau and compact the first 64 of them
     int base[kKnnQpw];
@@ -326,6 +337,9 @@ __global__ void edges_i64_to_i32_kernel(const long long* __restrict__ edges, int
 
 }  // namespace eq
 
+#ifndef EQ_KNN_PER_QUERY_MAX
+#define EQ_KNN_PER_QUERY_MAX 2048
+#endif
 extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, int32_t k, int32_t loop,
                                   int64_t* edges_i64, int32_t* row32, int32_t* col32, int32_t* row_hist,
                                   int32_t force_slow_path, void* stream) {
@@ -341,7 +355,7 @@ extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, i
     long long* e64 = reinterpret_cast<long long*>(edges_i64);
     if (n <= 256) {
         hipLaunchKernelGGL(knn_kernel<4>, grid, block, 0, s, x, n_clouds, n, k, loop, e64, row32, col32, row_hist, force_slow_path);
-    } else if (n <= 2048) {      // measured: the per-query kernel is as fast as the tiled one up to 2 048 points (17.6 us at B=1)
+    } else if (n <= EQ_KNN_PER_QUERY_MAX) {      // measured: the per-query kernel is as fast as the tiled one up to 2 048 points (17.6 us at B=1)
         hipLaunchKernelGGL(knn_kernel<32>, grid, block, 0, s, x, n_clouds, n, k, loop, e64, row32, col32, row_hist, force_slow_path);
     } else {                     // 4 096 / 8 192 points: 534 -> ~120 us for two 8 192-point clouds (no 128-value register arrays)
         const int bpc = ceil_div(n, 4 * kKnnQpw);
