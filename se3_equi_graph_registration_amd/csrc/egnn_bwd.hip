@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
                                                          const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                          const float* __restrict__ x, const float* __restrict__ P,
                                                          const float* __restrict__ dagg, const float* __restrict__ Gx, int n_edges,
-                                                         int chunk, int basis, float* __restrict__ dt1_out, float* __restrict__ gxr_out,
+                                                         int chunk, int basis, float* __restrict__ dt1_out, float* __restrict__ dt1b_out, float* __restrict__ gxr_out,
                                                          float* __restrict__ gxc_out, float* __restrict__ slab) {
     using C = Chunk16;
     constexpr int F = 32 + kB, FP = 32 + 4 * kB;
@@ -838,12 +838,14 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             for (int b = 0; b < 2; ++b) {
                 dt1[b] *= sgp[b];
                 st4(X + i * C::LD + 16 * b + 4 * g, dt1[b]);
-                if (valid) st4(dt1_out + (size_t)(base + el) * FP + 16 * b + 4 * g, dt1[b]);
+                if (valid) st4(dt1_out + (size_t)(base + el) * 32 + 16 * b + 4 * g, dt1[b]);      // 128-byte rows for every hidden_nf (see below)
             }
             if constexpr (kB == 1) {
                 if (g == 0) {
                     X[i * C::LD + 32] = dt1b;
-                    if (valid) st4(dt1_out + (size_t)(base + el) * FP + 32, f32x4{dt1b, 0.0f, 0.0f, 0.0f});
+                    // hidden_nf 33: the 33rd column is its own array behind the [E][32] block -- a 144-byte row would straddle cache
+                    // lines, and the col-side gather of the node backward reads these rows scattered (one line + one word per row)
+                    if (valid) dt1b_out[base + el] = dt1b;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -976,7 +978,7 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
         int blocks = ceil_div(ceil_div(E, chunk), NW);
         blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
         hipLaunchKernelGGL((edge_bwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * NW), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
-                           E, chunk, basis, dt1, gxr, gxc, slab);
+                           E, chunk, basis, dt1, dt1 + (size_t)E * 32, gxr, gxc, slab);
         *n_slabs = blocks;
     }
     return 0;
@@ -1136,13 +1138,13 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
     };
     // the 16-node MFMA kernels of egnn_node_bwd.hip: hidden_nf 33 always; hidden_nf 32 from EQ_NODE_BWD16_MIN nodes on (one
     // 2 048-point pair: 18.4 us against 15.3 us for the per-feature kernel; 16 pairs: 121 against 142 us)
-    const bool k16 = EQ_NODE_BWD16 != 0 && (F == 33 || N > EQ_NODE_BWD16_MIN);
+    const bool k16 = F == 33 || (EQ_NODE_BWD16 != 0 && N > EQ_NODE_BWD16_MIN);
     constexpr bool kFuse = (F == 32);                      // per-feature kernels: gather_bwd(l) + node_bwd(l-1) in one kernel
     int nslab = ngrid;                                     // slab copies per layer of the node-level kernels
     NodeBwd16Args na{};
     na.rptr = g->rptr; na.rperm = g->rperm; na.cptr = g->cptr; na.cperm = g->cperm;
     na.dt1 = work + B.dt1; na.gxr = work + B.gxr; na.gxc = work + B.gxc;
-    na.n_nodes = N; na.dh_part = work + B.dh_part; na.dagg = work + B.dagg; na.P = Pbuf;
+    na.n_nodes = N; na.n_edges = E; na.dh_part = work + B.dh_part; na.dagg = work + B.dagg; na.P = Pbuf;
     auto node_part = [&](int l) {                          // node-MLP backward of layer l
         na.lw_n = params + ML.layer0 + (size_t)l * ML.layer_size;
         na.h_n = hs + (size_t)l * N * FP; na.agg_n = aggs + (size_t)l * N * FP;
@@ -1186,9 +1188,10 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
                 continue;
             }
         }
-        hipLaunchKernelGGL((gather_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, g->rptr, g->rperm, g->cptr,
-                           g->cperm, work + B.dt1, work + B.gxr, work + B.gxc, work + B.dh_part, work + B.Gx[cur], h_l, N,
-                           work + B.Gh[nxt], work + B.Gx[nxt], (l == 0) ? grad_x_in : nullptr, work + B.gat_slab + slab_of(l));
+        if constexpr (F == 32)          // (hidden_nf 33 always takes the 16-node kernels above: its dt1 rows are split, see edge_bwd16_kernel)
+            hipLaunchKernelGGL((gather_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, g->rptr, g->rperm, g->cptr,
+                               g->cperm, work + B.dt1, work + B.gxr, work + B.gxc, work + B.dh_part, work + B.Gx[cur], h_l, N,
+                               work + B.Gh[nxt], work + B.Gx[nxt], (l == 0) ? grad_x_in : nullptr, work + B.gat_slab + slab_of(l));
         cur = nxt;
     }
     hipLaunchKernelGGL((embed_in_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_in, cfg->in_nf,

@@ -79,7 +79,7 @@ struct NodeBwd16Args {
     const int* rptr; const int* rperm; const int* cptr; const int* cperm;
     const float* dt1; const float* gxr; const float* gxc; const float* Gx;
     const float* h_g; const float* Gh_in; const float* h_n; const float* agg_n;
-    int n_nodes;
+    int n_nodes, n_edges;
     float* dh_part; float* dagg; float* P; float* Gx_new; float* gx_out3; float* Gh_out;
     float* gat_slab; float* node_slab;
 };

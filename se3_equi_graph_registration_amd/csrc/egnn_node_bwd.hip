@@ -202,11 +202,11 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
                 for (int u = 0; u < D; ++u) {
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
-                        vr[u][b] = er[u] >= 0 ? ldg4(a.dt1 + (size_t)er[u] * FP + 16 * b + 4 * g) : zero;
-                        vc[u][b] = ec[u] >= 0 ? ldg4(a.dt1 + (size_t)ec[u] * FP + 16 * b + 4 * g) : zero;
+                        vr[u][b] = er[u] >= 0 ? ldg4(a.dt1 + (size_t)er[u] * 32 + 16 * b + 4 * g) : zero;      // [E][32] rows + [E] border column
+                        vc[u][b] = ec[u] >= 0 ? ldg4(a.dt1 + (size_t)ec[u] * 32 + 16 * b + 4 * g) : zero;
                     }
-                    vrb[u] = (kB && er[u] >= 0) ? a.dt1[(size_t)er[u] * FP + 32] : 0.0f;
-                    vcb[u] = (kB && ec[u] >= 0) ? a.dt1[(size_t)ec[u] * FP + 32] : 0.0f;
+                    vrb[u] = (kB && er[u] >= 0) ? a.dt1[(size_t)a.n_edges * 32 + er[u]] : 0.0f;
+                    vcb[u] = (kB && ec[u] >= 0) ? a.dt1[(size_t)a.n_edges * 32 + ec[u]] : 0.0f;
                     const int e3 = g == 0 ? er[u] : ec[u];
                     tv[u] = (g < 2 && e3 >= 0) ? ldg4(d3 + (size_t)e3 * 4) : zero;
                 }
