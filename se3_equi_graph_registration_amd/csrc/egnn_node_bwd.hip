@@ -400,12 +400,22 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
             __syncthreads();
         }
         NB_STAMP(9);
-        for (int t = threadIdx.x; t < kSlab; t += 64 * NW) {         // copies added in fixed order
-            float v = lds[t];
+        if constexpr (kGat % 4 == 0 && kSlab % 4 == 0 && SB::gather % 4 == 0 && SB::node % 4 == 0) {
+            // copies added in fixed order, four entries per thread and step (hidden_nf 32: every slab boundary is 16-byte aligned)
+            for (int t = 4 * threadIdx.x; t < kSlab; t += 4 * 64 * NW) {
+                f32x4 v = lds4(lds + t);
 #pragma unroll
-            for (int w = 1; w < NC; ++w) v += lds[w * kSlab + t];
-            if (t < kGat) gat_dst[t] = v;
-            else node_dst[t - kGat] = v;
+                for (int w = 1; w < NC; ++w) v += lds4(lds + w * kSlab + t);
+                st4(t < kGat ? gat_dst + t : node_dst + (t - kGat), v);
+            }
+        } else {
+            for (int t = threadIdx.x; t < kSlab; t += 64 * NW) {
+                float v = lds[t];
+#pragma unroll
+                for (int w = 1; w < NC; ++w) v += lds[w * kSlab + t];
+                if (t < kGat) gat_dst[t] = v;
+                else node_dst[t - kGat] = v;
+            }
         }
     }
     NB_STAMP(10);
