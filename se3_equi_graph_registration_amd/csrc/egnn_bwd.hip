@@ -957,11 +957,20 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < SB::edge; t += 64 * NW) {
-        float a = scratch[0][t];
+    if constexpr (SB::edge % 4 == 0 && kScratch % 4 == 0) {        // hidden_nf 32: four entries per thread and step
+        for (int t = 4 * threadIdx.x; t < SB::edge; t += 4 * 64 * NW) {
+            f32x4 a = lds4(&scratch[0][t]);
 #pragma unroll
-        for (int w = 1; w < NW; ++w) a += scratch[w][t];
-        slab[(size_t)blockIdx.x * SB::edge + t] = a;
+            for (int w = 1; w < NW; ++w) a += lds4(&scratch[w][t]);
+            st4(slab + (size_t)blockIdx.x * SB::edge + t, a);
+        }
+    } else {
+        for (int t = threadIdx.x; t < SB::edge; t += 64 * NW) {
+            float a = scratch[0][t];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) a += scratch[w][t];
+            slab[(size_t)blockIdx.x * SB::edge + t] = a;
+        }
     }
     EQ_STAMP(15);
 }
