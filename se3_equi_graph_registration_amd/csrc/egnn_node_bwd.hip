@@ -45,6 +45,18 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     float* X0 = lds + wv * kWave;
     float *X1 = X0 + kTile, *Y0 = X0 + 2 * kTile, *Y1 = X0 + 3 * kTile, *Y2 = X0 + 4 * kTile;
+    // segment bounds of the wave's first tile: requested before the operand staging (and of every next tile one tile ahead), so the
+    // index loads behind them start right after the barrier
+    const int n_tiles = (a.n_nodes + NPT - 1) / NPT;
+    auto node_of = [&](int tile_) { const int jr_ = tile_ * NPT + (i % NPT); return jr_ < a.n_nodes ? jr_ : a.n_nodes - 1; };
+    int p_rlo = 0, p_rhi = 0, p_clo = 0, p_chi = 0;
+    auto request_bounds = [&](int tile_) {
+        if (kG && tile_ < n_tiles) {
+            const int j_ = node_of(tile_);
+            p_rlo = a.rptr[j_]; p_rhi = a.rptr[j_ + 1]; p_clo = a.cptr[j_]; p_chi = a.cptr[j_ + 1];
+        }
+    };
+    request_bounds(blockIdx.x * NW + wv);
     {   // ---- stage: element (i, k) of operand m; all loads of a thread before its first store
         auto el = [&](int m, int r, int c) -> const float* {
             switch (m) {
@@ -132,7 +144,6 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
         if (kB && g == 0) T[i * LD + 32] = vb;
     };
 
-    const int n_tiles = (a.n_nodes + NPT - 1) / NPT;
     NB_STAMP(0);
     for (int tile = blockIdx.x * NW + wv; tile < n_tiles; tile += gridDim.x * NW) {
         const int jr = tile * NPT + (i % NPT), part = i / NPT;
@@ -162,7 +173,8 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
         };
         if constexpr (kN && kEarly) load_node_inputs();
         if constexpr (kG) {
-            const int rlo = a.rptr[j], rlen = a.rptr[j + 1] - rlo, clo = a.cptr[j], clen = a.cptr[j + 1] - clo;
+            const int rlo = p_rlo, rlen = p_rhi - p_rlo, clo = p_clo, clen = p_chi - p_clo;
+            request_bounds(tile + gridDim.x * NW);
             f32x4 hg[2];
             float hgb = 0.0f;
             auto load_gather_inputs = [&]() {
