@@ -589,10 +589,12 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
 #endif
         if constexpr (EQ_NODE_FWD16 && (F == 32 || H == 1)) {
             // few nodes: one wave per CU or less, latency decides -> 16 rows in flight; many nodes: 4 (registers for occupancy)
-            // few nodes: less than one wave per SIMD, latency decides -> 4-node tiles, a whole neighbourhood in flight; many: 16-node tiles,
-            // 4 rows in flight (registers for occupancy)
+            // few nodes: one wave per CU or less, latency decides -> 16 rows in flight; many nodes: 4 (registers for occupancy).  Both sum
+            // a node's rows in ascending order, so a cloud's outputs do not depend on what else is in the batch
+            // (tests/test_gpu_fullsize.py::test_batching_is_exact_fullsize).  The 4-node tiles (NPT = 4: four copies share a segment,
+            // 9.0 -> 8.3 us at one pair) add partial sums in another order and are therefore not used.
             if (N <= EQ_NODE_FWD16_SMALL)
-                hipLaunchKernelGGL((node_fwd16_kernel<H, A, 6, F - 32, 4>), dim3(ceil_div(N, 4)), dim3(64), 0, s, lw, last ? nullptr : lw + ML.layer_size,
+                hipLaunchKernelGGL((node_fwd16_kernel<H, A, 16, F - 32>), dim3(ceil_div(N, 16)), dim3(64), 0, s, lw, last ? nullptr : lw + ML.layer_size,
                                    params + ML.w_out, params + ML.b_out, cfg->out_nf, g->rptr, m, trans, hbuf(l), xbuf(l), N, hbuf(l + 1), xn,
                                    training ? aggs + (size_t)l * N * FP : nullptr, P, h_out);
             else
