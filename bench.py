@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--forward-only", action="store_true", help="diagnostic: inference step (not the headline metric)")
     ap.add_argument("--reset-every", type=int, default=100, help="restore the initial weights every this many steps (see build_step)")
+    ap.add_argument("--dev-no-head", action="store_true", help="diagnostic (NOT the metric): the step without the pose head and its losses: kNN + index + "
+                    "EGNN forward/backward with a constant upstream gradient + Adam; the JSON line is marked invalid")
     ap.add_argument("--aten-head", action="store_true", help="diagnostic: pose head as PyTorch-ROCm ops instead of csrc/head.hip")
     ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default=None,
                     help="BASELINE.json configs: c2 = default (1 pair, 2048 pts); c3 = 16 pairs per step; c4 = one GPU's shard of the "
@@ -89,8 +91,21 @@ def build_step(pkg, args, dev, world):
     # one fused Adam launch over the flat bucket (two views: EGNN block, head; the per-tensor parameters are views of them); train :1412
     opt = pkg.FlatAdam([(egnn.flat_params, egnn.flat_grads), (dp.head.flat, dp.head.grad)], lr=1e-4)
 
+    cache = {}
+
     def fwd_bwd():
         graph = pkg.build_pair_graph(batch["src"], batch["tgt"], args.k, loop=True)
+        if args.dev_no_head:      # developer measurement only (not the metric): kNN + index + EGNN forward / backward + Adam, constant upstream gradient
+            B, N, F = args.batch, args.n, args.feat
+            if "h" not in cache:
+                cache["h"] = torch.cat([batch["feat_src"].reshape(B * N, F), batch["feat_tgt"].reshape(B * N, F)]).contiguous()
+                cache["x"] = torch.cat([batch["src"].reshape(B * N, 3), batch["tgt"].reshape(B * N, 3)]).contiguous()
+                cache["gh"] = torch.full((2 * B * N, F), 1e-3, device=dev); cache["gx"] = torch.full((2 * B * N, 3), 1e-3, device=dev)
+            if "ea" not in cache:
+                cache["ea"] = torch.ones(graph.n_edges, 1, device=dev)
+            ho, xo = egnn(cache["h"], cache["x"], graph, cache["ea"])
+            torch.autograd.backward([ho, xo], [cache["gh"], cache["gx"]])
+            return ho
         out = model(batch["feat_src"], batch["src"], graph, None, batch["feat_tgt"], batch["tgt"], graph, None,
                     batch["corr"], batch["labels"], batch["gt_pose"])
         if args.forward_only:
@@ -106,7 +121,6 @@ def build_step(pkg, args, dev, world):
         loss.backward(gradient=cache["one"])
         return loss
 
-    cache = {}
     dp.zero_grad()          # once: afterwards the Adam launch clears each gradient as it consumes it (optimizer.zero_grad() fused)
 
     def zero():
@@ -498,6 +512,8 @@ def main():
                        "reset_every": args.reset_every},
             "roofline": roof, "kernels": extra,
         }
+        if args.dev_no_head:
+            out["INVALID"] = "--dev-no-head: pose head and losses skipped (developer measurement, not the metric)"
         if dist_on:
             nb = sum(int(b.numel()) * 4 for b in S["dp"].buckets())
             out["multi_gpu"] = {"world_size": world, "backend": dist.get_backend(), "ranks_seen": ranks_seen,
