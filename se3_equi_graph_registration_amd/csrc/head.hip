@@ -443,16 +443,20 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
         return;
     }
     const int b = blockIdx.y;
+    EQ_STAMPK(5, 0);
     kabsch_moments_block(xs, xt, wts, N, aux, b, blockIdx.x, nb);     // thread 0 stores this block's record
+    EQ_STAMPK(5, 1);
     __shared__ int is_last;
     if (threadIdx.x == 0) {
         __threadfence();
         is_last = atomicAdd(reinterpret_cast<unsigned*>(pair_f) + (size_t)b * 4 + 3, 1u) == (unsigned)nb - 1u;
     }
     __syncthreads();
+    EQ_STAMPK(5, 2);
     if (!is_last) return;                                            // block-uniform
     __threadfence();
     if (threadIdx.x < 64) kabsch_solve_wave(nb, R, t, aux, b, threadIdx.x);
+    EQ_STAMPK(5, 3);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -9,6 +9,20 @@ __device__ inline double det3(const double m[9]) {
     return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
 }
 
+// 1/x and 1/sqrt(x) for normal positive x: hardware seed (~2^-26) + two Newton steps (full fp64 precision to a few ulp)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = fma(fma(-0.5 * x * r, r, 0.5), r, r);
+    r = fma(fma(-0.5 * x * r, r, 0.5), r, r);
+    return r;
+}
+
 // One-sided Jacobi: A V = B with orthogonal columns; sigma_i = |B_i|, U_i = B_i / sigma_i.
 __device__ inline void svd3_jacobi(const double A[9], double U[9], double sig[3], double V[9]) {
     double B[9];
@@ -23,11 +37,16 @@ __device__ inline void svd3_jacobi(const double A[9], double U[9], double sig[3]
                 be += B[r * 3 + q] * B[r * 3 + q];
                 ga += B[r * 3 + p] * B[r * 3 + q];
             }
-            if (fabs(ga) > 1e-300 && fabs(ga) > 1e-15 * sqrt(al * be)) {   // (1e-17 is below fp64 round-off: it never converged, 40 sweeps)
+            if (fabs(ga) > 1e-300 && ga * ga > 1e-30 * (al * be)) {   // |ga| > 1e-15 sqrt(al be)  (1e-17 is below fp64 round-off: it never converged)
                 rotated = true;
-                const double ze = (be - al) / (2.0 * ga);
-                const double tt = (ze == 0.0) ? 1.0 : copysign(1.0, ze) / (fabs(ze) + sqrt(1.0 + ze * ze));
-                const double c = 1.0 / sqrt(1.0 + tt * tt), s = c * tt;
+                // tan of the rotation angle, the smaller root of t^2 + 2 zeta t - 1 = 0 with zeta = (be - al) / (2 ga):
+                //   t = sign(de) 2 ga / (|de| + sqrt(de^2 + 4 ga^2)),  c = 1 / sqrt(1 + t^2),  s = c t
+                // with hardware reciprocal / reciprocal-square-root seeds + Newton steps (two rsqrt, one rcp) instead of three IEEE
+                // divisions and two square roots on one lane -- any (c, s) with c^2 + s^2 = 1 to round-off keeps the iteration orthogonal
+                const double de = be - al;
+                const double w = de * de + 4.0 * ga * ga;
+                const double tt = copysign(2.0 * ga, de >= 0.0 ? ga : -ga) * fast_rcp(fabs(de) + w * fast_rsqrt(w));
+                const double c = fast_rsqrt(1.0 + tt * tt), s = c * tt;
                 for (int r = 0; r < 3; ++r) {
                     const double bp = B[r * 3 + p], bq = B[r * 3 + q];
                     B[r * 3 + p] = c * bp - s * bq;
@@ -82,7 +101,6 @@ __device__ __forceinline__ double block_sum_d256(double v, double* red) {
 __device__ __forceinline__ void kabsch_moments_block(const float* __restrict__ src, const float* __restrict__ tgt,
                                                      const float* __restrict__ w, int n, float* __restrict__ aux, int b, int xb,
                                                      int nblocks) {
-    __shared__ double red[4];
     double* part = kabsch_part(aux, b);
     const float* s = src + (size_t)b * n * 3;
     const float* t = tgt + (size_t)b * n * 3;
@@ -102,25 +120,63 @@ __device__ __forceinline__ void kabsch_moments_block(const float* __restrict__ s
             for (int c = 0; c < 3; ++c) m[7 + a * 3 + c] += wi * sv[a] * tv[c];
         }
     }
+    // all 16 sums together.  Per wave a reduce-scatter butterfly: at distance o = 32, 16, 8, 4 a lane keeps one half of its values
+    // (the half selected by lane & o) and adds the partner's copy of it -- 8 + 4 + 2 + 1 exchanges instead of 16 x 6 -- then two
+    // more steps over lane & 3: lane l with (l & 3) == 0 ends up with the wave total of quantity q(l).  ONE barrier, then threads
+    // 0..15 add the four wave totals in wave order.  (16 separate block sums, 32 barriers, were 6 us of the tail launch.)
+    __shared__ double wsum[4][kKabschParts];
+    const int lane = threadIdx.x & 63;
+    int q_of_lane = 0;
+    {
+        double v[kKabschParts];
 #pragma unroll
-    for (int q = 0; q < kKabschParts; ++q) {
-        const double v = block_sum_d256(m[q], red);
-        if (threadIdx.x == 0) part[(size_t)xb * kKabschParts + q] = v;
+        for (int q = 0; q < kKabschParts; ++q) v[q] = m[q];
+        int n = kKabschParts;
+#pragma unroll
+        for (int o = 32; o >= 4; o >>= 1) {
+            n >>= 1;
+            const bool up = (lane & o) != 0;
+#pragma unroll
+            for (int i2 = 0; i2 < 8; ++i2) {
+                if (i2 < n) {
+                    const double keep = up ? v[i2 + n] : v[i2], send = up ? v[i2] : v[i2 + n];
+                    v[i2] = keep + __shfl_xor(send, o, 64);
+                }
+            }
+            q_of_lane += up ? n : 0;
+        }
+        v[0] += __shfl_xor(v[0], 2, 64);
+        v[0] += __shfl_xor(v[0], 1, 64);
+        m[0] = v[0];
     }
+    __syncthreads();                                     // (a previous use of wsum by this block is complete)
+    if ((lane & 3) == 0) wsum[threadIdx.x >> 6][q_of_lane] = m[0];
+    __syncthreads();
+    if (threadIdx.x < kKabschParts)
+        part[(size_t)xb * kKabschParts + threadIdx.x] = wsum[0][threadIdx.x] + wsum[1][threadIdx.x] + wsum[2][threadIdx.x] + wsum[3][threadIdx.x];
 }
 
 // pair b's solve from its nb partial records; called by ONE full wave (lane = 0..63)
 __device__ __forceinline__ void kabsch_solve_wave(int nb, float* __restrict__ Rout, float* __restrict__ tout, float* __restrict__ aux,
                                                   int b, int lane) {
     const double* part = kabsch_part(aux, b);
+    // lane q < 16 adds quantity q over the nb (<= 8) partial records in block order; lane 0 then collects the 16 sums through
+    // v_readlane (the 16 six-step fp64 shuffle trees this replaces were a quarter of the solve)
+    double mine = 0.0;
+    if (lane < kKabschParts) {
+        double pv[kKabschMaxBlocks];
+#pragma unroll
+        for (int k = 0; k < kKabschMaxBlocks; ++k) pv[k] = k < nb ? part[(size_t)k * kKabschParts + lane] : 0.0;
+#pragma unroll
+        for (int k = 0; k < kKabschMaxBlocks; ++k) mine += pv[k];
+    }
     double m[kKabschParts];
 #pragma unroll
     for (int q = 0; q < kKabschParts; ++q) {
-        double v = 0.0;
-        for (int k = lane; k < nb; k += 64) v += part[(size_t)k * kKabschParts + q];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        m[q] = v;
+        const unsigned long long bits = __double_as_longlong(mine);
+        const unsigned lo_ = __builtin_amdgcn_readlane((int)(unsigned)(bits & 0xffffffffull), q);
+        const unsigned hi_ = __builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), q);
+        m[q] = __longlong_as_double(((unsigned long long)hi_ << 32) | lo_);
     }
     if (lane == 0) {
         const double W = m[0];
