@@ -37,6 +37,40 @@ __device__ __forceinline__ double block_sum_d(double v, double* red /*[4]*/) {
     __syncthreads();
     return red[0] + red[1] + red[2] + red[3];
 }
+// NV (<= 8) block sums at once: per wave a reduce-scatter butterfly (W = 8 or 4 slots: at distance o = 32, 16[, 8] a lane keeps the
+// half of its slots selected by lane & o and adds the partner's copy, then the remaining distances on its single slot), ONE pair of
+// barriers, and every thread adds the four wave totals in wave order.  Replaces NV sequential block_sum_d (2 NV barriers, 12 NV
+// shuffles); the result is the same for every thread, the summation order differs from block_sum_d's.
+template <int NV>
+__device__ __forceinline__ void block_sum_dn(double (&v)[NV], double (*ws)[8] /* __shared__ [4][8] */) {
+    constexpr int W = NV > 4 ? 8 : 4;
+    static_assert(NV >= 1 && NV <= 8, "block_sum_dn: 1..8 values");
+    const int lane = threadIdx.x & 63;
+    double t[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) t[q] = q < NV ? v[q] : 0.0;
+    int n = W, slot = 0, o = 32;
+#pragma unroll
+    for (int step = 0; step < (W == 8 ? 3 : 2); ++step, o >>= 1) {
+        n >>= 1;
+        const bool up = (lane & o) != 0;
+#pragma unroll
+        for (int i2 = 0; i2 < W / 2; ++i2) {
+            if (i2 < n) {
+                const double keep = up ? t[i2 + n] : t[i2], send = up ? t[i2] : t[i2 + n];
+                t[i2] = keep + __shfl_xor(send, o, 64);
+            }
+        }
+        slot += up ? n : 0;
+    }
+#pragma unroll
+    for (int oo = (W == 8 ? 4 : 8); oo > 0; oo >>= 1) t[0] += __shfl_xor(t[0], oo, 64);
+    __syncthreads();
+    if ((lane & (W == 8 ? 7 : 15)) == 0 && slot < NV) ws[threadIdx.x >> 6][slot] = t[0];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) v[q] = ws[0][q] + ws[1][q] + ws[2][q] + ws[3][q];
+}
 __device__ __forceinline__ float block_max_f(float v, float* red /*[4]*/) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -119,8 +153,8 @@ __device__ __forceinline__ void head_stats(const double* __restrict__ partials, 
     for (int k = threadIdx.x; k < n_rec; k += 256)
 #pragma unroll
         for (int q = 0; q < 6; ++q) acc[q] += partials[(size_t)k * kHeadPartials + q];
-#pragma unroll
-    for (int q = 0; q < 6; ++q) acc[q] = block_sum_d(acc[q], red);
+    __shared__ double ws6[4][8];
+    block_sum_dn<6>(acc, ws6);
     const double ms = acc[0] / M, mr = acc[2] / M;
     const double vs = fmax((acc[1] - M * ms * ms) / (M - 1), 0.0), vr = fmax((acc[3] - M * mr * mr) / (M - 1), 0.0);
     st[0] = ms; st[1] = sqrt(vs); st[2] = mr; st[3] = sqrt(vr); st[4] = acc[4]; st[5] = acc[5];
@@ -154,6 +188,7 @@ __device__ __forceinline__ void gather_rows(const float* __restrict__ hs, const 
 }
      // in = 2F, h1 = F, h2 = F/2, out = 1
 constexpr int kCand = 512;              // candidate list of the radix select
+constexpr int kCandEarly = 256;         // ... and the size at which the select stops refining digits
 
 // K2: one workgroup per pair: softmax scalars, top-K (radix select + small bitonic sort), MLP, BCE
 __global__ __launch_bounds__(256) void head_pair_kernel(
@@ -238,6 +273,9 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
         need -= sel[1];
         prefix |= (unsigned)sel[0] << shift;
         mask |= 255u << shift;
+        // the keys below the selected bin (K - need of them) plus the bin itself are few enough to rank exactly: stop refining
+        // (typically after two of the four digits; block-uniform)
+        if ((K - need) + sel[2] <= kCandEarly) break;
     }
     EQ_STAMPK(3, 3);
     const int n_less = K - need, n_tie = sel[2];
@@ -248,7 +286,7 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
         __syncthreads();
         for (int i = tid; i < N; i += 256) {
             const unsigned v = khi[i];
-            if (v <= prefix) keys[atomicAdd(&sel[0], 1)] = ((u64)v << 32) | (unsigned)i;
+            if ((v & mask) <= prefix) keys[atomicAdd(&sel[0], 1)] = ((u64)v << 32) | (unsigned)i;
         }
         __syncthreads();
         EQ_STAMPK(3, 4);
@@ -330,7 +368,12 @@ __device__ __forceinline__ void head_weights_block(const WeightsJob& j, int xb, 
         const float e = zs - zr;
         q0 = (double)e * e; q1 = e; q2 = (double)e * (s - j.fin[2]);
     }
-    q0 = block_sum_d(q0, red); q1 = block_sum_d(q1, red); q2 = block_sum_d(q2, red);
+    {
+        __shared__ double ws3[4][8];
+        double qv[3] = {q0, q1, q2};
+        block_sum_dn<3>(qv, ws3);
+        q0 = qv[0]; q1 = qv[1]; q2 = qv[2];
+    }
     if (threadIdx.x == 0) {
         double* rec = j.partC + ((size_t)b * ((N + 255) / 256) + xb) * 3;
         rec[0] = q0; rec[1] = q1; rec[2] = q2;
@@ -413,7 +456,12 @@ __device__ __forceinline__ void head_finalize_block(const double* __restrict__ p
     double a0 = 0, a1 = 0, a2 = 0, bce = 0;
     for (int k = threadIdx.x; k < nC; k += 256) { a0 += partC[(size_t)k * 3]; a1 += partC[(size_t)k * 3 + 1]; a2 += partC[(size_t)k * 3 + 2]; }
     for (int b = threadIdx.x; b < B * nblk; b += 256) bce += pair_part[b];
-    a0 = block_sum_d(a0, red); a1 = block_sum_d(a1, red); a2 = block_sum_d(a2, red); bce = block_sum_d(bce, red);
+    {
+        __shared__ double ws4[4][8];
+        double av[4] = {a0, a1, a2, bce};
+        block_sum_dn<4>(av, ws4);
+        a0 = av[0]; a1 = av[1]; a2 = av[2]; bce = av[3];
+    }
     if (threadIdx.x == 0) {
         // EQUIGSPR_HEAD_NO_SIM_LOSS: the KITTI script's forward returns corr_loss alone (src/kitti_train_egnn_with_batch.py:766)
         out[0] = (float)(bce / ((double)B * K) + ((flags & EQUIGSPR_HEAD_NO_SIM_LOSS) ? 0.0 : a0 / (double)M));
