@@ -27,7 +27,7 @@ extern "C" {
 
 #define EQUIGSPR_EINVAL   (-1)  /* bad shape / size / null pointer                         */
 #define EQUIGSPR_ENOTSUP  (-2)  /* configuration outside the compiled kernel set             */
-#define EQUIGSPR_ABI_VERSION 7
+#define EQUIGSPR_ABI_VERSION 8
 
 /* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
  * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
@@ -188,7 +188,8 @@ int equigspr_kabsch_backward(const float* src, const float* tgt, const float* w,
  * equigspr_kabsch_forward(xs, xt, wts, ...) -- identical results and aux record -- inside the launch that finishes the
  * loss scalars, instead of two more launches.
  * Backward: g_corr_sim / g_equi are DEVICE scalars (may be NULL = 0); gw = dL/d wts from
- * equigspr_kabsch_backward; writes ghs,ght; ADDS the equi-loss terms into gxs,gxt (which hold the
+ * equigspr_kabsch_backward -- or, with kabsch_aux / grad_R / grad_t given (ABI 8), that Kabsch backward runs inside this call's
+ * first launch beside the MLP backward: gw is then an OUTPUT (scratch [B*N]) and gxs, gxt are written first; writes ghs,ght; ADDS the equi-loss terms into gxs,gxt (which hold the
  * Kabsch coordinate gradients); ADDS into grad_mlp. */
 #define EQUIGSPR_HEAD_NO_SIM_LOSS 1
 int64_t equigspr_head_mlp_size(int32_t F);
@@ -205,7 +206,8 @@ int equigspr_head_backward(const float* hs, const float* ht, const float* xs, co
                            const float* rsim, const float* cosv, const int32_t* pos, const float* wts,
                            const int64_t* top_idx, const float* logits, const float* a1_save,
                            const float* a2_save, const float* fin_scalars, const float* g_corr_sim,
-                           const float* g_equi, const float* gw, int32_t B, int32_t N, int32_t F, int32_t K, int32_t flags,
+                           const float* g_equi, float* gw, const float* kabsch_aux, const float* grad_R, const float* grad_t,
+                           int32_t B, int32_t N, int32_t F, int32_t K, int32_t flags,
                            void* work, float* dinp, float* mlp_slab, float* grad_mlp, float* ghs, float* ght,
                            float* gxs, float* gxt, void* stream);
 

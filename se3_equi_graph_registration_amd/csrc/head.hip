@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
     const float* __restrict__ w3, const float* __restrict__ b3, int B, int N, int Npad, int F, int K, MlpDims md,
     int* __restrict__ pos, long long* __restrict__ top_idx, float* __restrict__ logits,
     float* __restrict__ a1_save, float* __restrict__ a2_save, float* __restrict__ pair_f /*[B][4]*/,
-    double* __restrict__ pair_part /*[B][2]*/, float* __restrict__ fin) {
+    double* __restrict__ pair_part /*[B][2]*/, float* __restrict__ fin, unsigned* __restrict__ tickets) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double red[4];
     __shared__ float redf[4];
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
     if (tid == 0) {
         float* pf = pair_f + (size_t)b * 4;
         pf[0] = mx; pf[1] = (float)den; pf[2] = (den > 0.0) ? 1.0f : 0.0f; pf[3] = 0.0f;
+        tickets[b] = 0u;
         if (b == 0) { fin[2] = (float)st[0]; fin[3] = (float)st[1]; fin[4] = (float)st[2]; fin[5] = (float)st[3]; fin[8] = (float)st[4]; fin[9] = (float)st[5]; }
     }
     // ---- top-K (:684): ascending key == descending sim, then lower index.  MSB radix select on the value
@@ -513,13 +514,23 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict_
 // KB1: grid (ceil(K/kRowsPerBlock), B): BCE + MLP backward on this block's rows, its MLP weight-gradient slab;
 // one extra block per pair reduces gwu = sum_i gw_i u_i for the softmax backward.
 // mlp slab layout: dW1 [h1*in] | db1 [h1] | dW2 [h2*h1] | db2 [h2] | dW3 [h2] | db3 [1]
+// The Kabsch backward of the head's own Kabsch (grad_R, grad_t -> coordinate and weight gradients) rides in this launch as extra
+// grid columns: it only needs the upstream pose gradient, like the MLP blocks, so the two run side by side instead of one after
+// the other.  The block that finishes a pair's weight gradients last (ticket) also sums gwu for the softmax backward.
+struct KabschBwdJob {
+    const float *xs, *xt, *wts, *aux, *gR, *gt;
+    float *gxs, *gxt, *gw;
+    unsigned* tickets;
+    int nkb;                              // 0: gw comes from the caller (equigspr_kabsch_backward ran before)
+};
 __global__ __launch_bounds__(256) void head_pair_bwd_kernel(
     const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
     const float* __restrict__ sim, const float* __restrict__ pair_f, const float* __restrict__ gw,
     const long long* __restrict__ top_idx, const float* __restrict__ logits, const float* __restrict__ a1_save,
     const float* __restrict__ a2_save, const float* __restrict__ w1, const float* __restrict__ w2,
     const float* __restrict__ w3, const float* __restrict__ g_cs_ptr, int B, int N, int F, int K, MlpDims md,
-    float* __restrict__ pair_g /*[B]*/, float* __restrict__ dinp /*[B][K][in]*/, float* __restrict__ mlp_slab, int nblk) {
+    float* __restrict__ pair_g /*[B]*/, float* __restrict__ dinp /*[B][K][in]*/, float* __restrict__ mlp_slab, int nblk,
+    KabschBwdJob kj) {
     constexpr int R = kRowsPerBlock;
     __shared__ float inp[R * (kMaxIn + 1)];
     __shared__ float a1[R * (kMaxH1 + 1)];
@@ -540,7 +551,22 @@ __global__ __launch_bounds__(256) void head_pair_bwd_kernel(
     const float* yb = labels + (size_t)b * N;
     const float* gwb = gw + (size_t)b * N;
     const int ld_in = md.in + 1, ld1 = md.h1 + 1, ld2 = md.h2 + 1;
-    if ((int)blockIdx.x == nblk) {       // one extra block per pair (not on the MLP blocks' critical path): gwu = sum_i gw_i u_i
+    if ((int)blockIdx.x >= nblk) {       // extra blocks per pair (not on the MLP blocks' critical path)
+        bool do_gwu = (int)blockIdx.x == nblk && kj.nkb == 0;         // gw given by the caller: one block sums gwu = sum_i gw_i u_i
+        if ((int)blockIdx.x > nblk) {                                   // the Kabsch backward shares of this pair
+            kabsch_bwd_block(kj.xs, kj.xt, kj.wts, kj.aux, kj.gR, kj.gt, N, kj.gxs, kj.gxt, kj.gw, b, (int)blockIdx.x - nblk - 1, kj.nkb);
+            __shared__ int is_last;
+            __syncthreads();
+            if (tid == 0) {
+                __threadfence();
+                is_last = atomicAdd(kj.tickets + b, 1u) == (unsigned)kj.nkb - 1u;
+                if (is_last) kj.tickets[b] = 0u;                        // a second backward over the same forward starts from zero again
+            }
+            __syncthreads();
+            do_gwu = is_last != 0;                                      // block-uniform
+            if (do_gwu) __threadfence();
+        }
+        if (!do_gwu) return;
         const float mx = pair_f[b * 4], den = pair_f[b * 4 + 1];
         double gwu = 0;
         for (int i = tid; i < N; i += 256)
@@ -710,7 +736,7 @@ static inline size_t fwd_smem(int N, int Npad, int K, MlpDims md) {
     const size_t keys = sizeof(u64) * (size_t)(Npad > kCand ? Npad : kCand);
     return keys + sizeof(unsigned) * (size_t)N + 64;
 }
-struct HeadWork { double *partA, *partC, *pair_part; float *pair_f, *pair_g; int nbp, nC; size_t bytes; };
+struct HeadWork { double *partA, *partC, *pair_part; float *pair_f, *pair_g; unsigned* tickets; int nbp, nC; size_t bytes; };
 static inline HeadWork head_work(void* base, int B, int N) {   // pair_part sized for K = N: ceil(N / kRowsPerBlock) row blocks
     HeadWork w;
     w.nbp = ceil_div(N, 8);
@@ -722,6 +748,7 @@ static inline HeadWork head_work(void* base, int B, int N) {   // pair_part size
     w.pair_part = reinterpret_cast<double*>(p + o); o += sizeof(double) * (size_t)B * ceil_div(N, kRowsPerBlock);
     w.pair_f = reinterpret_cast<float*>(p + o); o += sizeof(float) * (size_t)B * 4;
     w.pair_g = reinterpret_cast<float*>(p + o); o += sizeof(float) * (size_t)B;
+    w.tickets = reinterpret_cast<unsigned*>(p + o); o += sizeof(unsigned) * (size_t)B;      // backward's per-pair ticket (zeroed by K2)
     w.bytes = o + 64;
     return w;
 }
@@ -773,7 +800,7 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
     }
     hipLaunchKernelGGL(head_pair_kernel, dim3(B), dim3(256), sm, s, hs, ht, labels, sim, W.partA, W.nbp, w1, b1, w2, b2, w3, b3,
                        B, N, Npad, F, K, md, pos, reinterpret_cast<long long*>(top_idx), logits, a1_save, a2_save, W.pair_f,
-                       W.pair_part, out_scalars);
+                       W.pair_part, out_scalars, W.tickets);
     const int nblk = ceil_div(K, kRowsPerBlock);
     const WeightsJob wj{sim, rsim, labels, W.pair_f, out_scalars, wts, W.partC};
     hipLaunchKernelGGL(head_mlp_kernel, dim3(nblk + ceil_div(N, 256), B), dim3(256), 0, s, hs, ht, labels,
@@ -798,7 +825,8 @@ extern "C" int equigspr_head_backward(const float* hs, const float* ht, const fl
                                       const float* rsim, const float* cosv, const int32_t* pos, const float* wts,
                                       const int64_t* top_idx, const float* logits, const float* a1_save,
                                       const float* a2_save, const float* fin_scalars, const float* g_corr_sim,
-                                      const float* g_equi, const float* gw, int32_t B, int32_t N, int32_t F, int32_t K,
+                                      const float* g_equi, float* gw, const float* kabsch_aux, const float* grad_R,
+                                      const float* grad_t, int32_t B, int32_t N, int32_t F, int32_t K,
                                       int32_t flags, void* work /* the forward's */, float* dinp, float* mlp_slab, float* grad_mlp /* += */,
                                       float* ghs, float* ght, float* gxs /* += */, float* gxt /* += */, void* stream) {
     using namespace eq;
@@ -812,9 +840,12 @@ extern "C" int equigspr_head_backward(const float* hs, const float* ht, const fl
     const float* w2 = w1 + md.h1 * md.in + md.h1;
     const float* w3 = w2 + md.h2 * md.h1 + md.h2;
     const int nblk = ceil_div(K, kRowsPerBlock);
-    hipLaunchKernelGGL(head_pair_bwd_kernel, dim3(nblk + 1, B), dim3(256), 0, s, hs, ht, labels, sim, W.pair_f, gw,
+    EQ_CHECK_ARG((kabsch_aux != nullptr) == (grad_R != nullptr) && (grad_R != nullptr) == (grad_t != nullptr), EQUIGSPR_EINVAL,
+                 "head_backward: kabsch_aux, grad_R, grad_t go together (all NULL: gw is an input)");
+    KabschBwdJob kj{xs, xt, wts, kabsch_aux, grad_R, grad_t, gxs, gxt, gw, W.tickets, grad_R ? kabsch_bwd_blocks(N) : 0};
+    hipLaunchKernelGGL(head_pair_bwd_kernel, dim3(nblk + 1 + kj.nkb, B), dim3(256), 0, s, hs, ht, labels, sim, W.pair_f, gw,
                        reinterpret_cast<const long long*>(top_idx), logits, a1_save, a2_save, w1, w2, w3, g_corr_sim, B, N, F, K,
-                       md, W.pair_g, dinp, mlp_slab, nblk);
+                       md, W.pair_g, dinp, mlp_slab, nblk, kj);
     const int msz = (int)equigspr_head_mlp_size(F);
     hipLaunchKernelGGL(head_node_bwd_kernel, dim3(W.nbp + ceil_div(msz, 32), B), dim3(256), 0, s, hs, ht, xs, xt, labels, gt_pose,
                        sim, rsim, cosv, pos, dinp, gw, W.pair_f, W.pair_g, fin_scalars, g_corr_sim, g_equi, B, N, F, K, md.in, ghs, ght,

@@ -221,4 +221,110 @@ __device__ __forceinline__ void kabsch_solve_wave(int nb, float* __restrict__ Ro
     }
 }
 
+// Kabsch backward of pair b, node share xb of nxb (256 threads; every block redoes the 3x3 part on its thread 0):
+// closed form through the polar factor (finite for repeated singular values); grads w.r.t. the clouds and the weights.
+__device__ __forceinline__ void kabsch_bwd_block(const float* __restrict__ src, const float* __restrict__ tgt,
+                                                 const float* __restrict__ w, const float* __restrict__ aux,
+                                                 const float* __restrict__ gR, const float* __restrict__ gt, int n,
+                                                 float* __restrict__ gsrc, float* __restrict__ gtgt, float* __restrict__ gw,
+                                                 int b, int xb, int nxb) {
+    __shared__ float sh[9 + 3 + 3];   // gH, g_cs, g_ct
+    const float* ax = aux + (size_t)b * EQUIGSPR_KABSCH_AUX;
+    if (threadIdx.x == 0) {
+        double cs[3], U[9], st[3], R[9], G[9], g_cs[3], g_ct[3], gtv[3];
+        for (int a = 0; a < 3; ++a) { cs[a] = ax[a]; st[a] = ax[15 + a]; gtv[a] = gt[b * 3 + a]; }
+        for (int i = 0; i < 9; ++i) { U[i] = ax[6 + i]; R[i] = ax[18 + i]; }
+        for (int a = 0; a < 3; ++a) {
+            g_ct[a] = gtv[a];
+            g_cs[a] = -(R[0 * 3 + a] * gtv[0] + R[1 * 3 + a] * gtv[1] + R[2 * 3 + a] * gtv[2]);
+            for (int c = 0; c < 3; ++c) G[a * 3 + c] = (double)gR[b * 9 + a * 3 + c] - gtv[a] * cs[c];
+        }
+        // M = U^T R^T G U
+        double T1[9], T2[9], M[9];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {                 // T1 = R^T G
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) acc += R[k * 3 + a] * G[k * 3 + c];
+                T1[a * 3 + c] = acc;
+            }
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {                 // T2 = T1 U
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) acc += T1[a * 3 + k] * U[k * 3 + c];
+                T2[a * 3 + c] = acc;
+            }
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {                 // M = U^T T2
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) acc += U[k * 3 + a] * T2[k * 3 + c];
+                M[a * 3 + c] = acc;
+            }
+        double Nm[9];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {
+                const double den = st[a] + st[c];
+                Nm[a * 3 + c] = (a != c && fabs(den) > 1e-30) ? M[a * 3 + c] / den : 0.0;
+            }
+        double Sk[9];                                       // N - N^T
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) Sk[a * 3 + c] = Nm[a * 3 + c] - Nm[c * 3 + a];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {                 // T1 = U Sk
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) acc += U[a * 3 + k] * Sk[k * 3 + c];
+                T1[a * 3 + c] = acc;
+            }
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {                 // T2 = T1 U^T  (= K - K^T)
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) acc += T1[a * 3 + k] * U[c * 3 + k];
+                T2[a * 3 + c] = acc;
+            }
+        double gH[9];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) {                 // gA = R T2 ; gH = gA^T
+                double acc = 0;
+                for (int k = 0; k < 3; ++k) acc += R[a * 3 + k] * T2[k * 3 + c];
+                gH[c * 3 + a] = acc;
+            }
+        for (int a = 0; a < 3; ++a) {
+            double a1 = 0, a2 = 0;
+            for (int c = 0; c < 3; ++c) {
+                a1 += gH[a * 3 + c] * ax[30 + c];            // gH * sum w (t-ct)
+                a2 += gH[c * 3 + a] * ax[27 + c];            // gH^T * sum w (s-cs)
+            }
+            g_cs[a] -= a1;
+            g_ct[a] -= a2;
+        }
+        for (int i = 0; i < 9; ++i) sh[i] = (float)gH[i];
+        for (int a = 0; a < 3; ++a) { sh[9 + a] = (float)g_cs[a]; sh[12 + a] = (float)g_ct[a]; }
+    }
+    __syncthreads();
+    float gH[9], g_cs[3], g_ct[3], cs[3], ct[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) gH[i] = sh[i];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { g_cs[a] = sh[9 + a]; g_ct[a] = sh[12 + a]; cs[a] = ax[a]; ct[a] = ax[3 + a]; }
+    const float* s = src + (size_t)b * n * 3;
+    const float* t = tgt + (size_t)b * n * 3;
+    for (int i = xb * 256 + threadIdx.x; i < n; i += nxb * 256) {
+        const float wi = w[(size_t)b * n + i];
+        float sv[3], tv[3], ds[3], dt[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { sv[a] = s[i * 3 + a]; tv[a] = t[i * 3 + a]; ds[a] = sv[a] - cs[a]; dt[a] = tv[a] - ct[a]; }
+        float gwi = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float hs = gH[a * 3 + 0] * dt[0] + gH[a * 3 + 1] * dt[1] + gH[a * 3 + 2] * dt[2];      // (gH dt)_a
+            const float ht = gH[0 * 3 + a] * ds[0] + gH[1 * 3 + a] * ds[1] + gH[2 * 3 + a] * ds[2];      // (gH^T ds)_a
+            if (gsrc) gsrc[((size_t)b * n + i) * 3 + a] = wi * (hs + g_cs[a]);
+            if (gtgt) gtgt[((size_t)b * n + i) * 3 + a] = wi * (ht + g_ct[a]);
+            gwi += ds[a] * hs + sv[a] * g_cs[a] + tv[a] * g_ct[a];
+        }
+        if (gw) gw[(size_t)b * n + i] = gwi;
+    }
+}
+
+__host__ __device__ inline int kabsch_bwd_blocks(int n) { const int nb = (n + 255) / 256; return nb < 1 ? 1 : (nb > 8 ? 8 : nb); }
+
 }  // namespace eq

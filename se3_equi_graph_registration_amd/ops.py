@@ -337,8 +337,8 @@ class _HeadFn(torch.autograd.Function):
         gt_ = torch.zeros(B, 3, **f32) if gt_ is None else gt_.contiguous()
         gx_all = torch.empty(2 * B * N, 3, **f32)
         gxs, gxt, gw = gx_all[:B * N], gx_all[B * N:], torch.empty_like(wts)
-        _lib.check(L.equigspr_kabsch_backward(_p(xs), _p(xt), _p(wts), _p(aux), _p(gR), _p(gt_), B, N, _p(gxs), _p(gxt),
-                                              _p(gw), _stream()), "kabsch_backward")
+        # the Kabsch backward (grad_R, grad_t -> coordinate / weight gradients) runs inside head_backward's first launch, beside the MLP
+        # backward blocks (ABI 8); equigspr_kabsch_backward stays the stand-alone op's backward
         gh_all = torch.empty(2 * B * N, Fd, **f32)
         ghs, ght = gh_all[:B * N], gh_all[B * N:]
         dinp = torch.empty(B, K, 2 * Fd, **f32)
@@ -351,7 +351,7 @@ class _HeadFn(torch.autograd.Function):
         g_eq = None if g_eq is None else g_eq.contiguous().float()
         _lib.check(L.equigspr_head_backward(_p(hs), _p(ht), _p(xs), _p(xt), _p(labels), _p(gt), _p(flat), _p(sim), _p(rsim),
                                             _p(cosv), _p(pos), _p(wts), _p(top_idx), _p(logits), _p(a1), _p(a2), _p(fin),
-                                            _p(g_cs), _p(g_eq), _p(gw), B, N, Fd, K, ctx.flags, _p(work), _p(dinp), _p(slab), _p(gmlp),
+                                            _p(g_cs), _p(g_eq), _p(gw), _p(aux), _p(gR), _p(gt_), B, N, Fd, K, ctx.flags, _p(work), _p(dinp), _p(slab), _p(gmlp),
                                             _p(ghs), _p(ght), _p(gxs), _p(gxt), _stream()), "head_backward")
         if in_place is not None:
             return (gh_all, gx_all, None, None, None, None, None, None, *([None] * len(ctx.mlp_shapes)))
