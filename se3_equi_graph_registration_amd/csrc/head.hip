@@ -96,8 +96,13 @@ __global__ __launch_bounds__(256) void head_node_kernel(const float* __restrict_
                                                         const float* __restrict__ labels, const float* __restrict__ gt_pose,
                                                         int B, int N, int F, int Fr, float* __restrict__ sim,
                                                         float* __restrict__ rsim, float* __restrict__ cosv,
-                                                        int* __restrict__ pos, double* __restrict__ partials) {
+                                                        int* __restrict__ pos, double* __restrict__ partials,
+                                                        unsigned* __restrict__ tickets /*[B + 1]*/) {
     __shared__ float nv[8][6];     // s, r, rot, feat, valid, (pad)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {           // the tickets of the launches behind this one (K2 per pair, K3 one for all)
+        tickets[blockIdx.y] = 0u;
+        if (blockIdx.y == 0) tickets[B] = 0u;
+    }
     const int slot = threadIdx.x >> 5, f = threadIdx.x & 31;
     const int b = blockIdx.y, n = blockIdx.x * 8 + slot;
     const bool live = n < N;
@@ -190,6 +195,40 @@ __device__ __forceinline__ void gather_rows(const float* __restrict__ hs, const 
 constexpr int kCand = 512;              // candidate list of the radix select
 constexpr int kCandEarly = 256;         // ... and the size at which the select stops refining digits
 
+// K2 (extra blocks of the head_pair_kernel launch): one thread per node: Kabsch weights (:718-724) and the similarity-MSE
+// partial sums (:777-781).  Block (xb, b) covers nodes [256 xb, 256 xb + 256) of pair b; its partials go to record b * nCw + xb.
+// The softmax scalars (mx, den, Su) and the batch statistics (mu_s, sd_s, mu_r, sd_r) come from the block's own evaluation of
+// the K1 partials (the same float values block 0 of the pair publishes for the backward).
+struct WeightsJob {
+    const float *sim, *rsim, *labels;
+    float* wts;
+    double* partC;
+};
+__device__ __forceinline__ void head_weights_block(const WeightsJob& j, int xb, int b, int N, float mx, float den, float Su,
+                                                   float mu_s, float sd_s, float mu_r, float sd_r) {
+    const int il = xb * 256 + (int)threadIdx.x;
+    double q0 = 0, q1 = 0, q2 = 0;
+    if (il < N) {
+        const size_t i = (size_t)b * N + il;
+        const float s = j.sim[i];
+        const float u = (j.labels[i] != 0.0f && den > 0.0f) ? expf(s - mx) / den : 0.0f;
+        j.wts[i] = u / (Su + 1e-6f);
+        const float zs = (s - mu_s) / (sd_s + 1e-6f), zr = (j.rsim[i] - mu_r) / (sd_r + 1e-6f);
+        const float e = zs - zr;
+        q0 = (double)e * e; q1 = e; q2 = (double)e * (s - mu_s);
+    }
+    {
+        __shared__ double ws3[4][8];
+        double qv[3] = {q0, q1, q2};
+        block_sum_dn<3>(qv, ws3);
+        q0 = qv[0]; q1 = qv[1]; q2 = qv[2];
+    }
+    if (threadIdx.x == 0) {
+        double* rec = j.partC + ((size_t)b * ((N + 255) / 256) + xb) * 3;
+        rec[0] = q0; rec[1] = q1; rec[2] = q2;
+    }
+}
+
 // K2: one workgroup per pair: softmax scalars, top-K (radix select + small bitonic sort), MLP, BCE
 __global__ __launch_bounds__(256) void head_pair_kernel(
     const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
@@ -198,7 +237,9 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
     const float* __restrict__ w3, const float* __restrict__ b3, int B, int N, int Npad, int F, int K, MlpDims md,
     int* __restrict__ pos, long long* __restrict__ top_idx, float* __restrict__ logits,
     float* __restrict__ a1_save, float* __restrict__ a2_save, float* __restrict__ pair_f /*[B][4]*/,
-    double* __restrict__ pair_part /*[B][2]*/, float* __restrict__ fin, unsigned* __restrict__ tickets) {
+    double* __restrict__ pair_part /*[B][2]*/, float* __restrict__ fin, unsigned* __restrict__ tickets, WeightsJob wj, int nwb,
+    const float* __restrict__ xs, const float* __restrict__ xt, float* __restrict__ kab_R, float* __restrict__ kab_t,
+    float* __restrict__ kab_aux) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double red[4];
     __shared__ float redf[4];
@@ -206,7 +247,10 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
     __shared__ unsigned histp[kHistCopies * 256];
     __shared__ int sel[3];
     __shared__ int wtot[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    // grid (1 + nwb, B): column 0 = the pair's select block, columns 1.. = its Kabsch-weight blocks.  EVERY block evaluates the
+    // batch statistics and its pair's softmax scalars from the K1 partials itself (a few microseconds, L2-resident), so the weight
+    // blocks need nothing from the select block and the two chains -- select -> MLP and weights -> Kabsch -- run side by side.
+    const int b = blockIdx.y, tid = threadIdx.x;
     const long long M = (long long)B * N;
     const float* sb = sim + (size_t)b * N;
     const float* yb = labels + (size_t)b * N;
@@ -227,10 +271,30 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
         if (bm > -INFINITY) den += pp[(size_t)k * kHeadPartials + 7] * (double)expf(bm - mx);
     }
     den = block_sum_d(den, red);
+    if (blockIdx.x > 0) {
+        // ---- Kabsch weights + similarity-MSE partials of this block's 256 nodes; the block that finishes the pair's weights last
+        // (ticket, zeroed by K1 and handed back as zero) computes the pair's Kabsch moments over them and solves the 3x3 problem
+        head_weights_block(wj, (int)blockIdx.x - 1, b, N, mx, (float)den, (den > 0.0) ? 1.0f : 0.0f, (float)st[0], (float)st[1],
+                           (float)st[2], (float)st[3]);
+        if (!kab_aux) return;
+        __shared__ int is_last;
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            is_last = atomicAdd(tickets + b, 1u) == (unsigned)nwb - 1u;
+            if (is_last) tickets[b] = 0u;               // the backward's ticket starts from zero
+        }
+        __syncthreads();
+        if (!is_last) return;                            // block-uniform
+        __threadfence();
+        kabsch_moments_block(xs, xt, wj.wts, N, kab_aux, b, 0, 1);
+        __syncthreads();
+        if (tid < 64) kabsch_solve_wave(1, kab_R, kab_t, kab_aux, b, tid);
+        return;
+    }
     if (tid == 0) {
         float* pf = pair_f + (size_t)b * 4;
         pf[0] = mx; pf[1] = (float)den; pf[2] = (den > 0.0) ? 1.0f : 0.0f; pf[3] = 0.0f;
-        tickets[b] = 0u;
         if (b == 0) { fin[2] = (float)st[0]; fin[3] = (float)st[1]; fin[4] = (float)st[2]; fin[5] = (float)st[3]; fin[8] = (float)st[4]; fin[9] = (float)st[5]; }
     }
     // ---- top-K (:684): ascending key == descending sim, then lower index.  MSB radix select on the value
@@ -330,6 +394,30 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
     }
 }
 
+// out[0] = corr_loss + sim_loss, out[1] = equi loss, out[2..5] = mu_s, sd_s, mu_r, sd_r (written by K2),
+// out[6] = sum e, out[7] = sum e (s - mu_s), out[8], out[9] = rot / feat sums (written by K2)
+__device__ __forceinline__ void head_finalize_block(const double* __restrict__ partC, int nC,
+                                                    const double* __restrict__ pair_part, int nblk, int B, int N, int K,
+                                                    float* __restrict__ out, int flags) {
+    __shared__ double red[4];
+    const long long M = (long long)B * N;
+    double a0 = 0, a1 = 0, a2 = 0, bce = 0;
+    for (int k = threadIdx.x; k < nC; k += 256) { a0 += partC[(size_t)k * 3]; a1 += partC[(size_t)k * 3 + 1]; a2 += partC[(size_t)k * 3 + 2]; }
+    for (int b = threadIdx.x; b < B * nblk; b += 256) bce += pair_part[b];
+    {
+        __shared__ double ws4[4][8];
+        double av[4] = {a0, a1, a2, bce};
+        block_sum_dn<4>(av, ws4);
+        a0 = av[0]; a1 = av[1]; a2 = av[2]; bce = av[3];
+    }
+    if (threadIdx.x == 0) {
+        // EQUIGSPR_HEAD_NO_SIM_LOSS: the KITTI script's forward returns corr_loss alone (src/kitti_train_egnn_with_batch.py:766)
+        out[0] = (float)(bce / ((double)B * K) + ((flags & EQUIGSPR_HEAD_NO_SIM_LOSS) ? 0.0 : a0 / (double)M));
+        out[1] = (float)(((double)out[8] + (double)out[9]) / (double)M);
+        out[6] = (float)a1; out[7] = (float)a2;
+    }
+}
+
 // K2b: the correspondence MLP on the K selected rows (:760-773), kRowsPerBlock rows per workgroup so the
 // work spreads over the chip instead of one CU per pair.  grid (ceil(K/kRowsPerBlock), B)
 constexpr int kRowsPerBlock = 8;
@@ -348,49 +436,13 @@ __device__ __forceinline__ void stage8(float* dst, const float* __restrict__ src
     }
 }
 
-// K3 (extra blocks of the head_mlp_kernel launch): one thread per node: Kabsch weights (:718-724) and the similarity-MSE
-// partial sums (:777-781).  Block (xb, b) covers nodes [256 xb, 256 xb + 256) of pair b; its partials go to record b * nCw + xb.
-struct WeightsJob {
-    const float *sim, *rsim, *labels, *pair_f, *fin;
-    float* wts;
-    double* partC;
-};
-__device__ __forceinline__ void head_weights_block(const WeightsJob& j, int xb, int b, int N) {
-    __shared__ double red[4];
-    const int il = xb * 256 + (int)threadIdx.x;
-    double q0 = 0, q1 = 0, q2 = 0;
-    if (il < N) {
-        const size_t i = (size_t)b * N + il;
-        const float mx = j.pair_f[b * 4], den = j.pair_f[b * 4 + 1], Su = j.pair_f[b * 4 + 2];
-        const float s = j.sim[i];
-        const float u = (j.labels[i] != 0.0f && den > 0.0f) ? expf(s - mx) / den : 0.0f;
-        j.wts[i] = u / (Su + 1e-6f);
-        const float zs = (s - j.fin[2]) / (j.fin[3] + 1e-6f), zr = (j.rsim[i] - j.fin[4]) / (j.fin[5] + 1e-6f);
-        const float e = zs - zr;
-        q0 = (double)e * e; q1 = e; q2 = (double)e * (s - j.fin[2]);
-    }
-    {
-        __shared__ double ws3[4][8];
-        double qv[3] = {q0, q1, q2};
-        block_sum_dn<3>(qv, ws3);
-        q0 = qv[0]; q1 = qv[1]; q2 = qv[2];
-    }
-    if (threadIdx.x == 0) {
-        double* rec = j.partC + ((size_t)b * ((N + 255) / 256) + xb) * 3;
-        rec[0] = q0; rec[1] = q1; rec[2] = q2;
-    }
-}
-
 __global__ __launch_bounds__(256) void head_mlp_kernel(
     const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
     const long long* __restrict__ top_idx, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
     int B, int N, int F, int K, MlpDims md, float* __restrict__ logits, float* __restrict__ a1_save,
-    float* __restrict__ a2_save, double* __restrict__ pair_part, int nblk, WeightsJob wj) {
-    if ((int)blockIdx.x >= nblk) {       // block-uniform: the Kabsch-weight blocks ride in this launch (both only need K2's outputs)
-        head_weights_block(wj, (int)blockIdx.x - nblk, blockIdx.y, N);
-        return;
-    }
+    float* __restrict__ a2_save, double* __restrict__ pair_part, int nblk, const double* __restrict__ partC, int nC,
+    float* __restrict__ out_scalars, int flags, unsigned* __restrict__ ticket /* one word: zeroed by K1, handed back as zero */) {
     __shared__ float inp[kRowsPerBlock * (kMaxIn + 1)];
     __shared__ float a1[kRowsPerBlock * (kMaxH1 + 1)];
     __shared__ float a2[kRowsPerBlock * (kMaxH2 + 1)];
@@ -444,68 +496,18 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(
         bce = fmaxf(z, 0.0f) - z * y + log1pf(expf(-fabsf(z)));                          // BCEWithLogits (:772-773)
     }
     bce = block_sum_d(bce, red);
-    if (tid == 0) pair_part[(size_t)b * nblk + blockIdx.x] = bce;
-}
-
-// out[0] = corr_loss + sim_loss, out[1] = equi loss, out[2..5] = mu_s, sd_s, mu_r, sd_r (written by K2),
-// out[6] = sum e, out[7] = sum e (s - mu_s), out[8], out[9] = rot / feat sums (written by K2)
-__device__ __forceinline__ void head_finalize_block(const double* __restrict__ partC, int nC,
-                                                    const double* __restrict__ pair_part, int nblk, int B, int N, int K,
-                                                    float* __restrict__ out, int flags) {
-    __shared__ double red[4];
-    const long long M = (long long)B * N;
-    double a0 = 0, a1 = 0, a2 = 0, bce = 0;
-    for (int k = threadIdx.x; k < nC; k += 256) { a0 += partC[(size_t)k * 3]; a1 += partC[(size_t)k * 3 + 1]; a2 += partC[(size_t)k * 3 + 2]; }
-    for (int b = threadIdx.x; b < B * nblk; b += 256) bce += pair_part[b];
-    {
-        __shared__ double ws4[4][8];
-        double av[4] = {a0, a1, a2, bce};
-        block_sum_dn<4>(av, ws4);
-        a0 = av[0]; a1 = av[1]; a2 = av[2]; bce = av[3];
-    }
-    if (threadIdx.x == 0) {
-        // EQUIGSPR_HEAD_NO_SIM_LOSS: the KITTI script's forward returns corr_loss alone (src/kitti_train_egnn_with_batch.py:766)
-        out[0] = (float)(bce / ((double)B * K) + ((flags & EQUIGSPR_HEAD_NO_SIM_LOSS) ? 0.0 : a0 / (double)M));
-        out[1] = (float)(((double)out[8] + (double)out[9]) / (double)M);
-        out[6] = (float)a1; out[7] = (float)a2;
-    }
-}
-
-__global__ __launch_bounds__(256) void head_finalize_kernel(const double* __restrict__ partC, int nC,
-                                                            const double* __restrict__ pair_part, int nblk, int B, int N, int K,
-                                                            float* __restrict__ out, int flags) {
-    head_finalize_block(partC, nC, pair_part, nblk, B, N, K, out, flags);
-}
-
-// K4, the training head's tail in ONE launch, grid (nb + 1, B).  Columns 0..nb-1: the fp64 Kabsch moments of pair b over
-// the weights K3 wrote; the block that finishes a pair last (ticket = the spare fourth word of the pair's pair_f record,
-// zeroed by K2 of the same call) solves it: release fence + device-scope atomic on the writers' side, acquire fence on the
-// reader's.  Column nb of pair 0: the loss scalars (head_finalize), which only need the previous launches.
-__global__ __launch_bounds__(256) void head_tail_kernel(const float* __restrict__ xs, const float* __restrict__ xt,
-                                                        const float* __restrict__ wts, int N, int nb, float* __restrict__ R,
-                                                        float* __restrict__ t, float* __restrict__ aux, float* __restrict__ pair_f,
-                                                        const double* __restrict__ partC, int nC,
-                                                        const double* __restrict__ pair_part, int nblk, int B, int K,
-                                                        float* __restrict__ out, int flags) {
-    if ((int)blockIdx.x == nb) {
-        if (blockIdx.y == 0) head_finalize_block(partC, nC, pair_part, nblk, B, N, K, out, flags);
-        return;
-    }
-    const int b = blockIdx.y;
-    EQ_STAMPK(5, 0);
-    kabsch_moments_block(xs, xt, wts, N, aux, b, blockIdx.x, nb);     // thread 0 stores this block's record
-    EQ_STAMPK(5, 1);
+    // ---- the block that finishes last over ALL pairs (ticket) turns the partial sums into the loss scalars
     __shared__ int is_last;
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
+        pair_part[(size_t)b * nblk + blockIdx.x] = bce;
         __threadfence();
-        is_last = atomicAdd(reinterpret_cast<unsigned*>(pair_f) + (size_t)b * 4 + 3, 1u) == (unsigned)nb - 1u;
+        is_last = atomicAdd(ticket, 1u) == gridDim.x * gridDim.y - 1u;
+        if (is_last) *ticket = 0u;
     }
     __syncthreads();
-    EQ_STAMPK(5, 2);
-    if (!is_last) return;                                            // block-uniform
+    if (!is_last) return;                                // block-uniform
     __threadfence();
-    if (threadIdx.x < 64) kabsch_solve_wave(nb, R, t, aux, b, threadIdx.x);
-    EQ_STAMPK(5, 3);
+    head_finalize_block(partC, nC, pair_part, nblk, B, N, K, out_scalars, flags);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -748,7 +750,7 @@ static inline HeadWork head_work(void* base, int B, int N) {   // pair_part size
     w.pair_part = reinterpret_cast<double*>(p + o); o += sizeof(double) * (size_t)B * ceil_div(N, kRowsPerBlock);
     w.pair_f = reinterpret_cast<float*>(p + o); o += sizeof(float) * (size_t)B * 4;
     w.pair_g = reinterpret_cast<float*>(p + o); o += sizeof(float) * (size_t)B;
-    w.tickets = reinterpret_cast<unsigned*>(p + o); o += sizeof(unsigned) * (size_t)B;      // backward's per-pair ticket (zeroed by K2)
+    w.tickets = reinterpret_cast<unsigned*>(p + o); o += sizeof(unsigned) * (size_t)(B + 1);      // per-pair tickets (K2 / the backward) + K3's; zeroed by K1, handed back as zero
     w.bytes = o + 64;
     return w;
 }
@@ -788,7 +790,7 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
     const float* w3 = b2 + md.h2;
     const float* b3 = w3 + md.h2;
     hipLaunchKernelGGL(head_node_kernel, dim3(W.nbp, B), dim3(256), 0, s, hs, ht, raw_hs, raw_ht, xs, xt, labels, gt_pose, B, N,
-                       F, F_raw, sim, rsim, cosv, pos, W.partA);
+                       F, F_raw, sim, rsim, cosv, pos, W.partA, W.tickets);
     const int Npad = next_pow2(N);
     const size_t sm = fwd_smem(N, Npad, K, md);
     static size_t sm_set = 0;
@@ -798,24 +800,19 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
         if (e != hipSuccess) { set_error("head_forward: %s", hipGetErrorString(e)); return (int)e; }
         sm_set = sm;
     }
-    hipLaunchKernelGGL(head_pair_kernel, dim3(B), dim3(256), sm, s, hs, ht, labels, sim, W.partA, W.nbp, w1, b1, w2, b2, w3, b3,
+    EQ_CHECK_ARG(!kabsch_aux || (kabsch_R && kabsch_t), EQUIGSPR_EINVAL, "head_forward: kabsch_R / kabsch_t are null");
+    const int nwb = ceil_div(N, 256);
+    const WeightsJob wj{sim, rsim, labels, wts, W.partC};
+    // K2: per pair the select block and, beside it, the weight blocks -> (ticket) Kabsch moments + solve (= equigspr_kabsch_forward
+    // on the weights, when kabsch_aux is given)
+    hipLaunchKernelGGL(head_pair_kernel, dim3(1 + nwb, B), dim3(256), sm, s, hs, ht, labels, sim, W.partA, W.nbp, w1, b1, w2, b2, w3, b3,
                        B, N, Npad, F, K, md, pos, reinterpret_cast<long long*>(top_idx), logits, a1_save, a2_save, W.pair_f,
-                       W.pair_part, out_scalars, W.tickets);
+                       W.pair_part, out_scalars, W.tickets, wj, nwb, xs, xt, kabsch_R, kabsch_t, kabsch_aux);
+    // K3: the MLP on the selected rows; the last block over all pairs (ticket) writes the loss scalars
     const int nblk = ceil_div(K, kRowsPerBlock);
-    const WeightsJob wj{sim, rsim, labels, W.pair_f, out_scalars, wts, W.partC};
-    hipLaunchKernelGGL(head_mlp_kernel, dim3(nblk + ceil_div(N, 256), B), dim3(256), 0, s, hs, ht, labels,
+    hipLaunchKernelGGL(head_mlp_kernel, dim3(nblk, B), dim3(256), 0, s, hs, ht, labels,
                        reinterpret_cast<const long long*>(top_idx), w1, b1, w2, b2, w3, b3, B, N, F, K, md, logits, a1_save, a2_save,
-                       W.pair_part, nblk, wj);
-    if (kabsch_aux) {      // + equigspr_kabsch_forward(xs, xt, wts) in the same launch as the loss scalars
-        EQ_CHECK_ARG(kabsch_R && kabsch_t, EQUIGSPR_EINVAL, "head_forward: kabsch_R / kabsch_t are null");
-        int nb = (N + 255) / 256;
-        if (nb > kKabschMaxBlocks) nb = kKabschMaxBlocks;
-        hipLaunchKernelGGL(head_tail_kernel, dim3(nb + 1, B), dim3(256), 0, s, xs, xt, wts, N, nb, kabsch_R, kabsch_t, kabsch_aux,
-                           W.pair_f, W.partC, W.nC, W.pair_part, nblk, B, K, out_scalars, (int)flags);
-    } else {
-        hipLaunchKernelGGL(head_finalize_kernel, dim3(1), dim3(256), 0, s, W.partC, W.nC, W.pair_part, nblk, B, N, K, out_scalars,
-                           (int)flags);
-    }
+                       W.pair_part, nblk, W.partC, W.nC, out_scalars, (int)flags, W.tickets + B);
     EQ_CHECK_LAUNCH("head_forward");
     return 0;
 }
