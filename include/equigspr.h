@@ -27,7 +27,7 @@ extern "C" {
 
 #define EQUIGSPR_EINVAL   (-1)  /* bad shape / size / null pointer                         */
 #define EQUIGSPR_ENOTSUP  (-2)  /* configuration outside the compiled kernel set             */
-#define EQUIGSPR_ABI_VERSION 8
+#define EQUIGSPR_ABI_VERSION 9
 
 /* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
  * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
@@ -189,7 +189,11 @@ int equigspr_kabsch_backward(const float* src, const float* tgt, const float* w,
  * loss scalars, instead of two more launches.
  * Backward: g_corr_sim / g_equi are DEVICE scalars (may be NULL = 0); gw = dL/d wts from
  * equigspr_kabsch_backward -- or, with kabsch_aux / grad_R / grad_t given (ABI 8), that Kabsch backward runs inside this call's
- * first launch beside the MLP backward: gw is then an OUTPUT (scratch [B*N]) and gxs, gxt are written first; writes ghs,ght; ADDS the equi-loss terms into gxs,gxt (which hold the
+ * first launch beside the MLP backward: gw is then an OUTPUT (scratch [B*N]) and gxs, gxt are written first (grad_R / grad_t may
+ * be NULL = zero).  step_loss (forward, ABI 9; needs kabsch_aux): [1 + 2B] floats = the training loop's scalar loss
+ * corr_loss + sim_loss + mean rot_loss + mean trans_loss (train :1117-1120), then rot_loss[B], trans_loss[B] -- evaluated inside the
+ * head's launches instead of equigspr_step_loss_forward; g_step_loss (backward, device scalar, needs kabsch_t) is the upstream
+ * gradient of that scalar: its pose terms join grad_R / grad_t, its corr/sim term joins g_corr_sim.  writes ghs,ght; ADDS the equi-loss terms into gxs,gxt (which hold the
  * Kabsch coordinate gradients); ADDS into grad_mlp. */
 #define EQUIGSPR_HEAD_NO_SIM_LOSS 1
 int64_t equigspr_head_mlp_size(int32_t F);
@@ -200,14 +204,14 @@ int equigspr_head_forward(const float* hs, const float* ht, const float* raw_hs,
                           const float* mlp, int32_t B, int32_t N, int32_t F, int32_t F_raw, int32_t K, int32_t flags,
                           float* sim, float* rsim, float* cosv, int32_t* pos, float* wts, int64_t* top_idx,
                           float* logits, float* a1_save, float* a2_save, void* work, float* out_scalars,
-                          float* kabsch_R, float* kabsch_t, float* kabsch_aux, void* stream);
+                          float* kabsch_R, float* kabsch_t, float* kabsch_aux, float* step_loss, void* stream);
 int equigspr_head_backward(const float* hs, const float* ht, const float* xs, const float* xt,
                            const float* labels, const float* gt_pose, const float* mlp, const float* sim,
                            const float* rsim, const float* cosv, const int32_t* pos, const float* wts,
                            const int64_t* top_idx, const float* logits, const float* a1_save,
                            const float* a2_save, const float* fin_scalars, const float* g_corr_sim,
                            const float* g_equi, float* gw, const float* kabsch_aux, const float* grad_R, const float* grad_t,
-                           int32_t B, int32_t N, int32_t F, int32_t K, int32_t flags,
+                           const float* kabsch_t, const float* g_step_loss, int32_t B, int32_t N, int32_t F, int32_t K, int32_t flags,
                            void* work, float* dinp, float* mlp_slab, float* grad_mlp, float* ghs, float* ght,
                            float* gxs, float* gxt, void* stream);
 

@@ -53,8 +53,8 @@ _SIGNATURES = {
     "equigspr_head_mlp_size": (c_int64, [c_int32]),
     "equigspr_head_work_bytes": (c_int64, [c_int32, c_int32]),
     "equigspr_head_slab_count": (c_int64, [c_int32, c_int32]),
-    "equigspr_head_forward": (ctypes.c_int, [c_void_p] * 9 + [c_int32] * 6 + [c_void_p] * 15),
-    "equigspr_head_backward": (ctypes.c_int, [c_void_p] * 23 + [c_int32] * 5 + [c_void_p] * 9),
+    "equigspr_head_forward": (ctypes.c_int, [c_void_p] * 9 + [c_int32] * 6 + [c_void_p] * 16),
+    "equigspr_head_backward": (ctypes.c_int, [c_void_p] * 25 + [c_int32] * 5 + [c_void_p] * 9),
     "equigspr_pose_loss_forward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "equigspr_pose_loss_backward": (ctypes.c_int, [c_void_p] * 5 + [c_int32] + [c_void_p] * 3),
     "equigspr_adam_step": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
@@ -104,7 +104,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if L.equigspr_abi_version() != 8:
+        if L.equigspr_abi_version() != 9:
             raise RuntimeError("libequigspr.so ABI version mismatch")
         _lib = L
     return _lib

@@ -17,6 +17,7 @@
 // Layouts: h_* [B,N,F] with row stride F; x_* [B,N,3]; labels [B,N] (float 0/1); gt_pose [B,16].
 #include "common.h"
 #include "kabsch_device.h"
+#include "pose_loss_device.h"
 
 namespace eq {
 
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
     float* __restrict__ a1_save, float* __restrict__ a2_save, float* __restrict__ pair_f /*[B][4]*/,
     double* __restrict__ pair_part /*[B][2]*/, float* __restrict__ fin, unsigned* __restrict__ tickets, WeightsJob wj, int nwb,
     const float* __restrict__ xs, const float* __restrict__ xt, float* __restrict__ kab_R, float* __restrict__ kab_t,
-    float* __restrict__ kab_aux) {
+    float* __restrict__ kab_aux, const float* __restrict__ gt_pose, float* __restrict__ step_loss /* [1 + 2B] or NULL */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double red[4];
     __shared__ float redf[4];
@@ -290,6 +291,8 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
         kabsch_moments_block(xs, xt, wj.wts, N, kab_aux, b, 0, 1);
         __syncthreads();
         if (tid < 64) kabsch_solve_wave(1, kab_R, kab_t, kab_aux, b, tid);
+        if (step_loss && tid == 0)       // this pair's terms of the training loop's loss (train :1117-1120); K3 adds them up
+            pose_loss_pair(kab_R + (size_t)b * 9, kab_t + (size_t)b * 3, gt_pose + (size_t)b * 16, step_loss[1 + b], step_loss[1 + B + b]);
         return;
     }
     if (tid == 0) {
@@ -442,7 +445,8 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
     int B, int N, int F, int K, MlpDims md, float* __restrict__ logits, float* __restrict__ a1_save,
     float* __restrict__ a2_save, double* __restrict__ pair_part, int nblk, const double* __restrict__ partC, int nC,
-    float* __restrict__ out_scalars, int flags, unsigned* __restrict__ ticket /* one word: zeroed by K1, handed back as zero */) {
+    float* __restrict__ out_scalars, int flags, unsigned* __restrict__ ticket /* one word: zeroed by K1, handed back as zero */,
+    float* __restrict__ step_loss) {
     __shared__ float inp[kRowsPerBlock * (kMaxIn + 1)];
     __shared__ float a1[kRowsPerBlock * (kMaxH1 + 1)];
     __shared__ float a2[kRowsPerBlock * (kMaxH2 + 1)];
@@ -508,6 +512,10 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(
     if (!is_last) return;                                // block-uniform
     __threadfence();
     head_finalize_block(partC, nC, pair_part, nblk, B, N, K, out_scalars, flags);
+    if (step_loss) {                                     // loss = (corr_loss + sim_loss) + mean rot + mean trans (train :1120)
+        __syncthreads();
+        step_loss_sum(step_loss + 1, step_loss + 1 + B, out_scalars[0], B, step_loss);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -521,6 +529,7 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(
 // the other.  The block that finishes a pair's weight gradients last (ticket) also sums gwu for the softmax backward.
 struct KabschBwdJob {
     const float *xs, *xt, *wts, *aux, *gR, *gt;
+    const float *g_step, *gt_pose, *kab_t;   // g_step != NULL: + d(step loss)/d(R, t) of the loss the forward evaluated (device scalar)
     float *gxs, *gxt, *gw;
     unsigned* tickets;
     int nkb;                              // 0: gw comes from the caller (equigspr_kabsch_backward ran before)
@@ -548,7 +557,7 @@ __global__ __launch_bounds__(256) void head_pair_bwd_kernel(
     const int b = blockIdx.y, tid = threadIdx.x;
     const int j0 = blockIdx.x * R;
     const int Kb = min(R, K - j0);
-    const float g_cs = g_cs_ptr ? g_cs_ptr[0] : 0.0f;
+    const float g_cs = (g_cs_ptr ? g_cs_ptr[0] : 0.0f) + (kj.g_step ? kj.g_step[0] : 0.0f);     // the step loss contains corr_loss + sim_loss once
     const float* sb = sim + (size_t)b * N;
     const float* yb = labels + (size_t)b * N;
     const float* gwb = gw + (size_t)b * N;
@@ -556,7 +565,23 @@ __global__ __launch_bounds__(256) void head_pair_bwd_kernel(
     if ((int)blockIdx.x >= nblk) {       // extra blocks per pair (not on the MLP blocks' critical path)
         bool do_gwu = (int)blockIdx.x == nblk && kj.nkb == 0;         // gw given by the caller: one block sums gwu = sum_i gw_i u_i
         if ((int)blockIdx.x > nblk) {                                   // the Kabsch backward shares of this pair
-            kabsch_bwd_block(kj.xs, kj.xt, kj.wts, kj.aux, kj.gR, kj.gt, N, kj.gxs, kj.gxt, kj.gw, b, (int)blockIdx.x - nblk - 1, kj.nkb);
+            __shared__ float gRt[12];                                   // this pair's upstream grad_R | grad_t
+            if (tid == 0) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) gRt[q] = kj.gR ? kj.gR[(size_t)b * 9 + q] : 0.0f;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) gRt[9 + q] = kj.gt ? kj.gt[(size_t)b * 3 + q] : 0.0f;
+                if (kj.g_step) {                                        // the step loss's own pose terms: mean over the batch
+                    float sR[9], sT[3];
+                    const float up = kj.g_step[0] / (float)B;
+                    pose_loss_grad_pair(kj.aux + (size_t)b * EQUIGSPR_KABSCH_AUX + 18, kj.kab_t + (size_t)b * 3, kj.gt_pose + (size_t)b * 16, up, up, sR, sT);
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) gRt[q] += sR[q];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) gRt[9 + q] += sT[q];
+                }
+            }
+            kabsch_bwd_block(kj.xs, kj.xt, kj.wts, kj.aux, gRt, gRt + 9, N, kj.gxs, kj.gxt, kj.gw, b, (int)blockIdx.x - nblk - 1, kj.nkb);
             __shared__ int is_last;
             __syncthreads();
             if (tid == 0) {
@@ -651,7 +676,8 @@ __global__ __launch_bounds__(256) void head_node_bwd_kernel(
     const float* __restrict__ pair_g, const float* __restrict__ fin, const float* __restrict__ g_cs_ptr,
     const float* __restrict__ g_equi_ptr, int B, int N, int F, int K, int in_dim, float* __restrict__ ghs,
     float* __restrict__ ght, float* __restrict__ gxs /* += */, float* __restrict__ gxt /* += */, int nbp,
-    const float* __restrict__ mlp_slab, int n_slabs, int msz, float* __restrict__ grad_mlp /* += */, int flags) {
+    const float* __restrict__ mlp_slab, int n_slabs, int msz, float* __restrict__ grad_mlp /* += */, int flags,
+    const float* __restrict__ g_step_ptr) {
     if ((int)blockIdx.x >= nbp) {        // block-uniform: the MLP weight-gradient slabs of KB1, summed in fixed order, ride in this launch
         // 32 consecutive entries x 8 slab partitions per block (partition p sums slabs p, p + 8, ...; the 8 partials are then
         // added in order): K = 2048 leaves thousands of slabs, a one-thread-per-entry loop over them is a serial latency chain
@@ -680,7 +706,7 @@ __global__ __launch_bounds__(256) void head_node_bwd_kernel(
     const long long i = (long long)b * N + n;
     const long long M = (long long)B * N;
     const float g_eq = g_equi_ptr ? g_equi_ptr[0] : 0.0f;
-    const float g_cs = g_cs_ptr ? g_cs_ptr[0] : 0.0f;
+    const float g_cs = (g_cs_ptr ? g_cs_ptr[0] : 0.0f) + (g_step_ptr ? g_step_ptr[0] : 0.0f);
     const float y = labels[i], s = sim[i];
     // softmax-normalised weights backward
     const float mx = pair_f[b * 4], den = pair_f[b * 4 + 1], Su = pair_f[b * 4 + 2], gwu = pair_g[b];
@@ -774,7 +800,7 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
                                      int32_t F_raw, int32_t K, int32_t flags, float* sim, float* rsim, float* cosv, int32_t* pos,
                                      float* wts, int64_t* top_idx, float* logits, float* a1_save, float* a2_save,
                                      void* work, float* out_scalars /* [16] device */, float* kabsch_R, float* kabsch_t,
-                                     float* kabsch_aux, void* stream) {
+                                     float* kabsch_aux, float* step_loss /* [1 + 2B] or NULL */, void* stream) {
     using namespace eq;
     EQ_CHECK_ARG(hs && ht && raw_hs && raw_ht && xs && xt && labels && gt_pose && mlp && sim && rsim && cosv && pos && wts &&
                      top_idx && logits && a1_save && a2_save && work && out_scalars, EQUIGSPR_EINVAL, "head_forward: null pointer");
@@ -801,18 +827,19 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
         sm_set = sm;
     }
     EQ_CHECK_ARG(!kabsch_aux || (kabsch_R && kabsch_t), EQUIGSPR_EINVAL, "head_forward: kabsch_R / kabsch_t are null");
+    EQ_CHECK_ARG(!step_loss || kabsch_aux, EQUIGSPR_EINVAL, "head_forward: step_loss needs the head's own Kabsch (kabsch_aux)");
     const int nwb = ceil_div(N, 256);
     const WeightsJob wj{sim, rsim, labels, wts, W.partC};
     // K2: per pair the select block and, beside it, the weight blocks -> (ticket) Kabsch moments + solve (= equigspr_kabsch_forward
     // on the weights, when kabsch_aux is given)
     hipLaunchKernelGGL(head_pair_kernel, dim3(1 + nwb, B), dim3(256), sm, s, hs, ht, labels, sim, W.partA, W.nbp, w1, b1, w2, b2, w3, b3,
                        B, N, Npad, F, K, md, pos, reinterpret_cast<long long*>(top_idx), logits, a1_save, a2_save, W.pair_f,
-                       W.pair_part, out_scalars, W.tickets, wj, nwb, xs, xt, kabsch_R, kabsch_t, kabsch_aux);
+                       W.pair_part, out_scalars, W.tickets, wj, nwb, xs, xt, kabsch_R, kabsch_t, kabsch_aux, gt_pose, step_loss);
     // K3: the MLP on the selected rows; the last block over all pairs (ticket) writes the loss scalars
     const int nblk = ceil_div(K, kRowsPerBlock);
     hipLaunchKernelGGL(head_mlp_kernel, dim3(nblk, B), dim3(256), 0, s, hs, ht, labels,
                        reinterpret_cast<const long long*>(top_idx), w1, b1, w2, b2, w3, b3, B, N, F, K, md, logits, a1_save, a2_save,
-                       W.pair_part, nblk, W.partC, W.nC, out_scalars, (int)flags, W.tickets + B);
+                       W.pair_part, nblk, W.partC, W.nC, out_scalars, (int)flags, W.tickets + B, step_loss);
     EQ_CHECK_LAUNCH("head_forward");
     return 0;
 }
@@ -823,7 +850,8 @@ extern "C" int equigspr_head_backward(const float* hs, const float* ht, const fl
                                       const int64_t* top_idx, const float* logits, const float* a1_save,
                                       const float* a2_save, const float* fin_scalars, const float* g_corr_sim,
                                       const float* g_equi, float* gw, const float* kabsch_aux, const float* grad_R,
-                                      const float* grad_t, int32_t B, int32_t N, int32_t F, int32_t K,
+                                      const float* grad_t, const float* kabsch_t, const float* g_step_loss,
+                                      int32_t B, int32_t N, int32_t F, int32_t K,
                                       int32_t flags, void* work /* the forward's */, float* dinp, float* mlp_slab, float* grad_mlp /* += */,
                                       float* ghs, float* ght, float* gxs /* += */, float* gxt /* += */, void* stream) {
     using namespace eq;
@@ -837,16 +865,18 @@ extern "C" int equigspr_head_backward(const float* hs, const float* ht, const fl
     const float* w2 = w1 + md.h1 * md.in + md.h1;
     const float* w3 = w2 + md.h2 * md.h1 + md.h2;
     const int nblk = ceil_div(K, kRowsPerBlock);
-    EQ_CHECK_ARG((kabsch_aux != nullptr) == (grad_R != nullptr) && (grad_R != nullptr) == (grad_t != nullptr), EQUIGSPR_EINVAL,
-                 "head_backward: kabsch_aux, grad_R, grad_t go together (all NULL: gw is an input)");
-    KabschBwdJob kj{xs, xt, wts, kabsch_aux, grad_R, grad_t, gxs, gxt, gw, W.tickets, grad_R ? kabsch_bwd_blocks(N) : 0};
+    EQ_CHECK_ARG((grad_R != nullptr) == (grad_t != nullptr), EQUIGSPR_EINVAL, "head_backward: grad_R and grad_t go together");
+    EQ_CHECK_ARG(!(grad_R || g_step_loss) || kabsch_aux, EQUIGSPR_EINVAL, "head_backward: grad_R / g_step_loss need kabsch_aux");
+    EQ_CHECK_ARG(!g_step_loss || kabsch_t, EQUIGSPR_EINVAL, "head_backward: g_step_loss needs kabsch_t");
+    KabschBwdJob kj{xs, xt, wts, kabsch_aux, grad_R, grad_t, g_step_loss, gt_pose, kabsch_t, gxs, gxt, gw, W.tickets,
+                    kabsch_aux ? kabsch_bwd_blocks(N) : 0};
     hipLaunchKernelGGL(head_pair_bwd_kernel, dim3(nblk + 1 + kj.nkb, B), dim3(256), 0, s, hs, ht, labels, sim, W.pair_f, gw,
                        reinterpret_cast<const long long*>(top_idx), logits, a1_save, a2_save, w1, w2, w3, g_corr_sim, B, N, F, K,
                        md, W.pair_g, dinp, mlp_slab, nblk, kj);
     const int msz = (int)equigspr_head_mlp_size(F);
     hipLaunchKernelGGL(head_node_bwd_kernel, dim3(W.nbp + ceil_div(msz, 32), B), dim3(256), 0, s, hs, ht, xs, xt, labels, gt_pose,
                        sim, rsim, cosv, pos, dinp, gw, W.pair_f, W.pair_g, fin_scalars, g_corr_sim, g_equi, B, N, F, K, md.in, ghs, ght,
-                       gxs, gxt, W.nbp, mlp_slab, B * nblk, msz, grad_mlp, (int)flags);
+                       gxs, gxt, W.nbp, mlp_slab, B * nblk, msz, grad_mlp, (int)flags, g_step_loss);
     EQ_CHECK_LAUNCH("head_backward");
     return 0;
 }

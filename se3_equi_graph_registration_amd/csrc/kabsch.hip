@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void kabsch_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ gR, const float* __restrict__ gt, int n,
                                                          float* __restrict__ gsrc, float* __restrict__ gtgt,
                                                          float* __restrict__ gw) {
-    kabsch_bwd_block(src, tgt, w, aux, gR, gt, n, gsrc, gtgt, gw, blockIdx.y, blockIdx.x, gridDim.x);
+    kabsch_bwd_block(src, tgt, w, aux, gR + (size_t)blockIdx.y * 9, gt + (size_t)blockIdx.y * 3, n, gsrc, gtgt, gw, blockIdx.y, blockIdx.x, gridDim.x);
 }
 
 }  // namespace eq

@@ -225,19 +225,19 @@ __device__ __forceinline__ void kabsch_solve_wave(int nb, float* __restrict__ Ro
 // closed form through the polar factor (finite for repeated singular values); grads w.r.t. the clouds and the weights.
 __device__ __forceinline__ void kabsch_bwd_block(const float* __restrict__ src, const float* __restrict__ tgt,
                                                  const float* __restrict__ w, const float* __restrict__ aux,
-                                                 const float* __restrict__ gR, const float* __restrict__ gt, int n,
+                                                 const float* gRb /* [9] of pair b */, const float* gtb /* [3] */, int n,
                                                  float* __restrict__ gsrc, float* __restrict__ gtgt, float* __restrict__ gw,
                                                  int b, int xb, int nxb) {
     __shared__ float sh[9 + 3 + 3];   // gH, g_cs, g_ct
     const float* ax = aux + (size_t)b * EQUIGSPR_KABSCH_AUX;
     if (threadIdx.x == 0) {
         double cs[3], U[9], st[3], R[9], G[9], g_cs[3], g_ct[3], gtv[3];
-        for (int a = 0; a < 3; ++a) { cs[a] = ax[a]; st[a] = ax[15 + a]; gtv[a] = gt[b * 3 + a]; }
+        for (int a = 0; a < 3; ++a) { cs[a] = ax[a]; st[a] = ax[15 + a]; gtv[a] = gtb[a]; }
         for (int i = 0; i < 9; ++i) { U[i] = ax[6 + i]; R[i] = ax[18 + i]; }
         for (int a = 0; a < 3; ++a) {
             g_ct[a] = gtv[a];
             g_cs[a] = -(R[0 * 3 + a] * gtv[0] + R[1 * 3 + a] * gtv[1] + R[2 * 3 + a] * gtv[2]);
-            for (int c = 0; c < 3; ++c) G[a * 3 + c] = (double)gR[b * 9 + a * 3 + c] - gtv[a] * cs[c];
+            for (int c = 0; c < 3; ++c) G[a * 3 + c] = (double)gRb[a * 3 + c] - gtv[a] * cs[c];
         }
         // M = U^T R^T G U
         double T1[9], T2[9], M[9];

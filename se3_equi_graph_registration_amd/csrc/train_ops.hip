@@ -5,30 +5,15 @@
 //               to four flat fp32 buckets in ONE launch; the step counter lives on the device so the whole
 //               optimizer step is hipGraph-capturable.
 #include "common.h"
+#include "pose_loss_device.h"
 
 namespace eq {
-
-// torch.clamp semantics: NaN propagates (fminf/fmaxf would turn it into a bound) -- e.g. the translation-direction cosine
-// of a zero translation (a pair without any valid correspondence gets R = I, t = 0, train :708-711) is NaN in the reference
-__device__ __forceinline__ float clamp_unit(float v) { return (v != v) ? v : fminf(fmaxf(v, -1.0f), 1.0f); }
 
 __global__ void pose_loss_fwd_kernel(const float* __restrict__ R, const float* __restrict__ t, const float* __restrict__ gt_pose,
                                      int B, float* __restrict__ rot_loss, float* __restrict__ trans_loss) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const float* Rb = R + (size_t)b * 9;
-    const float* G = gt_pose + (size_t)b * 16;
-    float tr = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) tr = fmaf(Rb[i * 3 + j], G[i * 4 + j], tr);          // trace(R^T R_gt)
-    rot_loss[b] = acosf(clamp_unit((tr - 1.0f) * 0.5f));
-    float dp = 0.0f, nt = 0.0f, ng = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { const float a = t[b * 3 + i], g = G[i * 4 + 3]; dp = fmaf(a, g, dp); nt = fmaf(a, a, nt); ng = fmaf(g, g, ng); }
-    const float c = dp / (sqrtf(nt) * sqrtf(ng));
-    trans_loss[b] = acosf(clamp_unit(c));
+    pose_loss_pair(R + (size_t)b * 9, t + (size_t)b * 3, gt_pose + (size_t)b * 16, rot_loss[b], trans_loss[b]);
 }
 
 __global__ void pose_loss_bwd_kernel(const float* __restrict__ R, const float* __restrict__ t, const float* __restrict__ gt_pose,
@@ -36,30 +21,8 @@ __global__ void pose_loss_bwd_kernel(const float* __restrict__ R, const float* _
                                      float* __restrict__ gR, float* __restrict__ gt) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const float* Rb = R + (size_t)b * 9;
-    const float* G = gt_pose + (size_t)b * 16;
-    float tr = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) tr = fmaf(Rb[i * 3 + j], G[i * 4 + j], tr);
-    const float x = (tr - 1.0f) * 0.5f;
-    // torch.clamp passes the gradient on [min, max] inclusive; acos'(x) = -1/sqrt(1-x^2) (the reference's singularity at x = 1)
-    const float dx = (x >= -1.0f && x <= 1.0f) ? -1.0f / sqrtf(1.0f - x * x) : 0.0f;
-    const float kr = (g_rot ? g_rot[b] : 0.0f) * dx * 0.5f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) gR[(size_t)b * 9 + i * 3 + j] = kr * G[i * 4 + j];
-    float dp = 0.0f, nt = 0.0f, ng = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { const float a = t[b * 3 + i], g = G[i * 4 + 3]; dp = fmaf(a, g, dp); nt = fmaf(a, a, nt); ng = fmaf(g, g, ng); }
-    const float lt = sqrtf(nt), lg = sqrtf(ng);
-    const float c = dp / (lt * lg);
-    const float dc = (c >= -1.0f && c <= 1.0f) ? -1.0f / sqrtf(1.0f - c * c) : 0.0f;
-    const float kt = (g_trans ? g_trans[b] : 0.0f) * dc;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) gt[b * 3 + i] = kt * (G[i * 4 + 3] / (lt * lg) - c * t[b * 3 + i] / nt);
+    pose_loss_grad_pair(R + (size_t)b * 9, t + (size_t)b * 3, gt_pose + (size_t)b * 16, g_rot ? g_rot[b] : 0.0f, g_trans ? g_trans[b] : 0.0f,
+                        gR + (size_t)b * 9, gt + (size_t)b * 3);
 }
 
 // Step loss of the training loop (train :1120): loss = corr_loss + mean_b(rot_loss) + mean_b(trans_loss) in ONE launch
@@ -68,31 +31,10 @@ __global__ __launch_bounds__(256) void step_loss_fwd_kernel(const float* __restr
                                                             const float* __restrict__ gt_pose, const float* __restrict__ closs, int B,
                                                             float* __restrict__ loss, float* __restrict__ rot_loss,
                                                             float* __restrict__ trans_loss) {
-    __shared__ float sr[256], st[256];
-    float ar = 0.0f, at = 0.0f;
-    for (int b = threadIdx.x; b < B; b += 256) {
-        const float* Rb = R + (size_t)b * 9;
-        const float* G = gt_pose + (size_t)b * 16;
-        float tr = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) tr = fmaf(Rb[i * 3 + j], G[i * 4 + j], tr);
-        const float rl = acosf(clamp_unit((tr - 1.0f) * 0.5f));
-        float dp = 0.0f, nt = 0.0f, ng = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) { const float a = t[b * 3 + i], g = G[i * 4 + 3]; dp = fmaf(a, g, dp); nt = fmaf(a, a, nt); ng = fmaf(g, g, ng); }
-        const float tl = acosf(clamp_unit(dp / (sqrtf(nt) * sqrtf(ng))));
-        rot_loss[b] = rl; trans_loss[b] = tl;
-        ar += rl; at += tl;
-    }
-    sr[threadIdx.x] = ar; st[threadIdx.x] = at;
+    for (int b = threadIdx.x; b < B; b += 256)
+        pose_loss_pair(R + (size_t)b * 9, t + (size_t)b * 3, gt_pose + (size_t)b * 16, rot_loss[b], trans_loss[b]);
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) { sr[threadIdx.x] += sr[threadIdx.x + off]; st[threadIdx.x] += st[threadIdx.x + off]; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) loss[0] = (closs ? closs[0] : 0.0f) + sr[0] / (float)B + st[0] / (float)B;
+    step_loss_sum(rot_loss, trans_loss, closs ? closs[0] : 0.0f, B, loss);
 }
 
 // d loss / d(R, t) = pose-loss gradients scaled by g/B (g = upstream scalar gradient, 1 when NULL)
@@ -101,29 +43,7 @@ __global__ void step_loss_bwd_kernel(const float* __restrict__ R, const float* _
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float up = (g ? g[0] : 1.0f) / (float)B;
-    const float* Rb = R + (size_t)b * 9;
-    const float* G = gt_pose + (size_t)b * 16;
-    float tr = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) tr = fmaf(Rb[i * 3 + j], G[i * 4 + j], tr);
-    const float x = (tr - 1.0f) * 0.5f;
-    const float dx = (x >= -1.0f && x <= 1.0f) ? -1.0f / sqrtf(1.0f - x * x) : 0.0f;
-    const float kr = up * dx * 0.5f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) gR[(size_t)b * 9 + i * 3 + j] = kr * G[i * 4 + j];
-    float dp = 0.0f, nt = 0.0f, ng = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { const float a = t[b * 3 + i], gg = G[i * 4 + 3]; dp = fmaf(a, gg, dp); nt = fmaf(a, a, nt); ng = fmaf(gg, gg, ng); }
-    const float lt = sqrtf(nt), lg = sqrtf(ng);
-    const float c = dp / (lt * lg);
-    const float dc = (c >= -1.0f && c <= 1.0f) ? -1.0f / sqrtf(1.0f - c * c) : 0.0f;
-    const float kt = up * dc;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) gt[b * 3 + i] = kt * (G[i * 4 + 3] / (lt * lg) - c * t[b * 3 + i] / nt);
+    pose_loss_grad_pair(R + (size_t)b * 9, t + (size_t)b * 3, gt_pose + (size_t)b * 16, up, up, gR + (size_t)b * 9, gt + (size_t)b * 3);
 }
 
 struct AdamBuckets {

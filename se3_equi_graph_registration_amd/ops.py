@@ -264,7 +264,9 @@ def weighted_kabsch(src: torch.Tensor, tgt: torch.Tensor, weights: torch.Tensor)
 # ----------------------------------------------------------------------------------- fused training head
 class _HeadFn(torch.autograd.Function):
     """equigspr_head_forward + equigspr_kabsch_forward, and their backwards, as one autograd node.
-    Outputs: R [B,3,3], t [B,3], corr_loss+sim_loss (scalar), equi loss (scalar), logits [B,K], top_idx [B,K]."""
+    Outputs: R [B,3,3], t [B,3], corr_loss+sim_loss (scalar), equi loss (scalar), logits [B,K], top_idx [B,K], and the training
+    loop's step loss (train :1117-1120) evaluated inside the head's launches: loss (scalar, differentiable), rot_loss [B],
+    trans_loss [B] (logging values)."""
 
     @staticmethod
     def forward(ctx, h_all, x_all, raw_hs, raw_ht, labels, gt_pose, topk, flags, *mlp_params):
@@ -312,29 +314,35 @@ class _HeadFn(torch.autograd.Function):
         R = torch.empty(B, 3, 3, **f32)
         t = torch.empty(B, 3, **f32)
         aux = torch.empty(B, KABSCH_AUX, **f32)
-        # the weighted Kabsch of (xs, xt, wts) rides in the head's last launch (moments, ticketed solve, loss scalars)
+        step = torch.empty(1 + 2 * B, **f32)
+        # the weighted Kabsch of (xs, xt, wts) rides in the head's second launch (weights -> ticket -> moments, solve); the step loss in the third
         _lib.check(L.equigspr_head_forward(_p(hs), _p(ht), _p(raw_hs), _p(raw_ht), _p(xs), _p(xt), _p(labels), _p(gt),
                                            _p(flat), B, N, Fd, raw_hs.shape[2], K, int(flags), _p(sim), _p(rsim), _p(cosv), _p(pos),
                                            _p(wts), _p(top_idx), _p(logits), _p(a1), _p(a2), _p(work), _p(fin),
-                                           _p(R), _p(t), _p(aux), _stream()), "head_forward")
-        ctx.save_for_backward(hs, ht, xs, xt, labels, gt, flat, sim, rsim, cosv, pos, wts, top_idx, logits, a1, a2, fin, aux, work)
+                                           _p(R), _p(t), _p(aux), _p(step), _stream()), "head_forward")
+        ctx.save_for_backward(hs, ht, xs, xt, labels, gt, flat, sim, rsim, cosv, pos, wts, top_idx, logits, a1, a2, fin, aux, work, t)
         ctx.dims = (B, N, Fd, K, msz)
         ctx.flags = int(flags)
         ctx.mlp_shapes = [tuple(q.shape) for q in mlp_params]
         ctx.mlp_params = list(mlp_params)
-        ctx.mark_non_differentiable(top_idx, logits)      # the logits' only consumer (BCE) is inside the head
+        rot_l, trans_l = step[1:1 + B], step[1 + B:]
+        ctx.mark_non_differentiable(top_idx, logits, rot_l, trans_l)      # the logits' only consumer (BCE) is inside the head
         ctx.set_materialize_grads(False)
-        return R, t, fin[0], fin[1], logits, top_idx
+        return R, t, fin[0], fin[1], logits, top_idx, step[0], rot_l, trans_l
 
     @staticmethod
-    def backward(ctx, gR, gt_, g_cs, g_eq, g_logits, _g_idx):
+    def backward(ctx, gR, gt_, g_cs, g_eq, g_logits, _g_idx, g_step, _g_rot, _g_trans):
         L = _lib.lib()
-        (hs, ht, xs, xt, labels, gt, flat, sim, rsim, cosv, pos, wts, top_idx, logits, a1, a2, fin, aux, work) = ctx.saved_tensors
+        (hs, ht, xs, xt, labels, gt, flat, sim, rsim, cosv, pos, wts, top_idx, logits, a1, a2, fin, aux, work, t_sv) = ctx.saved_tensors
         B, N, Fd, K, msz = ctx.dims
         dev = hs.device
         f32 = dict(dtype=torch.float32, device=dev)
-        gR = torch.zeros(B, 3, 3, **f32) if gR is None else gR.contiguous()
-        gt_ = torch.zeros(B, 3, **f32) if gt_ is None else gt_.contiguous()
+        if (gR is None) != (gt_ is None):               # the C entry takes both or neither (neither = zero)
+            gR = torch.zeros(B, 3, 3, **f32) if gR is None else gR
+            gt_ = torch.zeros(B, 3, **f32) if gt_ is None else gt_
+        gR = None if gR is None else gR.contiguous()
+        gt_ = None if gt_ is None else gt_.contiguous()
+        g_step = None if g_step is None else g_step.contiguous().float()
         gx_all = torch.empty(2 * B * N, 3, **f32)
         gxs, gxt, gw = gx_all[:B * N], gx_all[B * N:], torch.empty_like(wts)
         # the Kabsch backward (grad_R, grad_t -> coordinate / weight gradients) runs inside head_backward's first launch, beside the MLP
@@ -351,7 +359,7 @@ class _HeadFn(torch.autograd.Function):
         g_eq = None if g_eq is None else g_eq.contiguous().float()
         _lib.check(L.equigspr_head_backward(_p(hs), _p(ht), _p(xs), _p(xt), _p(labels), _p(gt), _p(flat), _p(sim), _p(rsim),
                                             _p(cosv), _p(pos), _p(wts), _p(top_idx), _p(logits), _p(a1), _p(a2), _p(fin),
-                                            _p(g_cs), _p(g_eq), _p(gw), _p(aux), _p(gR), _p(gt_), B, N, Fd, K, ctx.flags, _p(work), _p(dinp), _p(slab), _p(gmlp),
+                                            _p(g_cs), _p(g_eq), _p(gw), _p(aux), _p(gR), _p(gt_), _p(t_sv), _p(g_step), B, N, Fd, K, ctx.flags, _p(work), _p(dinp), _p(slab), _p(gmlp),
                                             _p(ghs), _p(ght), _p(gxs), _p(gxt), _stream()), "head_backward")
         if in_place is not None:
             return (gh_all, gx_all, None, None, None, None, None, None, *([None] * len(ctx.mlp_shapes)))

@@ -44,10 +44,14 @@ def pose_loss(pred_rot, pred_translation, gt_pose, delta=1.5):
 
 
 def registration_loss(pred_rot, pred_translation, corr_loss, gt_pose):
-    """The training loop's scalar loss ``corr_loss.mean() + rot_loss.mean() + trans_loss.mean()`` (train :1117-1120) as ONE
-    HIP launch each way; returns ``(loss, rot_loss [B], trans_loss [B])`` (the per-pair terms are for logging)."""
+    """The training loop's scalar loss ``corr_loss.mean() + rot_loss.mean() + trans_loss.mean()`` (train :1117-1120); returns
+    ``(loss, rot_loss [B], trans_loss [B])`` (the per-pair terms are for logging).  Called on the very outputs of the fused
+    training head it costs no launch (the head evaluated it, csrc/head.hip); on any other tensors ONE HIP launch each way."""
     if not pred_rot.is_cuda:
         raise RuntimeError("registration_loss: tensors must live on the GPU (this package has no CPU path)")
+    st = getattr(pred_rot, "_equigspr_step", None)
+    if st is not None and st[0] is pred_translation and st[1] is corr_loss and st[2] is gt_pose:
+        return st[3], st[4], st[5]            # evaluated inside the fused head's launches (one autograd node with the head)
     return ops.fused_step_loss(pred_rot.float(), pred_translation.float(), corr_loss, gt_pose)
 
 
@@ -153,10 +157,12 @@ class CrossAttentionPoseRegression(nn.Module):
                           self.mlp[4].weight, self.mlp[4].bias]
             h_o, x_o = self._egnn_out
             self._egnn_out = None
-            R, t, closs, total_loss, logits, top_idx = ops.fused_pose_head(h_o, x_o, raw_h_src, raw_h_tgt, labels,
-                                                                           gt_pose, self.topk, mlp_params,
-                                                                           flags=ops.HEAD_NO_SIM_LOSS if kitti else 0)
+            R, t, closs, total_loss, logits, top_idx, step, rot_l, trans_l = ops.fused_pose_head(
+                h_o, x_o, raw_h_src, raw_h_tgt, labels, gt_pose, self.topk, mlp_params, flags=ops.HEAD_NO_SIM_LOSS if kitti else 0)
             self.last_logits, self.last_top_idx = logits.detach(), top_idx
+            # the head's launches also evaluated the training loop's scalar loss for exactly these outputs (train :1117-1120);
+            # registration_loss(R, t, closs, gt_pose) hands it out instead of launching its own kernels
+            R._equigspr_step = (t, closs, gt_pose, step, rot_l, trans_l)
             return R, t, closs, total_loss, hs, xs, ht, xt, labels
         total_loss = egnn_equi_loss(hs, xs, ht, xt, gt_pose[:, :3, :3], gt_pose[:, :3, -1], labels)       # :677
         sim = torch.sum(hs * ht, dim=-1, keepdim=True)                                                     # :681

@@ -569,6 +569,35 @@ def test_fused_pose_loss_matches_aten(pk):
     assert torch.allclose(ref["cuda"][0], o_rl, rtol=2e-4, atol=2e-5) and torch.allclose(ref["cuda"][1], o_tl, rtol=2e-4, atol=2e-5)
 
 
+def test_step_loss_inside_head_equals_standalone_step_loss(pk, golden_dir):
+    """registration_loss on the fused head's own outputs is served by the head's launches (csrc/head.hip: per-pair terms by the
+    block that solves the pair, the sum by the MLP launch's last block; backward: the pose terms join grad_R / grad_t inside
+    the Kabsch-backward blocks, the corr/sim term joins g_corr_sim).  Same value and same parameter gradients as the
+    stand-alone step-loss kernels on the same tensors, for an upstream gradient != 1."""
+    from se3_equi_graph_registration_amd import ops
+    fx = np.load(os.path.join(golden_dir, "pair_n512_k12_l2_wellcond.npz"))
+    res = []
+    for inside in (True, False):
+        mt = _pair_models(pk, fx)["train"]
+        args = _pair_inputs(pk, fx)
+        out = mt(*args)
+        gt = args[-1]
+        if inside:
+            loss, rl, tl = pk.registration_loss(out[0], out[1], out[2], gt)
+            assert loss.grad_fn is out[0].grad_fn                         # one autograd node with the head: no launch of its own
+        else:
+            loss, rl, tl = ops.fused_step_loss(out[0].float(), out[1].float(), out[2], gt)
+        mt.zero_grad()
+        (loss * 0.7).backward()
+        res.append((loss.detach().clone(), rl.detach().clone(), tl.detach().clone(), mt.egnn.flat_grads.clone(),
+                    torch.cat([p.grad.reshape(-1) for p in mt.mlp.parameters()])))
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for u, v in zip(a[3:], b[3:]):
+        scale = float(v.abs().max())
+        assert float((u - v).abs().max()) <= 1e-5 * scale + 1e-9
+
+
 def test_registration_loss_matches_unfused(pk):
     """train :1120 as one launch: value and gradients equal corr.mean() + pose_loss means through autograd; CPU tensors raise."""
     g = torch.Generator().manual_seed(9)
