@@ -2,18 +2,21 @@
 // EGNN (src/3dmatch_train_egnn_with_batch.py:677-796) and its backward, as a handful of kernels instead
 // of ~220 small ATen launches:
 //   head_node_kernel   per node: sim = <h_s,h_t> (:681), raw_sim (:682), the two egnn_equi_loss terms
-//                      (:860-893); per-block fp64 partial sums for the batch-wide mean/std (:777-778)
-//   head_pair_kernel   per pair (one workgroup): masked softmax weights (:717-724), top-k by a full
-//                      bitonic sort in LDS (:684), gather + 3-layer MLP logits (:760-770), BCE (:772),
-//                      similarity-MSE partials (:777-781)
-//   head_mlp_kernel    the MLP on the top-k rows; the per-node Kabsch-weight blocks (head_weights_block) ride in
-//                      the same launch as extra grid columns (both depend only on head_pair_kernel)
-//   head_tail_kernel   Kabsch moments of the weighted clouds, the 3x3 SVD solve by the last block of each pair (ticket), and
-//                      the loss scalars (corr_loss + sim_loss, equi loss) in one launch; without Kabsch outputs the scalars
-//                      alone (head_finalize_kernel) and equigspr_kabsch_forward gives R, t from the weights
-//   backward: head_pair_bwd_kernel (softmax / BCE / MLP backward, MLP weight-gradient slabs),
+//                      (:860-893); per-block fp64 partial sums for the batch-wide mean/std (:777-778); zeroes the tickets
+//   head_pair_kernel   grid (1 + ceil(N/256), B).  Every block evaluates the batch statistics and its pair's masked-softmax
+//                      scalars (:717-724) from the K1 partials itself, so the two chains below need nothing from each other:
+//                        column 0: top-k (:684) by MSB radix select (early exit) + rank by counting in LDS;
+//                        columns 1..: Kabsch weights (:718-724) + similarity-MSE partials (:777-781) of 256 nodes each; the
+//                        block that finishes a pair's weights last (ticket) computes the Kabsch moments, solves the 3x3
+//                        problem (:726-758) and evaluates the pair's pose-loss terms (:896-962)
+//   head_mlp_kernel    the MLP on the top-k rows (:760-770) + BCE (:772), 8 rows per block; the block that finishes last over
+//                      all pairs (ticket) writes the loss scalars (corr_loss + sim_loss, equi loss) and the training loop's
+//                      step loss (:1117-1120)
+//   backward: head_pair_bwd_kernel (BCE / MLP backward + MLP weight-gradient slabs; beside them, as extra grid columns, the
+//             Kabsch backward with the step loss's pose gradient folded in -> ticket -> gwu for the softmax backward),
 //             head_node_bwd_kernel (d h_s, d h_t, d x_s, d x_t; extra grid columns sum the MLP slabs into the grads, +=)
-// (Independent small jobs share a launch as extra grid columns.)
+// Launch structure: independent jobs share a launch as extra grid columns; a many -> one dependency inside a launch is a ticket
+// (release fence + device-scope atomic; the last block continues behind an acquire fence; the counter is handed back as zero).
 // Layouts: h_* [B,N,F] with row stride F; x_* [B,N,3]; labels [B,N] (float 0/1); gt_pose [B,16].
 #include "common.h"
 #include "kabsch_device.h"
