@@ -27,6 +27,9 @@ constexpr int kEdgeBwdBlocks = 1024;  // max slab count of the edge kernel
 #ifndef EQ_NODE_BWD16
 #define EQ_NODE_BWD16 1
 #endif
+#ifndef EQ_EMBED_FUSE
+#define EQ_EMBED_FUSE 1               // per-feature path: embedding backward kernels folded into their neighbouring node kernels
+#endif
 #ifndef EQ_NODE_BWD16_MIN
 #define EQ_NODE_BWD16_MIN 16384
 #endif
@@ -251,12 +254,19 @@ __global__ __launch_bounds__(256) void embed_in_bwd_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------
 // node-MLP backward (+ re-projection of P for the edge recompute)
 // ---------------------------------------------------------------------------------------
-template <int F, int H, int A>
+// kEO (hidden_nf == out_nf == 32, the last layer's launch): the embedding_out backward rides in this kernel instead of its own
+// launch before it -- G_h = gh_out W_out per node straight into this kernel's G_h, G_x = gx_out, dW_out / db_out partials by
+// the wave that only had the bias sums (same outer-product order as embed_out_bwd_kernel: bitwise the same gradients).
+struct EmbedOutJob {
+    const float* w_out; const float* gh_out; const float* gx_out; const float* hL;
+    float* Gx; float* slab;
+};
+template <int F, int H, int A, bool kEO = false>
 __global__ __launch_bounds__(256, 3) void node_bwd_kernel(const float* __restrict__ lw, const float* __restrict__ Gh,
                                                        const float* __restrict__ h, const float* __restrict__ agg,
                                                        int n_nodes, float* __restrict__ dh_part,
                                                        float* __restrict__ dagg, float* __restrict__ P,
-                                                       float* __restrict__ slab) {
+                                                       float* __restrict__ slab, EmbedOutJob eo) {
     using LL = LP<F, H, A>;
     using SB = Slabs<F>;
     constexpr int FP = Geom<F>::FP, G = Geom<F>::G, NS = Geom<F>::NS, PS = Geom<F>::PS;
@@ -266,11 +276,15 @@ __global__ __launch_bounds__(256, 3) void node_bwd_kernel(const float* __restric
     __shared__ float dvv[NS][FP];
     __shared__ float wts[4 * F * (F + 1)];      // W4^T | W_src^T | W_tgt^T  (transposed, odd stride)
     __shared__ float w45[3 * F * F];            // W4 | W5 row-major (column reads are lane-consecutive)
+    __shared__ float eo_gho[kEO ? NS : 1][kEO ? 32 : 1];      // gh_out rows of the group
+    __shared__ float eo_hl[kEO ? NS : 1][kEO ? 32 : 1];       // h_L rows of the group
+    __shared__ float eo_w[kEO ? 32 * 32 : 1];                  // W_out [out][F]
     float* W4T = wts;
     float* WaT = wts + 2 * F * (F + 1);
     float* WbT = WaT + F * (F + 1);
     const int slot = threadIdx.x / G, f = threadIdx.x % G;
     EQ_STAMPK(1, 0);
+    if constexpr (kEO) stage_copy(eo_w, eo.w_out, 32 * 32);
     {   // all five matrices' loads in flight together, then the LDS stores
         const MapT<F> m4{2 * F, 2 * F};
         const MapW1T<F, H, A> ma{0}, mb{F};
@@ -311,13 +325,27 @@ __global__ __launch_bounds__(256, 3) void node_bwd_kernel(const float* __restric
     }
     if constexpr (F == 32 || F == 33) mo.init();
     else { aW4.init(); aW5.init(); ab4.init(); ab5.init(); }
+    MfmaOuter moE;                                   // kEO: wave 3 = dW_out
+    float mbo = 0.0f;                                // kEO: wave 2, lanes 32.. = db_out
+    if constexpr (kEO) moE.init();
     const int groups = (n_nodes + NS - 1) / NS;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int j = grp * NS + slot;
         const bool act = (j < n_nodes) && (f < F);
         float g = 0.0f, v = 0.0f;
         __syncthreads();
+        if constexpr (kEO) {
+            if (act) {
+                eo_gho[slot][f] = eo.gh_out[(size_t)j * 32 + f];
+                eo_hl[slot][f] = eo.hL[(size_t)j * FP + f];
+                if (f < 3) eo.Gx[(size_t)j * 4 + f] = eo.gx_out[(size_t)j * 3 + f];
+            }
+            __syncthreads();
+        }
         if (act) {
+            if constexpr (kEO) {
+                for (int o = 0; o < 32; ++o) g = fmaf(eo_gho[slot][o], eo_w[o * F + f], g);
+            } else
             g = Gh[(size_t)j * FP + f];
             vin[slot][f] = h[(size_t)j * FP + f];
             vin[slot][F + f] = agg[(size_t)j * FP + f];
@@ -356,6 +384,14 @@ __global__ __launch_bounds__(256, 3) void node_bwd_kernel(const float* __restric
                 for (int n = 0; n < NS; ++n)
                     if (n < ns) { mb4 += (lane < 32) ? dvv[n][lane & 31] : 0.0f; mb5 += (lane >= 32) ? ghv[n][lane & 31] : 0.0f; }
             }
+            if constexpr (kEO) {
+                if (wv == 3) moE.add(&eo_gho[0][0], 32, &eo_hl[0][0], 32, ns, lane);
+                else if (wv == 2 && lane >= 32) {
+#pragma unroll
+                    for (int n = 0; n < NS; ++n)
+                        if (n < ns) mbo += eo_gho[n][lane & 31];
+                }
+            }
             if constexpr (F == 33) {
                 if (lo_x >= 0) {
 #pragma unroll
@@ -382,6 +418,11 @@ __global__ __launch_bounds__(256, 3) void node_bwd_kernel(const float* __restric
         else if (wv == 2) mo.store(my + F * 2 * F + F, F, lane);
         else if (lane < 32) my[F * 2 * F + lane] = mb4;
         else my[F * 2 * F + F + F * F + (lane - 32)] = mb5;
+        if constexpr (kEO) {
+            float* me = eo.slab + (size_t)blockIdx.x * (32 * F + 32);
+            if (wv == 3) moE.store(me, F, lane);
+            else if (wv == 2 && lane >= 32) me[32 * F + (lane - 32)] = mbo;
+        }
         if constexpr (F == 33) {
             if (lo_x >= 0) my[lo_dst] = lo_acc;
             if (wv == 3 && lane == 0) { my[F * 2 * F + 32] = mb4b; my[F * 2 * F + F + F * F + 32] = mb5b; }
@@ -398,7 +439,14 @@ __global__ __launch_bounds__(256, 3) void node_bwd_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------
 // gather backward: dP_r, dP_c, dx through the inverse indices
 // ---------------------------------------------------------------------------------------
-template <int F, int H, int A>
+// kEI (hidden_nf == in_nf == 32, layer 0's launch): the embedding_in backward rides in this kernel instead of its own launch
+// behind it -- dW_in / db_in partials from the G_h this kernel has just produced (same outer-product order as embed_in_bwd_kernel),
+// optionally grad_h_in = G_h W_in.
+struct EmbedInJob {
+    const float* w_in; const float* h_in;
+    float* grad_h_in; float* slab;
+};
+template <int F, int H, int A, bool kEI = false>
 __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict__ lw, const int* __restrict__ rptr,
                                                          const int* __restrict__ rperm, const int* __restrict__ cptr,
                                                          const int* __restrict__ cperm, const float* __restrict__ dt1,
@@ -406,7 +454,7 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ dh_part, const float* __restrict__ Gx,
                                                          const float* __restrict__ h, int n_nodes,
                                                          float* __restrict__ Gh_new, float* __restrict__ Gx_new,
-                                                         float* __restrict__ gx_out3, float* __restrict__ slab) {
+                                                         float* __restrict__ gx_out3, float* __restrict__ slab, EmbedInJob ei) {
     using LL = LP<F, H, A>;
     using SB = Slabs<F>;
     constexpr int FP = Geom<F>::FP, G = Geom<F>::G, NS = Geom<F>::NS;
@@ -414,8 +462,14 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
     __shared__ float prv[NS][FP];
     __shared__ float pcv[NS][FP];
     __shared__ float w1[F * 2 * F];             // W1[:, 0:2F] row-major [o][2F]
+    __shared__ float ei_gv[kEI ? NS : 1][kEI ? 32 : 1];      // G_h rows of the group
+    __shared__ float ei_in[kEI ? NS : 1][kEI ? 32 : 1];      // h_in rows of the group
+    __shared__ float ei_w[kEI ? 32 * 32 : 1];                 // W_in [F][in]
     const int slot = threadIdx.x / G, f = threadIdx.x % G;
     EQ_STAMPK(2, 0);
+    if constexpr (kEI) {
+        if (ei.grad_h_in) stage_copy(ei_w, ei.w_in, 32 * 32);
+    }
     stage_batched<F * 2 * F>(w1, lw, F * 2 * F, [](int t) { const int o = t / (2 * F); return LL::w1_off(o, t - o * 2 * F); },
                              [](int t) { return t; });
     EQ_STAMPK(2, 1);
@@ -426,6 +480,9 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if constexpr (F == 32) mo.init();
     else { aWa.init(); aWb.init(); ab1.init(); }
+    MfmaOuter moI;                                  // kEI: wave 3 = dW_in
+    float mbi = 0.0f;                               // kEI: wave 2, lanes 32.. = db_in
+    if constexpr (kEI) moI.init();
     const int groups = (n_nodes + NS - 1) / NS;
     for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
         const int j = grp * NS + slot;
@@ -433,6 +490,9 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
         const bool act = live && f < F;
         float dpr = 0.0f, dpc = 0.0f;
         __syncthreads();
+        if constexpr (kEI) {
+            if (act) ei_in[slot][f] = ei.h_in[(size_t)j * 32 + f];
+        }
         if (live) {
             const int rlo = rptr[j], rhi = rptr[j + 1], clo = cptr[j], chi = cptr[j + 1];
             float gx = (f < 3) ? Gx[(size_t)j * 4 + f] : 0.0f;
@@ -458,10 +518,25 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
                 gh = fmaf(prv[slot][o], w1[o * 2 * F + f], gh);
                 gh = fmaf(pcv[slot][o], w1[o * 2 * F + F + f], gh);
             }
-            Gh_new[(size_t)j * FP + f] = gh;
+            if constexpr (kEI) ei_gv[slot][f] = gh;
+            else Gh_new[(size_t)j * FP + f] = gh;
         }
         const int ns = min(NS, n_nodes - grp * NS);
         EQ_STAMPK(2, 3);
+        if constexpr (kEI) {
+            __syncthreads();
+            if (act && ei.grad_h_in) {
+                float a_ = 0.0f;
+                for (int o = 0; o < 32; ++o) a_ = fmaf(ei_gv[slot][o], ei_w[o * 32 + f], a_);
+                ei.grad_h_in[(size_t)j * 32 + f] = a_;
+            }
+            if (wv == 3) moI.add(&ei_gv[0][0], 32, &ei_in[0][0], 32, ns, lane);
+            else if (wv == 2 && lane >= 32) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    if (n < ns) mbi += ei_gv[n][lane & 31];
+            }
+        }
         if constexpr (F == 32) {
             if (wv == 0) mo.add(&prv[0][0], FP, &hv[0][0], FP, ns, lane);
             else if (wv == 1) mo.add(&pcv[0][0], FP, &hv[0][0], FP, ns, lane);
@@ -481,6 +556,11 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float* __restrict
     if constexpr (F == 32) {
         if (wv < 2) mo.store(my + wv * F * F, F, lane);
         else if (wv == 2 && lane < 32) my[2 * F * F + lane] = mb1;
+        if constexpr (kEI) {
+            float* me = ei.slab + (size_t)blockIdx.x * (F * 32 + F);
+            if (wv == 3) moI.store(me, 32, lane);
+            else if (wv == 2 && lane >= 32) me[F * 32 + (lane - 32)] = mbi;
+        }
     } else {
         aWa.store(my, F, F);
         aWb.store(my + F * F, F, F);
@@ -1135,19 +1215,31 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
     int cur = 0;
     float* Gh = work + B.Gh[cur];
     float* Gx = work + B.Gx[cur];
-    // embedding_out
-    hipLaunchKernelGGL((embed_out_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_out, cfg->out_nf, gh_out,
-                       gx_out, hs + (size_t)L * N * FP, N, Gh, Gx, work + B.emb_slab);
-    auto slab_of = [&](int l) { return (size_t)l * B.layer_stride; };
-    float* const Pbuf = work + B.P;                        // the projection rows of layer l, re-made by the node backward for the edge recompute
-    auto launch_node_bwd = [&](int l) {
-        hipLaunchKernelGGL((node_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, params + ML.layer0 + (size_t)l * ML.layer_size,
-                           work + B.Gh[cur], hs + (size_t)l * N * FP, aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg,
-                           Pbuf, work + B.node_slab + slab_of(l));
-    };
     // the 16-node MFMA kernels of egnn_node_bwd.hip: hidden_nf 33 always; hidden_nf 32 from EQ_NODE_BWD16_MIN nodes on (one
     // 2 048-point pair: 18.4 us against 15.3 us for the per-feature kernel; 16 pairs: 121 against 142 us)
     const bool k16 = F == 33 || (EQ_NODE_BWD16 != 0 && N > EQ_NODE_BWD16_MIN);
+    // embedding_out: its own launch, or (per-feature kernels, hidden_nf == out_nf == 32) inside the last layer's node backward
+    const bool eo_fused = EQ_EMBED_FUSE != 0 && !k16 && F == 32 && cfg->out_nf == 32;
+    const bool ei_fused = EQ_EMBED_FUSE != 0 && !k16 && F == 32 && cfg->in_nf == 32;       // embedding_in: inside layer 0's gather backward
+    if (!eo_fused)
+        hipLaunchKernelGGL((embed_out_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_out, cfg->out_nf, gh_out,
+                           gx_out, hs + (size_t)L * N * FP, N, Gh, Gx, work + B.emb_slab);
+    auto slab_of = [&](int l) { return (size_t)l * B.layer_stride; };
+    float* const Pbuf = work + B.P;                        // the projection rows of layer l, re-made by the node backward for the edge recompute
+    auto launch_node_bwd = [&](int l) {
+        if constexpr (F == 32) {
+            if (eo_fused && l == L - 1) {
+                const EmbedOutJob eo{params + ML.w_out, gh_out, gx_out, hs + (size_t)L * N * FP, Gx, work + B.emb_slab};
+                hipLaunchKernelGGL((node_bwd_kernel<F, H, A, true>), dim3(ngrid), dim3(256), 0, s, params + ML.layer0 + (size_t)l * ML.layer_size,
+                                   work + B.Gh[cur], hs + (size_t)l * N * FP, aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg,
+                                   Pbuf, work + B.node_slab + slab_of(l), eo);
+                return;
+            }
+        }
+        hipLaunchKernelGGL((node_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, params + ML.layer0 + (size_t)l * ML.layer_size,
+                           work + B.Gh[cur], hs + (size_t)l * N * FP, aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg,
+                           Pbuf, work + B.node_slab + slab_of(l), EmbedOutJob{});
+    };
     constexpr bool kFuse = (F == 32);                      // per-feature kernels: gather_bwd(l) + node_bwd(l-1) in one kernel
     int nslab = ngrid;                                     // slab copies per layer of the node-level kernels
     NodeBwd16Args na{};
@@ -1197,14 +1289,23 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
                 continue;
             }
         }
-        if constexpr (F == 32)          // (hidden_nf 33 always takes the 16-node kernels above: its dt1 rows are split, see edge_bwd16_kernel)
-            hipLaunchKernelGGL((gather_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, g->rptr, g->rperm, g->cptr,
-                               g->cperm, work + B.dt1, work + B.gxr, work + B.gxc, work + B.dh_part, work + B.Gx[cur], h_l, N,
-                               work + B.Gh[nxt], work + B.Gx[nxt], (l == 0) ? grad_x_in : nullptr, work + B.gat_slab + slab_of(l));
+        if constexpr (F == 32) {        // (hidden_nf 33 always takes the 16-node kernels above: its dt1 rows are split, see edge_bwd16_kernel)
+            if (ei_fused && l == 0) {
+                const EmbedInJob ei{params + ML.w_in, h_in, grad_h_in, work + B.emb_slab2};
+                hipLaunchKernelGGL((gather_bwd_kernel<F, H, A, true>), dim3(ngrid), dim3(256), 0, s, lw, g->rptr, g->rperm, g->cptr,
+                                   g->cperm, work + B.dt1, work + B.gxr, work + B.gxc, work + B.dh_part, work + B.Gx[cur], h_l, N,
+                                   work + B.Gh[nxt], work + B.Gx[nxt], grad_x_in, work + B.gat_slab + slab_of(l), ei);
+            } else
+                hipLaunchKernelGGL((gather_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, g->rptr, g->rperm, g->cptr,
+                                   g->cperm, work + B.dt1, work + B.gxr, work + B.gxc, work + B.dh_part, work + B.Gx[cur], h_l, N,
+                                   work + B.Gh[nxt], work + B.Gx[nxt], (l == 0) ? grad_x_in : nullptr, work + B.gat_slab + slab_of(l),
+                                   EmbedInJob{});
+        }
         cur = nxt;
     }
-    hipLaunchKernelGGL((embed_in_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_in, cfg->in_nf,
-                       work + B.Gh[cur], h_in, N, grad_h_in, work + B.emb_slab2);
+    if (!ei_fused)
+        hipLaunchKernelGGL((embed_in_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_in, cfg->in_nf,
+                           work + B.Gh[cur], h_in, N, grad_h_in, work + B.emb_slab2);
     // all slab reductions at the end in ONE launch: grid rows 0..L-1 = the layers, row L = the two embeddings
     {
         const int n_out = cfg->out_nf * F + cfg->out_nf, n_in = F * cfg->in_nf + F;
@@ -1241,7 +1342,7 @@ static int time_edge_bwd_impl(const equigspr_egnn_config* cfg, const float* para
     (void)hipMemsetAsync(work + B.Gx[0], 0, sizeof(float) * (size_t)N * 4, s);
     hipLaunchKernelGGL((node_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, hs + (size_t)L * N * FP,
                        hs + (size_t)l * N * FP, aggs + (size_t)l * N * FP, N, work + B.dh_part, work + B.dagg, work + B.P,
-                       work + B.node_slab);
+                       work + B.node_slab, EmbedOutJob{});
     auto launch = [&]() {
         (void)launch_edge_bwd<F, H, A>(lw, g, edge_attr, xs + (size_t)l * N * 3, work + B.P, work + B.dagg, work + B.Gx[0],
                                        work + B.dt1, work + B.gxr, work + B.gxc, work + B.edge_slab, cfg->edge_basis, s, &egrid);
