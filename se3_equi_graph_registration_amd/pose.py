@@ -7,10 +7,12 @@
 MI355X-first differences (results unchanged):
   * all 2B clouds of a step go through ONE batched EGNN launch sequence instead of the
     reference's Python loop of 2B ``self.egnn`` calls (:645-669);
-  * the per-sample SVD loop (:702-758) is one batched Kabsch kernel; label masking is done
-    by zero weights, the ``det<0`` branch is a device-side select (no host sync).
-The small dense head (top-k, 3-layer MLP, BCE, similarity MSE) stays in PyTorch-ROCm ops on
-device tensors (negligible cost).
+  * everything after the EGNN -- similarities, batch statistics, masked-softmax weights, the per-sample SVD loop (:702-758) as a
+    batched weighted Kabsch (label masking by zero weights, the ``det<0`` branch a device-side select: no host sync), top-k,
+    the 3-layer MLP + BCE, similarity MSE, the equi loss and the training loop's scalar loss (:1117-1120) -- is the fused HIP
+    head of csrc/head.hip: 3 launches forward, 2 backward (``fused_head=True``, hidden width <= 64, N <= 8192);
+  * ``fused_head=False`` keeps the same head as PyTorch-ROCm ops on device tensors (the comparison path of the parity tests;
+    ~230 launches).
 """
 from __future__ import annotations
 
