@@ -1221,7 +1221,9 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
     // embedding_out: its own launch, or (per-feature kernels, hidden_nf == out_nf == 32) inside the last layer's node backward
     const bool eo_fused = EQ_EMBED_FUSE != 0 && !k16 && F == 32 && cfg->out_nf == 32;
     const bool ei_fused = EQ_EMBED_FUSE != 0 && !k16 && F == 32 && cfg->in_nf == 32;       // embedding_in: inside layer 0's gather backward
-    if (!eo_fused)
+    // ... and on the 16-node path (hidden_nf == in_nf / out_nf, 32 or 33) inside the first / last node_bwd16 launch
+    const bool eo16 = EQ_EMBED_FUSE != 0 && k16 && cfg->out_nf == F, ei16 = EQ_EMBED_FUSE != 0 && k16 && cfg->in_nf == F;
+    if (!eo_fused && !eo16)
         hipLaunchKernelGGL((embed_out_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_out, cfg->out_nf, gh_out,
                            gx_out, hs + (size_t)L * N * FP, N, Gh, Gx, work + B.emb_slab);
     auto slab_of = [&](int l) { return (size_t)l * B.layer_stride; };
@@ -1254,7 +1256,11 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
     if (k16) {
         node_part(L - 1);
         na.Gh_in = work + B.Gh[cur];
-        const int rc = launch_node_bwd16(F, H, A, kNodeBwdNode, na, s, &nslab);
+        if (eo16) {
+            na.w_out = params + ML.w_out; na.gh_out = gh_out; na.gx_out = gx_out; na.hL = hs + (size_t)L * N * FP;
+            na.Gx_new = Gx; na.emb_slab = work + B.emb_slab;
+        }
+        const int rc = launch_node_bwd16(F, H, A, kNodeBwdNode | (eo16 ? kNodeBwdEmbed : 0), na, s, &nslab);
         if (rc) return rc;
     } else if (kFuse) launch_node_bwd(L - 1);
     for (int l = L - 1; l >= 0; --l) {
@@ -1274,7 +1280,8 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
             na.gx_out3 = (l == 0) ? grad_x_in : nullptr;
             na.Gh_out = work + B.Gh[nxt];
             if (l > 0) node_part(l - 1);
-            const int rc = launch_node_bwd16(F, H, A, l > 0 ? (kNodeBwdGather | kNodeBwdNode) : kNodeBwdGather, na, s, &nslab);
+            if (l == 0 && ei16) { na.w_in = params + ML.w_in; na.h_in = h_in; na.grad_h_in = grad_h_in; na.emb_slab = work + B.emb_slab2; }
+            const int rc = launch_node_bwd16(F, H, A, l > 0 ? (kNodeBwdGather | kNodeBwdNode) : (kNodeBwdGather | (ei16 ? kNodeBwdEmbed : 0)), na, s, &nslab);
             if (rc) return rc;
             cur = nxt;
             continue;
@@ -1303,14 +1310,14 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
         }
         cur = nxt;
     }
-    if (!ei_fused)
+    if (!ei_fused && !ei16)
         hipLaunchKernelGGL((embed_in_bwd_kernel<F>), dim3(ngrid), dim3(256), 0, s, params + ML.w_in, cfg->in_nf,
                            work + B.Gh[cur], h_in, N, grad_h_in, work + B.emb_slab2);
     // all slab reductions at the end in ONE launch: grid rows 0..L-1 = the layers, row L = the two embeddings
     {
         const int n_out = cfg->out_nf * F + cfg->out_nf, n_in = F * cfg->in_nf + F;
-        const PlainJobs pj{work + B.emb_slab, ngrid, n_out, grad_params + ML.w_out, ceil_div(n_out, 32),
-                           work + B.emb_slab2, ngrid, n_in, grad_params + ML.w_in};
+        const PlainJobs pj{work + B.emb_slab, eo16 ? nslab : ngrid, n_out, grad_params + ML.w_out, ceil_div(n_out, 32),
+                           work + B.emb_slab2, ei16 ? nslab : ngrid, n_in, grad_params + ML.w_in};      // (the 16-node launches write their own slab count)
         const int gx_layer = ceil_div(ML.layer_size, 32), gx_plain = ceil_div(n_out, 32) + ceil_div(n_in, 32);
         hipLaunchKernelGGL((layer_grad_reduce_kernel<F, H, A>), dim3(gx_layer > gx_plain ? gx_layer : gx_plain, L + 1), dim3(256), 0, s,
                            work + B.node_slab, nslab, work + B.edge_slab, E > 0 ? egrid : 0, work + B.gat_slab, nslab,

@@ -82,8 +82,14 @@ struct NodeBwd16Args {
     int n_nodes, n_edges;
     float* dh_part; float* dagg; float* P; float* Gx_new; float* gx_out3; float* Gh_out;
     float* gat_slab; float* node_slab;
+    // kNodeBwdEmbed (hidden_nf == in_nf == out_nf): with the node-only launch the embedding_out backward (w_out, gh_out [N][F], gx_out
+    // [N][3], hL = the last layer's output rows; G_x goes to Gx_new), with the gather-only launch the embedding_in backward (w_in,
+    // h_in [N][F], grad_h_in [N][F] or NULL); emb_slab = that embedding's slab set
+    const float* w_out; const float* gh_out; const float* gx_out; const float* hL;
+    const float* w_in; const float* h_in; float* grad_h_in;
+    float* emb_slab;
 };
-enum { kNodeBwdGather = 1, kNodeBwdNode = 2 };
+enum { kNodeBwdGather = 1, kNodeBwdNode = 2, kNodeBwdEmbed = 4 };
 // launches the kernel for (hidden_nf F, heads H, edge attributes A); *n_slabs = slab copies written (per slab kind)
 int launch_node_bwd16(int F, int H, int A, int mode, const NodeBwd16Args& args, hipStream_t s, int* n_slabs);
 int node_bwd16_max_slabs(int n_nodes);

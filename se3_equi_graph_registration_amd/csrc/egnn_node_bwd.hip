@@ -25,20 +25,29 @@ namespace eq {
 #ifndef EQ_NB16_OCC
 #define EQ_NB16_OCC 1                // waves per SIMD the register allocation is held to
 #endif
-template <int H, int A, int kB, bool kG, bool kN, int NW, int NPT, int D>
+// kE: the embedding backward rides along (hidden_nf == in_nf == out_nf).  Node-only launch (the backward's first): G_h = gh_out W_out
+// instead of a G_h read, G_x = gx_out, dW_out += gh_out (x) h_L, db_out.  Gather-only launch (its last): dW_in += G_h (x) h_in, db_in,
+// optionally grad_h_in = G_h W_in, instead of a G_h write.  (Replaces embed_out_bwd_kernel / embed_in_bwd_kernel, which cost
+// 52 + 59 us per step at the KITTI shard in their 64-lanes-per-node form for hidden_nf 33.)
+template <int H, int A, int kB, bool kG, bool kN, int NW, int NPT, int D, bool kE = false>
 __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const NodeBwd16Args a) {
+    static_assert(!kE || (kG != kN), "embedding backward rides with the node-only or the gather-only launch");
+    constexpr bool kEO = kE && kN, kEI = kE && kG;
     constexpr int F = 32 + kB, FP = 32 + 4 * kB, LD = Chunk16::LD, NP = 16 / NPT;
     using LL = LP<F, H, A>;
     using SB = Slabs<F>;
     constexpr bool kAl = (kB == 0);
     constexpr int kTile = 16 * LD;                                   // one [16 nodes][LD] operand tile
     constexpr int kWave = 5 * kTile;
-    constexpr int kGat = kG ? SB::gather : 0, kSlab = kGat + (kN ? SB::node : 0);
+    constexpr int kEmb = F * F + F;                                    // dW_out | db_out  or  dW_in | db_in
+    constexpr int kGat = kG ? SB::gather : 0, kNod = kN ? SB::node : 0, kSlab = kGat + kNod + (kE ? kEmb : 0);
     constexpr int NC = NW > 4 ? 4 : NW;                               // slab copies in LDS: wave w adds into copy w % NC
     constexpr int kLds = NW * kWave > NC * kSlab ? NW * kWave : NC * kSlab;       // operand tiles, then the slab copies
-    // operand images: m = 0 W_src^T, 1 W_tgt^T of layer l | 2 W4[:, :F], 3 W4[:, F:], 4 W5^T, 5 W4[:, :F]^T, 6 W4[:, F:]^T, 7 W_src, 8 W_tgt
-    // of the node layer.  Each [32][WS]; hidden_nf 33: + column 32 | row 32 | corner per matrix.  Then b4 | b1 (FP each).
-    constexpr int MS = 32 * W16::WS, NM = 9, BS = 72;
+    // operand images: m = 0 W_in^T (kEI) | 1 W_src^T, 2 W_tgt^T of layer l | 3 W4[:, :F], 4 W4[:, F:], 5 W5^T, 6 W4[:, :F]^T, 7 W4[:, F:]^T,
+    // 8 W_src, 9 W_tgt of the node layer | 10 W_out^T (kEO).  Each [32][WS]; hidden_nf 33: + column 32 | row 32 | corner per matrix.
+    // Then b4 | b1 (FP each).  A launch stages the contiguous range of them it uses.
+    constexpr int MS = 32 * W16::WS, NM = 11, BS = 72;
+    enum { mWinT = 0, mWsT = 1, mWtT = 2, mW4h = 3, mW4a = 4, mW5T = 5, mW4hT = 6, mW4aT = 7, mWs = 8, mWt = 9, mWoutT = 10 };
     constexpr int o_bord = NM * MS, o_vec = o_bord + kB * NM * BS, kImg = o_vec + 2 * FP;
     __shared__ __attribute__((aligned(16))) float img[kImg];
     __shared__ __attribute__((aligned(16))) float lds[kLds];
@@ -60,19 +69,22 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
     {   // ---- stage: element (i, k) of operand m; all loads of a thread before its first store
         auto el = [&](int m, int r, int c) -> const float* {
             switch (m) {
-                case 0: return a.lw_g + LL::w1_off(c, r);
-                case 1: return a.lw_g + LL::w1_off(c, F + r);
-                case 2: return a.lw_n + LL::w4 + r * 2 * F + c;
-                case 3: return a.lw_n + LL::w4 + r * 2 * F + F + c;
-                case 4: return a.lw_n + LL::w5 + c * F + r;
-                case 5: return a.lw_n + LL::w4 + c * 2 * F + r;
-                case 6: return a.lw_n + LL::w4 + c * 2 * F + F + r;
-                case 7: return a.lw_n + LL::w1_off(r, c);
-                default: return a.lw_n + LL::w1_off(r, F + c);
+                case mWinT: return a.w_in + c * F + r;                 // A[i][f] = W_in[f][i]
+                case mWsT: return a.lw_g + LL::w1_off(c, r);
+                case mWtT: return a.lw_g + LL::w1_off(c, F + r);
+                case mW4h: return a.lw_n + LL::w4 + r * 2 * F + c;
+                case mW4a: return a.lw_n + LL::w4 + r * 2 * F + F + c;
+                case mW5T: return a.lw_n + LL::w5 + c * F + r;
+                case mW4hT: return a.lw_n + LL::w4 + c * 2 * F + r;
+                case mW4aT: return a.lw_n + LL::w4 + c * 2 * F + F + r;
+                case mWs: return a.lw_n + LL::w1_off(r, c);
+                case mWt: return a.lw_n + LL::w1_off(r, F + c);
+                default: return a.w_out + c * F + r;                   // A[f][o] = W_out[o][f]
             }
         };
-        constexpr int NT = 64 * NW, PER = 1024 / NT, M0 = kG ? 0 : 2, M1 = kN ? NM : 2, NBE = (M1 - M0) * BS, PB = (NBE + NT - 1) / NT;
-        auto transposed = [](int m) { return m < 2 || (m >= 4 && m <= 6); };        // walk the source rows: coalesced global reads
+        constexpr int NT = 64 * NW, PER = 1024 / NT, M0 = kEI ? 0 : (kG ? 1 : 3), M1 = kEO ? 11 : (kN ? 10 : 3);
+        constexpr int NBE = (M1 - M0) * BS, PB = (NBE + NT - 1) / NT;
+        auto transposed = [](int m) { return m <= mWtT || (m >= mW5T && m <= mW4aT) || m == mWoutT; };      // walk the source rows: coalesced global reads
         float v[NM][PER], vb[kB ? PB : 1], vv = 0.0f;
 #pragma unroll
         for (int m = M0; m < M1; ++m)
@@ -129,7 +141,24 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
         return 0.0f;
     };
 
-    f32x4 accA[2][2], accB[2][2], acc4a[2][2], acc4b[2][2], acc5[2][2];
+    f32x4 accA[2][2], accB[2][2], acc4a[2][2], acc4b[2][2], acc5[2][2], accE[2][2];      // accE: dW_out or dW_in (kE)
+    float cs_be[2] = {0.0f, 0.0f};
+    PassBorder pbE;
+    pbE.init();
+#pragma unroll
+    for (int x_ = 0; x_ < 2; ++x_)
+#pragma unroll
+        for (int y_ = 0; y_ < 2; ++y_) accE[x_][y_] = splat4(0.0f);
+    // a [N][F] row of the caller's tensors (row stride F: 16-byte rows only for hidden_nf 32)
+    auto load_rowF = [&](const float* __restrict__ base, int j_, f32x4 (&v_)[2], float& vb_) {
+        const float* p_ = base + (size_t)j_ * F;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if constexpr (kAl) v_[b] = ldg4(p_ + 16 * b + 4 * g);
+            else v_[b] = f32x4{p_[16 * b + 4 * g], p_[16 * b + 4 * g + 1], p_[16 * b + 4 * g + 2], p_[16 * b + 4 * g + 3]};
+        }
+        vb_ = kB ? p_[32] : 0.0f;
+    };
     float cs_b1[2] = {0.0f, 0.0f}, cs_b4[2] = {0.0f, 0.0f}, cs_b5[2] = {0.0f, 0.0f}, cs_none[2] = {0.0f, 0.0f};
     PassBorder pbA, pbB, pb4a, pb4b, pb5;
     pbA.init(); pbB.init(); pb4a.init(); pb4b.init(); pb5.init();
@@ -259,8 +288,8 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
                 }
             }
             // ---- G_h = dh_part + W_src^T dP_r + W_tgt^T dP_c   (W1 = [W_src | W_tgt | W_geo] per output row)
-            ghb += prod(0, dpr, dprb, gh);
-            ghb += prod(1, dpc, dpcb, gh);
+            ghb += prod(mWsT, dpr, dprb, gh);
+            ghb += prod(mWtT, dpc, dpcb, gh);
             NB_STAMP(4);
             // ---- dW_src += dP_r (x) h, dW_tgt += dP_c (x) h, db1 += dP_c
             if (!keep) { dpr[0] = dpr[1] = dpc[0] = dpc[1] = zero; dprb = dpcb = 0.0f; }
@@ -271,13 +300,56 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
             pass16<2, true, kB>(X1, Y0, LD, i, g, accB, cs_b1, pbB);
             }
             __builtin_amdgcn_wave_barrier();
-            if constexpr (!kN) {
+            if constexpr (!kN && !kEI) {
                 if (keep) {
                     st4(a.Gh_out + (size_t)j * FP + 4 * g, gh[0]);
                     st4(a.Gh_out + (size_t)j * FP + 16 + 4 * g, gh[1]);
                     if (kB && g == 0) st4(a.Gh_out + (size_t)j * FP + 32, f32x4{ghb, 0.0f, 0.0f, 0.0f});
                 }
             }
+            if constexpr (kEI) {
+                // ---- embedding_in backward: grad_h_in = G_h W_in (optional), dW_in += G_h (x) h_in, db_in += G_h
+                f32x4 hin[2];
+                float hinb;
+                load_rowF(a.h_in, j, hin, hinb);
+                if (a.grad_h_in) {
+                    f32x4 gi[2] = {zero, zero};
+                    const float gib = prod(mWinT, gh, ghb, gi);
+                    if (keep) {
+                        float* q_ = a.grad_h_in + (size_t)j * F;
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            if constexpr (kAl) st4(q_ + 16 * b + 4 * g, gi[b]);
+                            else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) q_[16 * b + 4 * g + r] = gi[b][r];
+                            }
+                        }
+                        if (kB && g == 0) q_[32] = gib;
+                    }
+                }
+                if (!keep) { gh[0] = gh[1] = zero; ghb = 0.0f; }
+                put(X0, gh, ghb); put(Y0, hin, hinb);
+                __builtin_amdgcn_wave_barrier();
+                pass16<2, true, kB>(X0, Y0, LD, i, g, accE, cs_be, pbE);
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else if constexpr (kEO) {
+            // ---- embedding_out backward: G_h = gh_out W_out, G_x = gx_out, dW_out += gh_out (x) h_L, db_out += gh_out
+            f32x4 go[2], hl[2];
+            float gob, hlb = 0.0f;
+            load_rowF(a.gh_out, j, go, gob);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) hl[b] = ldg4(a.hL + (size_t)j * FP + 16 * b + 4 * g);
+            if (kB) hlb = a.hL[(size_t)j * FP + 32];
+            if (g == 0 && keep) st4(a.Gx_new + (size_t)j * 4, f32x4{a.gx_out[(size_t)j * 3], a.gx_out[(size_t)j * 3 + 1], a.gx_out[(size_t)j * 3 + 2], 0.0f});
+            gh[0] = gh[1] = zero;
+            ghb = prod(mWoutT, go, gob, gh);
+            if (!keep) { go[0] = go[1] = zero; gob = 0.0f; }
+            put(X0, go, gob); put(Y0, hl, hlb);
+            __builtin_amdgcn_wave_barrier();
+            pass16<2, true, kB>(X0, Y0, LD, i, g, accE, cs_be, pbE);
+            __builtin_amdgcn_wave_barrier();
         } else {
 #pragma unroll
             for (int b = 0; b < 2; ++b) gh[b] = ldg4(a.Gh_in + (size_t)j * FP + 16 * b + 4 * g);
@@ -289,8 +361,8 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
             // ---- v = W4 [h | agg] + b4 ; hid = SiLU(v)
             f32x4 v[2] = {lds4(im + o_vec + 4 * g), lds4(im + o_vec + 16 + 4 * g)};
             float vb = kB ? im[o_vec + 32] : 0.0f;
-            vb += prod(2, hn, hnb, v);
-            vb += prod(3, an, anb, v);
+            vb += prod(mW4h, hn, hnb, v);
+            vb += prod(mW4a, an, anb, v);
             f32x4 hid[2], sp[2];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
@@ -301,12 +373,12 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
             const float sgb = kB ? sigmoid_fast(vb) : 0.0f, hidb = vb * sgb, spb = sgb * (1.0f + vb * (1.0f - sgb));
             // ---- dv = (W5^T G_h) SiLU'(v)
             f32x4 dv[2] = {zero, zero};
-            float dvb = prod(4, gh, ghb, dv) * spb;
+            float dvb = prod(mW5T, gh, ghb, dv) * spb;
 #pragma unroll
             for (int b = 0; b < 2; ++b) dv[b] *= sp[b];
             // ---- dh_part = G_h + W4[:, :F]^T dv ; dagg = W4[:, F:]^T dv
             f32x4 dh[2] = {gh[0], gh[1]}, da[2] = {zero, zero};
-            const float dhb = ghb + prod(5, dv, dvb, dh), dab = prod(6, dv, dvb, da);
+            const float dhb = ghb + prod(mW4hT, dv, dvb, dh), dab = prod(mW4aT, dv, dvb, da);
             if (keep) {
                 st4(a.dh_part + (size_t)j * FP + 4 * g, dh[0]); st4(a.dh_part + (size_t)j * FP + 16 + 4 * g, dh[1]);
                 st4(a.dagg + (size_t)j * FP + 4 * g, da[0]); st4(a.dagg + (size_t)j * FP + 16 + 4 * g, da[1]);
@@ -318,7 +390,7 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
             // ---- the layer's projection rows for the edge recompute: P = [W_src h | W_tgt h + b1]
             if (a.P) {
                 f32x4 pr[2] = {zero, zero}, pc[2] = {lds4(im + o_vec + FP + 4 * g), lds4(im + o_vec + FP + 16 + 4 * g)};
-                const float prb = prod(7, hn, hnb, pr), pcb = (kB ? im[o_vec + FP + 32] : 0.0f) + prod(8, hn, hnb, pc);
+                const float prb = prod(mWs, hn, hnb, pr), pcb = (kB ? im[o_vec + FP + 32] : 0.0f) + prod(mWt, hn, hnb, pc);
                 if (keep) {
                     float* prow = a.P + (size_t)j * 2 * FP + 4 * g;
                     st4(prow, pr[0]); st4(prow + 16, pr[1]); st4(prow + FP, pc[0]); st4(prow + FP + 16, pc[1]);
@@ -346,7 +418,8 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
     // ---- slab copies.  Column sums and border partials: over the four lane groups first
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        cs_b1[b] = gsum(cs_b1[b]); cs_b4[b] = gsum(cs_b4[b]); cs_b5[b] = gsum(cs_b5[b]);
+        cs_b1[b] = gsum(cs_b1[b]); cs_b4[b] = gsum(cs_b4[b]); cs_b5[b] = gsum(cs_b5[b]); cs_be[b] = gsum(cs_be[b]);
+        if constexpr (kB == 1 && kE) { pbE.bcol[b] = gsum(pbE.bcol[b]); pbE.brow[b] = gsum(pbE.brow[b]); }
         if constexpr (kB == 1) {
             PassBorder* pbs[5] = {&pbA, &pbB, &pb4a, &pb4b, &pb5};
 #pragma unroll
@@ -358,6 +431,7 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
 #pragma unroll
         for (int k = 0; k < 5; ++k) { pbs[k]->corner = gsum(pbs[k]->corner); pbs[k]->xbs = gsum(pbs[k]->xbs); }
     }
+    if constexpr (kB == 1 && kE) { pbE.corner = gsum(pbE.corner); pbE.xbs = gsum(pbE.xbs); }
     auto emit_all = [&](float* tg, float* tn, bool add) {
         // add: a second wave's values on top of the first's (LDS float add without return; two addends -> order-free)
         auto put1 = [&](float* p, float v) {
@@ -396,13 +470,18 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
             emit_mat(tn + F * 2 * F + F, F, 0, acc5, pb5);
             emit_vec(tn + F * 2 * F + F + F * F, cs_b5, pb5);
         }
+        if constexpr (kE) {                              // behind the gather / node part of the copy
+            float* te = tg + kGat + kNod;
+            emit_mat(te, F, 0, accE, pbE);
+            emit_vec(te + F * F, cs_be, pbE);
+        }
     };
     if (EQ_NB16_DBG & 4) return;
     float* gat_dst = kG ? a.gat_slab + (size_t)blockIdx.x * SB::gather : nullptr;
     float* node_dst = kN ? a.node_slab + (size_t)blockIdx.x * SB::node : nullptr;
-    if constexpr (NW == 1) {
-        emit_all(gat_dst, node_dst, false);
-    } else {
+    float* emb_dst = kE ? a.emb_slab + (size_t)blockIdx.x * kEmb : nullptr;
+    static_assert(NW > 1, "one slab copy per workgroup is assembled in LDS");
+    {
         __syncthreads();                                 // the operand tiles are dead: the LDS becomes the slab copies
         NB_STAMP(8);
         if (wv < NC) emit_all(lds + wv * kSlab, lds + wv * kSlab + kGat, false);
@@ -412,13 +491,13 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
             __syncthreads();
         }
         NB_STAMP(9);
-        if constexpr (kGat % 4 == 0 && kSlab % 4 == 0 && SB::gather % 4 == 0 && SB::node % 4 == 0) {
+        if constexpr (kGat % 4 == 0 && kSlab % 4 == 0 && SB::gather % 4 == 0 && SB::node % 4 == 0 && kEmb % 4 == 0) {
             // copies added in fixed order, four entries per thread and step (hidden_nf 32: every slab boundary is 16-byte aligned)
             for (int t = 4 * threadIdx.x; t < kSlab; t += 4 * 64 * NW) {
                 f32x4 v = lds4(lds + t);
 #pragma unroll
                 for (int w = 1; w < NC; ++w) v += lds4(lds + w * kSlab + t);
-                st4(t < kGat ? gat_dst + t : node_dst + (t - kGat), v);
+                st4(t < kGat ? gat_dst + t : (t < kGat + kNod ? node_dst + (t - kGat) : emb_dst + (t - kGat - kNod)), v);
             }
         } else {
             for (int t = threadIdx.x; t < kSlab; t += 64 * NW) {
@@ -426,7 +505,8 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
 #pragma unroll
                 for (int w = 1; w < NC; ++w) v += lds[w * kSlab + t];
                 if (t < kGat) gat_dst[t] = v;
-                else node_dst[t - kGat] = v;
+                else if (t < kGat + kNod) node_dst[t - kGat] = v;
+                else emb_dst[t - kGat - kNod] = v;
             }
         }
     }
@@ -448,7 +528,7 @@ int node_bwd16_max_slabs(int n_nodes) { return n_nodes < 1 ? 1 : (n_nodes + 15) 
 #ifndef EQ_NB16_NW
 #define EQ_NB16_NW 4                 // waves per workgroup of the many-node path (8 = two per SIMD measured slower: 130 vs 121 us at 65 536 nodes)
 #endif
-template <int H, int A, int kB, bool kG, bool kN>
+template <int H, int A, int kB, bool kG, bool kN, bool kE = false>
 static int launch_mode(const NodeBwd16Args& args, hipStream_t s, int* n_slabs) {
     constexpr int NW = 4, NWL = EQ_NB16_NW;
     const int N = args.n_nodes;
@@ -456,13 +536,13 @@ static int launch_mode(const NodeBwd16Args& args, hipStream_t s, int* n_slabs) {
         const int tiles = ceil_div(N, 4);
         int blocks = ceil_div(tiles, NW);
         blocks = blocks > 256 ? 256 : blocks;
-        hipLaunchKernelGGL((node_bwd16_kernel<H, A, kB, kG, kN, NW, 4, EQ_NB16_D>), dim3(blocks), dim3(64 * NW), 0, s, args);
+        hipLaunchKernelGGL((node_bwd16_kernel<H, A, kB, kG, kN, NW, 4, EQ_NB16_D, kE>), dim3(blocks), dim3(64 * NW), 0, s, args);
         *n_slabs = blocks;
     } else {
         const int tiles = ceil_div(N, 16);
         int blocks = ceil_div(tiles, NWL);
         blocks = blocks > 2048 / NWL ? 2048 / NWL : blocks;
-        hipLaunchKernelGGL((node_bwd16_kernel<H, A, kB, kG, kN, NWL, 16, EQ_NB16_DL>), dim3(blocks), dim3(64 * NWL), 0, s, args);
+        hipLaunchKernelGGL((node_bwd16_kernel<H, A, kB, kG, kN, NWL, 16, EQ_NB16_DL, kE>), dim3(blocks), dim3(64 * NWL), 0, s, args);
         *n_slabs = blocks;
     }
     return 0;
@@ -474,6 +554,8 @@ static int launch_cfg(int mode, const NodeBwd16Args& args, hipStream_t s, int* n
         case kNodeBwdGather | kNodeBwdNode: return launch_mode<H, A, kB, true, true>(args, s, n_slabs);
         case kNodeBwdGather: return launch_mode<H, A, kB, true, false>(args, s, n_slabs);
         case kNodeBwdNode: return launch_mode<H, A, kB, false, true>(args, s, n_slabs);
+        case kNodeBwdGather | kNodeBwdEmbed: return launch_mode<H, A, kB, true, false, true>(args, s, n_slabs);
+        case kNodeBwdNode | kNodeBwdEmbed: return launch_mode<H, A, kB, false, true, true>(args, s, n_slabs);
     }
     return EQUIGSPR_EINVAL;
 }
