@@ -280,6 +280,9 @@ __global__ __launch_bounds__(256, 3) void node_fwd_kernel(
 // straight from the parameter block (L2-resident, 16-byte rows) -- the lane-per-feature kernel spent a third of its time
 // staging four matrices into LDS per 8 nodes and the rest in barrier-separated LDS dot products.
 // ---------------------------------------------------------------------------------------
+#ifndef EQ_NODE_FWD16
+#define EQ_NODE_FWD16 1
+#endif
 #ifndef EQ_NODE_FWD16_SMALL
 #define EQ_NODE_FWD16_SMALL 16384
 #endif
@@ -501,6 +504,108 @@ __global__ __launch_bounds__(64) void node_fwd16_kernel(
     }
 }
 
+// embedding_in in the same form (in_nf == hidden_nf, 32 or 33): h_0 = W_in h_in + b_in, x_0 = x_in, P_0 = [W_src h_0 | W_tgt h_0 + b1]
+// for the first layer's edge kernel; one wave per 16 nodes, 16 + 32 MFMAs, all weights requested up front.  (The lane-per-feature
+// embed_in_kernel remains for other input widths.)
+template <int H, int A, int kB>
+__global__ __launch_bounds__(64) void embed_in16_kernel(const float* __restrict__ w_in, const float* __restrict__ b_in,
+                                                        const float* __restrict__ lw0, const float* __restrict__ h_in,
+                                                        const float* __restrict__ x_in, int n_nodes, float* __restrict__ h0,
+                                                        float* __restrict__ x0, float* __restrict__ P) {
+    constexpr int F = 32 + kB, FP = 32 + 4 * kB;
+    using LL = LP<F, H, A>;
+    constexpr bool kAl = (kB == 0);
+    const int lane = threadIdx.x, i = lane & 15, g = lane >> 4;
+    const int j = min((int)blockIdx.x * 16 + i, n_nodes - 1);
+    const bool live = (int)blockIdx.x * 16 + i < n_nodes;
+    f32x4 wia[2][2], hin[2], acc[2], pcb[2];
+    float as[2][2][4], at[2][2][4];
+#pragma unroll
+    for (int bo = 0; bo < 2; ++bo) {
+#pragma unroll
+        for (int bi = 0; bi < 2; ++bi) wia[bo][bi] = wquad<kAl>(w_in, 16 * bo + i, F, 16 * bi + 4 * g);
+        acc[bo] = wquad<kAl>(b_in, 0, 0, 16 * bo + 4 * g);
+    }
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                as[bi][bo][r] = lw0[LL::w1_off(16 * bo + i, 16 * bi + 4 * g + r)];
+                at[bi][bo][r] = lw0[LL::w1_off(16 * bo + i, F + 16 * bi + 4 * g + r)];
+            }
+#pragma unroll
+    for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pcb[bo][r] = lw0[LL::b1_off(16 * bo + 4 * g + r)];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) hin[b] = wquad<kAl>(h_in, j, F, 16 * b + 4 * g);
+    const float hinb = kB ? h_in[(size_t)j * F + 32] : 0.0f;
+    if (live && g == 0) {
+        x0[(size_t)j * 3 + 0] = x_in[(size_t)j * 3 + 0]; x0[(size_t)j * 3 + 1] = x_in[(size_t)j * 3 + 1]; x0[(size_t)j * 3 + 2] = x_in[(size_t)j * 3 + 2];
+    }
+    auto add_col = [&](f32x4 (&a_)[2], const float* __restrict__ w, int ld, int c, float vb) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a_[b][r] = fmaf(w[(size_t)(16 * b + 4 * g + r) * ld + c], vb, a_[b][r]);
+    };
+    auto row_dot = [&](const float* __restrict__ wrow, int c0, const f32x4 (&v)[2]) {
+        float p = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p = fmaf(wrow[c0 + 16 * b + 4 * g + r], v[b][r], p);
+        return p;
+    };
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[0] = mfma16(wia[0][bi][r], hin[bi][r], acc[0]);
+            acc[1] = mfma16(wia[1][bi][r], hin[bi][r], acc[1]);
+        }
+    float h0b = 0.0f;
+    if constexpr (kB == 1) {
+        add_col(acc, w_in, F, 32, hinb);
+        const float* w32 = w_in + (size_t)32 * F;
+        h0b = gsum(row_dot(w32, 0, hin)) + w32[32] * hinb + b_in[32];
+    }
+    if (live) {
+        st4(h0 + (size_t)j * FP + 4 * g, acc[0]);
+        st4(h0 + (size_t)j * FP + 16 + 4 * g, acc[1]);
+        if (kB && g == 0) st4(h0 + (size_t)j * FP + 32, f32x4{h0b, 0.0f, 0.0f, 0.0f});
+    }
+    f32x4 pr[2] = {splat4(0.0f), splat4(0.0f)}, pc[2] = {pcb[0], pcb[1]};
+#pragma unroll
+    for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            pr[0] = mfma16(as[bi][0][r], acc[bi][r], pr[0]);
+            pr[1] = mfma16(as[bi][1][r], acc[bi][r], pr[1]);
+            pc[0] = mfma16(at[bi][0][r], acc[bi][r], pc[0]);
+            pc[1] = mfma16(at[bi][1][r], acc[bi][r], pc[1]);
+        }
+    float prb = 0.0f, pcbb = 0.0f;
+    if constexpr (kB == 1) {          // H == 1 here: W1 is one [33][79] block
+        const float* w1 = lw0 + LL::w1_off(0, 0);
+        add_col(pr, w1, LL::D, 32, h0b);
+        add_col(pc, w1, LL::D, F + 32, h0b);
+        const float* w32 = w1 + (size_t)32 * LL::D;
+        prb = gsum(row_dot(w32, 0, acc)) + w32[32] * h0b;
+        pcbb = gsum(row_dot(w32, F, acc)) + w32[F + 32] * h0b + lw0[LL::b1_off(32)];
+    }
+    if (live) {
+        float* prow = P + (size_t)j * 2 * FP + 4 * g;
+        st4(prow, pr[0]); st4(prow + 16, pr[1]); st4(prow + FP, pc[0]); st4(prow + FP + 16, pc[1]);
+        if (kB && g == 0) {
+            st4(P + (size_t)j * 2 * FP + 32, f32x4{prb, 0.0f, 0.0f, 0.0f});
+            st4(P + (size_t)j * 2 * FP + FP + 32, f32x4{pcbb, 0.0f, 0.0f, 0.0f});
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------------------
@@ -575,6 +680,13 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
 #define EQ_NODE_FWD_BLOCKS 2048
 #endif
     const int node_grid = node_groups < EQ_NODE_FWD_BLOCKS ? node_groups : EQ_NODE_FWD_BLOCKS;
+    bool embed16 = false;
+    if constexpr (EQ_NODE_FWD16 && (F == 32 || H == 1)) embed16 = cfg->in_nf == F;
+    if (embed16) {
+        if constexpr (EQ_NODE_FWD16 && (F == 32 || H == 1))
+            hipLaunchKernelGGL((embed_in16_kernel<H, A, F - 32>), dim3(ceil_div(N, 16)), dim3(64), 0, s, params + ML.w_in, params + ML.b_in,
+                               params + ML.layer0, h_in, x_in, N, hbuf(0), xbuf(0), P);
+    } else
     hipLaunchKernelGGL((embed_in_kernel<F, H, A>), dim3(node_grid), dim3(256), 0, s, params, cfg->in_nf, ML.w_in,
                        ML.b_in, ML.layer0, h_in, x_in, N, hbuf(0), xbuf(0), P);
     for (int l = 0; l < L; ++l) {
@@ -584,9 +696,6 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
             launch_edge_fwd<F, H, A>(lw, g, edge_attr, xbuf(l), P, m, trans, cfg->edge_basis, s);
         }
         float* xn = last ? x_out : xbuf(l + 1);
-#ifndef EQ_NODE_FWD16
-#define EQ_NODE_FWD16 1
-#endif
         if constexpr (EQ_NODE_FWD16 && (F == 32 || H == 1)) {
             // few nodes: one wave per CU or less, latency decides -> 16 rows in flight; many nodes: 4 (registers for occupancy)
             // few nodes: one wave per CU or less, latency decides -> 16 rows in flight; many nodes: 4 (registers for occupancy).  Both sum
