@@ -303,11 +303,14 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(const int* __restrict__ p
     const int len = hi - lo;
     if (lane == 0) scratch[j] = 0;
     if (len <= 64) {
-        u64 key = lane < len ? (u64)(unsigned)perm[lo + lane] : ~0ull;
-        if (len > 1) key = wave_bitonic_sort(key, lane);          // wave-uniform condition: all 64 lanes take part
+        // distinct edge ids: a lane's final position is the number of smaller ids in the segment -- `len` broadcast steps of one
+        // v_readlane + compare + add (a k = 20 neighbourhood: ~60 instructions) instead of the 21-stage 64-lane bitonic network
+        const int key = lane < len ? perm[lo + lane] : 0x7fffffff;
+        int rank = 0;
+        for (int t = 0; t < len; ++t) rank += (__builtin_amdgcn_readlane(key, t) < key) ? 1 : 0;      // t is wave-uniform
         if (lane < len) {
-            if (len > 1) perm[lo + lane] = (int)(unsigned)key;
-            if (inv) inv[(int)(unsigned)key] = lo + lane;
+            if (len > 1) perm[lo + rank] = key;
+            if (inv) inv[key] = lo + rank;
         }
     } else {
         if (lane == 0) {
