@@ -23,7 +23,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for n in (1, 2, 3):
     for r in csv.DictReader(open(f"{out}/pmc_{n}.csv")):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if "edge_" in k:
+        if "edge_" in k or "knn_" in k:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k)
