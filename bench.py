@@ -17,9 +17,12 @@ Prints ONE JSON line on rank 0 (schema: see repo prompt) including
                   this box's host cores on a bounded sample of the same workload.
 """
 import argparse
+import copy
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,10 +34,11 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+PMC_FILES = ("r03_pmc_edge_kernels.json", "r03_pmc_edge_kernels_b16.json", "r02_pmc_edge_kernels.json")
 FP32_PEAK_TF = 157.3
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -64,13 +68,22 @@ def parse():
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="repeat the timed block of --steps steps until this much time has been measured; report the median block")
     ap.add_argument("--allow-eager", action="store_true", help="N>1: fall back to eager launches if hipGraph capture fails (default: exit non-zero)")
-    a = ap.parse_args()
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="pairs per step over ALL ranks, sharded contiguously with dp.shard_range (strong scaling: the same pairs at 1/2/4/8 "
+                         "GPUs; BASELINE configs[3] = --workload c4 --global-batch 64); 0 = --batch pairs on every rank (weak scaling)")
+    ap.add_argument("--eval-head", action="store_true", help="with --forward-only: the evaluation pair model (variant='eval', eval :643-827)")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="default run only: skip the extra `workloads` block (c3, c3 irreps, c4 shard, c5 with the evaluation head)")
+    ap.add_argument("--workload-seconds", type=float, default=0.5, help="seconds measured per entry of the `workloads` block")
+    a = ap.parse_args(argv)
+    a.explicit_workload = a.workload is not None or a.batch != 1 or a.n != 2048 or a.k != 20 or a.layers != 4 or a.feat != 32 or \
+        a.heads != 1 or a.forward_only or a.edge_basis != "frames" or a.global_batch > 0 or a.dev_no_head or a.aten_head
     if a.workload == "c3":
         a.batch = 16
     elif a.workload == "c4":
         a.batch, a.n, a.feat = 8, 4096, 33
     elif a.workload == "c5":
-        a.n, a.k, a.layers, a.forward_only = 8192, 32, 8, True
+        a.n, a.k, a.layers, a.forward_only, a.eval_head = 8192, 32, 8, True, True
     return a
 
 
@@ -78,16 +91,24 @@ def build_step(pkg, args, dev, world):
     torch.manual_seed(0)
     egnn = pkg.EGNN(args.feat, args.feat, args.feat, in_edge_nf=1, device=dev, n_layers=args.layers, num_heads=args.heads,
                     edge_basis=args.edge_basis)
-    model = pkg.CrossAttentionPoseRegression(egnn, num_nodes=args.n, hidden_nf=args.feat, device=dev,
+    variant = "eval" if (args.eval_head and args.forward_only) else "train"
+    model = pkg.CrossAttentionPoseRegression(egnn, num_nodes=args.n, hidden_nf=args.feat, device=dev, variant=variant,
                                              fused_head=not args.aten_head).to(dev)
     egnn._ensure_flat()
-    from se3_equi_graph_registration_amd.dp import DataParallelStep
+    from se3_equi_graph_registration_amd.dp import DataParallelStep, shard_range
     dp = DataParallelStep(model, egnn)
     dp.broadcast_parameters(0)
     rank = dist.get_rank() if world > 1 else 0
     scale = (3.0, 3.0, 3.0)
-    batch = pkg.synthetic_batch(1234 + rank * args.batch, args.batch, n=args.n, feat=args.feat, scale=scale, device=dev)
-    ones = torch.ones(args.batch, args.n * args.k, 1, device=dev)
+    if args.global_batch > 0:          # strong scaling: the SAME global batch at every world size, contiguous shard per rank
+        lo, hi = shard_range(args.global_batch, rank, world)
+        if hi <= lo:
+            raise SystemExit(f"--global-batch {args.global_batch} leaves rank {rank} of {world} without a pair")
+        args.batch = hi - lo
+        first = 1234 + lo
+    else:
+        first = 1234 + rank * args.batch
+    batch = pkg.synthetic_batch(first, args.batch, n=args.n, feat=args.feat, scale=scale, device=dev)
     # one fused Adam launch over the flat bucket (two views: EGNN block, head; the per-tensor parameters are views of them); train :1412
     opt = pkg.FlatAdam([(egnn.flat_params, egnn.flat_grads), (dp.head.flat, dp.head.grad)], lr=1e-4)
 
@@ -109,7 +130,7 @@ def build_step(pkg, args, dev, world):
         out = model(batch["feat_src"], batch["src"], graph, None, batch["feat_tgt"], batch["tgt"], graph, None,
                     batch["corr"], batch["labels"], batch["gt_pose"])
         if args.forward_only:
-            return out[2]
+            return out[0] if out[2] is None else out[2]          # the evaluation pair model returns scores = None (eval :826-827)
         R, t, closs = out[0], out[1], out[2]
         if args.aten_head:
             rl, tl = pkg.pose_loss(R, t, batch["gt_pose"])
@@ -142,7 +163,7 @@ def build_step(pkg, args, dev, world):
     def opt_step():
         opt.step(zero_grad=not args.aten_head)
 
-    return dict(model=model, egnn=egnn, dp=dp, batch=batch, ones=ones, fwd_bwd=fwd_bwd, zero=zero, opt_step=opt_step, restore=restore)
+    return dict(model=model, egnn=egnn, dp=dp, batch=batch, fwd_bwd=fwd_bwd, zero=zero, opt_step=opt_step, restore=restore)
 
 
 def make_runner(S, args, world, dev):
@@ -259,12 +280,23 @@ def split_graph_runner(S, args, dist_on, eager):
     return step
 
 
-# MFMA instructions the edge kernels issue per tile, and the flops of one such instruction (csrc/egnn_mfma16.h, egnn_mfma.h):
-#   hidden_nf 32: 16-edge sub-tiles of v_mfma_f32_16x16x4_f32 (2 048 flop): forward 8 + 16 + 16; backward recomputes those,
-#                 + three transposed products (16 + 16 + 8) + three weight-gradient outer products (16 + 16 + 8)
-#   hidden_nf 33: 32-edge tiles of v_mfma_f32_32x32x2_f32 (4 096 flop): forward 7 + 17 + 17 (one border step per product);
-#                 backward + 17 + 17 + 17 transposed and 16 + 16 + 16 outer products
-MFMA_PER_TILE = {32: dict(edges=16, flop=2048, fwd=40, bwd=120), 33: dict(edges=32, flop=4096, fwd=41, bwd=140)}
+# MFMA instructions the edge kernels issue per 16-edge sub-tile of v_mfma_f32_16x16x4_f32 (2 048 flop each; csrc/egnn_mfma16.h):
+#   forward 8 (geometry) + 16 (W2) + 16 (W6); the backward recomputes those, + three transposed products (16 + 16 + 8) + three
+#   weight-gradient outer products (16 + 16 + 8).  hidden_nf 33 runs the SAME matrix instructions on its 32 x 32 cores; feature 32
+#   (the "border") is vector-ALU work on top (its column of a product = 8 FMAs, its row a partial dot + one lane-group sum).
+# valu = vector-ALU instructions per sub-tile (SQ_INSTS_VALU - SQ_INSTS_MFMA over the sub-tiles of a launch; profiles/r03_sq_edge_kernels.json)
+MFMA_PER_TILE = {32: dict(edges=16, flop=2048, fwd=40, bwd=120, valu_fwd=190, valu_bwd=400),
+                 33: dict(edges=16, flop=2048, fwd=40, bwd=120, valu_fwd=290, valu_bwd=640)}
+SIMDS, ISSUE_CLOCK_GHZ = 1024, 2.1          # 256 CUs x 4 SIMDs; the clock the chip holds under this load
+
+
+def issue_floor_us(E, F, bwd):
+    """Lower bound of an edge kernel from instruction issue alone: on gfx950 the fp32 MFMA does not co-execute with vector-ALU work
+    of the same SIMD (tools/dev/coexec.hip), so a SIMD's time is >= 32 cycles per 16x16x4 MFMA + ~4 per vector instruction."""
+    mm = MFMA_PER_TILE[33 if F == 33 else 32]
+    tiles = (E + 15) // 16
+    cyc = (mm["bwd" if bwd else "fwd"] * 32 + mm["valu_bwd" if bwd else "valu_fwd"] * 4) * ((tiles + SIMDS - 1) // SIMDS)
+    return cyc / (ISSUE_CLOCK_GHZ * 1e3)
 
 
 def roofline(pkg, S, args, dev):
@@ -288,16 +320,18 @@ def roofline(pkg, S, args, dev):
                                         ctypes.c_void_p(x.data_ptr()), None, ctypes.c_void_p(work.data_ptr()), iters,
                                         ctypes.byref(ms), stream), "time_edge_fwd")
     fwd_ms = ms.value
-    _, _, saved = ops.egnn_forward(cfg, egnn.flat_params, graph, h, x, None, True)
-    bwork = torch.empty(int(L.equigspr_egnn_bwd_work_size(ctypes.byref(cfg), graph.n_nodes, E)), device=dev)
-    _lib.check(L.equigspr_time_edge_bwd(ctypes.byref(cfg), ctypes.c_void_p(egnn.flat_params.data_ptr()),
-                                        ctypes.byref(graph.struct), None, ctypes.c_void_p(saved.data_ptr()),
-                                        ctypes.c_void_p(bwork.data_ptr()), iters, ctypes.byref(ms), stream), "time_edge_bwd")
-    bwd_ms = ms.value
+    bwd_ms = None
+    if not args.forward_only:
+        _, _, saved = ops.egnn_forward(cfg, egnn.flat_params, graph, h, x, None, True)
+        bwork = torch.empty(int(L.equigspr_egnn_bwd_work_size(ctypes.byref(cfg), graph.n_nodes, E)), device=dev)
+        _lib.check(L.equigspr_time_edge_bwd(ctypes.byref(cfg), ctypes.c_void_p(egnn.flat_params.data_ptr()),
+                                            ctypes.byref(graph.struct), None, ctypes.c_void_p(saved.data_ptr()),
+                                            ctypes.c_void_p(bwork.data_ptr()), iters, ctypes.byref(ms), stream), "time_edge_bwd")
+        bwd_ms = ms.value
     F = args.feat
-    bytes_fwd = (2 * (F + 3) * 4 + 2 * 4 + 4 + (F + 3) * 4) * E          # SURVEY §8(d): 432 B/edge-layer at F=32
+    bytes_fwd = (2 * (F + 3) * 4 + 2 * 4 + 4 + (F + 3) * 4) * E          # SURVEY 8(d): 432 B/edge-layer at F=32
     bytes_bwd = 2 * bytes_fwd
-    # algorithmic flops per edge (SURVEY §8(d): the reference's 77-wide first layer counted per edge although its two
+    # algorithmic flops per edge (SURVEY 8(d): the reference's 77-wide first layer counted per edge although its two
     # h-blocks are projected once per node here), and the flops of the MFMA instructions the kernels actually issue
     flops_fwd = (2 * (2 * F + 13) * F + 2 * F * F + 2 * F * F + 2 * F + 12 * F) * E
     flops_bwd = flops_fwd + 2 * (2 * F * F + 2 * F * F + 2 * 13 * F) * E       # + transposed products + outer products (the backward recomputes the forward)
@@ -306,34 +340,43 @@ def roofline(pkg, S, args, dev):
     exe_fwd, exe_bwd = tiles * mm["fwd"] * mm["flop"], tiles * mm["bwd"] * mm["flop"]
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this command (profiles/), when they cover this workload
     traffic = {"fwd": None, "bwd": None, "source": None}
-    try:
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_edge_kernels.json")
-        pmc = json.load(open(pmc_path))
-        if pmc["workload"]["edges_per_launch"] == E and pmc["workload"]["feat"] == F:
-            traffic = {"fwd": pmc["edge_fwd_kernel"]["traffic_bytes"], "bwd": pmc["edge_bwd_kernel"]["traffic_bytes"],
-                       "source": "profiles/r02_pmc_edge_kernels.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2*FETCH+WRITE)"}
-    except Exception:
-        pass
-    dom_is_bwd = bwd_ms >= fwd_ms and not args.forward_only
+    for name in PMC_FILES:             # newest first; a file counts only when it was collected on exactly this launch shape
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if pmc["workload"]["edges_per_launch"] == E and pmc["workload"]["feat"] == F:
+                traffic = {"fwd": pmc["edge_fwd_kernel"]["traffic_bytes"], "bwd": pmc["edge_bwd_kernel"]["traffic_bytes"],
+                           "source": f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                                     "2*FETCH+WRITE per the gfx950 correction; collected by tools/profile_round.sh, not in this run)"}
+                break
+        except Exception:
+            continue
+    dom_is_bwd = bwd_ms is not None and bwd_ms >= fwd_ms
     a_f = bytes_fwd / (fwd_ms * 1e-3) / 1e9
-    a_b = bytes_bwd / (bwd_ms * 1e-3) / 1e9
-    roof = {"bound": "hbm", "kernel": "edge_bwd_kernel" if dom_is_bwd else "edge_fwd_kernel",
+    a_b = bytes_bwd / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
+    kname = ("edge_bwd16_kernel" if dom_is_bwd else "edge_fwd16_kernel") + (" (hidden_nf 33: border variant)" if F == 33 else "")
+    roof = {"bound": "hbm", "kernel": kname,
             "achieved": round(a_b if dom_is_bwd else a_f, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round((a_b if dom_is_bwd else a_f) / HBM_PEAK_GBS, 5), "traffic": traffic["bwd" if dom_is_bwd else "fwd"],
             "traffic_source": traffic["source"],
             "edges_per_launch": E, "algorithmic_bytes_per_launch": bytes_bwd if dom_is_bwd else bytes_fwd,
             "launch_ms": round(bwd_ms if dom_is_bwd else fwd_ms, 5),
+            "issue_floor_us": round(issue_floor_us(E, F, dom_is_bwd), 2),
+            "issue_floor_note": "(MFMA x 32 + vector-ALU x 4 cycles) per 16-edge sub-tile x sub-tiles per SIMD / 2.1 GHz: fp32 MFMA and VALU "
+                                "do not co-execute on gfx950 (profiles/r03_sq_edge_kernels.json, tools/dev/coexec.hip)",
             "backward_mode": "recompute (no per-edge activations kept by the forward)"}
     tf = lambda fl, t_ms: fl / (t_ms * 1e-3) / 1e12 / FP32_PEAK_TF
-    extra = {"edge_fwd_ms": round(fwd_ms, 5), "edge_bwd_ms": round(bwd_ms, 5),
+    extra = {"edge_fwd_ms": round(fwd_ms, 5), "edge_fwd_issue_floor_us": round(issue_floor_us(E, F, False), 2),
              "edge_fwd_form": "training form = inference form (the timed step runs this kernel)",
-             "edge_fwd_GBs": round(a_f, 2), "edge_bwd_GBs": round(a_b, 2),
-             "edge_fwd_fp32_frac": round(tf(flops_fwd, fwd_ms), 5), "edge_bwd_fp32_frac": round(tf(flops_bwd, bwd_ms), 5),
-             "edge_fwd_executed_mfma_frac": round(tf(exe_fwd, fwd_ms), 5), "edge_bwd_executed_mfma_frac": round(tf(exe_bwd, bwd_ms), 5),
+             "edge_fwd_GBs": round(a_f, 2), "edge_fwd_hbm_frac": round(a_f / HBM_PEAK_GBS, 5),
+             "edge_fwd_fp32_frac": round(tf(flops_fwd, fwd_ms), 5), "edge_fwd_executed_mfma_frac": round(tf(exe_fwd, fwd_ms), 5),
+             "edge_fwd_traffic": traffic["fwd"],
              "mfma_note": "fp32 MFMA shares the SIMD's fp32 lanes with the VALU on gfx950 (tools/dev/coexec.hip: no co-execution), so "
-                          "executed_mfma_frac is the share of the kernel's SIMD time spent in matrix instructions",
-             "edge_fwd_hbm_frac": round(a_f / HBM_PEAK_GBS, 5), "edge_bwd_hbm_frac": round(a_b / HBM_PEAK_GBS, 5),
-             "edge_fwd_traffic": traffic["fwd"], "edge_bwd_traffic": traffic["bwd"]}
+                          "executed_mfma_frac is the share of the kernel's SIMD time spent in matrix instructions"}
+    if bwd_ms is not None:
+        extra.update({"edge_bwd_ms": round(bwd_ms, 5), "edge_bwd_issue_floor_us": round(issue_floor_us(E, F, True), 2),
+                      "edge_bwd_GBs": round(a_b, 2), "edge_bwd_hbm_frac": round(a_b / HBM_PEAK_GBS, 5),
+                      "edge_bwd_fp32_frac": round(tf(flops_bwd, bwd_ms), 5), "edge_bwd_executed_mfma_frac": round(tf(exe_bwd, bwd_ms), 5),
+                      "edge_bwd_traffic": traffic["bwd"]})
     return roof, extra
 
 
@@ -395,33 +438,51 @@ def cpu_baseline(args):
                       f"{host_cores} cores: `cores` is the thread count used)"}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=dev)
-    rank = dist.get_rank() if world > 1 else 0
-    import se3_equi_graph_registration_amd as pkg
-    pkg.lib()
 
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start N ranks as CHILD processes (one per GPU, RCCL) through
+    torch.distributed.run -- before this process makes any HIP call, and never by exec -- relay their output, and end with rank 0's JSON
+    line.  Exits non-zero unless the line reports N distinct devices."""
+    n_dev = torch.cuda.device_count()            # counts devices without initialising the GPU
+    if n_dev < args.gpus:
+        print(f"[bench] --gpus {args.gpus} but this node exposes {n_dev} GPU(s)", file=sys.stderr)
+        raise SystemExit(2)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    line = None
+    for ln in reversed(lines):
+        if ln.lstrip().startswith("{"):
+            try:
+                line = json.loads(ln)
+                break
+            except ValueError:
+                continue
+    for ln in lines:
+        if line is None or not ln.lstrip().startswith("{"):
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"[bench] the {args.gpus}-rank launch failed (exit code {proc.returncode})", file=sys.stderr)
+        raise SystemExit(proc.returncode or 4)
+    print(json.dumps(line), flush=True)
+    seen = (line.get("multi_gpu") or {}).get("distinct_devices")
+    if line.get("n_gpus") != args.gpus or seen != args.gpus:
+        print(f"[bench] asked for {args.gpus} GPUs, the ranks saw {seen} distinct device(s)", file=sys.stderr)
+        raise SystemExit(5)
+
+
+def measure(pkg, args, dev, world, min_seconds):
+    """Builds the step of `args`, warms it up and times blocks of EXACTLY args.steps steps (barrier + synchronize on both sides,
+    MAX over ranks) until `min_seconds` have been measured; returns the state, the block times and how the step was launched."""
     S = build_step(pkg, args, dev, world)
-    # Everything runs on a non-default stream: on this ROCm stack an eager launch on the NULL stream between two
-    # hipGraph replays on the NULL stream faults in the next replay ("write access to a read-only page"; reproduced
-    # with a single mul_, profiles/README.md); on any other stream the same sequence is fine.  BENCH_NULL_STREAM=1
-    # keeps the null stream (to reproduce the finding).
-    if os.environ.get("BENCH_NULL_STREAM") != "1":
-        work_stream = torch.cuda.Stream()
-        work_stream.wait_stream(torch.cuda.current_stream())
-        torch.cuda.set_stream(work_stream)
     run, used_graph = make_runner(S, args, world, dev)
     dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     graph_mode = ("none" if not used_graph else
@@ -432,7 +493,6 @@ def main():
     S["restore"]()
 
     def timed_block():
-        """EXACTLY args.steps steps between barrier + synchronize on both sides; MAX over ranks (seconds)."""
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -454,20 +514,72 @@ def main():
         return dt
 
     # A block of `steps` steps can be a few milliseconds of GPU time (one pair per step): one hiccup would move the headline.
-    # The block is therefore repeated until --min-seconds have been measured (count fixed from the first block's rank-max
+    # The block is therefore repeated until min_seconds have been measured (count fixed from the first block's rank-max
     # time, so every rank runs the same number) and the MEDIAN block is reported; `steps` stays as given.
     blocks = [timed_block()]
-    n_blocks = 1 if args.min_seconds <= 0 else max(1, min(400, int(args.min_seconds / max(blocks[0], 1e-6)) + 1))
+    n_blocks = 1 if min_seconds <= 0 else max(1, min(400, int(min_seconds / max(blocks[0], 1e-6)) + 1))
     if n_blocks > 1 and n_blocks % 2 == 0:
         n_blocks += 1
     while len(blocks) < n_blocks:
         S["restore"]()
         blocks.append(timed_block())
-    el = sorted(blocks)[len(blocks) // 2]
     finite = bool(torch.isfinite(S["egnn"].flat_params).all().item())
+    return S, blocks, used_graph, graph_mode, finite
+
+
+def workload_text(args):
+    head = "evaluation pair model (eval :643-827)" if (args.eval_head and args.forward_only) else "pose head (Kabsch/SVD)"
+    return (f"{'inference' if args.forward_only else 'training'} step: {args.batch} pair(s)/GPU x {args.n} pts, k={args.k}, "
+            f"{args.layers} EGNN layers, F={args.feat}, heads={args.heads}, edge inputs={args.edge_basis}; kNN+index, EGNN fwd, {head}, "
+            + ("no backward" if args.forward_only else "losses, backward, grad all-reduce, Adam"))
+
+
+# The other BASELINE.json configs, measured in the default run next to the headline (each `--workload-seconds` of timed blocks, its
+# own HIP-event roofline): name -> (BASELINE config, bench flags, steps per block)
+EXTRA_WORKLOADS = (
+    ("c3_b16", "configs[2] shape: 3DMatch training, batch=16, the reference's edge inputs", ["--workload", "c3"], 20),
+    ("c3_b16_irreps", "configs[2]: 3DMatch training, batch=16, fused irrep-basis + message-passing kernel", ["--workload", "c3", "--edge-basis", "irreps"], 20),
+    ("c4_shard", "configs[3]: one GPU's shard of the KITTI batch (8 of 64 pairs x 4096 pts, F=33), training", ["--workload", "c4"], 15),
+    ("c5_eval", "configs[4]: 3DMatch eval sweep pair, 8192 pts, k=32, 8 layers, evaluation pair model", ["--workload", "c5"], 50),
+)
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and os.environ.get("RANK", "0") == "0":
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): measuring {world}", file=sys.stderr)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if dist_on:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    rank = dist.get_rank() if world > 1 else 0
+    import se3_equi_graph_registration_amd as pkg
+    pkg.lib()
+
+    # Everything runs on a non-default stream: on this ROCm stack an eager launch on the NULL stream between two
+    # hipGraph replays on the NULL stream faults in the next replay ("write access to a read-only page"; reproduced
+    # with a single mul_, profiles/README.md); on any other stream the same sequence is fine.  BENCH_NULL_STREAM=1
+    # keeps the null stream (to reproduce the finding).
+    if os.environ.get("BENCH_NULL_STREAM") != "1":
+        work_stream = torch.cuda.Stream()
+        work_stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(work_stream)
+    S, blocks, used_graph, graph_mode, finite = measure(pkg, args, dev, world, args.min_seconds)
+    el = sorted(blocks)[len(blocks) // 2]
 
     # evidence for the N>1 path: which devices the process group really spans, and what the gradient exchange costs alone
-    ranks_seen, allreduce_us = None, None
+    ranks_seen, allreduce_us, grad_hash = None, None, None
     if dist_on:
         props = torch.cuda.get_device_properties(dev)
         me = {"rank": rank, "local_rank": local_rank, "device": props.name, "uuid": str(getattr(props, "uuid", "")),
@@ -478,7 +590,6 @@ def main():
         else:
             gathered = [me]
         ranks_seen = gathered
-        bucket = S["dp"].buckets()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(5):
             S["dp"].sync(force=True)
@@ -490,38 +601,69 @@ def main():
         torch.cuda.synchronize()
         allreduce_us = round(ev0.elapsed_time(ev1) * 1e3 / 20, 2)
         S["restore"]()
+    if os.environ.get("BENCH_GRAD_HASH") == "1" and not args.forward_only:
+        # test hook (tests/test_gpu_bench_dist.py): the joint gradient bucket of ONE eager forward + backward from the initial weights
+        S["restore"](); S["dp"].zero_grad()
+        S["fwd_bwd"]()
+        if dist_on:
+            S["dp"].sync(force=True)
+        torch.cuda.synchronize()
+        g = torch.cat([b.reshape(-1) for b in S["dp"].buckets()]).double()
+        grad_hash = {"sum": float(g.sum()), "abs_sum": float(g.abs().sum()), "sq_sum": float((g * g).sum()), "numel": int(g.numel())}
+        S["dp"].zero_grad(); S["restore"]()
 
     out = None
     if rank == 0:
         roof, extra = roofline(pkg, S, args, dev)
+        n_pairs = args.global_batch if args.global_batch > 0 else world * args.batch
         out = {
             "metric": f"registration pairs/sec ({args.n}-pt, k={args.k}, {args.layers} EGNN layers)",
-            "value": round(world * args.batch * args.steps / el, 3), "unit": "pairs/s",
+            "value": round(n_pairs * args.steps / el, 3), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * el / args.steps, 5), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * el / args.steps, 5), "higher_is_better": True,
+            "scaling": "strong" if args.global_batch > 0 else "weak",
             "timing": {"blocks": len(blocks), "statistic": "median block of `steps` steps (rank-max per block)",
                        "ms_per_step_min": round(1e3 * min(blocks) / args.steps, 5), "ms_per_step_max": round(1e3 * max(blocks) / args.steps, 5),
                        "ms_per_step_first_block": round(1e3 * blocks[0] / args.steps, 5), "seconds_measured": round(sum(blocks), 3)},
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{'inference' if args.forward_only else 'training'} step: {args.batch} pair(s)/GPU x "
-                                   f"{args.n} pts, k={args.k}, {args.layers} EGNN layers, F={args.feat}, heads={args.heads}; "
-                                   "kNN+index, EGNN fwd, pose head (Kabsch/SVD), "
-                                   + ("no backward" if args.forward_only else "losses, backward, grad all-reduce, Adam"),
-                       "pairs_per_gpu": args.batch, "points": args.n, "k": args.k, "layers": args.layers, "edge_basis": args.edge_basis,
-                       "hipgraph": used_graph, "graph_mode": graph_mode, "parallelism": f"dp{world}", "params_finite": finite,
-                       "reset_every": args.reset_every},
+            "config": {"workload": workload_text(args),
+                       "pairs_per_gpu": args.batch, "global_batch": n_pairs, "points": args.n, "k": args.k, "layers": args.layers,
+                       "edge_basis": args.edge_basis, "hipgraph": used_graph, "graph_mode": graph_mode, "parallelism": f"dp{world}",
+                       "params_finite": finite, "reset_every": args.reset_every},
             "roofline": roof, "kernels": extra,
         }
         if args.dev_no_head:
             out["INVALID"] = "--dev-no-head: pose head and losses skipped (developer measurement, not the metric)"
+        if grad_hash is not None:
+            out["grad_hash"] = grad_hash
         if dist_on:
             nb = sum(int(b.numel()) * 4 for b in S["dp"].buckets())
             out["multi_gpu"] = {"world_size": world, "backend": dist.get_backend(), "ranks_seen": ranks_seen,
                                 "distinct_devices": len({(r["host"], r["uuid"] or r["pci_bus_id"] or r["local_rank"]) for r in ranks_seen}),
                                 "allreduce_bytes": nb, "allreduce_us_isolated": allreduce_us,
                                 "exchange": "one mean all-reduce of the joint flat gradient bucket per step"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+    del S
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not dist_on and not args.explicit_workload and not args.no_workloads:
+        # the default (driver) run: the other BASELINE configs beside the headline, so that their numbers are witnessed too
+        out["workloads"] = {}
+        for name, what, flags, steps in EXTRA_WORKLOADS:
+            wa = parse(flags + ["--steps", str(steps), "--warmup", "3"])
+            try:
+                Sw, bl, ug, gm, fin = measure(pkg, wa, dev, 1, args.workload_seconds)
+                elw = sorted(bl)[len(bl) // 2]
+                roof_w, extra_w = roofline(pkg, Sw, wa, dev)
+                out["workloads"][name] = {
+                    "baseline_config": what, "flags": " ".join(flags), "workload": workload_text(wa),
+                    "value": round(wa.batch * wa.steps / elw, 3), "unit": "pairs/s", "ms_per_step": round(1e3 * elw / wa.steps, 5),
+                    "steps": wa.steps, "blocks": len(bl), "seconds_measured": round(sum(bl), 3), "hipgraph": ug, "params_finite": fin,
+                    "roofline": roof_w, "kernels": extra_w}
+                del Sw
+            except Exception as exc:                        # one broken workload must not take the headline line down
+                out["workloads"][name] = {"baseline_config": what, "error": f"{type(exc).__name__}: {exc}"}
+            torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -18,6 +18,8 @@
 // Launch structure: independent jobs share a launch as extra grid columns; a many -> one dependency inside a launch is a ticket
 // (release fence + device-scope atomic; the last block continues behind an acquire fence; the counter is handed back as zero).
 // Layouts: h_* [B,N,F] with row stride F; x_* [B,N,3]; labels [B,N] (float 0/1); gt_pose [B,16].
+#include <mutex>
+
 #include "common.h"
 #include "kabsch_device.h"
 #include "pose_loss_device.h"
@@ -822,12 +824,18 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
                        F, F_raw, sim, rsim, cosv, pos, W.partA, W.tickets);
     const int Npad = next_pow2(N);
     const size_t sm = fwd_smem(N, Npad, K, md);
-    static size_t sm_set = 0;
-    if (sm > sm_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_pair_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        if (e != hipSuccess) { set_error("head_forward: %s", hipGetErrorString(e)); return (int)e; }
-        sm_set = sm;
+    {   // the dynamic-LDS limit is a per-device function attribute: keep the high-water mark per device, under a lock
+        static std::mutex mu;
+        static size_t sm_set[64] = {0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || sm > sm_set[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_pair_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            if (e != hipSuccess) { set_error("head_forward: %s", hipGetErrorString(e)); return (int)e; }
+            if (dev >= 0 && dev < 64) sm_set[dev] = sm;
+        }
     }
     EQ_CHECK_ARG(!kabsch_aux || (kabsch_R && kabsch_t), EQUIGSPR_EINVAL, "head_forward: kabsch_R / kabsch_t are null");
     EQ_CHECK_ARG(!step_loss || kabsch_aux, EQUIGSPR_EINVAL, "head_forward: step_loss needs the head's own Kabsch (kabsch_aux)");

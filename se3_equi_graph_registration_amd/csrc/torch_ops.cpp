@@ -5,7 +5,9 @@
 // ends, and there is exactly one implementation underneath.  Built by csrc/Makefile into ../libequigspr_torch.so (g++; no device
 // code here) and loaded with torch.ops.load_library (se3_equi_graph_registration_amd/torch_library.py).
 #include <ATen/ATen.h>
+#include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
+#include <torch/autograd.h>
 #include <torch/library.h>
 
 #include "../../include/equigspr.h"
@@ -13,6 +15,11 @@
 namespace {
 
 void* cur_stream(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+// every op runs on the device of its first tensor (the C-ABI launches on the CURRENT device: a tensor of another GPU must switch it)
+using DeviceGuard = c10::hip::HIPGuard;
+void same_device(const at::Tensor& a, const at::Tensor& b, const char* name) {
+    TORCH_CHECK(a.device() == b.device(), "equigspr: ", name, " lives on ", b.device(), ", expected ", a.device());
+}
 
 void check(int rc, const char* what) {
     TORCH_CHECK(rc == 0, "equigspr::", what, ": ", equigspr_last_error(), " (code ", rc, ")");
@@ -29,6 +36,8 @@ at::Tensor knn_graph(const at::Tensor& x, int64_t k, bool loop) {
     need(x, "x", at::kFloat, 2);
     TORCH_CHECK(x.size(1) == 3, "equigspr::knn_graph: x must be [n, 3]");
     const int64_t n = x.size(0);
+    TORCH_CHECK(k >= 1 && k <= n, "equigspr::knn_graph: need 1 <= k <= n");
+    DeviceGuard guard(x.device());
     auto out = at::empty({1, 2, n * k}, x.options().dtype(at::kLong));
     check(equigspr_knn_graph(x.data_ptr<float>(), 1, (int32_t)n, (int32_t)k, loop ? 1 : 0, out.data_ptr<int64_t>(), nullptr, nullptr,
                              nullptr, 0, cur_stream(x)), "knn_graph");
@@ -38,6 +47,8 @@ at::Tensor knn_graph(const at::Tensor& x, int64_t k, bool loop) {
 // build_inverse_index(key int32 [E], n_nodes) -> (ptr int32 [N + 1], perm int32 [E], inv int32 [E])   (stable counting sort)
 std::tuple<at::Tensor, at::Tensor, at::Tensor> build_inverse_index(const at::Tensor& key, int64_t n_nodes) {
     need(key, "key", at::kInt, 1);
+    TORCH_CHECK(n_nodes >= 1, "equigspr::build_inverse_index: n_nodes must be positive");
+    DeviceGuard guard(key.device());
     const int64_t e = key.size(0);
     auto o = key.options();
     auto ptr = at::empty({n_nodes + 1}, o), perm = at::empty({e}, o), inv = at::empty({e}, o), scratch = at::empty({n_nodes + 1}, o);
@@ -54,10 +65,18 @@ std::tuple<at::Tensor, at::Tensor> egnn_forward(const at::Tensor& params, const 
     need(params, "params", at::kFloat, 1); need(h, "h", at::kFloat, 2); need(x, "x", at::kFloat, 2);
     need(row, "row", at::kInt, 1); need(col, "col", at::kInt, 1);
     const int64_t n = h.size(0), e = row.size(0);
+    TORCH_CHECK(x.size(0) == n && x.size(1) == 3, "equigspr::egnn_forward: x must be [", n, ", 3]");
+    TORCH_CHECK(col.numel() == e, "equigspr::egnn_forward: row and col must have the same length");
+    TORCH_CHECK(!edge_attr.has_value() || edge_attr->numel() == e, "equigspr::egnn_forward: edge_attr must hold one value per edge");
+    same_device(h, params, "params"); same_device(h, x, "x"); same_device(h, row, "row"); same_device(h, col, "col");
+    if (edge_attr.has_value()) same_device(h, *edge_attr, "edge_attr");
+    DeviceGuard guard(h.device());
     equigspr_egnn_config cfg{(int32_t)h.size(1), (int32_t)hidden_nf, (int32_t)out_nf, edge_attr.has_value() ? 1 : 0, (int32_t)n_layers,
                              (int32_t)num_heads, (int32_t)edge_basis};
-    TORCH_CHECK(equigspr_egnn_param_count(&cfg) == params.numel(), "equigspr::egnn_forward: parameter block has ", params.numel(),
-                " floats, the configuration needs ", equigspr_egnn_param_count(&cfg));
+    const int64_t want = equigspr_egnn_param_count(&cfg);
+    TORCH_CHECK(want > 0, "equigspr::egnn_forward: unsupported configuration (in_nf ", h.size(1), ", hidden_nf ", hidden_nf, ", out_nf ", out_nf,
+                ", heads ", num_heads, ", layers ", n_layers, "): ", equigspr_last_error());
+    TORCH_CHECK(want == params.numel(), "equigspr::egnn_forward: parameter block has ", params.numel(), " floats, the configuration needs ", want);
     if (edge_attr.has_value()) need(*edge_attr, "edge_attr", at::kFloat, -1);
     auto io = row.options();
     auto rptr = at::empty({n + 1}, io), rperm = at::empty({e}, io), rinv = at::empty({e}, io), scratch = at::empty({n + 1}, io);
@@ -79,6 +98,10 @@ std::tuple<at::Tensor, at::Tensor> egnn_forward(const at::Tensor& params, const 
 std::tuple<at::Tensor, at::Tensor, at::Tensor> weighted_kabsch_forward(const at::Tensor& src, const at::Tensor& tgt, const at::Tensor& w) {
     need(src, "src", at::kFloat, 3); need(tgt, "tgt", at::kFloat, 3); need(w, "weights", at::kFloat, 2);
     const int64_t b = src.size(0), n = src.size(1);
+    TORCH_CHECK(src.size(2) == 3 && tgt.sizes() == src.sizes() && w.size(0) == b && w.size(1) == n,
+                "equigspr::weighted_kabsch_forward: need src, tgt [B, n, 3] and weights [B, n]");
+    same_device(src, tgt, "tgt"); same_device(src, w, "weights");
+    DeviceGuard guard(src.device());
     auto R = at::empty({b, 3, 3}, src.options()), t = at::empty({b, 3}, src.options()), aux = at::empty({b, EQUIGSPR_KABSCH_AUX}, src.options());
     check(equigspr_kabsch_forward(src.data_ptr<float>(), tgt.data_ptr<float>(), w.data_ptr<float>(), (int32_t)b, (int32_t)n,
                                   R.data_ptr<float>(), t.data_ptr<float>(), aux.data_ptr<float>(), cur_stream(src)), "kabsch_forward");
@@ -91,6 +114,11 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> weighted_kabsch_backward(const at
     need(src, "src", at::kFloat, 3); need(tgt, "tgt", at::kFloat, 3); need(w, "weights", at::kFloat, 2); need(aux, "aux", at::kFloat, 2);
     need(gR, "grad_R", at::kFloat, 3); need(gt, "grad_t", at::kFloat, 2);
     const int64_t b = src.size(0), n = src.size(1);
+    TORCH_CHECK(src.size(2) == 3 && tgt.sizes() == src.sizes() && w.size(0) == b && w.size(1) == n && aux.size(0) == b &&
+                    aux.size(1) == EQUIGSPR_KABSCH_AUX && gR.size(0) == b && gR.size(1) == 3 && gR.size(2) == 3 && gt.size(0) == b && gt.size(1) == 3,
+                "equigspr::weighted_kabsch_backward: need src, tgt [B, n, 3], weights [B, n], aux [B, ", EQUIGSPR_KABSCH_AUX, "], grad_R [B, 3, 3], grad_t [B, 3]");
+    same_device(src, tgt, "tgt"); same_device(src, w, "weights"); same_device(src, aux, "aux"); same_device(src, gR, "grad_R"); same_device(src, gt, "grad_t");
+    DeviceGuard guard(src.device());
     auto gs = at::empty_like(src), gtt = at::empty_like(tgt), gw = at::empty_like(w);
     check(equigspr_kabsch_backward(src.data_ptr<float>(), tgt.data_ptr<float>(), w.data_ptr<float>(), aux.data_ptr<float>(),
                                    gR.data_ptr<float>(), gt.data_ptr<float>(), (int32_t)b, (int32_t)n, gs.data_ptr<float>(),
@@ -99,6 +127,49 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> weighted_kabsch_backward(const at
 }
 
 int64_t abi_version() { return equigspr_abi_version(); }
+
+// ---- Autograd key.  weighted_kabsch_forward is differentiable: its backward is the C-ABI's closed-form Kabsch backward.  The other
+// ops are inference forms -- a tensor that requires grad raises instead of silently producing a non-differentiable output (training
+// goes through the Python autograd node around equigspr_egnn_forward / _backward, se3_equi_graph_registration_amd/egnn.py).
+struct KabschFn : torch::autograd::Function<KabschFn> {
+    static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const at::Tensor& src, const at::Tensor& tgt,
+                                                  const at::Tensor& w) {
+        at::AutoDispatchBelowADInplaceOrView below;
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("equigspr::weighted_kabsch_forward", "")
+                             .typed<std::tuple<at::Tensor, at::Tensor, at::Tensor>(const at::Tensor&, const at::Tensor&, const at::Tensor&)>();
+        auto out = op.call(src, tgt, w);
+        ctx->save_for_backward({src, tgt, w, std::get<2>(out)});
+        ctx->mark_non_differentiable({std::get<2>(out)});
+        return {std::get<0>(out), std::get<1>(out), std::get<2>(out)};
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list g) {
+        const auto sv = ctx->get_saved_variables();
+        const auto gR = g[0].defined() ? g[0].contiguous() : at::zeros({sv[0].size(0), 3, 3}, sv[0].options());
+        const auto gt = g[1].defined() ? g[1].contiguous() : at::zeros({sv[0].size(0), 3}, sv[0].options());
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("equigspr::weighted_kabsch_backward", "")
+                             .typed<std::tuple<at::Tensor, at::Tensor, at::Tensor>(const at::Tensor&, const at::Tensor&, const at::Tensor&,
+                                                                                  const at::Tensor&, const at::Tensor&, const at::Tensor&)>();
+        auto out = op.call(sv[0], sv[1], sv[2], sv[3], gR, gt);
+        return {std::get<0>(out), std::get<1>(out), std::get<2>(out)};
+    }
+};
+std::tuple<at::Tensor, at::Tensor, at::Tensor> weighted_kabsch_forward_autograd(const at::Tensor& src, const at::Tensor& tgt, const at::Tensor& w) {
+    auto out = KabschFn::apply(src, tgt, w);
+    return {out[0], out[1], out[2]};
+}
+bool wants_grad(const at::Tensor& t) { return at::GradMode::is_enabled() && t.defined() && t.requires_grad(); }
+std::tuple<at::Tensor, at::Tensor> egnn_forward_autograd(const at::Tensor& params, const at::Tensor& h, const at::Tensor& x, const at::Tensor& row,
+                                                         const at::Tensor& col, const c10::optional<at::Tensor>& edge_attr, int64_t hidden_nf,
+                                                         int64_t out_nf, int64_t n_layers, int64_t num_heads, int64_t edge_basis) {
+    TORCH_CHECK(!wants_grad(params) && !wants_grad(h) && !wants_grad(x),
+                "equigspr::egnn_forward is the inference form (no autograd): run it under torch.no_grad() / on detached tensors, or train "
+                "through se3_equi_graph_registration_amd.EGNN (autograd node over equigspr_egnn_forward / equigspr_egnn_backward)");
+    at::AutoDispatchBelowADInplaceOrView below;
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("equigspr::egnn_forward", "")
+                         .typed<std::tuple<at::Tensor, at::Tensor>(const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&,
+                                                                    const c10::optional<at::Tensor>&, int64_t, int64_t, int64_t, int64_t, int64_t)>();
+    return op.call(params, h, x, row, col, edge_attr, hidden_nf, out_nf, n_layers, num_heads, edge_basis);
+}
 
 }  // namespace
 
@@ -110,6 +181,11 @@ TORCH_LIBRARY(equigspr, m) {
           "int n_layers, int num_heads=1, int edge_basis=0) -> (Tensor, Tensor)");
     m.def("weighted_kabsch_forward(Tensor src, Tensor tgt, Tensor weights) -> (Tensor, Tensor, Tensor)");
     m.def("weighted_kabsch_backward(Tensor src, Tensor tgt, Tensor weights, Tensor aux, Tensor grad_R, Tensor grad_t) -> (Tensor, Tensor, Tensor)");
+}
+
+TORCH_LIBRARY_IMPL(equigspr, Autograd, m) {
+    m.impl("weighted_kabsch_forward", &weighted_kabsch_forward_autograd);
+    m.impl("egnn_forward", &egnn_forward_autograd);
 }
 
 TORCH_LIBRARY_IMPL(equigspr, CUDA, m) {       // the HIP backend key of a ROCm build of PyTorch

@@ -58,22 +58,81 @@ class E_GCL(nn.Module):
 
     def forward(self, h, edge_index, coord, edge_attr=None):
         """Stand-alone layer call (train :280-289) -> (h, coord, edge_attr).  Runs as a one-layer EGNN with identity embeddings
-        whose ``gcl_0`` IS this module (the same ``nn.Parameter`` objects, re-homed into that EGNN's flat block), so it is
-        differentiable like ``EGNN.forward``: parameter gradients land in this layer's ``.grad``."""
+        that holds a COPY of this layer's weights (refreshed at every call: a few KB on the device); the gradients of the copy are
+        handed back through autograd to this module's own parameters.  The layer's ``nn.Parameter``s are never re-homed, so a layer
+        that belongs to a model (``egnn.gcl_0(h, edges, x)``) keeps living in its EGNN's flat block -- optimizers and
+        data-parallel buckets built on that block stay valid."""
         wrap = self.__dict__.get("_standalone")
         dev = h.device
         if wrap is None or wrap.flat_params is None or wrap.flat_params.device != dev:
             f = self.hidden_nf
             wrap = EGNN(f, f, f, in_edge_nf=self.edges_in_d, device=dev, n_layers=1, num_heads=self.num_heads)
-            wrap._modules["gcl_0"] = self.to(dev)
             with torch.no_grad():
                 wrap.embedding_in.weight.copy_(torch.eye(f)); wrap.embedding_in.bias.zero_()
                 wrap.embedding_out.weight.copy_(torch.eye(f)); wrap.embedding_out.bias.zero_()
-            for q in (*wrap.embedding_in.parameters(), *wrap.embedding_out.parameters()):
-                q.requires_grad_(False)
-            self.__dict__["_standalone"] = wrap        # not a registered submodule: no parameter cycle
-        h2, x2 = wrap(h, coord, edge_index, edge_attr)
+            wrap._ensure_flat()
+            self.__dict__["_standalone"] = wrap        # not a registered submodule: no parameter cycle, not in state_dict()
+        if h.dim() != 2 or coord.dim() != 2:
+            raise RuntimeError("E_GCL.forward expects h [N,F] and coord [N,3]")
+        graph = wrap._graph_for(edge_index, h.shape[0])
+        if self.edges_in_d == 0:
+            ea = None
+        elif edge_attr is None:
+            raise RuntimeError("E_GCL was built with edges_in_d=1 but edge_attr is None")
+        else:
+            ea = edge_attr.reshape(-1).contiguous().float()
+        params = list(self.parameters())
+        training = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or h.requires_grad or coord.requires_grad)
+        if training and graph.cptr is None:
+            raise RuntimeError("E_GCL.forward: training needs a DeviceGraph built with need_col_index=True")
+        h2, x2 = _LayerFn.apply(h.contiguous().float(), coord.contiguous().float(), wrap, graph, ea, training, *params)
         return h2, x2, edge_attr
+
+    def __deepcopy__(self, memo):                       # the cached one-layer wrapper is per instance and rebuilt on demand
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k != "_standalone":
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k != "_standalone"}
+
+
+class _LayerFn(torch.autograd.Function):
+    """One E_GCL through the one-layer wrapper EGNN ``wrap`` (identity embeddings).  The layer's parameters are autograd inputs:
+    forward copies them into the wrapper's block, backward runs the HIP backward into the wrapper's gradient block and returns
+    its slices -- autograd then accumulates them into the layer's own ``.grad`` wherever those live."""
+
+    @staticmethod
+    def forward(ctx, h, x, wrap, graph, edge_attr, training, *params):
+        layer = wrap._modules["gcl_0"]
+        with torch.no_grad():
+            for dst, src in zip(layer.parameters(), params):
+                dst.copy_(src.detach())
+        h_out, x_out, saved = ops.egnn_forward(wrap.cfg, wrap.flat_params, graph, h, x, edge_attr, training)
+        ctx.wrap, ctx.graph, ctx.edge_attr, ctx.n_params = wrap, graph, edge_attr, len(params)
+        if training:
+            ctx.save_for_backward(h, saved, wrap.flat_params.clone())      # the weights THIS call ran with
+        return h_out, x_out
+
+    @staticmethod
+    def backward(ctx, gh, gx):
+        wrap = ctx.wrap
+        h, saved, flat = ctx.saved_tensors
+        n = ctx.graph.n_nodes
+        gh = torch.zeros(n, wrap.cfg.out_nf, dtype=torch.float32, device=h.device) if gh is None else gh
+        gx = torch.zeros(n, 3, dtype=torch.float32, device=h.device) if gx is None else gx
+        wrap.flat_grads.zero_()
+        wrap._attach_grads()
+        ghi, gxi = ops.egnn_backward(wrap.cfg, flat, ctx.graph, h, ctx.edge_attr, saved, gh.contiguous(), gx.contiguous(),
+                                     wrap.flat_grads, (ctx.needs_input_grad[0], ctx.needs_input_grad[1]))
+        layer = wrap._modules["gcl_0"]
+        pg = [p.grad.clone() if need else None for p, need in zip(layer.parameters(), ctx.needs_input_grad[6:])]
+        return (ghi, gxi, None, None, None, None, *pg)
 
 
 class _EgnnFn(torch.autograd.Function):

@@ -22,7 +22,7 @@ import torch.distributed as dist
 
 from . import ops
 from .datasets import DeviceBatches
-from .dp import DataParallelStep
+from .dp import DataParallelStep, shard_range
 from .graph import build_pair_graph
 from .metrics import evaluate_batch
 from .pose import registration_loss
@@ -130,24 +130,63 @@ def _step_is_finite(loss, optimizer, model):
     return bool(flag.item() > 0.5)
 
 
-def train_one_epoch(model, dataloader, optimizer, device, epoch, writer=None, use_pointnet=False, log_interval=10, beta=1, k=16,
-                    skip_nonfinite=False, loss_mode="3dmatch"):
-    """One pass over ``dataloader`` (7-tuples of the dataset classes); returns the average loss.
+def _process_group(optimizer):
+    """(rank, world, group) of the data-parallel job this optimizer synchronises over; (0, 1, None) for a single process."""
+    group = optimizer.dp.group if hasattr(optimizer, "dp") else None
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        return dist.get_rank(group), dist.get_world_size(group), group
+    return 0, 1, group
 
-    The reference's arccos pose loss is NaN / has a non-finite gradient at a perfect fit and for pairs without inliers.  The
-    reference runs under ``set_detect_anomaly(True)`` (:1124) and stops there: so does this loop by default (``RuntimeError``
-    on every rank of a data-parallel job, the decision is collective).  ``skip_nonfinite=True`` instead drops such a step on
-    all ranks together and keeps going.  Batches containing ``None`` are skipped as in the reference (:969).
-    ``loss_mode``: ``"3dmatch"`` = ``corr + rot + trans`` (train :1120); ``"kitti"`` = ``corr + equi``
-    (``src/kitti_train_egnn_with_batch.py:1089``)."""
-    model.train()
+
+def _all_ranks_have(have: bool, group, device) -> bool:
+    """MIN over the ranks of 'this rank holds a usable batch': a batch with a ``None`` member (an unreadable pair, train :969) is
+    skipped by EVERY rank or by none -- a rank that skipped alone would leave its peers in the finite-check and gradient
+    all-reduces of this step."""
+    flag_dev = device if dist.get_backend(group) == "nccl" else "cpu"
+    flag = torch.tensor([1.0 if have else 0.0], dtype=torch.float32, device=flag_dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item() > 0.5)
+
+
+def shard_batch(batch, rank: int, world: int):
+    """This rank's contiguous share (``dp.shard_range``) of a step batch whose tensors are stacked along dim 0 (SURVEY section 8(e):
+    pairs are independent -- the reference asserts there are no cross-pair edges, train :1020-1028).  Returns
+    ``(shard, n_local, n_global)``; ``n_local`` may be 0 when the batch holds fewer pairs than there are ranks."""
+    n_global = int(batch[0].shape[0])
+    lo, hi = shard_range(n_global, rank, world)
+    return tuple(item[lo:hi] if isinstance(item, torch.Tensor) else item for item in batch), hi - lo, n_global
+
+
+def run_training_batches(model, batches, optimizer, step_loss, device, epoch=0, log_interval=10, skip_nonfinite=False,
+                         shard_batches=True):
+    """The body of ``train_one_epoch`` over an iterable of step batches; ``step_loss(model, batch) -> scalar loss``.
+
+    Data-parallel contract (one process per GPU, every rank iterates the SAME sequence of global step batches):
+      * a batch is used only if every rank holds it (``_all_ranks_have``);
+      * with ``shard_batches`` every rank runs the pairs ``dp.shard_range(B, rank, world)`` of it; its loss -- a mean over its
+        pairs -- is weighted by ``n_local * world / B`` before ``backward`` so that the mean all-reduce of ``optimizer.step``
+        yields the gradient of the mean over all B pairs also when the shards are uneven; a rank left without a pair
+        contributes zero gradients and still joins both collectives.  (The training head's similarity-MSE term standardises over
+        the pairs it sees, train :777-781: like batch statistics under DDP it is evaluated per shard.)
+      * the non-finite decision is collective (``_step_is_finite``)."""
+    rank, world, group = _process_group(optimizer)
     total, n = 0.0, 0
-    for batch_idx, batch in enumerate(_device_batches(dataloader, device)):
-        if batch is None or any(item is None for item in batch):
+    for batch_idx, batch in enumerate(batches):
+        have = batch is not None and not any(item is None for item in batch)
+        if world > 1:
+            have = _all_ranks_have(have, group, device)
+        if not have:
             continue
+        n_local = n_global = 1
+        if world > 1 and shard_batches:
+            batch, n_local, n_global = shard_batch(batch, rank, world)
         optimizer.zero_grad()
-        _, loss, _, _ = _forward(model, batch, k, use_pointnet, loss_mode)
-        loss.backward()
+        if n_local > 0:
+            loss = step_loss(model, batch)
+            weight = n_local * world / n_global if (world > 1 and shard_batches) else 1.0
+            (loss if weight == 1.0 else loss * weight).backward()
+        else:
+            loss = torch.zeros((), device=device)           # no pair on this rank: zero gradients, same collectives
         if not _step_is_finite(loss, optimizer, model):
             if not skip_nonfinite:
                 raise RuntimeError(f"non-finite loss or gradient at epoch {epoch + 1}, batch {batch_idx + 1} (the reference stops "
@@ -160,35 +199,71 @@ def train_one_epoch(model, dataloader, optimizer, device, epoch, writer=None, us
         value = loss.item()
         optimizer.step()
         total, n = total + value, n + 1
-        if log_interval and batch_idx % log_interval == 0:
+        if log_interval and batch_idx % log_interval == 0 and rank == 0:
             print(f"Epoch [{epoch + 1}], Batch [{batch_idx + 1}], Loss: {value:.6f}")
-    avg = total / max(n, 1)
+    return total / max(n, 1)
+
+
+def train_one_epoch(model, dataloader, optimizer, device, epoch, writer=None, use_pointnet=False, log_interval=10, beta=1, k=16,
+                    skip_nonfinite=False, loss_mode="3dmatch", shard_batches=True):
+    """One pass over ``dataloader`` (7-tuples of the dataset classes); returns the average loss.
+
+    The reference's arccos pose loss is NaN / has a non-finite gradient at a perfect fit and for pairs without inliers.  The
+    reference runs under ``set_detect_anomaly(True)`` (:1124) and stops there: so does this loop by default (``RuntimeError``
+    on every rank of a data-parallel job, the decision is collective).  ``skip_nonfinite=True`` instead drops such a step on
+    all ranks together and keeps going.  Batches containing ``None`` are skipped as in the reference (:969) -- by all ranks
+    together.  Under ``torch.distributed`` (one process per GPU) every rank iterates the same loader and runs its
+    ``dp.shard_range`` share of each step batch (``shard_batches=False``: the loader already yields per-rank batches).
+    ``loss_mode``: ``"3dmatch"`` = ``corr + rot + trans`` (train :1120); ``"kitti"`` = ``corr + equi``
+    (``src/kitti_train_egnn_with_batch.py:1089``)."""
+    model.train()
+
+    def step_loss(m, batch):
+        return _forward(m, batch, k, use_pointnet, loss_mode)[1]
+
+    avg = run_training_batches(model, _device_batches(dataloader, device), optimizer, step_loss, device, epoch=epoch,
+                               log_interval=log_interval, skip_nonfinite=skip_nonfinite, shard_batches=shard_batches)
     print(f"Epoch [{epoch + 1}], Average Loss: {avg:.6f}")
     return avg
 
 
 @torch.no_grad()
-def validate(model, dataloader, device, epoch, writer=None, use_pointnet=False, beta=1, k=16):
-    """Returns ``(avg_loss, avg_rot_loss + avg_trans_loss, avg_corr_loss)`` over the batches with a finite loss."""
+def validate(model, dataloader, device, epoch, writer=None, use_pointnet=False, beta=1, k=16, process_group=None, shard_batches=True):
+    """Returns ``(avg_loss, avg_rot_loss + avg_trans_loss, avg_corr_loss)`` over the batches with a finite loss.  Under
+    ``torch.distributed`` every rank evaluates its ``dp.shard_range`` share of each batch (weight ``n_local / B``) and ONE
+    all-reduce at the end combines the running sums: no per-batch collective, so ranks may skip batches independently."""
     model.eval()
     was_variant = getattr(model, "variant", None)
     if was_variant is not None:
         model.variant = "train"          # the reference validates with the training forward (:1208) -- it needs the losses
-    sums, n = [0.0, 0.0, 0.0, 0.0], 0
+    world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(process_group) if world > 1 else 0
+    sums, n = [0.0, 0.0, 0.0, 0.0], 0.0
     try:
         for batch in _device_batches(dataloader, device):
             if batch is None or any(item is None for item in batch):
                 continue
+            weight = 1.0
+            if world > 1 and shard_batches:
+                batch, n_local, n_global = shard_batch(batch, rank, world)
+                if n_local == 0:
+                    continue
+                weight = n_local / n_global
             out, loss, rot, trans = _forward(model, batch, k, use_pointnet)
             vals = [loss.item(), rot.mean().item(), trans.mean().item(), out[2].mean().item()]
             if vals[0] != vals[0]:
                 continue
-            sums, n = [a + b for a, b in zip(sums, vals)], n + 1
+            sums, n = [a + weight * b for a, b in zip(sums, vals)], n + weight
     finally:
         if was_variant is not None:
             model.variant = was_variant
-    avg = [s / max(n, 1) for s in sums]
-    print(f"Validation Loss: {avg[0]:.6f} | Pose rot Loss: {avg[1]:.6f} | Pose trans Loss: {avg[2]:.6f}")
+    if world > 1:
+        acc = torch.tensor(sums + [n], dtype=torch.float64, device=device if dist.get_backend(process_group) == "nccl" else "cpu")
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=process_group)
+        sums, n = acc[:4].tolist(), float(acc[4])
+    avg = [s / max(n, 1e-12) if n > 0 else 0.0 for s in sums]
+    if rank == 0:
+        print(f"Validation Loss: {avg[0]:.6f} | Pose rot Loss: {avg[1]:.6f} | Pose trans Loss: {avg[2]:.6f}")
     return avg[0], avg[1] + avg[2], avg[3]
 
 

@@ -181,3 +181,76 @@ def _nan_worker(rank, world, port, q):
 def test_nonfinite_step_decision_is_collective():
     res = dict(_run_ranks(_nan_worker, 2))
     assert res[0] == res[1] == [True, False, False]
+
+
+# ---- the training loop under data parallelism: the None-batch skip is collective and every rank runs its
+# dp.shard_range share of each step batch, weighted so that uneven shards still give the gradient of the global mean
+class _SgdOpt:
+    """Stands in for train.StepOptimizer: the dp bucket contract + a plain SGD update after the mean all-reduce."""
+
+    def __init__(self, model, lr=0.1):
+        self.model, self.lr = model, lr
+        self.dp = DataParallelStep(model, model.egnn)
+        self.dp.broadcast_parameters(0)
+        self.dp.zero_grad()
+        self.steps = 0
+
+    def zero_grad(self):
+        self.dp.zero_grad()
+
+    def step(self):
+        self.dp.sync()
+        with torch.no_grad():
+            self.dp.joint.add_(self.dp.joint_grad, alpha=-self.lr)
+        self.steps += 1
+
+
+def _mean_loss(model, batch):
+    (x,) = batch
+    return model.mlp(model.egnn(x)).mean()
+
+
+def _loop_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from se3_equi_graph_registration_amd.train import run_training_batches
+    torch.manual_seed(3)
+    model = Pair()
+    opt = _SgdOpt(model)
+    g = torch.Generator().manual_seed(11)
+    data = [torch.randn(b, 4, generator=g) for b in (5, 4, 1, 6)]           # 5 and 1: uneven / empty shards at world = 2
+    batches = [(d,) for d in data]
+    if rank == 1:
+        batches[1] = None                                                   # an unreadable pair on ONE rank (train :969)
+    run_training_batches(model, batches, opt, _mean_loss, "cpu", log_interval=0)
+    q.put((rank, opt.steps, opt.dp.joint.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_loop_skips_none_batches_collectively_and_shards_by_rank():
+    res = sorted(_run_ranks(_loop_worker, 2), key=lambda t: t[0])
+    (_, s0, p0), (_, s1, p1) = res
+    assert s0 == s1 == 3                           # batch 1 dropped by BOTH ranks, no rank left alone in a collective
+    assert torch.equal(p0, p1)
+    # single-process reference over the same global batches (minus the skipped one)
+    torch.manual_seed(3)
+    ref = Pair()
+    g = torch.Generator().manual_seed(11)
+    data = [torch.randn(b, 4, generator=g) for b in (5, 4, 1, 6)]
+    params = [p for p in ref.parameters()]
+    for i, d in enumerate(data):
+        if i == 1:
+            continue
+        for p in params:
+            p.grad = None
+        _mean_loss(ref, (d,)).backward()
+        with torch.no_grad():
+            for p in params:
+                if p.grad is not None:
+                    p.add_(p.grad, alpha=-0.1)
+    flat_ref = torch.cat([p.detach().reshape(-1) for p in ref.egnn.parameters()])
+    torch.testing.assert_close(p0[:flat_ref.numel()], flat_ref, rtol=1e-5, atol=1e-6)
+    head_ref = torch.cat([p.detach().reshape(-1) for p in list(ref.mlp.parameters()) + list(ref.unused.parameters())])
+    off = (flat_ref.numel() + 63) // 64 * 64
+    torch.testing.assert_close(p0[off:off + head_ref.numel()], head_ref, rtol=1e-5, atol=1e-6)

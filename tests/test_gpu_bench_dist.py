@@ -1,0 +1,73 @@
+"""bench.py's N>1 path, exercised on ONE GPU as child processes:
+
+* ``BENCH_FORCE_DIST=1``: the real EGNN + pose head re-homed into the joint bucket, an RCCL process group (1 rank), the step as
+  two hipGraphs with the eager all-reduce between them, and as ONE graph with the collective captured (``--graph-collectives``);
+  the gradient of one step must be bit-identical to the non-distributed path (a 1-rank mean all-reduce is the identity);
+* ``--gpus N`` without a launcher environment starts N ranks itself -- on a 1-GPU box it must refuse loudly, not measure 1 GPU;
+* ``--global-batch`` shards with ``dp.shard_range``.
+Every run is a fresh child process (bench.py initialises the GPU and a process group of its own)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+SMALL = ["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--min-seconds", "0", "--no-workloads", "--n", "512", "--k", "12",
+         "--layers", "2"]
+
+
+def _bench(extra, env_extra=None, expect_rc=0):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + extra, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == expect_rc, f"rc={p.returncode}\n{p.stdout[-2000:]}\n{p.stderr[-4000:]}"
+    if expect_rc != 0:
+        return None, p
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    return json.loads(lines[-1]), p          # the JSON line is the LAST line of stdout (RCCL's banner is flushed before it)
+
+
+@pytest.fixture(scope="module")
+def plain():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    line, _ = _bench([], {"BENCH_GRAD_HASH": "1"})
+    assert "multi_gpu" not in line and line["n_gpus"] == 1 and line["config"]["hipgraph"] is True
+    return line
+
+
+@pytest.mark.parametrize("flags,mode", [([], "two graphs + eager all-reduce"), (["--graph-collectives"], "one graph")])
+def test_forced_dist_step_on_rccl_matches_the_plain_step(plain, flags, mode):
+    line, _ = _bench(flags, {"BENCH_FORCE_DIST": "1", "BENCH_GRAD_HASH": "1", "MASTER_PORT": "29611"})
+    mg = line["multi_gpu"]
+    assert mg["backend"] == "nccl" and mg["world_size"] == 1 and mg["distinct_devices"] == 1 and len(mg["ranks_seen"]) == 1
+    assert mg["allreduce_bytes"] > 100_000 and mg["allreduce_us_isolated"] > 0
+    assert line["config"]["graph_mode"] == mode and line["config"]["hipgraph"] is True
+    assert line["config"]["params_finite"] is True and line["value"] > 0
+    assert line["grad_hash"] == plain["grad_hash"], "the RCCL path changed the step's gradients"
+    assert plain["grad_hash"]["abs_sum"] > 0
+
+
+def test_gpus_flag_starts_ranks_itself_and_refuses_missing_devices():
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1)] + SMALL, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode == 2 and "exposes" in p.stderr and not p.stdout.strip()
+    if n >= 2:                      # a multi-GPU box: the self-launched job must really span two devices
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, env=env,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-4000:]
+        line = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+        assert line["n_gpus"] == 2 and line["multi_gpu"]["distinct_devices"] == 2
+
+
+def test_global_batch_is_sharded_with_shard_range():
+    line, _ = _bench(["--global-batch", "3"])
+    assert line["scaling"] == "strong" and line["config"]["pairs_per_gpu"] == 3 and line["config"]["global_batch"] == 3
+    assert abs(line["value"] - 3 * 1e3 / line["ms_per_step"]) < 1e-2 * line["value"]
