@@ -215,6 +215,27 @@ int equigspr_head_backward(const float* hs, const float* ht, const float* xs, co
                            void* work, float* dinp, float* mlp_slab, float* grad_mlp, float* ghs, float* ght,
                            float* gxs, float* gxt, void* stream);
 
+/* ---- A11: fused evaluation pair model ---------------------------------------------------------
+ * Replaces the body of the EVALUATION CrossAttentionPoseRegression.forward after the EGNN calls
+ * (src/eval_egnn_metrics.py:687-818): egnn_equi_loss on the EGNN outputs (:687), sim0 = <h0_s, h0_t> on the INPUT features
+ * (:691), top-K of sim0 (:694, ties by lower index), the correspondence MLP on the gathered EGNN features (:706-742), the
+ * conditional substitution of :758-768 INCLUDING its [K] vs [1,K,1] broadcast (the `where` result is [1,K,K] and scatter_ with
+ * an index of shape [1,K,1] consumes column 0: every top-K slot i receives where(cond(p[0], sim0[idx_i]), p[0], sim0[idx_i]),
+ * p[0] = the MLP score of the best-ranked row), W / (sum W + 1e-6) (:771), softmax over the N points (:774), / (sum + 1e-6)
+ * (:783), and the weighted Kabsch on the RAW coordinates of all N points (:786-818).  Inference only (the reference never
+ * back-propagates through this head).  Two launches.
+ *   hs, ht [B,N,F], xs, xt [B,N,3]: EGNN outputs;  raw_hs, raw_ht [B,N,F_raw], raw_xs, raw_xt [B,N,3]: the model inputs
+ *   outputs: sim [B,N] (<h_s,h_t>, unused by this head), sim0 [B,N], cosv [B,N], pos int32 [B,N] (rank in the top-K or -1),
+ *            wts [B,N] (the Kabsch weights), top_idx int64 [B,K], kabsch_R [B,9], kabsch_t [B,3], kabsch_aux [B,EQUIGSPR_KABSCH_AUX],
+ *            out_scalars [16] device: [1] = equi loss, [10 + min(b,5)] = p[0] of pair b
+ *   work: equigspr_head_work_bytes(B, N) bytes.  The reference runs this head at B = 1 only (:719,:773); pairs are independent here. */
+int equigspr_head_eval_forward(const float* hs, const float* ht, const float* raw_hs, const float* raw_ht,
+                               const float* xs, const float* xt, const float* raw_xs, const float* raw_xt,
+                               const float* labels, const float* gt_pose, const float* mlp, int32_t B, int32_t N,
+                               int32_t F, int32_t F_raw, int32_t K, float* sim, float* sim0, float* cosv, int32_t* pos,
+                               float* wts, int64_t* top_idx, void* work, float* out_scalars, float* kabsch_R,
+                               float* kabsch_t, float* kabsch_aux, void* stream);
+
 /* ---- A13 (pose part) + optimizer: small fused training-step kernels ------------------------
  * pose_loss: replaces pose_loss() (src/3dmatch_train_egnn_with_batch.py:896-962): rot_loss[b] =
  * arccos(clamp((trace(R^T R_gt)-1)/2)), trans_loss[b] = arccos(clamp(cos(t, t_gt))).  R [B,9], t [B,3],

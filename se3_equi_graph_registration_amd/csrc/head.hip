@@ -28,6 +28,8 @@ namespace eq {
 
 typedef unsigned long long u64;
 constexpr int kHeadPartials = 8;     // sum s, sum s^2, sum r, sum r^2, rot, feat, (unused x2)
+constexpr int kRowsPerBlock = 8;
+constexpr int kMaxIn = 128, kMaxH1 = 64, kMaxH2 = 32;     // MLP in = 2F, h1 = F, h2 = F/2 for F <= 64
 constexpr int kMaxN = 8192;          // head_pair_kernel keeps a pair's keys in LDS: 12 bytes per node
 
 __device__ __forceinline__ unsigned orderable(float v) {
@@ -235,6 +237,108 @@ __device__ __forceinline__ void head_weights_block(const WeightsJob& j, int xb, 
     }
 }
 
+// top-K of sb[0..N) (:684): rank r of top_idx = the r-th largest value, ties by lower index; pos[idx] = rank for the selected
+// nodes (the others keep the -1 written by head_node_kernel).  One 256-thread workgroup.  MSB radix select on the value bits
+// finds the K-th value T; candidates {v > T} + {v == T} are ranked exactly by counting; if more than kCand candidates tie
+// (degenerate inputs) fall back to a full bitonic sort.  keys: u64 [max(Npad, kCand)], khi: unsigned [N], histp: [16 * 256],
+// sel: int [3], wtot: int [4] -- all in LDS.  Ends without a barrier after the last global stores.
+constexpr int kHistCopies = 16;
+__device__ __forceinline__ void head_select_topk(const float* __restrict__ sb, int N, int Npad, int K, u64* keys, unsigned* khi,
+                                                 unsigned* histp, int* sel, int* wtot, long long* __restrict__ top_idx_b,
+                                                 int* __restrict__ pos_b) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < N; i += 256) khi[i] = ~orderable(sb[i]);
+    unsigned prefix = 0, mask = 0;
+    int need = K;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        // 16 privatised copies of the histogram (by lane & 15): the leading digits of similarity values fall into a
+        // handful of bins, and same-address LDS atomics serialise (the four passes were 18 k of this kernel's 34 k ticks)
+#pragma unroll
+        for (int r = 0; r < kHistCopies; ++r) histp[r * 256 + tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < N; i += 256) {
+            const unsigned v = khi[i];
+            if ((v & mask) == prefix) atomicAdd(&histp[(tid & (kHistCopies - 1)) * 256 + ((v >> shift) & 255u)], 1u);
+        }
+        __syncthreads();
+        {   // inclusive scan of the 256 bins (one per thread): wave scan + 4 wave totals; the selected bin is the
+            // first whose inclusive count reaches `need`
+            int c = 0;
+#pragma unroll
+            for (int r = 0; r < kHistCopies; ++r) c += (int)histp[r * 256 + tid];
+            int inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(inc, o, 64);
+                if ((tid & 63) >= o) inc += v;
+            }
+            if ((tid & 63) == 63) wtot[tid >> 6] = inc;
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < (tid >> 6); ++w) base += wtot[w];
+            inc += base;
+            if (inc >= need && inc - c < need) { sel[0] = tid; sel[1] = inc - c; sel[2] = c; }
+        }
+        __syncthreads();
+        need -= sel[1];
+        prefix |= (unsigned)sel[0] << shift;
+        mask |= 255u << shift;
+        // the keys below the selected bin (K - need of them) plus the bin itself are few enough to rank exactly: stop refining
+        // (typically after two of the four digits; block-uniform)
+        if ((K - need) + sel[2] <= kCandEarly) break;
+    }
+    EQ_STAMPK(3, 3);
+    const int n_less = K - need, n_tie = sel[2];
+    const int total = n_less + n_tie;
+    if (total <= kCand) {
+        __syncthreads();                    // every thread has read sel[] before it is reused as the candidate counter
+        if (tid == 0) sel[0] = 0;
+        __syncthreads();
+        for (int i = tid; i < N; i += 256) {
+            const unsigned v = khi[i];
+            if ((v & mask) <= prefix) keys[atomicAdd(&sel[0], 1)] = ((u64)v << 32) | (unsigned)i;
+        }
+        __syncthreads();
+        EQ_STAMPK(3, 4);
+        // <= kCand unique keys: rank by counting (one pass of broadcast LDS reads, one barrier) instead of a bitonic
+        // sort (36 barrier-separated stages at 256 keys); same order
+        for (int t = tid; t < total; t += 256) {
+            const u64 mine = keys[t];
+            int rank = 0;
+            for (int j = 0; j < total; ++j) rank += (keys[j] < mine) ? 1 : 0;
+            if (rank < K) {
+                const int idx = (int)(unsigned)(mine & 0xffffffffu);
+                top_idx_b[rank] = idx;
+                pos_b[idx] = rank;
+            }
+        }
+        EQ_STAMPK(3, 5);
+        return;
+    }
+    for (int i = tid; i < N; i += 256) keys[i] = ((u64)khi[i] << 32) | (unsigned)i;
+    for (int i = N + tid; i < Npad; i += 256) keys[i] = ~0ull;
+    const int P = Npad;
+    __syncthreads();
+    for (int k2 = 2; k2 <= P; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < P / 2; t += 256) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int hi = lo | j;
+                const bool up = (lo & k2) == 0;
+                const u64 a = keys[lo], c = keys[hi];
+                if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = tid; t < K; t += 256) {
+        const int idx = (int)(unsigned)(keys[t] & 0xffffffffu);
+        top_idx_b[t] = idx;
+        pos_b[idx] = t;
+    }
+}
+
 // K2: one workgroup per pair: softmax scalars, top-K (radix select + small bitonic sort), MLP, BCE
 __global__ __launch_bounds__(256) void head_pair_kernel(
     const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
@@ -249,7 +353,6 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double red[4];
     __shared__ float redf[4];
-    constexpr int kHistCopies = 16;
     __shared__ unsigned histp[kHistCopies * 256];
     __shared__ int sel[3];
     __shared__ int wtot[4];
@@ -305,101 +408,116 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
         pf[0] = mx; pf[1] = (float)den; pf[2] = (den > 0.0) ? 1.0f : 0.0f; pf[3] = 0.0f;
         if (b == 0) { fin[2] = (float)st[0]; fin[3] = (float)st[1]; fin[4] = (float)st[2]; fin[5] = (float)st[3]; fin[8] = (float)st[4]; fin[9] = (float)st[5]; }
     }
-    // ---- top-K (:684): ascending key == descending sim, then lower index.  MSB radix select on the value
-    //      bits finds the K-th value T; candidates {v < T} + {v == T} are sorted exactly; if more than kCand
-    //      candidates tie (degenerate inputs) fall back to a full bitonic sort.
     EQ_STAMPK(3, 2);
-    for (int i = tid; i < N; i += 256) khi[i] = ~orderable(sb[i]);
-    unsigned prefix = 0, mask = 0;
-    int need = K;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        // 16 privatised copies of the histogram (by lane & 15): the leading digits of similarity values fall into a
-        // handful of bins, and same-address LDS atomics serialise (the four passes were 18 k of this kernel's 34 k ticks)
-#pragma unroll
-        for (int r = 0; r < kHistCopies; ++r) histp[r * 256 + tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < N; i += 256) {
-            const unsigned v = khi[i];
-            if ((v & mask) == prefix) atomicAdd(&histp[(tid & (kHistCopies - 1)) * 256 + ((v >> shift) & 255u)], 1u);
-        }
-        __syncthreads();
-        {   // inclusive scan of the 256 bins (one per thread): wave scan + 4 wave totals; the selected bin is the
-            // first whose inclusive count reaches `need`
-            int c = 0;
-#pragma unroll
-            for (int r = 0; r < kHistCopies; ++r) c += (int)histp[r * 256 + tid];
-            int inc = c;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int v = __shfl_up(inc, o, 64);
-                if ((tid & 63) >= o) inc += v;
-            }
-            if ((tid & 63) == 63) wtot[tid >> 6] = inc;
-            __syncthreads();
-            int base = 0;
-            for (int w = 0; w < (tid >> 6); ++w) base += wtot[w];
-            inc += base;
-            if (inc >= need && inc - c < need) { sel[0] = tid; sel[1] = inc - c; sel[2] = c; }
-        }
-        __syncthreads();
-        need -= sel[1];
-        prefix |= (unsigned)sel[0] << shift;
-        mask |= 255u << shift;
-        // the keys below the selected bin (K - need of them) plus the bin itself are few enough to rank exactly: stop refining
-        // (typically after two of the four digits; block-uniform)
-        if ((K - need) + sel[2] <= kCandEarly) break;
+    head_select_topk(sb, N, Npad, K, keys, khi, histp, sel, wtot, top_idx + (size_t)b * K, pos + (size_t)b * N);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Evaluation pair model (src/eval_egnn_metrics.py:691-818), the part after the EGNN, per pair one 256-thread workgroup
+// (launch 2 of 2; launch 1 = head_node_kernel: sim0 = <h0_s, h0_t> on the INPUT features (:691) arrives as `rsim`, the equi-loss
+// partials (:687) as `partials`, pos = -1):
+//   top-K of sim0 (:694) -> p = mlp(cat(h_s[idx], h_t[idx])) (:706-742) -> the [K] vs [1,K,1] broadcast of :742,:758-768: the
+//   `where` result is [1,K,K] and scatter_(dim=1, index [1,K,1]) consumes column 0 only, so EVERY top-K slot i receives
+//   where(cond(p[0], sim0[idx_i]), p[0], sim0[idx_i]) -- only the MLP score of the best-ranked row is ever used, and only that
+//   row is evaluated here -> W / (sum W + 1e-6) (:771) -> softmax over the N points (:774) -> / (sum + 1e-6) (:783) ->
+//   weighted Kabsch on the RAW coordinates of all N points (:786-818).
+// out[1] = equi loss (b == 0 writes it), out[10 + min(b, 5)] = p[0] of pair b (diagnostic).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_eval_pair_kernel(
+    const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ sim0, const double* __restrict__ partials,
+    int nbp, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+    const float* __restrict__ w3, const float* __restrict__ b3, int B, int N, int Npad, int F, int K, MlpDims md,
+    int* __restrict__ pos, long long* __restrict__ top_idx, float* __restrict__ wts, const float* __restrict__ raw_xs,
+    const float* __restrict__ raw_xt, float* __restrict__ kab_R, float* __restrict__ kab_t, float* __restrict__ kab_aux,
+    float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ double red[4];
+    __shared__ float redf[4];
+    __shared__ unsigned histp[kHistCopies * 256];
+    __shared__ int sel[3];
+    __shared__ int wtot[4];
+    __shared__ float inp[kMaxIn], a1[kMaxH1], a2[kMaxH2];
+    __shared__ float p0_s;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const long long M = (long long)B * N;
+    const float* sb = sim0 + (size_t)b * N;
+    int* posb = pos + (size_t)b * N;
+    float* wb = wts + (size_t)b * N;
+    u64* keys = reinterpret_cast<u64*>(smem_raw);
+    unsigned* khi = reinterpret_cast<unsigned*>(smem_raw + sizeof(u64) * (size_t)(Npad > kCand ? Npad : kCand));
+    {
+        double st[6];
+        head_stats(partials, B * nbp, M, red, st);
+        if (b == 0 && tid == 0) { out[8] = (float)st[4]; out[9] = (float)st[5]; out[1] = (float)((st[4] + st[5]) / (double)M); }
     }
-    EQ_STAMPK(3, 3);
-    const int n_less = K - need, n_tie = sel[2];
-    const int total = n_less + n_tie;
-    int P;
-    if (total <= kCand) {
-        if (tid == 0) sel[0] = 0;
-        __syncthreads();
-        for (int i = tid; i < N; i += 256) {
-            const unsigned v = khi[i];
-            if ((v & mask) <= prefix) keys[atomicAdd(&sel[0], 1)] = ((u64)v << 32) | (unsigned)i;
-        }
-        __syncthreads();
-        EQ_STAMPK(3, 4);
-        // <= kCand unique keys: rank by counting (one pass of broadcast LDS reads, one barrier) instead of a bitonic
-        // sort (36 barrier-separated stages at 256 keys); same order
-        for (int t = tid; t < total; t += 256) {
-            const u64 mine = keys[t];
-            int rank = 0;
-            for (int j = 0; j < total; ++j) rank += (keys[j] < mine) ? 1 : 0;
-            if (rank < K) {
-                const int idx = (int)(unsigned)(mine & 0xffffffffu);
-                top_idx[(size_t)b * K + rank] = idx;
-                pos[(size_t)b * N + idx] = rank;
-            }
-        }
-        EQ_STAMPK(3, 5);
-        return;
-    } else {
-        for (int i = tid; i < N; i += 256) keys[i] = ((u64)khi[i] << 32) | (unsigned)i;
-        for (int i = N + tid; i < Npad; i += 256) keys[i] = ~0ull;
-        P = Npad;
+    head_select_topk(sb, N, Npad, K, keys, khi, histp, sel, wtot, top_idx + (size_t)b * K, posb);
+    __threadfence_block();
+    __syncthreads();
+    // ---- p[0]: the MLP on the best-ranked row (Linear(2F,F)-ReLU-Linear(F,F/2)-ReLU-Linear(F/2,1), train :594-600)
+    const int i0 = (int)top_idx[(size_t)b * K];
+    for (int c = tid; c < md.in; c += 256) {
+        const size_t rowoff = ((size_t)b * N + i0) * F;
+        inp[c] = (c < F) ? hs[rowoff + c] : ht[rowoff + (c - F)];
     }
     __syncthreads();
-    for (int k2 = 2; k2 <= P; k2 <<= 1) {
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < P / 2; t += 256) {
-                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int hi = lo | j;
-                const bool up = (lo & k2) == 0;
-                const u64 a = keys[lo], c = keys[hi];
-                if ((a > c) == up) { keys[lo] = c; keys[hi] = a; }
-            }
-            __syncthreads();
-        }
+    {   // four threads per output: partial dots over the input columns q, q + 4, ...; fixed-order sum of the four
+        const int o = tid >> 2, q = tid & 3;
+        float acc = 0.0f;
+        if (o < md.h1)
+            for (int c = q; c < md.in; c += 4) acc = fmaf(w1[(size_t)o * md.in + c], inp[c], acc);
+        const float s1 = acc + __shfl_xor(acc, 1, 64);
+        const float s2 = s1 + __shfl_xor(s1, 2, 64);
+        if (o < md.h1 && q == 0) a1[o] = fmaxf(s2 + b1[o], 0.0f);
     }
-    for (int t = tid; t < K; t += 256) {
-        const int idx = (int)(unsigned)(keys[t] & 0xffffffffu);
-        top_idx[(size_t)b * K + t] = idx;
-        pos[(size_t)b * N + idx] = t;
+    __syncthreads();
+    {
+        const int o = tid >> 2, q = tid & 3;
+        float acc = 0.0f;
+        if (o < md.h2)
+            for (int c = q; c < md.h1; c += 4) acc = fmaf(w2[(size_t)o * md.h1 + c], a1[c], acc);
+        const float s1 = acc + __shfl_xor(acc, 1, 64);
+        const float s2 = s1 + __shfl_xor(s1, 2, 64);
+        if (o < md.h2 && q == 0) a2[o] = fmaxf(s2 + b2[o], 0.0f);
     }
+    __syncthreads();
+    if (tid == 0) {
+        float z = b3[0];
+        for (int c = 0; c < md.h2; ++c) z = fmaf(w3[c], a2[c], z);
+        p0_s = z;
+        out[10 + (b < 5 ? b : 5)] = z;
+    }
+    __syncthreads();
+    const float p0 = p0_s;
+    // ---- W (:758-768), its sum, the softmax of W / (sum + 1e-6) and the final renormalisation
+    auto w_of = [&](int i) {
+        const float s = sb[i];
+        if (posb[i] < 0) return s;
+        const bool cond = (p0 > 0.5f && fabsf(p0 - 1.0f) < s) || (p0 > 0.5f && p0 < s);
+        return cond ? p0 : s;
+    };
+    double sw = 0.0;
+    for (int i = tid; i < N; i += 256) sw += (double)w_of(i);
+    sw = block_sum_d(sw, red);
+    const float denom = (float)sw + 1e-6f;
+    float mx = -INFINITY;
+    for (int i = tid; i < N; i += 256) mx = fmaxf(mx, w_of(i) / denom);
+    mx = block_max_f(mx, redf);
+    double se = 0.0;
+    for (int i = tid; i < N; i += 256) se += (double)expf(w_of(i) / denom - mx);
+    se = block_sum_d(se, red);
+    const float sef = (float)se;
+    double sn = 0.0;
+    for (int i = tid; i < N; i += 256) sn += (double)(expf(w_of(i) / denom - mx) / sef);
+    sn = block_sum_d(sn, red);
+    const float renorm = (float)sn + 1e-6f;
+    for (int i = tid; i < N; i += 256) wb[i] = (expf(w_of(i) / denom - mx) / sef) / renorm;
+    __threadfence();
+    __syncthreads();
+    // ---- weighted Kabsch on the raw coordinates, all N points (:786-818)
+    kabsch_moments_block(raw_xs, raw_xt, wts, N, kab_aux, b, 0, 1);
+    __threadfence_block();
+    __syncthreads();
+    if (tid < 64) kabsch_solve_wave(1, kab_R, kab_t, kab_aux, b, tid);
 }
 
 // out[0] = corr_loss + sim_loss, out[1] = equi loss, out[2..5] = mu_s, sd_s, mu_r, sd_r (written by K2),
@@ -428,8 +546,6 @@ __device__ __forceinline__ void head_finalize_block(const double* __restrict__ p
 
 // K2b: the correspondence MLP on the K selected rows (:760-773), kRowsPerBlock rows per workgroup so the
 // work spreads over the chip instead of one CU per pair.  grid (ceil(K/kRowsPerBlock), B)
-constexpr int kRowsPerBlock = 8;
-constexpr int kMaxIn = 128, kMaxH1 = 64, kMaxH2 = 32;
 
 // global -> LDS staging with 8 loads of a thread in flight before its 8 stores (a load/store pair per iteration exposes
 // one L2 round trip per element; the MLP blocks are latency-bound single workgroups)
@@ -889,6 +1005,52 @@ extern "C" int equigspr_head_backward(const float* hs, const float* ht, const fl
                        sim, rsim, cosv, pos, dinp, gw, W.pair_f, W.pair_g, fin_scalars, g_corr_sim, g_equi, B, N, F, K, md.in, ghs, ght,
                        gxs, gxt, W.nbp, mlp_slab, B * nblk, msz, grad_mlp, (int)flags, g_step_loss);
     EQ_CHECK_LAUNCH("head_backward");
+    return 0;
+}
+
+extern "C" int equigspr_head_eval_forward(const float* hs, const float* ht, const float* raw_hs, const float* raw_ht,
+                                          const float* xs, const float* xt, const float* raw_xs, const float* raw_xt,
+                                          const float* labels, const float* gt_pose, const float* mlp, int32_t B, int32_t N,
+                                          int32_t F, int32_t F_raw, int32_t K, float* sim, float* sim0, float* cosv, int32_t* pos,
+                                          float* wts, int64_t* top_idx, void* work, float* out_scalars, float* kabsch_R,
+                                          float* kabsch_t, float* kabsch_aux, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(hs && ht && raw_hs && raw_ht && xs && xt && raw_xs && raw_xt && labels && gt_pose && mlp && sim && sim0 && cosv &&
+                     pos && wts && top_idx && work && out_scalars && kabsch_R && kabsch_t && kabsch_aux,
+                 EQUIGSPR_EINVAL, "head_eval_forward: null pointer");
+    EQ_CHECK_ARG(B >= 1 && N >= 2 && F >= 2 && F <= 64 && F_raw >= 1 && F_raw <= 64 && K >= 1 && K <= N && N <= kMaxN,
+                 EQUIGSPR_ENOTSUP, "head_eval_forward: need 2<=F<=64, 1<=K<=N, N<=8192");
+    hipStream_t s = (hipStream_t)stream;
+    const MlpDims md{2 * F, F, F / 2};
+    const HeadWork W = head_work(work, B, N);
+    const float* w1 = mlp;
+    const float* b1 = w1 + md.h1 * md.in;
+    const float* w2 = b1 + md.h1;
+    const float* b2 = w2 + md.h2 * md.h1;
+    const float* w3 = b2 + md.h2;
+    const float* b3 = w3 + md.h2;
+    // launch 1: per node <h_s, h_t> (unused by this head), sim0 = <h0_s, h0_t> (:691), the equi-loss terms on the EGNN outputs (:687)
+    hipLaunchKernelGGL(head_node_kernel, dim3(W.nbp, B), dim3(256), 0, s, hs, ht, raw_hs, raw_ht, xs, xt, labels, gt_pose, B, N,
+                       F, F_raw, sim, sim0, cosv, pos, W.partA, W.tickets);
+    const int Npad = next_pow2(N);
+    const size_t sm = fwd_smem(N, Npad, K, md);
+    {
+        static std::mutex mu;
+        static size_t sm_set[64] = {0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || sm > sm_set[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&head_eval_pair_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+            if (e != hipSuccess) { set_error("head_eval_forward: %s", hipGetErrorString(e)); return (int)e; }
+            if (dev >= 0 && dev < 64) sm_set[dev] = sm;
+        }
+    }
+    hipLaunchKernelGGL(head_eval_pair_kernel, dim3(1, B), dim3(256), sm, s, hs, ht, sim0, W.partA, W.nbp, w1, b1, w2, b2, w3, b3, B, N,
+                       Npad, F, K, md, pos, reinterpret_cast<long long*>(top_idx), wts, raw_xs, raw_xt, kabsch_R, kabsch_t, kabsch_aux,
+                       out_scalars);
+    EQ_CHECK_LAUNCH("head_eval_forward");
     return 0;
 }
 

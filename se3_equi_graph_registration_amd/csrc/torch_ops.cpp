@@ -5,7 +5,7 @@
 // ends, and there is exactly one implementation underneath.  Built by csrc/Makefile into ../libequigspr_torch.so (g++; no device
 // code here) and loaded with torch.ops.load_library (se3_equi_graph_registration_amd/torch_library.py).
 #include <ATen/ATen.h>
-#include <c10/hip/HIPGuard.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/autograd.h>
 #include <torch/library.h>
@@ -16,7 +16,9 @@ namespace {
 
 void* cur_stream(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
 // every op runs on the device of its first tensor (the C-ABI launches on the CURRENT device: a tensor of another GPU must switch it)
-using DeviceGuard = c10::hip::HIPGuard;
+// (c10::DeviceGuard resolves the guard implementation registered for the tensor's device type: on a ROCm build of PyTorch the HIP
+// device masquerades as DeviceType::CUDA, which the un-masqueraded c10::hip::HIPGuard rejects)
+using DeviceGuard = c10::DeviceGuard;
 void same_device(const at::Tensor& a, const at::Tensor& b, const char* name) {
     TORCH_CHECK(a.device() == b.device(), "equigspr: ", name, " lives on ", b.device(), ", expected ", a.device());
 }

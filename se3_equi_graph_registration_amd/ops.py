@@ -398,6 +398,57 @@ def fused_pose_head(h_all, x_all, raw_hs, raw_ht, labels, gt_pose, topk, mlp_par
     return _HeadFn.apply(h_all, x_all, raw_hs, raw_ht, labels, gt_pose, topk, flags, *mlp_params)
 
 
+def _flat_mlp(mlp_params, msz):
+    """The pose-head MLP parameters as ONE flat fp32 tensor (a view when they are adjacent slices of a flat bucket)."""
+    p0 = mlp_params[0]
+    off, adjacent = 0, True
+    for q in mlp_params:
+        if q.data_ptr() != p0.data_ptr() + 4 * off or not q.is_contiguous():
+            adjacent = False
+            break
+        off += q.numel()
+    if adjacent and off == msz:
+        return p0.detach().reshape(-1).as_strided((msz,), (1,))
+    flat = torch.cat([q.detach().reshape(-1) for q in mlp_params])
+    if flat.numel() != msz:
+        raise RuntimeError("pose head MLP must be Linear(2F,F)-ReLU-Linear(F,F//2)-ReLU-Linear(F//2,1)")
+    return flat
+
+
+@torch.no_grad()
+def fused_eval_head(h_all, x_all, raw_hs, raw_ht, raw_xs, raw_xt, labels, gt_pose, topk, mlp_params):
+    """The evaluation pair model after the EGNN (eval :687-818) in two HIP launches (csrc/head.hip, equigspr_head_eval_forward).
+    ``h_all [2BN,F]``, ``x_all [2BN,3]`` = EGNN outputs for [src clouds..., tgt clouds...]; ``raw_*`` = the model inputs.
+    Returns ``(R [B,3,3], t [B,3], equi_loss, weights [B,N], top_idx [B,K], p0)``.  Inference only, like the reference's use."""
+    L = _lib.lib()
+    B, N, Fr = raw_hs.shape
+    Fd = h_all.shape[1]
+    dev = h_all.device
+    hs, ht = h_all[:B * N], h_all[B * N:]
+    xs, xt = x_all[:B * N], x_all[B * N:]
+    for name, t_ in (("h", h_all), ("x", x_all)):
+        _need(t_, name, torch.float32, 2)
+    raw_hs, raw_ht = _need(raw_hs.contiguous(), "h_src", torch.float32, 3), _need(raw_ht.contiguous(), "h_tgt", torch.float32, 3)
+    raw_xs, raw_xt = _need(raw_xs.contiguous(), "x_src", torch.float32, 3), _need(raw_xt.contiguous(), "x_tgt", torch.float32, 3)
+    labels = _need(labels.reshape(B, N).contiguous().float(), "labels", torch.float32, 2)
+    gt = _need(gt_pose.reshape(B, 16).contiguous().float(), "gt_pose", torch.float32, 2)
+    K = int(topk)
+    msz = int(L.equigspr_head_mlp_size(Fd))
+    flat = _flat_mlp(mlp_params, msz)
+    f32 = dict(dtype=torch.float32, device=dev)
+    sim, sim0, cosv, wts = (torch.empty(B, N, **f32) for _ in range(4))
+    pos = torch.empty(B, N, dtype=torch.int32, device=dev)
+    top_idx = torch.empty(B, K, dtype=torch.int64, device=dev)
+    work = torch.empty(int(L.equigspr_head_work_bytes(B, N)) // 8 + 1, dtype=torch.float64, device=dev)
+    fin = torch.empty(16, **f32)
+    R, t = torch.empty(B, 3, 3, **f32), torch.empty(B, 3, **f32)
+    aux = torch.empty(B, KABSCH_AUX, **f32)
+    _lib.check(L.equigspr_head_eval_forward(_p(hs), _p(ht), _p(raw_hs), _p(raw_ht), _p(xs), _p(xt), _p(raw_xs), _p(raw_xt), _p(labels),
+                                            _p(gt), _p(flat), B, N, Fd, Fr, K, _p(sim), _p(sim0), _p(cosv), _p(pos), _p(wts), _p(top_idx),
+                                            _p(work), _p(fin), _p(R), _p(t), _p(aux), _stream()), "head_eval_forward")
+    return R, t, fin[1], wts, top_idx, fin[10]
+
+
 # ----------------------------------------------------------------------------------- optional layers: trainable wrappers
 class _HipForwardAtenBackward(torch.autograd.Function):
     """Forward = a HIP kernel; backward = the same op re-expressed in PyTorch-ROCm device ops, re-run under autograd on the

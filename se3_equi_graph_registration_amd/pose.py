@@ -198,6 +198,20 @@ class CrossAttentionPoseRegression(nn.Module):
         if B != 1:
             raise RuntimeError("the evaluation head is defined for batch size 1 only (eval :719,:773)")
         hs, xs, ht, xt = self._run_egnn(h_src, x_src, edges_src, ea_src, h_tgt, x_tgt, edges_tgt, ea_tgt)
+        if self.topk > N:
+            raise RuntimeError(f"top-k of {self.topk} out of {N} points (torch.topk raises in the reference, eval :694)")
+        if (self.fused_head and not torch.is_grad_enabled() and hs.shape[-1] <= 64 and Fd <= 64 and N <= 8192
+                and self.mlp[0].in_features == 2 * hs.shape[-1]):
+            # two HIP launches (csrc/head.hip::head_eval_pair_kernel) instead of the ~35 ATen launches below; inference only,
+            # as the reference uses this head (evaluate_model runs under no_grad, eval :1150)
+            mlp_params = [self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias,
+                          self.mlp[4].weight, self.mlp[4].bias]
+            h_o, x_o = self._egnn_out
+            self._egnn_out = None
+            R, t, total_loss, wts, top_idx, p0 = ops.fused_eval_head(h_o, x_o, h_src, h_tgt, x_src, x_tgt, labels, gt_pose,
+                                                                      self.topk, mlp_params)
+            self.last_weights, self.last_top_idx, self.last_p0 = wts, top_idx, p0
+            return R, t, None, total_loss, hs, xs, ht, xt, labels
         total_loss = egnn_equi_loss(hs, xs, ht, xt, gt_pose[:, :3, :3], gt_pose[:, :3, -1], labels)
         sim0 = torch.sum(h_src * h_tgt, dim=-1, keepdim=True)                                              # :691
         _, top_idx = torch.topk(sim0.squeeze(-1), k=self.topk, dim=-1)                                     # :694
@@ -211,5 +225,6 @@ class CrossAttentionPoseRegression(nn.Module):
         W = W / (W.sum(dim=1, keepdim=True) + 1e-6)                                                        # :771
         wts = torch.softmax(W.squeeze(0).squeeze(-1), dim=-1)                                              # :774
         wts = wts / (wts.sum() + 1e-6)                                                                     # :783
+        self.last_weights, self.last_top_idx, self.last_p0 = wts.unsqueeze(0), top_idx, p[0]
         R, t = ops.weighted_kabsch(x_src, x_tgt, wts.unsqueeze(0))                                         # raw coords, all N
         return R, t, None, total_loss, hs, xs, ht, xt, labels

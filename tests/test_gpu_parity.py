@@ -294,6 +294,44 @@ def test_pair_forward_golden(pk, golden_dir, name, parity):
     assert abs(float(torch.det(Re[0])) - 1.0) < 1e-5
 
 
+@pytest.mark.parametrize("name", PAIR_FIX)
+def test_fused_eval_head_golden_and_vs_aten_glue(pk, golden_dir, name, parity):
+    """csrc/head.hip::head_eval_pair_kernel (eval :687-818 in two launches) against the reference's outputs in the fixtures, the
+    oracle's Kabsch weights (incl. the [K] vs [1,K,1] broadcast: only p[0] is used), and the same head written in ATen ops."""
+    fx = np.load(os.path.join(golden_dir, name))
+    ev = _pair_models(pk, fx)["eval"]
+    args = _pair_inputs(pk, fx)
+    out = {}
+    for fused in (True, False):
+        ev.fused_head = fused
+        with torch.no_grad():
+            R, t, scores, equi, *_ = ev(*args)
+        assert scores is None
+        out[fused] = dict(R=R.clone(), t=t.clone(), equi=equi.clone(), w=ev.last_weights.clone(), idx=ev.last_top_idx.clone(),
+                          p0=ev.last_p0.clone())
+    a, b = out[True], out[False]
+    eR, _ = parity(name, "eval_fused.R", a["R"], fx["f64.eval.R"], fx["f32.eval.R"])
+    eT, _ = parity(name, "eval_fused.t", a["t"], fx["f64.eval.t"], fx["f32.eval.t"])
+    assert eR <= NORTH_STAR_RT and eT <= NORTH_STAR_RT
+    np.testing.assert_allclose(a["equi"].item(), float(fx["f64.eval.equi_loss"]), rtol=2e-4, atol=1e-5)
+    assert set(a["idx"][0].tolist()) == set(b["idx"][0].tolist()) and int(a["idx"][0, 0]) == int(b["idx"][0, 0])
+    assert abs(float(a["p0"]) - float(b["p0"])) <= 1e-5 * max(1.0, abs(float(b["p0"])))
+    n = a["w"].shape[1]
+    assert float((a["w"] - b["w"]).abs().max()) <= 1e-5 / n             # weights are ~1/n
+    assert abs(float(a["w"].double().sum()) - 1.0) < 1e-5
+    assert torch.allclose(a["R"], b["R"], atol=2e-6) and torch.allclose(a["t"], b["t"], atol=2e-5)
+    # the oracle's weights on the same inputs (fp64), incl. which nodes had their similarity replaced by p[0]
+    from oracle import egnn_oracle as orc
+    we = {k[len("w.egnn."):]: torch.from_numpy(fx[k]).double() for k in fx.files if k.startswith("w.egnn.")}
+    wc = {k[2:]: torch.from_numpy(fx[k]).double() for k in fx.files
+          if k.startswith("w.") and not k.startswith("w.egnn.") and fx[k].dtype.kind == "f"}
+    cpu = [(x.detach().cpu().double() if x.is_floating_point() else x.detach().cpu()) for x in args]
+    with torch.no_grad():
+        _, ex = orc.pair_forward_eval(we, wc, *cpu)
+    assert set(ex["top_idx"][0].tolist()) == set(a["idx"][0].tolist())
+    assert float((a["w"][0].cpu().double() - ex["weights"]).abs().max()) <= 2e-5 / n
+
+
 def test_prebuilt_pair_graph_equals_edge_list_path(pk, golden_dir):
     fx = np.load(os.path.join(golden_dir, "pair_n512_k12_l2_wellcond.npz"))
     models = _pair_models(pk, fx)
@@ -957,6 +995,35 @@ def test_build_correspondences_vs_oracle(pk, n, m, dim, mutual):
         assert 0 < labels_o.sum() < labels_o.size or n < 10
 
 
+def test_match_kernels_golden(pk, golden_dir):
+    """csrc/match.hip against the correspondences and labels the REAL data_preprocess/3DMatch_Feature.py produced on the same
+    descriptors / key points (tests/golden/match_cases.npz, both splits, with and without the mutual check).  Index parity is exact
+    on every row / column whose best and second-best descriptor distances differ by more than the fp32 round-off of a 33-term dot
+    product (the fixture stores that gap); labels on every correspondence further than 1e-5 from the 0.10 m threshold."""
+    fx = np.load(os.path.join(golden_dir, "match_cases.npz"))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    for name in fx["cases"]:
+        g = lambda k: fx[f"{name}.{k}"]  # noqa: E731
+        mutual = bool(g("mutual"))
+        idx, _ = pk.match_descriptors(t(g("feat_0")), t(g("feat_1")))
+        rows = g("row_gap") > 2e-6
+        assert rows.mean() > 0.99
+        s64, t64 = g("feat_0").astype(np.float64), g("feat_1").astype(np.float64)
+        want_idx = np.argmin(2 - 2 * (s64 @ t64.T), axis=1)
+        assert np.array_equal(idx.cpu().numpy()[rows], want_idx[rows]), name
+        corr, labels, _ = pk.build_correspondences(t(g("feat_0")), t(g("feat_1")), t(g("xyz_0")), t(g("xyz_1")),
+                                                   t(g("gt_pose").astype(np.float32)), use_mutual=mutual, inlier_threshold=0.10)
+        corr, labels = corr.cpu().numpy(), labels.cpu().numpy()
+        if rows.all() and (not mutual or (g("col_gap") > 2e-6).all()):
+            assert np.array_equal(corr, g("corr")), name
+            clear = g("thr_gap") > 1e-5
+            assert clear.mean() > 0.99 and np.array_equal(labels[clear], g("labels")[clear]), name
+        else:                               # a near-tie somewhere: compare the correspondences both sides agree on
+            ref = {tuple(r): l for r, l in zip(g("corr").tolist(), g("labels").tolist())}
+            common = [i for i, r in enumerate(corr.tolist()) if tuple(r) in ref]
+            assert len(common) > 0.98 * len(ref), name
+
+
 def test_egnn_degenerate_graphs_vs_oracle(pk):
     """Edge cases of the graph input: no edges at all (every node isolated), a single node, one self loop."""
     torch.manual_seed(3)
@@ -1163,7 +1230,19 @@ def test_torch_library_ops_match_the_ctypes_path(pk):
     Rr, tt = pk.weighted_kabsch(sr, tr, wr)
     (Rr.sum() + tt.sum()).backward()
     assert torch.allclose(gs, sr.grad) and torch.allclose(gt_, tr.grad) and torch.allclose(gw, wr.grad)
+    # autograd through the dispatcher: weighted_kabsch_forward has an Autograd kernel (the C-ABI backward) ...
+    s2, t2_, w2 = src.clone().requires_grad_(True), tgt.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    Rd, td, _ = ops.weighted_kabsch_forward(s2, t2_, w2)
+    (Rd.sum() + td.sum()).backward()
+    assert torch.allclose(s2.grad, sr.grad) and torch.allclose(t2_.grad, tr.grad) and torch.allclose(w2.grad, wr.grad)
+    # ... and the inference-form egnn_forward refuses tensors that want a gradient instead of silently detaching them
+    with pytest.raises(RuntimeError, match="inference form"):
+        ops.egnn_forward(m.flat_params, h.clone().requires_grad_(True), x, row32, col32, torch.ones(n * k, device="cuda"), 32, 32, 2, 1, 0)
     with pytest.raises(RuntimeError):
         ops.egnn_forward(m.flat_params[:-1].contiguous(), h, x, row32, col32, None, 32, 32, 2, 1, 0)
+    with pytest.raises(RuntimeError, match="same length"):
+        ops.egnn_forward(m.flat_params, h, x, row32, col32[:-1].contiguous(), torch.ones(n * k, device="cuda"), 32, 32, 2, 1, 0)
+    with pytest.raises(RuntimeError, match="unsupported configuration"):
+        ops.egnn_forward(m.flat_params, h, x, row32, col32, torch.ones(n * k, device="cuda"), 32, 32, 2, 5, 0)
     with pytest.raises(RuntimeError):
         ops.knn_graph(x.double(), k, True)

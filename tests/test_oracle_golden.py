@@ -208,3 +208,18 @@ def test_pointnet_golden(golden_dir):
         assert np.abs(h1.numpy() - fx["conv1_" + tag]).max() <= tol * max(1.0, np.abs(fx["conv1_" + tag]).max())
         assert np.abs(pooled.numpy() - fx["pooled_" + tag]).max() <= tol * max(1.0, np.abs(fx["pooled_" + tag]).max())
         assert (h1.numpy()[3] == 0).all()                 # the node without incoming edges
+
+
+def test_correspondence_construction_golden(golden_dir):
+    """N3: oracle.build_correspondences vs what the REAL data_preprocess/3DMatch_Feature.py wrote (:157-196 train split,
+    :331-351 test split; fixtures from tests/golden/gen_match_golden.py, which executes that script on a synthetic dataset tree)."""
+    fx = np.load(os.path.join(golden_dir, "match_cases.npz"))
+    assert len(fx["cases"]) == 8
+    for name in fx["cases"]:
+        g = lambda k: fx[f"{name}.{k}"]  # noqa: E731
+        corr, labels, _, _ = orc.build_correspondences(g("feat_0"), g("feat_1"), g("xyz_0").astype(np.float64), g("xyz_1").astype(np.float64),
+                                                       g("gt_pose"), bool(g("mutual")), 0.10)
+        assert np.array_equal(corr, g("corr")), name
+        clear = g("thr_gap") > 1e-6              # the script labelled the un-rounded fp64 points; the record holds them as fp32
+        assert clear.mean() > 0.99 and np.array_equal(labels[clear], g("labels")[clear]), name
+        assert 0 < g("labels").sum() < g("labels").size

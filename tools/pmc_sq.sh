@@ -13,7 +13,7 @@ n=0
 for P in "$P1" "$P2" "$P3"; do
   n=$((n+1))
   rm -rf /tmp/pmc_$n
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/pmc_$n -- python3 $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph --min-seconds 0 "$@" > $OUT/pmc_$n.log 2>&1
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d /tmp/pmc_$n -- python3 $ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-workloads --no-graph --min-seconds 0 "$@" > $OUT/pmc_$n.log 2>&1
   cp "$(find /tmp/pmc_$n -name '*counter_collection.csv' | head -1)" $OUT/pmc_$n.csv
 done
 python3 - $OUT <<'PY'

@@ -1,6 +1,6 @@
 # Launch sequence (start offset us, duration us, kernel) of the last full training step of a short bench run under rocprofv3.
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d /tmp/seq -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --min-seconds 0 --steps 3 --warmup 2 > /tmp/seq.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/seq -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-workloads --min-seconds 0 --steps 3 --warmup 2 > /tmp/seq.log 2>&1
 f=$(find /tmp/seq -name "*kernel_trace.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
