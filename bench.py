@@ -285,8 +285,8 @@ def split_graph_runner(S, args, dist_on, eager):
 #   weight-gradient outer products (16 + 16 + 8).  hidden_nf 33 runs the SAME matrix instructions on its 32 x 32 cores; feature 32
 #   (the "border") is vector-ALU work on top (its column of a product = 8 FMAs, its row a partial dot + one lane-group sum).
 # valu = vector-ALU instructions per sub-tile (SQ_INSTS_VALU - SQ_INSTS_MFMA over the sub-tiles of a launch; profiles/r03_sq_edge_kernels.json)
-MFMA_PER_TILE = {32: dict(edges=16, flop=2048, fwd=40, bwd=120, valu_fwd=190, valu_bwd=400),
-                 33: dict(edges=16, flop=2048, fwd=40, bwd=120, valu_fwd=290, valu_bwd=640)}
+MFMA_PER_TILE = {32: dict(edges=16, flop=2048, fwd=40, bwd=120, valu_fwd=210, valu_bwd=435),
+                 33: dict(edges=16, flop=2048, fwd=40, bwd=120, valu_fwd=296, valu_bwd=654)}
 SIMDS, ISSUE_CLOCK_GHZ = 1024, 2.1          # 256 CUs x 4 SIMDs; the clock the chip holds under this load
 
 

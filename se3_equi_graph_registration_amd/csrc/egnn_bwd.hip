@@ -713,6 +713,9 @@ __global__ __launch_bounds__(256, 2) void gather_node_bwd_kernel(
 // front / back phases.
 // ---------------------------------------------------------------------------------------
 constexpr int kBwd16Waves = 8;
+#ifndef EQ_BWD16_RUNSUM
+#define EQ_BWD16_RUNSUM 0             // 1: db6 / db2 as per-lane running sums instead of column sums of pass16's tile reads (A/B knob)
+#endif
 #ifndef EQ_BWD16_NW33
 #define EQ_BWD16_NW33 8                // waves per workgroup (= 2 x waves per SIMD) of the hidden_nf = 33 variant
 #endif
@@ -747,14 +750,16 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
     float* Y = sc + C::o_y;
 
     f32x4 acc6[2][2], acc2[2][2], accg[2][1];
-    float cs_b6[2] = {0.0f, 0.0f}, cs_b2[2] = {0.0f, 0.0f}, cs_none[2] = {0.0f, 0.0f};
+    constexpr bool kRun = EQ_BWD16_RUNSUM && (kB == 0);                 // db6 / db2 as per-lane running sums (hidden_nf 32) or as column sums of pass16's tile reads (33)
+    f32x2 cs_none = {0.0f, 0.0f}, cs_b6 = {0.0f, 0.0f}, cs_b2 = {0.0f, 0.0f};
+    f32x4 ls_b6[2], ls_b2[2];                          // db6 = sum dq, db2 = sum du: per-lane running sums like dw7 / dgamma / dbeta
     f32x4 ls_w7[2], ls_gam[2], ls_bet[2];             // dw7, dgamma, dbeta: per-lane running sums, reduced once after the loop
     PassBorder pb6, pb2, pbg;                          // hidden_nf = 33: row / column 32 of dW6, dW2, row 32 of dWgeo
-    float lsb_w7 = 0.0f, lsb_gam = 0.0f, lsb_bet = 0.0f;     // ... and entry 32 of dw7, dgamma, dbeta (every lane of an edge adds the same)
+    float lsb_w7 = 0.0f, lsb_gam = 0.0f, lsb_bet = 0.0f, lsb_b6 = 0.0f, lsb_b2 = 0.0f;     // ... and entry 32 of dw7, dgamma, dbeta (every lane of an edge adds the same)
     pb6.init(); pb2.init(); pbg.init();
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-        ls_w7[a] = splat4(0.0f); ls_gam[a] = splat4(0.0f); ls_bet[a] = splat4(0.0f);
+        ls_w7[a] = splat4(0.0f); ls_gam[a] = splat4(0.0f); ls_bet[a] = splat4(0.0f); ls_b6[a] = splat4(0.0f); ls_b2[a] = splat4(0.0f);
         accg[a][0] = splat4(0.0f);
 #pragma unroll
         for (int b = 0; b < 2; ++b) { acc6[a][b] = splat4(0.0f); acc2[a][b] = splat4(0.0f); }
@@ -786,16 +791,11 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
         const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
         __builtin_amdgcn_wave_barrier();
         // first sub-tile's projection rows and dagg row: in flight with the coordinate gathers
-        PRowsT<kB> pw;
-        f32x4 da[2];
-        float dab = 0.0f;
-        {
-            const int rr = idx_r[i];
-            pw.load(P, rr, idx_c[i], g);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) da[b] = ldg4(dagg + (size_t)rr * FP + 16 * b + 4 * g);
-            if (kB) dab = dagg[(size_t)rr * FP + 32];
-        }
+        // the sub-tiles alternate between two register sets for their gathered projection rows: a sub-tile computes from one set
+        // while the next one's requests land in the other -- no copies at the end of a sub-tile.  The dagg row of a sub-tile is
+        // first used half way through it (dm): it is requested at the sub-tile's own start.
+        PRowsT<kB> ra, rb;
+        ra.load(P, idx_r[i], idx_c[i], g);
         const int chn = ch + ch_step;                  // the next chunk's indices
         int rn = r, cn = c, en = e;
         if (chn < n_chunks) { en = edge_of(chn); rn = row[en]; cn = col[en]; }
@@ -812,26 +812,23 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
         EQ_STAMP(3);
 
         const int n_sub = (cnt + 15) >> 4;
-        for (int sub = 0; sub < n_sub; ++sub) {
+        auto tile = [&](int sub, PRowsT<kB>& cur, PRowsT<kB>& nxt) __attribute__((always_inline)) {
             const int el = sub * 16 + i;
             const bool valid = el < cnt;
             const float ds = ds_buf[el];
             float* geo_rows = sc + C::o_geo + sub * 16 * C::GS;
             // next sub-tile's rows, requested before this one computes (the last one re-requests its own: harmless).  hidden_nf
-            // 33 has no registers to hold them (52 spilled at the 256 cap): it requests its rows when it needs them.
+            // 33 has no registers to hold them: it requests its rows when it needs them.
             constexpr bool kAhead = (kB == 0) || (EQ_BWD16_NW33 == 4);
-            PRowsT<kB> pn;
-            f32x4 dan[2];
-            float danb = 0.0f;
-            if (kAhead || sub > 0) {
-                const int eln = (kAhead ? (sub + 1 < n_sub ? sub + 1 : sub) : sub) * 16 + i;
-                const int rrn = idx_r[eln];
-                pn.load(P, rrn, idx_c[eln], g);
+            const int rr = idx_r[el];
+            if (!kAhead && sub > 0) cur.load(P, rr, idx_c[el], g);
+            f32x4 da[2];
 #pragma unroll
-                for (int b = 0; b < 2; ++b) dan[b] = ldg4(dagg + (size_t)rrn * FP + 16 * b + 4 * g);
-                if (kB) danb = dagg[(size_t)rrn * FP + 32];
-                if (!kAhead) { pw = pn; da[0] = dan[0]; da[1] = dan[1]; dab = danb; }
-            }
+            for (int b = 0; b < 2; ++b) da[b] = ldg4(dagg + (size_t)rr * FP + 16 * b + 4 * g);
+            const float dab = kB ? dagg[(size_t)rr * FP + 32] : 0.0f;
+            const int eln = (sub + 1 < n_sub ? sub + 1 : sub) * 16 + i;
+            if (kAhead) nxt.load(P, idx_r[eln], idx_c[eln], g);
+            const PRowsT<kB>& pw = cur;
             Sub16 o;
             tile_forward16<kB>(wsm, bord, geo_rows + i * C::GS, pw, i, g, o);
             if (g == 0) s_buf[el] = o.s;
@@ -840,10 +837,10 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             float dqb = 0.0f;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const f32x4 w7 = lds4(wsm + W16::o_vec + 4 * 32 + 16 * b + 4 * g);
-                const f32x4 sg = o.sgq[b], one = splat4(1.0f);
-                ls_w7[b] += (o.q[b] * sg) * splat4(ds);
-                dq[b] = w7 * splat4(ds) * (sg * (one + o.q[b] * (one - sg)));
+                const f32x4 w7ds = lds4(wsm + W16::o_vec + 4 * 32 + 16 * b + 4 * g) * splat4(ds);
+                ls_w7[b] = fma4(o.q[b] * o.sgq[b], splat4(ds), ls_w7[b]);
+                dq[b] = w7ds * silu_grad4(o.q[b], o.sgq[b]);
+                if (kRun) ls_b6[b] += dq[b];
                 st4(X + i * C::LD + 16 * b + 4 * g, dq[b]);
                 st4(Y + i * C::LD + 16 * b + 4 * g, o.m[b]);
             }
@@ -853,7 +850,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
                 if (g == 0) { X[i * C::LD + 32] = dqb; Y[i * C::LD + 32] = o.mb; }
             }
             __builtin_amdgcn_wave_barrier();
-            pass16<2, true, kB>(X, Y, C::LD, i, g, acc6, cs_b6, pb6);     // dW6 += dq^T m ; db6 += sum dq
+            pass16<2, !kRun, kB>(X, Y, C::LD, i, g, acc6, cs_b6, pb6);     // dW6 += dq^T m (; db6 += sum dq)
             __builtin_amdgcn_wave_barrier();
             EQ_STAMP(10);
             // ---- dm = dagg[row] + W6^T dq   (padding edges: dq = 0 and dagg masked)
@@ -869,16 +866,14 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             f32x4 du[2];
             float dub = 0.0f;
             {
-                float p1 = 0.0f, p2 = 0.0f;
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
-                    ls_gam[b] += dm[b] * o.xhat[b];
+                    ls_gam[b] = fma4(dm[b], o.xhat[b], ls_gam[b]);
                     ls_bet[b] += dm[b];
                     du[b] = dm[b] * lds4(wsm + W16::o_vec + 1 * 32 + 16 * b + 4 * g);
-                    p1 += hsum4(du[b]);
-                    p2 += hsum4(du[b] * o.xhat[b]);
                 }
-                float m1 = gsum(p1), m2 = gsum(p2);
+                float m1 = hsum8(du[0], du[1]), m2 = hsum4(fma4(du[1], o.xhat[1], du[0] * o.xhat[0]));
+                gsum2(m1, m2);
                 if constexpr (kB == 1) {
                     lsb_gam = fmaf(dmb, o.xhatb, lsb_gam);
                     lsb_bet += dmb;
@@ -886,24 +881,24 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
                     m1 += dub;
                     m2 = fmaf(dub, o.xhatb, m2);
                 }
-                m1 *= (1.0f / F); m2 *= (1.0f / F);
+                m1 *= -(1.0f / F); m2 *= -(1.0f / F);
 #pragma unroll
-                for (int b = 0; b < 2; ++b) du[b] = splat4(o.rstd) * (du[b] - splat4(m1) - o.xhat[b] * splat4(m2));
-                if constexpr (kB == 1) dub = o.rstd * (dub - m1 - o.xhatb * m2);
+                for (int b = 0; b < 2; ++b) du[b] = splat4(o.rstd) * fma4(o.xhat[b], splat4(m2), du[b] + splat4(m1));
+                if constexpr (kB == 1) dub = o.rstd * (dub + m1 + o.xhatb * m2);
             }
             f32x4 sgp[2];
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const f32x4 sg = o.sg1[b], one = splat4(1.0f);
-                sgp[b] = sg * (one + o.t1[b] * (one - sg));                 // SiLU'(t1)
+                sgp[b] = silu_grad4(o.t1[b], o.sg1[b]);                     // SiLU'(t1)
+                if (kRun) ls_b2[b] += du[b];
                 st4(X + i * C::LD + 16 * b + 4 * g, du[b]);
-                st4(Y + i * C::LD + 16 * b + 4 * g, o.t1[b] * sg);
+                st4(Y + i * C::LD + 16 * b + 4 * g, o.t1[b] * o.sg1[b]);
             }
             if constexpr (kB == 1) {
                 if (g == 0) { X[i * C::LD + 32] = dub; Y[i * C::LD + 32] = o.t1b * o.sg1b; }
             }
             __builtin_amdgcn_wave_barrier();
-            pass16<2, true, kB>(X, Y, C::LD, i, g, acc2, cs_b2, pb2);     // dW2 += du^T SiLU(t1) ; db2 += sum du
+            pass16<2, !kRun, kB>(X, Y, C::LD, i, g, acc2, cs_b2, pb2);     // dW2 += du^T SiLU(t1) (; db2 += sum du)
             __builtin_amdgcn_wave_barrier();
             EQ_STAMP(12);
             // ---- dt1 = (W2^T du) * SiLU'(t1)
@@ -942,8 +937,15 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             __builtin_amdgcn_wave_barrier();
             st4(geo_rows + i * C::GS + 4 * g, dg);
             __builtin_amdgcn_wave_barrier();
-            if (kAhead) { pw = pn; da[0] = dan[0]; da[1] = dan[1]; dab = danb; }
             EQ_STAMP(13);
+        };
+        if constexpr (kB == 0) {
+            for (int sub = 0; sub < n_sub; sub += 2) {
+                tile(sub, ra, rb);
+                if (sub + 1 < n_sub) tile(sub + 1, rb, ra);
+            }
+        } else {                                       // hidden_nf 33 requests its rows when it needs them: one register set
+            for (int sub = 0; sub < n_sub; ++sub) tile(sub, ra, ra);
         }
         // ---- back: one lane per edge, geometry backward (the geometry forward is recomputed from the stashed coordinates:
         // ~60 instructions per chunk against ~30 registers held across the sub-tile loop)
@@ -975,13 +977,13 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
     };
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        cs_b6[b] = gsum(cs_b6[b]);
-        cs_b2[b] = gsum(cs_b2[b]);
+        if (!kRun) { cs_b6[b] = gsum(cs_b6[b]); cs_b2[b] = gsum(cs_b2[b]); }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                   // per-lane sums: over the 16 edges (lanes) of the group
             ls_w7[b][k] = lane16_sum(ls_w7[b][k]);
             ls_gam[b][k] = lane16_sum(ls_gam[b][k]);
             ls_bet[b][k] = lane16_sum(ls_bet[b][k]);
+            if (kRun) { ls_b6[b][k] = lane16_sum(ls_b6[b][k]); ls_b2[b][k] = lane16_sum(ls_b2[b][k]); }
         }
         if constexpr (kB == 1) {
             pb6.bcol[b] = gsum(pb6.bcol[b]); pb6.brow[b] = gsum(pb6.brow[b]);
@@ -991,8 +993,8 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
     if constexpr (kB == 1) {
         pbg.brow[0] = gsum(pbg.brow[0]);
         pb6.corner = gsum(pb6.corner); pb2.corner = gsum(pb2.corner);
-        pb6.xbs = gsum(pb6.xbs); pb2.xbs = gsum(pb2.xbs);
-        lsb_w7 = lane16_sum(lsb_w7); lsb_gam = lane16_sum(lsb_gam); lsb_bet = lane16_sum(lsb_bet);     // g = 0's copy is written
+        lsb_w7 = lane16_sum(lsb_w7); lsb_gam = lane16_sum(lsb_gam); lsb_bet = lane16_sum(lsb_bet);
+        lsb_b6 = gsum(pb6.xbs); lsb_b2 = gsum(pb2.xbs);     // g = 0's copy is written
     }
     __builtin_amdgcn_wave_barrier();
     {
@@ -1012,13 +1014,13 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
                     sl[SB::e_gam + orow] = ls_gam[bx][k];
                     sl[SB::e_bet + orow] = ls_bet[bx][k];
                     sl[SB::e_w7 + orow] = ls_w7[bx][k];
+                    if (kRun) { sl[SB::e_b6 + orow] = ls_b6[bx][k]; sl[SB::e_b2 + orow] = ls_b2[bx][k]; }
                 }
             }
         if (g == 0) {
 #pragma unroll
             for (int bx = 0; bx < 2; ++bx) {
-                sl[SB::e_b2 + 16 * bx + i] = cs_b2[bx];
-                sl[SB::e_b6 + 16 * bx + i] = cs_b6[bx];
+                if (!kRun) { sl[SB::e_b2 + 16 * bx + i] = cs_b2[bx]; sl[SB::e_b6 + 16 * bx + i] = cs_b6[bx]; }
                 if constexpr (kB == 1) {
                     sl[SB::e_w6 + (16 * bx + i) * F + 32] = pb6.bcol[bx];      // column 32, rows 0..31
                     sl[SB::e_w6 + 32 * F + 16 * bx + i] = pb6.brow[bx];        // row 32, columns 0..31
@@ -1030,7 +1032,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
                 sl[SB::e_geo + 32 * 16 + i] = pbg.brow[0];
                 if (i == 0) {
                     sl[SB::e_w6 + 32 * F + 32] = pb6.corner; sl[SB::e_w2 + 32 * F + 32] = pb2.corner;
-                    sl[SB::e_b6 + 32] = pb6.xbs; sl[SB::e_b2 + 32] = pb2.xbs;
+                    sl[SB::e_b6 + 32] = lsb_b6; sl[SB::e_b2 + 32] = lsb_b2;
                     sl[SB::e_w7 + 32] = lsb_w7; sl[SB::e_gam + 32] = lsb_gam; sl[SB::e_bet + 32] = lsb_bet;
                 }
             }

@@ -36,7 +36,7 @@ struct PassBorder {
     __device__ __forceinline__ void init() { bcol[0] = bcol[1] = brow[0] = brow[1] = corner = xbs = 0.0f; }
 };
 template <int NBY, bool kColSum, int kB = 0>
-__device__ __forceinline__ void pass16(const float* X, const float* Y, int ldy, int i, int g, f32x4 (&acc)[2][NBY], float (&cs)[2],
+__device__ __forceinline__ void pass16(const float* X, const float* Y, int ldy, int i, int g, f32x4 (&acc)[2][NBY], f32x2& cs,
                                        PassBorder& pb) {
     float a0[4], a1[4], b0[4], b1[4], xb[4], yb[4];
 #pragma unroll
@@ -51,7 +51,7 @@ __device__ __forceinline__ void pass16(const float* X, const float* Y, int ldy, 
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        if (kColSum) { cs[0] += a0[s]; cs[1] += a1[s]; }
+        if (kColSum) cs += f32x2{a0[s], a1[s]};          // the two column sums as one packed add
         acc[0][0] = mfma16(a0[s], b0[s], acc[0][0]);
         acc[1][0] = mfma16(a1[s], b0[s], acc[1][0]);
         if constexpr (NBY == 2) {

@@ -26,6 +26,23 @@ __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ f32x4 ldg4(const float* __restrict__ p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Vector-form arithmetic: hipcc maps <2 x float> multiplies / adds / fmas to v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, which
+// issue in the time of ONE v_fma_f32 for two results (tools/dev/valu_cost.hip) -- and the edge kernels are bound by the number
+// of vector + matrix instructions they issue, so every per-feature expression is written on whole f32x4 values.
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+// sigmoid_fast (egnn_math.h) on four values: 2 packed multiplies, 4 v_exp_f32, 2 packed adds, 4 v_rcp_f32 (same arithmetic per element)
+__device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
+    const f32x4 t = v * splat4(-1.4426950408889634f);
+    const f32x4 e = f32x4{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1]), __builtin_amdgcn_exp2f(t[2]), __builtin_amdgcn_exp2f(t[3])} + splat4(1.0f);
+    return f32x4{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1]), __builtin_amdgcn_rcpf(e[2]), __builtin_amdgcn_rcpf(e[3])};
+}
+// SiLU'(x) = s (1 + x (1 - s)) with s = sigmoid(x), as two fused steps: a = x - x s, s + s a
+__device__ __forceinline__ f32x4 silu_grad4(f32x4 x, f32x4 sg) { return fma4(sg, fma4(-x, sg, x), sg); }
+__device__ __forceinline__ float hsum4(f32x4 v) { const f32x2 t = v.lo + v.hi; return t[0] + t[1]; }
+// sum of the eight entries of two vectors: (a + b) packed, then the halves, then the pair
+__device__ __forceinline__ float hsum8(f32x4 a, f32x4 b) { return hsum4(a + b); }
+
 // sum over the four lane groups g of an edge (lanes e, e + 16, e + 32, e + 48): two VALU lane swaps (v_permlane16_swap,
 // v_permlane32_swap: no LDS round trip, unlike ds_bpermute); every lane of the edge gets the bit-identical sum
 __device__ __forceinline__ float gsum(float v) {
@@ -33,6 +50,19 @@ __device__ __forceinline__ float gsum(float v) {
     const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);                // rows 0+1 | 2+3
     const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// gsum of TWO values for the price of three lane swaps instead of four (same summation order as gsum, bit-identical sums):
+// swap16(p, q) + add -> rows [p0+p1 | q0+q1 | p2+p3 | q2+q3]; swap32 with itself + add -> [P | Q | P | Q]; swap16 with itself
+// hands every row both totals.
+__device__ __forceinline__ void gsum2(float& p, float& q) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(q), false, false);
+    const float u = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false);
+    const float w = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    const auto c = __builtin_amdgcn_permlane16_swap(__float_as_uint(w), __float_as_uint(w), false, false);
+    p = __uint_as_float(c[0]);
+    q = __uint_as_float(c[1]);
 }
 
 // LDS image of a layer's edge-MLP weights.  Row strides chosen so that the per-lane 16-byte operand fetches
@@ -138,20 +168,11 @@ __device__ __forceinline__ void mv16(const float* mat, int i, int g, const f32x4
 // border of y = W v (hidden_nf = 33): acc += W[:, 32] vb (column vector `col`), returns W[32, :32] . v + wcc vb (row vector `row`)
 __device__ __forceinline__ float mv16_border(const float* col, const float* row, float wcc, int g, const f32x4 (&v)[2], float vb,
                                              f32x4 (&acc)[2]) {
-    float p = 0.0f;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        acc[b] += lds4(col + 16 * b + 4 * g) * splat4(vb);
-        const f32x4 t = lds4(row + 16 * b + 4 * g) * v[b];
-        p += (t[0] + t[1]) + (t[2] + t[3]);
-    }
-    return gsum(p) + wcc * vb;
+    for (int b = 0; b < 2; ++b) acc[b] = fma4(lds4(col + 16 * b + 4 * g), splat4(vb), acc[b]);
+    const float p = hsum4(fma4(lds4(row + 16 + 4 * g), v[1], lds4(row + 4 * g) * v[0]));
+    return fmaf(wcc, vb, gsum(p));
 }
-
-__device__ __forceinline__ f32x4 sigmoid4(f32x4 v) {
-    return f32x4{sigmoid_fast(v[0]), sigmoid_fast(v[1]), sigmoid_fast(v[2]), sigmoid_fast(v[3])};
-}
-__device__ __forceinline__ float hsum4(f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 
 // forward state of one 16-edge sub-tile (what the backward needs of it); the *b members: feature 32 (hidden_nf = 33)
 struct Sub16 {
@@ -169,17 +190,19 @@ struct PRowsT {
     static constexpr int FP = 32 + 4 * kB;
     f32x4 pr[2], pc[2];
     float prb, pcb;
-    __device__ __forceinline__ void load(const float* __restrict__ P, int r, int c, int g) {
+    __device__ __forceinline__ void load_r(const float* __restrict__ P, int r, int g) {       // row side: W_src h[row], a scattered gather
         const float* a = P + (size_t)r * (2 * FP);
-        const float* b_ = P + (size_t)c * (2 * FP) + FP;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            pr[b] = ldg4(a + 16 * b + 4 * g);
-            pc[b] = ldg4(b_ + 16 * b + 4 * g);
-        }
+        pr[0] = ldg4(a + 4 * g);
+        pr[1] = ldg4(a + 16 + 4 * g);
         prb = kB ? a[32] : 0.0f;
+    }
+    __device__ __forceinline__ void load_c(const float* __restrict__ P, int c, int g) {       // col side: W_tgt h[col] + b1; consecutive edges share their centre
+        const float* b_ = P + (size_t)c * (2 * FP) + FP;
+        pc[0] = ldg4(b_ + 4 * g);
+        pc[1] = ldg4(b_ + 16 + 4 * g);
         pcb = kB ? b_[32] : 0.0f;
     }
+    __device__ __forceinline__ void load(const float* __restrict__ P, int r, int c, int g) { load_r(P, r, g); load_c(P, c, g); }
 };
 using PRows = PRowsT<0>;
 
@@ -221,17 +244,18 @@ __device__ __forceinline__ void tile_forward16(const float* wsm, const float* bo
     }
     EQ_STAMP(6);
     // LayerNorm over the hidden features (biased variance, eps 1e-5; :249)
-    const float mean = (gsum(hsum4(u[0]) + hsum4(u[1])) + ub) * kInvF;
-    f32x4 c0 = u[0] - splat4(mean), c1 = u[1] - splat4(mean);
-    const float cb = ub - mean;
-    const float var = (gsum(hsum4(c0 * c0) + hsum4(c1 * c1)) + (kB ? cb * cb : 0.0f)) * kInvF;
+    const float nmean = (kB ? gsum(hsum8(u[0], u[1])) + ub : gsum(hsum8(u[0], u[1]))) * -kInvF;
+    const f32x4 c0 = u[0] + splat4(nmean), c1 = u[1] + splat4(nmean);
+    const float cb = ub + nmean;
+    const float sq = gsum(hsum4(fma4(c1, c1, c0 * c0)));
+    const float var = (kB ? fmaf(cb, cb, sq) : sq) * kInvF;
     o.rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
     o.xhat[0] = c0 * splat4(o.rstd);
     o.xhat[1] = c1 * splat4(o.rstd);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const f32x4 gam = lds4(wsm + W16::o_vec + 1 * 32 + 16 * b + 4 * g), bet = lds4(wsm + W16::o_vec + 2 * 32 + 16 * b + 4 * g);
-        o.m[b] = o.xhat[b] * gam + bet;
+        o.m[b] = fma4(o.xhat[b], gam, bet);
         o.q[b] = lds4(wsm + W16::o_vec + 3 * 32 + 16 * b + 4 * g);     // b6
     }
     EQ_STAMP(7);
@@ -242,14 +266,12 @@ __device__ __forceinline__ void tile_forward16(const float* wsm, const float* bo
         o.qb = bord[W16::b_sc + 5] + mv16_border(bord + W16::b_w6col, bord + W16::b_w6row, bord[W16::b_sc + 1], g, o.m, o.mb, o.q);
     }
     EQ_STAMP(8);
-    float sp = 0.0f;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        o.sgq[b] = sigmoid4(o.q[b]);
-        const f32x4 w7 = lds4(wsm + W16::o_vec + 4 * 32 + 16 * b + 4 * g);
-        sp += hsum4(w7 * (o.q[b] * o.sgq[b]));
+    {
+        o.sgq[0] = sigmoid4(o.q[0]);
+        o.sgq[1] = sigmoid4(o.q[1]);
+        const f32x4 w70 = lds4(wsm + W16::o_vec + 4 * 32 + 4 * g), w71 = lds4(wsm + W16::o_vec + 4 * 32 + 16 + 4 * g);
+        o.s = gsum(hsum4(fma4(w71, o.q[1] * o.sgq[1], w70 * (o.q[0] * o.sgq[0]))));
     }
-    o.s = gsum(sp);
     if constexpr (kB == 1) {
         o.sgqb = sigmoid_fast(o.qb);
         o.s = fmaf(bord[W16::b_sc + 6], o.qb * o.sgqb, o.s);

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
     };
 
     f32x4 accA[2][2], accB[2][2], acc4a[2][2], acc4b[2][2], acc5[2][2], accE[2][2];      // accE: dW_out or dW_in (kE)
-    float cs_be[2] = {0.0f, 0.0f};
+    f32x2 cs_be = {0.0f, 0.0f};
     PassBorder pbE;
     pbE.init();
 #pragma unroll
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
         }
         vb_ = kB ? p_[32] : 0.0f;
     };
-    float cs_b1[2] = {0.0f, 0.0f}, cs_b4[2] = {0.0f, 0.0f}, cs_b5[2] = {0.0f, 0.0f}, cs_none[2] = {0.0f, 0.0f};
+    f32x2 cs_b1 = {0.0f, 0.0f}, cs_b4 = {0.0f, 0.0f}, cs_b5 = {0.0f, 0.0f}, cs_none = {0.0f, 0.0f};
     PassBorder pbA, pbB, pb4a, pb4b, pb5;
     pbA.init(); pbB.init(); pb4a.init(); pb4b.init(); pb5.init();
 #pragma unroll
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
             }
             if (kB && g == 0 && i == 0) put1(dst + 32 * ld + c0 + 32, pb.corner);
         };
-        auto emit_vec = [&](float* dst, const float (&cs)[2], const PassBorder& pb) {
+        auto emit_vec = [&](float* dst, const f32x2& cs, const PassBorder& pb) {
             if (g == 0) {
                 put1(dst + i, cs[0]); put1(dst + 16 + i, cs[1]);
                 if (kB && i == 0) put1(dst + 32, pb.xbs);
