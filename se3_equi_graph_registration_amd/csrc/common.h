@@ -56,7 +56,7 @@ static inline int fpad(int F) { return round_up(F, 4); }
 
 inline bool config_supported(const equigspr_egnn_config* c) {
     if (!c) return false;
-    const bool f_ok = (c->hidden_nf == 32 && (c->num_heads == 1 || c->num_heads == 4)) ||
+    const bool f_ok = (c->hidden_nf == 32 && (c->num_heads == 1 || c->num_heads == 2 || c->num_heads == 4 || c->num_heads == 8)) ||
                       (c->hidden_nf == 33 && c->num_heads == 1);
     return f_ok && c->in_nf >= 1 && c->in_nf <= 64 && c->out_nf >= 1 && c->out_nf <= 64 &&
            (c->in_edge_nf == 0 || c->in_edge_nf == 1) && c->n_layers >= 1 && c->n_layers <= 16 &&

@@ -1062,7 +1062,7 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
                            const float* dagg, const float* Gx, float* dt1, float* gxr, float* gxc, float* slab,
                            int basis, hipStream_t s, int* n_slabs) {
     const int E = g->n_edges;
-    static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1 or 4 heads) or 33 (1 head)");
+    static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1, 2, 4 or 8 heads) or 33 (1 head)");
     {                                      // the 16-edge formulation (hidden_nf 33: with the border feature): one 8-wave workgroup per CU, persistent
         constexpr int NW = bwd16_waves(F - 32);
         const int chunk = edge_chunk_for(E, 256 * NW);
@@ -1393,6 +1393,7 @@ extern "C" int equigspr_egnn_backward(const equigspr_egnn_config* cfg, const flo
 #define EQ_DISPATCH(FF, HH, AA) \
     if (F == FF && H == HH && A == AA) return backward_impl<FF, HH, AA>(cfg, params, g, h_in, edge_attr, saved, grad_h_out, grad_x_out, grad_params, grad_h_in, grad_x_in, work, s);
     EQ_DISPATCH(32, 1, 1) EQ_DISPATCH(32, 1, 0) EQ_DISPATCH(32, 4, 1) EQ_DISPATCH(32, 4, 0)
+    EQ_DISPATCH(32, 2, 1) EQ_DISPATCH(32, 2, 0) EQ_DISPATCH(32, 8, 1) EQ_DISPATCH(32, 8, 0)
     EQ_DISPATCH(33, 1, 1) EQ_DISPATCH(33, 1, 0)
 #undef EQ_DISPATCH
     set_error("egnn_backward: no kernel for F=%d H=%d A=%d", F, H, A);
@@ -1410,6 +1411,7 @@ extern "C" int equigspr_time_edge_bwd(const equigspr_egnn_config* cfg, const flo
 #define EQ_DISPATCH(FF, HH, AA) \
     if (F == FF && H == HH && A == AA) return time_edge_bwd_impl<FF, HH, AA>(cfg, params, g, edge_attr, saved, bwd_work, iters, ms_out_host, s);
     EQ_DISPATCH(32, 1, 1) EQ_DISPATCH(32, 1, 0) EQ_DISPATCH(32, 4, 1) EQ_DISPATCH(32, 4, 0)
+    EQ_DISPATCH(32, 2, 1) EQ_DISPATCH(32, 2, 0) EQ_DISPATCH(32, 8, 1) EQ_DISPATCH(32, 8, 0)
     EQ_DISPATCH(33, 1, 1) EQ_DISPATCH(33, 1, 0)
 #undef EQ_DISPATCH
     return EQUIGSPR_ENOTSUP;

@@ -168,7 +168,7 @@ template <int F, int H, int A>
 static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
                             float* m, float* trans, int basis, hipStream_t s) {
     const int E = g->n_edges;
-    static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1 or 4 heads) or 33 (1 head)");
+    static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1, 2, 4 or 8 heads) or 33 (1 head)");
     {                                      // the 16-edge formulation (hidden_nf 33: with the border feature); EQ_FWD16_OCC 4-wave workgroups per CU
         constexpr int occ = fwd16_occ(F - 32);
         const int chunk = edge_chunk_for(E, 256 * 4 * occ);
@@ -739,7 +739,7 @@ extern "C" int equigspr_egnn_forward(const equigspr_egnn_config* cfg, const floa
                                      float* x_out, float* saved, float* work, void* stream) {
     using namespace eq;
     EQ_CHECK_ARG(config_supported(cfg), EQUIGSPR_ENOTSUP,
-                 "egnn_forward: unsupported config (hidden_nf in {32,33}, heads in {1,4}, in/out<=64, in_edge_nf in {0,1})");
+                 "egnn_forward: unsupported config (hidden_nf in {32,33}, heads in {1,2,4,8} (33: 1), in/out<=64, in_edge_nf in {0,1})");
     EQ_CHECK_ARG(params && g && h_in && x_in && h_out && x_out && work, EQUIGSPR_EINVAL, "egnn_forward: null pointer");
     EQ_CHECK_ARG(g->n_nodes >= 1 && g->n_edges >= 0 && g->rptr && (g->n_edges == 0 || (g->row && g->col && g->rperm && g->rinv)), EQUIGSPR_EINVAL,
                  "egnn_forward: incomplete graph");
@@ -748,6 +748,7 @@ extern "C" int equigspr_egnn_forward(const equigspr_egnn_config* cfg, const floa
 #define EQ_DISPATCH(FF, HH, AA) \
     if (F == FF && H == HH && A == AA) return forward_impl<FF, HH, AA>(cfg, params, g, h_in, x_in, edge_attr, h_out, x_out, saved, work, s);
     EQ_DISPATCH(32, 1, 1) EQ_DISPATCH(32, 1, 0) EQ_DISPATCH(32, 4, 1) EQ_DISPATCH(32, 4, 0)
+    EQ_DISPATCH(32, 2, 1) EQ_DISPATCH(32, 2, 0) EQ_DISPATCH(32, 8, 1) EQ_DISPATCH(32, 8, 0)
     EQ_DISPATCH(33, 1, 1) EQ_DISPATCH(33, 1, 0)
 #undef EQ_DISPATCH
     set_error("egnn_forward: no kernel for F=%d H=%d A=%d", F, H, A);
@@ -765,6 +766,7 @@ extern "C" int equigspr_time_edge_fwd(const equigspr_egnn_config* cfg, const flo
 #define EQ_DISPATCH(FF, HH, AA) \
     if (F == FF && H == HH && A == AA) return time_edge_fwd_impl<FF, HH, AA>(cfg, params, g, h_in, x_in, edge_attr, work, iters, ms_out_host, s);
     EQ_DISPATCH(32, 1, 1) EQ_DISPATCH(32, 1, 0) EQ_DISPATCH(32, 4, 1) EQ_DISPATCH(32, 4, 0)
+    EQ_DISPATCH(32, 2, 1) EQ_DISPATCH(32, 2, 0) EQ_DISPATCH(32, 8, 1) EQ_DISPATCH(32, 8, 0)
     EQ_DISPATCH(33, 1, 1) EQ_DISPATCH(33, 1, 0)
 #undef EQ_DISPATCH
     return EQUIGSPR_ENOTSUP;

@@ -565,6 +565,10 @@ int launch_node_bwd16(int F, int H, int A, int mode, const NodeBwd16Args& args, 
     if (F == 32 && H == 1 && A == 0) return launch_cfg<1, 0, 0>(mode, args, s, n_slabs);
     if (F == 32 && H == 4 && A == 1) return launch_cfg<4, 1, 0>(mode, args, s, n_slabs);
     if (F == 32 && H == 4 && A == 0) return launch_cfg<4, 0, 0>(mode, args, s, n_slabs);
+    if (F == 32 && H == 2 && A == 1) return launch_cfg<2, 1, 0>(mode, args, s, n_slabs);
+    if (F == 32 && H == 2 && A == 0) return launch_cfg<2, 0, 0>(mode, args, s, n_slabs);
+    if (F == 32 && H == 8 && A == 1) return launch_cfg<8, 1, 0>(mode, args, s, n_slabs);
+    if (F == 32 && H == 8 && A == 0) return launch_cfg<8, 0, 0>(mode, args, s, n_slabs);
     if (F == 33 && H == 1 && A == 1) return launch_cfg<1, 1, 1>(mode, args, s, n_slabs);
     if (F == 33 && H == 1 && A == 0) return launch_cfg<1, 0, 1>(mode, args, s, n_slabs);
     return EQUIGSPR_ENOTSUP;

@@ -3,8 +3,8 @@
 // knn: one 64-lane wavefront per query point, brute force over the query's cloud (N <= 8192
 // -> <= 128 candidates per lane held in VGPRs).  Selection is exact and deterministic:
 //   fast path : tau = k-th smallest of the 64 per-lane minima (an upper bound of the k-th
-//               distance), compact the (usually ~1.2k) candidates <= tau through LDS, one
-//               64-lane bitonic sort on (d2,index) keys, emit the first k.
+//               distance), compact the (usually ~1.2k) candidates <= tau through LDS, rank them
+//               by counting on their (d2,index) keys, the k smallest write their output slots.
 //   slow path : k rounds of wave-wide min extraction (taken when more than 64 candidates
 //               tie under tau, e.g. heavily duplicated points; also forced by tests).
 // Both paths produce the (d2, index)-lexicographic order of oracle.knn_graph bit for bit.
@@ -16,22 +16,6 @@
 namespace eq {
 
 typedef unsigned long long u64;
-
-__device__ __forceinline__ u64 wave_bitonic_sort(u64 key, int lane) {
-#pragma unroll
-    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
-#pragma unroll
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            const u64 other = __shfl_xor(key, j, 64);
-            const bool up = (lane & k2) == 0;
-            const bool lower = (lane & j) == 0;
-            const u64 mn = key < other ? key : other;
-            const u64 mx = key < other ? other : key;
-            key = (lower == up) ? mn : mx;
-        }
-    }
-    return key;
-}
 
 // k-th smallest (1-based) of the wave's 64 non-negative floats given as bit patterns (unsigned order = float order): bisection on
 // the value with one ballot + popcount per step -- one vector instruction per step against ~300 for a 64-lane bitonic sort.
@@ -59,11 +43,47 @@ __device__ __forceinline__ u64 pack_key(float d2, int idx) {
     return ((u64)__float_as_uint(d2) << 32) | (unsigned)idx;
 }
 
-template <int NPL>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Squared distances of TWO (query, candidate) pairs at once in the arithmetic contract of oracle.knn_graph --
+// d2 = fl(fl(fl(dx dx) + fl(dy dy)) + fl(dz dz)), no contraction -- as packed fp32 instructions (v_pk_add_f32 / v_pk_mul_f32: two
+// IEEE results per instruction, issued in the time of one; tools/dev/valu_cost.hip).  The difference is formed as p + (-q):
+// (p - q)^2 and (q - p)^2 are the same number.  `nq*` = the NEGATED query coordinates.
+__device__ __forceinline__ f32x2 dist2_pk(f32x2 px, f32x2 py, f32x2 pz, f32x2 nqx, f32x2 nqy, f32x2 nqz) {
+#pragma clang fp contract(off)
+    const f32x2 dx = px + nqx, dy = py + nqy, dz = pz + nqz;
+    const f32x2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    const f32x2 s = xx + yy;
+    return s + zz;
+}
+// position of this lane among the set bits of a ballot mask (= popcount of the mask below the lane): two v_mbcnt
+__device__ __forceinline__ int rank_in_mask(u64 mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// The cnt (<= 64) compacted candidates of a query, already in LDS: lane l < cnt takes key l and counts the keys smaller than its
+// own (uniform-address LDS reads = broadcasts; keys are distinct: the index is part of the key).  A lane whose rank is < k owns
+// output slot `rank` -- nothing is physically sorted (a 64-lane bitonic network on 64-bit keys is ~250 vector instructions and
+// 42 cross-lane moves; this is ~2 per candidate).  Returns the rank (>= 64 for lanes without a key).
+__device__ __forceinline__ int rank_by_counting(const u64* list, int cnt, int lane, u64& mine) {
+    mine = lane < cnt ? list[lane] : ~0ull;
+    int rank = lane < cnt ? 0 : 64;
+    int j = 0;
+    for (; j + 4 <= cnt; j += 4) {                      // cnt is wave-uniform
+        const u64 a = list[j], b = list[j + 1], c = list[j + 2], d = list[j + 3];
+        rank += (a < mine ? 1 : 0) + (b < mine ? 1 : 0) + (c < mine ? 1 : 0) + (d < mine ? 1 : 0);
+    }
+    for (; j < cnt; ++j) rank += list[j] < mine ? 1 : 0;
+    return rank;
+}
+
+// kLoop: the query itself is a candidate (loop=True, every reference call site); kFull: n == 64 NPL (no index guards)
+template <int NPL, bool kLoop, bool kFull>
 __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, int n_clouds, int n, int k,
-                                                 int loop, long long* __restrict__ edges,
+                                                 long long* __restrict__ edges,
                                                  int* __restrict__ row32, int* __restrict__ col32,
                                                  int* __restrict__ row_hist, int force_slow) {
+    static_assert(NPL % 2 == 0, "candidates are processed in pairs");
     __shared__ u64 list[64];
     const int lane = threadIdx.x;
     const int qg = blockIdx.x;                 // query id over all clouds
@@ -71,47 +91,45 @@ __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, in
     const int q = qg - cloud * n;
     const float* __restrict__ xc = x + (size_t)cloud * n * 3;
     const float qx = xc[q * 3 + 0], qy = xc[q * 3 + 1], qz = xc[q * 3 + 2];
+    const f32x2 nqx = {-qx, -qx}, nqy = {-qy, -qy}, nqz = {-qz, -qz};
     const float INF = __uint_as_float(0x7f800000u);
 
     float d[NPL];
     float lmin = INF;
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) {
-        const int idx = i * 64 + lane;
-        float v = INF;
-        if (idx < n) {
-            // exact, contraction-free arithmetic contract (see oracle.knn_graph)
-            const float dx = __fsub_rn(qx, xc[idx * 3 + 0]);
-            const float dy = __fsub_rn(qy, xc[idx * 3 + 1]);
-            const float dz = __fsub_rn(qz, xc[idx * 3 + 2]);
-            v = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-            if (!loop && idx == q) v = INF;
-        }
-        d[i] = v;
-        lmin = fminf(lmin, v);
+    for (int i = 0; i < NPL; i += 2) {
+        const int i0 = i * 64 + lane, i1 = i0 + 64;
+        const int j0 = kFull ? i0 : min(i0, n - 1), j1 = kFull ? i1 : min(i1, n - 1);
+        const f32x2 v = dist2_pk(f32x2{xc[j0 * 3 + 0], xc[j1 * 3 + 0]}, f32x2{xc[j0 * 3 + 1], xc[j1 * 3 + 1]},
+                                 f32x2{xc[j0 * 3 + 2], xc[j1 * 3 + 2]}, nqx, nqy, nqz);
+        float v0 = v[0], v1 = v[1];
+        if (!kFull) { v0 = i0 < n ? v0 : INF; v1 = i1 < n ? v1 : INF; }
+        if (!kLoop) { v0 = i0 == q ? INF : v0; v1 = i1 == q ? INF : v1; }
+        d[i] = v0; d[i + 1] = v1;
+        lmin = fminf(lmin, fminf(v0, v1));
     }
 
     int out_idx = 0;
-    // ---- fast path -------------------------------------------------------------------
+    // ---- fast path: tau = k-th smallest lane minimum (at least k candidates are <= tau); count and compact in one sweep
     const unsigned tau_bits = wave_kth_smallest_bits(__float_as_uint(lmin), k);
     const float tau = __uint_as_float(tau_bits);
     int cnt = 0;
 #pragma unroll
-    for (int i = 0; i < NPL; ++i) cnt += __popcll(__ballot(d[i] <= tau));
-    const bool fast = (cnt <= 64) && (cnt >= k) && !force_slow;   // wave-uniform
-    if (fast) {
-        int base = 0;
-        const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll
-        for (int i = 0; i < NPL; ++i) {
-            const bool pred = d[i] <= tau;
-            const u64 mask = __ballot(pred);
-            if (pred) list[base + __popcll(mask & lt_mask)] = pack_key(d[i], i * 64 + lane);
-            base += __popcll(mask);
+    for (int i = 0; i < NPL; ++i) {
+        const bool pred = d[i] <= tau;
+        const u64 mask = __ballot(pred);
+        if (mask) {                                     // wave-uniform: most 64-candidate rows hold no candidate <= tau
+            const int at = cnt + rank_in_mask(mask);
+            if (pred && at < 64) list[at] = pack_key(d[i], i * 64 + lane);
+            cnt += __popcll(mask);
         }
+    }
+    const bool fast = (cnt <= 64) && !force_slow;   // wave-uniform
+    int slot = lane;                                // output slot of this lane's out_idx
+    if (fast) {
         __syncthreads();   // single-wave block: orders the LDS writes before the reads below
-        u64 key = lane < cnt ? list[lane] : ~0ull;
-        key = wave_bitonic_sort(key, lane);
+        u64 key;
+        slot = rank_by_counting(list, cnt, lane, key);
         out_idx = (int)(unsigned)(key & 0xffffffffu);
     } else {
         // ---- slow path: k rounds of "smallest key strictly greater than the previous one"
@@ -131,8 +149,8 @@ __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, in
             have_last = true;
         }
     }
-    if (lane < k) {
-        const size_t e = (size_t)q * k + lane;
+    if (slot < k) {
+        const size_t e = (size_t)q * k + slot;
         const size_t epc = (size_t)n * k;
         if (edges) {
             edges[(size_t)cloud * 2 * epc + e] = out_idx;
@@ -146,14 +164,17 @@ __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, in
 
 // ---------------------------------------------------------------------------------------
 // Tiled multi-query form (used for n > 2 048): the per-query kernel above re-reads the whole cloud from L2 for every query
-// (1.6 GB of L2 traffic at B=16, and its 128-candidates-per-lane variant spills).  Here a workgroup of 4 waves owns 16
-// queries of one cloud; candidate tiles of 2 048 points are staged through LDS once per workgroup and every candidate read
-// from LDS is tested against the wave's 4 queries.  Two passes over the tiles (lane minima -> tau; count + compaction);
-// same lane <-> candidate assignment, same arithmetic, same key order as knn_kernel, so the results are bit-identical.
+// (and its 128-candidates-per-lane variant spills).  Here a workgroup of 4 waves owns 16 queries of one cloud; candidate tiles
+// of 2 048 points are staged through LDS once per workgroup and every candidate read from LDS is tested against the wave's 4
+// queries -- two queries per packed instruction.  Two passes over the tiles (lane minima -> tau; count + compaction); same
+// lane <-> candidate assignment, same arithmetic, same key order as knn_kernel, so the results are bit-identical.
 // The (rare) slow path of a query re-scans the cloud from global memory with its own wave.
 // ---------------------------------------------------------------------------------------
-constexpr int kKnnTile = 2048, kKnnQpw = 4;
-__global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict__ x, int n_clouds, int n, int k, int loop,
+constexpr int kKnnTile = 2048;
+// kKnnQpw = queries per wave (even: two per packed instruction): 8 when that still leaves >= 8 workgroups per CU (measured:
+// KITTI shard 197 -> 171 us), 4 otherwise (two 8 192-point clouds: 99 us against 122 with 8 and 109 with 2)
+template <bool kLoop, int kKnnQpw>
+__global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict__ x, int n_clouds, int n, int k,
                                                         long long* __restrict__ edges, int* __restrict__ row32,
                                                         int* __restrict__ col32, int* __restrict__ row_hist,
                                                         int force_slow) {
@@ -173,9 +194,23 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
         const int qq = min(qi[u], n - 1);
         qx[u] = xc[qq * 3 + 0]; qy[u] = xc[qq * 3 + 1]; qz[u] = xc[qq * 3 + 2];
     }
-    auto dist2 = [&](int u, float px, float py, float pz) {
-        // exact, contraction-free arithmetic contract (see oracle.knn_graph)
-        const float dx = __fsub_rn(qx[u], px), dy = __fsub_rn(qy[u], py), dz = __fsub_rn(qz[u], pz);
+    static_assert(kKnnQpw % 2 == 0, "two queries per packed instruction");
+    f32x2 nqx[kKnnQpw / 2], nqy[kKnnQpw / 2], nqz[kKnnQpw / 2];
+#pragma unroll
+    for (int h = 0; h < kKnnQpw / 2; ++h) {
+        nqx[h] = f32x2{-qx[2 * h], -qx[2 * h + 1]}; nqy[h] = f32x2{-qy[2 * h], -qy[2 * h + 1]}; nqz[h] = f32x2{-qz[2 * h], -qz[2 * h + 1]};
+    }
+    // the squared distances of one candidate to the wave's queries (queries 2h, 2h + 1 packed)
+    auto dist4 = [&](float px, float py, float pz, float (&v)[kKnnQpw]) {
+        const f32x2 p2x = {px, px}, p2y = {py, py}, p2z = {pz, pz};
+#pragma unroll
+        for (int h = 0; h < kKnnQpw / 2; ++h) {
+            const f32x2 a = dist2_pk(p2x, p2y, p2z, nqx[h], nqy[h], nqz[h]);
+            v[2 * h] = a[0]; v[2 * h + 1] = a[1];
+        }
+    };
+    auto dist2 = [&](int u, float px, float py, float pz) {   // scalar form of the same contract (slow path)
+        const float dx = __fsub_rn(px, qx[u]), dy = __fsub_rn(py, qy[u]), dz = __fsub_rn(pz, qz[u]);
         return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
     };
     auto stage = [&](int t0, int cnt) {
@@ -190,14 +225,14 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
     for (int t0 = 0; t0 < n; t0 += kKnnTile) {
         const int cnt = min(kKnnTile, n - t0);
         stage(t0, cnt);
+#pragma unroll 4
         for (int j = lane; j < cnt; j += 64) {
-            const float px = tile[3 * j], py = tile[3 * j + 1], pz = tile[3 * j + 2];
-            const int idx = t0 + j;
+            float v[kKnnQpw];
+            dist4(tile[3 * j], tile[3 * j + 1], tile[3 * j + 2], v);
 #pragma unroll
             for (int u = 0; u < kKnnQpw; ++u) {
-                float v = dist2(u, px, py, pz);
-                if (!loop && idx == qi[u]) v = INF;
-                lmin[u] = fminf(lmin[u], v);
+                if (!kLoop && t0 + j == qi[u]) v[u] = INF;
+                lmin[u] = fminf(lmin[u], v[u]);
             }
         }
     }
@@ -210,24 +245,29 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
     int base[kKnnQpw];
 #pragma unroll
     for (int u = 0; u < kKnnQpw; ++u) base[u] = 0;
-    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (int t0 = 0; t0 < n; t0 += kKnnTile) {
         const int cnt = min(kKnnTile, n - t0);
         stage(t0, cnt);
         for (int j0 = 0; j0 < cnt; j0 += 64) {             // wave-uniform trip count (ballots inside)
             const int j = j0 + lane;
-            const bool in = j < cnt;
-            const float px = in ? tile[3 * j] : 0.0f, py = in ? tile[3 * j + 1] : 0.0f, pz = in ? tile[3 * j + 2] : 0.0f;
+            const bool whole = j0 + 64 <= cnt;             // wave-uniform: no lane of this step is past the tile's end
+            const bool in = whole || j < cnt;
+            const int jj = in ? j : 0;
+            float v[kKnnQpw];
+            dist4(tile[3 * jj], tile[3 * jj + 1], tile[3 * jj + 2], v);
             const int idx = t0 + j;
 #pragma unroll
             for (int u = 0; u < kKnnQpw; ++u) {
-                float v = dist2(u, px, py, pz);
-                if (!in || (!loop && idx == qi[u])) v = INF;
-                const bool pred = v <= tau[u];
+                float vu = v[u];
+                if (!whole) vu = in ? vu : INF;
+                if (!kLoop) vu = idx == qi[u] ? INF : vu;
+                const bool pred = vu <= tau[u];
                 const u64 mask = __ballot(pred);
-                const int at = base[u] + __popcll(mask & lt_mask);
-                if (pred && at < 64) list[wv * kKnnQpw + u][at] = pack_key(v, idx);
-                base[u] += __popcll(mask);
+                if (mask) {                                // wave-uniform: few of the 64-candidate steps hold a candidate <= tau
+                    const int at = base[u] + rank_in_mask(mask);
+                    if (pred && at < 64) list[wv * kKnnQpw + u][at] = pack_key(vu, idx);
+                    base[u] += __popcll(mask);
+                }
             }
         }
     }
@@ -236,10 +276,10 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
     for (int u = 0; u < kKnnQpw; ++u) {
         if (qi[u] >= n) continue;                          // wave-uniform
         const int cnt = base[u];
-        int out_idx = 0;
+        int out_idx = 0, slot = lane;
         if ((cnt <= 64) && (cnt >= k) && !force_slow) {
-            u64 key = lane < cnt ? list[wv * kKnnQpw + u][lane] : ~0ull;
-            key = wave_bitonic_sort(key, lane);
+            u64 key;
+            slot = rank_by_counting(list[wv * kKnnQpw + u], cnt, lane, key);
             out_idx = (int)(unsigned)(key & 0xffffffffu);
         } else {
             // slow path: k rounds of "smallest key strictly greater than the previous one", distances recomputed from global
@@ -249,7 +289,7 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
                 u64 best = ~0ull;
                 for (int idx = lane; idx < n; idx += 64) {
                     float v = dist2(u, xc[idx * 3 + 0], xc[idx * 3 + 1], xc[idx * 3 + 2]);
-                    if (!loop && idx == qi[u]) v = INF;
+                    if (!kLoop && idx == qi[u]) v = INF;
                     const u64 key = pack_key(v, idx);
                     const bool ok = !have_last || key > last;
                     best = (ok && key < best) ? key : best;
@@ -260,9 +300,9 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
                 have_last = true;
             }
         }
-        if (lane < k) {
+        if (slot < k) {
             const int q = qi[u];
-            const size_t e = (size_t)q * k + lane;
+            const size_t e = (size_t)q * k + slot;
             const size_t epc = (size_t)n * k;
             if (edges) {
                 edges[(size_t)cloud * 2 * epc + e] = out_idx;
@@ -356,15 +396,29 @@ extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, i
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(n_clouds * n), block(64);
     long long* e64 = reinterpret_cast<long long*>(edges_i64);
+#define EQ_KNN_LAUNCH(NPL, LOOP, FULL) \
+    hipLaunchKernelGGL((knn_kernel<NPL, LOOP, FULL>), grid, block, 0, s, x, n_clouds, n, k, e64, row32, col32, row_hist, force_slow_path)
+#define EQ_KNN_PICK(NPL) \
+    do { const bool full = n == 64 * NPL; \
+         if (loop) { if (full) EQ_KNN_LAUNCH(NPL, true, true); else EQ_KNN_LAUNCH(NPL, true, false); } \
+         else { if (full) EQ_KNN_LAUNCH(NPL, false, true); else EQ_KNN_LAUNCH(NPL, false, false); } } while (0)
     if (n <= 256) {
-        hipLaunchKernelGGL(knn_kernel<4>, grid, block, 0, s, x, n_clouds, n, k, loop, e64, row32, col32, row_hist, force_slow_path);
-    } else if (n <= EQ_KNN_PER_QUERY_MAX) {      // measured: the per-query kernel is as fast as the tiled one up to 2 048 points (17.6 us at B=1)
-        hipLaunchKernelGGL(knn_kernel<32>, grid, block, 0, s, x, n_clouds, n, k, loop, e64, row32, col32, row_hist, force_slow_path);
-    } else {                     // 4 096 / 8 192 points: 534 -> ~120 us for two 8 192-point clouds (no 128-value register arrays)
-        const int bpc = ceil_div(n, 4 * kKnnQpw);
-        hipLaunchKernelGGL(knn_tiled_kernel, dim3(n_clouds * bpc), dim3(256), 0, s, x, n_clouds, n, k, loop, e64, row32, col32,
-                           row_hist, force_slow_path);
+        EQ_KNN_PICK(4);
+    } else if (n <= 1024) {
+        EQ_KNN_PICK(16);
+    } else if (n <= EQ_KNN_PER_QUERY_MAX) {      // measured: the per-query kernel is as fast as the tiled one up to 2 048 points
+        EQ_KNN_PICK(32);
+    } else {                     // 4 096 / 8 192 points (no 128-value register arrays)
+        const bool wide = (long long)n_clouds * ceil_div(n, 32) >= 2048;
+        const int bpc = ceil_div(n, wide ? 32 : 16);
+#define EQ_KNN_TILED(LOOP, QPW) \
+    hipLaunchKernelGGL((knn_tiled_kernel<LOOP, QPW>), dim3(n_clouds * bpc), dim3(256), 0, s, x, n_clouds, n, k, e64, row32, col32, row_hist, force_slow_path)
+        if (loop) { if (wide) EQ_KNN_TILED(true, 8); else EQ_KNN_TILED(true, 4); }
+        else { if (wide) EQ_KNN_TILED(false, 8); else EQ_KNN_TILED(false, 4); }
+#undef EQ_KNN_TILED
     }
+#undef EQ_KNN_PICK
+#undef EQ_KNN_LAUNCH
     EQ_CHECK_LAUNCH("knn_kernel");
     return 0;
 }

@@ -756,6 +756,10 @@ def main():
         gen_kitti_fixture("pair_kitti_n2048_k12_l2_f33.npz", 2048, 12, 33, 2, seed=5)
         gen_kitti_fixture("pair_kitti_n4096_k8_l1_f33.npz", 4096, 8, 33, 1, seed=6)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "heads":        # the head counts added in round 3 (any divisor of hidden_nf, train :186,:202-209)
+        gen_layer_fixture(tr, "layer_n128_k8_f32_h2.npz", 128, 8, 32, 2, 2, seed=15)
+        gen_layer_fixture(tr, "layer_n128_k8_f32_h8.npz", 128, 8, 32, 8, 2, seed=16)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "wellcond":     # regenerate just this fixture
         gen_pair_fixture(tr, ev, "pair_n512_k12_l2_wellcond.npz", 512, 12, 32, 2, 1, seed=3, out_scale=0.02, with_grads=True,
                          tgt_noise=0.05)
@@ -764,6 +768,8 @@ def main():
     gen_layer_fixture(tr, "layer_n128_k8_f33_h1.npz", 128, 8, 33, 1, 2, seed=12)
     gen_layer_fixture(tr, "layer_n128_k8_f32_h4.npz", 128, 8, 32, 4, 2, seed=13)
     gen_layer_fixture(tr, "layer_n96_k6_f32_h1_dup.npz", 96, 6, 32, 1, 1, seed=14, dup_points=True)
+    gen_layer_fixture(tr, "layer_n128_k8_f32_h2.npz", 128, 8, 32, 2, 2, seed=15)
+    gen_layer_fixture(tr, "layer_n128_k8_f32_h8.npz", 128, 8, 32, 8, 2, seed=16)
     gen_pair_fixture(tr, ev, "pair_n2048_k20_l4.npz", 2048, 20, 32, 4, 1, seed=0)
     gen_pair_fixture(tr, ev, "pair_n512_k12_l2_wellcond.npz", 512, 12, 32, 2, 1, seed=3, out_scale=0.02, with_grads=True,
                      tgt_noise=0.05)

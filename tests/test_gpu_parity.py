@@ -25,7 +25,7 @@ pytestmark = pytest.mark.gpu
 from oracle import egnn_oracle as orc  # noqa: E402  (checker only)
 
 LAYER_FIX = ["layer_n128_k8_f32_h1.npz", "layer_n128_k8_f33_h1.npz", "layer_n128_k8_f32_h4.npz",
-             "layer_n96_k6_f32_h1_dup.npz"]
+             "layer_n96_k6_f32_h1_dup.npz", "layer_n128_k8_f32_h2.npz", "layer_n128_k8_f32_h8.npz"]
 PAIR_FIX = ["pair_n2048_k20_l4.npz", "pair_n512_k12_l2_wellcond.npz", "pair_ckpt_n2048_k16_l3_h4.npz"]
 
 
@@ -451,6 +451,7 @@ def test_train_step_gradients_golden(pk, golden_dir, parity):
 
 
 @pytest.mark.parametrize("feat,heads,in_nf,out_nf,n,e", [(32, 4, 32, 32, 257, 3001), (33, 1, 33, 33, 257, 3001), (33, 1, 17, 40, 257, 3001),
+                                                         (32, 2, 32, 32, 257, 3001), (32, 8, 9, 32, 257, 3001), (32, 8, 32, 32, 16999, 70001),
                                                          (32, 1, 5, 64, 257, 3001), (32, 1, 5, 7, 16999, 70001), (32, 4, 32, 32, 16999, 70001),
                                                          (33, 1, 17, 40, 16999, 70001)])
 def test_backward_random_graph_vs_oracle_autograd(pk, feat, heads, in_nf, out_nf, n, e):
