@@ -223,7 +223,7 @@ int equigspr_head_backward(const float* hs, const float* ht, const float* xs, co
  * an index of shape [1,K,1] consumes column 0: every top-K slot i receives where(cond(p[0], sim0[idx_i]), p[0], sim0[idx_i]),
  * p[0] = the MLP score of the best-ranked row), W / (sum W + 1e-6) (:771), softmax over the N points (:774), / (sum + 1e-6)
  * (:783), and the weighted Kabsch on the RAW coordinates of all N points (:786-818).  Inference only (the reference never
- * back-propagates through this head).  Two launches.
+ * back-propagates through this head).  Three launches.
  *   hs, ht [B,N,F], xs, xt [B,N,3]: EGNN outputs;  raw_hs, raw_ht [B,N,F_raw], raw_xs, raw_xt [B,N,3]: the model inputs
  *   outputs: sim [B,N] (<h_s,h_t>, unused by this head), sim0 [B,N], cosv [B,N], pos int32 [B,N] (rank in the top-K or -1),
  *            wts [B,N] (the Kabsch weights), top_idx int64 [B,K], kabsch_R [B,9], kabsch_t [B,3], kabsch_aux [B,EQUIGSPR_KABSCH_AUX],

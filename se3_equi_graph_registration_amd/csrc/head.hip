@@ -414,21 +414,20 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
 
 // ---------------------------------------------------------------------------------------------------
 // Evaluation pair model (src/eval_egnn_metrics.py:691-818), the part after the EGNN, per pair one 256-thread workgroup
-// (launch 2 of 2; launch 1 = head_node_kernel: sim0 = <h0_s, h0_t> on the INPUT features (:691) arrives as `rsim`, the equi-loss
+// (launch 2 of 3; launch 1 = head_node_kernel: sim0 = <h0_s, h0_t> on the INPUT features (:691) arrives as `rsim`, the equi-loss
 // partials (:687) as `partials`, pos = -1):
 //   top-K of sim0 (:694) -> p = mlp(cat(h_s[idx], h_t[idx])) (:706-742) -> the [K] vs [1,K,1] broadcast of :742,:758-768: the
 //   `where` result is [1,K,K] and scatter_(dim=1, index [1,K,1]) consumes column 0 only, so EVERY top-K slot i receives
 //   where(cond(p[0], sim0[idx_i]), p[0], sim0[idx_i]) -- only the MLP score of the best-ranked row is ever used, and only that
-//   row is evaluated here -> W / (sum W + 1e-6) (:771) -> softmax over the N points (:774) -> / (sum + 1e-6) (:783) ->
-//   weighted Kabsch on the RAW coordinates of all N points (:786-818).
+//   row is evaluated here -> the scalars of W / (sum W + 1e-6) (:771) -> softmax over the N points (:774) -> / (sum + 1e-6) (:783).
+//   Launch 3 (head_eval_weights_kernel) writes the weights from these scalars and runs the weighted Kabsch.
 // out[1] = equi loss (b == 0 writes it), out[10 + min(b, 5)] = p[0] of pair b (diagnostic).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void head_eval_pair_kernel(
     const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ sim0, const double* __restrict__ partials,
     int nbp, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
     const float* __restrict__ w3, const float* __restrict__ b3, int B, int N, int Npad, int F, int K, MlpDims md,
-    int* __restrict__ pos, long long* __restrict__ top_idx, float* __restrict__ wts, const float* __restrict__ raw_xs,
-    const float* __restrict__ raw_xt, float* __restrict__ kab_R, float* __restrict__ kab_t, float* __restrict__ kab_aux,
+    int* __restrict__ pos, long long* __restrict__ top_idx, float* __restrict__ pair_f /*[B][4]*/, float* __restrict__ pair_g /*[B]*/,
     float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double red[4];
@@ -442,7 +441,6 @@ __global__ __launch_bounds__(256) void head_eval_pair_kernel(
     const long long M = (long long)B * N;
     const float* sb = sim0 + (size_t)b * N;
     int* posb = pos + (size_t)b * N;
-    float* wb = wts + (size_t)b * N;
     u64* keys = reinterpret_cast<u64*>(smem_raw);
     unsigned* khi = reinterpret_cast<unsigned*>(smem_raw + sizeof(u64) * (size_t)(Npad > kCand ? Npad : kCand));
     {
@@ -488,36 +486,100 @@ __global__ __launch_bounds__(256) void head_eval_pair_kernel(
     }
     __syncthreads();
     const float p0 = p0_s;
-    // ---- W (:758-768), its sum, the softmax of W / (sum + 1e-6) and the final renormalisation
-    auto w_of = [&](int i) {
-        const float s = sb[i];
-        if (posb[i] < 0) return s;
-        const bool cond = (p0 > 0.5f && fabsf(p0 - 1.0f) < s) || (p0 > 0.5f && p0 < s);
-        return cond ? p0 : s;
-    };
+    // ---- W (:758-768), its sum, the softmax of W / (sum + 1e-6) and the final renormalisation.  One sweep over the global
+    // similarities (W into LDS -- the select's key array is free now --, sum and maximum), the rest on the LDS copy.
+    float* Wl = reinterpret_cast<float*>(smem_raw);
+    __syncthreads();                                      // every thread is done with the keys / top_idx reads above
     double sw = 0.0;
-    for (int i = tid; i < N; i += 256) sw += (double)w_of(i);
+    float wmax = -INFINITY, wmin = INFINITY;
+    for (int i = tid; i < N; i += 256) {
+        const float s = sb[i];
+        float w = s;
+        if (posb[i] >= 0) {
+            const bool cond = (p0 > 0.5f && fabsf(p0 - 1.0f) < s) || (p0 > 0.5f && p0 < s);
+            w = cond ? p0 : s;
+        }
+        Wl[i] = w;
+        sw += (double)w;
+        wmax = fmaxf(wmax, w);
+        wmin = fminf(wmin, w);
+    }
     sw = block_sum_d(sw, red);
+    wmax = block_max_f(wmax, redf);
+    wmin = -block_max_f(-wmin, redf);
     const float denom = (float)sw + 1e-6f;
-    float mx = -INFINITY;
-    for (int i = tid; i < N; i += 256) mx = fmaxf(mx, w_of(i) / denom);
-    mx = block_max_f(mx, redf);
+    // the maximum of W / denom: division by a constant is monotonic (increasing for a positive, decreasing for a negative one)
+    const float mx = (denom < 0.0f ? wmin : wmax) / denom;
     double se = 0.0;
-    for (int i = tid; i < N; i += 256) se += (double)expf(w_of(i) / denom - mx);
+    for (int i = tid; i < N; i += 256) {
+        const float e = __builtin_amdgcn_exp2f((Wl[i] / denom - mx) * 1.4426950408889634f);      // exp(v - max) on the hardware exponential
+        Wl[i] = e;
+        se += (double)e;
+    }
     se = block_sum_d(se, red);
     const float sef = (float)se;
     double sn = 0.0;
-    for (int i = tid; i < N; i += 256) sn += (double)(expf(w_of(i) / denom - mx) / sef);
+    for (int i = tid; i < N; i += 256) {
+        const float w = Wl[i] / sef;
+        Wl[i] = w;
+        sn += (double)w;
+    }
     sn = block_sum_d(sn, red);
     const float renorm = (float)sn + 1e-6f;
-    for (int i = tid; i < N; i += 256) wb[i] = (expf(w_of(i) / denom - mx) / sef) / renorm;
+    // the pair's scalars for the weight blocks of the next launch (head_eval_weights_kernel)
+    if (tid == 0) {
+        float* pf = pair_f + (size_t)b * 4;
+        pf[0] = denom; pf[1] = mx; pf[2] = sef; pf[3] = renorm;
+        pair_g[b] = p0;
+    }
+}
+
+// Launch 3 of the evaluation head, grid (nkb <= 8, B): block xb writes the Kabsch weights of its interleaved share of pair b's points
+// (i = 256 xb + tid + 256 nkb j) from the pair's scalars, accumulates their fp64 moments (kabsch_moments_block: same partition),
+// and the block that finishes the pair last (ticket) solves the 3 x 3 problem on the RAW coordinates of all N points (:786-818).
+__global__ __launch_bounds__(256) void head_eval_weights_kernel(const float* __restrict__ sim0, const int* __restrict__ pos,
+                                                                const float* __restrict__ pair_f, const float* __restrict__ pair_g,
+                                                                int N, int nkb, float* __restrict__ wts,
+                                                                const float* __restrict__ raw_xs, const float* __restrict__ raw_xt,
+                                                                float* __restrict__ kab_R, float* __restrict__ kab_t,
+                                                                float* __restrict__ kab_aux, unsigned* __restrict__ tickets) {
+    const int b = blockIdx.y, xb = blockIdx.x, tid = threadIdx.x;
+    const float denom = pair_f[(size_t)b * 4], mx = pair_f[(size_t)b * 4 + 1], sef = pair_f[(size_t)b * 4 + 2], renorm = pair_f[(size_t)b * 4 + 3];
+    const float p0 = pair_g[b];
+    const float* sb = sim0 + (size_t)b * N;
+    const int* posb = pos + (size_t)b * N;
+    float* wb = wts + (size_t)b * N;
+    for (int i0 = xb * 256 + tid; i0 < N; i0 += nkb * 256 * 4) {         // four independent points per step: their loads overlap
+        float sv[4];
+        int pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * nkb * 256; sv[u] = i < N ? sb[i] : 0.0f; pv[u] = i < N ? posb[i] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * nkb * 256;
+            if (i >= N) continue;
+            const float sq = sv[u];
+            float w = sq;
+            if (pv[u] >= 0) {
+                const bool cond = (p0 > 0.5f && fabsf(p0 - 1.0f) < sq) || (p0 > 0.5f && p0 < sq);
+                w = cond ? p0 : sq;
+            }
+            const float e = __builtin_amdgcn_exp2f((w / denom - mx) * 1.4426950408889634f);       // as in head_eval_pair_kernel
+            wb[i] = (e / sef) / renorm;
+        }
+    }
+    kabsch_moments_block(raw_xs, raw_xt, wts, N, kab_aux, b, xb, nkb);     // reads back this thread's own stores (same index set)
+    __shared__ int is_last;
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        is_last = atomicAdd(tickets + b, 1u) == (unsigned)nkb - 1u;
+        if (is_last) tickets[b] = 0u;
+    }
+    __syncthreads();
+    if (!is_last) return;                                  // block-uniform
     __threadfence();
-    __syncthreads();
-    // ---- weighted Kabsch on the raw coordinates, all N points (:786-818)
-    kabsch_moments_block(raw_xs, raw_xt, wts, N, kab_aux, b, 0, 1);
-    __threadfence_block();
-    __syncthreads();
-    if (tid < 64) kabsch_solve_wave(1, kab_R, kab_t, kab_aux, b, tid);
+    if (tid < 64) kabsch_solve_wave(nkb, kab_R, kab_t, kab_aux, b, tid);
 }
 
 // out[0] = corr_loss + sim_loss, out[1] = equi loss, out[2..5] = mu_s, sd_s, mu_r, sd_r (written by K2),
@@ -1048,8 +1110,11 @@ extern "C" int equigspr_head_eval_forward(const float* hs, const float* ht, cons
         }
     }
     hipLaunchKernelGGL(head_eval_pair_kernel, dim3(1, B), dim3(256), sm, s, hs, ht, sim0, W.partA, W.nbp, w1, b1, w2, b2, w3, b3, B, N,
-                       Npad, F, K, md, pos, reinterpret_cast<long long*>(top_idx), wts, raw_xs, raw_xt, kabsch_R, kabsch_t, kabsch_aux,
-                       out_scalars);
+                       Npad, F, K, md, pos, reinterpret_cast<long long*>(top_idx), W.pair_f, W.pair_g, out_scalars);
+    // launch 3: the weights and their Kabsch moments spread over up to 8 blocks per pair (one per 1 024 points), ticket -> solve
+    const int nkb = min(kKabschMaxBlocks, ceil_div(N, 1024));
+    hipLaunchKernelGGL(head_eval_weights_kernel, dim3(nkb, B), dim3(256), 0, s, sim0, pos, W.pair_f, W.pair_g, N, nkb, wts, raw_xs, raw_xt,
+                       kabsch_R, kabsch_t, kabsch_aux, W.tickets);
     EQ_CHECK_LAUNCH("head_eval_forward");
     return 0;
 }

@@ -72,6 +72,7 @@ _KNN_COL_INDEX = {}
 
 
 _CSR_SCRATCH = {}
+_CSR_GRAPH_OWNED = []      # counter arrays adopted by captured hipGraphs (see _csr_scratch)
 
 
 def _csr_scratch(dev, n_words):
@@ -83,10 +84,14 @@ def _csr_scratch(dev, n_words):
     if buf is not None:
         return buf, 1
     if torch.cuda.is_current_stream_capturing():
-        # the capture stream is a fresh one: take the buffer an eager warm-up run left behind for this device and size
-        # (the captured graph then owns it: do not build graphs of that size eagerly on another stream while it replays)
-        for (d, _, n), other in _CSR_SCRATCH.items():
-            if d == key[0] and n == key[2]:
+        # The capture stream is a fresh one: take the zeroed buffer an eager warm-up run left behind for this device and size.
+        # The captured graph OWNS it from here on (its replays read and re-zero it through the raw pointer): it leaves the
+        # eager cache -- a later eager build of the same size, on whatever stream, gets a buffer of its own instead of
+        # racing with a replay -- and is kept alive for the life of the process.
+        for other_key, other in list(_CSR_SCRATCH.items()):
+            if other_key[0] == key[0] and other_key[2] == key[2]:
+                del _CSR_SCRATCH[other_key]
+                _CSR_GRAPH_OWNED.append(other)
                 return other, 1
         return torch.empty(n_words, dtype=torch.int32, device=dev), 0
     if len(_CSR_SCRATCH) > 32:
@@ -417,7 +422,7 @@ def _flat_mlp(mlp_params, msz):
 
 @torch.no_grad()
 def fused_eval_head(h_all, x_all, raw_hs, raw_ht, raw_xs, raw_xt, labels, gt_pose, topk, mlp_params):
-    """The evaluation pair model after the EGNN (eval :687-818) in two HIP launches (csrc/head.hip, equigspr_head_eval_forward).
+    """The evaluation pair model after the EGNN (eval :687-818) in three HIP launches (csrc/head.hip, equigspr_head_eval_forward).
     ``h_all [2BN,F]``, ``x_all [2BN,3]`` = EGNN outputs for [src clouds..., tgt clouds...]; ``raw_*`` = the model inputs.
     Returns ``(R [B,3,3], t [B,3], equi_loss, weights [B,N], top_idx [B,K], p0)``.  Inference only, like the reference's use."""
     L = _lib.lib()

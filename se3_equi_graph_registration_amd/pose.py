@@ -202,7 +202,7 @@ class CrossAttentionPoseRegression(nn.Module):
             raise RuntimeError(f"top-k of {self.topk} out of {N} points (torch.topk raises in the reference, eval :694)")
         if (self.fused_head and not torch.is_grad_enabled() and hs.shape[-1] <= 64 and Fd <= 64 and N <= 8192
                 and self.mlp[0].in_features == 2 * hs.shape[-1]):
-            # two HIP launches (csrc/head.hip::head_eval_pair_kernel) instead of the ~35 ATen launches below; inference only,
+            # three HIP launches (csrc/head.hip::head_eval_pair_kernel, head_eval_weights_kernel) instead of the ~35 ATen launches below; inference only,
             # as the reference uses this head (evaluate_model runs under no_grad, eval :1150)
             mlp_params = [self.mlp[0].weight, self.mlp[0].bias, self.mlp[2].weight, self.mlp[2].bias,
                           self.mlp[4].weight, self.mlp[4].bias]

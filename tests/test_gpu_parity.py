@@ -189,6 +189,35 @@ def test_build_csr_scratch_contract_and_inverse(pk):
         _lib.check(L.equigspr_build_csr(p(key32), e, n, p(ptr), p(perm), None, p(scratch), 3, ops._stream()), "build_csr")
 
 
+def test_captured_graph_owns_its_csr_scratch(pk):
+    """A hipGraph that captured an index build keeps the zero-on-exit counter array it adopted from the eager warm-up (its replays
+    use the raw pointer); later eager builds of the SAME size -- on any stream, also while the graph replays -- must get a buffer
+    of their own."""
+    from se3_equi_graph_registration_amd import ops
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(2, 700, 3, generator=g).cuda()
+    y = torch.rand(2, 700, 3, generator=g).cuda()
+    ref_x = pk.build_pair_graph(x[:1], x[1:], 7)                    # eager warm-up: leaves a zeroed scratch of this size in the cache
+    ref_y = pk.build_pair_graph(y[:1], y[1:], 7)
+    rx, ry = ref_x.rperm.clone(), ref_y.rperm.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            cap = pk.build_pair_graph(x[:1], x[1:], 7)
+    owned = [b.data_ptr() for b in ops._CSR_GRAPH_OWNED]
+    assert owned and all(b.data_ptr() not in owned for b in ops._CSR_SCRATCH.values())
+    other = torch.cuda.Stream()
+    for _ in range(20):                                             # replays on one stream, eager builds of the same size on another
+        graph.replay()
+        with torch.cuda.stream(other):
+            eager = pk.build_pair_graph(y[:1], y[1:], 7)
+    torch.cuda.synchronize()
+    assert torch.equal(cap.rperm, rx) and torch.equal(eager.rperm, ry)
+    assert all(int(b.abs().sum()) == 0 for b in ops._CSR_SCRATCH.values()) and all(int(b.abs().sum()) == 0 for b in ops._CSR_GRAPH_OWNED)
+
+
 # ------------------------------------------------------------------------------------ EGNN forward
 @pytest.mark.parametrize("name", LAYER_FIX)
 def test_egnn_forward_golden(pk, golden_dir, name, parity):

@@ -24,6 +24,7 @@ stats b1 --steps 200 --warmup 20
 stats b16 --workload c3 --steps 60 --warmup 10
 stats c4shard --workload c4 --steps 40 --warmup 5
 stats c5 --workload c5 --steps 100 --warmup 10
+stats b16_irreps --workload c3 --edge-basis irreps --steps 60 --warmup 10
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/prof_$c
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof_$c -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-workloads --no-graph --min-seconds 0 > "$OUT/pmc_$c.log" 2>&1
