@@ -31,7 +31,8 @@ extern "C" {
 
 /* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
  * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
- * Supported kernel set: hidden_nf in {32, 33}, num_heads in {1, 2, 4, 8} at hidden_nf 32 and 1 at 33,
+ * Supported kernel set: hidden_nf in {16, 32, 33, 48, 64} (32 / 33: MFMA edge kernels; the others: the lane-per-feature kernels of
+ * csrc/egnn_edge_lane.h), num_heads in {1, 2, 4, 8} (1 at hidden_nf 33; in_edge_nf 0 at 16 / 48 / 64 only with one head),
  * in_nf/out_nf <= 64, in_edge_nf in {0, 1}, 1 <= n_layers <= 16. */
 typedef struct equigspr_egnn_config {
     int32_t in_nf;       /* in_node_nf  */

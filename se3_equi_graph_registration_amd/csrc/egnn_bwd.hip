@@ -17,8 +17,16 @@
 #include "egnn_mfma.h"
 #include "egnn_mfma16.h"
 #include "egnn_bwd16.h"
+#include "egnn_edge_lane.h"
 
 #include <algorithm>
+#include <mutex>
+
+// hidden widths without an MFMA formulation (egnn_edge_lane.h): 16, 48, 64 with 1, 2, 4 or 8 heads (in_edge_nf 1; 0 with one head)
+#define EQ_DISPATCH_LANE_WIDTHS \
+    EQ_DISPATCH(16, 1, 1) EQ_DISPATCH(16, 1, 0) EQ_DISPATCH(16, 2, 1) EQ_DISPATCH(16, 4, 1) EQ_DISPATCH(16, 8, 1) \
+    EQ_DISPATCH(48, 1, 1) EQ_DISPATCH(48, 1, 0) EQ_DISPATCH(48, 2, 1) EQ_DISPATCH(48, 4, 1) EQ_DISPATCH(48, 8, 1) \
+    EQ_DISPATCH(64, 1, 1) EQ_DISPATCH(64, 1, 0) EQ_DISPATCH(64, 2, 1) EQ_DISPATCH(64, 4, 1) EQ_DISPATCH(64, 8, 1)
 
 namespace eq {
 
@@ -121,7 +129,7 @@ __device__ __forceinline__ void slab_flush(const float* sl, float* __restrict__ 
     __syncthreads();
     for (int t = threadIdx.x; t < size; t += 256) dst[(size_t)blockIdx.x * size + t] = sl[t];
 }
-template <int MAXN = 64 * 34>
+template <int MAXN = 64 * 64>      // the largest matrix staged this way: an embedding of 64 x 64
 __device__ __forceinline__ void stage_copy(float* dst, const float* __restrict__ src, int n) {
     stage_batched<MAXN>(dst, src, n, [](int t) { return t; }, [](int t) { return t; });
 }
@@ -1062,14 +1070,33 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
                            const float* dagg, const float* Gx, float* dt1, float* gxr, float* gxc, float* slab,
                            int basis, hipStream_t s, int* n_slabs) {
     const int E = g->n_edges;
-    static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1, 2, 4 or 8 heads) or 33 (1 head)");
-    {                                      // the 16-edge formulation (hidden_nf 33: with the border feature): one 8-wave workgroup per CU, persistent
+    if constexpr (F == 32 || (F == 33 && H == 1)) {       // the 16-edge MFMA formulation (hidden_nf 33: with the border feature): one 8-wave workgroup per CU, persistent
         constexpr int NW = bwd16_waves(F - 32);
         const int chunk = edge_chunk_for(E, 256 * NW);
         int blocks = ceil_div(ceil_div(E, chunk), NW);
         blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
         hipLaunchKernelGGL((edge_bwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * NW), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
                            E, chunk, basis, dt1, dt1 + (size_t)E * 32, gxr, gxc, slab);
+        *n_slabs = blocks;
+    } else {                                               // any other width: lane = feature (egnn_edge_lane.h), one slab per workgroup
+        int blocks = ceil_div(E, 4 * 16);
+        blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+        const size_t smem = edge_bwd_lane_smem<F, H>();
+        {   // more than 64 KB of dynamic LDS needs the attribute (per device; set once per device and instantiation)
+            static std::mutex mu;
+            static bool done[64] = {false};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            std::lock_guard<std::mutex> lk(mu);
+            if (dev < 0 || dev >= 64 || !done[dev]) {
+                hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_bwd_lane_kernel<F, H, A>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                if (err != hipSuccess) { set_error("hipFuncSetAttribute(edge_bwd_lane): %s", hipGetErrorString(err)); return (int)err; }
+                if (dev >= 0 && dev < 64) done[dev] = true;
+            }
+        }
+        hipLaunchKernelGGL((edge_bwd_lane_kernel<F, H, A>), dim3(blocks), dim3(256), smem, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx, E,
+                           basis, dt1, gxr, gxc, slab);
         *n_slabs = blocks;
     }
     return 0;
@@ -1298,13 +1325,18 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
                 continue;
             }
         }
-        if constexpr (F == 32) {        // (hidden_nf 33 always takes the 16-node kernels above: its dt1 rows are split, see edge_bwd16_kernel)
-            if (ei_fused && l == 0) {
-                const EmbedInJob ei{params + ML.w_in, h_in, grad_h_in, work + B.emb_slab2};
-                hipLaunchKernelGGL((gather_bwd_kernel<F, H, A, true>), dim3(ngrid), dim3(256), 0, s, lw, g->rptr, g->rperm, g->cptr,
-                                   g->cperm, work + B.dt1, work + B.gxr, work + B.gxc, work + B.dh_part, work + B.Gx[cur], h_l, N,
-                                   work + B.Gh[nxt], work + B.Gx[nxt], grad_x_in, work + B.gat_slab + slab_of(l), ei);
-            } else
+        if constexpr (F != 33) {        // (hidden_nf 33 always takes the 16-node kernels above: its dt1 rows are split, see edge_bwd16_kernel)
+            bool done = false;
+            if constexpr (F == 32) {
+                if (ei_fused && l == 0) {
+                    const EmbedInJob ei{params + ML.w_in, h_in, grad_h_in, work + B.emb_slab2};
+                    hipLaunchKernelGGL((gather_bwd_kernel<F, H, A, true>), dim3(ngrid), dim3(256), 0, s, lw, g->rptr, g->rperm, g->cptr,
+                                       g->cperm, work + B.dt1, work + B.gxr, work + B.gxc, work + B.dh_part, work + B.Gx[cur], h_l, N,
+                                       work + B.Gh[nxt], work + B.Gx[nxt], grad_x_in, work + B.gat_slab + slab_of(l), ei);
+                    done = true;
+                }
+            }
+            if (!done)
                 hipLaunchKernelGGL((gather_bwd_kernel<F, H, A>), dim3(ngrid), dim3(256), 0, s, lw, g->rptr, g->rperm, g->cptr,
                                    g->cperm, work + B.dt1, work + B.gxr, work + B.gxc, work + B.dh_part, work + B.Gx[cur], h_l, N,
                                    work + B.Gh[nxt], work + B.Gx[nxt], (l == 0) ? grad_x_in : nullptr, work + B.gat_slab + slab_of(l),
@@ -1394,6 +1426,7 @@ extern "C" int equigspr_egnn_backward(const equigspr_egnn_config* cfg, const flo
     if (F == FF && H == HH && A == AA) return backward_impl<FF, HH, AA>(cfg, params, g, h_in, edge_attr, saved, grad_h_out, grad_x_out, grad_params, grad_h_in, grad_x_in, work, s);
     EQ_DISPATCH(32, 1, 1) EQ_DISPATCH(32, 1, 0) EQ_DISPATCH(32, 4, 1) EQ_DISPATCH(32, 4, 0)
     EQ_DISPATCH(32, 2, 1) EQ_DISPATCH(32, 2, 0) EQ_DISPATCH(32, 8, 1) EQ_DISPATCH(32, 8, 0)
+    EQ_DISPATCH_LANE_WIDTHS
     EQ_DISPATCH(33, 1, 1) EQ_DISPATCH(33, 1, 0)
 #undef EQ_DISPATCH
     set_error("egnn_backward: no kernel for F=%d H=%d A=%d", F, H, A);
@@ -1412,6 +1445,7 @@ extern "C" int equigspr_time_edge_bwd(const equigspr_egnn_config* cfg, const flo
     if (F == FF && H == HH && A == AA) return time_edge_bwd_impl<FF, HH, AA>(cfg, params, g, edge_attr, saved, bwd_work, iters, ms_out_host, s);
     EQ_DISPATCH(32, 1, 1) EQ_DISPATCH(32, 1, 0) EQ_DISPATCH(32, 4, 1) EQ_DISPATCH(32, 4, 0)
     EQ_DISPATCH(32, 2, 1) EQ_DISPATCH(32, 2, 0) EQ_DISPATCH(32, 8, 1) EQ_DISPATCH(32, 8, 0)
+    EQ_DISPATCH_LANE_WIDTHS
     EQ_DISPATCH(33, 1, 1) EQ_DISPATCH(33, 1, 0)
 #undef EQ_DISPATCH
     return EQUIGSPR_ENOTSUP;

@@ -15,7 +15,14 @@
 //                 per-node projections (or embedding_out after the last layer).
 #include "egnn_mfma.h"
 #include "egnn_mfma16.h"
+#include "egnn_edge_lane.h"
 
+
+// hidden widths without an MFMA formulation (egnn_edge_lane.h): 16, 48, 64 with 1, 2, 4 or 8 heads (in_edge_nf 1; 0 with one head)
+#define EQ_DISPATCH_LANE_WIDTHS \
+    EQ_DISPATCH(16, 1, 1) EQ_DISPATCH(16, 1, 0) EQ_DISPATCH(16, 2, 1) EQ_DISPATCH(16, 4, 1) EQ_DISPATCH(16, 8, 1) \
+    EQ_DISPATCH(48, 1, 1) EQ_DISPATCH(48, 1, 0) EQ_DISPATCH(48, 2, 1) EQ_DISPATCH(48, 4, 1) EQ_DISPATCH(48, 8, 1) \
+    EQ_DISPATCH(64, 1, 1) EQ_DISPATCH(64, 1, 0) EQ_DISPATCH(64, 2, 1) EQ_DISPATCH(64, 4, 1) EQ_DISPATCH(64, 8, 1)
 
 namespace eq {
 
@@ -168,14 +175,18 @@ template <int F, int H, int A>
 static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const float* edge_attr, const float* x, const float* P,
                             float* m, float* trans, int basis, hipStream_t s) {
     const int E = g->n_edges;
-    static_assert(F == 32 || (F == 33 && H == 1), "edge kernels: hidden_nf 32 (1, 2, 4 or 8 heads) or 33 (1 head)");
-    {                                      // the 16-edge formulation (hidden_nf 33: with the border feature); EQ_FWD16_OCC 4-wave workgroups per CU
+    if constexpr (F == 32 || (F == 33 && H == 1)) {       // the 16-edge MFMA formulation (hidden_nf 33: with the border feature); EQ_FWD16_OCC 4-wave workgroups per CU
         constexpr int occ = fwd16_occ(F - 32);
         const int chunk = edge_chunk_for(E, 256 * 4 * occ);
         int blocks = ceil_div(ceil_div(E, chunk), kFwd16Waves);
         blocks = blocks < 1 ? 1 : (blocks > 256 * occ ? 256 * occ : blocks);
         hipLaunchKernelGGL((edge_fwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * kFwd16Waves), 0, s, lw, g->row, g->col, edge_attr, x, P,
                            g->rinv, E, chunk, basis, m, trans);
+    } else {                                               // any other width: lane = feature (egnn_edge_lane.h)
+        int blocks = ceil_div(E, 64);
+        blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+        hipLaunchKernelGGL((edge_fwd_lane_kernel<F, H, A>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P, g->rinv, E,
+                           basis, m, trans);
     }
 }
 
@@ -681,9 +692,9 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
 #endif
     const int node_grid = node_groups < EQ_NODE_FWD_BLOCKS ? node_groups : EQ_NODE_FWD_BLOCKS;
     bool embed16 = false;
-    if constexpr (EQ_NODE_FWD16 && (F == 32 || H == 1)) embed16 = cfg->in_nf == F;
+    if constexpr (EQ_NODE_FWD16 && (F == 32 || (F == 33 && H == 1))) embed16 = cfg->in_nf == F;
     if (embed16) {
-        if constexpr (EQ_NODE_FWD16 && (F == 32 || H == 1))
+        if constexpr (EQ_NODE_FWD16 && (F == 32 || (F == 33 && H == 1)))
             hipLaunchKernelGGL((embed_in16_kernel<H, A, F - 32>), dim3(ceil_div(N, 16)), dim3(64), 0, s, params + ML.w_in, params + ML.b_in,
                                params + ML.layer0, h_in, x_in, N, hbuf(0), xbuf(0), P);
     } else
@@ -696,7 +707,7 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
             launch_edge_fwd<F, H, A>(lw, g, edge_attr, xbuf(l), P, m, trans, cfg->edge_basis, s);
         }
         float* xn = last ? x_out : xbuf(l + 1);
-        if constexpr (EQ_NODE_FWD16 && (F == 32 || H == 1)) {
+        if constexpr (EQ_NODE_FWD16 && (F == 32 || (F == 33 && H == 1))) {
             // few nodes: one wave per CU or less, latency decides -> 16 rows in flight; many nodes: 4 (registers for occupancy)
             // few nodes: one wave per CU or less, latency decides -> 16 rows in flight; many nodes: 4 (registers for occupancy).  Both sum
             // a node's rows in ascending order, so a cloud's outputs do not depend on what else is in the batch
@@ -749,6 +760,7 @@ extern "C" int equigspr_egnn_forward(const equigspr_egnn_config* cfg, const floa
     if (F == FF && H == HH && A == AA) return forward_impl<FF, HH, AA>(cfg, params, g, h_in, x_in, edge_attr, h_out, x_out, saved, work, s);
     EQ_DISPATCH(32, 1, 1) EQ_DISPATCH(32, 1, 0) EQ_DISPATCH(32, 4, 1) EQ_DISPATCH(32, 4, 0)
     EQ_DISPATCH(32, 2, 1) EQ_DISPATCH(32, 2, 0) EQ_DISPATCH(32, 8, 1) EQ_DISPATCH(32, 8, 0)
+    EQ_DISPATCH_LANE_WIDTHS
     EQ_DISPATCH(33, 1, 1) EQ_DISPATCH(33, 1, 0)
 #undef EQ_DISPATCH
     set_error("egnn_forward: no kernel for F=%d H=%d A=%d", F, H, A);
@@ -767,6 +779,7 @@ extern "C" int equigspr_time_edge_fwd(const equigspr_egnn_config* cfg, const flo
     if (F == FF && H == HH && A == AA) return time_edge_fwd_impl<FF, HH, AA>(cfg, params, g, h_in, x_in, edge_attr, work, iters, ms_out_host, s);
     EQ_DISPATCH(32, 1, 1) EQ_DISPATCH(32, 1, 0) EQ_DISPATCH(32, 4, 1) EQ_DISPATCH(32, 4, 0)
     EQ_DISPATCH(32, 2, 1) EQ_DISPATCH(32, 2, 0) EQ_DISPATCH(32, 8, 1) EQ_DISPATCH(32, 8, 0)
+    EQ_DISPATCH_LANE_WIDTHS
     EQ_DISPATCH(33, 1, 1) EQ_DISPATCH(33, 1, 0)
 #undef EQ_DISPATCH
     return EQUIGSPR_ENOTSUP;

@@ -760,6 +760,10 @@ def main():
         gen_layer_fixture(tr, "layer_n128_k8_f32_h2.npz", 128, 8, 32, 2, 2, seed=15)
         gen_layer_fixture(tr, "layer_n128_k8_f32_h8.npz", 128, 8, 32, 8, 2, seed=16)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "widths":       # hidden widths other than 32 / 33 (--hidden_node_nf, train :1547)
+        gen_layer_fixture(tr, "layer_n96_k6_f64_h2.npz", 96, 6, 64, 2, 2, seed=17)
+        gen_layer_fixture(tr, "layer_n96_k6_f16_h4.npz", 96, 6, 16, 4, 2, seed=18)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "wellcond":     # regenerate just this fixture
         gen_pair_fixture(tr, ev, "pair_n512_k12_l2_wellcond.npz", 512, 12, 32, 2, 1, seed=3, out_scale=0.02, with_grads=True,
                          tgt_noise=0.05)
@@ -770,6 +774,8 @@ def main():
     gen_layer_fixture(tr, "layer_n96_k6_f32_h1_dup.npz", 96, 6, 32, 1, 1, seed=14, dup_points=True)
     gen_layer_fixture(tr, "layer_n128_k8_f32_h2.npz", 128, 8, 32, 2, 2, seed=15)
     gen_layer_fixture(tr, "layer_n128_k8_f32_h8.npz", 128, 8, 32, 8, 2, seed=16)
+    gen_layer_fixture(tr, "layer_n96_k6_f64_h2.npz", 96, 6, 64, 2, 2, seed=17)
+    gen_layer_fixture(tr, "layer_n96_k6_f16_h4.npz", 96, 6, 16, 4, 2, seed=18)
     gen_pair_fixture(tr, ev, "pair_n2048_k20_l4.npz", 2048, 20, 32, 4, 1, seed=0)
     gen_pair_fixture(tr, ev, "pair_n512_k12_l2_wellcond.npz", 512, 12, 32, 2, 1, seed=3, out_scale=0.02, with_grads=True,
                      tgt_noise=0.05)

@@ -25,7 +25,8 @@ pytestmark = pytest.mark.gpu
 from oracle import egnn_oracle as orc  # noqa: E402  (checker only)
 
 LAYER_FIX = ["layer_n128_k8_f32_h1.npz", "layer_n128_k8_f33_h1.npz", "layer_n128_k8_f32_h4.npz",
-             "layer_n96_k6_f32_h1_dup.npz", "layer_n128_k8_f32_h2.npz", "layer_n128_k8_f32_h8.npz"]
+             "layer_n96_k6_f32_h1_dup.npz", "layer_n128_k8_f32_h2.npz", "layer_n128_k8_f32_h8.npz",
+             "layer_n96_k6_f64_h2.npz", "layer_n96_k6_f16_h4.npz"]
 PAIR_FIX = ["pair_n2048_k20_l4.npz", "pair_n512_k12_l2_wellcond.npz", "pair_ckpt_n2048_k16_l3_h4.npz"]
 
 
@@ -481,6 +482,8 @@ def test_train_step_gradients_golden(pk, golden_dir, parity):
 
 @pytest.mark.parametrize("feat,heads,in_nf,out_nf,n,e", [(32, 4, 32, 32, 257, 3001), (33, 1, 33, 33, 257, 3001), (33, 1, 17, 40, 257, 3001),
                                                          (32, 2, 32, 32, 257, 3001), (32, 8, 9, 32, 257, 3001), (32, 8, 32, 32, 16999, 70001),
+                                                         (16, 1, 16, 16, 257, 3001), (48, 4, 20, 48, 257, 3001), (64, 8, 64, 64, 257, 3001),
+                                                         (64, 1, 64, 9, 2000, 9001),
                                                          (32, 1, 5, 64, 257, 3001), (32, 1, 5, 7, 16999, 70001), (32, 4, 32, 32, 16999, 70001),
                                                          (33, 1, 17, 40, 16999, 70001)])
 def test_backward_random_graph_vs_oracle_autograd(pk, feat, heads, in_nf, out_nf, n, e):
@@ -1122,7 +1125,8 @@ def test_pair_without_valid_correspondences_matches_reference_semantics(pk):
     assert torch.allclose(rl.cpu(), o_rl, atol=1e-5) and torch.allclose(tl[1].cpu(), o_tl[1], atol=1e-5)
 
 
-@pytest.mark.parametrize("feat,B,n,k,scale", [(32, 3, 1000, 7, 3.0), (33, 2, 777, 9, 60.0), (32, 1, 130, 5, 1.0)])
+@pytest.mark.parametrize("feat,B,n,k,scale", [(32, 3, 1000, 7, 3.0), (33, 2, 777, 9, 60.0), (32, 1, 130, 5, 1.0), (64, 2, 500, 6, 3.0),
+                                              (16, 1, 300, 5, 3.0)])
 def test_pair_train_head_odd_shapes_vs_oracle(pk, feat, B, n, k, scale):
     """Shapes that are not multiples of any tile size (points, k, batch), KITTI-scale coordinates, both hidden widths:
     R, t, the correspondence loss, the equi loss and the top-k index sets against the oracle."""
@@ -1151,7 +1155,7 @@ def test_pair_train_head_odd_shapes_vs_oracle(pk, feat, B, n, k, scale):
         assert set(model.last_top_idx[i].cpu().tolist()) == set(extras["top_idx"][i].tolist())
 
 
-@pytest.mark.parametrize("feat,B", [(33, 2), (32, 3)])
+@pytest.mark.parametrize("feat,B", [(33, 2), (32, 3), (48, 2)])
 def test_train_step_gradients_vs_oracle_autograd(pk, feat, B):
     """The whole training loss (train :1120) through the fused head, Kabsch, both EGNN passes: every parameter gradient
     against the oracle's autograd in fp32 and fp64 (hidden_nf = 33 exercises the border path of the MFMA backward)."""

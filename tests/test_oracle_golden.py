@@ -10,7 +10,8 @@ import torch
 from oracle import egnn_oracle as orc
 
 LAYER_FIX = ["layer_n128_k8_f32_h1.npz", "layer_n128_k8_f33_h1.npz", "layer_n128_k8_f32_h4.npz",
-             "layer_n96_k6_f32_h1_dup.npz", "layer_n128_k8_f32_h2.npz", "layer_n128_k8_f32_h8.npz"]
+             "layer_n96_k6_f32_h1_dup.npz", "layer_n128_k8_f32_h2.npz", "layer_n128_k8_f32_h8.npz",
+             "layer_n96_k6_f64_h2.npz", "layer_n96_k6_f16_h4.npz"]
 PAIR_FIX = ["pair_n2048_k20_l4.npz", "pair_n512_k12_l2_wellcond.npz", "pair_ckpt_n2048_k16_l3_h4.npz"]
 
 
