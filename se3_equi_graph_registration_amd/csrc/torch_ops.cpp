@@ -130,9 +130,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> weighted_kabsch_backward(const at
 
 int64_t abi_version() { return equigspr_abi_version(); }
 
-// ---- Autograd key.  weighted_kabsch_forward is differentiable: its backward is the C-ABI's closed-form Kabsch backward.  The other
-// ops are inference forms -- a tensor that requires grad raises instead of silently producing a non-differentiable output (training
-// goes through the Python autograd node around equigspr_egnn_forward / _backward, se3_equi_graph_registration_amd/egnn.py).
+// ---- Autograd key.  weighted_kabsch_forward and egnn_forward are differentiable through the dispatcher: their backward is the C-ABI's
+// (closed-form Kabsch backward; equigspr_egnn_backward on the activations the training-form forward kept).
 struct KabschFn : torch::autograd::Function<KabschFn> {
     static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const at::Tensor& src, const at::Tensor& tgt,
                                                   const at::Tensor& w) {
@@ -160,19 +159,116 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> weighted_kabsch_forward_autograd(
     return {out[0], out[1], out[2]};
 }
 bool wants_grad(const at::Tensor& t) { return at::GradMode::is_enabled() && t.defined() && t.requires_grad(); }
+
+equigspr_egnn_config make_cfg(const at::Tensor& h, bool has_attr, int64_t hidden_nf, int64_t out_nf, int64_t n_layers, int64_t num_heads,
+                              int64_t edge_basis) {
+    return equigspr_egnn_config{(int32_t)h.size(1), (int32_t)hidden_nf, (int32_t)out_nf, has_attr ? 1 : 0, (int32_t)n_layers, (int32_t)num_heads,
+                                (int32_t)edge_basis};
+}
+
+// egnn_backward(params, h, row, col, rptr, rperm, rinv, cptr, cperm, edge_attr?, saved, grad_h_out, grad_x_out, cfg ints)
+//   -> (grad_params, grad_h_in, grad_x_in)     (equigspr_egnn_backward: loss.backward() through EGNN.forward, train :1126)
+std::tuple<at::Tensor, at::Tensor, at::Tensor> egnn_backward(const at::Tensor& params, const at::Tensor& h, const at::Tensor& row,
+                                                             const at::Tensor& col, const at::Tensor& rptr, const at::Tensor& rperm,
+                                                             const at::Tensor& rinv, const at::Tensor& cptr, const at::Tensor& cperm,
+                                                             const c10::optional<at::Tensor>& edge_attr, const at::Tensor& saved,
+                                                             const at::Tensor& gh, const at::Tensor& gx, int64_t hidden_nf, int64_t out_nf,
+                                                             int64_t n_layers, int64_t num_heads, int64_t edge_basis) {
+    need(params, "params", at::kFloat, 1); need(h, "h", at::kFloat, 2); need(saved, "saved", at::kFloat, 1);
+    need(gh, "grad_h_out", at::kFloat, 2); need(gx, "grad_x_out", at::kFloat, 2);
+    for (const at::Tensor* t : {&row, &col, &rptr, &rperm, &rinv, &cptr, &cperm}) need(*t, "graph index", at::kInt, 1);
+    const int64_t n = h.size(0), e = row.size(0);
+    TORCH_CHECK(col.numel() == e && rperm.numel() >= e && rinv.numel() >= e && cperm.numel() >= e && rptr.numel() == n + 1 && cptr.numel() == n + 1,
+                "equigspr::egnn_backward: graph index sizes do not match N = ", n, ", E = ", e);
+    TORCH_CHECK(gh.size(0) == n && gh.size(1) == out_nf && gx.size(0) == n && gx.size(1) == 3, "equigspr::egnn_backward: grad_h_out [N, out_nf], grad_x_out [N, 3]");
+    if (edge_attr.has_value()) { need(*edge_attr, "edge_attr", at::kFloat, -1); TORCH_CHECK(edge_attr->numel() == e, "equigspr::egnn_backward: edge_attr must hold one value per edge"); }
+    DeviceGuard guard(h.device());
+    auto cfg = make_cfg(h, edge_attr.has_value(), hidden_nf, out_nf, n_layers, num_heads, edge_basis);
+    const int64_t want = equigspr_egnn_param_count(&cfg);
+    TORCH_CHECK(want > 0 && want == params.numel(), "equigspr::egnn_backward: configuration / parameter block mismatch");
+    TORCH_CHECK(saved.numel() >= equigspr_egnn_saved_size(&cfg, (int32_t)n, (int32_t)e), "equigspr::egnn_backward: `saved` is too small");
+    equigspr_graph g{(int32_t)n, (int32_t)e, row.data_ptr<int32_t>(), col.data_ptr<int32_t>(), rptr.data_ptr<int32_t>(), rperm.data_ptr<int32_t>(),
+                     cptr.data_ptr<int32_t>(), cperm.data_ptr<int32_t>(), rinv.data_ptr<int32_t>()};
+    auto gp = at::zeros_like(params);
+    auto ghi = at::empty_like(h), gxi = at::empty({n, 3}, h.options());
+    auto work = at::empty({equigspr_egnn_bwd_work_size(&cfg, (int32_t)n, (int32_t)e)}, h.options());
+    check(equigspr_egnn_backward(&cfg, params.data_ptr<float>(), &g, h.data_ptr<float>(), edge_attr.has_value() ? edge_attr->data_ptr<float>() : nullptr,
+                                 saved.data_ptr<float>(), gh.data_ptr<float>(), gx.data_ptr<float>(), gp.data_ptr<float>(), ghi.data_ptr<float>(),
+                                 gxi.data_ptr<float>(), work.data_ptr<float>(), cur_stream(h)), "egnn_backward");
+    return {gp, ghi, gxi};
+}
+
+// Autograd kernel of egnn_forward: the training form of equigspr_egnn_forward (node-level activations kept in `saved`, both inverse
+// indices built), backward = equigspr_egnn_backward -- EGNN.forward differentiable through the dispatcher (params, h and x).
+struct EgnnFn : torch::autograd::Function<EgnnFn> {
+    static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const at::Tensor& params, const at::Tensor& h_,
+                                                  const at::Tensor& x_, const at::Tensor& row, const at::Tensor& col,
+                                                  const c10::optional<at::Tensor>& edge_attr, int64_t hidden_nf, int64_t out_nf, int64_t n_layers,
+                                                  int64_t num_heads, int64_t edge_basis) {
+        at::AutoDispatchBelowADInplaceOrView below;
+        const at::Tensor p = params.detach().contiguous(), h = h_.detach().contiguous(), x = x_.detach().contiguous();
+        need(p, "params", at::kFloat, 1); need(h, "h", at::kFloat, 2); need(x, "x", at::kFloat, 2);
+        need(row, "row", at::kInt, 1); need(col, "col", at::kInt, 1);
+        const int64_t n = h.size(0), e = row.size(0);
+        TORCH_CHECK(x.size(0) == n && x.size(1) == 3 && col.numel() == e, "equigspr::egnn_forward: x must be [N, 3], row and col of one length");
+        if (edge_attr.has_value()) { need(*edge_attr, "edge_attr", at::kFloat, -1); TORCH_CHECK(edge_attr->numel() == e, "equigspr::egnn_forward: edge_attr must hold one value per edge"); }
+        DeviceGuard guard(h.device());
+        auto cfg = make_cfg(h, edge_attr.has_value(), hidden_nf, out_nf, n_layers, num_heads, edge_basis);
+        const int64_t want = equigspr_egnn_param_count(&cfg);
+        TORCH_CHECK(want > 0, "equigspr::egnn_forward: unsupported configuration: ", equigspr_last_error());
+        TORCH_CHECK(want == p.numel(), "equigspr::egnn_forward: parameter block has ", p.numel(), " floats, the configuration needs ", want);
+        auto io = row.options();
+        auto rptr = at::empty({n + 1}, io), rperm = at::empty({std::max<int64_t>(e, 1)}, io), rinv = at::empty({std::max<int64_t>(e, 1)}, io);
+        auto cptr = at::empty({n + 1}, io), cperm = at::empty({std::max<int64_t>(e, 1)}, io), scratch = at::empty({n + 1}, io);
+        void* s = cur_stream(h);
+        check(equigspr_build_csr(row.data_ptr<int32_t>(), (int32_t)e, (int32_t)n, rptr.data_ptr<int32_t>(), rperm.data_ptr<int32_t>(),
+                                 rinv.data_ptr<int32_t>(), scratch.data_ptr<int32_t>(), EQUIGSPR_SCRATCH_DIRTY, s), "build_csr(row)");
+        check(equigspr_build_csr(col.data_ptr<int32_t>(), (int32_t)e, (int32_t)n, cptr.data_ptr<int32_t>(), cperm.data_ptr<int32_t>(), nullptr,
+                                 scratch.data_ptr<int32_t>(), EQUIGSPR_SCRATCH_ZERO, s), "build_csr(col)");
+        equigspr_graph g{(int32_t)n, (int32_t)e, row.data_ptr<int32_t>(), col.data_ptr<int32_t>(), rptr.data_ptr<int32_t>(), rperm.data_ptr<int32_t>(),
+                         cptr.data_ptr<int32_t>(), cperm.data_ptr<int32_t>(), rinv.data_ptr<int32_t>()};
+        auto fo = h.options();
+        auto h_out = at::empty({n, out_nf}, fo), x_out = at::empty({n, 3}, fo);
+        auto saved = at::empty({equigspr_egnn_saved_size(&cfg, (int32_t)n, (int32_t)e)}, fo);
+        auto work = at::empty({equigspr_egnn_work_size(&cfg, (int32_t)n, (int32_t)e)}, fo);
+        check(equigspr_egnn_forward(&cfg, p.data_ptr<float>(), &g, h.data_ptr<float>(), x.data_ptr<float>(),
+                                    edge_attr.has_value() ? edge_attr->data_ptr<float>() : nullptr, h_out.data_ptr<float>(), x_out.data_ptr<float>(),
+                                    saved.data_ptr<float>(), work.data_ptr<float>(), s), "egnn_forward");
+        ctx->save_for_backward({p, h, row, col, rptr, rperm, rinv, cptr, cperm, saved, edge_attr.has_value() ? *edge_attr : at::Tensor()});
+        ctx->saved_data["cfg"] = std::vector<int64_t>{hidden_nf, out_nf, n_layers, num_heads, edge_basis};
+        return {h_out, x_out};
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list g) {
+        const auto sv = ctx->get_saved_variables();
+        const auto c = ctx->saved_data["cfg"].toIntVector();
+        const int64_t n = sv[1].size(0);
+        const auto gh = g[0].defined() ? g[0].contiguous() : at::zeros({n, c[1]}, sv[1].options());
+        const auto gx = g[1].defined() ? g[1].contiguous() : at::zeros({n, 3}, sv[1].options());
+        const c10::optional<at::Tensor> ea = sv[10].defined() ? c10::optional<at::Tensor>(sv[10]) : c10::nullopt;
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("equigspr::egnn_backward", "")
+                             .typed<std::tuple<at::Tensor, at::Tensor, at::Tensor>(const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&,
+                                                                                  const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&,
+                                                                                  const at::Tensor&, const c10::optional<at::Tensor>&, const at::Tensor&,
+                                                                                  const at::Tensor&, const at::Tensor&, int64_t, int64_t, int64_t, int64_t,
+                                                                                  int64_t)>();
+        auto out = op.call(sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7], sv[8], ea, sv[9], gh, gx, c[0], c[1], c[2], c[3], c[4]);
+        return {std::get<0>(out), std::get<1>(out), std::get<2>(out), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(),
+                at::Tensor(), at::Tensor()};
+    }
+};
 std::tuple<at::Tensor, at::Tensor> egnn_forward_autograd(const at::Tensor& params, const at::Tensor& h, const at::Tensor& x, const at::Tensor& row,
                                                          const at::Tensor& col, const c10::optional<at::Tensor>& edge_attr, int64_t hidden_nf,
                                                          int64_t out_nf, int64_t n_layers, int64_t num_heads, int64_t edge_basis) {
-    TORCH_CHECK(!wants_grad(params) && !wants_grad(h) && !wants_grad(x),
-                "equigspr::egnn_forward is the inference form (no autograd): run it under torch.no_grad() / on detached tensors, or train "
-                "through se3_equi_graph_registration_amd.EGNN (autograd node over equigspr_egnn_forward / equigspr_egnn_backward)");
-    at::AutoDispatchBelowADInplaceOrView below;
-    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("equigspr::egnn_forward", "")
-                         .typed<std::tuple<at::Tensor, at::Tensor>(const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&,
-                                                                    const c10::optional<at::Tensor>&, int64_t, int64_t, int64_t, int64_t, int64_t)>();
-    return op.call(params, h, x, row, col, edge_attr, hidden_nf, out_nf, n_layers, num_heads, edge_basis);
+    if (!wants_grad(params) && !wants_grad(h) && !wants_grad(x)) {          // inference form: nothing kept, no col index
+        at::AutoDispatchBelowADInplaceOrView below;
+        static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("equigspr::egnn_forward", "")
+                             .typed<std::tuple<at::Tensor, at::Tensor>(const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&,
+                                                                        const c10::optional<at::Tensor>&, int64_t, int64_t, int64_t, int64_t, int64_t)>();
+        return op.call(params, h, x, row, col, edge_attr, hidden_nf, out_nf, n_layers, num_heads, edge_basis);
+    }
+    auto out = EgnnFn::apply(params, h, x, row, col, edge_attr, hidden_nf, out_nf, n_layers, num_heads, edge_basis);
+    return {out[0], out[1]};
 }
-
 }  // namespace
 
 TORCH_LIBRARY(equigspr, m) {
@@ -181,6 +277,9 @@ TORCH_LIBRARY(equigspr, m) {
     m.def("build_inverse_index(Tensor key, int n_nodes) -> (Tensor, Tensor, Tensor)");
     m.def("egnn_forward(Tensor params, Tensor h, Tensor x, Tensor row, Tensor col, Tensor? edge_attr, int hidden_nf, int out_nf, "
           "int n_layers, int num_heads=1, int edge_basis=0) -> (Tensor, Tensor)");
+    m.def("egnn_backward(Tensor params, Tensor h, Tensor row, Tensor col, Tensor rptr, Tensor rperm, Tensor rinv, Tensor cptr, Tensor cperm, "
+          "Tensor? edge_attr, Tensor saved, Tensor grad_h_out, Tensor grad_x_out, int hidden_nf, int out_nf, int n_layers, int num_heads=1, "
+          "int edge_basis=0) -> (Tensor, Tensor, Tensor)");
     m.def("weighted_kabsch_forward(Tensor src, Tensor tgt, Tensor weights) -> (Tensor, Tensor, Tensor)");
     m.def("weighted_kabsch_backward(Tensor src, Tensor tgt, Tensor weights, Tensor aux, Tensor grad_R, Tensor grad_t) -> (Tensor, Tensor, Tensor)");
 }
@@ -194,6 +293,7 @@ TORCH_LIBRARY_IMPL(equigspr, CUDA, m) {       // the HIP backend key of a ROCm b
     m.impl("knn_graph", &knn_graph);
     m.impl("build_inverse_index", &build_inverse_index);
     m.impl("egnn_forward", &egnn_forward);
+    m.impl("egnn_backward", &egnn_backward);
     m.impl("weighted_kabsch_forward", &weighted_kabsch_forward);
     m.impl("weighted_kabsch_backward", &weighted_kabsch_backward);
 }

@@ -1269,9 +1269,18 @@ def test_torch_library_ops_match_the_ctypes_path(pk):
     Rd, td, _ = ops.weighted_kabsch_forward(s2, t2_, w2)
     (Rd.sum() + td.sum()).backward()
     assert torch.allclose(s2.grad, sr.grad) and torch.allclose(t2_.grad, tr.grad) and torch.allclose(w2.grad, wr.grad)
-    # ... and the inference-form egnn_forward refuses tensors that want a gradient instead of silently detaching them
-    with pytest.raises(RuntimeError, match="inference form"):
-        ops.egnn_forward(m.flat_params, h.clone().requires_grad_(True), x, row32, col32, torch.ones(n * k, device="cuda"), 32, 32, 2, 1, 0)
+    # ... and so has egnn_forward: the training form + equigspr_egnn_backward.  Same gradients as the package's own autograd node.
+    hp, xp = h.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    m.zero_grad()
+    ho_p, xo_p = m(hp, xp, [e[0], e[1]], torch.ones(n * k, 1, device="cuda"))
+    gh_, gx_ = torch.randn(n, 32, generator=g).cuda(), torch.randn(n, 3, generator=g).cuda()
+    ((ho_p * gh_).sum() + (xo_p * gx_).sum()).backward()
+    flat = m.flat_params.detach().clone().requires_grad_(True)
+    hd, xd = h.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ho_d, xo_d = ops.egnn_forward(flat, hd, xd, row32, col32, torch.ones(n * k, device="cuda"), 32, 32, 2, 1, 0)
+    assert torch.equal(ho_d, ho_p.detach()) and torch.equal(xo_d, xo_p.detach())
+    ((ho_d * gh_).sum() + (xo_d * gx_).sum()).backward()
+    assert torch.equal(flat.grad, m.flat_grads) and torch.equal(hd.grad, hp.grad) and torch.equal(xd.grad, xp.grad)
     with pytest.raises(RuntimeError):
         ops.egnn_forward(m.flat_params[:-1].contiguous(), h, x, row32, col32, None, 32, 32, 2, 1, 0)
     with pytest.raises(RuntimeError, match="same length"):
