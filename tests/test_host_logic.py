@@ -61,7 +61,11 @@ def test_state_dict_keys_and_shipped_checkpoint_shapes():
 
 def test_unsupported_configurations_fail_loudly():
     with pytest.raises(NotImplementedError):
-        pk.EGNN(32, 48, 32, in_edge_nf=1, device="cpu", n_layers=2)            # hidden size outside the kernel set
+        pk.EGNN(32, 40, 32, in_edge_nf=1, device="cpu", n_layers=2)            # hidden size outside the kernel set (16, 32, 33, 48, 64)
+    with pytest.raises(NotImplementedError):
+        pk.EGNN(33, 33, 33, in_edge_nf=1, device="cpu", n_layers=2, num_heads=3)   # hidden_nf 33 runs with one head only
+    for hid, heads in ((48, 1), (64, 8), (16, 2), (32, 2)):                         # ... and the widths / head counts added in round 3 construct
+        assert pk.EGNN(20, hid, 24, in_edge_nf=1, device="cpu", n_layers=1, num_heads=heads).cfg.hidden_nf == hid
     with pytest.raises(NotImplementedError):
         pk.EGNN(32, 32, 32, in_edge_nf=1, device="cpu", n_layers=2, normalize=True)
     with pytest.raises(NotImplementedError):
