@@ -27,7 +27,7 @@ extern "C" {
 
 #define EQUIGSPR_EINVAL   (-1)  /* bad shape / size / null pointer                         */
 #define EQUIGSPR_ENOTSUP  (-2)  /* configuration outside the compiled kernel set             */
-#define EQUIGSPR_ABI_VERSION 9
+#define EQUIGSPR_ABI_VERSION 10
 
 /* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
  * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
@@ -95,10 +95,14 @@ int64_t equigspr_egnn_layer_offset(const equigspr_egnn_config* cfg, int32_t laye
  *   row32/col32 [n_clouds*n*k] or NULL: same edges as GLOBAL int32 node ids (device format).
  *   row_hist   [n_clouds*n] int32 or NULL, +=: row_hist[i] += number of edges whose row (neighbour) is node i -- the
  *              histogram equigspr_build_csr(key = row32) starts from (pass EQUIGSPR_SCRATCH_HISTOGRAM there).
+ *   arrival    [n_clouds*n*k] int32 or NULL (ABI 10; needs row_hist): arrival[e] = the value row_hist[row32[e]] had when edge e
+ *              was counted -- a unique slot 0 .. deg-1 inside its row segment, in arrival order.  Handed to equigspr_build_csr
+ *              it turns the index fill into a plain scatter: the returning atomics (the slow part of the fill: scattered
+ *              returning atomics run at ~25 G/s chip-wide) are issued here, under the search's arithmetic.
  * Distance contract: d2 = fl(fl(fl(dx*dx)+fl(dy*dy))+fl(dz*dz)), ties by lower index.
  * Limits: 1 <= k <= 64, k <= n (k <= n-1 when loop==0), n <= 8192. */
 int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, int32_t k, int32_t loop,
-                       int64_t* edges_i64, int32_t* row32, int32_t* col32, int32_t* row_hist,
+                       int64_t* edges_i64, int32_t* row32, int32_t* col32, int32_t* row_hist, int32_t* arrival,
                        int32_t force_slow_path, void* stream);
 
 /* ---- graph index build ---------------------------------------------------------------
@@ -109,12 +113,15 @@ int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, int32_t k, i
  *   scratch_state says what scratch holds on entry: EQUIGSPR_SCRATCH_DIRTY (anything: it is cleared first),
  *   EQUIGSPR_SCRATCH_ZERO (all-zero: the clear is skipped) or EQUIGSPR_SCRATCH_HISTOGRAM (scratch[i] = number of edges
  *   with key i, e.g. the row_hist output of equigspr_knn_graph for key = row32: clear and count are skipped).  On return
- *   scratch is all-zero again, so one buffer can be handed from call to call on the same stream. */
+ *   scratch is all-zero again, so one buffer can be handed from call to call on the same stream.
+ *   arrival [E] or NULL (ABI 10; with EQUIGSPR_SCRATCH_HISTOGRAM): a unique slot of every edge inside its key's segment (the
+ *   `arrival` output of equigspr_knn_graph): the fill is then perm[ptr[key[e]] + arrival[e]] = e, no atomics; the ordering pass
+ *   that follows makes the result the same stable sort either way. */
 #define EQUIGSPR_SCRATCH_DIRTY 0
 #define EQUIGSPR_SCRATCH_ZERO 1
 #define EQUIGSPR_SCRATCH_HISTOGRAM 2
 int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n_nodes, int32_t* ptr, int32_t* perm,
-                       int32_t* inv, int32_t* scratch, int32_t scratch_state, void* stream);
+                       int32_t* inv, int32_t* scratch, int32_t scratch_state, const int32_t* arrival, void* stream);
 /* inv[perm[p]] = p for p in [0, n): the rinv field of equigspr_graph from rperm */
 int equigspr_invert_perm(const int32_t* perm, int32_t n, int32_t* inv, void* stream);
 /* int64 reference edge list [2,E] (one cloud, local ids) -> int32 global ids (+node_offset) */

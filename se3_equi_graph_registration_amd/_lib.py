@@ -33,8 +33,8 @@ _SIGNATURES = {
     "equigspr_egnn_param_count": (c_int64, [POINTER(EgnnConfig)]),
     "equigspr_egnn_layer_offset": (c_int64, [POINTER(EgnnConfig), c_int32]),
     "equigspr_knn_graph": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
-                                          c_void_p, c_void_p, c_int32, c_void_p]),
-    "equigspr_build_csr": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "equigspr_build_csr": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "equigspr_invert_perm": (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
     "equigspr_edges_i64_to_i32": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "equigspr_egnn_saved_size": (c_int64, [POINTER(EgnnConfig), c_int32, c_int32]),
@@ -105,7 +105,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if L.equigspr_abi_version() != 9:
+        if L.equigspr_abi_version() != 10:
             raise RuntimeError("libequigspr.so ABI version mismatch")
         _lib = L
     return _lib

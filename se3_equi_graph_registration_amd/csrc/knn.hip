@@ -82,7 +82,7 @@ template <int NPL, bool kLoop, bool kFull>
 __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, int n_clouds, int n, int k,
                                                  long long* __restrict__ edges,
                                                  int* __restrict__ row32, int* __restrict__ col32,
-                                                 int* __restrict__ row_hist, int force_slow) {
+                                                 int* __restrict__ row_hist, int* __restrict__ arrival, int force_slow) {
     static_assert(NPL % 2 == 0, "candidates are processed in pairs");
     __shared__ u64 list[64];
     const int lane = threadIdx.x;
@@ -158,7 +158,10 @@ __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, in
         }
         if (row32) row32[(size_t)cloud * epc + e] = cloud * n + out_idx;
         if (col32) col32[(size_t)cloud * epc + e] = cloud * n + q;
-        if (row_hist) atomicAdd(&row_hist[cloud * n + out_idx], 1);      // the key histogram build_csr(key = row) starts from
+        if (row_hist) {                                  // the key histogram build_csr(key = row) starts from; its old value = this edge's slot
+            const int slot_in_row = atomicAdd(&row_hist[cloud * n + out_idx], 1);
+            if (arrival) arrival[(size_t)cloud * epc + e] = slot_in_row;
+        }
     }
 }
 
@@ -177,7 +180,7 @@ template <bool kLoop, int kKnnQpw>
 __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict__ x, int n_clouds, int n, int k,
                                                         long long* __restrict__ edges, int* __restrict__ row32,
                                                         int* __restrict__ col32, int* __restrict__ row_hist,
-                                                        int force_slow) {
+                                                        int* __restrict__ arrival, int force_slow) {
     __shared__ float tile[kKnnTile * 3];
     __shared__ u64 list[4 * kKnnQpw][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -310,7 +313,10 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
             }
             if (row32) row32[(size_t)cloud * epc + e] = cloud * n + out_idx;
             if (col32) col32[(size_t)cloud * epc + e] = cloud * n + q;
-            if (row_hist) atomicAdd(&row_hist[cloud * n + out_idx], 1);
+            if (row_hist) {
+                const int slot_in_row = atomicAdd(&row_hist[cloud * n + out_idx], 1);
+                if (arrival) arrival[(size_t)cloud * epc + e] = slot_in_row;
+            }
         }
     }
 }
@@ -328,6 +334,12 @@ __global__ void csr_fill_kernel(const int* __restrict__ key, int n_edges, int* _
                                 int* __restrict__ perm) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n_edges) perm[atomicAdd(&cursor[key[e]], 1)] = e;
+}
+// the same with every edge's slot inside its segment already known (equigspr_knn_graph's `arrival`): a scatter, no atomics
+__global__ void csr_fill_ranked_kernel(const int* __restrict__ key, const int* __restrict__ arrival, int n_edges,
+                                       const int* __restrict__ ptr, int* __restrict__ perm) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_edges) perm[ptr[key[e]] + arrival[e]] = e;
 }
 
 // each node's segment back into ascending edge order (atomics filled it in arbitrary order):
@@ -384,7 +396,7 @@ __global__ void edges_i64_to_i32_kernel(const long long* __restrict__ edges, int
 #define EQ_KNN_PER_QUERY_MAX 2048
 #endif
 extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, int32_t k, int32_t loop,
-                                  int64_t* edges_i64, int32_t* row32, int32_t* col32, int32_t* row_hist,
+                                  int64_t* edges_i64, int32_t* row32, int32_t* col32, int32_t* row_hist, int32_t* arrival,
                                   int32_t force_slow_path, void* stream) {
     using namespace eq;
     EQ_CHECK_ARG(x != nullptr, EQUIGSPR_EINVAL, "knn_graph: x is null");
@@ -393,11 +405,12 @@ extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, i
     EQ_CHECK_ARG(k >= 1 && k <= 64, EQUIGSPR_ENOTSUP, "knn_graph: k=%d outside [1,64]", k);
     EQ_CHECK_ARG(k <= (loop ? n : n - 1), EQUIGSPR_EINVAL, "knn_graph: k=%d exceeds candidates (n=%d, loop=%d)", k, n, loop);
     EQ_CHECK_ARG((long long)n_clouds * n * k < (1ll << 31), EQUIGSPR_EINVAL, "knn_graph: edge count overflows int32");
+    EQ_CHECK_ARG(!arrival || row_hist, EQUIGSPR_EINVAL, "knn_graph: arrival needs row_hist");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(n_clouds * n), block(64);
     long long* e64 = reinterpret_cast<long long*>(edges_i64);
 #define EQ_KNN_LAUNCH(NPL, LOOP, FULL) \
-    hipLaunchKernelGGL((knn_kernel<NPL, LOOP, FULL>), grid, block, 0, s, x, n_clouds, n, k, e64, row32, col32, row_hist, force_slow_path)
+    hipLaunchKernelGGL((knn_kernel<NPL, LOOP, FULL>), grid, block, 0, s, x, n_clouds, n, k, e64, row32, col32, row_hist, arrival, force_slow_path)
 #define EQ_KNN_PICK(NPL) \
     do { const bool full = n == 64 * NPL; \
          if (loop) { if (full) EQ_KNN_LAUNCH(NPL, true, true); else EQ_KNN_LAUNCH(NPL, true, false); } \
@@ -412,7 +425,7 @@ extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, i
         const bool wide = (long long)n_clouds * ceil_div(n, 32) >= 2048;
         const int bpc = ceil_div(n, wide ? 32 : 16);
 #define EQ_KNN_TILED(LOOP, QPW) \
-    hipLaunchKernelGGL((knn_tiled_kernel<LOOP, QPW>), dim3(n_clouds * bpc), dim3(256), 0, s, x, n_clouds, n, k, e64, row32, col32, row_hist, force_slow_path)
+    hipLaunchKernelGGL((knn_tiled_kernel<LOOP, QPW>), dim3(n_clouds * bpc), dim3(256), 0, s, x, n_clouds, n, k, e64, row32, col32, row_hist, arrival, force_slow_path)
         if (loop) { if (wide) EQ_KNN_TILED(true, 8); else EQ_KNN_TILED(true, 4); }
         else { if (wide) EQ_KNN_TILED(false, 8); else EQ_KNN_TILED(false, 4); }
 #undef EQ_KNN_TILED
@@ -424,7 +437,8 @@ extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, i
 }
 
 extern "C" int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n_nodes, int32_t* ptr,
-                                  int32_t* perm, int32_t* inv, int32_t* scratch, int32_t scratch_state, void* stream) {
+                                  int32_t* perm, int32_t* inv, int32_t* scratch, int32_t scratch_state, const int32_t* arrival,
+                                  void* stream) {
     using namespace eq;
     EQ_CHECK_ARG(ptr && scratch && (n_edges == 0 || (key && perm)), EQUIGSPR_EINVAL, "build_csr: null pointer");
     EQ_CHECK_ARG(n_edges >= 0 && n_nodes >= 1, EQUIGSPR_EINVAL, "build_csr: bad sizes");
@@ -434,6 +448,7 @@ extern "C" int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n
     // word the count/fill passes touched, so a buffer can be handed from call to call (hipMemsetAsync of N+1 words is
     // two fill launches -- an aligned body and a tail -- i.e. ~10 us of a 0.5 ms step)
     EQ_CHECK_ARG(scratch_state >= 0 && scratch_state <= 2, EQUIGSPR_EINVAL, "build_csr: scratch_state must be 0, 1 or 2");
+    EQ_CHECK_ARG(!arrival || scratch_state == EQUIGSPR_SCRATCH_HISTOGRAM, EQUIGSPR_EINVAL, "build_csr: arrival goes with EQUIGSPR_SCRATCH_HISTOGRAM");
     if (scratch_state == EQUIGSPR_SCRATCH_DIRTY) {
         hipError_t err = hipMemsetAsync(scratch, 0, sizeof(int) * (size_t)(n_nodes + 1), s);
         if (err != hipSuccess) { set_error("build_csr memset: %s", hipGetErrorString(err)); return (int)err; }
@@ -444,7 +459,10 @@ extern "C" int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n
     const int chunks = ceil_div(n_nodes, kScanChunk);
     launch_exclusive_scan(scratch, n_nodes, ptr, (n_edges >= chunks && chunks <= 1024) ? perm : nullptr, s);
     if (n_edges > 0) {
-        hipLaunchKernelGGL(csr_fill_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, key, n_edges, scratch, perm);
+        if (arrival)
+            hipLaunchKernelGGL(csr_fill_ranked_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, key, arrival, n_edges, ptr, perm);
+        else
+            hipLaunchKernelGGL(csr_fill_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, key, n_edges, scratch, perm);
         hipLaunchKernelGGL(csr_sort_kernel, dim3(ceil_div(n_nodes, 4)), dim3(256), 0, s, ptr, n_nodes, perm, inv, scratch);
     }
     EQ_CHECK_LAUNCH("build_csr");

@@ -42,7 +42,7 @@ at::Tensor knn_graph(const at::Tensor& x, int64_t k, bool loop) {
     DeviceGuard guard(x.device());
     auto out = at::empty({1, 2, n * k}, x.options().dtype(at::kLong));
     check(equigspr_knn_graph(x.data_ptr<float>(), 1, (int32_t)n, (int32_t)k, loop ? 1 : 0, out.data_ptr<int64_t>(), nullptr, nullptr,
-                             nullptr, 0, cur_stream(x)), "knn_graph");
+                             nullptr, nullptr, 0, cur_stream(x)), "knn_graph");
     return out[0];
 }
 
@@ -55,7 +55,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> build_inverse_index(const at::Ten
     auto o = key.options();
     auto ptr = at::empty({n_nodes + 1}, o), perm = at::empty({e}, o), inv = at::empty({e}, o), scratch = at::empty({n_nodes + 1}, o);
     check(equigspr_build_csr(key.data_ptr<int32_t>(), (int32_t)e, (int32_t)n_nodes, ptr.data_ptr<int32_t>(), perm.data_ptr<int32_t>(),
-                             inv.data_ptr<int32_t>(), scratch.data_ptr<int32_t>(), EQUIGSPR_SCRATCH_DIRTY, cur_stream(key)), "build_csr");
+                             inv.data_ptr<int32_t>(), scratch.data_ptr<int32_t>(), EQUIGSPR_SCRATCH_DIRTY, nullptr, cur_stream(key)), "build_csr");
     return {ptr, perm, inv};
 }
 
@@ -84,7 +84,7 @@ std::tuple<at::Tensor, at::Tensor> egnn_forward(const at::Tensor& params, const 
     auto rptr = at::empty({n + 1}, io), rperm = at::empty({e}, io), rinv = at::empty({e}, io), scratch = at::empty({n + 1}, io);
     void* s = cur_stream(h);
     check(equigspr_build_csr(row.data_ptr<int32_t>(), (int32_t)e, (int32_t)n, rptr.data_ptr<int32_t>(), rperm.data_ptr<int32_t>(),
-                             rinv.data_ptr<int32_t>(), scratch.data_ptr<int32_t>(), EQUIGSPR_SCRATCH_DIRTY, s), "build_csr");
+                             rinv.data_ptr<int32_t>(), scratch.data_ptr<int32_t>(), EQUIGSPR_SCRATCH_DIRTY, nullptr, s), "build_csr");
     equigspr_graph g{(int32_t)n, (int32_t)e, row.data_ptr<int32_t>(), col.data_ptr<int32_t>(), rptr.data_ptr<int32_t>(),
                      rperm.data_ptr<int32_t>(), nullptr, nullptr, rinv.data_ptr<int32_t>()};
     auto fo = h.options();
@@ -222,9 +222,9 @@ struct EgnnFn : torch::autograd::Function<EgnnFn> {
         auto cptr = at::empty({n + 1}, io), cperm = at::empty({std::max<int64_t>(e, 1)}, io), scratch = at::empty({n + 1}, io);
         void* s = cur_stream(h);
         check(equigspr_build_csr(row.data_ptr<int32_t>(), (int32_t)e, (int32_t)n, rptr.data_ptr<int32_t>(), rperm.data_ptr<int32_t>(),
-                                 rinv.data_ptr<int32_t>(), scratch.data_ptr<int32_t>(), EQUIGSPR_SCRATCH_DIRTY, s), "build_csr(row)");
+                                 rinv.data_ptr<int32_t>(), scratch.data_ptr<int32_t>(), EQUIGSPR_SCRATCH_DIRTY, nullptr, s), "build_csr(row)");
         check(equigspr_build_csr(col.data_ptr<int32_t>(), (int32_t)e, (int32_t)n, cptr.data_ptr<int32_t>(), cperm.data_ptr<int32_t>(), nullptr,
-                                 scratch.data_ptr<int32_t>(), EQUIGSPR_SCRATCH_ZERO, s), "build_csr(col)");
+                                 scratch.data_ptr<int32_t>(), EQUIGSPR_SCRATCH_ZERO, nullptr, s), "build_csr(col)");
         equigspr_graph g{(int32_t)n, (int32_t)e, row.data_ptr<int32_t>(), col.data_ptr<int32_t>(), rptr.data_ptr<int32_t>(), rperm.data_ptr<int32_t>(),
                          cptr.data_ptr<int32_t>(), cperm.data_ptr<int32_t>(), rinv.data_ptr<int32_t>()};
         auto fo = h.options();

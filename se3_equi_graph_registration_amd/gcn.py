@@ -49,7 +49,7 @@ def build_graph(coordinates, k=25, device="cuda"):
     rptr = torch.empty(nt + 1, dtype=torch.int32, device=dev)
     rperm = torch.empty(nt * k, dtype=torch.int32, device=dev)
     scratch = torch.empty(nt + 1, dtype=torch.int32, device=dev)
-    _lib.check(L.equigspr_build_csr(_p(nbr), nt * k, nt, _p(rptr), _p(rperm), None, _p(scratch), 0, _stream()), "build_csr")
+    _lib.check(L.equigspr_build_csr(_p(nbr), nt * k, nt, _p(rptr), _p(rperm), None, _p(scratch), 0, None, _stream()), "build_csr")
     sigma2 = torch.empty(nc, dtype=torch.float64, device=dev)
     dinv = torch.empty(nt, dtype=torch.float32, device=dev)
     ptr = torch.empty(nt + 1, dtype=torch.int32, device=dev)

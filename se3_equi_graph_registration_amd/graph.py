@@ -53,9 +53,11 @@ def build_pair_graph(xyz_src: torch.Tensor, xyz_tgt: torch.Tensor, k: int, loop:
     hist, zeroed = ops._csr_scratch(x.device, nc * n + 1)      # the search leaves the row histogram of the index build in it
     if not zeroed:
         hist = None
+    # the histogram atomics of the search also hand every edge its slot inside its row segment: the index fill needs no atomics
+    arrival = torch.empty(nc * n * k, dtype=torch.int32, device=x.device) if hist is not None else None
     try:
-        _, r32, c32 = ops.knn_graph_batched(x, k, loop, want_i64=False, want_i32=True, row_hist=hist)
+        _, r32, c32 = ops.knn_graph_batched(x, k, loop, want_i64=False, want_i32=True, row_hist=hist, arrival=arrival)
     except Exception:
         ops._CSR_SCRATCH.clear()
         raise
-    return DeviceGraph(r32, c32, nc * n, knn_k=k, need_col_index=need_col_index, row_hist=hist)
+    return DeviceGraph(r32, c32, nc * n, knn_k=k, need_col_index=need_col_index, row_hist=hist, arrival=arrival)

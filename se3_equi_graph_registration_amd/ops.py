@@ -104,8 +104,10 @@ class DeviceGraph:
     """Batched graph in the device format (int32 global ids + inverse indices)."""
 
     def __init__(self, row32, col32, n_nodes: int, knn_k: Optional[int] = None, need_col_index: bool = True,
-                 row_hist: Optional[torch.Tensor] = None):
-        """``row_hist``: the zero-on-exit counter array already holding the row histogram (``knn_graph_batched``)."""
+                 row_hist: Optional[torch.Tensor] = None, arrival: Optional[torch.Tensor] = None):
+        """``row_hist``: the zero-on-exit counter array already holding the row histogram (``knn_graph_batched``);
+        ``arrival`` (with it): every edge's slot inside its row segment, as the search's histogram atomics returned it --
+        the index fill is then a plain scatter."""
         L = _lib.lib()
         self.row, self.col = _need(row32, "row32", torch.int32, 1), _need(col32, "col32", torch.int32, 1)
         self.n_nodes, self.n_edges = int(n_nodes), int(row32.numel())
@@ -116,7 +118,8 @@ class DeviceGraph:
         self.rinv = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
         try:      # one call: counting sort by row, the inverse permutation from the same pass, scratch handed back zeroed
             _lib.check(L.equigspr_build_csr(_p(self.row), self.n_edges, self.n_nodes, _p(self.rptr), _p(self.rperm),
-                                            _p(self.rinv), _p(scratch), zeroed, _stream()), "build_csr(row)")
+                                            _p(self.rinv), _p(scratch), zeroed, _p(arrival) if row_hist is not None else None, _stream()),
+                       "build_csr(row)")
         except Exception:
             _CSR_SCRATCH.clear()
             raise
@@ -135,7 +138,7 @@ class DeviceGraph:
                 self.cperm = torch.empty(max(self.n_edges, 1), dtype=torch.int32, device=dev)
                 try:
                     _lib.check(L.equigspr_build_csr(_p(self.col), self.n_edges, self.n_nodes, _p(self.cptr),
-                                                    _p(self.cperm), None, _p(scratch), 1, _stream()), "build_csr(col)")
+                                                    _p(self.cperm), None, _p(scratch), 1, None, _stream()), "build_csr(col)")
                 except Exception:
                     _CSR_SCRATCH.clear()
                     raise
@@ -166,10 +169,11 @@ class DeviceGraph:
 
 
 def knn_graph_batched(x: torch.Tensor, k: int, loop: bool = True, want_i64: bool = True, want_i32: bool = False,
-                      force_slow_path: bool = False, row_hist: Optional[torch.Tensor] = None):
+                      force_slow_path: bool = False, row_hist: Optional[torch.Tensor] = None, arrival: Optional[torch.Tensor] = None):
     """``x [n_clouds, n, 3]`` -> (edges int64 ``[n_clouds,2,n*k]`` | None, row32 | None, col32 | None).
     ``row_hist`` (int32, >= n_clouds*n words, zero on entry): also counts the edges per row node, which is where
-    ``equigspr_build_csr`` would otherwise start."""
+    ``equigspr_build_csr`` would otherwise start; ``arrival`` (int32 ``[n_clouds*n*k]``, with ``row_hist``): receives every
+    edge's slot inside its row segment (``DeviceGraph(..., row_hist=, arrival=)``)."""
     _need(x, "x", torch.float32, 3)
     nc, n, three = x.shape
     if three != 3:
@@ -178,8 +182,10 @@ def knn_graph_batched(x: torch.Tensor, k: int, loop: bool = True, want_i64: bool
     e64 = torch.empty(nc, 2, n * k, dtype=torch.int64, device=dev) if want_i64 else None
     r32 = torch.empty(nc * n * k, dtype=torch.int32, device=dev) if want_i32 else None
     c32 = torch.empty(nc * n * k, dtype=torch.int32, device=dev) if want_i32 else None
+    if arrival is not None and row_hist is None:
+        raise RuntimeError("knn_graph: arrival needs row_hist")
     _lib.check(_lib.lib().equigspr_knn_graph(_p(x), nc, n, int(k), int(bool(loop)), _p(e64), _p(r32), _p(c32), _p(row_hist),
-                                             int(bool(force_slow_path)), _stream()), "knn_graph")
+                                             _p(arrival), int(bool(force_slow_path)), _stream()), "knn_graph")
     return e64, r32, c32
 
 

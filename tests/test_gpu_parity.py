@@ -159,7 +159,7 @@ def test_build_csr_scratch_contract_and_inverse(pk):
         ptr = torch.empty(n + 1, dtype=torch.int32, device="cuda")
         perm = torch.empty(e, dtype=torch.int32, device="cuda")
         inv = torch.empty(e, dtype=torch.int32, device="cuda")
-        _lib.check(L.equigspr_build_csr(p(key32), e, n, p(ptr), p(perm), p(inv), p(scratch), is_zero, ops._stream()), "build_csr")
+        _lib.check(L.equigspr_build_csr(p(key32), e, n, p(ptr), p(perm), p(inv), p(scratch), is_zero, None, ops._stream()), "build_csr")
         np.testing.assert_array_equal(perm.cpu().numpy(), order)
         np.testing.assert_array_equal(inv.cpu().numpy(), inv_ref)
         np.testing.assert_array_equal(ptr.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(key.numpy(), minlength=n))]))
@@ -168,7 +168,7 @@ def test_build_csr_scratch_contract_and_inverse(pk):
         _lib.check(L.equigspr_invert_perm(p(perm), e, p(inv2), ops._stream()), "invert_perm")
         assert torch.equal(inv, inv2)
     # inv = NULL is allowed; the cached scratch of DeviceGraph survives many builds of different graphs
-    _lib.check(L.equigspr_build_csr(p(key32), e, n, p(ptr), p(perm), None, p(scratch), 1, ops._stream()), "build_csr")
+    _lib.check(L.equigspr_build_csr(p(key32), e, n, p(ptr), p(perm), None, p(scratch), 1, None, ops._stream()), "build_csr")
     np.testing.assert_array_equal(perm.cpu().numpy(), order)
     for seed in range(4):
         gg = torch.Generator().manual_seed(seed)
@@ -186,8 +186,17 @@ def test_build_csr_scratch_contract_and_inverse(pk):
         hist = torch.ones(2 * npts, dtype=torch.int32, device="cuda")
         _, r32, _ = ops.knn_graph_batched(x, k, True, want_i64=False, want_i32=True, row_hist=hist)
         np.testing.assert_array_equal(hist.cpu().numpy(), 1 + np.bincount(r32.cpu().numpy(), minlength=2 * npts))
+        # ABI 10: the arrival slots of the same atomics -> the index fill without atomics, same stable sort
+        hist0 = torch.zeros(2 * npts + 1, dtype=torch.int32, device="cuda")
+        arr = torch.full((2 * npts * k,), -1, dtype=torch.int32, device="cuda")
+        _, r32b, c32b = ops.knn_graph_batched(x, k, True, want_i64=False, want_i32=True, row_hist=hist0, arrival=arr)
+        a, r = arr.cpu().numpy(), r32b.cpu().numpy()
+        assert (a >= 0).all() and all(sorted(a[r == j].tolist()) == list(range(int((r == j).sum()))) for j in range(0, 2 * npts, 97))
+        gph = pk.DeviceGraph(r32b, c32b, 2 * npts, knn_k=k, row_hist=hist0, arrival=arr)
+        np.testing.assert_array_equal(gph.rperm.cpu().numpy(), np.argsort(r, kind="stable"))
+        assert int(hist0.abs().sum()) == 0
     with pytest.raises(RuntimeError, match="scratch_state"):
-        _lib.check(L.equigspr_build_csr(p(key32), e, n, p(ptr), p(perm), None, p(scratch), 3, ops._stream()), "build_csr")
+        _lib.check(L.equigspr_build_csr(p(key32), e, n, p(ptr), p(perm), None, p(scratch), 3, None, ops._stream()), "build_csr")
 
 
 def test_captured_graph_owns_its_csr_scratch(pk):
@@ -1155,13 +1164,14 @@ def test_pair_train_head_odd_shapes_vs_oracle(pk, feat, B, n, k, scale):
         assert set(model.last_top_idx[i].cpu().tolist()) == set(extras["top_idx"][i].tolist())
 
 
-@pytest.mark.parametrize("feat,B", [(33, 2), (32, 3), (48, 2)])
-def test_train_step_gradients_vs_oracle_autograd(pk, feat, B):
+@pytest.mark.parametrize("feat,B,n,k,layers", [(33, 2, 384, 10, 2), (32, 3, 384, 10, 2), (48, 2, 384, 10, 2),
+                                                (32, 1, 2048, 20, 4)])      # the last = BASELINE configs[1] at full size
+def test_train_step_gradients_vs_oracle_autograd(pk, feat, B, n, k, layers):
     """The whole training loss (train :1120) through the fused head, Kabsch, both EGNN passes: every parameter gradient
-    against the oracle's autograd in fp32 and fp64 (hidden_nf = 33 exercises the border path of the MFMA backward)."""
-    n, k = 384, 10
+    against the oracle's autograd in fp32 and fp64 (hidden_nf = 33 exercises the border path of the MFMA backward; the
+    2 048-point / k = 20 / 4-layer case is the headline workload itself, on a well-conditioned head)."""
     torch.manual_seed(2)
-    egnn = pk.EGNN(feat, feat, feat, in_edge_nf=1, device="cuda", n_layers=2)
+    egnn = pk.EGNN(feat, feat, feat, in_edge_nf=1, device="cuda", n_layers=layers)
     with torch.no_grad():
         egnn.embedding_out.weight.mul_(0.02); egnn.embedding_out.bias.mul_(0.02)          # well-conditioned head (SURVEY §0.7)
     model = pk.CrossAttentionPoseRegression(egnn, num_nodes=n, hidden_nf=feat, device="cuda").cuda()
