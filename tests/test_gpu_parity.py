@@ -528,6 +528,38 @@ def test_backward_random_graph_vs_oracle_autograd(pk, feat, heads, in_nf, out_nf
         _grad_check(p.grad, refs["f32"][pn], refs["f64"][pn], pn)
 
 
+@pytest.mark.parametrize("feat,heads", [(32, 1), (32, 4), (33, 1), (48, 1), (16, 1)])
+def test_no_edge_attribute_forward_backward_vs_oracle(pk, feat, heads):
+    """in_edge_nf = 0 (the reference E_GCL's own default, edges_in_d = 0, train :186): the edge MLP's first layer is 2F + 12 wide and
+    no attribute column exists -- forward and every gradient against the oracle, on the MFMA kernels and on the lane kernels."""
+    g = torch.Generator().manual_seed(71)
+    torch.manual_seed(4)
+    n, e = 300, 3500
+    m = pk.EGNN(feat, feat, feat, in_edge_nf=0, device="cuda", n_layers=2, num_heads=heads)
+    assert m.state_dict()["gcl_0.edge_mlps.0.0.weight"].shape[1] == 2 * feat + 12
+    h = torch.randn(n, feat, generator=g); x = torch.rand(n, 3, generator=g) * 2
+    row = torch.randint(0, n, (e,), generator=g); col = torch.randint(0, n, (e,), generator=g)
+    gh = torch.randn(n, feat, generator=g); gx = torch.randn(n, 3, generator=g)
+    refs = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        w = {k: v.detach().cpu().to(dt).requires_grad_(True) for k, v in m.state_dict().items()}
+        hh = h.to(dt).clone().requires_grad_(True); xx = x.to(dt).clone().requires_grad_(True)
+        ho, xo = orc.egnn_forward(w, hh, xx, [row, col], None)
+        ((ho * gh.to(dt)).sum() + (xo * gx.to(dt)).sum()).backward()
+        refs[tag] = dict(h=hh.grad.numpy(), x=xx.grad.numpy(), **{k: v.grad.numpy() for k, v in w.items()})
+        refs[tag + "_out"] = (ho.detach().numpy(), xo.detach().numpy())
+    hc = h.cuda().requires_grad_(True); xc = x.cuda().requires_grad_(True)
+    ho, xo = m(hc, xc, [row.cuda(), col.cuda()], None)
+    for got, a32, a64 in zip((ho, xo), refs["f32_out"], refs["f64_out"]):
+        assert np.abs(got.detach().cpu().numpy() - a64).max() <= anchored_tol(a32, a64)
+    m.zero_grad()
+    ((ho * gh.cuda()).sum() + (xo * gx.cuda()).sum()).backward()
+    _grad_check(hc.grad, refs["f32"]["h"], refs["f64"]["h"], "grad_h")
+    _grad_check(xc.grad, refs["f32"]["x"], refs["f64"]["x"], "grad_x")
+    for pn, p in m.named_parameters():
+        _grad_check(p.grad, refs["f32"][pn], refs["f64"][pn], pn)
+
+
 def test_smoke_entry(pk):
     import __graft_entry__
     __graft_entry__.smoke()
