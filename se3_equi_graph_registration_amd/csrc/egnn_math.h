@@ -51,6 +51,11 @@ EQ_HD float silu_grad(float v) {
 // Square root / reciprocal of the per-edge geometry.  On the device: the hardware instructions (v_sqrt_f32, v_rcp_f32,
 // <= 1 ulp) instead of the correctly rounded ~15-instruction sequences hipcc emits for sqrtf() and 1.0f / x -- the edge
 // geometry was a sixth of the edge kernels' vector instructions.  The host twin keeps libm.
+// CONTRACT: the identity-frame decision of edge_geometry (norm < 1e-6, train :152-163) is evaluated on these <= 1-ulp values.
+// Device and host twin can take different branches only when a norm lies within an ulp of 1e-6, i.e. |x_r - x_c| or
+// |x_r x x_c| of order 1e-14 (coordinates within ~1e-7 of each other and of the origin); exact zeros -- self loops, duplicated
+// points, a point at the origin -- give exactly 0 on both sides.  Outside that band the results agree to the anchored
+// tolerances of the parity tests, not bit for bit ("Frame decision contract").
 #if defined(__HIP_DEVICE_COMPILE__)
 #define EQ_SQRT(v) __builtin_amdgcn_sqrtf(v)
 #define EQ_RCP(v) __builtin_amdgcn_rcpf(v)
