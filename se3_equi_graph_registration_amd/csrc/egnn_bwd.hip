@@ -773,23 +773,35 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
         for (int b = 0; b < 2; ++b) { acc6[a][b] = splat4(0.0f); acc2[a][b] = splat4(0.0f); }
     }
 
-    const int n_chunks = (n_edges + chunk - 1) / chunk;
-    auto edge_of = [&](int ch_) { const int cnt_ = min(chunk, n_edges - ch_ * chunk); return ch_ * chunk + (lane < cnt_ ? lane : 0); };
+    // A wave's unit of work is a set of <= 4 sixteen-edge tiles that share one front and one back phase (one lane per edge):
+    // `chunk` / 16 consecutive tiles, or -- chunk == 16, small graphs, where a wave only gets two or three tiles in all -- the
+    // tiles ch, ch + S, ch + 2 S, ch + 3 S the wave would have taken one by one (S = ch_step: same tiles, same order, same
+    // sums), so that the ~500 vector instructions of a front + back are paid once per wave instead of once per tile.
+    const int n_tiles = (n_edges + 15) >> 4;
+    const bool strided = chunk == 16;
+    const int tpc = chunk >> 4;
+    const int n_chunks = strided ? n_tiles : (n_edges + chunk - 1) / chunk;
     // chunk -> wave, static (the summation order of the weight gradients is fixed): half-round k hands four consecutive chunks
     // (shared centre nodes) to every workgroup; waves 0..3 take the even half-rounds, waves 4..7 the odd ones.  Waves w and
     // w + 4 share a SIMD, so every SIMD of the chip gets the same number of chunks +- 1 (wave-linear rounds gave the CUs of
     // the low workgroups a whole extra chunk per wave: 2 or 3 of the 2.5 per wave at one 2 048-point pair).
     const int ch_step = gridDim.x * NW;
+    const int ts = strided ? ch_step : 1;              // tile stride inside a unit
+    const int unit_step = strided ? 4 * ch_step : ch_step;
+    auto edge_id = [&](int ch_) { return ((strided ? ch_ : ch_ * tpc) + (lane >> 4) * ts) * 16 + (lane & 15); };     // this lane's edge of unit ch_ (>= n_edges: none)
+    auto lane_live = [&](int e_) { return e_ < n_edges && (strided || lane < chunk); };
+    auto edge_of = [&](int ch_) { const int e_ = edge_id(ch_); return lane_live(e_) ? e_ : 0; };
     int ch = NW == 8 ? (blockIdx.x + (wv >> 2) * gridDim.x) * 4 + (wv & 3) : blockIdx.x * NW + wv;
     int e = ch < n_chunks ? edge_of(ch) : 0;
     int r = row[e], c = col[e];
-    for (; ch < n_chunks; ch += ch_step) {
+    for (; ch < n_chunks; ch += unit_step) {
         int off = 0;
         asm volatile("" : "+v"(off));
         const float* wsm = wsm_ + off;
         const float* bord = wsm + W16::border_base(true);
-        const int base = ch * chunk, cnt = min(chunk, n_edges - base);
-        const bool mine = lane < cnt;
+        const int t0 = strided ? ch : ch * tpc;        // first tile of the unit
+        const int n_sub = strided ? min(4, (n_tiles - t0 + ts - 1) / ts) : min(tpc, n_tiles - t0);
+        const bool mine = lane_live(edge_id(ch));
         EQ_STAMP(2);
         // ---- front: one lane per edge
         idx_r[lane] = r; idx_c[lane] = c;
@@ -804,7 +816,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
         // first used half way through it (dm): it is requested at the sub-tile's own start.
         PRowsT<kB> ra, rb;
         ra.load(P, idx_r[i], idx_c[i], g);
-        const int chn = ch + ch_step;                  // the next chunk's indices
+        const int chn = ch + unit_step;                // the next unit's indices
         int rn = r, cn = c, en = e;
         if (chn < n_chunks) { en = edge_of(chn); rn = row[en]; cn = col[en]; }
         {
@@ -819,10 +831,10 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
         __builtin_amdgcn_wave_barrier();
         EQ_STAMP(3);
 
-        const int n_sub = (cnt + 15) >> 4;
         auto tile = [&](int sub, PRowsT<kB>& cur, PRowsT<kB>& nxt) __attribute__((always_inline)) {
             const int el = sub * 16 + i;
-            const bool valid = el < cnt;
+            const int eg_ = (t0 + sub * ts) * 16 + i;   // the edge's index in the graph
+            const bool valid = eg_ < n_edges;
             const float ds = ds_buf[el];
             float* geo_rows = sc + C::o_geo + sub * 16 * C::GS;
             // next sub-tile's rows, requested before this one computes (the last one re-requests its own: harmless).  hidden_nf
@@ -921,14 +933,14 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             for (int b = 0; b < 2; ++b) {
                 dt1[b] *= sgp[b];
                 st4(X + i * C::LD + 16 * b + 4 * g, dt1[b]);
-                if (valid) st4(dt1_out + (size_t)(base + el) * 32 + 16 * b + 4 * g, dt1[b]);      // 128-byte rows for every hidden_nf (see below)
+                if (valid) st4(dt1_out + (size_t)eg_ * 32 + 16 * b + 4 * g, dt1[b]);      // 128-byte rows for every hidden_nf (see below)
             }
             if constexpr (kB == 1) {
                 if (g == 0) {
                     X[i * C::LD + 32] = dt1b;
                     // hidden_nf 33: the 33rd column is its own array behind the [E][32] block -- a 144-byte row would straddle cache
                     // lines, and the col-side gather of the node backward reads these rows scattered (one line + one word per row)
-                    if (valid) dt1b_out[base + el] = dt1b;
+                    if (valid) dt1b_out[eg_] = dt1b;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -969,8 +981,9 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             const float gd[3] = {s * gx2[0], s * gx2[1], s * gx2[2]};
             float gxr[3], gxc[3];
             edge_geometry_backward_mode(basis, xr2, xc2, eg, gg, gd, gxr, gxc);
-            reinterpret_cast<float4*>(gxr_out)[base + lane] = make_float4(gxr[0], gxr[1], gxr[2], 0.0f);
-            reinterpret_cast<float4*>(gxc_out)[base + lane] = make_float4(gxc[0], gxc[1], gxc[2], 0.0f);
+            const int eo = edge_id(ch);
+            reinterpret_cast<float4*>(gxr_out)[eo] = make_float4(gxr[0], gxr[1], gxr[2], 0.0f);
+            reinterpret_cast<float4*>(gxc_out)[eo] = make_float4(gxc[0], gxc[1], gxc[2], 0.0f);
         }
         __builtin_amdgcn_wave_barrier();
         r = rn; c = cn; e = en;

@@ -102,21 +102,32 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
     int* idx_c = reinterpret_cast<int*>(sc + C::o_c);
     int* pos = reinterpret_cast<int*>(sc + C::o_a);
     float* s_buf = sc + C::o_b;
-    const int n_chunks = (n_edges + chunk - 1) / chunk;
+    // A wave's unit of work: <= 4 sixteen-edge tiles behind one front (one lane per edge) -- `chunk` / 16 consecutive tiles, or,
+    // chunk == 16 (small graphs: one or two tiles per wave in all), the tiles ch, ch + S, ch + 2 S, ch + 3 S the wave would have
+    // taken one by one (S = the number of waves), so that it pays the front once (same scheme as the backward, egnn_bwd.hip).
+    const int n_tiles = (n_edges + 15) >> 4;
+    const bool strided = chunk == 16;
+    const int tpc = chunk >> 4;
+    const int n_chunks = strided ? n_tiles : (n_edges + chunk - 1) / chunk;
     // the four waves of a workgroup take four consecutive chunks (shared centre nodes: their rows hit in L1/L2)
     const int ch_step = n_waves;
+    const int ts = strided ? ch_step : 1;
+    const int unit_step = strided ? 4 * ch_step : ch_step;
     int ch = wave;
     if (ch >= n_chunks) return;
-    auto edge_of = [&](int ch_) { const int cnt_ = min(chunk, n_edges - ch_ * chunk); return ch_ * chunk + (lane < cnt_ ? lane : 0); };
+    auto edge_id = [&](int ch_) { return ((strided ? ch_ : ch_ * tpc) + (lane >> 4) * ts) * 16 + (lane & 15); };     // this lane's edge of unit ch_ (>= n_edges: none)
+    auto lane_live = [&](int e_) { return e_ < n_edges && (strided || lane < chunk); };
+    auto edge_of = [&](int ch_) { const int e_ = edge_id(ch_); return lane_live(e_) ? e_ : 0; };
     int e = edge_of(ch);
     int r = row[e], c = col[e], at = rinv[e];
-    for (; ch < n_chunks; ch += ch_step) {
+    for (; ch < n_chunks; ch += unit_step) {
         int off = 0;
         asm volatile("" : "+v"(off));                  // an opaque zero offset keeps the (loop-invariant) weight reads inside the loop
         const float* wsm = wsm_ + off;
         const float* bord = wsm + W16::border_base(false);
-        const int cnt = min(chunk, n_edges - ch * chunk);
-        const bool mine = lane < cnt;
+        const int t0 = strided ? ch : ch * tpc;
+        const int n_sub = strided ? min(4, (n_tiles - t0 + ts - 1) / ts) : min(tpc, n_tiles - t0);
+        const bool mine = lane_live(edge_id(ch));
         EQ_STAMP(2);
         // ---- front: one lane per edge
         idx_r[lane] = r; idx_c[lane] = c; pos[lane] = at;
@@ -127,7 +138,7 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
         __builtin_amdgcn_wave_barrier();
         PRowsT<kB> pw;                                 // first sub-tile's projection rows: in flight with the coordinate gathers
         pw.load(P, idx_r[i], idx_c[i], g);
-        const int chn = ch + ch_step;                  // the next chunk's indices
+        const int chn = ch + unit_step;                // the next unit's indices
         int rn = r, cn = c, atn = at, en = e;
         if (chn < n_chunks) { en = edge_of(chn); rn = row[en]; cn = col[en]; atn = rinv[en]; }
         EdgeGeo eg;
@@ -136,7 +147,6 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
         __builtin_amdgcn_wave_barrier();
         EQ_STAMP(3);
         // ---- the chunk's 16-edge sub-tiles
-        const int n_sub = (cnt + 15) >> 4;
         for (int sub = 0; sub < n_sub; ++sub) {
             const int el = sub * 16 + i;
             PRowsT<kB> pn;                             // next sub-tile's rows (the last one re-requests its own: harmless)
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
             }
             Sub16 o;
             tile_forward16<kB>(wsm, bord, sc + C::o_geo + el * C::GS, pw, i, g, o);
-            if (el < cnt) {
+            if ((t0 + sub * ts) * 16 + i < n_edges) {
                 // stored at the edge's position in the by-row (aggregation) order: node_fwd then streams its segment contiguously
                 float* dst = m_out + (size_t)pos[el] * FP + 4 * g;
                 st4(dst, o.m[0]);
