@@ -778,7 +778,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
     // tiles ch, ch + S, ch + 2 S, ch + 3 S the wave would have taken one by one (S = ch_step: same tiles, same order, same
     // sums), so that the ~500 vector instructions of a front + back are paid once per wave instead of once per tile.
     const int n_tiles = (n_edges + 15) >> 4;
-    const bool strided = chunk == 16;
+    const bool strided = chunk != 64;       // every size below the 64-edge regime: tile-granular shares (+- one tile per wave)
     const int tpc = chunk >> 4;
     const int n_chunks = strided ? n_tiles : (n_edges + chunk - 1) / chunk;
     // chunk -> wave, static (the summation order of the weight gradients is fixed): half-round k hands four consecutive chunks

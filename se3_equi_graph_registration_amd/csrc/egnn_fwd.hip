@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
     // chunk == 16 (small graphs: one or two tiles per wave in all), the tiles ch, ch + S, ch + 2 S, ch + 3 S the wave would have
     // taken one by one (S = the number of waves), so that it pays the front once (same scheme as the backward, egnn_bwd.hip).
     const int n_tiles = (n_edges + 15) >> 4;
-    const bool strided = chunk == 16;
+    const bool strided = chunk != 64;       // every size below the 64-edge regime: tile-granular shares (+- one tile per wave)
     const int tpc = chunk >> 4;
     const int n_chunks = strided ? n_tiles : (n_edges + chunk - 1) / chunk;
     // the four waves of a workgroup take four consecutive chunks (shared centre nodes: their rows hit in L1/L2)
