@@ -20,7 +20,7 @@ namespace eq {
 
 #define NB_STAMP(k) do { if constexpr (kG && kN) EQ_STAMPK(4, k); } while (0)     // developer trace build only (tools/trace_edge.py)
 #ifndef EQ_NB16_DBG
-#define EQ_NB16_DBG 0                // timing experiments only (wrong results): 1 = no segment loads, 2 = no outer products, 4 = no slab copies
+#define EQ_NB16_DBG 0                // timing experiments only (wrong results): 1 = no segment loads, 2 = no outer products, 4 = no slab copies, 8 = three col-side rows per node
 #endif
 #ifndef EQ_NB16_OCC
 #define EQ_NB16_OCC 1                // waves per SIMD the register allocation is held to
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
         };
         if constexpr (kN && kEarly) load_node_inputs();
         if constexpr (kG) {
-            const int rlo = p_rlo, rlen = p_rhi - p_rlo, clo = p_clo, clen = p_chi - p_clo;
+            const int rlo = p_rlo, rlen = p_rhi - p_rlo, clo = p_clo, clen = (EQ_NB16_DBG & 8) ? min(3, p_chi - p_clo) : p_chi - p_clo;
             request_bounds(tile + gridDim.x * NW);
             f32x4 hg[2];
             float hgb = 0.0f;

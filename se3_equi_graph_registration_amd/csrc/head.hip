@@ -30,6 +30,9 @@ typedef unsigned long long u64;
 constexpr int kHeadPartials = 8;     // sum s, sum s^2, sum r, sum r^2, rot, feat, (unused x2)
 constexpr int kRowsPerBlock = 8;
 constexpr int kMaxIn = 128, kMaxH1 = 64, kMaxH2 = 32;     // MLP in = 2F, h1 = F, h2 = F/2 for F <= 64
+#ifndef EQ_HEAD_FUSE_MLP
+#define EQ_HEAD_FUSE_MLP 1             // the MLP blocks of small batches ride in head_pair_kernel's launch (A/B knob)
+#endif
 constexpr int kMaxN = 8192;          // head_pair_kernel keeps a pair's keys in LDS: 12 bytes per node
 
 __device__ __forceinline__ unsigned orderable(float v) {
@@ -105,10 +108,11 @@ __global__ __launch_bounds__(256) void head_node_kernel(const float* __restrict_
                                                         int B, int N, int F, int Fr, float* __restrict__ sim,
                                                         float* __restrict__ rsim, float* __restrict__ cosv,
                                                         int* __restrict__ pos, double* __restrict__ partials,
-                                                        unsigned* __restrict__ tickets /*[B + 1]*/) {
+                                                        unsigned* __restrict__ tickets /*[3 B + 1]*/) {
     __shared__ float nv[8][6];     // s, r, rot, feat, valid, (pad)
     if (blockIdx.x == 0 && threadIdx.x == 0) {           // the tickets of the launches behind this one (K2 per pair, K3 one for all)
         tickets[blockIdx.y] = 0u;
+        tickets[B + 1 + blockIdx.y] = 0u; tickets[2 * B + 1 + blockIdx.y] = 0u;
         if (blockIdx.y == 0) tickets[B] = 0u;
     }
     const int slot = threadIdx.x >> 5, f = threadIdx.x & 31;
@@ -339,6 +343,19 @@ __device__ __forceinline__ void head_select_topk(const float* __restrict__ sb, i
     }
 }
 
+// (defined below, next to the stand-alone MLP launch)
+__device__ __forceinline__ void head_mlp_block(
+    float* lds, int b, int jb, const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
+    const long long* __restrict__ top_idx, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
+    int B, int N, int F, int K, MlpDims md, float* __restrict__ logits, float* __restrict__ a1_save,
+    float* __restrict__ a2_save, double* __restrict__ pair_part, int nblk, const double* __restrict__ partC, int nC,
+    float* __restrict__ out_scalars, int flags, unsigned* __restrict__ ticket, unsigned n_arrivals, float* __restrict__ step_loss,
+    unsigned* __restrict__ ready, unsigned* __restrict__ seen);
+__device__ __forceinline__ void head_finalize_all(const double* __restrict__ partC, int nC, const double* __restrict__ pair_part,
+                                                  int nblk, int B, int N, int K, float* __restrict__ out_scalars, int flags,
+                                                  float* __restrict__ step_loss);
+
 // K2: one workgroup per pair: softmax scalars, top-K (radix select + small bitonic sort), MLP, BCE
 __global__ __launch_bounds__(256) void head_pair_kernel(
     const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
@@ -349,13 +366,25 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
     float* __restrict__ a1_save, float* __restrict__ a2_save, float* __restrict__ pair_f /*[B][4]*/,
     double* __restrict__ pair_part /*[B][2]*/, float* __restrict__ fin, unsigned* __restrict__ tickets, WeightsJob wj, int nwb,
     const float* __restrict__ xs, const float* __restrict__ xt, float* __restrict__ kab_R, float* __restrict__ kab_t,
-    float* __restrict__ kab_aux, const float* __restrict__ gt_pose, float* __restrict__ step_loss /* [1 + 2B] or NULL */) {
+    float* __restrict__ kab_aux, const float* __restrict__ gt_pose, float* __restrict__ step_loss /* [1 + 2B] or NULL */,
+    int nmlp /* > 0: the MLP blocks ride in this launch as grid columns 1 + nwb .. */, int nC, int hflags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __shared__ double red[4];
     __shared__ float redf[4];
     __shared__ unsigned histp[kHistCopies * 256];
     __shared__ int sel[3];
     __shared__ int wtot[4];
+    // ticket words: [0, B) per pair (Kabsch weights), [B] the batch-wide arrival count, [B + 1, 2B + 1) "selection published",
+    // [2B + 1, 3B + 1) readers of the selection -- all zeroed by K1 and handed back as zero
+    if (nmlp > 0 && (int)blockIdx.x > nwb) {
+        // ---- MLP columns: stage the weights while the pair's select block (dispatched before this one) works, then its rows.
+        // Arrivals over the batch: B * nmlp MLP blocks + the B Kabsch tails; the last one writes the loss scalars.
+        const int bb = blockIdx.y;
+        head_mlp_block(reinterpret_cast<float*>(smem_raw), bb, (int)blockIdx.x - 1 - nwb, hs, ht, labels, top_idx, w1, b1, w2, b2, w3, b3, B, N, F,
+                       K, md, logits, a1_save, a2_save, pair_part, nmlp, wj.partC, nC, fin, hflags, tickets + B, (unsigned)B * (unsigned)(nmlp + 1),
+                       step_loss, tickets + B + 1 + bb, tickets + 2 * B + 1 + bb);
+        return;
+    }
     // grid (1 + nwb, B): column 0 = the pair's select block, columns 1.. = its Kabsch-weight blocks.  EVERY block evaluates the
     // batch statistics and its pair's softmax scalars from the K1 partials itself (a few microseconds, L2-resident), so the weight
     // blocks need nothing from the select block and the two chains -- select -> MLP and weights -> Kabsch -- run side by side.
@@ -401,6 +430,18 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
         if (tid < 64) kabsch_solve_wave(1, kab_R, kab_t, kab_aux, b, tid);
         if (step_loss && tid == 0)       // this pair's terms of the training loop's loss (train :1117-1120); K3 adds them up
             pose_loss_pair(kab_R + (size_t)b * 9, kab_t + (size_t)b * 3, gt_pose + (size_t)b * 16, step_loss[1 + b], step_loss[1 + B + b]);
+        if (nmlp > 0) {                  // the MLP blocks ride in this launch: this tail is one of the batch's arrivals
+            __syncthreads();
+            if (tid == 0) {
+                __threadfence();
+                is_last = atomicAdd(tickets + B, 1u) == (unsigned)B * (unsigned)(nmlp + 1) - 1u;
+                if (is_last) tickets[B] = 0u;
+            }
+            __syncthreads();
+            if (!is_last) return;        // block-uniform
+            __threadfence();
+            head_finalize_all(wj.partC, nC, pair_part, nmlp, B, N, K, fin, hflags, step_loss);
+        }
         return;
     }
     if (tid == 0) {
@@ -410,6 +451,10 @@ __global__ __launch_bounds__(256) void head_pair_kernel(
     }
     EQ_STAMPK(3, 2);
     head_select_topk(sb, N, Npad, K, keys, khi, histp, sel, wtot, top_idx + (size_t)b * K, pos + (size_t)b * N);
+    if (nmlp > 0) {                      // publish the selection to the pair's MLP blocks
+        __syncthreads();
+        if (tid == 0) { __threadfence(); atomicExch(tickets + B + 1 + b, 1u); }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -622,25 +667,44 @@ __device__ __forceinline__ void stage8(float* dst, const float* __restrict__ src
     }
 }
 
-__global__ __launch_bounds__(256) void head_mlp_kernel(
-    const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
+// LDS of one MLP block (floats): inp | a1 | a2 | W1^T | W2^T | W3 | biases | idxs | red (fp64 x 4)
+constexpr int kMlpLdsFloats = kRowsPerBlock * (kMaxIn + 1) + kRowsPerBlock * (kMaxH1 + 1) + kRowsPerBlock * (kMaxH2 + 1) +
+                              kMaxIn * (kMaxH1 + 1) + kMaxH1 * (kMaxH2 + 1) + kMaxH2 + (kMaxH1 + kMaxH2 + 1) + kRowsPerBlock + 1 + 8;
+constexpr size_t kMlpLdsBytes = sizeof(float) * (size_t)kMlpLdsFloats + 16;
+
+// the loss scalars from the partial sums of the whole batch (+ the training loop's step loss): run by the block that arrives last
+__device__ __forceinline__ void head_finalize_all(const double* __restrict__ partC, int nC, const double* __restrict__ pair_part,
+                                                  int nblk, int B, int N, int K, float* __restrict__ out_scalars, int flags,
+                                                  float* __restrict__ step_loss) {
+    head_finalize_block(partC, nC, pair_part, nblk, B, N, K, out_scalars, flags);
+    if (step_loss) {                                     // loss = (corr_loss + sim_loss) + mean rot + mean trans (train :1120)
+        __syncthreads();
+        step_loss_sum(step_loss + 1, step_loss + 1 + B, out_scalars[0], B, step_loss);
+    }
+}
+
+// One MLP block: rows j0 .. j0 + 7 of pair b's selection.  `ready` != NULL (the block rides in head_pair_kernel's launch): the
+// weights are staged first, then the block waits for its pair's select block to publish top_idx; the pair's last reader hands
+// `ready` / `seen` back as zero.  `ticket` counts `n_arrivals` blocks over the whole batch; the last one writes the loss scalars.
+__device__ __forceinline__ void head_mlp_block(
+    float* lds, int b, int jb, const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
     const long long* __restrict__ top_idx, const float* __restrict__ w1, const float* __restrict__ b1,
     const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
     int B, int N, int F, int K, MlpDims md, float* __restrict__ logits, float* __restrict__ a1_save,
     float* __restrict__ a2_save, double* __restrict__ pair_part, int nblk, const double* __restrict__ partC, int nC,
-    float* __restrict__ out_scalars, int flags, unsigned* __restrict__ ticket /* one word: zeroed by K1, handed back as zero */,
-    float* __restrict__ step_loss) {
-    __shared__ float inp[kRowsPerBlock * (kMaxIn + 1)];
-    __shared__ float a1[kRowsPerBlock * (kMaxH1 + 1)];
-    __shared__ float a2[kRowsPerBlock * (kMaxH2 + 1)];
-    __shared__ float W1[kMaxIn * (kMaxH1 + 1)];      // transposed [in][h1+1]
-    __shared__ float W2[kMaxH1 * (kMaxH2 + 1)];      // transposed [h1][h2+1]
-    __shared__ float W3[kMaxH2];
-    __shared__ float Bs[kMaxH1 + kMaxH2 + 1];
-    __shared__ int idxs[kRowsPerBlock];
-    __shared__ double red[4];
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const int j0 = blockIdx.x * kRowsPerBlock;
+    float* __restrict__ out_scalars, int flags, unsigned* __restrict__ ticket, unsigned n_arrivals, float* __restrict__ step_loss,
+    unsigned* __restrict__ ready, unsigned* __restrict__ seen) {
+    float* inp = lds;
+    float* a1 = inp + kRowsPerBlock * (kMaxIn + 1);
+    float* a2 = a1 + kRowsPerBlock * (kMaxH1 + 1);
+    float* W1 = a2 + kRowsPerBlock * (kMaxH2 + 1);      // transposed [in][h1+1]
+    float* W2 = W1 + kMaxIn * (kMaxH1 + 1);             // transposed [h1][h2+1]
+    float* W3 = W2 + kMaxH1 * (kMaxH2 + 1);
+    float* Bs = W3 + kMaxH2;
+    int* idxs = reinterpret_cast<int*>(Bs + (kMaxH1 + kMaxH2 + 1));
+    double* red = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(idxs + kRowsPerBlock) + 7) & ~(uintptr_t)7);
+    const int tid = threadIdx.x;
+    const int j0 = jb * kRowsPerBlock;
     const int Kb = min(kRowsPerBlock, K - j0);
     const int ld_in = md.in + 1, ld1 = md.h1 + 1, ld2 = md.h2 + 1;
     const float* yb = labels + (size_t)b * N;
@@ -650,8 +714,18 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(
     for (int t = tid; t < md.h1; t += 256) Bs[t] = b1[t];
     for (int t = tid; t < md.h2; t += 256) Bs[md.h1 + t] = b2[t];
     if (tid == 0) Bs[md.h1 + md.h2] = b3[0];
+    if (ready) {                                         // the select block of this pair is in the same launch, dispatched before this one
+        if (tid == 0) {
+            while (atomicAdd(ready, 0u) == 0u) __builtin_amdgcn_s_sleep(2);
+            __threadfence();
+        }
+        __syncthreads();
+    }
     if (tid < Kb) idxs[tid] = (int)top_idx[(size_t)b * K + j0 + tid];
     __syncthreads();
+    if (ready && tid == 0) {                             // the pair's last reader resets the flag for the next forward
+        if (atomicAdd(seen, 1u) == (unsigned)nblk - 1u) { *seen = 0u; atomicExch(ready, 0u); }
+    }
     gather_rows(hs, ht, idxs, b, N, F, Kb, md.in, ld_in, inp);
     __syncthreads();
     for (int t = tid; t < Kb * md.h1; t += 256) {
@@ -683,22 +757,33 @@ __global__ __launch_bounds__(256) void head_mlp_kernel(
         bce = fmaxf(z, 0.0f) - z * y + log1pf(expf(-fabsf(z)));                          // BCEWithLogits (:772-773)
     }
     bce = block_sum_d(bce, red);
-    // ---- the block that finishes last over ALL pairs (ticket) turns the partial sums into the loss scalars
-    __shared__ int is_last;
+    // ---- the block that arrives last over ALL pairs (ticket) turns the partial sums into the loss scalars
+    __shared__ int is_last_m;
     if (tid == 0) {
-        pair_part[(size_t)b * nblk + blockIdx.x] = bce;
+        pair_part[(size_t)b * nblk + jb] = bce;
         __threadfence();
-        is_last = atomicAdd(ticket, 1u) == gridDim.x * gridDim.y - 1u;
-        if (is_last) *ticket = 0u;
+        is_last_m = atomicAdd(ticket, 1u) == n_arrivals - 1u;
+        if (is_last_m) *ticket = 0u;
     }
     __syncthreads();
-    if (!is_last) return;                                // block-uniform
+    if (!is_last_m) return;                              // block-uniform
     __threadfence();
-    head_finalize_block(partC, nC, pair_part, nblk, B, N, K, out_scalars, flags);
-    if (step_loss) {                                     // loss = (corr_loss + sim_loss) + mean rot + mean trans (train :1120)
-        __syncthreads();
-        step_loss_sum(step_loss + 1, step_loss + 1 + B, out_scalars[0], B, step_loss);
-    }
+    head_finalize_all(partC, nC, pair_part, nblk, B, N, K, out_scalars, flags, step_loss);
+}
+
+// K3 (its own launch when the MLP blocks do not ride in K2): grid (ceil(K/kRowsPerBlock), B)
+__global__ __launch_bounds__(256) void head_mlp_kernel(
+    const float* __restrict__ hs, const float* __restrict__ ht, const float* __restrict__ labels,
+    const long long* __restrict__ top_idx, const float* __restrict__ w1, const float* __restrict__ b1,
+    const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
+    int B, int N, int F, int K, MlpDims md, float* __restrict__ logits, float* __restrict__ a1_save,
+    float* __restrict__ a2_save, double* __restrict__ pair_part, int nblk, const double* __restrict__ partC, int nC,
+    float* __restrict__ out_scalars, int flags, unsigned* __restrict__ ticket /* one word: zeroed by K1, handed back as zero */,
+    float* __restrict__ step_loss) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mlp_smem[];
+    head_mlp_block(reinterpret_cast<float*>(mlp_smem), blockIdx.y, blockIdx.x, hs, ht, labels, top_idx, w1, b1, w2, b2, w3, b3, B, N, F, K, md,
+                   logits, a1_save, a2_save, pair_part, nblk, partC, nC, out_scalars, flags, ticket, gridDim.x * gridDim.y, step_loss,
+                   nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -959,7 +1044,7 @@ static inline HeadWork head_work(void* base, int B, int N) {   // pair_part size
     w.pair_part = reinterpret_cast<double*>(p + o); o += sizeof(double) * (size_t)B * ceil_div(N, kRowsPerBlock);
     w.pair_f = reinterpret_cast<float*>(p + o); o += sizeof(float) * (size_t)B * 4;
     w.pair_g = reinterpret_cast<float*>(p + o); o += sizeof(float) * (size_t)B;
-    w.tickets = reinterpret_cast<unsigned*>(p + o); o += sizeof(unsigned) * (size_t)(B + 1);      // per-pair tickets (K2 / the backward) + K3's; zeroed by K1, handed back as zero
+    w.tickets = reinterpret_cast<unsigned*>(p + o); o += sizeof(unsigned) * (size_t)(3 * B + 1);  // per-pair tickets (K2 / the backward) + the batch-wide one + selection flags / reader counts; zeroed by K1, handed back as zero
     w.bytes = o + 64;
     return w;
 }
@@ -1001,7 +1086,11 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
     hipLaunchKernelGGL(head_node_kernel, dim3(W.nbp, B), dim3(256), 0, s, hs, ht, raw_hs, raw_ht, xs, xt, labels, gt_pose, B, N,
                        F, F_raw, sim, rsim, cosv, pos, W.partA, W.tickets);
     const int Npad = next_pow2(N);
-    const size_t sm = fwd_smem(N, Npad, K, md);
+    EQ_CHECK_ARG(!kabsch_aux || (kabsch_R && kabsch_t), EQUIGSPR_EINVAL, "head_forward: kabsch_R / kabsch_t are null");
+    EQ_CHECK_ARG(!step_loss || kabsch_aux, EQUIGSPR_EINVAL, "head_forward: step_loss needs the head's own Kabsch (kabsch_aux)");
+    const bool fuse_mlp = EQ_HEAD_FUSE_MLP && kabsch_aux && (long long)B * (1 + ceil_div(N, 256) + ceil_div(K, kRowsPerBlock)) <= 512;
+    const size_t sm_sel = fwd_smem(N, Npad, K, md);
+    const size_t sm = fuse_mlp && kMlpLdsBytes > sm_sel ? kMlpLdsBytes : sm_sel;
     {   // the dynamic-LDS limit is a per-device function attribute: keep the high-water mark per device, under a lock
         static std::mutex mu;
         static size_t sm_set[64] = {0};
@@ -1015,20 +1104,23 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
             if (dev >= 0 && dev < 64) sm_set[dev] = sm;
         }
     }
-    EQ_CHECK_ARG(!kabsch_aux || (kabsch_R && kabsch_t), EQUIGSPR_EINVAL, "head_forward: kabsch_R / kabsch_t are null");
-    EQ_CHECK_ARG(!step_loss || kabsch_aux, EQUIGSPR_EINVAL, "head_forward: step_loss needs the head's own Kabsch (kabsch_aux)");
     const int nwb = ceil_div(N, 256);
+    const int nblk = ceil_div(K, kRowsPerBlock);
     const WeightsJob wj{sim, rsim, labels, wts, W.partC};
     // K2: per pair the select block and, beside it, the weight blocks -> (ticket) Kabsch moments + solve (= equigspr_kabsch_forward
-    // on the weights, when kabsch_aux is given)
-    hipLaunchKernelGGL(head_pair_kernel, dim3(1 + nwb, B), dim3(256), sm, s, hs, ht, labels, sim, W.partA, W.nbp, w1, b1, w2, b2, w3, b3,
-                       B, N, Npad, F, K, md, pos, reinterpret_cast<long long*>(top_idx), logits, a1_save, a2_save, W.pair_f,
-                       W.pair_part, out_scalars, W.tickets, wj, nwb, xs, xt, kabsch_R, kabsch_t, kabsch_aux, gt_pose, step_loss);
+    // on the weights, when kabsch_aux is given) and -- small batches with the head's own Kabsch -- the MLP blocks of K3 as further
+    // grid columns: they stage their weights while the select block works and wait for its selection (a workgroup is dispatched
+    // after every workgroup with a lower linear index, so the select block of a pair is always running or done when its MLP
+    // blocks spin; the bound keeps the whole grid co-resident anyway).  Larger batches: K3 as its own launch.
+    hipLaunchKernelGGL(head_pair_kernel, dim3(1 + nwb + (fuse_mlp ? nblk : 0), B), dim3(256), sm, s, hs, ht, labels, sim, W.partA, W.nbp,
+                       w1, b1, w2, b2, w3, b3, B, N, Npad, F, K, md, pos, reinterpret_cast<long long*>(top_idx), logits, a1_save, a2_save,
+                       W.pair_f, W.pair_part, out_scalars, W.tickets, wj, nwb, xs, xt, kabsch_R, kabsch_t, kabsch_aux, gt_pose, step_loss,
+                       fuse_mlp ? nblk : 0, W.nC, (int)flags);
     // K3: the MLP on the selected rows; the last block over all pairs (ticket) writes the loss scalars
-    const int nblk = ceil_div(K, kRowsPerBlock);
-    hipLaunchKernelGGL(head_mlp_kernel, dim3(nblk, B), dim3(256), 0, s, hs, ht, labels,
-                       reinterpret_cast<const long long*>(top_idx), w1, b1, w2, b2, w3, b3, B, N, F, K, md, logits, a1_save, a2_save,
-                       W.pair_part, nblk, W.partC, W.nC, out_scalars, (int)flags, W.tickets + B, step_loss);
+    if (!fuse_mlp)
+        hipLaunchKernelGGL(head_mlp_kernel, dim3(nblk, B), dim3(256), kMlpLdsBytes, s, hs, ht, labels,
+                           reinterpret_cast<const long long*>(top_idx), w1, b1, w2, b2, w3, b3, B, N, F, K, md, logits, a1_save, a2_save,
+                           W.pair_part, nblk, W.partC, W.nC, out_scalars, (int)flags, W.tickets + B, step_loss);
     EQ_CHECK_LAUNCH("head_forward");
     return 0;
 }
