@@ -716,7 +716,8 @@ __device__ __forceinline__ void head_mlp_block(
     if (tid == 0) Bs[md.h1 + md.h2] = b3[0];
     if (ready) {                                         // the select block of this pair is in the same launch, dispatched before this one
         if (tid == 0) {
-            while (atomicAdd(ready, 0u) == 0u) __builtin_amdgcn_s_sleep(2);
+            for (int it = 0; __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && it < (1 << 22); ++it)
+                __builtin_amdgcn_s_sleep(2);      // bounded: wrong logits, never a hung GPU
             __threadfence();
         }
         __syncthreads();
