@@ -304,6 +304,10 @@ __global__ __launch_bounds__(256, 3) void node_fwd_kernel(
 #ifndef EQ_NODE_FWD16
 #define EQ_NODE_FWD16 1
 #endif
+#ifndef EQ_NODE_FWD16_NPT_SMALL
+#define EQ_NODE_FWD16_NPT_SMALL 16     // nodes per wave below EQ_NODE_FWD16_SMALL nodes (4: four copies share a node's segment -- another summation order; timing knob)
+#define EQ_NODE_FWD16_D_SMALL 16
+#endif
 #ifndef EQ_NODE_FWD16_SMALL
 #define EQ_NODE_FWD16_SMALL 16384
 #endif
@@ -724,7 +728,7 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
             // (tests/test_gpu_fullsize.py::test_batching_is_exact_fullsize).  The 4-node tiles (NPT = 4: four copies share a segment,
             // 9.0 -> 8.3 us at one pair) add partial sums in another order and are therefore not used.
             if (N <= EQ_NODE_FWD16_SMALL)
-                hipLaunchKernelGGL((node_fwd16_kernel<H, A, 16, F - 32>), dim3(ceil_div(N, 16)), dim3(64), 0, s, lw, last ? nullptr : lw + ML.layer_size,
+                hipLaunchKernelGGL((node_fwd16_kernel<H, A, EQ_NODE_FWD16_D_SMALL, F - 32, EQ_NODE_FWD16_NPT_SMALL>), dim3(ceil_div(N, EQ_NODE_FWD16_NPT_SMALL)), dim3(64), 0, s, lw, last ? nullptr : lw + ML.layer_size,
                                    params + ML.w_out, params + ML.b_out, cfg->out_nf, g->rptr, m, trans, hbuf(l), xbuf(l), N, hbuf(l + 1), xn,
                                    training ? aggs + (size_t)l * N * FP : nullptr, P, h_out);
             else
