@@ -658,6 +658,34 @@ def test_head_tail_ticket_is_deterministic_and_matches_two_launch_kabsch(pk):
     assert torch.allclose(c0, ref[2], rtol=2e-4, atol=1e-5)
 
 
+def test_head_mlp_columns_equal_standalone_mlp_launch(pk):
+    """Small batches run the head's MLP blocks as extra grid columns of the pair kernel (they wait for the pair's selection);
+    large ones launch them on their own.  Same rows, same arithmetic: the logits and selections of a pair are bit-identical
+    whichever way its batch was run, and R / t agree."""
+    torch.manual_seed(6)
+    B, n, feat, k = 40, 256, 32, 8                      # 40 x (1 + 1 + 16) workgroups > 512: the stand-alone MLP launch
+    egnn = pk.EGNN(feat, feat, feat, in_edge_nf=1, device="cuda", n_layers=1)
+    with torch.no_grad():
+        egnn.embedding_out.weight.mul_(0.05); egnn.embedding_out.bias.mul_(0.05)
+    model = pk.CrossAttentionPoseRegression(egnn, num_nodes=n, hidden_nf=feat, device="cuda").cuda()
+    b = pk.synthetic_batch(11, B, n=n, feat=feat, device="cuda")
+
+    def run(lo, hi):
+        graph = pk.build_pair_graph(b["src"][lo:hi], b["tgt"][lo:hi], k)
+        with torch.no_grad():
+            out = model(b["feat_src"][lo:hi], b["src"][lo:hi], graph, None, b["feat_tgt"][lo:hi], b["tgt"][lo:hi], graph, None,
+                        b["corr"][lo:hi], b["labels"][lo:hi], b["gt_pose"][lo:hi])
+        return out[0].clone(), out[1].clone(), model.last_logits.clone(), model.last_top_idx.clone()
+
+    R, t, lg, ti = run(0, B)
+    assert bool(torch.isfinite(lg).all()) and float(lg.abs().max()) > 0
+    for lo in range(0, B, 8):                           # 8 x 18 workgroups: the MLP rides in the pair kernel
+        r8, t8, lg8, ti8 = run(lo, lo + 8)
+        assert torch.equal(ti8, ti[lo:lo + 8])
+        assert torch.equal(lg8, lg[lo:lo + 8])
+        assert torch.allclose(r8, R[lo:lo + 8], atol=1e-6) and torch.allclose(t8, t[lo:lo + 8], atol=1e-6)
+
+
 # ------------------------------------------------------------------------------------ small fused training ops
 def test_fused_pose_loss_matches_aten(pk):
     g = torch.Generator().manual_seed(4)
