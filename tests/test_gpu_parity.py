@@ -494,7 +494,8 @@ def test_train_step_gradients_golden(pk, golden_dir, parity):
                                                          (16, 1, 16, 16, 257, 3001), (48, 4, 20, 48, 257, 3001), (64, 8, 64, 64, 257, 3001),
                                                          (64, 1, 64, 9, 2000, 9001),
                                                          (32, 1, 5, 64, 257, 3001), (32, 1, 5, 7, 16999, 70001), (32, 4, 32, 32, 16999, 70001),
-                                                         (33, 1, 17, 40, 16999, 70001)])
+                                                         (33, 1, 17, 40, 16999, 70001),
+                                                         (32, 1, 32, 32, 40, 5), (33, 1, 33, 33, 40, 17), (32, 1, 32, 32, 300, 1025)])      # fewer edges than one tile; one tile + 1; 64 tiles + 1
 def test_backward_random_graph_vs_oracle_autograd(pk, feat, heads, in_nf, out_nf, n, e):
     """Non-kNN edge list (hub, isolated nodes, self loops, multi-edges), random edge_attr, 3 layers; both hidden widths
     (33 = the MFMA kernels' border path), 1 and 4 heads, embedding widths that differ from the hidden width (odd ones:
@@ -505,7 +506,7 @@ def test_backward_random_graph_vs_oracle_autograd(pk, feat, heads, in_nf, out_nf
     m = pk.EGNN(in_nf, feat, out_nf, in_edge_nf=1, device="cuda", n_layers=3, num_heads=heads)
     h = torch.randn(n, in_nf, generator=g); x = torch.rand(n, 3, generator=g) * 2
     row = torch.randint(0, n - 7, (e,), generator=g); col = torch.randint(0, n - 7, (e,), generator=g)
-    row[:40] = 3; row[40:45] = col[40:45]
+    row[:min(40, e // 2)] = 3; row[40:45] = col[40:45]
     ea = torch.rand(e, 1, generator=g)
     gh = torch.randn(n, out_nf, generator=g); gx = torch.randn(n, 3, generator=g)
     refs = {}
