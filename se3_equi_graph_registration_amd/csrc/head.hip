@@ -714,15 +714,21 @@ __device__ __forceinline__ void head_mlp_block(
     for (int t = tid; t < md.h1; t += 256) Bs[t] = b1[t];
     for (int t = tid; t < md.h2; t += 256) Bs[md.h1 + t] = b2[t];
     if (tid == 0) Bs[md.h1 + md.h2] = b3[0];
+    __shared__ int wait_failed;
+    if (tid == 0) wait_failed = 0;
     if (ready) {                                         // the select block of this pair is in the same launch, dispatched before this one
         if (tid == 0) {
-            for (int it = 0; __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && it < (1 << 22); ++it)
-                __builtin_amdgcn_s_sleep(2);      // bounded: wrong logits, never a hung GPU
+            int it = 0;
+            while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && it < (1 << 22)) { __builtin_amdgcn_s_sleep(2); ++it; }
+            wait_failed = it >= (1 << 22);   // bounded (seconds): never a hung GPU; a wait that ran out poisons this block's logits and the loss with NaN
             __threadfence();
         }
         __syncthreads();
     }
-    if (tid < Kb) idxs[tid] = (int)top_idx[(size_t)b * K + j0 + tid];
+    if (tid < Kb) {
+        const int ix = (int)top_idx[(size_t)b * K + j0 + tid];
+        idxs[tid] = wait_failed ? 0 : min(max(ix, 0), N - 1);
+    }
     __syncthreads();
     if (ready && tid == 0) {                             // the pair's last reader resets the flag for the next forward
         if (atomicAdd(seen, 1u) == (unsigned)nblk - 1u) { *seen = 0u; atomicExch(ready, 0u); }
@@ -753,6 +759,7 @@ __device__ __forceinline__ void head_mlp_block(
     if (tid < Kb) {
         float z = Bs[md.h1 + md.h2];
         for (int i = 0; i < md.h2; ++i) z = fmaf(W3[i], a2[tid * ld2 + i], z);
+        if (wait_failed) z = __uint_as_float(0x7fc00000u);
         logits[(size_t)b * K + j0 + tid] = z;
         const float y = yb[idxs[tid]];
         bce = fmaxf(z, 0.0f) - z * y + log1pf(expf(-fabsf(z)));                          // BCEWithLogits (:772-773)
