@@ -194,7 +194,9 @@ int equigspr_kabsch_backward(const float* src, const float* tgt, const float* w,
  * (kitti :766); pass the same flags to the backward.
  * kabsch_R [B,9], kabsch_t [B,3], kabsch_aux [B*EQUIGSPR_KABSCH_AUX] (all three or all NULL): also performs
  * equigspr_kabsch_forward(xs, xt, wts, ...) -- identical results and aux record -- inside the launch that finishes the
- * loss scalars, instead of two more launches.
+ * loss scalars, instead of two more launches.  Launches: three (per-node similarities; per pair the selection beside the weight /
+ * Kabsch blocks; the MLP on the selected rows), or two when B * (1 + N/256 + K/8) <= 512 workgroups and kabsch_aux is given: the
+ * MLP workgroups then ride in the second launch and wait for their pair's selection (csrc/head.hip, head_mlp_block).
  * Backward: g_corr_sim / g_equi are DEVICE scalars (may be NULL = 0); gw = dL/d wts from
  * equigspr_kabsch_backward -- or, with kabsch_aux / grad_R / grad_t given (ABI 8), that Kabsch backward runs inside this call's
  * first launch beside the MLP backward: gw is then an OUTPUT (scratch [B*N]) and gxs, gxt are written first (grad_R / grad_t may
