@@ -727,6 +727,9 @@ constexpr int kBwd16Waves = 8;
 #ifndef EQ_BWD16_NW33
 #define EQ_BWD16_NW33 8                // waves per workgroup (= 2 x waves per SIMD) of the hidden_nf = 33 variant
 #endif
+#ifndef EQ_BWD33_LDS_BORDER
+#define EQ_BWD33_LDS_BORDER 1          // hidden_nf 33: the 16 border running sums of a lane live in LDS slots instead of registers (A/B knob)
+#endif
 constexpr int bwd16_waves(int kB) { return kB ? EQ_BWD16_NW33 : kBwd16Waves; }
 
 template <int H, int A, int kB = 0>
@@ -749,6 +752,16 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
     __syncthreads();
     EQ_STAMP(1);
     float* sc = scratch[wv];
+    // hidden_nf 33: the border running sums (PassBorder x 2 + dWgeo's row + dw7 / dgamma / dbeta entries) as 16 per-lane LDS slots,
+    // read-modified-written once per tile (a lane only ever touches its own slots: fixed order) -- 16 registers less to spill
+    constexpr bool kLdsB = (kB == 1) && (EQ_BWD33_LDS_BORDER != 0);
+    auto ladd = [](float* p_, float v_) { *p_ += v_; };      // plain read-modify-write of the lane's own slot (ds_add_f32 runs a lane at a time: 597 vs 326 us)
+    __shared__ float bsl_[kLdsB ? NW * 16 * 64 : 1];
+    float* bsl = bsl_ + (kLdsB ? wv * 16 * 64 + lane : 0);      // slot k at bsl[64 k]
+    if constexpr (kLdsB) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bsl[64 * k] = 0.0f;
+    }
     int* idx_r = reinterpret_cast<int*>(sc + C::o_r);
     int* idx_c = reinterpret_cast<int*>(sc + C::o_c);
     float* ds_buf = sc + C::o_a;
@@ -865,12 +878,22 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
                 st4(Y + i * C::LD + 16 * b + 4 * g, o.m[b]);
             }
             if constexpr (kB == 1) {
-                lsb_w7 = fmaf(o.qb * o.sgqb, ds, lsb_w7);
+                if constexpr (kLdsB) ladd(bsl + 64 * 13, o.qb * o.sgqb * ds);
+                else lsb_w7 = fmaf(o.qb * o.sgqb, ds, lsb_w7);
                 dqb = bord[W16::b_sc + 6] * ds * (o.sgqb * (1.0f + o.qb * (1.0f - o.sgqb)));
                 if (g == 0) { X[i * C::LD + 32] = dqb; Y[i * C::LD + 32] = o.mb; }
             }
             __builtin_amdgcn_wave_barrier();
-            pass16<2, !kRun, kB>(X, Y, C::LD, i, g, acc6, cs_b6, pb6);     // dW6 += dq^T m (; db6 += sum dq)
+            PassBorder t6, t2, tg;                      // kLdsB: this tile's border sums, flushed to the LDS slots below
+            if constexpr (kLdsB) { t6.init(); t2.init(); tg.init(); }
+            PassBorder& r6 = kLdsB ? t6 : pb6;
+            PassBorder& r2 = kLdsB ? t2 : pb2;
+            PassBorder& rg = kLdsB ? tg : pbg;
+            pass16<2, !kRun, kB>(X, Y, C::LD, i, g, acc6, cs_b6, r6);     // dW6 += dq^T m (; db6 += sum dq)
+            if constexpr (kLdsB) {
+                ladd(bsl + 64 * 0, t6.bcol[0]); ladd(bsl + 64 * 1, t6.bcol[1]); ladd(bsl + 64 * 2, t6.brow[0]);
+                ladd(bsl + 64 * 3, t6.brow[1]); ladd(bsl + 64 * 4, t6.corner); ladd(bsl + 64 * 5, t6.xbs);
+            }
             __builtin_amdgcn_wave_barrier();
             EQ_STAMP(10);
             // ---- dm = dagg[row] + W6^T dq   (padding edges: dq = 0 and dagg masked)
@@ -895,8 +918,8 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
                 float m1 = hsum8(du[0], du[1]), m2 = hsum4(fma4(du[1], o.xhat[1], du[0] * o.xhat[0]));
                 gsum2(m1, m2);
                 if constexpr (kB == 1) {
-                    lsb_gam = fmaf(dmb, o.xhatb, lsb_gam);
-                    lsb_bet += dmb;
+                    if constexpr (kLdsB) { ladd(bsl + 64 * 14, dmb * o.xhatb); ladd(bsl + 64 * 15, dmb); }
+                    else { lsb_gam = fmaf(dmb, o.xhatb, lsb_gam); lsb_bet += dmb; }
                     dub = dmb * bord[W16::b_sc + 3];
                     m1 += dub;
                     m2 = fmaf(dub, o.xhatb, m2);
@@ -918,7 +941,11 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
                 if (g == 0) { X[i * C::LD + 32] = dub; Y[i * C::LD + 32] = o.t1b * o.sg1b; }
             }
             __builtin_amdgcn_wave_barrier();
-            pass16<2, !kRun, kB>(X, Y, C::LD, i, g, acc2, cs_b2, pb2);     // dW2 += du^T SiLU(t1) (; db2 += sum du)
+            pass16<2, !kRun, kB>(X, Y, C::LD, i, g, acc2, cs_b2, r2);     // dW2 += du^T SiLU(t1) (; db2 += sum du)
+            if constexpr (kLdsB) {
+                ladd(bsl + 64 * 6, t2.bcol[0]); ladd(bsl + 64 * 7, t2.bcol[1]); ladd(bsl + 64 * 8, t2.brow[0]);
+                ladd(bsl + 64 * 9, t2.brow[1]); ladd(bsl + 64 * 10, t2.corner); ladd(bsl + 64 * 11, t2.xbs);
+            }
             __builtin_amdgcn_wave_barrier();
             EQ_STAMP(12);
             // ---- dt1 = (W2^T du) * SiLU'(t1)
@@ -944,7 +971,8 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            pass16<1, false, kB>(X, geo_rows, C::GS, i, g, accg, cs_none, pbg);     // dWgeo | dw_attr += dt1^T [geo, attr]
+            pass16<1, false, kB>(X, geo_rows, C::GS, i, g, accg, cs_none, rg);     // dWgeo | dw_attr += dt1^T [geo, attr]
+            if constexpr (kLdsB) ladd(bsl + 64 * 12, tg.brow[0]);
             // ---- dgeo = Wgeo^T dt1: rows 4 g + r of a 16-row product, left in the edge's (now consumed) geometry row
             f32x4 dg = splat4(0.0f);
 #pragma unroll
@@ -990,6 +1018,13 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
         EQ_STAMP(14);
     }
 
+    if constexpr (kLdsB) {                             // the border sums back from their LDS slots
+        __builtin_amdgcn_wave_barrier();
+        pb6.bcol[0] = bsl[64 * 0]; pb6.bcol[1] = bsl[64 * 1]; pb6.brow[0] = bsl[64 * 2]; pb6.brow[1] = bsl[64 * 3]; pb6.corner = bsl[64 * 4]; pb6.xbs = bsl[64 * 5];
+        pb2.bcol[0] = bsl[64 * 6]; pb2.bcol[1] = bsl[64 * 7]; pb2.brow[0] = bsl[64 * 8]; pb2.brow[1] = bsl[64 * 9]; pb2.corner = bsl[64 * 10]; pb2.xbs = bsl[64 * 11];
+        pbg.brow[0] = bsl[64 * 12];
+        lsb_w7 = bsl[64 * 13]; lsb_gam = bsl[64 * 14]; lsb_bet = bsl[64 * 15];
+    }
     // ---- partial sums of the waves: every wave writes a slab copy into its scratch, all threads add the copies in fixed order
     auto lane16_sum = [](float v) {                    // over the 16 lanes (edges) of a group
 #pragma unroll
