@@ -965,9 +965,11 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             if constexpr (kB == 1) {
                 if (g == 0) {
                     X[i * C::LD + 32] = dt1b;
-                    // hidden_nf 33: the 33rd column is its own array behind the [E][32] block -- a 144-byte row would straddle cache
-                    // lines, and the col-side gather of the node backward reads these rows scattered (one line + one word per row)
-                    if (valid) dt1b_out[eg_] = dt1b;
+                    // hidden_nf 33: a 144-byte row would straddle cache lines, so the 33rd column does not ride in the dt1 rows: it goes
+                    // out as the 4th component of the edge's two coordinate-gradient items (back phase), which the node backward reads
+                    // anyway -- a separate [E] column cost it two scattered 4-byte reads per edge (node backward 147.5 -> 134.1 us at the KITTI shard).  The edge's ds word is
+                    // consumed by now: it carries the value to the back phase.
+                    ds_buf[el] = dt1b;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -1010,8 +1012,9 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             float gxr[3], gxc[3];
             edge_geometry_backward_mode(basis, xr2, xc2, eg, gg, gd, gxr, gxc);
             const int eo = edge_id(ch);
-            reinterpret_cast<float4*>(gxr_out)[eo] = make_float4(gxr[0], gxr[1], gxr[2], 0.0f);
-            reinterpret_cast<float4*>(gxc_out)[eo] = make_float4(gxc[0], gxc[1], gxc[2], 0.0f);
+            const float dtb = kB ? ds_buf[lane] : 0.0f;
+            reinterpret_cast<float4*>(gxr_out)[eo] = make_float4(gxr[0], gxr[1], gxr[2], dtb);
+            reinterpret_cast<float4*>(gxc_out)[eo] = make_float4(gxc[0], gxc[1], gxc[2], dtb);
         }
         __builtin_amdgcn_wave_barrier();
         r = rn; c = cn; e = en;

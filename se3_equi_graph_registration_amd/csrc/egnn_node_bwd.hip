@@ -238,7 +238,6 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
             load_idx(0, er, ec);
             for (int base = 0; base < maxlen; base += D * NP) {
                 f32x4 vr[D][2], vc[D][2], tv[D];
-                float vrb[D], vcb[D];
 #pragma unroll
                 for (int u = 0; u < D; ++u) {
 #pragma unroll
@@ -246,8 +245,7 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
                         vr[u][b] = er[u] >= 0 ? ldg4(a.dt1 + (size_t)er[u] * 32 + 16 * b + 4 * g) : zero;      // [E][32] rows + [E] border column
                         vc[u][b] = ec[u] >= 0 ? ldg4(a.dt1 + (size_t)ec[u] * 32 + 16 * b + 4 * g) : zero;
                     }
-                    vrb[u] = (kB && er[u] >= 0) ? a.dt1[(size_t)a.n_edges * 32 + er[u]] : 0.0f;
-                    vcb[u] = (kB && ec[u] >= 0) ? a.dt1[(size_t)a.n_edges * 32 + ec[u]] : 0.0f;
+                    // (hidden_nf 33: the border column of dt1 arrives as tv.w from the edge backward and is summed in xs[3])
                     const int e3 = g == 0 ? er[u] : ec[u];
                     tv[u] = (g < 2 && e3 >= 0) ? ldg4(d3 + (size_t)e3 * 4) : zero;
                 }
@@ -256,7 +254,6 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
                 for (int u = 0; u < D; ++u) {
                     dpr[0] += vr[u][0]; dpr[1] += vr[u][1];
                     dpc[0] += vc[u][0]; dpc[1] += vc[u][1];
-                    if (kB) { dprb += vrb[u]; dpcb += vcb[u]; }
                     xs += tv[u];
                 }
             }
@@ -273,9 +270,12 @@ __global__ __launch_bounds__(64 * NW, EQ_NB16_OCC) void node_bwd16_kernel(const 
                             dpc[b][r] += __shfl_xor(dpc[b][r], o, 64);
                         }
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) xs[r] += __shfl_xor(xs[r], o, 64);
-                    if (kB) { dprb += __shfl_xor(dprb, o, 64); dpcb += __shfl_xor(dpcb, o, 64); }
+                    for (int r = 0; r < (kB ? 4 : 3); ++r) xs[r] += __shfl_xor(xs[r], o, 64);
                 }
+            }
+            if constexpr (kB == 1) {                    // lane group 0 summed the row side's border column, group 1 the col side's
+                dprb = __shfl(xs[3], i, 64);
+                dpcb = __shfl(xs[3], 16 + i, 64);
             }
             {   // G_x = identity + row-segment terms + col-segment terms
                 f32x4 xc;
