@@ -158,12 +158,14 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
             tile_forward16<kB>(wsm, bord, sc + C::o_geo + el * C::GS, pw, i, g, o);
             if ((t0 + sub * ts) * 16 + i < n_edges) {
                 // stored at the edge's position in the by-row (aggregation) order: node_fwd then streams its segment contiguously
-                float* dst = m_out + (size_t)pos[el] * FP + 4 * g;
+                // 128-byte rows for every hidden_nf: the 33rd feature of m leaves as the 4th component of the edge's `trans` item (back
+                // phase) -- 144-byte rows straddled two cache lines in every read of the node kernel (66 us against 47 at width 32)
+                float* dst = m_out + (size_t)pos[el] * 32 + 4 * g;
                 st4(dst, o.m[0]);
                 st4(dst + 16, o.m[1]);
                 if (g == 0) {
                     s_buf[el] = o.s;
-                    if (kB) st4(dst + 32, f32x4{o.mb, 0.0f, 0.0f, 0.0f});
+                    if (kB) reinterpret_cast<float*>(pos)[el] = o.mb;      // the edge's position word is consumed (every lane group read it above, in the same instruction)
                 }
             }
             pw = pn;
@@ -173,7 +175,8 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
         // ---- back: one lane per edge, trans = coord_diff * s   (:264)
         if (mine) {
             const float s = s_buf[lane];
-            reinterpret_cast<float4*>(trans_out)[at] = make_float4(eg.d[0] * s, eg.d[1] * s, eg.d[2] * s, 0.0f);
+            const float mb = kB ? reinterpret_cast<const float*>(pos)[lane] : 0.0f;
+            reinterpret_cast<float4*>(trans_out)[at] = make_float4(eg.d[0] * s, eg.d[1] * s, eg.d[2] * s, mb);
         }
         __builtin_amdgcn_wave_barrier();               // the next chunk's front overwrites the scratch
         r = rn; c = cn; at = atn; e = en;
@@ -379,22 +382,20 @@ __global__ __launch_bounds__(64) void node_fwd16_kernel(
     for (int a0 = 0; a0 < maxlen; a0 += D * NP) {
         f32x4 v[D][2];
         float4 tv[D];
-        float vb[D];
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             const int aa = a0 + part + u * NP;
             const bool in = aa < len;
             const size_t a = (size_t)(lo + (in ? aa : 0));
 #pragma unroll
-            for (int b = 0; b < 2; ++b) v[u][b] = in ? ldg4(m_in + a * FP + 16 * b + 4 * g) : splat4(0.0f);
-            vb[u] = (kB && in) ? m_in[a * FP + 32] : 0.0f;
+            for (int b = 0; b < 2; ++b) v[u][b] = in ? ldg4(m_in + a * 32 + 16 * b + 4 * g) : splat4(0.0f);      // [E][32] rows; the 33rd feature is tv.w
             tv[u] = (in && g == 0) ? reinterpret_cast<const float4*>(trans_in)[a] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int u = 0; u < D; ++u) {
             agg[0] += v[u][0]; agg[1] += v[u][1];
-            if (kB) aggb += vb[u];
             xs.x += tv[u].x; xs.y += tv[u].y; xs.z += tv[u].z;
+            if (kB) xs.w += tv[u].w;                   // lane group 0 sums the 33rd feature of m
         }
     }
     if constexpr (NP > 1) {                      // the copies of a node add up their parts (every copy gets the same sums)
@@ -404,10 +405,11 @@ __global__ __launch_bounds__(64) void node_fwd16_kernel(
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) agg[b][r] += __shfl_xor(agg[b][r], o, 64);
-            if (kB) aggb += __shfl_xor(aggb, o, 64);
+            if (kB) xs.w += __shfl_xor(xs.w, o, 64);
             xs.x += __shfl_xor(xs.x, o, 64); xs.y += __shfl_xor(xs.y, o, 64); xs.z += __shfl_xor(xs.z, o, 64);
         }
     }
+    if constexpr (kB == 1) aggb = __shfl(xs.w, i, 64);      // ... and hands the sum to the node's other three lanes
     if (live && g == 0) {                                                             // :267
         x_next[(size_t)j * 3 + 0] = x[(size_t)j * 3 + 0] + xs.x;
         x_next[(size_t)j * 3 + 1] = x[(size_t)j * 3 + 1] + xs.y;
