@@ -34,7 +34,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_FILES = ("r03_v5_pmc_edge_kernels.json", "r03_v2_pmc_edge_kernels.json", "r03_v1_pmc_edge_kernels.json", "r02_pmc_edge_kernels.json")
+PMC_FILES = ("r03_v6_pmc_edge_kernels.json", "r03_v2_pmc_edge_kernels.json", "r03_v1_pmc_edge_kernels.json", "r02_pmc_edge_kernels.json")
 FP32_PEAK_TF = 157.3
 
 
