@@ -727,6 +727,9 @@ constexpr int kBwd16Waves = 8;
 #ifndef EQ_BWD16_NW33
 #define EQ_BWD16_NW33 8                // waves per workgroup (= 2 x waves per SIMD) of the hidden_nf = 33 variant
 #endif
+#ifndef EQ_BWD33_AHEAD
+#define EQ_BWD33_AHEAD 0                // hidden_nf 33: prefetch the next tile's projection rows into a second register set (A/B knob)
+#endif
 #ifndef EQ_BWD33_LDS_BORDER
 #define EQ_BWD33_LDS_BORDER 1          // hidden_nf 33: the 16 border running sums of a lane live in LDS slots instead of registers (A/B knob)
 #endif
@@ -852,7 +855,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             float* geo_rows = sc + C::o_geo + sub * 16 * C::GS;
             // next sub-tile's rows, requested before this one computes (the last one re-requests its own: harmless).  hidden_nf
             // 33 has no registers to hold them: it requests its rows when it needs them.
-            constexpr bool kAhead = (kB == 0) || (EQ_BWD16_NW33 == 4);
+            constexpr bool kAhead = (kB == 0) || (EQ_BWD16_NW33 == 4) || (EQ_BWD33_AHEAD != 0);
             const int rr = idx_r[el];
             if (!kAhead && sub > 0) cur.load(P, rr, idx_c[el], g);
             f32x4 da[2];
@@ -989,7 +992,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             __builtin_amdgcn_wave_barrier();
             EQ_STAMP(13);
         };
-        if constexpr (kB == 0) {
+        if constexpr (kB == 0 || EQ_BWD33_AHEAD != 0) {
             for (int sub = 0; sub < n_sub; sub += 2) {
                 tile(sub, ra, rb);
                 if (sub + 1 < n_sub) tile(sub + 1, rb, ra);
