@@ -311,6 +311,9 @@ __global__ __launch_bounds__(256, 3) void node_fwd_kernel(
 #define EQ_NODE_FWD16_NPT_SMALL 16     // nodes per wave below EQ_NODE_FWD16_SMALL nodes (4: four copies share a node's segment -- another summation order; timing knob)
 #define EQ_NODE_FWD16_D_SMALL 16
 #endif
+#ifndef EQ_NODE_FWD16_D_LARGE
+#define EQ_NODE_FWD16_D_LARGE 4          // segment rows in flight per lane above EQ_NODE_FWD16_SMALL nodes
+#endif
 #ifndef EQ_NODE_FWD16_SMALL
 #define EQ_NODE_FWD16_SMALL 16384
 #endif
@@ -734,7 +737,7 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
                                    params + ML.w_out, params + ML.b_out, cfg->out_nf, g->rptr, m, trans, hbuf(l), xbuf(l), N, hbuf(l + 1), xn,
                                    training ? aggs + (size_t)l * N * FP : nullptr, P, h_out);
             else
-                hipLaunchKernelGGL((node_fwd16_kernel<H, A, 4, F - 32>), dim3(ceil_div(N, 16)), dim3(64), 0, s, lw, last ? nullptr : lw + ML.layer_size,
+                hipLaunchKernelGGL((node_fwd16_kernel<H, A, EQ_NODE_FWD16_D_LARGE, F - 32>), dim3(ceil_div(N, 16)), dim3(64), 0, s, lw, last ? nullptr : lw + ML.layer_size,
                                    params + ML.w_out, params + ML.b_out, cfg->out_nf, g->rptr, m, trans, hbuf(l), xbuf(l), N, hbuf(l + 1), xn,
                                    training ? aggs + (size_t)l * N * FP : nullptr, P, h_out);
         } else
