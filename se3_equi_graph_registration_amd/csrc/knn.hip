@@ -56,6 +56,15 @@ __device__ __forceinline__ f32x2 dist2_pk(f32x2 px, f32x2 py, f32x2 pz, f32x2 nq
     const f32x2 s = xx + yy;
     return s + zz;
 }
+// One pair, the same contract.  (NOT __fsub_rn / __fmul_rn / __fadd_rn: in this toolchain they are plain `x - y`, `x * y`, `x + y`
+// (__clang_hip_math.h), which hipcc's default -ffp-contract=fast fuses into FMAs once inlined -- keys an ulp away from the contract.)
+__device__ __forceinline__ float dist2_scalar(float px, float py, float pz, float qx, float qy, float qz) {
+#pragma clang fp contract(off)
+    const float dx = px - qx, dy = py - qy, dz = pz - qz;
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    const float s = xx + yy;
+    return s + zz;
+}
 // position of this lane among the set bits of a ballot mask (= popcount of the mask below the lane): two v_mbcnt
 __device__ __forceinline__ int rank_in_mask(u64 mask) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -213,8 +222,7 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
         }
     };
     auto dist2 = [&](int u, float px, float py, float pz) {   // scalar form of the same contract (slow path)
-        const float dx = __fsub_rn(px, qx[u]), dy = __fsub_rn(py, qy[u]), dz = __fsub_rn(pz, qz[u]);
-        return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        return dist2_scalar(px, py, pz, qx[u], qy[u], qz[u]);
     };
     auto stage = [&](int t0, int cnt) {
         __syncthreads();
