@@ -726,6 +726,7 @@ static int forward_impl(const equigspr_egnn_config* cfg, const float* params, co
             launch_edge_fwd<F, H, A>(lw, g, edge_attr, xbuf(l), P, m, trans, cfg->edge_basis, s);
         }
         float* xn = last ? x_out : xbuf(l + 1);
+        static_assert(EQ_NODE_FWD16 || F != 33, "hidden_nf 33: the edge kernel writes 128-byte message rows (33rd feature in trans.w), which only node_fwd16_kernel reads");
         if constexpr (EQ_NODE_FWD16 && (F == 32 || (F == 33 && H == 1))) {
             // few nodes: one wave per CU or less, latency decides -> 16 rows in flight; many nodes: 4 (registers for occupancy)
             // few nodes: one wave per CU or less, latency decides -> 16 rows in flight; many nodes: 4 (registers for occupancy).  Both sum
