@@ -5,7 +5,12 @@ A "step" = one full training pass of the hot path over one batch of synthetic pa
   k-NN graph for all 2B clouds (one launch) + inverse index -> batched EGNN forward ->
   pose head (top-k logits MLP, weighted Kabsch/SVD) -> losses (train :1120) -> backward
   (HIP EGNN + Kabsch backward) -> [one all-reduce of the flat gradient bucket over RCCL] ->
-  Adam step.  Inputs are resident in HBM before the timed region.
+  Adam step.
+Since round 4 the timed object is the PACKAGE's training loop, not a harness: `train.GraphedStep` (what `train.train_one_epoch`
+runs) over a ring of >= 64 DISTINCT synthetic pairs that start in host memory -- packing, the H2D copy of every batch (one step
+ahead, on a side stream), the hipGraph replay and the device-side non-finite guard are all inside the timed region.  The old
+construction (ONE fixed pair resident in HBM, replayed inside a hand-captured hipGraph) is measured beside it and reported as
+`fixed_pair_replay`; `--fixed-pair-replay` makes it the headline again (diagnostic).
 Default workload = BASELINE configs[1]: one 2048-point pair, k=20, 4 EGNN layers, batch=1,
 forward+backward on 1 GPU.  With --gpus N every rank processes its own batch (weak scaling:
 pairs are independent; the only exchange is the gradient all-reduce).
@@ -19,8 +24,11 @@ Prints ONE JSON line on rank 0 (schema: see repo prompt) including
 import argparse
 import copy
 import ctypes
+import glob
+import itertools
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -34,7 +42,10 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_FILES = ("r03_v6_pmc_edge_kernels.json", "r03_v2_pmc_edge_kernels.json", "r03_v1_pmc_edge_kernels.json", "r02_pmc_edge_kernels.json")
+# committed rocprofv3 evidence the line quotes (collected by tools/profile_round.sh -- counters and kernel traces need the profiler,
+# so they cannot be taken inside this run): newest first; a file counts only when it was collected on exactly this launch shape
+PMC_GLOBS = ("r04_*pmc_*.json", "r03_v6_pmc_edge_kernels.json", "r03_v2_pmc_edge_kernels.json", "r03_v1_pmc_edge_kernels.json", "r02_pmc_edge_kernels.json")
+IN_STEP_GLOBS = ("r04_*in_step.json",)
 FP32_PEAK_TF = 157.3
 
 
@@ -75,9 +86,16 @@ def parse(argv=None):
     ap.add_argument("--no-workloads", action="store_true",
                     help="default run only: skip the extra `workloads` block (c3, c3 irreps, c4 shard, c5 with the evaluation head)")
     ap.add_argument("--workload-seconds", type=float, default=0.5, help="seconds measured per entry of the `workloads` block")
+    ap.add_argument("--ring", type=int, default=64,
+                    help="distinct synthetic pairs per rank the product loop cycles through (host memory; every step's batch is packed and "
+                         "copied to the GPU inside the timed region)")
+    ap.add_argument("--fixed-pair-replay", action="store_true",
+                    help="diagnostic: the pre-round-4 construction as the headline -- ONE fixed batch resident in HBM, the step replayed from a "
+                         "hipGraph captured by this harness (no H2D, no distinct data); default = the package's own loop, train.GraphedStep")
+    ap.add_argument("--no-fixed-pair", action="store_true", help="default run only: skip the `fixed_pair_replay` side measurement")
     a = ap.parse_args(argv)
     a.explicit_workload = a.workload is not None or a.batch != 1 or a.n != 2048 or a.k != 20 or a.layers != 4 or a.feat != 32 or \
-        a.heads != 1 or a.forward_only or a.edge_basis != "frames" or a.global_batch > 0 or a.dev_no_head or a.aten_head
+        a.heads != 1 or a.forward_only or a.edge_basis != "frames" or a.global_batch > 0 or a.dev_no_head or a.aten_head or a.fixed_pair_replay
     if a.workload == "c3":
         a.batch = 16
     elif a.workload == "c4":
@@ -164,6 +182,81 @@ def build_step(pkg, args, dev, world):
         opt.step(zero_grad=not args.aten_head)
 
     return dict(model=model, egnn=egnn, dp=dp, batch=batch, fwd_bwd=fwd_bwd, zero=zero, opt_step=opt_step, restore=restore)
+
+
+def uses_product_loop(args):
+    """Training workloads are timed through the package's loop (train.GraphedStep); inference and the developer variants keep the
+    harness-side capture."""
+    return not (args.forward_only or args.fixed_pair_replay or args.dev_no_head or args.aten_head)
+
+
+def build_product(pkg, args, dev, world):
+    """The product path: model + train.make_optimizer + train.GraphedStep (the body of train.train_one_epoch, reference train
+    :964-1140) fed from a ring of distinct synthetic HOST batches in the 7-tuple layout of the dataset classes."""
+    from se3_equi_graph_registration_amd import train
+    from se3_equi_graph_registration_amd.dp import shard_range
+    torch.manual_seed(0)
+    egnn = pkg.EGNN(args.feat, args.feat, args.feat, in_edge_nf=1, device=dev, n_layers=args.layers, num_heads=args.heads,
+                    edge_basis=args.edge_basis)
+    model = pkg.CrossAttentionPoseRegression(egnn, num_nodes=args.n, hidden_nf=args.feat, device=dev, variant="train").to(dev)
+    model.train()
+    opt = train.make_optimizer(model, lr=1e-4)                  # reference: torch.optim.Adam(model.parameters(), lr) train :1412
+    opt.dp.broadcast_parameters(0)
+    force = os.environ.get("BENCH_FORCE_DIST") == "1"
+    stepper = train.GraphedStep(model, opt, k=args.k, graph_collectives=not args.split_graph, use_graphs=not args.no_graph,
+                                force_dist=force)
+    rank = dist.get_rank() if world > 1 else 0
+    strong = args.global_batch > 0
+    if strong:                 # the SAME global batches at every world size; GraphedStep shards them with dp.shard_range (SURVEY 8(e))
+        lo, hi = shard_range(args.global_batch, rank, world)
+        if hi <= lo:
+            raise SystemExit(f"--global-batch {args.global_batch} leaves rank {rank} of {world} without a pair")
+        args.batch = hi - lo
+        per_step = args.global_batch
+    else:
+        per_step = args.batch
+    n_batches = max(2, -(-args.ring // per_step))
+    ring = []
+    for j in range(n_batches):
+        first = 1234 + (j if strong else rank * n_batches + j) * per_step
+        b = pkg.synthetic_batch(first, per_step, n=args.n, feat=args.feat, scale=(3.0, 3.0, 3.0))
+        ring.append((b["corr"], b["labels"], b["src"], b["tgt"], b["feat_src"], b["feat_tgt"], b["gt_pose"]))
+    lo = shard_range(args.global_batch, rank, world)[0] if strong else 0
+    batch = {k: v[lo:lo + args.batch].to(dev) for k, v in zip(("corr", "labels", "src", "tgt", "feat_src", "feat_tgt", "gt_pose"), ring[0])}
+    pos = [0]
+    totals = {"applied": 0, "skipped": 0, "void": 0}
+
+    def run_steps(n):
+        def gen():
+            for _ in range(n):
+                yield ring[pos[0] % len(ring)]
+                pos[0] += 1
+        stepper.run(gen(), log_interval=0, skip_nonfinite=True, shard_batches=strong)
+        for key in totals:
+            totals[key] += stepper.last_stats[key]
+
+    # The reference's pose loss (train :952,:960) is arccos of a quantity that tends to 1 at a perfect fit, where its gradient is
+    # -inf; the guard rejects such a step (counted in `steps_rejected_nonfinite`).  To keep every timed block on the same footing the
+    # initial weights and a clean Adam state are restored BETWEEN blocks (outside the timed region).
+    bufs = [opt.dp.joint] if opt.dp.joint is not None else [egnn.flat_params, opt.dp.head.flat]
+    init = [t.clone() for t in bufs]
+
+    def restore():
+        with torch.no_grad():
+            for dst, src in zip(bufs, init):
+                dst.copy_(src)
+            opt.adam.reset_state()
+
+    def fwd_bwd():             # one eager forward + backward outside the loop object (test hook BENCH_GRAD_HASH)
+        graph = pkg.build_pair_graph(batch["src"], batch["tgt"], args.k, loop=True)
+        out = model(batch["feat_src"], batch["src"], graph, None, batch["feat_tgt"], batch["tgt"], graph, None,
+                    batch["corr"], batch["labels"], batch["gt_pose"])
+        loss, _, _ = pkg.registration_loss(out[0], out[1], out[2], batch["gt_pose"])
+        loss.backward()
+        return loss
+
+    return dict(model=model, egnn=egnn, dp=opt.dp, opt=opt, batch=batch, stepper=stepper, run_steps=run_steps, restore=restore,
+                fwd_bwd=fwd_bwd, ring_pairs=len(ring) * per_step, totals=totals, product=True)
 
 
 def make_runner(S, args, world, dev):
@@ -339,17 +432,30 @@ def roofline(pkg, S, args, dev):
     tiles = (E + mm["edges"] - 1) // mm["edges"]
     exe_fwd, exe_bwd = tiles * mm["fwd"] * mm["flop"], tiles * mm["bwd"] * mm["flop"]
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this command (profiles/), when they cover this workload
-    traffic = {"fwd": None, "bwd": None, "source": None}
-    for name in PMC_FILES:             # newest first; a file counts only when it was collected on exactly this launch shape
+    traffic = {"fwd": None, "bwd": None, "source": None, "node": None}
+    for name in [f for g in PMC_GLOBS for f in sorted(glob.glob(os.path.join(ROOT, "profiles", g)), reverse=True)]:
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            pmc = json.load(open(name))
             if pmc["workload"]["edges_per_launch"] == E and pmc["workload"]["feat"] == F:
-                traffic = {"fwd": pmc["edge_fwd_kernel"]["traffic_bytes"], "bwd": pmc["edge_bwd_kernel"]["traffic_bytes"],
-                           "source": f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
+                traffic = {"fwd": pmc["edge_fwd_kernel"]["traffic_bytes"], "bwd": (pmc.get("edge_bwd_kernel") or {}).get("traffic_bytes"),
+                           "node": {k: v["traffic_bytes"] for k, v in pmc.items() if isinstance(v, dict) and "traffic_bytes" in v and "node" in k},
+                           "source": f"profiles/{os.path.basename(name)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                                      "2*FETCH+WRITE per the gfx950 correction; collected by tools/profile_round.sh, not in this run)"}
                 break
         except Exception:
             continue
+    # the kernels' average duration INSIDE the step (rocprofv3 --kernel-trace --stats of this command's graph replays, committed)
+    in_step = {}
+    for name in [f for g in IN_STEP_GLOBS for f in sorted(glob.glob(os.path.join(ROOT, "profiles", g)), reverse=True)]:
+        try:
+            for w in json.load(open(name))["workloads"]:
+                if w["edges_per_launch"] == E and w["feat"] == F and bool(w["training"]) == (not args.forward_only):
+                    in_step = dict(w["kernels"], source=f"profiles/{os.path.basename(name)}: {w['source']}")
+                    break
+        except Exception:
+            continue
+        if in_step:
+            break
     dom_is_bwd = bwd_ms is not None and bwd_ms >= fwd_ms
     a_f = bytes_fwd / (fwd_ms * 1e-3) / 1e9
     a_b = bytes_bwd / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
@@ -360,10 +466,21 @@ def roofline(pkg, S, args, dev):
             "traffic_source": traffic["source"],
             "edges_per_launch": E, "algorithmic_bytes_per_launch": bytes_bwd if dom_is_bwd else bytes_fwd,
             "launch_ms": round(bwd_ms if dom_is_bwd else fwd_ms, 5),
+            "launch_ms_note": "HIP events around back-to-back launches of this one kernel (equigspr_time_edge_*): warm caches, no neighbours; "
+                              "in_step_* = the same kernel's average inside the replayed step under rocprofv3 (committed profile)",
             "issue_floor_us": round(issue_floor_us(E, F, dom_is_bwd), 2),
             "issue_floor_note": "(MFMA x 32 + vector-ALU x 4 cycles) per 16-edge sub-tile x sub-tiles per SIMD / 2.1 GHz: fp32 MFMA and VALU "
                                 "do not co-execute on gfx950 (profiles/r03_sq_edge_kernels.json, tools/dev/coexec.hip)",
             "backward_mode": "recompute (no per-edge activations kept by the forward)"}
+    kshort = "edge_bwd16_kernel" if dom_is_bwd else "edge_fwd16_kernel"
+    if kshort in in_step:
+        us = in_step[kshort]["avg_us"]
+        roof.update({"in_step_launch_us": us, "in_step_frac": round((bytes_bwd if dom_is_bwd else bytes_fwd) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                     "in_step_source": in_step["source"]})
+    else:
+        roof.update({"in_step_launch_us": None, "in_step_frac": None, "in_step_source": None})
+    if traffic["node"]:
+        roof["node_kernel_traffic"] = traffic["node"]
     tf = lambda fl, t_ms: fl / (t_ms * 1e-3) / 1e12 / FP32_PEAK_TF
     extra = {"edge_fwd_ms": round(fwd_ms, 5), "edge_fwd_issue_floor_us": round(issue_floor_us(E, F, False), 2),
              "edge_fwd_form": "training form = inference form (the timed step runs this kernel)",
@@ -440,12 +557,43 @@ def cpu_baseline(args):
 
 
 
+def visible_gpu_count():
+    """GPUs this process could open, counted WITHOUT the HIP runtime (the parent of a self-launched job must not initialise the GPU
+    before it starts its ranks): KFD topology nodes with compute units whose render node is accessible, capped by the
+    *_VISIBLE_DEVICES lists.  None when the topology cannot be read (then the ranks' own check decides)."""
+    n = None
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in sorted(os.listdir(base)):
+            props = open(os.path.join(base, d, "properties")).read()
+            simd = re.search(r"^simd_count\s+(\d+)", props, re.M)
+            if not simd or int(simd.group(1)) == 0:
+                continue                                   # a CPU node
+            minor = re.search(r"^drm_render_minor\s+(\d+)", props, re.M)
+            if minor and int(minor.group(1)) > 0 and not os.access(f"/dev/dri/renderD{minor.group(1)}", os.R_OK | os.W_OK):
+                continue                                   # not handed to this container
+            n += 1
+    except OSError:
+        n = None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            k = len([x for x in v.split(",") if x.strip() != ""])
+            n = k if n is None else min(n, k)
+    return n
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher environment: start N ranks as CHILD processes (one per GPU, RCCL) through
-    torch.distributed.run -- before this process makes any HIP call, and never by exec -- relay their output, and end with rank 0's JSON
-    line.  Exits non-zero unless the line reports N distinct devices."""
-    n_dev = torch.cuda.device_count()            # counts devices without initialising the GPU
-    if n_dev < args.gpus:
+    torch.distributed.run -- this parent never touches the HIP runtime (devices are counted from the KFD topology), and never execs --
+    relay their output, and end with rank 0's JSON line.  Exits non-zero unless the line reports N distinct devices."""
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD"):
+        print("[bench] --gpus N > 1 under rocprofv3: the profiler's preload has already initialised the GPU in this process; profile a "
+              "single rank, or launch the ranks with torch.distributed.run yourself", file=sys.stderr)
+        raise SystemExit(6)
+    n_dev = visible_gpu_count()
+    if n_dev is not None and n_dev < args.gpus:
         print(f"[bench] --gpus {args.gpus} but this node exposes {n_dev} GPU(s)", file=sys.stderr)
         raise SystemExit(2)
     with socket.socket() as sock:
@@ -458,6 +606,8 @@ def self_launch(args):
     env.setdefault("OMP_NUM_THREADS", "8")
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    if any(ln.startswith("BENCH_TOO_FEW_DEVICES") for ln in lines):       # the ranks found fewer devices than the topology promised
+        raise SystemExit(2)
     line = None
     for ln in reversed(lines):
         if ln.lstrip().startswith("{"):
@@ -482,14 +632,25 @@ def self_launch(args):
 def measure(pkg, args, dev, world, min_seconds):
     """Builds the step of `args`, warms it up and times blocks of EXACTLY args.steps steps (barrier + synchronize on both sides,
     MAX over ranks) until `min_seconds` have been measured; returns the state, the block times and how the step was launched."""
-    S = build_step(pkg, args, dev, world)
-    run, used_graph = make_runner(S, args, world, dev)
     dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
-    graph_mode = ("none" if not used_graph else
-                  "two graphs + eager all-reduce" if (args.split_graph or (dist_on and not args.graph_collectives)) and not args.forward_only
-                  else "one graph")
-    for _ in range(args.warmup):
-        run()
+    product = uses_product_loop(args)
+    if product:
+        S = build_product(pkg, args, dev, world)
+        S["run_steps"](max(args.warmup, 2))          # the first step runs eagerly, the hipGraphs are captured right after it
+        used_graph, graph_mode = S["stepper"].graphs is not None, S["stepper"].graph_mode
+        if dist_on and not used_graph and not args.no_graph and not args.allow_eager:
+            print("[bench] hipGraph capture failed on the multi-rank path", file=sys.stderr)
+            raise SystemExit(3)
+        run = None
+    else:
+        S = build_step(pkg, args, dev, world)
+        S["product"] = False
+        run, used_graph = make_runner(S, args, world, dev)
+        graph_mode = ("none" if not used_graph else
+                      "two graphs + eager all-reduce" if (args.split_graph or (dist_on and not args.graph_collectives)) and not args.forward_only
+                      else "one graph")
+        for _ in range(args.warmup):
+            run()
     S["restore"]()
 
     def timed_block():
@@ -498,10 +659,15 @@ def measure(pkg, args, dev, world, min_seconds):
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            run()
-            if args.reset_every > 0 and (i + 1) % args.reset_every == 0 and not args.forward_only:
-                S["restore"]()
+        if product:
+            # train.GraphedStep.run over the next `steps` host batches of the ring: packing (producer thread), one H2D copy per step on
+            # a side stream, graph replay, device-side guard, and the loop's own final synchronize + statistics read -- all timed
+            S["run_steps"](args.steps)
+        else:
+            for i in range(args.steps):
+                run()
+                if args.reset_every > 0 and (i + 1) % args.reset_every == 0 and not args.forward_only:
+                    S["restore"]()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -534,14 +700,63 @@ def workload_text(args):
             + ("no backward" if args.forward_only else "losses, backward, grad all-reduce, Adam"))
 
 
-# The other BASELINE.json configs, measured in the default run next to the headline (each `--workload-seconds` of timed blocks, its
-# own HIP-event roofline): name -> (BASELINE config, bench flags, steps per block)
+# The other BASELINE.json configs, measured in the same run next to the headline (each `--workload-seconds` of timed blocks, its
+# own HIP-event roofline): name -> (BASELINE config, bench flags, steps per block).  One GPU: the four single-GPU shapes.  N GPUs: what
+# SURVEY 8(e) asks of the scaling run -- 16 pairs per GPU (weak), the KITTI batch of 64 pairs sharded over the ranks (strong), the
+# eval sweep as independent replicas.
 EXTRA_WORKLOADS = (
     ("c3_b16", "configs[2] shape: 3DMatch training, batch=16, the reference's edge inputs", ["--workload", "c3"], 20),
     ("c3_b16_irreps", "configs[2]: 3DMatch training, batch=16, fused irrep-basis + message-passing kernel", ["--workload", "c3", "--edge-basis", "irreps"], 20),
     ("c4_shard", "configs[3]: one GPU's shard of the KITTI batch (8 of 64 pairs x 4096 pts, F=33), training", ["--workload", "c4"], 15),
     ("c5_eval", "configs[4]: 3DMatch eval sweep pair, 8192 pts, k=32, 8 layers, evaluation pair model", ["--workload", "c5"], 50),
 )
+EXTRA_WORKLOADS_MULTI = (
+    ("c3_b16", "configs[2] shape: 3DMatch training, 16 pairs per GPU (weak scaling)", ["--workload", "c3"], 20),
+    ("c4_global64", "configs[3]: KITTI pairs, 4096 pts, batch=64 sharded over the ranks (strong scaling)", ["--workload", "c4", "--global-batch", "64"], 10),
+    ("c5_eval", "configs[4]: 3DMatch eval sweep pair per GPU, 8192 pts, k=32, 8 layers, evaluation pair model (independent replicas)", ["--workload", "c5"], 50),
+)
+
+
+def allreduce_isolated_us(S):
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(5):
+        S["dp"].sync(force=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(20):
+        S["dp"].sync(force=True)
+    ev1.record()
+    torch.cuda.synchronize()
+    S["dp"].zero_grad()
+    return round(ev0.elapsed_time(ev1) * 1e3 / 20, 2)
+
+
+def entry_for(pkg, args, dev, world, rank, S, blocks, used_graph, graph_mode, finite):
+    """The measured numbers of one workload as a dict (rank 0 only; other ranks get None)."""
+    if rank != 0:
+        return None
+    el = sorted(blocks)[len(blocks) // 2]
+    roof, extra = roofline(pkg, S, args, dev)
+    n_pairs = args.global_batch if args.global_batch > 0 else world * args.batch
+    cfg = {"workload": workload_text(args), "pairs_per_gpu": args.batch, "global_batch": n_pairs, "points": args.n, "k": args.k,
+           "layers": args.layers, "edge_basis": args.edge_basis, "hipgraph": used_graph, "graph_mode": graph_mode,
+           "parallelism": f"dp{world}", "params_finite": finite}
+    if S.get("product"):
+        cfg.update({"loop": "train.GraphedStep = the body of train.train_one_epoch (static input slots, one hipGraph per slot, "
+                            "device-side non-finite guard; no host round trip per step)",
+                    "distinct_pairs_in_ring": S["ring_pairs"], "inputs": "host memory; packing + one H2D copy per step INSIDE the timed region",
+                    "steps_applied": S["totals"]["applied"], "steps_rejected_nonfinite": S["totals"]["skipped"],
+                    "weights_restored": "between timed blocks (outside the timed region)"})
+    else:
+        cfg.update({"loop": "harness-captured hipGraph over ONE fixed batch resident in HBM" if not args.forward_only else
+                            "harness-captured hipGraph of the inference forward over one fixed pair resident in HBM",
+                    "reset_every": args.reset_every})
+    return {"value": round(n_pairs * args.steps / el, 3), "unit": "pairs/s", "ms_per_step": round(1e3 * el / args.steps, 5),
+            "steps": args.steps, "scaling": "strong" if args.global_batch > 0 else "weak",
+            "timing": {"blocks": len(blocks), "statistic": "median block of `steps` steps (rank-max per block)",
+                       "ms_per_step_min": round(1e3 * min(blocks) / args.steps, 5), "ms_per_step_max": round(1e3 * max(blocks) / args.steps, 5),
+                       "ms_per_step_first_block": round(1e3 * blocks[0] / args.steps, 5), "seconds_measured": round(sum(blocks), 3)},
+            "config": cfg, "roofline": roof, "kernels": extra}
 
 
 def main():
@@ -552,6 +767,11 @@ def main():
     if world != args.gpus and os.environ.get("RANK", "0") == "0":
         print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): measuring {world}", file=sys.stderr)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        if local_rank == 0:          # the parent (self_launch) turns this marker into exit code 2
+            print(f"BENCH_TOO_FEW_DEVICES {torch.cuda.device_count()}", flush=True)
+            print(f"[bench] --gpus {args.gpus} but this node exposes {torch.cuda.device_count()} GPU(s)", file=sys.stderr)
+        raise SystemExit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
@@ -576,7 +796,6 @@ def main():
         work_stream.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(work_stream)
     S, blocks, used_graph, graph_mode, finite = measure(pkg, args, dev, world, args.min_seconds)
-    el = sorted(blocks)[len(blocks) // 2]
 
     # evidence for the N>1 path: which devices the process group really spans, and what the gradient exchange costs alone
     ranks_seen, allreduce_us, grad_hash = None, None, None
@@ -590,16 +809,7 @@ def main():
         else:
             gathered = [me]
         ranks_seen = gathered
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(5):
-            S["dp"].sync(force=True)
-        torch.cuda.synchronize()
-        ev0.record()
-        for _ in range(20):
-            S["dp"].sync(force=True)
-        ev1.record()
-        torch.cuda.synchronize()
-        allreduce_us = round(ev0.elapsed_time(ev1) * 1e3 / 20, 2)
+        allreduce_us = allreduce_isolated_us(S)
         S["restore"]()
     if os.environ.get("BENCH_GRAD_HASH") == "1" and not args.forward_only:
         # test hook (tests/test_gpu_bench_dist.py): the joint gradient bucket of ONE eager forward + backward from the initial weights
@@ -613,25 +823,13 @@ def main():
         S["dp"].zero_grad(); S["restore"]()
 
     out = None
+    entry = entry_for(pkg, args, dev, world, rank, S, blocks, used_graph, graph_mode, finite)
     if rank == 0:
-        roof, extra = roofline(pkg, S, args, dev)
-        n_pairs = args.global_batch if args.global_batch > 0 else world * args.batch
-        out = {
-            "metric": f"registration pairs/sec ({args.n}-pt, k={args.k}, {args.layers} EGNN layers)",
-            "value": round(n_pairs * args.steps / el, 3), "unit": "pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * el / args.steps, 5), "higher_is_better": True,
-            "scaling": "strong" if args.global_batch > 0 else "weak",
-            "timing": {"blocks": len(blocks), "statistic": "median block of `steps` steps (rank-max per block)",
-                       "ms_per_step_min": round(1e3 * min(blocks) / args.steps, 5), "ms_per_step_max": round(1e3 * max(blocks) / args.steps, 5),
-                       "ms_per_step_first_block": round(1e3 * blocks[0] / args.steps, 5), "seconds_measured": round(sum(blocks), 3)},
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload_text(args),
-                       "pairs_per_gpu": args.batch, "global_batch": n_pairs, "points": args.n, "k": args.k, "layers": args.layers,
-                       "edge_basis": args.edge_basis, "hipgraph": used_graph, "graph_mode": graph_mode, "parallelism": f"dp{world}",
-                       "params_finite": finite, "reset_every": args.reset_every},
-            "roofline": roof, "kernels": extra,
-        }
+        out = {"metric": f"registration pairs/sec ({args.n}-pt, k={args.k}, {args.layers} EGNN layers)",
+               "value": entry["value"], "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": entry["ms_per_step"], "higher_is_better": True, "scaling": entry["scaling"], "timing": entry["timing"],
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": entry["config"], "roofline": entry["roofline"],
+               "kernels": entry["kernels"]}
         if args.dev_no_head:
             out["INVALID"] = "--dev-no-head: pose head and losses skipped (developer measurement, not the metric)"
         if grad_hash is not None:
@@ -644,24 +842,56 @@ def main():
                                 "exchange": "one mean all-reduce of the joint flat gradient bucket per step"}
     del S
     torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and not dist_on and not args.explicit_workload and not args.no_workloads:
-        # the default (driver) run: the other BASELINE configs beside the headline, so that their numbers are witnessed too
-        out["workloads"] = {}
-        for name, what, flags, steps in EXTRA_WORKLOADS:
-            wa = parse(flags + ["--steps", str(steps), "--warmup", "3"])
+    default_run = not args.explicit_workload and not args.no_workloads
+    if default_run and not dist_on and not args.no_fixed_pair:
+        # what rounds 1-3 reported as the headline, for continuity: one fixed pair resident in HBM, harness-captured graph
+        fa = copy.copy(args)
+        fa.fixed_pair_replay = True
+        try:
+            Sf, bl, ug, gm, fin = measure(pkg, fa, dev, 1, 0.3)
+            elf = sorted(bl)[len(bl) // 2]
+            out["fixed_pair_replay"] = {"value": round(fa.batch * fa.steps / elf, 3), "unit": "pairs/s", "ms_per_step": round(1e3 * elf / fa.steps, 5),
+                                        "what": "ONE fixed synthetic pair resident in HBM, the step replayed from a hipGraph captured by bench.py, weights "
+                                                "restored every 100 steps inside the timed region (the headline of rounds 1-3; not a product path)",
+                                        "hipgraph": ug, "params_finite": fin}
+            del Sf
+        except Exception as exc:
+            out["fixed_pair_replay"] = {"error": f"{type(exc).__name__}: {exc}"}
+        torch.cuda.empty_cache()
+    if default_run:
+        # the other BASELINE configs beside the headline, so that their numbers are witnessed by the same (driver) run; with N ranks
+        # every rank takes part in every entry (collectives), rank 0 records
+        if rank == 0:
+            out["workloads"] = {}
+        for name, what, flags, steps in (EXTRA_WORKLOADS_MULTI if dist_on else EXTRA_WORKLOADS):
+            wa = parse(flags + ["--steps", str(steps), "--warmup", "3", "--gpus", str(world)])
+            err = None
             try:
-                Sw, bl, ug, gm, fin = measure(pkg, wa, dev, 1, args.workload_seconds)
-                elw = sorted(bl)[len(bl) // 2]
-                roof_w, extra_w = roofline(pkg, Sw, wa, dev)
-                out["workloads"][name] = {
-                    "baseline_config": what, "flags": " ".join(flags), "workload": workload_text(wa),
-                    "value": round(wa.batch * wa.steps / elw, 3), "unit": "pairs/s", "ms_per_step": round(1e3 * elw / wa.steps, 5),
-                    "steps": wa.steps, "blocks": len(bl), "seconds_measured": round(sum(bl), 3), "hipgraph": ug, "params_finite": fin,
-                    "roofline": roof_w, "kernels": extra_w}
+                Sw, bl, ug, gm, fin = measure(pkg, wa, dev, world, args.workload_seconds)
+                ar_us = allreduce_isolated_us(Sw) if (dist_on and not wa.forward_only) else None
+                e = entry_for(pkg, wa, dev, world, rank, Sw, bl, ug, gm, fin)
+                if rank == 0:
+                    e.update({"baseline_config": what, "flags": " ".join(flags)})
+                    if ar_us is not None:
+                        e["allreduce_us_isolated"] = ar_us
+                        e["allreduce_bytes"] = sum(int(b.numel()) * 4 for b in Sw["dp"].buckets())
+                    out["workloads"][name] = e
                 del Sw
             except Exception as exc:                        # one broken workload must not take the headline line down
-                out["workloads"][name] = {"baseline_config": what, "error": f"{type(exc).__name__}: {exc}"}
+                err = f"{type(exc).__name__}: {exc}"
+                if world > 1:                               # ... but with several ranks a lone failure would leave the others in a collective
+                    print(f"[bench] workload {name} failed on rank {rank}: {err}", file=sys.stderr)
+                    raise
+                out["workloads"][name] = {"baseline_config": what, "error": err}
             torch.cuda.empty_cache()
+        if rank == 0:
+            # a compact copy inside `roofline` (the block the driver's record keeps whole): one line per workload
+            keep = lambda e: {"value": e["value"], "ms_per_step": e["ms_per_step"], "kernel": e["roofline"]["kernel"],      # noqa: E731
+                              "frac": e["roofline"]["frac"], "launch_ms": e["roofline"]["launch_ms"], "traffic": e["roofline"]["traffic"],
+                              "in_step_frac": e["roofline"].get("in_step_frac"), "scaling": e["scaling"], "graph_mode": e["config"]["graph_mode"]}
+            out["roofline"]["workloads"] = {k: (keep(e) if "error" not in e else {"error": e["error"]}) for k, e in out["workloads"].items()}
+            if "fixed_pair_replay" in out:
+                out["roofline"]["fixed_pair_replay_ms_per_step"] = out["fixed_pair_replay"].get("ms_per_step")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if dist.is_initialized():

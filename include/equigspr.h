@@ -27,7 +27,7 @@ extern "C" {
 
 #define EQUIGSPR_EINVAL   (-1)  /* bad shape / size / null pointer                         */
 #define EQUIGSPR_ENOTSUP  (-2)  /* configuration outside the compiled kernel set             */
-#define EQUIGSPR_ABI_VERSION 10
+#define EQUIGSPR_ABI_VERSION 11
 
 /* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
  * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
@@ -263,6 +263,20 @@ int equigspr_pose_loss_backward(const float* R, const float* t, const float* gt_
 int equigspr_adam_step(int32_t n_buckets, float* const* params, float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const int64_t* sizes, float* step_dev, float lr, float beta1,
                        float beta2, float eps, int32_t clear_grads, void* stream);
+/* adam_step_guarded: the reference loop's per-step decision -- stop / skip when the loss or any gradient is not finite
+ * (train :1124 set_detect_anomaly; here train.run_training_batches) -- taken ON THE DEVICE inside the optimizer launch, so that a
+ * captured training step (train.GraphedStep; train_one_epoch :964-1140) replays without a host round trip.  Same update as
+ * adam_step with clear_grads = 1 when everything is finite; otherwise parameters, moments and the step count stay as they are
+ * and the gradients (and `extra`) are cleared.  All of gradient buckets, `extra_dev[n_extra]` (e.g. the spare words of a joint
+ * all-reduce bucket through which ranks signal each other) and `loss_dev[0]` (NULL = not examined) enter the verdict.
+ *   hyper_dev [5] device: lr, beta1, beta2, eps, loss weight (read at run time: schedulers act on a captured graph)
+ *   stats_dev [8] device, zero-initialised by the caller: [0] sum of loss * weight over applied steps, [1] applied steps,
+ *             [2] skipped steps, [3] 1 + number of guarded calls before the first skipped one (0 = none), [4] last loss,
+ *             [5] guarded calls, [6] void steps: a non-finite extra_dev[1] (when n_extra > 1) marks a step for which some rank had
+ *             no data -- rejected like any other, but counted here instead of [2] / [3].  Gradient buckets must be 16-byte aligned. */
+int equigspr_adam_step_guarded(int32_t n_buckets, float* const* params, float* const* grads, float* const* exp_avg,
+                               float* const* exp_avg_sq, const int64_t* sizes, float* step_dev, const float* hyper_dev,
+                               const float* loss_dev, float* stats_dev, float* extra_dev, int32_t n_extra, void* stream);
 
 /* ---- A15: SO3TensorProductLayer.forward (src/clean_so3_model.py:34-52) ------------------------
  * y = W2 relu(W1 vec(D x x^T) + b1) + b2, D = input_dim (the bmm of the two broadcast views sums D identical

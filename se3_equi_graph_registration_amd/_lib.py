@@ -60,6 +60,8 @@ _SIGNATURES = {
     "equigspr_pose_loss_backward": (ctypes.c_int, [c_void_p] * 5 + [c_int32] + [c_void_p] * 3),
     "equigspr_adam_step": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                           POINTER(c_int64), c_void_p] + [ctypes.c_float] * 4 + [c_int32, c_void_p]),
+    "equigspr_adam_step_guarded": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                                  POINTER(c_int64), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "equigspr_so3_tensor_product_forward": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 7),
     "equigspr_gcn_build_graph": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 11),
     "equigspr_gcn_adjacency_to_dense": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
@@ -105,7 +107,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if L.equigspr_abi_version() != 10:
+        if L.equigspr_abi_version() != 11:
             raise RuntimeError("libequigspr.so ABI version mismatch")
         _lib = L
     return _lib

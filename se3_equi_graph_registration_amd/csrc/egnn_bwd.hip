@@ -1300,7 +1300,9 @@ static int backward_impl(const equigspr_egnn_config* cfg, const float* params, c
     float* Gx = work + B.Gx[cur];
     // the 16-node MFMA kernels of egnn_node_bwd.hip: hidden_nf 33 always; hidden_nf 32 from EQ_NODE_BWD16_MIN nodes on (one
     // 2 048-point pair: 18.4 us against 15.3 us for the per-feature kernel; 16 pairs: 121 against 142 us)
-    const bool k16 = F == 33 || (EQ_NODE_BWD16 != 0 && N > EQ_NODE_BWD16_MIN);
+    // (only the MFMA widths have them: the lane widths 16 / 48 / 64 stay on the per-feature kernels at every size)
+    constexpr bool kHas16 = (F == 32 || F == 33);
+    const bool k16 = F == 33 || (kHas16 && EQ_NODE_BWD16 != 0 && N > EQ_NODE_BWD16_MIN);
     // embedding_out: its own launch, or (per-feature kernels, hidden_nf == out_nf == 32) inside the last layer's node backward
     const bool eo_fused = EQ_EMBED_FUSE != 0 && !k16 && F == 32 && cfg->out_nf == 32;
     const bool ei_fused = EQ_EMBED_FUSE != 0 && !k16 && F == 32 && cfg->in_nf == 32;       // embedding_in: inside layer 0's gather backward

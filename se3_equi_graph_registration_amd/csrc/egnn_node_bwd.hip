@@ -571,6 +571,7 @@ int launch_node_bwd16(int F, int H, int A, int mode, const NodeBwd16Args& args, 
     if (F == 32 && H == 8 && A == 0) return launch_cfg<8, 0, 0>(mode, args, s, n_slabs);
     if (F == 33 && H == 1 && A == 1) return launch_cfg<1, 1, 1>(mode, args, s, n_slabs);
     if (F == 33 && H == 1 && A == 0) return launch_cfg<1, 0, 1>(mode, args, s, n_slabs);
+    set_error("node_bwd16: no 16-node kernel for hidden_nf=%d, num_heads=%d, in_edge_nf=%d", F, H, A);
     return EQUIGSPR_ENOTSUP;
 }
 

@@ -77,6 +77,89 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamBuckets bk, float* __rest
     }
 }
 
+
+// The guarded step of the graphed training loop (train.GraphedStep): the reference loop's host decision "loss and every gradient
+// finite, else skip / stop" (train :1124 set_detect_anomaly; run_training_batches) evaluated on the device, so that a captured step
+// needs no host round trip.  Every workgroup scans ALL gradient buckets (+ `extra`, + the loss): all reach the same verdict without
+// any inter-workgroup wait.  Verdict finite: the plain Adam update, gradients cleared as consumed.  Verdict non-finite: NOTHING is
+// modified until every workgroup has drawn its ticket (a cleared entry could otherwise change a slower workgroup's verdict); the
+// last one then clears all gradients and `extra`.  The last workgroup also keeps the loop's running totals in `stats`:
+//   [0] sum of loss * hyper[4] over the applied steps   [1] applied steps   [2] skipped steps
+//   [3] 1 + index (count of guarded calls before it) of the FIRST skipped step, 0 = none   [4] the last loss   [5] guarded calls
+//   [6] void steps (extra[1] not finite: some rank had no data; not counted as skipped)
+// hyper (device): lr, beta1, beta2, eps, loss weight -- read at run time, so a scheduler's new lr reaches a captured graph.
+struct AdamGuard {
+    const float* hyper; const float* loss; float* stats; float* extra; int n_extra;
+};
+
+__global__ __launch_bounds__(256) void adam_guarded_kernel(AdamBuckets bk, float* __restrict__ step, AdamGuard gd) {
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    // largest |bit pattern| seen: >= 0x7f800000 <=> an inf or a NaN (one AND + one unsigned MAX per element)
+    unsigned top = 0u;
+    auto see = [&](float v) { const unsigned u = __float_as_uint(v) & 0x7fffffffu; top = u > top ? u : top; };
+    for (int k = 0; k < bk.count; ++k) {
+        const long long n4 = bk.n[k] >> 2;
+        const float4* g4 = reinterpret_cast<const float4*>(bk.g[k]);          // buckets are 16-byte aligned (checked on the host)
+        for (long long i = threadIdx.x; i < n4; i += 256) {
+            const float4 v = g4[i];
+            see(v.x); see(v.y); see(v.z); see(v.w);
+        }
+        for (long long i = (n4 << 2) + threadIdx.x; i < bk.n[k]; i += 256) see(bk.g[k][i]);
+    }
+    for (int i = threadIdx.x; i < gd.n_extra; i += 256) see(gd.extra[i]);
+    const float loss = gd.loss ? gd.loss[0] : 0.0f;
+    see(loss);
+    int bad = top >= 0x7f800000u;
+    if (bad) s_bad = 1;                      // benign race: every writer stores 1
+    __syncthreads();
+    bad = s_bad;
+    const float lr = gd.hyper[0], b1 = gd.hyper[1], b2 = gd.hyper[2], eps = gd.hyper[3];
+    const float tcur = step[0] + 1.0f;
+    if (!bad) {
+        const float bc1 = 1.0f - powf(b1, tcur), bc2s = sqrtf(1.0f - powf(b2, tcur));
+        const long long gid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
+        for (int k = 0; k < bk.count; ++k) {
+            for (long long i = gid; i < bk.n[k]; i += stride) {
+                const float g = bk.g[k][i];
+                const float m = b1 * bk.m[k][i] + (1.0f - b1) * g;
+                const float v = b2 * bk.v[k][i] + (1.0f - b2) * g * g;
+                bk.m[k][i] = m;
+                bk.v[k][i] = v;
+                bk.p[k][i] -= (lr / bc1) * m / (sqrtf(v) / bc2s + eps);
+                bk.g[k][i] = 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        unsigned* done = reinterpret_cast<unsigned*>(step + 1);
+        __threadfence();
+        s_last = atomicAdd(done, 1u) == gridDim.x - 1;
+        if (s_last) {
+            *done = 0u;
+            float* st = gd.stats;
+            // extra[1] non-finite = "a rank had no data for this step" (train.GraphedStep): a void step, not a rejected one
+            bool voided = false;
+            if (gd.n_extra > 1) { const float e1 = gd.extra[1]; voided = (__float_as_uint(e1) & 0x7fffffffu) >= 0x7f800000u; }
+            if (!bad) { step[0] = tcur; st[0] += loss * gd.hyper[4]; st[1] += 1.0f; }
+            else if (voided) st[6] += 1.0f;
+            else { st[2] += 1.0f; if (st[3] == 0.0f) st[3] = st[5] + 1.0f; }
+            st[4] = loss;
+            st[5] += 1.0f;
+        }
+    }
+    __syncthreads();
+    if (bad && s_last) {                     // every workgroup has finished reading: now the rejected gradients can go
+        __threadfence();
+        for (int k = 0; k < bk.count; ++k)
+            for (long long i = threadIdx.x; i < bk.n[k]; i += 256) bk.g[k][i] = 0.0f;
+        for (int i = threadIdx.x; i < gd.n_extra; i += 256) gd.extra[i] = 0.0f;
+    }
+}
+
 }  // namespace eq
 
 extern "C" int equigspr_pose_loss_forward(const float* R, const float* t, const float* gt_pose, int32_t B, float* rot_loss,
@@ -135,6 +218,33 @@ extern "C" int equigspr_adam_step(int32_t n_buckets, float* const* params, float
     if (clear_grads) hipLaunchKernelGGL(adam_kernel<true>, dim3(blocks), dim3(256), 0, s, bk, step_dev, lr, beta1, beta2, eps);
     else hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, s, bk, step_dev, lr, beta1, beta2, eps);
     EQ_CHECK_LAUNCH("adam_step");
+    return 0;
+}
+
+extern "C" int equigspr_adam_step_guarded(int32_t n_buckets, float* const* params, float* const* grads, float* const* exp_avg,
+                                          float* const* exp_avg_sq, const int64_t* sizes /* host arrays */, float* step_dev /* [2] */,
+                                          const float* hyper_dev /* [5] */, const float* loss_dev /* [1] or NULL */,
+                                          float* stats_dev /* [8] */, float* extra_dev, int32_t n_extra, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(n_buckets >= 1 && n_buckets <= 4 && params && grads && exp_avg && exp_avg_sq && sizes && step_dev && hyper_dev && stats_dev,
+                 EQUIGSPR_EINVAL, "adam_step_guarded: 1..4 buckets, non-null arrays, hyper and stats on the device");
+    EQ_CHECK_ARG(n_extra >= 0 && (n_extra == 0 || extra_dev), EQUIGSPR_EINVAL, "adam_step_guarded: extra_dev is NULL with n_extra > 0");
+    AdamBuckets bk;
+    bk.count = n_buckets;
+    long long tot = 0;
+    for (int k = 0; k < n_buckets; ++k) {
+        EQ_CHECK_ARG(((uintptr_t)grads[k] & 15) == 0, EQUIGSPR_EINVAL, "adam_step_guarded: gradient buckets must be 16-byte aligned");
+        bk.p[k] = params[k]; bk.g[k] = grads[k]; bk.m[k] = exp_avg[k]; bk.v[k] = exp_avg_sq[k]; bk.n[k] = sizes[k];
+        tot += sizes[k];
+    }
+    // every workgroup scans all `tot` gradients: bound the redundant reads (blocks * tot <= 16 M floats, i.e. 64 MB from L2)
+    long long blocks = ceil_div(tot, 256 * 4);
+    const long long cap = (16ll << 20) / (tot > 0 ? tot : 1);
+    if (blocks > cap) blocks = cap;
+    blocks = blocks < 16 ? 16 : (blocks > 1024 ? 1024 : blocks);
+    AdamGuard gd{hyper_dev, loss_dev, stats_dev, extra_dev, n_extra};
+    hipLaunchKernelGGL(adam_guarded_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, bk, step_dev, gd);
+    EQ_CHECK_LAUNCH("adam_step_guarded");
     return 0;
 }
 

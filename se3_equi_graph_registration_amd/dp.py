@@ -72,10 +72,12 @@ class DataParallelStep:
         egnn_ids = {id(p) for p in self.egnn.parameters()} if self.egnn is not None else set()
         rest = [p for p in model.parameters() if id(p) not in egnn_ids and p.requires_grad]
         self.joint = self.joint_grad = None
+        self.head_offset = 0
         if self.egnn is not None and hasattr(self.egnn, "rehome") and rest:
             # ONE buffer [EGNN block | pad to 64 floats | head parameters]: a single collective per step
             pe = sum(p.numel() for p in self.egnn.parameters())
-            off = (pe + 63) // 64 * 64
+            off = (pe + 2 + 63) // 64 * 64      # >= 2 spare words travel with the message (train.GraphedStep: per-rank step verdicts)
+            self.head_offset = off
             ph = sum(p.numel() for p in rest)
             dev = rest[0].device
             self.joint = torch.zeros(off + ph, dtype=torch.float32, device=dev)

@@ -75,6 +75,14 @@ _CSR_SCRATCH = {}
 _CSR_GRAPH_OWNED = []      # counter arrays adopted by captured hipGraphs (see _csr_scratch)
 
 
+def reserve_csr_scratch(dev, n_words):
+    """Put one more zeroed counter array of ``n_words`` words into the cache for the next hipGraph capture to adopt (a capture
+    takes a cached array rather than allocating one it would have to clear at every replay): ``train.GraphedStep`` calls
+    this before capturing each further copy of the step."""
+    key = (str(torch.device(dev)), -1 - len(_CSR_GRAPH_OWNED) - len(_CSR_SCRATCH), int(n_words))
+    _CSR_SCRATCH[key] = torch.zeros(int(n_words), dtype=torch.int32, device=dev)
+
+
 def _csr_scratch(dev, n_words):
     """The counter array of ``equigspr_build_csr``: the call leaves it all-zero, so one zero-initialised buffer per
     (device, stream, size) is handed from build to build and the per-call clear (two fill launches) disappears.
@@ -591,6 +599,45 @@ class FlatAdam:
         _lib.check(_lib.lib().equigspr_adam_step(len(self.buckets), self._p, self._g, self._m, self._v, self._n,
                                                  _p(self.step_dev), self.lr, self.betas[0], self.betas[1], self.eps,
                                                  int(bool(zero_grad)), _stream()), "adam_step")
+
+    # ---- the guarded step of the graphed training loop (train.GraphedStep)
+    def _guard_buffers(self):
+        if getattr(self, "hyper_dev", None) is None:
+            dev = self.buckets[0][0].device
+            self.hyper_dev = torch.zeros(8, dtype=torch.float32, device=dev)
+            self.stats_dev = torch.zeros(8, dtype=torch.float32, device=dev)
+            self._hyper_host = None
+
+    def push_hyper(self, loss_weight: float = 1.0):
+        """Device copy of (lr, beta1, beta2, eps, loss weight) for ``step_guarded``; re-sent only when a value changed, so a
+        scheduler's ``param_groups`` edit reaches a captured graph at its next replay (stream-ordered copy)."""
+        self._guard_buffers()
+        vals = (self.lr, self.betas[0], self.betas[1], self.eps, float(loss_weight))
+        if vals != self._hyper_host:
+            self.hyper_dev[:5].copy_(torch.tensor(vals, dtype=torch.float32), non_blocking=False)
+            self._hyper_host = vals
+
+    def step_guarded(self, loss: Optional[torch.Tensor] = None, extra: Optional[torch.Tensor] = None):
+        """``step(zero_grad=True)`` unless the loss, a gradient or a word of ``extra`` is not finite -- then nothing is updated and
+        the gradients are cleared; the verdict is taken inside the launch (``equigspr_adam_step_guarded``) and counted in
+        ``stats_dev``: no host round trip, hipGraph-capturable.  Call ``push_hyper`` first (outside any capture)."""
+        self._guard_buffers()
+        if self._hyper_host is None:
+            raise RuntimeError("FlatAdam.step_guarded: call push_hyper() first")
+        if loss is not None:
+            _need(loss.reshape(1), "loss", torch.float32, 1)
+        n_extra = 0 if extra is None else int(_need(extra, "extra", torch.float32, 1).numel())
+        _lib.check(_lib.lib().equigspr_adam_step_guarded(len(self.buckets), self._p, self._g, self._m, self._v, self._n,
+                                                         _p(self.step_dev), _p(self.hyper_dev), _p(loss), _p(self.stats_dev),
+                                                         _p(extra), n_extra, _stream()), "adam_step_guarded")
+
+    def guard_stats(self):
+        """Host copy (synchronises) of the guarded steps' running totals: ``loss_sum`` (weighted), ``applied``, ``skipped``,
+        ``first_skipped`` (0-based index among the guarded calls, ``None`` if none), ``last_loss``, ``calls``."""
+        self._guard_buffers()
+        v = self.stats_dev.tolist()
+        return {"loss_sum": v[0], "applied": int(v[1]), "skipped": int(v[2]), "first_skipped": int(v[3]) - 1 if v[3] > 0 else None,
+                "last_loss": v[4], "calls": int(v[5]), "void": int(v[6])}
 
     def reset_state(self):
         for t in self.exp_avg + self.exp_avg_sq + [self.step_dev]:

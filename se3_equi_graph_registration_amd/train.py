@@ -16,6 +16,9 @@ so the reference's ``StepLR`` (or any scheduler) drives it unchanged.
 Everything between the loader and ``loss.item()`` runs in the HIP kernels; batches are staged to HBM one step ahead.
 """
 import os
+import queue
+import sys
+import threading
 
 import torch
 import torch.distributed as dist
@@ -157,6 +160,369 @@ def shard_batch(batch, rank: int, world: int):
     return tuple(item[lo:hi] if isinstance(item, torch.Tensor) else item for item in batch), hi - lo, n_global
 
 
+class _Slot:
+    """One set of static step inputs in HBM: a single fp32 packet ``[xyz (2,B,N,3) | feat (2,B,N,F) | labels (B,N) | gt_pose (B,16) |
+    signal (4)]`` (one H2D copy per step) and the views the model reads.  ``signal[0]`` is 0, or NaN when this rank has nothing
+    valid to contribute to the step (data parallel: it then reaches every rank through the gradient bucket)."""
+
+    def __init__(self, B, N, F, device, pinned=False):
+        sizes = [2 * B * N * 3, 2 * B * N * F, B * N, B * 16, 4]
+        self.offsets = [0]
+        for n in sizes:
+            self.offsets.append(self.offsets[-1] + (n + 3) // 4 * 4)          # every segment 16-byte aligned
+        self.packet = (torch.zeros(self.offsets[-1], dtype=torch.float32).pin_memory() if pinned
+                       else torch.zeros(self.offsets[-1], dtype=torch.float32, device=device))
+        seg = lambda i, shape: self.packet[self.offsets[i]:self.offsets[i] + sizes[i]].view(shape)      # noqa: E731
+        self.xyz, self.feat = seg(0, (2, B, N, 3)), seg(1, (2, B, N, F))
+        self.labels, self.gt_pose, self.signal = seg(2, (B, N)), seg(3, (B, 4, 4)), seg(4, (4,))
+        self.h2d_done = self.consumed = None
+
+    def fill(self, batch):
+        """Pack a 7-tuple ``(corr, labels, xyz_0, xyz_1, feat_0, feat_1, gt_pose)`` (``corr`` is not an input of the forward)."""
+        _, labels, xyz_0, xyz_1, feat_0, feat_1, gt_pose = batch
+        self.xyz[0].copy_(xyz_0); self.xyz[1].copy_(xyz_1)
+        self.feat[0].copy_(feat_0); self.feat[1].copy_(feat_1)
+        self.labels.copy_(labels.reshape(self.labels.shape)); self.gt_pose.copy_(gt_pose)
+        self.signal.zero_()
+
+
+class GraphedStep:
+    """The training step of ``train_one_epoch`` (train :964-1140) -- kNN graphs, inverse index, EGNN forward, pose head, losses,
+    backward, [gradient all-reduce], Adam -- captured ONCE into a hipGraph per input slot and replayed per batch.
+
+    * Static inputs: ``slots`` packets in HBM (``_Slot``).  A producer thread packs each host batch into a pinned packet; ONE
+      H2D copy per step runs on a side stream while the previous step's graph is still executing (the slot it overwrites was
+      released by an event two steps earlier).
+    * No host round trip per step: the reference loop's "stop / skip on a non-finite loss or gradient" is taken on the device
+      inside the optimizer launch (``FlatAdam.step_guarded``); the running loss, the number of applied / skipped steps and the
+      first skipped step live in ``optimizer.adam.stats_dev`` and are read when the epoch ends (and, without blocking, at the log
+      interval).  A step that would have been rejected leaves weights, moments and step count untouched, so raising late loses nothing.
+    * The first batch of a new shape runs eagerly (a REAL step through the same kernels -- it also creates the cached index
+      arrays the capture adopts); the graphs are captured before the second one.  Batches of another shape (a short last batch)
+      run eagerly, batches with a ``None`` member are skipped (train :969).
+    * Data parallel (one process per GPU): every rank runs its ``dp.shard_range`` share; the loss is weighted so that the mean
+      all-reduce yields the gradient of the global mean; the all-reduce is captured INSIDE the step graph when RCCL allows it,
+      otherwise the step is two graphs around an eager all-reduce; a rank's non-finite loss / missing batch reaches every rank
+      through a spare word of the joint gradient bucket, so all ranks take the same decision without a second collective.
+    * Everything is enqueued on this object's own stream (eager launches on the NULL stream between hipGraph replays fault on
+      this ROCm stack); ``run`` makes the caller's stream wait for it before returning.
+    Weights after n steps are bit-identical to the eager loop's (``tests/test_gpu_train.py``)."""
+
+    def __init__(self, model, optimizer, k=16, loss_mode="3dmatch", slots=2, graph_collectives=True, use_graphs=True, depth=3,
+                 force_dist=False):
+        if not isinstance(optimizer, StepOptimizer):
+            raise TypeError("GraphedStep needs the package's StepOptimizer (train.make_optimizer): the guarded flat Adam is part of the step")
+        if loss_mode not in ("3dmatch", "kitti"):
+            raise ValueError("loss_mode: '3dmatch' or 'kitti'")
+        self.model, self.opt, self.k, self.loss_mode = model, optimizer, int(k), loss_mode
+        self.n_slots, self.depth = max(1, int(slots)), max(int(depth), 2)
+        self.graph_collectives, self.use_graphs = graph_collectives, use_graphs
+        self.device = optimizer.dp.joint_grad.device if optimizer.dp.joint_grad is not None else next(model.parameters()).device
+        if self.device.type != "cuda":
+            raise RuntimeError("GraphedStep: the model must live on the MI355X (HIP) device; this package has no CPU path")
+        self.stream = torch.cuda.Stream(self.device)
+        self.copy_stream = torch.cuda.Stream(self.device)
+        self.rank, self.world, self.group = _process_group(optimizer)
+        # force_dist: run the multi-rank code path (spare-word signalling, all-reduce inside / between the graphs) on a one-rank
+        # group -- how the tests exercise it on a single GPU
+        self.dist_on = self.world > 1 or (bool(force_dist) and dist.is_available() and dist.is_initialized())
+        self.shape = None                  # (B_local, N, F) of the captured step
+        self._capture_tried = False
+        self._last_idx = 0
+        self.slots, self.graphs, self.graph_mode = [], None, "eager"
+        self.steps_replayed = self.steps_eager = 0
+        self._seed = self._pad = None
+        self._call_batch = []              # guarded call -> batch index of the current epoch (for the error message)
+        self.last_stats = None             # FlatAdam.guard_stats() of the last run()
+
+    # ------------------------------------------------------------------ the step itself (eager or under capture)
+    def _spare_words(self):
+        """The unused words between the EGNN block and the head parameters of the joint gradient bucket (dp.DataParallelStep):
+        part of the all-reduced message, not an optimizer bucket."""
+        dp = self.opt.dp
+        if dp.joint_grad is None:
+            return None
+        pe = int(self.model.egnn.flat_grads.numel())
+        pad = dp.joint_grad[pe:dp.head_offset]
+        if pad.numel() < 2:
+            raise RuntimeError("GraphedStep: the joint gradient bucket has no spare words (dp.DataParallelStep leaves at least two)")
+        return pad
+
+    def _forward_backward(self, slot, seed):
+        batch = (None, slot.labels, slot.xyz[0], slot.xyz[1], slot.feat[0], slot.feat[1], slot.gt_pose)
+        loss = _forward(self.model, batch, self.k, False, self.loss_mode)[1]
+        loss.backward(gradient=seed)
+        if self.dist_on:
+            # two spare words of the all-reduced message carry this rank's verdict to every rank's guard: [0] = loss * 0 (NaN for
+            # a non-finite local loss), [1] = the slot's signal (NaN: this rank had no batch for the step)
+            torch.mul(loss.detach(), 0.0, out=self._pad[0])
+            self._pad[1].copy_(slot.signal[0])
+        return loss.detach()
+
+    def _apply(self, loss):
+        self.opt.adam.step_guarded(loss=loss, extra=self._pad[:2] if self.dist_on else None)
+
+    def _body(self, slot):
+        loss = self._forward_backward(slot, self._seed)
+        if self.dist_on:
+            self.opt.dp.sync(force=True)
+        self._apply(loss)
+        return loss
+
+    # ------------------------------------------------------------------ capture
+    def _prepare(self, B, N, F, n_global):
+        self.shape = (B, N, F)
+        self.slots = [_Slot(B, N, F, self.device) for _ in range(self.n_slots)]
+        for sl in self.slots:
+            sl.consumed = torch.cuda.Event()
+            sl.consumed.record(self.stream)
+        w = B * self.world / n_global if self.world > 1 else 1.0
+        self._seed = torch.full((), float(w), dtype=torch.float32, device=self.device)
+        self._loss_weight = B / n_global if self.world > 1 else 1.0
+        self._pad = self._spare_words() if self.dist_on else None
+        self.graphs, self.graph_mode, self._capture_tried, self._last_idx = None, "eager", False, 0
+
+    def _capture(self):
+        """Capture one copy of the step per slot (they share one memory pool: replays are sequential on one stream)."""
+        if not self.use_graphs:
+            return
+        n_words = 2 * self.shape[0] * self.shape[1] + 1
+        modes = ["one graph"] if not self.dist_on else \
+            (["one graph (all-reduce captured)"] if self.graph_collectives else []) + ["two graphs + eager all-reduce"]
+        for mode in modes:
+            graphs, pool, ok = [], None, True
+            try:
+                for sl in self.slots:
+                    ops.reserve_csr_scratch(self.device, n_words)
+                    torch.cuda.synchronize(self.device)
+                    if mode.startswith("one"):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                            self._body(sl)
+                        graphs.append((g,))
+                    else:
+                        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
+                            loss = self._forward_backward(sl, self._seed)
+                        with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
+                            self._apply(loss)
+                        graphs.append((ga, gb))
+                    pool = graphs[-1][0].pool()
+            except Exception as exc:                   # capture unsupported for this mode: try the next one
+                ok = False
+                print(f"[GraphedStep] hipGraph capture failed in mode '{mode}' ({type(exc).__name__}: {exc})", file=sys.stderr)
+                torch.cuda.synchronize(self.device)
+            if self.dist_on:                            # all ranks replay the same way or none does
+                ok = _all_ranks_have(ok, self.group, self.device)
+            if ok:
+                self.graphs, self.graph_mode = graphs, mode
+                return
+        self.graphs, self.graph_mode = None, "eager"
+
+    # ------------------------------------------------------------------ one step
+    def _launch(self, idx):
+        sl = self.slots[idx]
+        if self.graphs is None:
+            self._body(sl)
+            self.steps_eager += 1
+        else:
+            g = self.graphs[idx]
+            g[0].replay()
+            if len(g) == 2:
+                self.opt.dp.sync(force=True)
+                g[1].replay()
+            self.steps_replayed += 1
+        sl.consumed.record(self.stream)
+
+    def _usable_shape(self, batch):
+        _, labels, xyz_0, xyz_1, feat_0, feat_1, gt_pose = batch
+        return (xyz_0.dim() == 3 and xyz_0.shape == xyz_1.shape and feat_0.shape == feat_1.shape and feat_0.shape[:2] == xyz_0.shape[:2]
+                and labels.numel() == xyz_0.shape[0] * xyz_0.shape[1] and tuple(gt_pose.shape) == (xyz_0.shape[0], 4, 4))
+
+    def run(self, batches, epoch=0, log_interval=10, skip_nonfinite=False, shard_batches=True):
+        """The body of ``train_one_epoch`` over an iterable of step batches (host or device 7-tuples, ``None`` allowed).
+        Returns the average loss over the applied steps (the global mean under data parallel)."""
+        dev = self.device
+        caller = torch.cuda.current_stream(dev)
+        self.stream.wait_stream(caller)
+        adam = self.opt.adam
+        adam._guard_buffers()
+        with torch.cuda.stream(self.stream):
+            adam.stats_dev.zero_()
+        self._call_batch = []
+        pinned_free, pinned_shapes = queue.Queue(), set()
+        q = queue.Queue(maxsize=self.depth)
+        stop, abandoned = object(), threading.Event()
+
+        def put(item):
+            while not abandoned.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def take_pinned(shape):
+            """A free pinned packet of this shape (the H2D copy that last read it has completed)."""
+            if shape not in pinned_shapes:
+                pinned_shapes.add(shape)
+                for _ in range(self.depth + 2):
+                    pinned_free.put((_Slot(*shape, dev, pinned=True), None))
+            while not abandoned.is_set():
+                try:
+                    pk, ev = pinned_free.get(timeout=0.1)
+                except queue.Empty:
+                    continue
+                if tuple(pk.xyz.shape[1:3]) + (pk.feat.shape[3],) != shape:
+                    continue                                   # a packet of an earlier shape: dropped
+                if ev is not None:
+                    ev.synchronize()
+                return pk
+            return None
+
+        def produce():
+            try:
+                for batch_idx, batch in enumerate(batches):
+                    if batch is None or any(item is None for item in batch[1:]):
+                        if not put((batch_idx, None, None)):
+                            return
+                        continue
+                    batch = tuple(batch)
+                    if self.world > 1 and shard_batches:
+                        batch, _, n_global = shard_batch(batch, self.rank, self.world)
+                    else:                                      # the loader yields per-rank batches: equal shares assumed
+                        n_global = int(batch[2].shape[0]) * self.world
+                    shape = (int(batch[2].shape[0]), int(batch[2].shape[1]), int(batch[4].shape[-1]))
+                    if (not batch[2].is_cuda) and shape[0] > 0 and self._usable_shape(batch) and (self.shape is None or shape == self.shape):
+                        pk = take_pinned(shape)
+                        if pk is None:
+                            return
+                        pk.fill(batch)                         # host memcpy into pinned memory, off the launching thread
+                        item = (batch_idx, pk, n_global)
+                    else:
+                        item = (batch_idx, batch, n_global)
+                    if not put(item):
+                        return
+            except BaseException as e:      # surfaced in the consumer
+                put(e)
+            put(stop)
+
+        th = threading.Thread(target=produce, daemon=True)
+        th.start()
+        pending_log = []
+        nan_host = torch.full((1,), float("nan"))
+        try:
+            with torch.cuda.stream(self.stream):
+                while True:
+                    item = q.get()
+                    if isinstance(item, BaseException):
+                        raise item
+                    if item is stop:
+                        break
+                    batch_idx, payload, n_global = item
+                    have = payload is not None
+                    if self.dist_on and self.shape is None:
+                        # before the first step nothing is captured yet: the ranks agree by a collective whether the batch is usable
+                        have = _all_ranks_have(have, self.group, dev)
+                        if not have and isinstance(payload, _Slot):
+                            pinned_free.put((payload, None))
+                    if not have:
+                        if self.dist_on and self.shape is not None:
+                            # this rank has no batch, its peers may: run the step on the data of the previous one with the "void"
+                            # signal raised -- every rank's guard then rejects the step (ONE collective per step, no host sync)
+                            sl = self.slots[self._last_idx]
+                            sl.signal[:1].copy_(nan_host, non_blocking=False)
+                            self._launch(self._last_idx)
+                            sl.signal.zero_()
+                            self._call_batch.append(batch_idx)
+                        continue
+                    self.opt._push_hyperparameters()
+                    if isinstance(payload, _Slot):
+                        shape = tuple(payload.xyz.shape[1:3]) + (payload.feat.shape[3],)
+                        if self.shape is not None and self.shape != shape:
+                            # packed before the first step fixed the shape: take it as a batch of another shape (one object, one
+                            # static shape -- the first it sees; the decision must not depend on thread timing)
+                            self._eager_other_shape((None, payload.labels, payload.xyz[0], payload.xyz[1], payload.feat[0], payload.feat[1],
+                                                     payload.gt_pose), n_global)
+                            torch.cuda.current_stream(dev).synchronize()
+                            pinned_free.put((payload, None))
+                        else:
+                            if self.shape is None:
+                                self._prepare(*shape, n_global)
+                            adam.push_hyper(self._loss_weight)
+                            idx = (self._last_idx + 1) % self.n_slots
+                            sl = self.slots[idx]
+                            with torch.cuda.stream(self.copy_stream):
+                                self.copy_stream.wait_event(sl.consumed)
+                                sl.packet.copy_(payload.packet, non_blocking=True)
+                                ev = torch.cuda.Event()
+                                ev.record(self.copy_stream)
+                            pinned_free.put((payload, ev))
+                            self.stream.wait_event(ev)
+                            self._launch(idx)
+                            self._last_idx = idx
+                            if self.graphs is None and self.use_graphs and not self._capture_tried:
+                                self._capture_tried = True
+                                self._capture()             # the eager step above created the cached index arrays the capture adopts
+                    else:
+                        self._eager_other_shape(payload, n_global)
+                    self._call_batch.append(batch_idx)
+                    if log_interval and batch_idx % log_interval == 0 and self.rank == 0:
+                        host = torch.empty(8, dtype=torch.float32).pin_memory()
+                        host.copy_(adam.stats_dev, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(self.stream)
+                        pending_log.append((batch_idx, host, ev))
+                    while pending_log and pending_log[0][2].query():
+                        self._report(pending_log.pop(0), epoch, skip_nonfinite)
+        finally:
+            abandoned.set()
+            th.join()
+            caller.wait_stream(self.stream)
+        self.stream.synchronize()
+        for entry in pending_log:
+            self._report(entry, epoch, skip_nonfinite)
+        st = self.last_stats = adam.guard_stats()
+        self._check(st, epoch, skip_nonfinite)
+        loss_sum, applied = st["loss_sum"], st["applied"]
+        if self.world > 1:
+            acc = torch.tensor([loss_sum], dtype=torch.float64, device=dev if dist.get_backend(self.group) == "nccl" else "cpu")
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
+            loss_sum = float(acc[0])
+        return loss_sum / max(applied, 1)
+
+    def _eager_other_shape(self, batch, n_global):
+        """A batch the captured step cannot take (device tensors, another shape): the same step, launched eagerly on a
+        throw-away slot."""
+        B, N, F = int(batch[2].shape[0]), int(batch[2].shape[1]), int(batch[4].shape[-1])
+        sl = _Slot(B, N, F, self.device)
+        sl.fill(batch)
+        w = B * self.world / n_global if self.world > 1 else 1.0
+        seed = torch.full((), float(w), dtype=torch.float32, device=self.device)
+        self.opt.adam.push_hyper(B / n_global if self.world > 1 else 1.0)
+        if self.dist_on and self._pad is None:
+            self._pad = self._spare_words()
+        loss = self._forward_backward(sl, seed)
+        if self.dist_on:
+            self.opt.dp.sync(force=True)
+        self._apply(loss)
+        self.steps_eager += 1
+
+    def _check(self, st, epoch, skip_nonfinite):
+        if st["skipped"] > 0 and not skip_nonfinite:
+            k = st["first_skipped"]
+            where = self._call_batch[k] + 1 if k is not None and k < len(self._call_batch) else "?"
+            raise RuntimeError(f"non-finite loss or gradient at epoch {epoch + 1}, batch {where} (the reference stops here under "
+                               "set_detect_anomaly; the step was not applied; pass skip_nonfinite=True to drop such steps)")
+
+    def _report(self, entry, epoch, skip_nonfinite):
+        batch_idx, host, _ = entry
+        v = host.tolist()
+        self._check({"skipped": int(v[2]), "first_skipped": int(v[3]) - 1 if v[3] > 0 else None}, epoch, skip_nonfinite)
+        print(f"Epoch [{epoch + 1}], Batch [{batch_idx + 1}], Loss: {v[4]:.6f}")
+
+
 def run_training_batches(model, batches, optimizer, step_loss, device, epoch=0, log_interval=10, skip_nonfinite=False,
                          shard_batches=True):
     """The body of ``train_one_epoch`` over an iterable of step batches; ``step_loss(model, batch) -> scalar loss``.
@@ -198,14 +564,30 @@ def run_training_batches(model, batches, optimizer, step_loss, device, epoch=0, 
             continue
         value = loss.item()
         optimizer.step()
-        total, n = total + value, n + 1
+        # the local loss is a mean over this rank's pairs: weighted by its share, the sum over ranks (taken once, below) is the
+        # mean over the whole step batch
+        total, n = total + value * (n_local / n_global if (world > 1 and shard_batches) else 1.0), n + 1
         if log_interval and batch_idx % log_interval == 0 and rank == 0:
             print(f"Epoch [{epoch + 1}], Batch [{batch_idx + 1}], Loss: {value:.6f}")
+    if world > 1 and shard_batches:          # every rank returns the same epoch average (schedulers / early stopping stay in step)
+        acc = torch.tensor([total], dtype=torch.float64, device=device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+        total = float(acc[0])
     return total / max(n, 1)
 
 
+def graphed_step_for(model, optimizer, k=16, loss_mode="3dmatch", **kw) -> "GraphedStep":
+    """The ``GraphedStep`` of ``(model, optimizer, k, loss_mode)``, created on first use and kept on the optimizer (its captured
+    graphs hold pointers into the optimizer's buckets)."""
+    cache = optimizer.__dict__.setdefault("_graphed_steps", {})
+    key = (id(model), int(k), loss_mode)
+    if key not in cache:
+        cache[key] = GraphedStep(model, optimizer, k=k, loss_mode=loss_mode, **kw)
+    return cache[key]
+
+
 def train_one_epoch(model, dataloader, optimizer, device, epoch, writer=None, use_pointnet=False, log_interval=10, beta=1, k=16,
-                    skip_nonfinite=False, loss_mode="3dmatch", shard_batches=True):
+                    skip_nonfinite=False, loss_mode="3dmatch", shard_batches=True, graph="auto"):
     """One pass over ``dataloader`` (7-tuples of the dataset classes); returns the average loss.
 
     The reference's arccos pose loss is NaN / has a non-finite gradient at a perfect fit and for pairs without inliers.  The
@@ -215,8 +597,22 @@ def train_one_epoch(model, dataloader, optimizer, device, epoch, writer=None, us
     together.  Under ``torch.distributed`` (one process per GPU) every rank iterates the same loader and runs its
     ``dp.shard_range`` share of each step batch (``shard_batches=False``: the loader already yields per-rank batches).
     ``loss_mode``: ``"3dmatch"`` = ``corr + rot + trans`` (train :1120); ``"kitti"`` = ``corr + equi``
-    (``src/kitti_train_egnn_with_batch.py:1089``)."""
+    (``src/kitti_train_egnn_with_batch.py:1089``).
+    ``graph``: ``"auto"`` (default) runs the loop through ``GraphedStep`` whenever the optimizer is this package's ``StepOptimizer``
+    and ``use_pointnet`` is off -- same kernels, same weights bit for bit, no host round trip per step, and a non-finite step is
+    reported when the epoch ends (or at the next log line) instead of at once; ``False`` (or ``EQUIGSPR_EAGER_TRAINING=1``) keeps
+    the eager loop below; a ``GraphedStep`` instance is used as given."""
     model.train()
+    if graph == "auto":
+        graph = isinstance(optimizer, StepOptimizer) and not use_pointnet and os.environ.get("EQUIGSPR_EAGER_TRAINING") != "1"
+    if graph:
+        # the product loop: static input slots, the step captured once in a hipGraph and replayed per batch, the non-finite decision
+        # on the device (GraphedStep); the loader's host batches are packed and copied one step ahead
+        stepper = graph if isinstance(graph, GraphedStep) else graphed_step_for(model, optimizer, k=k, loss_mode=loss_mode)
+        loader = dataloader.loader if isinstance(dataloader, DeviceBatches) else dataloader
+        avg = stepper.run(loader, epoch=epoch, log_interval=log_interval, skip_nonfinite=skip_nonfinite, shard_batches=shard_batches)
+        print(f"Epoch [{epoch + 1}], Average Loss: {avg:.6f}")
+        return avg
 
     def step_loss(m, batch):
         return _forward(m, batch, k, use_pointnet, loss_mode)[1]

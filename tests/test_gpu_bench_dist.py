@@ -41,8 +41,12 @@ def plain():
     return line
 
 
-@pytest.mark.parametrize("flags,mode", [([], "two graphs + eager all-reduce"), (["--graph-collectives"], "one graph")])
+@pytest.mark.parametrize("flags,mode", [([], "one graph (all-reduce captured)"), (["--split-graph"], "two graphs + eager all-reduce"),
+                                        (["--fixed-pair-replay"], "two graphs + eager all-reduce"),
+                                        (["--fixed-pair-replay", "--graph-collectives"], "one graph")])
 def test_forced_dist_step_on_rccl_matches_the_plain_step(plain, flags, mode):
+    """The package's loop (train.GraphedStep: all-reduce captured inside the step graph by default, --split-graph = two graphs around
+    an eager all-reduce) and the harness-captured replay of rounds 1-3 (--fixed-pair-replay), each on a 1-rank RCCL group."""
     line, _ = _bench(flags, {"BENCH_FORCE_DIST": "1", "BENCH_GRAD_HASH": "1", "MASTER_PORT": "29611"})
     mg = line["multi_gpu"]
     assert mg["backend"] == "nccl" and mg["world_size"] == 1 and mg["distinct_devices"] == 1 and len(mg["ranks_seen"]) == 1
@@ -71,3 +75,23 @@ def test_global_batch_is_sharded_with_shard_range():
     line, _ = _bench(["--global-batch", "3"])
     assert line["scaling"] == "strong" and line["config"]["pairs_per_gpu"] == 3 and line["config"]["global_batch"] == 3
     assert abs(line["value"] - 3 * 1e3 / line["ms_per_step"]) < 1e-2 * line["value"]
+
+
+def test_multi_rank_default_line_carries_the_scaling_workloads():
+    """What the driver's `bench.py --gpus N` run must bring back, checked on the forced-dist path with one
+    rank: 16 pairs per GPU (weak), the KITTI batch of 64 sharded over the ranks (strong), the eval sweep pair -- each with its
+    roofline, the training ones with the isolated all-reduce time -- and the compact copy inside `roofline`."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BENCH_FORCE_DIST="1", MASTER_PORT="29617")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--min-seconds", "0.2", "--workload-seconds", "0.1",
+                        "--steps", "50", "--warmup", "5"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert p.returncode == 0, p.stderr[-4000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert line["config"]["graph_mode"] == "one graph (all-reduce captured)" and line["multi_gpu"]["allreduce_us_isolated"] > 0
+    w = line["workloads"]
+    assert set(w) == {"c3_b16", "c4_global64", "c5_eval"}, w.keys()
+    assert w["c3_b16"]["scaling"] == "weak" and w["c3_b16"]["config"]["pairs_per_gpu"] == 16 and w["c3_b16"]["allreduce_us_isolated"] > 0
+    assert w["c4_global64"]["scaling"] == "strong" and w["c4_global64"]["config"]["global_batch"] == 64 and w["c4_global64"]["allreduce_us_isolated"] > 0
+    assert w["c5_eval"]["config"]["points"] == 8192 and w["c5_eval"]["value"] > 0
+    for name, e in w.items():
+        assert e["roofline"]["frac"] > 0 and e["config"]["hipgraph"] is True, name
+        assert line["roofline"]["workloads"][name]["frac"] == e["roofline"]["frac"]

@@ -1,0 +1,169 @@
+"""train.GraphedStep -- the product's training loop (train_one_epoch, train :964-1140) as captured hipGraphs over static input
+slots: the weights it produces must equal the eager loop's BIT FOR BIT, with distinct batches per step, a non-finite step in the
+middle (rejected on the device), a short last batch, a learning-rate change between epochs, and on the multi-rank code path
+(1-rank RCCL group, all-reduce inside the graph and between two graphs, a step one rank has no data for)."""
+import copy
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pk():
+    import se3_equi_graph_registration_amd as pkg
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    pkg.lib()
+    return pkg
+
+
+def _model(pk, feat=32, layers=2, n=256, seed=0):
+    torch.manual_seed(seed)
+    egnn = pk.EGNN(feat, feat, feat, in_edge_nf=1, device="cuda", n_layers=layers)
+    return pk.CrossAttentionPoseRegression(egnn, num_nodes=n, hidden_nf=feat, device="cuda", topk=64).cuda()
+
+
+def _batches(pk, count, B=2, n=256, feat=32, first=100):
+    out = []
+    for i in range(count):
+        b = pk.synthetic_batch(first + i * B, B, n=n, feat=feat)
+        out.append((b["corr"], b["labels"], b["src"].clone(), b["tgt"].clone(), b["feat_src"].clone(), b["feat_tgt"].clone(), b["gt_pose"]))
+    return out
+
+
+def _state(model, opt):
+    return (model.egnn.flat_params.clone(), opt.dp.head.flat.clone(), [m.clone() for m in opt.adam.exp_avg], [v.clone() for v in opt.adam.exp_avg_sq],
+            float(opt.adam.step_dev[0]))
+
+
+def _assert_same(a, b):
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "weights differ between the graphed and the eager loop"
+    for x, y in zip(a[2] + a[3], b[2] + b[3]):
+        assert torch.equal(x, y), "Adam moments differ"
+    assert a[4] == b[4]
+
+
+def test_graphed_loop_equals_eager_loop_bit_for_bit(pk):
+    from se3_equi_graph_registration_amd import train
+    batches = _batches(pk, 7)
+    m_e, m_g = _model(pk), _model(pk)
+    o_e, o_g = train.make_optimizer(m_e, lr=1e-3), train.make_optimizer(m_g, lr=1e-3)
+    assert torch.equal(m_e.egnn.flat_params, m_g.egnn.flat_params)
+    le = train.train_one_epoch(m_e, batches, o_e, "cuda", 0, log_interval=0, k=8, graph=False)
+    lg = train.train_one_epoch(m_g, batches, o_g, "cuda", 0, log_interval=3, k=8)             # graph="auto"
+    st = train.graphed_step_for(m_g, o_g, k=8)
+    assert st.graph_mode == "one graph" and st.steps_eager == 1 and st.steps_replayed == 6
+    _assert_same(_state(m_e, o_e), _state(m_g, o_g))
+    assert lg == pytest.approx(le, rel=1e-6) and o_g.adam.guard_stats()["applied"] == 7
+    # a second epoch replays from its first batch on; a scheduler's new lr reaches the captured graphs
+    for o in (o_e, o_g):
+        for g in o.param_groups:
+            g["lr"] = 2.5e-4
+    train.train_one_epoch(m_e, batches[:4], o_e, "cuda", 1, log_interval=0, k=8, graph=False)
+    train.train_one_epoch(m_g, batches[:4], o_g, "cuda", 1, log_interval=0, k=8)
+    assert st.steps_eager == 1 and st.steps_replayed == 10
+    _assert_same(_state(m_e, o_e), _state(m_g, o_g))
+
+
+def test_nonfinite_step_is_rejected_on_the_device_and_short_last_batch_runs_eagerly(pk):
+    from se3_equi_graph_registration_amd import train
+    batches = _batches(pk, 6)
+    bad = list(batches[3]); bad[6] = bad[6].clone(); bad[6][0, :3, :3] = float("nan")
+    short = tuple(t[:1] for t in _batches(pk, 1, first=900)[0])                                # one pair instead of two
+    seq = batches[:3] + [tuple(bad), None] + batches[4:] + [short]
+    m_e, m_g = _model(pk, seed=3), _model(pk, seed=3)
+    o_e, o_g = train.make_optimizer(m_e, lr=1e-3), train.make_optimizer(m_g, lr=1e-3)
+    le = train.train_one_epoch(m_e, seq, o_e, "cuda", 0, log_interval=0, k=8, skip_nonfinite=True, graph=False)
+    lg = train.train_one_epoch(m_g, seq, o_g, "cuda", 0, log_interval=0, k=8, skip_nonfinite=True)
+    st = o_g.adam.guard_stats()
+    assert st["skipped"] == 1 and st["first_skipped"] == 3 and st["applied"] == 6 and st["calls"] == 7
+    _assert_same(_state(m_e, o_e), _state(m_g, o_g))
+    assert lg == pytest.approx(le, rel=1e-6)
+    assert float(o_g.dp.joint_grad.abs().max()) == 0.0                                      # the rejected gradients were cleared
+    gs = train.graphed_step_for(m_g, o_g, k=8)
+    assert gs.steps_eager == 2 and gs.steps_replayed == 5                                    # first batch + the short one
+    # without skip_nonfinite the epoch raises (late), and the rejected step has not touched the weights
+    before = _state(m_g, o_g)
+    with pytest.raises(RuntimeError, match="non-finite loss or gradient at epoch 2, batch 1"):
+        train.train_one_epoch(m_g, [tuple(bad)], o_g, "cuda", 1, log_interval=0, k=8)
+    _assert_same(before, _state(m_g, o_g))
+
+
+def test_device_batches_and_explicit_stepper(pk):
+    """Device-resident 7-tuples (what DeviceBatches yields) and an explicitly constructed GraphedStep with one slot."""
+    from se3_equi_graph_registration_amd import train
+    host = _batches(pk, 4)
+    dev = [tuple(t.cuda() for t in b) for b in host]
+    m_e, m_g = _model(pk, seed=5), _model(pk, seed=5)
+    o_e, o_g = train.make_optimizer(m_e, lr=1e-3), train.make_optimizer(m_g, lr=1e-3)
+    train.train_one_epoch(m_e, host, o_e, "cuda", 0, log_interval=0, k=8, graph=False)
+    stepper = train.GraphedStep(m_g, o_g, k=8, slots=1)
+    train.train_one_epoch(m_g, dev[:2], o_g, "cuda", 0, log_interval=0, k=8, graph=stepper)     # device tensors: eager steps
+    train.train_one_epoch(m_g, host[2:], o_g, "cuda", 0, log_interval=0, k=8, graph=stepper)    # host tensors: one eager, then replays
+    assert stepper.steps_eager == 3 and stepper.steps_replayed == 1
+    _assert_same(_state(m_e, o_e), _state(m_g, o_g))
+
+
+CHILD = r"""
+import json, os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import se3_equi_graph_registration_amd as pk
+from se3_equi_graph_registration_amd import train
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%(port)r, RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", device_id=torch.device("cuda", 0))
+
+def model(seed):
+    torch.manual_seed(seed)
+    egnn = pk.EGNN(32, 32, 32, in_edge_nf=1, device="cuda", n_layers=2)
+    return pk.CrossAttentionPoseRegression(egnn, num_nodes=256, hidden_nf=32, device="cuda", topk=64).cuda()
+
+def batches(count):
+    out = []
+    for i in range(count):
+        b = pk.synthetic_batch(100 + 2 * i, 2, n=256, feat=32)
+        out.append((b["corr"], b["labels"], b["src"].clone(), b["tgt"].clone(), b["feat_src"].clone(), b["feat_tgt"].clone(), b["gt_pose"]))
+    return out
+
+seq = batches(6)
+seq_void = seq[:3] + [None] + seq[3:]
+res = {}
+m0 = model(1); o0 = train.make_optimizer(m0, lr=1e-3)
+train.train_one_epoch(m0, seq, o0, "cuda", 0, log_interval=0, k=8, graph=False)
+ref = torch.cat([m0.egnn.flat_params, o0.dp.head.flat])
+for name, coll in (("captured", True), ("split", False)):
+    m = model(1); o = train.make_optimizer(m, lr=1e-3)
+    st = train.GraphedStep(m, o, k=8, graph_collectives=coll, force_dist=True)
+    train.train_one_epoch(m, seq_void, o, "cuda", 0, log_interval=0, k=8, graph=st)
+    got = torch.cat([m.egnn.flat_params, o.dp.head.flat])
+    res[name] = {"mode": st.graph_mode, "equal": bool(torch.equal(ref, got)), "stats": o.adam.guard_stats(),
+                 "replayed": st.steps_replayed, "eager": st.steps_eager}
+dist.destroy_process_group()
+print("RESULT " + json.dumps(res))
+"""
+
+
+def test_multi_rank_code_path_on_a_one_rank_rccl_group(pk):
+    """force_dist: spare-word signalling + the all-reduce inside the step graph (or between two graphs) on a 1-rank RCCL group, in
+    a child process; a batch this rank does not have becomes a void step (every rank's guard rejects it) and changes nothing."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "port": "29641"}], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          text=True, env=env, timeout=600)
+    line = [ln for ln in proc.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert proc.returncode == 0 and line, proc.stderr[-3000:]
+    res = json.loads(line[-1][len("RESULT "):])
+    assert res["captured"]["mode"].startswith("one graph") or res["captured"]["mode"].startswith("two graphs"), res
+    assert res["split"]["mode"] == "two graphs + eager all-reduce", res
+    for name in ("captured", "split"):
+        r = res[name]
+        assert r["equal"], (name, r)
+        assert r["stats"]["applied"] == 6 and r["stats"]["void"] == 1 and r["stats"]["skipped"] == 0, (name, r)
+        assert r["eager"] == 1 and r["replayed"] == 6, (name, r)
