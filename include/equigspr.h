@@ -273,10 +273,14 @@ int equigspr_adam_step(int32_t n_buckets, float* const* params, float* const* gr
  *   stats_dev [8] device, zero-initialised by the caller: [0] sum of loss * weight over applied steps, [1] applied steps,
  *             [2] skipped steps, [3] 1 + number of guarded calls before the first skipped one (0 = none), [4] last loss,
  *             [5] guarded calls, [6] void steps: a non-finite extra_dev[1] (when n_extra > 1) marks a step for which some rank had
- *             no data -- rejected like any other, but counted here instead of [2] / [3].  Gradient buckets must be 16-byte aligned. */
+ *             no data -- rejected like any other, but counted here instead of [2] / [3].  Gradient buckets must be 16-byte aligned.
+ *   progress_host: NULL, or one float of PINNED HOST memory (device-accessible) that receives stats[5] with a system-scope release
+ *             store at the end of every call: the launching thread learns "step n has completed" from plain memory -- no HIP event
+ *             on the compute stream (an event record after every hipGraph launch measured +5 us per step at one pair). */
 int equigspr_adam_step_guarded(int32_t n_buckets, float* const* params, float* const* grads, float* const* exp_avg,
                                float* const* exp_avg_sq, const int64_t* sizes, float* step_dev, const float* hyper_dev,
-                               const float* loss_dev, float* stats_dev, float* extra_dev, int32_t n_extra, void* stream);
+                               const float* loss_dev, float* stats_dev, float* extra_dev, int32_t n_extra,
+                               float* progress_host, void* stream);
 
 /* ---- A15: SO3TensorProductLayer.forward (src/clean_so3_model.py:34-52) ------------------------
  * y = W2 relu(W1 vec(D x x^T) + b1) + b2, D = input_dim (the bmm of the two broadcast views sums D identical

@@ -61,7 +61,7 @@ _SIGNATURES = {
     "equigspr_adam_step": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                           POINTER(c_int64), c_void_p] + [ctypes.c_float] * 4 + [c_int32, c_void_p]),
     "equigspr_adam_step_guarded": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
-                                                  POINTER(c_int64), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+                                                  POINTER(c_int64), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "equigspr_so3_tensor_product_forward": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 7),
     "equigspr_gcn_build_graph": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 11),
     "equigspr_gcn_adjacency_to_dense": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),

@@ -87,9 +87,10 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamBuckets bk, float* __rest
 //   [0] sum of loss * hyper[4] over the applied steps   [1] applied steps   [2] skipped steps
 //   [3] 1 + index (count of guarded calls before it) of the FIRST skipped step, 0 = none   [4] the last loss   [5] guarded calls
 //   [6] void steps (extra[1] not finite: some rank had no data; not counted as skipped)
+// progress_host (pinned host memory, may be NULL) receives stats[5] after every call.
 // hyper (device): lr, beta1, beta2, eps, loss weight -- read at run time, so a scheduler's new lr reaches a captured graph.
 struct AdamGuard {
-    const float* hyper; const float* loss; float* stats; float* extra; int n_extra;
+    const float* hyper; const float* loss; float* stats; float* extra; int n_extra; float* progress_host;
 };
 
 __global__ __launch_bounds__(256) void adam_guarded_kernel(AdamBuckets bk, float* __restrict__ step, AdamGuard gd) {
@@ -149,6 +150,10 @@ __global__ __launch_bounds__(256) void adam_guarded_kernel(AdamBuckets bk, float
             else { st[2] += 1.0f; if (st[3] == 0.0f) st[3] = st[5] + 1.0f; }
             st[4] = loss;
             st[5] += 1.0f;
+            if (gd.progress_host) {          // pinned HOST word: the launching thread sees "step n is done" without a HIP event
+                __threadfence_system();
+                __hip_atomic_store(gd.progress_host, st[5], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
     __syncthreads();
@@ -224,7 +229,8 @@ extern "C" int equigspr_adam_step(int32_t n_buckets, float* const* params, float
 extern "C" int equigspr_adam_step_guarded(int32_t n_buckets, float* const* params, float* const* grads, float* const* exp_avg,
                                           float* const* exp_avg_sq, const int64_t* sizes /* host arrays */, float* step_dev /* [2] */,
                                           const float* hyper_dev /* [5] */, const float* loss_dev /* [1] or NULL */,
-                                          float* stats_dev /* [8] */, float* extra_dev, int32_t n_extra, void* stream) {
+                                          float* stats_dev /* [8] */, float* extra_dev, int32_t n_extra, float* progress_host,
+                                          void* stream) {
     using namespace eq;
     EQ_CHECK_ARG(n_buckets >= 1 && n_buckets <= 4 && params && grads && exp_avg && exp_avg_sq && sizes && step_dev && hyper_dev && stats_dev,
                  EQUIGSPR_EINVAL, "adam_step_guarded: 1..4 buckets, non-null arrays, hyper and stats on the device");
@@ -242,7 +248,7 @@ extern "C" int equigspr_adam_step_guarded(int32_t n_buckets, float* const* param
     const long long cap = (16ll << 20) / (tot > 0 ? tot : 1);
     if (blocks > cap) blocks = cap;
     blocks = blocks < 16 ? 16 : (blocks > 1024 ? 1024 : blocks);
-    AdamGuard gd{hyper_dev, loss_dev, stats_dev, extra_dev, n_extra};
+    AdamGuard gd{hyper_dev, loss_dev, stats_dev, extra_dev, n_extra, progress_host};
     hipLaunchKernelGGL(adam_guarded_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, bk, step_dev, gd);
     EQ_CHECK_LAUNCH("adam_step_guarded");
     return 0;

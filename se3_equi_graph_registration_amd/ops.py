@@ -606,6 +606,8 @@ class FlatAdam:
             dev = self.buckets[0][0].device
             self.hyper_dev = torch.zeros(8, dtype=torch.float32, device=dev)
             self.stats_dev = torch.zeros(8, dtype=torch.float32, device=dev)
+            self.progress_host = torch.zeros(4, dtype=torch.float32).pin_memory()      # [0] = stats_dev[5], written by the kernel
+            self.progress = self.progress_host.numpy()
             self._hyper_host = None
 
     def push_hyper(self, loss_weight: float = 1.0):
@@ -629,7 +631,8 @@ class FlatAdam:
         n_extra = 0 if extra is None else int(_need(extra, "extra", torch.float32, 1).numel())
         _lib.check(_lib.lib().equigspr_adam_step_guarded(len(self.buckets), self._p, self._g, self._m, self._v, self._n,
                                                          _p(self.step_dev), _p(self.hyper_dev), _p(loss), _p(self.stats_dev),
-                                                         _p(extra), n_extra, _stream()), "adam_step_guarded")
+                                                         _p(extra), n_extra, ctypes.c_void_p(self.progress_host.data_ptr()), _stream()),
+                   "adam_step_guarded")
 
     def guard_stats(self):
         """Host copy (synchronises) of the guarded steps' running totals: ``loss_sum`` (weighted), ``applied``, ``skipped``,

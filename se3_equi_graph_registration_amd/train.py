@@ -19,7 +19,9 @@ import os
 import queue
 import sys
 import threading
+import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -175,14 +177,23 @@ class _Slot:
         seg = lambda i, shape: self.packet[self.offsets[i]:self.offsets[i] + sizes[i]].view(shape)      # noqa: E731
         self.xyz, self.feat = seg(0, (2, B, N, 3)), seg(1, (2, B, N, F))
         self.labels, self.gt_pose, self.signal = seg(2, (B, N)), seg(3, (B, 4, 4)), seg(4, (4,))
-        self.h2d_done = self.consumed = None
+        self.last_call = 0                 # the run's guarded call that last read this slot (GraphedStep.run)
 
     def fill(self, batch):
-        """Pack a 7-tuple ``(corr, labels, xyz_0, xyz_1, feat_0, feat_1, gt_pose)`` (``corr`` is not an input of the forward)."""
+        """Pack a 7-tuple ``(corr, labels, xyz_0, xyz_1, feat_0, feat_1, gt_pose)`` (``corr`` is not an input of the forward).
+        Host -> pinned packets go through numpy: one plain memcpy per member on the calling (producer) thread -- ``Tensor.copy_``
+        would fan a 0.5 MB copy out over an OpenMP team of all host cores, created afresh for a non-main thread (3.4 ms per
+        batch on the 256-core GPU box, measured)."""
         _, labels, xyz_0, xyz_1, feat_0, feat_1, gt_pose = batch
-        self.xyz[0].copy_(xyz_0); self.xyz[1].copy_(xyz_1)
-        self.feat[0].copy_(feat_0); self.feat[1].copy_(feat_1)
-        self.labels.copy_(labels.reshape(self.labels.shape)); self.gt_pose.copy_(gt_pose)
+        pairs = ((self.xyz[0], xyz_0), (self.xyz[1], xyz_1), (self.feat[0], feat_0), (self.feat[1], feat_1),
+                 (self.labels, labels.reshape(self.labels.shape)), (self.gt_pose, gt_pose))
+        if not self.packet.is_cuda and all(not src.is_cuda for _, src in pairs):
+            for dst, src in pairs:
+                np.copyto(dst.numpy(), src.detach().numpy(), casting="unsafe")
+            self.signal.numpy()[:] = 0.0
+            return
+        for dst, src in pairs:
+            dst.copy_(src)
         self.signal.zero_()
 
 
@@ -208,7 +219,7 @@ class GraphedStep:
       this ROCm stack); ``run`` makes the caller's stream wait for it before returning.
     Weights after n steps are bit-identical to the eager loop's (``tests/test_gpu_train.py``)."""
 
-    def __init__(self, model, optimizer, k=16, loss_mode="3dmatch", slots=2, graph_collectives=True, use_graphs=True, depth=3,
+    def __init__(self, model, optimizer, k=16, loss_mode="3dmatch", slots=3, graph_collectives=True, use_graphs=True, depth=3,
                  force_dist=False):
         if not isinstance(optimizer, StepOptimizer):
             raise TypeError("GraphedStep needs the package's StepOptimizer (train.make_optimizer): the guarded flat Adam is part of the step")
@@ -234,6 +245,7 @@ class GraphedStep:
         self._seed = self._pad = None
         self._call_batch = []              # guarded call -> batch index of the current epoch (for the error message)
         self.last_stats = None             # FlatAdam.guard_stats() of the last run()
+        self._pinned_free, self._pinned_shapes = queue.Queue(), set()
 
     # ------------------------------------------------------------------ the step itself (eager or under capture)
     def _spare_words(self):
@@ -273,9 +285,6 @@ class GraphedStep:
     def _prepare(self, B, N, F, n_global):
         self.shape = (B, N, F)
         self.slots = [_Slot(B, N, F, self.device) for _ in range(self.n_slots)]
-        for sl in self.slots:
-            sl.consumed = torch.cuda.Event()
-            sl.consumed.record(self.stream)
         w = B * self.world / n_global if self.world > 1 else 1.0
         self._seed = torch.full((), float(w), dtype=torch.float32, device=self.device)
         self._loss_weight = B / n_global if self.world > 1 else 1.0
@@ -332,7 +341,6 @@ class GraphedStep:
                 self.opt.dp.sync(force=True)
                 g[1].replay()
             self.steps_replayed += 1
-        sl.consumed.record(self.stream)
 
     def _usable_shape(self, batch):
         _, labels, xyz_0, xyz_1, feat_0, feat_1, gt_pose = batch
@@ -341,7 +349,14 @@ class GraphedStep:
 
     def run(self, batches, epoch=0, log_interval=10, skip_nonfinite=False, shard_batches=True):
         """The body of ``train_one_epoch`` over an iterable of step batches (host or device 7-tuples, ``None`` allowed).
-        Returns the average loss over the applied steps (the global mean under data parallel)."""
+        Returns the average loss over the applied steps (the global mean under data parallel).
+
+        Pipeline (measured on the MI355X, one 2048-point pair, tools/dev/step_timing.py): a replay is 0.363 ms; an event
+        recorded on the compute stream after every replay costs +5 us, a copy-stream H2D that WAITS (on the GPU) for such an
+        event +30..80 us, an independent H2D +3 us.  So nothing here makes one stream wait for another on the device: the host
+        learns that a step has finished from a pinned word the optimizer launch writes (``FlatAdam.progress``) and only then
+        overwrites that step's input slot; the H2D of batch t+1 is issued before the replay of batch t and has long completed
+        (checked on the host) when its own replay is launched."""
         dev = self.device
         caller = torch.cuda.current_stream(dev)
         self.stream.wait_stream(caller)
@@ -349,8 +364,13 @@ class GraphedStep:
         adam._guard_buffers()
         with torch.cuda.stream(self.stream):
             adam.stats_dev.zero_()
+        self.stream.synchronize()
+        adam.progress[0] = 0.0
+        for sl in self.slots:
+            sl.last_call = 0
+        self._calls = 0                    # guarded optimizer calls issued in this run (= FlatAdam.progress when all are done)
         self._call_batch = []
-        pinned_free, pinned_shapes = queue.Queue(), set()
+        pinned_free, pinned_shapes = self._pinned_free, self._pinned_shapes      # pinned packets outlive the run (hipHostMalloc is slow)
         q = queue.Queue(maxsize=self.depth)
         stop, abandoned = object(), threading.Event()
 
@@ -367,7 +387,7 @@ class GraphedStep:
             """A free pinned packet of this shape (the H2D copy that last read it has completed)."""
             if shape not in pinned_shapes:
                 pinned_shapes.add(shape)
-                for _ in range(self.depth + 2):
+                for _ in range(self.depth + 3):
                     pinned_free.put((_Slot(*shape, dev, pinned=True), None))
             while not abandoned.is_set():
                 try:
@@ -408,14 +428,78 @@ class GraphedStep:
                 put(e)
             put(stop)
 
+        # two Python threads share the interpreter lock: with the default 5 ms switch interval a hand-over at the wrong moment
+        # stalls the launching thread for several steps' worth of GPU time (measured: 2 of 400 steps took +4.5 ms)
+        switch_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(switch_interval, 1e-4))
         th = threading.Thread(target=produce, daemon=True)
         th.start()
         pending_log = []
         nan_host = torch.full((1,), float("nan"))
+        staged = None                      # (slot index, pinned packet, batch index): H2D issued, step not launched yet
+
+        tm = self.timing = {"get": 0.0, "wait_calls": 0.0, "ev_sync": 0.0, "launch": 0.0, "h2d": 0.0, "slow": []} if os.environ.get("EQUIGSPR_STEP_TIMING") == "1" else None
+
+        def note(what, dt):
+            tm[what] += dt
+            if dt > 5e-4:
+                tm["slow"].append((what, self._calls, round(dt * 1e3, 2)))
+
+        def wait_calls(n):
+            """Block (host) until the first ``n`` guarded calls of this run have completed on the GPU."""
+            prog = adam.progress
+            spins = 0
+            t0 = time.perf_counter()
+            while prog[0] < n:
+                spins += 1
+                if spins > 2000:
+                    time.sleep(2e-5)
+            if tm is not None:
+                note("wait_calls", time.perf_counter() - t0)
+
+        def launch_staged():
+            nonlocal staged
+            if staged is None:
+                return
+            idx, packet, batch_idx = staged
+            staged = None
+            t0 = time.perf_counter()
+            # the H2D went out one iteration ago: normally complete.  A host-side stream synchronize, not an event: an event record
+            # is a marker with a system-scope release on the GPU, which measurably slows the step running beside it (+35 us at
+            # one pair), and a device-side wait on such an event costs more still
+            self.copy_stream.synchronize()
+            pinned_free.put((packet, None))
+            t1 = time.perf_counter()
+            self._launch(idx)
+            if tm is not None:
+                note("ev_sync", t1 - t0); note("launch", time.perf_counter() - t1)
+            self._calls += 1
+            self.slots[idx].last_call = self._calls
+            self._last_idx = idx
+            self._call_batch.append(batch_idx)
+            if self.graphs is None and self.use_graphs and not self._capture_tried:
+                self._capture_tried = True
+                self.stream.synchronize()
+                self._capture()            # the eager step above created the cached index arrays the capture adopts
+            log_point(batch_idx)
+
+        def log_point(batch_idx):
+            if log_interval and batch_idx % log_interval == 0 and self.rank == 0:
+                host = torch.empty(8, dtype=torch.float32).pin_memory()
+                host.copy_(adam.stats_dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                pending_log.append((batch_idx, host, ev))
+            while pending_log and pending_log[0][2].query():
+                self._report(pending_log.pop(0), epoch, skip_nonfinite)
+
         try:
             with torch.cuda.stream(self.stream):
                 while True:
+                    t0 = time.perf_counter()
                     item = q.get()
+                    if tm is not None:
+                        note("get", time.perf_counter() - t0)
                     if isinstance(item, BaseException):
                         raise item
                     if item is stop:
@@ -431,54 +515,55 @@ class GraphedStep:
                         if self.dist_on and self.shape is not None:
                             # this rank has no batch, its peers may: run the step on the data of the previous one with the "void"
                             # signal raised -- every rank's guard then rejects the step (ONE collective per step, no host sync)
+                            launch_staged()
                             sl = self.slots[self._last_idx]
                             sl.signal[:1].copy_(nan_host, non_blocking=False)
                             self._launch(self._last_idx)
                             sl.signal.zero_()
+                            self._calls += 1
+                            sl.last_call = self._calls
                             self._call_batch.append(batch_idx)
                         continue
                     self.opt._push_hyperparameters()
-                    if isinstance(payload, _Slot):
-                        shape = tuple(payload.xyz.shape[1:3]) + (payload.feat.shape[3],)
-                        if self.shape is not None and self.shape != shape:
-                            # packed before the first step fixed the shape: take it as a batch of another shape (one object, one
-                            # static shape -- the first it sees; the decision must not depend on thread timing)
-                            self._eager_other_shape((None, payload.labels, payload.xyz[0], payload.xyz[1], payload.feat[0], payload.feat[1],
-                                                     payload.gt_pose), n_global)
-                            torch.cuda.current_stream(dev).synchronize()
+                    packed = isinstance(payload, _Slot)
+                    shape = (tuple(payload.xyz.shape[1:3]) + (payload.feat.shape[3],)) if packed else None
+                    if packed and (self.shape is None or self.shape == shape):
+                        if self.shape is None:
+                            self._prepare(*shape, n_global)
+                        adam.push_hyper(self._loss_weight)
+                        idx = ((staged[0] if staged is not None else self._last_idx) + 1) % self.n_slots
+                        sl = self.slots[idx]
+                        if staged is not None and staged[0] == idx:
+                            launch_staged()            # a single slot: no look-ahead
+                        wait_calls(sl.last_call)       # the step that last read this slot has finished (host-side knowledge)
+                        t0 = time.perf_counter()
+                        launch_staged()                # the previous batch: its H2D went out one iteration ago
+                        with torch.cuda.stream(self.copy_stream):
+                            sl.packet.copy_(payload.packet, non_blocking=True)
+                        if tm is not None:
+                            note("h2d", time.perf_counter() - t0)
+                        staged = (idx, payload, batch_idx)
+                        if self.graphs is None:        # no look-ahead before the graphs exist (first step, eager mode)
+                            launch_staged()
+                    else:
+                        # device tensors, or another shape than the captured one (one object, one static shape -- the first it
+                        # sees; a packet filled before that shape was fixed is taken as a batch of another shape)
+                        launch_staged()
+                        if packed:
+                            payload_batch = (None, payload.labels, payload.xyz[0], payload.xyz[1], payload.feat[0], payload.feat[1], payload.gt_pose)
+                            self._eager_other_shape(payload_batch, n_global)
+                            self.stream.synchronize()
                             pinned_free.put((payload, None))
                         else:
-                            if self.shape is None:
-                                self._prepare(*shape, n_global)
-                            adam.push_hyper(self._loss_weight)
-                            idx = (self._last_idx + 1) % self.n_slots
-                            sl = self.slots[idx]
-                            with torch.cuda.stream(self.copy_stream):
-                                self.copy_stream.wait_event(sl.consumed)
-                                sl.packet.copy_(payload.packet, non_blocking=True)
-                                ev = torch.cuda.Event()
-                                ev.record(self.copy_stream)
-                            pinned_free.put((payload, ev))
-                            self.stream.wait_event(ev)
-                            self._launch(idx)
-                            self._last_idx = idx
-                            if self.graphs is None and self.use_graphs and not self._capture_tried:
-                                self._capture_tried = True
-                                self._capture()             # the eager step above created the cached index arrays the capture adopts
-                    else:
-                        self._eager_other_shape(payload, n_global)
-                    self._call_batch.append(batch_idx)
-                    if log_interval and batch_idx % log_interval == 0 and self.rank == 0:
-                        host = torch.empty(8, dtype=torch.float32).pin_memory()
-                        host.copy_(adam.stats_dev, non_blocking=True)
-                        ev = torch.cuda.Event()
-                        ev.record(self.stream)
-                        pending_log.append((batch_idx, host, ev))
-                    while pending_log and pending_log[0][2].query():
-                        self._report(pending_log.pop(0), epoch, skip_nonfinite)
+                            self._eager_other_shape(payload, n_global)
+                        self._calls += 1
+                        self._call_batch.append(batch_idx)
+                        log_point(batch_idx)
+                launch_staged()
         finally:
             abandoned.set()
             th.join()
+            sys.setswitchinterval(switch_interval)
             caller.wait_stream(self.stream)
         self.stream.synchronize()
         for entry in pending_log:

@@ -41,9 +41,14 @@ def plain():
     return line
 
 
-@pytest.mark.parametrize("flags,mode", [([], "one graph (all-reduce captured)"), (["--split-graph"], "two graphs + eager all-reduce"),
-                                        (["--fixed-pair-replay"], "two graphs + eager all-reduce"),
-                                        (["--fixed-pair-replay", "--graph-collectives"], "one graph")])
+@pytest.fixture(scope="module")
+def plain_fixed():
+    line, _ = _bench(["--fixed-pair-replay"], {"BENCH_GRAD_HASH": "1"})
+    assert "multi_gpu" not in line and line["config"]["hipgraph"] is True and line["config"]["graph_mode"] == "one graph"
+    return line
+
+
+@pytest.mark.parametrize("flags,mode", [([], "one graph (all-reduce captured)"), (["--split-graph"], "two graphs + eager all-reduce")])
 def test_forced_dist_step_on_rccl_matches_the_plain_step(plain, flags, mode):
     """The package's loop (train.GraphedStep: all-reduce captured inside the step graph by default, --split-graph = two graphs around
     an eager all-reduce) and the harness-captured replay of rounds 1-3 (--fixed-pair-replay), each on a 1-rank RCCL group."""
@@ -95,3 +100,12 @@ def test_multi_rank_default_line_carries_the_scaling_workloads():
     for name, e in w.items():
         assert e["roofline"]["frac"] > 0 and e["config"]["hipgraph"] is True, name
         assert line["roofline"]["workloads"][name]["frac"] == e["roofline"]["frac"]
+
+
+@pytest.mark.parametrize("flags,mode", [(["--fixed-pair-replay"], "two graphs + eager all-reduce"),
+                                        (["--fixed-pair-replay", "--graph-collectives"], "one graph")])
+def test_forced_dist_harness_replay_matches_its_plain_form(plain_fixed, flags, mode):
+    """The harness-captured replay of rounds 1-3 (--fixed-pair-replay, a diagnostic since round 4) on the 1-rank RCCL group."""
+    line, _ = _bench(flags, {"BENCH_FORCE_DIST": "1", "BENCH_GRAD_HASH": "1", "MASTER_PORT": "29613"})
+    assert line["config"]["graph_mode"] == mode and line["config"]["hipgraph"] is True and line["multi_gpu"]["world_size"] == 1
+    assert line["grad_hash"] == plain_fixed["grad_hash"], "the RCCL path changed the step's gradients"
