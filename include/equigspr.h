@@ -270,7 +270,7 @@ int equigspr_adam_step(int32_t n_buckets, float* const* params, float* const* gr
  * and the gradients (and `extra`) are cleared.  All of gradient buckets, `extra_dev[n_extra]` (e.g. the spare words of a joint
  * all-reduce bucket through which ranks signal each other) and `loss_dev[0]` (NULL = not examined) enter the verdict.
  *   hyper_dev [5] device: lr, beta1, beta2, eps, loss weight (read at run time: schedulers act on a captured graph)
- *   stats_dev [8] device, zero-initialised by the caller: [0] sum of loss * weight over applied steps, [1] applied steps,
+ *   stats_dev [8] device, 16-byte aligned, zero-initialised by the caller: [0] sum of loss * weight over applied steps, [1] applied steps,
  *             [2] skipped steps, [3] 1 + number of guarded calls before the first skipped one (0 = none), [4] last loss,
  *             [5] guarded calls, [6] void steps: a non-finite extra_dev[1] (when n_extra > 1) marks a step for which some rank had
  *             no data -- rejected like any other, but counted here instead of [2] / [3].  Gradient buckets must be 16-byte aligned.

@@ -751,9 +751,6 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
     __shared__ __attribute__((aligned(16))) float scratch[NW][kScratch];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     EQ_STAMP(0);
-    stage_w16<H, A, true, 64 * NW, kB>(wsm_, lw);
-    __syncthreads();
-    EQ_STAMP(1);
     float* sc = scratch[wv];
     // hidden_nf 33: the border running sums (PassBorder x 2 + dWgeo's row + dw7 / dgamma / dbeta entries) as 16 per-lane LDS slots,
     // read-modified-written once per tile (a lane only ever touches its own slots: fixed order) -- 16 registers less to spill
@@ -809,7 +806,18 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
     auto edge_of = [&](int ch_) { const int e_ = edge_id(ch_); return lane_live(e_) ? e_ : 0; };
     int ch = NW == 8 ? (blockIdx.x + (wv >> 2) * gridDim.x) * 4 + (wv & 3) : blockIdx.x * NW + wv;
     int e = ch < n_chunks ? edge_of(ch) : 0;
+    // start-up order as in the forward kernel: first indices, then the weight image's loads, the first unit's coordinate gathers,
+    // and only then the image's LDS stores + the barrier
     int r = row[e], c = col[e];
+    StageW16<H, A, true, 64 * NW, kB> stage;
+    stage.load(lw);
+    float xr0[3], xc0[3], gx0[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { xr0[k] = x[(size_t)r * 3 + k]; xc0[k] = x[(size_t)c * 3 + k]; gx0[k] = Gx[(size_t)r * 4 + k]; }
+    stage.store(wsm_);
+    __syncthreads();
+    EQ_STAMP(1);
+    bool first = true;
     for (; ch < n_chunks; ch += unit_step) {
         int off = 0;
         asm volatile("" : "+v"(off));
@@ -822,8 +830,14 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
         // ---- front: one lane per edge
         idx_r[lane] = r; idx_c[lane] = c;
         float xr[3], xc[3], gxv[3];
+        if (first) {                                   // gathered during the start-up above
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { xr[k] = x[(size_t)r * 3 + k]; xc[k] = x[(size_t)c * 3 + k]; gxv[k] = Gx[(size_t)r * 4 + k]; }
+            for (int k = 0; k < 3; ++k) { xr[k] = xr0[k]; xc[k] = xc0[k]; gxv[k] = gx0[k]; }
+            first = false;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { xr[k] = x[(size_t)r * 3 + k]; xc[k] = x[(size_t)c * 3 + k]; gxv[k] = Gx[(size_t)r * 4 + k]; }
+        }
         const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
         __builtin_amdgcn_wave_barrier();
         // first sub-tile's projection rows and dagg row: in flight with the coordinate gathers

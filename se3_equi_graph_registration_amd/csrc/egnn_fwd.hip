@@ -94,9 +94,6 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int wave = blockIdx.x * kFwd16Waves + wv, n_waves = gridDim.x * kFwd16Waves;
     EQ_STAMP(0);
-    stage_w16<H, A, false, 64 * kFwd16Waves, kB>(wsm_, lw);
-    __syncthreads();
-    EQ_STAMP(1);
     float* sc = scratch[wv];
     int* idx_r = reinterpret_cast<int*>(sc + C::o_r);
     int* idx_c = reinterpret_cast<int*>(sc + C::o_c);
@@ -114,12 +111,24 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
     const int ts = strided ? ch_step : 1;
     const int unit_step = strided ? 4 * ch_step : ch_step;
     int ch = wave;
-    if (ch >= n_chunks) return;
     auto edge_id = [&](int ch_) { return ((strided ? ch_ : ch_ * tpc) + (lane >> 4) * ts) * 16 + (lane & 15); };     // this lane's edge of unit ch_ (>= n_edges: none)
     auto lane_live = [&](int e_) { return e_ < n_edges && (strided || lane < chunk); };
     auto edge_of = [&](int ch_) { const int e_ = edge_id(ch_); return lane_live(e_) ? e_ : 0; };
-    int e = edge_of(ch);
+    // Start-up order (a wave lives for one to three tiles on a small graph): the first unit's indices are requested BEFORE the weight
+    // image, its coordinates between the image's loads and its LDS stores -- index -> coordinate -> geometry and global -> LDS
+    // run side by side instead of one after the other.
+    int e = ch < n_chunks ? edge_of(ch) : 0;
     int r = row[e], c = col[e], at = rinv[e];
+    StageW16<H, A, false, 64 * kFwd16Waves, kB> stage;
+    stage.load(lw);
+    float xr0[3], xc0[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { xr0[k] = x[(size_t)r * 3 + k]; xc0[k] = x[(size_t)c * 3 + k]; }
+    stage.store(wsm_);
+    __syncthreads();
+    EQ_STAMP(1);
+    if (ch >= n_chunks) return;
+    bool first = true;
     for (; ch < n_chunks; ch += unit_step) {
         int off = 0;
         asm volatile("" : "+v"(off));                  // an opaque zero offset keeps the (loop-invariant) weight reads inside the loop
@@ -132,8 +141,14 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
         // ---- front: one lane per edge
         idx_r[lane] = r; idx_c[lane] = c; pos[lane] = at;
         float xr[3], xc[3];
+        if (first) {                                   // gathered during the start-up above
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { xr[k] = x[(size_t)r * 3 + k]; xc[k] = x[(size_t)c * 3 + k]; }
+            for (int k = 0; k < 3; ++k) { xr[k] = xr0[k]; xc[k] = xc0[k]; }
+            first = false;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { xr[k] = x[(size_t)r * 3 + k]; xc[k] = x[(size_t)c * 3 + k]; }
+        }
         const float attr = A ? (edge_attr ? edge_attr[e] : 1.0f) : 0.0f;
         __builtin_amdgcn_wave_barrier();
         PRowsT<kB> pw;                                 // first sub-tile's projection rows: in flight with the coordinate gathers

@@ -89,64 +89,78 @@ struct W16 {
     static constexpr int border_base(bool bwd) { return bwd ? bwd_size : fwd_size; }
 };
 
-// global -> LDS, all of a thread's loads before its first store.  NT = threads of the workgroup.
+// global -> LDS in two halves, so that a kernel can put other requests between them: load() issues all of a thread's global
+// loads (the edge kernels request their first indices BEFORE it and gather the coordinates between load() and store(): the
+// image's latency and the index -> coordinate chain overlap instead of adding up -- at one 2 048-point pair a wave lives for
+// only 2-3 tiles, so ~1 us of serial start-up is 5 % of the kernel), store() writes the image.  NT = threads of the workgroup.
+template <int H, int A, bool kBwd, int NT, int kB = 0>
+struct StageW16 {
+    static constexpr int F = 32 + kB;
+    using LL = LP<F, H, A>;
+    static constexpr int FH = F / H;
+    static constexpr int PER = 1024 / NT, PG = (512 + NT - 1) / NT;
+    float v2[PER], v6[PER], vg[PG], vv, vb;
+    __device__ __forceinline__ void load(const float* __restrict__ lw) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = threadIdx.x + NT * u, i = t >> 5, k = t & 31;
+            v2[u] = (i / FH == k / FH) ? lw[LL::w2_off(i, k)] : 0.0f;      // block-diagonal over the heads
+            v6[u] = lw[LL::w6 + i * F + k];
+        }
+#pragma unroll
+        for (int u = 0; u < PG; ++u) {
+            const int t = threadIdx.x + NT * u, i = (t >> 4) & 31, k = t & 15;
+            vg[u] = (t < 512 && k < kGeo + A) ? lw[LL::w1_off(i, 2 * F + k)] : 0.0f;
+        }
+        vv = 0.0f;
+        if (threadIdx.x < 160) {
+            const int w = threadIdx.x >> 5, k = threadIdx.x & 31;
+            vv = lw[w == 0 ? LL::b2_off(k) : (w == 1 ? LL::ln_g + k : (w == 2 ? LL::ln_b + k : (w == 3 ? LL::b6 + k : LL::w7 + k)))];
+        }
+        vb = 0.0f;
+        if (kB && threadIdx.x < W16::border_size) {
+            const int t = threadIdx.x, k = t & 31;
+            if (t < 32) vb = lw[LL::w2_off(k, 32)];
+            else if (t < 64) vb = lw[LL::w2_off(32, k)];
+            else if (t < 96) vb = lw[LL::w6 + k * F + 32];
+            else if (t < 128) vb = lw[LL::w6 + 32 * F + k];
+            else if (t < 144) vb = (t - 128 < kGeo + A) ? lw[LL::w1_off(32, 2 * F + (t - 128))] : 0.0f;
+            else {
+                const int q = t - 144;
+                vb = q == 0 ? lw[LL::w2_off(32, 32)] : q == 1 ? lw[LL::w6 + 32 * F + 32] : q == 2 ? lw[LL::b2_off(32)] : q == 3 ? lw[LL::ln_g + 32]
+                   : q == 4 ? lw[LL::ln_b + 32] : q == 5 ? lw[LL::b6 + 32] : q == 6 ? lw[LL::w7 + 32] : 0.0f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* sm) const {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int t = threadIdx.x + NT * u, i = t >> 5, k = t & 31;
+            sm[W16::o_w2 + i * W16::WS + k] = v2[u];
+            sm[W16::o_w6 + i * W16::WS + k] = v6[u];
+            if (kBwd) {
+                sm[W16::o_w2t + k * W16::WS + i] = v2[u];
+                sm[W16::o_w6t + k * W16::WS + i] = v6[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PG; ++u) {
+            const int t = threadIdx.x + NT * u, i = (t >> 4) & 31, k = t & 15;
+            if (t < 512) {
+                sm[W16::o_wg + i * W16::GS + k] = vg[u];
+                if (kBwd) sm[W16::o_wgt + k * W16::WS + i] = vg[u];
+            }
+        }
+        if (threadIdx.x < 160) sm[W16::o_vec + threadIdx.x] = vv;
+        if (kB && threadIdx.x < W16::border_size) sm[W16::border_base(kBwd) + threadIdx.x] = vb;
+    }
+};
+
 template <int H, int A, bool kBwd, int NT, int kB = 0>
 __device__ __forceinline__ void stage_w16(float* sm, const float* __restrict__ lw) {
-    constexpr int F = 32 + kB;
-    using LL = LP<F, H, A>;
-    constexpr int FH = F / H;
-    constexpr int PER = 1024 / NT, PG = (512 + NT - 1) / NT;
-    float v2[PER], v6[PER], vg[PG];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int t = threadIdx.x + NT * u, i = t >> 5, k = t & 31;
-        v2[u] = (i / FH == k / FH) ? lw[LL::w2_off(i, k)] : 0.0f;      // block-diagonal over the heads
-        v6[u] = lw[LL::w6 + i * F + k];
-    }
-#pragma unroll
-    for (int u = 0; u < PG; ++u) {
-        const int t = threadIdx.x + NT * u, i = (t >> 4) & 31, k = t & 15;
-        vg[u] = (t < 512 && k < kGeo + A) ? lw[LL::w1_off(i, 2 * F + k)] : 0.0f;
-    }
-    float vv = 0.0f;
-    if (threadIdx.x < 160) {
-        const int w = threadIdx.x >> 5, k = threadIdx.x & 31;
-        vv = lw[w == 0 ? LL::b2_off(k) : (w == 1 ? LL::ln_g + k : (w == 2 ? LL::ln_b + k : (w == 3 ? LL::b6 + k : LL::w7 + k)))];
-    }
-    float vb = 0.0f;
-    if (kB && threadIdx.x < W16::border_size) {
-        const int t = threadIdx.x, k = t & 31;
-        if (t < 32) vb = lw[LL::w2_off(k, 32)];
-        else if (t < 64) vb = lw[LL::w2_off(32, k)];
-        else if (t < 96) vb = lw[LL::w6 + k * F + 32];
-        else if (t < 128) vb = lw[LL::w6 + 32 * F + k];
-        else if (t < 144) vb = (t - 128 < kGeo + A) ? lw[LL::w1_off(32, 2 * F + (t - 128))] : 0.0f;
-        else {
-            const int q = t - 144;
-            vb = q == 0 ? lw[LL::w2_off(32, 32)] : q == 1 ? lw[LL::w6 + 32 * F + 32] : q == 2 ? lw[LL::b2_off(32)] : q == 3 ? lw[LL::ln_g + 32]
-               : q == 4 ? lw[LL::ln_b + 32] : q == 5 ? lw[LL::b6 + 32] : q == 6 ? lw[LL::w7 + 32] : 0.0f;
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int t = threadIdx.x + NT * u, i = t >> 5, k = t & 31;
-        sm[W16::o_w2 + i * W16::WS + k] = v2[u];
-        sm[W16::o_w6 + i * W16::WS + k] = v6[u];
-        if (kBwd) {
-            sm[W16::o_w2t + k * W16::WS + i] = v2[u];
-            sm[W16::o_w6t + k * W16::WS + i] = v6[u];
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < PG; ++u) {
-        const int t = threadIdx.x + NT * u, i = (t >> 4) & 31, k = t & 15;
-        if (t < 512) {
-            sm[W16::o_wg + i * W16::GS + k] = vg[u];
-            if (kBwd) sm[W16::o_wgt + k * W16::WS + i] = vg[u];
-        }
-    }
-    if (threadIdx.x < 160) sm[W16::o_vec + threadIdx.x] = vv;
-    if (kB && threadIdx.x < W16::border_size) sm[W16::border_base(kBwd) + threadIdx.x] = vb;
+    StageW16<H, A, kBwd, NT, kB> st;
+    st.load(lw);
+    st.store(sm);
 }
 
 // acc[bo] += W v for a 32 x 32 LDS image `mat` (row stride WS): 4 ds_read_b128, 16 MFMAs.  For y = W^T v pass the

@@ -93,43 +93,75 @@ struct AdamGuard {
     const float* hyper; const float* loss; float* stats; float* extra; int n_extra; float* progress_host;
 };
 
-__global__ __launch_bounds__(256) void adam_guarded_kernel(AdamBuckets bk, float* __restrict__ step, AdamGuard gd) {
+constexpr int kGuardThreads = 1024;
+__global__ __launch_bounds__(kGuardThreads) void adam_guarded_kernel(AdamBuckets bk, float* __restrict__ step, AdamGuard gd) {
+    constexpr int NT = kGuardThreads;
     __shared__ int s_bad;
-    if (threadIdx.x == 0) s_bad = 0;
+    // the running totals, requested now by the thread that may turn out to be the launch's last: they were written by the previous
+    // launch, and fetching them only after the ticket cost the tail of the kernel half a dozen serial memory round trips
+    float4 sA = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sB = sA;
+    float e1 = 0.0f;
+    if (threadIdx.x == 0) {
+        s_bad = 0;
+        sA = reinterpret_cast<const float4*>(gd.stats)[0];
+        sB = reinterpret_cast<const float4*>(gd.stats)[1];
+        if (gd.n_extra > 1) e1 = gd.extra[1];
+    }
+    // everything the update needs is requested before the scan, so that its latency hides under the scan's: the hyper-parameters,
+    // the step count, and the operands of the thread's first element of every bucket (all of them, for models up to blocks x 1024
+    // parameters per bucket)
+    const float lr = gd.hyper[0], b1 = gd.hyper[1], b2 = gd.hyper[2], eps = gd.hyper[3];
+    const float tcur = step[0] + 1.0f;
+    const long long gid = (long long)blockIdx.x * NT + threadIdx.x, stride = (long long)gridDim.x * NT;
+    float pg[4], pm[4], pv[4], pp[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool on = k < bk.count && gid < bk.n[k];
+        pg[k] = on ? bk.g[k][gid] : 0.0f; pm[k] = on ? bk.m[k][gid] : 0.0f; pv[k] = on ? bk.v[k][gid] : 0.0f; pp[k] = on ? bk.p[k][gid] : 0.0f;
+    }
     __syncthreads();
-    // largest |bit pattern| seen: >= 0x7f800000 <=> an inf or a NaN (one AND + one unsigned MAX per element)
+    // largest |bit pattern| seen: >= 0x7f800000 <=> an inf or a NaN (one AND + one unsigned MAX per element).  (The first version
+    // waited for every load before issuing the next -- 55 dependent round trips, 13 us for the 56 k gradients of the 4-layer model.)
     unsigned top = 0u;
     auto see = [&](float v) { const unsigned u = __float_as_uint(v) & 0x7fffffffu; top = u > top ? u : top; };
     for (int k = 0; k < bk.count; ++k) {
+        // sixteen 16-byte requests in flight per thread: each bucket of the 4-layer model (40 k + 16 k gradients) is one round trip
         const long long n4 = bk.n[k] >> 2;
         const float4* g4 = reinterpret_cast<const float4*>(bk.g[k]);          // buckets are 16-byte aligned (checked on the host)
-        for (long long i = threadIdx.x; i < n4; i += 256) {
-            const float4 v = g4[i];
-            see(v.x); see(v.y); see(v.z); see(v.w);
+        for (long long base = threadIdx.x; base < n4; base += 16 * NT) {
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const long long i = base + (long long)u * NT;
+                v[u] = i < n4 ? g4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { see(v[u].x); see(v[u].y); see(v[u].z); see(v[u].w); }
         }
-        for (long long i = (n4 << 2) + threadIdx.x; i < bk.n[k]; i += 256) see(bk.g[k][i]);
+        for (long long i = (n4 << 2) + threadIdx.x; i < bk.n[k]; i += NT) see(bk.g[k][i]);
     }
-    for (int i = threadIdx.x; i < gd.n_extra; i += 256) see(gd.extra[i]);
+    for (int i = threadIdx.x; i < gd.n_extra; i += NT) see(gd.extra[i]);
     const float loss = gd.loss ? gd.loss[0] : 0.0f;
     see(loss);
     int bad = top >= 0x7f800000u;
     if (bad) s_bad = 1;                      // benign race: every writer stores 1
     __syncthreads();
     bad = s_bad;
-    const float lr = gd.hyper[0], b1 = gd.hyper[1], b2 = gd.hyper[2], eps = gd.hyper[3];
-    const float tcur = step[0] + 1.0f;
     if (!bad) {
         const float bc1 = 1.0f - powf(b1, tcur), bc2s = sqrtf(1.0f - powf(b2, tcur));
-        const long long gid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
-        for (int k = 0; k < bk.count; ++k) {
-            for (long long i = gid; i < bk.n[k]; i += stride) {
-                const float g = bk.g[k][i];
-                const float m = b1 * bk.m[k][i] + (1.0f - b1) * g;
-                const float v = b2 * bk.v[k][i] + (1.0f - b2) * g * g;
-                bk.m[k][i] = m;
-                bk.v[k][i] = v;
-                bk.p[k][i] -= (lr / bc1) * m / (sqrtf(v) / bc2s + eps);
-                bk.g[k][i] = 0.0f;
+        auto update = [&](int k, long long i, float g, float m0, float v0, float p0) {
+            const float m = b1 * m0 + (1.0f - b1) * g;
+            const float v = b2 * v0 + (1.0f - b2) * g * g;
+            bk.m[k][i] = m;
+            bk.v[k][i] = v;
+            bk.p[k][i] = p0 - (lr / bc1) * m / (sqrtf(v) / bc2s + eps);
+            bk.g[k][i] = 0.0f;
+        };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < bk.count) {
+                if (gid < bk.n[k]) update(k, gid, pg[k], pm[k], pv[k], pp[k]);
+                for (long long i = gid + stride; i < bk.n[k]; i += stride) update(k, i, bk.g[k][i], bk.m[k][i], bk.v[k][i], bk.p[k][i]);
             }
         }
     }
@@ -141,27 +173,27 @@ __global__ __launch_bounds__(256) void adam_guarded_kernel(AdamBuckets bk, float
         s_last = atomicAdd(done, 1u) == gridDim.x - 1;
         if (s_last) {
             *done = 0u;
-            float* st = gd.stats;
             // extra[1] non-finite = "a rank had no data for this step" (train.GraphedStep): a void step, not a rejected one
-            bool voided = false;
-            if (gd.n_extra > 1) { const float e1 = gd.extra[1]; voided = (__float_as_uint(e1) & 0x7fffffffu) >= 0x7f800000u; }
-            if (!bad) { step[0] = tcur; st[0] += loss * gd.hyper[4]; st[1] += 1.0f; }
-            else if (voided) st[6] += 1.0f;
-            else { st[2] += 1.0f; if (st[3] == 0.0f) st[3] = st[5] + 1.0f; }
-            st[4] = loss;
-            st[5] += 1.0f;
-            if (gd.progress_host) {          // pinned HOST word: the launching thread sees "step n is done" without a HIP event
-                __threadfence_system();
-                __hip_atomic_store(gd.progress_host, st[5], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
+            const bool voided = (__float_as_uint(e1) & 0x7fffffffu) >= 0x7f800000u;
+            if (!bad) { step[0] = tcur; sA.x += loss * gd.hyper[4]; sA.y += 1.0f; }
+            else if (voided) sB.z += 1.0f;
+            else { sA.z += 1.0f; if (sA.w == 0.0f) sA.w = sB.y + 1.0f; }
+            sB.x = loss;
+            sB.y += 1.0f;
+            reinterpret_cast<float4*>(gd.stats)[0] = sA;
+            reinterpret_cast<float4*>(gd.stats)[1] = sB;
+            // pinned HOST word: the launching thread sees "step n is done" without a HIP event.  A RELAXED system-scope store: the host
+            // reads nothing but this word (it only needs to know that the step's kernels -- all earlier in the stream -- no longer read
+            // their input slot), so no system-scope release, i.e. no write-back of the whole L2, is wanted here
+            if (gd.progress_host) __hip_atomic_store(gd.progress_host, sB.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     __syncthreads();
     if (bad && s_last) {                     // every workgroup has finished reading: now the rejected gradients can go
         __threadfence();
         for (int k = 0; k < bk.count; ++k)
-            for (long long i = threadIdx.x; i < bk.n[k]; i += 256) bk.g[k][i] = 0.0f;
-        for (int i = threadIdx.x; i < gd.n_extra; i += 256) gd.extra[i] = 0.0f;
+            for (long long i = threadIdx.x; i < bk.n[k]; i += NT) bk.g[k][i] = 0.0f;
+        for (int i = threadIdx.x; i < gd.n_extra; i += NT) gd.extra[i] = 0.0f;
     }
 }
 
@@ -234,6 +266,7 @@ extern "C" int equigspr_adam_step_guarded(int32_t n_buckets, float* const* param
     using namespace eq;
     EQ_CHECK_ARG(n_buckets >= 1 && n_buckets <= 4 && params && grads && exp_avg && exp_avg_sq && sizes && step_dev && hyper_dev && stats_dev,
                  EQUIGSPR_EINVAL, "adam_step_guarded: 1..4 buckets, non-null arrays, hyper and stats on the device");
+    EQ_CHECK_ARG(((uintptr_t)stats_dev & 15) == 0, EQUIGSPR_EINVAL, "adam_step_guarded: stats_dev must be 16-byte aligned");
     EQ_CHECK_ARG(n_extra >= 0 && (n_extra == 0 || extra_dev), EQUIGSPR_EINVAL, "adam_step_guarded: extra_dev is NULL with n_extra > 0");
     AdamBuckets bk;
     bk.count = n_buckets;
@@ -244,12 +277,12 @@ extern "C" int equigspr_adam_step_guarded(int32_t n_buckets, float* const* param
         tot += sizes[k];
     }
     // every workgroup scans all `tot` gradients: bound the redundant reads (blocks * tot <= 16 M floats, i.e. 64 MB from L2)
-    long long blocks = ceil_div(tot, 256 * 4);
+    long long blocks = ceil_div(tot, kGuardThreads * 2);
     const long long cap = (16ll << 20) / (tot > 0 ? tot : 1);
     if (blocks > cap) blocks = cap;
-    blocks = blocks < 16 ? 16 : (blocks > 1024 ? 1024 : blocks);
+    blocks = blocks < 8 ? 8 : (blocks > 512 ? 512 : blocks);
     AdamGuard gd{hyper_dev, loss_dev, stats_dev, extra_dev, n_extra, progress_host};
-    hipLaunchKernelGGL(adam_guarded_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, bk, step_dev, gd);
+    hipLaunchKernelGGL(adam_guarded_kernel, dim3((int)blocks), dim3(kGuardThreads), 0, (hipStream_t)stream, bk, step_dev, gd);
     EQ_CHECK_LAUNCH("adam_step_guarded");
     return 0;
 }

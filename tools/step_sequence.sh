@@ -8,7 +8,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 # last occurrence of adam_kernel marks the end of a step; print the last full step
-ends = [i for i, n in enumerate(names) if "adam_kernel" in n]
+ends = [i for i, n in enumerate(names) if "adam_" in n]
 a, b = ends[-2] + 1, ends[-1] + 1
 t0 = int(rows[a]["Start_Timestamp"])
 for r in rows[a:b]:
