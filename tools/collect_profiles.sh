@@ -1,13 +1,14 @@
 #!/bin/bash
 # copy the judged summaries of one tools/profile_round.sh run from gpurun_out/<tag>/ into profiles/ (tracked)
-#   bash tools/collect_profiles.sh r03_v1
+#   bash tools/collect_profiles.sh r04_v1
 TAG=$1; SRC=gpurun_out/$TAG; DST=profiles
 cp $SRC/bench.json $DST/${TAG}_bench.json
 for w in b1 b16 b16_irreps c4shard c5; do
   cp $SRC/bench_$w.json $DST/${TAG}_bench_$w.json
   cp $SRC/kernel_stats_$w.csv $DST/${TAG}_kernel_stats_$w.csv
+  cp $SRC/pmc_$w.json $DST/${TAG}_pmc_$w.json
 done
-cp $SRC/pmc_edge_kernels.json $DST/${TAG}_pmc_edge_kernels.json
-mkdir -p $DST/${TAG}_pmc && cp $SRC/FETCH_SIZE_counter_collection.csv $SRC/WRITE_SIZE_counter_collection.csv $DST/${TAG}_pmc/
+cp $SRC/in_step.json $DST/${TAG}_in_step.json
+mkdir -p $DST/${TAG}_pmc && cp $SRC/*_counter_collection.csv $DST/${TAG}_pmc/
 cp $SRC/step_sequence.txt $DST/${TAG}_step_sequence.txt
 ls $DST | grep $TAG

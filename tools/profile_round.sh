@@ -1,35 +1,43 @@
 #!/bin/bash
-# Evidence run for profiles/: the default bench line, the B=16 / KITTI-shard / eval-sweep lines, the rocprofv3 kernel stats of
-# each of those commands, the two PMC passes (FETCH_SIZE / WRITE_SIZE collected separately, kernel-trace only) and the launch
-# sequence of one step.
-#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r02_v1'
-# Outputs land in gpurun_out/<tag>/ ; copy what should be judged into profiles/.
+# Evidence run for profiles/ (round 4 form): for the headline and every other BASELINE workload -- the bench line, the rocprofv3
+# kernel stats of the same command (hipGraph replays of the product loop), and the two PMC passes (FETCH_SIZE / WRITE_SIZE collected
+# separately, kernel-trace only, eager launches) summarised per kernel (edge AND node kernels); then the default (driver-form) line,
+# which quotes those files, and the launch sequence of one step.
+#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r04_v1'
+# Outputs land in gpurun_out/<tag>/ ; tools/collect_profiles.sh copies what should be judged into profiles/.
 set -u
 TAG=${1:-run}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-python3 "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
-tail -1 "$OUT/bench.json" | cut -c1-300
-stats() {  # name, bench args...
-  local name=$1; shift
+SPECS=""
+one() {  # name, edges per launch, feat, training(0|1), bench args...
+  local name=$1 edges=$2 feat=$3 training=$4; shift 4
   python3 "$ROOT/bench.py" --no-cpu-baseline --no-workloads "$@" > "$OUT/bench_$name.json" 2>> "$OUT/bench.err"
   rm -rf /tmp/prof_$name
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-workloads --min-seconds 0 "$@" > "$OUT/stats_$name.log" 2>&1
   cp "$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_$name.csv"
-  tail -1 "$OUT/bench_$name.json" | cut -c1-200
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/prof_${name}_$c
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof_${name}_$c -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-workloads --no-graph --min-seconds 0 "$@" --steps 5 --warmup 2 > "$OUT/pmc_${name}_$c.log" 2>&1
+    cp "$(find /tmp/prof_${name}_$c -name '*counter_collection.csv' | head -1)" "$OUT/${name}_${c}_counter_collection.csv"
+  done
+  python3 "$ROOT/tools/pmc_summary.py" "$OUT/${name}_FETCH_SIZE_counter_collection.csv" "$OUT/${name}_WRITE_SIZE_counter_collection.csv" "$OUT/pmc_$name.json" $edges $feat "$TAG" "$*" > /dev/null
+  local flags="$*"
+  SPECS="$SPECS $OUT/kernel_stats_$name.csv:$edges:$feat:$training:${flags// /+}"
+  tail -1 "$OUT/bench_$name.json" | cut -c1-160
 }
-stats b1 --steps 200 --warmup 20
-stats b16 --workload c3 --steps 60 --warmup 10
-stats c4shard --workload c4 --steps 40 --warmup 5
-stats c5 --workload c5 --steps 100 --warmup 10
-stats b16_irreps --workload c3 --edge-basis irreps --steps 60 --warmup 10
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/prof_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof_$c -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-workloads --no-graph --min-seconds 0 > "$OUT/pmc_$c.log" 2>&1
-  cp "$(find /tmp/prof_$c -name '*counter_collection.csv' | head -1)" "$OUT/${c}_counter_collection.csv"
-done
-python3 "$ROOT/tools/pmc_summary.py" "$OUT/FETCH_SIZE_counter_collection.csv" "$OUT/WRITE_SIZE_counter_collection.csv" "$OUT/pmc_edge_kernels.json" 81920 32 "$TAG" > /dev/null
+one b1 81920 32 1 --steps 200 --warmup 20
+one b16 1310720 32 1 --workload c3 --steps 60 --warmup 10
+one c4shard 1310720 33 1 --workload c4 --steps 40 --warmup 5
+one c5 524288 32 0 --workload c5 --steps 100 --warmup 10
+one b16_irreps 1310720 32 1 --workload c3 --edge-basis irreps --steps 60 --warmup 10
+python3 "$ROOT/tools/in_step_summary.py" "$OUT/in_step.json" "$TAG" $SPECS
+# the default line quotes the evidence above when it sits in profiles/: place this run's files there for the run (on the GPU box only)
+cp "$OUT/in_step.json" "$ROOT/profiles/${TAG}_in_step.json"
+for w in b1 b16 c4shard c5; do cp "$OUT/pmc_$w.json" "$ROOT/profiles/${TAG}_pmc_$w.json"; done
+python3 "$ROOT/bench.py" > "$OUT/bench.json" 2>> "$OUT/bench.err"
+tail -1 "$OUT/bench.json" | cut -c1-300
 bash "$ROOT/tools/step_sequence.sh" > "$OUT/step_sequence.txt" 2>&1
 ls -la "$OUT"
