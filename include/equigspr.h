@@ -246,6 +246,15 @@ int equigspr_head_eval_forward(const float* hs, const float* ht, const float* ra
                                float* wts, int64_t* top_idx, void* work, float* out_scalars, float* kabsch_R,
                                float* kabsch_t, float* kabsch_aux, void* stream);
 
+/* head_fuses_mlp: 1 when equigspr_head_forward (with its own Kabsch) runs the MLP blocks of this shape as extra grid columns of
+ * its pair launch -- only when the whole fused grid is resident on the current device at the launch's LDS size (occupancy query,
+ * cached), so that the columns' wait for their pair's selection rests on co-residency and not on dispatch order; 0: the MLP is its
+ * own launch.  head_wait_failures: how many such bounded waits have ever run out on this process's current device (they poison the
+ * affected logits and the loss with NaN; 0 on a healthy device, -1 on error); synchronises.  (train :677-796 has no counterpart:
+ * these describe the launch structure that replaces its ~230 ATen launches.) */
+int     equigspr_head_fuses_mlp(int32_t B, int32_t N, int32_t F, int32_t K);
+int64_t equigspr_head_wait_failures(void);
+
 /* ---- A13 (pose part) + optimizer: small fused training-step kernels ------------------------
  * pose_loss: replaces pose_loss() (src/3dmatch_train_egnn_with_batch.py:896-962): rot_loss[b] =
  * arccos(clamp((trace(R^T R_gt)-1)/2)), trans_loss[b] = arccos(clamp(cos(t, t_gt))).  R [B,9], t [B,3],

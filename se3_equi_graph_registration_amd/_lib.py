@@ -56,6 +56,8 @@ _SIGNATURES = {
     "equigspr_head_forward": (ctypes.c_int, [c_void_p] * 9 + [c_int32] * 6 + [c_void_p] * 16),
     "equigspr_head_backward": (ctypes.c_int, [c_void_p] * 25 + [c_int32] * 5 + [c_void_p] * 9),
     "equigspr_head_eval_forward": (ctypes.c_int, [c_void_p] * 11 + [c_int32] * 5 + [c_void_p] * 12),
+    "equigspr_head_fuses_mlp": (ctypes.c_int, [c_int32] * 4),
+    "equigspr_head_wait_failures": (c_int64, []),
     "equigspr_pose_loss_forward": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "equigspr_pose_loss_backward": (ctypes.c_int, [c_void_p] * 5 + [c_int32] + [c_void_p] * 3),
     "equigspr_adam_step": (ctypes.c_int, [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),

@@ -35,6 +35,10 @@ constexpr int kMaxIn = 128, kMaxH1 = 64, kMaxH2 = 32;     // MLP in = 2F, h1 = F
 #endif
 constexpr int kMaxN = 8192;          // head_pair_kernel keeps a pair's keys in LDS: 12 bytes per node
 
+// bounded waits that ran out (the MLP blocks riding in head_pair_kernel's launch wait for their pair's selection): cannot happen
+// while the launch is co-resident (the host only fuses then), kept as a safety net; read back by equigspr_head_wait_failures()
+__device__ unsigned g_head_wait_failures = 0u;
+
 __device__ __forceinline__ unsigned orderable(float v) {
     const unsigned b = __float_as_uint(v);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
@@ -721,6 +725,7 @@ __device__ __forceinline__ void head_mlp_block(
             int it = 0;
             while (__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && it < (1 << 22)) { __builtin_amdgcn_s_sleep(2); ++it; }
             wait_failed = it >= (1 << 22);   // bounded (seconds): never a hung GPU; a wait that ran out poisons this block's logits and the loss with NaN
+            if (wait_failed) atomicAdd(&g_head_wait_failures, 1u);      // ... and is counted, so that it can be told from a genuinely non-finite loss
             __threadfence();
         }
         __syncthreads();
@@ -1070,6 +1075,44 @@ extern "C" int64_t equigspr_head_work_bytes(int32_t B, int32_t N) {
     return (int64_t)eq::head_work(nullptr, B, N).bytes;
 }
 
+namespace eq {
+// workgroups of head_pair_kernel (256 threads, `smem` bytes of dynamic LDS) the current device holds at once; cached per device and
+// LDS size (the occupancy query costs ~10 us).  0 on error: the caller then does not fuse.
+static long long resident_pair_blocks(size_t smem) {
+    static std::mutex mu;
+    struct Entry { int dev; size_t smem; long long blocks; };
+    static Entry cache[16];
+    static int n_cache = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < n_cache; ++i)
+        if (cache[i].dev == dev && cache[i].smem == smem) return cache[i].blocks;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&head_pair_kernel), 256, smem) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    const long long blocks = (long long)per_cu * cus;
+    if (n_cache < 16) cache[n_cache++] = Entry{dev, smem, blocks};
+    return blocks;
+}
+}  // namespace eq
+
+extern "C" int equigspr_head_fuses_mlp(int32_t B, int32_t N, int32_t F, int32_t K) {
+    using namespace eq;
+    if (B < 1 || N < 1 || F < 1 || K < 1 || N > kMaxN) return 0;
+    const MlpDims md{2 * F, F, F / 2};
+    const size_t sm_sel = fwd_smem(N, next_pow2(N), K, md);
+    const size_t sm_fused = kMlpLdsBytes > sm_sel ? kMlpLdsBytes : sm_sel;
+    const long long fused_grid = (long long)B * (1 + ceil_div(N, 256) + ceil_div(K, kRowsPerBlock));
+    return (EQ_HEAD_FUSE_MLP && fused_grid <= 512 && fused_grid <= resident_pair_blocks(sm_fused)) ? 1 : 0;
+}
+
+extern "C" int64_t equigspr_head_wait_failures(void) {
+    unsigned v = 0u;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(eq::g_head_wait_failures), sizeof(v)) != hipSuccess) return -1;
+    return (int64_t)v;
+}
+
 extern "C" int equigspr_head_forward(const float* hs, const float* ht, const float* raw_hs, const float* raw_ht,
                                      const float* xs, const float* xt, const float* labels, const float* gt_pose,
                                      const float* mlp /* flat: w1,b1,w2,b2,w3,b3 */, int32_t B, int32_t N, int32_t F,
@@ -1096,9 +1139,15 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
     const int Npad = next_pow2(N);
     EQ_CHECK_ARG(!kabsch_aux || (kabsch_R && kabsch_t), EQUIGSPR_EINVAL, "head_forward: kabsch_R / kabsch_t are null");
     EQ_CHECK_ARG(!step_loss || kabsch_aux, EQUIGSPR_EINVAL, "head_forward: step_loss needs the head's own Kabsch (kabsch_aux)");
-    const bool fuse_mlp = EQ_HEAD_FUSE_MLP && kabsch_aux && (long long)B * (1 + ceil_div(N, 256) + ceil_div(K, kRowsPerBlock)) <= 512;
     const size_t sm_sel = fwd_smem(N, Npad, K, md);
-    const size_t sm = fuse_mlp && kMlpLdsBytes > sm_sel ? kMlpLdsBytes : sm_sel;
+    const size_t sm_fused = kMlpLdsBytes > sm_sel ? kMlpLdsBytes : sm_sel;
+    // The MLP blocks may ride in the pair kernel's launch only if the WHOLE fused grid is resident at once for the LDS this launch
+    // really asks for (N = 8 192: ~115 KB, one workgroup per CU): then every workgroup runs whatever the dispatch order is
+    // (MI355X_MICROARCH.md, contract [G]: HIP promises nothing about that order), and the consumers' wait for their pair's select
+    // block cannot starve it.  Otherwise the MLP is its own launch.
+    const long long fused_grid = (long long)B * (1 + ceil_div(N, 256) + ceil_div(K, kRowsPerBlock));
+    const bool fuse_mlp = EQ_HEAD_FUSE_MLP && kabsch_aux && fused_grid <= 512 && fused_grid <= resident_pair_blocks(sm_fused);
+    const size_t sm = fuse_mlp ? sm_fused : sm_sel;
     {   // the dynamic-LDS limit is a per-device function attribute: keep the high-water mark per device, under a lock
         static std::mutex mu;
         static size_t sm_set[64] = {0};
@@ -1117,9 +1166,9 @@ extern "C" int equigspr_head_forward(const float* hs, const float* ht, const flo
     const WeightsJob wj{sim, rsim, labels, wts, W.partC};
     // K2: per pair the select block and, beside it, the weight blocks -> (ticket) Kabsch moments + solve (= equigspr_kabsch_forward
     // on the weights, when kabsch_aux is given) and -- small batches with the head's own Kabsch -- the MLP blocks of K3 as further
-    // grid columns: they stage their weights while the select block works and wait for its selection (a workgroup is dispatched
-    // after every workgroup with a lower linear index, so the select block of a pair is always running or done when its MLP
-    // blocks spin; the bound keeps the whole grid co-resident anyway).  Larger batches: K3 as its own launch.
+    // grid columns: they stage their weights while the select block works and wait for its selection.  Forward progress rests on
+    // co-residency, not on dispatch order: fuse_mlp holds only when the whole fused grid fits the device at this launch's LDS size
+    // (resident_pair_blocks), so the select block a consumer waits for is running or done.  Larger batches: K3 as its own launch.
     hipLaunchKernelGGL(head_pair_kernel, dim3(1 + nwb + (fuse_mlp ? nblk : 0), B), dim3(256), sm, s, hs, ht, labels, sim, W.partA, W.nbp,
                        w1, b1, w2, b2, w3, b3, B, N, Npad, F, K, md, pos, reinterpret_cast<long long*>(top_idx), logits, a1_save, a2_save,
                        W.pair_f, W.pair_part, out_scalars, W.tickets, wj, nwb, xs, xt, kabsch_R, kabsch_t, kabsch_aux, gt_pose, step_loss,

@@ -182,6 +182,11 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> egnn_backward(const at::Tensor& p
                 "equigspr::egnn_backward: graph index sizes do not match N = ", n, ", E = ", e);
     TORCH_CHECK(gh.size(0) == n && gh.size(1) == out_nf && gx.size(0) == n && gx.size(1) == 3, "equigspr::egnn_backward: grad_h_out [N, out_nf], grad_x_out [N, 3]");
     if (edge_attr.has_value()) { need(*edge_attr, "edge_attr", at::kFloat, -1); TORCH_CHECK(edge_attr->numel() == e, "equigspr::egnn_backward: edge_attr must hold one value per edge"); }
+    // raw pointers of all of these go to the kernels under h's device guard: a tensor of another GPU would be an illegal access, not an error
+    same_device(h, params, "params"); same_device(h, row, "row"); same_device(h, col, "col"); same_device(h, rptr, "rptr");
+    same_device(h, rperm, "rperm"); same_device(h, rinv, "rinv"); same_device(h, cptr, "cptr"); same_device(h, cperm, "cperm");
+    same_device(h, saved, "saved"); same_device(h, gh, "grad_h_out"); same_device(h, gx, "grad_x_out");
+    if (edge_attr.has_value()) same_device(h, *edge_attr, "edge_attr");
     DeviceGuard guard(h.device());
     auto cfg = make_cfg(h, edge_attr.has_value(), hidden_nf, out_nf, n_layers, num_heads, edge_basis);
     const int64_t want = equigspr_egnn_param_count(&cfg);
@@ -206,6 +211,13 @@ struct EgnnFn : torch::autograd::Function<EgnnFn> {
                                                   const c10::optional<at::Tensor>& edge_attr, int64_t hidden_nf, int64_t out_nf, int64_t n_layers,
                                                   int64_t num_heads, int64_t edge_basis) {
         at::AutoDispatchBelowADInplaceOrView below;
+        // dtype / device before anything is detached or made contiguous (a CPU or other-GPU tensor must be a TORCH_CHECK error)
+        for (const auto* t : {&params, &h_, &x_}) {
+            TORCH_CHECK(t->is_cuda(), "equigspr::egnn_forward: params, h and x must live on the GPU (there is no CPU path)");
+            TORCH_CHECK(t->scalar_type() == at::kFloat, "equigspr::egnn_forward: params, h and x must be float32");
+        }
+        same_device(h_, params, "params"); same_device(h_, x_, "x"); same_device(h_, row, "row"); same_device(h_, col, "col");
+        if (edge_attr.has_value()) same_device(h_, *edge_attr, "edge_attr");
         const at::Tensor p = params.detach().contiguous(), h = h_.detach().contiguous(), x = x_.detach().contiguous();
         need(p, "params", at::kFloat, 1); need(h, "h", at::kFloat, 2); need(x, "x", at::kFloat, 2);
         need(row, "row", at::kInt, 1); need(col, "col", at::kInt, 1);

@@ -411,6 +411,22 @@ def _adjacent_grad_slice(params, total):
 HEAD_NO_SIM_LOSS = 1      # EQUIGSPR_HEAD_NO_SIM_LOSS
 
 
+def head_fuses_mlp(B: int, N: int, F: int, K: int) -> bool:
+    """Whether the training head runs the MLP blocks of this shape inside its pair launch (whole fused grid resident on the
+    current device) or as a launch of their own."""
+    return bool(_lib.lib().equigspr_head_fuses_mlp(int(B), int(N), int(F), int(K)))
+
+
+def head_wait_failures() -> int:
+    """Bounded in-launch waits of the fused head that ever ran out on the current device (synchronises; 0 on a healthy device).
+    The training loops check it when an epoch ends: such an event poisons the loss with NaN and must not pass for a genuinely
+    non-finite step."""
+    n = int(_lib.lib().equigspr_head_wait_failures())
+    if n < 0:
+        raise RuntimeError("equigspr_head_wait_failures: could not read the device counter")
+    return n
+
+
 def fused_pose_head(h_all, x_all, raw_hs, raw_ht, labels, gt_pose, topk, mlp_params, flags=0):
     """``h_all [2BN,F]``, ``x_all [2BN,3]`` = EGNN outputs for [src clouds..., tgt clouds...].  ``flags``: HEAD_NO_SIM_LOSS for
     the KITTI script's forward (corr_loss alone)."""

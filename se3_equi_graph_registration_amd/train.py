@@ -162,6 +162,16 @@ def shard_batch(batch, rank: int, world: int):
     return tuple(item[lo:hi] if isinstance(item, torch.Tensor) else item for item in batch), hi - lo, n_global
 
 
+def _check_head_waits(owner):
+    """A bounded in-launch wait of the fused head that ran out (csrc/head.hip) shows as a NaN loss: report it as what it is."""
+    seen = ops.head_wait_failures()
+    if seen > getattr(owner, "_head_wait_failures_seen", 0):
+        owner._head_wait_failures_seen = seen
+        raise RuntimeError(f"the fused pose head reported {seen} in-launch wait(s) that ran out (csrc/head.hip: MLP columns waiting for "
+                           "their pair's selection); the affected steps carried NaN losses and were not applied -- this indicates a "
+                           "device problem, not a non-finite loss of the model")
+
+
 class _Slot:
     """One set of static step inputs in HBM: a single fp32 packet ``[xyz (2,B,N,3) | feat (2,B,N,F) | labels (B,N) | gt_pose (B,16) |
     signal (4)]`` (one H2D copy per step) and the views the model reads.  ``signal[0]`` is 0, or NaN when this rank has nothing
@@ -569,6 +579,7 @@ class GraphedStep:
         for entry in pending_log:
             self._report(entry, epoch, skip_nonfinite)
         st = self.last_stats = adam.guard_stats()
+        _check_head_waits(self)
         self._check(st, epoch, skip_nonfinite)
         loss_sum, applied = st["loss_sum"], st["applied"]
         if self.world > 1:

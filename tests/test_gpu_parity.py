@@ -688,6 +688,41 @@ def test_head_mlp_columns_equal_standalone_mlp_launch(pk):
         assert torch.allclose(r8, R[lo:lo + 8], atol=1e-6) and torch.allclose(t8, t[lo:lo + 8], atol=1e-6)
 
 
+@pytest.mark.parametrize("B,N,K,expect_fused", [(5, 8192, 128, True), (10, 8192, 128, False), (16, 2048, 128, True), (20, 2048, 128, True),
+                                                  (21, 2048, 128, False)])
+def test_head_mlp_fusion_is_bounded_by_residency_and_replays_are_stable(pk, B, N, K, expect_fused):
+    """The MLP blocks ride in the pair kernel's launch only when the whole fused grid is resident at the launch's LDS size (at
+    N = 8192 that is one workgroup per CU: 5 pairs fit, 10 do not) -- forward progress then does not depend on dispatch order.  At
+    the limits: 200 forwards give finite, bit-identical logits / selections, and no in-launch wait ever runs out."""
+    from se3_equi_graph_registration_amd import ops
+    F = 32
+    assert ops.head_fuses_mlp(B, N, F, K) == expect_fused
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    h_all = (torch.randn(2 * B * N, F, generator=g) * 0.3).cuda()
+    x_all = (torch.rand(2 * B * N, 3, generator=g) * 3).cuda()
+    raw = torch.nn.functional.normalize(torch.randn(2, B, N, F, generator=g), dim=-1).cuda()
+    labels = (torch.rand(B, N, generator=g) < 0.5).float().cuda()
+    gt = torch.eye(4).repeat(B, 1, 1)
+    gt[:, :3, 3] = torch.rand(B, 3, generator=g) + 0.1
+    gt = gt.cuda()
+    torch.manual_seed(1)
+    mlp = torch.nn.Sequential(torch.nn.Linear(2 * F, F), torch.nn.ReLU(), torch.nn.Linear(F, F // 2), torch.nn.ReLU(), torch.nn.Linear(F // 2, 1)).cuda()
+    params = [mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, mlp[4].weight, mlp[4].bias]
+    before = ops.head_wait_failures()
+    ref = None
+    with torch.no_grad():
+        for it in range(200):
+            out = ops.fused_pose_head(h_all, x_all, raw[0], raw[1], labels, gt, K, params)
+            logits, top_idx, loss = out[4], out[5], out[2]          # out[2]: BCE + similarity-MSE (the arccos pose terms can be NaN on random poses)
+            if ref is None:
+                ref = (logits.clone(), top_idx.clone(), loss.clone())
+                assert bool(torch.isfinite(logits).all()) and bool(torch.isfinite(loss)) and float(logits.abs().max()) > 0
+            elif it % 10 == 0 or it == 199:
+                assert torch.equal(logits, ref[0]) and torch.equal(top_idx, ref[1]) and torch.equal(loss, ref[2]), it
+    torch.cuda.synchronize()
+    assert ops.head_wait_failures() == before
+
+
 # ------------------------------------------------------------------------------------ small fused training ops
 def test_fused_pose_loss_matches_aten(pk):
     g = torch.Generator().manual_seed(4)
