@@ -93,9 +93,12 @@ def parse(argv=None):
                     help="diagnostic: the pre-round-4 construction as the headline -- ONE fixed batch resident in HBM, the step replayed from a "
                          "hipGraph captured by this harness (no H2D, no distinct data); default = the package's own loop, train.GraphedStep")
     ap.add_argument("--no-fixed-pair", action="store_true", help="default run only: skip the `fixed_pair_replay` side measurement")
+    ap.add_argument("--morton", action="store_true",
+                    help="developer measurement: every synthetic pair's points re-ordered along a Morton curve of the source cloud (what a "
+                         "spatial re-ordering inside the EGNN could buy at most; DESIGN section 10)")
     a = ap.parse_args(argv)
     a.explicit_workload = a.workload is not None or a.batch != 1 or a.n != 2048 or a.k != 20 or a.layers != 4 or a.feat != 32 or \
-        a.heads != 1 or a.forward_only or a.edge_basis != "frames" or a.global_batch > 0 or a.dev_no_head or a.aten_head or a.fixed_pair_replay
+        a.heads != 1 or a.forward_only or a.edge_basis != "frames" or a.global_batch > 0 or a.dev_no_head or a.aten_head or a.fixed_pair_replay or a.morton
     if a.workload == "c3":
         a.batch = 16
     elif a.workload == "c4":
@@ -127,6 +130,8 @@ def build_step(pkg, args, dev, world):
     else:
         first = 1234 + rank * args.batch
     batch = pkg.synthetic_batch(first, args.batch, n=args.n, feat=args.feat, scale=scale, device=dev)
+    if args.morton:
+        batch = morton_order(batch)
     # one fused Adam launch over the flat bucket (two views: EGNN block, head; the per-tensor parameters are views of them); train :1412
     opt = pkg.FlatAdam([(egnn.flat_params, egnn.flat_grads), (dp.head.flat, dp.head.grad)], lr=1e-4)
 
@@ -184,6 +189,22 @@ def build_step(pkg, args, dev, world):
     return dict(model=model, egnn=egnn, dp=dp, batch=batch, fwd_bwd=fwd_bwd, zero=zero, opt_step=opt_step, restore=restore)
 
 
+def morton_order(batch):
+    """Re-order the points of every pair (source, target, descriptors, labels alike) along the Morton curve of the source cloud."""
+    src = batch["src"]
+    q = ((src - src.amin(dim=1, keepdim=True)) / (src.amax(dim=1, keepdim=True) - src.amin(dim=1, keepdim=True) + 1e-9) * 1023).long().clamp_(0, 1023)
+    code = torch.zeros(src.shape[:2], dtype=torch.long, device=src.device)
+    for bit in range(10):
+        for ax in range(3):
+            code |= ((q[..., ax] >> bit) & 1) << (3 * bit + ax)
+    perm = code.argsort(dim=1)
+    out = dict(batch)
+    for key in ("src", "tgt", "feat_src", "feat_tgt"):
+        out[key] = torch.gather(batch[key], 1, perm[..., None].expand(-1, -1, batch[key].shape[-1])).contiguous()
+    out["labels"] = torch.gather(batch["labels"], 1, perm).contiguous()
+    return out
+
+
 def uses_product_loop(args):
     """Training workloads are timed through the package's loop (train.GraphedStep); inference and the developer variants keep the
     harness-side capture."""
@@ -220,6 +241,8 @@ def build_product(pkg, args, dev, world):
     for j in range(n_batches):
         first = 1234 + (j if strong else rank * n_batches + j) * per_step
         b = pkg.synthetic_batch(first, per_step, n=args.n, feat=args.feat, scale=(3.0, 3.0, 3.0))
+        if args.morton:
+            b = morton_order(b)
         ring.append((b["corr"], b["labels"], b["src"], b["tgt"], b["feat_src"], b["feat_tgt"], b["gt_pose"]))
     lo = shard_range(args.global_batch, rank, world)[0] if strong else 0
     batch = {k: v[lo:lo + args.batch].to(dev) for k, v in zip(("corr", "labels", "src", "tgt", "feat_src", "feat_tgt", "gt_pose"), ring[0])}

@@ -281,6 +281,124 @@ std::tuple<at::Tensor, at::Tensor> egnn_forward_autograd(const at::Tensor& param
     auto out = EgnnFn::apply(params, h, x, row, col, edge_attr, hidden_nf, out_nf, n_layers, num_heads, edge_basis);
     return {out[0], out[1]};
 }
+
+// ---- one E_GCL layer through the dispatcher (egcl_forward / egcl_backward; reference E_GCL.forward, train :280-289).
+// A layer is a one-layer EGNN with identity embeddings: the composite op builds that parameter block out of ATen ops around the
+// caller's layer block, so autograd reaches `layer_params`, `h` and `x` through egnn_forward's own autograd kernel.
+at::Tensor one_layer_block(const at::Tensor& layer_params, int64_t F, bool has_attr, int64_t num_heads, int64_t edge_basis) {
+    equigspr_egnn_config cfg{(int32_t)F, (int32_t)F, (int32_t)F, has_attr ? 1 : 0, 1, (int32_t)num_heads, (int32_t)edge_basis};
+    const int64_t total = equigspr_egnn_param_count(&cfg), off = equigspr_egnn_layer_offset(&cfg, 0);
+    TORCH_CHECK(total > 0, "equigspr::egcl_forward: unsupported layer configuration (hidden_nf ", F, ", heads ", num_heads, "): ", equigspr_last_error());
+    TORCH_CHECK(layer_params.dim() == 1 && layer_params.numel() == total - off,
+                "equigspr::egcl_forward: the layer block has ", layer_params.numel(), " floats, hidden_nf ", F, " with ", num_heads, " head(s) needs ",
+                total - off);
+    TORCH_CHECK(off == 2 * (F * F + F), "equigspr::egcl_forward: unexpected parameter-block layout");
+    auto eye = at::eye(F, layer_params.options()).reshape({-1});
+    auto zero = at::zeros({F}, layer_params.options());
+    return at::cat({eye, zero, eye, zero, layer_params});          // [embedding_in | embedding_out | gcl_0] (include/equigspr.h)
+}
+std::tuple<at::Tensor, at::Tensor> egcl_forward(const at::Tensor& layer_params, const at::Tensor& h, const at::Tensor& x, const at::Tensor& row,
+                                                const at::Tensor& col, const c10::optional<at::Tensor>& edge_attr, int64_t num_heads, int64_t edge_basis) {
+    TORCH_CHECK(h.dim() == 2, "equigspr::egcl_forward: h must be [N, hidden_nf]");
+    const int64_t F = h.size(1);
+    auto block = one_layer_block(layer_params, F, edge_attr.has_value(), num_heads, edge_basis);
+    static auto op = c10::Dispatcher::singleton().findSchemaOrThrow("equigspr::egnn_forward", "")
+                         .typed<std::tuple<at::Tensor, at::Tensor>(const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&,
+                                                                    const c10::optional<at::Tensor>&, int64_t, int64_t, int64_t, int64_t, int64_t)>();
+    return op.call(block, h, x, row, col, edge_attr, F, F, 1, num_heads, edge_basis);
+}
+// egcl_backward(layer_params, h, x, row, col, edge_attr?, grad_h_out, grad_x_out, heads, basis) -> (grad_layer_params, grad_h, grad_x):
+// the layer's vector-Jacobian product as an explicit op (re-runs the training-form forward, then equigspr_egnn_backward)
+std::tuple<at::Tensor, at::Tensor, at::Tensor> egcl_backward(const at::Tensor& layer_params, const at::Tensor& h, const at::Tensor& x,
+                                                             const at::Tensor& row, const at::Tensor& col, const c10::optional<at::Tensor>& edge_attr,
+                                                             const at::Tensor& gh, const at::Tensor& gx, int64_t num_heads, int64_t edge_basis) {
+    at::AutoGradMode grad_on(true);
+    auto p = layer_params.detach().clone().requires_grad_(true), hh = h.detach().clone().requires_grad_(true), xx = x.detach().clone().requires_grad_(true);
+    auto out = egcl_forward(p, hh, xx, row, col, edge_attr, num_heads, edge_basis);
+    auto g = torch::autograd::grad({std::get<0>(out), std::get<1>(out)}, {p, hh, xx}, {gh, gx}, /*retain_graph=*/false, /*create_graph=*/false,
+                                   /*allow_unused=*/true);
+    auto or_zero = [](const at::Tensor& t, const at::Tensor& like) { return t.defined() ? t : at::zeros_like(like); };
+    return {or_zero(g[0], p), or_zero(g[1], hh), or_zero(g[2], xx)};
+}
+
+// ---- pose head and losses (inference forms; the training head's autograd node lives in the Python package, ops.py::_HeadFn)
+// head_eval_forward(h_all [2BN,F], x_all [2BN,3], raw_hs, raw_ht [B,N,Fr], raw_xs, raw_xt [B,N,3], labels [B,N], gt_pose [B,4,4], mlp, K)
+//   -> (R [B,3,3], t [B,3], equi_loss, weights [B,N], top_idx [B,K])        the evaluation pair model after the EGNN (eval :687-818)
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor> head_eval_forward(
+    const at::Tensor& h_all, const at::Tensor& x_all, const at::Tensor& raw_hs, const at::Tensor& raw_ht, const at::Tensor& raw_xs,
+    const at::Tensor& raw_xt, const at::Tensor& labels, const at::Tensor& gt_pose, const at::Tensor& mlp, int64_t K) {
+    need(h_all, "h_all", at::kFloat, 2); need(x_all, "x_all", at::kFloat, 2); need(raw_hs, "raw_h_src", at::kFloat, 3); need(raw_ht, "raw_h_tgt", at::kFloat, 3);
+    need(raw_xs, "raw_x_src", at::kFloat, 3); need(raw_xt, "raw_x_tgt", at::kFloat, 3); need(labels, "labels", at::kFloat, 2);
+    need(gt_pose, "gt_pose", at::kFloat, 3); need(mlp, "mlp", at::kFloat, 1);
+    const int64_t B = raw_hs.size(0), N = raw_hs.size(1), Fr = raw_hs.size(2), F = h_all.size(1);
+    TORCH_CHECK(h_all.size(0) == 2 * B * N && x_all.size(0) == 2 * B * N && x_all.size(1) == 3 && raw_ht.sizes() == raw_hs.sizes() &&
+                    raw_xs.size(0) == B && raw_xs.size(1) == N && raw_xs.size(2) == 3 && raw_xt.sizes() == raw_xs.sizes() && labels.size(0) == B &&
+                    labels.size(1) == N && gt_pose.size(0) == B && gt_pose.size(1) == 4 && gt_pose.size(2) == 4,
+                "equigspr::head_eval_forward: shapes do not describe B pairs of N points");
+    TORCH_CHECK(K >= 1 && K <= N && F <= 64 && Fr <= 64 && N <= 8192 && mlp.numel() == equigspr_head_mlp_size((int32_t)F),
+                "equigspr::head_eval_forward: need 1 <= K <= N <= 8192, widths <= 64 and the MLP block Linear(2F,F)-ReLU-Linear(F,F/2)-ReLU-Linear(F/2,1)");
+    for (const at::Tensor* t : {&x_all, &raw_hs, &raw_ht, &raw_xs, &raw_xt, &labels, &gt_pose, &mlp}) same_device(h_all, *t, "an argument");
+    DeviceGuard guard(h_all.device());
+    auto fo = h_all.options();
+    auto sim = at::empty({B, N}, fo), sim0 = at::empty({B, N}, fo), cosv = at::empty({B, N}, fo), wts = at::empty({B, N}, fo);
+    auto pos = at::empty({B, N}, fo.dtype(at::kInt)), top_idx = at::empty({B, K}, fo.dtype(at::kLong));
+    auto work = at::empty({equigspr_head_work_bytes((int32_t)B, (int32_t)N) / 8 + 1}, fo.dtype(at::kDouble));
+    auto fin = at::empty({16}, fo), R = at::empty({B, 3, 3}, fo), t = at::empty({B, 3}, fo), aux = at::empty({B, EQUIGSPR_KABSCH_AUX}, fo);
+    const float* hs = h_all.data_ptr<float>();
+    const float* xs = x_all.data_ptr<float>();
+    check(equigspr_head_eval_forward(hs, hs + B * N * F, raw_hs.data_ptr<float>(), raw_ht.data_ptr<float>(), xs, xs + B * N * 3, raw_xs.data_ptr<float>(),
+                                     raw_xt.data_ptr<float>(), labels.data_ptr<float>(), gt_pose.data_ptr<float>(), mlp.data_ptr<float>(), (int32_t)B,
+                                     (int32_t)N, (int32_t)F, (int32_t)Fr, (int32_t)K, sim.data_ptr<float>(), sim0.data_ptr<float>(), cosv.data_ptr<float>(),
+                                     pos.data_ptr<int32_t>(), wts.data_ptr<float>(), top_idx.data_ptr<int64_t>(), work.data_ptr<double>(),
+                                     fin.data_ptr<float>(), R.data_ptr<float>(), t.data_ptr<float>(), aux.data_ptr<float>(), cur_stream(h_all)),
+          "head_eval_forward");
+    return {R, t, fin[1], wts, top_idx};
+}
+// pose_loss_forward(R [B,3,3], t [B,3], gt_pose [B,4,4]) -> (rot_loss [B], trans_loss [B]); pose_loss_backward -> (grad_R, grad_t)   (train :896-962)
+std::tuple<at::Tensor, at::Tensor> pose_loss_forward(const at::Tensor& R, const at::Tensor& t, const at::Tensor& gt_pose) {
+    need(R, "pred_rot", at::kFloat, 3); need(t, "pred_translation", at::kFloat, 2); need(gt_pose, "gt_pose", at::kFloat, 3);
+    const int64_t B = R.size(0);
+    TORCH_CHECK(R.size(1) == 3 && R.size(2) == 3 && t.size(0) == B && t.size(1) == 3 && gt_pose.size(0) == B && gt_pose.size(1) == 4 && gt_pose.size(2) == 4,
+                "equigspr::pose_loss_forward: need R [B,3,3], t [B,3], gt_pose [B,4,4]");
+    same_device(R, t, "pred_translation"); same_device(R, gt_pose, "gt_pose");
+    DeviceGuard guard(R.device());
+    auto rot = at::empty({B}, R.options()), tr = at::empty({B}, R.options());
+    check(equigspr_pose_loss_forward(R.data_ptr<float>(), t.data_ptr<float>(), gt_pose.data_ptr<float>(), (int32_t)B, rot.data_ptr<float>(),
+                                     tr.data_ptr<float>(), cur_stream(R)), "pose_loss_forward");
+    return {rot, tr};
+}
+std::tuple<at::Tensor, at::Tensor> pose_loss_backward(const at::Tensor& R, const at::Tensor& t, const at::Tensor& gt_pose, const at::Tensor& g_rot,
+                                                      const at::Tensor& g_trans) {
+    need(R, "pred_rot", at::kFloat, 3); need(t, "pred_translation", at::kFloat, 2); need(gt_pose, "gt_pose", at::kFloat, 3);
+    need(g_rot, "grad_rot_loss", at::kFloat, 1); need(g_trans, "grad_trans_loss", at::kFloat, 1);
+    const int64_t B = R.size(0);
+    TORCH_CHECK(t.size(0) == B && gt_pose.size(0) == B && g_rot.numel() == B && g_trans.numel() == B, "equigspr::pose_loss_backward: batch sizes differ");
+    for (const at::Tensor* q : {&t, &gt_pose, &g_rot, &g_trans}) same_device(R, *q, "an argument");
+    DeviceGuard guard(R.device());
+    auto gR = at::empty_like(R), gt = at::empty_like(t);
+    check(equigspr_pose_loss_backward(R.data_ptr<float>(), t.data_ptr<float>(), gt_pose.data_ptr<float>(), g_rot.data_ptr<float>(), g_trans.data_ptr<float>(),
+                                      (int32_t)B, gR.data_ptr<float>(), gt.data_ptr<float>(), cur_stream(R)), "pose_loss_backward");
+    return {gR, gt};
+}
+struct PoseLossFn : torch::autograd::Function<PoseLossFn> {
+    static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const at::Tensor& R, const at::Tensor& t, const at::Tensor& gt) {
+        at::AutoDispatchBelowADInplaceOrView below;
+        auto Rc = R.detach().contiguous(), tc = t.detach().contiguous(), gc = gt.detach().contiguous();
+        auto out = pose_loss_forward(Rc, tc, gc);
+        ctx->save_for_backward({Rc, tc, gc});
+        return {std::get<0>(out), std::get<1>(out)};
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list g) {
+        const auto sv = ctx->get_saved_variables();
+        const auto zero = at::zeros({sv[0].size(0)}, sv[0].options());
+        auto out = pose_loss_backward(sv[0], sv[1], sv[2], g[0].defined() ? g[0].contiguous() : zero, g[1].defined() ? g[1].contiguous() : zero);
+        return {std::get<0>(out), std::get<1>(out), at::Tensor()};
+    }
+};
+std::tuple<at::Tensor, at::Tensor> pose_loss_forward_autograd(const at::Tensor& R, const at::Tensor& t, const at::Tensor& gt) {
+    auto out = PoseLossFn::apply(R, t, gt);
+    return {out[0], out[1]};
+}
 }  // namespace
 
 TORCH_LIBRARY(equigspr, m) {
@@ -294,11 +412,21 @@ TORCH_LIBRARY(equigspr, m) {
           "int edge_basis=0) -> (Tensor, Tensor, Tensor)");
     m.def("weighted_kabsch_forward(Tensor src, Tensor tgt, Tensor weights) -> (Tensor, Tensor, Tensor)");
     m.def("weighted_kabsch_backward(Tensor src, Tensor tgt, Tensor weights, Tensor aux, Tensor grad_R, Tensor grad_t) -> (Tensor, Tensor, Tensor)");
+    // composite ops (ATen glue around egnn_forward: autograd follows): one E_GCL layer, reference E_GCL.forward train :280-289
+    m.def("egcl_forward(Tensor layer_params, Tensor h, Tensor x, Tensor row, Tensor col, Tensor? edge_attr, int num_heads=1, int edge_basis=0) "
+          "-> (Tensor, Tensor)", &egcl_forward);
+    m.def("egcl_backward(Tensor layer_params, Tensor h, Tensor x, Tensor row, Tensor col, Tensor? edge_attr, Tensor grad_h_out, Tensor grad_x_out, "
+          "int num_heads=1, int edge_basis=0) -> (Tensor, Tensor, Tensor)", &egcl_backward);
+    m.def("head_eval_forward(Tensor h_all, Tensor x_all, Tensor raw_h_src, Tensor raw_h_tgt, Tensor raw_x_src, Tensor raw_x_tgt, Tensor labels, "
+          "Tensor gt_pose, Tensor mlp, int K) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
+    m.def("pose_loss_forward(Tensor pred_rot, Tensor pred_translation, Tensor gt_pose) -> (Tensor, Tensor)");
+    m.def("pose_loss_backward(Tensor pred_rot, Tensor pred_translation, Tensor gt_pose, Tensor grad_rot_loss, Tensor grad_trans_loss) -> (Tensor, Tensor)");
 }
 
 TORCH_LIBRARY_IMPL(equigspr, Autograd, m) {
     m.impl("weighted_kabsch_forward", &weighted_kabsch_forward_autograd);
     m.impl("egnn_forward", &egnn_forward_autograd);
+    m.impl("pose_loss_forward", &pose_loss_forward_autograd);
 }
 
 TORCH_LIBRARY_IMPL(equigspr, CUDA, m) {       // the HIP backend key of a ROCm build of PyTorch
@@ -308,4 +436,7 @@ TORCH_LIBRARY_IMPL(equigspr, CUDA, m) {       // the HIP backend key of a ROCm b
     m.impl("egnn_backward", &egnn_backward);
     m.impl("weighted_kabsch_forward", &weighted_kabsch_forward);
     m.impl("weighted_kabsch_backward", &weighted_kabsch_backward);
+    m.impl("head_eval_forward", &head_eval_forward);
+    m.impl("pose_loss_forward", &pose_loss_forward);
+    m.impl("pose_loss_backward", &pose_loss_backward);
 }

@@ -10,6 +10,10 @@ HIP stream) and returns ``torch.ops.equigspr``:
     h_out, x_out = ops.egnn_forward(flat_params, h, x, row32, col32, None, 32, 32, 4, 1, 0)
     R, t, aux = ops.weighted_kabsch_forward(src, tgt, w)                 # train :726-758
     g_src, g_tgt, g_w = ops.weighted_kabsch_backward(src, tgt, w, aux, grad_R, grad_t)
+    h2, x2 = ops.egcl_forward(layer_block, h, x, row32, col32, edge_attr, num_heads, 0)     # one E_GCL (train :280-289), differentiable
+    g_layer, g_h, g_x = ops.egcl_backward(layer_block, h, x, row32, col32, edge_attr, grad_h, grad_x, num_heads, 0)
+    R, t, equi, weights, top_idx = ops.head_eval_forward(h_all, x_all, raw_hs, raw_ht, raw_xs, raw_xt, labels, gt_pose, mlp_block, 128)  # eval :687-818
+    rot_loss, trans_loss = ops.pose_loss_forward(R, t, gt_pose)          # train :896-962, differentiable; pose_loss_backward is its explicit VJP
 
 No CPU kernels are registered: calling an op with CPU tensors raises the dispatcher's "no backend" error."""
 import os

@@ -1396,3 +1396,67 @@ def test_torch_library_ops_match_the_ctypes_path(pk):
         ops.egnn_forward(m.flat_params, h, x, row32, col32, torch.ones(n * k, device="cuda"), 32, 32, 2, 5, 0)
     with pytest.raises(RuntimeError):
         ops.knn_graph(x.double(), k, True)
+
+
+def test_torch_library_layer_head_and_loss_ops(pk):
+    """The dispatcher ops SURVEY section 8(b) lists beyond the whole-model forward: one E_GCL layer (egcl_forward with autograd,
+    egcl_backward as an explicit op) against the package's stand-alone E_GCL; the evaluation pair model's head and the pose loss against
+    the ctypes path."""
+    from se3_equi_graph_registration_amd import torch_library
+    ops = torch_library.load()
+    g = torch.Generator().manual_seed(5)
+    n, k, F = 300, 7, 32
+    x = (torch.rand(n, 3, generator=g) * 2).cuda()
+    h = torch.randn(n, F, generator=g).cuda()
+    e = pk.knn_graph(x, k, loop=True)
+    row32, col32 = e[0].int().contiguous(), e[1].int().contiguous()
+    torch.manual_seed(2)
+    layer = pk.E_GCL(F, F, F, edges_in_d=1, num_heads=4).cuda()
+    ea = torch.rand(n * k, 1, generator=g).cuda()
+    hr, xr = h.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    h_ref, x_ref, _ = layer(hr, [e[0], e[1]], xr, ea)
+    gh, gx = torch.randn(n, F, generator=g).cuda(), torch.randn(n, 3, generator=g).cuda()
+    layer.zero_grad()
+    ((h_ref * gh).sum() + (x_ref * gx).sum()).backward()
+    flat = torch.cat([p.detach().reshape(-1) for p in layer.parameters()])
+    h_o, x_o = ops.egcl_forward(flat, h, x, row32, col32, ea.reshape(-1), 4, 0)
+    assert torch.equal(h_o, h_ref.detach()) and torch.equal(x_o, x_ref.detach())
+    gp, ghi, gxi = ops.egcl_backward(flat, h, x, row32, col32, ea.reshape(-1), gh, gx, 4, 0)
+    ref_gp = torch.cat([p.grad.reshape(-1) for p in layer.parameters()])
+    assert torch.allclose(gp, ref_gp, rtol=1e-5, atol=1e-6) and torch.allclose(ghi, hr.grad, rtol=1e-5, atol=1e-6) and torch.allclose(gxi, xr.grad, rtol=1e-5, atol=1e-6)
+    fp = flat.clone().requires_grad_(True)                      # autograd through the composite op reaches the layer block
+    h2, x2 = ops.egcl_forward(fp, h, x, row32, col32, ea.reshape(-1), 4, 0)
+    ((h2 * gh).sum() + (x2 * gx).sum()).backward()
+    assert torch.allclose(fp.grad, ref_gp, rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError, match="layer block"):
+        ops.egcl_forward(flat[:-1], h, x, row32, col32, ea.reshape(-1), 4, 0)
+    # pose loss: forward, explicit backward, autograd
+    B = 4
+    q, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g)); q = (q * torch.sign(torch.det(q))[:, None, None]).contiguous().cuda()
+    gq, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g)); gq = gq * torch.sign(torch.det(gq))[:, None, None]
+    pose = torch.eye(4).repeat(B, 1, 1); pose[:, :3, :3] = gq; pose[:, :3, 3] = torch.rand(B, 3, generator=g); pose = pose.cuda()
+    t = torch.rand(B, 3, generator=g).cuda()
+    rot, tr = ops.pose_loss_forward(q, t, pose)
+    rot2, tr2 = pk.pose_loss(q, t, pose)
+    assert torch.equal(rot, rot2) and torch.equal(tr, tr2)
+    qa, ta = q.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    r3, t3 = ops.pose_loss_forward(qa, ta, pose)
+    (r3.sum() + 2 * t3.sum()).backward()
+    gR, gt_ = ops.pose_loss_backward(q, t, pose, torch.ones(B, device="cuda"), torch.full((B,), 2.0, device="cuda"))
+    assert torch.equal(qa.grad, gR) and torch.equal(ta.grad, gt_)
+    # evaluation head against the package's fused evaluation head (same C entry)
+    Bp, N, K = 1, 512, 128
+    torch.manual_seed(3)
+    egnn = pk.EGNN(F, F, F, in_edge_nf=1, device="cuda", n_layers=1)
+    model = pk.CrossAttentionPoseRegression(egnn, num_nodes=N, hidden_nf=F, device="cuda", variant="eval").cuda().eval()
+    b = pk.synthetic_batch(77, Bp, n=N, feat=F, device="cuda")
+    graph = pk.build_pair_graph(b["src"], b["tgt"], 8)
+    with torch.no_grad():
+        out = model(b["feat_src"], b["src"], graph, None, b["feat_tgt"], b["tgt"], graph, None, b["corr"], b["labels"], b["gt_pose"])
+        h_all = torch.cat([out[4].reshape(N, F), out[6].reshape(N, F)]).contiguous()
+        x_all = torch.cat([out[5].reshape(N, 3), out[7].reshape(N, 3)]).contiguous()
+        mlp = torch.cat([p.detach().reshape(-1) for p in model.mlp.parameters()])
+        R, tt, equi, wts, top_idx = ops.head_eval_forward(h_all, x_all, b["feat_src"].contiguous(), b["feat_tgt"].contiguous(), b["src"].contiguous(),
+                                                         b["tgt"].contiguous(), b["labels"], b["gt_pose"], mlp, K)
+    assert torch.equal(R, out[0]) and torch.equal(tt, out[1]) and torch.equal(equi, out[3]) and torch.equal(top_idx, model.last_top_idx)
+    assert torch.equal(wts, model.last_weights)

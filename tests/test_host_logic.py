@@ -282,7 +282,8 @@ def test_torch_library_registration_loads_and_has_no_cpu_backend():
     ops = torch_library.load()
     assert ops.abi_version() == pk.lib().equigspr_abi_version()
     assert str(torch.ops.equigspr.knn_graph.default._schema) == "equigspr::knn_graph(Tensor x, int k, bool loop=True) -> Tensor"
-    for name in ("build_inverse_index", "egnn_forward", "weighted_kabsch_forward", "weighted_kabsch_backward"):
+    for name in ("build_inverse_index", "egnn_forward", "egnn_backward", "weighted_kabsch_forward", "weighted_kabsch_backward", "egcl_forward",
+                 "egcl_backward", "head_eval_forward", "pose_loss_forward", "pose_loss_backward"):
         assert hasattr(torch.ops.equigspr, name)
     with pytest.raises(NotImplementedError):
         ops.knn_graph(torch.rand(10, 3), 3, True)
