@@ -206,9 +206,46 @@ def morton_order(batch):
 
 
 def uses_product_loop(args):
-    """Training workloads are timed through the package's loop (train.GraphedStep); inference and the developer variants keep the
-    harness-side capture."""
-    return not (args.forward_only or args.fixed_pair_replay or args.dev_no_head or args.aten_head)
+    """Training workloads are timed through the package's loop (train.GraphedStep), the evaluation sweep through train.GraphedEval
+    (the body of train.evaluate_model); the plain inference forward and the developer variants keep the harness-side capture."""
+    if args.fixed_pair_replay or args.dev_no_head or args.aten_head:
+        return False
+    return (not args.forward_only) or (args.eval_head and args.batch == 1 and args.global_batch == 0)
+
+
+def build_product_eval(pkg, args, dev, world):
+    """The evaluation sweep as the package runs it: train.GraphedEval (what train.evaluate_model uses; reference eval :1150-1296) over a
+    ring of distinct synthetic HOST pairs -- graphs, EGNN forward, evaluation head AND the four metrics per pair, H2D inside."""
+    from se3_equi_graph_registration_amd import train
+    torch.manual_seed(0)
+    egnn = pkg.EGNN(args.feat, args.feat, args.feat, in_edge_nf=1, device=dev, n_layers=args.layers, num_heads=args.heads,
+                    edge_basis=args.edge_basis)
+    model = pkg.CrossAttentionPoseRegression(egnn, num_nodes=args.n, hidden_nf=args.feat, device=dev, variant="eval").to(dev)
+    model.eval()
+    egnn._ensure_flat()
+    from se3_equi_graph_registration_amd.dp import DataParallelStep
+    dp = DataParallelStep(model, egnn)
+    rank = dist.get_rank() if world > 1 else 0
+    n_batches = max(2, min(args.ring, 16))
+    ring = []
+    for j in range(n_batches):
+        b = pkg.synthetic_batch(1234 + rank * n_batches + j, 1, n=args.n, feat=args.feat, scale=(3.0, 3.0, 3.0))
+        ring.append((b["corr"], b["labels"], b["src"], b["tgt"], b["feat_src"], b["feat_tgt"], b["gt_pose"]))
+    batch = {k: v.to(dev) for k, v in zip(("corr", "labels", "src", "tgt", "feat_src", "feat_tgt", "gt_pose"), ring[0])}
+    stepper = train.GraphedEval(model, k=args.k, use_graphs=not args.no_graph)
+    pos = [0]
+    totals = {"applied": 0, "skipped": 0, "void": 0}
+
+    def run_steps(n):
+        def gen():
+            for _ in range(n):
+                yield ring[pos[0] % len(ring)]
+                pos[0] += 1
+        table = stepper.run(gen())
+        totals["applied"] += int(table.shape[0])
+
+    return dict(model=model, egnn=egnn, dp=dp, batch=batch, stepper=stepper, run_steps=run_steps, restore=lambda: None,
+                ring_pairs=len(ring), totals=totals, product=True, eval_loop=True)
 
 
 def build_product(pkg, args, dev, world):
@@ -658,9 +695,10 @@ def measure(pkg, args, dev, world, min_seconds):
     dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     product = uses_product_loop(args)
     if product:
-        S = build_product(pkg, args, dev, world)
+        S = build_product_eval(pkg, args, dev, world) if args.forward_only else build_product(pkg, args, dev, world)
         S["run_steps"](max(args.warmup, 2))          # the first step runs eagerly, the hipGraphs are captured right after it
-        used_graph, graph_mode = S["stepper"].graphs is not None, S["stepper"].graph_mode
+        used_graph = S["stepper"].graphs is not None
+        graph_mode = getattr(S["stepper"], "graph_mode", "one graph" if used_graph else "eager")
         if dist_on and not used_graph and not args.no_graph and not args.allow_eager:
             print("[bench] hipGraph capture failed on the multi-rank path", file=sys.stderr)
             raise SystemExit(3)
@@ -764,7 +802,12 @@ def entry_for(pkg, args, dev, world, rank, S, blocks, used_graph, graph_mode, fi
     cfg = {"workload": workload_text(args), "pairs_per_gpu": args.batch, "global_batch": n_pairs, "points": args.n, "k": args.k,
            "layers": args.layers, "edge_basis": args.edge_basis, "hipgraph": used_graph, "graph_mode": graph_mode,
            "parallelism": f"dp{world}", "params_finite": finite}
-    if S.get("product"):
+    if S.get("eval_loop"):
+        cfg.update({"loop": "train.GraphedEval = the per-pair body of train.evaluate_model (static input slots, one hipGraph per slot: kNN + index, "
+                            "EGNN forward, evaluation head, the four metrics of tools/evaluation_metrics.py; the metric table read back once)",
+                    "distinct_pairs_in_ring": S["ring_pairs"], "inputs": "host memory; packing + one H2D copy per pair INSIDE the timed region",
+                    "pairs_evaluated": S["totals"]["applied"]})
+    elif S.get("product"):
         cfg.update({"loop": "train.GraphedStep = the body of train.train_one_epoch (static input slots, one hipGraph per slot, "
                             "device-side non-finite guard; no host round trip per step)",
                     "distinct_pairs_in_ring": S["ring_pairs"], "inputs": "host memory; packing + one H2D copy per step INSIDE the timed region",

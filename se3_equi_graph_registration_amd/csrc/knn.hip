@@ -4,8 +4,9 @@
 // -> <= 128 candidates per lane held in VGPRs).  Selection is exact and deterministic:
 //   fast path : tau = k-th smallest of the 64 per-lane minima (an upper bound of the k-th
 //               distance), compact the (usually ~1.2k) candidates <= tau through LDS, rank them
-//               by counting on their (d2,index) keys, the k smallest write their output slots.
-//   slow path : k rounds of wave-wide min extraction (taken when more than 64 candidates
+//               by counting on their (d2,index) keys (one key per lane up to 64 candidates, two up to
+//               128), the k smallest write their output slots.
+//   slow path : k rounds of wave-wide min extraction (taken when more than 128 candidates
 //               tie under tau, e.g. heavily duplicated points; also forced by tests).
 // Both paths produce the (d2, index)-lexicographic order of oracle.knn_graph bit for bit.
 //
@@ -86,6 +87,21 @@ __device__ __forceinline__ int rank_by_counting(const u64* list, int cnt, int la
     return rank;
 }
 
+// 64 < cnt <= 128 compacted candidates (k = 32 of 64 lane minima leaves ~44 candidates on average and a tail beyond 64 in a few
+// queries of every other 8 192-point cloud -- each of which used to take the slow path, ~0.6 ms): lane l ranks keys l and l + 64.
+__device__ __forceinline__ void rank_by_counting2(const u64* list, int cnt, int lane, u64& k0, u64& k1, int& r0, int& r1) {
+    k0 = list[lane];                                    // cnt > 64: every lane has a first key
+    k1 = lane + 64 < cnt ? list[lane + 64] : ~0ull;
+    r0 = 0;
+    r1 = lane + 64 < cnt ? 0 : 128;
+    for (int j = 0; j < cnt; ++j) {                     // cnt is wave-uniform
+        const u64 a = list[j];
+        r0 += a < k0 ? 1 : 0;
+        r1 += a < k1 ? 1 : 0;
+    }
+}
+constexpr int kKnnList = 128;                           // compaction list entries per query
+
 // kLoop: the query itself is a candidate (loop=True, every reference call site); kFull: n == 64 NPL (no index guards)
 template <int NPL, bool kLoop, bool kFull>
 __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, int n_clouds, int n, int k,
@@ -93,7 +109,7 @@ __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, in
                                                  int* __restrict__ row32, int* __restrict__ col32,
                                                  int* __restrict__ row_hist, int* __restrict__ arrival, int force_slow) {
     static_assert(NPL % 2 == 0, "candidates are processed in pairs");
-    __shared__ u64 list[64];
+    __shared__ u64 list[kKnnList];
     const int lane = threadIdx.x;
     const int qg = blockIdx.x;                 // query id over all clouds
     const int cloud = qg / n;
@@ -129,17 +145,25 @@ __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, in
         const u64 mask = __ballot(pred);
         if (mask) {                                     // wave-uniform: most 64-candidate rows hold no candidate <= tau
             const int at = cnt + rank_in_mask(mask);
-            if (pred && at < 64) list[at] = pack_key(d[i], i * 64 + lane);
+            if (pred && at < kKnnList) list[at] = pack_key(d[i], i * 64 + lane);
             cnt += __popcll(mask);
         }
     }
-    const bool fast = (cnt <= 64) && !force_slow;   // wave-uniform
+    const bool fast = (cnt <= kKnnList) && !force_slow;   // wave-uniform
     int slot = lane;                                // output slot of this lane's out_idx
+    int slot2 = 128, out_idx2 = 0;                  // second (slot, index) of a lane when 64 < cnt <= 128
     if (fast) {
         __syncthreads();   // single-wave block: orders the LDS writes before the reads below
-        u64 key;
-        slot = rank_by_counting(list, cnt, lane, key);
-        out_idx = (int)(unsigned)(key & 0xffffffffu);
+        if (cnt <= 64) {
+            u64 key;
+            slot = rank_by_counting(list, cnt, lane, key);
+            out_idx = (int)(unsigned)(key & 0xffffffffu);
+        } else {
+            u64 k0, k1;
+            rank_by_counting2(list, cnt, lane, k0, k1, slot, slot2);
+            out_idx = (int)(unsigned)(k0 & 0xffffffffu);
+            out_idx2 = (int)(unsigned)(k1 & 0xffffffffu);
+        }
     } else {
         // ---- slow path: k rounds of "smallest key strictly greater than the previous one"
         u64 last = 0;
@@ -158,20 +182,23 @@ __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, in
             have_last = true;
         }
     }
-    if (slot < k) {
-        const size_t e = (size_t)q * k + slot;
+    auto emit = [&](int slot_, int idx_) {
+        if (slot_ >= k) return;
+        const size_t e = (size_t)q * k + slot_;
         const size_t epc = (size_t)n * k;
         if (edges) {
-            edges[(size_t)cloud * 2 * epc + e] = out_idx;
+            edges[(size_t)cloud * 2 * epc + e] = idx_;
             edges[(size_t)cloud * 2 * epc + epc + e] = q;
         }
-        if (row32) row32[(size_t)cloud * epc + e] = cloud * n + out_idx;
+        if (row32) row32[(size_t)cloud * epc + e] = cloud * n + idx_;
         if (col32) col32[(size_t)cloud * epc + e] = cloud * n + q;
         if (row_hist) {                                  // the key histogram build_csr(key = row) starts from; its old value = this edge's slot
-            const int slot_in_row = atomicAdd(&row_hist[cloud * n + out_idx], 1);
+            const int slot_in_row = atomicAdd(&row_hist[cloud * n + idx_], 1);
             if (arrival) arrival[(size_t)cloud * epc + e] = slot_in_row;
         }
-    }
+    };
+    emit(slot, out_idx);
+    emit(slot2, out_idx2);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -191,7 +218,7 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
                                                         int* __restrict__ col32, int* __restrict__ row_hist,
                                                         int* __restrict__ arrival, int force_slow) {
     __shared__ float tile[kKnnTile * 3];
-    __shared__ u64 list[4 * kKnnQpw][64];
+    __shared__ u64 list[4 * kKnnQpw][kKnnList];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int bpc = (n + 4 * kKnnQpw - 1) / (4 * kKnnQpw);      // workgroups per cloud
     const int cloud = blockIdx.x / bpc;
@@ -276,7 +303,7 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
                 const u64 mask = __ballot(pred);
                 if (mask) {                                // wave-uniform: few of the 64-candidate steps hold a candidate <= tau
                     const int at = base[u] + rank_in_mask(mask);
-                    if (pred && at < 64) list[wv * kKnnQpw + u][at] = pack_key(vu, idx);
+                    if (pred && at < kKnnList) list[wv * kKnnQpw + u][at] = pack_key(vu, idx);
                     base[u] += __popcll(mask);
                 }
             }
@@ -287,11 +314,16 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
     for (int u = 0; u < kKnnQpw; ++u) {
         if (qi[u] >= n) continue;                          // wave-uniform
         const int cnt = base[u];
-        int out_idx = 0, slot = lane;
+        int out_idx = 0, slot = lane, out_idx2 = 0, slot2 = 128;
         if ((cnt <= 64) && (cnt >= k) && !force_slow) {
             u64 key;
             slot = rank_by_counting(list[wv * kKnnQpw + u], cnt, lane, key);
             out_idx = (int)(unsigned)(key & 0xffffffffu);
+        } else if ((cnt <= kKnnList) && (cnt >= k) && !force_slow) {
+            u64 k0, k1;
+            rank_by_counting2(list[wv * kKnnQpw + u], cnt, lane, k0, k1, slot, slot2);
+            out_idx = (int)(unsigned)(k0 & 0xffffffffu);
+            out_idx2 = (int)(unsigned)(k1 & 0xffffffffu);
         } else {
             // slow path: k rounds of "smallest key strictly greater than the previous one", distances recomputed from global
             u64 last = 0;
@@ -311,21 +343,24 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
                 have_last = true;
             }
         }
-        if (slot < k) {
+        auto emit = [&](int slot_, int idx_) {
+            if (slot_ >= k) return;
             const int q = qi[u];
-            const size_t e = (size_t)q * k + slot;
+            const size_t e = (size_t)q * k + slot_;
             const size_t epc = (size_t)n * k;
             if (edges) {
-                edges[(size_t)cloud * 2 * epc + e] = out_idx;
+                edges[(size_t)cloud * 2 * epc + e] = idx_;
                 edges[(size_t)cloud * 2 * epc + epc + e] = q;
             }
-            if (row32) row32[(size_t)cloud * epc + e] = cloud * n + out_idx;
+            if (row32) row32[(size_t)cloud * epc + e] = cloud * n + idx_;
             if (col32) col32[(size_t)cloud * epc + e] = cloud * n + q;
             if (row_hist) {
-                const int slot_in_row = atomicAdd(&row_hist[cloud * n + out_idx], 1);
+                const int slot_in_row = atomicAdd(&row_hist[cloud * n + idx_], 1);
                 if (arrival) arrival[(size_t)cloud * epc + e] = slot_in_row;
             }
-        }
+        };
+        emit(slot, out_idx);
+        emit(slot2, out_idx2);
     }
 }
 
@@ -354,8 +389,10 @@ __global__ void csr_fill_ranked_kernel(const int* __restrict__ key, const int* _
 // one wave per node, <= 64 entries sorted with a wave bitonic network, longer segments serially.  The same wave writes the
 // inverse permutation of its segment (inv[perm[p]] = p, optional) and hands the node's cursor word back as zero, so the
 // scratch array leaves build_csr the way it must enter it.
+constexpr int kCsrLongSeg = 1024;
 __global__ __launch_bounds__(256) void csr_sort_kernel(const int* __restrict__ ptr, int n_nodes, int* __restrict__ perm,
                                                        int* __restrict__ inv, int* __restrict__ scratch) {
+    __shared__ __attribute__((aligned(16))) int long_seg[4][kCsrLongSeg];
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= n_nodes) return;                     // wave-uniform
@@ -372,8 +409,31 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(const int* __restrict__ p
             if (len > 1) perm[lo + rank] = key;
             if (inv) inv[key] = lo + rank;
         }
+    } else if (len <= kCsrLongSeg) {
+        // a hub (a point in more than 64 neighbour lists: one or two per few clouds of uniform synthetic points, in-degree up to several
+        // hundred): the segment goes to LDS once and every lane ranks its entries by counting against broadcast reads, four keys per
+        // ds_read_b128 -- len^2 / 64 compares per lane.  (The first version insertion-sorted such a segment on ONE lane in global
+        // memory: 0.6 ms for an in-degree of ~150, 4 ms for ~450 -- found when the bench moved from one fixed pair to distinct pairs.)
+        int* sg = long_seg[threadIdx.x >> 6];
+        for (int a = lane; a < len; a += 64) sg[a] = perm[lo + a];
+        for (int a = len + lane; a < ((len + 3) & ~3); a += 64) sg[a] = 0x7fffffff;      // pad to whole int4 reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int4* sg4 = reinterpret_cast<const int4*>(sg);
+        const int n4 = (len + 3) >> 2;
+        for (int a = lane; a < len; a += 64) {
+            const int key = sg[a];
+            int rank = 0;
+            for (int t = 0; t < n4; ++t) {
+                const int4 v = sg4[t];
+                rank += (v.x < key ? 1 : 0) + (v.y < key ? 1 : 0) + (v.z < key ? 1 : 0) + (v.w < key ? 1 : 0);
+            }
+            perm[lo + rank] = key;
+            if (inv) inv[key] = lo + rank;
+        }
     } else {
-        if (lane == 0) {
+        if (lane == 0) {                                  // beyond the LDS budget (in-degree > 1024): serial, as a last resort
             for (int a = lo + 1; a < hi; ++a) {
                 const int v = perm[a];
                 int b = a - 1;

@@ -619,6 +619,184 @@ class GraphedStep:
         print(f"Epoch [{epoch + 1}], Batch [{batch_idx + 1}], Loss: {v[4]:.6f}")
 
 
+class GraphedEval:
+    """The per-pair body of ``evaluate_model`` (eval :1150-1296) -- kNN graphs, inverse index, EGNN forward, the evaluation pair
+    model's head, the four metrics of ``tools/evaluation_metrics.py`` -- captured once per input slot and replayed per pair; the same
+    input pipeline as ``GraphedStep`` (a producer thread packs each host batch into a pinned packet, one H2D copy per pair a step
+    ahead on a side stream, no device-side wait between streams).  A slot is reused once the event recorded behind its last replay
+    has completed (host-side wait).  ``run`` returns the ``[n_pairs, 5]`` float64 table (rotation error [deg], translation error
+    [cm], recall, precision, F1) on the host; batches of another shape than the first run eagerly, ``None`` batches are skipped."""
+
+    def __init__(self, model, k=16, tau=0.09, slots=3, use_graphs=True, depth=3):
+        self.model, self.k, self.tau = model, int(k), float(tau)
+        self.n_slots, self.depth, self.use_graphs = max(1, int(slots)), max(int(depth), 2), use_graphs
+        self.device = next(model.parameters()).device
+        if self.device.type != "cuda":
+            raise RuntimeError("GraphedEval: the model must live on the MI355X (HIP) device; this package has no CPU path")
+        self.stream, self.copy_stream = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
+        self.shape, self.slots, self.graphs, self.outs = None, [], None, []
+        self.steps_replayed = self.steps_eager = 0
+        self._capture_tried = False
+        self._pinned_free, self._pinned_shapes = queue.Queue(), set()
+
+    def _body(self, sl):
+        graph = build_pair_graph(sl.xyz[0], sl.xyz[1], self.k, loop=True)
+        out = self.model(sl.feat[0], sl.xyz[0], graph, None, sl.feat[1], sl.xyz[1], graph, None, None, sl.labels, sl.gt_pose)
+        m = evaluate_batch(out[0], out[1], sl.gt_pose, sl.xyz[0], sl.xyz[1], tau=self.tau)
+        return torch.stack([m["rotation_error"], m["translation_error"], m["recall"], m["precision"], m["f1"]], dim=1)
+
+    def _capture(self):
+        if not self.use_graphs:
+            return
+        graphs, outs, pool = [], [], None
+        try:
+            n_words = 2 * self.shape[0] * self.shape[1] + 1
+            for sl in self.slots:
+                ops.reserve_csr_scratch(self.device, n_words)
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    o = self._body(sl)
+                graphs.append(g); outs.append(o)
+                pool = g.pool()
+            self.graphs, self.outs = graphs, outs
+        except Exception as exc:
+            print(f"[GraphedEval] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
+            torch.cuda.synchronize(self.device)
+            self.graphs = None
+
+    @torch.no_grad()
+    def run(self, batches):
+        dev = self.device
+        caller = torch.cuda.current_stream(dev)
+        self.stream.wait_stream(caller)
+        was_training = self.model.training
+        self.model.eval()
+        q = queue.Queue(maxsize=self.depth)
+        stop, abandoned = object(), threading.Event()
+        pinned_free, pinned_shapes = self._pinned_free, self._pinned_shapes
+
+        def put(item):
+            while not abandoned.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def produce():
+            try:
+                for batch in batches:
+                    if batch is None or any(item is None for item in batch[1:]):
+                        continue
+                    batch = tuple(batch)
+                    shape = (int(batch[2].shape[0]), int(batch[2].shape[1]), int(batch[4].shape[-1]))
+                    if (not batch[2].is_cuda) and (self.shape is None or shape == self.shape):
+                        if shape not in pinned_shapes:
+                            pinned_shapes.add(shape)
+                            for _ in range(self.depth + 3):
+                                pinned_free.put(_Slot(*shape, dev, pinned=True))
+                        pk = None
+                        while pk is None and not abandoned.is_set():
+                            try:
+                                pk = pinned_free.get(timeout=0.1)
+                            except queue.Empty:
+                                continue
+                            if tuple(pk.xyz.shape[1:3]) + (pk.feat.shape[3],) != shape:
+                                pk = None
+                        if pk is None:
+                            return
+                        pk.fill(batch)
+                        item = pk
+                    else:
+                        item = batch
+                    if not put(item):
+                        return
+            except BaseException as e:
+                put(e)
+            put(stop)
+
+        switch_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(switch_interval, 1e-4))
+        th = threading.Thread(target=produce, daemon=True)
+        th.start()
+        rows, staged, last_idx = [], None, -1
+
+        def launch_staged():
+            nonlocal staged, last_idx
+            if staged is None:
+                return
+            idx, packet = staged
+            staged = None
+            self.copy_stream.synchronize()             # the H2D went out one iteration ago (host-side wait, no device-side one)
+            pinned_free.put(packet)
+            sl = self.slots[idx]
+            if self.graphs is None:
+                out = self._body(sl)
+                self.steps_eager += 1
+            else:
+                self.graphs[idx].replay()
+                out = self.outs[idx]
+                self.steps_replayed += 1
+            rows.append(out.clone())                   # the slot's output buffer is overwritten by its next replay
+            sl.done.record(self.stream)
+            last_idx = idx
+            if self.graphs is None and self.use_graphs and not self._capture_tried:
+                self._capture_tried = True
+                self.stream.synchronize()
+                self._capture()
+
+        try:
+            with torch.cuda.stream(self.stream):
+                while True:
+                    item = q.get()
+                    if isinstance(item, BaseException):
+                        raise item
+                    if item is stop:
+                        break
+                    if isinstance(item, _Slot) and (self.shape is None or self.shape == tuple(item.xyz.shape[1:3]) + (item.feat.shape[3],)):
+                        if self.shape is None:
+                            self.shape = tuple(item.xyz.shape[1:3]) + (item.feat.shape[3],)
+                            self.slots = [_Slot(*self.shape, dev) for _ in range(self.n_slots)]
+                            for sl in self.slots:
+                                sl.done = torch.cuda.Event()
+                        idx = ((staged[0] if staged is not None else last_idx) + 1) % self.n_slots
+                        if staged is not None and staged[0] == idx:
+                            launch_staged()
+                        sl = self.slots[idx]
+                        sl.done.synchronize()          # its last replay has finished reading it
+                        launch_staged()
+                        with torch.cuda.stream(self.copy_stream):
+                            sl.packet.copy_(item.packet, non_blocking=True)
+                        staged = (idx, item)
+                        if self.graphs is None:
+                            launch_staged()
+                    else:                                  # device tensors / another shape: the same body, eagerly
+                        launch_staged()
+                        if isinstance(item, _Slot):
+                            batch = (None, item.labels, item.xyz[0], item.xyz[1], item.feat[0], item.feat[1], item.gt_pose)
+                        else:
+                            batch = item
+                        B, N, F = int(batch[2].shape[0]), int(batch[2].shape[1]), int(batch[4].shape[-1])
+                        sl = _Slot(B, N, F, dev)
+                        sl.fill(batch)
+                        rows.append(self._body(sl))
+                        self.steps_eager += 1
+                        if isinstance(item, _Slot):
+                            self.stream.synchronize()
+                            pinned_free.put(item)
+                launch_staged()
+        finally:
+            abandoned.set()
+            th.join()
+            sys.setswitchinterval(switch_interval)
+            caller.wait_stream(self.stream)
+            self.model.train(was_training)
+        self.stream.synchronize()
+        return torch.cat(rows).cpu() if rows else torch.zeros(0, 5, dtype=torch.float64)
+
+
 def run_training_batches(model, batches, optimizer, step_loss, device, epoch=0, log_interval=10, skip_nonfinite=False,
                          shard_batches=True):
     """The body of ``train_one_epoch`` over an iterable of step batches; ``step_loss(model, batch) -> scalar loss``.
@@ -794,25 +972,38 @@ def load_checkpoint(checkpoint_path, pointnet=None, egnn=None, cross_attention=N
 
 
 @torch.no_grad()
-def evaluate_model(checkpoint_path, save_dir, model, dataloader, device, use_pointnet=False, k=16, tau=0.09, verbose=True):
+def evaluate_model(checkpoint_path, save_dir, model, dataloader, device, use_pointnet=False, k=16, tau=0.09, verbose=True, graph="auto"):
     """eval :1084-1296.  ``model`` is a ``CrossAttentionPoseRegression(variant="eval")`` (the evaluation head is defined for
     one pair at a time, eval :719); ``checkpoint_path=None`` evaluates the weights as they are.  Per pair the four numbers
     of ``tools/evaluation_metrics.py`` come from one kernel launch instead of a D2H copy + numpy; only the per-pair scalars
-    are read back.  Returns the reference's dict of averages and writes ``save_dir/evaluation_results.txt``."""
+    are read back.  Returns the reference's dict of averages and writes ``save_dir/evaluation_results.txt``.
+    ``graph="auto"`` (default, unless ``use_pointnet``): the per-pair body runs as captured hipGraphs over static input slots
+    (``GraphedEval``, kept on the model); ``False`` launches it eagerly; a ``GraphedEval`` instance is used as given."""
     os.makedirs(save_dir, exist_ok=True)
     if checkpoint_path is not None:
         load_checkpoint(checkpoint_path, None, model.egnn, model, optimizer=None, device=device)
     model.eval()
-    per_pair = []
-    for batch_idx, batch in enumerate(_device_batches(dataloader, device)):
-        corr, labels, xyz_0, xyz_1, feat_0, feat_1, gt_pose = batch
-        graph = build_pair_graph(xyz_0, xyz_1, k, loop=True)
-        if use_pointnet:
-            feat_0, feat_1 = _pointnet_features(graph, xyz_0, xyz_1)
-        out = model(feat_0, xyz_0, graph, None, feat_1, xyz_1, graph, None, corr, labels, gt_pose)
-        m = evaluate_batch(out[0], out[1], gt_pose, xyz_0, xyz_1, tau=tau)
-        per_pair.append(torch.stack([m["rotation_error"], m["translation_error"], m["recall"], m["f1"]], dim=1))
-    vals = torch.cat(per_pair).cpu().numpy() if per_pair else torch.zeros(0, 4).numpy()
+    if graph == "auto":
+        graph = not use_pointnet and os.environ.get("EQUIGSPR_EAGER_TRAINING") != "1"
+    if graph:
+        if not isinstance(graph, GraphedEval):
+            cache = model.__dict__.setdefault("_graphed_eval", {})
+            graph = cache.get((int(k), float(tau))) or cache.setdefault((int(k), float(tau)), GraphedEval(model, k=k, tau=tau))
+        table = graph.run(dataloader.loader if isinstance(dataloader, DeviceBatches) else dataloader)
+        vals = table[:, [0, 1, 2, 4]].numpy()
+    else:
+        per_pair = []
+        for batch_idx, batch in enumerate(_device_batches(dataloader, device)):
+            if batch is None or any(item is None for item in batch[1:]):
+                continue
+            corr, labels, xyz_0, xyz_1, feat_0, feat_1, gt_pose = batch
+            graph_ = build_pair_graph(xyz_0, xyz_1, k, loop=True)
+            if use_pointnet:
+                feat_0, feat_1 = _pointnet_features(graph_, xyz_0, xyz_1)
+            out = model(feat_0, xyz_0, graph_, None, feat_1, xyz_1, graph_, None, corr, labels, gt_pose)
+            m = evaluate_batch(out[0], out[1], gt_pose, xyz_0, xyz_1, tau=tau)
+            per_pair.append(torch.stack([m["rotation_error"], m["translation_error"], m["recall"], m["f1"]], dim=1))
+        vals = torch.cat(per_pair).cpu().numpy() if per_pair else torch.zeros(0, 4).numpy()
     if verbose:
         for i, (re, te, rc, f1) in enumerate(vals):
             print(f"Batch {i}: Rot Err: {re:.4f}, Trans Err: {te:.4f}, Recall: {rc:.4f}, F1: {f1:.4f}")

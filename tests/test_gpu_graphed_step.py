@@ -167,3 +167,30 @@ def test_multi_rank_code_path_on_a_one_rank_rccl_group(pk):
         assert r["equal"], (name, r)
         assert r["stats"]["applied"] == 6 and r["stats"]["void"] == 1 and r["stats"]["skipped"] == 0, (name, r)
         assert r["eager"] == 1 and r["replayed"] == 6, (name, r)
+
+
+def test_graphed_eval_equals_eager_eval(pk, tmp_path):
+    """train.GraphedEval (what evaluate_model runs by default): the per-pair metric table from captured graphs equals the eager
+    loop's bit for bit, incl. a pair of another size in the middle and a second run on the same object."""
+    from se3_equi_graph_registration_amd import train
+    torch.manual_seed(4)
+    egnn = pk.EGNN(32, 32, 32, in_edge_nf=1, device="cuda", n_layers=2)
+    model = pk.CrossAttentionPoseRegression(egnn, num_nodes=512, hidden_nf=32, device="cuda", variant="eval", topk=64).cuda()
+    pairs = [tuple(t for t in _batches(pk, 1, B=1, n=512, first=300 + i)[0]) for i in range(6)]
+    odd = _batches(pk, 1, B=1, n=384, first=400)[0]
+    seq = pairs[:3] + [odd, None] + pairs[3:]
+    eager = train.evaluate_model(None, str(tmp_path / "e"), model, seq, "cuda", k=8, verbose=False, graph=False)
+    ge = train.GraphedEval(model, k=8)
+    graphed = train.evaluate_model(None, str(tmp_path / "g"), model, seq, "cuda", k=8, verbose=False, graph=ge)
+    assert ge.steps_eager == 2 and ge.steps_replayed == 5 and ge.graphs is not None
+    assert eager == graphed
+    table = ge.run(pairs)
+    assert table.shape == (6, 5) and ge.steps_replayed == 11 and bool(torch.isfinite(table).all())
+    rows = []
+    for b in pairs:
+        g = pk.build_pair_graph(b[2].cuda(), b[3].cuda(), 8)
+        with torch.no_grad():
+            out = model(b[4].cuda(), b[2].cuda(), g, None, b[5].cuda(), b[3].cuda(), g, None, None, b[1].cuda(), b[6].cuda())
+        m = pk.evaluate_batch(out[0], out[1], b[6].cuda(), b[2].cuda(), b[3].cuda())
+        rows.append(torch.stack([m["rotation_error"], m["translation_error"], m["recall"], m["precision"], m["f1"]], dim=1))
+    assert torch.equal(table, torch.cat(rows).cpu())

@@ -138,6 +138,24 @@ def test_inverse_index_is_stable_counting_sort(pk):
     np.testing.assert_array_equal(dg.rinv.cpu().numpy()[:e], inv)    # written by the pass that orders the segments
 
 
+def test_knn_two_keys_per_lane_path_and_hub_segments_fullsize(pk):
+    """Distinct synthetic pairs exposed a cliff the single fixed bench pair never hit (round 4): queries whose tau leaves 65..128
+    candidates (k = 32 of 64 lane minima: a few per 8 192-point cloud, in three of eight seeds) took the slow path -- 0.6 ms each.
+    The two-keys-per-lane ranking must reproduce the exact slow path bit for bit on the very seeds that showed it (hub segments of
+    the index build: test_build_csr_scratch_contract_and_inverse)."""
+    from se3_equi_graph_registration_amd import ops
+    for seed, n, k in ((1236, 8192, 32), (1238, 8192, 32), (1239, 4096, 20)):
+        b = pk.synthetic_batch(seed, 1, n=n, device="cuda")
+        x = torch.cat([b["src"], b["tgt"]]).contiguous()
+        _, r_fast, c_fast = ops.knn_graph_batched(x, k, True, want_i64=False, want_i32=True)
+        _, r_slow, c_slow = ops.knn_graph_batched(x, k, True, want_i64=False, want_i32=True, force_slow_path=True)
+        assert torch.equal(r_fast, r_slow) and torch.equal(c_fast, c_slow), (seed, n, k)
+        graph = pk.build_pair_graph(b["src"], b["tgt"], k)
+        row = graph.row.cpu().numpy()
+        order = np.argsort(row, kind="stable")
+        np.testing.assert_array_equal(graph.rperm.cpu().numpy(), order)
+
+
 def test_build_csr_scratch_contract_and_inverse(pk):
     """ABI v3: build_csr also writes inv (same values as equigspr_invert_perm), accepts a scratch declared zero, and
     hands it back all-zero -- including hub segments longer than a wave (serial path) and isolated nodes."""
@@ -147,8 +165,10 @@ def test_build_csr_scratch_contract_and_inverse(pk):
     g = torch.Generator().manual_seed(5)
     n, e = 1500, 20000
     key = torch.randint(0, n - 100, (e,), generator=g)             # the last 100 nodes stay empty
-    key[:300] = 7                                                   # a 300-entry segment
+    key[:300] = 7                                                   # a 300-entry segment (hub: ranked from LDS by the whole wave)
     key[300:365] = 9                                                # 65: just past one wave
+    key[400:1424] = 11                                              # 1024: the largest segment of the LDS path ...
+    key[1500:2600] = 13                                             # ... and 1100: beyond it (serial last resort)
     key32 = key.to(torch.int32).cuda()
     order = np.argsort(key.numpy(), kind="stable")
     inv_ref = np.empty(e, dtype=np.int64)
