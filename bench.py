@@ -765,16 +765,18 @@ def workload_text(args):
 # own HIP-event roofline): name -> (BASELINE config, bench flags, steps per block).  One GPU: the four single-GPU shapes.  N GPUs: what
 # SURVEY 8(e) asks of the scaling run -- 16 pairs per GPU (weak), the KITTI batch of 64 pairs sharded over the ranks (strong), the
 # eval sweep as independent replicas.
+# (steps per block: a block is one call of the package's loop -- its start-up, the first batch's un-hidden H2D copy and its final
+# synchronize are inside the timed region, so a block is given enough steps to look like a stretch of an epoch, not like its first moments)
 EXTRA_WORKLOADS = (
-    ("c3_b16", "configs[2] shape: 3DMatch training, batch=16, the reference's edge inputs", ["--workload", "c3"], 20),
-    ("c3_b16_irreps", "configs[2]: 3DMatch training, batch=16, fused irrep-basis + message-passing kernel", ["--workload", "c3", "--edge-basis", "irreps"], 20),
-    ("c4_shard", "configs[3]: one GPU's shard of the KITTI batch (8 of 64 pairs x 4096 pts, F=33), training", ["--workload", "c4"], 15),
-    ("c5_eval", "configs[4]: 3DMatch eval sweep pair, 8192 pts, k=32, 8 layers, evaluation pair model", ["--workload", "c5"], 50),
+    ("c3_b16", "configs[2] shape: 3DMatch training, batch=16, the reference's edge inputs", ["--workload", "c3"], 80),
+    ("c3_b16_irreps", "configs[2]: 3DMatch training, batch=16, fused irrep-basis + message-passing kernel", ["--workload", "c3", "--edge-basis", "irreps"], 80),
+    ("c4_shard", "configs[3]: one GPU's shard of the KITTI batch (8 of 64 pairs x 4096 pts, F=33), training", ["--workload", "c4"], 60),
+    ("c5_eval", "configs[4]: 3DMatch eval sweep pair, 8192 pts, k=32, 8 layers, evaluation pair model", ["--workload", "c5"], 200),
 )
 EXTRA_WORKLOADS_MULTI = (
-    ("c3_b16", "configs[2] shape: 3DMatch training, 16 pairs per GPU (weak scaling)", ["--workload", "c3"], 20),
-    ("c4_global64", "configs[3]: KITTI pairs, 4096 pts, batch=64 sharded over the ranks (strong scaling)", ["--workload", "c4", "--global-batch", "64"], 10),
-    ("c5_eval", "configs[4]: 3DMatch eval sweep pair per GPU, 8192 pts, k=32, 8 layers, evaluation pair model (independent replicas)", ["--workload", "c5"], 50),
+    ("c3_b16", "configs[2] shape: 3DMatch training, 16 pairs per GPU (weak scaling)", ["--workload", "c3"], 80),
+    ("c4_global64", "configs[3]: KITTI pairs, 4096 pts, batch=64 sharded over the ranks (strong scaling)", ["--workload", "c4", "--global-batch", "64"], 20),
+    ("c5_eval", "configs[4]: 3DMatch eval sweep pair per GPU, 8192 pts, k=32, 8 layers, evaluation pair model (independent replicas)", ["--workload", "c5"], 200),
 )
 
 

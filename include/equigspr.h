@@ -69,6 +69,9 @@ typedef struct equigspr_graph {
 
 int         equigspr_abi_version(void);
 const char* equigspr_last_error(void);
+/* reads and thereby clears the HIP runtime's sticky per-thread "last error" (returns it): for a caller that has just handled a failed
+ * operation of its own -- an aborted hipGraph capture around these launches -- and goes on using the library (train.GraphedStep) */
+int         equigspr_clear_device_error(void);
 
 /* ---- parameter block ---------------------------------------------------------------
  * All EGNN parameters live in ONE flat fp32 buffer (and their gradients in another of the

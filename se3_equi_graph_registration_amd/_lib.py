@@ -30,6 +30,7 @@ class Graph(Structure):
 _SIGNATURES = {
     "equigspr_abi_version": (ctypes.c_int, []),
     "equigspr_last_error": (c_char_p, []),
+    "equigspr_clear_device_error": (ctypes.c_int, []),
     "equigspr_egnn_param_count": (c_int64, [POINTER(EgnnConfig)]),
     "equigspr_egnn_layer_offset": (c_int64, [POINTER(EgnnConfig), c_int32]),
     "equigspr_knn_graph": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,

@@ -39,6 +39,14 @@ extern "C" int equigspr_set_edge_chunk(int32_t chunk) {
 
 extern "C" int equigspr_abi_version(void) { return EQUIGSPR_ABI_VERSION; }
 extern "C" const char* equigspr_last_error(void) { return eq::g_err; }
+// The HIP runtime keeps the last error of the calling thread until someone reads it, and every launch wrapper here reads it
+// (EQ_CHECK_LAUNCH): after an ABORTED hipGraph capture (a collective that cannot be captured, say) the next, perfectly good launch
+// would report that stale error.  A caller that has handled such a failure clears it with this.  Returns the code it cleared.
+extern "C" int equigspr_clear_device_error(void) {
+    const hipError_t e = hipGetLastError();
+    (void)hipGetLastError();
+    return (int)e;
+}
 
 extern "C" int64_t equigspr_egnn_param_count(const equigspr_egnn_config* c) {
     if (!eq::config_supported(c)) return -1;

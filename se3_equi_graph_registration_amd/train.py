@@ -25,7 +25,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import _lib, ops
 from .datasets import DeviceBatches
 from .dp import DataParallelStep, shard_range
 from .graph import build_pair_graph
@@ -306,8 +306,12 @@ class GraphedStep:
         if not self.use_graphs:
             return
         n_words = 2 * self.shape[0] * self.shape[1] + 1
+        # only RCCL collectives can be captured (gloo moves device buffers through the host: a synchronous copy aborts the capture, and on
+        # this stack an aborted capture leaves PyTorch's capture stream unusable for the rest of the process -- so a mode that cannot
+        # work is not attempted; torch.cuda.Stream() objects come from a pool of 32 per device, a "fresh" one is no way around that)
+        can_capture_collective = self.graph_collectives and self.dist_on and dist.get_backend(self.group) == "nccl"
         modes = ["one graph"] if not self.dist_on else \
-            (["one graph (all-reduce captured)"] if self.graph_collectives else []) + ["two graphs + eager all-reduce"]
+            (["one graph (all-reduce captured)"] if can_capture_collective else []) + ["two graphs + eager all-reduce"]
         for mode in modes:
             graphs, pool, ok = [], None, True
             try:
@@ -331,6 +335,8 @@ class GraphedStep:
                 ok = False
                 print(f"[GraphedStep] hipGraph capture failed in mode '{mode}' ({type(exc).__name__}: {exc})", file=sys.stderr)
                 torch.cuda.synchronize(self.device)
+                _lib.lib().equigspr_clear_device_error()      # the aborted capture's error must not surface in the next launch
+                ops._CSR_SCRATCH.clear()                      # a scratch array the aborted capture adopted is in an unknown state
             if self.dist_on:                            # all ranks replay the same way or none does
                 ok = _all_ranks_have(ok, self.group, self.device)
             if ok:
@@ -663,6 +669,8 @@ class GraphedEval:
         except Exception as exc:
             print(f"[GraphedEval] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize(self.device)
+            _lib.lib().equigspr_clear_device_error()
+            ops._CSR_SCRATCH.clear()
             self.graphs = None
 
     @torch.no_grad()

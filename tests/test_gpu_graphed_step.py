@@ -194,3 +194,91 @@ def test_graphed_eval_equals_eager_eval(pk, tmp_path):
         m = pk.evaluate_batch(out[0], out[1], b[6].cuda(), b[2].cuda(), b[3].cuda())
         rows.append(torch.stack([m["rotation_error"], m["translation_error"], m["recall"], m["precision"], m["f1"]], dim=1))
     assert torch.equal(table, torch.cat(rows).cpu())
+
+
+CHILD2 = r"""
+import json, os, sys, torch
+import torch.distributed as dist
+sys.path.insert(0, %(root)r)
+rank = int(sys.argv[1])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%(port)r, RANK=str(rank), WORLD_SIZE="2")
+import se3_equi_graph_registration_amd as pk
+from se3_equi_graph_registration_amd import train
+torch.cuda.set_device(0)
+dist.init_process_group(backend="gloo", rank=rank, world_size=2)
+try:
+    probe = torch.ones(4, device="cuda")
+    dist.all_reduce(probe)
+    assert float(probe[0]) == 2.0
+except Exception as exc:
+    print("RESULT " + json.dumps({"skip": f"gloo cannot reduce device tensors here: {exc}"})); sys.exit(0)
+
+def model(seed):
+    torch.manual_seed(seed)
+    egnn = pk.EGNN(32, 32, 32, in_edge_nf=1, device="cuda", n_layers=2)
+    return pk.CrossAttentionPoseRegression(egnn, num_nodes=256, hidden_nf=32, device="cuda", topk=64).cuda()
+
+def batches(count, B):
+    out = []
+    for i in range(count):
+        b = pk.synthetic_batch(100 + B * i, B, n=256, feat=32)
+        out.append((b["corr"], b["labels"], b["src"].clone(), b["tgt"].clone(), b["feat_src"].clone(), b["feat_tgt"].clone(), b["gt_pose"]))
+    return out
+
+seq = batches(6, 4)                                   # global step batches of 4 pairs: 2 per rank
+bad = list(seq[2]); bad[6] = bad[6].clone(); bad[6][3, :3, :3] = float("nan")      # a non-finite pair in rank 1's shard only
+seq[2] = tuple(bad)
+lost = list(seq)
+if rank == 1:
+    lost[4] = None                                    # a batch only rank 1 cannot read
+res = {}
+for name, graph in (("eager", False), ("graphed", True)):
+    m = model(1); o = train.make_optimizer(m, lr=1e-3)
+    loss = train.train_one_epoch(m, lost, o, "cuda", 0, log_interval=0, k=8, skip_nonfinite=True, graph=graph)
+    w = torch.cat([m.egnn.flat_params, o.dp.head.flat])
+    both = [torch.zeros_like(w).cpu() for _ in range(2)]
+    dist.all_gather(both, w.cpu())
+    res[name] = {"loss": loss, "ranks_equal": bool(torch.equal(both[0], both[1])), "w": w.cpu(), "step": float(o.adam.step_dev[0])}
+    if graph:
+        st = train.graphed_step_for(m, o, k=8)
+        res[name].update({"mode": st.graph_mode, "stats": o.adam.guard_stats(), "replayed": st.steps_replayed, "eager_steps": st.steps_eager})
+out = {"ranks_equal": res["eager"]["ranks_equal"] and res["graphed"]["ranks_equal"],
+       "graphed_equals_eager": bool(torch.equal(res["eager"]["w"], res["graphed"]["w"])),
+       "max_diff": float((res["eager"]["w"] - res["graphed"]["w"]).abs().max()),
+       "loss": [res["eager"]["loss"], res["graphed"]["loss"]], "steps": [res["eager"]["step"], res["graphed"]["step"]],
+       "mode": res["graphed"]["mode"], "stats": res["graphed"]["stats"], "replayed": res["graphed"]["replayed"]}
+dist.barrier()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_two_ranks_share_one_gpu_over_gloo(pk):
+    """TWO real ranks (both on this GPU, gloo moving the device buckets through the host -- RCCL refuses two ranks on one device): the
+    sharded graphed loop against the sharded eager loop, with a non-finite pair in one rank's shard (both ranks must reject that step)
+    and a batch only one rank cannot read (the eager loop agrees by a collective to skip it, the graphed loop turns it into a void
+    step through the spare words of the gradient bucket).  Same weights on both ranks and in both loops, no deadlock."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    code = CHILD2 % {"root": ROOT, "port": "29647"}
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("the two-rank run did not finish (deadlock?)")
+        assert p.returncode == 0, e[-3000:]
+        line = [ln for ln in o.splitlines() if ln.startswith("RESULT ")]
+        assert line, e[-3000:]
+        outs.append(json.loads(line[-1][len("RESULT "):]))
+    if "skip" in outs[0]:
+        pytest.skip(outs[0]["skip"])
+    for r in outs:
+        assert r["ranks_equal"], r
+        assert r["graphed_equals_eager"], r
+        assert r["steps"] == [4.0, 4.0], r                       # six batches: one rejected (non-finite), one void / skipped
+        assert r["mode"] == "two graphs + eager all-reduce" and r["replayed"] >= 4, r
+        assert r["stats"]["applied"] == 4 and r["stats"]["skipped"] == 1 and r["stats"]["void"] == 1, r
+    assert outs[0]["loss"][0] == pytest.approx(outs[0]["loss"][1], rel=1e-5) and outs[0]["loss"] == outs[1]["loss"]
