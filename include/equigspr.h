@@ -302,6 +302,21 @@ int equigspr_so3_tensor_product_forward(const float* x, int32_t n_rows, int32_t 
                                         const float* w1, const float* b1, const float* w2, const float* b2,
                                         float* w1t_scratch, float* y, void* stream);
 
+/* ---- N4: typed irrep-basis message passing -----------------------------------------
+ * The layer the reference's basis (tools/basis.py::get_basis :153-205) was written for and its scripts never build: degree-0
+ * features f0 [N, C0i] and degree-1 features f1 [N, C1i, 3] (components in the basis' own real-SH order), pairwise kernels
+ * K = sum_J R_J(|r|) K_J(r / |r|) for the four (d_in, d_out) paths of degrees <= 1, messages from the features at `col`
+ * aggregated at `row` (train :252-256), plus a per-degree channel-mixing self-interaction.  Definition: oracle/irreps_oracle.py.
+ *   dist [E] = |x[row] - x[col]|;  radial [E, n_w] = the radial profile W_r2 SiLU(w_r1 dist + b_r1) + b_r2 (a plain GEMM: the
+ *   caller's library), laid out R00 [C0o,C0i] | R01 [C1o,C0i] | R10 [C0o,C1i] | R11 [C1o,C1i,3];  k00 [E], k01 [E,3], k10 [E,3],
+ *   k11 [E,3,3,3] = the '0,0' / '0,1' / '1,0' / '1,1' tensors of equigspr_sh_basis_forward (max_degree 1); on edges with dist = 0
+ *   the J >= 1 kernels count as zero;  col [E], rptr [N+1], rperm [E] = equigspr_build_csr(key = row);  1..32 channels per degree,
+ *   C0o + 3 C1o <= 128.  out0 [N, C0o], out1 [N, C1o, 3].  Deterministic (ascending edge order per node, no atomics).  Forward only. */
+int equigspr_irrep_conv_forward(const float* f0, const float* f1, const float* dist, const float* radial, const float* k00,
+                                const float* k01, const float* k10, const float* k11, const float* w_self0, const float* w_self1,
+                                const int32_t* col, const int32_t* rptr, const int32_t* rperm, int32_t n_nodes, int32_t n_edges,
+                                int32_t c0_in, int32_t c1_in, int32_t c0_out, int32_t c1_out, float* out0, float* out1, void* stream);
+
 /* ---- A17: gcnLayer (src/gcnLayer.py) ------------------------------------------------------------
  * build_graph :58-67 (_get_weights :28-46, get_normalize_adj :49-56): w_ij = exp(-d_ij^2 / sigma2), sigma2 =
  * mean_i(d(i, k-th neighbour))^2, no self loops, symmetrised by max, D^-1/2 A D^-1/2 -- returned as CSR by node

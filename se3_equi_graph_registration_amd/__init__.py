@@ -21,6 +21,7 @@ from . import sh  # noqa: F401  (A16: spherical harmonics / irrep basis)
 from .sh import (get_basis, get_spherical_harmonics, precompute_sh, basis_transformation_Q_J, irr_repr,  # noqa: F401
                  wigner_d_matrix, compose, J_dense)
 from .gcn import build_graph, GraphConvolution, GlobalPooling, KnnAdjacency  # noqa: F401
+from .irreps import IrrepConv, IrrepGNN, sh1_matrix  # noqa: F401  (N4: typed irrep-basis message passing)
 from . import datasets  # noqa: F401  (N3: pair-file formats, dataset classes, HBM-resident batches)
 from . import train  # noqa: F401  (train_one_epoch / validate / checkpoints in the reference layout)
 from .datasets import ThreeDMatchTrainVal, ThreeDMatchTest, KITTItrainVal, KITTItest, DeviceBatches  # noqa: F401
@@ -28,4 +29,4 @@ from .datasets import ThreeDMatchTrainVal, ThreeDMatchTest, KITTItrainVal, KITTI
 __all__ = ["EGNN", "E_GCL", "CrossAttentionPoseRegression", "knn_graph", "get_edges_batch", "get_edges_from_idx",
            "build_pair_graph", "DeviceGraph", "weighted_kabsch", "pose_loss", "registration_loss", "compute_losses", "egnn_equi_loss",
            "unsorted_segment_sum", "unsorted_segment_mean", "synthetic_pair", "synthetic_batch", "SO3TensorProductLayer", "FlatAdam", "build_graph", "GraphConvolution",
-           "GlobalPooling", "KnnAdjacency", "ThreeDMatchTrainVal", "ThreeDMatchTest", "KITTItrainVal", "KITTItest", "DeviceBatches"]
+           "GlobalPooling", "KnnAdjacency", "IrrepConv", "IrrepGNN", "ThreeDMatchTrainVal", "ThreeDMatchTest", "KITTItrainVal", "KITTItest", "DeviceBatches"]

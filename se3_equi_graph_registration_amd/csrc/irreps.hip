@@ -1,0 +1,139 @@
+// Typed irrep-basis message passing (SURVEY section 8(f) row N4 "proper": degree-0 AND degree-1 features carried through the layer,
+// the equivariant kernels K_J of tools/basis.py::get_basis :153-205 inside it).  The layer (definition: oracle/irreps_oracle.py):
+//
+//   m0[e, o]    = sum_i R00[e, o, i] K00[e] f0[col, i]  +  sum_i R10[e, o, i] (K10[e, :] . f1[col, i, :])
+//   m1[e, o, a] = sum_i R01[e, o, i] K01[e, a] f0[col, i]  +  sum_i sum_J R11[e, o, i, J] (K11[e, a, :, J] . f1[col, i, :])
+//   out0[n]     = W_s0 f0[n] + sum_{e: row = n} m0[e]            out1[n] = W_s1 f1[n] + sum_{e: row = n} m1[e]
+//
+// Division of labour: the radial profile R [E, n_w] = W_r2 SiLU(w_r1 |r| + b_r1) + b_r2 is a plain dense GEMM over all edges and
+// goes to the library (rocBLAS / hipBLASLt through ATen, MFMA); the basis tensors come from the existing SH kernels (csrc/sh.hip);
+// THIS kernel does what no library does: per edge the contraction of radial weights x basis x gathered features for both degrees,
+// and the aggregation at `row` -- a wave per destination node walking its incoming edges in ascending edge order (the inverse
+// index of the EGNN path: no atomics, the CPU scatter_add order, bitwise reproducible), the per-edge operands (gathered features,
+// basis, K.f contractions) in wave-private LDS, one output (o or (o, a)) per lane and accumulator.
+// Edges with r = 0 (self loops of knn_graph(..., loop=True)): the J >= 1 kernels are zero there (Y_J(0) is not covariant).
+#include "common.h"
+
+namespace eq {
+
+constexpr int kIrMaxC = 32;                    // channels per degree, in and out
+constexpr int kIrWaves = 4;
+
+struct IrrepConvArgs {
+    const float* f0; const float* f1; const float* dist;          // [N, C0i], [N, C1i, 3], [E]
+    const float* R;                                               // [E, n_w]: R00 | R01 | R10 | R11
+    const float* k00; const float* k01; const float* k10; const float* k11;      // [E], [E,3], [E,3], [E,3(out),3(in),3(J)]
+    const float* ws0; const float* ws1;                           // [C0o, C0i], [C1o, C1i]
+    const int* col; const int* rptr; const int* rperm;
+    int n_nodes, c0i, c1i, c0o, c1o;
+    float* out0; float* out1;                                     // [N, C0o], [N, C1o, 3]
+};
+
+__global__ __launch_bounds__(64 * kIrWaves) void irrep_conv_kernel(const IrrepConvArgs a) {
+    __shared__ float sm[kIrWaves][kIrMaxC + 3 * kIrMaxC + 40 + kIrMaxC + 9 * kIrMaxC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = blockIdx.x * kIrWaves + wv;
+    if (n >= a.n_nodes) return;                                   // wave-uniform
+    float* g0 = sm[wv];                        // f0[col, :]                       [C0i]
+    float* g1 = g0 + kIrMaxC;                  // f1[col, :, :]                    [C1i * 3]
+    float* kb = g1 + 3 * kIrMaxC;              // k00 | k01[3] | k10[3] | k11[27]  (J >= 1 parts zeroed on a self loop)
+    float* s1 = kb + 40;                       // K10 . f1[col, i]                 [C1i]
+    float* t1 = s1 + kIrMaxC;                  // K11[a, :, J] . f1[col, i]        [C1i][3 a][3 J]
+    const int c0i = a.c0i, c1i = a.c1i, c0o = a.c0o, c1o = a.c1o;
+    const int n_out = c0o + 3 * c1o;           // <= 128: two outputs per lane at most
+    const int o_r01 = c0o * c0i, o_r10 = o_r01 + c1o * c0i, o_r11 = o_r10 + c0o * c1i, n_w = o_r11 + c1o * c1i * 3;
+    float acc[2] = {0.0f, 0.0f};
+    const int lo = a.rptr[n], hi = a.rptr[n + 1];
+    for (int p = lo; p < hi; ++p) {
+        const int e = a.rperm[p];
+        const int c = a.col[e];
+        const float live = a.dist[e] > 0.0f ? 1.0f : 0.0f;
+        for (int t = lane; t < c0i; t += 64) g0[t] = a.f0[(size_t)c * c0i + t];
+        for (int t = lane; t < 3 * c1i; t += 64) g1[t] = a.f1[(size_t)c * 3 * c1i + t];
+        if (lane < 34) {
+            float v;
+            if (lane == 0) v = a.k00[e];
+            else if (lane < 4) v = a.k01[(size_t)e * 3 + lane - 1] * live;
+            else if (lane < 7) v = a.k10[(size_t)e * 3 + lane - 4] * live;
+            else { const int q = lane - 7; v = a.k11[(size_t)e * 27 + q] * ((q % 3) == 0 ? 1.0f : live); }      // [a][b][J]: J = q % 3
+            kb[lane] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int t = lane; t < c1i; t += 64) s1[t] = kb[4] * g1[3 * t] + kb[5] * g1[3 * t + 1] + kb[6] * g1[3 * t + 2];
+        for (int t = lane; t < 9 * c1i; t += 64) {
+            const int i = t / 9, aj = t - 9 * i, aa = aj / 3, J = aj - 3 * aa;
+            const float* k = kb + 7 + aa * 9 + J;                  // K11[aa][b][J], b stride 3
+            t1[t] = k[0] * g1[3 * i] + k[3] * g1[3 * i + 1] + k[6] * g1[3 * i + 2];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float* Re = a.R + (size_t)e * n_w;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int o = lane + 64 * u;
+            if (o >= n_out) break;
+            float m = 0.0f;
+            if (o < c0o) {
+                const float* r00 = Re + o * c0i;
+                const float* r10 = Re + o_r10 + o * c1i;
+                float s = 0.0f;
+                for (int i = 0; i < c0i; ++i) s = fmaf(r00[i], g0[i], s);
+                m = s * kb[0];
+                for (int i = 0; i < c1i; ++i) m = fmaf(r10[i], s1[i], m);
+            } else {
+                const int oo = (o - c0o) / 3, aa = (o - c0o) - 3 * oo;
+                const float* r01 = Re + o_r01 + oo * c0i;
+                const float* r11 = Re + o_r11 + oo * c1i * 3;
+                float s = 0.0f;
+                for (int i = 0; i < c0i; ++i) s = fmaf(r01[i], g0[i], s);
+                m = s * kb[1 + aa];
+                for (int i = 0; i < c1i; ++i) {
+                    const float* tt = t1 + 9 * i + 3 * aa;
+                    m = fmaf(r11[3 * i], tt[0], m);
+                    m = fmaf(r11[3 * i + 1], tt[1], m);
+                    m = fmaf(r11[3 * i + 2], tt[2], m);
+                }
+            }
+            acc[u] += m;
+        }
+        __builtin_amdgcn_wave_barrier();                          // the next edge overwrites the scratch
+    }
+    // self-interaction (channel mixing of the node's own features) + store
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int o = lane + 64 * u;
+        if (o >= n_out) break;
+        float v = acc[u];
+        if (o < c0o) {
+            for (int i = 0; i < c0i; ++i) v = fmaf(a.ws0[o * c0i + i], a.f0[(size_t)n * c0i + i], v);
+            a.out0[(size_t)n * c0o + o] = v;
+        } else {
+            const int oo = (o - c0o) / 3, aa = (o - c0o) - 3 * oo;
+            for (int i = 0; i < c1i; ++i) v = fmaf(a.ws1[oo * c1i + i], a.f1[((size_t)n * c1i + i) * 3 + aa], v);
+            a.out1[((size_t)n * c1o + oo) * 3 + aa] = v;
+        }
+    }
+}
+
+}  // namespace eq
+
+extern "C" int equigspr_irrep_conv_forward(const float* f0, const float* f1, const float* dist, const float* radial, const float* k00,
+                                           const float* k01, const float* k10, const float* k11, const float* w_self0,
+                                           const float* w_self1, const int32_t* col, const int32_t* rptr, const int32_t* rperm,
+                                           int32_t n_nodes, int32_t n_edges, int32_t c0_in, int32_t c1_in, int32_t c0_out, int32_t c1_out,
+                                           float* out0, float* out1, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(f0 && f1 && dist && radial && k00 && k01 && k10 && k11 && w_self0 && w_self1 && col && rptr && rperm && out0 && out1,
+                 EQUIGSPR_EINVAL, "irrep_conv_forward: null argument");
+    EQ_CHECK_ARG(n_nodes >= 1 && n_edges >= 0, EQUIGSPR_EINVAL, "irrep_conv_forward: n_nodes >= 1, n_edges >= 0");
+    EQ_CHECK_ARG(c0_in >= 1 && c1_in >= 1 && c0_out >= 1 && c1_out >= 1 && c0_in <= kIrMaxC && c1_in <= kIrMaxC && c0_out <= kIrMaxC &&
+                     c1_out <= kIrMaxC, EQUIGSPR_ENOTSUP, "irrep_conv_forward: 1..%d channels per degree", kIrMaxC);
+    EQ_CHECK_ARG(c0_out + 3 * c1_out <= 128, EQUIGSPR_ENOTSUP, "irrep_conv_forward: c0_out + 3 c1_out must be <= 128 (two outputs per lane)");
+    IrrepConvArgs a{f0, f1, dist, radial, k00, k01, k10, k11, w_self0, w_self1, col, rptr, rperm, n_nodes, c0_in, c1_in, c0_out, c1_out, out0, out1};
+    hipLaunchKernelGGL(irrep_conv_kernel, dim3(ceil_div(n_nodes, kIrWaves)), dim3(64 * kIrWaves), 0, (hipStream_t)stream, a);
+    EQ_CHECK_LAUNCH("irrep_conv_forward");
+    return 0;
+}

@@ -1,0 +1,152 @@
+"""Typed irrep-basis message passing ("irrep-basis message passing proper").
+
+The reference ships the equivariant weight basis (``tools/basis.py::get_basis`` :153-205, ``tools/irr_repr.py``,
+``tools/spherical_harmonics.py``; here ``sh.get_basis``) and no layer that uses it -- its scripts run the frame-vector EGNN.
+``IrrepConv`` is that layer for degrees 0 and 1: degree-0 features ``f0 [N, C0]`` and degree-1 features ``f1 [N, C1, 3]`` are BOTH
+carried through, every (d_in, d_out) path is a pairwise kernel ``sum_J R_J(|r_ij|) K_J(r_ij / |r_ij|)`` built from the basis tensors,
+messages are computed from the features at ``col`` and aggregated at ``row`` (the reference's conventions, train :252-256,:270-278),
+and a per-degree channel mixing acts as self-interaction.  The definition (and the parity statement: unpinned by construction, pinned
+by SO(3) covariance) is ``oracle/irreps_oracle.py``.
+
+MI355X-first split of the work: the radial profile over all edges is one plain GEMM -> the library (ATen / rocBLAS, MFMA); the
+basis tensors come from the SH kernels of ``csrc/sh.hip``; the contraction radial x basis x gathered features for both degrees and
+the atomic-free aggregation are ONE hand-written launch (``csrc/irreps.hip``).  Forward in HIP; under grad the backward re-runs the
+layer in device ops (``ops.hip_forward_aten_backward``) -- gradients with respect to the features and the weights (the geometry,
+i.e. ``x`` and the basis, is treated as constant, like the HIP ``get_basis`` itself).
+
+Degree-1 components are in the basis' own real-SH order (m = -1, 0, 1, polar axis on input component 1): ``Y_1(x) = A x / |x|`` with
+``A = sh1_matrix()``; in this convention ``A = -sqrt(3 / 4 pi) * I``, so a Cartesian vector ``v`` enters as ``A @ v`` and rotates
+with the plain rotation matrix.  No CPU path.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import _lib, sh
+from .ops import DeviceGraph, _need, _p, _stream, hip_forward_aten_backward
+
+
+def sh1_matrix(device="cuda", dtype=torch.float32) -> torch.Tensor:
+    """``A [3, 3]`` with ``Y_1(x) = A x / |x|`` in the basis' component order (evaluated by the HIP SH kernel, not hard-coded)."""
+    eye = torch.eye(3, dtype=torch.float32, device=device)
+    y = sh.precompute_sh(sh.get_spherical_from_cartesian(eye), 1)[1].reshape(3, 3)       # rows: Y_1(e_k)
+    return y.T.contiguous().to(dtype)
+
+
+class IrrepConv(nn.Module):
+    """``IrrepConv(c0_in, c1_in, c0_out, c1_out, hidden=32)``; ``forward(f0, f1, x, edges) -> (out0 [N, c0_out], out1 [N, c1_out, 3])``.
+
+    ``edges``: ``[row, col]`` (LongTensors / ``[2, E]``) or a ``DeviceGraph``.  1..32 channels per degree, ``c0_out + 3 c1_out <= 128``."""
+
+    def __init__(self, c0_in, c1_in, c0_out, c1_out, hidden=32, device="cuda"):
+        super().__init__()
+        for c in (c0_in, c1_in, c0_out, c1_out):
+            if not 1 <= c <= 32:
+                raise NotImplementedError("IrrepConv: 1..32 channels per degree (the HIP kernel's LDS layout)")
+        if c0_out + 3 * c1_out > 128:
+            raise NotImplementedError("IrrepConv: c0_out + 3 c1_out must be <= 128")
+        self.c0_in, self.c1_in, self.c0_out, self.c1_out, self.hidden = c0_in, c1_in, c0_out, c1_out, hidden
+        self.n_w = c0_out * c0_in + c1_out * c0_in + c0_out * c1_in + c1_out * c1_in * 3
+        self.radial = nn.Sequential(nn.Linear(1, hidden), nn.SiLU(), nn.Linear(hidden, self.n_w))
+        self.self0 = nn.Linear(c0_in, c0_out, bias=False)
+        self.self1 = nn.Linear(c1_in, c1_out, bias=False)
+        self.to(device)
+
+    # ---- pieces shared by the HIP forward and its device-op twin
+    @staticmethod
+    def _graph(edges, n_nodes):
+        if isinstance(edges, DeviceGraph):
+            return edges
+        row, col = edges[0], edges[1]
+        return DeviceGraph.from_edge_lists([torch.stack([row, col]).to(torch.int64)], n_nodes, need_col_index=False)
+
+    @staticmethod
+    def _geometry(x, graph):
+        """|r_ij| and the four degree <= 1 basis tensors of every edge (HIP: csrc/sh.hip); constants of the layer."""
+        row, col = graph.row[:graph.n_edges].long(), graph.col[:graph.n_edges].long()
+        r = (x[row] - x[col]).contiguous()
+        dist = r.norm(dim=-1).contiguous()
+        K = sh.get_basis(r, 1)
+        E = graph.n_edges
+        return dist, K["0,0"].reshape(E).contiguous(), K["0,1"].reshape(E, 3).contiguous(), K["1,0"].reshape(E, 3).contiguous(), \
+            K["1,1"].reshape(E, 27).contiguous()
+
+    def _radial(self, dist):
+        return self.radial(dist[:, None])                        # [E, n_w]: Linear(1, H) -> SiLU -> Linear(H, n_w): one library GEMM
+
+    def _hip(self, f0, f1, radial, ws0, ws1, dist, k00, k01, k10, k11, graph):
+        n = graph.n_nodes
+        out0 = torch.empty(n, self.c0_out, dtype=torch.float32, device=f0.device)
+        out1 = torch.empty(n, self.c1_out, 3, dtype=torch.float32, device=f0.device)
+        _lib.check(_lib.lib().equigspr_irrep_conv_forward(_p(f0), _p(f1), _p(dist), _p(radial.contiguous()), _p(k00), _p(k01), _p(k10), _p(k11),
+                                                          _p(ws0.contiguous()), _p(ws1.contiguous()), _p(graph.col), _p(graph.rptr),
+                                                          _p(graph.rperm), n, graph.n_edges, self.c0_in, self.c1_in, self.c0_out,
+                                                          self.c1_out, _p(out0), _p(out1), _stream()), "irrep_conv_forward")
+        return torch.cat([out0, out1.reshape(n, -1)], dim=1)        # one tensor for the autograd wrapper
+
+    def _aten(self, f0, f1, radial, ws0, ws1, dist, k00, k01, k10, k11, graph):
+        """The same layer in device ops (backward recompute only; follows oracle/irreps_oracle.py line by line)."""
+        row, col = graph.row[:graph.n_edges].long(), graph.col[:graph.n_edges].long()
+        c0o, c0i, c1o, c1i = self.c0_out, self.c0_in, self.c1_out, self.c1_in
+        o = 0
+        R00 = radial[:, o:o + c0o * c0i].view(-1, c0o, c0i); o += c0o * c0i
+        R01 = radial[:, o:o + c1o * c0i].view(-1, c1o, c0i); o += c1o * c0i
+        R10 = radial[:, o:o + c0o * c1i].view(-1, c0o, c1i); o += c0o * c1i
+        R11 = radial[:, o:o + c1o * c1i * 3].view(-1, c1o, c1i, 3)
+        live = (dist > 0).to(f0.dtype)[:, None]
+        k01, k10 = k01 * live, k10 * live
+        k11 = k11.view(-1, 3, 3, 3)
+        k11 = torch.cat([k11[..., :1], k11[..., 1:] * live[:, :, None, None]], dim=-1)
+        g0, g1 = f0[col], f1[col]
+        s1 = torch.einsum("eb,eib->ei", k10, g1)
+        m0 = torch.einsum("eoi,ei->eo", R00, g0) * k00[:, None] + torch.einsum("eoi,ei->eo", R10, s1)
+        t1 = torch.einsum("eabj,eib->eiaj", k11, g1)
+        m1 = torch.einsum("eoi,ei,ea->eoa", R01, g0, k01) + torch.einsum("eoij,eiaj->eoa", R11, t1)
+        out0 = (f0 @ ws0.T).index_add(0, row, m0)
+        out1 = torch.einsum("oi,nia->noa", ws1, f1).index_add(0, row, m1)
+        return torch.cat([out0, out1.reshape(out1.shape[0], -1)], dim=1)
+
+    def forward(self, f0, f1, x, edges):
+        f0 = _need(f0.contiguous().float(), "f0", torch.float32, 2)
+        f1 = _need(f1.contiguous().float(), "f1", torch.float32, 3)
+        x = _need(x.contiguous().float(), "x", torch.float32, 2)
+        n = x.shape[0]
+        if f0.shape != (n, self.c0_in) or f1.shape != (n, self.c1_in, 3) or x.shape[1] != 3:
+            raise RuntimeError(f"IrrepConv: need f0 [N, {self.c0_in}], f1 [N, {self.c1_in}, 3], x [N, 3]")
+        graph = self._graph(edges, n)
+        with torch.no_grad():
+            dist, k00, k01, k10, k11 = self._geometry(x.detach(), graph)
+        radial = self._radial(dist)                              # differentiable (ATen): the radial weights get their gradients here
+        ws0, ws1 = self.self0.weight, self.self1.weight
+        rest = (dist, k00, k01, k10, k11, graph)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (f0, f1, radial, ws0, ws1)):
+            out = hip_forward_aten_backward(self._hip, self._aten, (f0, f1, radial, ws0, ws1), rest)
+        else:
+            out = self._hip(f0, f1, radial.detach(), ws0.detach(), ws1.detach(), *rest)
+        return out[:, :self.c0_out], out[:, self.c0_out:].reshape(n, self.c1_out, 3)
+
+
+class IrrepGNN(nn.Module):
+    """A small stack of ``IrrepConv`` layers with gated non-linearities (norm-gated degree-1 channels, SiLU on degree 0) -- the typed
+    counterpart of ``EGNN``: ``forward(h [N, c0], v [N, c1, 3] or None, x [N, 3], edges) -> (h', v')``.  ``v = None`` starts the
+    degree-1 channels at zero (they are then created from the geometry by the 0 -> 1 path)."""
+
+    def __init__(self, c0_in, c0_hidden, c0_out, c1=8, n_layers=2, hidden=32, device="cuda"):
+        super().__init__()
+        dims0 = [c0_in] + [c0_hidden] * (n_layers - 1) + [c0_out]
+        self.c1 = c1
+        self.layers = nn.ModuleList([IrrepConv(dims0[i], c1, dims0[i + 1], c1, hidden, device) for i in range(n_layers)])
+        self.gates = nn.ModuleList([nn.Linear(dims0[i + 1], c1) for i in range(n_layers - 1)]).to(device)
+
+    def forward(self, h, v, x, edges):
+        n = x.shape[0]
+        if v is None:
+            v = torch.zeros(n, self.c1, 3, dtype=torch.float32, device=x.device)
+        graph = IrrepConv._graph(edges, n)
+        for i, layer in enumerate(self.layers):
+            h, v = layer(h, v, x, graph)
+            if i + 1 < len(self.layers):
+                v = v * torch.sigmoid(self.gates[i](h))[:, :, None]       # invariant gate: keeps degree 1 covariant
+                h = torch.nn.functional.silu(h)
+        return h, v
