@@ -5,8 +5,8 @@ The reference ships the equivariant weight basis (``tools/basis.py::get_basis`` 
 ``IrrepConv`` is that layer for degrees 0 and 1: degree-0 features ``f0 [N, C0]`` and degree-1 features ``f1 [N, C1, 3]`` are BOTH
 carried through, every (d_in, d_out) path is a pairwise kernel ``sum_J R_J(|r_ij|) K_J(r_ij / |r_ij|)`` built from the basis tensors,
 messages are computed from the features at ``col`` and aggregated at ``row`` (the reference's conventions, train :252-256,:270-278),
-and a per-degree channel mixing acts as self-interaction.  The definition (and the parity statement: unpinned by construction, pinned
-by SO(3) covariance) is ``oracle/irreps_oracle.py``.
+and a per-degree channel mixing acts as self-interaction.  The definition is written out in DESIGN.md section 2 and in the test
+infrastructure (parity unpinned by construction -- there is no reference layer -- pinned by SO(3) covariance).
 
 MI355X-first split of the work: the radial profile over all edges is one plain GEMM -> the library (ATen / rocBLAS, MFMA); the
 basis tensors come from the SH kernels of ``csrc/sh.hip``; the contraction radial x basis x gathered features for both degrees and
@@ -86,7 +86,7 @@ class IrrepConv(nn.Module):
         return torch.cat([out0, out1.reshape(n, -1)], dim=1)        # one tensor for the autograd wrapper
 
     def _aten(self, f0, f1, radial, ws0, ws1, dist, k00, k01, k10, k11, graph):
-        """The same layer in device ops (backward recompute only; follows oracle/irreps_oracle.py line by line)."""
+        """The same layer in device ops (backward recompute only; the layer definition line by line)."""
         row, col = graph.row[:graph.n_edges].long(), graph.col[:graph.n_edges].long()
         c0o, c0i, c1o, c1i = self.c0_out, self.c0_in, self.c1_out, self.c1_in
         o = 0
