@@ -257,6 +257,14 @@ class GraphedStep:
         self.last_stats = None             # FlatAdam.guard_stats() of the last run()
         self._pinned_free, self._pinned_shapes = queue.Queue(), set()
 
+    def reset(self):
+        """Drop the captured graphs and the static slots; the next ``run`` starts over (eager first step, new capture).  Call it after
+        changing anything a captured graph has baked in: which parameters require gradients, the model's structure or ``variant``, the
+        process group.  (Weights, optimizer state and hyper-parameters are read at replay time: loading a checkpoint or stepping a
+        scheduler needs no reset.)"""
+        self.shape, self.slots, self.graphs, self.graph_mode = None, [], None, "eager"
+        self._capture_tried, self._last_idx = False, 0
+
     # ------------------------------------------------------------------ the step itself (eager or under capture)
     def _spare_words(self):
         """The unused words between the EGNN block and the head parameters of the joint gradient bucket (dp.DataParallelStep):

@@ -282,3 +282,22 @@ def test_two_ranks_share_one_gpu_over_gloo(pk):
         assert r["mode"] == "two graphs + eager all-reduce" and r["replayed"] >= 4, r
         assert r["stats"]["applied"] == 4 and r["stats"]["skipped"] == 1 and r["stats"]["void"] == 1, r
     assert outs[0]["loss"][0] == pytest.approx(outs[0]["loss"][1], rel=1e-5) and outs[0]["loss"] == outs[1]["loss"]
+
+
+def test_kitti_loss_mode_width_33_through_the_graphed_loop(pk):
+    """The KITTI script's configuration (hidden_nf 33, variant="kitti": top-k = N, loss = corr + equi, kitti :1089) through the graphed
+    loop equals the eager loop bit for bit."""
+    from se3_equi_graph_registration_amd import train
+    def model():
+        torch.manual_seed(8)
+        egnn = pk.EGNN(33, 33, 33, in_edge_nf=1, device="cuda", n_layers=2)
+        return pk.CrossAttentionPoseRegression(egnn, num_nodes=256, hidden_nf=33, device="cuda", variant="kitti", topk=256).cuda()
+    batches = _batches(pk, 5, B=2, n=256, feat=33, first=500)
+    m_e, m_g = model(), model()
+    o_e, o_g = train.make_optimizer(m_e, lr=1e-3), train.make_optimizer(m_g, lr=1e-3)
+    le = train.train_one_epoch(m_e, batches, o_e, "cuda", 0, log_interval=0, k=8, loss_mode="kitti", graph=False)
+    lg = train.train_one_epoch(m_g, batches, o_g, "cuda", 0, log_interval=0, k=8, loss_mode="kitti")
+    st = train.graphed_step_for(m_g, o_g, k=8, loss_mode="kitti")
+    assert st.steps_replayed == 4 and st.graph_mode == "one graph"
+    _assert_same(_state(m_e, o_e), _state(m_g, o_g))
+    assert lg == pytest.approx(le, rel=1e-6)
