@@ -212,13 +212,17 @@ __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, in
 constexpr int kKnnTile = 2048;
 // kKnnQpw = queries per wave (even: two per packed instruction): 8 when that still leaves >= 8 workgroups per CU (measured:
 // KITTI shard 197 -> 171 us), 4 otherwise (two 8 192-point clouds: 99 us against 122 with 8 and 109 with 2)
-template <bool kLoop, int kKnnQpw>
+// kCap = entries of a query's compaction list: 64 (one key per lane) while k <= 24 -- the 24th of 64 lane minima leaves ~30 candidates,
+// > 64 practically never -- and 128 (two keys per lane, rank_by_counting2) above, where a k = 32 query keeps ~44 on average and a few
+// of every 16 384 exceed 64.  A template parameter because the list is LDS: 128 entries for the 32 queries of the 8-per-wave variant
+// cost it half its occupancy (KITTI shard, k = 20: 173 -> 264 us when every launch paid for them).
+template <bool kLoop, int kKnnQpw, int kCap>
 __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict__ x, int n_clouds, int n, int k,
                                                         long long* __restrict__ edges, int* __restrict__ row32,
                                                         int* __restrict__ col32, int* __restrict__ row_hist,
                                                         int* __restrict__ arrival, int force_slow) {
     __shared__ float tile[kKnnTile * 3];
-    __shared__ u64 list[4 * kKnnQpw][kKnnList];
+    __shared__ u64 list[4 * kKnnQpw][kCap];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int bpc = (n + 4 * kKnnQpw - 1) / (4 * kKnnQpw);      // workgroups per cloud
     const int cloud = blockIdx.x / bpc;
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
                 const u64 mask = __ballot(pred);
                 if (mask) {                                // wave-uniform: few of the 64-candidate steps hold a candidate <= tau
                     const int at = base[u] + rank_in_mask(mask);
-                    if (pred && at < kKnnList) list[wv * kKnnQpw + u][at] = pack_key(vu, idx);
+                    if (pred && at < kCap) list[wv * kKnnQpw + u][at] = pack_key(vu, idx);
                     base[u] += __popcll(mask);
                 }
             }
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
             u64 key;
             slot = rank_by_counting(list[wv * kKnnQpw + u], cnt, lane, key);
             out_idx = (int)(unsigned)(key & 0xffffffffu);
-        } else if ((cnt <= kKnnList) && (cnt >= k) && !force_slow) {
+        } else if (kCap > 64 && (cnt <= kCap) && (cnt >= k) && !force_slow) {
             u64 k0, k1;
             rank_by_counting2(list[wv * kKnnQpw + u], cnt, lane, k0, k1, slot, slot2);
             out_idx = (int)(unsigned)(k0 & 0xffffffffu);
@@ -492,10 +496,12 @@ extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, i
     } else {                     // 4 096 / 8 192 points (no 128-value register arrays)
         const bool wide = (long long)n_clouds * ceil_div(n, 32) >= 2048;
         const int bpc = ceil_div(n, wide ? 32 : 16);
-#define EQ_KNN_TILED(LOOP, QPW) \
-    hipLaunchKernelGGL((knn_tiled_kernel<LOOP, QPW>), dim3(n_clouds * bpc), dim3(256), 0, s, x, n_clouds, n, k, e64, row32, col32, row_hist, arrival, force_slow_path)
-        if (loop) { if (wide) EQ_KNN_TILED(true, 8); else EQ_KNN_TILED(true, 4); }
-        else { if (wide) EQ_KNN_TILED(false, 8); else EQ_KNN_TILED(false, 4); }
+#define EQ_KNN_TILED(LOOP, QPW, CAP) \
+    hipLaunchKernelGGL((knn_tiled_kernel<LOOP, QPW, CAP>), dim3(n_clouds * bpc), dim3(256), 0, s, x, n_clouds, n, k, e64, row32, col32, row_hist, arrival, force_slow_path)
+#define EQ_KNN_TILED_K(LOOP, QPW) do { if (k <= 24) EQ_KNN_TILED(LOOP, QPW, 64); else EQ_KNN_TILED(LOOP, QPW, 128); } while (0)
+        if (loop) { if (wide) EQ_KNN_TILED_K(true, 8); else EQ_KNN_TILED_K(true, 4); }
+        else { if (wide) EQ_KNN_TILED_K(false, 8); else EQ_KNN_TILED_K(false, 4); }
+#undef EQ_KNN_TILED_K
 #undef EQ_KNN_TILED
     }
 #undef EQ_KNN_PICK
