@@ -519,7 +519,9 @@ def roofline(pkg, S, args, dev):
     dom_is_bwd = bwd_ms is not None and bwd_ms >= fwd_ms
     a_f = bytes_fwd / (fwd_ms * 1e-3) / 1e9
     a_b = bytes_bwd / (bwd_ms * 1e-3) / 1e9 if bwd_ms else None
-    kname = ("edge_bwd16_kernel" if dom_is_bwd else "edge_fwd16_kernel") + (" (hidden_nf 33: border variant)" if F == 33 else "")
+    mfma_width = F in (32, 33)
+    kname = (("edge_bwd16_kernel" if dom_is_bwd else "edge_fwd16_kernel") + (" (hidden_nf 33: border variant)" if F == 33 else "")) if mfma_width else \
+        (("edge_bwd_lane_kernel" if dom_is_bwd else "edge_fwd_lane_kernel") + f" (hidden_nf {F}: lane-per-feature kernels, no MFMA formulation)")
     roof = {"bound": "hbm", "kernel": kname,
             "achieved": round(a_b if dom_is_bwd else a_f, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round((a_b if dom_is_bwd else a_f) / HBM_PEAK_GBS, 5), "traffic": traffic["bwd" if dom_is_bwd else "fwd"],
@@ -528,7 +530,7 @@ def roofline(pkg, S, args, dev):
             "launch_ms": round(bwd_ms if dom_is_bwd else fwd_ms, 5),
             "launch_ms_note": "HIP events around back-to-back launches of this one kernel (equigspr_time_edge_*): warm caches, no neighbours; "
                               "in_step_* = the same kernel's average inside the replayed step under rocprofv3 (committed profile)",
-            "issue_floor_us": round(issue_floor_us(E, F, dom_is_bwd), 2),
+            "issue_floor_us": round(issue_floor_us(E, F, dom_is_bwd), 2) if mfma_width else None,
             "issue_floor_note": "(MFMA x 32 + vector-ALU x 4 cycles) per 16-edge sub-tile x sub-tiles per SIMD / 2.1 GHz: fp32 MFMA and VALU "
                                 "do not co-execute on gfx950 (profiles/r03_sq_edge_kernels.json, tools/dev/coexec.hip)",
             "backward_mode": "recompute (no per-edge activations kept by the forward)"}

@@ -924,7 +924,8 @@ def validate(model, dataloader, device, epoch, writer=None, use_pointnet=False, 
         model.variant = "train"          # the reference validates with the training forward (:1208) -- it needs the losses
     world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(process_group) if world > 1 else 0
-    sums, n = [0.0, 0.0, 0.0, 0.0], 0.0
+    # running sums stay on the device (fp64): [loss, rot, trans, corr, weight] -- ONE read-back per call instead of four per batch
+    acc_dev = torch.zeros(5, dtype=torch.float64, device=device)
     try:
         for batch in _device_batches(dataloader, device):
             if batch is None or any(item is None for item in batch):
@@ -936,17 +937,18 @@ def validate(model, dataloader, device, epoch, writer=None, use_pointnet=False, 
                     continue
                 weight = n_local / n_global
             out, loss, rot, trans = _forward(model, batch, k, use_pointnet)
-            vals = [loss.item(), rot.mean().item(), trans.mean().item(), out[2].mean().item()]
-            if vals[0] != vals[0]:
-                continue
-            sums, n = [a + weight * b for a, b in zip(sums, vals)], n + weight
+            vals = torch.stack([loss.detach().double().reshape(()), rot.mean().double(), trans.mean().double(), out[2].mean().double(),
+                                torch.ones((), dtype=torch.float64, device=loss.device)])
+            ok = torch.isfinite(vals[0])                       # a batch with a non-finite loss does not count (as before)
+            acc_dev += torch.where(ok, vals * weight, torch.zeros_like(vals))
     finally:
         if was_variant is not None:
             model.variant = was_variant
     if world > 1:
-        acc = torch.tensor(sums + [n], dtype=torch.float64, device=device if dist.get_backend(process_group) == "nccl" else "cpu")
+        acc = acc_dev if dist.get_backend(process_group) == "nccl" else acc_dev.cpu()
         dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=process_group)
-        sums, n = acc[:4].tolist(), float(acc[4])
+        acc_dev = acc
+    sums, n = acc_dev[:4].tolist(), float(acc_dev[4])
     avg = [s / max(n, 1e-12) if n > 0 else 0.0 for s in sums]
     if rank == 0:
         print(f"Validation Loss: {avg[0]:.6f} | Pose rot Loss: {avg[1]:.6f} | Pose trans Loss: {avg[2]:.6f}")
