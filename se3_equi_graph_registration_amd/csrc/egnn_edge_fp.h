@@ -1,0 +1,217 @@
+// Feature-parallel MFMA edge kernels for the hidden widths that are whole multiples of 16 other than 32 (16, 48, 64; the reference
+// takes --hidden_node_nf and any num_heads dividing it: src/3dmatch_train_egnn_with_batch.py:1547, :186, :202-209).
+//
+// The 16-edge formulation of egnn_mfma16.h keeps ALL features of an edge in one wave: at hidden_nf 64 its backward would need 144
+// registers of weight-gradient accumulators on top of 96 of tile state -- it does not fit.  Here the NB = F / 16 waves of a tile
+// group each own ONE 16-feature block of every vector (lane (e = l & 15, g = l >> 4): edge e, features 16 w + 4 g + r -- the same
+// C/D layout, one f32x4 per vector instead of NB) and one block ROW of every matrix product and weight gradient:
+//   y_w = sum_bi W[16 w .., 16 bi ..] v_bi     needs the other waves' blocks v_bi: every wave publishes its block in an LDS tile
+//   V [16 edges][F] (ds_write_b128), a workgroup barrier, then reads all blocks back as MFMA B operands (ds_read_b128);
+//   LayerNorm / the coord scalar reduce over the F features: per-wave partial (hsum4 + two lane swaps) -> LDS [NB][16] -> barrier ->
+//   summed in fixed wave order by everyone (bitwise reproducible);
+//   weight gradients: wave w accumulates rows 16 w .. 16 w + 15 of dW6, dW2, dWgeo (NB + NB + 1 accumulators) -- no merge at the end,
+//   every wave writes its own rows of the workgroup's slab.
+// A workgroup runs kTpb tile groups side by side (two waves per SIMD at NB = 4) over one shared LDS weight image.
+// Same math as E_GCL.edge_model / coord_model (:231-268), same interfaces as the other edge kernels: m rows at the edge's
+// aggregation position, trans [E][4], dt1 rows [E][FP], gxr / gxc [E][4], Slabs<F>::edge.  (Round 4; the lane-per-feature kernels
+// of egnn_edge_lane.h were ~5x slower per flop: 506 / 124 us backward / forward per launch at hidden_nf 64, one 2 048-point pair.)
+#pragma once
+#include "egnn_bwd16.h"
+
+namespace eq {
+
+constexpr int fp_tpb(int F) { return F / 16 >= 3 ? 2 : 4; }             // tile groups per workgroup: 8 / 6 / 4 waves at 64 / 48 / 16
+constexpr int fp_threads(int F) { return 64 * (F / 16) * fp_tpb(F); }
+
+template <int F, int H, int A, bool kBwd>
+struct FpLayout {
+    static constexpr int NB = F / 16, FH = F / H;
+    static constexpr int kTpb = fp_tpb(F);
+    static constexpr int NW = NB * kTpb;
+    static constexpr int WS = F + 8;                                     // row stride of the F-column matrices (b128 A-operand reads conflict-free)
+    static constexpr int GS = 24;                                        // Wgeo [F][16 (+8)]
+    static constexpr int VS = F + 4;                                     // row stride of the exchange tiles [16 edges][F]
+    // weight image
+    static constexpr int o_w2 = 0;
+    static constexpr int o_w6 = o_w2 + F * WS;
+    static constexpr int o_wg = o_w6 + F * WS;
+    static constexpr int o_vec = o_wg + F * GS;                          // b2 | gamma | beta | b6 | w7
+    static constexpr int o_w2t = o_vec + 5 * F;                          // backward only: transposed copies
+    static constexpr int o_w6t = o_w2t + F * WS;
+    static constexpr int o_wgt = o_w6t + F * WS;                         // WgeoT [16][WS]
+    static constexpr int image = kBwd ? o_wgt + 16 * WS : o_w2t;
+    // per tile group
+    static constexpr int g_v = 0;                                        // V [16][VS]
+    static constexpr int g_x = g_v + 16 * VS;                            // backward: X, Y
+    static constexpr int g_y = g_x + (kBwd ? 16 * VS : 0);
+    static constexpr int g_geo = g_y + (kBwd ? 16 * VS : 0);             // [16][16]: geometry row, later dgeo
+    static constexpr int g_red = g_geo + 16 * 16;                        // [2][NB][16]
+    static constexpr int g_idx = g_red + 2 * NB * 16;                    // row, col, pos (ints), ds / s (floats): [4][16]
+    static constexpr int g_front = g_idx + 4 * 16;                       // backward: x_r, x_c, Gx[row] of the 16 edges [16][12]
+    static constexpr int group = g_front + (kBwd ? 16 * 12 : 0);
+    static constexpr int total = image + kTpb * group;
+    // a 16 x 16 block (bo, bi) of W2 is all zero when its rows and columns lie in different heads
+    // (heads need not be multiples of 16 wide -- hidden_nf 48 with 2 heads: 24 -- so compare the head RANGES the block's rows and columns touch)
+    static constexpr __device__ bool w2_block_live(int bo, int bi) {
+        return (16 * bo) / FH <= (16 * bi + 15) / FH && (16 * bi) / FH <= (16 * bo + 15) / FH;
+    }
+};
+
+template <int F, int H, int A, bool kBwd>
+__device__ __forceinline__ void fp_stage_image(float* sm, const float* __restrict__ lw, int nthreads) {
+    using L = FpLayout<F, H, A, kBwd>;
+    using LL = LP<F, H, A>;
+    constexpr int FH = F / H;
+    for (int t = threadIdx.x; t < F * F; t += nthreads) {
+        const int i = t / F, k = t - i * F;
+        const float v2 = (i / FH == k / FH) ? lw[LL::w2_off(i, k % FH)] : 0.0f;       // block-diagonal over the heads
+        const float v6 = lw[LL::w6 + i * F + k];
+        sm[L::o_w2 + i * L::WS + k] = v2;
+        sm[L::o_w6 + i * L::WS + k] = v6;
+        if (kBwd) { sm[L::o_w2t + k * L::WS + i] = v2; sm[L::o_w6t + k * L::WS + i] = v6; }
+    }
+    for (int t = threadIdx.x; t < F * 16; t += nthreads) {
+        const int i = t >> 4, k = t & 15;
+        const float v = k < kGeo + A ? lw[LL::w1_off(i, 2 * F + k)] : 0.0f;
+        sm[L::o_wg + i * L::GS + k] = v;
+        if (kBwd) sm[L::o_wgt + k * L::WS + i] = v;
+    }
+    for (int t = threadIdx.x; t < 5 * F; t += nthreads) {
+        const int w = t / F, k = t - w * F;
+        sm[L::o_vec + t] = lw[w == 0 ? LL::b2_off(k) : (w == 1 ? LL::ln_g + k : (w == 2 ? LL::ln_b + k : (w == 3 ? LL::b6 + k : LL::w7 + k)))];
+    }
+}
+
+// forward state of a tile as seen by wave w: its 16-feature block of every vector
+struct FpSub {
+    f32x4 t1, sg1, xhat, m, q, sgq;
+    float rstd, s;
+};
+
+// y_w (+)= sum over the live input blocks of  W[16 w + i][16 bi + 4 g + r] * V[e][16 bi + 4 g + r]
+template <int F, int H, int A, bool kBwd, bool kBlockDiag>
+__device__ __forceinline__ f32x4 fp_matvec(const float* mat, const float* V, int w, int i, int g, f32x4 acc) {
+    using L = FpLayout<F, H, A, kBwd>;
+#pragma unroll
+    for (int bi = 0; bi < L::NB; ++bi) {
+        if (kBlockDiag && !L::w2_block_live(w, bi)) continue;            // wave-uniform
+        const f32x4 a = lds4(mat + (16 * w + i) * L::WS + 16 * bi + 4 * g);
+        const f32x4 b = lds4(V + i * L::VS + 16 * bi + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16(a[r], b[r], acc);
+    }
+    return acc;
+}
+
+// sum over the NB waves' partials of the tile group (fixed order), after the caller's barrier
+template <int NB>
+__device__ __forceinline__ float fp_total(const float* red, int e) {
+    float s = red[e];
+#pragma unroll
+    for (int w = 1; w < NB; ++w) s += red[w * 16 + e];
+    return s;
+}
+
+// One tile's forward for wave w of its group.  Barriers: every call site runs the same number for all waves of the workgroup.
+// On entry the group's idx / geo rows are in LDS (front done + barrier).  Leaves m in V (published) and returns the state.
+template <int F, int H, int A, bool kBwd>
+__device__ __forceinline__ void fp_tile_forward(const float* img, float* grp, const float* __restrict__ P, int w, int i, int g, FpSub& o) {
+    using L = FpLayout<F, H, A, kBwd>;
+    constexpr int FP = Geom<F>::FP, NB = L::NB;
+    float* V = grp + L::g_v;
+    float* red = grp + L::g_red;
+    const int* idx = reinterpret_cast<const int*>(grp + L::g_idx);
+    const int rr = idx[i], cc = idx[16 + i];
+    f32x4 acc = ldg4(P + (size_t)rr * 2 * FP + 16 * w + 4 * g) + ldg4(P + (size_t)cc * 2 * FP + FP + 16 * w + 4 * g);
+    {
+        const f32x4 gv = lds4(grp + L::g_geo + i * 16 + 4 * g);
+        const f32x4 a = lds4(img + L::o_wg + (16 * w + i) * L::GS + 4 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma16(a[s], gv[s], acc);
+    }
+    o.t1 = acc;
+    o.sg1 = sigmoid4(acc);
+    st4(V + i * L::VS + 16 * w + 4 * g, acc * o.sg1);                    // SiLU (:245)
+    __syncthreads();
+    f32x4 u = fp_matvec<F, H, A, kBwd, true>(img + L::o_w2, V, w, i, g, lds4(img + L::o_vec + 0 * F + 16 * w + 4 * g));
+    // LayerNorm over the F features (biased variance, eps 1e-5; :249): mean first, then the centred second moment
+    {
+        const float p = gsum(hsum4(u));
+        if (g == 0) red[w * 16 + i] = p;
+    }
+    __syncthreads();
+    const float mean = fp_total<NB>(red, i) * (1.0f / F);
+    const f32x4 c = u - splat4(mean);
+    {
+        const float p = gsum(hsum4(c * c));
+        if (g == 0) red[NB * 16 + w * 16 + i] = p;
+    }
+    __syncthreads();
+    const float var = fp_total<NB>(red + NB * 16, i) * (1.0f / F);
+    o.rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+    o.xhat = c * splat4(o.rstd);
+    o.m = fma4(o.xhat, lds4(img + L::o_vec + 1 * F + 16 * w + 4 * g), lds4(img + L::o_vec + 2 * F + 16 * w + 4 * g));
+    st4(V + i * L::VS + 16 * w + 4 * g, o.m);                            // every wave is past its W2 product (two barriers ago)
+    __syncthreads();
+    o.q = fp_matvec<F, H, A, kBwd, false>(img + L::o_w6, V, w, i, g, lds4(img + L::o_vec + 3 * F + 16 * w + 4 * g));
+    o.sgq = sigmoid4(o.q);
+    {
+        const float p = gsum(hsum4(lds4(img + L::o_vec + 4 * F + 16 * w + 4 * g) * (o.q * o.sgq)));
+        if (g == 0) red[w * 16 + i] = p;                                 // the mean's partials were consumed before the second barrier
+    }
+    __syncthreads();
+    o.s = fp_total<NB>(red, i);                                          // :264
+}
+
+template <int F, int H, int A>
+__global__ __launch_bounds__(fp_threads(F)) void edge_fwd_fp_kernel(
+    const float* __restrict__ lw, const int* __restrict__ row, const int* __restrict__ col, const float* __restrict__ edge_attr,
+    const float* __restrict__ x, const float* __restrict__ P, const int* __restrict__ rinv, int n_edges, int basis,
+    float* __restrict__ m_out, float* __restrict__ trans_out) {
+    using L = FpLayout<F, H, A, false>;
+    constexpr int FP = Geom<F>::FP, NB = L::NB;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tg = wave / NB, w = wave - tg * NB, i = lane & 15, g = lane >> 4;
+    fp_stage_image<F, H, A, false>(sm, lw, 64 * L::NW);
+    float* grp = sm + L::image + tg * L::group;
+    int* idx = reinterpret_cast<int*>(grp + L::g_idx);
+    const int n_tiles = (n_edges + 15) >> 4;
+    const int stride = gridDim.x * L::kTpb;
+    const int iters = (n_tiles + stride - 1) / stride;                   // the same trip count for every tile group: barriers inside
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        const int tile = it * stride + blockIdx.x * L::kTpb + tg;
+        const int e = tile * 16 + lane;                                  // front lanes: wave w == 0, lanes 0..15
+        const bool front = w == 0 && lane < 16;
+        const bool live = tile < n_tiles && e < n_edges;
+        float d[3] = {0.0f, 0.0f, 0.0f};
+        int at = 0;
+        if (front) {
+            const int ee = live ? e : 0;
+            const int r = row[ee], c = col[ee];
+            at = rinv[ee];
+            float xr[3], xc[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { xr[k] = x[(size_t)r * 3 + k]; xc[k] = x[(size_t)c * 3 + k]; }
+            EdgeGeo eg;
+            edge_geometry_mode(basis, xr, xc, eg);
+            const float attr = A ? (edge_attr ? edge_attr[ee] : 1.0f) : 0.0f;
+            store_geo_row(grp + L::g_geo + lane * 16, eg, attr);
+            idx[lane] = r; idx[16 + lane] = c; idx[32 + lane] = live ? at : -1;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) d[k] = eg.d[k];
+        }
+        __syncthreads();
+        FpSub o;
+        fp_tile_forward<F, H, A, false>(sm, grp, P, w, i, g, o);
+        const int pos = idx[32 + i];
+        if (pos >= 0) st4(m_out + (size_t)pos * FP + 16 * w + 4 * g, o.m);            // at the edge's aggregation position
+        if (front && live) reinterpret_cast<float4*>(trans_out)[at] = make_float4(d[0] * o.s, d[1] * o.s, d[2] * o.s, 0.0f);      // trans = coord_diff * s (:264)
+        __syncthreads();                                                 // the next tile's front overwrites idx / geo / red
+    }
+}
+
+template <int F, int H, int A>
+static inline size_t edge_fwd_fp_smem() { return sizeof(float) * (size_t)FpLayout<F, H, A, false>::total; }
+
+}  // namespace eq
