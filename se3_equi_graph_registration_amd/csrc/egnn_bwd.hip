@@ -18,6 +18,7 @@
 #include "egnn_mfma16.h"
 #include "egnn_bwd16.h"
 #include "egnn_edge_lane.h"
+#include "egnn_edge_fp.h"
 
 #include <algorithm>
 #include <mutex>
@@ -720,6 +721,9 @@ __global__ __launch_bounds__(256, 2) void gather_node_bwd_kernel(
 // (40; operands transposed through wave-private LDS tiles).  Geometry forward / backward once per edge in the chunk's
 // front / back phases.
 // ---------------------------------------------------------------------------------------
+#ifndef EQ_EDGE_FP
+#define EQ_EDGE_FP 1                   // 0: hidden_nf 16 / 48 / 64 on the lane-per-feature kernels (A/B knob)
+#endif
 constexpr int kBwd16Waves = 8;
 #ifndef EQ_BWD16_RUNSUM
 #define EQ_BWD16_RUNSUM 0             // 1: db6 / db2 as per-lane running sums instead of column sums of pass16's tile reads (A/B knob)
@@ -1145,6 +1149,27 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
         blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
         hipLaunchKernelGGL((edge_bwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * NW), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
                            E, chunk, basis, dt1, dt1 + (size_t)E * 32, gxr, gxc, slab);
+        *n_slabs = blocks;
+    } else if constexpr (F % 16 == 0 && EQ_EDGE_FP != 0) {  // 16 / 48 / 64: the feature-parallel MFMA kernels (egnn_edge_fp.h), one slab per workgroup
+        using L = FpLayout<F, H, A, true>;
+        const size_t smem = edge_bwd_fp_smem<F, H, A>();
+        {
+            static std::mutex mu;
+            static bool done[64] = {false};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            std::lock_guard<std::mutex> lk(mu);
+            if (dev < 0 || dev >= 64 || !done[dev]) {
+                hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_bwd_fp_kernel<F, H, A>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                if (err != hipSuccess) { set_error("hipFuncSetAttribute(edge_bwd_fp): %s", hipGetErrorString(err)); return (int)err; }
+                if (dev >= 0 && dev < 64) done[dev] = true;
+            }
+        }
+        int blocks = ceil_div(ceil_div(E, 16), L::kTpb);
+        blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+        hipLaunchKernelGGL((edge_bwd_fp_kernel<F, H, A>), dim3(blocks), dim3(64 * L::NW), smem, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx, E,
+                           basis, dt1, gxr, gxc, slab);
         *n_slabs = blocks;
     } else {                                               // any other width: lane = feature (egnn_edge_lane.h), one slab per workgroup
         int blocks = ceil_div(E, 4 * 16);

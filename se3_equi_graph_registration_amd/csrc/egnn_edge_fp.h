@@ -42,10 +42,11 @@ struct FpLayout {
     static constexpr int image = kBwd ? o_wgt + 16 * WS : o_w2t;
     // per tile group
     static constexpr int g_v = 0;                                        // V [16][VS]
-    static constexpr int g_x = g_v + 16 * VS;                            // backward: X, Y
-    static constexpr int g_y = g_x + (kBwd ? 16 * VS : 0);
-    static constexpr int g_geo = g_y + (kBwd ? 16 * VS : 0);             // [16][16]: geometry row, later dgeo
-    static constexpr int g_red = g_geo + 16 * 16;                        // [2][NB][16]
+    static constexpr int g_x = g_v + 16 * VS;                            // backward: X (dq, then du), Z (dt1)
+    static constexpr int g_z = g_x + (kBwd ? 16 * VS : 0);
+    static constexpr int g_geo = g_z + (kBwd ? 16 * VS : 0);             // [16][16]: the edges' geometry rows
+    static constexpr int g_dgeo = g_geo + 16 * 16;                       // backward: [16][16] dL/dgeo
+    static constexpr int g_red = g_dgeo + (kBwd ? 16 * 16 : 0);          // [2][NB][16]
     static constexpr int g_idx = g_red + 2 * NB * 16;                    // row, col, pos (ints), ds / s (floats): [4][16]
     static constexpr int g_front = g_idx + 4 * 16;                       // backward: x_r, x_c, Gx[row] of the 16 edges [16][12]
     static constexpr int group = g_front + (kBwd ? 16 * 12 : 0);
@@ -213,5 +214,189 @@ __global__ __launch_bounds__(fp_threads(F)) void edge_fwd_fp_kernel(
 
 template <int F, int H, int A>
 static inline size_t edge_fwd_fp_smem() { return sizeof(float) * (size_t)FpLayout<F, H, A, false>::total; }
+
+// acc[by] += X_w^T Y_by over the 16 edges of the tiles (K step s, lane group g <-> edge s + 4 g, as pass16): rows 16 w .. of the
+// outer product.  kBlockDiag: only the blocks a head of W2 touches.
+template <int F, int H, int A, int NBY, bool kBlockDiag>
+__device__ __forceinline__ void fp_outer(const float* X, const float* Y, int ldy, int w, int i, int g, f32x4 (&acc)[NBY]) {
+    using L = FpLayout<F, H, A, true>;
+    float a[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = X[(s + 4 * g) * L::VS + 16 * w + i];
+#pragma unroll
+    for (int by = 0; by < NBY; ++by) {
+        if (kBlockDiag && !L::w2_block_live(w, by)) continue;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[by] = mfma16(a[s], Y[(s + 4 * g) * ldy + 16 * by + i], acc[by]);
+    }
+}
+
+template <int F, int H, int A>
+__global__ __launch_bounds__(fp_threads(F)) void edge_bwd_fp_kernel(
+    const float* __restrict__ lw, const int* __restrict__ row, const int* __restrict__ col, const float* __restrict__ edge_attr,
+    const float* __restrict__ x, const float* __restrict__ P, const float* __restrict__ dagg, const float* __restrict__ Gx, int n_edges,
+    int basis, float* __restrict__ dt1_out, float* __restrict__ gxr_out, float* __restrict__ gxc_out, float* __restrict__ slab) {
+    using L = FpLayout<F, H, A, true>;
+    using SB = Slabs<F>;
+    constexpr int FP = Geom<F>::FP, NB = L::NB, FH = F / H;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tg = wave / NB, w = wave - tg * NB, i = lane & 15, g = lane >> 4;
+    fp_stage_image<F, H, A, true>(sm, lw, 64 * L::NW);
+    float* grp = sm + L::image + tg * L::group;
+    float* V = grp + L::g_v;
+    float* X = grp + L::g_x;
+    float* Z = grp + L::g_z;
+    float* geo = grp + L::g_geo;
+    float* dgeo = grp + L::g_dgeo;
+    float* red = grp + L::g_red;
+    int* idx = reinterpret_cast<int*>(grp + L::g_idx);
+    float* dsb = grp + L::g_idx + 32;                                    // dL/ds of the 16 edges (0 for padding edges)
+    float* fr = grp + L::g_front + (lane & 15) * 12;
+    f32x4 acc6[NB], acc2[NB], accg[1];
+    f32x4 ls_w7 = splat4(0.0f), ls_gam = splat4(0.0f), ls_bet = splat4(0.0f), ls_b6 = splat4(0.0f), ls_b2 = splat4(0.0f);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { acc6[b] = splat4(0.0f); acc2[b] = splat4(0.0f); }
+    accg[0] = splat4(0.0f);
+    const int n_tiles = (n_edges + 15) >> 4;
+    const int stride = gridDim.x * L::kTpb;
+    const int iters = (n_tiles + stride - 1) / stride;
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        const int tile = it * stride + blockIdx.x * L::kTpb + tg;
+        const int e = tile * 16 + lane;
+        const bool front = w == 0 && lane < 16;
+        const bool live = tile < n_tiles && e < n_edges;
+        if (front) {
+            const int ee = live ? e : 0;
+            const int r = row[ee], c = col[ee];
+            float xr[3], xc[3], gxv[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { xr[k] = x[(size_t)r * 3 + k]; xc[k] = x[(size_t)c * 3 + k]; gxv[k] = Gx[(size_t)r * 4 + k]; }
+            EdgeGeo eg;
+            edge_geometry_mode(basis, xr, xc, eg);
+            const float attr = A ? (edge_attr ? edge_attr[ee] : 1.0f) : 0.0f;
+            store_geo_row(geo + lane * 16, eg, attr);
+            idx[lane] = r; idx[16 + lane] = c;
+            dsb[lane] = live ? dot3(eg.d, gxv) : 0.0f;                   // dL/ds of the coord head (:264); 0 masks padding edges
+            st4(fr, f32x4{xr[0], xr[1], xr[2], xc[0]});
+            st4(fr + 4, f32x4{xc[1], xc[2], gxv[0], gxv[1]});
+            fr[8] = gxv[2];
+        }
+        __syncthreads();
+        const bool valid = tile < n_tiles && tile * 16 + i < n_edges;    // this lane's edge (i) exists
+        const int eg_ = tile * 16 + i;
+        FpSub o;
+        fp_tile_forward<F, H, A, true>(sm, grp, P, w, i, g, o);          // recompute; leaves m in V
+        // ---- coord head backward: s = w7 . SiLU(q)
+        const float ds = dsb[i];
+        ls_w7 = fma4(o.q * o.sgq, splat4(ds), ls_w7);
+        const f32x4 dq = lds4(sm + L::o_vec + 4 * F + 16 * w + 4 * g) * splat4(ds) * silu_grad4(o.q, o.sgq);
+        ls_b6 += dq;
+        st4(X + i * L::VS + 16 * w + 4 * g, dq);
+        const f32x4 da = valid ? ldg4(dagg + (size_t)idx[i] * FP + 16 * w + 4 * g) : splat4(0.0f);
+        __syncthreads();
+        fp_outer<F, H, A, NB, false>(X, V, L::VS, w, i, g, acc6);        // dW6 rows += dq^T m
+        // ---- dm = dagg[row] + W6^T dq
+        const f32x4 dm = fp_matvec<F, H, A, true, false>(sm + L::o_w6t, X, w, i, g, da);
+        ls_gam = fma4(dm, o.xhat, ls_gam);
+        ls_bet += dm;
+        // ---- LayerNorm backward
+        f32x4 du = dm * lds4(sm + L::o_vec + 1 * F + 16 * w + 4 * g);
+        {
+            float m1 = hsum4(du), m2 = hsum4(du * o.xhat);
+            gsum2(m1, m2);
+            if (g == 0) { red[w * 16 + i] = m1; red[NB * 16 + w * 16 + i] = m2; }
+        }
+        __syncthreads();                                                 // ... and every wave is past its reads of X (dq) and V (m)
+        {
+            const float m1 = fp_total<NB>(red, i) * -(1.0f / F), m2 = fp_total<NB>(red + NB * 16, i) * -(1.0f / F);
+            du = splat4(o.rstd) * fma4(o.xhat, splat4(m2), du + splat4(m1));
+        }
+        ls_b2 += du;
+        st4(X + i * L::VS + 16 * w + 4 * g, du);
+        st4(V + i * L::VS + 16 * w + 4 * g, o.t1 * o.sg1);               // SiLU(t1) again
+        __syncthreads();
+        fp_outer<F, H, A, NB, true>(X, V, L::VS, w, i, g, acc2);         // dW2 rows += du^T SiLU(t1)
+        // ---- dt1 = (W2^T du) * SiLU'(t1)
+        f32x4 dt1 = fp_matvec<F, H, A, true, true>(sm + L::o_w2t, X, w, i, g, splat4(0.0f));
+        dt1 *= silu_grad4(o.t1, o.sg1);
+        if (valid) st4(dt1_out + (size_t)eg_ * FP + 16 * w + 4 * g, dt1);
+        st4(Z + i * L::VS + 16 * w + 4 * g, dt1);
+        __syncthreads();
+        fp_outer<F, H, A, 1, false>(Z, geo, 16, w, i, g, accg);          // dWgeo | dw_attr rows += dt1^T [geo, attr]
+        if (w == 0) {                                                    // dgeo = Wgeo^T dt1: one 16-row block, this wave's job
+            f32x4 dg = splat4(0.0f);
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi) {
+                const f32x4 a = lds4(sm + L::o_wgt + i * L::WS + 16 * bi + 4 * g);
+                const f32x4 b = lds4(Z + i * L::VS + 16 * bi + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dg = mfma16(a[r], b[r], dg);
+            }
+            st4(dgeo + i * 16 + 4 * g, dg);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- back: one lane per edge, geometry backward from the stashed coordinates
+            if (front && live) {
+                const f32x4 f0 = lds4(fr), f1 = lds4(fr + 4);
+                const float xr2[3] = {f0[0], f0[1], f0[2]}, xc2[3] = {f0[3], f1[0], f1[1]}, gx2[3] = {f1[2], f1[3], fr[8]};
+                EdgeGeo eg;
+                edge_geometry_mode(basis, xr2, xc2, eg);
+                const f32x4 g0 = lds4(dgeo + lane * 16), g1 = lds4(dgeo + lane * 16 + 4), g2 = lds4(dgeo + lane * 16 + 8);
+                const float gg[kGeo] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3], g2[0], g2[1], g2[2], g2[3]};
+                const float gd[3] = {o.s * gx2[0], o.s * gx2[1], o.s * gx2[2]};
+                float gxr[3], gxc[3];
+                edge_geometry_backward_mode(basis, xr2, xc2, eg, gg, gd, gxr, gxc);
+                reinterpret_cast<float4*>(gxr_out)[e] = make_float4(gxr[0], gxr[1], gxr[2], 0.0f);
+                reinterpret_cast<float4*>(gxc_out)[e] = make_float4(gxc[0], gxc[1], gxc[2], 0.0f);
+            }
+        }
+        __syncthreads();                                                 // the next tile's front overwrites idx / geo / the tiles
+    }
+    // ---- per-lane running sums: over the 16 edges (lanes) of the group
+    auto lane16_sum = [](float v) {
+#pragma unroll
+        for (int o_ = 1; o_ <= 8; o_ <<= 1) v += __shfl_xor(v, o_, 64);
+        return v;
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ls_w7[k] = lane16_sum(ls_w7[k]); ls_gam[k] = lane16_sum(ls_gam[k]); ls_bet[k] = lane16_sum(ls_bet[k]);
+        ls_b6[k] = lane16_sum(ls_b6[k]); ls_b2[k] = lane16_sum(ls_b2[k]);
+    }
+    // ---- the tile groups of the workgroup own the same rows: summed in LDS in fixed order, one slab per workgroup
+    __syncthreads();
+    float* sl = sm;                                                      // every wave is past its last image read
+    for (int t = threadIdx.x; t < SB::edge; t += 64 * L::NW) sl[t] = 0.0f;
+    __syncthreads();
+    for (int q = 0; q < L::kTpb; ++q) {
+        if (tg == q) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int orow = 16 * w + 4 * g + k;
+#pragma unroll
+                for (int by = 0; by < NB; ++by) {
+                    const int ocol = 16 * by + i;
+                    sl[SB::e_w6 + orow * F + ocol] += acc6[by][k];
+                    if (orow / FH == ocol / FH) sl[SB::e_w2 + orow * F + ocol] += acc2[by][k];      // the dense F x F block stays zero outside the heads' diagonal blocks
+                }
+                sl[SB::e_geo + orow * 16 + i] += accg[0][k];
+                if (i == 0) {
+                    sl[SB::e_gam + orow] += ls_gam[k]; sl[SB::e_bet + orow] += ls_bet[k]; sl[SB::e_w7 + orow] += ls_w7[k];
+                    sl[SB::e_b6 + orow] += ls_b6[k]; sl[SB::e_b2 + orow] += ls_b2[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < SB::edge; t += 64 * L::NW) slab[(size_t)blockIdx.x * SB::edge + t] = sl[t];
+}
+
+template <int F, int H, int A>
+static inline size_t edge_bwd_fp_smem() {
+    const size_t a = (size_t)FpLayout<F, H, A, true>::total, b = (size_t)Slabs<F>::edge;
+    return sizeof(float) * (a > b ? a : b);
+}
 
 }  // namespace eq
