@@ -104,6 +104,19 @@ __device__ __forceinline__ f32x4 fp_matvec(const float* mat, const float* V, int
     return acc;
 }
 
+// the exchange barrier of a tile group: its NB waves must meet.  One wave per group (hidden_nf 16): nobody else to wait for -- a
+// wave-level fence instead of stalling on the workgroup's other, unrelated tile groups
+template <int NB>
+__device__ __forceinline__ void fp_sync() {
+    if constexpr (NB == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 // sum over the NB waves' partials of the tile group (fixed order), after the caller's barrier
 template <int NB>
 __device__ __forceinline__ float fp_total(const float* red, int e) {
@@ -133,34 +146,34 @@ __device__ __forceinline__ void fp_tile_forward(const float* img, float* grp, co
     o.t1 = acc;
     o.sg1 = sigmoid4(acc);
     st4(V + i * L::VS + 16 * w + 4 * g, acc * o.sg1);                    // SiLU (:245)
-    __syncthreads();
+    fp_sync<NB>();
     f32x4 u = fp_matvec<F, H, A, kBwd, true>(img + L::o_w2, V, w, i, g, lds4(img + L::o_vec + 0 * F + 16 * w + 4 * g));
     // LayerNorm over the F features (biased variance, eps 1e-5; :249): mean first, then the centred second moment
     {
         const float p = gsum(hsum4(u));
         if (g == 0) red[w * 16 + i] = p;
     }
-    __syncthreads();
+    fp_sync<NB>();
     const float mean = fp_total<NB>(red, i) * (1.0f / F);
     const f32x4 c = u - splat4(mean);
     {
         const float p = gsum(hsum4(c * c));
         if (g == 0) red[NB * 16 + w * 16 + i] = p;
     }
-    __syncthreads();
+    fp_sync<NB>();
     const float var = fp_total<NB>(red + NB * 16, i) * (1.0f / F);
     o.rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
     o.xhat = c * splat4(o.rstd);
     o.m = fma4(o.xhat, lds4(img + L::o_vec + 1 * F + 16 * w + 4 * g), lds4(img + L::o_vec + 2 * F + 16 * w + 4 * g));
     st4(V + i * L::VS + 16 * w + 4 * g, o.m);                            // every wave is past its W2 product (two barriers ago)
-    __syncthreads();
+    fp_sync<NB>();
     o.q = fp_matvec<F, H, A, kBwd, false>(img + L::o_w6, V, w, i, g, lds4(img + L::o_vec + 3 * F + 16 * w + 4 * g));
     o.sgq = sigmoid4(o.q);
     {
         const float p = gsum(hsum4(lds4(img + L::o_vec + 4 * F + 16 * w + 4 * g) * (o.q * o.sgq)));
         if (g == 0) red[w * 16 + i] = p;                                 // the mean's partials were consumed before the second barrier
     }
-    __syncthreads();
+    fp_sync<NB>();
     o.s = fp_total<NB>(red, i);                                          // :264
 }
 
@@ -202,13 +215,13 @@ __global__ __launch_bounds__(fp_threads(F)) void edge_fwd_fp_kernel(
 #pragma unroll
             for (int k = 0; k < 3; ++k) d[k] = eg.d[k];
         }
-        __syncthreads();
+        fp_sync<NB>();
         FpSub o;
         fp_tile_forward<F, H, A, false>(sm, grp, P, w, i, g, o);
         const int pos = idx[32 + i];
         if (pos >= 0) st4(m_out + (size_t)pos * FP + 16 * w + 4 * g, o.m);            // at the edge's aggregation position
         if (front && live) reinterpret_cast<float4*>(trans_out)[at] = make_float4(d[0] * o.s, d[1] * o.s, d[2] * o.s, 0.0f);      // trans = coord_diff * s (:264)
-        __syncthreads();                                                 // the next tile's front overwrites idx / geo / red
+        fp_sync<NB>();                                                 // the next tile's front overwrites idx / geo / red
     }
 }
 
@@ -282,7 +295,7 @@ __global__ __launch_bounds__(fp_threads(F)) void edge_bwd_fp_kernel(
             st4(fr + 4, f32x4{xc[1], xc[2], gxv[0], gxv[1]});
             fr[8] = gxv[2];
         }
-        __syncthreads();
+        fp_sync<NB>();
         const bool valid = tile < n_tiles && tile * 16 + i < n_edges;    // this lane's edge (i) exists
         const int eg_ = tile * 16 + i;
         FpSub o;
@@ -294,7 +307,7 @@ __global__ __launch_bounds__(fp_threads(F)) void edge_bwd_fp_kernel(
         ls_b6 += dq;
         st4(X + i * L::VS + 16 * w + 4 * g, dq);
         const f32x4 da = valid ? ldg4(dagg + (size_t)idx[i] * FP + 16 * w + 4 * g) : splat4(0.0f);
-        __syncthreads();
+        fp_sync<NB>();
         fp_outer<F, H, A, NB, false>(X, V, L::VS, w, i, g, acc6);        // dW6 rows += dq^T m
         // ---- dm = dagg[row] + W6^T dq
         const f32x4 dm = fp_matvec<F, H, A, true, false>(sm + L::o_w6t, X, w, i, g, da);
@@ -307,7 +320,7 @@ __global__ __launch_bounds__(fp_threads(F)) void edge_bwd_fp_kernel(
             gsum2(m1, m2);
             if (g == 0) { red[w * 16 + i] = m1; red[NB * 16 + w * 16 + i] = m2; }
         }
-        __syncthreads();                                                 // ... and every wave is past its reads of X (dq) and V (m)
+        fp_sync<NB>();                                                 // ... and every wave is past its reads of X (dq) and V (m)
         {
             const float m1 = fp_total<NB>(red, i) * -(1.0f / F), m2 = fp_total<NB>(red + NB * 16, i) * -(1.0f / F);
             du = splat4(o.rstd) * fma4(o.xhat, splat4(m2), du + splat4(m1));
@@ -315,14 +328,14 @@ __global__ __launch_bounds__(fp_threads(F)) void edge_bwd_fp_kernel(
         ls_b2 += du;
         st4(X + i * L::VS + 16 * w + 4 * g, du);
         st4(V + i * L::VS + 16 * w + 4 * g, o.t1 * o.sg1);               // SiLU(t1) again
-        __syncthreads();
+        fp_sync<NB>();
         fp_outer<F, H, A, NB, true>(X, V, L::VS, w, i, g, acc2);         // dW2 rows += du^T SiLU(t1)
         // ---- dt1 = (W2^T du) * SiLU'(t1)
         f32x4 dt1 = fp_matvec<F, H, A, true, true>(sm + L::o_w2t, X, w, i, g, splat4(0.0f));
         dt1 *= silu_grad4(o.t1, o.sg1);
         if (valid) st4(dt1_out + (size_t)eg_ * FP + 16 * w + 4 * g, dt1);
         st4(Z + i * L::VS + 16 * w + 4 * g, dt1);
-        __syncthreads();
+        fp_sync<NB>();
         fp_outer<F, H, A, 1, false>(Z, geo, 16, w, i, g, accg);          // dWgeo | dw_attr rows += dt1^T [geo, attr]
         if (w == 0) {                                                    // dgeo = Wgeo^T dt1: one 16-row block, this wave's job
             f32x4 dg = splat4(0.0f);
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(fp_threads(F)) void edge_bwd_fp_kernel(
                 reinterpret_cast<float4*>(gxc_out)[e] = make_float4(gxc[0], gxc[1], gxc[2], 0.0f);
             }
         }
-        __syncthreads();                                                 // the next tile's front overwrites idx / geo / the tiles
+        fp_sync<NB>();                                                 // the next tile's front overwrites idx / geo / the tiles
     }
     // ---- per-lane running sums: over the 16 edges (lanes) of the group
     auto lane16_sum = [](float v) {
