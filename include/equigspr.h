@@ -317,6 +317,17 @@ int equigspr_irrep_conv_forward(const float* f0, const float* f1, const float* d
                                 const float* k01, const float* k10, const float* k11, const float* w_self0, const float* w_self1,
                                 const int32_t* col, const int32_t* rptr, const int32_t* rperm, int32_t n_nodes, int32_t n_edges,
                                 int32_t c0_in, int32_t c1_in, int32_t c0_out, int32_t c1_out, float* out0, float* out1, void* stream);
+/* irrep_moments_forward: the aggregate-then-transform form of the same layer.  The radial profile is linear in the hidden radial
+ * activations (H <= 32 of them; `hid` is [E, 32], zero padded beyond column H, 16-byte aligned), so the sum over a node's incoming
+ * edges is taken first:
+ *   moments[n, j, h] = sum_{e: row = n} c[e, j] * hid~[e, h],  hid~ = [hid, 1],
+ *   c[e, :] = [ K00 f0[col] (C0i) | K10 . f1[col] (C1i) | K01[a] f0[col] (a-major, 3 C0i) | K11[a, :, J] . f1[col] ((a, J)-major, 9 C1i) ]
+ * (Lc = 4 C0i + 10 C1i <= 256 entries; J >= 1 kernels zero where dist = 0), in ascending edge order, no atomics.  The caller applies
+ * the radial weights to moments [N, Lc, H + 1] with dense GEMMs over nodes: nothing of size [E, n_w] is formed. */
+int equigspr_irrep_moments_forward(const float* f0, const float* f1, const float* dist, const float* hid, const float* k00,
+                                   const float* k01, const float* k10, const float* k11, const int32_t* col, const int32_t* rptr,
+                                   const int32_t* rperm, int32_t n_nodes, int32_t n_edges, int32_t c0_in, int32_t c1_in,
+                                   int32_t hidden, float* moments, void* stream);
 
 /* ---- A17: gcnLayer (src/gcnLayer.py) ------------------------------------------------------------
  * build_graph :58-67 (_get_weights :28-46, get_normalize_adj :49-56): w_ij = exp(-d_ij^2 / sigma2), sigma2 =

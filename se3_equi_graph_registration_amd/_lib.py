@@ -74,6 +74,7 @@ _SIGNATURES = {
     "equigspr_sh_forward": (ctypes.c_int, [c_void_p, c_int32, ctypes.c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "equigspr_sh_basis_forward": (ctypes.c_int, [c_void_p, ctypes.c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "equigspr_irrep_conv_forward": (ctypes.c_int, [c_void_p] * 13 + [c_int32] * 6 + [c_void_p] * 3),
+    "equigspr_irrep_moments_forward": (ctypes.c_int, [c_void_p] * 11 + [c_int32] * 5 + [c_void_p] * 2),
     "equigspr_eval_metrics": (ctypes.c_int, [c_void_p] * 5 + [c_int32, c_int32, ctypes.c_double, c_void_p, c_void_p]),
     "equigspr_pointnet_layer_forward": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 7 + [c_int32, c_void_p, c_void_p, c_void_p]),
     "equigspr_global_max_pool": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

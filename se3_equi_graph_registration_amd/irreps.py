@@ -8,9 +8,12 @@ messages are computed from the features at ``col`` and aggregated at ``row`` (th
 and a per-degree channel mixing acts as self-interaction.  The definition is written out in DESIGN.md section 2 and in the test
 infrastructure (parity unpinned by construction -- there is no reference layer -- pinned by SO(3) covariance).
 
-MI355X-first split of the work: the radial profile over all edges is one plain GEMM -> the library (ATen / rocBLAS, MFMA); the
-basis tensors come from the SH kernels of ``csrc/sh.hip``; the contraction radial x basis x gathered features for both degrees and
-the atomic-free aggregation are ONE hand-written launch (``csrc/irreps.hip``).  Forward in HIP; under grad the backward re-runs the
+MI355X-first split of the work: the basis tensors come from the SH kernels of ``csrc/sh.hip``; because the radial profile is LINEAR in
+the hidden radial activations, the sum over a node's incoming edges is taken BEFORE the radial weights are applied -- one hand-written
+launch accumulates per-node moments of [basis x gathered features] (x) [hid, 1] in ascending edge order (``csrc/irreps.hip``), and the
+radial weights then act on the moments as dense GEMMs over NODES (the library, MFMA): nothing of size [E, n_w] is formed (566 MB at one
+2 048-point pair).  Channel counts beyond that kernel's register budget (4 c0_in + 10 c1_in > 256) take the direct form: the radial
+profile as one GEMM over all edges + a contraction / aggregation launch.  Forward in HIP; under grad the backward re-runs the
 layer in device ops (``ops.hip_forward_aten_backward``) -- gradients with respect to the features and the weights (the geometry,
 i.e. ``x`` and the basis, is treated as constant, like the HIP ``get_basis`` itself).
 
@@ -85,6 +88,43 @@ class IrrepConv(nn.Module):
                                                           self.c1_out, _p(out0), _p(out1), _stream()), "irrep_conv_forward")
         return torch.cat([out0, out1.reshape(n, -1)], dim=1)        # one tensor for the autograd wrapper
 
+    # ---- aggregate-then-transform (the fast path): the radial profile is linear in the hidden radial activations, so the sum over a
+    # node's incoming edges is taken first (one HIP launch: per-node moments of [basis x gathered features] (x) [hid, 1]) and the radial
+    # weights are applied to the moments by dense GEMMs over NODES -- nothing of size [E, n_w] exists
+    def _fast_ok(self):
+        return self.hidden <= 32 and 4 * self.c0_in + 10 * self.c1_in <= 256
+
+    def _hip_fast(self, f0, f1, ws0, ws1, dist, k00, k01, k10, k11, graph):
+        n, H, HA = graph.n_nodes, self.hidden, self.hidden + 1
+        c0o, c0i, c1o, c1i = self.c0_out, self.c0_in, self.c1_out, self.c1_in
+        lin1, lin2 = self.radial[0], self.radial[2]
+        hid = torch.zeros(graph.n_edges, 32, dtype=torch.float32, device=f0.device)                    # [E, 32]: H columns, zero padded
+        hid[:, :H] = torch.nn.functional.silu(torch.addmm(lin1.bias.detach(), dist[:, None], lin1.weight.detach().t()))
+        Lc = 4 * c0i + 10 * c1i
+        M = torch.empty(n, Lc, HA, dtype=torch.float32, device=f0.device)
+        _lib.check(_lib.lib().equigspr_irrep_moments_forward(_p(f0), _p(f1), _p(dist), _p(hid), _p(k00), _p(k01), _p(k10), _p(k11), _p(graph.col),
+                                                             _p(graph.rptr), _p(graph.rperm), n, graph.n_edges, c0i, c1i, H, _p(M), _stream()),
+                   "irrep_moments_forward")
+        W = torch.cat([lin2.weight.detach(), lin2.bias.detach()[:, None]], dim=1)                    # [n_w, H + 1]: the bias rides on hid~'s constant 1
+        o = 0
+        W00 = W[o:o + c0o * c0i].reshape(c0o, c0i * HA); o += c0o * c0i
+        W01 = W[o:o + c1o * c0i].reshape(c1o, c0i * HA); o += c1o * c0i
+        W10 = W[o:o + c0o * c1i].reshape(c0o, c1i * HA); o += c0o * c1i
+        W11 = W[o:o + c1o * c1i * 3].reshape(c1o, c1i, 3, HA).permute(0, 2, 1, 3).reshape(c1o, 3 * c1i * HA)      # (J, i, h): the moments' order
+        o10, o01, o11 = c0i, c0i + c1i, c0i + c1i + 3 * c0i
+        out0 = torch.addmm(f0 @ ws0.t(), M[:, :o10].reshape(n, c0i * HA), W00.t())
+        out0 = torch.addmm(out0, M[:, o10:o01].reshape(n, c1i * HA), W10.t())
+        m01 = M[:, o01:o11].reshape(n * 3, c0i * HA)                                                   # rows (n, a)
+        m11 = M[:, o11:].reshape(n * 3, 3 * c1i * HA)
+        o1 = torch.addmm(m01 @ W01.t(), m11, W11.t()).view(n, 3, c1o).permute(0, 2, 1)                 # [n, o, a]
+        out1 = o1 + torch.einsum("oi,nia->noa", ws1, f1)
+        return torch.cat([out0, out1.reshape(n, -1)], dim=1)
+
+    def _hip_train(self, f0, f1, radial, ws0, ws1, *rest):
+        """Forward of the autograd wrapper: ``radial`` (= ``self._radial(dist)``, needed as a differentiable INPUT of the device-op
+        backward) is not read -- the fast path applies the same weights to the per-node moments."""
+        return self._hip_fast(f0, f1, ws0, ws1, *rest) if self._fast_ok() else self._hip(f0, f1, radial, ws0, ws1, *rest)
+
     def _aten(self, f0, f1, radial, ws0, ws1, dist, k00, k01, k10, k11, graph):
         """The same layer in device ops (backward recompute only; the layer definition line by line)."""
         row, col = graph.row[:graph.n_edges].long(), graph.col[:graph.n_edges].long()
@@ -117,13 +157,17 @@ class IrrepConv(nn.Module):
         graph = self._graph(edges, n)
         with torch.no_grad():
             dist, k00, k01, k10, k11 = self._geometry(x.detach(), graph)
-        radial = self._radial(dist)                              # differentiable (ATen): the radial weights get their gradients here
         ws0, ws1 = self.self0.weight, self.self1.weight
         rest = (dist, k00, k01, k10, k11, graph)
-        if torch.is_grad_enabled() and any(t.requires_grad for t in (f0, f1, radial, ws0, ws1)):
-            out = hip_forward_aten_backward(self._hip, self._aten, (f0, f1, radial, ws0, ws1), rest)
+        training = torch.is_grad_enabled() and (f0.requires_grad or f1.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if training:
+            radial = self._radial(dist)                          # differentiable (ATen): the radial weights get their gradients through it
+            out = hip_forward_aten_backward(self._hip_train, self._aten, (f0, f1, radial, ws0, ws1), rest)
+        elif self._fast_ok():
+            out = self._hip_fast(f0, f1, ws0.detach(), ws1.detach(), *rest)
         else:
-            out = self._hip(f0, f1, radial.detach(), ws0.detach(), ws1.detach(), *rest)
+            with torch.no_grad():
+                out = self._hip(f0, f1, self._radial(dist), ws0.detach(), ws1.detach(), *rest)
         return out[:, :self.c0_out], out[:, self.c0_out:].reshape(n, self.c1_out, 3)
 
 
