@@ -593,6 +593,8 @@ class GraphedStep:
         for entry in pending_log:
             self._report(entry, epoch, skip_nonfinite)
         st = self.last_stats = adam.guard_stats()
+        if st["applied"] > 0:
+            self.opt._opt_called = True        # what torch's lr_scheduler looks at to tell "scheduler.step() before optimizer.step()"
         _check_head_waits(self)
         self._check(st, epoch, skip_nonfinite)
         loss_sum, applied = st["loss_sum"], st["applied"]
