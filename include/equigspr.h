@@ -32,8 +32,8 @@ extern "C" {
 /* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
  * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
  * Supported kernel set: hidden_nf in {16, 32, 33, 48, 64} (32 / 33: the 16-edge MFMA edge kernels of csrc/egnn_mfma16.h; 16 / 48 / 64:
- * the feature-parallel MFMA edge kernels of csrc/egnn_edge_fp.h), num_heads in {1, 2, 4, 8} (1 at hidden_nf 33; in_edge_nf 0 at
- * 16 / 48 / 64 only with one head: the instantiation list),
+ * the feature-parallel MFMA edge kernels of csrc/egnn_edge_fp.h), num_heads in {1, 2, 4, 8} (1 at hidden_nf 33: the other divisors
+ * of 33 are not instantiated),
  * in_nf/out_nf <= 64, in_edge_nf in {0, 1}, 1 <= n_layers <= 16. */
 typedef struct equigspr_egnn_config {
     int32_t in_nf;       /* in_node_nf  */

@@ -58,9 +58,8 @@ inline bool config_supported(const equigspr_egnn_config* c) {
     if (!c) return false;
     const int hd = c->num_heads;
     const bool h_ok = hd == 1 || hd == 2 || hd == 4 || hd == 8;
-    const bool lane_width = c->hidden_nf == 16 || c->hidden_nf == 48 || c->hidden_nf == 64;      // egnn_edge_fp.h / egnn_edge_lane.h: in_edge_nf 0 only with one head (instantiation list)
-    const bool f_ok = (c->hidden_nf == 32 && h_ok) || (c->hidden_nf == 33 && hd == 1) ||
-                      (lane_width && h_ok && (c->in_edge_nf == 1 || hd == 1));
+    const bool fp_width = c->hidden_nf == 16 || c->hidden_nf == 48 || c->hidden_nf == 64;        // egnn_edge_fp.h
+    const bool f_ok = (c->hidden_nf == 32 && h_ok) || (c->hidden_nf == 33 && hd == 1) || (fp_width && h_ok);
     return f_ok && c->in_nf >= 1 && c->in_nf <= 64 && c->out_nf >= 1 && c->out_nf <= 64 &&
            (c->in_edge_nf == 0 || c->in_edge_nf == 1) && c->n_layers >= 1 && c->n_layers <= 16 &&
            (c->edge_basis == EQUIGSPR_BASIS_FRAMES || c->edge_basis == EQUIGSPR_BASIS_IRREPS);

@@ -23,8 +23,11 @@
 // hidden widths without an MFMA formulation (egnn_edge_lane.h): 16, 48, 64 with 1, 2, 4 or 8 heads (in_edge_nf 1; 0 with one head)
 #define EQ_DISPATCH_LANE_WIDTHS \
     EQ_DISPATCH(16, 1, 1) EQ_DISPATCH(16, 1, 0) EQ_DISPATCH(16, 2, 1) EQ_DISPATCH(16, 4, 1) EQ_DISPATCH(16, 8, 1) \
+    EQ_DISPATCH(16, 2, 0) EQ_DISPATCH(16, 4, 0) EQ_DISPATCH(16, 8, 0) \
     EQ_DISPATCH(48, 1, 1) EQ_DISPATCH(48, 1, 0) EQ_DISPATCH(48, 2, 1) EQ_DISPATCH(48, 4, 1) EQ_DISPATCH(48, 8, 1) \
-    EQ_DISPATCH(64, 1, 1) EQ_DISPATCH(64, 1, 0) EQ_DISPATCH(64, 2, 1) EQ_DISPATCH(64, 4, 1) EQ_DISPATCH(64, 8, 1)
+    EQ_DISPATCH(48, 2, 0) EQ_DISPATCH(48, 4, 0) EQ_DISPATCH(48, 8, 0) \
+    EQ_DISPATCH(64, 1, 1) EQ_DISPATCH(64, 1, 0) EQ_DISPATCH(64, 2, 1) EQ_DISPATCH(64, 4, 1) EQ_DISPATCH(64, 8, 1) \
+    EQ_DISPATCH(64, 2, 0) EQ_DISPATCH(64, 4, 0) EQ_DISPATCH(64, 8, 0)
 
 namespace eq {
 

@@ -48,7 +48,7 @@ def make_config(in_nf, hidden_nf, out_nf, in_edge_nf, n_layers, num_heads, edge_
     if _lib.lib().equigspr_egnn_param_count(ctypes.byref(cfg)) < 0:
         raise NotImplementedError(
             f"EGNN config outside the compiled HIP kernel set: hidden_nf={hidden_nf} (16|32|33|48|64), num_heads={num_heads} "
-            f"(1|2|4|8; 1 at hidden_nf 33; in_edge_nf 0 at widths 16/48/64 only with one head), in/out_nf<=64, in_edge_nf in (0,1), n_layers<=16")
+            f"(1|2|4|8; 1 at hidden_nf 33), in/out_nf<=64, in_edge_nf in (0,1), n_layers<=16")
     return cfg
 
 

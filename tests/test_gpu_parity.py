@@ -551,7 +551,7 @@ def test_backward_random_graph_vs_oracle_autograd(pk, feat, heads, in_nf, out_nf
         _grad_check(p.grad, refs["f32"][pn], refs["f64"][pn], pn)
 
 
-@pytest.mark.parametrize("feat,heads", [(32, 1), (32, 4), (33, 1), (48, 1), (16, 1)])
+@pytest.mark.parametrize("feat,heads", [(32, 1), (32, 4), (33, 1), (48, 1), (16, 1), (64, 4), (48, 2), (16, 8)])
 def test_no_edge_attribute_forward_backward_vs_oracle(pk, feat, heads):
     """in_edge_nf = 0 (the reference E_GCL's own default, edges_in_d = 0, train :186): the edge MLP's first layer is 2F + 12 wide and
     no attribute column exists -- forward and every gradient against the oracle, on the MFMA kernels and on the lane kernels."""
