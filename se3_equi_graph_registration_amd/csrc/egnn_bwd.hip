@@ -1170,7 +1170,7 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
             }
         }
         int blocks = ceil_div(ceil_div(E, 16), L::kTpb);
-        blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+        blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);          // = bwd_layout's slab copies for these widths
         hipLaunchKernelGGL((edge_bwd_fp_kernel<F, H, A>), dim3(blocks), dim3(64 * L::NW), smem, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx, E,
                            basis, dt1, gxr, gxc, slab);
         *n_slabs = blocks;
@@ -1308,7 +1308,9 @@ static BwdLayout bwd_layout(int F, int in_nf, int out_nf, int64_t N, int64_t E, 
     // slab sets: one per layer (layer l at + l * layer_stride), sized for the blocks this problem actually launches
     const int NS = 256 / (F <= 32 ? 32 : 64);
     const size_t node_blocks = std::min<size_t>((N + NS - 1) / NS, kNodeBwdBlocks);
-    const size_t edge_blocks = 256;                    // persistent edge_bwd grid: at most one workgroup per CU
+    // slab copies of the edge backward: one workgroup per CU for the persistent 16-edge kernels; the feature-parallel kernels of
+    // hidden_nf 16 / 48 / 64 run up to two small workgroups per CU
+    const size_t edge_blocks = (F % 16 == 0 && F != 32) ? 512 : 256;
     const size_t emb = (size_t)64 * F + 64;
     B.emb_slab = take(node_blocks * emb);
     B.emb_slab2 = take(node_blocks * emb);

@@ -11,7 +11,7 @@
 //   summed in fixed wave order by everyone (bitwise reproducible);
 //   weight gradients: wave w accumulates rows 16 w .. 16 w + 15 of dW6, dW2, dWgeo (NB + NB + 1 accumulators) -- no merge at the end,
 //   every wave writes its own rows of the workgroup's slab.
-// A workgroup runs kTpb tile groups side by side (two waves per SIMD at NB = 4) over one shared LDS weight image.
+// Tile groups per workgroup: fp_tpb below.
 // Same math as E_GCL.edge_model / coord_model (:231-268), same interfaces as the other edge kernels: m rows at the edge's
 // aggregation position, trans [E][4], dt1 rows [E][FP], gxr / gxc [E][4], Slabs<F>::edge.  (Round 4; the lane-per-feature kernels
 // of egnn_edge_lane.h were ~5x slower per flop: 506 / 124 us backward / forward per launch at hidden_nf 64, one 2 048-point pair.)
@@ -20,13 +20,16 @@
 
 namespace eq {
 
-constexpr int fp_tpb(int F) { return F / 16 >= 3 ? 2 : 4; }             // tile groups per workgroup: 8 / 6 / 4 waves at 64 / 48 / 16
-constexpr int fp_threads(int F) { return 64 * (F / 16) * fp_tpb(F); }
+// tile groups per workgroup (measured at hidden_nf 64, one pair): the forward likes two (36 us against 44 with one), the backward one
+// (83 us against 93 with two once its image had shrunk to 43 KB) -- a workgroup barrier then synchronises exactly the NB waves that
+// exchange data, and the workgroups a CU holds run out of step.  hidden_nf 16: four one-wave groups, no workgroup barrier in the tile loop.
+constexpr int fp_tpb(int F, bool bwd) { return F / 16 >= 3 ? (bwd ? 1 : 2) : 4; }
+constexpr int fp_threads(int F, bool bwd) { return 64 * (F / 16) * fp_tpb(F, bwd); }
 
 template <int F, int H, int A, bool kBwd>
 struct FpLayout {
     static constexpr int NB = F / 16, FH = F / H;
-    static constexpr int kTpb = fp_tpb(F);
+    static constexpr int kTpb = fp_tpb(F, kBwd);
     static constexpr int NW = NB * kTpb;
     static constexpr int WS = F + 8;                                     // row stride of the F-column matrices (b128 A-operand reads conflict-free)
     static constexpr int GS = 24;                                        // Wgeo [F][16 (+8)]
@@ -36,10 +39,9 @@ struct FpLayout {
     static constexpr int o_w6 = o_w2 + F * WS;
     static constexpr int o_wg = o_w6 + F * WS;
     static constexpr int o_vec = o_wg + F * GS;                          // b2 | gamma | beta | b6 | w7
-    static constexpr int o_w2t = o_vec + 5 * F;                          // backward only: transposed copies
-    static constexpr int o_w6t = o_w2t + F * WS;
-    static constexpr int o_wgt = o_w6t + F * WS;                         // WgeoT [16][WS]
-    static constexpr int image = kBwd ? o_wgt + 16 * WS : o_w2t;
+    static constexpr int image = o_vec + 5 * F;                          // (no transposed copies: the backward reads W^T operands column-wise,
+                                                                         //  four ds_read_b32 instead of one b128 -- the image stays at 43 KB at
+                                                                         //  width 64 and two workgroups share a CU)
     // per tile group
     static constexpr int g_v = 0;                                        // V [16][VS]
     static constexpr int g_x = g_v + 16 * VS;                            // backward: X (dq, then du), Z (dt1)
@@ -69,13 +71,11 @@ __device__ __forceinline__ void fp_stage_image(float* sm, const float* __restric
         const float v6 = lw[LL::w6 + i * F + k];
         sm[L::o_w2 + i * L::WS + k] = v2;
         sm[L::o_w6 + i * L::WS + k] = v6;
-        if (kBwd) { sm[L::o_w2t + k * L::WS + i] = v2; sm[L::o_w6t + k * L::WS + i] = v6; }
     }
     for (int t = threadIdx.x; t < F * 16; t += nthreads) {
         const int i = t >> 4, k = t & 15;
         const float v = k < kGeo + A ? lw[LL::w1_off(i, 2 * F + k)] : 0.0f;
         sm[L::o_wg + i * L::GS + k] = v;
-        if (kBwd) sm[L::o_wgt + k * L::WS + i] = v;
     }
     for (int t = threadIdx.x; t < 5 * F; t += nthreads) {
         const int w = t / F, k = t - w * F;
@@ -100,6 +100,22 @@ __device__ __forceinline__ f32x4 fp_matvec(const float* mat, const float* V, int
         const f32x4 b = lds4(V + i * L::VS + 16 * bi + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc = mfma16(a[r], b[r], acc);
+    }
+    return acc;
+}
+
+// y_w (+)= sum over the live input blocks of  W^T[16 w + i][16 bi + 4 g + r] * V[e][16 bi + 4 g + r]  =  W[16 bi + 4 g + r][16 w + i] * ...
+// read column-wise from the un-transposed image (lanes i = 0..15 touch consecutive words: conflict-free)
+template <int F, int H, int A, bool kBlockDiag>
+__device__ __forceinline__ f32x4 fp_matvec_t(const float* mat, const float* V, int w, int i, int g, f32x4 acc) {
+    using L = FpLayout<F, H, A, true>;
+#pragma unroll
+    for (int bi = 0; bi < L::NB; ++bi) {
+        if (kBlockDiag && !L::w2_block_live(bi, w)) continue;            // wave-uniform
+        const float* col = mat + (16 * bi + 4 * g) * L::WS + 16 * w + i;
+        const f32x4 b = lds4(V + i * L::VS + 16 * bi + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16(col[r * L::WS], b[r], acc);
     }
     return acc;
 }
@@ -178,7 +194,7 @@ __device__ __forceinline__ void fp_tile_forward(const float* img, float* grp, co
 }
 
 template <int F, int H, int A>
-__global__ __launch_bounds__(fp_threads(F)) void edge_fwd_fp_kernel(
+__global__ __launch_bounds__(fp_threads(F, false)) void edge_fwd_fp_kernel(
     const float* __restrict__ lw, const int* __restrict__ row, const int* __restrict__ col, const float* __restrict__ edge_attr,
     const float* __restrict__ x, const float* __restrict__ P, const int* __restrict__ rinv, int n_edges, int basis,
     float* __restrict__ m_out, float* __restrict__ trans_out) {
@@ -245,7 +261,7 @@ __device__ __forceinline__ void fp_outer(const float* X, const float* Y, int ldy
 }
 
 template <int F, int H, int A>
-__global__ __launch_bounds__(fp_threads(F)) void edge_bwd_fp_kernel(
+__global__ __launch_bounds__(fp_threads(F, true)) void edge_bwd_fp_kernel(
     const float* __restrict__ lw, const int* __restrict__ row, const int* __restrict__ col, const float* __restrict__ edge_attr,
     const float* __restrict__ x, const float* __restrict__ P, const float* __restrict__ dagg, const float* __restrict__ Gx, int n_edges,
     int basis, float* __restrict__ dt1_out, float* __restrict__ gxr_out, float* __restrict__ gxc_out, float* __restrict__ slab) {
@@ -310,7 +326,7 @@ __global__ __launch_bounds__(fp_threads(F)) void edge_bwd_fp_kernel(
         fp_sync<NB>();
         fp_outer<F, H, A, NB, false>(X, V, L::VS, w, i, g, acc6);        // dW6 rows += dq^T m
         // ---- dm = dagg[row] + W6^T dq
-        const f32x4 dm = fp_matvec<F, H, A, true, false>(sm + L::o_w6t, X, w, i, g, da);
+        const f32x4 dm = fp_matvec_t<F, H, A, false>(sm + L::o_w6, X, w, i, g, da);
         ls_gam = fma4(dm, o.xhat, ls_gam);
         ls_bet += dm;
         // ---- LayerNorm backward
@@ -331,7 +347,7 @@ __global__ __launch_bounds__(fp_threads(F)) void edge_bwd_fp_kernel(
         fp_sync<NB>();
         fp_outer<F, H, A, NB, true>(X, V, L::VS, w, i, g, acc2);         // dW2 rows += du^T SiLU(t1)
         // ---- dt1 = (W2^T du) * SiLU'(t1)
-        f32x4 dt1 = fp_matvec<F, H, A, true, true>(sm + L::o_w2t, X, w, i, g, splat4(0.0f));
+        f32x4 dt1 = fp_matvec_t<F, H, A, true>(sm + L::o_w2, X, w, i, g, splat4(0.0f));
         dt1 *= silu_grad4(o.t1, o.sg1);
         if (valid) st4(dt1_out + (size_t)eg_ * FP + 16 * w + 4 * g, dt1);
         st4(Z + i * L::VS + 16 * w + 4 * g, dt1);
@@ -341,10 +357,10 @@ __global__ __launch_bounds__(fp_threads(F)) void edge_bwd_fp_kernel(
             f32x4 dg = splat4(0.0f);
 #pragma unroll
             for (int bi = 0; bi < NB; ++bi) {
-                const f32x4 a = lds4(sm + L::o_wgt + i * L::WS + 16 * bi + 4 * g);
+                const float* colg = sm + L::o_wg + (16 * bi + 4 * g) * L::GS + i;          // Wgeo^T[i][16 bi + 4 g + r] = Wgeo[16 bi + 4 g + r][i]
                 const f32x4 b = lds4(Z + i * L::VS + 16 * bi + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dg = mfma16(a[r], b[r], dg);
+                for (int r = 0; r < 4; ++r) dg = mfma16(colg[r * L::GS], b[r], dg);
             }
             st4(dgeo + i * 16 + 4 * g, dg);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
