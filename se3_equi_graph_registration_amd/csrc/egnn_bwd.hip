@@ -1053,11 +1053,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
         lsb_w7 = bsl[64 * 13]; lsb_gam = bsl[64 * 14]; lsb_bet = bsl[64 * 15];
     }
     // ---- partial sums of the waves: every wave writes a slab copy into its scratch, all threads add the copies in fixed order
-    auto lane16_sum = [](float v) {                    // over the 16 lanes (edges) of a group
-#pragma unroll
-        for (int o_ = 1; o_ <= 8; o_ <<= 1) v += __shfl_xor(v, o_, 64);
-        return v;
-    };
+    auto lane16_sum = [](float v) { return row16_sum(v); };      // over the 16 lanes (edges) of a group
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         if (!kRun) { cs_b6[b] = gsum(cs_b6[b]); cs_b2[b] = gsum(cs_b2[b]); }
@@ -1080,6 +1076,9 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
         lsb_b6 = gsum(pb6.xbs); lsb_b2 = gsum(pb2.xbs);     // g = 0's copy is written
     }
     __builtin_amdgcn_wave_barrier();
+#ifdef EQ_TRACE_MERGE
+    EQ_STAMP(4);
+#endif
     {
         float* sl = sc;
 #pragma unroll
@@ -1121,7 +1120,13 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             }
         }
     }
+#ifdef EQ_TRACE_MERGE
+    EQ_STAMP(5);
+#endif
     __syncthreads();
+#ifdef EQ_TRACE_MERGE
+    EQ_STAMP(6);
+#endif
     if constexpr (SB::edge % 4 == 0 && kScratch % 4 == 0) {        // hidden_nf 32: four entries per thread and step
         for (int t = 4 * threadIdx.x; t < SB::edge; t += 4 * 64 * NW) {
             f32x4 a = lds4(&scratch[0][t]);

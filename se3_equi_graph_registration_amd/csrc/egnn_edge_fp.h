@@ -384,11 +384,7 @@ __global__ __launch_bounds__(fp_threads(F, true)) void edge_bwd_fp_kernel(
         fp_sync<NB>();                                                 // the next tile's front overwrites idx / geo / the tiles
     }
     // ---- per-lane running sums: over the 16 edges (lanes) of the group
-    auto lane16_sum = [](float v) {
-#pragma unroll
-        for (int o_ = 1; o_ <= 8; o_ <<= 1) v += __shfl_xor(v, o_, 64);
-        return v;
-    };
+    auto lane16_sum = [](float v) { return row16_sum(v); };      // over the 16 lanes (edges) of a group
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         ls_w7[k] = lane16_sum(ls_w7[k]); ls_gam[k] = lane16_sum(ls_gam[k]); ls_bet[k] = lane16_sum(ls_bet[k]);

@@ -65,6 +65,19 @@ __device__ __forceinline__ void gsum2(float& p, float& q) {
     q = __uint_as_float(c[1]);
 }
 
+// sum over the 16 lanes of a row (lanes 16 g .. 16 g + 15: the 16 edges of a tile), every lane gets the sum: four VALU adds whose
+// second operand is swizzled in flight (DPP: quad xor 1, quad xor 2, half-row mirror, row mirror) -- the same pairing tree as
+// __shfl_xor 1, 2, 4, 8 (bit-identical sums) without its four ds_bpermute round trips per value (28 values per wave at the end of
+// edge_bwd16: 3.7 k -> 1.1 k cycles of every wave's tail, trace build)
+__device__ __forceinline__ float row16_sum(float v) {
+    auto step = [](float x, int y) { return x + __int_as_float(y); };
+    v = step(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));      // quad_perm [1, 0, 3, 2]
+    v = step(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));      // quad_perm [2, 3, 0, 1]
+    v = step(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));     // row_half_mirror
+    v = step(v, __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));     // row_mirror
+    return v;
+}
+
 // LDS image of a layer's edge-MLP weights.  Row strides chosen so that the per-lane 16-byte operand fetches
 // (row = 16 bo + i, column 16 bi + 4 g) of every 16-lane ds_read_b128 group fall on distinct banks.
 // hidden_nf = 33 (kB = 1): the 32 x 32 cores stay on the matrix cores; feature 32 (the "border") is a scalar per edge held by

@@ -11,7 +11,7 @@ import se3_equi_graph_registration_amd as pk
 from se3_equi_graph_registration_amd import _lib, ops
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-N, K, F = 2048, 20, 32
+N, K, F = 2048, (int(sys.argv[2]) if len(sys.argv) > 2 else 20), 32
 dev = torch.device("cuda:0")
 L = _lib.lib()
 raw = ctypes.CDLL(os.environ["EQUIGSPR_LIB"])
@@ -81,3 +81,9 @@ report("edge_bwd16 (last chunk / sub-tile of each wave)", buf,
         (5, "geo product, sigmoid"), (6, "W2"), (7, "LayerNorm"), (8, "W6"), (9, "sigmoid, w7 dot"), (10, "dq, stage, dW6 pass"),
         (11, "dagg rows, W6^T dq"), (12, "LN bwd, stage, dW2 pass"), (13, "W2^T du, dt1 store, dWgeo pass, Wgeo^T dt1"),
         (14, "back: geometry bwd + stores"), (15, "other chunks' wait + block reduce + slab")], 8)
+if os.environ.get("EQ_TRACE_MERGE"):       # trace library built with -DEQ_TRACE_MERGE: slots 4, 5, 6 are re-used by the merge
+    st = buf.cpu().numpy().reshape(-1, SLOTS)[:WAVES]
+    st = st[st[:, 0] > 0]
+    for a, b, lab in [(14, 4, "lane sums"), (4, 5, "slab copy -> LDS"), (5, 6, "workgroup barrier"), (6, 15, "block sum + slab store (drained)")]:
+        d = st[:, b] - st[:, a]
+        print(f"   merge: {lab:40s} median {int(np.median(d)):7d}  p90 {int(np.percentile(d, 90)):7d}")
