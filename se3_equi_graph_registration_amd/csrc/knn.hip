@@ -203,27 +203,37 @@ __global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, in
 
 // ---------------------------------------------------------------------------------------
 // Tiled multi-query form (used for n > 2 048): the per-query kernel above re-reads the whole cloud from L2 for every query
-// (and its 128-candidates-per-lane variant spills).  Here a workgroup of 4 waves owns 16 queries of one cloud; candidate tiles
-// of 2 048 points are staged through LDS once per workgroup and every candidate read from LDS is tested against the wave's 4
-// queries -- two queries per packed instruction.  Two passes over the tiles (lane minima -> tau; count + compaction); same
-// lane <-> candidate assignment, same arithmetic, same key order as knn_kernel, so the results are bit-identical.
+// (and its 128-candidates-per-lane variant spills).  Here a workgroup of 4 waves owns 16 (32) queries of one cloud; candidate tiles
+// of 2 048 points are staged through LDS once per workgroup and pass.  Same lane <-> candidate assignment (candidate 64 s + l of a
+// tile belongs to lane l), same arithmetic, same key order as knn_kernel, so the results are bit-identical.
+//   pass 1: every candidate read from LDS is tested against the wave's 4 (8) queries, two queries per packed instruction; a lane
+//           keeps the minimum of each 16-candidate CHUNK it owns (2 per tile: s < 16, s >= 16) -> lane minima -> tau.
+//   pass 2: only the chunks whose minimum is <= tau can hold a candidate <= tau: ~1 chunk per candidate, ~30-45 of the cloud's
+//           256-512.  Per query, the live chunks of a tile (two ballots) are visited four per step (16 lanes each) and their
+//           candidates <= tau compacted -- ~8-14 steps per query instead of re-scanning all 64-128 (with the point-wise staging
+//           below: two 8 192-point clouds, k = 32: 102 -> 76 us per launch; sixteen 4 096-point clouds, k = 20: 175 -> 136 us).
+// The tile is stored lane-major and rotated: candidate 64 s + l at point 32 l + ((s + l) & 31) -- pass 1 (lane l reads its s-th
+// candidate) and pass 2 (16 lanes read the 16 candidates of a chunk) are both free of LDS bank conflicts without padding (one
+// padded point per lane had cost the 8-queries-per-wave variant a workgroup per CU).
 // The (rare) slow path of a query re-scans the cloud from global memory with its own wave.
 // ---------------------------------------------------------------------------------------
 constexpr int kKnnTile = 2048;
+__device__ __forceinline__ int knn_tile_point(int l, int s) { return 32 * l + ((s + l) & 31); }      // of candidate 64 s + l
 // kKnnQpw = queries per wave (even: two per packed instruction): 8 when that still leaves >= 8 workgroups per CU (measured:
 // KITTI shard 197 -> 171 us), 4 otherwise (two 8 192-point clouds: 99 us against 122 with 8 and 109 with 2)
 // kCap = entries of a query's compaction list: 64 (one key per lane) while k <= 24 -- the 24th of 64 lane minima leaves ~30 candidates,
 // > 64 practically never -- and 128 (two keys per lane, rank_by_counting2) above, where a k = 32 query keeps ~44 on average and a few
 // of every 16 384 exceed 64.  A template parameter because the list is LDS: 128 entries for the 32 queries of the 8-per-wave variant
 // cost it half its occupancy (KITTI shard, k = 20: 173 -> 264 us when every launch paid for them).
-template <bool kLoop, int kKnnQpw, int kCap>
+// kTiles = tiles of the cloud (2: n <= 4 096, 4: n <= 8 192): the chunk minima are registers, 2 kTiles per query.
+template <bool kLoop, int kKnnQpw, int kCap, int kTiles>
 __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict__ x, int n_clouds, int n, int k,
                                                         long long* __restrict__ edges, int* __restrict__ row32,
                                                         int* __restrict__ col32, int* __restrict__ row_hist,
                                                         int* __restrict__ arrival, int force_slow) {
     __shared__ float tile[kKnnTile * 3];
     __shared__ u64 list[4 * kKnnQpw][kCap];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform BY CONSTRUCTION: the query ids and pass 2's chunk masks stay scalar
     const int bpc = (n + 4 * kKnnQpw - 1) / (4 * kKnnQpw);      // workgroups per cloud
     const int cloud = blockIdx.x / bpc;
     const int q0 = (blockIdx.x - cloud * bpc) * 4 * kKnnQpw + wv * kKnnQpw;
@@ -252,63 +262,124 @@ __global__ __launch_bounds__(256) void knn_tiled_kernel(const float* __restrict_
             v[2 * h] = a[0]; v[2 * h + 1] = a[1];
         }
     };
-    auto dist2 = [&](int u, float px, float py, float pz) {   // scalar form of the same contract (slow path)
+    auto dist2 = [&](int u, float px, float py, float pz) {   // scalar form of the same contract (pass 2, slow path)
         return dist2_scalar(px, py, pz, qx[u], qy[u], qz[u]);
     };
+    // a thread stages whole points: candidate j = 256 q + threadIdx.x of the tile has lane id j & 63 = this thread's lane and
+    // s = j >> 6 = 4 q + wave -- no divisions, and all 24 loads of a thread are in flight before the first LDS write (the
+    // element-wise loop this replaces exposed the L2 latency several times per tile: 30 us of a 93 us launch at two 8 192-point clouds)
     auto stage = [&](int t0, int cnt) {
         __syncthreads();
-        for (int i = threadIdx.x; i < cnt * 3; i += 256) tile[i] = xc[(size_t)t0 * 3 + i];
+        const float* src = xc + (size_t)t0 * 3;
+        float px[8], py[8], pz[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int j = min(256 * q + (int)threadIdx.x, cnt - 1);
+            px[q] = src[3 * j]; py[q] = src[3 * j + 1]; pz[q] = src[3 * j + 2];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (256 * q + (int)threadIdx.x < cnt) {
+                float* dst = tile + 3 * knn_tile_point(lane, 4 * q + wv);
+                dst[0] = px[q]; dst[1] = py[q]; dst[2] = pz[q];
+            }
+        }
         __syncthreads();
     };
-    // ---- pass 1: per-lane minima
-    float lmin[kKnnQpw];
+    // ---- pass 1: per-lane minima, kept per 16-candidate chunk
+    float cmin[kTiles][2][kKnnQpw];
 #pragma unroll
-    for (int u = 0; u < kKnnQpw; ++u) lmin[u] = INF;
-    for (int t0 = 0; t0 < n; t0 += kKnnTile) {
-        const int cnt = min(kKnnTile, n - t0);
-        stage(t0, cnt);
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int u = 0; u < kKnnQpw; ++u) cmin[t][hf][u] = INF;
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) {
+        const int t0 = t * kKnnTile;
+        if (t0 < n) {                                       // uniform over the grid's workgroups of a launch
+            const int cnt = min(kKnnTile, n - t0);
+            stage(t0, cnt);
+            const bool whole = cnt == kKnnTile;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll 4
-        for (int j = lane; j < cnt; j += 64) {
-            float v[kKnnQpw];
-            dist4(tile[3 * j], tile[3 * j + 1], tile[3 * j + 2], v);
+                for (int s = 16 * hf; s < 16 * hf + 16; ++s) {
+                    if (whole || 64 * s + lane < cnt) {
+                        float v[kKnnQpw];
+                        const float* pt = tile + 3 * knn_tile_point(lane, s);
+                        dist4(pt[0], pt[1], pt[2], v);
 #pragma unroll
-            for (int u = 0; u < kKnnQpw; ++u) {
-                if (!kLoop && t0 + j == qi[u]) v[u] = INF;
-                lmin[u] = fminf(lmin[u], v[u]);
+                        for (int u = 0; u < kKnnQpw; ++u) {
+                            if (!kLoop && t0 + 64 * s + lane == qi[u]) v[u] = INF;
+                            cmin[t][hf][u] = fminf(cmin[t][hf][u], v[u]);
+                        }
+                    }
+                }
             }
         }
     }
     float tau[kKnnQpw];
 #pragma unroll
     for (int u = 0; u < kKnnQpw; ++u) {
-        tau[u] = __uint_as_float(wave_kth_smallest_bits(__float_as_uint(lmin[u]), k));
+        float lmin = INF;
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) lmin = fminf(lmin, fminf(cmin[t][0][u], cmin[t][1][u]));
+        tau[u] = __uint_as_float(wave_kth_smallest_bits(__float_as_uint(lmin), k));
     }
-    // ---- pass 2: count the candidates <= tau and compact the first 64 of them
+    // ---- pass 2: the candidates <= tau of the live chunks, compacted (the first kCap of them)
     int base[kKnnQpw];
 #pragma unroll
     for (int u = 0; u < kKnnQpw; ++u) base[u] = 0;
-    for (int t0 = 0; t0 < n; t0 += kKnnTile) {
-        const int cnt = min(kKnnTile, n - t0);
-        stage(t0, cnt);
-        for (int j0 = 0; j0 < cnt; j0 += 64) {             // wave-uniform trip count (ballots inside)
-            const int j = j0 + lane;
-            const bool whole = j0 + 64 <= cnt;             // wave-uniform: no lane of this step is past the tile's end
-            const bool in = whole || j < cnt;
-            const int jj = in ? j : 0;
-            float v[kKnnQpw];
-            dist4(tile[3 * jj], tile[3 * jj + 1], tile[3 * jj + 2], v);
-            const int idx = t0 + j;
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t) {
+        const int t0 = t * kKnnTile;
+        if (t0 < n) {
+            const int cnt = min(kKnnTile, n - t0);
+            stage(t0, cnt);
 #pragma unroll
             for (int u = 0; u < kKnnQpw; ++u) {
-                float vu = v[u];
-                if (!whole) vu = in ? vu : INF;
-                if (!kLoop) vu = idx == qi[u] ? INF : vu;
-                const bool pred = vu <= tau[u];
-                const u64 mask = __ballot(pred);
-                if (mask) {                                // wave-uniform: few of the 64-candidate steps hold a candidate <= tau
-                    const int at = base[u] + rank_in_mask(mask);
-                    if (pred && at < kCap) list[wv * kKnnQpw + u][at] = pack_key(vu, idx);
-                    base[u] += __popcll(mask);
+                // chunk id = 64 * half + lane.  The live chunks of the query in this tile, in rank order, WITHOUT scalar bit loops (popping
+                // four set bits per step from the two ballot masks cost ~50 scalar instructions a step, and the CU's one scalar unit
+                // was the kernel's bottleneck: 35 us of pass 2 at two 8 192-point clouds): every lane sends its id to the lane of its
+                // rank -- live lanes to ranks 0 .. n0 - 1, the others behind them, a bijection, so one ds_permute per half and no LDS
+                // memory -- and a step's four chunk ids are one ds_bpermute pull.
+                if (qi[u] >= n) continue;                  // wave-uniform: a query past the cloud's end has no output
+                const bool p0 = cmin[t][0][u] <= tau[u], p1 = cmin[t][1][u] <= tau[u];
+                const u64 m0 = __ballot(p0), m1 = __ballot(p1);
+                const int n0 = __popcll(m0), tot = n0 + __popcll(m1);
+                if (tot == 0) continue;
+                const int k0 = rank_in_mask(m0), k1 = rank_in_mask(m1);
+                const int ids0 = __builtin_amdgcn_ds_permute(4 * (p0 ? k0 : n0 + (lane - k0)), lane);                 // ids0[r] = r-th live lane of half 0
+                const int ids1 = __builtin_amdgcn_ds_permute(4 * (p1 ? k1 : (tot - n0) + (lane - k1)), 64 + lane);     // ... of half 1 (as chunk ids)
+                // rank r of the query's list: half 0's n0 chunks, then half 1's
+                const int lo = __builtin_amdgcn_ds_bpermute(4 * ((lane - n0) & 63), ids1);
+                const int ids_a = lane < n0 ? ids0 : lo;                                                                // ranks 0 .. 63
+                const int ids_b = __builtin_amdgcn_ds_bpermute(4 * ((64 + lane - n0) & 63), ids1);                      // ranks 64 .. 127 (tot > 64 only: n0 > 0 there)
+                for (int r0 = 0; r0 < tot; r0 += 4) {
+                    const int rr = r0 + (lane >> 4);
+                    const int from_a = __builtin_amdgcn_ds_bpermute(4 * (rr & 63), ids_a);
+                    int my = from_a;
+                    if (tot > 64) {                        // wave-uniform, practically never
+                        const int from_b = __builtin_amdgcn_ds_bpermute(4 * (rr & 63), ids_b);
+                        my = rr < 64 ? from_a : from_b;
+                    }
+                    my = rr < tot ? my : -1;
+                    const int l = my & 63, sft = ((my >> 6) << 4) + (lane & 15);
+                    const int j = 64 * sft + l;
+                    const bool in = my >= 0 && j < cnt;
+                    const float* pt = tile + 3 * (in ? knn_tile_point(l, sft) : 0);
+                    float vu = dist2(u, pt[0], pt[1], pt[2]);
+                    const int idx = t0 + j;
+                    vu = in ? vu : INF;
+                    if (!kLoop) vu = idx == qi[u] ? INF : vu;
+                    const bool pred = in && vu <= tau[u];
+                    const u64 mask = __ballot(pred);
+                    if (mask) {
+                        const int at = base[u] + rank_in_mask(mask);
+                        if (pred && at < kCap) list[wv * kKnnQpw + u][at] = pack_key(vu, idx);
+                        base[u] += __popcll(mask);
+                    }
                 }
             }
         }
@@ -497,7 +568,8 @@ extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, i
         const bool wide = (long long)n_clouds * ceil_div(n, 32) >= 2048;
         const int bpc = ceil_div(n, wide ? 32 : 16);
 #define EQ_KNN_TILED(LOOP, QPW, CAP) \
-    hipLaunchKernelGGL((knn_tiled_kernel<LOOP, QPW, CAP>), dim3(n_clouds * bpc), dim3(256), 0, s, x, n_clouds, n, k, e64, row32, col32, row_hist, arrival, force_slow_path)
+    do { if (n <= 2 * kKnnTile) hipLaunchKernelGGL((knn_tiled_kernel<LOOP, QPW, CAP, 2>), dim3(n_clouds * bpc), dim3(256), 0, s, x, n_clouds, n, k, e64, row32, col32, row_hist, arrival, force_slow_path); \
+         else hipLaunchKernelGGL((knn_tiled_kernel<LOOP, QPW, CAP, 4>), dim3(n_clouds * bpc), dim3(256), 0, s, x, n_clouds, n, k, e64, row32, col32, row_hist, arrival, force_slow_path); } while (0)
 #define EQ_KNN_TILED_K(LOOP, QPW) do { if (k <= 24) EQ_KNN_TILED(LOOP, QPW, 64); else EQ_KNN_TILED(LOOP, QPW, 128); } while (0)
         if (loop) { if (wide) EQ_KNN_TILED_K(true, 8); else EQ_KNN_TILED_K(true, 4); }
         else { if (wide) EQ_KNN_TILED_K(false, 8); else EQ_KNN_TILED_K(false, 4); }

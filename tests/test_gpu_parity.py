@@ -156,6 +156,32 @@ def test_knn_two_keys_per_lane_path_and_hub_segments_fullsize(pk):
         np.testing.assert_array_equal(graph.rperm.cpu().numpy(), order)
 
 
+def test_knn_tiled_chunk_pruned_pass_shapes(pk):
+    """The tiled kernel's second pass only visits the 16-candidate chunks whose minimum is <= tau (round 4): clouds that are not
+    multiples of the tile / chunk / workgroup sizes, both list capacities (k <= 24, k > 24), both tile counts (n <= 4 096, <= 8 192),
+    no self loops, spatially SORTED points (neighbours in consecutive indices) and the 8-queries-per-wave variant of large batches."""
+    from se3_equi_graph_registration_amd import ops
+    g = torch.Generator().manual_seed(11)
+    for n, k, loop in ((2049, 5, True), (3000, 24, False), (4097, 25, True), (5000, 20, True), (6160, 33, False), (8191, 32, True)):
+        x = torch.rand(n, 3, generator=g) * 2.0
+        assert torch.equal(pk.knn_graph(x.cuda(), k, loop=loop).cpu(), orc.knn_graph(x, k, loop=loop)), (n, k, loop)
+    x = torch.rand(4500, 3, generator=g)
+    x = x[torch.argsort(x[:, 0])].contiguous()                       # sorted along x
+    assert torch.equal(pk.knn_graph(x.cuda(), 20, loop=True).cpu(), orc.knn_graph(x, 20, loop=True))
+    xb = torch.rand(3, 2500, 3, generator=g)
+    xb[1, 1250:] = xb[1, :1250]                                       # duplicates inside one cloud of a batch
+    e64, _, _ = pk.knn_graph_batched(xb.cuda(), 12, True, want_i64=True, want_i32=False)
+    for b in range(3):
+        assert torch.equal(e64[b].cpu(), orc.knn_graph(xb[b], 12, loop=True))
+    for clouds, n, k in ((16, 4096, 20), (20, 4000, 30), (8, 8192, 32), (10, 5000, 7)):      # >= 2 048 32-query workgroups: 8 queries per wave
+        xw = torch.rand(clouds, n, 3, generator=g).cuda()
+        _, r_fast, c_fast = ops.knn_graph_batched(xw, k, True, want_i64=False, want_i32=True)
+        _, r_slow, c_slow = ops.knn_graph_batched(xw, k, True, want_i64=False, want_i32=True, force_slow_path=True)
+        assert torch.equal(r_fast, r_slow) and torch.equal(c_fast, c_slow), (clouds, n, k)
+        ref = orc.knn_graph(xw[clouds - 1].cpu(), k, loop=True)
+        assert torch.equal(r_fast.view(clouds, -1)[clouds - 1].cpu().long(), ref[0] + n * (clouds - 1))
+
+
 def test_build_csr_scratch_contract_and_inverse(pk):
     """ABI v3: build_csr also writes inv (same values as equigspr_invert_perm), accepts a scratch declared zero, and
     hands it back all-zero -- including hub segments longer than a wave (serial path) and isolated nodes."""
