@@ -5,7 +5,7 @@ import torch
 import se3_equi_graph_registration_amd as pkg
 from se3_equi_graph_registration_amd import ops
 dev = torch.device("cuda:0")
-for pairs, n, k in ((1, 8192, 32), (8, 4096, 20), (1, 4096, 20), (4, 8192, 32), (1, 3000, 16)):
+for pairs, n, k in ((1, 8192, 32), (8, 4096, 20), (1, 4096, 20), (4, 8192, 32), (1, 3000, 16), (1, 2048, 20), (16, 2048, 20)):
     ts = []
     for seed in range(1234, 1238):
         b = pkg.synthetic_batch(seed, pairs, n=n, device=dev)

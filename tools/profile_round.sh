@@ -41,11 +41,11 @@ python3 "$ROOT/bench.py" > "$OUT/bench.json" 2>> "$OUT/bench.err"
 tail -1 "$OUT/bench.json" | cut -c1-300
 bash "$ROOT/tools/step_sequence.sh" > "$OUT/step_sequence.txt" 2>&1
 ls -la "$OUT"
-# the lane-per-feature edge kernels (hidden_nf 16 / 48 / 64: no MFMA formulation yet) -- a tracked profile of what they cost
+# hidden_nf 16 / 48 / 64: the feature-parallel MFMA edge kernels (csrc/egnn_edge_fp.h) -- a tracked profile of what they cost
 cd /tmp
-for f in 64 48; do
+for f in 64 48 16; do
   rm -rf /tmp/prof_lane$f
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_lane$f -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-workloads --min-seconds 0 --feat $f --heads 2 --steps 20 --warmup 3 > "$OUT/stats_lane$f.log" 2>&1
-  cp "$(find /tmp/prof_lane$f -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_lane_f$f.csv"
+  cp "$(find /tmp/prof_lane$f -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_fp_f$f.csv"
   tail -1 "$OUT/stats_lane$f.log" | cut -c1-160
 done
