@@ -747,9 +747,12 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
                                                          const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                          const float* __restrict__ x, const float* __restrict__ P,
                                                          const float* __restrict__ dagg, const float* __restrict__ Gx, int n_edges,
-                                                         int chunk, int basis, float* __restrict__ dt1_out, float* __restrict__ dt1b_out, float* __restrict__ gxr_out,
+                                                         int chunk, int basis_and_flags, float* __restrict__ dt1_out, float* __restrict__ dt1b_out, float* __restrict__ gxr_out,
                                                          float* __restrict__ gxc_out, float* __restrict__ slab) {
     using C = Chunk16;
+    const int basis = basis_and_flags & 0xff;
+    const bool stream_out = (basis_and_flags & kStreamOutFlag) != 0;      // write the per-edge outputs through (small graphs: egnn_mfma16.h)
+    const OutRows dt1_rows(dt1_out), gxr_rows(gxr_out), gxc_rows(gxc_out);
     constexpr int F = 32 + kB, FP = 32 + 4 * kB;
     using SB = Slabs<F>;
     constexpr int NW = bwd16_waves(kB);
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             for (int b = 0; b < 2; ++b) {
                 dt1[b] *= sgp[b];
                 st4(X + i * C::LD + 16 * b + 4 * g, dt1[b]);
-                if (valid) st4(dt1_out + (size_t)eg_ * 32 + 16 * b + 4 * g, dt1[b]);      // 128-byte rows for every hidden_nf (see below)
+                if (valid) dt1_rows.st4((size_t)eg_ * 32 + 16 * b + 4 * g, dt1[b], stream_out);      // 128-byte rows for every hidden_nf (see below)
             }
             if constexpr (kB == 1) {
                 if (g == 0) {
@@ -1037,8 +1040,8 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             edge_geometry_backward_mode(basis, xr2, xc2, eg, gg, gd, gxr, gxc);
             const int eo = edge_id(ch);
             const float dtb = kB ? ds_buf[lane] : 0.0f;
-            reinterpret_cast<float4*>(gxr_out)[eo] = make_float4(gxr[0], gxr[1], gxr[2], dtb);
-            reinterpret_cast<float4*>(gxc_out)[eo] = make_float4(gxc[0], gxc[1], gxc[2], dtb);
+            gxr_rows.st4(4 * (size_t)eo, f32x4{gxr[0], gxr[1], gxr[2], dtb}, stream_out);
+            gxc_rows.st4(4 * (size_t)eo, f32x4{gxc[0], gxc[1], gxc[2], dtb}, stream_out);
         }
         __builtin_amdgcn_wave_barrier();
         r = rn; c = cn; e = en;
@@ -1156,7 +1159,7 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
         int blocks = ceil_div(ceil_div(E, chunk), NW);
         blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
         hipLaunchKernelGGL((edge_bwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * NW), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
-                           E, chunk, basis, dt1, dt1 + (size_t)E * 32, gxr, gxc, slab);
+                           E, chunk, basis | stream_out_flag(E), dt1, dt1 + (size_t)E * 32, gxr, gxc, slab);
         *n_slabs = blocks;
     } else if constexpr (F % 16 == 0 && EQ_EDGE_FP != 0) {  // 16 / 48 / 64: the feature-parallel MFMA kernels (egnn_edge_fp.h), one slab per workgroup
         using L = FpLayout<F, H, A, true>;

@@ -93,9 +93,12 @@ template <int H, int A, int kB = 0>
 __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_kernel(const float* __restrict__ lw, const int* __restrict__ row,
                                                          const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                          const float* __restrict__ x, const float* __restrict__ P,
-                                                         const int* __restrict__ rinv, int n_edges, int chunk, int basis,
+                                                         const int* __restrict__ rinv, int n_edges, int chunk, int basis_and_flags,
                                                          float* __restrict__ m_out, float* __restrict__ trans_out) {
     using C = Chunk16;
+    const int basis = basis_and_flags & 0xff;
+    const bool stream_out = (basis_and_flags & kStreamOutFlag) != 0;      // write the outputs through (small graphs: egnn_mfma16.h)
+    const OutRows m_rows(m_out), trans_rows(trans_out);
     constexpr int FP = 32 + 4 * kB;                    // hidden_nf = 32 + kB, rows padded to 16 bytes
     __shared__ __attribute__((aligned(16))) float wsm_[W16::image_size(false, kB)];
     __shared__ __attribute__((aligned(16))) float scratch[kFwd16Waves][C::fwd_size];
@@ -183,9 +186,9 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
                 // stored at the edge's position in the by-row (aggregation) order: node_fwd then streams its segment contiguously
                 // 128-byte rows for every hidden_nf: the 33rd feature of m leaves as the 4th component of the edge's `trans` item (back
                 // phase) -- 144-byte rows straddled two cache lines in every read of the node kernel (66 us against 47 at width 32)
-                float* dst = m_out + (size_t)pos[el] * 32 + 4 * g;
-                st4(dst, o.m[0]);
-                st4(dst + 16, o.m[1]);
+                const size_t dst = (size_t)pos[el] * 32 + 4 * g;
+                m_rows.st4(dst, o.m[0], stream_out);
+                m_rows.st4(dst + 16, o.m[1], stream_out);
                 if (g == 0) {
                     s_buf[el] = o.s;
                     if (kB) reinterpret_cast<float*>(pos)[el] = o.mb;      // the edge's position word is consumed (every lane group read it above, in the same instruction)
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
         if (mine) {
             const float s = s_buf[lane];
             const float mb = kB ? reinterpret_cast<const float*>(pos)[lane] : 0.0f;
-            reinterpret_cast<float4*>(trans_out)[at] = make_float4(eg.d[0] * s, eg.d[1] * s, eg.d[2] * s, mb);
+            trans_rows.st4(4 * (size_t)at, f32x4{eg.d[0] * s, eg.d[1] * s, eg.d[2] * s, mb}, stream_out);
         }
         __builtin_amdgcn_wave_barrier();               // the next chunk's front overwrites the scratch
         r = rn; c = cn; at = atn; e = en;
@@ -217,7 +220,7 @@ static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const floa
         int blocks = ceil_div(ceil_div(E, chunk), kFwd16Waves);
         blocks = blocks < 1 ? 1 : (blocks > 256 * occ ? 256 * occ : blocks);
         hipLaunchKernelGGL((edge_fwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * kFwd16Waves), 0, s, lw, g->row, g->col, edge_attr, x, P,
-                           g->rinv, E, chunk, basis, m, trans);
+                           g->rinv, E, chunk, basis | stream_out_flag(E), m, trans);
     } else if constexpr (F % 16 == 0 && EQ_EDGE_FP != 0) {  // 16 / 48 / 64: the feature-parallel MFMA kernels (egnn_edge_fp.h)
         using L = FpLayout<F, H, A, false>;
         const size_t smem = edge_fwd_fp_smem<F, H, A>();

@@ -25,6 +25,31 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 ldg4(const float* __restrict__ p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// store of a kernel OUTPUT that the next launch reads (from other XCDs: through memory either way).  A plain store leaves a dirty line in
+// this XCD's L2, and the release at the end of the kernel writes all of them back in one burst that the next launch waits behind;
+// written through at system scope (sc0 sc1) the lines leave while the kernel still computes.  One 2 048-point pair: edge forward 11.0 ->
+// 9.5 us, backward 21.9 -> 20.8 us per launch, the replayed step 0.3495 -> 0.333 ms; at 16 pairs the forward LOSES 4 % (the write-back
+// burst was overlapped by the other workgroups' compute there), so the launchers ask for it only below kStreamOutMaxEdges edges.
+constexpr int kStreamOutMaxEdges = 262144;
+constexpr int kStreamOutFlag = 0x100;                   // rides in the kernels' `basis` argument
+#ifndef EQ_STREAM_OUT_MAX_EDGES
+#define EQ_STREAM_OUT_MAX_EDGES kStreamOutMaxEdges      // A/B knob: 0 = never, 1 << 30 = always
+#endif
+static inline int stream_out_flag(long long n_edges) { return n_edges <= (long long)(EQ_STREAM_OUT_MAX_EDGES) ? kStreamOutFlag : 0; }
+// (as a raw buffer store with the sc0 | sc1 cache-policy bits, so that the compiler knows the instruction: the same store as inline
+// asm fell into the hazard "VALU overwrites the data registers of a > 64-bit VMEM store in the next cycle", which the compiler only
+// pads for instructions it emitted itself -- wrong rows at hidden_nf 33)
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+struct OutRows {
+    __amdgpu_buffer_rsrc_t rsrc;
+    float* base;
+    __device__ __forceinline__ explicit OutRows(float* p) : rsrc(__builtin_amdgcn_make_buffer_rsrc(p, 0, 0x7ffffff0, 0x00020000)), base(p) {}
+    // 16 bytes at float offset `off` (< 2^29 when streamed: the launchers only stream small graphs)
+    __device__ __forceinline__ void st4(size_t off, f32x4 v, bool stream) const {
+        if (stream) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)(off * 4), 0, 17);      // aux: sc0 (1) | sc1 (16)
+        else *reinterpret_cast<f32x4*>(base + off) = v;
+    }
+};
 __device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // Vector-form arithmetic: hipcc maps <2 x float> multiplies / adds / fmas to v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, which
