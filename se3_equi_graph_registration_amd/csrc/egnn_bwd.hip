@@ -50,6 +50,19 @@ constexpr int kEdgeBwdBlocks = 1024;  // max slab count of the edge kernel
 // NS nodes has left its vectors in LDS, ALL 256 threads accumulate: thread (f = tid % G, c = tid / G)
 // owns row f, column chunk c of the matrix -- distinct outputs per thread, so there is no
 // cross-thread reduction at all, and the partial goes straight to the block's global slab.
+// a gradient-slab word: written through at system scope (global_store_dword sc0 sc1) -- the slabs are read once, by the reduction
+// launch at the end of the backward, from other XCDs; left dirty in L2 they are 6-12 MB per node-level launch at one pair that the
+// end-of-kernel write-back pushes out in one burst while the next launch waits (see OutRows, egnn_mfma16.h)
+#ifndef EQ_STREAM_SLABS
+#define EQ_STREAM_SLABS 1
+#endif
+__device__ __forceinline__ void st_slab(float* p, float v) {
+#if EQ_STREAM_SLABS
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#else
+    *p = v;
+#endif
+}
 template <int G, int NCOLS>
 struct OuterAcc {
     static constexpr int NC = 256 / G, CPC = (NCOLS + NC - 1) / NC;
@@ -81,7 +94,7 @@ struct OuterAcc {
 #pragma unroll
             for (int j = 0; j < CPC; ++j) {
                 const int col = c * CPC + j;
-                if (col < ncols) dst[f * ncols + col] = acc[j];
+                if (col < ncols) st_slab(dst + f * ncols + col, acc[j]);
             }
         }
     }
@@ -100,7 +113,7 @@ struct VecAcc {
         }
     }
     __device__ __forceinline__ void store(float* __restrict__ dst, int nrows) const {
-        if (threadIdx.x < G && (int)(threadIdx.x % G) < nrows) dst[threadIdx.x % G] = acc;
+        if (threadIdx.x < G && (int)(threadIdx.x % G) < nrows) st_slab(dst + threadIdx.x % G, acc);
     }
 };
 // hidden_nf == 32: the same outer-product sums on the matrix cores.  One wave owns one 32x32 block
@@ -125,13 +138,13 @@ struct MfmaOuter {
     __device__ __forceinline__ void store(float* __restrict__ dst, int ld, int lane) const {   // dst[o * ld + i]
         const int el = lane & 31, h = lane >> 5;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dst[fidx(r, h) * ld + el] = acc[r];
+        for (int r = 0; r < 16; ++r) st_slab(dst + fidx(r, h) * ld + el, acc[r]);
     }
 };
 
 __device__ __forceinline__ void slab_flush(const float* sl, float* __restrict__ dst, int size) {
     __syncthreads();
-    for (int t = threadIdx.x; t < size; t += 256) dst[(size_t)blockIdx.x * size + t] = sl[t];
+    for (int t = threadIdx.x; t < size; t += 256) st_slab(dst + (size_t)blockIdx.x * size + t, sl[t]);
 }
 template <int MAXN = 64 * 64>      // the largest matrix staged this way: an embedding of 64 x 64
 __device__ __forceinline__ void stage_copy(float* dst, const float* __restrict__ src, int n) {
@@ -706,12 +719,12 @@ __global__ __launch_bounds__(256, 2) void gather_node_bwd_kernel(
     }
     float* myg = gat_slab + (size_t)blockIdx.x * SB::gather;
     if (wv >= 2) moG.store(myg + (wv - 2) * F * F, F, lane);
-    else if (wv == 0 && lane < 32) myg[2 * F * F + lane] = mb1;
+    else if (wv == 0 && lane < 32) st_slab(myg + 2 * F * F + lane, mb1);
     float* myn = node_slab + (size_t)blockIdx.x * SB::node;
     if (wv < 2) moN.store(myn + 32 * wv, 2 * F, lane);
     else if (wv == 2) moN.store(myn + F * 2 * F + F, F, lane);
-    else if (lane < 32) myn[F * 2 * F + lane] = mb4;
-    else myn[F * 2 * F + F + F * F + (lane - 32)] = mb5;
+    else if (lane < 32) st_slab(myn + F * 2 * F + lane, mb4);
+    else st_slab(myn + F * 2 * F + F + F * F + (lane - 32), mb5);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -747,12 +760,11 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
                                                          const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                          const float* __restrict__ x, const float* __restrict__ P,
                                                          const float* __restrict__ dagg, const float* __restrict__ Gx, int n_edges,
-                                                         int chunk, int basis_and_flags, float* __restrict__ dt1_out, float* __restrict__ dt1b_out, float* __restrict__ gxr_out,
+                                                         int chunk, int basis, float* __restrict__ dt1_out, float* __restrict__ dt1b_out, float* __restrict__ gxr_out,
                                                          float* __restrict__ gxc_out, float* __restrict__ slab) {
     using C = Chunk16;
-    const int basis = basis_and_flags & 0xff;
-    const bool stream_out = (basis_and_flags & kStreamOutFlag) != 0;      // write the per-edge outputs through (small graphs: egnn_mfma16.h)
-    const OutRows dt1_rows(dt1_out), gxr_rows(gxr_out), gxc_rows(gxc_out);
+    const bool stream_out = stream_out_edges(n_edges);                  // write the outputs through (small graphs: egnn_mfma16.h)
+    const OutRows dt1_rows(dt1_out), gxr_rows(gxr_out), gxc_rows(gxc_out), slab_rows(slab);
     constexpr int F = 32 + kB, FP = 32 + 4 * kB;
     using SB = Slabs<F>;
     constexpr int NW = bwd16_waves(kB);
@@ -1135,14 +1147,14 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             f32x4 a = lds4(&scratch[0][t]);
 #pragma unroll
             for (int w = 1; w < NW; ++w) a += lds4(&scratch[w][t]);
-            st4(slab + (size_t)blockIdx.x * SB::edge + t, a);
+            slab_rows.st4((size_t)blockIdx.x * SB::edge + t, a, stream_out);
         }
     } else {
         for (int t = threadIdx.x; t < SB::edge; t += 64 * NW) {
             float a = scratch[0][t];
 #pragma unroll
             for (int w = 1; w < NW; ++w) a += scratch[w][t];
-            slab[(size_t)blockIdx.x * SB::edge + t] = a;
+            slab_rows.st1((size_t)blockIdx.x * SB::edge + t, a, stream_out);
         }
     }
     EQ_STAMP(15);
@@ -1159,7 +1171,7 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
         int blocks = ceil_div(ceil_div(E, chunk), NW);
         blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
         hipLaunchKernelGGL((edge_bwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * NW), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
-                           E, chunk, basis | stream_out_flag(E), dt1, dt1 + (size_t)E * 32, gxr, gxc, slab);
+                           E, chunk, basis, dt1, dt1 + (size_t)E * 32, gxr, gxc, slab);
         *n_slabs = blocks;
     } else if constexpr (F % 16 == 0 && EQ_EDGE_FP != 0) {  // 16 / 48 / 64: the feature-parallel MFMA kernels (egnn_edge_fp.h), one slab per workgroup
         using L = FpLayout<F, H, A, true>;

@@ -93,11 +93,10 @@ template <int H, int A, int kB = 0>
 __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_kernel(const float* __restrict__ lw, const int* __restrict__ row,
                                                          const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                          const float* __restrict__ x, const float* __restrict__ P,
-                                                         const int* __restrict__ rinv, int n_edges, int chunk, int basis_and_flags,
+                                                         const int* __restrict__ rinv, int n_edges, int chunk, int basis,
                                                          float* __restrict__ m_out, float* __restrict__ trans_out) {
     using C = Chunk16;
-    const int basis = basis_and_flags & 0xff;
-    const bool stream_out = (basis_and_flags & kStreamOutFlag) != 0;      // write the outputs through (small graphs: egnn_mfma16.h)
+    const bool stream_out = stream_out_edges(n_edges);                  // write the outputs through (small graphs: egnn_mfma16.h)
     const OutRows m_rows(m_out), trans_rows(trans_out);
     constexpr int FP = 32 + 4 * kB;                    // hidden_nf = 32 + kB, rows padded to 16 bytes
     __shared__ __attribute__((aligned(16))) float wsm_[W16::image_size(false, kB)];
@@ -220,7 +219,7 @@ static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const floa
         int blocks = ceil_div(ceil_div(E, chunk), kFwd16Waves);
         blocks = blocks < 1 ? 1 : (blocks > 256 * occ ? 256 * occ : blocks);
         hipLaunchKernelGGL((edge_fwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * kFwd16Waves), 0, s, lw, g->row, g->col, edge_attr, x, P,
-                           g->rinv, E, chunk, basis | stream_out_flag(E), m, trans);
+                           g->rinv, E, chunk, basis, m, trans);
     } else if constexpr (F % 16 == 0 && EQ_EDGE_FP != 0) {  // 16 / 48 / 64: the feature-parallel MFMA kernels (egnn_edge_fp.h)
         using L = FpLayout<F, H, A, false>;
         const size_t smem = edge_fwd_fp_smem<F, H, A>();

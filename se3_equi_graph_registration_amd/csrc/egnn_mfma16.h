@@ -29,13 +29,11 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 // this XCD's L2, and the release at the end of the kernel writes all of them back in one burst that the next launch waits behind;
 // written through at system scope (sc0 sc1) the lines leave while the kernel still computes.  One 2 048-point pair: edge forward 11.0 ->
 // 9.5 us, backward 21.9 -> 20.8 us per launch, the replayed step 0.3495 -> 0.333 ms; at 16 pairs the forward LOSES 4 % (the write-back
-// burst was overlapped by the other workgroups' compute there), so the launchers ask for it only below kStreamOutMaxEdges edges.
-constexpr int kStreamOutMaxEdges = 262144;
-constexpr int kStreamOutFlag = 0x100;                   // rides in the kernels' `basis` argument
+// burst was overlapped by the other workgroups' compute there), so the kernels do it only below EQ_STREAM_OUT_MAX_EDGES edges (the node-level forward's 2 MB of outputs: no difference either way; the gradient slabs of the small-problem node backward: st_slab, egnn_bwd.hip).
 #ifndef EQ_STREAM_OUT_MAX_EDGES
-#define EQ_STREAM_OUT_MAX_EDGES kStreamOutMaxEdges      // A/B knob: 0 = never, 1 << 30 = always
+#define EQ_STREAM_OUT_MAX_EDGES 393216                  // A/B knob: 0 = never, 1 << 30 = always (4 pairs of 2 048 points still gain, 16 lose)
 #endif
-static inline int stream_out_flag(long long n_edges) { return n_edges <= (long long)(EQ_STREAM_OUT_MAX_EDGES) ? kStreamOutFlag : 0; }
+__device__ __forceinline__ bool stream_out_edges(int n_edges) { return n_edges <= EQ_STREAM_OUT_MAX_EDGES; }
 // (as a raw buffer store with the sc0 | sc1 cache-policy bits, so that the compiler knows the instruction: the same store as inline
 // asm fell into the hazard "VALU overwrites the data registers of a > 64-bit VMEM store in the next cycle", which the compiler only
 // pads for instructions it emitted itself -- wrong rows at hidden_nf 33)
@@ -48,6 +46,10 @@ struct OutRows {
     __device__ __forceinline__ void st4(size_t off, f32x4 v, bool stream) const {
         if (stream) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rsrc, (int)(off * 4), 0, 17);      // aux: sc0 (1) | sc1 (16)
         else *reinterpret_cast<f32x4*>(base + off) = v;
+    }
+    __device__ __forceinline__ void st1(size_t off, float v, bool stream) const {
+        if (stream) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rsrc, (int)(off * 4), 0, 17);
+        else base[off] = v;
     }
 };
 __device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
