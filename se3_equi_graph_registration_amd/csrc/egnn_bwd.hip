@@ -52,7 +52,8 @@ constexpr int kEdgeBwdBlocks = 1024;  // max slab count of the edge kernel
 // cross-thread reduction at all, and the partial goes straight to the block's global slab.
 // a gradient-slab word: written through at system scope (global_store_dword sc0 sc1) -- the slabs are read once, by the reduction
 // launch at the end of the backward, from other XCDs; left dirty in L2 they are 6-12 MB per node-level launch at one pair that the
-// end-of-kernel write-back pushes out in one burst while the next launch waits (see OutRows, egnn_mfma16.h)
+// end-of-kernel write-back pushes out in one burst while the next launch waits (see OutRows, egnn_mfma16.h).  Only for stores whose lanes
+// cover whole rows (coalesced): the MFMA outer products of hidden_nf 32 and the LDS-staged slabs
 #ifndef EQ_STREAM_SLABS
 #define EQ_STREAM_SLABS 1
 #endif
@@ -94,7 +95,7 @@ struct OuterAcc {
 #pragma unroll
             for (int j = 0; j < CPC; ++j) {
                 const int col = c * CPC + j;
-                if (col < ncols) st_slab(dst + f * ncols + col, acc[j]);
+                if (col < ncols) dst[f * ncols + col] = acc[j];      // (plain: a lane's words are a row apart -- written through, every 4-byte word is its own memory transaction: 2.37 vs 1.35 ms per step at width 64)
             }
         }
     }
@@ -113,7 +114,7 @@ struct VecAcc {
         }
     }
     __device__ __forceinline__ void store(float* __restrict__ dst, int nrows) const {
-        if (threadIdx.x < G && (int)(threadIdx.x % G) < nrows) st_slab(dst + threadIdx.x % G, acc);
+        if (threadIdx.x < G && (int)(threadIdx.x % G) < nrows) dst[threadIdx.x % G] = acc;
     }
 };
 // hidden_nf == 32: the same outer-product sums on the matrix cores.  One wave owns one 32x32 block

@@ -208,6 +208,8 @@ __global__ __launch_bounds__(fp_threads(F, false)) void edge_fwd_fp_kernel(
     const int n_tiles = (n_edges + 15) >> 4;
     const int stride = gridDim.x * L::kTpb;
     const int iters = (n_tiles + stride - 1) / stride;                   // the same trip count for every tile group: barriers inside
+    const bool stream_out = stream_out_edges(n_edges);                   // small graphs: outputs written through (OutRows, egnn_mfma16.h)
+    const OutRows m_rows(m_out), trans_rows(trans_out);
     __syncthreads();
     for (int it = 0; it < iters; ++it) {
         const int tile = it * stride + blockIdx.x * L::kTpb + tg;
@@ -235,8 +237,8 @@ __global__ __launch_bounds__(fp_threads(F, false)) void edge_fwd_fp_kernel(
         FpSub o;
         fp_tile_forward<F, H, A, false>(sm, grp, P, w, i, g, o);
         const int pos = idx[32 + i];
-        if (pos >= 0) st4(m_out + (size_t)pos * FP + 16 * w + 4 * g, o.m);            // at the edge's aggregation position
-        if (front && live) reinterpret_cast<float4*>(trans_out)[at] = make_float4(d[0] * o.s, d[1] * o.s, d[2] * o.s, 0.0f);      // trans = coord_diff * s (:264)
+        if (pos >= 0) m_rows.st4((size_t)pos * FP + 16 * w + 4 * g, o.m, stream_out);            // at the edge's aggregation position
+        if (front && live) trans_rows.st4(4 * (size_t)at, f32x4{d[0] * o.s, d[1] * o.s, d[2] * o.s, 0.0f}, stream_out);      // trans = coord_diff * s (:264)
         fp_sync<NB>();                                                 // the next tile's front overwrites idx / geo / red
     }
 }
@@ -289,6 +291,8 @@ __global__ __launch_bounds__(fp_threads(F, true)) void edge_bwd_fp_kernel(
     const int n_tiles = (n_edges + 15) >> 4;
     const int stride = gridDim.x * L::kTpb;
     const int iters = (n_tiles + stride - 1) / stride;
+    const bool stream_out = stream_out_edges(n_edges);
+    const OutRows dt1_rows(dt1_out), gxr_rows(gxr_out), gxc_rows(gxc_out), slab_rows(slab);
     __syncthreads();
     for (int it = 0; it < iters; ++it) {
         const int tile = it * stride + blockIdx.x * L::kTpb + tg;
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(fp_threads(F, true)) void edge_bwd_fp_kernel(
         // ---- dt1 = (W2^T du) * SiLU'(t1)
         f32x4 dt1 = fp_matvec_t<F, H, A, true>(sm + L::o_w2, X, w, i, g, splat4(0.0f));
         dt1 *= silu_grad4(o.t1, o.sg1);
-        if (valid) st4(dt1_out + (size_t)eg_ * FP + 16 * w + 4 * g, dt1);
+        if (valid) dt1_rows.st4((size_t)eg_ * FP + 16 * w + 4 * g, dt1, stream_out);
         st4(Z + i * L::VS + 16 * w + 4 * g, dt1);
         fp_sync<NB>();
         fp_outer<F, H, A, 1, false>(Z, geo, 16, w, i, g, accg);          // dWgeo | dw_attr rows += dt1^T [geo, attr]
@@ -377,8 +381,8 @@ __global__ __launch_bounds__(fp_threads(F, true)) void edge_bwd_fp_kernel(
                 const float gd[3] = {o.s * gx2[0], o.s * gx2[1], o.s * gx2[2]};
                 float gxr[3], gxc[3];
                 edge_geometry_backward_mode(basis, xr2, xc2, eg, gg, gd, gxr, gxc);
-                reinterpret_cast<float4*>(gxr_out)[e] = make_float4(gxr[0], gxr[1], gxr[2], 0.0f);
-                reinterpret_cast<float4*>(gxc_out)[e] = make_float4(gxc[0], gxc[1], gxc[2], 0.0f);
+                gxr_rows.st4(4 * (size_t)e, f32x4{gxr[0], gxr[1], gxr[2], 0.0f}, stream_out);
+                gxc_rows.st4(4 * (size_t)e, f32x4{gxc[0], gxc[1], gxc[2], 0.0f}, stream_out);
             }
         }
         fp_sync<NB>();                                                 // the next tile's front overwrites idx / geo / the tiles
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(fp_threads(F, true)) void edge_bwd_fp_kernel(
         }
         __syncthreads();
     }
-    for (int t = threadIdx.x; t < SB::edge; t += 64 * L::NW) slab[(size_t)blockIdx.x * SB::edge + t] = sl[t];
+    for (int t = threadIdx.x; t < SB::edge; t += 64 * L::NW) slab_rows.st1((size_t)blockIdx.x * SB::edge + t, sl[t], stream_out);
 }
 
 template <int F, int H, int A>
