@@ -33,7 +33,7 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 #ifndef EQ_STREAM_OUT_MAX_EDGES
 #define EQ_STREAM_OUT_MAX_EDGES 393216                  // A/B knob: 0 = never, 1 << 30 = always (4 pairs of 2 048 points still gain, 16 lose)
 #endif
-__device__ __forceinline__ bool stream_out_edges(int n_edges) { return n_edges <= EQ_STREAM_OUT_MAX_EDGES; }
+__device__ __forceinline__ bool stream_out_edges(int n_edges) { return (EQ_STREAM_OUT_MAX_EDGES) > 0 && n_edges <= (EQ_STREAM_OUT_MAX_EDGES); }
 // (as a raw buffer store with the sc0 | sc1 cache-policy bits, so that the compiler knows the instruction: the same store as inline
 // asm fell into the hazard "VALU overwrites the data registers of a > 64-bit VMEM store in the next cycle", which the compiler only
 // pads for instructions it emitted itself -- wrong rows at hidden_nf 33)
