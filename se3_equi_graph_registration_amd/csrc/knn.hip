@@ -460,6 +460,49 @@ __global__ void csr_fill_ranked_kernel(const int* __restrict__ key, const int* _
     if (e < n_edges) perm[ptr[key[e]] + arrival[e]] = e;
 }
 
+// The ranked fill with the scan INSIDE (<= 8 192 nodes: one or two 2 048-point pairs): every workgroup recomputes the exclusive
+// prefix of the row counts in LDS -- <= 32 KB from L2, all workgroups at once -- instead of waiting behind a single-workgroup
+// scan launch (5.8 us + a kernel boundary for ten barrier-separated steps of one workgroup); workgroup 0 also writes ptr.
+// The count array is left as it is: the sort pass hands it back zeroed.
+constexpr int kFusedScanMaxNodes = 8192;
+__global__ __launch_bounds__(256) void csr_scan_fill_ranked_kernel(const int* __restrict__ cnt, int n_nodes, const int* __restrict__ key,
+                                                                   const int* __restrict__ arrival, int n_edges, int* __restrict__ ptr,
+                                                                   int* __restrict__ perm) {
+    __shared__ int pre[kFusedScanMaxNodes + 1];
+    __shared__ int wsum[4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int per = (n_nodes + 255) >> 8;                 // <= 32 consecutive counts per thread
+    const int lo = t * per;
+    int v[32];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        v[i] = (i < per && lo + i < n_nodes) ? cnt[lo + i] : 0;
+        s += v[i];
+    }
+    int inc = s;                                          // inclusive scan over the wave, then over the four waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int run = inc - s;
+    for (int w = 0; w < wv; ++w) run += wsum[w];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i < per && lo + i < n_nodes) pre[lo + i] = run;
+        run += v[i];
+    }
+    if (t == 255) pre[n_nodes] = run;
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int i = t; i <= n_nodes; i += 256) ptr[i] = pre[i];
+    const int e = blockIdx.x * 256 + t;
+    if (e < n_edges) perm[pre[key[e]] + arrival[e]] = e;
+}
+
 // each node's segment back into ascending edge order (atomics filled it in arbitrary order):
 // one wave per node, <= 64 entries sorted with a wave bitonic network, longer segments serially.  The same wave writes the
 // inverse permutation of its segment (inv[perm[p]] = p, optional) and hands the node's cursor word back as zero, so the
@@ -601,6 +644,12 @@ extern "C" int equigspr_build_csr(const int32_t* key, int32_t n_edges, int32_t n
     }
     if (n_edges > 0 && scratch_state != EQUIGSPR_SCRATCH_HISTOGRAM)      // (equigspr_knn_graph can leave the histogram behind)
         hipLaunchKernelGGL(csr_count_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, key, n_edges, scratch);
+    if (arrival && n_edges > 0 && n_nodes <= kFusedScanMaxNodes) {      // the k-NN path of one or two pairs: scan inside the fill
+        hipLaunchKernelGGL(csr_scan_fill_ranked_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, scratch, n_nodes, key, arrival, n_edges, ptr, perm);
+        hipLaunchKernelGGL(csr_sort_kernel, dim3(ceil_div(n_nodes, 4)), dim3(256), 0, s, ptr, n_nodes, perm, inv, scratch);
+        EQ_CHECK_LAUNCH("build_csr");
+        return 0;
+    }
     // large N: two-level scan; its chunk totals borrow the head of `perm`, which is only written by the fill below
     const int chunks = ceil_div(n_nodes, kScanChunk);
     launch_exclusive_scan(scratch, n_nodes, ptr, (n_edges >= chunks && chunks <= 1024) ? perm : nullptr, s);
