@@ -468,19 +468,24 @@ def roofline(pkg, S, args, dev):
     ms = ctypes.c_float(0.0)
     iters = 50
     # the training-mode forward keeps nothing per edge (the backward recomputes), so this IS the kernel of the timed step
-    _lib.check(L.equigspr_time_edge_fwd(ctypes.byref(cfg), ctypes.c_void_p(egnn.flat_params.data_ptr()),
-                                        ctypes.byref(graph.struct), ctypes.c_void_p(h.data_ptr()),
-                                        ctypes.c_void_p(x.data_ptr()), None, ctypes.c_void_p(work.data_ptr()), iters,
-                                        ctypes.byref(ms), stream), "time_edge_fwd")
-    fwd_ms = ms.value
+    # median of five 50-launch measurements: a single one showed outliers of +10 % on a shared box (profiles/r04_v6_bench.json, c3_b16)
+    def median_of(call, what, reps=5):
+        vals = []
+        for _ in range(reps):
+            _lib.check(call(), what)
+            vals.append(ms.value)
+        return sorted(vals)[reps // 2]
+    fwd_ms = median_of(lambda: L.equigspr_time_edge_fwd(ctypes.byref(cfg), ctypes.c_void_p(egnn.flat_params.data_ptr()),
+                                                        ctypes.byref(graph.struct), ctypes.c_void_p(h.data_ptr()),
+                                                        ctypes.c_void_p(x.data_ptr()), None, ctypes.c_void_p(work.data_ptr()), iters,
+                                                        ctypes.byref(ms), stream), "time_edge_fwd")
     bwd_ms = None
     if not args.forward_only:
         _, _, saved = ops.egnn_forward(cfg, egnn.flat_params, graph, h, x, None, True)
         bwork = torch.empty(int(L.equigspr_egnn_bwd_work_size(ctypes.byref(cfg), graph.n_nodes, E)), device=dev)
-        _lib.check(L.equigspr_time_edge_bwd(ctypes.byref(cfg), ctypes.c_void_p(egnn.flat_params.data_ptr()),
-                                            ctypes.byref(graph.struct), None, ctypes.c_void_p(saved.data_ptr()),
-                                            ctypes.c_void_p(bwork.data_ptr()), iters, ctypes.byref(ms), stream), "time_edge_bwd")
-        bwd_ms = ms.value
+        bwd_ms = median_of(lambda: L.equigspr_time_edge_bwd(ctypes.byref(cfg), ctypes.c_void_p(egnn.flat_params.data_ptr()),
+                                                            ctypes.byref(graph.struct), None, ctypes.c_void_p(saved.data_ptr()),
+                                                            ctypes.c_void_p(bwork.data_ptr()), iters, ctypes.byref(ms), stream), "time_edge_bwd")
     F = args.feat
     bytes_fwd = (2 * (F + 3) * 4 + 2 * 4 + 4 + (F + 3) * 4) * E          # 432 B/edge-layer at F=32
     bytes_bwd = 2 * bytes_fwd

@@ -320,10 +320,12 @@ int equigspr_irrep_conv_forward(const float* f0, const float* f1, const float* d
 /* irrep_moments_forward: the aggregate-then-transform form of the same layer.  The radial profile is linear in the hidden radial
  * activations (H <= 32 of them; `hid` is [E, 32], zero padded beyond column H, 16-byte aligned), so the sum over a node's incoming
  * edges is taken first:
- *   moments[n, j, h] = sum_{e: row = n} c[e, j] * hid~[e, h],  hid~ = [hid, 1],
+ *   m[n, j, h] = sum_{e: row = n} c[e, j] * hid~[e, h],  hid~ = [hid, 1],
  *   c[e, :] = [ K00 f0[col] (C0i) | K10 . f1[col] (C1i) | K01[a] f0[col] (a-major, 3 C0i) | K11[a, :, J] . f1[col] ((a, J)-major, 9 C1i) ]
- * (Lc = 4 C0i + 10 C1i <= 256 entries; J >= 1 kernels zero where dist = 0), in ascending edge order, no atomics.  The caller applies
- * the radial weights to moments [N, Lc, H + 1] with dense GEMMs over nodes: nothing of size [E, n_w] is formed. */
+ * (Lc = 4 C0i + 10 C1i <= 256 entries; J >= 1 kernels zero where dist = 0), in ascending edge order, no atomics.  `moments`
+ * (N * Lc * (H + 1) floats) receives the four paths as four consecutive arrays, each the contiguous A operand of its node-level GEMM:
+ *   S00 [N][C0i (H+1)] | S10 [N][C1i (H+1)] | S01 [N * 3][C0i (H+1)] (rows (n, a)) | S11 [N * 3][3 C1i (H+1)] (rows (n, a), columns (J, i, h)).
+ * The caller applies the radial weights to them with dense GEMMs over nodes: nothing of size [E, n_w] is formed. */
 int equigspr_irrep_moments_forward(const float* f0, const float* f1, const float* dist, const float* hid, const float* k00,
                                    const float* k01, const float* k10, const float* k11, const int32_t* col, const int32_t* rptr,
                                    const int32_t* rperm, int32_t n_nodes, int32_t n_edges, int32_t c0_in, int32_t c1_in,

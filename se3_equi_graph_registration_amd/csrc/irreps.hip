@@ -200,8 +200,10 @@ __global__ __launch_bounds__(64 * kIrWaves) void irrep_moments_kernel(const Irre
         acc[kIrMaxH] += cj;                                             // the constant 1 of hid~ (column H of the output)
         __builtin_amdgcn_wave_barrier();                                // the next edge overwrites kb
     }
-    // M[n, j, h]: the wave's 64 rows (33 values each) are ONE contiguous block -- transposed through LDS and streamed out (a lane writing
-    // its own row stores 4 bytes at a stride of 132: 0.27 ms for the 112 MB of one pair)
+    // The wave's 64 rows (H + 1 values each) are transposed through LDS and streamed out row by row (a lane writing its own row
+    // stores 4 bytes at a stride of 132: 0.27 ms for the 112 MB of one pair).  Destination: FOUR arrays, one per path, each the
+    // contiguous A operand of its node-level GEMM (one [N, Lc, H + 1] block made the caller copy two of them, 90 MB at one pair):
+    //   S00 [N][C0i (H+1)] | S10 [N][C1i (H+1)] | S01 [N * 3][C0i (H+1)] (rows (n, a)) | S11 [N * 3][3 C1i (H+1)] (rows (n, a), columns (J, i, h))
     float* tile = tiles[wv];
 #pragma unroll
     for (int h = 0; h < kIrMaxH; ++h)
@@ -211,9 +213,31 @@ __global__ __launch_bounds__(64 * kIrWaves) void irrep_moments_kernel(const Irre
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int rows = min(64, Lc - 64 * q);
-    float* dst = a.M + ((size_t)n * Lc + 64 * q) * HA;
-    for (int k = lane; k < rows * HA; k += 64) dst[k] = tile[k];
+    // entry t = 64 q + lane of the operand vector -> its row's first word in the sectioned output (entries of a section are contiguous)
+    __shared__ long long rowbase[kIrWaves][64];
+    {
+        const size_t N_ = (size_t)a.n_nodes;
+        size_t base;
+        if (t < o10) base = ((size_t)n * c0i + t) * HA;
+        else if (t < o01) base = N_ * c0i * HA + ((size_t)n * c1i + (t - o10)) * HA;
+        else if (t < o11) base = N_ * (c0i + c1i) * HA + ((size_t)n * 3 * c0i + (t - o01)) * HA;
+        else base = N_ * (c0i + c1i + 3 * c0i) * HA + ((size_t)n * 9 * c1i + (t - o11)) * HA;
+        rowbase[wv][lane] = (long long)base;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // two rows per step: lanes 0..31 / 32..63 (H + 1 <= 33 > 32: the last column of both rows goes out in a second store)
+    for (int r0 = 0; r0 < rows; r0 += 2) {
+        const int r = r0 + (lane >> 5), hh = lane & 31;
+        if (r < rows) {
+            float* dst = a.M + rowbase[wv][r];
+            if (hh < HA) dst[hh] = tile[r * HA + hh];
+            if (hh == 0 && HA > 32) dst[32] = tile[r * HA + 32];
+        }
+    }
 }
+
 
 }  // namespace eq
 

@@ -42,7 +42,7 @@ with torch.no_grad():
     lin1 = layer.radial[0]
     hid = torch.zeros(graph.n_edges, 32, device="cuda"); hid[:, :H] = torch.nn.functional.silu(torch.addmm(lin1.bias, dist[:, None], lin1.weight.t()))
     Lc = 4 * layer.c0_in + 10 * layer.c1_in
-    M = torch.empty(n, Lc, HA, device="cuda")
+    M = torch.empty(n * Lc * HA, device="cuda")
     def mom():
         _lib.check(_lib.lib().equigspr_irrep_moments_forward(_p(f0), _p(f1), _p(dist), _p(hid), _p(k00), _p(k01), _p(k10), _p(k11), _p(graph.col),
                                                              _p(graph.rptr), _p(graph.rperm), n, graph.n_edges, layer.c0_in, layer.c1_in, H, _p(M), _stream()), "m")
