@@ -27,7 +27,7 @@ extern "C" {
 
 #define EQUIGSPR_EINVAL   (-1)  /* bad shape / size / null pointer                         */
 #define EQUIGSPR_ENOTSUP  (-2)  /* configuration outside the compiled kernel set             */
-#define EQUIGSPR_ABI_VERSION 11
+#define EQUIGSPR_ABI_VERSION 12
 
 /* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
  * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
@@ -323,7 +323,7 @@ int equigspr_irrep_conv_forward(const float* f0, const float* f1, const float* d
  *   m[n, j, h] = sum_{e: row = n} c[e, j] * hid~[e, h],  hid~ = [hid, 1],
  *   c[e, :] = [ K00 f0[col] (C0i) | K10 . f1[col] (C1i) | K01[a] f0[col] (a-major, 3 C0i) | K11[a, :, J] . f1[col] ((a, J)-major, 9 C1i) ]
  * (Lc = 4 C0i + 10 C1i <= 256 entries; J >= 1 kernels zero where dist = 0), in ascending edge order, no atomics.  `moments`
- * (N * Lc * (H + 1) floats) receives the four paths as four consecutive arrays, each the contiguous A operand of its node-level GEMM:
+ * (N * Lc * (H + 1) floats) receives (ABI 12; one [N, Lc, H + 1] block before) the four paths as four consecutive arrays, each the contiguous A operand of its node-level GEMM:
  *   S00 [N][C0i (H+1)] | S10 [N][C1i (H+1)] | S01 [N * 3][C0i (H+1)] (rows (n, a)) | S11 [N * 3][3 C1i (H+1)] (rows (n, a), columns (J, i, h)).
  * The caller applies the radial weights to them with dense GEMMs over nodes: nothing of size [E, n_w] is formed. */
 int equigspr_irrep_moments_forward(const float* f0, const float* f1, const float* dist, const float* hid, const float* k00,

@@ -112,7 +112,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if L.equigspr_abi_version() != 11:
+        if L.equigspr_abi_version() != 12:
             raise RuntimeError("libequigspr.so ABI version mismatch")
         _lib = L
     return _lib
