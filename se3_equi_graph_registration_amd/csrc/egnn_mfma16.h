@@ -31,7 +31,7 @@ __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4
 // 9.5 us, backward 21.9 -> 20.8 us per launch, the replayed step 0.3495 -> 0.333 ms; at 16 pairs the forward LOSES 4 % (the write-back
 // burst was overlapped by the other workgroups' compute there), so the kernels do it only below EQ_STREAM_OUT_MAX_EDGES edges (the node-level forward's 2 MB of outputs: no difference either way; the gradient slabs of the small-problem node backward: st_slab, egnn_bwd.hip).
 #ifndef EQ_STREAM_OUT_MAX_EDGES
-#define EQ_STREAM_OUT_MAX_EDGES 393216                  // A/B knob: 0 = never, 1 << 30 = always (4 pairs of 2 048 points still gain, 16 lose)
+#define EQ_STREAM_OUT_MAX_EDGES 500000                  // A/B knob: 0 = never, 1 << 30 = always (6 pairs of 2 048 points gain 1.6 %, 8 and the 524 288-edge eval pair are neutral, 16 lose)
 #endif
 __device__ __forceinline__ bool stream_out_edges(int n_edges) { return (EQ_STREAM_OUT_MAX_EDGES) > 0 && n_edges <= (EQ_STREAM_OUT_MAX_EDGES); }
 // (as a raw buffer store with the sc0 | sc1 cache-policy bits, so that the compiler knows the instruction: the same store as inline

@@ -544,7 +544,7 @@ def test_train_step_gradients_golden(pk, golden_dir, parity):
                                                          (48, 2, 48, 48, 16999, 70001), (64, 4, 64, 64, 16999, 70001),      # lane widths above the 16-node threshold
                                                          (32, 1, 32, 32, 40, 5), (33, 1, 33, 33, 40, 17), (32, 1, 32, 32, 300, 1025),      # fewer edges than one tile; one tile + 1; 64 tiles + 1
                                                          (64, 2, 64, 64, 40, 5), (48, 1, 48, 48, 40, 17), (16, 4, 16, 16, 300, 1025), (64, 8, 30, 64, 300, 4099),   # the same for the feature-parallel kernels
-                                                         (32, 1, 32, 32, 20000, 400001), (33, 1, 33, 33, 20000, 400001), (48, 2, 48, 48, 20000, 400001)])   # above the edge count below which the edge kernels write their outputs through (plain stores here)
+                                                         (32, 1, 32, 32, 20000, 500001), (33, 1, 33, 33, 20000, 500001), (48, 2, 48, 48, 20000, 500001)])   # above the edge count below which the edge kernels write their outputs through (plain stores here)
 def test_backward_random_graph_vs_oracle_autograd(pk, feat, heads, in_nf, out_nf, n, e):
     """Non-kNN edge list (hub, isolated nodes, self loops, multi-edges), random edge_attr, 3 layers; both hidden widths
     (33 = the MFMA kernels' border path), 1 and 4 heads, embedding widths that differ from the hidden width (odd ones:
