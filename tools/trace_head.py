@@ -72,6 +72,9 @@ print("head_tail waves:", live.sum())
 for k, lab in ((1, "moments block (from start)"), (2, "fence + ticket"), (3, "solve (last block only)")):
     ok = (st[:, k] > 0) & (st[:, k - 1] > 0)
     d = st[ok, k] - st[ok, k - 1]
+    if ok.sum() == 0:
+        print(f"  {lab:32s} (no stamps: this phase runs inside another launch now)")
+        continue
     print(f"  {lab:32s} n={ok.sum():3d}  cycles: median {int(np.median(d)):7d}  max {int(d.max()):7d}")
 st = buf.cpu().numpy().reshape(-1, SLOTS)[3 * WAVES:4 * WAVES]
 live = st[:, 0] > 0
@@ -80,4 +83,7 @@ print("head_pair waves:", live.sum())
 for k, lab in ((1, "batch statistics from partials (fp64)"), (2, "masked-softmax scalars"), (3, "keys + 4 radix-select passes"), (4, "candidate compaction"), (5, "rank by counting + writes")):
     ok = (st[:, k] > 0) & (st[:, k - 1] > 0)
     d = st[ok, k] - st[ok, k - 1]
+    if ok.sum() == 0:
+        print(f"  {lab:40s} (no stamps)")
+        continue
     print(f"  {lab:40s} n={ok.sum():3d}  cycles: median {int(np.median(d)):7d}  max {int(d.max()):7d}")
