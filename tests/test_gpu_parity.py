@@ -182,6 +182,24 @@ def test_knn_tiled_chunk_pruned_pass_shapes(pk):
         assert torch.equal(r_fast.view(clouds, -1)[clouds - 1].cpu().long(), ref[0] + n * (clouds - 1))
 
 
+def test_index_build_with_the_scan_inside_the_fill(pk):
+    """Graphs of <= 8 192 nodes from the k-NN path take the fused scan + ranked fill launch (round 4): sizes around its per-thread
+    chunking (1 .. 32 counts per thread), exactly 8 192 nodes, and just above (the two-launch path) must all give the stable
+    counting sort of the edges by row, its inverse, and a scratch handed back zeroed (a second build on the same buffers)."""
+    for n, k in ((64, 8), (100, 7), (129, 16), (300, 20), (2048, 20), (4096, 20), (4100, 12)):
+        b = pk.synthetic_batch(77 + n, 1, n=n, device="cuda")
+        for rep in range(2):
+            graph = pk.build_pair_graph(b["src"], b["tgt"], k)
+            row = graph.row[:graph.n_edges].cpu().numpy()
+            order = np.argsort(row, kind="stable")
+            np.testing.assert_array_equal(graph.rperm[:graph.n_edges].cpu().numpy(), order)
+            cnt = np.bincount(row, minlength=graph.n_nodes)
+            np.testing.assert_array_equal(graph.rptr.cpu().numpy(), np.concatenate([[0], np.cumsum(cnt)]))
+            inv = np.empty(graph.n_edges, dtype=np.int64)
+            inv[order] = np.arange(graph.n_edges)
+            np.testing.assert_array_equal(graph.rinv[:graph.n_edges].cpu().numpy(), inv)
+
+
 def test_build_csr_scratch_contract_and_inverse(pk):
     """ABI v3: build_csr also writes inv (same values as equigspr_invert_perm), accepts a scratch declared zero, and
     hands it back all-zero -- including hub segments longer than a wave (serial path) and isolated nodes."""
