@@ -140,9 +140,13 @@ struct IrrepMomentsArgs {
     float* M;                                                                   // [N, Lc, H + 1]
 };
 
-__global__ __launch_bounds__(64 * kIrWaves) void irrep_moments_kernel(const IrrepMomentsArgs a) {
+constexpr int kIrRowsPerPass = 16;
+#ifndef EQ_IR_MOM_OCC
+#define EQ_IR_MOM_OCC 8                     // workgroups per CU = waves per SIMD the register budget is set for (the per-edge chain index -> rows -> LDS -> FMAs is latency: 194 us at four waves, 137 at eight, one pair)
+#endif
+__global__ __launch_bounds__(64 * kIrWaves, EQ_IR_MOM_OCC) void irrep_moments_kernel(const IrrepMomentsArgs a) {
     __shared__ float sm[kIrWaves][40];
-    __shared__ float tiles[kIrWaves][64 * (kIrMaxH + 1)];
+    __shared__ float tiles[kIrWaves][kIrRowsPerPass * (kIrMaxH + 1)];      // transposing buffer of the output: 16 rows at a time (a 64-row buffer, 8.4 KB per wave, held the kernel at four waves per SIMD)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int c0i = a.c0i, c1i = a.c1i, H = a.H, HA = H + 1;
     const int o10 = c0i, o01 = o10 + c1i, o11 = o01 + 3 * c0i, Lc = o11 + 9 * c1i;
@@ -205,13 +209,6 @@ __global__ __launch_bounds__(64 * kIrWaves) void irrep_moments_kernel(const Irre
     // contiguous A operand of its node-level GEMM (one [N, Lc, H + 1] block made the caller copy two of them, 90 MB at one pair):
     //   S00 [N][C0i (H+1)] | S10 [N][C1i (H+1)] | S01 [N * 3][C0i (H+1)] (rows (n, a)) | S11 [N * 3][3 C1i (H+1)] (rows (n, a), columns (J, i, h))
     float* tile = tiles[wv];
-#pragma unroll
-    for (int h = 0; h < kIrMaxH; ++h)
-        if (h < H) tile[lane * HA + h] = acc[h];
-    tile[lane * HA + H] = acc[kIrMaxH];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int rows = min(64, Lc - 64 * q);
     // entry t = 64 q + lane of the operand vector -> its row's first word in the sectioned output (entries of a section are contiguous)
     __shared__ long long rowbase[kIrWaves][64];
@@ -224,17 +221,36 @@ __global__ __launch_bounds__(64 * kIrWaves) void irrep_moments_kernel(const Irre
         else base = N_ * (c0i + c1i + 3 * c0i) * HA + ((size_t)n * 9 * c1i + (t - o11)) * HA;
         rowbase[wv][lane] = (long long)base;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // two rows per step: lanes 0..31 / 32..63 (H + 1 <= 33 > 32: the last column of both rows goes out in a second store)
-    for (int r0 = 0; r0 < rows; r0 += 2) {
-        const int r = r0 + (lane >> 5), hh = lane & 31;
-        if (r < rows) {
-            float* dst = a.M + rowbase[wv][r];
-            if (hh < HA) dst[hh] = tile[r * HA + hh];
-            if (hh == 0 && HA > 32) dst[32] = tile[r * HA + 32];
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto path_of = [&](int tt) { return tt < o10 ? 0 : (tt < o01 ? 1 : (tt < o11 ? 2 : 3)); };
+    for (int r0 = 0; r0 < rows; r0 += kIrRowsPerPass) {                  // wave-uniform
+        const int nr = min(kIrRowsPerPass, rows - r0);
+        const int lr = lane - r0;                                        // this lane's row inside the pass
+        if (lr >= 0 && lr < nr) {
+#pragma unroll
+            for (int h = 0; h < kIrMaxH; ++h)
+                if (h < H) tile[lr * HA + h] = acc[h];
+            tile[lr * HA + H] = acc[kIrMaxH];
         }
+        wave_sync();
+        if (path_of(64 * q + r0) == path_of(64 * q + r0 + nr - 1)) {     // the pass lies inside ONE path's array: one contiguous block
+            float* dst = a.M + rowbase[wv][r0];
+            for (int k = lane; k < nr * HA; k += 64) dst[k] = tile[k];
+        } else {                                                         // two rows per step: lanes 0..31 / 32..63 (H + 1 <= 33)
+            for (int rr = 0; rr < nr; rr += 2) {
+                const int r = rr + (lane >> 5), hh = lane & 31;
+                if (r < nr) {
+                    float* dst = a.M + rowbase[wv][r0 + r];
+                    if (hh < HA) dst[hh] = tile[r * HA + hh];
+                    if (hh == 0 && HA > 32) dst[32] = tile[r * HA + 32];
+                }
+            }
+        }
+        wave_sync();                                                     // the next pass overwrites the buffer
     }
 }
 
