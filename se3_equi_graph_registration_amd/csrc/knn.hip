@@ -104,7 +104,9 @@ constexpr int kKnnList = 128;                           // compaction list entri
 
 // kLoop: the query itself is a candidate (loop=True, every reference call site); kFull: n == 64 NPL (no index guards)
 template <int NPL, bool kLoop, bool kFull>
-__global__ __launch_bounds__(64) void knn_kernel(const float* __restrict__ x, int n_clouds, int n, int k,
+// (32 candidates per lane: register budget of EXACTLY five waves per SIMD -- 95 instead of 97 registers, nothing spilled: sixteen 2 048-point pairs 88.5 -> 80.5 us per launch;
+// six waves spill five registers: 94 us)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NPL >= 32 ? 5 : 1, NPL >= 32 ? 5 : 8))) void knn_kernel(const float* __restrict__ x, int n_clouds, int n, int k,
                                                  long long* __restrict__ edges,
                                                  int* __restrict__ row32, int* __restrict__ col32,
                                                  int* __restrict__ row_hist, int* __restrict__ arrival, int force_slow) {
