@@ -969,6 +969,18 @@ def main():
                               "frac": e["roofline"]["frac"], "launch_ms": e["roofline"]["launch_ms"], "traffic": e["roofline"]["traffic"],
                               "in_step_frac": e["roofline"].get("in_step_frac"), "scaling": e["scaling"], "graph_mode": e["config"]["graph_mode"]}
             out["roofline"]["workloads"] = {k: (keep(e) if "error" not in e else {"error": e["error"]}) for k, e in out["workloads"].items()}
+            # ... and FLAT scalars beside it: the driver's BENCH record keeps the scalar members of `roofline` and drops nested ones
+            for k, e in out["workloads"].items():
+                if "error" in e:
+                    out["roofline"][f"{k}_error"] = e["error"][:120]
+                    continue
+                r = e["roofline"]
+                out["roofline"][f"{k}_value"], out["roofline"][f"{k}_ms"] = e["value"], e["ms_per_step"]
+                out["roofline"][f"{k}_frac"], out["roofline"][f"{k}_launch_us"] = r["frac"], round(1e3 * r["launch_ms"], 2)
+                if r.get("in_step_frac") is not None:
+                    out["roofline"][f"{k}_in_step_frac"] = r["in_step_frac"]
+                if r.get("fwd_frac") is not None:
+                    out["roofline"][f"{k}_fwd_frac"] = r["fwd_frac"]
             if "fixed_pair_replay" in out:
                 out["roofline"]["fixed_pair_replay_ms_per_step"] = out["fixed_pair_replay"].get("ms_per_step")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -27,7 +27,7 @@ extern "C" {
 
 #define EQUIGSPR_EINVAL   (-1)  /* bad shape / size / null pointer                         */
 #define EQUIGSPR_ENOTSUP  (-2)  /* configuration outside the compiled kernel set             */
-#define EQUIGSPR_ABI_VERSION 12
+#define EQUIGSPR_ABI_VERSION 13
 
 /* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
  * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
@@ -303,33 +303,53 @@ int equigspr_so3_tensor_product_forward(const float* x, int32_t n_rows, int32_t 
                                         const float* w1, const float* b1, const float* w2, const float* b2,
                                         float* w1t_scratch, float* y, void* stream);
 
-/* ---- N4: typed irrep-basis message passing -----------------------------------------
- * The layer the reference's basis (tools/basis.py::get_basis :153-205) was written for and its scripts never build: degree-0
- * features f0 [N, C0i] and degree-1 features f1 [N, C1i, 3] (components in the basis' own real-SH order), pairwise kernels
- * K = sum_J R_J(|r|) K_J(r / |r|) for the four (d_in, d_out) paths of degrees <= 1, messages from the features at `col`
- * aggregated at `row` (train :252-256), plus a per-degree channel-mixing self-interaction.  Definition: oracle/irreps_oracle.py.
- *   dist [E] = |x[row] - x[col]|;  radial [E, n_w] = the radial profile W_r2 SiLU(w_r1 dist + b_r1) + b_r2 (a plain GEMM: the
- *   caller's library), laid out R00 [C0o,C0i] | R01 [C1o,C0i] | R10 [C0o,C1i] | R11 [C1o,C1i,3];  k00 [E], k01 [E,3], k10 [E,3],
- *   k11 [E,3,3,3] = the '0,0' / '0,1' / '1,0' / '1,1' tensors of equigspr_sh_basis_forward (max_degree 1); on edges with dist = 0
- *   the J >= 1 kernels count as zero;  col [E], rptr [N+1], rperm [E] = equigspr_build_csr(key = row);  1..32 channels per degree,
- *   C0o + 3 C1o <= 128.  out0 [N, C0o], out1 [N, C1o, 3].  Deterministic (ascending edge order per node, no atomics).  Forward only. */
-int equigspr_irrep_conv_forward(const float* f0, const float* f1, const float* dist, const float* radial, const float* k00,
-                                const float* k01, const float* k10, const float* k11, const float* w_self0, const float* w_self1,
-                                const int32_t* col, const int32_t* rptr, const int32_t* rperm, int32_t n_nodes, int32_t n_edges,
-                                int32_t c0_in, int32_t c1_in, int32_t c0_out, int32_t c1_out, float* out0, float* out1, void* stream);
-/* irrep_moments_forward: the aggregate-then-transform form of the same layer.  The radial profile is linear in the hidden radial
- * activations (H <= 32 of them; `hid` is [E, 32], zero padded beyond column H, 16-byte aligned), so the sum over a node's incoming
- * edges is taken first:
- *   m[n, j, h] = sum_{e: row = n} c[e, j] * hid~[e, h],  hid~ = [hid, 1],
- *   c[e, :] = [ K00 f0[col] (C0i) | K10 . f1[col] (C1i) | K01[a] f0[col] (a-major, 3 C0i) | K11[a, :, J] . f1[col] ((a, J)-major, 9 C1i) ]
- * (Lc = 4 C0i + 10 C1i <= 256 entries; J >= 1 kernels zero where dist = 0), in ascending edge order, no atomics.  `moments`
- * (N * Lc * (H + 1) floats) receives (ABI 12; one [N, Lc, H + 1] block before) the four paths as four consecutive arrays, each the contiguous A operand of its node-level GEMM:
- *   S00 [N][C0i (H+1)] | S10 [N][C1i (H+1)] | S01 [N * 3][C0i (H+1)] (rows (n, a)) | S11 [N * 3][3 C1i (H+1)] (rows (n, a), columns (J, i, h)).
- * The caller applies the radial weights to them with dense GEMMs over nodes: nothing of size [E, n_w] is formed. */
-int equigspr_irrep_moments_forward(const float* f0, const float* f1, const float* dist, const float* hid, const float* k00,
-                                   const float* k01, const float* k10, const float* k11, const int32_t* col, const int32_t* rptr,
-                                   const int32_t* rperm, int32_t n_nodes, int32_t n_edges, int32_t c0_in, int32_t c1_in,
-                                   int32_t hidden, float* moments, void* stream);
+/* ---- N4: typed irrep-basis message passing (ABI 13: one kernel path, forward AND backward) -----------
+ * The layer the reference's basis (tools/basis.py::get_basis :153-205, tools/irr_repr.py:103-104,
+ * tools/spherical_harmonics.py:75-123) was written for and its scripts never build: degree-0 features f0 [N, C0i] and degree-1
+ * features f1 [N, C1i, 3] (components in the basis' own real-SH order), pairwise kernels K = sum_J R_J(|r|) K_J(r / |r|) for the
+ * four (d_in, d_out) paths of degrees <= 1, messages from the features at `col` aggregated at `row` (train :252-256, :270-278),
+ * plus a per-degree channel-mixing self-interaction.  Definition: oracle/irreps_oracle.py.
+ *   r = x[row] - x[col], d = |r|, u = r / d;   hid = SiLU(w_r1 d + b_r1) [H];   R = W_r2 hid + b_r2, rows laid out
+ *   R00 [C0o, C0i] | R01 [C1o, C0i] | R10 [C0o, C1i] | R11 [C1o, C1i, 3 (J)]   (n_w = C0o C0i + C1o C0i + C0o C1i + 3 C1o C1i);
+ *   m0[e, o]    = sum_i R00[o, i] K00 f0[col, i]    + sum_i R10[o, i] (K10 . f1[col, i, :])
+ *   m1[e, o, a] = sum_i R01[o, i] K01[a] f0[col, i] + sum_i sum_J R11[o, i, J] (K11[a, :, J] . f1[col, i, :])
+ *   out0[n] = W_s0 f0[n] + sum_{e: row = n} m0[e],   out1[n] = W_s1 f1[n] + sum_{e: row = n} m1[e].
+ * The basis of degrees <= 1 is evaluated in CLOSED FORM inside the kernels (no [E, 27] tensors):
+ *   K00 = k00;  K01[a] = k01 u_a;  K10[b] = k10 u_b;  K11[a, b, 0] = k11_0 delta_ab;  K11[a, b, 1] = k11_1 eps_abc u_c;
+ *   K11[a, b, 2] = k11_2 (u_a u_b - delta_ab / 3);  on an edge with r = 0 (self loops) the J >= 1 kernels are zero.
+ * The six constants belong to the config: the host fits them to its own get_basis (Q_J is defined up to sign). */
+typedef struct equigspr_irrep_config {
+    int32_t c0_in, c1_in, c0_out, c1_out;   /* 1..32 channels per degree */
+    int32_t hidden;                          /* radial hidden width H: 16 or 32 */
+    float k00, k01, k10, k11_0, k11_1, k11_2;
+} equigspr_irrep_config;
+
+/* floats of the per-node moments a forward leaves for the backward: M [N, Lc, H] | Mb [N, Lc],
+ * Lc = 4 ceil16(C0i) + 10 pad(C1i), pad = 8 / 16 / 32;  M[n, j, h] = sum_{e: row = n} c[e, j] hid[e, h], Mb = the same with hid = 1,
+ * c[e] = [K00 f0 | K01[a] f0 (a-major) | K10 . f1 | K11[a, :, J] . f1 ((a, J)-major)] (every slot padded to its channel padding). */
+int64_t equigspr_irrep_moments_size(const equigspr_irrep_config* cfg, int32_t n_nodes);
+/* floats of scratch equigspr_irrep_conv_backward needs */
+int64_t equigspr_irrep_bwd_work_size(const equigspr_irrep_config* cfg, int32_t n_nodes, int32_t n_edges);
+
+/* Forward: two launches (moments: closed-form basis x gathered features x radial hidden activations, aggregated per node in
+ * ascending edge order on the matrix cores; node: the radial weights applied to the moments + bias + self-interaction).
+ *   w_r1 [H], b_r1 [H] (radial.0), w_r2 [n_w, H], b_r2 [n_w] (radial.2), w_self0 [C0o, C0i], w_self1 [C1o, C1i];
+ *   g: row / col / rptr / rperm (cptr / cperm for the backward); f0 [N, C0i], f1 [N, C1i, 3], x [N, 3];
+ *   out0 [N, C0o], out1 [N, C1o, 3]; moments: equigspr_irrep_moments_size floats (kept by the caller for the backward).
+ * Deterministic (no atomics), hipGraph-capturable (no allocation, no synchronisation). */
+int equigspr_irrep_conv_forward(const equigspr_irrep_config* cfg, const float* w_r1, const float* b_r1, const float* w_r2,
+                                const float* b_r2, const float* w_self0, const float* w_self1, const equigspr_graph* g,
+                                const float* f0, const float* f1, const float* x, float* out0, float* out1, float* moments,
+                                void* stream);
+/* Backward for EVERY input: the features (d_f0, d_f1: the adjoint convolution = the same two kernels on the reversed edges with
+ * transposed weights), the geometry (d_x [N, 3], ACCUMULATED: a stack of layers on fixed coordinates sums into one buffer) and
+ * all six parameter tensors (OVERWRITTEN).  `moments` = what the forward of the same inputs left.  d_f0 / d_f1 / d_x may be NULL
+ * (not computed).  work: equigspr_irrep_bwd_work_size floats. */
+int equigspr_irrep_conv_backward(const equigspr_irrep_config* cfg, const float* w_r1, const float* b_r1, const float* w_r2,
+                                 const float* b_r2, const float* w_self0, const float* w_self1, const equigspr_graph* g,
+                                 const float* f0, const float* f1, const float* x, const float* moments, const float* g_out0,
+                                 const float* g_out1, float* d_f0, float* d_f1, float* d_x, float* d_w_r1, float* d_b_r1,
+                                 float* d_w_r2, float* d_b_r2, float* d_w_self0, float* d_w_self1, float* work, void* stream);
 
 /* ---- A17: gcnLayer (src/gcnLayer.py) ------------------------------------------------------------
  * build_graph :58-67 (_get_weights :28-46, get_normalize_adj :49-56): w_ij = exp(-d_ij^2 / sigma2), sigma2 =

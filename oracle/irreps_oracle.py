@@ -60,7 +60,10 @@ def irrep_conv(w, f0, f1, x, edges):
     R01 = R[:, o:o + c1o * c0i].view(-1, c1o, c0i); o += c1o * c0i
     R10 = R[:, o:o + c0o * c1i].view(-1, c0o, c1i); o += c0o * c1i
     R11 = R[:, o:o + c1o * c1i * 3].view(-1, c1o, c1i, 3)
-    K = so.get_basis(r.to(torch.float64), 1)
+    # (differentiable in x: on a self loop the direction handed to the basis is a constant -- the J >= 1 kernels are masked below and
+    # the J = 0 kernels do not depend on it -- so that atan2(0, 0) never enters the autograd graph)
+    safe = torch.where(d > 0, r, torch.tensor([0.3, 0.4, 0.5], dtype=r.dtype).expand_as(r))
+    K = so.get_basis(safe.to(torch.float64), 1)
     k00 = K["0,0"].to(x.dtype).reshape(-1)                      # [E]
     k01 = K["0,1"].to(x.dtype).reshape(-1, 3)                   # [E, 3 (out component)]
     k10 = K["1,0"].to(x.dtype).reshape(-1, 3)                   # [E, 3 (in component)]

@@ -27,6 +27,12 @@ class Graph(Structure):
                 ("rptr", c_void_p), ("rperm", c_void_p), ("cptr", c_void_p), ("cperm", c_void_p), ("rinv", c_void_p)]
 
 
+class IrrepConfig(Structure):
+    _fields_ = [("c0_in", c_int32), ("c1_in", c_int32), ("c0_out", c_int32), ("c1_out", c_int32), ("hidden", c_int32),
+                ("k00", ctypes.c_float), ("k01", ctypes.c_float), ("k10", ctypes.c_float), ("k11_0", ctypes.c_float),
+                ("k11_1", ctypes.c_float), ("k11_2", ctypes.c_float)]
+
+
 _SIGNATURES = {
     "equigspr_abi_version": (ctypes.c_int, []),
     "equigspr_last_error": (c_char_p, []),
@@ -73,8 +79,10 @@ _SIGNATURES = {
     "equigspr_gcn_global_pool": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "equigspr_sh_forward": (ctypes.c_int, [c_void_p, c_int32, ctypes.c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "equigspr_sh_basis_forward": (ctypes.c_int, [c_void_p, ctypes.c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
-    "equigspr_irrep_conv_forward": (ctypes.c_int, [c_void_p] * 13 + [c_int32] * 6 + [c_void_p] * 3),
-    "equigspr_irrep_moments_forward": (ctypes.c_int, [c_void_p] * 11 + [c_int32] * 5 + [c_void_p] * 2),
+    "equigspr_irrep_moments_size": (c_int64, [POINTER(IrrepConfig), c_int32]),
+    "equigspr_irrep_bwd_work_size": (c_int64, [POINTER(IrrepConfig), c_int32, c_int32]),
+    "equigspr_irrep_conv_forward": (ctypes.c_int, [POINTER(IrrepConfig)] + [c_void_p] * 6 + [POINTER(Graph)] + [c_void_p] * 7),
+    "equigspr_irrep_conv_backward": (ctypes.c_int, [POINTER(IrrepConfig)] + [c_void_p] * 6 + [POINTER(Graph)] + [c_void_p] * 17),
     "equigspr_eval_metrics": (ctypes.c_int, [c_void_p] * 5 + [c_int32, c_int32, ctypes.c_double, c_void_p, c_void_p]),
     "equigspr_pointnet_layer_forward": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 7 + [c_int32, c_void_p, c_void_p, c_void_p]),
     "equigspr_global_max_pool": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
@@ -112,7 +120,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if L.equigspr_abi_version() != 12:
+        if L.equigspr_abi_version() != 13:
             raise RuntimeError("libequigspr.so ABI version mismatch")
         _lib = L
     return _lib

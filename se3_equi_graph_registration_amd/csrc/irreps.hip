@@ -1,294 +1,1046 @@
-// Typed irrep-basis message passing (SURVEY section 8(f) row N4 "proper": degree-0 AND degree-1 features carried through the layer,
-// the equivariant kernels K_J of tools/basis.py::get_basis :153-205 inside it).  The layer (definition: oracle/irreps_oracle.py):
+// Typed irrep-basis message passing (SURVEY section 8(f) row N4 "proper"): the tensor-field layer the reference's basis
+// (tools/basis.py::get_basis :153-205, tools/irr_repr.py:103-104, tools/spherical_harmonics.py:75-123) was written for and its
+// scripts never build.  Degree-0 features f0 [N, C0] and degree-1 features f1 [N, C1, 3] are both carried through; every
+// (d_in, d_out) path is a pairwise kernel sum_J R_J(|r|) K_J(r / |r|); messages go from `col` to `row` (train :252-256, :270-278).
+// Definition: oracle/irreps_oracle.py.
 //
-//   m0[e, o]    = sum_i R00[e, o, i] K00[e] f0[col, i]  +  sum_i R10[e, o, i] (K10[e, :] . f1[col, i, :])
-//   m1[e, o, a] = sum_i R01[e, o, i] K01[e, a] f0[col, i]  +  sum_i sum_J R11[e, o, i, J] (K11[e, a, :, J] . f1[col, i, :])
-//   out0[n]     = W_s0 f0[n] + sum_{e: row = n} m0[e]            out1[n] = W_s1 f1[n] + sum_{e: row = n} m1[e]
+//   d = |r|, r = x[row] - x[col], u = r / d          hid = SiLU(w_r1 d + b_r1)  [H]         R = W_r2 hid + b_r2
+//   m0[e, o]    = sum_i R00[o, i] K00 f0[col, i]    + sum_i R10[o, i] (K10 . f1[col, i])
+//   m1[e, o, a] = sum_i R01[o, i] K01[a] f0[col, i] + sum_i sum_J R11[o, i, J] (K11[a, :, J] . f1[col, i])
+//   out0[n] = W_s0 f0[n] + sum_{e: row = n} m0[e]        out1[n] = W_s1 f1[n] + sum_{e: row = n} m1[e]
 //
-// Division of labour: the radial profile R [E, n_w] = W_r2 SiLU(w_r1 |r| + b_r1) + b_r2 is a plain dense GEMM over all edges and
-// goes to the library (rocBLAS / hipBLASLt through ATen, MFMA); the basis tensors come from the existing SH kernels (csrc/sh.hip);
-// THIS kernel does what no library does: per edge the contraction of radial weights x basis x gathered features for both degrees,
-// and the aggregation at `row` -- a wave per destination node walking its incoming edges in ascending edge order (the inverse
-// index of the EGNN path: no atomics, the CPU scatter_add order, bitwise reproducible), the per-edge operands (gathered features,
-// basis, K.f contractions) in wave-private LDS, one output (o or (o, a)) per lane and accumulator.
-// Edges with r = 0 (self loops of knn_graph(..., loop=True)): the J >= 1 kernels are zero there (Y_J(0) is not covariant).
+// MI355X formulation (round 5: one first-class kernel path, no basis tensors in HBM, no library GEMMs):
+//  * The degree <= 1 basis in CLOSED FORM, in registers (the constants -- Q_J's signs included -- are fitted on the host to the
+//    package's own get_basis, sh.degree1_closed_form):  K00 = k00,  K01[a] = k01 u_a,  K10[b] = k10 u_b,
+//    K11[a, b, 0] = k110 delta_ab,  K11[a, b, 1] = k111 eps_abc u_c,  K11[a, b, 2] = k112 (u_a u_b - delta_ab / 3);  on a self
+//    loop (r = 0) the J >= 1 kernels are zero (Y_J(0) is not covariant).
+//  * AGGREGATE, THEN TRANSFORM: R is linear in hid~ = [hid, 1], so the sum over a node's incoming edges is taken before the
+//    radial weights act.  Per edge the operand vector
+//        c[e] = [ K00 f0 (C0) | K01[a] f0 (3 C0) | K10 . f1 (C1) | K11[a, :, J] . f1 ((a, J)-major, 9 C1) ]
+//    and the per-node moments M[n, j, h] = sum_{e -> n} c[e, j] hid[e, h], Mb[n, j] = sum_e c[e, j] (the bias column).
+//    `irrep_moments16_kernel`: a wave per (node, half of c); the moments are OUTER PRODUCTS with K = the node's edges, on
+//    v_mfma_f32_16x16x4_f32: A = hid [16 h x 4 edges], B = c [4 edges x 16 entries]; both operands are computed in the lane
+//    that feeds them (lane (idx = l & 15, k = l >> 4)): the gathered feature rows are read as 64-byte segments, the per-edge
+//    geometry once per edge by the one-lane-per-edge front phase (wave-private LDS, broadcast reads).
+//  * `irrep_node16_kernel`: out = W M (+ bias, + self-interaction) for 16 nodes per workgroup, the waves splitting K; the
+//    radial weights are read IN PLACE from the parameter tensor (address = out * so + in * si + h: the same kernel applies the
+//    transposed weights of the backward by swapping the strides).
+//  * Backward: the adjoint of a tensor-field convolution is a tensor-field convolution on the reversed edges with transposed
+//    weights -- the SAME two kernels give d f0 / d f1 (aggregate at `col`, gather the output gradients from `row`);
+//    `irrep_expand16_kernel` (dM = W^T g) + `irrep_geom_bwd_kernel` (per edge: d hid, d u -> d x, d w_r1, d b_r1) +
+//    `irrep_wgrad16_kernel` (dW = g^T M over node ranges, slabs summed in fixed order) complete it.  No atomics anywhere:
+//    bitwise reproducible.
+#include <type_traits>
+
 #include "common.h"
+#include "egnn_mfma16.h"
 
 namespace eq {
+namespace ir {
 
-constexpr int kIrMaxC = 32;                    // channels per degree, in and out
-constexpr int kIrWaves = 4;
+constexpr int kMaxC = 32;
 
-struct IrrepConvArgs {
-    const float* f0; const float* f1; const float* dist;          // [N, C0i], [N, C1i, 3], [E]
-    const float* R;                                               // [E, n_w]: R00 | R01 | R10 | R11
-    const float* k00; const float* k01; const float* k10; const float* k11;      // [E], [E,3], [E,3], [E,3(out),3(in),3(J)]
-    const float* ws0; const float* ws1;                           // [C0o, C0i], [C1o, C1i]
-    const int* col; const int* rptr; const int* rperm;
-    int n_nodes, c0i, c1i, c0o, c1o;
-    float* out0; float* out1;                                     // [N, C0o], [N, C1o, 3]
-};
-
-__global__ __launch_bounds__(64 * kIrWaves) void irrep_conv_kernel(const IrrepConvArgs a) {
-    __shared__ float sm[kIrWaves][kIrMaxC + 3 * kIrMaxC + 40 + kIrMaxC + 9 * kIrMaxC];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int n = blockIdx.x * kIrWaves + wv;
-    if (n >= a.n_nodes) return;                                   // wave-uniform
-    float* g0 = sm[wv];                        // f0[col, :]                       [C0i]
-    float* g1 = g0 + kIrMaxC;                  // f1[col, :, :]                    [C1i * 3]
-    float* kb = g1 + 3 * kIrMaxC;              // k00 | k01[3] | k10[3] | k11[27]  (J >= 1 parts zeroed on a self loop)
-    float* s1 = kb + 40;                       // K10 . f1[col, i]                 [C1i]
-    float* t1 = s1 + kIrMaxC;                  // K11[a, :, J] . f1[col, i]        [C1i][3 a][3 J]
-    const int c0i = a.c0i, c1i = a.c1i, c0o = a.c0o, c1o = a.c1o;
-    const int n_out = c0o + 3 * c1o;           // <= 128: two outputs per lane at most
-    const int o_r01 = c0o * c0i, o_r10 = o_r01 + c1o * c0i, o_r11 = o_r10 + c0o * c1i, n_w = o_r11 + c1o * c1i * 3;
-    float acc[2] = {0.0f, 0.0f};
-    const int lo = a.rptr[n], hi = a.rptr[n + 1];
-    for (int p = lo; p < hi; ++p) {
-        const int e = a.rperm[p];
-        const int c = a.col[e];
-        const float live = a.dist[e] > 0.0f ? 1.0f : 0.0f;
-        for (int t = lane; t < c0i; t += 64) g0[t] = a.f0[(size_t)c * c0i + t];
-        for (int t = lane; t < 3 * c1i; t += 64) g1[t] = a.f1[(size_t)c * 3 * c1i + t];
-        if (lane < 34) {
-            float v;
-            if (lane == 0) v = a.k00[e];
-            else if (lane < 4) v = a.k01[(size_t)e * 3 + lane - 1] * live;
-            else if (lane < 7) v = a.k10[(size_t)e * 3 + lane - 4] * live;
-            else { const int q = lane - 7; v = a.k11[(size_t)e * 27 + q] * ((q % 3) == 0 ? 1.0f : live); }      // [a][b][J]: J = q % 3
-            kb[lane] = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int t = lane; t < c1i; t += 64) s1[t] = kb[4] * g1[3 * t] + kb[5] * g1[3 * t + 1] + kb[6] * g1[3 * t + 2];
-        for (int t = lane; t < 9 * c1i; t += 64) {
-            const int i = t / 9, aj = t - 9 * i, aa = aj / 3, J = aj - 3 * aa;
-            const float* k = kb + 7 + aa * 9 + J;                  // K11[aa][b][J], b stride 3
-            t1[t] = k[0] * g1[3 * i] + k[3] * g1[3 * i + 1] + k[6] * g1[3 * i + 2];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float* Re = a.R + (size_t)e * n_w;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int o = lane + 64 * u;
-            if (o >= n_out) break;
-            float m = 0.0f;
-            if (o < c0o) {
-                const float* r00 = Re + o * c0i;
-                const float* r10 = Re + o_r10 + o * c1i;
-                float s = 0.0f;
-                for (int i = 0; i < c0i; ++i) s = fmaf(r00[i], g0[i], s);
-                m = s * kb[0];
-                for (int i = 0; i < c1i; ++i) m = fmaf(r10[i], s1[i], m);
-            } else {
-                const int oo = (o - c0o) / 3, aa = (o - c0o) - 3 * oo;
-                const float* r01 = Re + o_r01 + oo * c0i;
-                const float* r11 = Re + o_r11 + oo * c1i * 3;
-                float s = 0.0f;
-                for (int i = 0; i < c0i; ++i) s = fmaf(r01[i], g0[i], s);
-                m = s * kb[1 + aa];
-                for (int i = 0; i < c1i; ++i) {
-                    const float* tt = t1 + 9 * i + 3 * aa;
-                    m = fmaf(r11[3 * i], tt[0], m);
-                    m = fmaf(r11[3 * i + 1], tt[1], m);
-                    m = fmaf(r11[3 * i + 2], tt[2], m);
-                }
-            }
-            acc[u] += m;
-        }
-        __builtin_amdgcn_wave_barrier();                          // the next edge overwrites the scratch
-    }
-    // self-interaction (channel mixing of the node's own features) + store
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int o = lane + 64 * u;
-        if (o >= n_out) break;
-        float v = acc[u];
-        if (o < c0o) {
-            for (int i = 0; i < c0i; ++i) v = fmaf(a.ws0[o * c0i + i], a.f0[(size_t)n * c0i + i], v);
-            a.out0[(size_t)n * c0o + o] = v;
-        } else {
-            const int oo = (o - c0o) / 3, aa = (o - c0o) - 3 * oo;
-            for (int i = 0; i < c1i; ++i) v = fmaf(a.ws1[oo * c1i + i], a.f1[((size_t)n * c1i + i) * 3 + aa], v);
-            a.out1[((size_t)n * c1o + oo) * 3 + aa] = v;
-        }
-    }
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// channel padding of the operand vector: degree-0 slots in multiples of 16 entries, degree-1 slots 8 / 16 / 32
+static inline int pad0(int c) { return round_up(c, 16); }
+static inline int pad1(int c) { return c <= 8 ? 8 : (c <= 16 ? 16 : 32); }
 
-// ---- aggregate-then-transform form (the fast path) --------------------------------------------------------------------------
-// The radial profile is LINEAR in the hidden radial activations: R[e, w] = sum_h W_r2[w, h] hid[e, h] + b_r2[w].  So the sum over a
-// node's incoming edges can be taken BEFORE the radial weights are applied:
-//     out0[n, o] = sum_{h, i} W_r2[(o, i) of R00, h] * M00[n, i, h] + ...,    M00[n, i, h] = sum_{e -> n} hid~[e, h] * (K00[e] f0[col, i])
-// with hid~ = [hid, 1] (the 1 carries the bias), and likewise for the other three paths with their per-edge operands
-//     c[e, :] = [ K00 f0 (C0i) | K10 . f1 (C1i) | K01[a] f0 (3 C0i) | K11[a, :, J] . f1 (9 C1i) ]            (Lc = 4 C0i + 10 C1i values).
-// This kernel accumulates the per-node moment matrix M[n, j, h] = sum_e c[e, j] hid~[e, h] (an outer product per edge: Lc (H + 1) FMAs
-// instead of the n_w H of the radial GEMM -- 6.9 k against 55 k at 32 + 8 channels), in ascending edge order; the radial weights are then
-// applied to M by dense GEMMs over NODES (library).  Nothing of size [E, n_w] is ever formed (566 MB at one 2 048-point pair).
-// A wave per node; lane l owns c-entries j = l, l + 64, l + 128, l + 192 (Lc <= 256) and all H + 1 <= 33 columns of their rows.
-constexpr int kIrMaxH = 32;
-constexpr int kIrMaxLc = 256;
+struct Consts { float k00, k01, k10, k110, k111, k112; };
 
-struct IrrepMomentsArgs {
-    const float* f0; const float* f1; const float* dist; const float* hid;      // hid [E, 32]: H columns, zero padded
-    const float* k00; const float* k01; const float* k10; const float* k11;
-    const int* col; const int* rptr; const int* rperm;
-    int n_nodes, c0i, c1i, H;
-    float* M;                                                                   // [N, Lc, H + 1]
+// ------------------------------------------------------------------------------------------------ moments
+struct MomArgs {
+    const float* x; const float* f0; const float* f1;       // [N, 3], [N, c0], [N, c1, 3]: the features are gathered at src[e]
+    const int* ptr; const int* perm; const int* src;        // node n aggregates the edges perm[ptr[n] .. ptr[n + 1]) (ascending edge id)
+    const float* w1; const float* b1;                       // radial.0: [H], [H]
+    Consts k;
+    int n_nodes, c0, c1, c0p, c1p, lc;
+    float* M; float* Mb;                                    // [N, lc, H], [N, lc]
 };
 
-constexpr int kIrRowsPerPass = 16;
-#ifndef EQ_IR_MOM_OCC
-#define EQ_IR_MOM_OCC 8                     // workgroups per CU = waves per SIMD the register budget is set for (the per-edge chain index -> rows -> LDS -> FMAs is latency: 194 us at four waves, 137 at eight, one pair)
-#endif
-__global__ __launch_bounds__(64 * kIrWaves, EQ_IR_MOM_OCC) void irrep_moments_kernel(const IrrepMomentsArgs a) {
-    __shared__ float sm[kIrWaves][40];
-    __shared__ float tiles[kIrWaves][kIrRowsPerPass * (kIrMaxH + 1)];      // transposing buffer of the output: 16 rows at a time (a 64-row buffer, 8.4 KB per wave, held the kernel at four waves per SIMD)
+// One wave per (node, unit): unit 0 = the 4 c0p entries built from f0, units 1.. = 80-entry groups of the 10 c1p built from f1.
+// r = x[n] - x[src]: the caller flips k01 / k10 when it aggregates at the other end of the edges (the adjoint).
+template <int NH, int B0, int C1P>
+__global__ __launch_bounds__(256) void irrep_moments16_kernel(const MomArgs a) {
+    __shared__ float4 geo[4][2][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int c0i = a.c0i, c1i = a.c1i, H = a.H, HA = H + 1;
-    const int o10 = c0i, o01 = o10 + c1i, o11 = o01 + 3 * c0i, Lc = o11 + 9 * c1i;
-    const int nq = (Lc + 63) >> 6;             // 64-entry slices of the operand vector c: one WAVE per (node, slice)
-    // The node, its edge range and everything indexed by an edge are wave-uniform: told to the compiler (readfirstlane) they live in
-    // scalar registers, and hid~[e, h] is the SCALAR operand of the outer product's FMAs.  One slice per wave keeps a wave at 33
-    // accumulators (~60 VGPRs, eight waves per SIMD): the per-edge chain  basis -> LDS -> operand -> FMAs  is latency, and occupancy
-    // is what hides it (all four slices in one wave: 181 VGPRs, two waves per SIMD, 286 us at one pair; with the hid~ row read from
-    // LDS instead of scalar registers: 0.8 ms).
-    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * kIrWaves + wv);
-    const int n = wid / nq, q = wid - n * nq;
-    if (n >= a.n_nodes) return;
-    float* kb = sm[wv];                        // k00 | k01[3] | k10[3] | k11[27]  (J >= 1 parts zeroed on a self loop)
-    // this lane's entry of the operand vector, decoded once: c[j] = kb[ks] * f0[foff] (dot == 0) or sum_b kb[ks + b * kst] * f1[foff + b] (dot == 1)
-    int dot = 0, foff = 0, ks = 0, kst = 0;
-    const int t = lane + 64 * q;
-    if (t < o10) { foff = t; ks = 0; }
-    else if (t < o01) { dot = 1; foff = 3 * (t - o10); ks = 4; kst = 1; }
-    else if (t < o11) { const int u = t - o01, aa = u / c0i; foff = u - aa * c0i; ks = 1 + aa; }
-    else if (t < Lc) { const int u = t - o11, aj = u / c1i, i = u - aj * c1i, aa = aj / 3, J = aj - 3 * aa;      // [a][J][i]
-                       dot = 1; foff = 3 * i; ks = 7 + aa * 9 + J; kst = 3; }
-    else dot = -1;                                                      // no entry: contributes zeros
-    float acc[kIrMaxH + 1];
+    const int n = blockIdx.x * 4 + wv;
+    if (n >= a.n_nodes) return;                               // wave-uniform
+    constexpr int H = 16 * NH;
+    const int j = lane & 15, kq = lane >> 4;
+    float w1v[NH], b1v[NH];
 #pragma unroll
-    for (int h = 0; h <= kIrMaxH; ++h) acc[h] = 0.0f;
-    const int lo = a.rptr[n], hi = a.rptr[n + 1];
-    for (int p = lo; p < hi; ++p) {
-        const int e = a.rperm[p];
-        const int c = a.col[e];
-        const float live = a.dist[e] > 0.0f ? 1.0f : 0.0f;
-        if (lane < 34) {
-            float v;
-            if (lane == 0) v = a.k00[e];
-            else if (lane < 4) v = a.k01[(size_t)e * 3 + lane - 1] * live;
-            else if (lane < 7) v = a.k10[(size_t)e * 3 + lane - 4] * live;
-            else { const int u = lane - 7; v = a.k11[(size_t)e * 27 + u] * ((u % 3) == 0 ? 1.0f : live); }
-            kb[lane] = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const float* f0r = a.f0 + (size_t)c * c0i;
-        const float* f1r = a.f1 + (size_t)c * 3 * c1i;
-        float cj = 0.0f;
-        if (dot == 0) cj = kb[ks] * f0r[foff];
-        else if (dot == 1) cj = kb[ks] * f1r[foff] + kb[ks + kst] * f1r[foff + 1] + kb[ks + 2 * kst] * f1r[foff + 2];
-        // the hid row: always kIrMaxH columns (the caller pads with zeros), fetched as whole 16-byte scalar loads -- a per-column
-        // `if (h < H)` made every column its own s_load + s_waitcnt + branch: 32 serial scalar-memory round trips per edge
-        const float4* h4 = reinterpret_cast<const float4*>(a.hid + (size_t)e * kIrMaxH);
-        float hv[kIrMaxH];
-#pragma unroll
-        for (int u = 0; u < kIrMaxH / 4; ++u) { const float4 v = h4[u]; hv[4 * u] = v.x; hv[4 * u + 1] = v.y; hv[4 * u + 2] = v.z; hv[4 * u + 3] = v.w; }
-#pragma unroll
-        for (int h = 0; h < kIrMaxH; ++h) acc[h] = fmaf(cj, hv[h], acc[h]);
-        acc[kIrMaxH] += cj;                                             // the constant 1 of hid~ (column H of the output)
-        __builtin_amdgcn_wave_barrier();                                // the next edge overwrites kb
-    }
-    // The wave's 64 rows (H + 1 values each) are transposed through LDS and streamed out row by row (a lane writing its own row
-    // stores 4 bytes at a stride of 132: 0.27 ms for the 112 MB of one pair).  Destination: FOUR arrays, one per path, each the
-    // contiguous A operand of its node-level GEMM (one [N, Lc, H + 1] block made the caller copy two of them, 90 MB at one pair):
-    //   S00 [N][C0i (H+1)] | S10 [N][C1i (H+1)] | S01 [N * 3][C0i (H+1)] (rows (n, a)) | S11 [N * 3][3 C1i (H+1)] (rows (n, a), columns (J, i, h))
-    float* tile = tiles[wv];
-    const int rows = min(64, Lc - 64 * q);
-    // entry t = 64 q + lane of the operand vector -> its row's first word in the sectioned output (entries of a section are contiguous)
-    __shared__ long long rowbase[kIrWaves][64];
-    {
-        const size_t N_ = (size_t)a.n_nodes;
-        size_t base;
-        if (t < o10) base = ((size_t)n * c0i + t) * HA;
-        else if (t < o01) base = N_ * c0i * HA + ((size_t)n * c1i + (t - o10)) * HA;
-        else if (t < o11) base = N_ * (c0i + c1i) * HA + ((size_t)n * 3 * c0i + (t - o01)) * HA;
-        else base = N_ * (c0i + c1i + 3 * c0i) * HA + ((size_t)n * 9 * c1i + (t - o11)) * HA;
-        rowbase[wv][lane] = (long long)base;
-    }
-    auto wave_sync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int hb = 0; hb < NH; ++hb) { w1v[hb] = a.w1[16 * hb + j]; b1v[hb] = a.b1[16 * hb + j]; }
+    const float xn0 = a.x[(size_t)n * 3], xn1 = a.x[(size_t)n * 3 + 1], xn2 = a.x[(size_t)n * 3 + 2];
+    const int lo = a.ptr[n], hi = a.ptr[n + 1];
+    float4* gA = geo[wv][0];
+    float4* gB = geo[wv][1];
+    // front phase, one lane per edge of the chunk: (u, d) and the edge's scalar factors (zero for the padding slots of the last
+    // k-step: such a slot then contributes c = 0 to every moment)
+    auto front = [&](int base, int cnt) {
+        const bool valid = lane < cnt;
+        const int e = valid ? a.perm[base + lane] : 0;
+        const int s = valid ? a.src[e] : n;
+        const float r0 = xn0 - a.x[(size_t)s * 3], r1 = xn1 - a.x[(size_t)s * 3 + 1], r2 = xn2 - a.x[(size_t)s * 3 + 2];
+        const float d = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+        const bool live = valid && d > 0.0f;                 // self loop / duplicated point: only the J = 0 kernels act
+        const float inv = live ? 1.0f / d : 0.0f;
+        gA[lane] = make_float4(r0 * inv, r1 * inv, r2 * inv, d);
+        gB[lane] = make_float4(valid ? a.k.k00 : 0.0f, valid ? a.k.k110 : 0.0f, live ? a.k.k112 : 0.0f, __int_as_float(s));
     };
-    auto path_of = [&](int tt) { return tt < o10 ? 0 : (tt < o01 ? 1 : (tt < o11 ? 2 : 3)); };
-    for (int r0 = 0; r0 < rows; r0 += kIrRowsPerPass) {                  // wave-uniform
-        const int nr = min(kIrRowsPerPass, rows - r0);
-        const int lr = lane - r0;                                        // this lane's row inside the pass
-        if (lr >= 0 && lr < nr) {
+    const int unit = blockIdx.y;
+    if (unit == 0) {
+        // ---- c00 = K00 f0 | c01[a] = K01[a] f0: blocks (slot s = 0..3, sub): entry 16 (s B0 + sub) + j
+        f32x4 acc[4 * B0][NH];
+        float bs[4 * B0];
 #pragma unroll
-            for (int h = 0; h < kIrMaxH; ++h)
-                if (h < H) tile[lr * HA + h] = acc[h];
-            tile[lr * HA + H] = acc[kIrMaxH];
+        for (int t = 0; t < 4 * B0; ++t) {
+            bs[t] = 0.0f;
+#pragma unroll
+            for (int hb = 0; hb < NH; ++hb) acc[t][hb] = splat4(0.0f);
+        }
+        for (int base = lo; base < hi; base += 64) {
+            const int cnt = min(64, hi - base);
+            front(base, cnt);
+            wave_sync();
+            const int nks = (cnt + 3) >> 2;
+            for (int ks = 0; ks < nks; ++ks) {
+                const float4 A = gA[4 * ks + kq], B = gB[4 * ks + kq];
+                const float* f0r = a.f0 + (size_t)__float_as_int(B.w) * a.c0;
+                float g[B0];
+#pragma unroll
+                for (int sub = 0; sub < B0; ++sub) g[sub] = (16 * sub + j < a.c0) ? f0r[16 * sub + j] : 0.0f;
+                float hid[NH];
+#pragma unroll
+                for (int hb = 0; hb < NH; ++hb) hid[hb] = silu(fmaf(w1v[hb], A.w, b1v[hb]));
+                const float ku[4] = {B.x, a.k.k01 * A.x, a.k.k01 * A.y, a.k.k01 * A.z};
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int sub = 0; sub < B0; ++sub) {
+                        const float c = ku[s] * g[sub];
+                        bs[s * B0 + sub] += c;
+#pragma unroll
+                        for (int hb = 0; hb < NH; ++hb) acc[s * B0 + sub][hb] = mfma16(hid[hb], c, acc[s * B0 + sub][hb]);
+                    }
+            }
+            wave_sync();                                          // the next chunk overwrites the geometry
+        }
+        // D[h][entry]: lane (entry = j, g = kq) holds h = 16 hb + 4 g + r
+#pragma unroll
+        for (int t = 0; t < 4 * B0; ++t) {
+            const size_t ent = (size_t)n * a.lc + 16 * t + j;
+#pragma unroll
+            for (int hb = 0; hb < NH; ++hb) st4(a.M + ent * H + 16 * hb + 4 * kq, acc[t][hb]);
+            const float tot = gsum(bs[t]);
+            if (kq == 0) a.Mb[ent] = tot;
+        }
+        return;
+    }
+    // ---- c10 = K10 . f1 (slot 0) | c11[a, J] = K11[a, :, J] . f1 (slot 1 + 3 a + J): five 16-entry blocks per wave
+    f32x4 acc[5][NH];
+    float bs[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        bs[t] = 0.0f;
+#pragma unroll
+        for (int hb = 0; hb < NH; ++hb) acc[t][hb] = splat4(0.0f);
+    }
+    // C1P = 8: lane halves hold slots 2 t | 2 t + 1 of channel j & 7; C1P >= 16: slots S0 + t (S0 = 0 / 5) of channel 16 sub + j
+    const int q = unit - 1;
+    const int S0 = (C1P == 8) ? 0 : 5 * (q & 1), sub = (C1P == 8) ? 0 : (q >> 1);
+    const int ch = (C1P == 8) ? (j & 7) : 16 * sub + j;
+    const bool upper = (C1P == 8) && (j >= 8);
+    const bool ch_ok = ch < a.c1;
+    for (int base = lo; base < hi; base += 64) {
+        const int cnt = min(64, hi - base);
+        front(base, cnt);
+        wave_sync();
+        const int nks = (cnt + 3) >> 2;
+        for (int ks = 0; ks < nks; ++ks) {
+            const float4 A = gA[4 * ks + kq], B = gB[4 * ks + kq];
+            const float* f1r = a.f1 + ((size_t)__float_as_int(B.w) * a.c1 + ch) * 3;
+            const float g0 = ch_ok ? f1r[0] : 0.0f, g1 = ch_ok ? f1r[1] : 0.0f, g2 = ch_ok ? f1r[2] : 0.0f;
+            float hid[NH];
+#pragma unroll
+            for (int hb = 0; hb < NH; ++hb) hid[hb] = silu(fmaf(w1v[hb], A.w, b1v[hb]));
+            const float sd = A.x * g0 + A.y * g1 + A.z * g2;                       // u . g
+            const float cr[3] = {g1 * A.z - g2 * A.y, g2 * A.x - g0 * A.z, g0 * A.y - g1 * A.x};      // g x u = eps_abc g_b u_c
+            const float gv[3] = {g0, g1, g2}, uv[3] = {A.x, A.y, A.z};
+            float ent[10];
+            ent[0] = a.k.k10 * sd;
+#pragma unroll
+            for (int aa = 0; aa < 3; ++aa) {
+                ent[1 + 3 * aa] = B.y * gv[aa];
+                ent[2 + 3 * aa] = a.k.k111 * cr[aa];
+                ent[3 + 3 * aa] = B.z * (uv[aa] * sd - gv[aa] * (1.0f / 3.0f));
+            }
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                float c;
+                if (C1P == 8) c = upper ? ent[2 * t + 1] : ent[2 * t];
+                else c = S0 ? ent[5 + t] : ent[t];
+                bs[t] += c;
+#pragma unroll
+                for (int hb = 0; hb < NH; ++hb) acc[t][hb] = mfma16(hid[hb], c, acc[t][hb]);
+            }
         }
         wave_sync();
-        if (path_of(64 * q + r0) == path_of(64 * q + r0 + nr - 1)) {     // the pass lies inside ONE path's array: one contiguous block
-            float* dst = a.M + rowbase[wv][r0];
-            for (int k = lane; k < nr * HA; k += 64) dst[k] = tile[k];
-        } else {                                                         // two rows per step: lanes 0..31 / 32..63 (H + 1 <= 33)
-            for (int rr = 0; rr < nr; rr += 2) {
-                const int r = rr + (lane >> 5), hh = lane & 31;
-                if (r < nr) {
-                    float* dst = a.M + rowbase[wv][r0 + r];
-                    if (hh < HA) dst[hh] = tile[r * HA + hh];
-                    if (hh == 0 && HA > 32) dst[32] = tile[r * HA + 32];
-                }
-            }
-        }
-        wave_sync();                                                     // the next pass overwrites the buffer
+    }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int e_in = (C1P == 8) ? 16 * t + j : (S0 + t) * a.c1p + 16 * sub + j;
+        const size_t ent = (size_t)n * a.lc + 4 * a.c0p + e_in;
+#pragma unroll
+        for (int hb = 0; hb < NH; ++hb) st4(a.M + ent * H + 16 * hb + 4 * kq, acc[t][hb]);
+        const float tot = gsum(bs[t]);
+        if (kq == 0) a.Mb[ent] = tot;
     }
 }
 
+// ------------------------------------------------------------------------------------------------ node GEMM: out = W M
+// One path's radial weights inside the parameter tensors: W(out, in, h) = w[out * so + in * si + h], bias(out, in) = b[(out * so
+// + in * si) / H]  (path 11: + J * H, + J).  Forward: so = C_in * H (x 3 for path 11), si = H (x 3); the adjoint swaps the roles.
+struct PathW { const float* w; const float* b; int so, si; };
+struct SelfW { const float* w; int so, si; };
+struct NodeArgs {
+    const float* M; const float* Mb; const float* f0; const float* f1;     // moments of the c0 / c1 INPUT channels; node features
+    PathW p00, p10, p01, p11;       // p10: degree-1 input -> degree-0 output; p01: degree-0 input -> degree-1 output
+    SelfW s0, s1;
+    int n_nodes, c0, c1, c0p, c1p, lc, o0, o1;
+    float* out0; float* out1;       // [N, o0], [N, o1, 3]
+};
 
+constexpr int kNodeWaves = 8;
+
+template <int NH, int NCB0, int NCB1>
+__global__ __launch_bounds__(64 * kNodeWaves) void irrep_node16_kernel(const NodeArgs a) {
+    constexpr int H = 16 * NH, NT = NCB0 + 3 * NCB1;
+    __shared__ f32x4 part[kNodeWaves][NT][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int nA = min(n0 + i16, a.n_nodes - 1);                 // the A operand's node (rows beyond the end repeat the last one)
+    f32x4 acc0[NCB0], acc1[3][NCB1];
+#pragma unroll
+    for (int cb = 0; cb < NCB0; ++cb) acc0[cb] = splat4(0.0f);
+#pragma unroll
+    for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+        for (int cb = 0; cb < NCB1; ++cb) acc1[aa][cb] = splat4(0.0f);
+    const float* Mn = a.M + (size_t)nA * a.lc * H;
+    const float* Mbn = a.Mb + (size_t)nA * a.lc;
+    const int f1base = 4 * a.c0p;
+    // B operand of a weight row: W(o, in, 16 t + 4 kq + r); rows beyond the output count are zero
+    auto wrow = [&](const float* w, int so, int si, int o, int on, int in, f32x4 (&bv)[NH]) {
+        const float* p = w + (size_t)min(o, on - 1) * so + (size_t)in * si;
+#pragma unroll
+        for (int t = 0; t < NH; ++t) bv[t] = o < on ? ldg4(p + 16 * t + 4 * kq) : splat4(0.0f);
+    };
+    auto mrow = [&](int entry, f32x4 (&av)[NH]) {
+#pragma unroll
+        for (int t = 0; t < NH; ++t) av[t] = ldg4(Mn + (size_t)entry * H + 16 * t + 4 * kq);
+    };
+    // ---- degree-0 outputs: K = (i, h) over c00 and c10
+    for (int i = wv; i < a.c0 + a.c1; i += kNodeWaves) {
+        const bool d0 = i < a.c0;
+        const int in = d0 ? i : i - a.c0;
+        f32x4 av[NH];
+        mrow(d0 ? in : f1base + in, av);
+        const PathW& p = d0 ? a.p00 : a.p10;
+#pragma unroll
+        for (int cb = 0; cb < NCB0; ++cb) {
+            f32x4 bv[NH];
+            wrow(p.w, p.so, p.si, 16 * cb + i16, a.o0, in, bv);
+#pragma unroll
+            for (int t = 0; t < NH; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc0[cb] = mfma16(av[t][r], bv[t][r], acc0[cb]);
+        }
+    }
+    // ---- degree-1 outputs: per component a the same weights act on the moments of c01[a] / c11[a, J]
+    for (int i = wv; i < a.c0 + 3 * a.c1; i += kNodeWaves) {
+        const bool d0 = i < a.c0;
+        const int in = d0 ? i : (i - a.c0) / 3, J = d0 ? 0 : (i - a.c0) - 3 * in;
+        f32x4 bv[NCB1][NH];
+#pragma unroll
+        for (int cb = 0; cb < NCB1; ++cb) {
+            if (d0) wrow(a.p01.w, a.p01.so, a.p01.si, 16 * cb + i16, a.o1, in, bv[cb]);
+            else wrow(a.p11.w + J * H, a.p11.so, a.p11.si, 16 * cb + i16, a.o1, in, bv[cb]);
+        }
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa) {
+            f32x4 av[NH];
+            mrow(d0 ? a.c0p * (1 + aa) + in : f1base + a.c1p * (1 + 3 * aa + J) + in, av);
+#pragma unroll
+            for (int cb = 0; cb < NCB1; ++cb)
+#pragma unroll
+                for (int t = 0; t < NH; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc1[aa][cb] = mfma16(av[t][r], bv[cb][t][r], acc1[aa][cb]);
+        }
+    }
+    // ---- bias column (K = entries, Mb) and self-interaction (K = input channels, the node's own features): four entries per step
+    for (int i0 = 4 * wv; i0 < a.c0 + a.c1; i0 += 4 * kNodeWaves) {          // degree-0 outputs
+        const int i = i0 + kq;                                               // c0 % 4 == 0 is not required: per-lane path choice
+        const bool live = i < a.c0 + a.c1, d0 = i < a.c0;
+        const int in = d0 ? i : i - a.c0;
+        const float am = live ? Mbn[d0 ? in : f1base + in] : 0.0f;
+        const float as = live ? (d0 ? a.f0[(size_t)nA * a.c0 + in] : 0.0f) : 0.0f;
+        const PathW& p = d0 ? a.p00 : a.p10;
+#pragma unroll
+        for (int cb = 0; cb < NCB0; ++cb) {
+            const int o = 16 * cb + i16;
+            const bool ok = live && o < a.o0;
+            const float bm = ok ? p.b[((size_t)o * p.so + (size_t)in * p.si) / H] : 0.0f;
+            const float bsf = (ok && d0) ? a.s0.w[(size_t)o * a.s0.so + (size_t)in * a.s0.si] : 0.0f;
+            acc0[cb] = mfma16(am, bm, acc0[cb]);
+            acc0[cb] = mfma16(as, bsf, acc0[cb]);
+        }
+    }
+    for (int i0 = 4 * wv; i0 < a.c0 + 3 * a.c1; i0 += 4 * kNodeWaves) {      // degree-1 outputs
+        const int i = i0 + kq;
+        const bool live = i < a.c0 + 3 * a.c1, d0 = i < a.c0;
+        const int in = d0 ? i : (i - a.c0) / 3, J = d0 ? 0 : (i - a.c0) - 3 * in;
+        const bool self = live && !d0 && J == 0;                             // W_s1 f1[n, in, a]: once per input channel
+        float bm[NCB1], bsf[NCB1];
+#pragma unroll
+        for (int cb = 0; cb < NCB1; ++cb) {
+            const int o = 16 * cb + i16;
+            const bool ok = live && o < a.o1;
+            bm[cb] = !ok ? 0.0f : (d0 ? a.p01.b[((size_t)o * a.p01.so + (size_t)in * a.p01.si) / H]
+                                      : a.p11.b[((size_t)o * a.p11.so + (size_t)in * a.p11.si) / H + J]);
+            bsf[cb] = (self && o < a.o1) ? a.s1.w[(size_t)o * a.s1.so + (size_t)in * a.s1.si] : 0.0f;
+        }
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa) {
+            const float am = live ? Mbn[d0 ? a.c0p * (1 + aa) + in : f1base + a.c1p * (1 + 3 * aa + J) + in] : 0.0f;
+            const float as = self ? a.f1[((size_t)nA * a.c1 + in) * 3 + aa] : 0.0f;
+#pragma unroll
+            for (int cb = 0; cb < NCB1; ++cb) {
+                acc1[aa][cb] = mfma16(am, bm[cb], acc1[aa][cb]);
+                acc1[aa][cb] = mfma16(as, bsf[cb], acc1[aa][cb]);
+            }
+        }
+    }
+    // ---- the waves' partial tiles are summed in wave order (fixed: bitwise reproducible) and stored; D[node][o]: lane (o = i16,
+    // g = kq) holds nodes 4 g + r
+#pragma unroll
+    for (int cb = 0; cb < NCB0; ++cb) part[wv][cb][lane] = acc0[cb];
+#pragma unroll
+    for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+        for (int cb = 0; cb < NCB1; ++cb) part[wv][NCB0 + aa * NCB1 + cb][lane] = acc1[aa][cb];
+    __syncthreads();
+    for (int t = wv; t < NT; t += kNodeWaves) {
+        f32x4 s = part[0][t][lane];
+#pragma unroll
+        for (int w = 1; w < kNodeWaves; ++w) s += part[w][t][lane];
+        const bool deg0 = t < NCB0;
+        const int aa = deg0 ? 0 : (t - NCB0) / NCB1, cb = deg0 ? t : (t - NCB0) - aa * NCB1;
+        const int o = 16 * cb + i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + 4 * kq + r;
+            if (n >= a.n_nodes) continue;
+            if (deg0) { if (o < a.o0) a.out0[(size_t)n * a.o0 + o] = s[r]; }
+            else if (o < a.o1) a.out1[((size_t)n * a.o1 + o) * 3 + aa] = s[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dM = W^T g
+// The gradient of the moments (for the geometry backward): dM[n, j, h] = sum_o W(o, j, h) g[n, o] with the path's output gradient
+// (g0 for c00 / c10, g1[:, :, a] for c01[a] / c11[a, J]); dMb likewise with the biases.  Padded entries are written as zeros.
+// D[node][h] = sum_o A[node][o] B[o][h]: the 16 nodes' gradient rows stay in registers as A operands for the whole tile.
+struct ExpArgs {
+    const float* g0; const float* g1;                    // [N, o0], [N, o1, 3]
+    PathW p00, p10, p01, p11;                            // forward descriptors
+    int n_nodes, c0, c1, c0p, c1p, lc, o0, o1;
+    float* dM; float* dMb;                               // [N, lc, H], [N, lc]
+};
+
+template <int NH>
+__global__ __launch_bounds__(64 * kNodeWaves) void irrep_expand16_kernel(const ExpArgs a) {
+    constexpr int H = 16 * NH;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int nA = min(n0 + i16, a.n_nodes - 1);
+    // A operands: g[nA][4 s + kq], s = 0..7 (output channels beyond the count: zero)
+    float ga[4][8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int o = 4 * s + kq;
+        ga[0][s] = o < a.o0 ? a.g0[(size_t)nA * a.o0 + o] : 0.0f;
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa) ga[1 + aa][s] = o < a.o1 ? a.g1[((size_t)nA * a.o1 + o) * 3 + aa] : 0.0f;
+    }
+    const int f1base = 4 * a.c0p;
+    for (int e = wv; e < a.lc; e += kNodeWaves) {                       // wave-uniform entry
+        int src, in, J = 0, cin, on;
+        const PathW* p;
+        if (e < f1base) {
+            const int s = e / a.c0p;
+            in = e - s * a.c0p; cin = a.c0;
+            src = s == 0 ? 0 : s; p = s == 0 ? &a.p00 : &a.p01; on = s == 0 ? a.o0 : a.o1;
+        } else {
+            const int q = e - f1base, s = q / a.c1p;
+            in = q - s * a.c1p; cin = a.c1;
+            if (s == 0) { src = 0; p = &a.p10; on = a.o0; }
+            else { const int aa = (s - 1) / 3; J = (s - 1) - 3 * aa; src = 1 + aa; p = &a.p11; on = a.o1; }
+        }
+        const bool real = in < cin;
+        f32x4 acc[NH];
+#pragma unroll
+        for (int t = 0; t < NH; ++t) acc[t] = splat4(0.0f);
+        float bsum = 0.0f;
+        if (real) {
+            const float* wp = p->w + (size_t)in * p->si + J * H;
+            const float* bp = p->b + ((size_t)in * p->si) / H + J;
+            const int nks = (on + 3) >> 2;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s >= nks) break;
+                const int o = 4 * s + kq;
+                const bool ok = o < on;
+                const float av = src == 0 ? ga[0][s] : (src == 1 ? ga[1][s] : (src == 2 ? ga[2][s] : ga[3][s]));
+#pragma unroll
+                for (int t = 0; t < NH; ++t) acc[t] = mfma16(av, ok ? wp[(size_t)o * p->so + 16 * t + i16] : 0.0f, acc[t]);
+                bsum = fmaf(av, ok ? bp[((size_t)o * p->so) / H] : 0.0f, bsum);
+            }
+        }
+        bsum = gsum(bsum);
+        // D[node][h]: lane (h = i16, g = kq) holds nodes 4 g + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + 4 * kq + r;
+            if (n >= a.n_nodes) continue;
+#pragma unroll
+            for (int t = 0; t < NH; ++t) a.dM[((size_t)n * a.lc + e) * H + 16 * t + i16] = acc[t][r];
+        }
+        if (kq == 0 && n0 + i16 < a.n_nodes) a.dMb[(size_t)(n0 + i16) * a.lc + e] = bsum;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: geometry + radial.0
+// Per edge e (row = n):  d c[e, j] = sum_h dM[n, j, h] hid[e, h] + dMb[n, j],   d hid[e, h] = sum_j dM[n, j, h] c[e, j];  from d c the
+// gradient of the unit vector u (the closed-form basis is linear / quadratic in u), from d hid the gradient of d = |r| (through
+// SiLU and w_r1) and the sums d w_r1, d b_r1;  d r = dd u + (du - (du . u) u) / d  (zero on a self loop).
+// A wave per node; its edges in blocks of 16: lane (e = l & 15, g = l >> 4) owns edge e and the four entries 16 blk + 4 g + r of
+// every 16-entry block -- the C/D layout of D[entry][edge] (d c) AND the B operand of D[h][edge] = sum_j dM[j][h] c[e][j] (d hid),
+// so c is computed once, in the lane that consumes it both ways.  The block's dM tile goes through a wave-private LDS tile (read as
+// rows for d c, as columns for d hid).
+struct GeomArgs {
+    const float* x; const float* f0; const float* f1;
+    const int* ptr; const int* perm; const int* src;
+    const float* w1; const float* b1;
+    Consts k;
+    int n_nodes, c0, c1, c0p, c1p, lc;
+    const float* dM; const float* dMb;
+    float* dr;          // [E, 4]: d loss / d r_e (the caller scatters +dr to row, -dr to col)
+    float* dxr;         // [N, 4]: sum of dr over the node's row segment
+    float* slab;        // [ceil(N / 4), 2 H]: per-workgroup sums of d w_r1 | d b_r1
+};
+
+// contribution of one f1-part slot to the operand c and (given D = d c) to du, for one channel's vector gv; SLOT: 0 = K10 . f1,
+// 1 + 3 a + J = K11[a, :, J] . f1
+template <int SLOT>
+__device__ __forceinline__ float slot_c(const float (&gv)[3], const float (&u)[3], float sd, const Consts& k, float k110v, float k112l) {
+    if (SLOT == 0) return k.k10 * sd;
+    constexpr int aa = (SLOT - 1) / 3, J = (SLOT - 1) % 3;
+    if (J == 0) return k110v * gv[aa];
+    if (J == 1) return k.k111 * (gv[(aa + 1) % 3] * u[(aa + 2) % 3] - gv[(aa + 2) % 3] * u[(aa + 1) % 3]);
+    return k112l * (u[aa] * sd - gv[aa] * (1.0f / 3.0f));
+}
+template <int SLOT>
+__device__ __forceinline__ void slot_du(const float (&gv)[3], const float (&u)[3], float sd, const Consts& k, float k112l, float D,
+                                        float (&du)[3]) {
+    if (SLOT == 0) {
+        const float t = k.k10 * D;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) du[c] = fmaf(t, gv[c], du[c]);
+        return;
+    }
+    constexpr int aa = (SLOT - 1) / 3, J = (SLOT - 1) % 3;
+    if (J == 1) {                 // c = k111 (g x u)_a: d/du = k111 D (e_a x g)
+        const float t = k.k111 * D;
+        du[(aa + 1) % 3] = fmaf(-t, gv[(aa + 2) % 3], du[(aa + 1) % 3]);
+        du[(aa + 2) % 3] = fmaf(t, gv[(aa + 1) % 3], du[(aa + 2) % 3]);
+    } else if (J == 2) {          // c = k112 (u_a (u . g) - g_a / 3): d/du = k112 D ((u . g) e_a + u_a g)
+        const float t = k112l * D;
+        du[aa] = fmaf(t, sd, du[aa]);
+        const float tu = t * u[aa];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) du[c] = fmaf(tu, gv[c], du[c]);
+    }
+}
+
+constexpr int kTileStride = 36;      // dM tile [16 entries][H <= 32] in LDS: rows 36 floats apart (16-byte aligned rows, column reads spread over the banks)
+
+template <int NH, int C1P>
+__global__ __launch_bounds__(256) void irrep_geom_bwd_kernel(const GeomArgs a) {
+    constexpr int H = 16 * NH;
+    __shared__ float tile_s[4][16 * kTileStride];
+    __shared__ float red[4][2 * 32];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wv;
+    const int i16 = lane & 15, g = lane >> 4;
+    float* tile = tile_s[wv];
+    // lane-owned radial hidden units in the two layouts: B operand of d c (h = 16 t + 4 g + r) = C/D rows of d hid
+    float w1v[NH][4], b1v[NH][4], aw[NH][4], ab[NH][4];
+#pragma unroll
+    for (int t = 0; t < NH; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            w1v[t][r] = a.w1[16 * t + 4 * g + r];
+            b1v[t][r] = a.b1[16 * t + 4 * g + r];
+            aw[t][r] = ab[t][r] = 0.0f;
+        }
+    const bool node_ok = n < a.n_nodes;                      // wave-uniform
+    const int nn = node_ok ? n : a.n_nodes - 1;
+    const int lo = node_ok ? a.ptr[nn] : 0, hi = node_ok ? a.ptr[nn + 1] : 0;
+    const float xn0 = a.x[(size_t)nn * 3], xn1 = a.x[(size_t)nn * 3 + 1], xn2 = a.x[(size_t)nn * 3 + 2];
+    const float* dMn = a.dM + (size_t)nn * a.lc * H;
+    const float* dMbn = a.dMb + (size_t)nn * a.lc;
+    const int f1base = 4 * a.c0p, B0 = a.c0p >> 4;
+    float xs0 = 0.0f, xs1 = 0.0f, xs2 = 0.0f;               // sum of dr over the node's edges
+    for (int base = lo; base < hi; base += 16) {
+        const int cnt = min(16, hi - base);
+        const bool valid = i16 < cnt;
+        const int eid = valid ? a.perm[base + i16] : 0;
+        const int s = valid ? a.src[eid] : nn;
+        const float r0 = xn0 - a.x[(size_t)s * 3], r1 = xn1 - a.x[(size_t)s * 3 + 1], r2 = xn2 - a.x[(size_t)s * 3 + 2];
+        const float d = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+        const bool live = valid && d > 0.0f;
+        const float inv = live ? 1.0f / d : 0.0f;
+        const float u[3] = {r0 * inv, r1 * inv, r2 * inv};
+        const float k00v = valid ? a.k.k00 : 0.0f, k110v = valid ? a.k.k110 : 0.0f, k112l = live ? a.k.k112 : 0.0f;
+        // hid[e][h] for the lane's h = 16 t + 4 g + r (B operand of d c), and SiLU' for the d hid epilogue
+        f32x4 hid[NH], dsl[NH];
+#pragma unroll
+        for (int t = 0; t < NH; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float z = fmaf(w1v[t][r], d, b1v[t][r]);
+                hid[t][r] = silu(z);
+                dsl[t][r] = silu_grad(z);
+            }
+        f32x4 dh[NH];
+#pragma unroll
+        for (int t = 0; t < NH; ++t) dh[t] = splat4(0.0f);
+        float du[3] = {0.0f, 0.0f, 0.0f};
+        // one 16-entry block: stage the dM tile, d c (optional), d hid; `cv` = the lane's four operand values c[e][16 blk + 4 g + r]
+        auto block = [&](int blk, const f32x4& cv, bool want_dc, f32x4& dc) {
+            // tile rows: lane (j = i16, kq = g) loads dM[n][16 blk + j][16 t + 4 g ..]
+            f32x4 arow[NH];
+#pragma unroll
+            for (int t = 0; t < NH; ++t) {
+                arow[t] = ldg4(dMn + ((size_t)(16 * blk + i16)) * H + 16 * t + 4 * g);
+                st4(tile + i16 * kTileStride + 16 * t + 4 * g, arow[t]);
+            }
+            wave_sync();
+            if (want_dc) {
+                dc = ldg4(dMbn + 16 * blk + 4 * g);                               // D[entry][edge]: lane (e, g) holds entries 4 g + r
+#pragma unroll
+                for (int t = 0; t < NH; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dc = mfma16(arow[t][r], hid[t][r], dc);
+            }
+            // d hid: D[h][e] += sum_j dM[j][h] c[e][j]; k-step r: A lane (h = i16, kq = g) = dM[16 blk + 4 g + r][16 t + h]
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < NH; ++t) dh[t] = mfma16(tile[(4 * g + r) * kTileStride + 16 * t + i16], cv[r], dh[t]);
+            wave_sync();                                                          // the next block overwrites the tile
+        };
+        // ---- entries built from f0: c00 = K00 f0 (no u in it: d c not needed), c01[a] = k01 u_a f0
+        const float* f0r = a.f0 + (size_t)s * a.c0;
+        for (int sub = 0; sub < B0; ++sub) {
+            const int i0 = 16 * sub + 4 * g;
+            f32x4 gv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gv[r] = (i0 + r < a.c0) ? f0r[i0 + r] : 0.0f;
+            f32x4 dc;
+            block(sub, gv * splat4(k00v), false, dc);
+#pragma unroll
+            for (int aa = 0; aa < 3; ++aa) {
+                block((1 + aa) * B0 + sub, gv * splat4(a.k.k01 * u[aa]), true, dc);
+                du[aa] = fmaf(a.k.k01, dc[0] * gv[0] + dc[1] * gv[1] + dc[2] * gv[2] + dc[3] * gv[3], du[aa]);
+            }
+        }
+        // ---- entries built from f1
+        if (C1P == 8) {
+            // block t holds slots 2 t (lane groups g = 0, 1) and 2 t + 1 (g = 2, 3) of channels 4 (g & 1) + r
+            const int ch0 = 4 * (g & 1);
+            const bool up = g >= 2;
+            float gv[4][3], sd[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = ch0 + r < a.c1;
+                const float* f1r = a.f1 + ((size_t)s * a.c1 + ch0 + r) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gv[r][c] = ok ? f1r[c] : 0.0f;
+                sd[r] = u[0] * gv[r][0] + u[1] * gv[r][1] + u[2] * gv[r][2];
+            }
+            auto pair = [&](auto tag) {
+                constexpr int t = decltype(tag)::value;
+                f32x4 cv, dc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float lo_ = slot_c<2 * t>(gv[r], u, sd[r], a.k, k110v, k112l);
+                    const float hi_ = slot_c<2 * t + 1>(gv[r], u, sd[r], a.k, k110v, k112l);
+                    cv[r] = up ? hi_ : lo_;
+                }
+                block((f1base >> 4) + t, cv, true, dc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    slot_du<2 * t>(gv[r], u, sd[r], a.k, k112l, up ? 0.0f : dc[r], du);
+                    slot_du<2 * t + 1>(gv[r], u, sd[r], a.k, k112l, up ? dc[r] : 0.0f, du);
+                }
+            };
+            pair(std::integral_constant<int, 0>{}); pair(std::integral_constant<int, 1>{}); pair(std::integral_constant<int, 2>{});
+            pair(std::integral_constant<int, 3>{}); pair(std::integral_constant<int, 4>{});
+        } else {
+            constexpr int SB = C1P / 16;
+            for (int sub = 0; sub < SB; ++sub) {
+                const int ch0 = 16 * sub + 4 * g;
+                float gv[4][3], sd[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = ch0 + r < a.c1;
+                    const float* f1r = a.f1 + ((size_t)s * a.c1 + ch0 + r) * 3;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) gv[r][c] = ok ? f1r[c] : 0.0f;
+                    sd[r] = u[0] * gv[r][0] + u[1] * gv[r][1] + u[2] * gv[r][2];
+                }
+                auto one = [&](auto tag) {
+                    constexpr int SL = decltype(tag)::value;
+                    f32x4 cv, dc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cv[r] = slot_c<SL>(gv[r], u, sd[r], a.k, k110v, k112l);
+                    constexpr bool needs = (SL == 0) || ((SL - 1) % 3 != 0);       // J = 0 has no u in it
+                    block((f1base >> 4) + SL * SB + sub, cv, needs, dc);
+                    if (needs) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) slot_du<SL>(gv[r], u, sd[r], a.k, k112l, dc[r], du);
+                    }
+                };
+                one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
+                one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+                one(std::integral_constant<int, 6>{}); one(std::integral_constant<int, 7>{}); one(std::integral_constant<int, 8>{});
+                one(std::integral_constant<int, 9>{});
+            }
+        }
+        // ---- the edge's totals: d hid is D[h][e] with lane (e, g) holding h = 16 t + 4 g + r
+        float dd = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NH; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float q = dh[t][r] * dsl[t][r];          // d loss / d z[e, h]
+                dd = fmaf(q, w1v[t][r], dd);
+                aw[t][r] = fmaf(q, d, aw[t][r]);
+                ab[t][r] += q;
+            }
+        dd = gsum(dd);
+        du[0] = gsum(du[0]); du[1] = gsum(du[1]); du[2] = gsum(du[2]);
+        const float dun = du[0] * u[0] + du[1] * u[1] + du[2] * u[2];
+        float dr[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dr[c] = live ? fmaf(dd, u[c], (du[c] - dun * u[c]) * inv) : 0.0f;
+        if (valid && g == 0) reinterpret_cast<float4*>(a.dr)[eid] = make_float4(dr[0], dr[1], dr[2], 0.0f);
+        xs0 += row16_sum(dr[0]); xs1 += row16_sum(dr[1]); xs2 += row16_sum(dr[2]);
+    }
+    if (node_ok && lane == 0) reinterpret_cast<float4*>(a.dxr)[n] = make_float4(xs0, xs1, xs2, 0.0f);
+    // ---- d w_r1 / d b_r1: sum over the wave's 16 edge lanes, then over the workgroup's waves in wave order
+#pragma unroll
+    for (int t = 0; t < NH; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sw = row16_sum(aw[t][r]), sb = row16_sum(ab[t][r]);
+            if (i16 == 0) { red[wv][16 * t + 4 * g + r] = sw; red[wv][32 + 16 * t + 4 * g + r] = sb; }
+        }
+    __syncthreads();
+    if (threadIdx.x < 2 * H) {
+        const int which = threadIdx.x / H, h = threadIdx.x - which * H;
+        const float v = red[0][32 * which + h] + red[1][32 * which + h] + red[2][32 * which + h] + red[3][32 * which + h];
+        a.slab[(size_t)blockIdx.x * 2 * H + threadIdx.x] = v;
+    }
+}
+
+// d x[n] += (sum of dr over the edges with row = n) - (sum over the edges with col = n): r = x[row] - x[col]
+__global__ void irrep_dx_kernel(const float* __restrict__ dr, const float* __restrict__ dxr, const int* __restrict__ cptr,
+                                const int* __restrict__ cperm, int n_nodes, float* __restrict__ dx) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= n_nodes) return;
+    float4 acc = reinterpret_cast<const float4*>(dxr)[n];
+    for (int p = cptr[n]; p < cptr[n + 1]; ++p) {
+        const float4 v = reinterpret_cast<const float4*>(dr)[cperm[p]];
+        acc.x -= v.x; acc.y -= v.y; acc.z -= v.z;
+    }
+    dx[(size_t)n * 3] += acc.x; dx[(size_t)n * 3 + 1] += acc.y; dx[(size_t)n * 3 + 2] += acc.z;
+}
+
+// ------------------------------------------------------------------------------------------------ backward: weight gradients
+// d W(o, j, h) = sum_n g[n, o] M[n, j, h] (+ the three components a for the degree-1 outputs), d bias likewise with Mb, d W_self
+// with the node's own features: GEMMs with K = nodes.  A wave owns up to four weight rows ("group": same path) and a node range;
+// D[h][o] = sum_n A[h][n] B[n][o] with A = the moment rows (lane (h = l & 15, k = l >> 4): M[n0 + k][entry][16 t + h]) and
+// B = the output gradients; every node range writes its own slab in the parameter layout, summed later in fixed order.
+struct WgradArgs {
+    const float* M; const float* Mb; const float* f0; const float* f1; const float* g0; const float* g1;
+    int n_nodes, c0, c1, c0p, c1p, lc, o0, o1, H;
+    int off00, off01, off10, off11, n_w;      // row offsets inside radial.2
+    int nodes_per_split;
+    float* slab;                                // [splits][P]: d W_r2 [n_w, H] | d b_r2 [n_w] | d W_s0 [o0, c0] | d W_s1 [o1, c1]
+    int P;
+};
+
+// groups: [0, G00): R00 rows i (4 per group) | [.., +G10): R10 | [.., +G01): R01 | [.., +G11): R11 rows (i, J) | self0 blocks | self1 blocks
+template <int NH>
+__global__ __launch_bounds__(64) void irrep_wgrad16_kernel(const WgradArgs a) {
+    constexpr int H = 16 * NH;
+    const int lane = threadIdx.x, i16 = lane & 15, kq = lane >> 4;
+    const int G00 = (a.c0 + 3) >> 2, G10 = (a.c1 + 3) >> 2, G01 = G00, G11 = (3 * a.c1 + 3) >> 2;
+    const int GS0 = (a.c0 + 15) >> 4, GS1 = (a.c1 + 15) >> 4;
+    int grp = blockIdx.x;
+    const int split = blockIdx.y;
+    const int nb = split * a.nodes_per_split, ne = min(a.n_nodes, nb + a.nodes_per_split);
+    float* slab = a.slab + (size_t)split * a.P;
+    const int f1base = 4 * a.c0p;
+    int kind;                      // 0: R00, 1: R10, 2: R01, 3: R11, 4: self0, 5: self1
+    if (grp < G00) kind = 0;
+    else if ((grp -= G00) < G10) kind = 1;
+    else if ((grp -= G10) < G01) kind = 2;
+    else if ((grp -= G01) < G11) kind = 3;
+    else if ((grp -= G11) < GS0) kind = 4;
+    else { grp -= GS0; kind = 5; }
+    const bool deg1 = kind == 2 || kind == 3 || kind == 5;      // output gradient: g1 (three components) or g0
+    const int on = deg1 ? a.o1 : a.o0;
+    const int ncb = (on + 15) >> 4;
+    if (kind >= 4) {
+        // ---- d W_self[o][i] = sum_n g[n, o] f[n, i]: D[i][o], A lane (i = i16, k): f[n0 + k][16 grp + i16]
+        const int cin = kind == 4 ? a.c0 : a.c1;
+        const int i = 16 * grp + i16;
+        f32x4 acc[2] = {splat4(0.0f), splat4(0.0f)};
+        for (int n0 = nb; n0 < ne; n0 += 4) {
+            const int nk = n0 + kq;
+            const bool ok = nk < ne;
+            for (int aa = 0; aa < (deg1 ? 3 : 1); ++aa) {
+                const float av = (ok && i < cin) ? (deg1 ? a.f1[((size_t)nk * a.c1 + i) * 3 + aa] : a.f0[(size_t)nk * a.c0 + i]) : 0.0f;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    if (cb >= ncb) break;
+                    const int o = 16 * cb + i16;
+                    const float bv = (ok && o < on) ? (deg1 ? a.g1[((size_t)nk * a.o1 + o) * 3 + aa] : a.g0[(size_t)nk * a.o0 + o]) : 0.0f;
+                    acc[cb] = mfma16(av, bv, acc[cb]);
+                }
+            }
+        }
+        // D[i][o]: lane (o = i16, g = kq) holds i = 16 grp + 4 g + r
+        float* dst = slab + (size_t)a.n_w * (H + 1) + (kind == 4 ? 0 : (size_t)a.o0 * a.c0);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            if (cb >= ncb) break;
+            const int o = 16 * cb + i16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ii = 16 * grp + 4 * kq + r;
+                if (o < on && ii < cin) dst[(size_t)o * cin + ii] = acc[cb][r];
+            }
+        }
+        return;
+    }
+    // ---- radial.2 rows: up to four (in, J) rows of one path
+    const int cin = (kind == 0 || kind == 2) ? a.c0 : a.c1;
+    const int nrow_total = kind == 3 ? 3 * a.c1 : cin;
+    const int row0 = 4 * grp;
+    f32x4 acc[4][NH][2];
+    float bacc[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            bacc[q][cb] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NH; ++t) acc[q][t][cb] = splat4(0.0f);
+        }
+    for (int n0 = nb; n0 < ne; n0 += 4) {
+        const int nk = n0 + kq;
+        const bool ok = nk < ne;
+        const float* Mn = a.M + (size_t)(ok ? nk : nb) * a.lc * H;
+        const float* Mbn = a.Mb + (size_t)(ok ? nk : nb) * a.lc;
+        for (int aa = 0; aa < (deg1 ? 3 : 1); ++aa) {
+            float bv[2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int o = 16 * cb + i16;
+                bv[cb] = (ok && cb < ncb && o < on) ? (deg1 ? a.g1[((size_t)nk * a.o1 + o) * 3 + aa] : a.g0[(size_t)nk * a.o0 + o]) : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = row0 + q;
+                if (row >= nrow_total) break;                                     // wave-uniform
+                int entry;
+                if (kind == 0) entry = row;
+                else if (kind == 1) entry = f1base + row;
+                else if (kind == 2) entry = a.c0p * (1 + aa) + row;
+                else { const int in = row / 3, J = row - 3 * in; entry = f1base + a.c1p * (1 + 3 * aa + J) + in; }
+                const float mb = ok ? Mbn[entry] : 0.0f;
+#pragma unroll
+                for (int t = 0; t < NH; ++t) {
+                    const float av = ok ? Mn[(size_t)entry * H + 16 * t + i16] : 0.0f;
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        if (cb >= ncb) break;
+                        acc[q][t][cb] = mfma16(av, bv[cb], acc[q][t][cb]);
+                    }
+                }
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) bacc[q][cb] = fmaf(mb, bv[cb], bacc[q][cb]);
+            }
+        }
+    }
+    // D[h][o]: lane (o = i16, g = kq) holds h = 16 t + 4 g + r.  Parameter layout: row index (o * cin + in) (* 3 + J for R11)
+    const int off = kind == 0 ? a.off00 : (kind == 1 ? a.off10 : (kind == 2 ? a.off01 : a.off11));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = row0 + q;
+        if (row >= nrow_total) break;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            if (cb >= ncb) break;
+            const int o = 16 * cb + i16;
+            const size_t prow = (size_t)off + (size_t)o * nrow_total + row;       // R11: o * (3 c1) + (in * 3 + J) = (o * c1 + in) * 3 + J
+            const float bt = gsum(bacc[q][cb]);
+            if (o < on) {
+#pragma unroll
+                for (int t = 0; t < NH; ++t) st4(slab + prow * H + 16 * t + 4 * kq, acc[q][t][cb]);
+                if (kq == 0) slab[(size_t)a.n_w * H + prow] = bt;
+            }
+        }
+    }
+}
+
+// sums of the slabs in fixed order -> the parameter gradients (overwritten)
+__global__ void irrep_wreduce_kernel(const float* __restrict__ slab, int splits, int P, int n_wH, int n_w, int ns0, int ns1,
+                                     float* __restrict__ d_w2, float* __restrict__ d_b2, float* __restrict__ d_ws0,
+                                     float* __restrict__ d_ws1, const float* __restrict__ gslab, int gsplits, int H,
+                                     float* __restrict__ d_w1, float* __restrict__ d_b1) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < P) {
+        float s = 0.0f;
+        for (int k = 0; k < splits; ++k) s += slab[(size_t)k * P + idx];
+        if (idx < n_wH) d_w2[idx] = s;
+        else if (idx < n_wH + n_w) d_b2[idx - n_wH] = s;
+        else if (idx < n_wH + n_w + ns0) d_ws0[idx - n_wH - n_w] = s;
+        else d_ws1[idx - n_wH - n_w - ns0] = s;
+    } else if (idx < P + 2 * H) {
+        const int j = idx - P;
+        float s = 0.0f;
+        for (int k = 0; k < gsplits; ++k) s += gslab[(size_t)k * 2 * H + j];
+        if (j < H) d_w1[j] = s; else d_b1[j - H] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct Layout {
+    int c0i, c1i, c0o, c1o, H;
+    int off00, off01, off10, off11;        // row offsets of the four paths inside radial.2.weight / .bias (R00 | R01 | R10 | R11)
+};
+static Layout layout_of(const equigspr_irrep_config* c) {
+    Layout L{c->c0_in, c->c1_in, c->c0_out, c->c1_out, c->hidden, 0, 0, 0, 0};
+    L.off01 = L.c0o * L.c0i;
+    L.off10 = L.off01 + L.c1o * L.c0i;
+    L.off11 = L.off10 + L.c0o * L.c1i;
+    return L;
+}
+static bool config_ok(const equigspr_irrep_config* c) {
+    if (!c) return false;
+    auto ch = [](int v) { return v >= 1 && v <= kMaxC; };
+    return ch(c->c0_in) && ch(c->c1_in) && ch(c->c0_out) && ch(c->c1_out) && (c->hidden == 16 || c->hidden == 32);
+}
+
+template <int NH>
+static void launch_moments(const MomArgs& a, hipStream_t s) {
+    const int B0 = a.c0p / 16, units = 1 + (a.c1p == 8 ? 1 : 2 * (a.c1p / 16));
+    const dim3 grid(ceil_div(a.n_nodes, 4), units), block(256);
+#define EQ_IR_MOM(BB, CC) \
+    if (B0 == BB && a.c1p == CC) { hipLaunchKernelGGL((irrep_moments16_kernel<NH, BB, CC>), grid, block, 0, s, a); return; }
+    EQ_IR_MOM(1, 8) EQ_IR_MOM(1, 16) EQ_IR_MOM(1, 32) EQ_IR_MOM(2, 8) EQ_IR_MOM(2, 16) EQ_IR_MOM(2, 32)
+#undef EQ_IR_MOM
+}
+
+template <int NH>
+static void launch_node(const NodeArgs& a, hipStream_t s) {
+    const int cb0 = ceil_div(a.o0, 16), cb1 = ceil_div(a.o1, 16);
+    const dim3 grid(ceil_div(a.n_nodes, 16)), block(64 * kNodeWaves);
+#define EQ_IR_NODE(AA, BB) \
+    if (cb0 == AA && cb1 == BB) { hipLaunchKernelGGL((irrep_node16_kernel<NH, AA, BB>), grid, block, 0, s, a); return; }
+    EQ_IR_NODE(1, 1) EQ_IR_NODE(1, 2) EQ_IR_NODE(2, 1) EQ_IR_NODE(2, 2)
+#undef EQ_IR_NODE
+}
+
+// forward direction: aggregate at row, gather from col, weights as stored
+static void conv_forward(const equigspr_irrep_config* c, const Layout& L, const float* w_r1, const float* b_r1, const float* w_r2,
+                         const float* b_r2, const float* ws0, const float* ws1, const equigspr_graph* g, const float* f0,
+                         const float* f1, const float* x, float* out0, float* out1, float* M, float* Mb, hipStream_t s) {
+    const int H = L.H, c0p = pad0(L.c0i), c1p = pad1(L.c1i), lc = 4 * c0p + 10 * c1p;
+    MomArgs m{x, f0, f1, g->rptr, g->rperm, g->col, w_r1, b_r1, Consts{c->k00, c->k01, c->k10, c->k11_0, c->k11_1, c->k11_2},
+              g->n_nodes, L.c0i, L.c1i, c0p, c1p, lc, M, Mb};
+    NodeArgs nd{M, Mb, f0, f1,
+                PathW{w_r2 + (size_t)L.off00 * H, b_r2 + L.off00, L.c0i * H, H},
+                PathW{w_r2 + (size_t)L.off10 * H, b_r2 + L.off10, L.c1i * H, H},
+                PathW{w_r2 + (size_t)L.off01 * H, b_r2 + L.off01, L.c0i * H, H},
+                PathW{w_r2 + (size_t)L.off11 * H, b_r2 + L.off11, L.c1i * 3 * H, 3 * H},
+                SelfW{ws0, L.c0i, 1}, SelfW{ws1, L.c1i, 1},
+                g->n_nodes, L.c0i, L.c1i, c0p, c1p, lc, L.c0o, L.c1o, out0, out1};
+    if (H == 16) { launch_moments<1>(m, s); launch_node<1>(nd, s); }
+    else { launch_moments<2>(m, s); launch_node<2>(nd, s); }
+}
+
+
+// ---- backward: scratch layout and launches
+static inline int64_t r4(int64_t v) { return (v + 3) / 4 * 4; }
+struct BwdPlan {
+    int lc, lc_r, groups, splits, nodes_per_split, P, gsplits;
+    int64_t o_Mr, o_Mbr, o_dM, o_dMb, o_dr, o_dxr, o_gslab, o_wslab, total;
+};
+static BwdPlan plan_bwd(const Layout& L, int n_nodes, int n_edges) {
+    BwdPlan p{};
+    const int H = L.H;
+    p.lc = 4 * pad0(L.c0i) + 10 * pad1(L.c1i);
+    p.lc_r = 4 * pad0(L.c0o) + 10 * pad1(L.c1o);
+    const int n_w = L.off11 + 3 * L.c1o * L.c1i;
+    p.P = n_w * (H + 1) + L.c0o * L.c0i + L.c1o * L.c1i;
+    p.groups = 2 * ceil_div(L.c0i, 4) + ceil_div(L.c1i, 4) + ceil_div(3 * L.c1i, 4) + ceil_div(L.c0i, 16) + ceil_div(L.c1i, 16);
+    int want = ceil_div(2048, p.groups);                                 // ~2 k waves in flight
+    want = max(1, min(want, ceil_div(max(n_nodes, 1), 16)));
+    p.nodes_per_split = round_up(ceil_div(max(n_nodes, 1), want), 4);
+    p.splits = ceil_div(max(n_nodes, 1), p.nodes_per_split);
+    p.gsplits = ceil_div(max(n_nodes, 1), 4);
+    int64_t o = 0;
+    p.o_Mr = o;    o += r4((int64_t)n_nodes * p.lc_r * H);
+    p.o_Mbr = o;   o += r4((int64_t)n_nodes * p.lc_r);
+    p.o_dM = o;    o += r4((int64_t)n_nodes * p.lc * H);
+    p.o_dMb = o;   o += r4((int64_t)n_nodes * p.lc);
+    p.o_dr = o;    o += r4((int64_t)max(n_edges, 1) * 4);
+    p.o_dxr = o;   o += r4((int64_t)n_nodes * 4);
+    p.o_gslab = o; o += r4((int64_t)p.gsplits * 2 * H);
+    p.o_wslab = o; o += r4((int64_t)p.splits * p.P);
+    p.total = o;
+    return p;
+}
+
+template <int NH>
+static void launch_geom(const GeomArgs& a, hipStream_t s) {
+    const dim3 grid(ceil_div(a.n_nodes, 4)), block(256);
+    if (a.c1p == 8) hipLaunchKernelGGL((irrep_geom_bwd_kernel<NH, 8>), grid, block, 0, s, a);
+    else if (a.c1p == 16) hipLaunchKernelGGL((irrep_geom_bwd_kernel<NH, 16>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((irrep_geom_bwd_kernel<NH, 32>), grid, block, 0, s, a);
+}
+
+static void conv_backward(const equigspr_irrep_config* c, const Layout& L, const float* w_r1, const float* b_r1, const float* w_r2,
+                          const float* b_r2, const float* ws0, const float* ws1, const equigspr_graph* g, const float* f0,
+                          const float* f1, const float* x, const float* M, const float* g0, const float* g1, float* d_f0, float* d_f1,
+                          float* d_x, float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_ws0, float* d_ws1, float* work,
+                          hipStream_t s) {
+    const int H = L.H, N = g->n_nodes;
+    const BwdPlan p = plan_bwd(L, N, g->n_edges);
+    const Consts kf{c->k00, c->k01, c->k10, c->k11_0, c->k11_1, c->k11_2};
+    const int c0p = pad0(L.c0i), c1p = pad1(L.c1i);
+    const float* Mb = M + (int64_t)N * p.lc * H;
+    const PathW f00{w_r2 + (size_t)L.off00 * H, b_r2 + L.off00, L.c0i * H, H}, f10{w_r2 + (size_t)L.off10 * H, b_r2 + L.off10, L.c1i * H, H},
+        f01{w_r2 + (size_t)L.off01 * H, b_r2 + L.off01, L.c0i * H, H}, f11{w_r2 + (size_t)L.off11 * H, b_r2 + L.off11, L.c1i * 3 * H, 3 * H};
+    if (d_f0 && d_f1) {
+        // the adjoint convolution: aggregate at col, gather the output gradients from row; r' = x[col] - x[row] = -r flips the two
+        // kernels that are odd in u (K01 <-> K10 also swap roles); transposed weights = swapped strides
+        const int c0pr = pad0(L.c0o), c1pr = pad1(L.c1o);
+        MomArgs m{x, g0, g1, g->cptr, g->cperm, g->row, w_r1, b_r1, Consts{c->k00, -c->k10, -c->k01, c->k11_0, c->k11_1, c->k11_2},
+                  N, L.c0o, L.c1o, c0pr, c1pr, p.lc_r, work + p.o_Mr, work + p.o_Mbr};
+        NodeArgs nd{work + p.o_Mr, work + p.o_Mbr, g0, g1,
+                    PathW{f00.w, f00.b, H, L.c0i * H},               // G0 -> d f0: R00^T
+                    PathW{f01.w, f01.b, H, L.c0i * H},               // G1 -> d f0: R01^T
+                    PathW{f10.w, f10.b, H, L.c1i * H},               // G0 -> d f1: R10^T
+                    PathW{f11.w, f11.b, 3 * H, L.c1i * 3 * H},       // G1 -> d f1: R11^T
+                    SelfW{ws0, 1, L.c0i}, SelfW{ws1, 1, L.c1i},
+                    N, L.c0o, L.c1o, c0pr, c1pr, p.lc_r, L.c0i, L.c1i, d_f0, d_f1};
+        if (H == 16) { launch_moments<1>(m, s); launch_node<1>(nd, s); }
+        else { launch_moments<2>(m, s); launch_node<2>(nd, s); }
+    }
+    // geometry + radial.0
+    ExpArgs ex{g0, g1, f00, f10, f01, f11, N, L.c0i, L.c1i, c0p, c1p, p.lc, L.c0o, L.c1o, work + p.o_dM, work + p.o_dMb};
+    GeomArgs ge{x, f0, f1, g->rptr, g->rperm, g->col, w_r1, b_r1, kf, N, L.c0i, L.c1i, c0p, c1p, p.lc, work + p.o_dM, work + p.o_dMb,
+                work + p.o_dr, work + p.o_dxr, work + p.o_gslab};
+    const dim3 egrid(ceil_div(N, 16)), eblock(64 * kNodeWaves);
+    if (H == 16) { hipLaunchKernelGGL((irrep_expand16_kernel<1>), egrid, eblock, 0, s, ex); launch_geom<1>(ge, s); }
+    else { hipLaunchKernelGGL((irrep_expand16_kernel<2>), egrid, eblock, 0, s, ex); launch_geom<2>(ge, s); }
+    if (d_x) hipLaunchKernelGGL(irrep_dx_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, work + p.o_dr, work + p.o_dxr, g->cptr, g->cperm, N, d_x);
+    // weight gradients
+    const int n_w = L.off11 + 3 * L.c1o * L.c1i;
+    WgradArgs wa{M, Mb, f0, f1, g0, g1, N, L.c0i, L.c1i, c0p, c1p, p.lc, L.c0o, L.c1o, H, L.off00, L.off01, L.off10, L.off11, n_w,
+                 p.nodes_per_split, work + p.o_wslab, p.P};
+    const dim3 wgrid(p.groups, p.splits);
+    if (H == 16) hipLaunchKernelGGL((irrep_wgrad16_kernel<1>), wgrid, dim3(64), 0, s, wa);
+    else hipLaunchKernelGGL((irrep_wgrad16_kernel<2>), wgrid, dim3(64), 0, s, wa);
+    hipLaunchKernelGGL(irrep_wreduce_kernel, dim3(ceil_div(p.P + 2 * H, 256)), dim3(256), 0, s, work + p.o_wslab, p.splits, p.P, n_w * H, n_w,
+                       L.c0o * L.c0i, L.c1o * L.c1i, d_w2, d_b2, d_ws0, d_ws1, work + p.o_gslab, p.gsplits, H, d_w1, d_b1);
+}
+
+}  // namespace ir
 }  // namespace eq
 
-extern "C" int equigspr_irrep_conv_forward(const float* f0, const float* f1, const float* dist, const float* radial, const float* k00,
-                                           const float* k01, const float* k10, const float* k11, const float* w_self0,
-                                           const float* w_self1, const int32_t* col, const int32_t* rptr, const int32_t* rperm,
-                                           int32_t n_nodes, int32_t n_edges, int32_t c0_in, int32_t c1_in, int32_t c0_out, int32_t c1_out,
-                                           float* out0, float* out1, void* stream) {
+extern "C" int64_t equigspr_irrep_moments_size(const equigspr_irrep_config* cfg, int32_t n_nodes) {
+    using namespace eq::ir;
+    if (!config_ok(cfg) || n_nodes < 0) return -1;
+    const int64_t lc = 4 * pad0(cfg->c0_in) + 10 * pad1(cfg->c1_in);
+    return (int64_t)n_nodes * lc * (cfg->hidden + 1);
+}
+
+extern "C" int equigspr_irrep_conv_forward(const equigspr_irrep_config* cfg, const float* w_r1, const float* b_r1, const float* w_r2,
+                                           const float* b_r2, const float* w_self0, const float* w_self1, const equigspr_graph* g,
+                                           const float* f0, const float* f1, const float* x, float* out0, float* out1,
+                                           float* moments, void* stream) {
     using namespace eq;
-    EQ_CHECK_ARG(f0 && f1 && dist && radial && k00 && k01 && k10 && k11 && w_self0 && w_self1 && col && rptr && rperm && out0 && out1,
-                 EQUIGSPR_EINVAL, "irrep_conv_forward: null argument");
-    EQ_CHECK_ARG(n_nodes >= 1 && n_edges >= 0, EQUIGSPR_EINVAL, "irrep_conv_forward: n_nodes >= 1, n_edges >= 0");
-    EQ_CHECK_ARG(c0_in >= 1 && c1_in >= 1 && c0_out >= 1 && c1_out >= 1 && c0_in <= kIrMaxC && c1_in <= kIrMaxC && c0_out <= kIrMaxC &&
-                     c1_out <= kIrMaxC, EQUIGSPR_ENOTSUP, "irrep_conv_forward: 1..%d channels per degree", kIrMaxC);
-    EQ_CHECK_ARG(c0_out + 3 * c1_out <= 128, EQUIGSPR_ENOTSUP, "irrep_conv_forward: c0_out + 3 c1_out must be <= 128 (two outputs per lane)");
-    IrrepConvArgs a{f0, f1, dist, radial, k00, k01, k10, k11, w_self0, w_self1, col, rptr, rperm, n_nodes, c0_in, c1_in, c0_out, c1_out, out0, out1};
-    hipLaunchKernelGGL(irrep_conv_kernel, dim3(ceil_div(n_nodes, kIrWaves)), dim3(64 * kIrWaves), 0, (hipStream_t)stream, a);
+    using namespace eq::ir;
+    EQ_CHECK_ARG(config_ok(cfg), EQUIGSPR_ENOTSUP, "irrep_conv_forward: 1..%d channels per degree, hidden 16 or 32", kMaxC);
+    EQ_CHECK_ARG(w_r1 && b_r1 && w_r2 && b_r2 && w_self0 && w_self1 && g && f0 && f1 && x && out0 && out1 && moments, EQUIGSPR_EINVAL,
+                 "irrep_conv_forward: null argument");
+    EQ_CHECK_ARG(g->n_nodes >= 1 && g->n_edges >= 0 && g->rptr && (g->n_edges == 0 || (g->col && g->rperm)), EQUIGSPR_EINVAL,
+                 "irrep_conv_forward: incomplete graph (col, rptr, rperm)");
+    const Layout L = layout_of(cfg);
+    const int64_t lc = 4 * pad0(L.c0i) + 10 * pad1(L.c1i);
+    conv_forward(cfg, L, w_r1, b_r1, w_r2, b_r2, w_self0, w_self1, g, f0, f1, x, out0, out1, moments,
+                 moments + (int64_t)g->n_nodes * lc * L.H, (hipStream_t)stream);
     EQ_CHECK_LAUNCH("irrep_conv_forward");
     return 0;
 }
 
-extern "C" int equigspr_irrep_moments_forward(const float* f0, const float* f1, const float* dist, const float* hid, const float* k00,
-                                              const float* k01, const float* k10, const float* k11, const int32_t* col, const int32_t* rptr,
-                                              const int32_t* rperm, int32_t n_nodes, int32_t n_edges, int32_t c0_in, int32_t c1_in,
-                                              int32_t hidden, float* moments, void* stream) {
+extern "C" int64_t equigspr_irrep_bwd_work_size(const equigspr_irrep_config* cfg, int32_t n_nodes, int32_t n_edges) {
+    using namespace eq::ir;
+    if (!config_ok(cfg) || n_nodes < 0 || n_edges < 0) return -1;
+    return plan_bwd(layout_of(cfg), n_nodes, n_edges).total;
+}
+
+extern "C" int equigspr_irrep_conv_backward(const equigspr_irrep_config* cfg, const float* w_r1, const float* b_r1, const float* w_r2,
+                                            const float* b_r2, const float* w_self0, const float* w_self1, const equigspr_graph* g,
+                                            const float* f0, const float* f1, const float* x, const float* moments, const float* g_out0,
+                                            const float* g_out1, float* d_f0, float* d_f1, float* d_x, float* d_w_r1, float* d_b_r1,
+                                            float* d_w_r2, float* d_b_r2, float* d_w_self0, float* d_w_self1, float* work, void* stream) {
     using namespace eq;
-    EQ_CHECK_ARG(f0 && f1 && dist && hid && k00 && k01 && k10 && k11 && col && rptr && rperm && moments, EQUIGSPR_EINVAL,
-                 "irrep_moments_forward: null argument");
-    EQ_CHECK_ARG(n_nodes >= 1 && n_edges >= 0, EQUIGSPR_EINVAL, "irrep_moments_forward: n_nodes >= 1, n_edges >= 0");
-    EQ_CHECK_ARG(c0_in >= 1 && c1_in >= 1 && c0_in <= kIrMaxC && c1_in <= kIrMaxC && hidden >= 1 && hidden <= kIrMaxH &&
-                     4 * c0_in + 10 * c1_in <= kIrMaxLc, EQUIGSPR_ENOTSUP,
-                 "irrep_moments_forward: 1..%d channels per degree with 4 c0_in + 10 c1_in <= %d, hidden <= %d", kIrMaxC, kIrMaxLc, kIrMaxH);
-    IrrepMomentsArgs a{f0, f1, dist, hid, k00, k01, k10, k11, col, rptr, rperm, n_nodes, c0_in, c1_in, hidden, moments};
-    const int nq = ceil_div(4 * c0_in + 10 * c1_in, 64);           // one wave per (node, 64-entry slice of the operand vector)
-    hipLaunchKernelGGL(irrep_moments_kernel, dim3(ceil_div((long long)n_nodes * nq, kIrWaves)), dim3(64 * kIrWaves), 0, (hipStream_t)stream, a);
-    EQ_CHECK_LAUNCH("irrep_moments_forward");
+    using namespace eq::ir;
+    EQ_CHECK_ARG(config_ok(cfg), EQUIGSPR_ENOTSUP, "irrep_conv_backward: 1..%d channels per degree, hidden 16 or 32", kMaxC);
+    EQ_CHECK_ARG(w_r1 && b_r1 && w_r2 && b_r2 && w_self0 && w_self1 && g && f0 && f1 && x && moments && g_out0 && g_out1 && d_w_r1 &&
+                     d_b_r1 && d_w_r2 && d_b_r2 && d_w_self0 && d_w_self1 && work, EQUIGSPR_EINVAL, "irrep_conv_backward: null argument");
+    EQ_CHECK_ARG((d_f0 == nullptr) == (d_f1 == nullptr), EQUIGSPR_EINVAL, "irrep_conv_backward: d_f0 and d_f1 are computed together (both or neither)");
+    EQ_CHECK_ARG(g->n_nodes >= 1 && g->n_edges >= 0 && g->rptr && g->cptr && (g->n_edges == 0 || (g->row && g->col && g->rperm && g->cperm)),
+                 EQUIGSPR_EINVAL, "irrep_conv_backward: incomplete graph (row, col and both inverse indices)");
+    conv_backward(cfg, layout_of(cfg), w_r1, b_r1, w_r2, b_r2, w_self0, w_self1, g, f0, f1, x, moments, g_out0, g_out1, d_f0, d_f1, d_x,
+                  d_w_r1, d_b_r1, d_w_r2, d_b_r2, d_w_self0, d_w_self1, work, (hipStream_t)stream);
+    EQ_CHECK_LAUNCH("irrep_conv_backward");
     return 0;
 }

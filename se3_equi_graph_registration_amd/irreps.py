@@ -1,21 +1,20 @@
 """Typed irrep-basis message passing ("irrep-basis message passing proper").
 
-The reference ships the equivariant weight basis (``tools/basis.py::get_basis`` :153-205, ``tools/irr_repr.py``,
-``tools/spherical_harmonics.py``; here ``sh.get_basis``) and no layer that uses it -- its scripts run the frame-vector EGNN.
+The reference ships the equivariant weight basis (``tools/basis.py::get_basis`` :153-205, ``tools/irr_repr.py:103-104``,
+``tools/spherical_harmonics.py:75-123``; here ``sh.get_basis``) and no layer that uses it -- its scripts run the frame-vector EGNN.
 ``IrrepConv`` is that layer for degrees 0 and 1: degree-0 features ``f0 [N, C0]`` and degree-1 features ``f1 [N, C1, 3]`` are BOTH
 carried through, every (d_in, d_out) path is a pairwise kernel ``sum_J R_J(|r_ij|) K_J(r_ij / |r_ij|)`` built from the basis tensors,
 messages are computed from the features at ``col`` and aggregated at ``row`` (the reference's conventions, train :252-256,:270-278),
-and a per-degree channel mixing acts as self-interaction.  The definition is written out in DESIGN.md section 2 and in the test
-infrastructure (parity unpinned by construction -- there is no reference layer -- pinned by SO(3) covariance).
+and a per-degree channel mixing acts as self-interaction.  The definition is written out in ``oracle/irreps_oracle.py`` (test
+infrastructure; parity unpinned by construction -- there is no reference layer -- pinned by SO(3) covariance).
 
-MI355X-first split of the work: the basis tensors come from the SH kernels of ``csrc/sh.hip``; because the radial profile is LINEAR in
-the hidden radial activations, the sum over a node's incoming edges is taken BEFORE the radial weights are applied -- one hand-written
-launch accumulates per-node moments of [basis x gathered features] (x) [hid, 1] in ascending edge order (``csrc/irreps.hip``), and the
-radial weights then act on the moments as dense GEMMs over NODES (the library, MFMA): nothing of size [E, n_w] is formed (566 MB at one
-2 048-point pair).  Channel counts beyond that kernel's register budget (4 c0_in + 10 c1_in > 256) take the direct form: the radial
-profile as one GEMM over all edges + a contraction / aggregation launch.  Forward in HIP; under grad the backward re-runs the
-layer in device ops (``ops.hip_forward_aten_backward``) -- gradients with respect to the features and the weights (the geometry,
-i.e. ``x`` and the basis, is treated as constant, like the HIP ``get_basis`` itself).
+One kernel path (``csrc/irreps.hip``, round 5), forward and backward, no library call and no basis tensor in HBM:
+  * the degree <= 1 basis in closed form inside the kernels (``sh.degree1_closed_form``: six constants fitted to ``get_basis``);
+  * aggregate-then-transform: the radial profile is LINEAR in the hidden radial activations, so per-node moments of
+    [basis x gathered features] (x) [hid, 1] are accumulated first (outer products on the matrix cores, ascending edge order) and the
+    radial weights act on them per NODE in a second launch that reads the weights in place;
+  * backward for every input: features (the adjoint convolution -- the same two kernels on the reversed edges with transposed
+    weights), coordinates ``x``, radial and self-interaction weights.
 
 Degree-1 components are in the basis' own real-SH order (m = -1, 0, 1, polar axis on input component 1): ``Y_1(x) = A x / |x|`` with
 ``A = sh1_matrix()``; in this convention ``A = -sqrt(3 / 4 pi) * I``, so a Cartesian vector ``v`` enters as ``A @ v`` and rotates
@@ -23,11 +22,13 @@ with the plain rotation matrix.  No CPU path.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 from torch import nn
 
 from . import _lib, sh
-from .ops import DeviceGraph, _need, _p, _stream, hip_forward_aten_backward
+from .ops import DeviceGraph, _need, _p, _stream
 
 
 def sh1_matrix(device="cuda", dtype=torch.float32) -> torch.Tensor:
@@ -37,156 +38,93 @@ def sh1_matrix(device="cuda", dtype=torch.float32) -> torch.Tensor:
     return y.T.contiguous().to(dtype)
 
 
+def _config(c0_in, c1_in, c0_out, c1_out, hidden) -> _lib.IrrepConfig:
+    return _lib.IrrepConfig(c0_in, c1_in, c0_out, c1_out, hidden, *sh.degree1_closed_form())
+
+
+class _IrrepConvFn(torch.autograd.Function):
+    """``equigspr_irrep_conv_forward`` / ``_backward``: gradients for f0, f1, x and all six parameter tensors from HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, f0, f1, x, w1, b1, w2, b2, ws0, ws1, cfg, graph, training):
+        L = _lib.lib()
+        n = x.shape[0]
+        dev = x.device
+        out0 = torch.empty(n, cfg.c0_out, dtype=torch.float32, device=dev)
+        out1 = torch.empty(n, cfg.c1_out, 3, dtype=torch.float32, device=dev)
+        moments = torch.empty(L.equigspr_irrep_moments_size(ctypes.byref(cfg), n), dtype=torch.float32, device=dev)
+        _lib.check(L.equigspr_irrep_conv_forward(ctypes.byref(cfg), _p(w1), _p(b1), _p(w2), _p(b2), _p(ws0), _p(ws1),
+                                                 ctypes.byref(graph.struct), _p(f0), _p(f1), _p(x), _p(out0), _p(out1), _p(moments),
+                                                 _stream()), "irrep_conv_forward")
+        if training:
+            ctx.save_for_backward(f0, f1, x, w1, b1, w2, b2, ws0, ws1, moments)
+            ctx.cfg, ctx.graph = cfg, graph
+        return out0, out1
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        f0, f1, x, w1, b1, w2, b2, ws0, ws1, moments = ctx.saved_tensors
+        cfg, graph = ctx.cfg, ctx.graph
+        L = _lib.lib()
+        n, dev = x.shape[0], x.device
+        g0 = torch.zeros(n, cfg.c0_out, dtype=torch.float32, device=dev) if g0 is None else g0.contiguous().float()
+        g1 = torch.zeros(n, cfg.c1_out, 3, dtype=torch.float32, device=dev) if g1 is None else g1.contiguous().float()
+        need_f = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        d_f0 = torch.empty_like(f0) if need_f else None
+        d_f1 = torch.empty_like(f1) if need_f else None
+        d_x = torch.zeros_like(x) if ctx.needs_input_grad[2] else None             # the kernel ACCUMULATES into d_x
+        dw1, db1, dw2, db2, dws0, dws1 = (torch.empty_like(t) for t in (w1, b1, w2, b2, ws0, ws1))
+        work = torch.empty(L.equigspr_irrep_bwd_work_size(ctypes.byref(cfg), n, graph.n_edges), dtype=torch.float32, device=dev)
+        _lib.check(L.equigspr_irrep_conv_backward(ctypes.byref(cfg), _p(w1), _p(b1), _p(w2), _p(b2), _p(ws0), _p(ws1),
+                                                  ctypes.byref(graph.struct), _p(f0), _p(f1), _p(x), _p(moments), _p(g0), _p(g1),
+                                                  _p(d_f0), _p(d_f1), _p(d_x), _p(dw1), _p(db1), _p(dw2), _p(db2), _p(dws0), _p(dws1),
+                                                  _p(work), _stream()), "irrep_conv_backward")
+        return d_f0, d_f1, d_x, dw1, db1, dw2, db2, dws0, dws1, None, None, None
+
+
 class IrrepConv(nn.Module):
     """``IrrepConv(c0_in, c1_in, c0_out, c1_out, hidden=32)``; ``forward(f0, f1, x, edges) -> (out0 [N, c0_out], out1 [N, c1_out, 3])``.
 
-    ``edges``: ``[row, col]`` (LongTensors / ``[2, E]``) or a ``DeviceGraph``.  1..32 channels per degree, ``c0_out + 3 c1_out <= 128``."""
+    ``edges``: ``[row, col]`` (LongTensors / ``[2, E]``) or a ``DeviceGraph``.  1..32 channels per degree; ``hidden`` (the width of
+    the radial MLP) 16 or 32.  Differentiable in f0, f1, x and every parameter (HIP backward)."""
 
     def __init__(self, c0_in, c1_in, c0_out, c1_out, hidden=32, device="cuda"):
         super().__init__()
         for c in (c0_in, c1_in, c0_out, c1_out):
             if not 1 <= c <= 32:
-                raise NotImplementedError("IrrepConv: 1..32 channels per degree (the HIP kernel's LDS layout)")
-        if c0_out + 3 * c1_out > 128:
-            raise NotImplementedError("IrrepConv: c0_out + 3 c1_out must be <= 128")
+                raise NotImplementedError("IrrepConv: 1..32 channels per degree")
+        if hidden not in (16, 32):
+            raise NotImplementedError("IrrepConv: the radial MLP's hidden width must be 16 or 32 (16-column MFMA blocks)")
         self.c0_in, self.c1_in, self.c0_out, self.c1_out, self.hidden = c0_in, c1_in, c0_out, c1_out, hidden
         self.n_w = c0_out * c0_in + c1_out * c0_in + c0_out * c1_in + c1_out * c1_in * 3
         self.radial = nn.Sequential(nn.Linear(1, hidden), nn.SiLU(), nn.Linear(hidden, self.n_w))
         self.self0 = nn.Linear(c0_in, c0_out, bias=False)
         self.self1 = nn.Linear(c1_in, c1_out, bias=False)
+        self.cfg = _config(c0_in, c1_in, c0_out, c1_out, hidden)
         self.to(device)
 
-    # ---- pieces shared by the HIP forward and its device-op twin
     @staticmethod
-    def _graph(edges, n_nodes):
+    def _graph(edges, n_nodes, need_col_index=True):
         if isinstance(edges, DeviceGraph):
             return edges
         row, col = edges[0], edges[1]
-        return DeviceGraph.from_edge_lists([torch.stack([row, col]).to(torch.int64)], n_nodes, need_col_index=False)
+        return DeviceGraph.from_edge_lists([torch.stack([row, col]).to(torch.int64)], n_nodes, need_col_index=need_col_index)
 
-    @staticmethod
-    def _geometry(x, graph):
-        """|r_ij| and the four degree <= 1 basis tensors of every edge (HIP: csrc/sh.hip); constants of the layer."""
-        row, col = graph.row[:graph.n_edges].long(), graph.col[:graph.n_edges].long()
-        r = (x[row] - x[col]).contiguous()
-        dist = r.norm(dim=-1).contiguous()
-        K = sh.get_basis(r, 1)
-        E = graph.n_edges
-        return dist, K["0,0"].reshape(E).contiguous(), K["0,1"].reshape(E, 3).contiguous(), K["1,0"].reshape(E, 3).contiguous(), \
-            K["1,1"].reshape(E, 27).contiguous()
-
-    def _radial(self, dist):
-        return self.radial(dist[:, None])                        # [E, n_w]: Linear(1, H) -> SiLU -> Linear(H, n_w): one library GEMM
-
-    def _hip(self, f0, f1, radial, ws0, ws1, dist, k00, k01, k10, k11, graph):
-        n = graph.n_nodes
-        out0 = torch.empty(n, self.c0_out, dtype=torch.float32, device=f0.device)
-        out1 = torch.empty(n, self.c1_out, 3, dtype=torch.float32, device=f0.device)
-        _lib.check(_lib.lib().equigspr_irrep_conv_forward(_p(f0), _p(f1), _p(dist), _p(radial.contiguous()), _p(k00), _p(k01), _p(k10), _p(k11),
-                                                          _p(ws0.contiguous()), _p(ws1.contiguous()), _p(graph.col), _p(graph.rptr),
-                                                          _p(graph.rperm), n, graph.n_edges, self.c0_in, self.c1_in, self.c0_out,
-                                                          self.c1_out, _p(out0), _p(out1), _stream()), "irrep_conv_forward")
-        return torch.cat([out0, out1.reshape(n, -1)], dim=1)        # one tensor for the autograd wrapper
-
-    # ---- aggregate-then-transform (the fast path): the radial profile is linear in the hidden radial activations, so the sum over a
-    # node's incoming edges is taken first (one HIP launch: per-node moments of [basis x gathered features] (x) [hid, 1]) and the radial
-    # weights are applied to the moments by dense GEMMs over NODES -- nothing of size [E, n_w] exists
-    def _fast_ok(self):
-        return self.hidden <= 32 and 4 * self.c0_in + 10 * self.c1_in <= 256
-
-    def _hip_fast(self, f0, f1, ws0, ws1, dist, k00, k01, k10, k11, graph):
-        n, H, HA = graph.n_nodes, self.hidden, self.hidden + 1
-        c0o, c0i, c1o, c1i = self.c0_out, self.c0_in, self.c1_out, self.c1_in
-        lin1, lin2 = self.radial[0], self.radial[2]
-        hid = torch.zeros(graph.n_edges, 32, dtype=torch.float32, device=f0.device)                    # [E, 32]: H columns, zero padded
-        hid[:, :H] = torch.nn.functional.silu(torch.addmm(lin1.bias.detach(), dist[:, None], lin1.weight.detach().t()))
-        Lc = 4 * c0i + 10 * c1i
-        M = torch.empty(n * Lc * HA, dtype=torch.float32, device=f0.device)                           # S00 | S10 | S01 | S11 (include/equigspr.h)
-        _lib.check(_lib.lib().equigspr_irrep_moments_forward(_p(f0), _p(f1), _p(dist), _p(hid), _p(k00), _p(k01), _p(k10), _p(k11), _p(graph.col),
-                                                             _p(graph.rptr), _p(graph.rperm), n, graph.n_edges, c0i, c1i, H, _p(M), _stream()),
-                   "irrep_moments_forward")
-        W00, W01, W10, W11 = self._path_weights()
-        e10, e01, e11 = n * c0i * HA, n * (c0i + c1i) * HA, n * (c0i + c1i + 3 * c0i) * HA               # section starts: views, no copies
-        out0 = torch.addmm(f0 @ ws0.t(), M[:e10].view(n, c0i * HA), W00.t())
-        out0 = torch.addmm(out0, M[e10:e01].view(n, c1i * HA), W10.t())
-        m01 = M[e01:e11].view(n * 3, c0i * HA)                                                         # rows (n, a)
-        m11 = M[e11:].view(n * 3, 3 * c1i * HA)
-        o1 = torch.addmm(m01 @ W01.t(), m11, W11.t()).view(n, 3, c1o).permute(0, 2, 1)                 # [n, o, a]
-        out1 = o1 + torch.einsum("oi,nia->noa", ws1, f1)
-        return torch.cat([out0, out1.reshape(n, -1)], dim=1)
-
-    def _path_weights(self):
-        """The second radial Linear as the four GEMM operands of the fast path ([out, in * (H + 1)], transposed at use), rebuilt only when
-        its weight or bias was written since (tensor version counters): four small launches per call otherwise."""
-        lin2 = self.radial[2]
-        key = (lin2.weight._version, lin2.bias._version, lin2.weight.data_ptr(), lin2.bias.data_ptr())
-        hit = getattr(self, "_pw_cache", None)
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        c0o, c0i, c1o, c1i, HA = self.c0_out, self.c0_in, self.c1_out, self.c1_in, self.hidden + 1
-        W = torch.cat([lin2.weight.detach(), lin2.bias.detach()[:, None]], dim=1)                    # [n_w, H + 1]: the bias rides on hid~'s constant 1
-        o = 0
-        W00 = W[o:o + c0o * c0i].reshape(c0o, c0i * HA); o += c0o * c0i
-        W01 = W[o:o + c1o * c0i].reshape(c1o, c0i * HA); o += c1o * c0i
-        W10 = W[o:o + c0o * c1i].reshape(c0o, c1i * HA); o += c0o * c1i
-        W11 = W[o:o + c1o * c1i * 3].reshape(c1o, c1i, 3, HA).permute(0, 2, 1, 3).reshape(c1o, 3 * c1i * HA)      # (J, i, h): the moments' order
-        out = (W00.contiguous(), W01.contiguous(), W10.contiguous(), W11.contiguous())
-        self._pw_cache = (key, out)
-        return out
-
-    def _hip_train(self, f0, f1, radial, ws0, ws1, *rest):
-        """Forward of the autograd wrapper: ``radial`` (= ``self._radial(dist)``, needed as a differentiable INPUT of the device-op
-        backward) is not read -- the fast path applies the same weights to the per-node moments."""
-        return self._hip_fast(f0, f1, ws0, ws1, *rest) if self._fast_ok() else self._hip(f0, f1, radial, ws0, ws1, *rest)
-
-    def _aten(self, f0, f1, radial, ws0, ws1, dist, k00, k01, k10, k11, graph):
-        """The same layer in device ops (backward recompute only; the layer definition line by line)."""
-        row, col = graph.row[:graph.n_edges].long(), graph.col[:graph.n_edges].long()
-        c0o, c0i, c1o, c1i = self.c0_out, self.c0_in, self.c1_out, self.c1_in
-        o = 0
-        R00 = radial[:, o:o + c0o * c0i].view(-1, c0o, c0i); o += c0o * c0i
-        R01 = radial[:, o:o + c1o * c0i].view(-1, c1o, c0i); o += c1o * c0i
-        R10 = radial[:, o:o + c0o * c1i].view(-1, c0o, c1i); o += c0o * c1i
-        R11 = radial[:, o:o + c1o * c1i * 3].view(-1, c1o, c1i, 3)
-        live = (dist > 0).to(f0.dtype)[:, None]
-        k01, k10 = k01 * live, k10 * live
-        k11 = k11.view(-1, 3, 3, 3)
-        k11 = torch.cat([k11[..., :1], k11[..., 1:] * live[:, :, None, None]], dim=-1)
-        g0, g1 = f0[col], f1[col]
-        s1 = torch.einsum("eb,eib->ei", k10, g1)
-        m0 = torch.einsum("eoi,ei->eo", R00, g0) * k00[:, None] + torch.einsum("eoi,ei->eo", R10, s1)
-        t1 = torch.einsum("eabj,eib->eiaj", k11, g1)
-        m1 = torch.einsum("eoi,ei,ea->eoa", R01, g0, k01) + torch.einsum("eoij,eiaj->eoa", R11, t1)
-        out0 = (f0 @ ws0.T).index_add(0, row, m0)
-        out1 = torch.einsum("oi,nia->noa", ws1, f1).index_add(0, row, m1)
-        return torch.cat([out0, out1.reshape(out1.shape[0], -1)], dim=1)
-
-    def forward(self, f0, f1, x, edges, geometry=None):
-        """``geometry``: the tuple ``_geometry(x, graph)`` returned for the SAME ``x`` and graph (a stack of layers on fixed coordinates
-        computes it once: five launches, ~0.1 ms per pair)."""
+    def forward(self, f0, f1, x, edges):
         f0 = _need(f0.contiguous().float(), "f0", torch.float32, 2)
         f1 = _need(f1.contiguous().float(), "f1", torch.float32, 3)
         x = _need(x.contiguous().float(), "x", torch.float32, 2)
         n = x.shape[0]
         if f0.shape != (n, self.c0_in) or f1.shape != (n, self.c1_in, 3) or x.shape[1] != 3:
             raise RuntimeError(f"IrrepConv: need f0 [N, {self.c0_in}], f1 [N, {self.c1_in}, 3], x [N, 3]")
-        graph = self._graph(edges, n)
-        if geometry is None:
-            with torch.no_grad():
-                geometry = self._geometry(x.detach(), graph)
-        dist, k00, k01, k10, k11 = geometry
-        ws0, ws1 = self.self0.weight, self.self1.weight
-        rest = (dist, k00, k01, k10, k11, graph)
-        training = torch.is_grad_enabled() and (f0.requires_grad or f1.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if training:
-            radial = self._radial(dist)                          # differentiable (ATen): the radial weights get their gradients through it
-            out = hip_forward_aten_backward(self._hip_train, self._aten, (f0, f1, radial, ws0, ws1), rest)
-        elif self._fast_ok():
-            out = self._hip_fast(f0, f1, ws0.detach(), ws1.detach(), *rest)
-        else:
-            with torch.no_grad():
-                out = self._hip(f0, f1, self._radial(dist), ws0.detach(), ws1.detach(), *rest)
-        return out[:, :self.c0_out], out[:, self.c0_out:].reshape(n, self.c1_out, 3)
+        lin1, lin2 = self.radial[0], self.radial[2]
+        params = (lin1.weight, lin1.bias, lin2.weight, lin2.bias, self.self0.weight, self.self1.weight)
+        training = torch.is_grad_enabled() and (f0.requires_grad or f1.requires_grad or x.requires_grad or
+                                                any(p.requires_grad for p in params))
+        graph = self._graph(edges, n, need_col_index=training)
+        if training and graph.cptr is None:
+            raise RuntimeError("IrrepConv.forward: the backward needs a DeviceGraph built with need_col_index=True")
+        return _IrrepConvFn.apply(f0, f1, x, *params, self.cfg, graph, training)
 
 
 class IrrepGNN(nn.Module):
@@ -207,10 +145,8 @@ class IrrepGNN(nn.Module):
             v = torch.zeros(n, self.c1, 3, dtype=torch.float32, device=x.device)
         graph = IrrepConv._graph(edges, n)
         xc = _need(x.contiguous().float(), "x", torch.float32, 2)
-        with torch.no_grad():
-            geometry = IrrepConv._geometry(xc.detach(), graph)        # the coordinates do not change through the stack: one basis for all layers
         for i, layer in enumerate(self.layers):
-            h, v = layer(h, v, xc, graph, geometry)
+            h, v = layer(h, v, xc, graph)
             if i + 1 < len(self.layers):
                 v = v * torch.sigmoid(self.gates[i](h))[:, :, None]       # invariant gate: keeps degree 1 covariant
                 h = torch.nn.functional.silu(h)

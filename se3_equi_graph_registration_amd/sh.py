@@ -305,6 +305,50 @@ def _q_table(d_in, d_out, device):
     return torch.from_numpy(tab).to(device)
 
 
+def _host_basis_degree1(pts):
+    """The degree <= 1 basis tensors of ``get_basis`` at host points, fp64 numpy (``_host_sh`` + ``_q_np``: the same constants the HIP
+    basis kernel multiplies with): K00 [n], K01 [n, 3 (out)], K10 [n, 3 (in)], K11 [n, 3 (out), 3 (in), 3 (J)]."""
+    pts = np.asarray(pts, dtype=np.float64)
+    # tools/basis.py:76: the polar axis is input component 1 -- (x, y, z) -> (z, x, y) is what get_spherical_from_cartesian hands the SH code
+    perm = pts[:, [2, 0, 1]]
+    y = {l: _host_sh(l, perm) for l in range(3)}
+    k = {}
+    for d_in, d_out in product(range(2), range(2)):
+        ks = [y[J] @ _q_np(J, d_in, d_out).T for J in range(abs(d_in - d_out), d_in + d_out + 1)]
+        k[(d_in, d_out)] = np.stack(ks, axis=-1).reshape(len(pts), 2 * d_out + 1, 2 * d_in + 1, -1)
+    return k[(0, 0)].reshape(-1), k[(0, 1)].reshape(-1, 3), k[(1, 0)].reshape(-1, 3), k[(1, 1)]
+
+
+@lru_cache(maxsize=None)
+def degree1_closed_form():
+    """The six constants of the degree <= 1 basis in closed form (what ``csrc/irreps.hip`` evaluates in registers instead of
+    reading ``get_basis`` tensors).  With u = r / |r| (tools/basis.py:153-205 restricted to max_degree = 1):
+
+        K['0,0'] = k00                       K['0,1'][a] = k01 u_a                   K['1,0'][b] = k10 u_b
+        K['1,1'][a, b, J=0] = k11_0 delta_ab     [.., J=1] = k11_1 eps_abc u_c     [.., J=2] = k11_2 (u_a u_b - delta_ab / 3)
+
+    (Schur: the unique rotation-covariant tensors of each type; degree-1 components are Cartesian up to the factor of ``Y_1``.)  The
+    constants -- signs included: ``Q_J`` is only defined up to sign -- are FITTED to the basis the package itself builds (host fp64:
+    ``_host_sh`` and ``_q_np``) at a set of directions, and the fit must be exact to 1e-12, so the closed form can never drift from
+    ``get_basis``.  Returns ``(k00, k01, k10, k11_0, k11_1, k11_2)`` as Python floats."""
+    pts = np.random.default_rng(11).standard_normal((24, 3))
+    u = pts / np.linalg.norm(pts, axis=1, keepdims=True)
+    k00, k01, k10, k11 = _host_basis_degree1(pts)
+    eps = np.zeros((3, 3, 3))
+    eps[0, 1, 2] = eps[1, 2, 0] = eps[2, 0, 1] = 1.0
+    eps[0, 2, 1] = eps[2, 1, 0] = eps[1, 0, 2] = -1.0
+    eye = np.eye(3)
+    forms = [(k00, np.ones(len(u))), (k01, u), (k10, u), (k11[..., 0], np.broadcast_to(eye, (len(u), 3, 3))),
+             (k11[..., 1], np.einsum("abc,nc->nab", eps, u)), (k11[..., 2], np.einsum("na,nb->nab", u, u) - eye / 3.0)]
+    out = []
+    for got, form in forms:
+        c = float((got * form).sum() / (form * form).sum())
+        if np.abs(got - c * form).max() > 1e-12:
+            raise RuntimeError("degree1_closed_form: the degree <= 1 basis does not have the expected closed form")
+        out.append(c)
+    return tuple(out)
+
+
 def get_basis(r_ij, max_degree, differentiable=False):
     """Equivariant weight basis ``{'d_in,d_out': [*batch, 1, 2 d_out+1, 1, 2 d_in+1, 2 min(d_in,d_out)+1]}`` from Cartesian
     relative positions (tools/basis.py:153-205).  The HIP op is forward-only, so ``differentiable=True`` is rejected."""

@@ -172,6 +172,9 @@ def _check_head_waits(owner):
                            "device problem, not a non-finite loss of the model")
 
 
+_EMPTY_SHARD = object()        # GraphedStep.run: "this rank's share of the step batch holds no pair"
+
+
 class _Slot:
     """One set of static step inputs in HBM: a single fp32 packet ``[xyz (2,B,N,3) | feat (2,B,N,F) | labels (B,N) | gt_pose (B,16) |
     signal (4)]`` (one H2D copy per step) and the views the model reads.  ``signal[0]`` is 0, or NaN when this rank has nothing
@@ -248,6 +251,8 @@ class GraphedStep:
         # group -- how the tests exercise it on a single GPU
         self.dist_on = self.world > 1 or (bool(force_dist) and dist.is_available() and dist.is_initialized())
         self.shape = None                  # (B_local, N, F) of the captured step
+        self._n_global = None              # ... and the global batch size its loss weight was computed for
+        self._voted = False                # data parallel: a first batch has been accepted by all ranks
         self._capture_tried = False
         self._last_idx = 0
         self.slots, self.graphs, self.graph_mode = [], None, "eager"
@@ -263,7 +268,7 @@ class GraphedStep:
         process group.  (Weights, optimizer state and hyper-parameters are read at replay time: loading a checkpoint or stepping a
         scheduler needs no reset.)"""
         self.shape, self.slots, self.graphs, self.graph_mode = None, [], None, "eager"
-        self._capture_tried, self._last_idx = False, 0
+        self._capture_tried, self._last_idx, self._n_global, self._voted = False, 0, None, False
 
     # ------------------------------------------------------------------ the step itself (eager or under capture)
     def _spare_words(self):
@@ -301,8 +306,10 @@ class GraphedStep:
 
     # ------------------------------------------------------------------ capture
     def _prepare(self, B, N, F, n_global):
-        self.shape = (B, N, F)
+        self.shape, self._n_global = (B, N, F), n_global
         self.slots = [_Slot(B, N, F, self.device) for _ in range(self.n_slots)]
+        # the slots' zero-fill runs on this object's stream, their first H2D on the copy stream: order the two once, here
+        torch.cuda.current_stream(self.device).synchronize()
         w = B * self.world / n_global if self.world > 1 else 1.0
         self._seed = torch.full((), float(w), dtype=torch.float32, device=self.device)
         self._loss_weight = B / n_global if self.world > 1 else 1.0
@@ -438,7 +445,14 @@ class GraphedStep:
                     else:                                      # the loader yields per-rank batches: equal shares assumed
                         n_global = int(batch[2].shape[0]) * self.world
                     shape = (int(batch[2].shape[0]), int(batch[2].shape[1]), int(batch[4].shape[-1]))
-                    if (not batch[2].is_cuda) and shape[0] > 0 and self._usable_shape(batch) and (self.shape is None or shape == self.shape):
+                    if shape[0] == 0:
+                        # fewer pairs than ranks in a short last batch: this rank's shard is empty.  Alone (no peers) the batch is
+                        # skipped like a None batch; under data parallel the rank contributes zero gradients and still joins the
+                        # step's collective (_eager_empty) -- its peers are already on their way into the all-reduce
+                        if not put((batch_idx, _EMPTY_SHARD if self.dist_on else None, n_global)):
+                            return
+                        continue
+                    if (not batch[2].is_cuda) and self._usable_shape(batch) and (self.shape is None or shape == self.shape):
                         pk = take_pinned(shape)
                         if pk is None:
                             return
@@ -474,10 +488,21 @@ class GraphedStep:
             prog = adam.progress
             spins = 0
             t0 = time.perf_counter()
+            check_at = t0 + 2.0
             while prog[0] < n:
                 spins += 1
                 if spins > 2000:
                     time.sleep(2e-5)
+                    if time.perf_counter() > check_at:
+                        # a step that never reaches its optimizer launch (an aborted graph node, an asynchronous device error) would
+                        # leave this loop spinning for ever: query() raises a pending device error; a drained stream with the count
+                        # still short means the launch is lost
+                        if self.stream.query() and prog[0] < n:
+                            time.sleep(1e-3)               # the pinned word is written by the kernel's last workgroup: let it land
+                            if prog[0] < n:
+                                raise RuntimeError(f"GraphedStep: guarded optimizer call {n} of this run never reported completion "
+                                                   f"(progress {int(prog[0])}, stream idle): a step's launches were lost")
+                        check_at = time.perf_counter() + 2.0
             if tm is not None:
                 note("wait_calls", time.perf_counter() - t0)
 
@@ -530,13 +555,27 @@ class GraphedStep:
                         break
                     batch_idx, payload, n_global = item
                     have = payload is not None
-                    if self.dist_on and self.shape is None:
-                        # before the first step nothing is captured yet: the ranks agree by a collective whether the batch is usable
+                    if self.dist_on and not self._voted:
+                        # until a first batch has been accepted nothing is captured: the ranks agree by a collective whether the
+                        # batch is usable (a rank whose shard of it is empty HOLDS it)
                         have = _all_ranks_have(have, self.group, dev)
-                        if not have and isinstance(payload, _Slot):
-                            pinned_free.put((payload, None))
+                        self._voted = have
+                        if not have:
+                            if isinstance(payload, _Slot):
+                                pinned_free.put((payload, None))
+                            continue
+                    if payload is _EMPTY_SHARD or (not have and self.dist_on and self.shape is None):
+                        # no pair for this rank (void = no readable batch at all, and no captured step to replay with the void
+                        # signal): zero gradients, the step's ONE collective, the same decision as its peers
+                        launch_staged()
+                        self.opt._push_hyperparameters()
+                        self._eager_empty(void=payload is not _EMPTY_SHARD)
+                        self._calls += 1
+                        self._call_batch.append(batch_idx)
+                        log_point(batch_idx)
+                        continue
                     if not have:
-                        if self.dist_on and self.shape is not None:
+                        if self.dist_on:
                             # this rank has no batch, its peers may: run the step on the data of the previous one with the "void"
                             # signal raised -- every rank's guard then rejects the step (ONE collective per step, no host sync)
                             launch_staged()
@@ -551,7 +590,9 @@ class GraphedStep:
                     self.opt._push_hyperparameters()
                     packed = isinstance(payload, _Slot)
                     shape = (tuple(payload.xyz.shape[1:3]) + (payload.feat.shape[3],)) if packed else None
-                    if packed and (self.shape is None or self.shape == shape):
+                    # the captured graphs have the loss weight of THEIR global batch size baked in (``_seed``): a batch whose local
+                    # shape matches but whose global size differs (an uneven last batch) runs eagerly with its own weight
+                    if packed and (self.shape is None or (self.shape == shape and n_global == self._n_global)):
                         if self.shape is None:
                             self._prepare(*shape, n_global)
                         adam.push_hyper(self._loss_weight)
@@ -618,6 +659,22 @@ class GraphedStep:
         loss = self._forward_backward(sl, seed)
         if self.dist_on:
             self.opt.dp.sync(force=True)
+        self._apply(loss)
+        self.steps_eager += 1
+
+    def _eager_empty(self, void=False):
+        """This rank's shard of the step batch is empty (a short last batch with fewer pairs than ranks; ``DataLoader``'s default
+        ``drop_last=False``): it contributes zero gradients -- the buckets are clear, every step clears them as it consumes them --
+        and loss 0 with weight 0, joins the step's ONE collective and applies the same averaged update as its peers (the contract
+        of ``run_training_batches``).  Its peers run this batch eagerly or by replay; either way one all-reduce per rank."""
+        self.opt.adam.push_hyper(0.0)
+        if self._pad is None:
+            self._pad = self._spare_words()
+        self._pad[:2].zero_()
+        if void:                           # "this rank could not read the batch": every rank's guard rejects the step
+            self._pad[1].fill_(float("nan"))
+        loss = torch.zeros((), dtype=torch.float32, device=self.device)
+        self.opt.dp.sync(force=True)
         self._apply(loss)
         self.steps_eager += 1
 
@@ -779,6 +836,7 @@ class GraphedEval:
                             self.slots = [_Slot(*self.shape, dev) for _ in range(self.n_slots)]
                             for sl in self.slots:
                                 sl.done = torch.cuda.Event()
+                            self.stream.synchronize()          # zero-fill (this stream) before the first H2D (copy stream)
                         idx = ((staged[0] if staged is not None else last_idx) + 1) % self.n_slots
                         if staged is not None and staged[0] == idx:
                             launch_staged()

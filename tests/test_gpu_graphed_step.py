@@ -226,11 +226,16 @@ def batches(count, B):
     return out
 
 seq = batches(6, 4)                                   # global step batches of 4 pairs: 2 per rank
-bad = list(seq[2]); bad[6] = bad[6].clone(); bad[6][3, :3, :3] = float("nan")      # a non-finite pair in rank 1's shard only
-seq[2] = tuple(bad)
-lost = list(seq)
-if rank == 1:
-    lost[4] = None                                    # a batch only rank 1 cannot read
+if sys.argv[2] == "tails":
+    # short last batches (DataLoader's drop_last=False): 3 pairs -> shards of 2 and 1 (rank 0's LOCAL shape equals the captured one, its
+    # loss weight does not: 2 * 2 / 3 instead of 1), then 1 pair -> rank 1's shard is EMPTY (zero gradients, still in the collective)
+    lost = seq[:4] + [tuple(t[:3] for t in seq[4]), tuple(t[:1] for t in seq[5])]
+else:
+    bad = list(seq[2]); bad[6] = bad[6].clone(); bad[6][3, :3, :3] = float("nan")      # a non-finite pair in rank 1's shard only
+    seq[2] = tuple(bad)
+    lost = list(seq)
+    if rank == 1:
+        lost[4] = None                                    # a batch only rank 1 cannot read
 res = {}
 for name, graph in (("eager", False), ("graphed", True)):
     m = model(1); o = train.make_optimizer(m, lr=1e-3)
@@ -253,14 +258,11 @@ print("RESULT " + json.dumps(out))
 """
 
 
-def test_two_ranks_share_one_gpu_over_gloo(pk):
-    """TWO real ranks (both on this GPU, gloo moving the device buckets through the host -- RCCL refuses two ranks on one device): the
-    sharded graphed loop against the sharded eager loop, with a non-finite pair in one rank's shard (both ranks must reject that step)
-    and a batch only one rank cannot read (the eager loop agrees by a collective to skip it, the graphed loop turns it into a void
-    step through the spare words of the gradient bucket).  Same weights on both ranks and in both loops, no deadlock."""
+def _two_ranks(scenario, port):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    code = CHILD2 % {"root": ROOT, "port": "29647"}
-    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(2)]
+    code = CHILD2 % {"root": ROOT, "port": port}
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), scenario], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(2)]
     outs = []
     for p in procs:
         try:
@@ -275,6 +277,30 @@ def test_two_ranks_share_one_gpu_over_gloo(pk):
         outs.append(json.loads(line[-1][len("RESULT "):]))
     if "skip" in outs[0]:
         pytest.skip(outs[0]["skip"])
+    return outs
+
+
+def test_two_ranks_short_last_batches_uneven_and_empty_shards(pk):
+    """ADVICE round 4 (high + medium): a tail batch of 3 pairs on 2 ranks (shards 2 | 1: rank 0's local shape equals the captured step's,
+    but the loss weight of the captured graphs belongs to a global batch of 4) and a tail batch of ONE pair (rank 1's shard is empty: it
+    must contribute zero gradients and still join the all-reduce -- its peer is already inside it).  The graphed loop must finish (no
+    deadlock) with the eager sharded loop's weights, bit for bit, on both ranks."""
+    outs = _two_ranks("tails", "29653")
+    for r in outs:
+        assert r["ranks_equal"], r
+        assert r["graphed_equals_eager"], r
+        assert r["steps"] == [6.0, 6.0], r
+        assert r["stats"]["applied"] == 6 and r["stats"]["skipped"] == 0 and r["stats"]["void"] == 0, r
+        assert r["replayed"] == 3, r                             # batches 2-4; the first and the two tails run eagerly
+    assert outs[0]["loss"][0] == pytest.approx(outs[0]["loss"][1], rel=1e-5) and outs[0]["loss"] == outs[1]["loss"]
+
+
+def test_two_ranks_share_one_gpu_over_gloo(pk):
+    """TWO real ranks (both on this GPU, gloo moving the device buckets through the host -- RCCL refuses two ranks on one device): the
+    sharded graphed loop against the sharded eager loop, with a non-finite pair in one rank's shard (both ranks must reject that step)
+    and a batch only one rank cannot read (the eager loop agrees by a collective to skip it, the graphed loop turns it into a void
+    step through the spare words of the gradient bucket).  Same weights on both ranks and in both loops, no deadlock."""
+    outs = _two_ranks("lost", "29647")
     for r in outs:
         assert r["ranks_equal"], r
         assert r["graphed_equals_eager"], r

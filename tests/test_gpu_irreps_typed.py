@@ -1,6 +1,7 @@
 """The typed irrep-basis layer on the GPU (csrc/irreps.hip behind irreps.IrrepConv): HIP forward against
-the fp64 definition (oracle/irreps_oracle.py), gradients of the device-op backward against the oracle's autograd, SO(3) covariance
-of the layer and of a small stack at full size on kNN graphs with self loops."""
+the fp64 definition (oracle/irreps_oracle.py), the HIP backward against the definition's fp64 autograd for EVERY input (features,
+coordinates, radial and self-interaction weights), SO(3) covariance of outputs and gradients of the layer and of a small stack at full
+size on kNN graphs with self loops."""
 import numpy as np
 import pytest
 import torch
@@ -50,26 +51,77 @@ def test_forward_matches_the_definition(pk, dims):
     assert torch.equal(o0, p0) and torch.equal(o1, p1)
 
 
-def test_backward_matches_the_definitions_autograd(pk):
-    dims, n, e = (6, 4, 5, 7), 120, 1500
+@pytest.mark.parametrize("dims,hidden", [((6, 4, 5, 7), 16), ((32, 8, 32, 8), 32), ((16, 16, 8, 12), 32), ((3, 20, 20, 3), 16), ((1, 1, 1, 1), 32)])
+def test_backward_matches_the_definitions_autograd(pk, dims, hidden):
+    """HIP backward (adjoint convolution, geometry kernel, weight-gradient GEMMs) against the fp64 autograd of the definition for EVERY
+    input: f0, f1, the coordinates x, radial.0 / radial.2 weights and biases, both self-interaction matrices.  Graph with a hub
+    (> 64 incoming edges), isolated nodes and self loops (r = 0: only the J = 0 kernels act, no gradient through the direction)."""
+    n, e = 120, 1500
     g, row, col = _graph(4, n, e)
-    torch.manual_seed(9)
-    layer = pk.IrrepConv(*dims, hidden=16)
+    torch.manual_seed(9 + sum(dims))
+    layer = pk.IrrepConv(*dims, hidden=hidden)
     x = torch.randn(n, 3, generator=g)
     f0 = torch.randn(n, dims[0], generator=g); f1 = torch.randn(n, dims[1], 3, generator=g)
     g0 = torch.randn(n, dims[2], generator=g); g1 = torch.randn(n, dims[3], 3, generator=g)
-    a0, a1 = f0.cuda().requires_grad_(True), f1.cuda().requires_grad_(True)
-    o0, o1 = layer(a0, a1, x.cuda(), [row.cuda(), col.cuda()])
+    a0, a1, ax = f0.cuda().requires_grad_(True), f1.cuda().requires_grad_(True), x.cuda().requires_grad_(True)
+    o0, o1 = layer(a0, a1, ax, [row.cuda(), col.cuda()])
     layer.zero_grad()
     ((o0 * g0.cuda()).sum() + (o1 * g1.cuda()).sum()).backward()
     w = {k: v.clone().requires_grad_(True) for k, v in _weights(layer).items()}
-    b0, b1 = f0.double().requires_grad_(True), f1.double().requires_grad_(True)
-    r0, r1 = io.irrep_conv(w, b0, b1, x.double(), [row, col])
+    b0, b1, bx = f0.double().requires_grad_(True), f1.double().requires_grad_(True), x.double().requires_grad_(True)
+    r0, r1 = io.irrep_conv(w, b0, b1, bx, [row, col])
     ((r0 * g0.double()).sum() + (r1 * g1.double()).sum()).backward()
-    for name, got, want in [("f0", a0.grad, b0.grad), ("f1", a1.grad, b1.grad)] + [(k, p.grad, w[k].grad) for k, p in layer.named_parameters()]:
+    assert torch.isfinite(bx.grad).all()
+    for name, got, want in [("f0", a0.grad, b0.grad), ("f1", a1.grad, b1.grad), ("x", ax.grad, bx.grad)] + \
+            [(k, p.grad, w[k].grad) for k, p in layer.named_parameters()]:
+        assert got is not None, name
         want = want.reshape(got.shape)
         tol = 5e-5 * max(1.0, float(want.abs().max()))
-        assert float((got.cpu().double() - want).abs().max()) <= tol, name
+        assert float((got.cpu().double() - want).abs().max()) <= tol, (name, float((got.cpu().double() - want).abs().max()), tol)
+    # bitwise reproducible (no atomics; slabs summed in fixed order)
+    first = [p.grad.clone() for p in layer.parameters()] + [a0.grad.clone(), a1.grad.clone(), ax.grad.clone()]
+    for t in (a0, a1, ax):
+        t.grad = None
+    layer.zero_grad()
+    o0, o1 = layer(a0, a1, ax, [row.cuda(), col.cuda()])
+    ((o0 * g0.cuda()).sum() + (o1 * g1.cuda()).sum()).backward()
+    second = [p.grad for p in layer.parameters()] + [a0.grad, a1.grad, ax.grad]
+    assert all(torch.equal(u, v) for u, v in zip(first, second))
+
+
+def test_gradients_are_so3_covariant_fullsize(pk):
+    """2 x 2048 points, k = 20 (self loops included): for a rotation-invariant loss of the outputs the gradient with respect to the
+    coordinates rotates with the cloud, the degree-1 feature gradient with D^1, the weight gradients are invariant."""
+    b = pk.synthetic_batch(33, 1, n=2048, device="cuda")
+    graph = pk.build_pair_graph(b["src"], b["tgt"], 20)
+    x = torch.cat([b["src"][0], b["tgt"][0]]).contiguous()
+    n = x.shape[0]
+    g = torch.Generator().manual_seed(5)
+    f0 = torch.randn(n, 32, generator=g).cuda()
+    v = torch.randn(n, 8, 3, generator=g).cuda()
+    t0 = torch.randn(n, 32, generator=g).cuda()
+    rm = torch.from_numpy(so._rot(1.1, 0.6, 2.9)).float().cuda()
+    torch.manual_seed(1)
+    layer = pk.IrrepConv(32, 8, 32, 8)
+
+    def grads(xx, vv):
+        xx, vv, ff = xx.clone().requires_grad_(True), vv.clone().requires_grad_(True), f0.clone().requires_grad_(True)
+        layer.zero_grad()
+        o0, o1 = layer(ff, vv, xx, graph)
+        ((o0 * t0).sum() + (o1 * o1).sum()).backward()          # invariant: a fixed scalar target on degree 0, the squared norm on degree 1
+        return xx.grad, vv.grad, ff.grad, [p.grad.clone() for p in layer.parameters()]
+
+    gx, gv, gf, gw = grads(x, v)
+    # degree-1 features are Cartesian vectors up to the factor of Y_1 (A = c I): they rotate with the plain rotation matrix
+    rx, rv, rf, rw = grads((x @ rm.T).contiguous(), torch.einsum("ab,nib->nia", rm, v).contiguous())
+    sx, sv = float(gx.abs().max()), float(gv.abs().max())
+    assert sx > 1e-3 and sv > 1e-3
+    # fp32 run against fp32 run: two independently rounded evaluations (the 1 / d terms of close pairs dominate the coordinate gradient)
+    assert float((rx - gx @ rm.T).abs().max()) <= 5e-4 * max(1.0, sx)
+    assert float((rv - torch.einsum("ab,nib->nia", rm, gv)).abs().max()) <= 5e-4 * max(1.0, sv)
+    assert float((rf - gf).abs().max()) <= 5e-4 * max(1.0, float(gf.abs().max()))
+    for u, w_ in zip(gw, rw):
+        assert float((u - w_).abs().max()) <= 5e-4 * max(1.0, float(u.abs().max()))
 
 
 def test_layer_and_stack_are_so3_covariant_on_knn_graphs(pk):
@@ -111,6 +163,8 @@ def test_unsupported_shapes_and_cpu_tensors_fail_loudly(pk):
         pk.IrrepConv(33, 8, 8, 8)
     with pytest.raises(NotImplementedError):
         pk.IrrepConv(8, 8, 32, 32 + 1)
+    with pytest.raises(NotImplementedError):
+        pk.IrrepConv(8, 8, 8, 8, hidden=24)
     layer = pk.IrrepConv(4, 4, 4, 4)
     with pytest.raises(RuntimeError):
         layer(torch.zeros(5, 4), torch.zeros(5, 4, 3), torch.zeros(5, 3), [torch.zeros(3, dtype=torch.long), torch.zeros(3, dtype=torch.long)])
