@@ -351,6 +351,33 @@ int equigspr_irrep_conv_backward(const equigspr_irrep_config* cfg, const float* 
                                  const float* g_out1, float* d_f0, float* d_f1, float* d_x, float* d_w_r1, float* d_b_r1,
                                  float* d_w_r2, float* d_b_r2, float* d_w_self0, float* d_w_self1, float* work, void* stream);
 
+/* ---- the typed network: a stack of the layer above behind the EGNN interface (irreps.IrrepEGNN; N4, ABI 13) ----------------
+ * (h [N, in_nf], x [N, 3]) -> (h_out [N, out_nf], x_out [N, 3]):  f0 = h, f1 = 0 [N, c1, 3];  per layer l = 0 .. L-1:
+ *   (p0, p1) = irrep_conv_l(f0, f1, x)  with degree-0 widths in_nf -> hidden_nf -> ... -> out_nf and c1 degree-1 channels throughout;
+ *   l < L-1:  f0 = SiLU(p0),  f1 = p1 * sigmoid(W_g p0 + b_g)[:, :, None]   (an invariant gate per degree-1 channel);
+ *   h_out = p0 of the last layer,  x_out = x + sum_i w_x[i] p1[:, i, :]       (equivariant coordinate update, cf. train :262-268).
+ * The coordinates are fixed through the stack (the graph is built once, train :1005), so d x sums over the layers.
+ * Parameter block (fp32, 16-byte aligned; every tensor starts on a 16-byte boundary -- equigspr_irrep_gnn_param_offset): per layer
+ *   radial.0.weight [H] | radial.0.bias [H] | radial.2.weight [n_w, H] | radial.2.bias [n_w] | self0.weight | self1.weight,
+ * then per gate  weight [c1, c0] | bias [c1],  then the coordinate head w_x [c1]  (which = 0..5 per layer, 6 / 7 gate, 8 head). */
+typedef struct equigspr_irrep_gnn_config {
+    int32_t in_nf, hidden_nf, out_nf, c1, n_layers, radial_hidden;   /* 1..32 channels, 1..16 layers, radial_hidden 16 or 32 */
+    float k00, k01, k10, k11_0, k11_1, k11_2;                        /* closed form of the degree <= 1 basis (see above) */
+} equigspr_irrep_gnn_config;
+int64_t equigspr_irrep_gnn_param_count(const equigspr_irrep_gnn_config* cfg);     /* floats, padding included */
+int64_t equigspr_irrep_gnn_param_offset(const equigspr_irrep_gnn_config* cfg, int32_t layer, int32_t which);
+int64_t equigspr_irrep_gnn_saved_size(const equigspr_irrep_gnn_config* cfg, int32_t n_nodes, int32_t n_edges);
+int64_t equigspr_irrep_gnn_work_size(const equigspr_irrep_gnn_config* cfg, int32_t n_nodes, int32_t n_edges);
+/* forward: 3 launches per layer (moments, node, gate / coordinate head); `saved` (saved_size floats) holds the layer inputs, the
+ * pre-gate outputs and the moments -- the backward's inputs, and the forward's own buffers (always required). */
+int equigspr_irrep_gnn_forward(const equigspr_irrep_gnn_config* cfg, const float* params, const equigspr_graph* g, const float* h_in,
+                               const float* x, float* h_out, float* x_out, float* saved, void* stream);
+/* backward: parameter gradients are ACCUMULATED into `grads` (same layout as `params`; the flat gradient bucket of the optimizer and
+ * the all-reduce), d_x [N, 3] is ACCUMULATED (may be NULL), d_h_in [N, in_nf] is overwritten (may be NULL). */
+int equigspr_irrep_gnn_backward(const equigspr_irrep_gnn_config* cfg, const float* params, const equigspr_graph* g, const float* h_in,
+                                const float* x, const float* saved, const float* g_h, const float* g_x, float* d_h_in, float* d_x,
+                                float* grads, float* work, void* stream);
+
 /* ---- A17: gcnLayer (src/gcnLayer.py) ------------------------------------------------------------
  * build_graph :58-67 (_get_weights :28-46, get_normalize_adj :49-56): w_ij = exp(-d_ij^2 / sigma2), sigma2 =
  * mean_i(d(i, k-th neighbour))^2, no self loops, symmetrised by max, D^-1/2 A D^-1/2 -- returned as CSR by node

@@ -84,3 +84,18 @@ def irrep_conv(w, f0, f1, x, edges):
     out0 = out0.index_add(0, row, m0)
     out1 = out1.index_add(0, row, m1)
     return out0, out1
+
+
+def irrep_egnn(w, h, x, edges, n_layers):
+    """DEFINITION of ``irreps.IrrepEGNN`` (the typed network behind the EGNN interface): ``w`` = its ``state_dict`` (fp64):
+    ``layers.l.*`` (``param_shapes``), ``gates.l.{weight, bias}``, ``coord.weight [1, c1]``.  f1 starts at zero; SiLU on degree 0 and an
+    invariant sigmoid gate per degree-1 channel between the layers; ``x_out = x + sum_i w_x[i] f1[:, i, :]`` after the last."""
+    c1 = w["coord.weight"].shape[1]
+    f0, f1 = h, torch.zeros(x.shape[0], c1, 3, dtype=h.dtype)
+    for l in range(n_layers):
+        wl = {k[len(f"layers.{l}."):]: v for k, v in w.items() if k.startswith(f"layers.{l}.")}
+        f0, f1 = irrep_conv(wl, f0, f1, x, edges)
+        if l + 1 < n_layers:
+            f1 = f1 * torch.sigmoid(f0 @ w[f"gates.{l}.weight"].T + w[f"gates.{l}.bias"])[:, :, None]
+            f0 = F.silu(f0)
+    return f0, x + torch.einsum("i,nia->na", w["coord.weight"][0], f1)

@@ -21,7 +21,7 @@ from . import sh  # noqa: F401  (A16: spherical harmonics / irrep basis)
 from .sh import (get_basis, get_spherical_harmonics, precompute_sh, basis_transformation_Q_J, irr_repr,  # noqa: F401
                  wigner_d_matrix, compose, J_dense)
 from .gcn import build_graph, GraphConvolution, GlobalPooling, KnnAdjacency  # noqa: F401
-from .irreps import IrrepConv, IrrepGNN, sh1_matrix  # noqa: F401  (N4: typed irrep-basis message passing)
+from .irreps import IrrepConv, IrrepEGNN, IrrepGNN, sh1_matrix  # noqa: F401  (N4: typed irrep-basis message passing)
 from . import datasets  # noqa: F401  (N3: pair-file formats, dataset classes, HBM-resident batches)
 from . import train  # noqa: F401  (train_one_epoch / validate / checkpoints in the reference layout)
 from .datasets import ThreeDMatchTrainVal, ThreeDMatchTest, KITTItrainVal, KITTItest, DeviceBatches  # noqa: F401

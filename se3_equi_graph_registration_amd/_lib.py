@@ -33,6 +33,12 @@ class IrrepConfig(Structure):
                 ("k11_1", ctypes.c_float), ("k11_2", ctypes.c_float)]
 
 
+class IrrepGnnConfig(Structure):
+    _fields_ = [("in_nf", c_int32), ("hidden_nf", c_int32), ("out_nf", c_int32), ("c1", c_int32), ("n_layers", c_int32),
+                ("radial_hidden", c_int32), ("k00", ctypes.c_float), ("k01", ctypes.c_float), ("k10", ctypes.c_float),
+                ("k11_0", ctypes.c_float), ("k11_1", ctypes.c_float), ("k11_2", ctypes.c_float)]
+
+
 _SIGNATURES = {
     "equigspr_abi_version": (ctypes.c_int, []),
     "equigspr_last_error": (c_char_p, []),
@@ -82,6 +88,12 @@ _SIGNATURES = {
     "equigspr_irrep_moments_size": (c_int64, [POINTER(IrrepConfig), c_int32]),
     "equigspr_irrep_bwd_work_size": (c_int64, [POINTER(IrrepConfig), c_int32, c_int32]),
     "equigspr_irrep_conv_forward": (ctypes.c_int, [POINTER(IrrepConfig)] + [c_void_p] * 6 + [POINTER(Graph)] + [c_void_p] * 7),
+    "equigspr_irrep_gnn_param_count": (c_int64, [POINTER(IrrepGnnConfig)]),
+    "equigspr_irrep_gnn_param_offset": (c_int64, [POINTER(IrrepGnnConfig), c_int32, c_int32]),
+    "equigspr_irrep_gnn_saved_size": (c_int64, [POINTER(IrrepGnnConfig), c_int32, c_int32]),
+    "equigspr_irrep_gnn_work_size": (c_int64, [POINTER(IrrepGnnConfig), c_int32, c_int32]),
+    "equigspr_irrep_gnn_forward": (ctypes.c_int, [POINTER(IrrepGnnConfig), c_void_p, POINTER(Graph)] + [c_void_p] * 6),
+    "equigspr_irrep_gnn_backward": (ctypes.c_int, [POINTER(IrrepGnnConfig), c_void_p, POINTER(Graph)] + [c_void_p] * 10),
     "equigspr_irrep_conv_backward": (ctypes.c_int, [POINTER(IrrepConfig)] + [c_void_p] * 6 + [POINTER(Graph)] + [c_void_p] * 17),
     "equigspr_eval_metrics": (ctypes.c_int, [c_void_p] * 5 + [c_int32, c_int32, ctypes.c_double, c_void_p, c_void_p]),
     "equigspr_pointnet_layer_forward": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 7 + [c_int32, c_void_p, c_void_p, c_void_p]),

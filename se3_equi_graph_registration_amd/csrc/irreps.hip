@@ -108,12 +108,21 @@ __global__ __launch_bounds__(256) void irrep_moments16_kernel(const MomArgs a) {
             front(base, cnt);
             wave_sync();
             const int nks = (cnt + 3) >> 2;
+            // the gathered feature rows of k-step ks + 1 are requested before the products of k-step ks (index -> row is a
+            // dependent chain of two memory round trips; with three waves per SIMD nothing else hides it)
+            auto gather = [&](int ks, float (&gg)[B0]) {
+                const float* f0r = a.f0 + (size_t)__float_as_int(gB[4 * ks + kq].w) * a.c0;
+#pragma unroll
+                for (int sub = 0; sub < B0; ++sub) gg[sub] = (16 * sub + j < a.c0) ? f0r[16 * sub + j] : 0.0f;
+            };
+            float gnext[B0];
+            gather(0, gnext);
             for (int ks = 0; ks < nks; ++ks) {
                 const float4 A = gA[4 * ks + kq], B = gB[4 * ks + kq];
-                const float* f0r = a.f0 + (size_t)__float_as_int(B.w) * a.c0;
                 float g[B0];
 #pragma unroll
-                for (int sub = 0; sub < B0; ++sub) g[sub] = (16 * sub + j < a.c0) ? f0r[16 * sub + j] : 0.0f;
+                for (int sub = 0; sub < B0; ++sub) g[sub] = gnext[sub];
+                if (ks + 1 < nks) gather(ks + 1, gnext);
                 float hid[NH];
 #pragma unroll
                 for (int hb = 0; hb < NH; ++hb) hid[hb] = silu(fmaf(w1v[hb], A.w, b1v[hb]));
@@ -161,10 +170,17 @@ __global__ __launch_bounds__(256) void irrep_moments16_kernel(const MomArgs a) {
         front(base, cnt);
         wave_sync();
         const int nks = (cnt + 3) >> 2;
+        auto gather = [&](int ks, float (&gg)[3]) {
+            const float* f1r = a.f1 + ((size_t)__float_as_int(gB[4 * ks + kq].w) * a.c1 + ch) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gg[c] = ch_ok ? f1r[c] : 0.0f;
+        };
+        float gnext[3];
+        gather(0, gnext);
         for (int ks = 0; ks < nks; ++ks) {
             const float4 A = gA[4 * ks + kq], B = gB[4 * ks + kq];
-            const float* f1r = a.f1 + ((size_t)__float_as_int(B.w) * a.c1 + ch) * 3;
-            const float g0 = ch_ok ? f1r[0] : 0.0f, g1 = ch_ok ? f1r[1] : 0.0f, g2 = ch_ok ? f1r[2] : 0.0f;
+            const float g0 = gnext[0], g1 = gnext[1], g2 = gnext[2];
+            if (ks + 1 < nks) gather(ks + 1, gnext);
             float hid[NH];
 #pragma unroll
             for (int hb = 0; hb < NH; ++hb) hid[hb] = silu(fmaf(w1v[hb], A.w, b1v[hb]));
@@ -403,25 +419,31 @@ __global__ __launch_bounds__(64 * kNodeWaves) void irrep_expand16_kernel(const E
             const float* wp = p->w + (size_t)in * p->si + J * H;
             const float* bp = p->b + ((size_t)in * p->si) / H + J;
             const int nks = (on + 3) >> 2;
+            // D[h][node] = sum_o A[h][o] B[o][node]: A lane (h = i16, k = kq) = W(o = 4 s + kq, ., 16 t + h); all of the entry's weight
+            // loads are requested before the first product
+            float wv[8][NH], bw[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int o = 4 * s + kq;
+                const bool ok = s < nks && o < on;
+#pragma unroll
+                for (int t = 0; t < NH; ++t) wv[s][t] = ok ? wp[(size_t)o * p->so + 16 * t + i16] : 0.0f;
+                bw[s] = ok ? bp[((size_t)o * p->so) / H] : 0.0f;
+            }
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 if (s >= nks) break;
-                const int o = 4 * s + kq;
-                const bool ok = o < on;
-                const float av = src == 0 ? ga[0][s] : (src == 1 ? ga[1][s] : (src == 2 ? ga[2][s] : ga[3][s]));
+                const float gvv = src == 0 ? ga[0][s] : (src == 1 ? ga[1][s] : (src == 2 ? ga[2][s] : ga[3][s]));
 #pragma unroll
-                for (int t = 0; t < NH; ++t) acc[t] = mfma16(av, ok ? wp[(size_t)o * p->so + 16 * t + i16] : 0.0f, acc[t]);
-                bsum = fmaf(av, ok ? bp[((size_t)o * p->so) / H] : 0.0f, bsum);
+                for (int t = 0; t < NH; ++t) acc[t] = mfma16(wv[s][t], gvv, acc[t]);
+                bsum = fmaf(gvv, bw[s], bsum);
             }
         }
         bsum = gsum(bsum);
-        // D[node][h]: lane (h = i16, g = kq) holds nodes 4 g + r
+        // lane (node = i16, g = kq) holds h = 16 t + 4 g + r: one 16-byte store per tile
+        if (n0 + i16 < a.n_nodes) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + 4 * kq + r;
-            if (n >= a.n_nodes) continue;
-#pragma unroll
-            for (int t = 0; t < NH; ++t) a.dM[((size_t)n * a.lc + e) * H + 16 * t + i16] = acc[t][r];
+            for (int t = 0; t < NH; ++t) st4(a.dM + ((size_t)(n0 + i16) * a.lc + e) * H + 16 * t + 4 * kq, acc[t]);
         }
         if (kq == 0 && n0 + i16 < a.n_nodes) a.dMb[(size_t)(n0 + i16) * a.lc + e] = bsum;
     }
@@ -534,18 +556,28 @@ __global__ __launch_bounds__(256) void irrep_geom_bwd_kernel(const GeomArgs a) {
 #pragma unroll
         for (int t = 0; t < NH; ++t) dh[t] = splat4(0.0f);
         float du[3] = {0.0f, 0.0f, 0.0f};
+        f32x4 apre[NH], bpre;
+        auto fetch = [&](int blk) {
+#pragma unroll
+            for (int t = 0; t < NH; ++t) apre[t] = ldg4(dMn + ((size_t)(16 * blk + i16)) * H + 16 * t + 4 * g);
+            bpre = ldg4(dMbn + 16 * blk + 4 * g);
+        };
+        fetch(0);
+        const int f1b = f1base >> 4;
         // one 16-entry block: stage the dM tile, d c (optional), d hid; `cv` = the lane's four operand values c[e][16 blk + 4 g + r]
-        auto block = [&](int blk, const f32x4& cv, bool want_dc, f32x4& dc) {
-            // tile rows: lane (j = i16, kq = g) loads dM[n][16 blk + j][16 t + 4 g ..]
+        // (the tile of block `next` is requested while this block computes: tile rows: lane (j = i16, kq = g) loads
+        // dM[n][16 blk + j][16 t + 4 g ..]; with two waves per SIMD nothing else covers the round trip)
+        auto block = [&](int blk, int next, const f32x4& cv, bool want_dc, f32x4& dc) {
             f32x4 arow[NH];
 #pragma unroll
-            for (int t = 0; t < NH; ++t) {
-                arow[t] = ldg4(dMn + ((size_t)(16 * blk + i16)) * H + 16 * t + 4 * g);
-                st4(tile + i16 * kTileStride + 16 * t + 4 * g, arow[t]);
-            }
+            for (int t = 0; t < NH; ++t) arow[t] = apre[t];
+            const f32x4 brow = bpre;
+            fetch(next);
+#pragma unroll
+            for (int t = 0; t < NH; ++t) st4(tile + i16 * kTileStride + 16 * t + 4 * g, arow[t]);
             wave_sync();
             if (want_dc) {
-                dc = ldg4(dMbn + 16 * blk + 4 * g);                               // D[entry][edge]: lane (e, g) holds entries 4 g + r
+                dc = brow;                                                        // D[entry][edge]: lane (e, g) holds entries 4 g + r
 #pragma unroll
                 for (int t = 0; t < NH; ++t)
 #pragma unroll
@@ -566,10 +598,10 @@ __global__ __launch_bounds__(256) void irrep_geom_bwd_kernel(const GeomArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) gv[r] = (i0 + r < a.c0) ? f0r[i0 + r] : 0.0f;
             f32x4 dc;
-            block(sub, gv * splat4(k00v), false, dc);
+            block(sub, B0 + sub, gv * splat4(k00v), false, dc);
 #pragma unroll
             for (int aa = 0; aa < 3; ++aa) {
-                block((1 + aa) * B0 + sub, gv * splat4(a.k.k01 * u[aa]), true, dc);
+                block((1 + aa) * B0 + sub, aa < 2 ? (2 + aa) * B0 + sub : (sub + 1 < B0 ? sub + 1 : f1b), gv * splat4(a.k.k01 * u[aa]), true, dc);
                 du[aa] = fmaf(a.k.k01, dc[0] * gv[0] + dc[1] * gv[1] + dc[2] * gv[2] + dc[3] * gv[3], du[aa]);
             }
         }
@@ -596,7 +628,7 @@ __global__ __launch_bounds__(256) void irrep_geom_bwd_kernel(const GeomArgs a) {
                     const float hi_ = slot_c<2 * t + 1>(gv[r], u, sd[r], a.k, k110v, k112l);
                     cv[r] = up ? hi_ : lo_;
                 }
-                block((f1base >> 4) + t, cv, true, dc);
+                block(f1b + t, t < 4 ? f1b + t + 1 : 0, cv, true, dc);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     slot_du<2 * t>(gv[r], u, sd[r], a.k, k112l, up ? 0.0f : dc[r], du);
@@ -624,7 +656,7 @@ __global__ __launch_bounds__(256) void irrep_geom_bwd_kernel(const GeomArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) cv[r] = slot_c<SL>(gv[r], u, sd[r], a.k, k110v, k112l);
                     constexpr bool needs = (SL == 0) || ((SL - 1) % 3 != 0);       // J = 0 has no u in it
-                    block((f1base >> 4) + SL * SB + sub, cv, needs, dc);
+                    block(f1b + SL * SB + sub, SL < 9 ? f1b + (SL + 1) * SB + sub : (sub + 1 < SB ? f1b + sub + 1 : 0), cv, needs, dc);
                     if (needs) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) slot_du<SL>(gv[r], u, sd[r], a.k, k112l, dc[r], du);
@@ -769,17 +801,20 @@ __global__ __launch_bounds__(64) void irrep_wgrad16_kernel(const WgradArgs a) {
 #pragma unroll
             for (int t = 0; t < NH; ++t) acc[q][t][cb] = splat4(0.0f);
         }
+    // (rows beyond the range are read from its last node -- valid memory, no branch around the loads -- and weighted with zero)
+#pragma unroll 2
     for (int n0 = nb; n0 < ne; n0 += 4) {
-        const int nk = n0 + kq;
-        const bool ok = nk < ne;
-        const float* Mn = a.M + (size_t)(ok ? nk : nb) * a.lc * H;
-        const float* Mbn = a.Mb + (size_t)(ok ? nk : nb) * a.lc;
+        const bool ok = n0 + kq < ne;
+        const int nk = ok ? n0 + kq : ne - 1;
+        const float* Mn = a.M + (size_t)nk * a.lc * H;
+        const float* Mbn = a.Mb + (size_t)nk * a.lc;
         for (int aa = 0; aa < (deg1 ? 3 : 1); ++aa) {
             float bv[2];
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
-                const int o = 16 * cb + i16;
-                bv[cb] = (ok && cb < ncb && o < on) ? (deg1 ? a.g1[((size_t)nk * a.o1 + o) * 3 + aa] : a.g0[(size_t)nk * a.o0 + o]) : 0.0f;
+                const int o = min(16 * cb + i16, on - 1);
+                const float gvv = deg1 ? a.g1[((size_t)nk * a.o1 + o) * 3 + aa] : a.g0[(size_t)nk * a.o0 + o];
+                bv[cb] = (ok && cb < ncb && 16 * cb + i16 < on) ? gvv : 0.0f;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -790,10 +825,10 @@ __global__ __launch_bounds__(64) void irrep_wgrad16_kernel(const WgradArgs a) {
                 else if (kind == 1) entry = f1base + row;
                 else if (kind == 2) entry = a.c0p * (1 + aa) + row;
                 else { const int in = row / 3, J = row - 3 * in; entry = f1base + a.c1p * (1 + 3 * aa + J) + in; }
-                const float mb = ok ? Mbn[entry] : 0.0f;
+                const float mb = Mbn[entry];
 #pragma unroll
                 for (int t = 0; t < NH; ++t) {
-                    const float av = ok ? Mn[(size_t)entry * H + 16 * t + i16] : 0.0f;
+                    const float av = Mn[(size_t)entry * H + 16 * t + i16];
 #pragma unroll
                     for (int cb = 0; cb < 2; ++cb) {
                         if (cb >= ncb) break;
@@ -826,24 +861,45 @@ __global__ __launch_bounds__(64) void irrep_wgrad16_kernel(const WgradArgs a) {
     }
 }
 
-// sums of the slabs in fixed order -> the parameter gradients (overwritten)
-__global__ void irrep_wreduce_kernel(const float* __restrict__ slab, int splits, int P, int n_wH, int n_w, int ns0, int ns1,
-                                     float* __restrict__ d_w2, float* __restrict__ d_b2, float* __restrict__ d_ws0,
-                                     float* __restrict__ d_ws1, const float* __restrict__ gslab, int gsplits, int H,
-                                     float* __restrict__ d_w1, float* __restrict__ d_b1) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < P) {
+// sums of the slabs in fixed order -> the parameter gradients (overwritten).  Blocks [0, nbA): one thread per radial.2 / self
+// gradient entry, the slabs' values requested eight at a time; blocks nbA ..: ONE workgroup per entry of d w_r1 | d b_r1 (N / 4
+// partials each: thread t sums the partials t, t + 256, ... in order, then a fixed tree over the threads).
+__global__ __launch_bounds__(256) void irrep_wreduce_kernel(const float* __restrict__ slab, int splits, int P, int n_wH, int n_w, int ns0,
+                                                            int ns1, float* __restrict__ d_w2, float* __restrict__ d_b2,
+                                                            float* __restrict__ d_ws0, float* __restrict__ d_ws1,
+                                                            const float* __restrict__ gslab, int gsplits, int H, int nbA,
+                                                            float* __restrict__ d_w1, float* __restrict__ d_b1, int accumulate) {
+    __shared__ float tree[256];
+    if ((int)blockIdx.x < nbA) {
+        const int idx = blockIdx.x * 256 + threadIdx.x;
+        if (idx >= P) return;
         float s = 0.0f;
-        for (int k = 0; k < splits; ++k) s += slab[(size_t)k * P + idx];
-        if (idx < n_wH) d_w2[idx] = s;
-        else if (idx < n_wH + n_w) d_b2[idx - n_wH] = s;
-        else if (idx < n_wH + n_w + ns0) d_ws0[idx - n_wH - n_w] = s;
-        else d_ws1[idx - n_wH - n_w - ns0] = s;
-    } else if (idx < P + 2 * H) {
-        const int j = idx - P;
-        float s = 0.0f;
-        for (int k = 0; k < gsplits; ++k) s += gslab[(size_t)k * 2 * H + j];
-        if (j < H) d_w1[j] = s; else d_b1[j - H] = s;
+        int k = 0;
+        for (; k + 8 <= splits; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(k + u) * P + idx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < splits; ++k) s += slab[(size_t)k * P + idx];
+        float* dst = idx < n_wH ? d_w2 + idx : (idx < n_wH + n_w ? d_b2 + (idx - n_wH)
+                   : (idx < n_wH + n_w + ns0 ? d_ws0 + (idx - n_wH - n_w) : d_ws1 + (idx - n_wH - n_w - ns0)));
+        *dst = accumulate ? *dst + s : s;
+        return;
+    }
+    const int j = blockIdx.x - nbA;                       // 0 .. 2 H - 1
+    float s = 0.0f;
+    for (int k = threadIdx.x; k < gsplits; k += 256) s += gslab[(size_t)k * 2 * H + j];
+    tree[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) tree[threadIdx.x] += tree[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float* dst = j < H ? d_w1 + j : d_b1 + (j - H);
+        *dst = accumulate ? *dst + tree[0] : tree[0];
     }
 }
 
@@ -918,7 +974,7 @@ static BwdPlan plan_bwd(const Layout& L, int n_nodes, int n_edges) {
     const int n_w = L.off11 + 3 * L.c1o * L.c1i;
     p.P = n_w * (H + 1) + L.c0o * L.c0i + L.c1o * L.c1i;
     p.groups = 2 * ceil_div(L.c0i, 4) + ceil_div(L.c1i, 4) + ceil_div(3 * L.c1i, 4) + ceil_div(L.c0i, 16) + ceil_div(L.c1i, 16);
-    int want = ceil_div(2048, p.groups);                                 // ~2 k waves in flight
+    int want = ceil_div(4096, p.groups);                                 // ~4 k waves: four per SIMD (the accumulators' budget)
     want = max(1, min(want, ceil_div(max(n_nodes, 1), 16)));
     p.nodes_per_split = round_up(ceil_div(max(n_nodes, 1), want), 4);
     p.splits = ceil_div(max(n_nodes, 1), p.nodes_per_split);
@@ -948,7 +1004,7 @@ static void conv_backward(const equigspr_irrep_config* c, const Layout& L, const
                           const float* b_r2, const float* ws0, const float* ws1, const equigspr_graph* g, const float* f0,
                           const float* f1, const float* x, const float* M, const float* g0, const float* g1, float* d_f0, float* d_f1,
                           float* d_x, float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_ws0, float* d_ws1, float* work,
-                          hipStream_t s) {
+                          hipStream_t s, int accumulate = 0) {
     const int H = L.H, N = g->n_nodes;
     const BwdPlan p = plan_bwd(L, N, g->n_edges);
     const Consts kf{c->k00, c->k01, c->k10, c->k11_0, c->k11_1, c->k11_2};
@@ -987,8 +1043,214 @@ static void conv_backward(const equigspr_irrep_config* c, const Layout& L, const
     const dim3 wgrid(p.groups, p.splits);
     if (H == 16) hipLaunchKernelGGL((irrep_wgrad16_kernel<1>), wgrid, dim3(64), 0, s, wa);
     else hipLaunchKernelGGL((irrep_wgrad16_kernel<2>), wgrid, dim3(64), 0, s, wa);
-    hipLaunchKernelGGL(irrep_wreduce_kernel, dim3(ceil_div(p.P + 2 * H, 256)), dim3(256), 0, s, work + p.o_wslab, p.splits, p.P, n_w * H, n_w,
-                       L.c0o * L.c0i, L.c1o * L.c1i, d_w2, d_b2, d_ws0, d_ws1, work + p.o_gslab, p.gsplits, H, d_w1, d_b1);
+    const int nbA = ceil_div(p.P, 256);
+    hipLaunchKernelGGL(irrep_wreduce_kernel, dim3(nbA + 2 * H), dim3(256), 0, s, work + p.o_wslab, p.splits, p.P, n_w * H, n_w,
+                       L.c0o * L.c0i, L.c1o * L.c1i, d_w2, d_b2, d_ws0, d_ws1, work + p.o_gslab, p.gsplits, H, nbA, d_w1, d_b1, accumulate);
+}
+
+
+// ================================================================================================ the typed network (IrrepEGNN)
+// A stack of the layer above behind the EGNN interface (h [N, in_nf], x [N, 3]) -> (h [N, out_nf], x [N, 3]):
+//   f0 = h, f1 = 0;  per layer l:  (p0, p1) = conv_l(f0, f1, x);  l < L - 1:  f0 = SiLU(p0),  f1 = p1 * sigmoid(W_g p0 + b_g)  (an
+//   invariant gate per degree-1 channel: keeps degree 1 covariant);  h_out = p0 of the last layer,  x_out = x + sum_i w_x[i] p1[:, i, :]
+//   (degree-1 features are Cartesian vectors up to the factor of Y_1: an equivariant coordinate update, as E_GCL.coord_model :262-268).
+// The coordinates stay fixed through the stack (one graph, one geometry), so d x sums over the layers.
+struct GnnPlan {
+    int L, H, c1, n_nodes;
+    int c0[17];                                   // degree-0 widths: c0[0] = in_nf, c0[1..L-1] = hidden_nf, c0[L] = out_nf
+    int64_t o_w1[16], o_b1[16], o_w2[16], o_b2[16], o_s0[16], o_s1[16], o_gw[16], o_gb[16], o_wx, n_params;
+    int64_t s_f0[16], s_f1[16], s_p0[16], s_p1[16], s_M[16], saved_total;     // saved activations (floats); s_f0[0] is unused (= h_in)
+    int64_t bwd_conv_work, w_g0, w_g1, w_d0, w_d1, w_slab, work_total;
+    int gate_blocks;
+};
+static equigspr_irrep_config layer_cfg(const equigspr_irrep_gnn_config* c, const GnnPlan& P, int l) {
+    return equigspr_irrep_config{P.c0[l], P.c1, P.c0[l + 1], P.c1, P.H, c->k00, c->k01, c->k10, c->k11_0, c->k11_1, c->k11_2};
+}
+static bool gnn_ok(const equigspr_irrep_gnn_config* c) {
+    auto ch = [](int v) { return v >= 1 && v <= kMaxC; };
+    return c && ch(c->in_nf) && ch(c->hidden_nf) && ch(c->out_nf) && ch(c->c1) && c->n_layers >= 1 && c->n_layers <= 16 &&
+           (c->radial_hidden == 16 || c->radial_hidden == 32);
+}
+static GnnPlan plan_gnn(const equigspr_irrep_gnn_config* c, int n_nodes, int n_edges) {
+    GnnPlan P{};
+    P.L = c->n_layers; P.H = c->radial_hidden; P.c1 = c->c1; P.n_nodes = n_nodes;
+    for (int l = 0; l <= P.L; ++l) P.c0[l] = l == 0 ? c->in_nf : (l == P.L ? c->out_nf : c->hidden_nf);
+    // parameter block in named_parameters() order of irreps.IrrepEGNN: all layers, then all gates, then the coordinate head; every
+    // tensor starts on a 16-byte boundary (the kernels read weight rows as float4)
+    int64_t o = 0;
+    auto take = [&](int64_t n) { const int64_t at = o; o += r4(n); return at; };
+    for (int l = 0; l < P.L; ++l) {
+        const int ci = P.c0[l], co = P.c0[l + 1], c1 = P.c1;
+        const int64_t n_w = (int64_t)co * ci + (int64_t)c1 * ci + (int64_t)co * c1 + 3LL * c1 * c1;
+        P.o_w1[l] = take(P.H); P.o_b1[l] = take(P.H); P.o_w2[l] = take(n_w * P.H); P.o_b2[l] = take(n_w);
+        P.o_s0[l] = take((int64_t)co * ci); P.o_s1[l] = take((int64_t)c1 * c1);
+    }
+    for (int l = 0; l + 1 < P.L; ++l) { P.o_gw[l] = take((int64_t)P.c1 * P.c0[l + 1]); P.o_gb[l] = take(P.c1); }
+    P.o_wx = take(P.c1);
+    P.n_params = o;
+    // saved activations
+    o = 0;
+    int64_t conv_work = 0;
+    const int64_t N = n_nodes;
+    for (int l = 0; l < P.L; ++l) {
+        const equigspr_irrep_config lc = layer_cfg(c, P, l);
+        P.s_f0[l] = l == 0 ? -1 : take(N * P.c0[l]);
+        P.s_f1[l] = take(N * P.c1 * 3);
+        P.s_p0[l] = take(N * P.c0[l + 1]);
+        P.s_p1[l] = take(N * P.c1 * 3);
+        const int64_t lcn = 4 * pad0(lc.c0_in) + 10 * pad1(lc.c1_in);
+        P.s_M[l] = take(N * lcn * (P.H + 1));
+        const int64_t w = plan_bwd(layout_of(&lc), n_nodes, n_edges).total;
+        conv_work = w > conv_work ? w : conv_work;
+    }
+    P.saved_total = o;
+    // backward scratch: the convolution's own + two pairs of gradient buffers (ping-pong through the layers) + gate / head slabs
+    o = 0;
+    P.bwd_conv_work = take(conv_work);
+    const int cmax = max(max(c->in_nf, c->hidden_nf), c->out_nf);
+    P.w_g0 = take(N * cmax); P.w_g1 = take(N * P.c1 * 3); P.w_d0 = take(N * cmax); P.w_d1 = take(N * P.c1 * 3);
+    P.gate_blocks = ceil_div(max(n_nodes, 1), 64);
+    P.w_slab = take((int64_t)P.gate_blocks * (P.c1 * (kMaxC + 1) + P.c1));
+    P.work_total = o;
+    return P;
+}
+
+// ---- gate: f0 = SiLU(p0), f1 = p1 * sigmoid(W_g p0 + b_g).  64 nodes per workgroup (256 threads: four per node); the weight
+// gradients d W_g [c1, c0] | d b_g [c1] as one slab per workgroup (LDS outer product over the workgroup's nodes), summed in order later.
+__global__ __launch_bounds__(256) void irrep_gate_fwd_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                             const float* __restrict__ wg, const float* __restrict__ bg, int n_nodes,
+                                                             int c0, int c1, float* __restrict__ f0, float* __restrict__ f1) {
+    __shared__ float w_s[kMaxC * (kMaxC + 1)];
+    for (int t = threadIdx.x; t < c1 * c0; t += 256) w_s[(t / c0) * (kMaxC + 1) + t % c0] = wg[t];
+    __syncthreads();
+    const int n = blockIdx.x * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
+    if (n >= n_nodes) return;
+    const float* pr = p0 + (size_t)n * c0;
+    for (int i = q; i < c0; i += 4) f0[(size_t)n * c0 + i] = silu(pr[i]);
+    for (int ch = q; ch < c1; ch += 4) {
+        float z = bg[ch];
+        for (int i = 0; i < c0; ++i) z = fmaf(w_s[ch * (kMaxC + 1) + i], pr[i], z);
+        const float gt = sigmoid_fast(z);
+#pragma unroll
+        for (int a_ = 0; a_ < 3; ++a_) f1[((size_t)n * c1 + ch) * 3 + a_] = p1[((size_t)n * c1 + ch) * 3 + a_] * gt;
+    }
+}
+
+// backward of the gate: inputs d f0, d f1 (gradients of the NEXT layer's inputs) -> g0 = d p0, g1 = d p1
+__global__ __launch_bounds__(256) void irrep_gate_bwd_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                             const float* __restrict__ wg, const float* __restrict__ bg,
+                                                             const float* __restrict__ d_f0, const float* __restrict__ d_f1, int n_nodes,
+                                                             int c0, int c1, float* __restrict__ g0, float* __restrict__ g1,
+                                                             float* __restrict__ slab) {
+    __shared__ float w_s[kMaxC * (kMaxC + 1)];
+    __shared__ float dz_s[64][kMaxC + 1];
+    __shared__ float p_s[64][kMaxC + 1];
+    for (int t = threadIdx.x; t < c1 * c0; t += 256) w_s[(t / c0) * (kMaxC + 1) + t % c0] = wg[t];
+    const int ln = threadIdx.x >> 2, q = threadIdx.x & 3;
+    const int n = blockIdx.x * 64 + ln;
+    const bool ok = n < n_nodes;
+    const float* pr = p0 + (size_t)(ok ? n : 0) * c0;
+    for (int i = q; i < c0; i += 4) p_s[ln][i] = ok ? pr[i] : 0.0f;
+    __syncthreads();
+    for (int ch = q; ch < c1; ch += 4) {
+        float z = bg[ch];
+        for (int i = 0; i < c0; ++i) z = fmaf(w_s[ch * (kMaxC + 1) + i], p_s[ln][i], z);
+        const float gt = sigmoid_fast(z);
+        float dot = 0.0f;
+        if (ok) {
+#pragma unroll
+            for (int a_ = 0; a_ < 3; ++a_) {
+                const size_t at = ((size_t)n * c1 + ch) * 3 + a_;
+                const float df = d_f1[at];
+                g1[at] = df * gt;
+                dot = fmaf(df, p1[at], dot);
+            }
+        }
+        dz_s[ln][ch] = ok ? dot * gt * (1.0f - gt) : 0.0f;                    // d loss / d (W_g p0 + b_g)
+    }
+    __syncthreads();
+    if (ok) {
+        for (int i = q; i < c0; i += 4) {
+            float v = d_f0[(size_t)n * c0 + i] * silu_grad(p_s[ln][i]);
+            for (int ch = 0; ch < c1; ++ch) v = fmaf(w_s[ch * (kMaxC + 1) + i], dz_s[ln][ch], v);
+            g0[(size_t)n * c0 + i] = v;
+        }
+    }
+    // slab: d W_g[ch][i] = sum over the workgroup's nodes (ascending) of dz[n][ch] p0[n][i];  d b_g[ch] = sum dz[n][ch]
+    float* sl = slab + (size_t)blockIdx.x * (c1 * (c0 + 1));
+    for (int t = threadIdx.x; t < c1 * (c0 + 1); t += 256) {
+        const int ch = t / (c0 + 1), i = t - ch * (c0 + 1);
+        float s = 0.0f;
+        for (int m = 0; m < 64; ++m) s = fmaf(dz_s[m][ch], i < c0 ? p_s[m][i] : 1.0f, s);
+        sl[t] = s;
+    }
+}
+
+// out[j] (+)= sum_k slab[k][j], k ascending: one workgroup per column block of 256 threads x 1 column (small slabs)
+__global__ __launch_bounds__(256) void irrep_colsum_kernel(const float* __restrict__ slab, int rows, int cols, const int* __restrict__ map,
+                                                           float* __restrict__ out_a, int split, float* __restrict__ out_b, int accumulate) {
+    __shared__ float tree[256];
+    const int j = blockIdx.x;
+    float s = 0.0f;
+    for (int k = threadIdx.x; k < rows; k += 256) s += slab[(size_t)k * cols + j];
+    tree[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) tree[threadIdx.x] += tree[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // gate slabs are laid out [ch][c0 + 1]: column (ch, i < c0) -> out_a[ch * c0 + i], column (ch, c0) -> out_b[ch]; split = c0 + 1
+        float* dst;
+        if (split > 0) { const int ch = j / split, i = j - ch * split; dst = i < split - 1 ? out_a + (size_t)ch * (split - 1) + i : out_b + ch; }
+        else dst = out_a + j;
+        *dst = accumulate ? *dst + tree[0] : tree[0];
+    }
+}
+
+// coordinate head: x_out = x + sum_i w_x[i] v[:, i, :]
+__global__ void irrep_coord_fwd_kernel(const float* __restrict__ x, const float* __restrict__ v, const float* __restrict__ wx, int n_nodes,
+                                       int c1, float* __restrict__ x_out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_nodes * 3) return;
+    const int n = t / 3, a_ = t - 3 * n;
+    float s = x[t];
+    for (int i = 0; i < c1; ++i) s = fmaf(wx[i], v[((size_t)n * c1 + i) * 3 + a_], s);
+    x_out[t] = s;
+}
+// backward: g1[n, i, a] = w_x[i] g_x[n, a];  d w_x[i] = sum_{n, a} v[n, i, a] g_x[n, a] (slab per workgroup of 256 nodes);  d x += g_x
+__global__ __launch_bounds__(256) void irrep_coord_bwd_kernel(const float* __restrict__ v, const float* __restrict__ wx,
+                                                              const float* __restrict__ gx, int n_nodes, int c1, float* __restrict__ g1,
+                                                              float* __restrict__ d_x, float* __restrict__ slab) {
+    __shared__ float part[256][kMaxC + 1];
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = n < n_nodes;
+    float g[3] = {0.0f, 0.0f, 0.0f};
+    if (ok) {
+#pragma unroll
+        for (int a_ = 0; a_ < 3; ++a_) {
+            g[a_] = gx[(size_t)n * 3 + a_];
+            if (d_x) d_x[(size_t)n * 3 + a_] += g[a_];
+        }
+    }
+    for (int i = 0; i < c1; ++i) {
+        float dot = 0.0f;
+        if (ok) {
+#pragma unroll
+            for (int a_ = 0; a_ < 3; ++a_) {
+                const size_t at = ((size_t)n * c1 + i) * 3 + a_;
+                dot = fmaf(v[at], g[a_], dot);
+                g1[at] = wx[i] * g[a_];
+            }
+        }
+        part[threadIdx.x][i] = dot;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < c1) {
+        float s = 0.0f;
+        for (int m = 0; m < 256; ++m) s += part[m][threadIdx.x];
+        slab[(size_t)blockIdx.x * c1 + threadIdx.x] = s;
+    }
 }
 
 }  // namespace ir
@@ -1042,5 +1304,118 @@ extern "C" int equigspr_irrep_conv_backward(const equigspr_irrep_config* cfg, co
     conv_backward(cfg, layout_of(cfg), w_r1, b_r1, w_r2, b_r2, w_self0, w_self1, g, f0, f1, x, moments, g_out0, g_out1, d_f0, d_f1, d_x,
                   d_w_r1, d_b_r1, d_w_r2, d_b_r2, d_w_self0, d_w_self1, work, (hipStream_t)stream);
     EQ_CHECK_LAUNCH("irrep_conv_backward");
+    return 0;
+}
+
+// ---- the typed network behind the EGNN interface (irreps.IrrepEGNN)
+extern "C" int64_t equigspr_irrep_gnn_param_count(const equigspr_irrep_gnn_config* cfg) {
+    using namespace eq::ir;
+    if (!gnn_ok(cfg)) return -1;
+    return plan_gnn(cfg, 1, 1).n_params;
+}
+extern "C" int64_t equigspr_irrep_gnn_param_offset(const equigspr_irrep_gnn_config* cfg, int32_t layer, int32_t which) {
+    using namespace eq::ir;
+    if (!gnn_ok(cfg) || layer < 0 || layer >= cfg->n_layers || which < 0 || which > 8) return -1;
+    const GnnPlan P = plan_gnn(cfg, 1, 1);
+    switch (which) {
+        case 0: return P.o_w1[layer];
+        case 1: return P.o_b1[layer];
+        case 2: return P.o_w2[layer];
+        case 3: return P.o_b2[layer];
+        case 4: return P.o_s0[layer];
+        case 5: return P.o_s1[layer];
+        case 6: return layer + 1 < P.L ? P.o_gw[layer] : -1;
+        case 7: return layer + 1 < P.L ? P.o_gb[layer] : -1;
+        default: return P.o_wx;
+    }
+}
+extern "C" int64_t equigspr_irrep_gnn_saved_size(const equigspr_irrep_gnn_config* cfg, int32_t n_nodes, int32_t n_edges) {
+    using namespace eq::ir;
+    if (!gnn_ok(cfg) || n_nodes < 0 || n_edges < 0) return -1;
+    return plan_gnn(cfg, n_nodes, n_edges).saved_total;
+}
+extern "C" int64_t equigspr_irrep_gnn_work_size(const equigspr_irrep_gnn_config* cfg, int32_t n_nodes, int32_t n_edges) {
+    using namespace eq::ir;
+    if (!gnn_ok(cfg) || n_nodes < 0 || n_edges < 0) return -1;
+    return plan_gnn(cfg, n_nodes, n_edges).work_total;
+}
+
+extern "C" int equigspr_irrep_gnn_forward(const equigspr_irrep_gnn_config* cfg, const float* params, const equigspr_graph* g,
+                                          const float* h_in, const float* x, float* h_out, float* x_out, float* saved, void* stream) {
+    using namespace eq;
+    using namespace eq::ir;
+    EQ_CHECK_ARG(gnn_ok(cfg), EQUIGSPR_ENOTSUP, "irrep_gnn_forward: 1..%d channels per degree, 1..16 layers, radial hidden 16 or 32", kMaxC);
+    EQ_CHECK_ARG(params && g && h_in && x && h_out && x_out && saved, EQUIGSPR_EINVAL, "irrep_gnn_forward: null argument");
+    EQ_CHECK_ARG(g->n_nodes >= 1 && g->n_edges >= 0 && g->rptr && (g->n_edges == 0 || (g->col && g->rperm)), EQUIGSPR_EINVAL,
+                 "irrep_gnn_forward: incomplete graph (col, rptr, rperm)");
+    EQ_CHECK_ARG(((uintptr_t)params & 15) == 0 && ((uintptr_t)saved & 15) == 0, EQUIGSPR_EINVAL, "irrep_gnn_forward: params / saved must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const int N = g->n_nodes;
+    const GnnPlan P = plan_gnn(cfg, N, g->n_edges);
+    EQ_CHECK_ARG(hipMemsetAsync(saved + P.s_f1[0], 0, sizeof(float) * (size_t)N * P.c1 * 3, s) == hipSuccess, EQUIGSPR_EINVAL, "irrep_gnn_forward: memset failed");
+    for (int l = 0; l < P.L; ++l) {
+        const equigspr_irrep_config lc = layer_cfg(cfg, P, l);
+        const Layout Ly = layout_of(&lc);
+        const bool last = l + 1 == P.L;
+        const float* f0 = l == 0 ? h_in : saved + P.s_f0[l];
+        const float* f1 = saved + P.s_f1[l];
+        float* p0 = last ? h_out : saved + P.s_p0[l];
+        float* p1 = saved + P.s_p1[l];
+        float* M = saved + P.s_M[l];
+        const int64_t lcn = 4 * pad0(Ly.c0i) + 10 * pad1(Ly.c1i);
+        conv_forward(&lc, Ly, params + P.o_w1[l], params + P.o_b1[l], params + P.o_w2[l], params + P.o_b2[l], params + P.o_s0[l],
+                     params + P.o_s1[l], g, f0, f1, x, p0, p1, M, M + (int64_t)N * lcn * P.H, s);
+        if (!last)
+            hipLaunchKernelGGL(irrep_gate_fwd_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, s, p0, p1, params + P.o_gw[l], params + P.o_gb[l], N,
+                               P.c0[l + 1], P.c1, saved + P.s_f0[l + 1], saved + P.s_f1[l + 1]);
+        else
+            hipLaunchKernelGGL(irrep_coord_fwd_kernel, dim3(ceil_div(3 * N, 256)), dim3(256), 0, s, x, p1, params + P.o_wx, N, P.c1, x_out);
+    }
+    EQ_CHECK_LAUNCH("irrep_gnn_forward");
+    return 0;
+}
+
+extern "C" int equigspr_irrep_gnn_backward(const equigspr_irrep_gnn_config* cfg, const float* params, const equigspr_graph* g,
+                                           const float* h_in, const float* x, const float* saved, const float* g_h, const float* g_x,
+                                           float* d_h_in, float* d_x, float* grads, float* work, void* stream) {
+    using namespace eq;
+    using namespace eq::ir;
+    EQ_CHECK_ARG(gnn_ok(cfg), EQUIGSPR_ENOTSUP, "irrep_gnn_backward: unsupported config");
+    EQ_CHECK_ARG(params && g && h_in && x && saved && g_h && g_x && grads && work, EQUIGSPR_EINVAL, "irrep_gnn_backward: null argument");
+    EQ_CHECK_ARG(g->n_nodes >= 1 && g->n_edges >= 0 && g->rptr && g->cptr && (g->n_edges == 0 || (g->row && g->col && g->rperm && g->cperm)),
+                 EQUIGSPR_EINVAL, "irrep_gnn_backward: incomplete graph (row, col and both inverse indices)");
+    hipStream_t s = (hipStream_t)stream;
+    const int N = g->n_nodes;
+    const GnnPlan P = plan_gnn(cfg, N, g->n_edges);
+    float* cw = work + P.bwd_conv_work;
+    float* g0 = work + P.w_g0; float* g1 = work + P.w_g1; float* d0 = work + P.w_d0; float* d1 = work + P.w_d1;
+    float* slab = work + P.w_slab;
+    // coordinate head: g1 = w_x (x) g_x, d w_x, d x += g_x
+    const int cb = ceil_div(N, 256);
+    hipLaunchKernelGGL(irrep_coord_bwd_kernel, dim3(cb), dim3(256), 0, s, saved + P.s_p1[P.L - 1], params + P.o_wx, g_x, N, P.c1, g1, d_x, slab);
+    hipLaunchKernelGGL(irrep_colsum_kernel, dim3(P.c1), dim3(256), 0, s, slab, cb, P.c1, (const int*)nullptr, grads + P.o_wx, 0, (float*)nullptr, 1);
+    const float* gout0 = g_h;
+    for (int l = P.L - 1; l >= 0; --l) {
+        const equigspr_irrep_config lc = layer_cfg(cfg, P, l);
+        const Layout Ly = layout_of(&lc);
+        const float* f0 = l == 0 ? h_in : saved + P.s_f0[l];
+        const float* f1 = saved + P.s_f1[l];
+        const bool want_f = l > 0 || d_h_in != nullptr;
+        float* df0 = !want_f ? nullptr : (l == 0 ? d_h_in : d0);
+        float* df1 = !want_f ? nullptr : d1;
+        conv_backward(&lc, Ly, params + P.o_w1[l], params + P.o_b1[l], params + P.o_w2[l], params + P.o_b2[l], params + P.o_s0[l],
+                      params + P.o_s1[l], g, f0, f1, x, saved + P.s_M[l], gout0, g1, df0, df1, d_x, grads + P.o_w1[l], grads + P.o_b1[l],
+                      grads + P.o_w2[l], grads + P.o_b2[l], grads + P.o_s0[l], grads + P.o_s1[l], cw, s, 1);
+        if (l > 0) {
+            // through the gate between layers l - 1 and l: (d0, d1) = d (f0_l, f1_l) -> (g0, g1) = d (p0, p1) of layer l - 1
+            const int c0 = P.c0[l];
+            hipLaunchKernelGGL(irrep_gate_bwd_kernel, dim3(P.gate_blocks), dim3(256), 0, s, saved + P.s_p0[l - 1], saved + P.s_p1[l - 1],
+                               params + P.o_gw[l - 1], params + P.o_gb[l - 1], d0, d1, N, c0, P.c1, g0, g1, slab);
+            hipLaunchKernelGGL(irrep_colsum_kernel, dim3(P.c1 * (c0 + 1)), dim3(256), 0, s, slab, P.gate_blocks, P.c1 * (c0 + 1),
+                               (const int*)nullptr, grads + P.o_gw[l - 1], c0 + 1, grads + P.o_gb[l - 1], 1);
+            gout0 = g0;
+        }
+    }
+    EQ_CHECK_LAUNCH("irrep_gnn_backward");
     return 0;
 }

@@ -75,7 +75,7 @@ class DataParallelStep:
         self.head_offset = 0
         if self.egnn is not None and hasattr(self.egnn, "rehome") and rest:
             # ONE buffer [EGNN block | pad to 64 floats | head parameters]: a single collective per step
-            pe = sum(p.numel() for p in self.egnn.parameters())
+            pe = self.egnn.flat_numel() if hasattr(self.egnn, "flat_numel") else sum(p.numel() for p in self.egnn.parameters())
             off = (pe + 2 + 63) // 64 * 64      # >= 2 spare words travel with the message (train.GraphedStep: per-rank step verdicts)
             self.head_offset = off
             ph = sum(p.numel() for p in rest)

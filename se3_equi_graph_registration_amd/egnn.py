@@ -19,6 +19,7 @@ import torch
 from torch import nn
 
 from . import ops
+from .flat import FlatParamsMixin
 from .ops import DeviceGraph
 
 
@@ -161,7 +162,7 @@ class _EgnnFn(torch.autograd.Function):
         return ghi, gxi, None, None, None, None, None
 
 
-class EGNN(nn.Module):
+class EGNN(FlatParamsMixin, nn.Module):
     """Drop-in for the reference ``EGNN`` (train :293-340)."""
 
     def __init__(self, in_node_nf, hidden_nf, out_node_nf, in_edge_nf=0, device="cuda:0", act_fn=nn.SiLU(), n_layers=5,
@@ -186,86 +187,12 @@ class EGNN(nn.Module):
         self._graph_cache = {}
         self.to(device)                                             # train :326
 
-    # -- flat parameter block ----------------------------------------------------------
-    def _ordered_params(self) -> List[nn.Parameter]:
-        return [p for _, p in self.named_parameters()]      # == C-ABI block order (include/equigspr.h)
-
-    def rehome(self, flat: torch.Tensor, grads: torch.Tensor):
-        """Move the parameter block and its gradient bucket into caller-owned storage (fp32, ``param_count`` elements
-        each, 16-byte aligned) -- ``dp.DataParallelStep`` uses this to put the EGNN and the pose-head parameters in ONE
-        buffer, so the gradient exchange is a single all-reduce."""
-        self._ensure_flat(storage=(flat, grads))
-
-    def _ensure_flat(self, storage=None):
-        ps = self._ordered_params()
-        flat = self.flat_params if storage is None else None
-        ok = flat is not None and flat.device == ps[0].device
-        if ok:
-            off = 0
-            base = flat.data_ptr()
-            for p in ps:
-                if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
-                    ok = False
-                    break
-                off += p.numel()
-        if ok:
-            return
-        dev = ps[0].device
-        if dev.type != "cuda":
-            raise RuntimeError("EGNN parameters are on %s: this package runs only on the MI355X (HIP) device; "
-                               "move the module with .to('cuda')" % dev)
-        total = sum(p.numel() for p in ps)
+    # -- flat parameter block: flat.FlatParamsMixin (named_parameters() order == the C-ABI block order, include/equigspr.h)
+    def _flat_layout(self):
+        offs, total = FlatParamsMixin._flat_layout(self)
         if total != ops.param_count(self.cfg):
             raise RuntimeError("internal: parameter count differs from the C-ABI block layout")
-        if storage is None:
-            flat = torch.empty(total, dtype=torch.float32, device=dev)
-            grads = torch.zeros(total, dtype=torch.float32, device=dev)
-        else:
-            flat, grads = storage
-            for t in (flat, grads):
-                if (t.dtype != torch.float32 or t.numel() != total or t.device != dev or not t.is_contiguous()
-                        or t.data_ptr() % 16):
-                    raise RuntimeError("EGNN.rehome: storage must be contiguous fp32 CUDA tensors of param_count elements, 16-byte aligned")
-            with torch.no_grad():
-                grads.zero_()
-        off = 0
-        with torch.no_grad():
-            for p in ps:
-                n = p.numel()
-                flat[off:off + n].copy_(p.detach().reshape(-1).float())
-                old_grad = p.grad
-                p.data = flat[off:off + n].view(p.shape)
-                if old_grad is not None:
-                    grads[off:off + n].copy_(old_grad.reshape(-1))
-                p.grad = grads[off:off + n].view(p.shape)
-                off += n
-        self.flat_params, self.flat_grads = flat, grads
-
-    def _attach_grads(self):
-        """(Re)attach ``.grad`` views into the flat bucket.  A parameter whose ``.grad`` is ``None``
-        was reset by ``optimizer.zero_grad(set_to_none=True)``: its slice of the bucket is zeroed
-        first, because the backward kernels ACCUMULATE into the bucket."""
-        ps = self._ordered_params()
-        missing = [p.grad is None for p in ps]
-        if not any(missing):
-            return
-        if all(missing):
-            self.flat_grads.zero_()
-        off = 0
-        for p, miss in zip(ps, missing):
-            n = p.numel()
-            if miss:
-                if not all(missing):
-                    self.flat_grads[off:off + n].zero_()
-                p.grad = self.flat_grads[off:off + n].view(p.shape)
-            off += n
-
-    def zero_grad(self, set_to_none: bool = False):          # keep the bucket views alive by default
-        if self.flat_grads is not None and not set_to_none:
-            self.flat_grads.zero_()
-            self._attach_grads()
-        else:
-            super().zero_grad(set_to_none=set_to_none)
+        return offs, total
 
     # -- graph handling ----------------------------------------------------------------
     def _graph_for(self, edges, n_nodes: int) -> DeviceGraph:

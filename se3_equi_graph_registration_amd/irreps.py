@@ -5,8 +5,8 @@ The reference ships the equivariant weight basis (``tools/basis.py::get_basis`` 
 ``IrrepConv`` is that layer for degrees 0 and 1: degree-0 features ``f0 [N, C0]`` and degree-1 features ``f1 [N, C1, 3]`` are BOTH
 carried through, every (d_in, d_out) path is a pairwise kernel ``sum_J R_J(|r_ij|) K_J(r_ij / |r_ij|)`` built from the basis tensors,
 messages are computed from the features at ``col`` and aggregated at ``row`` (the reference's conventions, train :252-256,:270-278),
-and a per-degree channel mixing acts as self-interaction.  The definition is written out in ``oracle/irreps_oracle.py`` (test
-infrastructure; parity unpinned by construction -- there is no reference layer -- pinned by SO(3) covariance).
+and a per-degree channel mixing acts as self-interaction.  The definition is written out in DESIGN.md section 2 and in the test
+infrastructure (parity unpinned by construction -- there is no reference layer -- pinned by SO(3) covariance).
 
 One kernel path (``csrc/irreps.hip``, round 5), forward and backward, no library call and no basis tensor in HBM:
   * the degree <= 1 basis in closed form inside the kernels (``sh.degree1_closed_form``: six constants fitted to ``get_basis``);
@@ -28,6 +28,7 @@ import torch
 from torch import nn
 
 from . import _lib, sh
+from .flat import FlatParamsMixin
 from .ops import DeviceGraph, _need, _p, _stream
 
 
@@ -151,3 +152,97 @@ class IrrepGNN(nn.Module):
                 v = v * torch.sigmoid(self.gates[i](h))[:, :, None]       # invariant gate: keeps degree 1 covariant
                 h = torch.nn.functional.silu(h)
         return h, v
+
+
+# ------------------------------------------------------------------------------------------------ the typed network behind the EGNN interface
+class _IrrepGnnFn(torch.autograd.Function):
+    """``equigspr_irrep_gnn_forward`` / ``_backward``: the whole stack in HIP launches; parameter gradients are accumulated by the
+    kernels straight into ``model.flat_grads`` (whose views are the parameters' ``.grad``), only the input gradients travel through
+    autograd (``anchor`` = one parameter, so that the node exists when only the weights require gradients)."""
+
+    @staticmethod
+    def forward(ctx, h, x, anchor, model, graph, training):
+        L = _lib.lib()
+        cfg, n, dev = model.cfg, x.shape[0], x.device
+        h_out = torch.empty(n, cfg.out_nf, dtype=torch.float32, device=dev)
+        x_out = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        saved = torch.empty(L.equigspr_irrep_gnn_saved_size(ctypes.byref(cfg), n, graph.n_edges), dtype=torch.float32, device=dev)
+        _lib.check(L.equigspr_irrep_gnn_forward(ctypes.byref(cfg), _p(model.flat_params), ctypes.byref(graph.struct), _p(h), _p(x),
+                                                _p(h_out), _p(x_out), _p(saved), _stream()), "irrep_gnn_forward")
+        if training:
+            ctx.save_for_backward(h, x, saved)
+            ctx.model, ctx.graph = model, graph
+        return h_out, x_out
+
+    @staticmethod
+    def backward(ctx, gh, gx):
+        h, x, saved = ctx.saved_tensors
+        model, graph = ctx.model, ctx.graph
+        L = _lib.lib()
+        cfg, n, dev = model.cfg, x.shape[0], x.device
+        gh = torch.zeros(n, cfg.out_nf, dtype=torch.float32, device=dev) if gh is None else gh.contiguous().float()
+        gx = torch.zeros(n, 3, dtype=torch.float32, device=dev) if gx is None else gx.contiguous().float()
+        model._attach_grads()
+        d_h = torch.empty_like(h) if ctx.needs_input_grad[0] else None
+        d_x = torch.zeros_like(x) if ctx.needs_input_grad[1] else None            # accumulated over the layers and the head
+        work = torch.empty(L.equigspr_irrep_gnn_work_size(ctypes.byref(cfg), n, graph.n_edges), dtype=torch.float32, device=dev)
+        _lib.check(L.equigspr_irrep_gnn_backward(ctypes.byref(cfg), _p(model.flat_params), ctypes.byref(graph.struct), _p(h), _p(x), _p(saved),
+                                                 _p(gh), _p(gx), _p(d_h), _p(d_x), _p(model.flat_grads), _p(work), _stream()),
+                   "irrep_gnn_backward")
+        return d_h, d_x, None, None, None, None
+
+
+class IrrepEGNN(FlatParamsMixin, nn.Module):
+    """The typed irrep-basis network behind the reference's ``EGNN`` interface (train :293-340; signature donor
+    ``src/clean_so3_model.py:162``): ``forward(h [N, in_node_nf], x [N, 3], edges, edge_attr) -> (h [N, out_node_nf], x [N, 3])``, so it
+    drops into ``CrossAttentionPoseRegression(egnn=IrrepEGNN(...))``, ``train.make_optimizer`` and ``train.GraphedStep`` unchanged.
+
+    ``n_layers`` x ``IrrepConv`` with degree-0 widths ``in -> hidden -> ... -> out`` and ``c1`` degree-1 channels (created from the
+    geometry by the 0 -> 1 path: the input has none), SiLU on degree 0 and an invariant sigmoid gate per degree-1 channel between
+    the layers, and the equivariant coordinate update ``x + sum_i w_x[i] v_i`` at the end: h is rotation / translation INVARIANT, x
+    covariant.  ``edge_attr`` is accepted and ignored (``in_edge_nf`` must be 0: the kernels of this layer are functions of the
+    geometry alone).  All parameters live in one flat block (``flat.FlatParamsMixin``); every launch is a hand-written HIP kernel
+    (``equigspr_irrep_gnn_forward`` / ``_backward``): 3 per layer forward, 8-10 per layer backward, hipGraph-capturable."""
+
+    def __init__(self, in_node_nf, hidden_nf, out_node_nf, in_edge_nf=0, device="cuda:0", n_layers=4, c1=8, radial_hidden=32):
+        super().__init__()
+        if in_edge_nf != 0:
+            raise NotImplementedError("IrrepEGNN: in_edge_nf must be 0 (the typed layer has no edge attribute input)")
+        self.in_node_nf, self.hidden_nf, self.out_node_nf, self.in_edge_nf = in_node_nf, hidden_nf, out_node_nf, 0
+        self.n_layers, self.c1, self.device = n_layers, c1, device
+        dims0 = [in_node_nf] + [hidden_nf] * (n_layers - 1) + [out_node_nf]
+        self.layers = nn.ModuleList([IrrepConv(dims0[i], c1, dims0[i + 1], c1, radial_hidden, device) for i in range(n_layers)])
+        self.gates = nn.ModuleList([nn.Linear(dims0[i + 1], c1) for i in range(n_layers - 1)])
+        self.coord = nn.Linear(c1, 1, bias=False)
+        nn.init.xavier_uniform_(self.coord.weight, gain=1e-3)           # a small coordinate step at initialisation, as train :219-220
+        self.cfg = _lib.IrrepGnnConfig(in_node_nf, hidden_nf, out_node_nf, c1, n_layers, radial_hidden, *sh.degree1_closed_form())
+        if _lib.lib().equigspr_irrep_gnn_param_count(ctypes.byref(self.cfg)) < 0:
+            raise NotImplementedError("IrrepEGNN: 1..32 channels per degree, 1..16 layers, radial_hidden 16 or 32")
+        self.to(device)
+
+    def _flat_layout(self):
+        L = _lib.lib()
+        cfg = ctypes.byref(self.cfg)
+        offs = []
+        for l in range(self.n_layers):
+            offs += [int(L.equigspr_irrep_gnn_param_offset(cfg, l, w)) for w in range(6)]
+        for l in range(self.n_layers - 1):
+            offs += [int(L.equigspr_irrep_gnn_param_offset(cfg, l, 6)), int(L.equigspr_irrep_gnn_param_offset(cfg, l, 7))]
+        offs.append(int(L.equigspr_irrep_gnn_param_offset(cfg, 0, 8)))
+        ps = self._ordered_params()
+        if len(offs) != len(ps) or min(offs) < 0:
+            raise RuntimeError("internal: IrrepEGNN parameters do not match the C-ABI block layout")
+        return offs, int(L.equigspr_irrep_gnn_param_count(cfg))
+
+    def forward(self, h, x, edges, edge_attr=None):
+        self._ensure_flat()
+        if h.dim() != 2 or x.dim() != 2 or h.shape[1] != self.in_node_nf or x.shape[1] != 3 or h.shape[0] != x.shape[0]:
+            raise RuntimeError(f"IrrepEGNN.forward expects h [N, {self.in_node_nf}] and x [N, 3] (one cloud or a pre-batched graph)")
+        h = _need(h.contiguous().float(), "h", torch.float32, 2)
+        x = _need(x.contiguous().float(), "x", torch.float32, 2)
+        anchor = self.coord.weight
+        training = torch.is_grad_enabled() and (anchor.requires_grad or h.requires_grad or x.requires_grad)
+        graph = IrrepConv._graph(edges, h.shape[0], need_col_index=training)
+        if training and graph.cptr is None:
+            raise RuntimeError("IrrepEGNN.forward: training needs a DeviceGraph built with need_col_index=True")
+        return _IrrepGnnFn.apply(h, x, anchor, self, graph, training)

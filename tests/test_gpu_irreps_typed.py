@@ -168,3 +168,76 @@ def test_unsupported_shapes_and_cpu_tensors_fail_loudly(pk):
     layer = pk.IrrepConv(4, 4, 4, 4)
     with pytest.raises(RuntimeError):
         layer(torch.zeros(5, 4), torch.zeros(5, 4, 3), torch.zeros(5, 3), [torch.zeros(3, dtype=torch.long), torch.zeros(3, dtype=torch.long)])
+
+
+@pytest.mark.parametrize("dims", [(32, 32, 32, 8, 3, 32), (12, 20, 8, 4, 2, 16), (30, 32, 27, 7, 2, 32)])
+def test_irrep_egnn_matches_the_definition_forward_and_backward(pk, dims):
+    """The typed network behind the EGNN interface (equigspr_irrep_gnn_forward / _backward: convolutions, gates, coordinate head in
+    HIP launches, parameter gradients accumulated into the flat bucket) against the fp64 autograd of its definition: outputs, the
+    gradients of h and x and of EVERY parameter; odd channel counts (30, 27, 7) exercise the 16-byte padding of the parameter block."""
+    in_nf, hid, out_nf, c1, layers, rh = dims
+    n, e = 150, 2000
+    g, row, col = _graph(8, n, e)
+    torch.manual_seed(3 + sum(dims))
+    net = pk.IrrepEGNN(in_nf, hid, out_nf, n_layers=layers, c1=c1, radial_hidden=rh)
+    with torch.no_grad():
+        net.coord.weight.mul_(300.0)                       # a visible coordinate update
+    x = torch.randn(n, 3, generator=g)
+    h = torch.randn(n, in_nf, generator=g)
+    th, tx = torch.randn(n, out_nf, generator=g), torch.randn(n, 3, generator=g)
+    ah, ax = h.cuda().requires_grad_(True), x.cuda().requires_grad_(True)
+    ho, xo = net(ah, ax, [row.cuda(), col.cuda()], None)
+    net.zero_grad()
+    ((ho * th.cuda()).sum() + (xo * tx.cuda()).sum()).backward()
+    w = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    bh, bx = h.double().requires_grad_(True), x.double().requires_grad_(True)
+    rh_, rx_ = io.irrep_egnn(w, bh, bx, [row, col], layers)
+    ((rh_ * th.double()).sum() + (rx_ * tx.double()).sum()).backward()
+    s = max(1.0, float(rh_.abs().max()))
+    assert float((ho.detach().cpu().double() - rh_).abs().max()) <= 3e-5 * s
+    assert float((xo.detach().cpu().double() - rx_).abs().max()) <= 3e-5 * max(1.0, float(rx_.abs().max()))
+    for name, got, want in [("h", ah.grad, bh.grad), ("x", ax.grad, bx.grad)] + [(k, p.grad, w[k].grad) for k, p in net.named_parameters()]:
+        assert got is not None and want is not None, name
+        want = want.reshape(got.shape)
+        tol = 1e-4 * max(1.0, float(want.abs().max()))
+        assert float((got.cpu().double() - want).abs().max()) <= tol, (name, float((got.cpu().double() - want).abs().max()), tol)
+    # the parameters are views into one flat block, their gradients views into one flat bucket
+    assert all(p.data_ptr() >= net.flat_params.data_ptr() and p.data_ptr() < net.flat_params.data_ptr() + 4 * net.flat_params.numel()
+               for p in net.parameters())
+    assert float(net.flat_grads.abs().sum()) > 0
+
+
+def test_irrep_egnn_is_se3_covariant_and_drops_into_the_pair_model(pk):
+    """h invariant, x covariant under rotation + translation at 2 x 2048 points, k = 20; and the network replaces the frame-vector EGNN
+    inside CrossAttentionPoseRegression: one training step (forward, fused head, backward, flat Adam) runs and changes the weights."""
+    from se3_equi_graph_registration_amd import train
+    b = pk.synthetic_batch(5, 1, n=2048, device="cuda")
+    graph = pk.build_pair_graph(b["src"], b["tgt"], 20)
+    x = torch.cat([b["src"][0], b["tgt"][0]]).contiguous()
+    h = torch.cat([b["feat_src"][0], b["feat_tgt"][0]]).contiguous()
+    torch.manual_seed(0)
+    net = pk.IrrepEGNN(32, 32, 32, n_layers=4, c1=8)
+    with torch.no_grad():
+        net.coord.weight.mul_(300.0)
+    rm = torch.from_numpy(so._rot(0.4, 2.2, 5.0)).float().cuda()
+    t = torch.tensor([0.3, -1.1, 0.7], device="cuda")
+    with torch.no_grad():
+        h1, x1 = net(h, x, graph, None)
+        h2, x2 = net(h, (x @ rm.T + t).contiguous(), graph, None)
+    assert float((x1 - x).abs().max()) > 1e-3
+    assert float((h2 - h1).abs().max()) <= 5e-5 * max(1.0, float(h1.abs().max()))
+    assert float((x2 - (x1 @ rm.T + t)).abs().max()) <= 5e-5 * max(1.0, float(x1.abs().max()))
+    # inside the pair model
+    torch.manual_seed(1)
+    egnn = pk.IrrepEGNN(32, 32, 32, n_layers=2, c1=8)
+    model = pk.CrossAttentionPoseRegression(egnn, num_nodes=2048, hidden_nf=32, device="cuda").cuda()
+    opt = train.make_optimizer(model, lr=1e-3)
+    before = egnn.flat_params.clone()
+    bb = pk.synthetic_batch(77, 2, n=2048)
+    batches = [(bb["corr"], bb["labels"], bb["src"], bb["tgt"], bb["feat_src"], bb["feat_tgt"], bb["gt_pose"])] * 3
+    loss = train.train_one_epoch(model, batches, opt, "cuda", 0, log_interval=0, k=20, skip_nonfinite=True)
+    st = opt.adam.guard_stats()
+    assert st["applied"] + st["skipped"] == 3 and st["applied"] >= 1 and loss == loss
+    assert not torch.equal(before, egnn.flat_params)
+    gs = train.graphed_step_for(model, opt, k=20)
+    assert gs.steps_replayed >= 1, (gs.graph_mode, gs.steps_eager)

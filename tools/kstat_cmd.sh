@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=$1; shift
 OUT=$ROOT/gpurun_out/kstat_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k -- python3 "$@" > $OUT/out.txt 2> $OUT/err.txt
+S=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k -- python3 $ROOT/$S "$@" > $OUT/out.txt 2> $OUT/err.txt
 cd $ROOT
 python3 - <<PY
 import csv, glob
