@@ -76,6 +76,10 @@ def parse(argv=None):
                          "KITTI batch (8 pairs x 4096 pts, F=33); c5 = eval sweep (8192 pts, k=32, 8 layers, inference)")
     ap.add_argument("--edge-basis", choices=["frames", "irreps"], default="frames",
                     help="frames = the reference's edge inputs; irreps = the fused irrep-basis message passing (SURVEY 8(f) N4, configs[2])")
+    ap.add_argument("--network", choices=["egnn", "irreps"], default="egnn",
+                    help="egnn = the reference's frame-vector EGNN (E_GCL); irreps = the typed irrep-basis network behind the same interface "
+                         "(irreps.IrrepEGNN: degree-0 + degree-1 features through tensor-field layers, SURVEY 8(f) N4)")
+    ap.add_argument("--c1", type=int, default=8, help="--network irreps: degree-1 channels")
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="repeat the timed block of --steps steps until this much time has been measured; report the median block")
     ap.add_argument("--allow-eager", action="store_true", help="N>1: fall back to eager launches if hipGraph capture fails (default: exit non-zero)")
@@ -98,7 +102,7 @@ def parse(argv=None):
                          "spatial re-ordering inside the EGNN could buy at most; DESIGN section 10)")
     a = ap.parse_args(argv)
     a.explicit_workload = a.workload is not None or a.batch != 1 or a.n != 2048 or a.k != 20 or a.layers != 4 or a.feat != 32 or \
-        a.heads != 1 or a.forward_only or a.edge_basis != "frames" or a.global_batch > 0 or a.dev_no_head or a.aten_head or a.fixed_pair_replay or a.morton
+        a.heads != 1 or a.forward_only or a.edge_basis != "frames" or a.global_batch > 0 or a.dev_no_head or a.aten_head or a.fixed_pair_replay or a.morton or a.network != "egnn"
     if a.workload == "c3":
         a.batch = 16
     elif a.workload == "c4":
@@ -108,10 +112,16 @@ def parse(argv=None):
     return a
 
 
+def make_network(pkg, args, dev):
+    if args.network == "irreps":
+        return pkg.IrrepEGNN(args.feat, args.feat, args.feat, device=dev, n_layers=args.layers, c1=args.c1)
+    return pkg.EGNN(args.feat, args.feat, args.feat, in_edge_nf=1, device=dev, n_layers=args.layers, num_heads=args.heads,
+                    edge_basis=args.edge_basis)
+
+
 def build_step(pkg, args, dev, world):
     torch.manual_seed(0)
-    egnn = pkg.EGNN(args.feat, args.feat, args.feat, in_edge_nf=1, device=dev, n_layers=args.layers, num_heads=args.heads,
-                    edge_basis=args.edge_basis)
+    egnn = make_network(pkg, args, dev)
     variant = "eval" if (args.eval_head and args.forward_only) else "train"
     model = pkg.CrossAttentionPoseRegression(egnn, num_nodes=args.n, hidden_nf=args.feat, device=dev, variant=variant,
                                              fused_head=not args.aten_head).to(dev)
@@ -210,7 +220,7 @@ def uses_product_loop(args):
     (the body of train.evaluate_model); the plain inference forward and the developer variants keep the harness-side capture."""
     if args.fixed_pair_replay or args.dev_no_head or args.aten_head:
         return False
-    return (not args.forward_only) or (args.eval_head and args.batch == 1 and args.global_batch == 0)
+    return (not args.forward_only) or (args.eval_head and args.global_batch == 0)
 
 
 def build_product_eval(pkg, args, dev, world):
@@ -218,9 +228,9 @@ def build_product_eval(pkg, args, dev, world):
     ring of distinct synthetic HOST pairs -- graphs, EGNN forward, evaluation head AND the four metrics per pair, H2D inside."""
     from se3_equi_graph_registration_amd import train
     torch.manual_seed(0)
-    egnn = pkg.EGNN(args.feat, args.feat, args.feat, in_edge_nf=1, device=dev, n_layers=args.layers, num_heads=args.heads,
-                    edge_basis=args.edge_basis)
+    egnn = make_network(pkg, args, dev)
     model = pkg.CrossAttentionPoseRegression(egnn, num_nodes=args.n, hidden_nf=args.feat, device=dev, variant="eval").to(dev)
+    model.batched_eval = args.batch > 1          # extension: B independent pairs per launch (the reference evaluates one at a time)
     model.eval()
     egnn._ensure_flat()
     from se3_equi_graph_registration_amd.dp import DataParallelStep
@@ -229,7 +239,7 @@ def build_product_eval(pkg, args, dev, world):
     n_batches = max(2, min(args.ring, 16))
     ring = []
     for j in range(n_batches):
-        b = pkg.synthetic_batch(1234 + rank * n_batches + j, 1, n=args.n, feat=args.feat, scale=(3.0, 3.0, 3.0))
+        b = pkg.synthetic_batch(1234 + (rank * n_batches + j) * args.batch, args.batch, n=args.n, feat=args.feat, scale=(3.0, 3.0, 3.0))
         ring.append((b["corr"], b["labels"], b["src"], b["tgt"], b["feat_src"], b["feat_tgt"], b["gt_pose"]))
     batch = {k: v.to(dev) for k, v in zip(("corr", "labels", "src", "tgt", "feat_src", "feat_tgt", "gt_pose"), ring[0])}
     stepper = train.GraphedEval(model, k=args.k, use_graphs=not args.no_graph)
@@ -254,8 +264,7 @@ def build_product(pkg, args, dev, world):
     from se3_equi_graph_registration_amd import train
     from se3_equi_graph_registration_amd.dp import shard_range
     torch.manual_seed(0)
-    egnn = pkg.EGNN(args.feat, args.feat, args.feat, in_edge_nf=1, device=dev, n_layers=args.layers, num_heads=args.heads,
-                    edge_basis=args.edge_basis)
+    egnn = make_network(pkg, args, dev)
     model = pkg.CrossAttentionPoseRegression(egnn, num_nodes=args.n, hidden_nf=args.feat, device=dev, variant="train").to(dev)
     model.train()
     opt = train.make_optimizer(model, lr=1e-4)                  # reference: torch.optim.Adam(model.parameters(), lr) train :1412
@@ -452,8 +461,73 @@ def issue_floor_us(E, F, bwd):
     return cyc / (ISSUE_CLOCK_GHZ * 1e3)
 
 
+def roofline_irreps(pkg, S, args, dev):
+    """--network irreps: HIP-event timing of ONE typed message-passing layer (irreps.IrrepConv, hidden -> hidden channels), forward
+    (moments + node launch) and backward (adjoint moments + node, expand, geometry, dx, weight gradients, reduce), on the stream the
+    launches go to.  Algorithmic bytes per edge and layer, forward: the gathered source rows (C0 + 3 C1) * 4 + both endpoints'
+    coordinates 24 + indices 8 + the edge's contribution to the destination rows (C0 + 3 C1) * 4; backward twice that."""
+    batch = S["batch"]
+    B, N = args.batch, args.n
+    graph = pkg.build_pair_graph(batch["src"], batch["tgt"], args.k, loop=True)
+    x = torch.cat([batch["src"].reshape(B * N, 3), batch["tgt"].reshape(B * N, 3)]).contiguous()
+    layer = S["egnn"].layers[min(1, len(S["egnn"].layers) - 1)]
+    c0, c1 = layer.c0_in, layer.c1_in
+    g = torch.Generator(device="cpu").manual_seed(3)
+    f0 = torch.randn(x.shape[0], c0, generator=g).to(dev)
+    f1 = torch.randn(x.shape[0], c1, 3, generator=g).to(dev)
+    E = graph.n_edges
+
+    def timed(fn, iters=20, reps=5):
+        vals = []
+        for _ in range(reps):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            e1.synchronize()
+            vals.append(e0.elapsed_time(e1) / iters)
+        return sorted(vals)[reps // 2]
+
+    def fwd():
+        with torch.no_grad():
+            layer(f0, f1, x, graph)
+    fwd_ms = timed(fwd)
+    bwd_ms = None
+    if not args.forward_only:
+        a0, a1, ax = f0.clone().requires_grad_(True), f1.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        o0, o1 = layer(a0, a1, ax, graph)
+        go0, go1 = torch.randn_like(o0), torch.randn_like(o1)
+        bwd_ms = timed(lambda: torch.autograd.backward([o0, o1], [go0, go1], retain_graph=True))
+        layer.zero_grad()
+    bytes_fwd = ((c0 + 3 * c1) * 4 + 24 + 8 + (layer.c0_out + 3 * layer.c1_out) * 4) * E
+    bytes_bwd = 2 * bytes_fwd
+    H = layer.hidden
+    lc = 4 * ((c0 + 15) // 16 * 16) + 10 * (8 if c1 <= 8 else 16 if c1 <= 16 else 32)
+    flops_fwd = 2 * (4 * c0 + 10 * c1) * (H + 1) * E + 2 * layer.n_w * (H + 1) * graph.n_nodes     # outer products per edge + radial weights per node
+    dom_b = bwd_ms is not None
+    ms = bwd_ms if dom_b else fwd_ms
+    by = bytes_bwd if dom_b else bytes_fwd
+    roof = {"bound": "hbm", "kernel": ("irrep_conv layer backward: adjoint irrep_moments16 + irrep_node16, irrep_expand16, irrep_geom_bwd, irrep_dx, "
+                                       "irrep_wgrad16, irrep_wreduce (8 launches)" if dom_b else
+                                       "irrep_conv layer forward: irrep_moments16_kernel + irrep_node16_kernel (2 launches)"),
+            "achieved": round(by / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "traffic": None, "traffic_source": None, "edges_per_launch": E, "algorithmic_bytes_per_launch": by, "launch_ms": round(ms, 5),
+            "launch_ms_note": "HIP events around back-to-back calls of one layer (all of its launches); the aggregate-then-transform form moves "
+                              f"per-node moments of {lc * (H + 1) * 4} B per node through HBM between its two launches -- traffic the algorithmic "
+                              "byte count does not contain",
+            "fwd_frac": round(bytes_fwd / (fwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "issue_floor_us": None, "in_step_launch_us": None,
+            "in_step_frac": None, "in_step_source": None, "backward_mode": "moments kept by the forward (N x Lc x (H + 1) floats per layer)"}
+    extra = {"layer_fwd_ms": round(fwd_ms, 5), "layer_bwd_ms": None if bwd_ms is None else round(bwd_ms, 5), "channels": [c0, c1], "radial_hidden": H,
+             "moment_bytes_per_layer": graph.n_nodes * lc * (H + 1) * 4, "layer_fwd_fp32_frac": round(flops_fwd / (fwd_ms * 1e-3) / 1e12 / FP32_PEAK_TF, 5)}
+    return roof, extra
+
+
 def roofline(pkg, S, args, dev):
     """HIP-event timing of the edge (message-passing) kernels, forward and backward, on the stream they are launched on."""
+    if args.network == "irreps":
+        return roofline_irreps(pkg, S, args, dev)
     from se3_equi_graph_registration_amd import _lib, ops
     L = _lib.lib()
     egnn, batch = S["egnn"], S["batch"]
@@ -768,7 +842,9 @@ def measure(pkg, args, dev, world, min_seconds):
 def workload_text(args):
     head = "evaluation pair model (eval :643-827)" if (args.eval_head and args.forward_only) else "pose head (Kabsch/SVD)"
     return (f"{'inference' if args.forward_only else 'training'} step: {args.batch} pair(s)/GPU x {args.n} pts, k={args.k}, "
-            f"{args.layers} EGNN layers, F={args.feat}, heads={args.heads}, edge inputs={args.edge_basis}; kNN+index, EGNN fwd, {head}, "
+            + (f"{args.layers} EGNN layers, F={args.feat}, heads={args.heads}, edge inputs={args.edge_basis}" if args.network == "egnn" else
+               f"{args.layers} typed irrep-basis layers (IrrepEGNN: {args.feat} degree-0 + {args.c1} degree-1 channels)")
+            + f"; kNN+index, network fwd, {head}, "
             + ("no backward" if args.forward_only else "losses, backward, grad all-reduce, Adam"))
 
 
@@ -783,6 +859,12 @@ EXTRA_WORKLOADS = (
     ("c3_b16_irreps", "configs[2]: 3DMatch training, batch=16, fused irrep-basis + message-passing kernel", ["--workload", "c3", "--edge-basis", "irreps"], 80),
     ("c4_shard", "configs[3]: one GPU's shard of the KITTI batch (8 of 64 pairs x 4096 pts, F=33), training", ["--workload", "c4"], 60),
     ("c5_eval", "configs[4]: 3DMatch eval sweep pair, 8192 pts, k=32, 8 layers, evaluation pair model", ["--workload", "c5"], 200),
+    ("c1_infer", "configs[0] on the GPU: one 2048-pt pair, k=20, 4 layers, forward + evaluation head + metrics (train.GraphedEval)",
+     ["--forward-only", "--eval-head"], 400),
+    ("c1_infer_b16", "configs[0] batched: 16 independent 2048-pt pairs per launch through the same loop (model.batched_eval)",
+     ["--forward-only", "--eval-head", "--batch", "16"], 60),
+    ("irrepgnn", "N4: the typed irrep-basis network (32 degree-0 + 8 degree-1 channels, 4 layers) in the pair model, one 2048-pt pair, k=20, training step",
+     ["--network", "irreps"], 100),
 )
 EXTRA_WORKLOADS_MULTI = (
     ("c3_b16", "configs[2] shape: 3DMatch training, 16 pairs per GPU (weak scaling)", ["--workload", "c3"], 80),

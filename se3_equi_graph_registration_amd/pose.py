@@ -195,8 +195,10 @@ class CrossAttentionPoseRegression(nn.Module):
         """eval :643-827 (B = 1), including the [K] vs [1,K,1] broadcasting quirk of :742,:758-768:
         only the first MLP score p[0] ever reaches the weights."""
         B, N, Fd = h_src.shape
-        if B != 1:
-            raise RuntimeError("the evaluation head is defined for batch size 1 only (eval :719,:773)")
+        batched = B != 1 and getattr(self, "batched_eval", False)
+        if B != 1 and not batched:
+            raise RuntimeError("the evaluation head is defined for batch size 1 only (eval :719,:773); set model.batched_eval = True to "
+                               "evaluate B independent pairs per call (extension: every pair gets exactly what a batch-of-one call gives it)")
         hs, xs, ht, xt = self._run_egnn(h_src, x_src, edges_src, ea_src, h_tgt, x_tgt, edges_tgt, ea_tgt)
         if self.topk > N:
             raise RuntimeError(f"top-k of {self.topk} out of {N} points (torch.topk raises in the reference, eval :694)")
@@ -212,6 +214,8 @@ class CrossAttentionPoseRegression(nn.Module):
                                                                       self.topk, mlp_params)
             self.last_weights, self.last_top_idx, self.last_p0 = wts, top_idx, p0
             return R, t, None, total_loss, hs, xs, ht, xt, labels
+        if batched:
+            raise RuntimeError("batched_eval needs the fused evaluation head (no_grad, N <= 8192, widths <= 64)")
         total_loss = egnn_equi_loss(hs, xs, ht, xt, gt_pose[:, :3, :3], gt_pose[:, :3, -1], labels)
         sim0 = torch.sum(h_src * h_tgt, dim=-1, keepdim=True)                                              # :691
         _, top_idx = torch.topk(sim0.squeeze(-1), k=self.topk, dim=-1)                                     # :694

@@ -327,3 +327,33 @@ def test_kitti_loss_mode_width_33_through_the_graphed_loop(pk):
     assert st.steps_replayed == 4 and st.graph_mode == "one graph"
     _assert_same(_state(m_e, o_e), _state(m_g, o_g))
     assert lg == pytest.approx(le, rel=1e-6)
+
+
+def test_batched_evaluation_equals_per_pair_evaluation_bit_for_bit(pk):
+    """B independent pairs per launch (model.batched_eval; the reference evaluates one pair per call, eval
+    :719) give every pair EXACTLY the R, t and metrics of its own batch-of-one call -- through the eager model and through
+    train.GraphedEval."""
+    from se3_equi_graph_registration_amd import train
+    model = _model(pk, seed=5)
+    model.variant = "eval"
+    model.eval()
+    b = pk.synthetic_batch(300, 4, n=256, feat=32, device="cuda")
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="batch size 1 only"):
+            g4 = pk.build_pair_graph(b["src"], b["tgt"], 8)
+            model(b["feat_src"], b["src"], g4, None, b["feat_tgt"], b["tgt"], g4, None, None, b["labels"], b["gt_pose"])
+        model.batched_eval = True
+        g4 = pk.build_pair_graph(b["src"], b["tgt"], 8)
+        R4, t4 = model(b["feat_src"], b["src"], g4, None, b["feat_tgt"], b["tgt"], g4, None, None, b["labels"], b["gt_pose"])[:2]
+        for i in range(4):
+            sl = slice(i, i + 1)
+            g1 = pk.build_pair_graph(b["src"][sl].contiguous(), b["tgt"][sl].contiguous(), 8)
+            R1, t1 = model(b["feat_src"][sl].contiguous(), b["src"][sl].contiguous(), g1, None, b["feat_tgt"][sl].contiguous(),
+                           b["tgt"][sl].contiguous(), g1, None, None, b["labels"][sl].contiguous(), b["gt_pose"][sl].contiguous())[:2]
+            assert torch.equal(R1[0], R4[i]) and torch.equal(t1[0], t4[i]), i
+    host = {k: v.cpu() for k, v in b.items()}
+    tup = lambda sl: (host["corr"][sl], host["labels"][sl], host["src"][sl], host["tgt"][sl], host["feat_src"][sl], host["feat_tgt"][sl], host["gt_pose"][sl])
+    batched = train.GraphedEval(model, k=8).run([tup(slice(0, 4))] * 3)
+    model.batched_eval = False
+    single = train.GraphedEval(model, k=8).run([tup(slice(i, i + 1)) for i in range(4)] * 3)
+    assert batched.shape == (12, 5) and torch.equal(batched, single)
