@@ -331,8 +331,11 @@ int64_t equigspr_irrep_moments_size(const equigspr_irrep_config* cfg, int32_t n_
 /* floats of scratch equigspr_irrep_conv_backward needs */
 int64_t equigspr_irrep_bwd_work_size(const equigspr_irrep_config* cfg, int32_t n_nodes, int32_t n_edges);
 
-/* Forward: two launches (moments: closed-form basis x gathered features x radial hidden activations, aggregated per node in
- * ascending edge order on the matrix cores; node: the radial weights applied to the moments + bias + self-interaction).
+/* Forward.  keep_moments != 0 (training): two launches (moments: closed-form basis x gathered features x radial hidden
+ * activations, aggregated per node in ascending edge order on the matrix cores; node: the radial weights applied to the moments +
+ * bias + self-interaction).  keep_moments == 0 (inference): ONE fused launch when the shape allows it (<= 32 degree-0 and <= 8
+ * degree-1 input channels, H = 32): the moments of 16 nodes go through an LDS tile in chunks and never reach HBM (`moments` is then
+ * only scratch for the shapes the fused kernel does not take; always pass it).
  *   w_r1 [H], b_r1 [H] (radial.0), w_r2 [n_w, H], b_r2 [n_w] (radial.2), w_self0 [C0o, C0i], w_self1 [C1o, C1i];
  *   g: row / col / rptr / rperm (cptr / cperm for the backward); f0 [N, C0i], f1 [N, C1i, 3], x [N, 3];
  *   out0 [N, C0o], out1 [N, C1o, 3]; moments: equigspr_irrep_moments_size floats (kept by the caller for the backward).
@@ -340,7 +343,7 @@ int64_t equigspr_irrep_bwd_work_size(const equigspr_irrep_config* cfg, int32_t n
 int equigspr_irrep_conv_forward(const equigspr_irrep_config* cfg, const float* w_r1, const float* b_r1, const float* w_r2,
                                 const float* b_r2, const float* w_self0, const float* w_self1, const equigspr_graph* g,
                                 const float* f0, const float* f1, const float* x, float* out0, float* out1, float* moments,
-                                void* stream);
+                                int32_t keep_moments, void* stream);
 /* Backward for EVERY input: the features (d_f0, d_f1: the adjoint convolution = the same two kernels on the reversed edges with
  * transposed weights), the geometry (d_x [N, 3], ACCUMULATED: a stack of layers on fixed coordinates sums into one buffer) and
  * all six parameter tensors (OVERWRITTEN).  `moments` = what the forward of the same inputs left.  d_f0 / d_f1 / d_x may be NULL
@@ -368,10 +371,11 @@ int64_t equigspr_irrep_gnn_param_count(const equigspr_irrep_gnn_config* cfg);   
 int64_t equigspr_irrep_gnn_param_offset(const equigspr_irrep_gnn_config* cfg, int32_t layer, int32_t which);
 int64_t equigspr_irrep_gnn_saved_size(const equigspr_irrep_gnn_config* cfg, int32_t n_nodes, int32_t n_edges);
 int64_t equigspr_irrep_gnn_work_size(const equigspr_irrep_gnn_config* cfg, int32_t n_nodes, int32_t n_edges);
-/* forward: 3 launches per layer (moments, node, gate / coordinate head); `saved` (saved_size floats) holds the layer inputs, the
- * pre-gate outputs and the moments -- the backward's inputs, and the forward's own buffers (always required). */
+/* forward: 3 launches per layer (moments, node, gate / coordinate head; training == 0: the fused convolution where the shape allows
+ * it, 2 launches per layer); `saved` (saved_size floats) holds the layer inputs, the pre-gate outputs and the moments -- the
+ * backward's inputs, and the forward's own buffers (always required). */
 int equigspr_irrep_gnn_forward(const equigspr_irrep_gnn_config* cfg, const float* params, const equigspr_graph* g, const float* h_in,
-                               const float* x, float* h_out, float* x_out, float* saved, void* stream);
+                               const float* x, float* h_out, float* x_out, float* saved, int32_t training, void* stream);
 /* backward: parameter gradients are ACCUMULATED into `grads` (same layout as `params`; the flat gradient bucket of the optimizer and
  * the all-reduce), d_x [N, 3] is ACCUMULATED (may be NULL), d_h_in [N, in_nf] is overwritten (may be NULL). */
 int equigspr_irrep_gnn_backward(const equigspr_irrep_gnn_config* cfg, const float* params, const equigspr_graph* g, const float* h_in,

@@ -87,12 +87,12 @@ _SIGNATURES = {
     "equigspr_sh_basis_forward": (ctypes.c_int, [c_void_p, ctypes.c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "equigspr_irrep_moments_size": (c_int64, [POINTER(IrrepConfig), c_int32]),
     "equigspr_irrep_bwd_work_size": (c_int64, [POINTER(IrrepConfig), c_int32, c_int32]),
-    "equigspr_irrep_conv_forward": (ctypes.c_int, [POINTER(IrrepConfig)] + [c_void_p] * 6 + [POINTER(Graph)] + [c_void_p] * 7),
+    "equigspr_irrep_conv_forward": (ctypes.c_int, [POINTER(IrrepConfig)] + [c_void_p] * 6 + [POINTER(Graph)] + [c_void_p] * 6 + [c_int32, c_void_p]),
     "equigspr_irrep_gnn_param_count": (c_int64, [POINTER(IrrepGnnConfig)]),
     "equigspr_irrep_gnn_param_offset": (c_int64, [POINTER(IrrepGnnConfig), c_int32, c_int32]),
     "equigspr_irrep_gnn_saved_size": (c_int64, [POINTER(IrrepGnnConfig), c_int32, c_int32]),
     "equigspr_irrep_gnn_work_size": (c_int64, [POINTER(IrrepGnnConfig), c_int32, c_int32]),
-    "equigspr_irrep_gnn_forward": (ctypes.c_int, [POINTER(IrrepGnnConfig), c_void_p, POINTER(Graph)] + [c_void_p] * 6),
+    "equigspr_irrep_gnn_forward": (ctypes.c_int, [POINTER(IrrepGnnConfig), c_void_p, POINTER(Graph)] + [c_void_p] * 5 + [c_int32, c_void_p]),
     "equigspr_irrep_gnn_backward": (ctypes.c_int, [POINTER(IrrepGnnConfig), c_void_p, POINTER(Graph)] + [c_void_p] * 10),
     "equigspr_irrep_conv_backward": (ctypes.c_int, [POINTER(IrrepConfig)] + [c_void_p] * 6 + [POINTER(Graph)] + [c_void_p] * 17),
     "equigspr_eval_metrics": (ctypes.c_int, [c_void_p] * 5 + [c_int32, c_int32, ctypes.c_double, c_void_p, c_void_p]),

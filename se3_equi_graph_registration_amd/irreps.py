@@ -56,7 +56,7 @@ class _IrrepConvFn(torch.autograd.Function):
         moments = torch.empty(L.equigspr_irrep_moments_size(ctypes.byref(cfg), n), dtype=torch.float32, device=dev)
         _lib.check(L.equigspr_irrep_conv_forward(ctypes.byref(cfg), _p(w1), _p(b1), _p(w2), _p(b2), _p(ws0), _p(ws1),
                                                  ctypes.byref(graph.struct), _p(f0), _p(f1), _p(x), _p(out0), _p(out1), _p(moments),
-                                                 _stream()), "irrep_conv_forward")
+                                                 int(bool(training)), _stream()), "irrep_conv_forward")
         if training:
             ctx.save_for_backward(f0, f1, x, w1, b1, w2, b2, ws0, ws1, moments)
             ctx.cfg, ctx.graph = cfg, graph
@@ -168,7 +168,7 @@ class _IrrepGnnFn(torch.autograd.Function):
         x_out = torch.empty(n, 3, dtype=torch.float32, device=dev)
         saved = torch.empty(L.equigspr_irrep_gnn_saved_size(ctypes.byref(cfg), n, graph.n_edges), dtype=torch.float32, device=dev)
         _lib.check(L.equigspr_irrep_gnn_forward(ctypes.byref(cfg), _p(model.flat_params), ctypes.byref(graph.struct), _p(h), _p(x),
-                                                _p(h_out), _p(x_out), _p(saved), _stream()), "irrep_gnn_forward")
+                                                _p(h_out), _p(x_out), _p(saved), int(bool(training)), _stream()), "irrep_gnn_forward")
         if training:
             ctx.save_for_backward(h, x, saved)
             ctx.model, ctx.graph = model, graph

@@ -48,5 +48,10 @@ def fwd_bwd():
 
 lc = 4 * ((c0 + 15) // 16 * 16) + 10 * (8 if c1 <= 8 else 16 if c1 <= 16 else 32)
 print(f"pairs={B}: N={n} E={graph.n_edges} channels {c0}+{c1} hidden {layer.hidden} n_w={layer.n_w}  moments {n * lc * 33 * 4 / 1e6:.0f} MB")
-print(f"   forward (2 launches):              {t(fwd):9.1f} us")
+def fwd_train():
+    o0, o1 = layer(a0, a1, ax, graph)
+
+
+print(f"   forward, inference (fused: 1 launch):  {t(fwd):9.1f} us")
+print(f"   forward, training (moments kept: 2 launches): {t(fwd_train):9.1f} us")
 print(f"   forward + backward (eager, autograd): {t(fwd_bwd):9.1f} us")
