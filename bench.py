@@ -601,10 +601,8 @@ def roofline(pkg, S, args, dev):
     mfma_width = F in (32, 33)
     if mfma_width:
         kname = ("edge_bwd16_kernel" if dom_is_bwd else "edge_fwd16_kernel") + (" (hidden_nf 33: border variant)" if F == 33 else "")
-    elif F % 16 == 0:
-        kname = ("edge_bwd_fp_kernel" if dom_is_bwd else "edge_fwd_fp_kernel") + f" (hidden_nf {F}: feature-parallel MFMA kernels, csrc/egnn_edge_fp.h)"
     else:
-        kname = ("edge_bwd_lane_kernel" if dom_is_bwd else "edge_fwd_lane_kernel") + f" (hidden_nf {F}: lane-per-feature kernels, no MFMA formulation)"
+        kname = ("edge_bwd_fp_kernel" if dom_is_bwd else "edge_fwd_fp_kernel") + f" (hidden_nf {F}: feature-parallel MFMA kernels, csrc/egnn_edge_fp.h)"
     roof = {"bound": "hbm", "kernel": kname,
             "achieved": round(a_b if dom_is_bwd else a_f, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round((a_b if dom_is_bwd else a_f) / HBM_PEAK_GBS, 5), "traffic": traffic["bwd" if dom_is_bwd else "fwd"],

@@ -17,13 +17,12 @@
 #include "egnn_mfma.h"
 #include "egnn_mfma16.h"
 #include "egnn_bwd16.h"
-#include "egnn_edge_lane.h"
 #include "egnn_edge_fp.h"
 
 #include <algorithm>
 #include <mutex>
 
-// hidden widths without an MFMA formulation (egnn_edge_lane.h): 16, 48, 64 with 1, 2, 4 or 8 heads (in_edge_nf 1; 0 with one head)
+// hidden widths on the feature-parallel MFMA kernels (egnn_edge_fp.h): 16, 48, 64 with 1, 2, 4 or 8 heads (in_edge_nf 1; 0 with one head)
 #define EQ_DISPATCH_LANE_WIDTHS \
     EQ_DISPATCH(16, 1, 1) EQ_DISPATCH(16, 1, 0) EQ_DISPATCH(16, 2, 1) EQ_DISPATCH(16, 4, 1) EQ_DISPATCH(16, 8, 1) \
     EQ_DISPATCH(16, 2, 0) EQ_DISPATCH(16, 4, 0) EQ_DISPATCH(16, 8, 0) \
@@ -738,9 +737,6 @@ __global__ __launch_bounds__(256, 2) void gather_node_bwd_kernel(
 // (40; operands transposed through wave-private LDS tiles).  Geometry forward / backward once per edge in the chunk's
 // front / back phases.
 // ---------------------------------------------------------------------------------------
-#ifndef EQ_EDGE_FP
-#define EQ_EDGE_FP 1                   // 0: hidden_nf 16 / 48 / 64 on the lane-per-feature kernels (A/B knob)
-#endif
 constexpr int kBwd16Waves = 8;
 #ifndef EQ_BWD16_RUNSUM
 #define EQ_BWD16_RUNSUM 0             // 1: db6 / db2 as per-lane running sums instead of column sums of pass16's tile reads (A/B knob)
@@ -1174,7 +1170,7 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
         hipLaunchKernelGGL((edge_bwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * NW), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
                            E, chunk, basis, dt1, dt1 + (size_t)E * 32, gxr, gxc, slab);
         *n_slabs = blocks;
-    } else if constexpr (F % 16 == 0 && EQ_EDGE_FP != 0) {  // 16 / 48 / 64: the feature-parallel MFMA kernels (egnn_edge_fp.h), one slab per workgroup
+    } else if constexpr (F % 16 == 0) {  // 16 / 48 / 64: the feature-parallel MFMA kernels (egnn_edge_fp.h), one slab per workgroup
         using L = FpLayout<F, H, A, true>;
         const size_t smem = edge_bwd_fp_smem<F, H, A>();
         {
@@ -1195,26 +1191,8 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
         hipLaunchKernelGGL((edge_bwd_fp_kernel<F, H, A>), dim3(blocks), dim3(64 * L::NW), smem, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx, E,
                            basis, dt1, gxr, gxc, slab);
         *n_slabs = blocks;
-    } else {                                               // any other width: lane = feature (egnn_edge_lane.h), one slab per workgroup
-        int blocks = ceil_div(E, 4 * 16);
-        blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
-        const size_t smem = edge_bwd_lane_smem<F, H>();
-        {   // more than 64 KB of dynamic LDS needs the attribute (per device; set once per device and instantiation)
-            static std::mutex mu;
-            static bool done[64] = {false};
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            std::lock_guard<std::mutex> lk(mu);
-            if (dev < 0 || dev >= 64 || !done[dev]) {
-                hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(&edge_bwd_lane_kernel<F, H, A>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-                if (err != hipSuccess) { set_error("hipFuncSetAttribute(edge_bwd_lane): %s", hipGetErrorString(err)); return (int)err; }
-                if (dev >= 0 && dev < 64) done[dev] = true;
-            }
-        }
-        hipLaunchKernelGGL((edge_bwd_lane_kernel<F, H, A>), dim3(blocks), dim3(256), smem, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx, E,
-                           basis, dt1, gxr, gxc, slab);
-        *n_slabs = blocks;
+    } else {
+        static_assert(F % 16 == 0, "hidden widths: 32 / 33 (16-edge MFMA kernels) and 16 / 48 / 64 (feature-parallel MFMA kernels)");
     }
     return 0;
 }

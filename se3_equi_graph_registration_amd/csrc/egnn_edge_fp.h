@@ -14,7 +14,7 @@
 // Tile groups per workgroup: fp_tpb below.
 // Same math as E_GCL.edge_model / coord_model (:231-268), same interfaces as the other edge kernels: m rows at the edge's
 // aggregation position, trans [E][4], dt1 rows [E][FP], gxr / gxc [E][4], Slabs<F>::edge.  (Round 4; the lane-per-feature kernels
-// of egnn_edge_lane.h were ~5x slower per flop: 506 / 124 us backward / forward per launch at hidden_nf 64, one 2 048-point pair.)
+// of rounds 1-3 (csrc/egnn_edge_lane.h, removed in round 5) were ~5x slower per flop: 506 / 124 us backward / forward per launch at hidden_nf 64, one 2 048-point pair.)
 #pragma once
 #include "egnn_bwd16.h"
 

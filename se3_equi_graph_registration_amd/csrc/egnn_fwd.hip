@@ -15,12 +15,11 @@
 //                 per-node projections (or embedding_out after the last layer).
 #include "egnn_mfma.h"
 #include "egnn_mfma16.h"
-#include "egnn_edge_lane.h"
 #include "egnn_edge_fp.h"
 #include <mutex>
 
 
-// hidden widths without an MFMA formulation (egnn_edge_lane.h): 16, 48, 64 with 1, 2, 4 or 8 heads (in_edge_nf 1; 0 with one head)
+// hidden widths on the feature-parallel MFMA kernels (egnn_edge_fp.h): 16, 48, 64 with 1, 2, 4 or 8 heads (in_edge_nf 1; 0 with one head)
 #define EQ_DISPATCH_LANE_WIDTHS \
     EQ_DISPATCH(16, 1, 1) EQ_DISPATCH(16, 1, 0) EQ_DISPATCH(16, 2, 1) EQ_DISPATCH(16, 4, 1) EQ_DISPATCH(16, 8, 1) \
     EQ_DISPATCH(16, 2, 0) EQ_DISPATCH(16, 4, 0) EQ_DISPATCH(16, 8, 0) \
@@ -75,9 +74,6 @@ __global__ __launch_bounds__(256) void embed_in_kernel(const float* __restrict__
 // Latency chain of a chunk: indices (requested one chunk ahead) -> coordinate gathers + the first sub-tile's projection
 // rows together -> geometry -> sub-tiles (each requests the next one's projection rows before it computes).
 // ---------------------------------------------------------------------------------------
-#ifndef EQ_EDGE_FP
-#define EQ_EDGE_FP 1                   // 0: hidden_nf 16 / 48 / 64 on the lane-per-feature kernels (A/B knob)
-#endif
 constexpr int kFwd16Waves = 4;
 #ifndef EQ_FWD16_OCC
 #define EQ_FWD16_OCC 3                 // 4-wave workgroups per CU (= waves per SIMD) the register budget is set for
@@ -220,7 +216,7 @@ static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const floa
         blocks = blocks < 1 ? 1 : (blocks > 256 * occ ? 256 * occ : blocks);
         hipLaunchKernelGGL((edge_fwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * kFwd16Waves), 0, s, lw, g->row, g->col, edge_attr, x, P,
                            g->rinv, E, chunk, basis, m, trans);
-    } else if constexpr (F % 16 == 0 && EQ_EDGE_FP != 0) {  // 16 / 48 / 64: the feature-parallel MFMA kernels (egnn_edge_fp.h)
+    } else if constexpr (F % 16 == 0) {  // 16 / 48 / 64: the feature-parallel MFMA kernels (egnn_edge_fp.h)
         using L = FpLayout<F, H, A, false>;
         const size_t smem = edge_fwd_fp_smem<F, H, A>();
         {   // more than 64 KB of dynamic LDS needs the attribute (per device and instantiation)
@@ -239,11 +235,8 @@ static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const floa
         blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
         hipLaunchKernelGGL((edge_fwd_fp_kernel<F, H, A>), dim3(blocks), dim3(64 * L::NW), smem, s, lw, g->row, g->col, edge_attr, x, P, g->rinv, E,
                            basis, m, trans);
-    } else {                                               // any other width: lane = feature (egnn_edge_lane.h)
-        int blocks = ceil_div(E, 64);
-        blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-        hipLaunchKernelGGL((edge_fwd_lane_kernel<F, H, A>), dim3(blocks), dim3(256), 0, s, lw, g->row, g->col, edge_attr, x, P, g->rinv, E,
-                           basis, m, trans);
+    } else {
+        static_assert(F % 16 == 0, "hidden widths: 32 / 33 (16-edge MFMA kernels) and 16 / 48 / 64 (feature-parallel MFMA kernels)");
     }
 }
 
