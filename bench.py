@@ -772,7 +772,7 @@ def self_launch(args):
         raise SystemExit(5)
 
 
-def measure(pkg, args, dev, world, min_seconds):
+def measure(pkg, args, dev, world, min_seconds, beat=lambda: None):
     """Builds the step of `args`, warms it up and times blocks of EXACTLY args.steps steps (barrier + synchronize on both sides,
     MAX over ranks) until `min_seconds` have been measured; returns the state, the block times and how the step was launched."""
     dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
@@ -833,6 +833,7 @@ def measure(pkg, args, dev, world, min_seconds):
     while len(blocks) < n_blocks:
         S["restore"]()
         blocks.append(timed_block())
+        beat()
     finite = bool(torch.isfinite(S["egnn"].flat_params).all().item())
     return S, blocks, used_graph, graph_mode, finite
 
@@ -918,6 +919,56 @@ def entry_for(pkg, args, dev, world, rank, S, blocks, used_graph, graph_mode, fi
             "config": cfg, "roofline": roof, "kernels": extra}
 
 
+_WATCHDOG = r"""
+import os, signal, sys, time
+pid, path, limit = int(sys.argv[1]), sys.argv[2], float(sys.argv[3])
+while True:
+    time.sleep(2.0)
+    try:
+        os.kill(pid, 0)
+    except OSError:
+        sys.exit(0)                                    # the rank is gone: nothing to watch
+    try:
+        age = time.time() - os.path.getmtime(path)
+    except OSError:
+        sys.exit(0)                                    # the rank removed its heartbeat file: it finished
+    if age > limit:
+        sys.stderr.write(f"[bench watchdog] rank process {pid} made no progress for {age:.0f} s (a collective that never completes?): killing it\n")
+        sys.stderr.flush()
+        os.kill(pid, signal.SIGKILL)
+        sys.exit(3)
+"""
+
+
+def start_watchdog():
+    """Multi-rank runs: a CHILD process (started before this process initialises the GPU) that kills this rank when its heartbeat
+    file goes stale -- a collective that never completes (a captured all-reduce that hangs at replay, a dead peer) must end the job
+    with a non-zero exit code instead of a hang; the launcher (torch.distributed.run / self_launch) then tears down the other ranks.
+    Returns the heartbeat function.  BENCH_WATCHDOG_S: seconds without progress (default 600; 0 = off)."""
+    import atexit, tempfile
+    limit = float(os.environ.get("BENCH_WATCHDOG_S", "600"))
+    if limit <= 0:
+        return lambda: None
+    fd, path = tempfile.mkstemp(prefix="bench_heartbeat_")
+    os.close(fd)
+    child = subprocess.Popen([sys.executable, "-c", _WATCHDOG, str(os.getpid()), path, str(limit)])
+
+    def beat():
+        try:
+            os.utime(path, None)
+        except OSError:
+            pass
+
+    def done():
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+        child.terminate()
+    atexit.register(done)
+    return beat
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -926,6 +977,8 @@ def main():
     if world != args.gpus and os.environ.get("RANK", "0") == "0":
         print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): measuring {world}", file=sys.stderr)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_env = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    beat = start_watchdog() if dist_env else (lambda: None)        # before anything touches the GPU
     if world > 1 and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
         if local_rank == 0:          # the parent (self_launch) turns this marker into exit code 2
             print(f"BENCH_TOO_FEW_DEVICES {torch.cuda.device_count()}", flush=True)
@@ -954,7 +1007,9 @@ def main():
         work_stream = torch.cuda.Stream()
         work_stream.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(work_stream)
-    S, blocks, used_graph, graph_mode, finite = measure(pkg, args, dev, world, args.min_seconds)
+    beat()
+    S, blocks, used_graph, graph_mode, finite = measure(pkg, args, dev, world, args.min_seconds, beat)
+    beat()
 
     # evidence for the N>1 path: which devices the process group really spans, and what the gradient exchange costs alone
     ranks_seen, allreduce_us, grad_hash = None, None, None
@@ -1026,7 +1081,8 @@ def main():
             wa = parse(flags + ["--steps", str(steps), "--warmup", "3", "--gpus", str(world)])
             err = None
             try:
-                Sw, bl, ug, gm, fin = measure(pkg, wa, dev, world, args.workload_seconds)
+                beat()
+                Sw, bl, ug, gm, fin = measure(pkg, wa, dev, world, args.workload_seconds, beat)
                 ar_us = allreduce_isolated_us(Sw) if (dist_on and not wa.forward_only) else None
                 e = entry_for(pkg, wa, dev, world, rank, Sw, bl, ug, gm, fin)
                 if rank == 0:

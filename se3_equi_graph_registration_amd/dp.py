@@ -10,6 +10,9 @@ The message is ~220-340 KiB: latency-bound on xGMI, so it is not chunked further
 """
 from __future__ import annotations
 
+import os
+import subprocess
+import sys
 from typing import Iterable, List, Optional
 
 import torch
@@ -129,3 +132,71 @@ class DataParallelStep:
             else:
                 dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
                 b.mul_(1.0 / self.world)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Is an RCCL collective INSIDE a hipGraph safe to replay with this job's ranks?  Captured on a one-rank group it works (tests); a
+# replay that hangs with N real ranks cannot be recovered from inside the process (the stream never drains, and a process that has
+# initialised the GPU must not re-exec).  So the question is put to THROW-AWAY child processes before the training loop commits to
+# "one graph (all-reduce captured)": every rank starts one child (fresh GPU context on the same device, its own RCCL group on another
+# port) that captures an all-reduce of the job's message size in a graph and replays it; the parent rank only waits -- with a timeout,
+# after which it kills the child -- and the ranks agree on the verdict with one MIN all-reduce.  No -> "two graphs + eager all-reduce".
+_PROBE = r"""
+import os, sys, torch, torch.distributed as dist
+rank, world, dev, numel = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", init_method=f"tcp://{sys.argv[5]}:{sys.argv[6]}", rank=rank, world_size=world)
+buf = torch.ones(numel, dtype=torch.float32, device="cuda")
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    dist.all_reduce(buf, op=dist.ReduceOp.AVG)          # communicator set-up outside the capture
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        dist.all_reduce(buf, op=dist.ReduceOp.AVG)
+    for _ in range(5):
+        g.replay()
+    s.synchronize()
+assert float(buf[0]) == 1.0
+print("PROBE_OK", flush=True)
+os._exit(0)
+"""
+_PROBE_RESULT = {}
+
+
+def captured_collectives_work(group, device, numel: int = 65536, timeout: float = 90.0) -> bool:
+    """True when every rank's probe child replayed a captured RCCL all-reduce of ``numel`` floats (see above).  One-rank groups and
+    ``EQUIGSPR_TRUST_CAPTURED_COLLECTIVES=1`` skip the probe (True); ``=0`` forces False.  Cached per (group size, device)."""
+    world = dist.get_world_size(group)
+    force = os.environ.get("EQUIGSPR_TRUST_CAPTURED_COLLECTIVES")
+    if force is not None:
+        return force != "0"
+    if world == 1 and os.environ.get("EQUIGSPR_PROBE_ONE_RANK") != "1":
+        return True
+    dev = torch.device(device)
+    key = (world, dev.index)
+    if key in _PROBE_RESULT:
+        return _PROBE_RESULT[key]
+    rank = dist.get_rank(group)
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 101
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    ok = False
+    child = subprocess.Popen([sys.executable, "-c", _PROBE, str(rank), str(world), str(dev.index or 0), str(int(numel)), addr, str(port)],
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    try:
+        out, err = child.communicate(timeout=timeout)
+        ok = child.returncode == 0 and "PROBE_OK" in out
+        if not ok:
+            print(f"[dp] captured-collective probe failed on rank {rank} (rc {child.returncode}): {err[-400:]}", file=sys.stderr)
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.communicate()
+        print(f"[dp] captured-collective probe timed out after {timeout:.0f} s on rank {rank}: the step will use an eager all-reduce "
+              "between two graphs", file=sys.stderr)
+    flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    _PROBE_RESULT[key] = bool(flag.item() > 0.5)
+    return _PROBE_RESULT[key]

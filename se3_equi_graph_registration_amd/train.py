@@ -325,6 +325,11 @@ class GraphedStep:
         # this stack an aborted capture leaves PyTorch's capture stream unusable for the rest of the process -- so a mode that cannot
         # work is not attempted; torch.cuda.Stream() objects come from a pool of 32 per device, a "fresh" one is no way around that)
         can_capture_collective = self.graph_collectives and self.dist_on and dist.get_backend(self.group) == "nccl"
+        if can_capture_collective:
+            # a captured collective that hangs at replay cannot be recovered from in-process: throw-away child processes try it first
+            from .dp import captured_collectives_work
+            nb = int(self.opt.dp.joint_grad.numel()) if self.opt.dp.joint_grad is not None else 65536
+            can_capture_collective = captured_collectives_work(self.group, self.device, numel=nb)
         modes = ["one graph"] if not self.dist_on else \
             (["one graph (all-reduce captured)"] if can_capture_collective else []) + ["two graphs + eager all-reduce"]
         for mode in modes:

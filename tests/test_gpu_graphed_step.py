@@ -357,3 +357,28 @@ def test_batched_evaluation_equals_per_pair_evaluation_bit_for_bit(pk):
     model.batched_eval = False
     single = train.GraphedEval(model, k=8).run([tup(slice(i, i + 1)) for i in range(4)] * 3)
     assert batched.shape == (12, 5) and torch.equal(batched, single)
+
+
+def test_captured_collective_probe_runs_in_a_child_process(pk):
+    """before the loop commits to an all-reduce captured inside the step graph, throw-away child processes
+    replay a captured RCCL all-reduce (dp.captured_collectives_work).  Here: a one-rank RCCL group with the probe forced on -- the child
+    must come back with a verdict (True on this stack), and the forced-off switch must make the loop take two graphs + eager all-reduce."""
+    code = r"""
+import os, sys, json, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", RANK="0", WORLD_SIZE="1", EQUIGSPR_PROBE_ONE_RANK="1")
+import se3_equi_graph_registration_amd as pk
+from se3_equi_graph_registration_amd import dp
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+ok = dp.captured_collectives_work(None, "cuda:0", numel=70000, timeout=240.0)
+os.environ["EQUIGSPR_TRUST_CAPTURED_COLLECTIVES"] = "0"
+off = dp.captured_collectives_work(None, "cuda:0")
+dist.destroy_process_group()
+print("RESULT " + json.dumps({"ok": ok, "off": off}))
+""" % {"root": ROOT}
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")][-1][len("RESULT "):])
+    assert res["ok"] is True and res["off"] is False, (res, p.stderr[-2000:])
