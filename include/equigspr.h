@@ -324,10 +324,12 @@ typedef struct equigspr_irrep_config {
     float k00, k01, k10, k11_0, k11_1, k11_2;
 } equigspr_irrep_config;
 
-/* floats of the per-node moments a forward leaves for the backward: M [N, Lc, H] | Mb [N, Lc],
+/* floats of what a forward leaves for the backward: the per-node moments M [N, Lc, H] | Mb [N, Lc] and the per-edge geometry table
+ * (unit vector, length and source node of every edge in aggregation order: 20 bytes per edge, computed once per call and read by
+ * every kernel instead of the index -> source -> coordinate chain),
  * Lc = 4 ceil16(C0i) + 10 pad(C1i), pad = 8 / 16 / 32;  M[n, j, h] = sum_{e: row = n} c[e, j] hid[e, h], Mb = the same with hid = 1,
  * c[e] = [K00 f0 | K01[a] f0 (a-major) | K10 . f1 | K11[a, :, J] . f1 ((a, J)-major)] (every slot padded to its channel padding). */
-int64_t equigspr_irrep_moments_size(const equigspr_irrep_config* cfg, int32_t n_nodes);
+int64_t equigspr_irrep_moments_size(const equigspr_irrep_config* cfg, int32_t n_nodes, int32_t n_edges);
 /* floats of scratch equigspr_irrep_conv_backward needs */
 int64_t equigspr_irrep_bwd_work_size(const equigspr_irrep_config* cfg, int32_t n_nodes, int32_t n_edges);
 

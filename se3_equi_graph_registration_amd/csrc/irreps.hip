@@ -53,14 +53,31 @@ static inline int pad1(int c) { return c <= 8 ? 8 : (c <= 16 ? 16 : 32); }
 struct Consts { float k00, k01, k10, k110, k111, k112; };
 
 // ------------------------------------------------------------------------------------------------ moments
+// Per-edge geometry in AGGREGATION order (irrep_edge_table_kernel): position p of node n's segment [ptr[n], ptr[n + 1]) holds the
+// unit vector and length of r = x[n] - x[src] and the source node -- one coalesced read per wave instead of the dependent chain
+// index -> source -> coordinates -> sqrt / divide in every launch of every layer (the coordinates are fixed through a stack).
+struct EdgeTab { const float4* geo; const int* src; };       // [E] (u0, u1, u2, d), [E]
+
 struct MomArgs {
-    const float* x; const float* f0; const float* f1;       // [N, 3], [N, c0], [N, c1, 3]: the features are gathered at src[e]
-    const int* ptr; const int* perm; const int* src;        // node n aggregates the edges perm[ptr[n] .. ptr[n + 1]) (ascending edge id)
+    const float* f0; const float* f1;                       // [N, c0], [N, c1, 3]: the features are gathered at tab.src[p]
+    const int* ptr; EdgeTab tab;                            // node n aggregates the positions ptr[n] .. ptr[n + 1] (ascending edge id)
     const float* w1; const float* b1;                       // radial.0: [H], [H]
     Consts k;
     int n_nodes, c0, c1, c0p, c1p, lc;
     float* M; float* Mb;                                    // [N, lc, H], [N, lc]
 };
+
+__global__ void irrep_edge_table_kernel(const float* __restrict__ x, const int* __restrict__ agg, const int* __restrict__ src,
+                                       const int* __restrict__ perm, int n_edges, float4* __restrict__ geo, int* __restrict__ srcs) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_edges) return;
+    const int e = perm[p], n = agg[e], s = src[e];
+    const float r0 = x[(size_t)n * 3] - x[(size_t)s * 3], r1 = x[(size_t)n * 3 + 1] - x[(size_t)s * 3 + 1], r2 = x[(size_t)n * 3 + 2] - x[(size_t)s * 3 + 2];
+    const float d = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+    const float inv = d > 0.0f ? 1.0f / d : 0.0f;            // self loop / duplicated point: u = 0, only the J = 0 kernels act
+    geo[p] = make_float4(r0 * inv, r1 * inv, r2 * inv, d);
+    srcs[p] = s;
+}
 
 // One wave per (node, unit): unit 0 = the 4 c0p entries built from f0, units 1.. = 80-entry groups of the 10 c1p built from f1.
 // r = x[n] - x[src]: the caller flips k01 / k10 when it aggregates at the other end of the edges (the adjoint).
@@ -75,7 +92,6 @@ __global__ __launch_bounds__(256) void irrep_moments16_kernel(const MomArgs a) {
     float w1v[NH], b1v[NH];
 #pragma unroll
     for (int hb = 0; hb < NH; ++hb) { w1v[hb] = a.w1[16 * hb + j]; b1v[hb] = a.b1[16 * hb + j]; }
-    const float xn0 = a.x[(size_t)n * 3], xn1 = a.x[(size_t)n * 3 + 1], xn2 = a.x[(size_t)n * 3 + 2];
     const int lo = a.ptr[n], hi = a.ptr[n + 1];
     float4* gA = geo[wv][0];
     float4* gB = geo[wv][1];
@@ -83,13 +99,10 @@ __global__ __launch_bounds__(256) void irrep_moments16_kernel(const MomArgs a) {
     // k-step: such a slot then contributes c = 0 to every moment)
     auto front = [&](int base, int cnt) {
         const bool valid = lane < cnt;
-        const int e = valid ? a.perm[base + lane] : 0;
-        const int s = valid ? a.src[e] : n;
-        const float r0 = xn0 - a.x[(size_t)s * 3], r1 = xn1 - a.x[(size_t)s * 3 + 1], r2 = xn2 - a.x[(size_t)s * 3 + 2];
-        const float d = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
-        const bool live = valid && d > 0.0f;                 // self loop / duplicated point: only the J = 0 kernels act
-        const float inv = live ? 1.0f / d : 0.0f;
-        gA[lane] = make_float4(r0 * inv, r1 * inv, r2 * inv, d);
+        const float4 gv = valid ? a.tab.geo[base + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const int s = valid ? a.tab.src[base + lane] : n;
+        const bool live = valid && gv.w > 0.0f;              // self loop / duplicated point: only the J = 0 kernels act
+        gA[lane] = gv;
         gB[lane] = make_float4(valid ? a.k.k00 : 0.0f, valid ? a.k.k110 : 0.0f, live ? a.k.k112 : 0.0f, __int_as_float(s));
     };
     const int unit = blockIdx.y;
@@ -143,6 +156,9 @@ __global__ __launch_bounds__(256) void irrep_moments16_kernel(const MomArgs a) {
 #pragma unroll
         for (int t = 0; t < 4 * B0; ++t) {
             const size_t ent = (size_t)n * a.lc + 16 * t + j;
+#ifdef EQ_IR_DBG_NOSTORE
+            if (acc[t][0][0] == 123.456f)
+#endif
 #pragma unroll
             for (int hb = 0; hb < NH; ++hb) st4(a.M + ent * H + 16 * hb + 4 * kq, acc[t][hb]);
             const float tot = gsum(bs[t]);
@@ -211,6 +227,9 @@ __global__ __launch_bounds__(256) void irrep_moments16_kernel(const MomArgs a) {
     for (int t = 0; t < 5; ++t) {
         const int e_in = (C1P == 8) ? 16 * t + j : (S0 + t) * a.c1p + 16 * sub + j;
         const size_t ent = (size_t)n * a.lc + 4 * a.c0p + e_in;
+#ifdef EQ_IR_DBG_NOSTORE
+        if (acc[t][0][0] == 123.456f)
+#endif
 #pragma unroll
         for (int hb = 0; hb < NH; ++hb) st4(a.M + ent * H + 16 * hb + 4 * kq, acc[t][hb]);
         const float tot = gsum(bs[t]);
@@ -261,43 +280,71 @@ __global__ __launch_bounds__(64 * kNodeWaves) void irrep_node16_kernel(const Nod
 #pragma unroll
         for (int t = 0; t < NH; ++t) av[t] = ldg4(Mn + (size_t)entry * H + 16 * t + 4 * kq);
     };
-    // ---- degree-0 outputs: K = (i, h) over c00 and c10
-    for (int i = wv; i < a.c0 + a.c1; i += kNodeWaves) {
-        const bool d0 = i < a.c0;
-        const int in = d0 ? i : i - a.c0;
-        f32x4 av[NH];
-        mrow(d0 ? in : f1base + in, av);
-        const PathW& p = d0 ? a.p00 : a.p10;
+    // ---- degree-0 outputs: K = (i, h) over c00 and c10.  The operands of step i + kNodeWaves are requested before the products of
+    // step i (two waves per SIMD: an exposed L2 / HBM round trip per step was most of this kernel's time)
+    {
+        const int n0s = a.c0 + a.c1;
+        f32x4 avn[NH], bvn[NCB0][NH];
+        auto fetch0 = [&](int i) {
+            const bool d0 = i < a.c0;
+            const int in = d0 ? i : i - a.c0;
+            mrow(d0 ? in : f1base + in, avn);
+            const PathW& p = d0 ? a.p00 : a.p10;
 #pragma unroll
-        for (int cb = 0; cb < NCB0; ++cb) {
-            f32x4 bv[NH];
-            wrow(p.w, p.so, p.si, 16 * cb + i16, a.o0, in, bv);
+            for (int cb = 0; cb < NCB0; ++cb) wrow(p.w, p.so, p.si, 16 * cb + i16, a.o0, in, bvn[cb]);
+        };
+        if (wv < n0s) fetch0(wv);
+        for (int i = wv; i < n0s; i += kNodeWaves) {
+            f32x4 av[NH], bv[NCB0][NH];
 #pragma unroll
-            for (int t = 0; t < NH; ++t)
+            for (int t = 0; t < NH; ++t) {
+                av[t] = avn[t];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc0[cb] = mfma16(av[t][r], bv[t][r], acc0[cb]);
-        }
-    }
-    // ---- degree-1 outputs: per component a the same weights act on the moments of c01[a] / c11[a, J]
-    for (int i = wv; i < a.c0 + 3 * a.c1; i += kNodeWaves) {
-        const bool d0 = i < a.c0;
-        const int in = d0 ? i : (i - a.c0) / 3, J = d0 ? 0 : (i - a.c0) - 3 * in;
-        f32x4 bv[NCB1][NH];
+                for (int cb = 0; cb < NCB0; ++cb) bv[cb][t] = bvn[cb][t];
+            }
+            if (i + kNodeWaves < n0s) fetch0(i + kNodeWaves);
 #pragma unroll
-        for (int cb = 0; cb < NCB1; ++cb) {
-            if (d0) wrow(a.p01.w, a.p01.so, a.p01.si, 16 * cb + i16, a.o1, in, bv[cb]);
-            else wrow(a.p11.w + J * H, a.p11.so, a.p11.si, 16 * cb + i16, a.o1, in, bv[cb]);
-        }
-#pragma unroll
-        for (int aa = 0; aa < 3; ++aa) {
-            f32x4 av[NH];
-            mrow(d0 ? a.c0p * (1 + aa) + in : f1base + a.c1p * (1 + 3 * aa + J) + in, av);
-#pragma unroll
-            for (int cb = 0; cb < NCB1; ++cb)
+            for (int cb = 0; cb < NCB0; ++cb)
 #pragma unroll
                 for (int t = 0; t < NH; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc1[aa][cb] = mfma16(av[t][r], bv[cb][t][r], acc1[aa][cb]);
+                    for (int r = 0; r < 4; ++r) acc0[cb] = mfma16(av[t][r], bv[cb][t][r], acc0[cb]);
+        }
+    }
+    // ---- degree-1 outputs: per component a the same weights act on the moments of c01[a] / c11[a, J]
+    {
+        const int n1s = a.c0 + 3 * a.c1;
+        f32x4 avn[3][NH], bvn[NCB1][NH];
+        auto fetch1 = [&](int i) {
+            const bool d0 = i < a.c0;
+            const int in = d0 ? i : (i - a.c0) / 3, J = d0 ? 0 : (i - a.c0) - 3 * in;
+#pragma unroll
+            for (int cb = 0; cb < NCB1; ++cb) {
+                if (d0) wrow(a.p01.w, a.p01.so, a.p01.si, 16 * cb + i16, a.o1, in, bvn[cb]);
+                else wrow(a.p11.w + J * H, a.p11.so, a.p11.si, 16 * cb + i16, a.o1, in, bvn[cb]);
+            }
+#pragma unroll
+            for (int aa = 0; aa < 3; ++aa) mrow(d0 ? a.c0p * (1 + aa) + in : f1base + a.c1p * (1 + 3 * aa + J) + in, avn[aa]);
+        };
+        if (wv < n1s) fetch1(wv);
+        for (int i = wv; i < n1s; i += kNodeWaves) {
+            f32x4 av[3][NH], bv[NCB1][NH];
+#pragma unroll
+            for (int t = 0; t < NH; ++t) {
+#pragma unroll
+                for (int aa = 0; aa < 3; ++aa) av[aa][t] = avn[aa][t];
+#pragma unroll
+                for (int cb = 0; cb < NCB1; ++cb) bv[cb][t] = bvn[cb][t];
+            }
+            if (i + kNodeWaves < n1s) fetch1(i + kNodeWaves);
+#pragma unroll
+            for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+                for (int cb = 0; cb < NCB1; ++cb)
+#pragma unroll
+                    for (int t = 0; t < NH; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc1[aa][cb] = mfma16(av[aa][t][r], bv[cb][t][r], acc1[aa][cb]);
         }
     }
     // ---- bias column (K = entries, Mb) and self-interaction (K = input channels, the node's own features): four entries per step
@@ -393,8 +440,7 @@ struct FusedShape {
 // phase A for one node and one chunk: blocks 3 CHUNK .. of the operand vector -> tile rows of the node
 template <int B0, int CHUNK>
 __device__ __forceinline__ void fused_phase_a(const MomArgs& a, int n, int lo, int hi, const float4& cA, const float4& cB, float4* gA,
-                                              float4* gB, float* tile_n, float* mb_n, int lane, const float (&w1v)[2], const float (&b1v)[2],
-                                              float xn0, float xn1, float xn2) {
+                                              float4* gB, float* tile_n, float* mb_n, int lane, const float (&w1v)[2], const float (&b1v)[2]) {
     constexpr int NB = FusedShape<B0>::NB, bf = 3 * CHUNK, nb = (NB - bf) < 3 ? (NB - bf) : 3;
     constexpr bool has_f1 = bf + nb > 4 * B0;
     constexpr bool sub0 = (bf < 4 * B0) && ((bf % B0 == 0) || (nb > 1 && bf + 1 < 4 * B0 && (bf + 1) % B0 == 0) || (nb > 2 && bf + 2 < 4 * B0 && (bf + 2) % B0 == 0));
@@ -411,14 +457,10 @@ __device__ __forceinline__ void fused_phase_a(const MomArgs& a, int n, int lo, i
         if (base == lo) { gA[lane] = cA; gB[lane] = cB; }       // the node's first 64 edges: geometry kept in registers
         else {
             const bool valid = lane < cnt;
-            const int e = valid ? a.perm[base + lane] : 0;
-            const int s = valid ? a.src[e] : n;
-            const float r0 = xn0 - a.x[(size_t)s * 3], r1 = xn1 - a.x[(size_t)s * 3 + 1], r2 = xn2 - a.x[(size_t)s * 3 + 2];
-            const float d = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
-            const bool live = valid && d > 0.0f;
-            const float inv = live ? 1.0f / d : 0.0f;
-            gA[lane] = make_float4(r0 * inv, r1 * inv, r2 * inv, d);
-            gB[lane] = make_float4(valid ? a.k.k00 : 0.0f, valid ? a.k.k110 : 0.0f, live ? a.k.k112 : 0.0f, __int_as_float(s));
+            const float4 gv = valid ? a.tab.geo[base + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const int s = valid ? a.tab.src[base + lane] : n;
+            gA[lane] = gv;
+            gB[lane] = make_float4(valid ? a.k.k00 : 0.0f, valid ? a.k.k110 : 0.0f, (valid && gv.w > 0.0f) ? a.k.k112 : 0.0f, __int_as_float(s));
         }
         wave_sync();
         const int nks = (cnt + 3) >> 2;
@@ -498,7 +540,6 @@ __global__ __launch_bounds__(64 * kFW) void irrep_conv_fused_kernel(const MomArg
     // ---- the two nodes of this wave: edge range and the geometry of their first 64 edges (one lane per edge), kept in registers
     int nn[2], lo[2], hi[2];
     float4 cA[2], cB[2];
-    float xn[2][3];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int n = n0 + 2 * wv + u;
@@ -506,18 +547,12 @@ __global__ __launch_bounds__(64 * kFW) void irrep_conv_fused_kernel(const MomArg
         nn[u] = ok ? n : a.n_nodes - 1;
         lo[u] = ok ? a.ptr[nn[u]] : 0;
         hi[u] = ok ? a.ptr[nn[u] + 1] : 0;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) xn[u][c] = a.x[(size_t)nn[u] * 3 + c];
         const int cnt = min(64, hi[u] - lo[u]);
         const bool valid = lane < cnt;
-        const int e = valid ? a.perm[lo[u] + lane] : 0;
-        const int s = valid ? a.src[e] : nn[u];
-        const float r0 = xn[u][0] - a.x[(size_t)s * 3], r1 = xn[u][1] - a.x[(size_t)s * 3 + 1], r2 = xn[u][2] - a.x[(size_t)s * 3 + 2];
-        const float d = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
-        const bool live = valid && d > 0.0f;
-        const float inv = live ? 1.0f / d : 0.0f;
-        cA[u] = make_float4(r0 * inv, r1 * inv, r2 * inv, d);
-        cB[u] = make_float4(valid ? a.k.k00 : 0.0f, valid ? a.k.k110 : 0.0f, live ? a.k.k112 : 0.0f, __int_as_float(s));
+        const float4 gv = valid ? a.tab.geo[lo[u] + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const int s = valid ? a.tab.src[lo[u] + lane] : nn[u];
+        cA[u] = gv;
+        cB[u] = make_float4(valid ? a.k.k00 : 0.0f, valid ? a.k.k110 : 0.0f, (valid && gv.w > 0.0f) ? a.k.k112 : 0.0f, __int_as_float(s));
     }
     f32x4 acc0[NCB0], acc1[3][NCB1];
 #pragma unroll
@@ -541,59 +576,70 @@ __global__ __launch_bounds__(64 * kFW) void irrep_conv_fused_kernel(const MomArg
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             fused_phase_a<B0, CH>(a, nn[u], lo[u], hi[u], cA[u], cB[u], gA, gB, tile + (size_t)(2 * wv + u) * kFS, mbt + (2 * wv + u) * 48, lane,
-                                  w1v, b1v, xn[u][0], xn[u][1], xn[u][2]);
+                                  w1v, b1v);
         __syncthreads();
-        // phase B: the chunk's entries, one per wave at a time
+        // phase B: the chunk's entries, one per wave at a time; the weight rows of the wave's NEXT entry are requested before the
+        // products of this one (they come from L2: an exposed round trip per entry otherwise)
         const float* tA = tile + (size_t)i16 * kFS;
-        for (int el = wv; el < 16 * nb; el += kFW) {
+        struct Ent { bool live, deg0; int aa; f32x4 bv[NCB0 > NCB1 ? NCB0 : NCB1][2]; float bb[NCB0 > NCB1 ? NCB0 : NCB1]; };
+        auto fetch = [&](int el, Ent& E_) {
             const int e = 48 * CH + el;                                  // wave-uniform
-            int in, J = 0, aa = 0, cin;
+            int in, J = 0, cin;
             const PathW* p;
-            bool deg0;
+            E_.aa = 0;
             if (e < f1base) {
                 const int sl = e / a.c0p;
                 in = e - sl * a.c0p; cin = a.c0;
-                deg0 = sl == 0; p = deg0 ? &nd.p00 : &nd.p01; aa = deg0 ? 0 : sl - 1;
+                E_.deg0 = sl == 0; p = E_.deg0 ? &nd.p00 : &nd.p01; E_.aa = E_.deg0 ? 0 : sl - 1;
             } else {
                 const int q = e - f1base, sl = q / a.c1p;
                 in = q - sl * a.c1p; cin = a.c1;
-                deg0 = sl == 0;
-                if (deg0) p = &nd.p10;
-                else { aa = (sl - 1) / 3; J = (sl - 1) - 3 * aa; p = &nd.p11; }
+                E_.deg0 = sl == 0;
+                if (E_.deg0) p = &nd.p10;
+                else { E_.aa = (sl - 1) / 3; J = (sl - 1) - 3 * E_.aa; p = &nd.p11; }
             }
-            if (in >= cin) continue;
+            E_.live = in < cin;
+            if (!E_.live) return;
+            const int on = E_.deg0 ? nd.o0 : nd.o1;
+#pragma unroll
+            for (int cb = 0; cb < (NCB0 > NCB1 ? NCB0 : NCB1); ++cb) {
+                if (cb >= (E_.deg0 ? NCB0 : NCB1)) break;
+                const int o = 16 * cb + i16;
+                wrow(p->w + J * H, p->so, p->si, o, on, in, E_.bv[cb]);
+                E_.bb[cb] = (kq == 0 && o < on) ? p->b[((size_t)o * p->so + (size_t)in * p->si) / H + J] : 0.0f;
+            }
+        };
+        Ent nxt;
+        nxt.live = false;
+        if (wv < 16 * nb) fetch(wv, nxt);
+        for (int el = wv; el < 16 * nb; el += kFW) {
+            const Ent cur = nxt;
+            if (el + kFW < 16 * nb) fetch(el + kFW, nxt);
+            if (!cur.live) continue;
             f32x4 av[2];
             av[0] = lds4(tA + el * kFHP + 4 * kq);
             av[1] = lds4(tA + el * kFHP + 16 + 4 * kq);
             const float mb = kq == 0 ? mbt[i16 * 48 + el] : 0.0f;      // the bias column as one more K step (k = 0 only)
-            if (deg0) {
+            if (cur.deg0) {
 #pragma unroll
                 for (int cb = 0; cb < NCB0; ++cb) {
-                    f32x4 bv[2];
-                    const int o = 16 * cb + i16;
-                    wrow(p->w, p->so, p->si, o, nd.o0, in, bv);
-                    const float bb = (kq == 0 && o < nd.o0) ? p->b[((size_t)o * p->so + (size_t)in * p->si) / H] : 0.0f;
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc0[cb] = mfma16(av[t][r], bv[t][r], acc0[cb]);
-                    acc0[cb] = mfma16(mb, bb, acc0[cb]);
+                        for (int r = 0; r < 4; ++r) acc0[cb] = mfma16(av[t][r], cur.bv[cb][t][r], acc0[cb]);
+                    acc0[cb] = mfma16(mb, cur.bb[cb], acc0[cb]);
                 }
             } else {
 #pragma unroll
                 for (int cb = 0; cb < NCB1; ++cb) {
-                    f32x4 bv[2];
-                    const int o = 16 * cb + i16;
-                    wrow(p->w + J * H, p->so, p->si, o, nd.o1, in, bv);
-                    const float bb = (kq == 0 && o < nd.o1) ? p->b[((size_t)o * p->so + (size_t)in * p->si) / H + J] : 0.0f;
                     // (aa is wave-uniform: one accumulator per component)
-                    f32x4 acc = aa == 0 ? acc1[0][cb] : (aa == 1 ? acc1[1][cb] : acc1[2][cb]);
+                    f32x4 acc = cur.aa == 0 ? acc1[0][cb] : (cur.aa == 1 ? acc1[1][cb] : acc1[2][cb]);
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc = mfma16(av[t][r], bv[t][r], acc);
-                    acc = mfma16(mb, bb, acc);
-                    if (aa == 0) acc1[0][cb] = acc; else if (aa == 1) acc1[1][cb] = acc; else acc1[2][cb] = acc;
+                        for (int r = 0; r < 4; ++r) acc = mfma16(av[t][r], cur.bv[cb][t][r], acc);
+                    acc = mfma16(mb, cur.bb[cb], acc);
+                    if (cur.aa == 0) acc1[0][cb] = acc; else if (cur.aa == 1) acc1[1][cb] = acc; else acc1[2][cb] = acc;
                 }
             }
         }
@@ -689,21 +735,26 @@ struct ExpArgs {
     float* dM; float* dMb;                               // [N, lc, H], [N, lc]
 };
 
+constexpr int kExpTiles = 2;            // 16-node tiles per workgroup: every weight row a wave loads feeds both (the weights come from L2: 228 KB per workgroup at 32 + 8 channels)
+
 template <int NH>
 __global__ __launch_bounds__(64 * kNodeWaves) void irrep_expand16_kernel(const ExpArgs a) {
     constexpr int H = 16 * NH;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    const int nA = min(n0 + i16, a.n_nodes - 1);
-    // A operands: g[nA][4 s + kq], s = 0..7 (output channels beyond the count: zero)
-    float ga[4][8];
+    const int n0 = blockIdx.x * 16 * kExpTiles;
+    // B operands: g[node][4 s + kq], s = 0..7 (output channels beyond the count: zero), per tile
+    float ga[kExpTiles][4][8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int o = 4 * s + kq;
-        ga[0][s] = o < a.o0 ? a.g0[(size_t)nA * a.o0 + o] : 0.0f;
+    for (int tl = 0; tl < kExpTiles; ++tl) {
+        const int nA = min(n0 + 16 * tl + i16, a.n_nodes - 1);
 #pragma unroll
-        for (int aa = 0; aa < 3; ++aa) ga[1 + aa][s] = o < a.o1 ? a.g1[((size_t)nA * a.o1 + o) * 3 + aa] : 0.0f;
+        for (int s = 0; s < 8; ++s) {
+            const int o = 4 * s + kq;
+            ga[tl][0][s] = o < a.o0 ? a.g0[(size_t)nA * a.o0 + o] : 0.0f;
+#pragma unroll
+            for (int aa = 0; aa < 3; ++aa) ga[tl][1 + aa][s] = o < a.o1 ? a.g1[((size_t)nA * a.o1 + o) * 3 + aa] : 0.0f;
+        }
     }
     const int f1base = 4 * a.c0p;
     for (int e = wv; e < a.lc; e += kNodeWaves) {                       // wave-uniform entry
@@ -720,41 +771,52 @@ __global__ __launch_bounds__(64 * kNodeWaves) void irrep_expand16_kernel(const E
             else { const int aa = (s - 1) / 3; J = (s - 1) - 3 * aa; src = 1 + aa; p = &a.p11; on = a.o1; }
         }
         const bool real = in < cin;
-        f32x4 acc[NH];
+        f32x4 acc[kExpTiles][NH];
+        float bsum[kExpTiles];
 #pragma unroll
-        for (int t = 0; t < NH; ++t) acc[t] = splat4(0.0f);
-        float bsum = 0.0f;
+        for (int tl = 0; tl < kExpTiles; ++tl) {
+            bsum[tl] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NH; ++t) acc[tl][t] = splat4(0.0f);
+        }
         if (real) {
             const float* wp = p->w + (size_t)in * p->si + J * H;
             const float* bp = p->b + ((size_t)in * p->si) / H + J;
             const int nks = (on + 3) >> 2;
             // D[h][node] = sum_o A[h][o] B[o][node]: A lane (h = i16, k = kq) = W(o = 4 s + kq, ., 16 t + h); all of the entry's weight
             // loads are requested before the first product
-            float wv[8][NH], bw[8];
+            float wv_[8][NH], bw[8];
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int o = 4 * s + kq;
                 const bool ok = s < nks && o < on;
 #pragma unroll
-                for (int t = 0; t < NH; ++t) wv[s][t] = ok ? wp[(size_t)o * p->so + 16 * t + i16] : 0.0f;
+                for (int t = 0; t < NH; ++t) wv_[s][t] = ok ? wp[(size_t)o * p->so + 16 * t + i16] : 0.0f;
                 bw[s] = ok ? bp[((size_t)o * p->so) / H] : 0.0f;
             }
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 if (s >= nks) break;
-                const float gvv = src == 0 ? ga[0][s] : (src == 1 ? ga[1][s] : (src == 2 ? ga[2][s] : ga[3][s]));
 #pragma unroll
-                for (int t = 0; t < NH; ++t) acc[t] = mfma16(wv[s][t], gvv, acc[t]);
-                bsum = fmaf(gvv, bw[s], bsum);
+                for (int tl = 0; tl < kExpTiles; ++tl) {
+                    const float gvv = src == 0 ? ga[tl][0][s] : (src == 1 ? ga[tl][1][s] : (src == 2 ? ga[tl][2][s] : ga[tl][3][s]));
+#pragma unroll
+                    for (int t = 0; t < NH; ++t) acc[tl][t] = mfma16(wv_[s][t], gvv, acc[tl][t]);
+                    bsum[tl] = fmaf(gvv, bw[s], bsum[tl]);
+                }
             }
         }
-        bsum = gsum(bsum);
         // lane (node = i16, g = kq) holds h = 16 t + 4 g + r: one 16-byte store per tile
-        if (n0 + i16 < a.n_nodes) {
 #pragma unroll
-            for (int t = 0; t < NH; ++t) st4(a.dM + ((size_t)(n0 + i16) * a.lc + e) * H + 16 * t + 4 * kq, acc[t]);
+        for (int tl = 0; tl < kExpTiles; ++tl) {
+            const float bt = gsum(bsum[tl]);
+            const int n = n0 + 16 * tl + i16;
+            if (n < a.n_nodes) {
+#pragma unroll
+                for (int t = 0; t < NH; ++t) st4(a.dM + ((size_t)n * a.lc + e) * H + 16 * t + 4 * kq, acc[tl][t]);
+                if (kq == 0) a.dMb[(size_t)n * a.lc + e] = bt;
+            }
         }
-        if (kq == 0 && n0 + i16 < a.n_nodes) a.dMb[(size_t)(n0 + i16) * a.lc + e] = bsum;
     }
 }
 
@@ -767,8 +829,8 @@ __global__ __launch_bounds__(64 * kNodeWaves) void irrep_expand16_kernel(const E
 // so c is computed once, in the lane that consumes it both ways.  The block's dM tile goes through a wave-private LDS tile (read as
 // rows for d c, as columns for d hid).
 struct GeomArgs {
-    const float* x; const float* f0; const float* f1;
-    const int* ptr; const int* perm; const int* src;
+    const float* f0; const float* f1;
+    const int* ptr; const int* perm; EdgeTab tab;
     const float* w1; const float* b1;
     Consts k;
     int n_nodes, c0, c1, c0p, c1p, lc;
@@ -835,7 +897,6 @@ __global__ __launch_bounds__(256) void irrep_geom_bwd_kernel(const GeomArgs a) {
     const bool node_ok = n < a.n_nodes;                      // wave-uniform
     const int nn = node_ok ? n : a.n_nodes - 1;
     const int lo = node_ok ? a.ptr[nn] : 0, hi = node_ok ? a.ptr[nn + 1] : 0;
-    const float xn0 = a.x[(size_t)nn * 3], xn1 = a.x[(size_t)nn * 3 + 1], xn2 = a.x[(size_t)nn * 3 + 2];
     const float* dMn = a.dM + (size_t)nn * a.lc * H;
     const float* dMbn = a.dMb + (size_t)nn * a.lc;
     const int f1base = 4 * a.c0p, B0 = a.c0p >> 4;
@@ -844,12 +905,12 @@ __global__ __launch_bounds__(256) void irrep_geom_bwd_kernel(const GeomArgs a) {
         const int cnt = min(16, hi - base);
         const bool valid = i16 < cnt;
         const int eid = valid ? a.perm[base + i16] : 0;
-        const int s = valid ? a.src[eid] : nn;
-        const float r0 = xn0 - a.x[(size_t)s * 3], r1 = xn1 - a.x[(size_t)s * 3 + 1], r2 = xn2 - a.x[(size_t)s * 3 + 2];
-        const float d = sqrtf(r0 * r0 + r1 * r1 + r2 * r2);
+        const float4 gq = valid ? a.tab.geo[base + i16] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const int s = valid ? a.tab.src[base + i16] : nn;
+        const float d = gq.w;
         const bool live = valid && d > 0.0f;
         const float inv = live ? 1.0f / d : 0.0f;
-        const float u[3] = {r0 * inv, r1 * inv, r2 * inv};
+        const float u[3] = {gq.x, gq.y, gq.z};
         const float k00v = valid ? a.k.k00 : 0.0f, k110v = valid ? a.k.k110 : 0.0f, k112l = live ? a.k.k112 : 0.0f;
         // hid[e][h] for the lane's h = 16 t + 4 g + r (B operand of d c), and SiLU' for the d hid epilogue
         f32x4 hid[NH], dsl[NH];
@@ -1110,8 +1171,8 @@ __global__ __launch_bounds__(64) void irrep_wgrad16_kernel(const WgradArgs a) {
 #pragma unroll
             for (int t = 0; t < NH; ++t) acc[q][t][cb] = splat4(0.0f);
         }
-    // (rows beyond the range are read from its last node -- valid memory, no branch around the loads -- and weighted with zero)
-#pragma unroll 2
+    // (rows beyond the range are read from its last node -- valid memory, no branch around the loads -- and weighted with zero.  Eight
+    // nodes per iteration with every load requested up front was measured too: 116 + 64 registers, two waves per SIMD, the same 70 us)
     for (int n0 = nb; n0 < ne; n0 += 4) {
         const bool ok = n0 + kq < ne;
         const int nk = ok ? n0 + kq : ne - 1;
@@ -1250,13 +1311,26 @@ static void launch_node(const NodeArgs& a, hipStream_t s) {
 #undef EQ_IR_NODE
 }
 
+static inline int64_t r4(int64_t v) { return (v + 3) / 4 * 4; }
+// per-edge geometry table in a float buffer: [E] float4 | [E] int32
+static inline int64_t tab_floats(int n_edges) { return r4(5LL * (n_edges > 0 ? n_edges : 1)); }
+static EdgeTab make_table(const float* x, const int* agg, const int* src, const int* perm, int n_edges, float* buf, hipStream_t s) {
+    float4* geo = reinterpret_cast<float4*>(buf);
+    int* srcs = reinterpret_cast<int*>(buf + 4 * (size_t)(n_edges > 0 ? n_edges : 1));
+    if (n_edges > 0) hipLaunchKernelGGL(irrep_edge_table_kernel, dim3(ceil_div(n_edges, 256)), dim3(256), 0, s, x, agg, src, perm, n_edges, geo, srcs);
+    return EdgeTab{geo, srcs};
+}
+static EdgeTab table_at(const float* buf, int n_edges) {
+    return EdgeTab{reinterpret_cast<const float4*>(buf), reinterpret_cast<const int*>(buf + 4 * (size_t)(n_edges > 0 ? n_edges : 1))};
+}
+
 // forward direction: aggregate at row, gather from col, weights as stored
 static void conv_forward(const equigspr_irrep_config* c, const Layout& L, const float* w_r1, const float* b_r1, const float* w_r2,
                          const float* b_r2, const float* ws0, const float* ws1, const equigspr_graph* g, const float* f0,
-                         const float* f1, const float* x, float* out0, float* out1, float* M, float* Mb, hipStream_t s,
+                         const float* f1, const EdgeTab& tab, float* out0, float* out1, float* M, float* Mb, hipStream_t s,
                          bool keep_moments = true) {
     const int H = L.H, c0p = pad0(L.c0i), c1p = pad1(L.c1i), lc = 4 * c0p + 10 * c1p;
-    MomArgs m{x, f0, f1, g->rptr, g->rperm, g->col, w_r1, b_r1, Consts{c->k00, c->k01, c->k10, c->k11_0, c->k11_1, c->k11_2},
+    MomArgs m{f0, f1, g->rptr, tab, w_r1, b_r1, Consts{c->k00, c->k01, c->k10, c->k11_0, c->k11_1, c->k11_2},
               g->n_nodes, L.c0i, L.c1i, c0p, c1p, lc, M, Mb};
     NodeArgs nd{M, Mb, f0, f1,
                 PathW{w_r2 + (size_t)L.off00 * H, b_r2 + L.off00, L.c0i * H, H},
@@ -1271,10 +1345,9 @@ static void conv_forward(const equigspr_irrep_config* c, const Layout& L, const 
 
 
 // ---- backward: scratch layout and launches
-static inline int64_t r4(int64_t v) { return (v + 3) / 4 * 4; }
 struct BwdPlan {
     int lc, lc_r, groups, splits, nodes_per_split, P, gsplits;
-    int64_t o_Mr, o_Mbr, o_dM, o_dMb, o_dr, o_dxr, o_gslab, o_wslab, total;
+    int64_t o_Mr, o_Mbr, o_dM, o_dMb, o_dr, o_dxr, o_gslab, o_wslab, o_tabR, total;
 };
 static BwdPlan plan_bwd(const Layout& L, int n_nodes, int n_edges) {
     BwdPlan p{};
@@ -1298,6 +1371,7 @@ static BwdPlan plan_bwd(const Layout& L, int n_nodes, int n_edges) {
     p.o_dxr = o;   o += r4((int64_t)n_nodes * 4);
     p.o_gslab = o; o += r4((int64_t)p.gsplits * 2 * H);
     p.o_wslab = o; o += r4((int64_t)p.splits * p.P);
+    p.o_tabR = o;  o += tab_floats(n_edges);
     p.total = o;
     return p;
 }
@@ -1312,9 +1386,9 @@ static void launch_geom(const GeomArgs& a, hipStream_t s) {
 
 static void conv_backward(const equigspr_irrep_config* c, const Layout& L, const float* w_r1, const float* b_r1, const float* w_r2,
                           const float* b_r2, const float* ws0, const float* ws1, const equigspr_graph* g, const float* f0,
-                          const float* f1, const float* x, const float* M, const float* g0, const float* g1, float* d_f0, float* d_f1,
-                          float* d_x, float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_ws0, float* d_ws1, float* work,
-                          hipStream_t s, int accumulate = 0) {
+                          const float* f1, const EdgeTab& tabF, const EdgeTab& tabR, const float* M, const float* g0, const float* g1,
+                          float* d_f0, float* d_f1, float* d_x, float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_ws0,
+                          float* d_ws1, float* work, hipStream_t s, int accumulate = 0) {
     const int H = L.H, N = g->n_nodes;
     const BwdPlan p = plan_bwd(L, N, g->n_edges);
     const Consts kf{c->k00, c->k01, c->k10, c->k11_0, c->k11_1, c->k11_2};
@@ -1326,7 +1400,7 @@ static void conv_backward(const equigspr_irrep_config* c, const Layout& L, const
         // the adjoint convolution: aggregate at col, gather the output gradients from row; r' = x[col] - x[row] = -r flips the two
         // kernels that are odd in u (K01 <-> K10 also swap roles); transposed weights = swapped strides
         const int c0pr = pad0(L.c0o), c1pr = pad1(L.c1o);
-        MomArgs m{x, g0, g1, g->cptr, g->cperm, g->row, w_r1, b_r1, Consts{c->k00, -c->k10, -c->k01, c->k11_0, c->k11_1, c->k11_2},
+        MomArgs m{g0, g1, g->cptr, tabR, w_r1, b_r1, Consts{c->k00, -c->k10, -c->k01, c->k11_0, c->k11_1, c->k11_2},
                   N, L.c0o, L.c1o, c0pr, c1pr, p.lc_r, work + p.o_Mr, work + p.o_Mbr};
         NodeArgs nd{work + p.o_Mr, work + p.o_Mbr, g0, g1,
                     PathW{f00.w, f00.b, H, L.c0i * H},               // G0 -> d f0: R00^T
@@ -1341,9 +1415,9 @@ static void conv_backward(const equigspr_irrep_config* c, const Layout& L, const
     }
     // geometry + radial.0
     ExpArgs ex{g0, g1, f00, f10, f01, f11, N, L.c0i, L.c1i, c0p, c1p, p.lc, L.c0o, L.c1o, work + p.o_dM, work + p.o_dMb};
-    GeomArgs ge{x, f0, f1, g->rptr, g->rperm, g->col, w_r1, b_r1, kf, N, L.c0i, L.c1i, c0p, c1p, p.lc, work + p.o_dM, work + p.o_dMb,
+    GeomArgs ge{f0, f1, g->rptr, g->rperm, tabF, w_r1, b_r1, kf, N, L.c0i, L.c1i, c0p, c1p, p.lc, work + p.o_dM, work + p.o_dMb,
                 work + p.o_dr, work + p.o_dxr, work + p.o_gslab};
-    const dim3 egrid(ceil_div(N, 16)), eblock(64 * kNodeWaves);
+    const dim3 egrid(ceil_div(N, 16 * kExpTiles)), eblock(64 * kNodeWaves);
     if (H == 16) { hipLaunchKernelGGL((irrep_expand16_kernel<1>), egrid, eblock, 0, s, ex); launch_geom<1>(ge, s); }
     else { hipLaunchKernelGGL((irrep_expand16_kernel<2>), egrid, eblock, 0, s, ex); launch_geom<2>(ge, s); }
     if (d_x) hipLaunchKernelGGL(irrep_dx_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, work + p.o_dr, work + p.o_dxr, g->cptr, g->cperm, N, d_x);
@@ -1370,7 +1444,7 @@ struct GnnPlan {
     int L, H, c1, n_nodes;
     int c0[17];                                   // degree-0 widths: c0[0] = in_nf, c0[1..L-1] = hidden_nf, c0[L] = out_nf
     int64_t o_w1[16], o_b1[16], o_w2[16], o_b2[16], o_s0[16], o_s1[16], o_gw[16], o_gb[16], o_wx, n_params;
-    int64_t s_f0[16], s_f1[16], s_p0[16], s_p1[16], s_M[16], saved_total;     // saved activations (floats); s_f0[0] is unused (= h_in)
+    int64_t s_f0[16], s_f1[16], s_p0[16], s_p1[16], s_M[16], s_tabF, s_tabR, saved_total;     // saved activations (floats); s_f0[0] is unused (= h_in)
     int64_t bwd_conv_work, w_g0, w_g1, w_d0, w_d1, w_slab, work_total;
     int gate_blocks;
 };
@@ -1414,6 +1488,8 @@ static GnnPlan plan_gnn(const equigspr_irrep_gnn_config* c, int n_nodes, int n_e
         const int64_t w = plan_bwd(layout_of(&lc), n_nodes, n_edges).total;
         conv_work = w > conv_work ? w : conv_work;
     }
+    P.s_tabF = take(tab_floats(n_edges));             // the stack's coordinates are fixed: one geometry table per direction for all layers
+    P.s_tabR = take(tab_floats(n_edges));
     P.saved_total = o;
     // backward scratch: the convolution's own + two pairs of gradient buffers (ping-pong through the layers) + gate / head slabs
     o = 0;
@@ -1567,11 +1643,11 @@ __global__ __launch_bounds__(256) void irrep_coord_bwd_kernel(const float* __res
 }  // namespace ir
 }  // namespace eq
 
-extern "C" int64_t equigspr_irrep_moments_size(const equigspr_irrep_config* cfg, int32_t n_nodes) {
+extern "C" int64_t equigspr_irrep_moments_size(const equigspr_irrep_config* cfg, int32_t n_nodes, int32_t n_edges) {
     using namespace eq::ir;
-    if (!config_ok(cfg) || n_nodes < 0) return -1;
+    if (!config_ok(cfg) || n_nodes < 0 || n_edges < 0) return -1;
     const int64_t lc = 4 * pad0(cfg->c0_in) + 10 * pad1(cfg->c1_in);
-    return (int64_t)n_nodes * lc * (cfg->hidden + 1);
+    return r4((int64_t)n_nodes * lc * (cfg->hidden + 1)) + tab_floats(n_edges);       // M | Mb | the edge geometry table
 }
 
 extern "C" int equigspr_irrep_conv_forward(const equigspr_irrep_config* cfg, const float* w_r1, const float* b_r1, const float* w_r2,
@@ -1585,9 +1661,12 @@ extern "C" int equigspr_irrep_conv_forward(const equigspr_irrep_config* cfg, con
                  "irrep_conv_forward: null argument");
     EQ_CHECK_ARG(g->n_nodes >= 1 && g->n_edges >= 0 && g->rptr && (g->n_edges == 0 || (g->col && g->rperm)), EQUIGSPR_EINVAL,
                  "irrep_conv_forward: incomplete graph (col, rptr, rperm)");
+    EQ_CHECK_ARG(g->n_edges == 0 || g->row, EQUIGSPR_EINVAL, "irrep_conv_forward: incomplete graph (row)");
     const Layout L = layout_of(cfg);
     const int64_t lc = 4 * pad0(L.c0i) + 10 * pad1(L.c1i);
-    conv_forward(cfg, L, w_r1, b_r1, w_r2, b_r2, w_self0, w_self1, g, f0, f1, x, out0, out1, moments,
+    float* tbuf = moments + r4((int64_t)g->n_nodes * lc * (L.H + 1));
+    const EdgeTab tab = make_table(x, g->row, g->col, g->rperm, g->n_edges, tbuf, (hipStream_t)stream);
+    conv_forward(cfg, L, w_r1, b_r1, w_r2, b_r2, w_self0, w_self1, g, f0, f1, tab, out0, out1, moments,
                  moments + (int64_t)g->n_nodes * lc * L.H, (hipStream_t)stream, keep_moments != 0);
     EQ_CHECK_LAUNCH("irrep_conv_forward");
     return 0;
@@ -1612,7 +1691,12 @@ extern "C" int equigspr_irrep_conv_backward(const equigspr_irrep_config* cfg, co
     EQ_CHECK_ARG((d_f0 == nullptr) == (d_f1 == nullptr), EQUIGSPR_EINVAL, "irrep_conv_backward: d_f0 and d_f1 are computed together (both or neither)");
     EQ_CHECK_ARG(g->n_nodes >= 1 && g->n_edges >= 0 && g->rptr && g->cptr && (g->n_edges == 0 || (g->row && g->col && g->rperm && g->cperm)),
                  EQUIGSPR_EINVAL, "irrep_conv_backward: incomplete graph (row, col and both inverse indices)");
-    conv_backward(cfg, layout_of(cfg), w_r1, b_r1, w_r2, b_r2, w_self0, w_self1, g, f0, f1, x, moments, g_out0, g_out1, d_f0, d_f1, d_x,
+    const Layout L = layout_of(cfg);
+    const int64_t lc = 4 * pad0(L.c0i) + 10 * pad1(L.c1i);
+    const EdgeTab tabF = table_at(moments + r4((int64_t)g->n_nodes * lc * (L.H + 1)), g->n_edges);      // left by the forward
+    const BwdPlan bp = plan_bwd(L, g->n_nodes, g->n_edges);
+    const EdgeTab tabR = d_f0 ? make_table(x, g->col, g->row, g->cperm, g->n_edges, work + bp.o_tabR, (hipStream_t)stream) : EdgeTab{nullptr, nullptr};
+    conv_backward(cfg, L, w_r1, b_r1, w_r2, b_r2, w_self0, w_self1, g, f0, f1, tabF, tabR, moments, g_out0, g_out1, d_f0, d_f1, d_x,
                   d_w_r1, d_b_r1, d_w_r2, d_b_r2, d_w_self0, d_w_self1, work, (hipStream_t)stream);
     EQ_CHECK_LAUNCH("irrep_conv_backward");
     return 0;
@@ -1665,6 +1749,12 @@ extern "C" int equigspr_irrep_gnn_forward(const equigspr_irrep_gnn_config* cfg, 
     const int N = g->n_nodes;
     const GnnPlan P = plan_gnn(cfg, N, g->n_edges);
     EQ_CHECK_ARG(hipMemsetAsync(saved + P.s_f1[0], 0, sizeof(float) * (size_t)N * P.c1 * 3, s) == hipSuccess, EQUIGSPR_EINVAL, "irrep_gnn_forward: memset failed");
+    EQ_CHECK_ARG(g->n_edges == 0 || g->row, EQUIGSPR_EINVAL, "irrep_gnn_forward: incomplete graph (row)");
+    const EdgeTab tabF = make_table(x, g->row, g->col, g->rperm, g->n_edges, saved + P.s_tabF, s);
+    if (training) {
+        EQ_CHECK_ARG(g->cptr && (g->n_edges == 0 || g->cperm), EQUIGSPR_EINVAL, "irrep_gnn_forward: training needs the col index (cptr, cperm)");
+        make_table(x, g->col, g->row, g->cperm, g->n_edges, saved + P.s_tabR, s);
+    }
     for (int l = 0; l < P.L; ++l) {
         const equigspr_irrep_config lc = layer_cfg(cfg, P, l);
         const Layout Ly = layout_of(&lc);
@@ -1676,7 +1766,7 @@ extern "C" int equigspr_irrep_gnn_forward(const equigspr_irrep_gnn_config* cfg, 
         float* M = saved + P.s_M[l];
         const int64_t lcn = 4 * pad0(Ly.c0i) + 10 * pad1(Ly.c1i);
         conv_forward(&lc, Ly, params + P.o_w1[l], params + P.o_b1[l], params + P.o_w2[l], params + P.o_b2[l], params + P.o_s0[l],
-                     params + P.o_s1[l], g, f0, f1, x, p0, p1, M, M + (int64_t)N * lcn * P.H, s, training != 0);
+                     params + P.o_s1[l], g, f0, f1, tabF, p0, p1, M, M + (int64_t)N * lcn * P.H, s, training != 0);
         if (!last)
             hipLaunchKernelGGL(irrep_gate_fwd_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, s, p0, p1, params + P.o_gw[l], params + P.o_gb[l], N,
                                P.c0[l + 1], P.c1, saved + P.s_f0[l + 1], saved + P.s_f1[l + 1]);
@@ -1702,6 +1792,7 @@ extern "C" int equigspr_irrep_gnn_backward(const equigspr_irrep_gnn_config* cfg,
     float* cw = work + P.bwd_conv_work;
     float* g0 = work + P.w_g0; float* g1 = work + P.w_g1; float* d0 = work + P.w_d0; float* d1 = work + P.w_d1;
     float* slab = work + P.w_slab;
+    const EdgeTab tabF = table_at(saved + P.s_tabF, g->n_edges), tabR = table_at(saved + P.s_tabR, g->n_edges);
     // coordinate head: g1 = w_x (x) g_x, d w_x, d x += g_x
     const int cb = ceil_div(N, 256);
     hipLaunchKernelGGL(irrep_coord_bwd_kernel, dim3(cb), dim3(256), 0, s, saved + P.s_p1[P.L - 1], params + P.o_wx, g_x, N, P.c1, g1, d_x, slab);
@@ -1716,7 +1807,7 @@ extern "C" int equigspr_irrep_gnn_backward(const equigspr_irrep_gnn_config* cfg,
         float* df0 = !want_f ? nullptr : (l == 0 ? d_h_in : d0);
         float* df1 = !want_f ? nullptr : d1;
         conv_backward(&lc, Ly, params + P.o_w1[l], params + P.o_b1[l], params + P.o_w2[l], params + P.o_b2[l], params + P.o_s0[l],
-                      params + P.o_s1[l], g, f0, f1, x, saved + P.s_M[l], gout0, g1, df0, df1, d_x, grads + P.o_w1[l], grads + P.o_b1[l],
+                      params + P.o_s1[l], g, f0, f1, tabF, tabR, saved + P.s_M[l], gout0, g1, df0, df1, d_x, grads + P.o_w1[l], grads + P.o_b1[l],
                       grads + P.o_w2[l], grads + P.o_b2[l], grads + P.o_s0[l], grads + P.o_s1[l], cw, s, 1);
         if (l > 0) {
             // through the gate between layers l - 1 and l: (d0, d1) = d (f0_l, f1_l) -> (g0, g1) = d (p0, p1) of layer l - 1

@@ -53,7 +53,7 @@ class _IrrepConvFn(torch.autograd.Function):
         dev = x.device
         out0 = torch.empty(n, cfg.c0_out, dtype=torch.float32, device=dev)
         out1 = torch.empty(n, cfg.c1_out, 3, dtype=torch.float32, device=dev)
-        moments = torch.empty(L.equigspr_irrep_moments_size(ctypes.byref(cfg), n), dtype=torch.float32, device=dev)
+        moments = torch.empty(L.equigspr_irrep_moments_size(ctypes.byref(cfg), n, graph.n_edges), dtype=torch.float32, device=dev)
         _lib.check(L.equigspr_irrep_conv_forward(ctypes.byref(cfg), _p(w1), _p(b1), _p(w2), _p(b2), _p(ws0), _p(ws1),
                                                  ctypes.byref(graph.struct), _p(f0), _p(f1), _p(x), _p(out0), _p(out1), _p(moments),
                                                  int(bool(training)), _stream()), "irrep_conv_forward")
