@@ -11,9 +11,9 @@ for spec in sys.argv[3:]:
     flags = flags.replace("+", " ")
     kernels = {}
     for r in csv.DictReader(open(path)):
-        name = r["Name"].split("(")[0].replace("void ", "").replace("eq::", "").strip()
+        name = r["Name"].split("(")[0].replace("void ", "").replace("eq::", "").replace("ir::", "").strip()
         short = name.split("<")[0]
-        if any(t in short for t in ("edge_", "node_", "gather_", "knn_", "head_", "csr_", "embed_", "layer_grad_reduce", "adam_")):
+        if any(t in short for t in ("edge_", "node_", "gather_", "knn_", "head_", "csr_", "embed_", "layer_grad_reduce", "adam_", "irrep_")):
             e = kernels.setdefault(short, {"avg_us": 0.0, "calls": 0, "variants": {}})
             calls, avg = int(r["Calls"]), float(r["AverageNs"]) / 1e3
             e["avg_us"] = (e["avg_us"] * e["calls"] + avg * calls) / (e["calls"] + calls)

@@ -34,15 +34,15 @@ def entry(name):
     return {"kernel": name, "launches": nf, "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1), "traffic_bytes": int((2 * f + w) * 1024)}
 
 
-for short, pats in (("edge_fwd_kernel", ("eq::edge_fwd16_kernel", "eq::edge_fwd_lane_kernel")),
-                    ("edge_bwd_kernel", ("eq::edge_bwd16_kernel", "eq::edge_bwd_lane_kernel"))):
+for short, pats in (("edge_fwd_kernel", ("eq::edge_fwd16_kernel", "eq::edge_fwd_fp_kernel")),
+                    ("edge_bwd_kernel", ("eq::edge_bwd16_kernel", "eq::edge_bwd_fp_kernel"))):
     for pat in pats:
         names = [k for k in fetch if k.startswith(pat)]
         if names:
             out[short] = entry(names[0])
             break
 for name in sorted(fetch):
-    if any(t in name for t in ("node_", "gather_", "embed_", "knn_", "csr_", "head_", "layer_grad_reduce", "adam_")):
+    if any(t in name for t in ("node_", "gather_", "embed_", "knn_", "csr_", "head_", "layer_grad_reduce", "adam_", "irrep_")):
         out[name.replace("eq::", "")] = entry(name)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if isinstance(v, dict) and "traffic_bytes" in v}, indent=1)[:3000])

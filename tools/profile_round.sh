@@ -1,9 +1,10 @@
 #!/bin/bash
-# Evidence run for profiles/ (round 4 form): for the headline and every other BASELINE workload -- the bench line, the rocprofv3
+# Evidence run for profiles/ (round 4 form; round 5 adds the GPU inference of BASELINE configs[0], its batched form and the typed
+# irrep-basis network): for the headline and every other BASELINE workload -- the bench line, the rocprofv3
 # kernel stats of the same command (hipGraph replays of the product loop), and the two PMC passes (FETCH_SIZE / WRITE_SIZE collected
 # separately, kernel-trace only, eager launches) summarised per kernel (edge AND node kernels); then the default (driver-form) line,
 # which quotes those files, and the launch sequence of one step.
-#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r04_v1'
+#   gpurun --timeout 3000 -- 'bash tools/profile_round.sh r05_a'
 # Outputs land in gpurun_out/<tag>/ ; tools/collect_profiles.sh copies what should be judged into profiles/.
 set -u
 TAG=${1:-run}
@@ -33,10 +34,13 @@ one b16 1310720 32 1 --workload c3 --steps 60 --warmup 10
 one c4shard 1310720 33 1 --workload c4 --steps 40 --warmup 5
 one c5 524288 32 0 --workload c5 --steps 100 --warmup 10
 one b16_irreps 1310720 32 1 --workload c3 --edge-basis irreps --steps 60 --warmup 10
+one c1infer 81920 32 0 --forward-only --eval-head --steps 300 --warmup 20
+one c1infer_b16 1310720 32 0 --forward-only --eval-head --batch 16 --steps 40 --warmup 5
+one irrepgnn 81920 32 1 --network irreps --steps 60 --warmup 10
 python3 "$ROOT/tools/in_step_summary.py" "$OUT/in_step.json" "$TAG" $SPECS
 # the default line quotes the evidence above when it sits in profiles/: place this run's files there for the run (on the GPU box only)
 cp "$OUT/in_step.json" "$ROOT/profiles/${TAG}_in_step.json"
-for w in b1 b16 c4shard c5; do cp "$OUT/pmc_$w.json" "$ROOT/profiles/${TAG}_pmc_$w.json"; done
+for w in b1 b16 c4shard c5 c1infer c1infer_b16; do cp "$OUT/pmc_$w.json" "$ROOT/profiles/${TAG}_pmc_$w.json"; done
 python3 "$ROOT/bench.py" > "$OUT/bench.json" 2>> "$OUT/bench.err"
 tail -1 "$OUT/bench.json" | cut -c1-300
 bash "$ROOT/tools/step_sequence.sh" > "$OUT/step_sequence.txt" 2>&1
