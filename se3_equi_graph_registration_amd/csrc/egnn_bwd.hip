@@ -835,6 +835,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
     for (int k = 0; k < 3; ++k) { xr0[k] = x[(size_t)r * 3 + k]; xc0[k] = x[(size_t)c * 3 + k]; gx0[k] = Gx[(size_t)r * 4 + k]; }
     stage.store(wsm_);
     __syncthreads();
+    build_frags16<true, kB>(wsm_);
     EQ_STAMP(1);
     bool first = true;
     for (; ch < n_chunks; ch += unit_step) {
@@ -899,7 +900,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             if (kAhead) nxt.load(P, idx_r[eln], idx_c[eln], g);
             const PRowsT<kB>& pw = cur;
             Sub16 o;
-            tile_forward16<kB>(wsm, bord, geo_rows + i * C::GS, pw, i, g, o);
+            tile_forward16<kB, true>(wsm, bord, geo_rows + i * C::GS, pw, i, g, o);
             if (g == 0) s_buf[el] = o.s;
             // ---- coord head backward: s = w7 . SiLU(q)
             f32x4 dq[2];
@@ -937,7 +938,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             float dmb = 0.0f;
 #pragma unroll
             for (int b = 0; b < 2; ++b) dm[b] = valid ? da[b] : splat4(0.0f);
-            mv16(wsm + W16::o_w6t, i, g, dq, dm);
+            mv16_edge<true, kB>(wsm, W16::f_w6t, i, g, dq, dm);
             if constexpr (kB == 1)      // W6^T: its column 32 is W6's row 32 and vice versa
                 dmb = (valid ? dab : 0.0f) + mv16_border(bord + W16::b_w6row, bord + W16::b_w6col, bord[W16::b_sc + 1], g, dq, dqb, dm);
             EQ_STAMP(11);
@@ -987,7 +988,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             // ---- dt1 = (W2^T du) * SiLU'(t1)
             f32x4 dt1[2] = {splat4(0.0f), splat4(0.0f)};
             float dt1b = 0.0f;
-            mv16(wsm + W16::o_w2t, i, g, du, dt1);
+            mv16_edge<true, kB>(wsm, W16::f_w2t, i, g, du, dt1);
             if constexpr (kB == 1) {
                 dt1b = mv16_border(bord + W16::b_w2row, bord + W16::b_w2col, bord[W16::b_sc + 0], g, du, dub, dt1);
                 dt1b *= o.sg1b * (1.0f + o.t1b * (1.0f - o.sg1b));

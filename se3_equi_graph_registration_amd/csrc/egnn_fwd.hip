@@ -85,7 +85,10 @@ constexpr int kFwd16Waves = 4;
 #endif
 constexpr int fwd16_occ(int kB) { return kB ? EQ_FWD16_OCC33 : EQ_FWD16_OCC; }
 
-template <int H, int A, int kB = 0>
+// kBf (experimental, EQ_EDGE_BF16X3 = 1 builds only; egnn_mfma16.h): the W2 / W6 products on the bf16 matrix pipe with 3-way split
+// operands; the fragments are staged with the fp32 image (threads 0..127 fetch their eight weights per matrix straight from global
+// memory: no second barrier).  ONE path for every graph size, so that a cloud's outputs do not depend on what else is in the batch.
+template <int H, int A, int kB = 0, bool kBf = W16::use_bf16(false, kB)>
 __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_kernel(const float* __restrict__ lw, const int* __restrict__ row,
                                                          const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                          const float* __restrict__ x, const float* __restrict__ P,
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
     const bool stream_out = stream_out_edges(n_edges);                  // write the outputs through (small graphs: egnn_mfma16.h)
     const OutRows m_rows(m_out), trans_rows(trans_out);
     constexpr int FP = 32 + 4 * kB;                    // hidden_nf = 32 + kB, rows padded to 16 bytes
-    __shared__ __attribute__((aligned(16))) float wsm_[W16::image_size(false, kB)];
+    __shared__ __attribute__((aligned(16))) float wsm_[kBf ? W16::image_size(false, kB) : W16::image_size_fp32(false, kB)];
     __shared__ __attribute__((aligned(16))) float scratch[kFwd16Waves][C::fwd_size];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     const int wave = blockIdx.x * kFwd16Waves + wv, n_waves = gridDim.x * kFwd16Waves;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
     // run side by side instead of one after the other.
     int e = ch < n_chunks ? edge_of(ch) : 0;
     int r = row[e], c = col[e], at = rinv[e];
-    StageW16<H, A, false, 64 * kFwd16Waves, kB> stage;
+    StageW16<H, A, false, 64 * kFwd16Waves, kB, kBf> stage;
     stage.load(lw);
     float xr0[3], xc0[3];
 #pragma unroll
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(64 * kFwd16Waves, fwd16_occ(kB)) void edge_fwd16_ke
                 pn.load(P, idx_r[eln], idx_c[eln], g);
             }
             Sub16 o;
-            tile_forward16<kB>(wsm, bord, sc + C::o_geo + el * C::GS, pw, i, g, o);
+            tile_forward16<kB, false, kBf>(wsm, bord, sc + C::o_geo + el * C::GS, pw, i, g, o);
             if ((t0 + sub * ts) * 16 + i < n_edges) {
                 // stored at the edge's position in the by-row (aggregation) order: node_fwd then streams its segment contiguously
                 // 128-byte rows for every hidden_nf: the 33rd feature of m leaves as the 4th component of the edge's `trans` item (back

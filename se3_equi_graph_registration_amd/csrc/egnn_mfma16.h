@@ -17,9 +17,23 @@
 #pragma once
 #include "egnn_device.h"
 
+// EXPERIMENTAL (round 5, default OFF): the 32 x 32 mat-vec products of the edge kernels on the bf16 matrix pipe with 3-way split
+// operands (x = hi + mid + lo, each bf16; the six products with i + j <= 2 accumulate in fp32): 12 v_mfma_f32_16x16x32_bf16 instead
+// of 16 v_mfma_f32_16x16x4_f32.  The isolated tile passes its criterion (tools/dev/bf16_split.hip: 1.33-1.35 x including the split's
+// vector instructions, max error 1.9e-7 against 3.3e-7 for the fp32 chain), but inside the kernels (profiles/r05_bf16x3_edge_kernels.txt):
+//   * forward, hidden_nf 32: correct at every size (differences to the fp32 build <= 1e-6 relative); 103 -> 101.5 us at 16 pairs,
+//     9.95 -> 11.8 us at one pair (eight spilled registers at the three-waves budget; a wave lives for two or three tiles there);
+//   * forward, hidden_nf 33 and backward, hidden_nf 32: 2^-10 relative errors on graphs where a wave's persistent loop runs more than
+//     one unit (> ~4 tiles per wave; forward-type and transposed products alike; chunk regime and store policy irrelevant; exact on
+//     small graphs) -- NOT understood, so nothing ships on this path.  1 = build it (tools/dev A/B only).
+#ifndef EQ_EDGE_BF16X3
+#define EQ_EDGE_BF16X3 0
+#endif
+
 namespace eq {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -105,6 +119,25 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// ---- 3-way bf16 split of eight floats (x = hi + mid + lo to 24 bits) and the fragment layout of a 32 x 32 matrix for
+// v_mfma_f32_16x16x32_bf16: [3 levels][2 row blocks][64 lanes] x 8 bf16; K index j of lane group g <-> feature 16 (j >> 2) + 4 g + (j & 3)
+__device__ __forceinline__ void split3_bf16(const f32x4 (&v)[2], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = v[j >> 2][j & 3];
+        const __bf16 h = (__bf16)x;
+        const float r1 = x - (float)h;
+        const __bf16 m = (__bf16)r1;
+        hi[j] = h; mid[j] = m; lo[j] = (__bf16)(r1 - (float)m);
+    }
+}
+__device__ __forceinline__ void frag_store(const f32x4 (&x)[2], float* frag, int bo, int l) {
+    bf16x8 hi, mid, lo;
+    split3_bf16(x, hi, mid, lo);
+    bf16x8* f = reinterpret_cast<bf16x8*>(frag);
+    f[(0 * 2 + bo) * 64 + l] = hi; f[(1 * 2 + bo) * 64 + l] = mid; f[(2 * 2 + bo) * 64 + l] = lo;
+}
+
 // LDS image of a layer's edge-MLP weights.  Row strides chosen so that the per-lane 16-byte operand fetches
 // (row = 16 bo + i, column 16 bi + 4 g) of every 16-lane ds_read_b128 group fall on distinct banks.
 // hidden_nf = 33 (kB = 1): the 32 x 32 cores stay on the matrix cores; feature 32 (the "border") is a scalar per edge held by
@@ -125,22 +158,46 @@ struct W16 {
     // border block (kB = 1), relative to its base: W2[:,32] | W2[32,:] | W6[:,32] | W6[32,:] | Wgeo[32,:16] | scalars
     static constexpr int b_w2col = 0, b_w2row = 32, b_w6col = 64, b_w6row = 96, b_wgrow = 128, b_sc = 144;
     static constexpr int border_size = 152;                // scalars: W2[32][32], W6[32][32], b2, gamma, beta, b6, w7 of feature 32
-    static constexpr int image_size(bool bwd, int kB) { return (bwd ? bwd_size : fwd_size) + kB * border_size; }
     static constexpr int border_base(bool bwd) { return bwd ? bwd_size : fwd_size; }
+    // bf16 x 3 fragments of the 32 x 32 matrices (EQ_EDGE_BF16X3): per matrix [3 levels][2 row blocks][64 lanes] x 8 bf16 = 1536 floats;
+    // forward: W2, W6; backward: + W2^T, W6^T
+    static constexpr int frag_floats = 3 * 2 * 64 * 4;
+    static constexpr int frag_base(bool bwd, int kB) { return (bwd ? bwd_size : fwd_size) + kB * border_size; }
+    static constexpr int f_w2 = 0, f_w6 = 1, f_w2t = 2, f_w6t = 3;
+    // (the hidden_nf 33 backward has no LDS left for them -- 187 KB with the fragments -- and keeps the fp32 products)
+// developer A/B: bit 0 = the forward kernel, bit 1 = the backward kernel (fragments by build_frags16 after the image's barrier)
+#ifndef EQ_BF16X3_KERNELS
+#define EQ_BF16X3_KERNELS 1
+#endif
+    static constexpr bool use_bf16(bool bwd, int kB) { return EQ_EDGE_BF16X3 != 0 && !(bwd && kB == 1) && ((EQ_BF16X3_KERNELS >> (bwd ? 1 : 0)) & 1); }
+    static constexpr int image_size_fp32(bool bwd, int kB) { return frag_base(bwd, kB); }
+    static constexpr int image_size(bool bwd, int kB) { return frag_base(bwd, kB) + (use_bf16(bwd, kB) ? (bwd ? 4 : 2) * frag_floats : 0); }
 };
 
 // global -> LDS in two halves, so that a kernel can put other requests between them: load() issues all of a thread's global
 // loads (the edge kernels request their first indices BEFORE it and gather the coordinates between load() and store(): the
 // image's latency and the index -> coordinate chain overlap instead of adding up -- at one 2 048-point pair a wave lives for
 // only 2-3 tiles, so ~1 us of serial start-up is 5 % of the kernel), store() writes the image.  NT = threads of the workgroup.
-template <int H, int A, bool kBwd, int NT, int kB = 0>
+template <int H, int A, bool kBwd, int NT, int kB = 0, bool kFrag = false>
 struct StageW16 {
     static constexpr int F = 32 + kB;
     using LL = LP<F, H, A>;
     static constexpr int FH = F / H;
     static constexpr int PER = 1024 / NT, PG = (512 + NT - 1) / NT;
     float v2[PER], v6[PER], vg[PG], vv, vb;
+    f32x4 f2[2], f6[2];          // kFrag: threads 0..127 also fetch the eight W2 / W6 weights of their (row block, lane) fragment
     __device__ __forceinline__ void load(const float* __restrict__ lw) {
+        if constexpr (kFrag) {
+            if (threadIdx.x < 128) {
+                const int bo = threadIdx.x >> 6, l = threadIdx.x & 63, ii = 16 * bo + (l & 15), gg = l >> 4;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * (j >> 2) + 4 * gg + (j & 3);
+                    f2[j >> 2][j & 3] = (ii / FH == k / FH) ? lw[LL::w2_off(ii, k)] : 0.0f;
+                    f6[j >> 2][j & 3] = lw[LL::w6 + ii * F + k];
+                }
+            }
+        }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int t = threadIdx.x + NT * u, i = t >> 5, k = t & 31;
@@ -193,6 +250,14 @@ struct StageW16 {
         }
         if (threadIdx.x < 160) sm[W16::o_vec + threadIdx.x] = vv;
         if (kB && threadIdx.x < W16::border_size) sm[W16::border_base(kBwd) + threadIdx.x] = vb;
+        if constexpr (kFrag) {
+            if (threadIdx.x < 128) {
+                const int bo = threadIdx.x >> 6, l = threadIdx.x & 63;
+                float* fb = sm + W16::frag_base(kBwd, kB);
+                frag_store(f2, fb + W16::f_w2 * W16::frag_floats, bo, l);
+                frag_store(f6, fb + W16::f_w6 * W16::frag_floats, bo, l);
+            }
+        }
     }
 };
 
@@ -219,6 +284,59 @@ __device__ __forceinline__ void mv16(const float* mat, int i, int g, const f32x4
             acc[1] = mfma16(a[bi][1][r], v[bi][r], acc[1]);
         }
 }
+// ---- the same product on split-bf16 operands: the lane's own eight features of the L16 layout are the B operand as they stand
+// frag: [3 levels][2 row blocks][64 lanes] fragments of the matrix (build_frag16); acc[bo] += (W v)[16 bo + ...]
+__device__ __forceinline__ void mv16_bf(const float* frag, int lane, const f32x4 (&v)[2], f32x4 (&acc)[2]) {
+    const bf16x8* f = reinterpret_cast<const bf16x8*>(frag);
+    bf16x8 vh, vm, vl;
+    split3_bf16(v, vh, vm, vl);
+#pragma unroll
+    for (int bo = 0; bo < 2; ++bo) {
+        const bf16x8 ah = f[(0 * 2 + bo) * 64 + lane], am = f[(1 * 2 + bo) * 64 + lane], al = f[(2 * 2 + bo) * 64 + lane];
+        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, vh, acc[bo], 0, 0, 0);        // smallest terms first
+        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, vl, acc[bo], 0, 0, 0);
+        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, vm, acc[bo], 0, 0, 0);
+        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, vh, acc[bo], 0, 0, 0);
+        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, vm, acc[bo], 0, 0, 0);
+        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, vh, acc[bo], 0, 0, 0);
+    }
+}
+// fragments of the fp32 image `mat` (row stride WS, as mv16 reads it) -> frag: threads 0..127 of the workgroup, one (row block, lane) each
+__device__ __forceinline__ void build_frag16(const float* mat, float* frag, int t) {
+    const int bo = t >> 6, l = t & 63, i = l & 15, g = l >> 4;
+    f32x4 x[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j >> 2][j & 3] = mat[(16 * bo + i) * W16::WS + 16 * (j >> 2) + 4 * g + (j & 3)];
+    frag_store(x, frag, bo, l);
+}
+// after the fp32 image is complete (and a workgroup barrier): the split fragments of its 32 x 32 matrices; followed by another barrier
+template <bool kBwd, int kB, bool kBf = true>
+__device__ __forceinline__ void build_frags16(float* sm) {
+    if constexpr (kBf && W16::use_bf16(kBwd, kB)) {
+    float* fb = sm + W16::frag_base(kBwd, kB);
+    const int t = threadIdx.x;
+    if (t < 128) {
+        build_frag16(sm + W16::o_w2, fb + W16::f_w2 * W16::frag_floats, t);
+        build_frag16(sm + W16::o_w6, fb + W16::f_w6 * W16::frag_floats, t);
+    } else if (kBwd && t < 256) {
+        build_frag16(sm + W16::o_w2t, fb + W16::f_w2t * W16::frag_floats, t - 128);
+        build_frag16(sm + W16::o_w6t, fb + W16::f_w6t * W16::frag_floats, t - 128);
+    }
+    __syncthreads();
+    }
+}
+// the edge kernels' product: split-bf16 fragments or the fp32 image
+template <bool kBwd, int kB, bool kBf = true>
+__device__ __forceinline__ void mv16_edge(const float* wsm, int which, int i, int g, const f32x4 (&v)[2], f32x4 (&acc)[2]) {
+#ifndef EQ_BF16X3_WHICH
+#define EQ_BF16X3_WHICH 15
+#endif
+    if (kBf && W16::use_bf16(kBwd, kB) && ((EQ_BF16X3_WHICH >> which) & 1))
+        mv16_bf(wsm + W16::frag_base(kBwd, kB) + which * W16::frag_floats, 16 * g + i, v, acc);
+    else
+        mv16(wsm + (which == W16::f_w2 ? W16::o_w2 : which == W16::f_w6 ? W16::o_w6 : which == W16::f_w2t ? W16::o_w2t : W16::o_w6t), i, g, v, acc);
+}
+
 // border of y = W v (hidden_nf = 33): acc += W[:, 32] vb (column vector `col`), returns W[32, :32] . v + wcc vb (row vector `row`)
 __device__ __forceinline__ float mv16_border(const float* col, const float* row, float wcc, int g, const f32x4 (&v)[2], float vb,
                                              f32x4 (&acc)[2]) {
@@ -262,7 +380,7 @@ using PRows = PRowsT<0>;
 
 // wsm: the workgroup's weight image (through an opaque offset so the loop-invariant reads stay inside the loop), bord: its
 // border block; geo_row: this edge's 16 geometry values in LDS; pw: its projection rows (already in registers).
-template <int kB>
+template <int kB, bool kBwdImg = false, bool kBf = true>
 __device__ __forceinline__ void tile_forward16(const float* wsm, const float* bord, const float* geo_row, const PRowsT<kB>& pw, int i,
                                                int g, Sub16& o) {
     constexpr float kInvF = 1.0f / (32 + kB);
@@ -290,7 +408,7 @@ __device__ __forceinline__ void tile_forward16(const float* wsm, const float* bo
         u[b] = lds4(wsm + W16::o_vec + 0 * 32 + 16 * b + 4 * g);       // b2
     }
     EQ_STAMP(5);
-    mv16(wsm + W16::o_w2, i, g, a1v, u);
+    mv16_edge<kBwdImg, kB, kBf>(wsm, W16::f_w2, i, g, a1v, u);
     float ub = 0.0f;
     if constexpr (kB == 1) {
         o.sg1b = sigmoid_fast(o.t1b);
@@ -313,7 +431,7 @@ __device__ __forceinline__ void tile_forward16(const float* wsm, const float* bo
         o.q[b] = lds4(wsm + W16::o_vec + 3 * 32 + 16 * b + 4 * g);     // b6
     }
     EQ_STAMP(7);
-    mv16(wsm + W16::o_w6, i, g, o.m, o.q);
+    mv16_edge<kBwdImg, kB, kBf>(wsm, W16::f_w6, i, g, o.m, o.q);
     if constexpr (kB == 1) {
         o.xhatb = cb * o.rstd;
         o.mb = fmaf(o.xhatb, bord[W16::b_sc + 3], bord[W16::b_sc + 4]);

@@ -36,7 +36,7 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8& hi, bf16x8& 
 
 // MODE 0: fp32 MFMA tile chain; MODE 1: bf16 x 3 tile chain.  `iters` dependent tiles per wave.
 template <int MODE>
-__global__ __launch_bounds__(512) void chain_kernel(const float* __restrict__ W, const float* __restrict__ v0, float* __restrict__ out, int iters) {
+__global__ __launch_bounds__(512) void chain_kernel(const float* __restrict__ W, const float* __restrict__ v0, float* __restrict__ out, int iters, float bias = 0.0f) {
     __shared__ float wf[32 * WS];
     __shared__ bf16x8 ws[3][2][64];           // [level][bo][lane]: the A fragment of lane (row i, g): W[16 bo + i][feat_of(g, j)], pre-split
     const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(512) void chain_kernel(const float* __restrict__ W,
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[b][r] = v0[((size_t)(wave & 63) * 16 + i) * 32 + 16 * b + 4 * g + r];
     for (int it = 0; it < iters; ++it) {
-        f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+        f32x4 acc[2] = {f32x4{bias, bias, bias, bias}, f32x4{bias, bias, bias, bias}};
         if (MODE == 0) {
             f32x4 a[2][2];
 #pragma unroll
@@ -126,6 +126,25 @@ int main() {
             e_f32 = fmax(e_f32, fabs(o0[t * 32 + o] - ref)); e_bf = fmax(e_bf, fabs(o1[t * 32 + o] - ref));
         }
     printf("one tile vs fp64 (|y| up to %.2f): fp32 MFMA max err %.3e   bf16 x 3 (6 products) max err %.3e\n", ymax, e_f32, e_bf);
+    // ---- stress: wide dynamic range inside the vector (lognormal, sigma 3) and an accumulator that starts at a large bias
+    for (int trial = 0; trial < 3; ++trial) {
+        const float bias = trial == 0 ? 0.0f : (trial == 1 ? 37.5f : 4000.0f);
+        std::vector<float> V2(n_v);
+        for (auto& x : V2) { const float u1 = (rand() + 1.0f) / (RAND_MAX + 2.0f), u2 = rand() / (float)RAND_MAX; x = expf(3.0f * sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2)) * ((rand() & 1) ? 1.f : -1.f); }
+        (void)hipMemcpy(dV, V2.data(), n_v * 4, hipMemcpyHostToDevice);
+        chain_kernel<0><<<16, 256>>>(dW, dV, dO, 1, bias); (void)hipMemcpy(o0.data(), dO, o0.size() * 4, hipMemcpyDeviceToHost);
+        chain_kernel<1><<<16, 256>>>(dW, dV, dO, 1, bias); (void)hipMemcpy(o1.data(), dO, o1.size() * 4, hipMemcpyDeviceToHost);
+        double ef = 0, eb = 0, sc = 0;
+        for (int t = 0; t < 64 * 16; ++t)
+            for (int o = 0; o < 32; ++o) {
+                double y = bias, ab = fabs(bias);
+                for (int k = 0; k < 32; ++k) { y += (double)W[o * 32 + k] * (double)V2[t * 32 + k]; ab += fabs((double)W[o * 32 + k] * (double)V2[t * 32 + k]); }
+                const double ref = y * 0.17f + (double)V2[t * 32 + o] * 0.5;
+                ef = fmax(ef, fabs(o0[t * 32 + o] - ref) / ab); eb = fmax(eb, fabs(o1[t * 32 + o] - ref) / ab);
+            }
+        printf("stress (lognormal vector, accumulator starts at %.1f): max error / sum|a b|: fp32 MFMA %.3e   bf16 x 3 %.3e\n", bias, ef, eb);
+    }
+    (void)hipMemcpy(dV, V.data(), n_v * 4, hipMemcpyHostToDevice);
     // ---- time: dependent chains, all CUs, one / two waves per SIMD
     const int iters = 20000;
     for (int wps = 1; wps <= 2; ++wps) {
