@@ -287,3 +287,53 @@ def test_torch_library_registration_loads_and_has_no_cpu_backend():
         assert hasattr(torch.ops.equigspr, name)
     with pytest.raises(NotImplementedError):
         ops.knn_graph(torch.rand(10, 3), 3, True)
+
+
+def test_irrep_abi_sizes_and_parameter_layout():
+    """Host-side queries of the N4 C-ABI (no GPU): moments / work / saved sizes grow with the graph, unsupported shapes are refused, and
+    the typed network's parameter block puts every tensor on a 16-byte boundary in named_parameters() order (what flat.FlatParamsMixin
+    lays the nn.Parameters out by)."""
+    import ctypes
+    from se3_equi_graph_registration_amd import _lib, sh
+    L = pk.lib()
+    k = sh.degree1_closed_form()
+    cfg = _lib.IrrepConfig(32, 8, 32, 8, 32, *k)
+    lc = 4 * 32 + 10 * 8
+    assert L.equigspr_irrep_moments_size(ctypes.byref(cfg), 4096, 81920) == 4096 * lc * 33 + 5 * 81920
+    assert L.equigspr_irrep_bwd_work_size(ctypes.byref(cfg), 4096, 81920) > 2 * 4096 * lc * 33
+    assert L.equigspr_irrep_moments_size(ctypes.byref(_lib.IrrepConfig(33, 8, 32, 8, 32, *k)), 16, 16) == -1      # > 32 channels
+    assert L.equigspr_irrep_moments_size(ctypes.byref(_lib.IrrepConfig(32, 8, 32, 8, 24, *k)), 16, 16) == -1      # radial hidden 24
+    g = _lib.IrrepGnnConfig(30, 32, 27, 7, 3, 32, *k)
+    total = L.equigspr_irrep_gnn_param_count(ctypes.byref(g))
+    offs = [L.equigspr_irrep_gnn_param_offset(ctypes.byref(g), l, w) for l in range(3) for w in range(6)]
+    offs += [L.equigspr_irrep_gnn_param_offset(ctypes.byref(g), l, w) for l in range(2) for w in (6, 7)]
+    offs.append(L.equigspr_irrep_gnn_param_offset(ctypes.byref(g), 0, 8))
+    assert all(o >= 0 and o % 4 == 0 for o in offs) and offs == sorted(offs) and len(set(offs)) == len(offs)
+    assert offs[-1] + 7 <= total and total % 4 == 0
+    assert L.equigspr_irrep_gnn_param_offset(ctypes.byref(g), 2, 6) == -1          # the last layer has no gate
+    assert L.equigspr_irrep_gnn_saved_size(ctypes.byref(g), 1000, 20000) > 0 and L.equigspr_irrep_gnn_work_size(ctypes.byref(g), 1000, 20000) > 0
+
+
+def test_captured_collective_probe_switches():
+    """dp.captured_collectives_work: the environment switches decide without a process group or a GPU."""
+    import os
+    from se3_equi_graph_registration_amd import dp
+    old = os.environ.get("EQUIGSPR_TRUST_CAPTURED_COLLECTIVES")
+    try:
+        os.environ["EQUIGSPR_TRUST_CAPTURED_COLLECTIVES"] = "0"
+        import torch.distributed as dist
+        mine = not dist.is_initialized()
+        if mine:
+            dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:29713", rank=0, world_size=1)
+        try:
+            assert dp.captured_collectives_work(None, "cpu") is False
+            os.environ["EQUIGSPR_TRUST_CAPTURED_COLLECTIVES"] = "1"
+            assert dp.captured_collectives_work(None, "cpu") is True
+        finally:
+            if mine:
+                dist.destroy_process_group()
+    finally:
+        if old is None:
+            os.environ.pop("EQUIGSPR_TRUST_CAPTURED_COLLECTIVES", None)
+        else:
+            os.environ["EQUIGSPR_TRUST_CAPTURED_COLLECTIVES"] = old

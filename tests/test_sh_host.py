@@ -82,3 +82,29 @@ def test_q_j_intertwines_and_is_cached_on_disk(tmp_path):
     third = subprocess.run([sys.executable, "-c", code.replace("(2, 1, 1)", "(1, 1, 0)")],
                            env=dict(env, CLEAR_CACHE="1", CACHE_PATH=str(tmp_path / "cache")), capture_output=True, text=True, timeout=300)
     assert third.returncode == 0 and len(os.listdir(tmp_path / "cache")) == n_before                  # CLEAR_CACHE: nothing written
+
+
+def test_degree1_closed_form_matches_the_oracle_basis():
+    """The six constants the N4 kernels evaluate in registers (sh.degree1_closed_form, fitted to the package's own host basis) reproduce
+    the ORACLE's get_basis tensors of degrees <= 1 (tools/basis.py:153-205 restated) at random directions: K00, K01, K10 and the three
+    J-components of K11 in closed form."""
+    import numpy as np
+    import torch
+    from oracle import sh_oracle as so
+    from se3_equi_graph_registration_amd import sh
+    k00, k01, k10, k110, k111, k112 = sh.degree1_closed_form()
+    pts = np.random.default_rng(3).standard_normal((40, 3))
+    u = pts / np.linalg.norm(pts, axis=1, keepdims=True)
+    K = so.get_basis(torch.from_numpy(pts), 1)
+    eps = np.zeros((3, 3, 3))
+    eps[0, 1, 2] = eps[1, 2, 0] = eps[2, 0, 1] = 1.0
+    eps[0, 2, 1] = eps[2, 1, 0] = eps[1, 0, 2] = -1.0
+    k11 = K["1,1"].reshape(-1, 3, 3, 3).numpy()
+    assert np.abs(K["0,0"].reshape(-1).numpy() - k00).max() < 1e-12
+    assert np.abs(K["0,1"].reshape(-1, 3).numpy() - k01 * u).max() < 1e-12
+    assert np.abs(K["1,0"].reshape(-1, 3).numpy() - k10 * u).max() < 1e-12
+    assert np.abs(k11[..., 0] - k110 * np.eye(3)).max() < 1e-12
+    assert np.abs(k11[..., 1] - k111 * np.einsum("abc,nc->nab", eps, u)).max() < 1e-12
+    assert np.abs(k11[..., 2] - k112 * (np.einsum("na,nb->nab", u, u) - np.eye(3) / 3.0)).max() < 1e-12
+    # Y_1(x) = c x / |x| with the same constant up to the sign convention of Q: |k01| = |k00| = 1 / sqrt(4 pi)
+    assert abs(abs(k01) - (4 * np.pi) ** -0.5) < 1e-12 and abs(k00 - (4 * np.pi) ** -0.5) < 1e-12
