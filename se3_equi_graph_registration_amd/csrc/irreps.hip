@@ -30,6 +30,7 @@
 //    `irrep_expand16_kernel` (dM = W^T g) + `irrep_geom_bwd_kernel` (per edge: d hid, d u -> d x, d w_r1, d b_r1) +
 //    `irrep_wgrad16_kernel` (dW = g^T M over node ranges, slabs summed in fixed order) complete it.  No atomics anywhere:
 //    bitwise reproducible.
+#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -572,6 +573,7 @@ __global__ __launch_bounds__(64 * kFW) void irrep_conv_fused_kernel(const MomArg
     auto chunk = [&](auto tag) {
         constexpr int CH = decltype(tag)::value;
         constexpr int nb = (NB - 3 * CH) < 3 ? (NB - 3 * CH) : 3;
+        if (3 * CH >= 4 * B0 && a.c1 == 0) return;                     // workgroup-uniform: a chunk of c10 / c11 blocks, none active
         // phase A
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -705,10 +707,12 @@ __global__ __launch_bounds__(64 * kFW) void irrep_conv_fused_kernel(const MomArg
 static constexpr size_t kFusedLds = (16 * kFS + 16 * 48) * sizeof(float) + (size_t)kFW * 128 * sizeof(float4);
 
 // fused launch when the shape fits (B0 = 2 or 1, C1P = 8, H = 32); returns false otherwise
+// Off by default (equigspr_set_irrep_fused): measured 77 us against 39 + 30 us for the two launches at one 2 048-point pair and equal
+// to them at 16 pairs -- it removes the moments' 224 MB of HBM traffic per layer and the buffer itself, but
+// re-walks every node's edges once per chunk at two waves per SIMD.
+static std::atomic<int> g_use_fused{0};
 static bool launch_fused(const MomArgs& m, const NodeArgs& nd, int H, hipStream_t s) {
-#ifdef EQ_IR_NO_FUSED
-    return false;
-#endif
+    if (!g_use_fused.load(std::memory_order_relaxed)) return false;
     if (H != 32 || m.c1p != 8 || (m.c0p != 32 && m.c0p != 16)) return false;
     const int cb0 = ceil_div(nd.o0, 16), cb1 = ceil_div(nd.o1, 16);
     const dim3 grid(ceil_div(m.n_nodes, 16)), block(64 * kFW);
@@ -975,8 +979,9 @@ __global__ __launch_bounds__(256) void irrep_geom_bwd_kernel(const GeomArgs a) {
                 du[aa] = fmaf(a.k.k01, dc[0] * gv[0] + dc[1] * gv[1] + dc[2] * gv[2] + dc[3] * gv[3], du[aa]);
             }
         }
-        // ---- entries built from f1
-        if (C1P == 8) {
+        // ---- entries built from f1 (none active: the first layer of a stack whose input has no degree-1 features)
+        if (a.c1 == 0) {
+        } else if (C1P == 8) {
             // block t holds slots 2 t (lane groups g = 0, 1) and 2 t + 1 (g = 2, 3) of channels 4 (g & 1) + r
             const int ch0 = 4 * (g & 1);
             const bool up = g >= 2;
@@ -1293,7 +1298,7 @@ static bool config_ok(const equigspr_irrep_config* c) {
 
 template <int NH>
 static void launch_moments(const MomArgs& a, hipStream_t s) {
-    const int B0 = a.c0p / 16, units = 1 + (a.c1p == 8 ? 1 : 2 * (a.c1p / 16));
+    const int B0 = a.c0p / 16, units = a.c1 == 0 ? 1 : 1 + (a.c1p == 8 ? 1 : 2 * (a.c1p / 16));
     const dim3 grid(ceil_div(a.n_nodes, 4), units), block(256);
 #define EQ_IR_MOM(BB, CC) \
     if (B0 == BB && a.c1p == CC) { hipLaunchKernelGGL((irrep_moments16_kernel<NH, BB, CC>), grid, block, 0, s, a); return; }
@@ -1328,17 +1333,20 @@ static EdgeTab table_at(const float* buf, int n_edges) {
 static void conv_forward(const equigspr_irrep_config* c, const Layout& L, const float* w_r1, const float* b_r1, const float* w_r2,
                          const float* b_r2, const float* ws0, const float* ws1, const equigspr_graph* g, const float* f0,
                          const float* f1, const EdgeTab& tab, float* out0, float* out1, float* M, float* Mb, hipStream_t s,
-                         bool keep_moments = true) {
-    const int H = L.H, c0p = pad0(L.c0i), c1p = pad1(L.c1i), lc = 4 * c0p + 10 * c1p;
+                         bool keep_moments = true, bool f1_zero = false) {
+    // f1_zero (the first layer of IrrepEGNN: the input has no degree-1 features): the kernels run with ZERO active degree-1 input
+    // channels -- same layouts and offsets (c1p), the c10 / c11 entries neither computed nor read
+    const int H = L.H, c0p = pad0(L.c0i), c1p = pad1(L.c1i), lc = 4 * c0p + 10 * c1p, c1a = f1_zero ? 0 : L.c1i;
     MomArgs m{f0, f1, g->rptr, tab, w_r1, b_r1, Consts{c->k00, c->k01, c->k10, c->k11_0, c->k11_1, c->k11_2},
-              g->n_nodes, L.c0i, L.c1i, c0p, c1p, lc, M, Mb};
+              g->n_nodes, L.c0i, c1a, c0p, c1p, lc, M, Mb};
     NodeArgs nd{M, Mb, f0, f1,
                 PathW{w_r2 + (size_t)L.off00 * H, b_r2 + L.off00, L.c0i * H, H},
                 PathW{w_r2 + (size_t)L.off10 * H, b_r2 + L.off10, L.c1i * H, H},
                 PathW{w_r2 + (size_t)L.off01 * H, b_r2 + L.off01, L.c0i * H, H},
                 PathW{w_r2 + (size_t)L.off11 * H, b_r2 + L.off11, L.c1i * 3 * H, 3 * H},
                 SelfW{ws0, L.c0i, 1}, SelfW{ws1, L.c1i, 1},
-                g->n_nodes, L.c0i, L.c1i, c0p, c1p, lc, L.c0o, L.c1o, out0, out1};
+                g->n_nodes, L.c0i, c1a, c0p, c1p, lc, L.c0o, L.c1o, out0, out1};
+    if (!keep_moments && launch_fused(m, nd, H, s)) return;
     if (H == 16) { launch_moments<1>(m, s); launch_node<1>(nd, s); }
     else { launch_moments<2>(m, s); launch_node<2>(nd, s); }
 }
@@ -1388,8 +1396,8 @@ static void conv_backward(const equigspr_irrep_config* c, const Layout& L, const
                           const float* b_r2, const float* ws0, const float* ws1, const equigspr_graph* g, const float* f0,
                           const float* f1, const EdgeTab& tabF, const EdgeTab& tabR, const float* M, const float* g0, const float* g1,
                           float* d_f0, float* d_f1, float* d_x, float* d_w1, float* d_b1, float* d_w2, float* d_b2, float* d_ws0,
-                          float* d_ws1, float* work, hipStream_t s, int accumulate = 0) {
-    const int H = L.H, N = g->n_nodes;
+                          float* d_ws1, float* work, hipStream_t s, int accumulate = 0, bool f1_zero = false) {
+    const int H = L.H, N = g->n_nodes, c1a = f1_zero ? 0 : L.c1i;
     const BwdPlan p = plan_bwd(L, N, g->n_edges);
     const Consts kf{c->k00, c->k01, c->k10, c->k11_0, c->k11_1, c->k11_2};
     const int c0p = pad0(L.c0i), c1p = pad1(L.c1i);
@@ -1414,8 +1422,8 @@ static void conv_backward(const equigspr_irrep_config* c, const Layout& L, const
         else { launch_moments<2>(m, s); launch_node<2>(nd, s); }
     }
     // geometry + radial.0
-    ExpArgs ex{g0, g1, f00, f10, f01, f11, N, L.c0i, L.c1i, c0p, c1p, p.lc, L.c0o, L.c1o, work + p.o_dM, work + p.o_dMb};
-    GeomArgs ge{f0, f1, g->rptr, g->rperm, tabF, w_r1, b_r1, kf, N, L.c0i, L.c1i, c0p, c1p, p.lc, work + p.o_dM, work + p.o_dMb,
+    ExpArgs ex{g0, g1, f00, f10, f01, f11, N, L.c0i, c1a, c0p, c1p, p.lc, L.c0o, L.c1o, work + p.o_dM, work + p.o_dMb};
+    GeomArgs ge{f0, f1, g->rptr, g->rperm, tabF, w_r1, b_r1, kf, N, L.c0i, c1a, c0p, c1p, p.lc, work + p.o_dM, work + p.o_dMb,
                 work + p.o_dr, work + p.o_dxr, work + p.o_gslab};
     const dim3 egrid(ceil_div(N, 16 * kExpTiles)), eblock(64 * kNodeWaves);
     if (H == 16) { hipLaunchKernelGGL((irrep_expand16_kernel<1>), egrid, eblock, 0, s, ex); launch_geom<1>(ge, s); }
@@ -1423,9 +1431,12 @@ static void conv_backward(const equigspr_irrep_config* c, const Layout& L, const
     if (d_x) hipLaunchKernelGGL(irrep_dx_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, work + p.o_dr, work + p.o_dxr, g->cptr, g->cperm, N, d_x);
     // weight gradients
     const int n_w = L.off11 + 3 * L.c1o * L.c1i;
-    WgradArgs wa{M, Mb, f0, f1, g0, g1, N, L.c0i, L.c1i, c0p, c1p, p.lc, L.c0o, L.c1o, H, L.off00, L.off01, L.off10, L.off11, n_w,
+    WgradArgs wa{M, Mb, f0, f1, g0, g1, N, L.c0i, c1a, c0p, c1p, p.lc, L.c0o, L.c1o, H, L.off00, L.off01, L.off10, L.off11, n_w,
                  p.nodes_per_split, work + p.o_wslab, p.P};
-    const dim3 wgrid(p.groups, p.splits);
+    // (no active degree-1 input: the groups of R10 / R11 / W_s1 rows do not exist -- their slab words are cleared, their gradients are zero)
+    const int groups = f1_zero ? 2 * ceil_div(L.c0i, 4) + ceil_div(L.c0i, 16) : p.groups;
+    if (f1_zero) (void)hipMemsetAsync(work + p.o_wslab, 0, sizeof(float) * (size_t)p.splits * p.P, s);
+    const dim3 wgrid(groups, p.splits);
     if (H == 16) hipLaunchKernelGGL((irrep_wgrad16_kernel<1>), wgrid, dim3(64), 0, s, wa);
     else hipLaunchKernelGGL((irrep_wgrad16_kernel<2>), wgrid, dim3(64), 0, s, wa);
     const int nbA = ceil_div(p.P, 256);
@@ -1672,6 +1683,11 @@ extern "C" int equigspr_irrep_conv_forward(const equigspr_irrep_config* cfg, con
     return 0;
 }
 
+extern "C" int equigspr_set_irrep_fused(int32_t on) {
+    eq::ir::g_use_fused.store(on ? 1 : 0, std::memory_order_relaxed);
+    return 0;
+}
+
 extern "C" int64_t equigspr_irrep_bwd_work_size(const equigspr_irrep_config* cfg, int32_t n_nodes, int32_t n_edges) {
     using namespace eq::ir;
     if (!config_ok(cfg) || n_nodes < 0 || n_edges < 0) return -1;
@@ -1766,7 +1782,7 @@ extern "C" int equigspr_irrep_gnn_forward(const equigspr_irrep_gnn_config* cfg, 
         float* M = saved + P.s_M[l];
         const int64_t lcn = 4 * pad0(Ly.c0i) + 10 * pad1(Ly.c1i);
         conv_forward(&lc, Ly, params + P.o_w1[l], params + P.o_b1[l], params + P.o_w2[l], params + P.o_b2[l], params + P.o_s0[l],
-                     params + P.o_s1[l], g, f0, f1, tabF, p0, p1, M, M + (int64_t)N * lcn * P.H, s, training != 0);
+                     params + P.o_s1[l], g, f0, f1, tabF, p0, p1, M, M + (int64_t)N * lcn * P.H, s, training != 0, l == 0);
         if (!last)
             hipLaunchKernelGGL(irrep_gate_fwd_kernel, dim3(ceil_div(N, 64)), dim3(256), 0, s, p0, p1, params + P.o_gw[l], params + P.o_gb[l], N,
                                P.c0[l + 1], P.c1, saved + P.s_f0[l + 1], saved + P.s_f1[l + 1]);
@@ -1808,7 +1824,7 @@ extern "C" int equigspr_irrep_gnn_backward(const equigspr_irrep_gnn_config* cfg,
         float* df1 = !want_f ? nullptr : d1;
         conv_backward(&lc, Ly, params + P.o_w1[l], params + P.o_b1[l], params + P.o_w2[l], params + P.o_b2[l], params + P.o_s0[l],
                       params + P.o_s1[l], g, f0, f1, tabF, tabR, saved + P.s_M[l], gout0, g1, df0, df1, d_x, grads + P.o_w1[l], grads + P.o_b1[l],
-                      grads + P.o_w2[l], grads + P.o_b2[l], grads + P.o_s0[l], grads + P.o_s1[l], cw, s, 1);
+                      grads + P.o_w2[l], grads + P.o_b2[l], grads + P.o_s0[l], grads + P.o_s1[l], cw, s, 1, l == 0);
         if (l > 0) {
             // through the gate between layers l - 1 and l: (d0, d1) = d (f0_l, f1_l) -> (g0, g1) = d (p0, p1) of layer l - 1
             const int c0 = P.c0[l];
