@@ -82,8 +82,11 @@ __global__ void irrep_edge_table_kernel(const float* __restrict__ x, const int* 
 
 // One wave per (node, unit): unit 0 = the 4 c0p entries built from f0, units 1.. = 80-entry groups of the 10 c1p built from f1.
 // r = x[n] - x[src]: the caller flips k01 / k10 when it aggregates at the other end of the edges (the adjoint).
+#ifndef EQ_IR_MOM_OCC
+#define EQ_IR_MOM_OCC 5                 // workgroups per CU (= waves per SIMD) the register budget is set for; one pair: 43.3 us at three (140 registers), 35.7-36.9 at four (105), 33.1 at five
+#endif
 template <int NH, int B0, int C1P>
-__global__ __launch_bounds__(256) void irrep_moments16_kernel(const MomArgs a) {
+__global__ __launch_bounds__(256, EQ_IR_MOM_OCC) void irrep_moments16_kernel(const MomArgs a) {
     __shared__ float4 geo[4][2][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n = blockIdx.x * 4 + wv;
@@ -251,7 +254,11 @@ struct NodeArgs {
     float* out0; float* out1;       // [N, o0], [N, o1, 3]
 };
 
-constexpr int kNodeWaves = 8;
+#ifndef EQ_IR_NODE_WAVES
+#define EQ_IR_NODE_WAVES 16             // one pair has 256 node tiles: 16 waves per workgroup = four per SIMD (32.3 -> 29.1 us against 8)
+#endif
+constexpr int kNodeWaves = EQ_IR_NODE_WAVES;      // irrep_node16_kernel: waves per workgroup (they split K)
+constexpr int kExpWaves = 8;                       // irrep_expand16_kernel: waves per workgroup (one entry each per group)
 
 template <int NH, int NCB0, int NCB1>
 __global__ __launch_bounds__(64 * kNodeWaves) void irrep_node16_kernel(const NodeArgs a) {
@@ -739,10 +746,12 @@ struct ExpArgs {
     float* dM; float* dMb;                               // [N, lc, H], [N, lc]
 };
 
-constexpr int kExpTiles = 2;            // 16-node tiles per workgroup: every weight row a wave loads feeds both (the weights come from L2: 228 KB per workgroup at 32 + 8 channels)
+constexpr int kExpLd = kExpWaves * 32 + 4;      // floats between nodes of the staging buffer (= 4 mod 32: conflict-free 16-byte writes of 8 nodes)
+constexpr int kExpTiles = 1;
+constexpr int kExpSplit = 2;            // workgroups per node tile (each takes a contiguous share of the entry groups): four waves per SIMD at one pair instead of two            // 16-node tiles per workgroup: every weight row a wave loads feeds both (the weights come from L2: 228 KB per workgroup at 32 + 8 channels)
 
 template <int NH>
-__global__ __launch_bounds__(64 * kNodeWaves) void irrep_expand16_kernel(const ExpArgs a) {
+__global__ __launch_bounds__(64 * kExpWaves) void irrep_expand16_kernel(const ExpArgs a) {
     constexpr int H = 16 * NH;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
@@ -761,20 +770,51 @@ __global__ __launch_bounds__(64 * kNodeWaves) void irrep_expand16_kernel(const E
         }
     }
     const int f1base = 4 * a.c0p;
-    for (int e = wv; e < a.lc; e += kNodeWaves) {                       // wave-uniform entry
-        int src, in, J = 0, cin, on;
+    // one entry's weights (A operands): W(o = 4 s + kq, entry, 16 t + i16) and the bias; requested one entry ahead (one wave per SIMD
+    // at one pair: the L2 round trip of an entry's sixteen loads was exposed 26 times per wave)
+    struct Ent { bool real; int src, nks; float wv_[8][NH], bw[8]; };
+    auto fetch = [&](int e, Ent& E_) {
+        int in, J = 0, cin, on;
         const PathW* p;
         if (e < f1base) {
             const int s = e / a.c0p;
             in = e - s * a.c0p; cin = a.c0;
-            src = s == 0 ? 0 : s; p = s == 0 ? &a.p00 : &a.p01; on = s == 0 ? a.o0 : a.o1;
+            E_.src = s == 0 ? 0 : s; p = s == 0 ? &a.p00 : &a.p01; on = s == 0 ? a.o0 : a.o1;
         } else {
             const int q = e - f1base, s = q / a.c1p;
             in = q - s * a.c1p; cin = a.c1;
-            if (s == 0) { src = 0; p = &a.p10; on = a.o0; }
-            else { const int aa = (s - 1) / 3; J = (s - 1) - 3 * aa; src = 1 + aa; p = &a.p11; on = a.o1; }
+            if (s == 0) { E_.src = 0; p = &a.p10; on = a.o0; }
+            else { const int aa = (s - 1) / 3; J = (s - 1) - 3 * aa; E_.src = 1 + aa; p = &a.p11; on = a.o1; }
         }
-        const bool real = in < cin;
+        E_.real = in < cin;
+        E_.nks = (on + 3) >> 2;
+        if (!E_.real) return;
+        const float* wp = p->w + (size_t)in * p->si + J * H;
+        const float* bp = p->b + ((size_t)in * p->si) / H + J;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int o = 4 * s + kq;
+            const bool ok = s < E_.nks && o < on;
+#pragma unroll
+            for (int t = 0; t < NH; ++t) E_.wv_[s][t] = ok ? wp[(size_t)o * p->so + 16 * t + i16] : 0.0f;
+            E_.bw[s] = ok ? bp[((size_t)o * p->so) / H] : 0.0f;
+        }
+    };
+    Ent nxt;
+    nxt.real = false; nxt.src = 0; nxt.nks = 0;
+    // this workgroup's share of the groups of 8 entries
+    const int n_grp = a.lc / kExpWaves, per = (n_grp + kExpSplit - 1) / kExpSplit;
+    const int e_lo = (int)blockIdx.y * per * kExpWaves, e_hi = min(a.lc, e_lo + per * kExpWaves);
+    if (e_lo + wv < e_hi) fetch(e_lo + wv, nxt);
+    // The tiles leave through LDS: a wave's own tile is 16 nodes x 64 bytes per store instruction, 27 KB apart (measured: 110 MB in
+    // 92 us = 1.2 TB/s); staged as [node][8 entries][H] the workgroup writes every node's 8 entries as ONE contiguous 1 KB row per
+    // instruction.  Two buffers: one barrier per group of 8 entries.
+    __shared__ __attribute__((aligned(16))) float stage[2][16 * kExpTiles * kExpLd];
+    int buf = 0;
+    for (int e0 = e_lo; e0 < e_hi; e0 += kExpWaves, buf ^= 1) {        // lc is a multiple of 16: every group is complete
+        const int e = e0 + wv;                                          // wave-uniform entry
+        const Ent cur = nxt;
+        if (e + kExpWaves < e_hi) fetch(e + kExpWaves, nxt);
         f32x4 acc[kExpTiles][NH];
         float bsum[kExpTiles];
 #pragma unroll
@@ -783,43 +823,38 @@ __global__ __launch_bounds__(64 * kNodeWaves) void irrep_expand16_kernel(const E
 #pragma unroll
             for (int t = 0; t < NH; ++t) acc[tl][t] = splat4(0.0f);
         }
-        if (real) {
-            const float* wp = p->w + (size_t)in * p->si + J * H;
-            const float* bp = p->b + ((size_t)in * p->si) / H + J;
-            const int nks = (on + 3) >> 2;
-            // D[h][node] = sum_o A[h][o] B[o][node]: A lane (h = i16, k = kq) = W(o = 4 s + kq, ., 16 t + h); all of the entry's weight
-            // loads are requested before the first product
-            float wv_[8][NH], bw[8];
+        if (cur.real) {
+            // D[h][node] = sum_o A[h][o] B[o][node]
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const int o = 4 * s + kq;
-                const bool ok = s < nks && o < on;
-#pragma unroll
-                for (int t = 0; t < NH; ++t) wv_[s][t] = ok ? wp[(size_t)o * p->so + 16 * t + i16] : 0.0f;
-                bw[s] = ok ? bp[((size_t)o * p->so) / H] : 0.0f;
-            }
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (s >= nks) break;
+                if (s >= cur.nks) break;
 #pragma unroll
                 for (int tl = 0; tl < kExpTiles; ++tl) {
-                    const float gvv = src == 0 ? ga[tl][0][s] : (src == 1 ? ga[tl][1][s] : (src == 2 ? ga[tl][2][s] : ga[tl][3][s]));
+                    const float gvv = cur.src == 0 ? ga[tl][0][s] : (cur.src == 1 ? ga[tl][1][s] : (cur.src == 2 ? ga[tl][2][s] : ga[tl][3][s]));
 #pragma unroll
-                    for (int t = 0; t < NH; ++t) acc[tl][t] = mfma16(wv_[s][t], gvv, acc[tl][t]);
-                    bsum[tl] = fmaf(gvv, bw[s], bsum[tl]);
+                    for (int t = 0; t < NH; ++t) acc[tl][t] = mfma16(cur.wv_[s][t], gvv, acc[tl][t]);
+                    bsum[tl] = fmaf(gvv, cur.bw[s], bsum[tl]);
                 }
             }
         }
-        // lane (node = i16, g = kq) holds h = 16 t + 4 g + r: one 16-byte store per tile
+        // lane (node = i16, g = kq) holds h = 16 t + 4 g + r  ->  stage[node][wv][h]
+        float* st = stage[buf];
 #pragma unroll
         for (int tl = 0; tl < kExpTiles; ++tl) {
             const float bt = gsum(bsum[tl]);
-            const int n = n0 + 16 * tl + i16;
-            if (n < a.n_nodes) {
+            const int nl = 16 * tl + i16;
 #pragma unroll
-                for (int t = 0; t < NH; ++t) st4(a.dM + ((size_t)n * a.lc + e) * H + 16 * t + 4 * kq, acc[tl][t]);
-                if (kq == 0) a.dMb[(size_t)n * a.lc + e] = bt;
-            }
+            for (int t = 0; t < NH; ++t) st4(st + nl * kExpLd + wv * H + 16 * t + 4 * kq, acc[tl][t]);
+            if (kq == 0 && n0 + nl < a.n_nodes) a.dMb[(size_t)(n0 + nl) * a.lc + e] = bt;
+        }
+        __syncthreads();
+        // rows out: wave w takes nodes w, w + 8, ...; 8 entries x H floats = one contiguous run per node
+        constexpr int RUN = kExpWaves * H;                             // floats per node and group (256 at H = 32: one 1 KB instruction)
+        for (int nl = wv; nl < 16 * kExpTiles; nl += kExpWaves) {
+            const int n = n0 + nl;
+            if (n >= a.n_nodes) continue;                               // wave-uniform
+            for (int c = 4 * lane; c < RUN; c += 256)
+                st4(a.dM + ((size_t)n * a.lc + e0) * H + c, lds4(st + nl * kExpLd + c));
         }
     }
 }
@@ -879,8 +914,11 @@ __device__ __forceinline__ void slot_du(const float (&gv)[3], const float (&u)[3
 
 constexpr int kTileStride = 36;      // dM tile [16 entries][H <= 32] in LDS: rows 36 floats apart (16-byte aligned rows, column reads spread over the banks)
 
+#ifndef EQ_IR_GEOM_OCC
+#define EQ_IR_GEOM_OCC 2
+#endif
 template <int NH, int C1P>
-__global__ __launch_bounds__(256) void irrep_geom_bwd_kernel(const GeomArgs a) {
+__global__ __launch_bounds__(256, EQ_IR_GEOM_OCC) void irrep_geom_bwd_kernel(const GeomArgs a) {
     constexpr int H = 16 * NH;
     __shared__ float tile_s[4][16 * kTileStride];
     __shared__ float red[4][2 * 32];
@@ -1108,11 +1146,15 @@ struct WgradArgs {
 };
 
 // groups: [0, G00): R00 rows i (4 per group) | [.., +G10): R10 | [.., +G01): R01 | [.., +G11): R11 rows (i, J) | self0 blocks | self1 blocks
+#ifndef EQ_IR_WG_ROWS
+#define EQ_IR_WG_ROWS 4                 // weight rows per wave (accumulator tiles = rows x NH x 2)
+#endif
+constexpr int kWgRows = EQ_IR_WG_ROWS;
 template <int NH>
 __global__ __launch_bounds__(64) void irrep_wgrad16_kernel(const WgradArgs a) {
     constexpr int H = 16 * NH;
     const int lane = threadIdx.x, i16 = lane & 15, kq = lane >> 4;
-    const int G00 = (a.c0 + 3) >> 2, G10 = (a.c1 + 3) >> 2, G01 = G00, G11 = (3 * a.c1 + 3) >> 2;
+    const int G00 = (a.c0 + kWgRows - 1) / kWgRows, G10 = (a.c1 + kWgRows - 1) / kWgRows, G01 = G00, G11 = (3 * a.c1 + kWgRows - 1) / kWgRows;
     const int GS0 = (a.c0 + 15) >> 4, GS1 = (a.c1 + 15) >> 4;
     int grp = blockIdx.x;
     const int split = blockIdx.y;
@@ -1165,11 +1207,11 @@ __global__ __launch_bounds__(64) void irrep_wgrad16_kernel(const WgradArgs a) {
     // ---- radial.2 rows: up to four (in, J) rows of one path
     const int cin = (kind == 0 || kind == 2) ? a.c0 : a.c1;
     const int nrow_total = kind == 3 ? 3 * a.c1 : cin;
-    const int row0 = 4 * grp;
-    f32x4 acc[4][NH][2];
-    float bacc[4][2];
+    const int row0 = kWgRows * grp;
+    f32x4 acc[kWgRows][NH][2];
+    float bacc[kWgRows][2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < kWgRows; ++q)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             bacc[q][cb] = 0.0f;
@@ -1192,7 +1234,7 @@ __global__ __launch_bounds__(64) void irrep_wgrad16_kernel(const WgradArgs a) {
                 bv[cb] = (ok && cb < ncb && 16 * cb + i16 < on) ? gvv : 0.0f;
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < kWgRows; ++q) {
                 const int row = row0 + q;
                 if (row >= nrow_total) break;                                     // wave-uniform
                 int entry;
@@ -1218,7 +1260,7 @@ __global__ __launch_bounds__(64) void irrep_wgrad16_kernel(const WgradArgs a) {
     // D[h][o]: lane (o = i16, g = kq) holds h = 16 t + 4 g + r.  Parameter layout: row index (o * cin + in) (* 3 + J for R11)
     const int off = kind == 0 ? a.off00 : (kind == 1 ? a.off10 : (kind == 2 ? a.off01 : a.off11));
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < kWgRows; ++q) {
         const int row = row0 + q;
         if (row >= nrow_total) break;
 #pragma unroll
@@ -1364,7 +1406,7 @@ static BwdPlan plan_bwd(const Layout& L, int n_nodes, int n_edges) {
     p.lc_r = 4 * pad0(L.c0o) + 10 * pad1(L.c1o);
     const int n_w = L.off11 + 3 * L.c1o * L.c1i;
     p.P = n_w * (H + 1) + L.c0o * L.c0i + L.c1o * L.c1i;
-    p.groups = 2 * ceil_div(L.c0i, 4) + ceil_div(L.c1i, 4) + ceil_div(3 * L.c1i, 4) + ceil_div(L.c0i, 16) + ceil_div(L.c1i, 16);
+    p.groups = 2 * ceil_div(L.c0i, kWgRows) + ceil_div(L.c1i, kWgRows) + ceil_div(3 * L.c1i, kWgRows) + ceil_div(L.c0i, 16) + ceil_div(L.c1i, 16);
     int want = ceil_div(4096, p.groups);                                 // ~4 k waves: four per SIMD (the accumulators' budget)
     want = max(1, min(want, ceil_div(max(n_nodes, 1), 16)));
     p.nodes_per_split = round_up(ceil_div(max(n_nodes, 1), want), 4);
@@ -1425,7 +1467,7 @@ static void conv_backward(const equigspr_irrep_config* c, const Layout& L, const
     ExpArgs ex{g0, g1, f00, f10, f01, f11, N, L.c0i, c1a, c0p, c1p, p.lc, L.c0o, L.c1o, work + p.o_dM, work + p.o_dMb};
     GeomArgs ge{f0, f1, g->rptr, g->rperm, tabF, w_r1, b_r1, kf, N, L.c0i, c1a, c0p, c1p, p.lc, work + p.o_dM, work + p.o_dMb,
                 work + p.o_dr, work + p.o_dxr, work + p.o_gslab};
-    const dim3 egrid(ceil_div(N, 16 * kExpTiles)), eblock(64 * kNodeWaves);
+    const dim3 egrid(ceil_div(N, 16 * kExpTiles), kExpSplit), eblock(64 * kExpWaves);
     if (H == 16) { hipLaunchKernelGGL((irrep_expand16_kernel<1>), egrid, eblock, 0, s, ex); launch_geom<1>(ge, s); }
     else { hipLaunchKernelGGL((irrep_expand16_kernel<2>), egrid, eblock, 0, s, ex); launch_geom<2>(ge, s); }
     if (d_x) hipLaunchKernelGGL(irrep_dx_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, work + p.o_dr, work + p.o_dxr, g->cptr, g->cperm, N, d_x);
@@ -1434,7 +1476,7 @@ static void conv_backward(const equigspr_irrep_config* c, const Layout& L, const
     WgradArgs wa{M, Mb, f0, f1, g0, g1, N, L.c0i, c1a, c0p, c1p, p.lc, L.c0o, L.c1o, H, L.off00, L.off01, L.off10, L.off11, n_w,
                  p.nodes_per_split, work + p.o_wslab, p.P};
     // (no active degree-1 input: the groups of R10 / R11 / W_s1 rows do not exist -- their slab words are cleared, their gradients are zero)
-    const int groups = f1_zero ? 2 * ceil_div(L.c0i, 4) + ceil_div(L.c0i, 16) : p.groups;
+    const int groups = f1_zero ? 2 * ceil_div(L.c0i, kWgRows) + ceil_div(L.c0i, 16) : p.groups;
     if (f1_zero) (void)hipMemsetAsync(work + p.o_wslab, 0, sizeof(float) * (size_t)p.splits * p.P, s);
     const dim3 wgrid(groups, p.splits);
     if (H == 16) hipLaunchKernelGGL((irrep_wgrad16_kernel<1>), wgrid, dim3(64), 0, s, wa);
