@@ -399,6 +399,121 @@ std::tuple<at::Tensor, at::Tensor> pose_loss_forward_autograd(const at::Tensor& 
     auto out = PoseLossFn::apply(R, t, gt);
     return {out[0], out[1]};
 }
+
+// ---- N4: typed irrep-basis message passing (equigspr_irrep_conv_forward / _backward; no reference layer exists -- the consumer the basis
+// of tools/basis.py:153-205 was written for).  basis = the six closed-form constants (k00, k01, k10, k11_0, k11_1, k11_2).
+struct IrrepGraph {
+    at::Tensor rptr, rperm, rinv, cptr, cperm, scratch;
+    equigspr_graph g;
+};
+IrrepGraph irrep_graph(const at::Tensor& row, const at::Tensor& col, int64_t n, bool need_col, void* s) {
+    IrrepGraph G;
+    const int64_t e = row.size(0);
+    auto io = row.options();
+    G.rptr = at::empty({n + 1}, io); G.rperm = at::empty({std::max<int64_t>(e, 1)}, io); G.rinv = at::empty({std::max<int64_t>(e, 1)}, io);
+    G.scratch = at::empty({n + 1}, io);
+    check(equigspr_build_csr(row.data_ptr<int32_t>(), (int32_t)e, (int32_t)n, G.rptr.data_ptr<int32_t>(), G.rperm.data_ptr<int32_t>(),
+                             G.rinv.data_ptr<int32_t>(), G.scratch.data_ptr<int32_t>(), EQUIGSPR_SCRATCH_DIRTY, nullptr, s), "build_csr(row)");
+    if (need_col) {
+        G.cptr = at::empty({n + 1}, io); G.cperm = at::empty({std::max<int64_t>(e, 1)}, io);
+        check(equigspr_build_csr(col.data_ptr<int32_t>(), (int32_t)e, (int32_t)n, G.cptr.data_ptr<int32_t>(), G.cperm.data_ptr<int32_t>(),
+                                 nullptr, G.scratch.data_ptr<int32_t>(), EQUIGSPR_SCRATCH_DIRTY, nullptr, s), "build_csr(col)");
+    }
+    G.g = equigspr_graph{(int32_t)n, (int32_t)e, row.data_ptr<int32_t>(), col.data_ptr<int32_t>(), G.rptr.data_ptr<int32_t>(),
+                         G.rperm.data_ptr<int32_t>(), need_col ? G.cptr.data_ptr<int32_t>() : nullptr,
+                         need_col ? G.cperm.data_ptr<int32_t>() : nullptr, G.rinv.data_ptr<int32_t>()};
+    return G;
+}
+equigspr_irrep_config irrep_cfg(const at::Tensor& f0, const at::Tensor& f1, const at::Tensor& w_r1, const at::Tensor& ws0, const at::Tensor& ws1,
+                                c10::ArrayRef<double> basis) {
+    TORCH_CHECK(basis.size() == 6, "equigspr::irrep_conv: basis = (k00, k01, k10, k11_0, k11_1, k11_2)");
+    TORCH_CHECK(ws0.dim() == 2 && ws1.dim() == 2 && ws0.size(1) == f0.size(1) && ws1.size(1) == f1.size(1), "equigspr::irrep_conv: w_self0 [C0o, C0i], w_self1 [C1o, C1i]");
+    return equigspr_irrep_config{(int32_t)f0.size(1), (int32_t)f1.size(1), (int32_t)ws0.size(0), (int32_t)ws1.size(0), (int32_t)w_r1.numel(),
+                                 (float)basis[0], (float)basis[1], (float)basis[2], (float)basis[3], (float)basis[4], (float)basis[5]};
+}
+void irrep_check(const at::Tensor& f0, const at::Tensor& f1, const at::Tensor& x, const at::Tensor& row, const at::Tensor& col,
+                 std::initializer_list<const at::Tensor*> params) {
+    need(f0, "f0", at::kFloat, 2); need(f1, "f1", at::kFloat, 3); need(x, "x", at::kFloat, 2); need(row, "row", at::kInt, 1); need(col, "col", at::kInt, 1);
+    const int64_t n = x.size(0);
+    TORCH_CHECK(x.size(1) == 3 && f0.size(0) == n && f1.size(0) == n && f1.size(2) == 3 && col.numel() == row.numel(),
+                "equigspr::irrep_conv: f0 [N, C0], f1 [N, C1, 3], x [N, 3], row / col [E]");
+    same_device(f0, f1, "f1"); same_device(f0, x, "x"); same_device(f0, row, "row"); same_device(f0, col, "col");
+    for (const at::Tensor* p : params) { need(*p, "parameter", at::kFloat, -1); same_device(f0, *p, "parameter"); }
+}
+// -> (out0 [N, C0o], out1 [N, C1o, 3], moments)
+std::tuple<at::Tensor, at::Tensor, at::Tensor> irrep_conv_forward(const at::Tensor& f0, const at::Tensor& f1, const at::Tensor& x, const at::Tensor& row,
+                                                                  const at::Tensor& col, const at::Tensor& w_r1, const at::Tensor& b_r1,
+                                                                  const at::Tensor& w_r2, const at::Tensor& b_r2, const at::Tensor& ws0,
+                                                                  const at::Tensor& ws1, c10::ArrayRef<double> basis) {
+    irrep_check(f0, f1, x, row, col, {&w_r1, &b_r1, &w_r2, &b_r2, &ws0, &ws1});
+    DeviceGuard guard(f0.device());
+    auto cfg = irrep_cfg(f0, f1, w_r1, ws0, ws1, basis);
+    const int64_t n = x.size(0), e = row.size(0);
+    const int64_t msz = equigspr_irrep_moments_size(&cfg, (int32_t)n, (int32_t)e);
+    TORCH_CHECK(msz >= 0, "equigspr::irrep_conv_forward: unsupported shape (1..32 channels per degree, radial hidden width 16 or 32)");
+    const int64_t n_w = (int64_t)cfg.c0_out * cfg.c0_in + (int64_t)cfg.c1_out * cfg.c0_in + (int64_t)cfg.c0_out * cfg.c1_in + 3LL * cfg.c1_out * cfg.c1_in;
+    TORCH_CHECK(b_r1.numel() == cfg.hidden && w_r2.numel() == n_w * cfg.hidden && b_r2.numel() == n_w, "equigspr::irrep_conv_forward: radial parameter sizes");
+    void* s = cur_stream(f0);
+    auto G = irrep_graph(row, col, n, false, s);
+    auto o = f0.options();
+    auto out0 = at::empty({n, cfg.c0_out}, o), out1 = at::empty({n, cfg.c1_out, 3}, o), moments = at::empty({msz}, o);
+    check(equigspr_irrep_conv_forward(&cfg, w_r1.data_ptr<float>(), b_r1.data_ptr<float>(), w_r2.data_ptr<float>(), b_r2.data_ptr<float>(),
+                                      ws0.data_ptr<float>(), ws1.data_ptr<float>(), &G.g, f0.data_ptr<float>(), f1.data_ptr<float>(), x.data_ptr<float>(),
+                                      out0.data_ptr<float>(), out1.data_ptr<float>(), moments.data_ptr<float>(), 1, s), "irrep_conv_forward");
+    return {out0, out1, moments};
+}
+// -> (d_f0, d_f1, d_x, d_w_r1, d_b_r1, d_w_r2, d_b_r2, d_w_self0, d_w_self1)
+std::vector<at::Tensor> irrep_conv_backward(const at::Tensor& f0, const at::Tensor& f1, const at::Tensor& x, const at::Tensor& row, const at::Tensor& col,
+                                            const at::Tensor& w_r1, const at::Tensor& b_r1, const at::Tensor& w_r2, const at::Tensor& b_r2,
+                                            const at::Tensor& ws0, const at::Tensor& ws1, c10::ArrayRef<double> basis, const at::Tensor& moments,
+                                            const at::Tensor& g0, const at::Tensor& g1) {
+    irrep_check(f0, f1, x, row, col, {&w_r1, &b_r1, &w_r2, &b_r2, &ws0, &ws1, &moments, &g0, &g1});
+    DeviceGuard guard(f0.device());
+    auto cfg = irrep_cfg(f0, f1, w_r1, ws0, ws1, basis);
+    const int64_t n = x.size(0), e = row.size(0);
+    TORCH_CHECK(g0.numel() == n * cfg.c0_out && g1.numel() == n * cfg.c1_out * 3, "equigspr::irrep_conv_backward: g0 [N, C0o], g1 [N, C1o, 3]");
+    TORCH_CHECK(moments.numel() == equigspr_irrep_moments_size(&cfg, (int32_t)n, (int32_t)e), "equigspr::irrep_conv_backward: `moments` is not what the forward of these shapes left");
+    void* s = cur_stream(f0);
+    auto G = irrep_graph(row, col, n, true, s);
+    auto o = f0.options();
+    auto d_f0 = at::empty_like(f0), d_f1 = at::empty_like(f1), d_x = at::zeros_like(x);
+    auto dw1 = at::empty_like(w_r1), db1 = at::empty_like(b_r1), dw2 = at::empty_like(w_r2), db2 = at::empty_like(b_r2), ds0 = at::empty_like(ws0), ds1 = at::empty_like(ws1);
+    auto work = at::empty({equigspr_irrep_bwd_work_size(&cfg, (int32_t)n, (int32_t)e)}, o);
+    check(equigspr_irrep_conv_backward(&cfg, w_r1.data_ptr<float>(), b_r1.data_ptr<float>(), w_r2.data_ptr<float>(), b_r2.data_ptr<float>(),
+                                       ws0.data_ptr<float>(), ws1.data_ptr<float>(), &G.g, f0.data_ptr<float>(), f1.data_ptr<float>(), x.data_ptr<float>(),
+                                       moments.data_ptr<float>(), g0.data_ptr<float>(), g1.data_ptr<float>(), d_f0.data_ptr<float>(), d_f1.data_ptr<float>(),
+                                       d_x.data_ptr<float>(), dw1.data_ptr<float>(), db1.data_ptr<float>(), dw2.data_ptr<float>(), db2.data_ptr<float>(),
+                                       ds0.data_ptr<float>(), ds1.data_ptr<float>(), work.data_ptr<float>(), s), "irrep_conv_backward");
+    return {d_f0, d_f1, d_x, dw1, db1, dw2, db2, ds0, ds1};
+}
+struct IrrepConvFn : torch::autograd::Function<IrrepConvFn> {
+    static torch::autograd::variable_list forward(torch::autograd::AutogradContext* ctx, const at::Tensor& f0, const at::Tensor& f1, const at::Tensor& x,
+                                                  const at::Tensor& row, const at::Tensor& col, const at::Tensor& w_r1, const at::Tensor& b_r1,
+                                                  const at::Tensor& w_r2, const at::Tensor& b_r2, const at::Tensor& ws0, const at::Tensor& ws1,
+                                                  std::vector<double> basis) {
+        at::AutoDispatchBelowADInplaceOrView below;
+        auto out = irrep_conv_forward(f0, f1, x, row, col, w_r1, b_r1, w_r2, b_r2, ws0, ws1, basis);
+        ctx->save_for_backward({f0, f1, x, row, col, w_r1, b_r1, w_r2, b_r2, ws0, ws1, std::get<2>(out)});
+        ctx->saved_data["basis"] = basis;
+        ctx->mark_non_differentiable({std::get<2>(out)});
+        return {std::get<0>(out), std::get<1>(out), std::get<2>(out)};
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list g) {
+        const auto sv = ctx->get_saved_variables();
+        const auto basis = ctx->saved_data["basis"].toDoubleVector();
+        const auto g0 = g[0].defined() ? g[0].contiguous() : at::zeros({sv[0].size(0), sv[9].size(0)}, sv[0].options());
+        const auto g1 = g[1].defined() ? g[1].contiguous() : at::zeros({sv[0].size(0), sv[10].size(0), 3}, sv[0].options());
+        auto d = irrep_conv_backward(sv[0], sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], sv[7], sv[8], sv[9], sv[10], basis, sv[11], g0, g1);
+        return {d[0], d[1], d[2], at::Tensor(), at::Tensor(), d[3], d[4], d[5], d[6], d[7], d[8], at::Tensor()};
+    }
+};
+std::tuple<at::Tensor, at::Tensor, at::Tensor> irrep_conv_forward_autograd(const at::Tensor& f0, const at::Tensor& f1, const at::Tensor& x, const at::Tensor& row,
+                                                                           const at::Tensor& col, const at::Tensor& w_r1, const at::Tensor& b_r1,
+                                                                           const at::Tensor& w_r2, const at::Tensor& b_r2, const at::Tensor& ws0,
+                                                                           const at::Tensor& ws1, c10::ArrayRef<double> basis) {
+    auto out = IrrepConvFn::apply(f0, f1, x, row, col, w_r1, b_r1, w_r2, b_r2, ws0, ws1, basis.vec());
+    return {out[0], out[1], out[2]};
+}
 }  // namespace
 
 TORCH_LIBRARY(equigspr, m) {
@@ -421,12 +536,18 @@ TORCH_LIBRARY(equigspr, m) {
           "Tensor gt_pose, Tensor mlp, int K) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("pose_loss_forward(Tensor pred_rot, Tensor pred_translation, Tensor gt_pose) -> (Tensor, Tensor)");
     m.def("pose_loss_backward(Tensor pred_rot, Tensor pred_translation, Tensor gt_pose, Tensor grad_rot_loss, Tensor grad_trans_loss) -> (Tensor, Tensor)");
+    // N4: typed irrep-basis message passing; differentiable in f0, f1, x and all six parameter tensors (HIP backward)
+    m.def("irrep_conv_forward(Tensor f0, Tensor f1, Tensor x, Tensor row, Tensor col, Tensor w_r1, Tensor b_r1, Tensor w_r2, Tensor b_r2, "
+          "Tensor w_self0, Tensor w_self1, float[] basis) -> (Tensor, Tensor, Tensor)");
+    m.def("irrep_conv_backward(Tensor f0, Tensor f1, Tensor x, Tensor row, Tensor col, Tensor w_r1, Tensor b_r1, Tensor w_r2, Tensor b_r2, "
+          "Tensor w_self0, Tensor w_self1, float[] basis, Tensor moments, Tensor g_out0, Tensor g_out1) -> Tensor[]");
 }
 
 TORCH_LIBRARY_IMPL(equigspr, Autograd, m) {
     m.impl("weighted_kabsch_forward", &weighted_kabsch_forward_autograd);
     m.impl("egnn_forward", &egnn_forward_autograd);
     m.impl("pose_loss_forward", &pose_loss_forward_autograd);
+    m.impl("irrep_conv_forward", &irrep_conv_forward_autograd);
 }
 
 TORCH_LIBRARY_IMPL(equigspr, CUDA, m) {       // the HIP backend key of a ROCm build of PyTorch
@@ -439,4 +560,6 @@ TORCH_LIBRARY_IMPL(equigspr, CUDA, m) {       // the HIP backend key of a ROCm b
     m.impl("head_eval_forward", &head_eval_forward);
     m.impl("pose_loss_forward", &pose_loss_forward);
     m.impl("pose_loss_backward", &pose_loss_backward);
+    m.impl("irrep_conv_forward", &irrep_conv_forward);
+    m.impl("irrep_conv_backward", &irrep_conv_backward);
 }

@@ -269,3 +269,43 @@ def test_fused_launch_equals_the_two_launch_form(pk):
                 assert float((u - v).abs().max()) <= 2e-5 * max(1.0, float(u.abs().max())), dims
     finally:
         _lib.lib().equigspr_set_irrep_fused(0)
+
+
+def test_torch_library_irrep_conv_ops_match_the_ctypes_path(pk):
+    """torch.ops.equigspr.irrep_conv_forward (autograd registered in csrc/torch_ops.cpp) and the explicit irrep_conv_backward op
+    call the same C-ABI entries as irreps.IrrepConv: bit-identical outputs and gradients for every input; argument checks raise."""
+    from se3_equi_graph_registration_amd import sh, torch_library
+    ops = torch_library.load()
+    n, e = 200, 2500
+    g, row, col = _graph(21, n, e)
+    torch.manual_seed(3)
+    layer = pk.IrrepConv(12, 5, 9, 6, hidden=32)
+    x = torch.randn(n, 3, generator=g).cuda()
+    f0 = torch.randn(n, 12, generator=g).cuda(); f1 = torch.randn(n, 5, 3, generator=g).cuda()
+    g0 = torch.randn(n, 9, generator=g).cuda(); g1 = torch.randn(n, 6, 3, generator=g).cuda()
+    row32, col32 = row.int().cuda(), col.int().cuda()
+    basis = [float(c) for c in sh.degree1_closed_form()]
+    lin1, lin2 = layer.radial[0], layer.radial[2]
+    names = ["radial.0.weight", "radial.0.bias", "radial.2.weight", "radial.2.bias", "self0.weight", "self1.weight"]
+    params = [lin1.weight, lin1.bias, lin2.weight, lin2.bias, layer.self0.weight, layer.self1.weight]
+    a0, a1, ax = f0.clone().requires_grad_(True), f1.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    o0, o1 = layer(a0, a1, ax, [row.cuda(), col.cuda()])
+    layer.zero_grad()
+    ((o0 * g0).sum() + (o1 * g1).sum()).backward()
+    want = {k: p.grad.clone() for k, p in zip(names, params)}
+    b0, b1, bx = f0.clone().requires_grad_(True), f1.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    q = [p.detach().clone().requires_grad_(True) for p in params]
+    p0, p1, moments = ops.irrep_conv_forward(b0, b1, bx, row32, col32, *q, basis)
+    assert torch.equal(p0, o0) and torch.equal(p1, o1) and not moments.requires_grad
+    ((p0 * g0).sum() + (p1 * g1).sum()).backward()
+    assert torch.equal(b0.grad, a0.grad) and torch.equal(b1.grad, a1.grad) and torch.equal(bx.grad, ax.grad)
+    for k, t in zip(names, q):
+        assert torch.equal(t.grad, want[k]), k
+    d = ops.irrep_conv_backward(f0, f1, x, row32, col32, *[p.detach() for p in params], basis, moments, g0, g1)
+    assert len(d) == 9 and torch.equal(d[0], a0.grad) and torch.equal(d[2], ax.grad) and torch.equal(d[5], want["radial.2.weight"])
+    with pytest.raises(RuntimeError, match="basis"):
+        ops.irrep_conv_forward(f0, f1, x, row32, col32, *[p.detach() for p in params], basis[:5])
+    with pytest.raises(RuntimeError):
+        ops.irrep_conv_forward(f0, f1[:, :4].contiguous(), x, row32, col32, *[p.detach() for p in params], basis)
+    with pytest.raises(RuntimeError, match="moments"):
+        ops.irrep_conv_backward(f0, f1, x, row32, col32, *[p.detach() for p in params], basis, moments[:-1].contiguous(), g0, g1)
