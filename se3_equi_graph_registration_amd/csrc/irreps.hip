@@ -594,18 +594,22 @@ __global__ __launch_bounds__(64 * kFW) void irrep_conv_fused_kernel(const MomArg
         auto fetch = [&](int el, Ent& E_) {
             const int e = 48 * CH + el;                                  // wave-uniform
             int in, J = 0, cin;
-            const PathW* p;
+            PathW pv;                                                    // by value: scalar selects, no reloads of the descriptor
+            PathW* p = &pv;
             E_.aa = 0;
             if (e < f1base) {
                 const int sl = e / a.c0p;
                 in = e - sl * a.c0p; cin = a.c0;
-                E_.deg0 = sl == 0; p = E_.deg0 ? &nd.p00 : &nd.p01; E_.aa = E_.deg0 ? 0 : sl - 1;
+                E_.deg0 = sl == 0; E_.aa = E_.deg0 ? 0 : sl - 1;
+                pv.w = E_.deg0 ? nd.p00.w : nd.p01.w; pv.b = E_.deg0 ? nd.p00.b : nd.p01.b;
+                pv.so = E_.deg0 ? nd.p00.so : nd.p01.so; pv.si = E_.deg0 ? nd.p00.si : nd.p01.si;
             } else {
                 const int q = e - f1base, sl = q / a.c1p;
                 in = q - sl * a.c1p; cin = a.c1;
                 E_.deg0 = sl == 0;
-                if (E_.deg0) p = &nd.p10;
-                else { E_.aa = (sl - 1) / 3; J = (sl - 1) - 3 * E_.aa; p = &nd.p11; }
+                if (!E_.deg0) { E_.aa = (sl - 1) / 3; J = (sl - 1) - 3 * E_.aa; }
+                pv.w = E_.deg0 ? nd.p10.w : nd.p11.w; pv.b = E_.deg0 ? nd.p10.b : nd.p11.b;
+                pv.so = E_.deg0 ? nd.p10.so : nd.p11.so; pv.si = E_.deg0 ? nd.p10.si : nd.p11.si;
             }
             E_.live = in < cin;
             if (!E_.live) return;
@@ -747,115 +751,122 @@ struct ExpArgs {
 };
 
 constexpr int kExpLd = kExpWaves * 32 + 4;      // floats between nodes of the staging buffer (= 4 mod 32: conflict-free 16-byte writes of 8 nodes)
-constexpr int kExpTiles = 1;
-constexpr int kExpSplit = 2;            // workgroups per node tile (each takes a contiguous share of the entry groups): four waves per SIMD at one pair instead of two            // 16-node tiles per workgroup: every weight row a wave loads feeds both (the weights come from L2: 228 KB per workgroup at 32 + 8 channels)
+constexpr int kExpSplit = 2;            // workgroups per node tile (each takes a contiguous share of the entry groups): four waves per SIMD at one pair instead of two
 
-template <int NH>
+// a loaded value where `ok`, +0.0 elsewhere -- by AND, so the load itself stays unconditional (a select lets the compiler move the load
+// under a branch, and every branch around a load costs the s_waitcnt pass its exact count: it falls back to vmcnt(0), which also
+// waits for the prefetch of the next step)
+__device__ __forceinline__ float keep_if(float v, bool ok) { return __int_as_float(__float_as_int(v) & (ok ? -1 : 0)); }
+
+// NKS0 / NKS1: K steps (four output channels each) of the paths with degree-0 / degree-1 OUTPUT gradients -- compile-time, so every
+// entry of a run requests the same number of loads and the next entry's weights can stay in flight across this entry's products.
+template <int NH, int NKS0, int NKS1>
 __global__ __launch_bounds__(64 * kExpWaves) void irrep_expand16_kernel(const ExpArgs a) {
     constexpr int H = 16 * NH;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
-    const int n0 = blockIdx.x * 16 * kExpTiles;
-    // B operands: g[node][4 s + kq], s = 0..7 (output channels beyond the count: zero), per tile
-    float ga[kExpTiles][4][8];
+    const int n0 = blockIdx.x * 16;
+    // B operands: g[node][4 s + kq] (output channels beyond the count: zero)
+    const int nA = min(n0 + i16, a.n_nodes - 1);
+    float g0r[NKS0], g1r[3][NKS1];
 #pragma unroll
-    for (int tl = 0; tl < kExpTiles; ++tl) {
-        const int nA = min(n0 + 16 * tl + i16, a.n_nodes - 1);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int o = 4 * s + kq;
-            ga[tl][0][s] = o < a.o0 ? a.g0[(size_t)nA * a.o0 + o] : 0.0f;
-#pragma unroll
-            for (int aa = 0; aa < 3; ++aa) ga[tl][1 + aa][s] = o < a.o1 ? a.g1[((size_t)nA * a.o1 + o) * 3 + aa] : 0.0f;
-        }
+    for (int s = 0; s < NKS0; ++s) {
+        const int o = 4 * s + kq;
+        g0r[s] = keep_if(a.g0[(size_t)nA * a.o0 + min(o, a.o0 - 1)], o < a.o0);
     }
-    const int f1base = 4 * a.c0p;
-    // one entry's weights (A operands): W(o = 4 s + kq, entry, 16 t + i16) and the bias; requested one entry ahead (one wave per SIMD
-    // at one pair: the L2 round trip of an entry's sixteen loads was exposed 26 times per wave)
-    struct Ent { bool real; int src, nks; float wv_[8][NH], bw[8]; };
-    auto fetch = [&](int e, Ent& E_) {
-        int in, J = 0, cin, on;
-        const PathW* p;
-        if (e < f1base) {
-            const int s = e / a.c0p;
-            in = e - s * a.c0p; cin = a.c0;
-            E_.src = s == 0 ? 0 : s; p = s == 0 ? &a.p00 : &a.p01; on = s == 0 ? a.o0 : a.o1;
-        } else {
-            const int q = e - f1base, s = q / a.c1p;
-            in = q - s * a.c1p; cin = a.c1;
-            if (s == 0) { E_.src = 0; p = &a.p10; on = a.o0; }
-            else { const int aa = (s - 1) / 3; J = (s - 1) - 3 * aa; E_.src = 1 + aa; p = &a.p11; on = a.o1; }
-        }
-        E_.real = in < cin;
-        E_.nks = (on + 3) >> 2;
-        if (!E_.real) return;
-        const float* wp = p->w + (size_t)in * p->si + J * H;
-        const float* bp = p->b + ((size_t)in * p->si) / H + J;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int o = 4 * s + kq;
-            const bool ok = s < E_.nks && o < on;
+    for (int s = 0; s < NKS1; ++s) {
+        const int o = 4 * s + kq;
 #pragma unroll
-            for (int t = 0; t < NH; ++t) E_.wv_[s][t] = ok ? wp[(size_t)o * p->so + 16 * t + i16] : 0.0f;
-            E_.bw[s] = ok ? bp[((size_t)o * p->so) / H] : 0.0f;
-        }
-    };
-    Ent nxt;
-    nxt.real = false; nxt.src = 0; nxt.nks = 0;
+        for (int aa = 0; aa < 3; ++aa) g1r[aa][s] = keep_if(a.g1[((size_t)nA * a.o1 + min(o, a.o1 - 1)) * 3 + aa], o < a.o1);
+    }
     // this workgroup's share of the groups of 8 entries
     const int n_grp = a.lc / kExpWaves, per = (n_grp + kExpSplit - 1) / kExpSplit;
     const int e_lo = (int)blockIdx.y * per * kExpWaves, e_hi = min(a.lc, e_lo + per * kExpWaves);
-    if (e_lo + wv < e_hi) fetch(e_lo + wv, nxt);
     // The tiles leave through LDS: a wave's own tile is 16 nodes x 64 bytes per store instruction, 27 KB apart (measured: 110 MB in
     // 92 us = 1.2 TB/s); staged as [node][8 entries][H] the workgroup writes every node's 8 entries as ONE contiguous 1 KB row per
     // instruction.  Two buffers: one barrier per group of 8 entries.
-    __shared__ __attribute__((aligned(16))) float stage[2][16 * kExpTiles * kExpLd];
+    __shared__ __attribute__((aligned(16))) float stage[2][16 * kExpLd];
     int buf = 0;
-    for (int e0 = e_lo; e0 < e_hi; e0 += kExpWaves, buf ^= 1) {        // lc is a multiple of 16: every group is complete
-        const int e = e0 + wv;                                          // wave-uniform entry
-        const Ent cur = nxt;
-        if (e + kExpWaves < e_hi) fetch(e + kExpWaves, nxt);
-        f32x4 acc[kExpTiles][NH];
-        float bsum[kExpTiles];
+    // One RUN = the entries of one path (c00 | c01 x 3 | c10 | c11 x 9): descriptor, output-gradient degree and K-step count fixed.
+    // blockw: entries per slot (c0p / c1p); slots: aa (c01) or 3 aa + J (c11).
+    auto run = [&](auto nks_tag, const bool deg1, const bool hasJ, int rb, int re, const float* pw, const float* pb, int so, int si, int on,
+                   int cin, int blockw) {
+        constexpr int NKS = decltype(nks_tag)::value;
+        struct Ent { float w[NKS][NH], b[NKS]; };
+        const int lo = max(rb, e_lo), hi = min(re, e_hi);
+        if (lo >= hi) return;                                               // workgroup-uniform
+        const int soh = so / H;
+        auto fetch = [&](int e, Ent& E_) {                                  // e wave-uniform; NKS * (NH + 1) loads, always
+            const int q = e - rb, slot = q / blockw;
+            const int in = min(q - slot * blockw, cin - 1);                 // pad entries read the last real row (never used)
+            const int J = hasJ ? slot % 3 : 0;
+            const float* wp = pw + (size_t)in * si + J * H + i16;
+            const float* bp = pb + ((size_t)in * si) / H + J;
 #pragma unroll
-        for (int tl = 0; tl < kExpTiles; ++tl) {
-            bsum[tl] = 0.0f;
+            for (int s = 0; s < NKS; ++s) {
+                const int o = 4 * s + kq, oc = min(o, on - 1);
 #pragma unroll
-            for (int t = 0; t < NH; ++t) acc[tl][t] = splat4(0.0f);
-        }
-        if (cur.real) {
-            // D[h][node] = sum_o A[h][o] B[o][node]
+                for (int t = 0; t < NH; ++t) E_.w[s][t] = keep_if(wp[(size_t)oc * so + 16 * t], o < on);
+                E_.b[s] = keep_if(bp[(size_t)oc * soh], o < on);
+            }
+        };
+        Ent nxt;
+        const int last = hi - kExpWaves + wv;                               // this wave's last entry of the run
+        fetch(lo + wv, nxt);
+        for (int e0 = lo; e0 < hi; e0 += kExpWaves, buf ^= 1) {
+            const int e = e0 + wv;
+            const Ent cur = nxt;
+            fetch(min(e + kExpWaves, last), nxt);                           // (the last one again at the end: unconditional)
+            const int q = e - rb, slot = q / blockw;
+            const bool real = q - slot * blockw < cin;
+            const int aa = hasJ ? slot / 3 : slot;                          // component of g1 (deg1 runs)
+            f32x4 acc[NH];
+            float bsum = 0.0f;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (s >= cur.nks) break;
+            for (int t = 0; t < NH; ++t) acc[t] = splat4(0.0f);
+            if (real) {
+                // D[h][node] = sum_o A[h][o] B[o][node]
 #pragma unroll
-                for (int tl = 0; tl < kExpTiles; ++tl) {
-                    const float gvv = cur.src == 0 ? ga[tl][0][s] : (cur.src == 1 ? ga[tl][1][s] : (cur.src == 2 ? ga[tl][2][s] : ga[tl][3][s]));
+                for (int s = 0; s < NKS; ++s) {
+                    // (the component's row by masks, not by `?:` -- the compiler turns a select chain over g1r into an indexed
+                    // scratch array, and a scratch load is one more vmcnt(0))
+                    float gvv;
+                    const float g1v = __int_as_float(__float_as_int(keep_if(g1r[0][s], aa == 0)) | __float_as_int(keep_if(g1r[1][s], aa == 1)) |
+                                                     __float_as_int(keep_if(g1r[2][s], aa == 2)));
+                    if constexpr (NKS == NKS0 && NKS == NKS1) gvv = deg1 ? g1v : g0r[s];
+                    else if constexpr (NKS == NKS0) gvv = g0r[s];
+                    else gvv = g1v;
 #pragma unroll
-                    for (int t = 0; t < NH; ++t) acc[tl][t] = mfma16(cur.wv_[s][t], gvv, acc[tl][t]);
-                    bsum[tl] = fmaf(gvv, cur.bw[s], bsum[tl]);
+                    for (int t = 0; t < NH; ++t) acc[t] = mfma16(cur.w[s][t], gvv, acc[t]);
+                    bsum = fmaf(gvv, cur.b[s], bsum);
                 }
             }
-        }
-        // lane (node = i16, g = kq) holds h = 16 t + 4 g + r  ->  stage[node][wv][h]
-        float* st = stage[buf];
+            // lane (node = i16, g = kq) holds h = 16 t + 4 g + r  ->  stage[node][wv][h]
+            float* st = stage[buf];
+            const float bt = gsum(bsum);
 #pragma unroll
-        for (int tl = 0; tl < kExpTiles; ++tl) {
-            const float bt = gsum(bsum[tl]);
-            const int nl = 16 * tl + i16;
-#pragma unroll
-            for (int t = 0; t < NH; ++t) st4(st + nl * kExpLd + wv * H + 16 * t + 4 * kq, acc[tl][t]);
-            if (kq == 0 && n0 + nl < a.n_nodes) a.dMb[(size_t)(n0 + nl) * a.lc + e] = bt;
+            for (int t = 0; t < NH; ++t) st4(st + i16 * kExpLd + wv * H + 16 * t + 4 * kq, acc[t]);
+            if (kq == 0 && n0 + i16 < a.n_nodes) a.dMb[(size_t)(n0 + i16) * a.lc + e] = bt;
+            __syncthreads();
+            // rows out: wave w takes nodes w, w + 8; 8 entries x H floats = one contiguous run per node
+            constexpr int RUN = kExpWaves * H;                             // floats per node and group (256 at H = 32: one 1 KB instruction)
+            for (int nl = wv; nl < 16; nl += kExpWaves) {
+                const int n = n0 + nl;
+                if (n >= a.n_nodes) continue;                               // wave-uniform
+                for (int c = 4 * lane; c < RUN; c += 256)
+                    st4(a.dM + ((size_t)n * a.lc + e0) * H + c, lds4(st + nl * kExpLd + c));
+            }
         }
-        __syncthreads();
-        // rows out: wave w takes nodes w, w + 8, ...; 8 entries x H floats = one contiguous run per node
-        constexpr int RUN = kExpWaves * H;                             // floats per node and group (256 at H = 32: one 1 KB instruction)
-        for (int nl = wv; nl < 16 * kExpTiles; nl += kExpWaves) {
-            const int n = n0 + nl;
-            if (n >= a.n_nodes) continue;                               // wave-uniform
-            for (int c = 4 * lane; c < RUN; c += 256)
-                st4(a.dM + ((size_t)n * a.lc + e0) * H + c, lds4(st + nl * kExpLd + c));
-        }
+    };
+    const int f1base = 4 * a.c0p;
+    run(std::integral_constant<int, NKS0>{}, false, false, 0, a.c0p, a.p00.w, a.p00.b, a.p00.so, a.p00.si, a.o0, a.c0, a.c0p);
+    run(std::integral_constant<int, NKS1>{}, true, false, a.c0p, f1base, a.p01.w, a.p01.b, a.p01.so, a.p01.si, a.o1, a.c0, a.c0p);
+    if (a.c1 > 0) {
+        run(std::integral_constant<int, NKS0>{}, false, false, f1base, f1base + a.c1p, a.p10.w, a.p10.b, a.p10.so, a.p10.si, a.o0, a.c1, a.c1p);
+        run(std::integral_constant<int, NKS1>{}, true, true, f1base + a.c1p, a.lc, a.p11.w, a.p11.b, a.p11.so, a.p11.si, a.o1, a.c1, a.c1p);
+    } else {
+        // no active degree-1 input: its entries' gradients are never read (the geometry kernel skips the section)
     }
 }
 
@@ -1150,11 +1161,109 @@ struct WgradArgs {
 #define EQ_IR_WG_ROWS 4                 // weight rows per wave (accumulator tiles = rows x NH x 2)
 #endif
 constexpr int kWgRows = EQ_IR_WG_ROWS;
-template <int NH>
-__global__ __launch_bounds__(64) void irrep_wgrad16_kernel(const WgradArgs a) {
+#ifndef EQ_IR_WG_OCC
+#define EQ_IR_WG_OCC 4                  // waves per SIMD the register budget is held to
+#endif
+// The radial.2 rows of one wave: D[h][o] += sum over (node, component) of M[node][entry(row, component)][h] g[node][o][component].
+// One STEP = four nodes (the MFMA's K) x one component.  Straight-line body: the rows past the path's end read its last row (valid
+// memory, results never stored), so every load of a step is requested before the first MFMA, and the NEXT step's loads before this
+// step's MFMAs (the version with a break per row made the compiler wait for each 64-byte load in turn: 8 memory latencies per step,
+// 2.2 us per step, 90 us per launch).
+template <int NH, int NCB, int NAA>
+__device__ __forceinline__ void wgrad_rows(const WgradArgs& a, int kind, int grp, int nb, int ne, float* __restrict__ slab) {
     constexpr int H = 16 * NH;
     const int lane = threadIdx.x, i16 = lane & 15, kq = lane >> 4;
-    const int G00 = (a.c0 + kWgRows - 1) / kWgRows, G10 = (a.c1 + kWgRows - 1) / kWgRows, G01 = G00, G11 = (3 * a.c1 + kWgRows - 1) / kWgRows;
+    const int cin = (kind == 0 || kind == 2) ? a.c0 : a.c1;
+    const int on = NAA == 3 ? a.o1 : a.o0;
+    // rows q = 0 .. kWgRows - 1 are CONSECUTIVE entries of one 16-padded block of the operand vector (R11: consecutive input channels
+    // of one J), so one address per node serves all of them by immediate offsets; rows past the path's end read pad entries of the same
+    // block (allocated; whatever they hold stays in accumulators that are never stored)
+    int in0, J = 0;
+    if (kind == 3) { const int gin = (a.c1 + kWgRows - 1) / kWgRows; J = grp / gin; in0 = kWgRows * (grp - J * gin); }
+    else in0 = kWgRows * grp;
+    const int ent0 = (kind == 0 ? 0 : kind == 1 ? 4 * a.c0p : kind == 2 ? a.c0p : 4 * a.c0p + a.c1p * (1 + J)) + in0;
+    const int astride = kind == 2 ? a.c0p : 3 * a.c1p;
+    int gcol[NCB];                                    // this lane's output channel per column block (clamped: masked below)
+    bool gok[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) { gcol[cb] = min(16 * cb + i16, on - 1); gok[cb] = 16 * cb + i16 < on; }
+    const float* gbase = NAA == 3 ? a.g1 : a.g0;
+    const int gstride = NAA == 3 ? 3 * a.o1 : a.o0;   // floats per node
+
+    f32x4 acc[kWgRows][NH][NCB];
+    float bacc[kWgRows][NCB];
+#pragma unroll
+    for (int q = 0; q < kWgRows; ++q)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            bacc[q][cb] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NH; ++t) acc[q][t][cb] = splat4(0.0f);
+        }
+    struct Stage { float av[kWgRows][NH]; float mb[kWgRows]; float bv[NCB]; };
+    const int nsteps = ((ne - nb + 3) >> 2) * NAA;
+    auto request = [&](int step, Stage& st) {
+        const int it = NAA == 3 ? step / 3 : step, aa = NAA == 3 ? step - 3 * it : 0;
+        const int n = nb + 4 * it + kq;
+        const bool ok = n < ne;
+        const int nk = ok ? n : ne - 1;
+        const float* Mn = a.M + ((size_t)nk * a.lc + ent0 + aa * astride) * H + i16;
+        const float* Mbn = a.Mb + (size_t)nk * a.lc + ent0 + aa * astride;
+        const float* gn = gbase + (size_t)nk * gstride;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) st.bv[cb] = keep_if(NAA == 3 ? gn[gcol[cb] * 3 + aa] : gn[gcol[cb]], ok && gok[cb]);
+#pragma unroll
+        for (int q = 0; q < kWgRows; ++q) {
+            st.mb[q] = Mbn[q];
+#pragma unroll
+            for (int t = 0; t < NH; ++t) st.av[q][t] = Mn[q * H + 16 * t];
+        }
+    };
+    auto consume = [&](const Stage& st) {
+#pragma unroll
+        for (int q = 0; q < kWgRows; ++q) {
+#pragma unroll
+            for (int t = 0; t < NH; ++t)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[q][t][cb] = mfma16(st.av[q][t], st.bv[cb], acc[q][t][cb]);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) bacc[q][cb] = fmaf(st.mb[q], st.bv[cb], bacc[q][cb]);
+        }
+    };
+    Stage s0, s1;
+    request(0, s0);                                                       // (nsteps >= 1: the grid has no empty split)
+    int step = 0;
+    for (; step + 2 <= nsteps; step += 2) {
+        request(step + 1, s1);
+        consume(s0);
+        request(min(step + 2, nsteps - 1), s0);                              // (unconditional: the last step again at the end)
+        consume(s1);
+    }
+    if (step < nsteps) consume(s0);
+    // D[h][o]: lane (o = i16, g = kq) holds h = 16 t + 4 g + r.  Parameter layout: row index (o * cin + in) (* 3 + J for R11)
+    const int off = kind == 0 ? a.off00 : (kind == 1 ? a.off10 : (kind == 2 ? a.off01 : a.off11));
+#pragma unroll
+    for (int q = 0; q < kWgRows; ++q) {
+        if (in0 + q >= cin) break;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int o = 16 * cb + i16;
+            const size_t prow = (size_t)off + (kind == 3 ? ((size_t)o * cin + in0 + q) * 3 + J : (size_t)o * cin + in0 + q);
+            const float bt = gsum(bacc[q][cb]);
+            if (o < on) {
+#pragma unroll
+                for (int t = 0; t < NH; ++t) st4(slab + prow * H + 16 * t + 4 * kq, acc[q][t][cb]);
+                if (kq == 0) slab[(size_t)a.n_w * H + prow] = bt;
+            }
+        }
+    }
+}
+
+template <int NH>
+__global__ __launch_bounds__(64, EQ_IR_WG_OCC) void irrep_wgrad16_kernel(const WgradArgs a) {
+    constexpr int H = 16 * NH;
+    const int lane = threadIdx.x, i16 = lane & 15, kq = lane >> 4;
+    const int G00 = (a.c0 + kWgRows - 1) / kWgRows, G10 = (a.c1 + kWgRows - 1) / kWgRows, G01 = G00, G11 = 3 * G10;
     const int GS0 = (a.c0 + 15) >> 4, GS1 = (a.c1 + 15) >> 4;
     int grp = blockIdx.x;
     const int split = blockIdx.y;
@@ -1204,78 +1313,9 @@ __global__ __launch_bounds__(64) void irrep_wgrad16_kernel(const WgradArgs a) {
         }
         return;
     }
-    // ---- radial.2 rows: up to four (in, J) rows of one path
-    const int cin = (kind == 0 || kind == 2) ? a.c0 : a.c1;
-    const int nrow_total = kind == 3 ? 3 * a.c1 : cin;
-    const int row0 = kWgRows * grp;
-    f32x4 acc[kWgRows][NH][2];
-    float bacc[kWgRows][2];
-#pragma unroll
-    for (int q = 0; q < kWgRows; ++q)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            bacc[q][cb] = 0.0f;
-#pragma unroll
-            for (int t = 0; t < NH; ++t) acc[q][t][cb] = splat4(0.0f);
-        }
-    // (rows beyond the range are read from its last node -- valid memory, no branch around the loads -- and weighted with zero.  Eight
-    // nodes per iteration with every load requested up front was measured too: 116 + 64 registers, two waves per SIMD, the same 70 us)
-    for (int n0 = nb; n0 < ne; n0 += 4) {
-        const bool ok = n0 + kq < ne;
-        const int nk = ok ? n0 + kq : ne - 1;
-        const float* Mn = a.M + (size_t)nk * a.lc * H;
-        const float* Mbn = a.Mb + (size_t)nk * a.lc;
-        for (int aa = 0; aa < (deg1 ? 3 : 1); ++aa) {
-            float bv[2];
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int o = min(16 * cb + i16, on - 1);
-                const float gvv = deg1 ? a.g1[((size_t)nk * a.o1 + o) * 3 + aa] : a.g0[(size_t)nk * a.o0 + o];
-                bv[cb] = (ok && cb < ncb && 16 * cb + i16 < on) ? gvv : 0.0f;
-            }
-#pragma unroll
-            for (int q = 0; q < kWgRows; ++q) {
-                const int row = row0 + q;
-                if (row >= nrow_total) break;                                     // wave-uniform
-                int entry;
-                if (kind == 0) entry = row;
-                else if (kind == 1) entry = f1base + row;
-                else if (kind == 2) entry = a.c0p * (1 + aa) + row;
-                else { const int in = row / 3, J = row - 3 * in; entry = f1base + a.c1p * (1 + 3 * aa + J) + in; }
-                const float mb = Mbn[entry];
-#pragma unroll
-                for (int t = 0; t < NH; ++t) {
-                    const float av = Mn[(size_t)entry * H + 16 * t + i16];
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) {
-                        if (cb >= ncb) break;
-                        acc[q][t][cb] = mfma16(av, bv[cb], acc[q][t][cb]);
-                    }
-                }
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) bacc[q][cb] = fmaf(mb, bv[cb], bacc[q][cb]);
-            }
-        }
-    }
-    // D[h][o]: lane (o = i16, g = kq) holds h = 16 t + 4 g + r.  Parameter layout: row index (o * cin + in) (* 3 + J for R11)
-    const int off = kind == 0 ? a.off00 : (kind == 1 ? a.off10 : (kind == 2 ? a.off01 : a.off11));
-#pragma unroll
-    for (int q = 0; q < kWgRows; ++q) {
-        const int row = row0 + q;
-        if (row >= nrow_total) break;
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            if (cb >= ncb) break;
-            const int o = 16 * cb + i16;
-            const size_t prow = (size_t)off + (size_t)o * nrow_total + row;       // R11: o * (3 c1) + (in * 3 + J) = (o * c1 + in) * 3 + J
-            const float bt = gsum(bacc[q][cb]);
-            if (o < on) {
-#pragma unroll
-                for (int t = 0; t < NH; ++t) st4(slab + prow * H + 16 * t + 4 * kq, acc[q][t][cb]);
-                if (kq == 0) slab[(size_t)a.n_w * H + prow] = bt;
-            }
-        }
-    }
+    // ---- radial.2 rows: up to kWgRows (in, J) rows of one path
+    if (deg1) { if (ncb == 2) wgrad_rows<NH, 2, 3>(a, kind, grp, nb, ne, slab); else wgrad_rows<NH, 1, 3>(a, kind, grp, nb, ne, slab); }
+    else { if (ncb == 2) wgrad_rows<NH, 2, 1>(a, kind, grp, nb, ne, slab); else wgrad_rows<NH, 1, 1>(a, kind, grp, nb, ne, slab); }
 }
 
 // sums of the slabs in fixed order -> the parameter gradients (overwritten).  Blocks [0, nbA): one thread per radial.2 / self
@@ -1406,8 +1446,11 @@ static BwdPlan plan_bwd(const Layout& L, int n_nodes, int n_edges) {
     p.lc_r = 4 * pad0(L.c0o) + 10 * pad1(L.c1o);
     const int n_w = L.off11 + 3 * L.c1o * L.c1i;
     p.P = n_w * (H + 1) + L.c0o * L.c0i + L.c1o * L.c1i;
-    p.groups = 2 * ceil_div(L.c0i, kWgRows) + ceil_div(L.c1i, kWgRows) + ceil_div(3 * L.c1i, kWgRows) + ceil_div(L.c0i, 16) + ceil_div(L.c1i, 16);
-    int want = ceil_div(4096, p.groups);                                 // ~4 k waves: four per SIMD (the accumulators' budget)
+    p.groups = 2 * ceil_div(L.c0i, kWgRows) + 4 * ceil_div(L.c1i, kWgRows) + ceil_div(L.c0i, 16) + ceil_div(L.c1i, 16);
+#ifndef EQ_WG_WANT
+#define EQ_WG_WANT 4096
+#endif
+    int want = ceil_div(EQ_WG_WANT, p.groups);                                 // ~4 k waves: four per SIMD (the accumulators' budget)
     want = max(1, min(want, ceil_div(max(n_nodes, 1), 16)));
     p.nodes_per_split = round_up(ceil_div(max(n_nodes, 1), want), 4);
     p.splits = ceil_div(max(n_nodes, 1), p.nodes_per_split);
@@ -1424,6 +1467,14 @@ static BwdPlan plan_bwd(const Layout& L, int n_nodes, int n_edges) {
     p.o_tabR = o;  o += tab_floats(n_edges);
     p.total = o;
     return p;
+}
+
+template <int NH>
+static void launch_expand(const ExpArgs& a, dim3 grid, dim3 block, hipStream_t s) {
+    const int k0 = a.o0 <= 8 ? 2 : (a.o0 <= 16 ? 4 : 8), k1 = a.o1 <= 8 ? 2 : (a.o1 <= 16 ? 4 : 8);
+#define EQ_IR_EXP(A, B) if (k0 == A && k1 == B) { hipLaunchKernelGGL((irrep_expand16_kernel<NH, A, B>), grid, block, 0, s, a); return; }
+    EQ_IR_EXP(2, 2) EQ_IR_EXP(2, 4) EQ_IR_EXP(2, 8) EQ_IR_EXP(4, 2) EQ_IR_EXP(4, 4) EQ_IR_EXP(4, 8) EQ_IR_EXP(8, 2) EQ_IR_EXP(8, 4) EQ_IR_EXP(8, 8)
+#undef EQ_IR_EXP
 }
 
 template <int NH>
@@ -1467,9 +1518,9 @@ static void conv_backward(const equigspr_irrep_config* c, const Layout& L, const
     ExpArgs ex{g0, g1, f00, f10, f01, f11, N, L.c0i, c1a, c0p, c1p, p.lc, L.c0o, L.c1o, work + p.o_dM, work + p.o_dMb};
     GeomArgs ge{f0, f1, g->rptr, g->rperm, tabF, w_r1, b_r1, kf, N, L.c0i, c1a, c0p, c1p, p.lc, work + p.o_dM, work + p.o_dMb,
                 work + p.o_dr, work + p.o_dxr, work + p.o_gslab};
-    const dim3 egrid(ceil_div(N, 16 * kExpTiles), kExpSplit), eblock(64 * kExpWaves);
-    if (H == 16) { hipLaunchKernelGGL((irrep_expand16_kernel<1>), egrid, eblock, 0, s, ex); launch_geom<1>(ge, s); }
-    else { hipLaunchKernelGGL((irrep_expand16_kernel<2>), egrid, eblock, 0, s, ex); launch_geom<2>(ge, s); }
+    const dim3 egrid(ceil_div(N, 16), kExpSplit), eblock(64 * kExpWaves);
+    if (H == 16) { launch_expand<1>(ex, egrid, eblock, s); launch_geom<1>(ge, s); }
+    else { launch_expand<2>(ex, egrid, eblock, s); launch_geom<2>(ge, s); }
     if (d_x) hipLaunchKernelGGL(irrep_dx_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, work + p.o_dr, work + p.o_dxr, g->cptr, g->cperm, N, d_x);
     // weight gradients
     const int n_w = L.off11 + 3 * L.c1o * L.c1i;
