@@ -57,6 +57,12 @@ struct Consts { float k00, k01, k10, k110, k111, k112; };
 // Per-edge geometry in AGGREGATION order (irrep_edge_table_kernel): position p of node n's segment [ptr[n], ptr[n + 1]) holds the
 // unit vector and length of r = x[n] - x[src] and the source node -- one coalesced read per wave instead of the dependent chain
 // index -> source -> coordinates -> sqrt / divide in every launch of every layer (the coordinates are fixed through a stack).
+// a loaded value where `ok`, zero elsewhere -- by a MULTIPLICATION with 1 / 0, so the load itself stays unconditional: a select (or an
+// AND with a 0 / -1 mask, which the compiler folds back into a select) lets it move the load under a branch, and every branch
+// around a load costs the s_waitcnt pass its exact count -- it falls back to vmcnt(0), which also waits for the prefetch of the
+// next step.  (The masked lanes read clamped, valid addresses: finite values, so x * 0 is a zero.)
+__device__ __forceinline__ float keep_if(float v, bool ok) { return v * (ok ? 1.0f : 0.0f); }
+
 struct EdgeTab { const float4* geo; const int* src; };       // [E] (u0, u1, u2, d), [E]
 
 struct MomArgs {
@@ -753,11 +759,6 @@ struct ExpArgs {
 constexpr int kExpLd = kExpWaves * 32 + 4;      // floats between nodes of the staging buffer (= 4 mod 32: conflict-free 16-byte writes of 8 nodes)
 constexpr int kExpSplit = 2;            // workgroups per node tile (each takes a contiguous share of the entry groups): four waves per SIMD at one pair instead of two
 
-// a loaded value where `ok`, +0.0 elsewhere -- by AND, so the load itself stays unconditional (a select lets the compiler move the load
-// under a branch, and every branch around a load costs the s_waitcnt pass its exact count: it falls back to vmcnt(0), which also
-// waits for the prefetch of the next step)
-__device__ __forceinline__ float keep_if(float v, bool ok) { return __int_as_float(__float_as_int(v) & (ok ? -1 : 0)); }
-
 // NKS0 / NKS1: K steps (four output channels each) of the paths with degree-0 / degree-1 OUTPUT gradients -- compile-time, so every
 // entry of a run requests the same number of loads and the next entry's weights can stay in flight across this entry's products.
 template <int NH, int NKS0, int NKS1>
@@ -807,8 +808,8 @@ __global__ __launch_bounds__(64 * kExpWaves) void irrep_expand16_kernel(const Ex
             for (int s = 0; s < NKS; ++s) {
                 const int o = 4 * s + kq, oc = min(o, on - 1);
 #pragma unroll
-                for (int t = 0; t < NH; ++t) E_.w[s][t] = keep_if(wp[(size_t)oc * so + 16 * t], o < on);
-                E_.b[s] = keep_if(bp[(size_t)oc * soh], o < on);
+                for (int t = 0; t < NH; ++t) E_.w[s][t] = wp[(size_t)oc * so + 16 * t];      // (rows past `on`: clamped, and their
+                E_.b[s] = bp[(size_t)oc * soh];                                               //  B operand g is zero)
             }
         };
         Ent nxt;
@@ -832,8 +833,8 @@ __global__ __launch_bounds__(64 * kExpWaves) void irrep_expand16_kernel(const Ex
                     // (the component's row by masks, not by `?:` -- the compiler turns a select chain over g1r into an indexed
                     // scratch array, and a scratch load is one more vmcnt(0))
                     float gvv;
-                    const float g1v = __int_as_float(__float_as_int(keep_if(g1r[0][s], aa == 0)) | __float_as_int(keep_if(g1r[1][s], aa == 1)) |
-                                                     __float_as_int(keep_if(g1r[2][s], aa == 2)));
+                    const float g1v = __int_as_float((__float_as_int(g1r[0][s]) & (aa == 0 ? -1 : 0)) | (__float_as_int(g1r[1][s]) & (aa == 1 ? -1 : 0)) |
+                                                     (__float_as_int(g1r[2][s]) & (aa == 2 ? -1 : 0)));
                     if constexpr (NKS == NKS0 && NKS == NKS1) gvv = deg1 ? g1v : g0r[s];
                     else if constexpr (NKS == NKS0) gvv = g0r[s];
                     else gvv = g1v;
@@ -1183,10 +1184,9 @@ __device__ __forceinline__ void wgrad_rows(const WgradArgs& a, int kind, int grp
     else in0 = kWgRows * grp;
     const int ent0 = (kind == 0 ? 0 : kind == 1 ? 4 * a.c0p : kind == 2 ? a.c0p : 4 * a.c0p + a.c1p * (1 + J)) + in0;
     const int astride = kind == 2 ? a.c0p : 3 * a.c1p;
-    int gcol[NCB];                                    // this lane's output channel per column block (clamped: masked below)
-    bool gok[NCB];
+    int gcol[NCB];                                    // this lane's output channel per column block (clamped; columns past `on` are not stored)
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) { gcol[cb] = min(16 * cb + i16, on - 1); gok[cb] = 16 * cb + i16 < on; }
+    for (int cb = 0; cb < NCB; ++cb) gcol[cb] = min(16 * cb + i16, on - 1);
     const float* gbase = NAA == 3 ? a.g1 : a.g0;
     const int gstride = NAA == 3 ? 3 * a.o1 : a.o0;   // floats per node
 
@@ -1200,7 +1200,7 @@ __device__ __forceinline__ void wgrad_rows(const WgradArgs& a, int kind, int grp
 #pragma unroll
             for (int t = 0; t < NH; ++t) acc[q][t][cb] = splat4(0.0f);
         }
-    struct Stage { float av[kWgRows][NH]; float mb[kWgRows]; float bv[NCB]; };
+    struct Stage { float av[kWgRows][NH]; float mb[kWgRows]; float bv[NCB]; float okf; };   // raw loads; the mask is applied in consume()
     const int nsteps = ((ne - nb + 3) >> 2) * NAA;
     auto request = [&](int step, Stage& st) {
         const int it = NAA == 3 ? step / 3 : step, aa = NAA == 3 ? step - 3 * it : 0;
@@ -1210,8 +1210,9 @@ __device__ __forceinline__ void wgrad_rows(const WgradArgs& a, int kind, int grp
         const float* Mn = a.M + ((size_t)nk * a.lc + ent0 + aa * astride) * H + i16;
         const float* Mbn = a.Mb + (size_t)nk * a.lc + ent0 + aa * astride;
         const float* gn = gbase + (size_t)nk * gstride;
+        st.okf = ok ? 1.0f : 0.0f;          // nodes past the range: zero B operand (output columns past `on` are never stored: no mask)
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) st.bv[cb] = keep_if(NAA == 3 ? gn[gcol[cb] * 3 + aa] : gn[gcol[cb]], ok && gok[cb]);
+        for (int cb = 0; cb < NCB; ++cb) st.bv[cb] = NAA == 3 ? gn[gcol[cb] * 3 + aa] : gn[gcol[cb]];
 #pragma unroll
         for (int q = 0; q < kWgRows; ++q) {
             st.mb[q] = Mbn[q];
@@ -1220,14 +1221,17 @@ __device__ __forceinline__ void wgrad_rows(const WgradArgs& a, int kind, int grp
         }
     };
     auto consume = [&](const Stage& st) {
+        float b[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) b[cb] = st.bv[cb] * st.okf;
 #pragma unroll
         for (int q = 0; q < kWgRows; ++q) {
 #pragma unroll
             for (int t = 0; t < NH; ++t)
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) acc[q][t][cb] = mfma16(st.av[q][t], st.bv[cb], acc[q][t][cb]);
+                for (int cb = 0; cb < NCB; ++cb) acc[q][t][cb] = mfma16(st.av[q][t], b[cb], acc[q][t][cb]);
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) bacc[q][cb] = fmaf(st.mb[q], st.bv[cb], bacc[q][cb]);
+            for (int cb = 0; cb < NCB; ++cb) bacc[q][cb] = fmaf(st.mb[q], b[cb], bacc[q][cb]);
         }
     };
     Stage s0, s1;
