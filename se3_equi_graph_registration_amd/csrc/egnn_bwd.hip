@@ -1167,7 +1167,10 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
         constexpr int NW = bwd16_waves(F - 32);
         const int chunk = edge_chunk_for(E, 256 * NW);
         int blocks = ceil_div(ceil_div(E, chunk), NW);
-        blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
+#ifndef EQ_BWD16_MAXBLOCKS
+#define EQ_BWD16_MAXBLOCKS 256          // developer: fewer workgroups = more units per wave on small graphs
+#endif
+        blocks = blocks < 1 ? 1 : (blocks > EQ_BWD16_MAXBLOCKS ? EQ_BWD16_MAXBLOCKS : blocks);
         hipLaunchKernelGGL((edge_bwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * NW), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
                            E, chunk, basis, dt1, dt1 + (size_t)E * 32, gxr, gxc, slab);
         *n_slabs = blocks;

@@ -121,7 +121,30 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // ---- 3-way bf16 split of eight floats (x = hi + mid + lo to 24 bits) and the fragment layout of a 32 x 32 matrix for
 // v_mfma_f32_16x16x32_bf16: [3 levels][2 row blocks][64 lanes] x 8 bf16; K index j of lane group g <-> feature 16 (j >> 2) + 4 g + (j & 3)
+#ifndef EQ_BF_SPLIT_TRUNC
+#define EQ_BF_SPLIT_TRUNC 1            // 1: split by truncation with integer ops; 0: by v_cvt_pk_bf16_f32 (round to nearest)
+#endif
 __device__ __forceinline__ void split3_bf16(const f32x4 (&v)[2], bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+#if EQ_BF_SPLIT_TRUNC
+    // hi = the upper 16 bits of x, mid = those of x - hi, lo = those of x - hi - mid: both differences are exact, the three pieces
+    // carry 24 mantissa bits.  Only AND / SUB / V_PERM: in the edge kernels the v_cvt_pk_bf16_f32 form gave run-to-run different
+    // results (a stale mid / lo operand in the matrix instruction that follows the conversion when the wave does not stall in
+    // between: profiles/r05_bf16x3_edge_kernels.txt), this form does not use the conversion instruction at all.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 H, M, L;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float x0 = v[p >> 1][2 * (p & 1)], x1 = v[p >> 1][2 * (p & 1) + 1];
+        const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+        const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u), r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+        const unsigned a0 = __float_as_uint(r0), a1 = __float_as_uint(r1);
+        const float s0 = r0 - __uint_as_float(a0 & 0xffff0000u), s1 = r1 - __uint_as_float(a1 & 0xffff0000u);
+        H[p] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                 // [x1's upper half | x0's upper half]
+        M[p] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+        L[p] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+    hi = __builtin_bit_cast(bf16x8, H); mid = __builtin_bit_cast(bf16x8, M); lo = __builtin_bit_cast(bf16x8, L);
+#else
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float x = v[j >> 2][j & 3];
@@ -130,6 +153,7 @@ __device__ __forceinline__ void split3_bf16(const f32x4 (&v)[2], bf16x8& hi, bf1
         const __bf16 m = (__bf16)r1;
         hi[j] = h; mid[j] = m; lo[j] = (__bf16)(r1 - (float)m);
     }
+#endif
 }
 __device__ __forceinline__ void frag_store(const f32x4 (&x)[2], float* frag, int bo, int l) {
     bf16x8 hi, mid, lo;
@@ -162,7 +186,10 @@ struct W16 {
     // bf16 x 3 fragments of the 32 x 32 matrices (EQ_EDGE_BF16X3): per matrix [3 levels][2 row blocks][64 lanes] x 8 bf16 = 1536 floats;
     // forward: W2, W6; backward: + W2^T, W6^T
     static constexpr int frag_floats = 3 * 2 * 64 * 4;
-    static constexpr int frag_base(bool bwd, int kB) { return (bwd ? bwd_size : fwd_size) + kB * border_size; }
+#ifndef EQ_FRAG_PAD
+#define EQ_FRAG_PAD 0                  // developer: floats of unused LDS in front of the fragments
+#endif
+    static constexpr int frag_base(bool bwd, int kB) { return (bwd ? bwd_size : fwd_size) + kB * border_size + ((bwd && kB == 1) ? 0 : EQ_FRAG_PAD); }
     static constexpr int f_w2 = 0, f_w6 = 1, f_w2t = 2, f_w6t = 3;
     // (the hidden_nf 33 backward has no LDS left for them -- 187 KB with the fragments -- and keeps the fp32 products)
 // developer A/B: bit 0 = the forward kernel, bit 1 = the backward kernel (fragments by build_frags16 after the image's barrier)
@@ -171,7 +198,10 @@ struct W16 {
 #endif
     static constexpr bool use_bf16(bool bwd, int kB) { return EQ_EDGE_BF16X3 != 0 && !(bwd && kB == 1) && ((EQ_BF16X3_KERNELS >> (bwd ? 1 : 0)) & 1); }
     static constexpr int image_size_fp32(bool bwd, int kB) { return frag_base(bwd, kB); }
-    static constexpr int image_size(bool bwd, int kB) { return frag_base(bwd, kB) + (use_bf16(bwd, kB) ? (bwd ? 4 : 2) * frag_floats : 0); }
+#ifndef EQ_FRAG_TAIL
+#define EQ_FRAG_TAIL 0                 // developer: floats of unused LDS behind the fragments
+#endif
+    static constexpr int image_size(bool bwd, int kB) { return frag_base(bwd, kB) + (use_bf16(bwd, kB) ? (bwd ? 4 : 2) * frag_floats + EQ_FRAG_TAIL : 0); }
 };
 
 // global -> LDS in two halves, so that a kernel can put other requests between them: load() issues all of a thread's global
@@ -286,20 +316,28 @@ __device__ __forceinline__ void mv16(const float* mat, int i, int g, const f32x4
 }
 // ---- the same product on split-bf16 operands: the lane's own eight features of the L16 layout are the B operand as they stand
 // frag: [3 levels][2 row blocks][64 lanes] fragments of the matrix (build_frag16); acc[bo] += (W v)[16 bo + ...]
+// EQ_BF_PIN (developer): idle cycles tied to the accumulator registers -- 1: after each chain's last instruction, 2: after every instruction
+#ifndef EQ_BF_PIN
+#define EQ_BF_PIN 0
+#endif
 __device__ __forceinline__ void mv16_bf(const float* frag, int lane, const f32x4 (&v)[2], f32x4 (&acc)[2]) {
     const bf16x8* f = reinterpret_cast<const bf16x8*>(frag);
     bf16x8 vh, vm, vl;
     split3_bf16(v, vh, vm, vl);
+#define EQ_BF_STEP(A_, B_) do { acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, acc[bo], 0, 0, 0); \
+        if (EQ_BF_PIN == 2) asm volatile("s_nop 7" : "+v"(acc[bo])); } while (0)
 #pragma unroll
     for (int bo = 0; bo < 2; ++bo) {
         const bf16x8 ah = f[(0 * 2 + bo) * 64 + lane], am = f[(1 * 2 + bo) * 64 + lane], al = f[(2 * 2 + bo) * 64 + lane];
-        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, vh, acc[bo], 0, 0, 0);        // smallest terms first
-        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, vl, acc[bo], 0, 0, 0);
-        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, vm, acc[bo], 0, 0, 0);
-        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, vh, acc[bo], 0, 0, 0);
-        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, vm, acc[bo], 0, 0, 0);
-        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, vh, acc[bo], 0, 0, 0);
+        EQ_BF_STEP(al, vh);        // smallest terms first
+        EQ_BF_STEP(ah, vl);
+        EQ_BF_STEP(am, vm);
+        EQ_BF_STEP(am, vh);
+        EQ_BF_STEP(ah, vm);
+        EQ_BF_STEP(ah, vh);
+        if (EQ_BF_PIN == 1) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[bo]));
     }
+#undef EQ_BF_STEP
 }
 // fragments of the fp32 image `mat` (row stride WS, as mv16 reads it) -> frag: threads 0..127 of the workgroup, one (row block, lane) each
 __device__ __forceinline__ void build_frag16(const float* mat, float* frag, int t) {

@@ -955,12 +955,22 @@ __global__ __launch_bounds__(256, EQ_IR_GEOM_OCC) void irrep_geom_bwd_kernel(con
     const float* dMbn = a.dMb + (size_t)nn * a.lc;
     const int f1base = 4 * a.c0p, B0 = a.c0p >> 4;
     float xs0 = 0.0f, xs1 = 0.0f, xs2 = 0.0f;               // sum of dr over the node's edges
+    // the table rows of a block's edges: unconditional loads (clamped position, masked below), the NEXT block's requested while this
+    // one computes (three dependent round trips per block otherwise: position -> source -> feature row)
+    int eid_n = 0, s_n = 0;
+    float4 gq_n = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    auto front = [&](int base_) {
+        const int p = min(base_ + i16, hi - 1);
+        eid_n = a.perm[p]; gq_n = a.tab.geo[p]; s_n = a.tab.src[p];
+    };
+    if (lo < hi) front(lo);
     for (int base = lo; base < hi; base += 16) {
         const int cnt = min(16, hi - base);
         const bool valid = i16 < cnt;
-        const int eid = valid ? a.perm[base + i16] : 0;
-        const float4 gq = valid ? a.tab.geo[base + i16] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const int s = valid ? a.tab.src[base + i16] : nn;
+        const float vf = valid ? 1.0f : 0.0f;
+        const int eid = eid_n, s = s_n;                               // (a padding lane keeps a real source row: its factors are zero)
+        const float4 gq = make_float4(gq_n.x * vf, gq_n.y * vf, gq_n.z * vf, gq_n.w * vf);
+        front(base + 16);
         const float d = gq.w;
         const bool live = valid && d > 0.0f;
         const float inv = live ? 1.0f / d : 0.0f;
@@ -1020,7 +1030,7 @@ __global__ __launch_bounds__(256, EQ_IR_GEOM_OCC) void irrep_geom_bwd_kernel(con
             const int i0 = 16 * sub + 4 * g;
             f32x4 gv;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) gv[r] = (i0 + r < a.c0) ? f0r[i0 + r] : 0.0f;
+            for (int r = 0; r < 4; ++r) gv[r] = keep_if(f0r[min(i0 + r, a.c0 - 1)], i0 + r < a.c0);
             f32x4 dc;
             block(sub, B0 + sub, gv * splat4(k00v), false, dc);
 #pragma unroll
@@ -1039,9 +1049,9 @@ __global__ __launch_bounds__(256, EQ_IR_GEOM_OCC) void irrep_geom_bwd_kernel(con
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool ok = ch0 + r < a.c1;
-                const float* f1r = a.f1 + ((size_t)s * a.c1 + ch0 + r) * 3;
+                const float* f1r = a.f1 + ((size_t)s * a.c1 + min(ch0 + r, a.c1 - 1)) * 3;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) gv[r][c] = ok ? f1r[c] : 0.0f;
+                for (int c = 0; c < 3; ++c) gv[r][c] = keep_if(f1r[c], ok);
                 sd[r] = u[0] * gv[r][0] + u[1] * gv[r][1] + u[2] * gv[r][2];
             }
             auto pair = [&](auto tag) {
@@ -1070,9 +1080,9 @@ __global__ __launch_bounds__(256, EQ_IR_GEOM_OCC) void irrep_geom_bwd_kernel(con
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bool ok = ch0 + r < a.c1;
-                    const float* f1r = a.f1 + ((size_t)s * a.c1 + ch0 + r) * 3;
+                    const float* f1r = a.f1 + ((size_t)s * a.c1 + min(ch0 + r, a.c1 - 1)) * 3;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) gv[r][c] = ok ? f1r[c] : 0.0f;
+                    for (int c = 0; c < 3; ++c) gv[r][c] = keep_if(f1r[c], ok);
                     sd[r] = u[0] * gv[r][0] + u[1] * gv[r][1] + u[2] * gv[r][2];
                 }
                 auto one = [&](auto tag) {

@@ -5,16 +5,17 @@ import numpy as np, torch
 import se3_equi_graph_registration_amd as pk
 out = sys.argv[1]
 n, e, feat = int(sys.argv[2]), int(sys.argv[3]), 32
+A = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 g = torch.Generator().manual_seed(33)
 torch.manual_seed(9)
-m = pk.EGNN(feat, feat, feat, in_edge_nf=1, device="cuda", n_layers=3, num_heads=1)
+m = pk.EGNN(feat, feat, feat, in_edge_nf=A, device="cuda", n_layers=3, num_heads=1)
 h = torch.randn(n, feat, generator=g); x = torch.rand(n, 3, generator=g) * 2
 row = torch.randint(0, n - 7, (e,), generator=g); col = torch.randint(0, n - 7, (e,), generator=g)
 row[:min(40, e // 2)] = 3; row[40:45] = col[40:45]
 ea = torch.rand(e, 1, generator=g)
 gh = torch.randn(n, feat, generator=g); gx = torch.randn(n, 3, generator=g)
 hc = h.cuda().requires_grad_(True); xc = x.cuda().requires_grad_(True)
-ho, xo = m(hc, xc, [row.cuda(), col.cuda()], ea.cuda())
+ho, xo = m(hc, xc, [row.cuda(), col.cuda()], ea.cuda() if A else None)
 m.zero_grad()
 ((ho * gh.cuda()).sum() + (xo * gx.cuda()).sum()).backward()
 d = {"ho": ho, "xo": xo, "grad_h": hc.grad, "grad_x": xc.grad}
