@@ -897,7 +897,11 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             for (int b = 0; b < 2; ++b) da[b] = ldg4(dagg + (size_t)rr * FP + 16 * b + 4 * g);
             const float dab = kB ? dagg[(size_t)rr * FP + 32] : 0.0f;
             const int eln = (sub + 1 < n_sub ? sub + 1 : sub) * 16 + i;
+#ifdef EQ_BWD16_NOREREQ
+            if (kAhead && sub + 1 < n_sub) nxt.load(P, idx_r[eln], idx_c[eln], g);
+#else
             if (kAhead) nxt.load(P, idx_r[eln], idx_c[eln], g);
+#endif
             const PRowsT<kB>& pw = cur;
             Sub16 o;
             tile_forward16<kB, true>(wsm, bord, geo_rows + i * C::GS, pw, i, g, o);
