@@ -864,6 +864,7 @@ EXTRA_WORKLOADS = (
      ["--forward-only", "--eval-head", "--batch", "16"], 60),
     ("irrepgnn", "N4: the typed irrep-basis network (32 degree-0 + 8 degree-1 channels, 4 layers) in the pair model, one 2048-pt pair, k=20, training step",
      ["--network", "irreps"], 100),
+    ("irrepgnn_b8", "N4: the same typed network, 8 pairs of 2048 pts per step (the moments of a layer: 0.9 GB)", ["--network", "irreps", "--batch", "8"], 20),
 )
 EXTRA_WORKLOADS_MULTI = (
     ("c3_b16", "configs[2] shape: 3DMatch training, 16 pairs per GPU (weak scaling)", ["--workload", "c3"], 80),
