@@ -575,7 +575,10 @@ def roofline(pkg, S, args, dev):
     for name in [f for g in PMC_GLOBS for f in sorted(glob.glob(os.path.join(ROOT, "profiles", g)), reverse=True)]:
         try:
             pmc = json.load(open(name))
-            if pmc["workload"]["edges_per_launch"] == E and pmc["workload"]["feat"] == F:
+            fl = pmc["workload"].get("flags", "")
+            same_kind = ((("--forward-only" in fl) or ("--workload c5" in fl)) == bool(args.forward_only) and ("--network irreps" in fl) == (args.network == "irreps")
+                         and ("--edge-basis irreps" in fl) == (args.edge_basis == "irreps"))
+            if pmc["workload"]["edges_per_launch"] == E and pmc["workload"]["feat"] == F and same_kind:
                 traffic = {"fwd": pmc["edge_fwd_kernel"]["traffic_bytes"], "bwd": (pmc.get("edge_bwd_kernel") or {}).get("traffic_bytes"),
                            "node": {k: v["traffic_bytes"] for k, v in pmc.items() if isinstance(v, dict) and "traffic_bytes" in v and "node" in k},
                            "source": f"profiles/{os.path.basename(name)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
