@@ -447,17 +447,20 @@ def split_graph_runner(S, args, dist_on, eager):
 #   weight-gradient outer products (16 + 16 + 8).  hidden_nf 33 runs the SAME matrix instructions on its 32 x 32 cores; feature 32
 #   (the "border") is vector-ALU work on top (its column of a product = 8 FMAs, its row a partial dot + one lane-group sum).
 # valu = vector-ALU instructions per sub-tile (SQ_INSTS_VALU - SQ_INSTS_MFMA over the sub-tiles of a launch; profiles/r03_sq_edge_kernels.json)
-MFMA_PER_TILE = {32: dict(edges=16, flop=2048, fwd=40, bwd=120, valu_fwd=210, valu_bwd=435),
-                 33: dict(edges=16, flop=2048, fwd=40, bwd=120, valu_fwd=296, valu_bwd=654)}
+# per 16-edge sub-tile: fp32 matrix instructions (16x16x4, 32 cycles) | bf16 x 3 ones (16x16x32, 16 cycles: the W2 / W6 products and, in
+# the backward, their transposes -- 12 each; the hidden_nf 33 backward keeps all four on fp32) | vector instructions (incl. the splits)
+MFMA_PER_TILE = {32: dict(edges=16, flop=2048, fwd=40, bwd=120, fwd32=8, fwd16=24, bwd32=56, bwd16=48, valu_fwd=270, valu_bwd=555),
+                 33: dict(edges=16, flop=2048, fwd=40, bwd=120, fwd32=8, fwd16=24, bwd32=120, bwd16=0, valu_fwd=356, valu_bwd=654)}
 SIMDS, ISSUE_CLOCK_GHZ = 1024, 2.1          # 256 CUs x 4 SIMDs; the clock the chip holds under this load
 
 
 def issue_floor_us(E, F, bwd):
     """Lower bound of an edge kernel from instruction issue alone: on gfx950 the fp32 MFMA does not co-execute with vector-ALU work
-    of the same SIMD (tools/dev/coexec.hip), so a SIMD's time is >= 32 cycles per 16x16x4 MFMA + ~4 per vector instruction."""
+    of the same SIMD (tools/dev/coexec.hip), so a SIMD's time is >= 32 cycles per 16x16x4 fp32 MFMA + 16 per 16x16x32 bf16 MFMA (the split products) + ~4 per vector instruction."""
     mm = MFMA_PER_TILE[33 if F == 33 else 32]
     tiles = (E + 15) // 16
-    cyc = (mm["bwd" if bwd else "fwd"] * 32 + mm["valu_bwd" if bwd else "valu_fwd"] * 4) * ((tiles + SIMDS - 1) // SIMDS)
+    d = "bwd" if bwd else "fwd"
+    cyc = (mm[d + "32"] * 32 + mm[d + "16"] * 16 + mm["valu_" + d] * 4) * ((tiles + SIMDS - 1) // SIMDS)
     return cyc / (ISSUE_CLOCK_GHZ * 1e3)
 
 
@@ -569,7 +572,8 @@ def roofline(pkg, S, args, dev):
     flops_bwd = flops_fwd + 2 * (2 * F * F + 2 * F * F + 2 * 13 * F) * E       # + transposed products + outer products (the backward recomputes the forward)
     mm = MFMA_PER_TILE[33 if F == 33 else 32]
     tiles = (E + mm["edges"] - 1) // mm["edges"]
-    exe_fwd, exe_bwd = tiles * mm["fwd"] * mm["flop"], tiles * mm["bwd"] * mm["flop"]
+    # share of a SIMD's time spent issuing matrix instructions: (fp32 x 32 + bf16 x 16 cycles) x sub-tiles per SIMD / (launch time x clock)
+    mfma_share = lambda d, t_ms: ((mm[d + "32"] * 32 + mm[d + "16"] * 16) * ((tiles + SIMDS - 1) // SIMDS)) / (t_ms * 1e-3 * ISSUE_CLOCK_GHZ * 1e9)
     # HBM traffic per launch from the committed rocprofv3 PMC passes of this command (profiles/), when they cover this workload
     traffic = {"fwd": None, "bwd": None, "source": None, "node": None}
     for name in [f for g in PMC_GLOBS for f in sorted(glob.glob(os.path.join(ROOT, "profiles", g)), reverse=True)]:
@@ -615,7 +619,7 @@ def roofline(pkg, S, args, dev):
             "launch_ms_note": "HIP events around back-to-back launches of this one kernel (equigspr_time_edge_*): warm caches, no neighbours; "
                               "in_step_* = the same kernel's average inside the replayed step under rocprofv3 (committed profile)",
             "issue_floor_us": round(issue_floor_us(E, F, dom_is_bwd), 2) if mfma_width else None,
-            "issue_floor_note": "(MFMA x 32 + vector-ALU x 4 cycles) per 16-edge sub-tile x sub-tiles per SIMD / 2.1 GHz: fp32 MFMA and VALU "
+            "issue_floor_note": "(fp32 MFMA x 32 + bf16 MFMA x 16 + vector-ALU x 4 cycles) per 16-edge sub-tile x sub-tiles per SIMD / 2.1 GHz: MFMA and VALU "
                                 "do not co-execute on gfx950 (profiles/r03_sq_edge_kernels.json, tools/dev/coexec.hip)",
             "backward_mode": "recompute (no per-edge activations kept by the forward)"}
     kshort = "edge_bwd16_kernel" if dom_is_bwd else "edge_fwd16_kernel"
@@ -631,14 +635,15 @@ def roofline(pkg, S, args, dev):
     extra = {"edge_fwd_ms": round(fwd_ms, 5), "edge_fwd_issue_floor_us": round(issue_floor_us(E, F, False), 2),
              "edge_fwd_form": "training form = inference form (the timed step runs this kernel)",
              "edge_fwd_GBs": round(a_f, 2), "edge_fwd_hbm_frac": round(a_f / HBM_PEAK_GBS, 5),
-             "edge_fwd_fp32_frac": round(tf(flops_fwd, fwd_ms), 5), "edge_fwd_executed_mfma_frac": round(tf(exe_fwd, fwd_ms), 5),
+             "edge_fwd_fp32_frac": round(tf(flops_fwd, fwd_ms), 5), "edge_fwd_executed_mfma_frac": round(mfma_share("fwd", fwd_ms), 5),
              "edge_fwd_traffic": traffic["fwd"],
-             "mfma_note": "fp32 MFMA shares the SIMD's fp32 lanes with the VALU on gfx950 (tools/dev/coexec.hip: no co-execution), so "
-                          "executed_mfma_frac is the share of the kernel's SIMD time spent in matrix instructions"}
+             "mfma_note": "fp32 MFMA shares the SIMD's fp32 lanes with the VALU on gfx950 (tools/dev/coexec.hip: no co-execution); "
+                          "executed_mfma_frac is the share of a SIMD's time spent issuing matrix instructions (fp32 16x16x4: 32 cycles, the "
+                          "bf16 x 3 split products' 16x16x32: 16 cycles)"}
     if bwd_ms is not None:
         extra.update({"edge_bwd_ms": round(bwd_ms, 5), "edge_bwd_issue_floor_us": round(issue_floor_us(E, F, True), 2),
                       "edge_bwd_GBs": round(a_b, 2), "edge_bwd_hbm_frac": round(a_b / HBM_PEAK_GBS, 5),
-                      "edge_bwd_fp32_frac": round(tf(flops_bwd, bwd_ms), 5), "edge_bwd_executed_mfma_frac": round(tf(exe_bwd, bwd_ms), 5),
+                      "edge_bwd_fp32_frac": round(tf(flops_bwd, bwd_ms), 5), "edge_bwd_executed_mfma_frac": round(mfma_share("bwd", bwd_ms), 5),
                       "edge_bwd_traffic": traffic["bwd"]})
     return roof, extra
 

@@ -17,17 +17,18 @@
 #pragma once
 #include "egnn_device.h"
 
-// EXPERIMENTAL (round 5, default OFF): the 32 x 32 mat-vec products of the edge kernels on the bf16 matrix pipe with 3-way split
-// operands (x = hi + mid + lo, each bf16; the six products with i + j <= 2 accumulate in fp32): 12 v_mfma_f32_16x16x32_bf16 instead
-// of 16 v_mfma_f32_16x16x4_f32.  The isolated tile passes its criterion (tools/dev/bf16_split.hip: 1.33-1.35 x including the split's
-// vector instructions, max error 1.9e-7 against 3.3e-7 for the fp32 chain), but inside the kernels (profiles/r05_bf16x3_edge_kernels.txt):
-//   * forward, hidden_nf 32: correct at every size (differences to the fp32 build <= 1e-6 relative); 103 -> 101.5 us at 16 pairs,
-//     9.95 -> 11.8 us at one pair (eight spilled registers at the three-waves budget; a wave lives for two or three tiles there);
-//   * forward, hidden_nf 33 and backward, hidden_nf 32: 2^-10 relative errors on graphs where a wave's persistent loop runs more than
-//     one unit (> ~4 tiles per wave; forward-type and transposed products alike; chunk regime and store policy irrelevant; exact on
-//     small graphs) -- NOT understood, so nothing ships on this path.  1 = build it (tools/dev A/B only).
+// The 32 x 32 mat-vec products of the edge kernels (W2, W6 and, in the backward, their transposes) run on the bf16 matrix pipe with
+// 3-way split operands (x = hi + mid + lo, each bf16; the six products with i + j <= 2 accumulate in fp32): 12
+// v_mfma_f32_16x16x32_bf16 (16 cycles each) instead of 16 v_mfma_f32_16x16x4_f32 (32 cycles each); differences to the fp32 products
+// <= 1e-6 relative (tools/dev/bf16_split.hip: 1.33-1.35 x on the tile including the split's vector work; max error 1.9e-7 against
+// fp64, the fp32 tile's is 3.3e-7).  Default since the end of round 5: 16 pairs forward 0.67 -> 0.73 / backward 0.62 -> 0.67 of the
+// HBM roofline, hidden_nf 33 forward 0.60 -> 0.63, one pair unchanged (profiles/r05_bf16x3_edge_kernels.txt).  The hidden_nf 33
+// backward keeps the fp32 products (no LDS for the fragments).  ONE path for every graph size: a cloud's outputs do not depend on
+// what else is in the batch.  The product is a CLOSED group (mv16_bf, EQ_BF_GUARD): an operand register reused as a load's
+// destination behind the instruction that reads it was the source of run-to-run different results (part F of that file).
+// 0 = the fp32 products (A/B).
 #ifndef EQ_EDGE_BF16X3
-#define EQ_EDGE_BF16X3 0
+#define EQ_EDGE_BF16X3 1
 #endif
 
 namespace eq {
@@ -194,7 +195,7 @@ struct W16 {
     // (the hidden_nf 33 backward has no LDS left for them -- 187 KB with the fragments -- and keeps the fp32 products)
 // developer A/B: bit 0 = the forward kernel, bit 1 = the backward kernel (fragments by build_frags16 after the image's barrier)
 #ifndef EQ_BF16X3_KERNELS
-#define EQ_BF16X3_KERNELS 1
+#define EQ_BF16X3_KERNELS 3
 #endif
     static constexpr bool use_bf16(bool bwd, int kB) { return EQ_EDGE_BF16X3 != 0 && !(bwd && kB == 1) && ((EQ_BF16X3_KERNELS >> (bwd ? 1 : 0)) & 1); }
     static constexpr int image_size_fp32(bool bwd, int kB) { return frag_base(bwd, kB); }
@@ -316,28 +317,43 @@ __device__ __forceinline__ void mv16(const float* mat, int i, int g, const f32x4
 }
 // ---- the same product on split-bf16 operands: the lane's own eight features of the L16 layout are the B operand as they stand
 // frag: [3 levels][2 row blocks][64 lanes] fragments of the matrix (build_frag16); acc[bo] += (W v)[16 bo + ...]
-// EQ_BF_PIN (developer): idle cycles tied to the accumulator registers -- 1: after each chain's last instruction, 2: after every instruction
-#ifndef EQ_BF_PIN
-#define EQ_BF_PIN 0
+// EQ_BF_GUARD: 1 = the product is a closed group -- nothing is scheduled into it, and every operand register (the six weight
+// fragments, the three split levels of v) stays allocated until its last matrix instruction has been issued and EQ_BF_GUARD_NOPS
+// idle issue slots have passed.  Measured (profiles/r05_bf16x3_edge_kernels.txt part F): without it the compiler reuses an operand
+// register as the destination of a global / LDS load right behind the instruction that reads it (legal if operands are read at
+// issue); when that load returns early (a cache hit) while the dependent chain of twelve is still queued behind the other wave of
+// the SIMD, the instruction computes with the loaded data instead.
+#ifndef EQ_BF_GUARD
+#define EQ_BF_GUARD 1
+#endif
+#ifndef EQ_BF_GUARD_NOPS
+#define EQ_BF_GUARD_NOPS 1             // x "s_nop 7" behind the group
 #endif
 __device__ __forceinline__ void mv16_bf(const float* frag, int lane, const f32x4 (&v)[2], f32x4 (&acc)[2]) {
     const bf16x8* f = reinterpret_cast<const bf16x8*>(frag);
     bf16x8 vh, vm, vl;
     split3_bf16(v, vh, vm, vl);
-#define EQ_BF_STEP(A_, B_) do { acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_, B_, acc[bo], 0, 0, 0); \
-        if (EQ_BF_PIN == 2) asm volatile("s_nop 7" : "+v"(acc[bo])); } while (0)
+    bf16x8 ah[2], am[2], al[2];
+#if EQ_BF_GUARD
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+    for (int bo = 0; bo < 2; ++bo) { ah[bo] = f[(0 * 2 + bo) * 64 + lane]; am[bo] = f[(1 * 2 + bo) * 64 + lane]; al[bo] = f[(2 * 2 + bo) * 64 + lane]; }
 #pragma unroll
     for (int bo = 0; bo < 2; ++bo) {
-        const bf16x8 ah = f[(0 * 2 + bo) * 64 + lane], am = f[(1 * 2 + bo) * 64 + lane], al = f[(2 * 2 + bo) * 64 + lane];
-        EQ_BF_STEP(al, vh);        // smallest terms first
-        EQ_BF_STEP(ah, vl);
-        EQ_BF_STEP(am, vm);
-        EQ_BF_STEP(am, vh);
-        EQ_BF_STEP(ah, vm);
-        EQ_BF_STEP(ah, vh);
-        if (EQ_BF_PIN == 1) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[bo]));
+        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[bo], vh, acc[bo], 0, 0, 0);        // smallest terms first
+        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[bo], vl, acc[bo], 0, 0, 0);
+        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[bo], vm, acc[bo], 0, 0, 0);
+        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[bo], vh, acc[bo], 0, 0, 0);
+        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[bo], vm, acc[bo], 0, 0, 0);
+        acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[bo], vh, acc[bo], 0, 0, 0);
     }
-#undef EQ_BF_STEP
+#if EQ_BF_GUARD
+#pragma unroll
+    for (int n = 0; n < EQ_BF_GUARD_NOPS; ++n)
+        asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]) : "v"(ah[0]), "v"(am[0]), "v"(al[0]), "v"(ah[1]), "v"(am[1]), "v"(al[1]), "v"(vh), "v"(vm), "v"(vl));
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 }
 // fragments of the fp32 image `mat` (row stride WS, as mv16 reads it) -> frag: threads 0..127 of the workgroup, one (row block, lane) each
 __device__ __forceinline__ void build_frag16(const float* mat, float* frag, int t) {
