@@ -21,8 +21,8 @@
 // 3-way split operands (x = hi + mid + lo, each bf16; the six products with i + j <= 2 accumulate in fp32): 12
 // v_mfma_f32_16x16x32_bf16 (16 cycles each) instead of 16 v_mfma_f32_16x16x4_f32 (32 cycles each); differences to the fp32 products
 // <= 1e-6 relative (tools/dev/bf16_split.hip: 1.33-1.35 x on the tile including the split's vector work; max error 1.9e-7 against
-// fp64, the fp32 tile's is 3.3e-7).  Default since the end of round 5: 16 pairs forward 0.67 -> 0.73 / backward 0.62 -> 0.67 of the
-// HBM roofline, hidden_nf 33 forward 0.60 -> 0.63, one pair unchanged (profiles/r05_bf16x3_edge_kernels.txt).  The hidden_nf 33
+// fp64, the fp32 tile's is 3.3e-7).  Default since the end of round 5: 16 pairs forward 0.67 -> 0.73 / backward 0.62 -> 0.68 of the
+// HBM roofline, hidden_nf 33 forward 0.60 -> 0.63, one pair backward 0.44 -> 0.46 (profiles/r05_bf16x3_edge_kernels.txt).  The hidden_nf 33
 // backward keeps the fp32 products (no LDS for the fragments).  ONE path for every graph size: a cloud's outputs do not depend on
 // what else is in the batch.  The product is a CLOSED group (mv16_bf, EQ_BF_GUARD): an operand register reused as a load's
 // destination behind the instruction that reads it was the source of run-to-run different results (part F of that file).
