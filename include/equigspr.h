@@ -34,7 +34,10 @@ extern "C" {
  * Supported kernel set: hidden_nf in {16, 32, 33, 48, 64} (32 / 33: the 16-edge MFMA edge kernels of csrc/egnn_mfma16.h; 16 / 48 / 64:
  * the feature-parallel MFMA edge kernels of csrc/egnn_edge_fp.h), num_heads in {1, 2, 4, 8} (1 at hidden_nf 33: the other divisors
  * of 33 are not instantiated),
- * in_nf/out_nf <= 64, in_edge_nf in {0, 1}, 1 <= n_layers <= 16. */
+ * in_nf/out_nf <= 64, in_edge_nf in {0, 1}, 1 <= n_layers <= 16.
+ * Arithmetic: fp32 storage and accumulation everywhere.  At hidden_nf 32 / 33 the two 32 x 32 products of the edge MLP (and their
+ * transposes in the hidden_nf 32 backward) are evaluated as six bf16 x bf16 -> fp32 matrix products on 3-way split operands
+ * (x = hi + mid + lo): within 1e-6 relative of the fp32 product, bitwise reproducible run to run, independent of the batch. */
 typedef struct equigspr_egnn_config {
     int32_t in_nf;       /* in_node_nf  */
     int32_t hidden_nf;   /* hidden_nf   */
