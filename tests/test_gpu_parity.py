@@ -1526,3 +1526,37 @@ def test_torch_library_layer_head_and_loss_ops(pk):
                                                          b["tgt"].contiguous(), b["labels"], b["gt_pose"], mlp, K)
     assert torch.equal(R, out[0]) and torch.equal(tt, out[1]) and torch.equal(equi, out[3]) and torch.equal(top_idx, model.last_top_idx)
     assert torch.equal(wts, model.last_weights)
+
+
+def test_edge_kernels_are_reproducible_when_waves_run_many_units(pk):
+    """Regression guard for the split-bf16 products (csrc/egnn_mfma16.h mv16_bf, EQ_BF_GUARD): without the closed instruction groups a
+    load returning early into an operand register of a queued matrix instruction corrupted 1-6 of 3 000 tiles, different ones every run
+    (profiles/r05_bf16x3_edge_kernels.txt) -- only where a wave's persistent loop runs several units.  A ring graph of 40 000 nodes x 16
+    edges gives every wave ~20 tiles (5 units); forward outputs and all gradients must be bit-identical run to run, and agree (2e-5)
+    with the same nodes in a graph cut to 1/8 of the ring, where every wave runs ONE unit (away from the cut)."""
+    g = torch.Generator().manual_seed(5)
+
+    def run(n):
+        torch.manual_seed(2)
+        m = pk.EGNN(32, 32, 32, in_edge_nf=1, device="cuda", n_layers=1, num_heads=1)
+        gg = torch.Generator().manual_seed(7)
+        h = torch.randn(40000, 32, generator=gg)[:n].cuda()
+        x = (torch.rand(40000, 3, generator=gg) * 2)[:n].cuda()
+        ea = torch.rand(40000 * 16, 1, generator=gg)[:n * 16].cuda()
+        gh = torch.randn(40000, 32, generator=gg)[:n].cuda()
+        gx = torch.randn(40000, 3, generator=gg)[:n].cuda()
+        row = torch.arange(n).repeat_interleave(16)
+        col = (row + 1) % n
+        hc, xc = h.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ho, xo = m(hc, xc, [row.cuda(), col.cuda()], ea)
+        m.zero_grad()
+        ((ho * gh).sum() + (xo * gx).sum()).backward()
+        return ho.detach(), xo.detach(), hc.grad, xc.grad, m.flat_grads.clone()
+
+    a, b = run(40000), run(40000)
+    for u, v in zip(a, b):
+        assert torch.isfinite(u).all() and torch.equal(u, v)
+    c = run(5000)                                            # the same leading nodes in a small graph: one unit per wave, other node kernels
+    sl = slice(100, 4800)                                    # away from the ring's closing edge
+    for u, v in zip(a[:4], c[:4]):
+        assert float((u[sl] - v[sl]).abs().max()) <= 2e-5 * max(1.0, float(v[sl].abs().max()))
