@@ -337,3 +337,39 @@ def test_captured_collective_probe_switches():
             os.environ.pop("EQUIGSPR_TRUST_CAPTURED_COLLECTIVES", None)
         else:
             os.environ["EQUIGSPR_TRUST_CAPTURED_COLLECTIVES"] = old
+
+
+def test_bench_line_stays_within_the_drivers_record():
+    """BENCH_r05.json: `parsed` null -- the default run's line had grown to 32.7 KB.  bench.compact_line turns the full record (here: round
+    5's committed one, eight extra workloads + fixed-pair replay + cpu_baseline) into the line the driver parses: contract scalars,
+    config, scalar-only roofline with one flat set per workload, cpu_baseline; under bench.LINE_BUDGET bytes."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    full = json.loads(open(os.path.join(root, "profiles", "r05_d_bench.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 20000 and len(full["workloads"]) == 8
+    full["roofline"].pop("workloads", None)
+    # worst case: every workload also carries counter traffic and a measured rate, and an N > 1 run's multi_gpu block with 8 ranks
+    for e in full["workloads"].values():
+        e["roofline"].setdefault("measured_GBs", 1234.5)
+        e["roofline"]["traffic"] = e["roofline"].get("traffic") or 123456789
+    full["multi_gpu"] = {"world_size": 8, "backend": "nccl", "ranks_seen": [{"rank": i, "uuid": "x" * 40} for i in range(8)],
+                         "distinct_devices": 8, "allreduce_bytes": 131072, "allreduce_us_isolated": 31.0, "exchange": "one mean all-reduce"}
+    line = bench.compact_line(full, "bench_full.json")
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_BUDGET <= 6144, len(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["value"] == full["value"] and line["config"]["workload"] == full["config"]["workload"]
+    r = line["roofline"]
+    assert all(not isinstance(v, (dict, list)) for v in r.values())
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert r[k] == full["roofline"][k]
+    for name, e in full["workloads"].items():
+        assert r[f"{name}_value"] == e["value"] and r[f"{name}_frac"] == e["roofline"]["frac"]
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    assert "ranks_seen" not in line["multi_gpu"] and line["full_record"] == "bench_full.json"
