@@ -27,7 +27,7 @@ extern "C" {
 
 #define EQUIGSPR_EINVAL   (-1)  /* bad shape / size / null pointer                         */
 #define EQUIGSPR_ENOTSUP  (-2)  /* configuration outside the compiled kernel set             */
-#define EQUIGSPR_ABI_VERSION 13
+#define EQUIGSPR_ABI_VERSION 14
 
 /* EGNN architecture.  Mirrors EGNN.__init__ (src/3dmatch_train_egnn_with_batch.py:294-326)
  * plus num_heads (E_GCL.__init__ :186; the shipped checkpoints need 4).
@@ -478,6 +478,17 @@ int equigspr_correspondence_labels(const float* src_pts, const float* tgt_pts, c
 /* Developer / test knob: chunk size (edges per wave pass) of the hidden_nf = 32 edge kernels: 16, 32, 48, 64, or 0 = automatic
  * (by problem size).  Process-wide; results are bit-identical run to run for any fixed value. */
 int equigspr_set_edge_chunk(int32_t chunk);
+/* Arithmetic of the two 32 x 32 products of the edge MLP (W2, W6; in the backward also their transposes) in the hidden_nf 32 / 33
+ * edge kernels -- where the reference computes `nn.Linear` in fp32 (train :231-268):
+ *   0 = split-bf16 (default): six bf16 x bf16 -> fp32 matrix products on 3-way split operands, <= 1e-6 relative from the fp32 product;
+ *   1 = fp32 matrix products (v_mfma_f32_16x16x4_f32: an exact fmaf chain), 5-9 % slower at batch scale.
+ * Process-wide, takes effect at the next launch (hipGraphs captured before keep the kernels they captured).  The environment
+ * variable EQUIGSPR_EDGE_PRODUCTS=fp32|bf16x3 sets the initial value.  Both forms are bit-reproducible run to run. */
+int equigspr_set_edge_products(int32_t fp32);
+/* Developer / test knob: upper bound on the workgroups of the 16-edge kernels (0 = the default, one persistent workgroup per CU slot).
+ * A small cap makes every wave run many units on a small graph: the regime the reproducibility tests of the split products need
+ * (tests/test_gpu_parity.py::test_split_products_match_fp32_products_tile_by_tile).  EQUIGSPR_EDGE_MAXBLOCKS sets the initial value. */
+int equigspr_set_edge_grid_cap(int32_t max_blocks);
 int equigspr_time_edge_fwd(const equigspr_egnn_config* cfg, const float* params, const equigspr_graph* g,
                            const float* h_in, const float* x_in, const float* edge_attr, float* work,
                            int32_t iters, float* ms_out_host, void* stream);

@@ -59,6 +59,8 @@ _SIGNATURES = {
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_void_p]),
     "equigspr_set_edge_chunk": (ctypes.c_int, [c_int32]),
+    "equigspr_set_edge_products": (ctypes.c_int, [c_int32]),
+    "equigspr_set_edge_grid_cap": (ctypes.c_int, [c_int32]),
     "equigspr_time_edge_fwd": (ctypes.c_int, [POINTER(EgnnConfig), c_void_p, POINTER(Graph), c_void_p, c_void_p, c_void_p,
                                               c_void_p, c_int32, POINTER(ctypes.c_float), c_void_p]),
     "equigspr_time_edge_bwd": (ctypes.c_int, [POINTER(EgnnConfig), c_void_p, POINTER(Graph), c_void_p, c_void_p, c_void_p,
@@ -133,7 +135,7 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
-        if L.equigspr_abi_version() != 13:
+        if L.equigspr_abi_version() != 14:
             raise RuntimeError("libequigspr.so ABI version mismatch")
         _lib = L
     return _lib

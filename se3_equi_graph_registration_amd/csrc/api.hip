@@ -3,6 +3,7 @@
 
 #include <atomic>
 #include <stdlib.h>
+#include <string.h>
 
 namespace eq {
 static thread_local char g_err[512] = "";
@@ -28,7 +29,41 @@ int edge_chunk_for(int n_edges, int waves_resident) {
     if ((long long)n_edges >= 32ll * 2 * waves_resident) return 32;
     return 16;
 }
+// Arithmetic of the edge kernels' 32 x 32 products (egnn_mfma16.h): 0 = split-bf16 (default), 1 = fp32.  -1 = not yet read from the environment.
+static std::atomic<int> g_edge_fp32{-1};
+bool edge_products_fp32() {
+    int v = g_edge_fp32.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("EQUIGSPR_EDGE_PRODUCTS");
+        v = (e && (!strcmp(e, "fp32") || !strcmp(e, "1"))) ? 1 : 0;
+        g_edge_fp32.store(v, std::memory_order_relaxed);
+    }
+    return v == 1;
+}
+// Upper bound on the workgroups of the 16-edge kernels (developer / test knob; 0 = the kernel's default)
+static std::atomic<int> g_edge_cap{-1};
+int edge_grid_cap(int dflt) {
+    int v = g_edge_cap.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = getenv("EQUIGSPR_EDGE_MAXBLOCKS");
+        v = e ? atoi(e) : 0;
+        if (v < 0) v = 0;
+        g_edge_cap.store(v, std::memory_order_relaxed);
+    }
+    return (v > 0 && v < dflt) ? v : dflt;
+}
 }  // namespace eq
+
+extern "C" int equigspr_set_edge_products(int32_t fp32) {
+    EQ_CHECK_ARG(fp32 == 0 || fp32 == 1, EQUIGSPR_EINVAL, "set_edge_products: 0 (split-bf16) or 1 (fp32)");
+    eq::g_edge_fp32.store(fp32, std::memory_order_relaxed);
+    return 0;
+}
+extern "C" int equigspr_set_edge_grid_cap(int32_t max_blocks) {
+    EQ_CHECK_ARG(max_blocks >= 0, EQUIGSPR_EINVAL, "set_edge_grid_cap: >= 0 (0 = default)");
+    eq::g_edge_cap.store(max_blocks, std::memory_order_relaxed);
+    return 0;
+}
 
 extern "C" int equigspr_set_edge_chunk(int32_t chunk) {
     EQ_CHECK_ARG(chunk == 0 || chunk == 16 || chunk == 32 || chunk == 48 || chunk == 64, EQUIGSPR_EINVAL,

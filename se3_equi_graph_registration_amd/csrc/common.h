@@ -29,6 +29,8 @@ namespace eq {
 
 void set_error(const char* fmt, ...);   // api.hip
 int edge_chunk_for(int n_edges, int waves_resident);   // api.hip: chunk size of the 16-edge kernels
+bool edge_products_fp32();                              // api.hip: equigspr_set_edge_products / EQUIGSPR_EDGE_PRODUCTS
+int edge_grid_cap(int dflt);                            // api.hip: equigspr_set_edge_grid_cap / EQUIGSPR_EDGE_MAXBLOCKS
 
 #define EQ_CHECK_ARG(cond, code, ...)            \
     do {                                         \

@@ -752,7 +752,7 @@ constexpr int kBwd16Waves = 8;
 #endif
 constexpr int bwd16_waves(int kB) { return kB ? EQ_BWD16_NW33 : kBwd16Waves; }
 
-template <int H, int A, int kB = 0>
+template <int H, int A, int kB = 0, bool kBf = W16::use_bf16(true, kB)>
 __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const float* __restrict__ lw, const int* __restrict__ row,
                                                          const int* __restrict__ col, const float* __restrict__ edge_attr,
                                                          const float* __restrict__ x, const float* __restrict__ P,
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
     using SB = Slabs<F>;
     constexpr int NW = bwd16_waves(kB);
     constexpr int kScratch = C::bwd_size > SB::edge ? C::bwd_size : SB::edge;      // reused for the waves' slab copies
-    __shared__ __attribute__((aligned(16))) float wsm_[W16::image_size(true, kB)];
+    __shared__ __attribute__((aligned(16))) float wsm_[kBf ? W16::image_size(true, kB) : W16::image_size_fp32(true, kB)];
     __shared__ __attribute__((aligned(16))) float scratch[NW][kScratch];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     EQ_STAMP(0);
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
     for (int k = 0; k < 3; ++k) { xr0[k] = x[(size_t)r * 3 + k]; xc0[k] = x[(size_t)c * 3 + k]; gx0[k] = Gx[(size_t)r * 4 + k]; }
     stage.store(wsm_);
     __syncthreads();
-    build_frags16<true, kB>(wsm_);
+    build_frags16<true, kB, kBf>(wsm_);
     EQ_STAMP(1);
     bool first = true;
     for (; ch < n_chunks; ch += unit_step) {
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
 #endif
             const PRowsT<kB>& pw = cur;
             Sub16 o;
-            tile_forward16<kB, true>(wsm, bord, geo_rows + i * C::GS, pw, i, g, o);
+            tile_forward16<kB, true, kBf>(wsm, bord, geo_rows + i * C::GS, pw, i, g, o);
             if (g == 0) s_buf[el] = o.s;
             // ---- coord head backward: s = w7 . SiLU(q)
             f32x4 dq[2];
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             float dmb = 0.0f;
 #pragma unroll
             for (int b = 0; b < 2; ++b) dm[b] = valid ? da[b] : splat4(0.0f);
-            mv16_edge<true, kB>(wsm, W16::f_w6t, i, g, dq, dm);
+            mv16_edge<true, kB, kBf>(wsm, W16::f_w6t, i, g, dq, dm);
             if constexpr (kB == 1)      // W6^T: its column 32 is W6's row 32 and vice versa
                 dmb = (valid ? dab : 0.0f) + mv16_border(bord + W16::b_w6row, bord + W16::b_w6col, bord[W16::b_sc + 1], g, dq, dqb, dm);
             EQ_STAMP(11);
@@ -992,7 +992,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             // ---- dt1 = (W2^T du) * SiLU'(t1)
             f32x4 dt1[2] = {splat4(0.0f), splat4(0.0f)};
             float dt1b = 0.0f;
-            mv16_edge<true, kB>(wsm, W16::f_w2t, i, g, du, dt1);
+            mv16_edge<true, kB, kBf>(wsm, W16::f_w2t, i, g, du, dt1);
             if constexpr (kB == 1) {
                 dt1b = mv16_border(bord + W16::b_w2row, bord + W16::b_w2col, bord[W16::b_sc + 0], g, du, dub, dt1);
                 dt1b *= o.sg1b * (1.0f + o.t1b * (1.0f - o.sg1b));
@@ -1174,9 +1174,15 @@ static int launch_edge_bwd(const float* lw, const equigspr_graph* g, const float
 #ifndef EQ_BWD16_MAXBLOCKS
 #define EQ_BWD16_MAXBLOCKS 256          // developer: fewer workgroups = more units per wave on small graphs
 #endif
-        blocks = blocks < 1 ? 1 : (blocks > EQ_BWD16_MAXBLOCKS ? EQ_BWD16_MAXBLOCKS : blocks);
-        hipLaunchKernelGGL((edge_bwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * NW), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
-                           E, chunk, basis, dt1, dt1 + (size_t)E * 32, gxr, gxc, slab);
+        const int cap = edge_grid_cap(EQ_BWD16_MAXBLOCKS);
+        blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+        // the 32 x 32 products: split-bf16 (default) or fp32 (equigspr_set_edge_products / EQUIGSPR_EDGE_PRODUCTS=fp32)
+        if (W16::use_bf16(true, F - 32) && !edge_products_fp32())
+            hipLaunchKernelGGL((edge_bwd16_kernel<H, A, F - 32, true>), dim3(blocks), dim3(64 * NW), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
+                               E, chunk, basis, dt1, dt1 + (size_t)E * 32, gxr, gxc, slab);
+        else
+            hipLaunchKernelGGL((edge_bwd16_kernel<H, A, F - 32, false>), dim3(blocks), dim3(64 * NW), 0, s, lw, g->row, g->col, edge_attr, x, P, dagg, Gx,
+                               E, chunk, basis, dt1, dt1 + (size_t)E * 32, gxr, gxc, slab);
         *n_slabs = blocks;
     } else if constexpr (F % 16 == 0) {  // 16 / 48 / 64: the feature-parallel MFMA kernels (egnn_edge_fp.h), one slab per workgroup
         using L = FpLayout<F, H, A, true>;

@@ -216,9 +216,14 @@ static void launch_edge_fwd(const float* lw, const equigspr_graph* g, const floa
         constexpr int occ = fwd16_occ(F - 32);
         const int chunk = edge_chunk_for(E, 256 * 4 * occ);
         int blocks = ceil_div(ceil_div(E, chunk), kFwd16Waves);
-        blocks = blocks < 1 ? 1 : (blocks > 256 * occ ? 256 * occ : blocks);
-        hipLaunchKernelGGL((edge_fwd16_kernel<H, A, F - 32>), dim3(blocks), dim3(64 * kFwd16Waves), 0, s, lw, g->row, g->col, edge_attr, x, P,
-                           g->rinv, E, chunk, basis, m, trans);
+        const int cap = edge_grid_cap(256 * occ);
+        blocks = blocks < 1 ? 1 : (blocks > cap ? cap : blocks);
+        if (W16::use_bf16(false, F - 32) && !edge_products_fp32())       // split-bf16 products (default) or fp32 (equigspr_set_edge_products)
+            hipLaunchKernelGGL((edge_fwd16_kernel<H, A, F - 32, true>), dim3(blocks), dim3(64 * kFwd16Waves), 0, s, lw, g->row, g->col, edge_attr, x, P,
+                               g->rinv, E, chunk, basis, m, trans);
+        else
+            hipLaunchKernelGGL((edge_fwd16_kernel<H, A, F - 32, false>), dim3(blocks), dim3(64 * kFwd16Waves), 0, s, lw, g->row, g->col, edge_attr, x, P,
+                               g->rinv, E, chunk, basis, m, trans);
     } else if constexpr (F % 16 == 0) {  // 16 / 48 / 64: the feature-parallel MFMA kernels (egnn_edge_fp.h)
         using L = FpLayout<F, H, A, false>;
         const size_t smem = edge_fwd_fp_smem<F, H, A>();

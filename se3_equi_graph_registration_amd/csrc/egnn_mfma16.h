@@ -329,6 +329,9 @@ __device__ __forceinline__ void mv16(const float* mat, int i, int g, const f32x4
 #ifndef EQ_BF_GUARD_NOPS
 #define EQ_BF_GUARD_NOPS 1             // x "s_nop 7" behind the group
 #endif
+#ifndef EQ_BF_GUARD_LOADS_FIRST
+#define EQ_BF_GUARD_LOADS_FIRST 1      // 1: no load is issued between the group's first and last matrix instruction (see mv16_bf)
+#endif
 #ifndef EQ_BF_GUARD_HALF
 #define EQ_BF_GUARD_HALF 1             // 1: one closed group per row block (three fragments alive at a time instead of six: no spills in the backward; 20.7 -> 19.1 us at one pair)
 #endif
@@ -341,6 +344,12 @@ __device__ __forceinline__ void mv16_bf(const float* frag, int lane, const f32x4
     for (int bo = 0; bo < 2; ++bo) {
         __builtin_amdgcn_sched_barrier(0);
         const bf16x8 ah = f[(0 * 2 + bo) * 64 + lane], am = f[(1 * 2 + bo) * 64 + lane], al = f[(2 * 2 + bo) * 64 + lane];
+#if EQ_BF_GUARD_LOADS_FIRST
+        // all three fragment reads are ISSUED before the first matrix instruction: without this the register allocator hands the
+        // third fragment the registers of the incoming accumulator (the C source of the first instruction, dead behind it) and the
+        // ds_read lands there three wait states behind the instruction (tools/isa_lint.py: 24 such pairs in the round-5 backward)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, vh, acc[bo], 0, 0, 0);        // smallest terms first
         acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, vl, acc[bo], 0, 0, 0);
         acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, vm, acc[bo], 0, 0, 0);

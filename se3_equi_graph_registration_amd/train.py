@@ -254,6 +254,8 @@ class GraphedStep:
         self._n_global = None              # ... and the global batch size its loss weight was computed for
         self._voted = False                # data parallel: a first batch has been accepted by all ranks
         self._capture_tried = False
+        self._shape_step_done = False      # an eager step of the static shape has run (its cached index arrays exist: capture can adopt them)
+        self._capture_votes = 0            # data parallel: steps at which the ranks voted on capturing (bounded: _capture_when_possible)
         self._last_idx = 0
         self.slots, self.graphs, self.graph_mode = [], None, "eager"
         self.steps_replayed = self.steps_eager = 0
@@ -269,6 +271,7 @@ class GraphedStep:
         scheduler needs no reset.)"""
         self.shape, self.slots, self.graphs, self.graph_mode = None, [], None, "eager"
         self._capture_tried, self._last_idx, self._n_global, self._voted = False, 0, None, False
+        self._shape_step_done, self._capture_votes = False, 0
 
     # ------------------------------------------------------------------ the step itself (eager or under capture)
     def _spare_words(self):
@@ -315,6 +318,7 @@ class GraphedStep:
         self._loss_weight = B / n_global if self.world > 1 else 1.0
         self._pad = self._spare_words() if self.dist_on else None
         self.graphs, self.graph_mode, self._capture_tried, self._last_idx = None, "eager", False, 0
+        self._shape_step_done = False
 
     def _capture(self):
         """Capture one copy of the step per slot (they share one memory pool: replays are sequential on one stream)."""
@@ -364,12 +368,34 @@ class GraphedStep:
                 return
         self.graphs, self.graph_mode = None, "eager"
 
+    def _capture_when_possible(self):
+        """Called by EVERY rank after EVERY step of a run until the graphs exist (or capture has been tried and given up).
+        One process: capture right after the first eager step of the static shape.  Data parallel: `_capture` contains collectives (the
+        per-mode vote, the captured-collective probe), so the decision to enter it is itself collective -- a MIN over 'this rank has run
+        an eager step of its static shape': a rank whose shard of the first batch was empty (a global batch smaller than the world;
+        ADVICE round 5) has nothing to capture yet, and its peers wait with theirs until it has; they all capture behind the same
+        later step.  (Before: the ranks with data entered `_capture` alone and their vote paired with the next step's all-reduce.)"""
+        if not self.use_graphs or self.graphs is not None or self._capture_tried:
+            return
+        ready = self.shape is not None and self._shape_step_done
+        if self.dist_on:
+            ready = _all_ranks_have(ready, self.group, self.device)
+            self._capture_votes += 1
+            if not ready and self._capture_votes >= 8:      # some rank never gets a batch of a static shape: stay eager, stop asking
+                self._capture_tried = True                  # (every rank counts the same votes: the same decision everywhere)
+        if not ready:
+            return
+        self._capture_tried = True
+        self.stream.synchronize()
+        self._capture()
+
     # ------------------------------------------------------------------ one step
     def _launch(self, idx):
         sl = self.slots[idx]
         if self.graphs is None:
             self._body(sl)
             self.steps_eager += 1
+            self._shape_step_done = True
         else:
             g = self.graphs[idx]
             g[0].replay()
@@ -531,10 +557,7 @@ class GraphedStep:
             self.slots[idx].last_call = self._calls
             self._last_idx = idx
             self._call_batch.append(batch_idx)
-            if self.graphs is None and self.use_graphs and not self._capture_tried:
-                self._capture_tried = True
-                self.stream.synchronize()
-                self._capture()            # the eager step above created the cached index arrays the capture adopts
+            self._capture_when_possible()  # the eager step above created the cached index arrays the capture adopts
             log_point(batch_idx)
 
         def log_point(batch_idx):
@@ -577,6 +600,7 @@ class GraphedStep:
                         self._eager_empty(void=payload is not _EMPTY_SHARD)
                         self._calls += 1
                         self._call_batch.append(batch_idx)
+                        self._capture_when_possible()
                         log_point(batch_idx)
                         continue
                     if not have:
@@ -591,6 +615,7 @@ class GraphedStep:
                             self._calls += 1
                             sl.last_call = self._calls
                             self._call_batch.append(batch_idx)
+                            self._capture_when_possible()
                         continue
                     self.opt._push_hyperparameters()
                     packed = isinstance(payload, _Slot)
@@ -628,6 +653,7 @@ class GraphedStep:
                             self._eager_other_shape(payload, n_global)
                         self._calls += 1
                         self._call_batch.append(batch_idx)
+                        self._capture_when_possible()
                         log_point(batch_idx)
                 launch_staged()
         finally:

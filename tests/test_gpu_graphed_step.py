@@ -238,6 +238,10 @@ if sys.argv[2] == "tails":
     # short last batches (DataLoader's drop_last=False): 3 pairs -> shards of 2 and 1 (rank 0's LOCAL shape equals the captured one, its
     # loss weight does not: 2 * 2 / 3 instead of 1), then 1 pair -> rank 1's shard is EMPTY (zero gradients, still in the collective)
     lost = seq[:4] + [tuple(t[:3] for t in seq[4]), tuple(t[:1] for t in seq[5])]
+elif sys.argv[2] == "small_first":
+    # the FIRST accepted batch has fewer pairs than ranks (ADVICE round 5: batch_size 1 on 2 ranks): rank 1's shard of it is empty, so
+    # rank 1 has nothing to capture behind that step -- the capture (its votes are collectives) must wait until every rank can
+    lost = [tuple(t[:1] for t in seq[0])] + seq[1:5] + [tuple(t[:1] for t in seq[5])]
 else:
     bad = list(seq[2]); bad[6] = bad[6].clone(); bad[6][3, :3, :3] = float("nan")      # a non-finite pair in rank 1's shard only
     seq[2] = tuple(bad)
@@ -300,6 +304,24 @@ def test_two_ranks_short_last_batches_uneven_and_empty_shards(pk):
         assert r["steps"] == [6.0, 6.0], r
         assert r["stats"]["applied"] == 6 and r["stats"]["skipped"] == 0 and r["stats"]["void"] == 0, r
         assert r["replayed"] == 3, r                             # batches 2-4; the first and the two tails run eagerly
+    assert outs[0]["loss"][0] == pytest.approx(outs[0]["loss"][1], rel=1e-5) and outs[0]["loss"] == outs[1]["loss"]
+
+
+def test_two_ranks_first_batch_smaller_than_the_world(pk):
+    """the first accepted batch holds ONE pair for two ranks.  Rank 0 runs it eagerly and would capture behind
+    it; rank 1's shard is empty (zero gradients, the step's one all-reduce) and cannot.  The decision to capture is collective
+    (`GraphedStep._capture_when_possible`): both ranks capture behind the second step, replay batches 3-5, and end with the eager
+    sharded loop's weights, bit for bit -- no deadlock, no collective paired with the wrong one."""
+    outs = _two_ranks("small_first", "29659")
+    for r in outs:
+        assert r["ranks_equal"], r
+        assert r["graphed_equals_eager"], r
+        assert r["steps"] == [6.0, 6.0], r
+        assert r["stats"]["applied"] == 6 and r["stats"]["skipped"] == 0 and r["stats"]["void"] == 0, r
+        assert r["mode"] == "two graphs + eager all-reduce", r
+    # one object, one static shape -- the first it sees: rank 0's is the one-pair shard of batch 1 (it replays the one-pair tail only, the
+    # two-pair shards run eagerly); rank 1's is the two-pair shard of batch 2 (batches 3-5 replayed, its empty tail shard eager)
+    assert outs[0]["replayed"] == 1 and outs[1]["replayed"] == 3, outs
     assert outs[0]["loss"][0] == pytest.approx(outs[0]["loss"][1], rel=1e-5) and outs[0]["loss"] == outs[1]["loss"]
 
 

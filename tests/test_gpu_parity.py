@@ -1560,3 +1560,48 @@ def test_edge_kernels_are_reproducible_when_waves_run_many_units(pk):
     sl = slice(100, 4800)                                    # away from the ring's closing edge
     for u, v in zip(a[:4], c[:4]):
         assert float((u[sl] - v[sl]).abs().max()) <= 2e-5 * max(1.0, float(v[sl].abs().max()))
+
+
+@pytest.mark.parametrize("feat", [32, 33])
+@pytest.mark.parametrize("n,caps", [(3000, (1, 8, 0)), (40000, (8, 0))])
+def test_split_products_match_fp32_products_tile_by_tile(pk, feat, n, caps):
+    """The split-bf16 products against the SAME kernels on fp32 products (equigspr_set_edge_products, ABI 14), tile by tile: a ring graph
+    whose node k owns the 16-edge tile k, so one wrong tile (the round-5 hazard lost a split level of 1-6 tiles in 3 000: ~1e-2 of the
+    tile's values) shows at nodes k / k + 1.  Workgroup caps (equigspr_set_edge_grid_cap) 1 / 8 put up to ~90 units on every wave with
+    two waves per SIMD -- the regime the defect needed; every run must also be bit-identical to the first."""
+    from se3_equi_graph_registration_amd import _lib
+    L = _lib.lib()
+
+    def run(fp32, cap):
+        _lib.check(L.equigspr_set_edge_products(1 if fp32 else 0), "set_edge_products")
+        _lib.check(L.equigspr_set_edge_grid_cap(cap), "set_edge_grid_cap")
+        torch.manual_seed(2)
+        m = pk.EGNN(feat, feat, feat, in_edge_nf=1, device="cuda", n_layers=1, num_heads=1)
+        g = torch.Generator().manual_seed(5)
+        h = torch.randn(n, feat, generator=g).cuda()
+        x = (torch.rand(n, 3, generator=g) * 2).cuda()
+        row = torch.arange(n).repeat_interleave(16)
+        col = (row + 1) % n
+        ea = torch.rand(row.numel(), 1, generator=g).cuda()
+        gh, gx = torch.randn(n, feat, generator=g).cuda(), torch.randn(n, 3, generator=g).cuda()
+        hc, xc = h.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ho, xo = m(hc, xc, [row.cuda(), col.cuda()], ea)
+        m.zero_grad()
+        ((ho * gh).sum() + (xo * gx).sum()).backward()
+        return ho.detach(), xo.detach(), hc.grad, xc.grad, m.flat_grads.clone()
+
+    try:
+        ref = run(True, 0)
+        assert all(torch.equal(u, v) for u, v in zip(ref, run(True, 0)))
+        for cap in caps:
+            first = run(False, cap)
+            for name, u, v in zip(("h_out", "x_out", "grad_h", "grad_x"), first[:4], ref[:4]):
+                d = (u - v).abs().reshape(n, -1).max(dim=1).values / v.abs().max()
+                assert float(d.max()) <= 2e-5, (name, cap, int((d > 2e-5).sum()), float(d.max()))
+            assert float((first[4] - ref[4]).abs().max()) <= 2e-5 * float(ref[4].abs().max()), cap
+            for _ in range(2):
+                again = run(False, cap)
+                assert all(torch.equal(u, v) for u, v in zip(first, again)), cap
+    finally:
+        L.equigspr_set_edge_products(0)
+        L.equigspr_set_edge_grid_cap(0)

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 16 and "equigspr_egnn_forward" in names and "equigspr_knn_graph" in names
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.equigspr_abi_version() == 13
+    assert lib.equigspr_abi_version() == 14
     # every declared symbol has a ctypes signature (no compute call is made here)
     assert set(names) == set(_lib._SIGNATURES.keys())
 
