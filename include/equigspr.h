@@ -107,7 +107,9 @@ int64_t equigspr_egnn_layer_offset(const equigspr_egnn_config* cfg, int32_t laye
  *              it turns the index fill into a plain scatter: the returning atomics (the slow part of the fill: scattered
  *              returning atomics run at ~25 G/s chip-wide) are issued here, under the search's arithmetic.
  * Distance contract: d2 = fl(fl(fl(dx*dx)+fl(dy*dy))+fl(dz*dz)), ties by lower index.
- * Limits: 1 <= k <= 64, k <= n (k <= n-1 when loop==0), n <= 8192. */
+ * Limits: 1 <= k <= n (k <= n-1 when loop==0); n_clouds*n*k < 2^31.  k <= 64 and n <= 8192 run on the tuned kernels (a wave per
+ * query up to 2 048 points, LDS candidate tiles above); larger k or n (torch_cluster accepts any: src/gcnn.py:31) take a streaming
+ * kernel with the same output order (ABI 14; O(k n) distance evaluations per query). */
 int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, int32_t k, int32_t loop,
                        int64_t* edges_i64, int32_t* row32, int32_t* col32, int32_t* row_hist, int32_t* arrival,
                        int32_t force_slow_path, void* stream);

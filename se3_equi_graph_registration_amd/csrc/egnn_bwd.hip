@@ -766,7 +766,9 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
     using SB = Slabs<F>;
     constexpr int NW = bwd16_waves(kB);
     constexpr int kScratch = C::bwd_size > SB::edge ? C::bwd_size : SB::edge;      // reused for the waves' slab copies
-    __shared__ __attribute__((aligned(16))) float wsm_[kBf ? W16::image_size(true, kB) : W16::image_size_fp32(true, kB)];
+    constexpr bool kSl = W16::slim(true, kB, kBf);                       // hidden_nf 33 on split products: no fp32 images of the 32 x 32 matrices
+    constexpr int o_vec = W16::vec(kSl), o_wgt = W16::wgt(kSl);
+    __shared__ __attribute__((aligned(16))) float wsm_[W16::image_floats(true, kB, kBf)];
     __shared__ __attribute__((aligned(16))) float scratch[NW][kScratch];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
     EQ_STAMP(0);
@@ -775,11 +777,14 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
     // read-modified-written once per tile (a lane only ever touches its own slots: fixed order) -- 16 registers less to spill
     constexpr bool kLdsB = (kB == 1) && (EQ_BWD33_LDS_BORDER != 0);
     auto ladd = [](float* p_, float v_) { *p_ += v_; };      // plain read-modify-write of the lane's own slot (ds_add_f32 runs a lane at a time: 597 vs 326 us)
-    __shared__ float bsl_[kLdsB ? NW * 16 * 64 : 1];
-    float* bsl = bsl_ + (kLdsB ? wv * 16 * 64 + lane : 0);      // slot k at bsl[64 k]
+    // (slim image, i.e. split products: 14 slots -- dgamma / dbeta of the border feature stay in two registers; the 4 KB make the room
+    // the fragments still lacked: 162 528 bytes of LDS either way)
+    constexpr int kSlots = kSl ? 14 : 16;
+    __shared__ float bsl_[kLdsB ? NW * kSlots * 64 : 1];
+    float* bsl = bsl_ + (kLdsB ? wv * kSlots * 64 + lane : 0);      // slot k at bsl[64 k]
     if constexpr (kLdsB) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) bsl[64 * k] = 0.0f;
+        for (int k = 0; k < kSlots; ++k) bsl[64 * k] = 0.0f;
     }
     int* idx_r = reinterpret_cast<int*>(sc + C::o_r);
     int* idx_c = reinterpret_cast<int*>(sc + C::o_c);
@@ -828,7 +833,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
     // start-up order as in the forward kernel: first indices, then the weight image's loads, the first unit's coordinate gathers,
     // and only then the image's LDS stores + the barrier
     int r = row[e], c = col[e];
-    StageW16<H, A, true, 64 * NW, kB> stage;
+    StageW16<H, A, true, 64 * NW, kB, kSl> stage;
     stage.load(lw);
     float xr0[3], xc0[3], gx0[3];
 #pragma unroll
@@ -842,7 +847,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
         int off = 0;
         asm volatile("" : "+v"(off));
         const float* wsm = wsm_ + off;
-        const float* bord = wsm + W16::border_base(true);
+        const float* bord = wsm + W16::border_at(true, kSl);
         const int t0 = strided ? ch : ch * tpc;        // first tile of the unit
         const int n_sub = strided ? min(4, (n_tiles - t0 + ts - 1) / ts) : min(tpc, n_tiles - t0);
         const bool mine = lane_live(edge_id(ch));
@@ -911,7 +916,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             float dqb = 0.0f;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const f32x4 w7ds = lds4(wsm + W16::o_vec + 4 * 32 + 16 * b + 4 * g) * splat4(ds);
+                const f32x4 w7ds = lds4(wsm + o_vec + 4 * 32 + 16 * b + 4 * g) * splat4(ds);
                 ls_w7[b] = fma4(o.q[b] * o.sgq[b], splat4(ds), ls_w7[b]);
                 dq[b] = w7ds * silu_grad4(o.q[b], o.sgq[b]);
                 if (kRun) ls_b6[b] += dq[b];
@@ -954,12 +959,12 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
                 for (int b = 0; b < 2; ++b) {
                     ls_gam[b] = fma4(dm[b], o.xhat[b], ls_gam[b]);
                     ls_bet[b] += dm[b];
-                    du[b] = dm[b] * lds4(wsm + W16::o_vec + 1 * 32 + 16 * b + 4 * g);
+                    du[b] = dm[b] * lds4(wsm + o_vec + 1 * 32 + 16 * b + 4 * g);
                 }
                 float m1 = hsum8(du[0], du[1]), m2 = hsum4(fma4(du[1], o.xhat[1], du[0] * o.xhat[0]));
                 gsum2(m1, m2);
                 if constexpr (kB == 1) {
-                    if constexpr (kLdsB) { ladd(bsl + 64 * 14, dmb * o.xhatb); ladd(bsl + 64 * 15, dmb); }
+                    if constexpr (kLdsB && kSlots == 16) { ladd(bsl + 64 * 14, dmb * o.xhatb); ladd(bsl + 64 * 15, dmb); }
                     else { lsb_gam = fmaf(dmb, o.xhatb, lsb_gam); lsb_bet += dmb; }
                     dub = dmb * bord[W16::b_sc + 3];
                     m1 += dub;
@@ -1020,7 +1025,7 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             f32x4 dg = splat4(0.0f);
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const f32x4 a = lds4(wsm + W16::o_wgt + i * W16::WS + 16 * b + 4 * g);
+                const f32x4 a = lds4(wsm + o_wgt + i * W16::WS + 16 * b + 4 * g);
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) dg = mfma16(a[rq], dt1[b][rq], dg);
             }
@@ -1067,7 +1072,8 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
         pb6.bcol[0] = bsl[64 * 0]; pb6.bcol[1] = bsl[64 * 1]; pb6.brow[0] = bsl[64 * 2]; pb6.brow[1] = bsl[64 * 3]; pb6.corner = bsl[64 * 4]; pb6.xbs = bsl[64 * 5];
         pb2.bcol[0] = bsl[64 * 6]; pb2.bcol[1] = bsl[64 * 7]; pb2.brow[0] = bsl[64 * 8]; pb2.brow[1] = bsl[64 * 9]; pb2.corner = bsl[64 * 10]; pb2.xbs = bsl[64 * 11];
         pbg.brow[0] = bsl[64 * 12];
-        lsb_w7 = bsl[64 * 13]; lsb_gam = bsl[64 * 14]; lsb_bet = bsl[64 * 15];
+        lsb_w7 = bsl[64 * 13];
+        if constexpr (kSlots == 16) { lsb_gam = bsl[64 * 14]; lsb_bet = bsl[64 * 15]; }
     }
     // ---- partial sums of the waves: every wave writes a slab copy into its scratch, all threads add the copies in fixed order
     auto lane16_sum = [](float v) { return row16_sum(v); };      // over the 16 lanes (edges) of a group

@@ -192,13 +192,29 @@ struct W16 {
 #endif
     static constexpr int frag_base(bool bwd, int kB) { return (bwd ? bwd_size : fwd_size) + kB * border_size + ((bwd && kB == 1) ? 0 : EQ_FRAG_PAD); }
     static constexpr int f_w2 = 0, f_w6 = 1, f_w2t = 2, f_w6t = 3;
-    // (the hidden_nf 33 backward has no LDS left for them -- 187 KB with the fragments -- and keeps the fp32 products)
+    // (the hidden_nf 33 backward has no LDS for images + fragments -- 187 KB -- and takes the SLIM image below)
 // developer A/B: bit 0 = the forward kernel, bit 1 = the backward kernel (fragments by build_frags16 after the image's barrier)
 #ifndef EQ_BF16X3_KERNELS
 #define EQ_BF16X3_KERNELS 3
 #endif
-    static constexpr bool use_bf16(bool bwd, int kB) { return EQ_EDGE_BF16X3 != 0 && !(bwd && kB == 1) && ((EQ_BF16X3_KERNELS >> (bwd ? 1 : 0)) & 1); }
+#ifndef EQ_BWD33_BF16
+#define EQ_BWD33_BF16 1                // hidden_nf 33 backward on the split products (round 6: the SLIM image below makes the LDS room)
+#endif
+    static constexpr bool use_bf16(bool bwd, int kB) { return EQ_EDGE_BF16X3 != 0 && (EQ_BWD33_BF16 != 0 || !(bwd && kB == 1)) && ((EQ_BF16X3_KERNELS >> (bwd ? 1 : 0)) & 1); }
     static constexpr int image_size_fp32(bool bwd, int kB) { return frag_base(bwd, kB); }
+    // SLIM image (the hidden_nf 33 backward on split products: 162.5 KB of LDS with the fp32 images AND the fragments would be 187 KB):
+    // the four 32 x 32 fp32 images (W2, W6, their transposes: 20 KB) are not stored at all -- every product of them reads the bf16
+    // fragments, which StageW16 builds straight from global memory -- Wgeo | vectors | Wgeo^T | border | fragments remain.
+    static constexpr bool slim(bool bwd, int kB, bool bf) { return bwd && kB == 1 && bf && use_bf16(bwd, kB); }
+    static constexpr int wg(bool sl) { return sl ? 0 : o_wg; }
+    static constexpr int vec(bool sl) { return sl ? 32 * GS : o_vec; }
+    static constexpr int wgt(bool sl) { return sl ? 32 * GS + 5 * 32 : o_wgt; }
+    static constexpr int slim_size = 32 * GS + 5 * 32 + 16 * WS;
+    static constexpr int border_at(bool bwd, bool sl) { return sl ? slim_size : border_base(bwd); }
+    static constexpr int frag_at(bool bwd, int kB, bool sl) { return sl ? slim_size + border_size : frag_base(bwd, kB); }
+    static constexpr int image_floats(bool bwd, int kB, bool bf) {
+        return slim(bwd, kB, bf) ? slim_size + border_size + 4 * frag_floats : (bf && use_bf16(bwd, kB) ? image_size(bwd, kB) : image_size_fp32(bwd, kB));
+    }
 #ifndef EQ_FRAG_TAIL
 #define EQ_FRAG_TAIL 0                 // developer: floats of unused LDS behind the fragments
 #endif
@@ -215,8 +231,10 @@ struct StageW16 {
     using LL = LP<F, H, A>;
     static constexpr int FH = F / H;
     static constexpr int PER = 1024 / NT, PG = (512 + NT - 1) / NT;
+    static constexpr bool kSlim = W16::slim(kBwd, kB, kFrag);       // no fp32 images of the 32 x 32 matrices: fragments only
+    static_assert(!kSlim || NT >= 256, "the slim image's transposed fragments are fetched by threads 128..255");
     float v2[PER], v6[PER], vg[PG], vv, vb;
-    f32x4 f2[2], f6[2];          // kFrag: threads 0..127 also fetch the eight W2 / W6 weights of their (row block, lane) fragment
+    f32x4 f2[2], f6[2];          // kFrag: threads 0..127 also fetch the eight W2 / W6 weights of their (row block, lane) fragment (slim: 128..255 those of W2^T / W6^T)
     __device__ __forceinline__ void load(const float* __restrict__ lw) {
         if constexpr (kFrag) {
             if (threadIdx.x < 128) {
@@ -227,10 +245,19 @@ struct StageW16 {
                     f2[j >> 2][j & 3] = (ii / FH == k / FH) ? lw[LL::w2_off(ii, k)] : 0.0f;
                     f6[j >> 2][j & 3] = lw[LL::w6 + ii * F + k];
                 }
+            } else if (kSlim && threadIdx.x < 256) {      // (W^T)[ii][k] = W[k][ii]: 16 strided 4-byte reads of L2-resident weights, once per workgroup
+                const int tt = threadIdx.x - 128, bo = tt >> 6, l = tt & 63, ii = 16 * bo + (l & 15), gg = l >> 4;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * (j >> 2) + 4 * gg + (j & 3);
+                    f2[j >> 2][j & 3] = (ii / FH == k / FH) ? lw[LL::w2_off(k, ii)] : 0.0f;
+                    f6[j >> 2][j & 3] = lw[LL::w6 + k * F + ii];
+                }
             }
         }
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
+            if constexpr (kSlim) break;
             const int t = threadIdx.x + NT * u, i = t >> 5, k = t & 31;
             v2[u] = (i / FH == k / FH) ? lw[LL::w2_off(i, k)] : 0.0f;      // block-diagonal over the heads
             v6[u] = lw[LL::w6 + i * F + k];
@@ -263,6 +290,7 @@ struct StageW16 {
     __device__ __forceinline__ void store(float* sm) const {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
+            if constexpr (kSlim) break;
             const int t = threadIdx.x + NT * u, i = t >> 5, k = t & 31;
             sm[W16::o_w2 + i * W16::WS + k] = v2[u];
             sm[W16::o_w6 + i * W16::WS + k] = v6[u];
@@ -275,18 +303,22 @@ struct StageW16 {
         for (int u = 0; u < PG; ++u) {
             const int t = threadIdx.x + NT * u, i = (t >> 4) & 31, k = t & 15;
             if (t < 512) {
-                sm[W16::o_wg + i * W16::GS + k] = vg[u];
-                if (kBwd) sm[W16::o_wgt + k * W16::WS + i] = vg[u];
+                sm[W16::wg(kSlim) + i * W16::GS + k] = vg[u];
+                if (kBwd) sm[W16::wgt(kSlim) + k * W16::WS + i] = vg[u];
             }
         }
-        if (threadIdx.x < 160) sm[W16::o_vec + threadIdx.x] = vv;
-        if (kB && threadIdx.x < W16::border_size) sm[W16::border_base(kBwd) + threadIdx.x] = vb;
+        if (threadIdx.x < 160) sm[W16::vec(kSlim) + threadIdx.x] = vv;
+        if (kB && threadIdx.x < W16::border_size) sm[W16::border_at(kBwd, kSlim) + threadIdx.x] = vb;
         if constexpr (kFrag) {
+            float* fb = sm + W16::frag_at(kBwd, kB, kSlim);
             if (threadIdx.x < 128) {
                 const int bo = threadIdx.x >> 6, l = threadIdx.x & 63;
-                float* fb = sm + W16::frag_base(kBwd, kB);
                 frag_store(f2, fb + W16::f_w2 * W16::frag_floats, bo, l);
                 frag_store(f6, fb + W16::f_w6 * W16::frag_floats, bo, l);
+            } else if (kSlim && threadIdx.x < 256) {
+                const int tt = threadIdx.x - 128, bo = tt >> 6, l = tt & 63;
+                frag_store(f2, fb + W16::f_w2t * W16::frag_floats, bo, l);
+                frag_store(f6, fb + W16::f_w6t * W16::frag_floats, bo, l);
             }
         }
     }
@@ -396,7 +428,7 @@ __device__ __forceinline__ void build_frag16(const float* mat, float* frag, int 
 // after the fp32 image is complete (and a workgroup barrier): the split fragments of its 32 x 32 matrices; followed by another barrier
 template <bool kBwd, int kB, bool kBf = true>
 __device__ __forceinline__ void build_frags16(float* sm) {
-    if constexpr (kBf && W16::use_bf16(kBwd, kB)) {
+    if constexpr (kBf && W16::use_bf16(kBwd, kB) && !W16::slim(kBwd, kB, kBf)) {      // (slim image: StageW16 wrote the fragments)
     float* fb = sm + W16::frag_base(kBwd, kB);
     const int t = threadIdx.x;
     if (t < 128) {
@@ -415,8 +447,9 @@ __device__ __forceinline__ void mv16_edge(const float* wsm, int which, int i, in
 #ifndef EQ_BF16X3_WHICH
 #define EQ_BF16X3_WHICH 15
 #endif
+    static_assert(!W16::slim(kBwd, kB, kBf) || EQ_BF16X3_WHICH == 15, "the slim image has no fp32 matrices to fall back to");
     if (kBf && W16::use_bf16(kBwd, kB) && ((EQ_BF16X3_WHICH >> which) & 1))
-        mv16_bf(wsm + W16::frag_base(kBwd, kB) + which * W16::frag_floats, 16 * g + i, v, acc);
+        mv16_bf(wsm + W16::frag_at(kBwd, kB, W16::slim(kBwd, kB, kBf)) + which * W16::frag_floats, 16 * g + i, v, acc);
     else
         mv16(wsm + (which == W16::f_w2 ? W16::o_w2 : which == W16::f_w6 ? W16::o_w6 : which == W16::f_w2t ? W16::o_w2t : W16::o_w6t), i, g, v, acc);
 }
@@ -468,13 +501,15 @@ template <int kB, bool kBwdImg = false, bool kBf = true>
 __device__ __forceinline__ void tile_forward16(const float* wsm, const float* bord, const float* geo_row, const PRowsT<kB>& pw, int i,
                                                int g, Sub16& o) {
     constexpr float kInvF = 1.0f / (32 + kB);
+    constexpr bool kSl = W16::slim(kBwdImg, kB, kBf);
+    constexpr int o_wg = W16::wg(kSl), o_vec = W16::vec(kSl);
     f32x4 acc[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[b] = pw.pr[b] + pw.pc[b];
     o.t1b = 0.0f; o.sg1b = 0.0f; o.xhatb = 0.0f; o.mb = 0.0f; o.qb = 0.0f; o.sgqb = 0.0f;
     {   // + Wgeo [geo | attr]: K = 16, step s <-> geometry entry 4 g + s
         const f32x4 gv = lds4(geo_row + 4 * g);
-        const f32x4 a0 = lds4(wsm + W16::o_wg + i * W16::GS + 4 * g), a1 = lds4(wsm + W16::o_wg + (16 + i) * W16::GS + 4 * g);
+        const f32x4 a0 = lds4(wsm + o_wg + i * W16::GS + 4 * g), a1 = lds4(wsm + o_wg + (16 + i) * W16::GS + 4 * g);
         EQ_STAMP(4);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -489,7 +524,7 @@ __device__ __forceinline__ void tile_forward16(const float* wsm, const float* bo
         o.t1[b] = acc[b];
         o.sg1[b] = sigmoid4(acc[b]);
         a1v[b] = acc[b] * o.sg1[b];                                    // SiLU (:245)
-        u[b] = lds4(wsm + W16::o_vec + 0 * 32 + 16 * b + 4 * g);       // b2
+        u[b] = lds4(wsm + o_vec + 0 * 32 + 16 * b + 4 * g);       // b2
     }
     EQ_STAMP(5);
     mv16_edge<kBwdImg, kB, kBf>(wsm, W16::f_w2, i, g, a1v, u);
@@ -510,9 +545,9 @@ __device__ __forceinline__ void tile_forward16(const float* wsm, const float* bo
     o.xhat[1] = c1 * splat4(o.rstd);
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const f32x4 gam = lds4(wsm + W16::o_vec + 1 * 32 + 16 * b + 4 * g), bet = lds4(wsm + W16::o_vec + 2 * 32 + 16 * b + 4 * g);
+        const f32x4 gam = lds4(wsm + o_vec + 1 * 32 + 16 * b + 4 * g), bet = lds4(wsm + o_vec + 2 * 32 + 16 * b + 4 * g);
         o.m[b] = fma4(o.xhat[b], gam, bet);
-        o.q[b] = lds4(wsm + W16::o_vec + 3 * 32 + 16 * b + 4 * g);     // b6
+        o.q[b] = lds4(wsm + o_vec + 3 * 32 + 16 * b + 4 * g);     // b6
     }
     EQ_STAMP(7);
     mv16_edge<kBwdImg, kB, kBf>(wsm, W16::f_w6, i, g, o.m, o.q);
@@ -525,7 +560,7 @@ __device__ __forceinline__ void tile_forward16(const float* wsm, const float* bo
     {
         o.sgq[0] = sigmoid4(o.q[0]);
         o.sgq[1] = sigmoid4(o.q[1]);
-        const f32x4 w70 = lds4(wsm + W16::o_vec + 4 * 32 + 4 * g), w71 = lds4(wsm + W16::o_vec + 4 * 32 + 16 + 4 * g);
+        const f32x4 w70 = lds4(wsm + o_vec + 4 * 32 + 4 * g), w71 = lds4(wsm + o_vec + 4 * 32 + 16 + 4 * g);
         o.s = gsum(hsum4(fma4(w71, o.q[1] * o.sgq[1], w70 * (o.q[0] * o.sgq[0]))));
     }
     if constexpr (kB == 1) {

@@ -578,6 +578,53 @@ __global__ void edges_i64_to_i32_kernel(const long long* __restrict__ edges, int
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// General form (k > 64 or n > 8 192: the sizes torch_cluster.knn_graph accepts and the kernels above do not): a wave per query,
+// the cloud streamed from global memory (L2) once per output slot -- round t extracts the smallest (d2, index) key strictly greater
+// than round t - 1's, so the output is the same (d2, index)-lexicographic order, bit for bit, for any k <= n and any n.  O(k n)
+// distance evaluations per query: a compatibility path (k = 100 over 2 048 points: ~0.2 G evaluations per cloud), not a tuned one.
+// ---------------------------------------------------------------------------------------
+template <bool kLoop>
+__global__ __launch_bounds__(64) void knn_stream_kernel(const float* __restrict__ x, int n_clouds, int n, int k,
+                                                        long long* __restrict__ edges, int* __restrict__ row32, int* __restrict__ col32,
+                                                        int* __restrict__ row_hist, int* __restrict__ arrival) {
+    const int lane = threadIdx.x;
+    const long long qg = blockIdx.x;
+    const int cloud = (int)(qg / n);
+    const int q = (int)(qg - (long long)cloud * n);
+    const float* __restrict__ xc = x + (size_t)cloud * n * 3;
+    const float qx = xc[q * 3 + 0], qy = xc[q * 3 + 1], qz = xc[q * 3 + 2];
+    const size_t epc = (size_t)n * k;
+    u64 last = 0;
+    bool have_last = false;
+    for (int t = 0; t < k; ++t) {
+        u64 best = ~0ull;
+        for (int j = lane; j < n; j += 64) {
+            if (!kLoop && j == q) continue;
+            const u64 key = pack_key(dist2_scalar(xc[j * 3 + 0], xc[j * 3 + 1], xc[j * 3 + 2], qx, qy, qz), j);
+            const bool ok = !have_last || key > last;
+            best = (ok && key < best) ? key : best;
+        }
+        best = wave_min_u64(best);
+        last = best;
+        have_last = true;
+        if (lane == 0) {
+            const int idx = (int)(unsigned)(best & 0xffffffffu);
+            const size_t e = (size_t)q * k + t;
+            if (edges) {
+                edges[(size_t)cloud * 2 * epc + e] = idx;
+                edges[(size_t)cloud * 2 * epc + epc + e] = q;
+            }
+            if (row32) row32[(size_t)cloud * epc + e] = cloud * n + idx;
+            if (col32) col32[(size_t)cloud * epc + e] = cloud * n + q;
+            if (row_hist) {
+                const int slot_in_row = atomicAdd(&row_hist[cloud * n + idx], 1);
+                if (arrival) arrival[(size_t)cloud * epc + e] = slot_in_row;
+            }
+        }
+    }
+}
+
 }  // namespace eq
 
 #ifndef EQ_KNN_PER_QUERY_MAX
@@ -589,14 +636,20 @@ extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, i
     using namespace eq;
     EQ_CHECK_ARG(x != nullptr, EQUIGSPR_EINVAL, "knn_graph: x is null");
     EQ_CHECK_ARG(n_clouds >= 1 && n >= 1, EQUIGSPR_EINVAL, "knn_graph: need n_clouds>=1, n>=1");
-    EQ_CHECK_ARG(n <= 8192, EQUIGSPR_ENOTSUP, "knn_graph: n=%d > 8192 points per cloud", n);
-    EQ_CHECK_ARG(k >= 1 && k <= 64, EQUIGSPR_ENOTSUP, "knn_graph: k=%d outside [1,64]", k);
+    EQ_CHECK_ARG(k >= 1, EQUIGSPR_EINVAL, "knn_graph: k=%d < 1", k);
+    EQ_CHECK_ARG((long long)n_clouds * n < (1ll << 31), EQUIGSPR_EINVAL, "knn_graph: node count overflows int32");
     EQ_CHECK_ARG(k <= (loop ? n : n - 1), EQUIGSPR_EINVAL, "knn_graph: k=%d exceeds candidates (n=%d, loop=%d)", k, n, loop);
     EQ_CHECK_ARG((long long)n_clouds * n * k < (1ll << 31), EQUIGSPR_EINVAL, "knn_graph: edge count overflows int32");
     EQ_CHECK_ARG(!arrival || row_hist, EQUIGSPR_EINVAL, "knn_graph: arrival needs row_hist");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(n_clouds * n), block(64);
     long long* e64 = reinterpret_cast<long long*>(edges_i64);
+    if (k > 64 || n > 8192) {      // beyond the tuned kernels' register / LDS plans: the streaming form (same order, any k <= n, any n)
+        if (loop) hipLaunchKernelGGL(knn_stream_kernel<true>, grid, block, 0, s, x, n_clouds, n, k, e64, row32, col32, row_hist, arrival);
+        else hipLaunchKernelGGL(knn_stream_kernel<false>, grid, block, 0, s, x, n_clouds, n, k, e64, row32, col32, row_hist, arrival);
+        EQ_CHECK_LAUNCH("knn_stream_kernel");
+        return 0;
+    }
 #define EQ_KNN_LAUNCH(NPL, LOOP, FULL) \
     hipLaunchKernelGGL((knn_kernel<NPL, LOOP, FULL>), grid, block, 0, s, x, n_clouds, n, k, e64, row32, col32, row_hist, arrival, force_slow_path)
 #define EQ_KNN_PICK(NPL) \

@@ -178,9 +178,15 @@ def captured_collectives_work(group, device, numel: int = 65536, timeout: float 
     if key in _PROBE_RESULT:
         return _PROBE_RESULT[key]
     rank = dist.get_rank(group)
-    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-    port = int(os.environ.get("MASTER_PORT", "29500")) + 101
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # where the probe children rendezvous: EQUIGSPR_PROBE_ADDR / EQUIGSPR_PROBE_PORT when given (a sub-group whose rank 0 does not sit on
+    # MASTER_ADDR, a taken port), else the job's MASTER_ADDR and MASTER_PORT + 101.  The children inherit this process's environment
+    # UNCHANGED (HSA_* / NCCL_* included: the probe must test the parent's transport, not a different one).
+    # The verdict is a HEURISTIC -- a bare all-reduce graph in a fresh process says "captured RCCL collectives replay on this stack",
+    # not that the full step graph will; the safety net at run time is GraphedStep's bounded progress wait (it raises) and the
+    # bench's watchdog child (it kills the rank), not this probe.
+    addr = os.environ.get("EQUIGSPR_PROBE_ADDR") or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("EQUIGSPR_PROBE_PORT") or int(os.environ.get("MASTER_PORT", "29500")) + 101)
+    env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
     ok = False

@@ -17,16 +17,35 @@ def knn_graph(x: torch.Tensor, k: int, batch=None, loop: bool = False, flow: str
               force_slow_path: bool = False) -> torch.Tensor:
     """``x [N,3]`` -> LongTensor ``[2, N*k]``: row 0 = neighbour, row 1 = centre, centre-major,
     ascending (distance, index).  NOTE torch_cluster's default is ``loop=False``; the reference
-    always passes ``loop=True``."""
-    if batch is not None:
-        raise NotImplementedError("knn_graph: pass one cloud per call (as the reference does) or use build_pair_graph")
+    always passes ``loop=True``.
+
+    ``batch`` (``src/gcnn.py:31`` passes it; train :1473-1474 calls the function on a whole batch): a sorted LongTensor ``[N]``
+    assigning every point to a cloud, neighbours are searched inside a point's own cloud only.  Clouds of EQUAL size are one
+    launch of the batched kernel (``ops.knn_graph_batched`` over ``[B, n, 3]``); ragged batches raise (the batched kernel's
+    clouds share one size -- split them, or pad the data set as the reference's loaders do)."""
     if flow != "source_to_target":
         raise NotImplementedError("knn_graph: only flow='source_to_target' (the reference default)")
     if x.dim() != 2 or x.shape[1] != 3:
         raise RuntimeError("knn_graph: x must be [N,3]")
-    e64, _, _ = ops.knn_graph_batched(x.contiguous().float().unsqueeze(0), k, loop, want_i64=True,
-                                      force_slow_path=force_slow_path)
-    return e64[0]
+    if batch is None:
+        e64, _, _ = ops.knn_graph_batched(x.contiguous().float().unsqueeze(0), k, loop, want_i64=True,
+                                          force_slow_path=force_slow_path)
+        return e64[0]
+    if batch.dim() != 1 or batch.numel() != x.shape[0]:
+        raise RuntimeError("knn_graph: batch must be a vector with one entry per point")
+    if x.shape[0] == 0:
+        return torch.empty(2, 0, dtype=torch.int64, device=x.device)
+    counts = torch.unique_consecutive(batch, return_counts=True)[1]
+    n = int(counts[0])
+    if bool((batch[1:] < batch[:-1]).any()):
+        raise RuntimeError("knn_graph: batch must be sorted (torch_cluster's contract)")
+    if bool((counts != n).any()):
+        raise NotImplementedError("knn_graph: clouds of different sizes in one batch (sizes "
+                                  f"{sorted(set(counts.tolist()))[:4]}...): call it per cloud, or use equal-sized clouds")
+    nb = int(counts.numel())
+    e64, _, _ = ops.knn_graph_batched(x.contiguous().float().view(nb, n, 3), k, loop, want_i64=True, force_slow_path=force_slow_path)
+    off = (torch.arange(nb, device=x.device, dtype=torch.int64) * n).view(nb, 1, 1)
+    return (e64 + off).permute(1, 0, 2).reshape(2, nb * n * k)
 
 
 def get_edges_from_idx(graph_idx):

@@ -221,6 +221,8 @@ class IrrepEGNN(FlatParamsMixin, nn.Module):
         self.to(device)
 
     def _flat_layout(self):
+        if getattr(self, "_layout_cache", None) is not None:          # the configuration is fixed at construction: 8 L ctypes calls once, not per forward
+            return self._layout_cache
         L = _lib.lib()
         cfg = ctypes.byref(self.cfg)
         offs = []
@@ -232,7 +234,8 @@ class IrrepEGNN(FlatParamsMixin, nn.Module):
         ps = self._ordered_params()
         if len(offs) != len(ps) or min(offs) < 0:
             raise RuntimeError("internal: IrrepEGNN parameters do not match the C-ABI block layout")
-        return offs, int(L.equigspr_irrep_gnn_param_count(cfg))
+        self._layout_cache = (offs, int(L.equigspr_irrep_gnn_param_count(cfg)))
+        return self._layout_cache
 
     def forward(self, h, x, edges, edge_attr=None):
         self._ensure_flat()
@@ -240,8 +243,11 @@ class IrrepEGNN(FlatParamsMixin, nn.Module):
             raise RuntimeError(f"IrrepEGNN.forward expects h [N, {self.in_node_nf}] and x [N, 3] (one cloud or a pre-batched graph)")
         h = _need(h.contiguous().float(), "h", torch.float32, 2)
         x = _need(x.contiguous().float(), "x", torch.float32, 2)
-        anchor = self.coord.weight
-        training = torch.is_grad_enabled() and (anchor.requires_grad or h.requires_grad or x.requires_grad)
+        # training = any parameter or input wants a gradient (a frozen `coord.weight` beside trainable layers used to
+        # switch the whole forward to inference); the autograd anchor is a parameter that requires grad, so that backward is called
+        wants = [p for p in self.parameters() if p.requires_grad]
+        anchor = wants[0] if wants else self.coord.weight
+        training = torch.is_grad_enabled() and (bool(wants) or h.requires_grad or x.requires_grad)
         graph = IrrepConv._graph(edges, h.shape[0], need_col_index=training)
         if training and graph.cptr is None:
             raise RuntimeError("IrrepEGNN.forward: training needs a DeviceGraph built with need_col_index=True")
