@@ -44,8 +44,8 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 # committed rocprofv3 evidence the line quotes (collected by tools/profile_round.sh -- counters and kernel traces need the profiler,
 # so they cannot be taken inside this run): newest first; a file counts only when it was collected on exactly this launch shape
-PMC_GLOBS = ("r05_*pmc_*.json", "r04_*pmc_*.json", "r03_v6_pmc_edge_kernels.json", "r03_v2_pmc_edge_kernels.json", "r03_v1_pmc_edge_kernels.json", "r02_pmc_edge_kernels.json")
-IN_STEP_GLOBS = ("r05_*in_step.json", "r04_*in_step.json")
+PMC_GLOBS = ("r06_*pmc_*.json", "r05_*pmc_*.json", "r04_*pmc_*.json", "r03_v6_pmc_edge_kernels.json", "r02_pmc_edge_kernels.json")
+IN_STEP_GLOBS = ("r06_*in_step.json", "r05_*in_step.json", "r04_*in_step.json")
 FP32_PEAK_TF = 157.3
 
 

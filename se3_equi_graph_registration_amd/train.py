@@ -107,9 +107,10 @@ def _pointnet_features(graph, xyz_0, xyz_1):
     return feats[:B * N].view(B, N, -1), feats[B * N:].view(B, N, -1)
 
 
-def _forward(model, batch, k, use_pointnet=False, loss_mode="3dmatch"):
+def _forward(model, batch, k, use_pointnet=False, loss_mode="3dmatch", graph=None):
     corr, labels, xyz_0, xyz_1, feat_0, feat_1, gt_pose = batch
-    graph = build_pair_graph(xyz_0, xyz_1, k, loop=True)        # knn_graph(xyz[i], k=16, loop=True) per cloud (:1005-1006)
+    if graph is None:                                           # (GraphedStep hands over a graph it built one step ahead)
+        graph = build_pair_graph(xyz_0, xyz_1, k, loop=True)    # knn_graph(xyz[i], k=16, loop=True) per cloud (:1005-1006)
     if use_pointnet:
         feat_0, feat_1 = _pointnet_features(graph, xyz_0, xyz_1)
     out = model(feat_0, xyz_0, graph, None, feat_1, xyz_1, graph, None, corr, labels, gt_pose)
@@ -233,7 +234,7 @@ class GraphedStep:
     Weights after n steps are bit-identical to the eager loop's (``tests/test_gpu_train.py``)."""
 
     def __init__(self, model, optimizer, k=16, loss_mode="3dmatch", slots=3, graph_collectives=True, use_graphs=True, depth=3,
-                 force_dist=False):
+                 force_dist=False, build_ahead=None):
         if not isinstance(optimizer, StepOptimizer):
             raise TypeError("GraphedStep needs the package's StepOptimizer (train.make_optimizer): the guarded flat Adam is part of the step")
         if loss_mode not in ("3dmatch", "kitti"):
@@ -246,6 +247,17 @@ class GraphedStep:
             raise RuntimeError("GraphedStep: the model must live on the MI355X (HIP) device; this package has no CPU path")
         self.stream = torch.cuda.Stream(self.device)
         self.copy_stream = torch.cuda.Stream(self.device)
+        # build_ahead (round 6): the k-NN graph + inverse index of a batch depend on nothing but its coordinates, and are 30 us of the
+        # 330 us one-pair step.  Each slot gets a SECOND captured graph holding only that build; it is replayed on `build_stream` as
+        # soon as the slot's H2D copy has landed -- one step ahead, beside the previous step's kernels -- and the step graph proper
+        # waits for an event recorded behind it (a wait on an already-signalled event of a compute stream costs the waiting stream
+        # 1-2 us on this stack, tools/dev/ahead_probe.py; an event on the COPY stream is what was expensive, so the hand-over from
+        # the copy to the build is a host-side synchronize, as before).  EQUIGSPR_BUILD_AHEAD=0 turns it off.
+        if build_ahead is None:
+            build_ahead = os.environ.get("EQUIGSPR_BUILD_AHEAD", "1") != "0"
+        self.build_ahead = bool(build_ahead) and use_graphs
+        self.build_stream = torch.cuda.Stream(self.device) if self.build_ahead else None
+        self.build_graphs, self._built = None, []      # per slot: the captured build, the event recorded behind its last replay
         self.rank, self.world, self.group = _process_group(optimizer)
         # force_dist: run the multi-rank code path (spare-word signalling, all-reduce inside / between the graphs) on a one-rank
         # group -- how the tests exercise it on a single GPU
@@ -270,6 +282,7 @@ class GraphedStep:
         process group.  (Weights, optimizer state and hyper-parameters are read at replay time: loading a checkpoint or stepping a
         scheduler needs no reset.)"""
         self.shape, self.slots, self.graphs, self.graph_mode = None, [], None, "eager"
+        self.build_graphs, self._built = None, []
         self._capture_tried, self._last_idx, self._n_global, self._voted = False, 0, None, False
         self._shape_step_done, self._capture_votes = False, 0
 
@@ -286,9 +299,9 @@ class GraphedStep:
             raise RuntimeError("GraphedStep: the joint gradient bucket has no spare words (dp.DataParallelStep leaves at least two)")
         return pad
 
-    def _forward_backward(self, slot, seed):
+    def _forward_backward(self, slot, seed, graph=None):
         batch = (None, slot.labels, slot.xyz[0], slot.xyz[1], slot.feat[0], slot.feat[1], slot.gt_pose)
-        loss = _forward(self.model, batch, self.k, False, self.loss_mode)[1]
+        loss = _forward(self.model, batch, self.k, False, self.loss_mode, graph=graph)[1]
         loss.backward(gradient=seed)
         if self.dist_on:
             # two spare words of the all-reduced message carry this rank's verdict to every rank's guard: [0] = loss * 0 (NaN for
@@ -300,8 +313,8 @@ class GraphedStep:
     def _apply(self, loss):
         self.opt.adam.step_guarded(loss=loss, extra=self._pad[:2] if self.dist_on else None)
 
-    def _body(self, slot):
-        loss = self._forward_backward(slot, self._seed)
+    def _body(self, slot, graph=None):
+        loss = self._forward_backward(slot, self._seed, graph=graph)
         if self.dist_on:
             self.opt.dp.sync(force=True)
         self._apply(loss)
@@ -338,19 +351,33 @@ class GraphedStep:
             (["one graph (all-reduce captured)"] if can_capture_collective else []) + ["two graphs + eager all-reduce"]
         for mode in modes:
             graphs, pool, ok = [], None, True
+            builds, bpool = [], None
             try:
                 for sl in self.slots:
                     ops.reserve_csr_scratch(self.device, n_words)
                     torch.cuda.synchronize(self.device)
+                    pair_graph = None
+                    if self.build_ahead:
+                        # the slot's graph build as a capture of its own, in a memory pool of its own: its replays run on another
+                        # stream BESIDE the step graphs' replays, so the two sets must not share recycled blocks (the build graphs
+                        # replay one after the other on one stream: they share theirs)
+                        gbuild = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gbuild, pool=bpool, stream=self.build_stream, capture_error_mode="thread_local"):
+                            pair_graph = build_pair_graph(sl.xyz[0], sl.xyz[1], self.k, loop=True)
+                        builds.append((gbuild, pair_graph))
+                        bpool = gbuild.pool()
+                        with torch.cuda.stream(self.build_stream):
+                            gbuild.replay()                        # the captured launches have not run: the step capture below reads nothing,
+                        self.build_stream.synchronize()            # but the first replay of the step must find a built graph
                     if mode.startswith("one"):
                         g = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                            self._body(sl)
+                            self._body(sl, graph=pair_graph)
                         graphs.append((g,))
                     else:
                         ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                         with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
-                            loss = self._forward_backward(sl, self._seed)
+                            loss = self._forward_backward(sl, self._seed, graph=pair_graph)
                         with torch.cuda.graph(gb, pool=ga.pool(), capture_error_mode="thread_local"):
                             self._apply(loss)
                         graphs.append((ga, gb))
@@ -365,8 +392,10 @@ class GraphedStep:
                 ok = _all_ranks_have(ok, self.group, self.device)
             if ok:
                 self.graphs, self.graph_mode = graphs, mode
+                self.build_graphs = builds if self.build_ahead else None
+                self._built = [None] * len(self.slots)
                 return
-        self.graphs, self.graph_mode = None, "eager"
+        self.graphs, self.graph_mode, self.build_graphs = None, "eager", None
 
     def _capture_when_possible(self):
         """Called by EVERY rank after EVERY step of a run until the graphs exist (or capture has been tried and given up).
@@ -398,11 +427,25 @@ class GraphedStep:
             self._shape_step_done = True
         else:
             g = self.graphs[idx]
+            if self.build_graphs is not None:
+                if self._built[idx] is None:           # no build is in flight for this slot (the first replay after the capture): build now
+                    self._build(idx)
+                self.stream.wait_event(self._built[idx])
             g[0].replay()
             if len(g) == 2:
                 self.opt.dp.sync(force=True)
                 g[1].replay()
             self.steps_replayed += 1
+
+    def _build(self, idx):
+        """Replay slot ``idx``'s graph build on the build stream (its input coordinates are in HBM: the caller has synchronized the
+        copy stream) and record the event the slot's step waits for."""
+        with torch.cuda.stream(self.build_stream):
+            self.build_graphs[idx][0].replay()
+            ev = self._built[idx]
+            if ev is None:
+                ev = self._built[idx] = torch.cuda.Event()
+            ev.record(self.build_stream)
 
     def _usable_shape(self, batch):
         _, labels, xyz_0, xyz_1, feat_0, feat_1, gt_pose = batch
@@ -447,17 +490,22 @@ class GraphedStep:
 
         def take_pinned(shape):
             """A free pinned packet of this shape (the H2D copy that last read it has completed)."""
-            if shape not in pinned_shapes:
-                pinned_shapes.add(shape)
-                for _ in range(self.depth + 3):
-                    pinned_free.put((_Slot(*shape, dev, pinned=True), None))
             while not abandoned.is_set():
+                if shape not in pinned_shapes:
+                    pinned_shapes.add(shape)
+                    for _ in range(self.depth + 3):
+                        pinned_free.put((_Slot(*shape, dev, pinned=True), None))
                 try:
                     pk, ev = pinned_free.get(timeout=0.1)
                 except queue.Empty:
                     continue
-                if tuple(pk.xyz.shape[1:3]) + (pk.feat.shape[3],) != shape:
-                    continue                                   # a packet of an earlier shape: dropped
+                other = tuple(pk.xyz.shape[1:3]) + (pk.feat.shape[3],)
+                if other != shape:
+                    # a packet of another shape: dropped -- and forgotten, so that the shape gets fresh packets should it come back
+                    # (before: a one-pair first batch, then full batches, then a one-pair tail waited for ever on packets that the
+                    # full batches' requests had thrown away; found by the two-rank test with a first batch smaller than the world)
+                    pinned_shapes.discard(other)
+                    continue
                 if ev is not None:
                     ev.synchronize()
                 return pk
@@ -635,6 +683,11 @@ class GraphedStep:
                         launch_staged()                # the previous batch: its H2D went out one iteration ago
                         with torch.cuda.stream(self.copy_stream):
                             sl.packet.copy_(payload.packet, non_blocking=True)
+                        if self.build_graphs is not None:
+                            # the slot's k-NN graph + index one step ahead, beside the step launched just above (host-side hand-over
+                            # from the copy stream: ~10 us of host time that the replay in flight hides)
+                            self.copy_stream.synchronize()
+                            self._build(idx)
                         if tm is not None:
                             note("h2d", time.perf_counter() - t0)
                         staged = (idx, payload, batch_idx)
@@ -731,7 +784,7 @@ class GraphedEval:
     has completed (host-side wait).  ``run`` returns the ``[n_pairs, 5]`` float64 table (rotation error [deg], translation error
     [cm], recall, precision, F1) on the host; batches of another shape than the first run eagerly, ``None`` batches are skipped."""
 
-    def __init__(self, model, k=16, tau=0.09, slots=3, use_graphs=True, depth=3):
+    def __init__(self, model, k=16, tau=0.09, slots=3, use_graphs=True, depth=3, build_ahead=None):
         self.model, self.k, self.tau = model, int(k), float(tau)
         self.n_slots, self.depth, self.use_graphs = max(1, int(slots)), max(int(depth), 2), use_graphs
         self.device = next(model.parameters()).device
@@ -742,9 +795,24 @@ class GraphedEval:
         self.steps_replayed = self.steps_eager = 0
         self._capture_tried = False
         self._pinned_free, self._pinned_shapes = queue.Queue(), set()
+        # the slot's k-NN graph + index one pair ahead on a second stream, as in GraphedStep (17 % of the one-pair inference step)
+        if build_ahead is None:
+            build_ahead = os.environ.get("EQUIGSPR_BUILD_AHEAD", "1") != "0"
+        self.build_ahead = bool(build_ahead) and use_graphs
+        self.build_stream = torch.cuda.Stream(self.device) if self.build_ahead else None
+        self.build_graphs, self._built = None, []
 
-    def _body(self, sl):
-        graph = build_pair_graph(sl.xyz[0], sl.xyz[1], self.k, loop=True)
+    def _build(self, idx):
+        with torch.cuda.stream(self.build_stream):
+            self.build_graphs[idx][0].replay()
+            ev = self._built[idx]
+            if ev is None:
+                ev = self._built[idx] = torch.cuda.Event()
+            ev.record(self.build_stream)
+
+    def _body(self, sl, graph=None):
+        if graph is None:
+            graph = build_pair_graph(sl.xyz[0], sl.xyz[1], self.k, loop=True)
         out = self.model(sl.feat[0], sl.xyz[0], graph, None, sl.feat[1], sl.xyz[1], graph, None, None, sl.labels, sl.gt_pose)
         m = evaluate_batch(out[0], out[1], sl.gt_pose, sl.xyz[0], sl.xyz[1], tau=self.tau)
         return torch.stack([m["rotation_error"], m["translation_error"], m["recall"], m["precision"], m["f1"]], dim=1)
@@ -753,23 +821,35 @@ class GraphedEval:
         if not self.use_graphs:
             return
         graphs, outs, pool = [], [], None
+        builds, bpool = [], None
         try:
             n_words = 2 * self.shape[0] * self.shape[1] + 1
             for sl in self.slots:
                 ops.reserve_csr_scratch(self.device, n_words)
                 torch.cuda.synchronize(self.device)
+                pair_graph = None
+                if self.build_ahead:                   # the build as a capture (and memory pool) of its own: see GraphedStep._capture
+                    gbuild = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gbuild, pool=bpool, stream=self.build_stream, capture_error_mode="thread_local"):
+                        pair_graph = build_pair_graph(sl.xyz[0], sl.xyz[1], self.k, loop=True)
+                    builds.append((gbuild, pair_graph))
+                    bpool = gbuild.pool()
+                    with torch.cuda.stream(self.build_stream):
+                        gbuild.replay()
+                    self.build_stream.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                    o = self._body(sl)
+                    o = self._body(sl, graph=pair_graph)
                 graphs.append(g); outs.append(o)
                 pool = g.pool()
             self.graphs, self.outs = graphs, outs
+            self.build_graphs, self._built = (builds if self.build_ahead else None), [None] * len(self.slots)
         except Exception as exc:
             print(f"[GraphedEval] hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly", file=sys.stderr)
             torch.cuda.synchronize(self.device)
             _lib.lib().equigspr_clear_device_error()
             ops._CSR_SCRATCH.clear()
-            self.graphs = None
+            self.graphs, self.build_graphs = None, None
 
     @torch.no_grad()
     def run(self, batches):
@@ -799,17 +879,19 @@ class GraphedEval:
                     batch = tuple(batch)
                     shape = (int(batch[2].shape[0]), int(batch[2].shape[1]), int(batch[4].shape[-1]))
                     if (not batch[2].is_cuda) and (self.shape is None or shape == self.shape):
-                        if shape not in pinned_shapes:
-                            pinned_shapes.add(shape)
-                            for _ in range(self.depth + 3):
-                                pinned_free.put(_Slot(*shape, dev, pinned=True))
                         pk = None
                         while pk is None and not abandoned.is_set():
+                            if shape not in pinned_shapes:
+                                pinned_shapes.add(shape)
+                                for _ in range(self.depth + 3):
+                                    pinned_free.put(_Slot(*shape, dev, pinned=True))
                             try:
                                 pk = pinned_free.get(timeout=0.1)
                             except queue.Empty:
                                 continue
-                            if tuple(pk.xyz.shape[1:3]) + (pk.feat.shape[3],) != shape:
+                            other = tuple(pk.xyz.shape[1:3]) + (pk.feat.shape[3],)
+                            if other != shape:                 # dropped and forgotten (see GraphedStep.run.take_pinned)
+                                pinned_shapes.discard(other)
                                 pk = None
                         if pk is None:
                             return
@@ -842,6 +924,10 @@ class GraphedEval:
                 out = self._body(sl)
                 self.steps_eager += 1
             else:
+                if self.build_graphs is not None:
+                    if self._built[idx] is None:
+                        self._build(idx)
+                    self.stream.wait_event(self._built[idx])
                 self.graphs[idx].replay()
                 out = self.outs[idx]
                 self.steps_replayed += 1
@@ -876,6 +962,9 @@ class GraphedEval:
                         launch_staged()
                         with torch.cuda.stream(self.copy_stream):
                             sl.packet.copy_(item.packet, non_blocking=True)
+                        if self.build_graphs is not None:
+                            self.copy_stream.synchronize()
+                            self._build(idx)
                         staged = (idx, item)
                         if self.graphs is None:
                             launch_staged()
