@@ -340,9 +340,7 @@ int64_t equigspr_irrep_bwd_work_size(const equigspr_irrep_config* cfg, int32_t n
 
 /* Forward.  keep_moments != 0 (training): two launches (moments: closed-form basis x gathered features x radial hidden
  * activations, aggregated per node in ascending edge order on the matrix cores; node: the radial weights applied to the moments +
- * bias + self-interaction).  keep_moments == 0 (inference) with equigspr_set_irrep_fused(1): ONE fused launch when the shape allows it
- * (<= 32 degree-0 and <= 8 degree-1 input channels, H = 32): the moments of 16 nodes go through an LDS tile in chunks and never reach
- * HBM (`moments` is then only scratch for the shapes the fused kernel does not take; always pass it).
+ * bias + self-interaction).  keep_moments == 0 (inference): the same two launches, `moments` is scratch (always pass it).
  *   w_r1 [H], b_r1 [H] (radial.0), w_r2 [n_w, H], b_r2 [n_w] (radial.2), w_self0 [C0o, C0i], w_self1 [C1o, C1i];
  *   g: row / col / rptr / rperm (cptr / cperm for the backward); f0 [N, C0i], f1 [N, C1i, 3], x [N, 3];
  *   out0 [N, C0o], out1 [N, C1o, 3]; moments: equigspr_irrep_moments_size floats (kept by the caller for the backward).
@@ -351,10 +349,6 @@ int equigspr_irrep_conv_forward(const equigspr_irrep_config* cfg, const float* w
                                 const float* b_r2, const float* w_self0, const float* w_self1, const equigspr_graph* g,
                                 const float* f0, const float* f1, const float* x, float* out0, float* out1, float* moments,
                                 int32_t keep_moments, void* stream);
-/* 1: inference forwards (keep_moments == 0) and the adjoint convolution of the backward run as ONE fused launch where the shape allows
- * it (the moments go through LDS, nothing of size N x Lc x H exists); 0 (default): always the two launches, which are as fast or faster
- * on the MI355X.  Process-wide; same results to the last few bits (another summation grouping of the K dimension). */
-int equigspr_set_irrep_fused(int32_t on);
 /* Backward for EVERY input: the features (d_f0, d_f1: the adjoint convolution = the same two kernels on the reversed edges with
  * transposed weights), the geometry (d_x [N, 3], ACCUMULATED: a stack of layers on fixed coordinates sums into one buffer) and
  * all six parameter tensors (OVERWRITTEN).  `moments` = what the forward of the same inputs left.  d_f0 / d_f1 / d_x may be NULL

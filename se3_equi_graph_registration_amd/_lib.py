@@ -88,7 +88,6 @@ _SIGNATURES = {
     "equigspr_sh_forward": (ctypes.c_int, [c_void_p, c_int32, ctypes.c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "equigspr_sh_basis_forward": (ctypes.c_int, [c_void_p, ctypes.c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "equigspr_irrep_moments_size": (c_int64, [POINTER(IrrepConfig), c_int32, c_int32]),
-    "equigspr_set_irrep_fused": (ctypes.c_int, [c_int32]),
     "equigspr_irrep_bwd_work_size": (c_int64, [POINTER(IrrepConfig), c_int32, c_int32]),
     "equigspr_irrep_conv_forward": (ctypes.c_int, [POINTER(IrrepConfig)] + [c_void_p] * 6 + [POINTER(Graph)] + [c_void_p] * 6 + [c_int32, c_void_p]),
     "equigspr_irrep_gnn_param_count": (c_int64, [POINTER(IrrepGnnConfig)]),

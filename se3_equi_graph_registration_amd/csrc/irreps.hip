@@ -430,320 +430,9 @@ __global__ __launch_bounds__(64 * kNodeWaves) void irrep_node16_kernel(const Nod
     }
 }
 
-// ------------------------------------------------------------------------------------------------ fused layer: moments -> LDS -> out
-// The two launches above move the moments (N x Lc x (H + 1) floats: 112 MB at one 2 048-point pair) through HBM.  This kernel keeps
-// them on the CU: a workgroup owns 16 destination nodes and walks the operand vector in CHUNKS of three 16-entry blocks --
-//   phase A: every wave computes the chunk's moments of two of the nodes (the outer products of irrep_moments16_kernel) and leaves
-//            them in an LDS tile [16 nodes][48 entries][H] (the C/D layout has ONE node per wave-instruction; the next product needs
-//            the node on the lane, so the tile is the transposition);
-//   phase B: the waves split the chunk's entries and apply the radial weights: D[node][o] += sum_h M[node][entry][h] W(o, entry, h)
-//            with the A operands read back from the tile (ds_read_b128), the weights from the parameter tensor (L2);
-// the partial output tiles stay in registers across the chunks and are summed over the waves in fixed order at the end.  The
-// per-edge geometry is computed once per node (one lane per edge) and kept in registers; each chunk replays it into the wave's
-// LDS rows.  Shapes: 17..32 degree-0 and 1..8 degree-1 input channels (B0 = 2, C1P = 8: the BASELINE-like 32 + 8 network), H = 32.
-constexpr int kFW = 8;                         // waves per workgroup
-constexpr int kFHP = 36;                       // floats between entries of the tile (rows 16-byte aligned; the D-tile stores hit distinct banks)
-constexpr int kFS = 48 * kFHP + 8;             // floats between nodes (= 8 mod 64: the ds_read_b128 A operands of 16 nodes hit distinct banks)
-
-template <int B0>
-struct FusedShape {
-    static constexpr int NB = 4 * B0 + 5;                  // 16-entry blocks of the operand vector (C1P = 8)
-    static constexpr int NCH = (NB + 2) / 3;
-};
-
-// phase A for one node and one chunk: blocks 3 CHUNK .. of the operand vector -> tile rows of the node
-template <int B0, int CHUNK>
-__device__ __forceinline__ void fused_phase_a(const MomArgs& a, int n, int lo, int hi, const float4& cA, const float4& cB, float4* gA,
-                                              float4* gB, float* tile_n, float* mb_n, int lane, const float (&w1v)[2], const float (&b1v)[2]) {
-    constexpr int NB = FusedShape<B0>::NB, bf = 3 * CHUNK, nb = (NB - bf) < 3 ? (NB - bf) : 3;
-    constexpr bool has_f1 = bf + nb > 4 * B0;
-    constexpr bool sub0 = (bf < 4 * B0) && ((bf % B0 == 0) || (nb > 1 && bf + 1 < 4 * B0 && (bf + 1) % B0 == 0) || (nb > 2 && bf + 2 < 4 * B0 && (bf + 2) % B0 == 0));
-    constexpr bool sub1 = (B0 > 1) && (bf < 4 * B0) && ((bf % B0 == 1) || (nb > 1 && bf + 1 < 4 * B0 && (bf + 1) % B0 == 1) || (nb > 2 && bf + 2 < 4 * B0 && (bf + 2) % B0 == 1));
-    const int j = lane & 15, kq = lane >> 4;
-    const int ch = j & 7;
-    const bool upper = j >= 8, ch_ok = ch < a.c1;
-    f32x4 acc[3][2];
-    float bs[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) { bs[q] = 0.0f; acc[q][0] = splat4(0.0f); acc[q][1] = splat4(0.0f); }
-    for (int base = lo; base < hi; base += 64) {
-        const int cnt = min(64, hi - base);
-        if (base == lo) { gA[lane] = cA; gB[lane] = cB; }       // the node's first 64 edges: geometry kept in registers
-        else {
-            const bool valid = lane < cnt;
-            const float4 gv = valid ? a.tab.geo[base + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            const int s = valid ? a.tab.src[base + lane] : n;
-            gA[lane] = gv;
-            gB[lane] = make_float4(valid ? a.k.k00 : 0.0f, valid ? a.k.k110 : 0.0f, (valid && gv.w > 0.0f) ? a.k.k112 : 0.0f, __int_as_float(s));
-        }
-        wave_sync();
-        const int nks = (cnt + 3) >> 2;
-        float g0n[2] = {0.0f, 0.0f}, g1n[3] = {0.0f, 0.0f, 0.0f};
-        auto gather = [&](int ks) {
-            const int s = __float_as_int(gB[4 * ks + kq].w);
-            if (sub0) g0n[0] = (j < a.c0) ? a.f0[(size_t)s * a.c0 + j] : 0.0f;
-            if (sub1) g0n[1] = (16 + j < a.c0) ? a.f0[(size_t)s * a.c0 + 16 + j] : 0.0f;
-            if (has_f1) {
-                const float* f1r = a.f1 + ((size_t)s * a.c1 + ch) * 3;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) g1n[c] = ch_ok ? f1r[c] : 0.0f;
-            }
-        };
-        gather(0);
-        for (int ks = 0; ks < nks; ++ks) {
-            const float4 A = gA[4 * ks + kq], B = gB[4 * ks + kq];
-            const float g0v[2] = {g0n[0], g0n[1]}, gv[3] = {g1n[0], g1n[1], g1n[2]};
-            if (ks + 1 < nks) gather(ks + 1);
-            const float hid0 = silu(fmaf(w1v[0], A.w, b1v[0])), hid1 = silu(fmaf(w1v[1], A.w, b1v[1]));
-            const float uv[3] = {A.x, A.y, A.z};
-            float ent[10];
-            if (has_f1) {
-                const float sd = A.x * gv[0] + A.y * gv[1] + A.z * gv[2];
-                const float cr[3] = {gv[1] * A.z - gv[2] * A.y, gv[2] * A.x - gv[0] * A.z, gv[0] * A.y - gv[1] * A.x};
-                ent[0] = a.k.k10 * sd;
-#pragma unroll
-                for (int aa = 0; aa < 3; ++aa) {
-                    ent[1 + 3 * aa] = B.y * gv[aa];
-                    ent[2 + 3 * aa] = a.k.k111 * cr[aa];
-                    ent[3 + 3 * aa] = B.z * (uv[aa] * sd - gv[aa] * (1.0f / 3.0f));
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < nb; ++q) {
-                const int b = bf + q;                       // compile-time after unrolling
-                float c;
-                if (b < 4 * B0) {
-                    const int sl = b / B0, sb = b % B0;
-                    c = (sl == 0 ? B.x : a.k.k01 * uv[sl == 0 ? 0 : sl - 1]) * g0v[sb];
-                } else {
-                    const int t = b - 4 * B0;
-                    c = upper ? ent[2 * t + 1] : ent[2 * t];
-                }
-                bs[q] += c;
-                acc[q][0] = mfma16(hid0, c, acc[q][0]);
-                acc[q][1] = mfma16(hid1, c, acc[q][1]);
-            }
-        }
-        wave_sync();
-    }
-    // D[h][entry]: lane (entry = j, g = kq) holds h = 16 hb + 4 g + r  ->  tile_n[entry][h]
-#pragma unroll
-    for (int q = 0; q < nb; ++q) {
-        st4(tile_n + (16 * q + j) * kFHP + 4 * kq, acc[q][0]);
-        st4(tile_n + (16 * q + j) * kFHP + 16 + 4 * kq, acc[q][1]);
-        const float tot = gsum(bs[q]);
-        if (kq == 0) mb_n[16 * q + j] = tot;
-    }
-}
-
-template <int B0, int NCB0, int NCB1>
-__global__ __launch_bounds__(64 * kFW) void irrep_conv_fused_kernel(const MomArgs a, const NodeArgs nd) {
-    constexpr int H = 32, NT = NCB0 + 3 * NCB1, NCH = FusedShape<B0>::NCH, NB = FusedShape<B0>::NB;
-    extern __shared__ __align__(16) float smem[];
-    float* tile = smem;                                        // [16][kFS]
-    float* mbt = tile + 16 * kFS;                              // [16][48]
-    float4* geo = reinterpret_cast<float4*>(mbt + 16 * 48);    // [kFW][2][64]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int i16 = lane & 15, kq = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    float4* gA = geo + (size_t)wv * 128;
-    float4* gB = gA + 64;
-    float w1v[2], b1v[2];
-#pragma unroll
-    for (int hb = 0; hb < 2; ++hb) { w1v[hb] = a.w1[16 * hb + i16]; b1v[hb] = a.b1[16 * hb + i16]; }
-    // ---- the two nodes of this wave: edge range and the geometry of their first 64 edges (one lane per edge), kept in registers
-    int nn[2], lo[2], hi[2];
-    float4 cA[2], cB[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int n = n0 + 2 * wv + u;
-        const bool ok = n < a.n_nodes;
-        nn[u] = ok ? n : a.n_nodes - 1;
-        lo[u] = ok ? a.ptr[nn[u]] : 0;
-        hi[u] = ok ? a.ptr[nn[u] + 1] : 0;
-        const int cnt = min(64, hi[u] - lo[u]);
-        const bool valid = lane < cnt;
-        const float4 gv = valid ? a.tab.geo[lo[u] + lane] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const int s = valid ? a.tab.src[lo[u] + lane] : nn[u];
-        cA[u] = gv;
-        cB[u] = make_float4(valid ? a.k.k00 : 0.0f, valid ? a.k.k110 : 0.0f, (valid && gv.w > 0.0f) ? a.k.k112 : 0.0f, __int_as_float(s));
-    }
-    f32x4 acc0[NCB0], acc1[3][NCB1];
-#pragma unroll
-    for (int cb = 0; cb < NCB0; ++cb) acc0[cb] = splat4(0.0f);
-#pragma unroll
-    for (int aa = 0; aa < 3; ++aa)
-#pragma unroll
-        for (int cb = 0; cb < NCB1; ++cb) acc1[aa][cb] = splat4(0.0f);
-    const int nA = min(n0 + i16, a.n_nodes - 1);
-    const int f1base = 4 * a.c0p;
-    // B operand of a weight row (cf. irrep_node16_kernel)
-    auto wrow = [&](const float* w, int so, int si, int o, int on, int in, f32x4 (&bv)[2]) {
-        const float* p = w + (size_t)min(o, on - 1) * so + (size_t)in * si;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) bv[t] = o < on ? ldg4(p + 16 * t + 4 * kq) : splat4(0.0f);
-    };
-    auto chunk = [&](auto tag) {
-        constexpr int CH = decltype(tag)::value;
-        constexpr int nb = (NB - 3 * CH) < 3 ? (NB - 3 * CH) : 3;
-        if (3 * CH >= 4 * B0 && a.c1 == 0) return;                     // workgroup-uniform: a chunk of c10 / c11 blocks, none active
-        // phase A
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            fused_phase_a<B0, CH>(a, nn[u], lo[u], hi[u], cA[u], cB[u], gA, gB, tile + (size_t)(2 * wv + u) * kFS, mbt + (2 * wv + u) * 48, lane,
-                                  w1v, b1v);
-        __syncthreads();
-        // phase B: the chunk's entries, one per wave at a time; the weight rows of the wave's NEXT entry are requested before the
-        // products of this one (they come from L2: an exposed round trip per entry otherwise)
-        const float* tA = tile + (size_t)i16 * kFS;
-        struct Ent { bool live, deg0; int aa; f32x4 bv[NCB0 > NCB1 ? NCB0 : NCB1][2]; float bb[NCB0 > NCB1 ? NCB0 : NCB1]; };
-        auto fetch = [&](int el, Ent& E_) {
-            const int e = 48 * CH + el;                                  // wave-uniform
-            int in, J = 0, cin;
-            PathW pv;                                                    // by value: scalar selects, no reloads of the descriptor
-            PathW* p = &pv;
-            E_.aa = 0;
-            if (e < f1base) {
-                const int sl = e / a.c0p;
-                in = e - sl * a.c0p; cin = a.c0;
-                E_.deg0 = sl == 0; E_.aa = E_.deg0 ? 0 : sl - 1;
-                pv.w = E_.deg0 ? nd.p00.w : nd.p01.w; pv.b = E_.deg0 ? nd.p00.b : nd.p01.b;
-                pv.so = E_.deg0 ? nd.p00.so : nd.p01.so; pv.si = E_.deg0 ? nd.p00.si : nd.p01.si;
-            } else {
-                const int q = e - f1base, sl = q / a.c1p;
-                in = q - sl * a.c1p; cin = a.c1;
-                E_.deg0 = sl == 0;
-                if (!E_.deg0) { E_.aa = (sl - 1) / 3; J = (sl - 1) - 3 * E_.aa; }
-                pv.w = E_.deg0 ? nd.p10.w : nd.p11.w; pv.b = E_.deg0 ? nd.p10.b : nd.p11.b;
-                pv.so = E_.deg0 ? nd.p10.so : nd.p11.so; pv.si = E_.deg0 ? nd.p10.si : nd.p11.si;
-            }
-            E_.live = in < cin;
-            if (!E_.live) return;
-            const int on = E_.deg0 ? nd.o0 : nd.o1;
-#pragma unroll
-            for (int cb = 0; cb < (NCB0 > NCB1 ? NCB0 : NCB1); ++cb) {
-                if (cb >= (E_.deg0 ? NCB0 : NCB1)) break;
-                const int o = 16 * cb + i16;
-                wrow(p->w + J * H, p->so, p->si, o, on, in, E_.bv[cb]);
-                E_.bb[cb] = (kq == 0 && o < on) ? p->b[((size_t)o * p->so + (size_t)in * p->si) / H + J] : 0.0f;
-            }
-        };
-        Ent nxt;
-        nxt.live = false;
-        if (wv < 16 * nb) fetch(wv, nxt);
-        for (int el = wv; el < 16 * nb; el += kFW) {
-            const Ent cur = nxt;
-            if (el + kFW < 16 * nb) fetch(el + kFW, nxt);
-            if (!cur.live) continue;
-            f32x4 av[2];
-            av[0] = lds4(tA + el * kFHP + 4 * kq);
-            av[1] = lds4(tA + el * kFHP + 16 + 4 * kq);
-            const float mb = kq == 0 ? mbt[i16 * 48 + el] : 0.0f;      // the bias column as one more K step (k = 0 only)
-            if (cur.deg0) {
-#pragma unroll
-                for (int cb = 0; cb < NCB0; ++cb) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc0[cb] = mfma16(av[t][r], cur.bv[cb][t][r], acc0[cb]);
-                    acc0[cb] = mfma16(mb, cur.bb[cb], acc0[cb]);
-                }
-            } else {
-#pragma unroll
-                for (int cb = 0; cb < NCB1; ++cb) {
-                    // (aa is wave-uniform: one accumulator per component)
-                    f32x4 acc = cur.aa == 0 ? acc1[0][cb] : (cur.aa == 1 ? acc1[1][cb] : acc1[2][cb]);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc = mfma16(av[t][r], cur.bv[cb][t][r], acc);
-                    acc = mfma16(mb, cur.bb[cb], acc);
-                    if (cur.aa == 0) acc1[0][cb] = acc; else if (cur.aa == 1) acc1[1][cb] = acc; else acc1[2][cb] = acc;
-                }
-            }
-        }
-        __syncthreads();                                                // the next chunk overwrites the tile
-    };
-    chunk(std::integral_constant<int, 0>{});
-    if constexpr (NCH > 1) chunk(std::integral_constant<int, 1>{});
-    if constexpr (NCH > 2) chunk(std::integral_constant<int, 2>{});
-    if constexpr (NCH > 3) chunk(std::integral_constant<int, 3>{});
-    if constexpr (NCH > 4) chunk(std::integral_constant<int, 4>{});
-    // ---- self-interaction (K = input channels, the node's own features): four channels per step, the steps dealt over the waves
-    for (int i0 = 4 * wv; i0 < nd.c0; i0 += 4 * kFW) {
-        const int i = i0 + kq;
-        const bool live = i < nd.c0;
-        const float as = live ? nd.f0[(size_t)nA * nd.c0 + i] : 0.0f;
-#pragma unroll
-        for (int cb = 0; cb < NCB0; ++cb) {
-            const int o = 16 * cb + i16;
-            const float bsf = (live && o < nd.o0) ? nd.s0.w[(size_t)o * nd.s0.so + (size_t)i * nd.s0.si] : 0.0f;
-            acc0[cb] = mfma16(as, bsf, acc0[cb]);
-        }
-    }
-    for (int i0 = 4 * wv; i0 < nd.c1; i0 += 4 * kFW) {
-        const int i = i0 + kq;
-        const bool live = i < nd.c1;
-#pragma unroll
-        for (int aa = 0; aa < 3; ++aa) {
-            const float as = live ? nd.f1[((size_t)nA * nd.c1 + i) * 3 + aa] : 0.0f;
-#pragma unroll
-            for (int cb = 0; cb < NCB1; ++cb) {
-                const int o = 16 * cb + i16;
-                const float bsf = (live && o < nd.o1) ? nd.s1.w[(size_t)o * nd.s1.so + (size_t)i * nd.s1.si] : 0.0f;
-                acc1[aa][cb] = mfma16(as, bsf, acc1[aa][cb]);
-            }
-        }
-    }
-    // ---- sum of the waves' partial tiles in wave order (the tile memory is free now), store
-    f32x4* part = reinterpret_cast<f32x4*>(tile);                      // [kFW][NT][64]
-#pragma unroll
-    for (int cb = 0; cb < NCB0; ++cb) part[((size_t)wv * NT + cb) * 64 + lane] = acc0[cb];
-#pragma unroll
-    for (int aa = 0; aa < 3; ++aa)
-#pragma unroll
-        for (int cb = 0; cb < NCB1; ++cb) part[((size_t)wv * NT + NCB0 + aa * NCB1 + cb) * 64 + lane] = acc1[aa][cb];
-    __syncthreads();
-    for (int t = wv; t < NT; t += kFW) {
-        f32x4 sum = part[(size_t)t * 64 + lane];
-#pragma unroll
-        for (int w = 1; w < kFW; ++w) sum += part[((size_t)w * NT + t) * 64 + lane];
-        const bool deg0 = t < NCB0;
-        const int aa = deg0 ? 0 : (t - NCB0) / NCB1, cb = deg0 ? t : (t - NCB0) - aa * NCB1;
-        const int o = 16 * cb + i16;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + 4 * kq + r;
-            if (n >= a.n_nodes) continue;
-            if (deg0) { if (o < nd.o0) nd.out0[(size_t)n * nd.o0 + o] = sum[r]; }
-            else if (o < nd.o1) nd.out1[((size_t)n * nd.o1 + o) * 3 + aa] = sum[r];
-        }
-    }
-}
-
-static constexpr size_t kFusedLds = (16 * kFS + 16 * 48) * sizeof(float) + (size_t)kFW * 128 * sizeof(float4);
-
-// fused launch when the shape fits (B0 = 2 or 1, C1P = 8, H = 32); returns false otherwise
-// Off by default (equigspr_set_irrep_fused): measured 77 us against 39 + 30 us for the two launches at one 2 048-point pair and equal
-// to them at 16 pairs -- it removes the moments' 224 MB of HBM traffic per layer and the buffer itself, but
-// re-walks every node's edges once per chunk at two waves per SIMD.
-static std::atomic<int> g_use_fused{0};
-static bool launch_fused(const MomArgs& m, const NodeArgs& nd, int H, hipStream_t s) {
-    if (!g_use_fused.load(std::memory_order_relaxed)) return false;
-    if (H != 32 || m.c1p != 8 || (m.c0p != 32 && m.c0p != 16)) return false;
-    const int cb0 = ceil_div(nd.o0, 16), cb1 = ceil_div(nd.o1, 16);
-    const dim3 grid(ceil_div(m.n_nodes, 16)), block(64 * kFW);
-#define EQ_IR_FUSED(BB, AA, CC) \
-    if (m.c0p == 16 * BB && cb0 == AA && cb1 == CC) { \
-        static bool once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&irrep_conv_fused_kernel<BB, AA, CC>), \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLds) == hipSuccess); \
-        if (!once) return false; \
-        hipLaunchKernelGGL((irrep_conv_fused_kernel<BB, AA, CC>), grid, block, kFusedLds, s, m, nd); return true; }
-    EQ_IR_FUSED(2, 2, 1) EQ_IR_FUSED(2, 1, 1) EQ_IR_FUSED(1, 2, 1) EQ_IR_FUSED(1, 1, 1)
-    EQ_IR_FUSED(2, 2, 2) EQ_IR_FUSED(2, 1, 2) EQ_IR_FUSED(1, 2, 2) EQ_IR_FUSED(1, 1, 2)
-#undef EQ_IR_FUSED
-    return false;
-}
+// (Round 5's opt-in `irrep_conv_fused_kernel` -- both launches above in one, the moments kept in an LDS tile -- was deleted in round 6:
+// 77 us against 39 + 30 us at one pair, equal at 16 pairs (its phase A re-walks every node's edges once per operand chunk at two
+// waves per SIMD), a third code path that nothing used by default.  DESIGN.md section 9 keeps the measurement.)
 
 // ------------------------------------------------------------------------------------------------ backward: dM = W^T g
 // The gradient of the moments (for the geometry backward): dM[n, j, h] = sum_o W(o, j, h) g[n, o] with the path's output gradient
@@ -1442,7 +1131,6 @@ static void conv_forward(const equigspr_irrep_config* c, const Layout& L, const 
                 PathW{w_r2 + (size_t)L.off11 * H, b_r2 + L.off11, L.c1i * 3 * H, 3 * H},
                 SelfW{ws0, L.c0i, 1}, SelfW{ws1, L.c1i, 1},
                 g->n_nodes, L.c0i, c1a, c0p, c1p, lc, L.c0o, L.c1o, out0, out1};
-    if (!keep_moments && launch_fused(m, nd, H, s)) return;
     if (H == 16) { launch_moments<1>(m, s); launch_node<1>(nd, s); }
     else { launch_moments<2>(m, s); launch_node<2>(nd, s); }
 }
@@ -1524,8 +1212,7 @@ static void conv_backward(const equigspr_irrep_config* c, const Layout& L, const
                     PathW{f11.w, f11.b, 3 * H, L.c1i * 3 * H},       // G1 -> d f1: R11^T
                     SelfW{ws0, 1, L.c0i}, SelfW{ws1, 1, L.c1i},
                     N, L.c0o, L.c1o, c0pr, c1pr, p.lc_r, L.c0i, L.c1i, d_f0, d_f1};
-        if (launch_fused(m, nd, H, s)) {}
-        else if (H == 16) { launch_moments<1>(m, s); launch_node<1>(nd, s); }
+        if (H == 16) { launch_moments<1>(m, s); launch_node<1>(nd, s); }
         else { launch_moments<2>(m, s); launch_node<2>(nd, s); }
     }
     // geometry + radial.0
@@ -1787,11 +1474,6 @@ extern "C" int equigspr_irrep_conv_forward(const equigspr_irrep_config* cfg, con
     conv_forward(cfg, L, w_r1, b_r1, w_r2, b_r2, w_self0, w_self1, g, f0, f1, tab, out0, out1, moments,
                  moments + (int64_t)g->n_nodes * lc * L.H, (hipStream_t)stream, keep_moments != 0);
     EQ_CHECK_LAUNCH("irrep_conv_forward");
-    return 0;
-}
-
-extern "C" int equigspr_set_irrep_fused(int32_t on) {
-    eq::ir::g_use_fused.store(on ? 1 : 0, std::memory_order_relaxed);
     return 0;
 }
 

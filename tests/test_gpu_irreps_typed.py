@@ -243,34 +243,6 @@ def test_irrep_egnn_is_se3_covariant_and_drops_into_the_pair_model(pk):
     assert gs.steps_replayed >= 1, (gs.graph_mode, gs.steps_eager)
 
 
-def test_fused_launch_equals_the_two_launch_form(pk):
-    """equigspr_set_irrep_fused(1): moments -> LDS -> radial weights in ONE launch (inference forward and the adjoint convolution of the
-    backward).  Same layer, same inputs: outputs and feature gradients agree with the two-launch form to fp32 round-off (the K dimension
-    is grouped differently), for the BASELINE-like 32 + 8 channels and for shapes with padding (20 + 5, 9 + 1 output channels)."""
-    from se3_equi_graph_registration_amd import _lib
-    n, e = 500, 9000
-    g, row, col = _graph(21, n, e)
-    try:
-        for dims in [(32, 8, 32, 8), (20, 5, 9, 1), (16, 8, 32, 20)]:
-            torch.manual_seed(sum(dims))
-            layer = pk.IrrepConv(*dims, hidden=32)
-            x = (torch.randn(n, 3, generator=g) * 1.5).cuda()
-            f0 = torch.randn(n, dims[0], generator=g).cuda(); f1 = torch.randn(n, dims[1], 3, generator=g).cuda()
-            res = []
-            for fused in (0, 1):
-                _lib.lib().equigspr_set_irrep_fused(fused)
-                with torch.no_grad():
-                    o0, o1 = layer(f0, f1, x, [row.cuda(), col.cuda()])
-                a0, a1 = f0.clone().requires_grad_(True), f1.clone().requires_grad_(True)
-                p0, p1 = layer(a0, a1, x, [row.cuda(), col.cuda()])
-                (p0.sum() + (p1 * p1).sum()).backward()
-                res.append((o0, o1, a0.grad, a1.grad))
-            for u, v in zip(*res):
-                assert float((u - v).abs().max()) <= 2e-5 * max(1.0, float(u.abs().max())), dims
-    finally:
-        _lib.lib().equigspr_set_irrep_fused(0)
-
-
 def test_torch_library_irrep_conv_ops_match_the_ctypes_path(pk):
     """torch.ops.equigspr.irrep_conv_forward (autograd registered in csrc/torch_ops.cpp) and the explicit irrep_conv_backward op
     call the same C-ABI entries as irreps.IrrepConv: bit-identical outputs and gradients for every input; argument checks raise."""

@@ -53,9 +53,5 @@ def fwd_train():
 
 
 print(f"   forward, inference (edge table + moments + node):  {t(fwd):9.1f} us")
-from se3_equi_graph_registration_amd import _lib
-_lib.lib().equigspr_set_irrep_fused(1)
-print(f"   forward, inference, fused launch (equigspr_set_irrep_fused(1)):  {t(fwd):9.1f} us")
-_lib.lib().equigspr_set_irrep_fused(0)
 print(f"   forward, training (moments kept: 2 launches): {t(fwd_train):9.1f} us")
 print(f"   forward + backward (eager, autograd): {t(fwd_bwd):9.1f} us")
