@@ -12,6 +12,6 @@ import csv, glob
 f = sorted(glob.glob("$OUT/**/*kernel_stats.csv", recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 print("== $TAG", "$*")
-for r in rows[:14]:
+for r in rows[:28]:
     print("  %-46s calls %5s avg %9.1f us  %6s%%" % (r["Name"].replace("void ", "").replace("eq::", "")[:46], r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"][:5]))
 PY
