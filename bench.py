@@ -516,11 +516,28 @@ def roofline_irreps(pkg, S, args, dev):
     dom_b = bwd_ms is not None
     ms = bwd_ms if dom_b else fwd_ms
     by = bytes_bwd if dom_b else bytes_fwd
+    # HBM traffic of one layer from the committed PMC passes of the typed network's step (profiles/): forward = moments + node launches,
+    # backward = their adjoint pair + expand + geometry + weight gradients + reduce + dx
+    t_fwd = t_bwd = t_src = None
+    for name in [f for g_ in PMC_GLOBS for f in sorted(glob.glob(os.path.join(ROOT, "profiles", g_)), reverse=True)]:
+        try:
+            pmc = json.load(open(name))
+            if "--network irreps" not in pmc["workload"].get("flags", "") or pmc["workload"]["edges_per_launch"] != E:
+                continue
+            per = lambda key: sum(v["traffic_bytes"] for k_, v in pmc.items() if isinstance(v, dict) and "traffic_bytes" in v and key in k_)     # noqa: E731
+            t_fwd = per("irrep_moments16") + per("irrep_node16")
+            t_bwd = t_fwd + per("irrep_expand16") + per("irrep_geom_bwd") + per("irrep_wgrad16") + per("irrep_wreduce") + per("irrep_dx")
+            t_src = f"profiles/{os.path.basename(name)}"
+            break
+        except Exception:
+            continue
     roof = {"bound": "hbm", "kernel": ("irrep_conv layer backward: adjoint irrep_moments16 + irrep_node16, irrep_expand16, irrep_geom_bwd, irrep_dx, "
                                        "irrep_wgrad16, irrep_wreduce (8 launches)" if dom_b else
                                        "irrep_conv layer forward: irrep_moments16_kernel + irrep_node16_kernel (2 launches)"),
             "achieved": round(by / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-            "traffic": None, "traffic_source": None, "edges_per_launch": E, "algorithmic_bytes_per_launch": by, "launch_ms": round(ms, 5),
+            "traffic": (t_bwd if dom_b else t_fwd), "traffic_source": t_src,
+            "measured_GBs": None if (t_bwd if dom_b else t_fwd) is None else round((t_bwd if dom_b else t_fwd) / (ms * 1e-3) / 1e9, 1),
+            "fwd_traffic": t_fwd, "edges_per_launch": E, "algorithmic_bytes_per_launch": by, "launch_ms": round(ms, 5),
             "launch_ms_note": "HIP events around back-to-back calls of one layer (all of its launches); the aggregate-then-transform form moves "
                               f"per-node moments of {lc * (H + 1) * 4} B per node through HBM between its two launches -- traffic the algorithmic "
                               "byte count does not contain",
@@ -670,6 +687,9 @@ def cpu_baseline(args):
     wc = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()
           if not k.startswith("egnn.") and v.is_floating_point()}
     b = pkg.synthetic_batch(1234, args.batch, n=args.n, feat=args.feat)
+    # the optimizer step of the training workload (train :1412: Adam) is part of the CPU leg too; lr = 0 keeps the weights where they
+    # are (one repeated pair walks into the singular point of the reference's arccos loss otherwise) at the same arithmetic cost
+    cpu_opt = None if args.forward_only else torch.optim.Adam([v for v in list(we.values()) + list(wc.values()) if v.requires_grad], lr=0.0)
 
     def step():
         t0 = time.perf_counter()
@@ -682,8 +702,8 @@ def cpu_baseline(args):
         if not args.forward_only:
             rl, tl = orc.pose_loss(res[0], res[1], b["gt_pose"])
             (res[2].mean() + rl.mean() + tl.mean()).backward()
-            for v in list(we.values()) + list(wc.values()):
-                v.grad = None
+            cpu_opt.step()
+            cpu_opt.zero_grad(set_to_none=True)
         return t_knn
 
     # pick the thread count: this path is many small memory-bound ATen ops, and all host cores
@@ -709,7 +729,7 @@ def cpu_baseline(args):
             "threads": best_t, "host_cores": host_cores,
             "knn_seconds": round(t_knn, 3), "model_seconds": round(el - t_knn, 3),
             "sample": f"{n_done} steps of the same workload (B={args.batch}, N={args.n}, k={args.k}, L={args.layers}, "
-                      f"{'forward' if args.forward_only else 'forward+backward'}, no optimizer step) in {el:.1f}s: kNN (cdist+topk) "
+                      f"{'forward' if args.forward_only else 'forward+backward+Adam'}) in {el:.1f}s: kNN (cdist+topk) "
                       f"{t_knn:.2f}s, model {el - t_knn:.2f}s; torch CPU threads={best_t} (fastest of 8/16/32/64 on a host with "
                       f"{host_cores} cores: `cores` is the thread count used)"}
 

@@ -465,6 +465,7 @@ class GraphedStep:
         overwrites that step's input slot; the H2D of batch t+1 is issued before the replay of batch t and has long completed
         (checked on the host) when its own replay is launched."""
         dev = self.device
+        _t_entry = time.perf_counter()
         caller = torch.cuda.current_stream(dev)
         self.stream.wait_stream(caller)
         adam = self.opt.adam
@@ -558,6 +559,8 @@ class GraphedStep:
         staged = None                      # (slot index, pinned packet, batch index): H2D issued, step not launched yet
 
         tm = self.timing = {"get": 0.0, "wait_calls": 0.0, "ev_sync": 0.0, "launch": 0.0, "h2d": 0.0, "slow": []} if os.environ.get("EQUIGSPR_STEP_TIMING") == "1" else None
+        if tm is not None:
+            tm["phase_setup"] = time.perf_counter() - _t_entry       # entry -> producer thread running
 
         def note(what, dt):
             tm[what] += dt
@@ -711,15 +714,21 @@ class GraphedStep:
                         self._capture_when_possible()
                         log_point(batch_idx)
                 launch_staged()
+                if tm is not None:
+                    tm["phase_loop"] = time.perf_counter() - _t_entry    # ... -> the last step has been launched
         finally:
             abandoned.set()
             th.join()
             sys.setswitchinterval(switch_interval)
             caller.wait_stream(self.stream)
         self.stream.synchronize()
+        if tm is not None:
+            tm["phase_drain"] = time.perf_counter() - _t_entry           # ... -> the stream has drained
         for entry in pending_log:
             self._report(entry, epoch, skip_nonfinite)
         st = self.last_stats = adam.guard_stats()
+        if tm is not None:
+            tm["phase_stats"] = time.perf_counter() - _t_entry           # ... -> the statistics have been read back
         if st["applied"] > 0:
             self.opt._opt_called = True        # what torch's lr_scheduler looks at to tell "scheduler.step() before optimizer.step()"
         _check_head_waits(self)
