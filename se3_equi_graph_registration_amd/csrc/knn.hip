@@ -627,8 +627,13 @@ __global__ __launch_bounds__(64) void knn_stream_kernel(const float* __restrict_
 
 }  // namespace eq
 
+// Largest cloud the wave-per-query kernel takes.  Alone the two forms tie at 2 048 points (16 us); since round 6 the graph build runs on a
+// second stream BESIDE the previous step's kernels (train.GraphedStep build_ahead), and there the tiled form -- one sixteenth of the L2
+// reads: every workgroup stages the cloud once for its 16 queries -- disturbs them less although it takes longer itself (35 vs 22 us
+// under contention): one pair training 0.3242 -> 0.3182 ms, inference pair 5 842-6 420 -> 6 188-6 826 pairs/s, 16 pairs +0.6 %
+// (three alternating runs each, one box).  2 048: the round-5 choice.
 #ifndef EQ_KNN_PER_QUERY_MAX
-#define EQ_KNN_PER_QUERY_MAX 2048
+#define EQ_KNN_PER_QUERY_MAX 1024
 #endif
 extern "C" int equigspr_knn_graph(const float* x, int32_t n_clouds, int32_t n, int32_t k, int32_t loop,
                                   int64_t* edges_i64, int32_t* row32, int32_t* col32, int32_t* row_hist, int32_t* arrival,
