@@ -11,5 +11,7 @@ done
 cp $SRC/in_step.json $DST/${TAG}_in_step.json
 mkdir -p $DST/${TAG}_pmc && cp $SRC/*_counter_collection.csv $DST/${TAG}_pmc/
 cp $SRC/step_sequence.txt $DST/${TAG}_step_sequence.txt
+[ -f $SRC/step_sequence_build_ahead.txt ] && cp $SRC/step_sequence_build_ahead.txt $DST/${TAG}_step_sequence_build_ahead.txt
+[ -f $SRC/bench_full.json ] && cp $SRC/bench_full.json $DST/${TAG}_bench_full.json
 for f in 64 48 16; do [ -f $SRC/kernel_stats_fp_f$f.csv ] && cp $SRC/kernel_stats_fp_f$f.csv $DST/${TAG}_kernel_stats_fp_f$f.csv; done
 ls $DST | grep $TAG

@@ -25,3 +25,12 @@ print(f"main queue {mainq}: {len(ad)} steps; gap adam -> next step's first kerne
 side = [r for r in rows if r["Queue_Id"] != mainq and any(t in r["Kernel_Name"] for t in ("knn", "csr_"))]
 if side:
     print(f"build queue: {len(side)} kernels, median durations:", {k: round(mid([(r['e'] - r['s']) / 1e3 for r in side if k in r['Kernel_Name']]), 1) for k in ("knn", "csr_scan", "csr_sort")})
+
+if "--timeline" in sys.argv:
+    # two consecutive steps in the middle of the run, both queues: start offset (us), duration (us), queue, kernel
+    k = len(ad) // 2
+    lo, hi = ad[k - 1]["e"], ad[k + 1]["e"]
+    print(f"\ntimeline of two consecutive steps (queue {mainq} = the step graphs, the other queue = the graph builds running ahead):")
+    for r in rows:
+        if lo <= r["s"] <= hi:
+            print(f"{(r['s'] - lo) / 1e3:9.1f} {(r['e'] - r['s']) / 1e3:7.1f}  q{r['Queue_Id']}  {r['Kernel_Name'].replace('void ', '').replace('eq::', '')[:80]}")

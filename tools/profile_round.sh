@@ -17,7 +17,11 @@ one() {  # name, edges per launch, feat, training(0|1), bench args...
   local name=$1 edges=$2 feat=$3 training=$4; shift 4
   python3 "$ROOT/bench.py" --no-cpu-baseline --no-workloads "$@" > "$OUT/bench_$name.json" 2>> "$OUT/bench.err"
   rm -rf /tmp/prof_$name
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-workloads --min-seconds 0 "$@" > "$OUT/stats_$name.log" 2>&1
+  # (round 6: the per-kernel statistics are taken in the SERIAL form of the step -- EQUIGSPR_BUILD_AHEAD=0, the graph build inside the step
+  # graph: the same kernels, one queue, no overlap -- so that a launch's duration is its own; the shipped form runs the build on a second
+  # stream beside the previous step, where durations of overlapping launches inflate each other and one cold replay of the build graph
+  # dominates the averages.  The concurrent form's timeline is recorded separately: step_sequence.txt / gaps.txt below.)
+  EQUIGSPR_BUILD_AHEAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-workloads --min-seconds 0 "$@" > "$OUT/stats_$name.log" 2>&1
   cp "$(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_$name.csv"
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/prof_${name}_$c
@@ -40,16 +44,13 @@ one irrepgnn 81920 32 1 --network irreps --steps 60 --warmup 10
 python3 "$ROOT/tools/in_step_summary.py" "$OUT/in_step.json" "$TAG" $SPECS
 # the default line quotes the evidence above when it sits in profiles/: place this run's files there for the run (on the GPU box only)
 cp "$OUT/in_step.json" "$ROOT/profiles/${TAG}_in_step.json"
-for w in b1 b16 c4shard c5 c1infer c1infer_b16; do cp "$OUT/pmc_$w.json" "$ROOT/profiles/${TAG}_pmc_$w.json"; done
+for w in b1 b16 b16_irreps c4shard c5 c1infer c1infer_b16 irrepgnn; do cp "$OUT/pmc_$w.json" "$ROOT/profiles/${TAG}_pmc_$w.json"; done
 python3 "$ROOT/bench.py" > "$OUT/bench.json" 2>> "$OUT/bench.err"
+cp "$ROOT/bench_full.json" "$OUT/bench_full.json"
 tail -1 "$OUT/bench.json" | cut -c1-300
-bash "$ROOT/tools/step_sequence.sh" > "$OUT/step_sequence.txt" 2>&1
+EQUIGSPR_BUILD_AHEAD=0 bash "$ROOT/tools/step_sequence.sh" > "$OUT/step_sequence.txt" 2>&1
+# the shipped (build-ahead) form: both queues of two consecutive steps, and the idle gap between step graphs
+rm -rf /tmp/seq_ahead
+rocprofv3 --kernel-trace --output-format csv -d /tmp/seq_ahead -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-workloads --no-fixed-pair --min-seconds 0 --steps 60 --warmup 10 > /tmp/seq_ahead.log 2>&1
+python3 "$ROOT/tools/dev/trace_gaps2.py" "$(find /tmp/seq_ahead -name '*kernel_trace.csv' | head -1)" --timeline > "$OUT/step_sequence_build_ahead.txt" 2>&1
 ls -la "$OUT"
-# hidden_nf 16 / 48 / 64: the feature-parallel MFMA edge kernels (csrc/egnn_edge_fp.h) -- a tracked profile of what they cost
-cd /tmp
-for f in 64 48 16; do
-  rm -rf /tmp/prof_lane$f
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_lane$f -- python3 "$ROOT/bench.py" --no-cpu-baseline --no-workloads --min-seconds 0 --feat $f --heads 2 --steps 20 --warmup 3 > "$OUT/stats_lane$f.log" 2>&1
-  cp "$(find /tmp/prof_lane$f -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats_fp_f$f.csv"
-  tail -1 "$OUT/stats_lane$f.log" | cut -c1-160
-done
