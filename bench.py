@@ -689,7 +689,8 @@ def cpu_baseline(args):
     b = pkg.synthetic_batch(1234, args.batch, n=args.n, feat=args.feat)
     # the optimizer step of the training workload (train :1412: Adam) is part of the CPU leg too; lr = 0 keeps the weights where they
     # are (one repeated pair walks into the singular point of the reference's arccos loss otherwise) at the same arithmetic cost
-    cpu_opt = None if args.forward_only else torch.optim.Adam([v for v in list(we.values()) + list(wc.values()) if v.requires_grad], lr=0.0)
+    cpu_params = [v for v in list(we.values()) + list(wc.values()) if v.requires_grad]
+    cpu_opt = None if args.forward_only else torch.optim.Adam(cpu_params, lr=0.0)
 
     def step():
         t0 = time.perf_counter()
@@ -702,6 +703,9 @@ def cpu_baseline(args):
         if not args.forward_only:
             rl, tl = orc.pose_loss(res[0], res[1], b["gt_pose"])
             (res[2].mean() + rl.mean() + tl.mean()).backward()
+            for v in cpu_params:                 # a non-finite gradient (the arccos loss at a perfect fit) must not reach the weights: 0 x NaN = NaN even at lr = 0
+                if v.grad is not None:
+                    torch.nan_to_num_(v.grad, nan=0.0, posinf=0.0, neginf=0.0)
             cpu_opt.step()
             cpu_opt.zero_grad(set_to_none=True)
         return t_knn
@@ -1213,7 +1217,11 @@ def main():
                 out["workloads"][name] = {"baseline_config": what, "error": err}
             torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args)
+        try:
+            out["cpu_baseline"] = cpu_baseline(args)
+        except Exception as exc:                    # the reported baseline must never take the measured line down with it
+            print(f"[bench] cpu_baseline failed: {type(exc).__name__}: {exc}", file=sys.stderr)
+            out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": None, "kind": "port", "sample": f"failed: {type(exc).__name__}: {str(exc)[:120]}"}
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -373,3 +373,21 @@ def test_bench_line_stays_within_the_drivers_record():
         assert r[f"{name}_value"] == e["value"] and r[f"{name}_frac"] == e["roofline"]["frac"]
     assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
     assert "ranks_seen" not in line["multi_gpu"] and line["full_record"] == "bench_full.json"
+
+
+def test_bench_cpu_baseline_leg_runs_and_survives_nonfinite_gradients():
+    """bench.py's `cpu_baseline` leg (the oracle: forward + backward + Adam on the host cores) on a small workload: it must return the
+    contract's members with a positive rate -- and keep running when a gradient is not finite (the reference's arccos loss at a perfect
+    fit: round 6's first version let 0 x NaN into the weights through Adam and crashed the default run in the oracle's SVD)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = bench.parse(["--n", "128", "--k", "8", "--layers", "2", "--cpu-seconds", "1.0"])
+    threads = torch.get_num_threads()
+    try:
+        out = bench.cpu_baseline(args)
+    finally:
+        torch.set_num_threads(threads)
+    assert out["value"] > 0 and out["unit"] == "pairs/s" and out["kind"] == "port" and out["cores"] >= 1 and "Adam" in out["sample"]
