@@ -1012,7 +1012,7 @@ def entry_for(pkg, args, dev, world, rank, S, blocks, used_graph, graph_mode, fi
            "layers": args.layers, "edge_basis": args.edge_basis, "hipgraph": used_graph, "graph_mode": graph_mode,
            "parallelism": f"dp{world}", "params_finite": finite,
            "arithmetic": "fp32 storage and accumulation; the 32 x 32 products of the edge MLP as six bf16 x bf16 -> fp32 matrix products on "
-                         "3-way split operands (x = hi + mid + lo, 24 mantissa bits: within 1e-6 relative of the fp32 product, DESIGN section 9 item 7)"}
+                         "3-way split operands (x = hi + mid + lo, 24 mantissa bits: within 1e-6 relative of the fp32 product, DESIGN section 9 item 2; EQUIGSPR_EDGE_PRODUCTS=fp32 selects fp32 products)"}
     if S.get("eval_loop"):
         cfg.update({"loop": "train.GraphedEval = the per-pair body of train.evaluate_model (static input slots, one hipGraph per slot: kNN + index, "
                             "EGNN forward, evaluation head, the four metrics of tools/evaluation_metrics.py; the metric table read back once)",
