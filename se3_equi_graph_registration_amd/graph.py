@@ -21,8 +21,7 @@ def knn_graph(x: torch.Tensor, k: int, batch=None, loop: bool = False, flow: str
 
     ``batch`` (``src/gcnn.py:31`` passes it; train :1473-1474 calls the function on a whole batch): a sorted LongTensor ``[N]``
     assigning every point to a cloud, neighbours are searched inside a point's own cloud only.  Clouds of EQUAL size are one
-    launch of the batched kernel (``ops.knn_graph_batched`` over ``[B, n, 3]``); ragged batches raise (the batched kernel's
-    clouds share one size -- split them, or pad the data set as the reference's loaders do)."""
+    launch of the batched kernel (``ops.knn_graph_batched`` over ``[B, n, 3]``); a ragged batch takes one launch per cloud."""
     if flow != "source_to_target":
         raise NotImplementedError("knn_graph: only flow='source_to_target' (the reference default)")
     if x.dim() != 2 or x.shape[1] != 3:
@@ -40,8 +39,16 @@ def knn_graph(x: torch.Tensor, k: int, batch=None, loop: bool = False, flow: str
     if bool((batch[1:] < batch[:-1]).any()):
         raise RuntimeError("knn_graph: batch must be sorted (torch_cluster's contract)")
     if bool((counts != n).any()):
-        raise NotImplementedError("knn_graph: clouds of different sizes in one batch (sizes "
-                                  f"{sorted(set(counts.tolist()))[:4]}...): call it per cloud, or use equal-sized clouds")
+        # ragged batch: one launch per cloud (the batched kernel's clouds share one size); same edges, same order as torch_cluster's
+        out, start = [], 0
+        for c in counts.tolist():
+            if k > (c if loop else c - 1):
+                raise RuntimeError(f"knn_graph: k={k} exceeds the {c} candidates of a cloud of this batch")
+            e64, _, _ = ops.knn_graph_batched(x[start:start + c].contiguous().float().unsqueeze(0), k, loop, want_i64=True,
+                                              force_slow_path=force_slow_path)
+            out.append(e64[0] + start)
+            start += c
+        return torch.cat(out, dim=1)
     nb = int(counts.numel())
     e64, _, _ = ops.knn_graph_batched(x.contiguous().float().view(nb, n, 3), k, loop, want_i64=True, force_slow_path=force_slow_path)
     off = (torch.arange(nb, device=x.device, dtype=torch.int64) * n).view(nb, 1, 1)

@@ -131,7 +131,7 @@ def test_knn_beyond_the_tuned_kernels_matches_oracle_bit_exact(pk, n, k, loop):
 
 def test_knn_graph_batch_vector(pk):
     """`knn_graph(x, k, batch=...)` (src/gcnn.py:31; train :1473-1474): a sorted batch vector of equal-sized clouds = one launch of the
-    batched kernel, global node ids, cloud after cloud (torch_cluster's layout); ragged or unsorted batches raise."""
+    batched kernel, global node ids, cloud after cloud (torch_cluster's layout); a ragged batch = one launch per cloud; unsorted raises."""
     g = torch.Generator().manual_seed(11)
     nb, n, k = 3, 257, 9
     x = torch.rand(nb * n, 3, generator=g)
@@ -142,8 +142,9 @@ def test_knn_graph_batch_vector(pk):
     assert bool((batch[got[0]] == batch[got[1]]).all())                       # no edge crosses clouds
     one = pk.knn_graph(x[:n].cuda(), k, batch=torch.zeros(n, dtype=torch.long).cuda(), loop=False).cpu()
     assert torch.equal(one, orc.knn_graph(x[:n], k, loop=False))
-    with pytest.raises(NotImplementedError):
-        pk.knn_graph(x[:2 * n - 1].cuda(), k, batch=batch[:2 * n - 1].cuda(), loop=True)       # ragged
+    rag = pk.knn_graph(x[:2 * n - 7].cuda(), k, batch=batch[:2 * n - 7].cuda(), loop=True).cpu()     # ragged: 257 + 250 points, a launch per cloud
+    ref_rag = torch.cat([orc.knn_graph(x[:n], k, loop=True), orc.knn_graph(x[n:2 * n - 7], k, loop=True) + n], dim=1)
+    assert torch.equal(rag, ref_rag)
     with pytest.raises(RuntimeError):
         pk.knn_graph(x.cuda(), k, batch=batch.flip(0).cuda(), loop=True)                       # not sorted
     with pytest.raises(RuntimeError):
