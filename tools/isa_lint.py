@@ -47,22 +47,36 @@ def regs(tok):
     return frozenset((m.group(1), r) for r in range(int(m.group(2)), int(m.group(3)) + 1))
 
 
+_MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
 def disassemble(path, workdir):
-    """gfx950 disassembly text of an object / shared library built by hipcc (its .hip_fatbin bundle), or None without device code."""
-    fat = os.path.join(workdir, os.path.basename(path) + ".fatbin")
-    co = os.path.join(workdir, os.path.basename(path) + ".co")
+    """gfx950 disassembly text of an object / shared library built by hipcc, or None without device code.  An object's .hip_fatbin
+    section is one offload bundle; a linked library's is the concatenation of its objects' bundles: each is unbundled on its own."""
+    base = os.path.join(workdir, os.path.basename(path))
+    fat = base + ".fatbin"
     r = subprocess.run([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", path, os.path.join(workdir, "discard.o")],
                        capture_output=True, text=True)
     if r.returncode != 0 or not os.path.exists(fat) or os.path.getsize(fat) == 0:
         return None
-    r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--targets={TARGET}", f"--input={fat}", f"--output={co}"],
-                       capture_output=True, text=True)
-    if r.returncode != 0:
+    blob = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(re.escape(_MAGIC), blob)]
+    if not starts:
         return None
-    r = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", "--no-show-raw-insn", co], capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"llvm-objdump failed on {co}: {r.stderr[-400:]}")
-    return r.stdout
+    texts = []
+    for k, a in enumerate(starts):
+        piece, co = f"{base}.{k}.bundle", f"{base}.{k}.co"
+        with open(piece, "wb") as fh:
+            fh.write(blob[a:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        r = subprocess.run([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", f"--targets={TARGET}", f"--input={piece}",
+                            f"--output={co}"], capture_output=True, text=True)
+        if r.returncode != 0 or not os.path.exists(co) or os.path.getsize(co) == 0:
+            continue
+        r = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", co], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"llvm-objdump failed on {co}: {r.stderr[-400:]}")
+        texts.append(r.stdout)
+    return "\n".join(texts) if texts else None
 
 
 def parse(text):
@@ -197,7 +211,10 @@ def lint_file(path, min_cycles, workdir):
 
 
 def default_objects():
-    return sorted(glob.glob(os.path.join(ROOT, "se3_equi_graph_registration_amd", "csrc", "*.o")))
+    """The objects of the in-tree build; without them (a tree that ships only the linked library) the library itself."""
+    objs = sorted(glob.glob(os.path.join(ROOT, "se3_equi_graph_registration_amd", "csrc", "*.o")))
+    so = os.path.join(ROOT, "se3_equi_graph_registration_amd", "libequigspr.so")
+    return objs or ([so] if os.path.exists(so) else [])
 
 
 def run(paths=None, min_cycles=8):
