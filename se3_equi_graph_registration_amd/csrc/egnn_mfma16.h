@@ -255,12 +255,13 @@ struct StageW16 {
                 }
             }
         }
+        if constexpr (!kSlim) {                          // the fp32 images of W2 / W6 (the slim image has fragments only)
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            if constexpr (kSlim) break;
-            const int t = threadIdx.x + NT * u, i = t >> 5, k = t & 31;
-            v2[u] = (i / FH == k / FH) ? lw[LL::w2_off(i, k)] : 0.0f;      // block-diagonal over the heads
-            v6[u] = lw[LL::w6 + i * F + k];
+            for (int u = 0; u < PER; ++u) {
+                const int t = threadIdx.x + NT * u, i = t >> 5, k = t & 31;
+                v2[u] = (i / FH == k / FH) ? lw[LL::w2_off(i, k)] : 0.0f;      // block-diagonal over the heads
+                v6[u] = lw[LL::w6 + i * F + k];
+            }
         }
 #pragma unroll
         for (int u = 0; u < PG; ++u) {
@@ -288,15 +289,16 @@ struct StageW16 {
         }
     }
     __device__ __forceinline__ void store(float* sm) const {
+        if constexpr (!kSlim) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            if constexpr (kSlim) break;
-            const int t = threadIdx.x + NT * u, i = t >> 5, k = t & 31;
-            sm[W16::o_w2 + i * W16::WS + k] = v2[u];
-            sm[W16::o_w6 + i * W16::WS + k] = v6[u];
-            if (kBwd) {
-                sm[W16::o_w2t + k * W16::WS + i] = v2[u];
-                sm[W16::o_w6t + k * W16::WS + i] = v6[u];
+            for (int u = 0; u < PER; ++u) {
+                const int t = threadIdx.x + NT * u, i = t >> 5, k = t & 31;
+                sm[W16::o_w2 + i * W16::WS + k] = v2[u];
+                sm[W16::o_w6 + i * W16::WS + k] = v6[u];
+                if (kBwd) {
+                    sm[W16::o_w2t + k * W16::WS + i] = v2[u];
+                    sm[W16::o_w6t + k * W16::WS + i] = v6[u];
+                }
             }
         }
 #pragma unroll
