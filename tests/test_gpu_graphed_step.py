@@ -3,6 +3,7 @@ slots: the weights it produces must equal the eager loop's BIT FOR BIT, with dis
 middle (rejected on the device), a short last batch, a learning-rate change between epochs, and on the multi-rank code path
 (1-rank RCCL group, all-reduce inside the graph and between two graphs, a step one rank has no data for)."""
 import copy
+import itertools
 import json
 import os
 import subprocess
@@ -78,6 +79,32 @@ def test_graphed_loop_equals_eager_loop_bit_for_bit(pk):
     train.train_one_epoch(m_g, batches[:4], o_g, "cuda", 1, log_interval=0, k=8)
     assert st.steps_eager == 1 and st.steps_replayed == 10
     _assert_same(_state(m_e, o_e), _state(m_g, o_g))
+
+
+@pytest.mark.parametrize("n,layers,k,steps", [(256, 2, 8, 1500), (2048, 4, 20, 600)])
+def test_build_ahead_soak_equals_the_serial_form_bit_for_bit(pk, n, layers, k, steps):
+    """Round 6 runs every slot's k-NN + index build on a second stream one step ahead (GraphedStep(build_ahead=True), the default).  A race
+    between a build, the H2D copy of its slot or the step that reads its index arrays would show as weights that differ from the serial
+    form (build inside the step graph) -- rarely, so this is a soak: 1 500 steps of a small model and 600 of the BASELINE shape (2 048
+    points, k = 20, 4 layers) over 48 distinct batches, in both forms and the build-ahead form twice; weights, Adam moments and the step count must agree to the last bit in all three runs."""
+    from se3_equi_graph_registration_amd import train
+    ring = _batches(pk, 48, B=2 if n == 256 else 1, n=n)
+
+    def run(ahead):
+        m = _model(pk, layers=layers, n=n)
+        o = train.make_optimizer(m, lr=2e-4)
+        st = train.GraphedStep(m, o, k=k, build_ahead=ahead)
+        loss = st.run(itertools.islice(itertools.cycle(ring), steps), log_interval=0, skip_nonfinite=True)
+        assert st.steps_replayed == steps - 1 and (st.build_graphs is not None) == ahead
+        return _state(m, o), loss, o.adam.guard_stats()
+
+    a, la, sa = run(True)
+    b, lb, sb = run(False)
+    c, lc, sc = run(True)
+    assert sa["applied"] + sa["skipped"] == steps and sa == sb == sc, (sa, sb, sc)
+    _assert_same(a, b)
+    _assert_same(a, c)
+    assert la == lb == lc
 
 
 def test_nonfinite_step_is_rejected_on_the_device_and_short_last_batch_runs_eagerly(pk):
