@@ -409,6 +409,16 @@ int equigspr_gcn_conv_forward(const float* x, int32_t n_batch, int32_t c_in, int
                               const float* weight, const float* bias, float* y, void* stream);
 /* GlobalPooling.forward :90-94: x [B,C,n] -> out [B,2C] = [max over n | mean over n] */
 int equigspr_gcn_global_pool(const float* x, int32_t n_batch, int32_t channels, int32_t n, float* out, void* stream);
+/* Backward of the two launches above (ABI 14; the reference never trains these layers -- gcnLayer.py:100-107 is a demo -- here they are
+ * trainable modules).  Weights: grad_w [c_out, c_in] = sum_{b,i} grad_y[b,o,i] agg[b,c,i] with agg = x aggregated over the adjacency
+ * (recomputed into agg_scratch [n_batch, c_in, n]; dense-adjacency callers pass x @ adj there and adj_ptr = NULL), grad_b [c_out] (or NULL).
+ * The INPUT gradient is equigspr_gcn_conv_forward itself on grad_y with the transposed weight and no bias (symmetric adjacency).
+ * Pooling: grad_x[b,c,i] = grad_out[b, C + c] / n + (x == max ? grad_out[b, c] / #ties : 0)  (torch.amax's split between ties). */
+int equigspr_gcn_conv_backward_weights(const float* x, const float* grad_y, int32_t n_batch, int32_t c_in, int32_t c_out, int32_t n,
+                                       const int32_t* adj_ptr, const int32_t* adj_idx, const float* adj_val, int32_t adj_clouds,
+                                       float* agg_scratch, float* grad_w, float* grad_b, void* stream);
+int equigspr_gcn_global_pool_backward(const float* x, const float* grad_out, int32_t n_batch, int32_t channels, int32_t n,
+                                      float* grad_x, void* stream);
 
 /* ---- A16: real spherical harmonics and the equivariant kernel basis (tools/) --------------------------
  * equigspr_sh_forward: all degrees 0..max_l in one pass; Y row layout [(max_l+1)^2], degree l at [l^2, (l+1)^2),

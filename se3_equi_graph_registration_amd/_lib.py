@@ -85,6 +85,9 @@ _SIGNATURES = {
     "equigspr_gcn_conv_forward": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                                  c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "equigspr_gcn_global_pool": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "equigspr_gcn_conv_backward_weights": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                                          c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "equigspr_gcn_global_pool_backward": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     "equigspr_sh_forward": (ctypes.c_int, [c_void_p, c_int32, ctypes.c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "equigspr_sh_basis_forward": (ctypes.c_int, [c_void_p, ctypes.c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "equigspr_irrep_moments_size": (c_int64, [POINTER(IrrepConfig), c_int32, c_int32]),

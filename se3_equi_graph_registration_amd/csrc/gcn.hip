@@ -164,6 +164,75 @@ __global__ __launch_bounds__(256) void gcn_pool_kernel(const float* __restrict__
     }
 }
 
+// ---- backward of the layer (round 6; the reference never trains it, gcnLayer.py:100-107 is a demo: here it is a trainable module) ----------
+// agg[b][c][i] = sum_{(j,v) in adj(i)} v x[b][c][j]: the aggregation half of the forward alone (for the weight gradient)
+__global__ __launch_bounds__(256) void gcn_agg_kernel(const float* __restrict__ x, int n_batch, int c_in, int n, const int* __restrict__ ptr,
+                                                      const int* __restrict__ idx, const float* __restrict__ val, int adj_clouds,
+                                                      float* __restrict__ agg) {
+    const int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= n_batch * n) return;
+    const int b = gi / n, i = gi - b * n;
+    const float* xb = x + (size_t)b * c_in * n;
+    const int node = (adj_clouds == 1 ? 0 : b) * n + i;
+    const int lo = ptr[node], hi = ptr[node + 1];
+    for (int c = 0; c < c_in; ++c) {
+        float a = 0.0f;
+        for (int p = lo; p < hi; ++p) a = fmaf(val[p], xb[(size_t)c * n + idx[p]], a);
+        agg[((size_t)b * c_in + c) * n + i] = a;
+    }
+}
+// dW[o][c] = sum_{b,i} dy[b][o][i] agg[b][c][i]; blockIdx.y == c_in: db[o] = sum_{b,i} dy[b][o][i].  One workgroup per entry, fixed tree.
+__global__ __launch_bounds__(256) void gcn_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ agg, int n_batch, int c_in,
+                                                        int c_out, int n, float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ float red[256];
+    const int o = blockIdx.x, c = blockIdx.y;
+    const bool bias = c == c_in;
+    float a = 0.0f;
+    for (int b = 0; b < n_batch; ++b) {
+        const float* g = dy + ((size_t)b * c_out + o) * n;
+        const float* r = bias ? nullptr : agg + ((size_t)b * c_in + c) * n;
+        for (int i = threadIdx.x; i < n; i += 256) a = bias ? a + g[i] : fmaf(g[i], r[i], a);
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (bias) { if (db) db[o] = red[0]; }
+        else dw[(size_t)o * c_in + c] = red[0];
+    }
+}
+// GlobalPooling backward: grad_x[b][c][i] = g_mean / n + (x == max ? g_max / #ties : 0)   (torch.amax's even split between ties)
+__global__ __launch_bounds__(256) void gcn_pool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout, int channels, int n,
+                                                           float* __restrict__ gx) {
+    __shared__ float smax[256];
+    __shared__ int scnt[256];
+    const int b = blockIdx.x / channels, c = blockIdx.x - b * channels;
+    const float* row = x + ((size_t)b * channels + c) * n;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, row[i]);
+    smax[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + off]);
+        __syncthreads();
+    }
+    m = smax[0];
+    int k = 0;
+    for (int i = threadIdx.x; i < n; i += 256) k += row[i] == m ? 1 : 0;
+    scnt[threadIdx.x] = k;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) scnt[threadIdx.x] += scnt[threadIdx.x + off];
+        __syncthreads();
+    }
+    const float gmax = gout[(size_t)b * 2 * channels + c] / (float)scnt[0], gmean = gout[(size_t)b * 2 * channels + channels + c] / (float)n;
+    float* out = gx + ((size_t)b * channels + c) * n;
+    for (int i = threadIdx.x; i < n; i += 256) out[i] = gmean + (row[i] == m ? gmax : 0.0f);
+}
+
 }  // namespace eq
 
 extern "C" int equigspr_gcn_build_graph(const float* coords, int32_t n_clouds, int32_t n, int32_t k, const int32_t* nbr,
@@ -226,5 +295,35 @@ extern "C" int equigspr_gcn_global_pool(const float* x, int32_t n_batch, int32_t
     EQ_CHECK_ARG(x && out && n_batch >= 1 && channels >= 1 && n >= 1, EQUIGSPR_EINVAL, "gcn_global_pool: bad args");
     hipLaunchKernelGGL(gcn_pool_kernel, dim3(n_batch * channels), dim3(256), 0, (hipStream_t)stream, x, channels, n, out);
     EQ_CHECK_LAUNCH("gcn_global_pool");
+    return 0;
+}
+
+/* Backward of equigspr_gcn_conv_forward for the weights: agg_scratch [n_batch, c_in, n] (sparse adjacency: filled here; dense path: the
+ * caller passes x @ adj in it and adj_ptr == NULL), grad_w [c_out, c_in], grad_b [c_out] or NULL.  The input gradient is the forward
+ * itself on grad_y with the transposed weight (the normalised adjacency is symmetric). */
+extern "C" int equigspr_gcn_conv_backward_weights(const float* x, const float* grad_y, int32_t n_batch, int32_t c_in, int32_t c_out, int32_t n,
+                                                  const int32_t* adj_ptr, const int32_t* adj_idx, const float* adj_val, int32_t adj_clouds,
+                                                  float* agg_scratch, float* grad_w, float* grad_b, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(grad_y && agg_scratch && grad_w && n_batch >= 1 && n >= 1 && c_in >= 1 && c_out >= 1, EQUIGSPR_EINVAL,
+                 "gcn_conv_backward_weights: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (adj_ptr) {
+        EQ_CHECK_ARG(x && adj_idx && adj_val && (adj_clouds == 1 || adj_clouds == n_batch), EQUIGSPR_EINVAL,
+                     "gcn_conv_backward_weights: adjacency must hold 1 or n_batch clouds");
+        hipLaunchKernelGGL(gcn_agg_kernel, dim3(ceil_div((long long)n_batch * n, 256)), dim3(256), 0, s, x, n_batch, c_in, n, adj_ptr, adj_idx,
+                           adj_val, adj_clouds, agg_scratch);
+    }
+    hipLaunchKernelGGL(gcn_wgrad_kernel, dim3(c_out, c_in + 1), dim3(256), 0, s, grad_y, agg_scratch, n_batch, c_in, c_out, n, grad_w, grad_b);
+    EQ_CHECK_LAUNCH("gcn_conv_backward_weights");
+    return 0;
+}
+
+extern "C" int equigspr_gcn_global_pool_backward(const float* x, const float* grad_out, int32_t n_batch, int32_t channels, int32_t n,
+                                                 float* grad_x, void* stream) {
+    using namespace eq;
+    EQ_CHECK_ARG(x && grad_out && grad_x && n_batch >= 1 && channels >= 1 && n >= 1, EQUIGSPR_EINVAL, "gcn_global_pool_backward: bad args");
+    hipLaunchKernelGGL(gcn_pool_bwd_kernel, dim3(n_batch * channels), dim3(256), 0, (hipStream_t)stream, x, grad_out, channels, n, grad_x);
+    EQ_CHECK_LAUNCH("gcn_global_pool_backward");
     return 0;
 }

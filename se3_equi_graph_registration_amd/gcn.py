@@ -4,8 +4,9 @@
 than as the reference's scipy ``[N, N]`` matrix; ``GraphConvolution`` consumes it in one fused gather + 1x1-conv
 kernel (a dense ``[B, N, N]`` adjacency tensor, as the reference's ``forward`` signature allows, is also accepted:
 the product with it is one library GEMM, the conv stays in HIP); ``GlobalPooling`` is a block reduction.
-The reference imports these layers but never calls them; here they are trainable: under grad the backward re-runs the layer
-in device ops on the saved inputs (ops.hip_forward_aten_backward)."""
+The reference imports these layers but never calls them; here they are trainable, forward AND backward in HIP (round 6:
+``_GcnConvFn`` / ``_GcnPoolFn`` over ``equigspr_gcn_conv_backward_weights`` / ``equigspr_gcn_global_pool_backward``; the input
+gradient of the convolution is the forward kernel itself on the output gradient with the transposed weight)."""
 from __future__ import annotations
 
 import numpy as np
@@ -13,7 +14,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .ops import _need, _p, _stream, knn_graph_batched, hip_forward_aten_backward
+from .ops import _need, _p, _stream, knn_graph_batched
 
 
 class KnnAdjacency:
@@ -61,6 +62,83 @@ def build_graph(coordinates, k=25, device="cuda"):
     return KnnAdjacency(ptr, idx, val, nc, n, squeeze)
 
 
+def _gcn_conv(x, w2, bias, adj, sparse, dense_adj):
+    """y = W (x aggregated over adj) + bias through the HIP kernel; ``adj``: KnnAdjacency (sparse) or ignored (dense: ``dense_adj``)."""
+    b, c_in, n = x.shape
+    c_out = w2.shape[0]
+    L = _lib.lib()
+    y = torch.empty(b, c_out, n, dtype=torch.float32, device=x.device)
+    if sparse:
+        _lib.check(L.equigspr_gcn_conv_forward(_p(x), b, c_in, c_out, n, _p(adj.ptr), _p(adj.idx), _p(adj.val), adj.n_clouds,
+                                               _p(w2), _p(bias), _p(y), _stream()), "gcn_conv_forward")
+    else:
+        agg = torch.bmm(x, dense_adj).contiguous()       # plain library GEMM
+        _lib.check(L.equigspr_gcn_conv_forward(_p(agg), b, c_in, c_out, n, None, None, None, 0, _p(w2), _p(bias), _p(y), _stream()),
+                   "gcn_conv_forward")
+    return y
+
+
+class _GcnConvFn(torch.autograd.Function):
+    """GraphConvolution.forward (gcnLayer.py:70-80) with a HIP backward: grad_x = the forward kernel on grad_y with W^T (the normalised
+    adjacency is symmetric; a dense adjacency is transposed explicitly), grad_W / grad_b from ``equigspr_gcn_conv_backward_weights``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, adj, sparse):
+        c_out, c_in = weight.shape[0], x.shape[1]
+        w2 = weight.reshape(c_out, c_in).contiguous()
+        dense = None if sparse else (adj if adj.dim() == 3 else adj[None]).expand(x.shape[0], -1, -1).contiguous()
+        y = _gcn_conv(x, w2, None if bias is None else bias.contiguous(), adj, sparse, dense)
+        ctx.save_for_backward(x, w2, dense if dense is not None else x.new_empty(0))
+        ctx.adj, ctx.sparse, ctx.has_bias, ctx.wshape = adj, sparse, bias is not None, weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w2, dense = ctx.saved_tensors
+        gy = gy.contiguous().float()
+        b, c_in, n = x.shape
+        c_out = w2.shape[0]
+        L = _lib.lib()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _gcn_conv(gy, w2.t().contiguous(), None, ctx.adj, ctx.sparse, None if ctx.sparse else dense.transpose(1, 2).contiguous())
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw = torch.empty(c_out, c_in, dtype=torch.float32, device=x.device)
+            gb = torch.empty(c_out, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            if ctx.sparse:
+                agg = torch.empty(b, c_in, n, dtype=torch.float32, device=x.device)
+                _lib.check(L.equigspr_gcn_conv_backward_weights(_p(x), _p(gy), b, c_in, c_out, n, _p(ctx.adj.ptr), _p(ctx.adj.idx),
+                                                                _p(ctx.adj.val), ctx.adj.n_clouds, _p(agg), _p(gw), _p(gb), _stream()),
+                           "gcn_conv_backward_weights")
+            else:
+                agg = torch.bmm(x, dense).contiguous()
+                _lib.check(L.equigspr_gcn_conv_backward_weights(None, _p(gy), b, c_in, c_out, n, None, None, None, 0, _p(agg), _p(gw), _p(gb),
+                                                                _stream()), "gcn_conv_backward_weights")
+            gw = gw.reshape(ctx.wshape)
+        return gx, gw, gb, None, None
+
+
+class _GcnPoolFn(torch.autograd.Function):
+    """GlobalPooling.forward (gcnLayer.py:90-94): max || mean over the points; HIP backward (ties of the max share its gradient evenly)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        b, c, n = x.shape
+        out = torch.empty(b, 2 * c, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().equigspr_gcn_global_pool(_p(x), b, c, n, _p(out), _stream()), "gcn_global_pool")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        b, c, n = x.shape
+        gx = torch.empty_like(x)
+        _lib.check(_lib.lib().equigspr_gcn_global_pool_backward(_p(x), _p(g.contiguous().float()), b, c, n, _p(gx), _stream()),
+                   "gcn_global_pool_backward")
+        return gx
+
+
 def _wants_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
@@ -72,53 +150,24 @@ class GraphConvolution(nn.Module):
 
     def forward(self, adj, x):
         """``x [B, C_in, n]``; ``adj``: ``KnnAdjacency`` (1 or B clouds) or dense ``[B, n, n]`` -> ``[B, C_out, n]``.
-        Under grad the backward re-runs the layer in device ops (ops.hip_forward_aten_backward); the adjacency is a constant."""
+        Forward and backward are HIP launches (``_GcnConvFn``); the adjacency is a constant."""
         x = _need(x.contiguous().float(), "x", torch.float32, 3)
         b, c_in, n = x.shape
-        c_out = self.conv.out_channels
-        L = _lib.lib()
         sparse = isinstance(adj, KnnAdjacency)
         if sparse:
             if adj.n != n or adj.n_clouds not in (1, b):
                 raise RuntimeError(f"GraphConvolution: adjacency ({adj.n_clouds} x {adj.n}) does not match x {tuple(x.shape)}")
         else:
             adj = _need(adj, "adj", torch.float32, 3)
-
-        def hip(x_, w_, bias_):
-            w2 = w_.reshape(c_out, c_in).contiguous()
-            y = torch.empty(b, c_out, n, dtype=torch.float32, device=x_.device)
-            if sparse:
-                _lib.check(L.equigspr_gcn_conv_forward(_p(x_), b, c_in, c_out, n, _p(adj.ptr), _p(adj.idx), _p(adj.val), adj.n_clouds,
-                                                       _p(w2), _p(bias_), _p(y), _stream()), "gcn_conv_forward")
-            else:
-                agg = torch.bmm(x_, adj).contiguous()       # plain library GEMM
-                _lib.check(L.equigspr_gcn_conv_forward(_p(agg), b, c_in, c_out, n, None, None, None, 0, _p(w2), _p(bias_), _p(y), _stream()),
-                           "gcn_conv_forward")
-            return y
-
-        def aten(x_, w_, bias_):
-            dense = adj.to_dense() if sparse else adj
-            dense = dense if dense.dim() == 3 else dense[None]
-            out = torch.einsum("oc,bcn->bon", w_.reshape(c_out, c_in), torch.matmul(x_, dense))      # gcnLayer.py:76-79
-            return out if bias_ is None else out + bias_[None, :, None]
-
         w, bias = self.conv.weight, self.conv.bias
         if _wants_grad(x, w, bias):
-            return hip_forward_aten_backward(hip, aten, (x, w, bias))
-        return hip(x, w.detach(), None if bias is None else bias.detach().contiguous())
+            return _GcnConvFn.apply(x, w, bias, adj, sparse)
+        with torch.no_grad():
+            return _GcnConvFn.apply(x, w.detach(), None if bias is None else bias.detach(), adj, sparse)
 
 
 class GlobalPooling(nn.Module):
     def forward(self, x):
-        """``x [B, C, n]`` -> ``[B, 2C]`` = max over points || mean over points (gcnLayer.py:90-94)."""
+        """``x [B, C, n]`` -> ``[B, 2C]`` = max over points || mean over points (gcnLayer.py:90-94); HIP forward and backward."""
         x = _need(x.contiguous().float(), "x", torch.float32, 3)
-        b, c, n = x.shape
-
-        def hip(x_):
-            out = torch.empty(b, 2 * c, dtype=torch.float32, device=x_.device)
-            _lib.check(_lib.lib().equigspr_gcn_global_pool(_p(x_), b, c, n, _p(out), _stream()), "gcn_global_pool")
-            return out
-
-        if _wants_grad(x):
-            return hip_forward_aten_backward(hip, lambda x_: torch.cat([x_.amax(dim=2), x_.mean(dim=2)], dim=1), (x,))
-        return hip(x)
+        return _GcnPoolFn.apply(x)

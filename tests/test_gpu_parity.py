@@ -1098,9 +1098,24 @@ def test_gcn_conv_and_pool_golden(pk, golden_dir):
     (layer.conv(torch.matmul(xr, adj.to_dense()[None] if adj.to_dense().dim() == 2 else adj.to_dense())) * gy).sum().backward()
     for a, b_ in zip(g_sparse, (xr.grad, layer.conv.weight.grad, layer.conv.bias.grad)):
         assert torch.allclose(a, b_, rtol=1e-4, atol=1e-4 * float(b_.abs().max()))
-    pg = y_sparse.clone().requires_grad_(True)
-    pk.GlobalPooling()(pg).sum().backward()
-    assert pg.grad is not None and bool(torch.isfinite(pg.grad).all()) and float(pg.grad.abs().sum()) > 0
+    ref_grads = (xr.grad.clone(), layer.conv.weight.grad.clone(), layer.conv.bias.grad.clone())
+    # ... the dense-adjacency call form through the same HIP backward (round 6: _GcnConvFn; the adjacency is transposed explicitly there)
+    dense = adj.to_dense()
+    dense = (dense[None] if dense.dim() == 2 else dense).contiguous()
+    xd = x.clone().requires_grad_(True)
+    layer.zero_grad()
+    (layer(dense, xd) * gy).sum().backward()
+    for a, b_ in zip((xd.grad, layer.conv.weight.grad, layer.conv.bias.grad), ref_grads):
+        assert torch.allclose(a, b_, rtol=1e-4, atol=1e-4 * float(b_.abs().max()))
+    # GlobalPooling: HIP backward against autograd of max || mean (ties of the max share the gradient, as torch.amax does)
+    gp = torch.randn(y_sparse.shape[0], 2 * y_sparse.shape[1], device="cuda")
+    pg = y_sparse.clone()
+    pg[0, 0, 5] = pg[0, 0, 9] = pg[0, 0].max() + 1.0                       # a tie of the maximum
+    pg.requires_grad_(True)
+    (pk.GlobalPooling()(pg) * gp).sum().backward()
+    pr = pg.detach().clone().requires_grad_(True)
+    (torch.cat([pr.amax(dim=2), pr.mean(dim=2)], dim=1) * gp).sum().backward()
+    assert torch.allclose(pg.grad, pr.grad, rtol=1e-6, atol=1e-7) and float(pg.grad[0, 0, 5]) == float(pg.grad[0, 0, 9])
 
 
 @pytest.mark.parametrize("n,k,c_in,c_out", [(1024, 25, 3, 64), (257, 5, 33, 7)])
