@@ -464,6 +464,20 @@ int equigspr_pointnet_layer_forward(const float* h, const float* pos, int32_t n_
 /* torch_geometric.nn.global_max_pool(x, batch) (:95) for an ascending batch vector: out [n_batches, channels] */
 int equigspr_global_max_pool(const float* x, const int64_t* batch_sorted, int32_t n_nodes, int32_t channels,
                              int32_t n_batches, float* out, void* stream);
+/* Backward of the two entries above (ABI 14; the reference builds a fresh, untrained PointNet per batch at train :1034 and never
+ * optimises it -- here the modules are trainable).  Layer: src / tptr / tperm as in the forward, sptr / sperm = the edges sorted by
+ * SOURCE (DeviceGraph.rptr / rperm); grad_out [n, c_out]; grad_h [n, c_in], grad_pos [n, 3], grad_w1 [c_out, c_in + 3], grad_b1 [c_out],
+ * grad_w2 [c_out, c_out], grad_b2 [c_out]: each may be NULL, written (not accumulated).  The maximum's gradient goes to ONE incoming edge
+ * per channel -- the first maximum in the target's segment, as torch_geometric's max aggregation routes it.  work:
+ * equigspr_pointnet_layer_backward_work_size floats.  Pool: grad_x[i][f] = grad_out[b][f] / #ties where x[i][f] is its graph's maximum. */
+int64_t equigspr_pointnet_layer_backward_work_size(int32_t n_nodes, int32_t n_edges, int32_t c_in, int32_t c_out);
+int equigspr_pointnet_layer_backward(const float* h, const float* pos, int32_t n_nodes, int32_t n_edges, int32_t c_in, int32_t c_out,
+                                     const int32_t* src, const int32_t* tptr, const int32_t* tperm, const int32_t* sptr,
+                                     const int32_t* sperm, const float* w1, const float* b1, const float* w2, const float* b2,
+                                     int32_t relu_out, const float* grad_out, float* work, float* grad_h, float* grad_pos,
+                                     float* grad_w1, float* grad_b1, float* grad_w2, float* grad_b2, void* stream);
+int equigspr_global_max_pool_backward(const float* x, const int64_t* batch_sorted, int32_t n_nodes, int32_t channels,
+                                      int32_t n_batches, const float* grad_out, float* grad_x, void* stream);
 
 /* ---- N3: correspondence construction (data_preprocess/3DMatch_Feature.py:157-196, test split :331-351) ----------
  * nearest_idx[i] = argmin_j sqrt(2 - 2 <src_desc_i, tgt_desc_j> + 1e-6) (first minimum, as np.argmin; unit-norm descriptors),

@@ -103,6 +103,11 @@ _SIGNATURES = {
     "equigspr_eval_metrics": (ctypes.c_int, [c_void_p] * 5 + [c_int32, c_int32, ctypes.c_double, c_void_p, c_void_p]),
     "equigspr_pointnet_layer_forward": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 7 + [c_int32, c_void_p, c_void_p, c_void_p]),
     "equigspr_global_max_pool": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    "equigspr_pointnet_layer_backward_work_size": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+    "equigspr_pointnet_layer_backward": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p,
+                                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "equigspr_global_max_pool_backward": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "equigspr_step_loss_forward": (ctypes.c_int, [c_void_p] * 4 + [c_int32] + [c_void_p] * 4),
     "equigspr_step_loss_backward": (ctypes.c_int, [c_void_p] * 4 + [c_int32] + [c_void_p] * 3),
     "equigspr_match_descriptors": (ctypes.c_int, [c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

@@ -1221,13 +1221,16 @@ def test_pointnet_golden(pk, golden_dir):
     # trainable: the whole encoder's gradients against the oracle's autograd (fp64)
     gy = torch.randn(pooled.shape, generator=torch.Generator().manual_seed(2)).cuda()
     feats = t("feats").clone().requires_grad_(True)
+    posg = t("pos").clone().requires_grad_(True)                 # round 6: HIP backward, the coordinates' gradient included
     net.zero_grad()
-    (net(t("pos"), feats, t("edge_index"), t("batch")) * gy).sum().backward()
+    (net(posg, feats, t("edge_index"), t("batch")) * gy).sum().backward()
     w = {k: v.detach().cpu().double().requires_grad_(True) for k, v in net.state_dict().items()}
     fr = t("feats").cpu().double().requires_grad_(True)
-    _, ref = orc.pointnet_forward(w, t("pos").cpu().double(), fr, t("edge_index").cpu(), t("batch").cpu())
+    pr = t("pos").cpu().double().requires_grad_(True)
+    _, ref = orc.pointnet_forward(w, pr, fr, t("edge_index").cpu(), t("batch").cpu())
     (ref * gy.cpu().double()).sum().backward()
     assert torch.allclose(feats.grad.cpu().double(), fr.grad, rtol=2e-4, atol=2e-4 * float(fr.grad.abs().max()))
+    assert torch.allclose(posg.grad.cpu().double(), pr.grad, rtol=2e-4, atol=2e-4 * float(pr.grad.abs().max()))
     for name, p_ in net.named_parameters():
         assert torch.allclose(p_.grad.cpu().double(), w[name].grad, rtol=2e-4, atol=2e-4 * float(w[name].grad.abs().max()) + 1e-9), name
 
