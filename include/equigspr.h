@@ -307,6 +307,14 @@ int equigspr_adam_step_guarded(int32_t n_buckets, float* const* params, float* c
 int equigspr_so3_tensor_product_forward(const float* x, int32_t n_rows, int32_t input_dim, int32_t output_dim,
                                         const float* w1, const float* b1, const float* w2, const float* b2,
                                         float* w1t_scratch, float* y, void* stream);
+/* Backward (ABI 14): grad_y [n_rows, 32] -> grad_x [n_rows, 32], grad_w1 [64, 1024], grad_b1 [64], grad_w2 [32, 64], grad_b2 [32] (each may be
+ * NULL; written, not accumulated).  The [n_rows, D*D] tensor product is not materialised here either: the hidden layer is recomputed by the
+ * forward's first product, dW1 forms its B operand D x_i x_j on the fly (K = rows, 32x32x2 MFMA), grad_x contracts G = W1^T dh block by
+ * block in registers.  work: equigspr_so3_tensor_product_backward_work_size(n_rows) floats.  Deterministic. */
+int64_t equigspr_so3_tensor_product_backward_work_size(int32_t n_rows);
+int equigspr_so3_tensor_product_backward(const float* x, const float* grad_y, int32_t n_rows, int32_t input_dim, int32_t output_dim,
+                                         const float* w1, const float* b1, const float* w2, float* work, float* grad_x,
+                                         float* grad_w1, float* grad_b1, float* grad_w2, float* grad_b2, void* stream);
 
 /* ---- N4: typed irrep-basis message passing (ABI 13: one kernel path, forward AND backward) -----------
  * The layer the reference's basis (tools/basis.py::get_basis :153-205, tools/irr_repr.py:103-104,

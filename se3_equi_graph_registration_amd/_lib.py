@@ -82,6 +82,9 @@ _SIGNATURES = {
     "equigspr_so3_tensor_product_forward": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 7),
     "equigspr_gcn_build_graph": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32] + [c_void_p] * 11),
     "equigspr_gcn_adjacency_to_dense": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "equigspr_so3_tensor_product_backward_work_size": (c_int64, [c_int32]),
+    "equigspr_so3_tensor_product_backward": (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "equigspr_gcn_conv_forward": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                                  c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "equigspr_gcn_global_pool": (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),

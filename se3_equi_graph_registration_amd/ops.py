@@ -484,47 +484,6 @@ def fused_eval_head(h_all, x_all, raw_hs, raw_ht, raw_xs, raw_xt, labels, gt_pos
     return R, t, fin[1], wts, top_idx, fin[10]
 
 
-# ----------------------------------------------------------------------------------- optional layers: trainable wrappers
-class _HipForwardAtenBackward(torch.autograd.Function):
-    """Forward = a HIP kernel; backward = the same op re-expressed in PyTorch-ROCm device ops, re-run under autograd on the
-    saved inputs.  For the optional layers the reference imports but never trains (SO3TensorProductLayer, PointNet,
-    GraphConvolution, poolings): they become ordinary trainable ``nn.Module``s without hand-written backward kernels --
-    PyTorch as plumbing, nothing leaves the device.  ``n_t`` leading tensor arguments are differentiable inputs."""
-
-    @staticmethod
-    def forward(ctx, hip_forward, aten_forward, n_t, *args):
-        tensors, rest = args[:n_t], args[n_t:]
-        with torch.no_grad():
-            out = hip_forward(*tensors, *rest)
-        ctx.save_for_backward(*[t for t in tensors if t is not None])
-        ctx.mask = [t is not None for t in tensors]
-        ctx.aten, ctx.rest, ctx.n_t = aten_forward, rest, n_t
-        return out
-
-    @staticmethod
-    def backward(ctx, gout):
-        saved = list(ctx.saved_tensors)
-        tensors, need = [], []
-        for k, present in enumerate(ctx.mask):
-            t = saved.pop(0).detach() if present else None
-            if t is not None and ctx.needs_input_grad[3 + k] and t.is_floating_point():
-                t = t.requires_grad_(True)
-                need.append((k, t))
-            tensors.append(t)
-        grads = [None] * ctx.n_t
-        if need:
-            with torch.enable_grad():
-                out = ctx.aten(*tensors, *ctx.rest)
-            got = torch.autograd.grad(out, [t for _, t in need], gout.contiguous(), allow_unused=True)
-            for (k, _), gk in zip(need, got):
-                grads[k] = gk
-        return (None, None, None, *grads, *([None] * len(ctx.rest)))
-
-
-def hip_forward_aten_backward(hip_forward, aten_forward, tensors, rest=()):
-    return _HipForwardAtenBackward.apply(hip_forward, aten_forward, len(tensors), *tensors, *rest)
-
-
 # ----------------------------------------------------------------------------------- pose loss / Adam
 class _PoseLossFn(torch.autograd.Function):
     @staticmethod

@@ -86,17 +86,6 @@ class PointNetLayer(nn.Module):
         super().__init__()
         self.mlp = nn.Sequential(nn.Linear(in_channels + 3, out_channels), nn.ReLU(), nn.Linear(out_channels, out_channels))
 
-    @staticmethod
-    def _aten(h, pos, w1, b1, w2, b2, row, col, relu_out):
-        """PointNetLayer.forward :61-68 in device ops (backward recompute): max over incoming edges of mlp([h_j, pos_j - pos_i]),
-        0 for nodes without incoming edges."""
-        j, i = row.long(), col.long()
-        msg = torch.cat([h[j], pos[j] - pos[i]], dim=-1)
-        msg = torch.addmm(b2, torch.relu(torch.addmm(b1, msg, w1.t())), w2.t())
-        out = torch.zeros(h.shape[0], msg.shape[1], dtype=msg.dtype, device=msg.device)
-        out = out.scatter_reduce(0, i[:, None].expand_as(msg), msg, reduce="amax", include_self=False)
-        return torch.relu(out) if relu_out else out
-
     def forward(self, h, pos, edge_index, _relu_out=False):
         h = _need(h.contiguous().float(), "h", torch.float32, 2)
         pos = _need(pos.contiguous().float(), "pos", torch.float32, 2)
