@@ -101,7 +101,12 @@ class _GcnConvFn(torch.autograd.Function):
         L = _lib.lib()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _gcn_conv(gy, w2.t().contiguous(), None, ctx.adj, ctx.sparse, None if ctx.sparse else dense.transpose(1, 2).contiguous())
+            dense_t = None if ctx.sparse else dense.transpose(1, 2).contiguous()
+            if c_out <= 64:
+                gx = _gcn_conv(gy, w2.t().contiguous(), None, ctx.adj, ctx.sparse, dense_t)
+            else:       # the kernel aggregates <= 64 channels per thread: mix the channels first (one library GEMM), aggregate with W = I
+                mixed = torch.matmul(w2.t(), gy).contiguous()
+                gx = _gcn_conv(mixed, torch.eye(c_in, dtype=torch.float32, device=x.device), None, ctx.adj, ctx.sparse, dense_t)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw = torch.empty(c_out, c_in, dtype=torch.float32, device=x.device)
             gb = torch.empty(c_out, dtype=torch.float32, device=x.device) if ctx.has_bias else None

@@ -1118,6 +1118,25 @@ def test_gcn_conv_and_pool_golden(pk, golden_dir):
     assert torch.allclose(pg.grad, pr.grad, rtol=1e-6, atol=1e-7) and float(pg.grad[0, 0, 5]) == float(pg.grad[0, 0, 9])
 
 
+def test_gcn_backward_wide_output_and_batched_adjacency(pk):
+    """GraphConvolution(3, 128) (more output channels than the kernel aggregates per thread: the input gradient mixes the channels with one
+    library GEMM first) and a per-cloud adjacency of a batch of two: gradients against device autograd of the reference formula."""
+    g = torch.Generator().manual_seed(4)
+    coords = torch.randn(2, 300, 3, generator=g).cuda()
+    x = torch.randn(2, 3, 300, generator=g).cuda()
+    adj = pk.build_graph(coords, k=9)
+    layer = pk.GraphConvolution(3, 128).cuda()
+    gy = torch.randn(2, 128, 300, generator=g).cuda()
+    xg = x.clone().requires_grad_(True)
+    (layer(adj, xg) * gy).sum().backward()
+    got = (xg.grad.clone(), layer.conv.weight.grad.clone(), layer.conv.bias.grad.clone())
+    layer.zero_grad()
+    xr = x.clone().requires_grad_(True)
+    (layer.conv(torch.matmul(xr, adj.to_dense())) * gy).sum().backward()
+    for a, b_ in zip(got, (xr.grad, layer.conv.weight.grad, layer.conv.bias.grad)):
+        assert torch.allclose(a, b_, rtol=1e-4, atol=1e-4 * float(b_.abs().max()))
+
+
 @pytest.mark.parametrize("n,k,c_in,c_out", [(1024, 25, 3, 64), (257, 5, 33, 7)])
 def test_gcn_random_vs_oracle(pk, n, k, c_in, c_out):
     g = torch.Generator().manual_seed(n + k)
