@@ -3,7 +3,8 @@
 #   bash tools/collect_profiles.sh r05_a
 TAG=$1; SRC=gpurun_out/$TAG; DST=profiles
 cp $SRC/bench.json $DST/${TAG}_bench.json
-for w in b1 b16 b16_irreps c4shard c5 c1infer c1infer_b16 irrepgnn; do
+for w in b1 b16 b16_irreps c4shard c5 c1infer c1infer_b16 irrepgnn irrepgnn_b8; do
+  [ -f $SRC/bench_$w.json ] || continue
   cp $SRC/bench_$w.json $DST/${TAG}_bench_$w.json
   cp $SRC/kernel_stats_$w.csv $DST/${TAG}_kernel_stats_$w.csv
   cp $SRC/pmc_$w.json $DST/${TAG}_pmc_$w.json

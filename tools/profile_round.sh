@@ -41,10 +41,11 @@ one b16_irreps 1310720 32 1 --workload c3 --edge-basis irreps --steps 60 --warmu
 one c1infer 81920 32 0 --forward-only --eval-head --steps 300 --warmup 20
 one c1infer_b16 1310720 32 0 --forward-only --eval-head --batch 16 --steps 40 --warmup 5
 one irrepgnn 81920 32 1 --network irreps --steps 60 --warmup 10
+one irrepgnn_b8 655360 32 1 --network irreps --batch 8 --steps 20 --warmup 3
 python3 "$ROOT/tools/in_step_summary.py" "$OUT/in_step.json" "$TAG" $SPECS
 # the default line quotes the evidence above when it sits in profiles/: place this run's files there for the run (on the GPU box only)
 cp "$OUT/in_step.json" "$ROOT/profiles/${TAG}_in_step.json"
-for w in b1 b16 b16_irreps c4shard c5 c1infer c1infer_b16 irrepgnn; do cp "$OUT/pmc_$w.json" "$ROOT/profiles/${TAG}_pmc_$w.json"; done
+for w in b1 b16 b16_irreps c4shard c5 c1infer c1infer_b16 irrepgnn irrepgnn_b8; do cp "$OUT/pmc_$w.json" "$ROOT/profiles/${TAG}_pmc_$w.json"; done
 python3 "$ROOT/bench.py" > "$OUT/bench.json" 2>> "$OUT/bench.err"
 cp "$ROOT/bench_full.json" "$OUT/bench_full.json"
 tail -1 "$OUT/bench.json" | cut -c1-300
