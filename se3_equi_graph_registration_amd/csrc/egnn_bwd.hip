@@ -15,6 +15,12 @@
 // Every workgroup writes its partial weight gradients to a private slab; a reduce kernel sums
 // the slabs in fixed order into the flat gradient block (+=): bitwise reproducible, no atomics.
 #include "egnn_mfma.h"
+// the backward's split-bf16 products are NOT closed instruction groups: the scheduler overlaps them with the surrounding loads and
+// weight-gradient products (16 pairs 206 -> 199 us, hidden_nf 33 259 -> 253 us, 4 instead of 14 spill accesses).  Exact and
+// bit-identical run to run once the kernel has no packed fp32 instructions (egnn_mfma16.h, profiles/r06_pk_margin.txt).
+#ifndef EQ_BF_GUARD
+#define EQ_BF_GUARD 0
+#endif
 #include "egnn_mfma16.h"
 #include "egnn_bwd16.h"
 #include "egnn_edge_fp.h"
@@ -752,6 +758,24 @@ constexpr int kBwd16Waves = 8;
 #endif
 constexpr int bwd16_waves(int kB) { return kB ? EQ_BWD16_NW33 : kBwd16Waves; }
 
+#ifdef EQ_DEBUG_TILE
+// debugging aid (tools/dev/guard_fail_tile.py): the vectors of every chunk's last sub-tile, 64 floats per lane
+__device__ float g_dbg_tile[(size_t)64 * 64 * 8192];
+extern "C" int equigspr_debug_tile(float* host, int n_tiles) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dbg_tile), sizeof(float) * 64 * 64 * (size_t)n_tiles);
+}
+#define EQ_DBG8(slot, v) do { if (sub == 3) { float* p_ = g_dbg_tile + (((size_t)(t0 >> 2) * 64 + lane) * 64) + 8 * (slot); \
+    for (int k_ = 0; k_ < 4; ++k_) { p_[k_] = (v)[0][k_]; p_[4 + k_] = (v)[1][k_]; } } } while (0)
+#else
+#define EQ_DBG8(slot, v) do { } while (0)
+#endif
+#ifdef EQ_DEBUG_BACK
+// debugging aid (tools/dev/guard_fail_pattern.py): the back phase's inputs per edge
+__device__ float g_dbg_back[32 * (1 << 20)];
+extern "C" int equigspr_debug_back(float* host, int n_edges) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_dbg_back), sizeof(float) * 32 * (size_t)n_edges);
+}
+#endif
 template <int H, int A, int kB = 0, bool kBf = W16::use_bf16(true, kB)>
 __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const float* __restrict__ lw, const int* __restrict__ row,
                                                          const int* __restrict__ col, const float* __restrict__ edge_attr,
@@ -878,6 +902,15 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             EdgeGeo eg;
             edge_geometry_mode(basis, xr, xc, eg);
             store_geo_row(sc + C::o_geo + lane * C::GS, eg, attr);
+#ifdef EQ_DEBUG_TILE
+            if (!strided) {
+                float* p_ = g_dbg_tile + (((size_t)ch * 64 + lane) * 64) + 32;
+                for (int k_ = 0; k_ < 12; ++k_) p_[k_] = eg.g[k_];
+                for (int k_ = 0; k_ < 3; ++k_) { p_[12 + k_] = xr[k_]; p_[15 + k_] = xc[k_]; p_[18 + k_] = eg.p[k_]; }
+                p_[21] = eg.pn; p_[22] = eg.inv_nb; p_[23] = eg.inv_na; p_[24] = attr; p_[25] = (float)r; p_[26] = (float)c;
+                for (int k_ = 0; k_ < 3; ++k_) p_[27 + k_] = eg.d[k_];
+            }
+#endif
             ds_buf[lane] = mine ? dot3(eg.d, gxv) : 0.0f;           // dL/ds of the coord head (:264); 0 masks padding edges
             st4(front, f32x4{xr[0], xr[1], xr[2], xc[0]});
             st4(front + 4, f32x4{xc[1], xc[2], gxv[0], gxv[1]});
@@ -910,6 +943,8 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             const PRowsT<kB>& pw = cur;
             Sub16 o;
             tile_forward16<kB, true, kBf>(wsm, bord, geo_rows + i * C::GS, pw, i, g, o);
+            EQ_DBG8(0, o.t1); EQ_DBG8(1, pw.pr); EQ_DBG8(2, pw.pc);
+            { const f32x4 gv_[2] = {lds4(geo_rows + i * C::GS + 4 * g), lds4(geo_rows + i * C::GS + 4 * ((g + 1) & 3))}; EQ_DBG8(3, gv_); }
             if (g == 0) s_buf[el] = o.s;
             // ---- coord head backward: s = w7 . SiLU(q)
             f32x4 dq[2];
@@ -1058,6 +1093,16 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             float gxr[3], gxc[3];
             edge_geometry_backward_mode(basis, xr2, xc2, eg, gg, gd, gxr, gxc);
             const int eo = edge_id(ch);
+#ifdef EQ_DEBUG_BACK
+            {
+                float* dbg_ = g_dbg_back + 32 * (size_t)eo;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) dbg_[k] = gg[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { dbg_[12 + k] = xr2[k]; dbg_[15 + k] = xc2[k]; dbg_[18 + k] = gx2[k]; dbg_[21 + k] = gxr[k]; dbg_[24 + k] = gxc[k]; dbg_[27 + k] = eg.d[k]; }
+                dbg_[30] = s; dbg_[31] = ds_buf[lane];
+            }
+#endif
             const float dtb = kB ? ds_buf[lane] : 0.0f;
             gxr_rows.st4(4 * (size_t)eo, f32x4{gxr[0], gxr[1], gxr[2], dtb}, stream_out);
             gxc_rows.st4(4 * (size_t)eo, f32x4{gxc[0], gxc[1], gxc[2], dtb}, stream_out);

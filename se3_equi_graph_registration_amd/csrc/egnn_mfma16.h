@@ -24,8 +24,14 @@
 // fp64, the fp32 tile's is 3.3e-7).  Default since the end of round 5: 16 pairs forward 0.67 -> 0.73 / backward 0.62 -> 0.68 of the
 // HBM roofline, hidden_nf 33 forward 0.60 -> 0.63, one pair backward 0.44 -> 0.46 (profiles/r05_bf16x3_edge_kernels.txt).  The hidden_nf 33
 // backward keeps the fp32 products (no LDS for the fragments).  ONE path for every graph size: a cloud's outputs do not depend on
-// what else is in the batch.  The product is a CLOSED group (mv16_bf, EQ_BF_GUARD): an operand register reused as a load's
-// destination behind the instruction that reads it was the source of run-to-run different results (part F of that file).
+// what else is in the batch.
+// RUN-TO-RUN DIFFERENT RESULTS (round 5) AND WHAT THEY WERE (round 6, profiles/r06_mfma_hazard_probe.txt): not the matrix instructions.  With
+// packed fp32 instructions in the kernel (v_pk_add / mul / fma_f32) and a schedule that mixes loads or other matrix instructions into the
+// products, the lane-per-edge geometry of ~0.5 % of the 64-edge chunks came out wrong in lanes 48..63 (a v_pk_add_f32 with op_sel
+// returned src0 - 0 from sources that read back correct; its scalar form is exact).  Both edge kernels are therefore compiled WITHOUT
+// packed fp32 instructions (csrc/Makefile EDGE_FLAGS; tools/isa_lint.py checks the objects): exact and bit-identical in every schedule
+// tried, fenced or not.  The forward keeps its products as closed instruction groups (EQ_BF_GUARD 1: 10 % faster at one pair), the
+// backward does not (EQ_BF_GUARD 0 in egnn_bwd.hip: 2.5-4 % faster, fewer spills at hidden_nf 33).
 // 0 = the fp32 products (A/B).
 #ifndef EQ_EDGE_BF16X3
 #define EQ_EDGE_BF16X3 1
@@ -351,12 +357,13 @@ __device__ __forceinline__ void mv16(const float* mat, int i, int g, const f32x4
 }
 // ---- the same product on split-bf16 operands: the lane's own eight features of the L16 layout are the B operand as they stand
 // frag: [3 levels][2 row blocks][64 lanes] fragments of the matrix (build_frag16); acc[bo] += (W v)[16 bo + ...]
-// EQ_BF_GUARD: 1 = the product is a closed group -- nothing is scheduled into it, and every operand register (the six weight
-// fragments, the three split levels of v) stays allocated until its last matrix instruction has been issued and EQ_BF_GUARD_NOPS
-// idle issue slots have passed.  Measured (profiles/r05_bf16x3_edge_kernels.txt part F): without it the compiler reuses an operand
-// register as the destination of a global / LDS load right behind the instruction that reads it (legal if operands are read at
-// issue); when that load returns early (a cache hit) while the dependent chain of twelve is still queued behind the other wave of
-// the SIMD, the instruction computes with the loaded data instead.
+// EQ_BF_GUARD: 1 = the product is a closed instruction group (sched_barriers around it, the fragment reads in front of the first
+// matrix instruction, EQ_BF_GUARD_NOPS x `s_nop 7` behind the last).  A SCHEDULING choice, not a hazard fence: tools/dev/mfma_war_probe.hip
+// shows that a source of v_mfma_f32_16x16x32_bf16 may be overwritten by a VALU instruction, an LDS read or a global load in the very
+// next slot (0 wrong results in 10^9), that interleaved and D != C chains are exact, and the unfenced build is exact once the packed
+// fp32 instructions are gone (see the head of this file).  The software-managed rules the probe does confirm are the compiler's own:
+// 2 wait states between a VALU write and a matrix instruction's A / B read (1 for C), 7 between the instruction and a VALU read of D, 1
+// between a TRANS result and its VALU use.
 #ifndef EQ_BF_GUARD
 #define EQ_BF_GUARD 1
 #endif
@@ -365,6 +372,9 @@ __device__ __forceinline__ void mv16(const float* mat, int i, int g, const f32x4
 #endif
 #ifndef EQ_BF_GUARD_LOADS_FIRST
 #define EQ_BF_GUARD_LOADS_FIRST 1      // 1: no load is issued between the group's first and last matrix instruction (see mv16_bf)
+#endif
+#ifndef EQ_BF_GUARD_MASK
+#define EQ_BF_GUARD_MASK 0             // __builtin_amdgcn_sched_barrier mask of the group's fences: which instruction classes MAY cross (0 = none; experiments only)
 #endif
 #ifndef EQ_BF_GUARD_HALF
 #define EQ_BF_GUARD_HALF 1             // 1: one closed group per row block (three fragments alive at a time instead of six: no spills in the backward; 20.7 -> 19.1 us at one pair)
@@ -376,13 +386,12 @@ __device__ __forceinline__ void mv16_bf(const float* frag, int lane, const f32x4
 #if EQ_BF_GUARD && EQ_BF_GUARD_HALF
 #pragma unroll
     for (int bo = 0; bo < 2; ++bo) {
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(EQ_BF_GUARD_MASK);
         const bf16x8 ah = f[(0 * 2 + bo) * 64 + lane], am = f[(1 * 2 + bo) * 64 + lane], al = f[(2 * 2 + bo) * 64 + lane];
 #if EQ_BF_GUARD_LOADS_FIRST
-        // all three fragment reads are ISSUED before the first matrix instruction: without this the register allocator hands the
-        // third fragment the registers of the incoming accumulator (the C source of the first instruction, dead behind it) and the
-        // ds_read lands there three wait states behind the instruction (tools/isa_lint.py: 24 such pairs in the round-5 backward)
-        __builtin_amdgcn_sched_barrier(0);
+        // all three fragment reads are issued before the first matrix instruction (otherwise the allocator hands the third fragment
+        // the registers of the incoming accumulator and the read sits inside the chain: harmless, but the group is no longer closed)
+        __builtin_amdgcn_sched_barrier(EQ_BF_GUARD_MASK);
 #endif
         acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, vh, acc[bo], 0, 0, 0);        // smallest terms first
         acc[bo] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, vl, acc[bo], 0, 0, 0);
@@ -393,12 +402,12 @@ __device__ __forceinline__ void mv16_bf(const float* frag, int lane, const f32x4
 #pragma unroll
         for (int n = 0; n < EQ_BF_GUARD_NOPS; ++n)
             asm volatile("s_nop 7" : "+v"(acc[bo]) : "v"(ah), "v"(am), "v"(al), "v"(vh), "v"(vm), "v"(vl));
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(EQ_BF_GUARD_MASK);
     }
 #else
     bf16x8 ah[2], am[2], al[2];
 #if EQ_BF_GUARD
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(EQ_BF_GUARD_MASK);
 #endif
 #pragma unroll
     for (int bo = 0; bo < 2; ++bo) { ah[bo] = f[(0 * 2 + bo) * 64 + lane]; am[bo] = f[(1 * 2 + bo) * 64 + lane]; al[bo] = f[(2 * 2 + bo) * 64 + lane]; }
@@ -415,7 +424,7 @@ __device__ __forceinline__ void mv16_bf(const float* frag, int lane, const f32x4
 #pragma unroll
     for (int n = 0; n < EQ_BF_GUARD_NOPS; ++n)
         asm volatile("s_nop 7" : "+v"(acc[0]), "+v"(acc[1]) : "v"(ah[0]), "v"(am[0]), "v"(al[0]), "v"(ah[1]), "v"(am[1]), "v"(al[1]), "v"(vh), "v"(vm), "v"(vl));
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(EQ_BF_GUARD_MASK);
 #endif
 #endif
 }

@@ -1,5 +1,6 @@
-"""The MFMA operand-overwrite rule as a build invariant: tools/isa_lint.py over the gfx950 code objects of
-the shipped library.  CPU suite: hipcc cross-compiles here and llvm-objdump reads the result; nothing runs on a GPU."""
+"""What the split-bf16 kernels must not contain, as a build invariant (the rule is round 6's:
+profiles/r06_mfma_hazard_probe.txt): tools/isa_lint.py over the gfx950 code objects of the shipped library.  CPU suite: hipcc cross-compiles
+here and llvm-objdump reads the result; nothing runs on a GPU."""
 import importlib.util
 import os
 
@@ -50,20 +51,38 @@ def test_parser_and_rule_on_a_synthetic_listing():
     v, n_multi, n_single, n_d1, _ = isa_lint.lint_kernel("k_fp32", ks["k_fp32"], 8)
     assert v == [] and n_multi == 0 and n_single == 1 and n_d1 == 1
     assert isa_lint.regs("v[86:89]") == {("v", 86), ("v", 87), ("v", 88), ("v", 89)} and isa_lint.regs("a3") == {("a", 3)} and not isa_lint.regs("s[4:5]")
+    # RULE 1: packed fp32 arithmetic next to split-operand matrix instructions is a violation; alone (or next to the fp32 forms) it is not
+    ks = isa_lint.parse("""
+0000000000005000 <k_pk_bad>:
+\tv_pk_add_f32 v[122:123], v[92:93], v[86:87] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]// 000000005000: D3B24A7A 480B0D5C
+\tv_mfma_f32_16x16x32_bf16 v[20:23], v[86:89], v[60:63], v[20:23]// 000000005008: D3B50014 04527956
+\tv_pk_mov_b32 v[96:97], v[92:93], v[86:87] op_sel:[1,0]        // 000000005010: D3B30860 1802AD5C
+\ts_endpgm                                                   // 000000005018: BF810000
+0000000000006000 <k_pk_ok>:
+\tv_pk_fma_f32 v[94:95], v[122:123], v[122:123], v[94:95]    // 000000006000: D3B0405E 1D7AF57A
+\tv_mfma_f32_16x16x4_f32 v[14:17], v114, v117, v[14:17]      // 000000006008: D3C5000E 043AEB72
+\ts_endpgm                                                   // 000000006010: BF810000
+""")
+    bad = isa_lint.packed_fp32("k_pk_bad", ks["k_pk_bad"])
+    assert len(bad) == 1 and bad[0]["instruction"].startswith("v_pk_add_f32") and bad[0]["rule"] == "packed_fp32"
+    assert isa_lint.packed_fp32("k_pk_ok", ks["k_pk_ok"]) == []
 
 
 @needs_llvm
-def test_shipped_code_objects_keep_mfma_operands_until_the_group_has_issued():
-    """Every gfx950 code object of the library: no VMEM / LDS load writes an A, B or C source register of a multi-register-operand MFMA
-    within 8 issue cycles of it (the closed groups of csrc/egnn_mfma16.h: sched_barrier, operands kept alive over `s_nop 7`, fragment
-    reads issued before the first matrix instruction).  The split products must actually be there (>= 18 kernels), or the lint checks nothing."""
+def test_shipped_split_product_kernels_hold_no_packed_fp32():
+    """Every gfx950 code object of the library: a kernel with multi-register-operand matrix instructions (the split-bf16 products of
+    csrc/egnn_mfma16.h) contains no v_pk_add / mul / fma_f32 -- the one property that separated exact from run-to-run different builds in
+    profiles/r06_pk_margin.txt.  The split products must actually be there (>= 18 kernels), or the lint checks nothing; the forward kernel
+    keeps them as closed groups (no load into a source within 8 issue cycles), the backward deliberately does not."""
     objs = isa_lint.default_objects()
     assert objs, "build the library first (__graft_entry__.build())"
     reports = isa_lint.run(objs, 8)
     assert reports, "no gfx950 code objects found"
-    violations = [v for r in reports for v in r["violations"]]
-    assert not violations, violations[:5]
+    packed = [v for r in reports for v in r["packed_fp32"]]
+    assert not packed, packed[:5]
     multi = {(r["file"], k): v for r in reports for k, v in r["kernels"].items() if v["mfma_multi_operand"]}
     assert len(multi) >= 18 and sum(v["mfma_multi_operand"] for v in multi.values()) >= 1000, len(multi)
-    margins = [v["min_cycles_to_overwriting_load"] for v in multi.values() if v["min_cycles_to_overwriting_load"] is not None]
-    assert margins and min(margins) >= 8, min(margins)
+    fwd = [r for r in reports if r["file"].endswith(("egnn_fwd.o", "libequigspr.so"))]
+    assert fwd
+    if fwd[0]["file"].endswith("egnn_fwd.o"):
+        assert not fwd[0]["violations"], fwd[0]["violations"][:3]

@@ -39,20 +39,21 @@ def run(n, feat, fp32, cap):
     torch.cuda.synchronize()
     return [t.detach().double().cpu() for t in (ho, xo, hc.grad, xc.grad)], m.flat_grads.detach().double().cpu()
 out = []
-for feat in (32, 33):
+for feat in [int(f) for f in sys.argv[2].split(',')]:
     for n in (3000, 40000):
         ref, refp = run(n, feat, True, 0)
         for cap in (1, 8, 64, 0):
             res = [run(n, feat, False, cap) for _ in range(runs)]
-            bad, worst, same = 0, 0.0, True
+            bad, worst, same, per = 0, 0.0, True, [0, 0, 0, 0]
             for (ts, p) in res:
-                for a, b in zip(ts, ref):
+                for q, (a, b) in enumerate(zip(ts, ref)):
                     d = (a - b).abs().reshape(n, -1).max(dim=1).values / b.abs().max()
-                    bad = max(bad, int((d > 2e-5).sum())); worst = max(worst, float(d.max()))
+                    bad = max(bad, int((d > 2e-5).sum())); worst = max(worst, float(d.max())); per[q] = max(per[q], int((d > 2e-5).sum()))
                 worst_p = float(((p - refp).abs().max() / refp.abs().max()))
                 same = same and all(torch.equal(a, b) for a, b in zip(ts, res[0][0])) and torch.equal(p, res[0][1])
             out.append({"hidden_nf": feat, "nodes": n, "tiles": n, "grid_cap": cap, "runs": runs, "wrong_nodes_max": bad, "worst_rel_diff": worst,
-                        "param_grad_rel_diff": worst_p, "bit_identical_runs": same})
+                        "param_grad_rel_diff": worst_p, "bit_identical_runs": same,
+                        "wrong_nodes_by_tensor": dict(zip(("h_out", "x_out", "grad_h", "grad_x"), per))})
 print("RESULT " + json.dumps(out))
 """
 
@@ -61,13 +62,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("variants", nargs="*", help="name=path pairs")
     ap.add_argument("--runs", type=int, default=5)
+    ap.add_argument("--feats", default="32,33", help="hidden_nf values to run")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     libs = [("default", os.path.join(ROOT, "se3_equi_graph_registration_amd", "libequigspr.so"))] + [tuple(v.split("=", 1)) for v in a.variants]
     report = {}
     for name, path in libs:
         env = dict(os.environ, EQUIGSPR_LIB=os.path.abspath(path))
-        p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, str(a.runs)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, str(a.runs), a.feats], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
         if p.returncode != 0 or not line:
             report[name] = {"error": p.stderr[-1500:]}
@@ -76,7 +78,7 @@ def main():
         report[name] = json.loads(line[-1][7:])
         for r in report[name]:
             print(f"{name:10s} F={r['hidden_nf']} tiles={r['tiles']:6d} cap={r['grid_cap']:3d}: wrong nodes {r['wrong_nodes_max']:5d}  worst {r['worst_rel_diff']:.2e}  "
-                  f"params {r['param_grad_rel_diff']:.2e}  bit-identical runs: {r['bit_identical_runs']}")
+                  f"params {r['param_grad_rel_diff']:.2e}  bit-identical runs: {r['bit_identical_runs']}  by tensor {r.get('wrong_nodes_by_tensor')}")
     if a.out:
         json.dump(report, open(a.out, "w"), indent=1)
 

@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
-"""ISA lint of the shipped gfx950 code objects: the MFMA operand-overwrite rule as a CHECKED invariant.
+"""ISA lint of the shipped gfx950 code objects: what the split-bf16 kernels must not contain, as a CHECKED invariant.
 
-Background (profiles/r05_bf16x3_edge_kernels.txt part F): inside the split-bf16 products of the edge kernels
-(`mv16_bf`, csrc/egnn_mfma16.h) the compiler once re-used an A/B operand register of a `v_mfma_f32_16x16x32_bf16` as the destination
-of a global / LDS load issued right behind it; on the MI355X that produced run-to-run different tiles.  The fix makes every product a
-closed instruction group (`sched_barrier` + operands kept alive over `EQ_BF_GUARD_NOPS` x `s_nop 7`).  Nothing but the generated code
-says whether that still holds after a compiler bump or an edit, so this tool reads the generated code:
+Background (profiles/r06_mfma_hazard_probe.txt).  Round 5 saw run-to-run different tiles from the edge kernels once their
+32 x 32 products ran as split-bf16 matrix instructions, blamed a load landing in a source register of `v_mfma_f32_16x16x32_bf16`, and fenced the
+products.  Round 6 measured the hardware (tools/dev/mfma_war_probe.hip) and bisected the failing build:
+  * a source register of the matrix instruction may be overwritten in the very next issue slot by a VALU instruction, an LDS read or a
+    global load -- 0 wrong results in 10^9 probes, with and without a second wave on the SIMD; fenced or unfenced made no difference once
+  * the packed fp32 instructions were gone: WITH `v_pk_add / mul / fma_f32` in the kernel, schedules that mix loads or matrix instructions
+    into the products computed the lane-per-edge geometry wrong in lanes 48..63 of ~0.5 % of the 64-edge chunks (a `v_pk_add_f32` with
+    op_sel returned src0 - 0 from sources that read back correct; the scalar instruction in its place is exact); WITHOUT them every
+    schedule tried is exact and bit-identical over 5 runs x 16 configurations.
+So the rule this tool FAILS on is:
 
-  for every MFMA whose A or B operand is a multi-register tuple (the bf16 / f16 / fp8 forms; 128-bit operands are what the hazard
-  was seen on), walk every path that leaves the instruction (fall-through and branch targets) and require that no VMEM / LDS / flat /
-  scratch LOAD whose destination overlaps one of the instruction's A, B or C source registers issues before `--min-cycles` issue
-  cycles have passed (default 8 = one `s_nop 7`; an s_nop N counts N + 1, a matrix instruction 4, everything else 1).
+  RULE 1  a kernel that contains multi-register-operand matrix instructions (the bf16 / f16 / fp8 forms) contains no packed fp32
+          arithmetic (`v_pk_add_f32`, `v_pk_mul_f32`, `v_pk_fma_f32`).  csrc/Makefile builds egnn_fwd / egnn_bwd with
+          `-target-feature -packed-fp32-ops` for that.
 
-The single-register-operand fp32 forms (`v_mfma_f32_16x16x4_f32`: A and B are one VGPR each, read in the issue cycle) are counted
-and reported -- loads DO overwrite their operands at distance 1 in the shipped kernels, with bit-exact, reproducible results in every
-run since round 1 -- but not failed.
+It also REPORTS (does not fail on; `--strict-overwrite` turns it back into a failure) the older statistic: loads whose destination
+overlaps an A, B or C source of such an instruction within `--min-cycles` issue cycles behind it (an s_nop N counts N + 1, a matrix
+instruction 4, everything else 1), following fall-through and branch targets.  The forward kernel keeps its products as closed groups
+(0 such pairs); the backward does not (the scheduler overlaps the products with the surrounding loads: ~200 pairs, exact results).
 
-Usage:  python tools/isa_lint.py [--min-cycles 8] [--json out.json] [objects or shared libraries ...]
+Usage:  python tools/isa_lint.py [--min-cycles 8] [--strict-overwrite] [--json out.json] [objects or shared libraries ...]
         (default: every csrc/*.o that carries gfx950 code).  Exit code 1 on a violation.  Needs /opt/rocm/lib/llvm/bin.
 Used by tests/test_isa_lint.py (CPU suite) and `make -C csrc lint`."""
 import argparse
@@ -35,6 +40,15 @@ TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 _REG = re.compile(r"([va])(?:\[(\d+):(\d+)\]|(\d+))")
 _LOAD = re.compile(r"^(global_load|buffer_load|flat_load|scratch_load|ds_read|ds_load|tbuffer_load|global_atomic\w*_rtn|ds_\w+_rtn|ds_bpermute|ds_permute|ds_swizzle|ds_consume|ds_append)")
 _BRANCH = re.compile(r"^s_c?branch")
+_PACKED_F32 = re.compile(r"^v_pk_(add|mul|fma)_f32")
+
+
+def packed_fp32(name, ins):
+    """RULE 1: the packed fp32 arithmetic instructions of a kernel that also holds multi-register-operand matrix instructions."""
+    multi = any(m.startswith(("v_mfma", "v_smfmac")) and len(o) >= 4 and (len(regs(o[1])) > 1 or len(regs(o[2])) > 1) for _, m, o, _ in ins)
+    if not multi:
+        return []
+    return [{"kernel": name, "rule": "packed_fp32", "instruction": f"{m} {', '.join(o)}", "addr": hex(a or 0)} for a, m, o, _ in ins if _PACKED_F32.match(m)]
 
 
 def regs(tok):
@@ -199,8 +213,9 @@ def lint_file(path, min_cycles, workdir):
     text = disassemble(path, workdir)
     if text is None:
         return None
-    out = {"file": os.path.relpath(path, ROOT), "kernels": {}, "violations": []}
+    out = {"file": os.path.relpath(path, ROOT), "kernels": {}, "violations": [], "packed_fp32": []}
     for name, ins in parse(text).items():
+        out["packed_fp32"] += packed_fp32(name, ins)
         v, n_multi, n_single, n_d1, _ = lint_kernel(name, ins, min_cycles)
         if n_multi or n_single:
             out["kernels"][name] = {"mfma_multi_operand": n_multi, "mfma_fp32_single_operand": n_single,
@@ -231,26 +246,27 @@ def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("paths", nargs="*")
     ap.add_argument("--min-cycles", type=int, default=8)
+    ap.add_argument("--strict-overwrite", action="store_true", help="also fail on loads into matrix-instruction sources (the round-5 rule)")
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
     reports = run(a.paths, a.min_cycles)
+    n_p = sum(len(r["packed_fp32"]) for r in reports)
     n_v = sum(len(r["violations"]) for r in reports)
     for r in reports:
         km = {k: v for k, v in r["kernels"].items() if v["mfma_multi_operand"]}
         print(f"{r['file']}: {len(r['kernels'])} kernels with MFMAs, {len(km)} with multi-register-operand MFMAs "
-              f"({sum(v['mfma_multi_operand'] for v in km.values())} instructions), violations: {len(r['violations'])}; "
-              f"fp32 single-operand MFMAs: {sum(v['mfma_fp32_single_operand'] for v in r['kernels'].values())} "
-              f"({sum(v['fp32_with_distance_le_1_overwrite'] for v in r['kernels'].values())} with an overwriting load within 1 cycle)")
-        margins = [v["min_cycles_to_overwriting_load"] for v in km.values() if v["min_cycles_to_overwriting_load"] is not None]
-        if margins:
-            print(f"    smallest distance from a multi-operand MFMA to a load overwriting its sources: {min(margins)} issue cycles")
-        for v in r["violations"][:20]:
-            print(f"    VIOLATION {v['kernel'][:60]}: {v['mfma']} @ {v['mfma_addr']}  <-  {v['load']} @ {v['load_addr']} after {v['issue_cycles_between']} cycles")
+              f"({sum(v['mfma_multi_operand'] for v in km.values())} instructions); packed fp32 in those kernels: {len(r['packed_fp32'])}; "
+              f"loads into their sources within {a.min_cycles} cycles (reported): {len(r['violations'])}")
+        for v in r["packed_fp32"][:10]:
+            print(f"    PACKED FP32 {v['kernel'][:60]}: {v['instruction']} @ {v['addr']}")
+        if a.strict_overwrite:
+            for v in r["violations"][:20]:
+                print(f"    OVERWRITE {v['kernel'][:60]}: {v['mfma']} @ {v['mfma_addr']}  <-  {v['load']} @ {v['load_addr']} after {v['issue_cycles_between']} cycles")
     if a.json:
         json.dump({"min_cycles": a.min_cycles, "reports": reports}, open(a.json, "w"), indent=1)
-    print(f"isa_lint: {n_v} violation(s) in {len(reports)} code object(s) (rule: no load into an A/B/C source of a multi-register-operand MFMA within "
-          f"{a.min_cycles} issue cycles)")
-    return 1 if n_v else 0
+    print(f"isa_lint: {n_p} packed fp32 instruction(s) in kernels with split-operand matrix instructions (RULE 1), {n_v} source-overwriting load(s) "
+          f"within {a.min_cycles} issue cycles ({'checked' if a.strict_overwrite else 'reported only'}), {len(reports)} code object(s)")
+    return 1 if (n_p or (a.strict_overwrite and n_v)) else 0
 
 
 if __name__ == "__main__":
