@@ -1679,8 +1679,8 @@ def test_edge_kernels_are_reproducible_when_waves_run_many_units(pk):
 @pytest.mark.parametrize("n,caps", [(3000, (1, 8, 0)), (40000, (8, 0))])
 def test_split_products_match_fp32_products_tile_by_tile(pk, feat, n, caps):
     """The split-bf16 products against the SAME kernels on fp32 products (equigspr_set_edge_products, ABI 14), tile by tile: a ring graph
-    whose node k owns the 16-edge tile k, so one wrong tile (the round-5 hazard lost a split level of 1-6 tiles in 3 000: ~1e-2 of the
-    tile's values) shows at nodes k / k + 1.  Workgroup caps (equigspr_set_edge_grid_cap) 1 / 8 put up to ~90 units on every wave with
+    whose node k owns the 16-edge tile k, so one wrong tile (round 5's defect -- packed fp32 instructions miscomputing the lane-per-edge geometry
+    of ~0.5 % of the chunks, profiles/r06_mfma_hazard_probe.txt: ~1e-2 of the tile's values) shows at nodes k / k + 1.  Workgroup caps (equigspr_set_edge_grid_cap) 1 / 8 put up to ~90 units on every wave with
     two waves per SIMD -- the regime the defect needed; every run must also be bit-identical to the first."""
     from se3_equi_graph_registration_amd import _lib
     L = _lib.lib()

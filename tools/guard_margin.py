@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Margin of the closed-group guard around the split-bf16 products (csrc/egnn_mfma16.h mv16_bf), measured on the GPU.
+"""Tile-by-tile exactness and run-to-run reproducibility of the split-bf16 edge kernels per library variant (fenced / unfenced products,
+with / without packed fp32 instructions, ISA-patched forms: profiles/r06_mfma_hazard_probe.txt), measured on the GPU.
 
 For every library variant given (built here with `make -C csrc variant_edge NAME=.. DEFS=..`; the default library is always included)
 the harness of profiles/r05_bf16x3_edge_kernels.txt part D runs in a CHILD process (EQUIGSPR_LIB selects the library): one EGNN layer,
