@@ -12,9 +12,9 @@ products.  Round 6 measured the hardware (tools/dev/mfma_war_probe.hip) and bise
     schedule tried is exact and bit-identical over 5 runs x 16 configurations.
 So the rule this tool FAILS on is:
 
-  RULE 1  a kernel that contains multi-register-operand matrix instructions (the bf16 / f16 / fp8 forms) contains no packed fp32
-          arithmetic (`v_pk_add_f32`, `v_pk_mul_f32`, `v_pk_fma_f32`).  csrc/Makefile builds egnn_fwd / egnn_bwd with
-          `-target-feature -packed-fp32-ops` for that.
+  RULE 1  no kernel of the library contains packed fp32 arithmetic (`v_pk_add_f32`, `v_pk_mul_f32`, `v_pk_fma_f32`).  The defect was seen
+          in the two kernels that hold multi-register-operand matrix instructions (the split-bf16 products); its mechanism is not
+          understood, so the rule covers all of them.  csrc/Makefile builds with `-target-feature -packed-fp32-ops` for that.
 
 It also REPORTS (does not fail on; `--strict-overwrite` turns it back into a failure) the older statistic: loads whose destination
 overlaps an A, B or C source of such an instruction within `--min-cycles` issue cycles behind it (an s_nop N counts N + 1, a matrix
@@ -44,11 +44,11 @@ _PACKED_F32 = re.compile(r"^v_pk_(add|mul|fma)_f32")
 
 
 def packed_fp32(name, ins):
-    """RULE 1: the packed fp32 arithmetic instructions of a kernel that also holds multi-register-operand matrix instructions."""
+    """RULE 1: the packed fp32 arithmetic instructions of a kernel (`beside_split_products`: the kernel also holds multi-register-operand
+    matrix instructions -- the combination the defect was seen in)."""
     multi = any(m.startswith(("v_mfma", "v_smfmac")) and len(o) >= 4 and (len(regs(o[1])) > 1 or len(regs(o[2])) > 1) for _, m, o, _ in ins)
-    if not multi:
-        return []
-    return [{"kernel": name, "rule": "packed_fp32", "instruction": f"{m} {', '.join(o)}", "addr": hex(a or 0)} for a, m, o, _ in ins if _PACKED_F32.match(m)]
+    return [{"kernel": name, "rule": "packed_fp32", "beside_split_products": multi, "instruction": f"{m} {', '.join(o)}", "addr": hex(a or 0)}
+            for a, m, o, _ in ins if _PACKED_F32.match(m)]
 
 
 def regs(tok):
@@ -255,7 +255,7 @@ def main():
     for r in reports:
         km = {k: v for k, v in r["kernels"].items() if v["mfma_multi_operand"]}
         print(f"{r['file']}: {len(r['kernels'])} kernels with MFMAs, {len(km)} with multi-register-operand MFMAs "
-              f"({sum(v['mfma_multi_operand'] for v in km.values())} instructions); packed fp32 in those kernels: {len(r['packed_fp32'])}; "
+              f"({sum(v['mfma_multi_operand'] for v in km.values())} instructions); packed fp32 instructions: {len(r['packed_fp32'])} ({sum(v['beside_split_products'] for v in r['packed_fp32'])} beside split products); "
               f"loads into their sources within {a.min_cycles} cycles (reported): {len(r['violations'])}")
         for v in r["packed_fp32"][:10]:
             print(f"    PACKED FP32 {v['kernel'][:60]}: {v['instruction']} @ {v['addr']}")
@@ -264,7 +264,7 @@ def main():
                 print(f"    OVERWRITE {v['kernel'][:60]}: {v['mfma']} @ {v['mfma_addr']}  <-  {v['load']} @ {v['load_addr']} after {v['issue_cycles_between']} cycles")
     if a.json:
         json.dump({"min_cycles": a.min_cycles, "reports": reports}, open(a.json, "w"), indent=1)
-    print(f"isa_lint: {n_p} packed fp32 instruction(s) in kernels with split-operand matrix instructions (RULE 1), {n_v} source-overwriting load(s) "
+    print(f"isa_lint: {n_p} packed fp32 instruction(s) (RULE 1), {n_v} source-overwriting load(s) "
           f"within {a.min_cycles} issue cycles ({'checked' if a.strict_overwrite else 'reported only'}), {len(reports)} code object(s)")
     return 1 if (n_p or (a.strict_overwrite and n_v)) else 0
 
