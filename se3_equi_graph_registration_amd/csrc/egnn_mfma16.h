@@ -28,8 +28,8 @@
 // RUN-TO-RUN DIFFERENT RESULTS (round 5) AND WHAT THEY WERE (round 6, profiles/r06_mfma_hazard_probe.txt): not the matrix instructions.  With
 // packed fp32 instructions in the kernel (v_pk_add / mul / fma_f32) and a schedule that mixes loads or other matrix instructions into the
 // products, the lane-per-edge geometry of ~0.5 % of the 64-edge chunks came out wrong in lanes 48..63 (a v_pk_add_f32 with op_sel
-// returned src0 - 0 from sources that read back correct; its scalar form is exact).  Both edge kernels are therefore compiled WITHOUT
-// packed fp32 instructions (csrc/Makefile EDGE_FLAGS; tools/isa_lint.py checks the objects): exact and bit-identical in every schedule
+// returned src0 - 0 from sources that read back correct; its scalar form is exact).  The library is therefore compiled WITHOUT
+// packed fp32 instructions (csrc/Makefile PACKED_FLAGS; tools/isa_lint.py checks the objects): exact and bit-identical in every schedule
 // tried, fenced or not.  The forward keeps its products as closed instruction groups (EQ_BF_GUARD 1: 10 % faster at one pair), the
 // backward does not (EQ_BF_GUARD 0 in egnn_bwd.hip: 2.5-4 % faster, fewer spills at hidden_nf 33).
 // 0 = the fp32 products (A/B).
