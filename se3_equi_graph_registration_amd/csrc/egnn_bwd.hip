@@ -920,6 +920,9 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
         EQ_STAMP(3);
 
         auto tile = [&](int sub, PRowsT<kB>& cur, PRowsT<kB>& nxt) __attribute__((always_inline)) {
+#if defined(EQ_DEBUG_STRIP) && EQ_DEBUG_STRIP == 1
+            if (sub >= 0) return;                      // debugging aid: the sub-tiles do nothing (what is left: front phase, back phase, slab merge)
+#endif
             const int el = sub * 16 + i;
             const int eg_ = (t0 + sub * ts) * 16 + i;   // the edge's index in the graph
             const bool valid = eg_ < n_edges;
@@ -943,6 +946,9 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             const PRowsT<kB>& pw = cur;
             Sub16 o;
             tile_forward16<kB, true, kBf>(wsm, bord, geo_rows + i * C::GS, pw, i, g, o);
+#if defined(EQ_DEBUG_STRIP) && EQ_DEBUG_STRIP == 2
+            { ls_bet[0] += o.q[0] + o.m[0] + o.t1[0]; ls_bet[1] += o.q[1] + o.m[1] + o.t1[1]; if (g == 0) s_buf[el] = o.s; return; }   // forward recompute only
+#endif
             EQ_DBG8(0, o.t1); EQ_DBG8(1, pw.pr); EQ_DBG8(2, pw.pc);
             { const f32x4 gv_[2] = {lds4(geo_rows + i * C::GS + 4 * g), lds4(geo_rows + i * C::GS + 4 * ((g + 1) & 3))}; EQ_DBG8(3, gv_); }
             if (g == 0) s_buf[el] = o.s;
@@ -971,6 +977,9 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             PassBorder& r2 = kLdsB ? t2 : pb2;
             PassBorder& rg = kLdsB ? tg : pbg;
             pass16<2, !kRun, kB>(X, Y, C::LD, i, g, acc6, cs_b6, r6);     // dW6 += dq^T m (; db6 += sum dq)
+#if defined(EQ_DEBUG_STRIP) && EQ_DEBUG_STRIP == 3
+            { ls_bet[0] += dq[0]; ls_bet[1] += dq[1]; return; }                  // ... + coord-head backward + dW6 pass
+#endif
             if constexpr (kLdsB) {
                 ladd(bsl + 64 * 0, t6.bcol[0]); ladd(bsl + 64 * 1, t6.bcol[1]); ladd(bsl + 64 * 2, t6.brow[0]);
                 ladd(bsl + 64 * 3, t6.brow[1]); ladd(bsl + 64 * 4, t6.corner); ladd(bsl + 64 * 5, t6.xbs);
@@ -983,6 +992,9 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
 #pragma unroll
             for (int b = 0; b < 2; ++b) dm[b] = valid ? da[b] : splat4(0.0f);
             mv16_edge<true, kB, kBf>(wsm, W16::f_w6t, i, g, dq, dm);
+#if defined(EQ_DEBUG_STRIP) && EQ_DEBUG_STRIP == 4
+            { ls_bet[0] += dm[0]; ls_bet[1] += dm[1]; return; }                  // ... + dm = dagg + W6^T dq
+#endif
             if constexpr (kB == 1)      // W6^T: its column 32 is W6's row 32 and vice versa
                 dmb = (valid ? dab : 0.0f) + mv16_border(bord + W16::b_w6row, bord + W16::b_w6col, bord[W16::b_sc + 1], g, dq, dqb, dm);
             EQ_STAMP(11);
@@ -1033,6 +1045,9 @@ __global__ __launch_bounds__(64 * bwd16_waves(kB)) void edge_bwd16_kernel(const 
             f32x4 dt1[2] = {splat4(0.0f), splat4(0.0f)};
             float dt1b = 0.0f;
             mv16_edge<true, kB, kBf>(wsm, W16::f_w2t, i, g, du, dt1);
+#if defined(EQ_DEBUG_STRIP) && EQ_DEBUG_STRIP == 5
+            { ls_bet[0] += dt1[0]; ls_bet[1] += dt1[1]; return; }                // ... + LayerNorm backward + dW2 pass + dt1 = W2^T du
+#endif
             if constexpr (kB == 1) {
                 dt1b = mv16_border(bord + W16::b_w2row, bord + W16::b_w2col, bord[W16::b_sc + 0], g, du, dub, dt1);
                 dt1b *= o.sg1b * (1.0f + o.t1b * (1.0f - o.sg1b));

@@ -1065,6 +1065,76 @@ static void run_pkexec(const char* what) {
     CHECK(hipFree(sink));
 }
 
+// ---- the SAME wave alternating split-bf16 product chains and packed fp32 on per-lane data (what the stripped failing kernel still does:
+// front phase with packed fp32 -> sub-tiles with bf16 products -> back phase -> next front phase), 8 waves per workgroup, two per SIMD
+template <int NMFMA, int GAP, int REGS = 0>
+__global__ __launch_bounds__(512) void alt_kernel(unsigned long long* __restrict__ bad, int iters, float* __restrict__ sink) {
+    __shared__ float lds_f[64 * 4 * 8];
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < 64 * 4 * 8; t += 512) lds_f[t] = __uint_as_float(0x3f803f80u);
+    __syncthreads();
+    const bf16x8* f = reinterpret_cast<const bf16x8*>(lds_f);
+    bf16x8 b;
+    for (int j = 0; j < 8; ++j) b[j] = (__bf16)(1.0f + 0.01f * j);
+    f32x4 acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0};
+    unsigned long long wrong = 0;
+    float x0 = 1.0f + lane * 0.25f, x1 = 2.0f + lane * 0.5f, y0 = 0.125f * (lane + 3), y1 = 7.0f - lane;
+    for (int it = 0; it < iters; ++it) {
+        // phase A: matrix chains with LDS reads between
+        for (int r = 0; r < NMFMA; ++r) {
+            bf16x8 a = f[((r * 3 + wave) & 7) * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+            a = f[((r * 5 + 1) & 7) * 64 + lane];
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc2, 0, 0, 0);
+        }
+        acc[0] *= 1e-3f; acc2[1] *= 1e-3f;
+        for (int j = 0; j < GAP; ++j) __builtin_amdgcn_s_sleep(1);
+        // phase B: packed fp32 with operand selects, against the scalar results
+        float lo, hi, lo2, hi2, lo3, hi3;
+        if constexpr (REGS == 0)
+        asm volatile("v_mov_b32 v22, %6\n v_mov_b32 v23, %7\n v_mov_b32 v26, %8\n v_mov_b32 v27, %9\n s_nop 1\n"
+                     "v_pk_mov_b32 v[32:33], v[22:23], v[26:27] op_sel:[1,0]\n"
+                     "v_pk_add_f32 v[28:29], v[22:23], v[26:27] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                     "v_pk_add_f32 v[34:35], v[22:23], v[32:33] neg_lo:[0,1] neg_hi:[0,1]\n"
+                     "v_pk_fma_f32 v[30:31], v[28:29], v[28:29], v[22:23] op_sel_hi:[1,1,0]\n s_nop 3\n"
+                     "v_mov_b32 %0, v28\n v_mov_b32 %1, v29\n v_mov_b32 %2, v30\n v_mov_b32 %3, v31\n v_mov_b32 %4, v34\n v_mov_b32 %5, v35\n"
+                     : "=&v"(lo), "=&v"(hi), "=&v"(lo2), "=&v"(hi2), "=&v"(lo3), "=&v"(hi3) : "v"(x0), "v"(x1), "v"(y0), "v"(y1)
+                     : "v22", "v23", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35");
+        else        // the failing build's own registers (v[92:93] - v[86:87] -> v[122:123]: all four VGPR banks in one instruction)
+        asm volatile("v_mov_b32 v92, %6\n v_mov_b32 v93, %7\n v_mov_b32 v86, %8\n v_mov_b32 v87, %9\n v_mov_b32 v90, %6\n v_mov_b32 v91, %7\n s_nop 1\n"
+                     "v_pk_mov_b32 v[96:97], v[92:93], v[86:87] op_sel:[1,0]\n"
+                     "v_pk_add_f32 v[122:123], v[92:93], v[86:87] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
+                     "v_pk_add_f32 v[116:117], v[90:91], v[96:97] neg_lo:[0,1] neg_hi:[0,1]\n"
+                     "v_pk_fma_f32 v[94:95], v[122:123], v[122:123], v[92:93] op_sel_hi:[1,1,0]\n s_nop 3\n"
+                     "v_mov_b32 %0, v122\n v_mov_b32 %1, v123\n v_mov_b32 %2, v94\n v_mov_b32 %3, v95\n v_mov_b32 %4, v116\n v_mov_b32 %5, v117\n"
+                     : "=&v"(lo), "=&v"(hi), "=&v"(lo2), "=&v"(hi2), "=&v"(lo3), "=&v"(hi3) : "v"(x0), "v"(x1), "v"(y0), "v"(y1)
+                     : "v86", "v87", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v116", "v117", "v122", "v123");
+        const float e_lo = x0 - y1, e_hi = x1 - y0;
+        wrong += (lo != e_lo) || (hi != e_hi) || (lo2 != fmaf(e_lo, e_lo, x0)) || (hi2 != fmaf(e_hi, e_hi, x0)) || (lo3 != x0 - x1) || (hi3 != x1 - y0);
+        x0 += 0.5f; y1 -= 0.25f;
+    }
+    if (acc[0] + acc2[1] == 123.456f) sink[0] = acc[0];
+    if (wrong) atomicAdd(bad + (lane >> 4), wrong);
+}
+template <int NMFMA, int GAP, int REGS = 0>
+static void run_alt(const char* what) {
+    const int iters = 30000;
+    float* sink; CHECK(hipMalloc(&sink, 4));
+    for (int blocks = 1; blocks <= 256; blocks *= 256) {
+        CHECK(hipMemset(g_bad4, 0, 32));
+        hipLaunchKernelGGL((alt_kernel<NMFMA, GAP, REGS>), dim3(blocks), dim3(512), 0, 0, g_bad4, iters, sink);
+        CHECK(hipDeviceSynchronize());
+        unsigned long long b[4];
+        CHECK(hipMemcpy(b, g_bad4, 32, hipMemcpyDeviceToHost));
+        const double per = (double)iters * blocks * 8 * 16;
+        printf("alt    %-58s blocks %3d  wrong per million, lanes 0-15 | 16-31 | 32-47 | 48-63: %9.2f %9.2f %9.2f %9.2f\n", what, blocks,
+               1e6 * b[0] / per, 1e6 * b[1] / per, 1e6 * b[2] / per, 1e6 * b[3] / per);
+    }
+    CHECK(hipFree(sink));
+}
+
 int main() {
     CHECK(hipMalloc(&g_junk, 64 * 4 * sizeof(float)));
     CHECK(hipMalloc(&g_bad, 16));
@@ -1083,6 +1153,8 @@ int main() {
     sweep_raw<T_A, 1>("A", "v_perm"); sweep_raw<T_B, 1>("B", "v_perm"); sweep_raw<T_C, 1>("C", "v_perm");
     sweep_raw<T_A, 2>("A", "ds_read"); sweep_raw<T_B, 2>("B", "ds_read"); sweep_raw<T_C, 2>("C", "ds_read");
     CHECK(hipMalloc(&g_bad4, 32));
+    run_alt<6, 0, 1>("12 bf16 products, then packed fp32 in the failing build's registers"); run_alt<24, 2, 1>("48 products, sleep, the failing build's registers");
+    run_alt<6, 0>("12 bf16 products, then packed fp32, same wave"); run_alt<24, 0>("48 bf16 products, then packed fp32"); run_alt<6, 3>("12 products, short sleep, packed fp32"); run_alt<1, 0>("2 products, packed fp32");
     run_pkexec<48, 0>("region over lanes 0..47; s_or exec; v_pk_add"); run_pkexec<48, 1>("region over lanes 0..47; s_or exec; s_waitcnt; v_pk_add");
     run_pkexec<48, 2>("region over lanes 0..47; s_or exec; s_waitcnt; v_pk_mov; v_pk_add"); run_pkexec<64, 2>("region over all lanes; s_or exec; s_waitcnt; v_pk_mov; v_pk_add");
     run_pkexec<0, 2>("region over no lane (exec 0); s_or exec; s_waitcnt; v_pk_mov; v_pk_add"); run_pkexec<16, 0>("region over lanes 0..15; s_or exec; v_pk_add");
