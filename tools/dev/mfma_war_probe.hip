@@ -1089,11 +1089,11 @@ __global__ __launch_bounds__(512) void alt_kernel(unsigned long long* __restrict
             a = f[((r * 5 + 1) & 7) * 64 + lane];
             acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc2, 0, 0, 0);
         }
-        acc[0] *= 1e-3f; acc2[1] *= 1e-3f;
+        if constexpr (REGS != 2) { acc[0] *= 1e-3f; acc2[1] *= 1e-3f; }      // REGS == 2: the products' results are not read: the packed ops run while they execute
         for (int j = 0; j < GAP; ++j) __builtin_amdgcn_s_sleep(1);
         // phase B: packed fp32 with operand selects, against the scalar results
         float lo, hi, lo2, hi2, lo3, hi3;
-        if constexpr (REGS == 0)
+        if constexpr (REGS == 0 || REGS == 2)
         asm volatile("v_mov_b32 v22, %6\n v_mov_b32 v23, %7\n v_mov_b32 v26, %8\n v_mov_b32 v27, %9\n s_nop 1\n"
                      "v_pk_mov_b32 v[32:33], v[22:23], v[26:27] op_sel:[1,0]\n"
                      "v_pk_add_f32 v[28:29], v[22:23], v[26:27] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n"
@@ -1153,6 +1153,7 @@ int main() {
     sweep_raw<T_A, 1>("A", "v_perm"); sweep_raw<T_B, 1>("B", "v_perm"); sweep_raw<T_C, 1>("C", "v_perm");
     sweep_raw<T_A, 2>("A", "ds_read"); sweep_raw<T_B, 2>("B", "ds_read"); sweep_raw<T_C, 2>("C", "ds_read");
     CHECK(hipMalloc(&g_bad4, 32));
+    run_alt<6, 0, 2>("12 bf16 products IN FLIGHT, packed fp32 right behind them"); run_alt<2, 0, 2>("4 products in flight, packed fp32 behind"); run_alt<24, 0, 2>("48 products in flight, packed fp32 behind");
     run_alt<6, 0, 1>("12 bf16 products, then packed fp32 in the failing build's registers"); run_alt<24, 2, 1>("48 products, sleep, the failing build's registers");
     run_alt<6, 0>("12 bf16 products, then packed fp32, same wave"); run_alt<24, 0>("48 bf16 products, then packed fp32"); run_alt<6, 3>("12 products, short sleep, packed fp32"); run_alt<1, 0>("2 products, packed fp32");
     run_pkexec<48, 0>("region over lanes 0..47; s_or exec; v_pk_add"); run_pkexec<48, 1>("region over lanes 0..47; s_or exec; s_waitcnt; v_pk_add");
